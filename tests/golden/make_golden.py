@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate the parity fixtures and golden outputs under tests/golden/.
+
+TEST INFRASTRUCTURE.  Runs only in the dev container, where the reference checkout is mounted
+at /root/reference and `make -C oracle ref` has produced
+
+    oracle/_ref/pandepth_ref   the reference CLI compiled from its own sources
+    oracle/_ref/sam2bam        SAM -> BAM+BAI helper linked against the reference's libhts.a
+
+What is committed is data only: seeded synthetic inputs (SAM/BAM/BAI/GFF/GTF/BED/list) and the
+reference's outputs on them (the `.stat.gz` / `.SiteDepth.gz` files, byte for byte, plus a
+manifest with sha256 of the gz bytes and of the decompressed text).  No reference source is
+copied.  Re-running this script must reproduce the committed files bit for bit.
+
+    python tests/golden/make_golden.py            # regenerate everything
+"""
+import gzip
+import hashlib
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+SAM2BAM = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+
+
+def cigar_ref_span(cig):
+    n, span = "", 0
+    for ch in cig:
+        if ch.isdigit():
+            n += ch
+        else:
+            if ch in "MDN=X":
+                span += int(n)
+            n = ""
+    return span
+
+
+def sam_header(contigs, sorted_=True):
+    h = "@HD\tVN:1.6\tSO:%s\n" % ("coordinate" if sorted_ else "unsorted")
+    for name, ln in contigs:
+        h += "@SQ\tSN:%s\tLN:%d\n" % (name, ln)
+    return h
+
+
+def sam_line(i, flag, rname, pos1, mapq, cigar):
+    return "r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t*\t*\n" % (i, flag, rname, pos1, mapq, cigar)
+
+
+def to_bam(sam, bam, index=True):
+    cmd = [SAM2BAM, sam, bam] + ([] if index else ["noindex"])
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+
+
+# ---------------------------------------------------------------------------------------------
+# F1: small multi-mode fixture
+# ---------------------------------------------------------------------------------------------
+F1_CONTIGS = [("chrA", 1001), ("chrB", 500), ("chrC", 1)]
+F1_CIGARS = ["50M", "20M5D30M", "10S40M", "25M100N25M", "30M2I18M", "50=", "20=1X29=", "5H45M3S",
+             "2D48M", "10M1D10M1D10M1D20M"]
+
+
+def f1_reads(seed, n=600):
+    rng = random.Random(seed)
+    recs = []
+    for i in range(n):
+        ci = 0 if rng.random() < 0.6 else 1
+        name, ln = F1_CONTIGS[ci]
+        cig = rng.choice(F1_CIGARS)
+        span = cigar_ref_span(cig)
+        # allow a small overhang past the contig end (reference pads its arrays); keep < 90
+        pos1 = rng.randint(1, ln - span + 60) if ln - span + 60 >= 1 else 1
+        pos1 = max(1, pos1)
+        flag = rng.choice([0, 0, 0, 16, 16, 256, 1024, 512, 99, 147, 2048])
+        mapq = rng.choice([0, 10, 20, 60, 60])
+        if rng.random() < 0.03:      # unmapped read placed at its mate's position (no CIGAR)
+            flag, cig = 4 | 1 | 64, "*"
+        recs.append((ci, pos1, flag, mapq, cig))
+    return recs
+
+
+def build_f1(d):
+    os.makedirs(d, exist_ok=True)
+    recs = f1_reads(42)
+    srt = sorted(range(len(recs)), key=lambda k: (recs[k][0], recs[k][1], k))
+    sam = sam_header(F1_CONTIGS, True)
+    for k in srt:
+        ci, pos1, flag, mapq, cig = recs[k]
+        sam += sam_line(k, flag, F1_CONTIGS[ci][0], pos1, mapq, cig)
+    write(os.path.join(d, "f1.sam"), sam)
+    to_bam(os.path.join(d, "f1.sam"), os.path.join(d, "f1.bam"), True)
+    # the same records with no index next to them (forces the sorted no-index stream)
+    shutil.copy(os.path.join(d, "f1.bam"), os.path.join(d, "f1_noidx.bam"))
+    # unsorted: shuffled order, header says unsorted
+    rng = random.Random(7)
+    order = list(range(len(recs)))
+    rng.shuffle(order)
+    usam = sam_header(F1_CONTIGS, False)
+    for k in order:
+        ci, pos1, flag, mapq, cig = recs[k]
+        usam += sam_line(k, flag, F1_CONTIGS[ci][0], pos1, mapq, cig)
+    write(os.path.join(d, "f1_unsorted.sam"), usam)
+    to_bam(os.path.join(d, "f1_unsorted.sam"), os.path.join(d, "f1_unsorted.bam"), False)
+    # two more samples for the list mode
+    for s, seed in (("f1_s2", 43), ("f1_s3", 44)):
+        r2 = f1_reads(seed, 400)
+        srt2 = sorted(range(len(r2)), key=lambda k: (r2[k][0], r2[k][1], k))
+        t = sam_header(F1_CONTIGS, True)
+        for k in srt2:
+            ci, pos1, flag, mapq, cig = r2[k]
+            t += sam_line(k, flag, F1_CONTIGS[ci][0], pos1, mapq, cig)
+        write(os.path.join(d, s + ".sam"), t)
+        to_bam(os.path.join(d, s + ".sam"), os.path.join(d, s + ".bam"), True)
+        os.remove(os.path.join(d, s + ".sam"))
+    write(os.path.join(d, "f1_3.list"), "f1.bam\nf1_s2.bam\n\nf1_s3.bam\n")
+    write(os.path.join(d, "f1_mixed.list"), "f1.bam\nf1_noidx.bam\nf1_unsorted.bam\n")
+
+    gff = "\n".join([
+        "##gff-version 3",
+        "# comment line",
+        "chrA\tsrc\tgene\t100\t700\t.\t+\t.\tID=g1",
+        "chrA\tsrc\tmRNA\t100\t700\t.\t+\t.\tID=g1.t1;Parent=g1",
+        "chrA\tsrc\texon\t100\t260\t.\t+\t.\tID=g1.t1.e1;Parent=g1.t1",
+        "chrA\tsrc\tCDS\t120\t260\t.\t+\t0\tID=g1.t1.c1;Parent=g1.t1",
+        "chrA\tsrc\texon\t400\t520\t.\t+\t.\tID=g1.t1.e2;Parent=g1.t1",
+        "chrA\tsrc\tCDS\t400\t520\t.\t+\t0\tID=g1.t1.c2;Parent=g1.t1",
+        "chrA\tsrc\texon\t600\t700\t.\t+\t.\tID=g1.t1.e3;Parent=g1.t1",
+        "chrA\tsrc\tCDS\t600\t690\t.\t+\t0\tID=g1.t1.c3;Parent=g1.t1",
+        "chrA\tsrc\tCDS\t120\t200\t.\t-\t0\tID=g0.t1.c1;Parent=g0.t1",
+        "chrA\tsrc\tCDS\t120\t180\t.\t-\t0\tID=g0.t0.c1;Parent=g0.t0",
+        "chrA\tsrc\tCDS\t900\t1001\t.\t-\t0\tParent=g2.t1",
+        "chrA\tsrc\tCDS\t650\t720\t.\t-\t0\tID=ov1;Parent=g3.t1,g3.t2",
+        "chrA\tsrc\tCDS\t721\t760\t.\t-\t0\tID=adj1;Parent=g4.t1",
+        "chrB\tsrc\tCDS\t1\t90\t.\t+\t0\tID=b1.c1;Parent=b1.t1",
+        "chrB\tsrc\tCDS\t200\t500\t.\t+\t0\tID=b2.c1;Parent=b2.t1;Note=x",
+        "chrB\tsrc\tCDS\t250\t300\t.\t+\t0\tID=b2.c2;Parent=b2.t1",
+        "chrB\tsrc\texon\t10\t40\t.\t+\t.\tID=onlyid",
+        "chrZ\tsrc\tCDS\t5\t50\t.\t+\t0\tID=z1;Parent=z.t1",
+        "",
+    ]) + "\n"
+    write(os.path.join(d, "f1.gff"), gff)
+
+    gtf = "\n".join([
+        "# gtf comment",
+        'chrA\tsrc\tCDS\t120\t260\t.\t+\t0\tgene_id "g1"; transcript_id "g1.t1";',
+        'chrA\tsrc\tCDS\t400\t520\t.\t+\t0\tgene_id "g1"; transcript_id "g1.t1";',
+        'chrA\tsrc\texon\t100\t260\t.\t+\t.\tgene_id "g1"; transcript_id "g1.t1";',
+        'chrA\tsrc\tCDS\t120\t200\t.\t-\t0\tgene_id "g0"; transcript_id "g0.t1";',
+        'chrA\tsrc\tCDS\t900\t1001\t.\t-\t0\tgene_id "g2"; transcript_id "g2.t1"; extra "y";',
+        'chrB\tsrc\tCDS\t200\t500\t.\t+\t0\tgene_id "b2"; transcript_id "b2.t1";',
+        'chrB\tsrc\tCDS\t1\t90\t.\t+\t0\tgene_id "b1"; transcript_id "b1.t1";',
+        'chrZ\tsrc\tCDS\t5\t50\t.\t+\t0\tgene_id "z"; transcript_id "z.t1";',
+    ]) + "\n"
+    write(os.path.join(d, "f1.gtf"), gtf)
+
+    bed3 = "\n".join([
+        "#chr\tstart\tend",
+        "chrA\t100\t200",
+        "chrA\t150\t400",
+        "chrA\t0900\t1001",
+        "chrB\t1\t500",
+        "chrB\t300\t250",
+        "chrQ\t1\t10",
+        "chrA\t100\t200",
+        "chrA\t401\t401",
+    ]) + "\n"
+    write(os.path.join(d, "f1.bed3"), bed3)
+
+    bed4 = "\n".join([
+        "chrA\t100\t200\tr1",
+        "chrA\t150\t400\tr2",
+        "chrA\t500\t600\tr1",
+        "chrB\t10\t260\tq2",
+        "chrB\t10\t60\tq1",
+        "chrB\t300\t250\tbad",
+        "chrA\t700\t1001\ttail",
+    ]) + "\n"
+    write(os.path.join(d, "f1.bed4"), bed4)
+
+
+F1_CASES = [
+    # name, args (inputs are relative to the fixture dir)
+    ("chr", ["-i", "f1.bam"]),
+    ("chr_t1", ["-i", "f1.bam", "-t", "1"]),
+    ("chr_q20", ["-i", "f1.bam", "-q", "20"]),
+    ("chr_x0", ["-i", "f1.bam", "-x", "0"]),
+    ("chr_d3", ["-i", "f1.bam", "-d", "3"]),
+    ("chr_s", ["-i", "f1.bam", "-s"]),
+    ("chr_a", ["-i", "f1.bam", "-a"]),
+    ("chr_sam", ["-i", "f1.sam"]),
+    ("chr_noidx", ["-i", "f1_noidx.bam"]),
+    ("chr_unsorted", ["-i", "f1_unsorted.bam"]),
+    ("chr_unsorted_sam_a", ["-i", "f1_unsorted.sam", "-a"]),
+    ("w100", ["-i", "f1.bam", "-w", "100"]),
+    ("w100_a", ["-i", "f1.bam", "-w", "100", "-a"]),
+    ("w100_s", ["-i", "f1.bam", "-w", "100", "-s"]),
+    ("w1", ["-i", "f1.bam", "-w", "1"]),
+    ("w149_d2", ["-i", "f1.bam", "-w", "149", "-d", "2"]),
+    ("w150", ["-i", "f1.bam", "-w", "150"]),
+    ("w200", ["-i", "f1.bam", "-w", "200"]),
+    ("w200_a", ["-i", "f1.bam", "-w", "200", "-a"]),
+    ("w200_s", ["-i", "f1.bam", "-w", "200", "-s"]),
+    ("w1000", ["-i", "f1.bam", "-w", "1000"]),
+    ("gff", ["-i", "f1.bam", "-g", "f1.gff"]),
+    ("gff_exon", ["-i", "f1.bam", "-g", "f1.gff", "-f", "exon"]),
+    ("gff_a", ["-i", "f1.bam", "-g", "f1.gff", "-a"]),
+    ("gff_s_a", ["-i", "f1.bam", "-g", "f1.gff", "-s", "-a"]),
+    ("gff_unsorted_a", ["-i", "f1_unsorted.bam", "-g", "f1.gff", "-a"]),
+    ("gff_w", ["-i", "f1.bam", "-g", "f1.gff", "-w", "100"]),
+    ("gtf", ["-i", "f1.bam", "-g", "f1.gtf"]),
+    ("bed3", ["-i", "f1.bam", "-b", "f1.bed3"]),
+    ("bed3_a", ["-i", "f1.bam", "-b", "f1.bed3", "-a"]),
+    ("bed4_d10", ["-i", "f1.bam", "-b", "f1.bed4", "-d", "10"]),
+    ("bed4_s", ["-i", "f1.bam", "-b", "f1.bed4", "-s"]),
+    ("list3", ["-i", "f1_3.list"]),
+    ("list3_a", ["-i", "f1_3.list", "-a"]),
+    ("list3_w100", ["-i", "f1_3.list", "-w", "100"]),
+    ("list3_w200", ["-i", "f1_3.list", "-w", "200"]),
+    ("list3_gff", ["-i", "f1_3.list", "-g", "f1.gff"]),
+    ("list3_bed4", ["-i", "f1_3.list", "-b", "f1.bed4"]),
+    ("list_mixed_gff_a", ["-i", "f1_mixed.list", "-g", "f1.gff", "-a"]),
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# F2: 18-bit wrap fixture (262150 stacked reads)
+# ---------------------------------------------------------------------------------------------
+F2_CONTIGS = [("w1", 400), ("w2", 300)]
+
+
+def build_f2(d):
+    os.makedirs(d, exist_ok=True)
+    sam = [sam_header(F2_CONTIGS, True)]
+    k = 0
+    for _ in range(262150):
+        sam.append("r\t0\tw1\t101\t60\t10M\t*\t0\t0\t*\t*\n")
+        k += 1
+    for _ in range(7):
+        sam.append("r\t0\tw1\t105\t60\t20M\t*\t0\t0\t*\t*\n")
+    for _ in range(5):
+        sam.append("r\t0\tw2\t11\t60\t30M\t*\t0\t0\t*\t*\n")
+    write(os.path.join(d, "f2.sam"), "".join(sam))
+    to_bam(os.path.join(d, "f2.sam"), os.path.join(d, "f2.bam"), True)
+    os.remove(os.path.join(d, "f2.sam"))
+    write(os.path.join(d, "f2_2.list"), "f2.bam\nf2.bam\n")
+    write(os.path.join(d, "f2.bed4"), "w1\t90\t140\thot\nw2\t1\t300\tcold\n")
+
+
+F2_CASES = [
+    ("chr", ["-i", "f2.bam"]),                 # uint32 cells
+    ("chr_s", ["-i", "f2.bam", "-s"]),         # 18-bit cells
+    ("chr_a", ["-i", "f2.bam", "-a"]),         # 18-bit cells
+    ("w50", ["-i", "f2.bam", "-w", "50"]),     # mode 6, 18-bit
+    ("w150", ["-i", "f2.bam", "-w", "150"]),   # mode 5, uint32
+    ("bed4", ["-i", "f2.bam", "-b", "f2.bed4"]),
+    ("bed4_a", ["-i", "f2.bam", "-b", "f2.bed4", "-a"]),
+    ("list2", ["-i", "f2_2.list"]),            # 2 x 262150 = 524300 -> mod 2^18
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# F3: config-1 "tiny.bam": ~10k reads on a 1 000 003 bp reference
+# ---------------------------------------------------------------------------------------------
+F3_CONTIGS = [("chr1", 700001), ("chr2", 250000), ("chr3", 50001), ("chr4", 1)]
+
+
+def build_f3(d):
+    os.makedirs(d, exist_ok=True)
+    rng = random.Random(42)
+    recs = []
+    total = sum(l for _, l in F3_CONTIGS)
+    for i in range(10000):
+        x = rng.randrange(total - 1)
+        ci = 0
+        while x >= F3_CONTIGS[ci][1]:
+            x -= F3_CONTIGS[ci][1]
+            ci += 1
+        ln = F3_CONTIGS[ci][1]
+        u = rng.random()
+        if u < 0.85:
+            cig = "150M"
+        elif u < 0.90:
+            a = rng.randint(10, 140)
+            cig = "%dM%dD%dM" % (a, rng.randint(1, 20), 150 - a)
+        elif u < 0.95:
+            a = rng.randint(10, 130)
+            ins = rng.randint(1, 10)
+            cig = "%dM%dI%dM" % (a, ins, 150 - a - ins)
+        elif u < 0.99:
+            s = rng.randint(1, 40)
+            cig = "%dS%dM" % (s, 150 - s)
+        else:
+            a = rng.randint(20, 130)
+            cig = "%dM%dN%dM" % (a, rng.randint(100, 5000), 150 - a)
+        span = cigar_ref_span(cig)
+        pos1 = min(x + 1, max(1, ln - span + 1))
+        v = rng.random()
+        flag = 0 if rng.random() < 0.5 else 16
+        if v < 0.02:
+            flag |= 1024
+        elif v < 0.03:
+            flag |= 256
+        elif v < 0.04:
+            flag |= 512
+        mapq = rng.choice([0, 20, 60, 60, 60])
+        recs.append((ci, pos1, flag, mapq, cig))
+    srt = sorted(range(len(recs)), key=lambda k: (recs[k][0], recs[k][1], k))
+    sam = [sam_header(F3_CONTIGS, True)]
+    for k in srt:
+        ci, pos1, flag, mapq, cig = recs[k]
+        sam.append(sam_line(k, flag, F3_CONTIGS[ci][0], pos1, mapq, cig))
+    for k in range(50):     # unmapped, unplaced reads at the end of the file
+        sam.append("u%d\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n" % k)
+    write(os.path.join(d, "tiny.sam"), "".join(sam))
+    to_bam(os.path.join(d, "tiny.sam"), os.path.join(d, "tiny.bam"), True)
+    os.remove(os.path.join(d, "tiny.sam"))
+    # synthetic annotation: 40 transcripts with 1-6 CDS each
+    g = ["##gff-version 3"]
+    rg = random.Random(5)
+    for t in range(40):
+        ci = rg.choice([0, 0, 0, 1, 1, 2])
+        name, ln = F3_CONTIGS[ci]
+        s = rg.randint(1, ln - 40000)
+        for e in range(rg.randint(1, 6)):
+            el = rg.randint(60, 600)
+            g.append("%s\tsyn\tCDS\t%d\t%d\t.\t+\t0\tID=t%d.c%d;Parent=t%d" % (name, s, s + el - 1, t, e, t))
+            s += el + rg.randint(50, 5000)
+    write(os.path.join(d, "tiny.gff"), "\n".join(g) + "\n")
+
+
+F3_CASES = [
+    ("chr", ["-i", "tiny.bam"]),
+    ("chr_s", ["-i", "tiny.bam", "-s"]),
+    ("gff", ["-i", "tiny.bam", "-g", "tiny.gff"]),
+    ("w1000", ["-i", "tiny.bam", "-w", "1000"]),
+    ("w100", ["-i", "tiny.bam", "-w", "100"]),
+    ("w100_a", ["-i", "tiny.bam", "-w", "100", "-a"]),
+]
+
+BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
+
+
+def run_cases(fx, d, cases, manifest):
+    outd = os.path.join(d, "expected")
+    if os.path.isdir(outd):
+        shutil.rmtree(outd)
+    os.makedirs(outd)
+    for name, args in cases:
+        prefix = os.path.join("expected", name)
+        cmd = [REF] + args + ["-o", prefix]
+        p = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        entry = {"fixture": fx, "name": name, "args": args, "returncode": p.returncode,
+                 "stdout": p.stdout.decode(), "outputs": {}}
+        for fn in sorted(os.listdir(outd)):
+            if not fn.startswith(name + "."):
+                continue
+            path = os.path.join(outd, fn)
+            gzb = open(path, "rb").read()
+            txt = gzip.decompress(gzb)
+            suffix = fn[len(name) + 1:]
+            keep = len(txt) <= BIG_OUTPUT
+            entry["outputs"][suffix] = {"gz_sha256": sha(gzb), "text_sha256": sha(txt),
+                                        "text_bytes": len(txt), "committed": keep}
+            if not keep:
+                os.remove(path)
+        manifest.append(entry)
+        print("%-4s %-22s rc=%d %s" % (fx, name, p.returncode, " ".join(sorted(entry["outputs"]))))
+
+
+def main():
+    if not (os.path.exists(REF) and os.path.exists(SAM2BAM)):
+        sys.exit("build the reference oracle first: make -C oracle ref")
+    manifest = []
+    for fx, build, cases in (("f1", build_f1, F1_CASES), ("f2", build_f2, F2_CASES),
+                             ("f3", build_f3, F3_CASES)):
+        d = os.path.join(HERE, fx)
+        build(d)
+        run_cases(fx, d, cases, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()
