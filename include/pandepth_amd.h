@@ -1,0 +1,140 @@
+/* pandepth_amd.h — C-ABI of the MI355X-native per-base depth engine.
+ *
+ * The reference (HuiyangYu/PanDepth, src/PanDepth.cpp = "PD") has no plugin / FFI interface:
+ * its depth engine is a set of C++ functions operating on host arrays inside one translation
+ * unit.  This header cuts the boundary exactly along that seam.  Each entry point names the
+ * reference code it replaces; a maintainer's call-site patch is shown in INTEGRATION.md.
+ *
+ *   producer (stays on the host)     : the htslib record loop + CIGAR walk, PD:434-460
+ *   consumer (this library, on HBM)  : depth storage            PD:4129-4145, PD:715-721, PD:2687-2699
+ *                                      per-base increment       PD:449-452 (and its 6 copies)
+ *                                      interval statistics      PD:295-327, PD:329-348
+ *                                      small-window sweep       PD:4366-4389
+ *                                      per-site read-back       PD:4278-4281
+ *                                      multi-BAM accumulation   PD:2704-3014
+ *
+ * Conventions: plain C, caller owns every host buffer, the context owns all device memory and
+ * one HIP stream; every function returns 0 on success or a negative PD_E* code, and
+ * pd_strerror(ctx) gives the text of the last failure.  One context per GPU.
+ * pd_push_intervals* may be called from several host threads (serialised inside); everything
+ * else is single-caller.  All arithmetic is integer and bit-exact with the reference.
+ *
+ * The library REFUSES to run without a gfx950 device: pd_create fails with PD_ENODEV.  There
+ * is no CPU fallback inside it.
+ */
+#ifndef PANDEPTH_AMD_H_
+#define PANDEPTH_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_ABI_VERSION 1
+
+enum {
+    PD_OK = 0,
+    PD_EINVAL = -1,   /* bad argument                                  */
+    PD_ENODEV = -2,   /* no usable gfx950 device / HIP runtime failure  */
+    PD_ENOMEM = -3,   /* device or pinned-host allocation failed       */
+    PD_ESTATE = -4,   /* call not valid in the context's current state */
+    PD_EHIP   = -5    /* a HIP call failed; see pd_strerror            */
+};
+
+typedef struct pd_ctx pd_ctx;
+
+/* One M/=/X CIGAR run: cells [beg, end) of contig tid, 0-based — exactly the range the
+ * reference's inner `for (; StartRead<endTmp; StartRead++) depth[tid][StartRead]++` visits
+ * (PD:449-452).  Runs are clipped to [0, contig_len] on the device (the reference lets reads
+ * overhang into its +500 padding, PD:4132; those cells are never reported). */
+typedef struct pd_iv { int32_t tid, beg, end; } pd_iv;
+
+/* One CDSList entry: 1-based inclusive (first, second) on contig tid, visited by the reference
+ * as cells [first-1, second) (PD:336-337, PD:313-314). */
+typedef struct pd_region { int32_t tid, first, second; } pd_region;
+
+/* flags for pd_push_intervals / pd_push_intervals_device / pd_stage_submit */
+#define PD_PUSH_DEFAULT 0u   /* any order: two device atomics per run                             */
+#define PD_PUSH_SORTED  1u   /* caller promises the batch is sorted by (tid, beg), as the runs of
+                              * a coordinate-sorted BAM are when only each read's first run is
+                              * taken: owner-tile scatter (LDS accumulate, plain 16-byte RMW flush,
+                              * no global atomics).  A broken promise is detected on the device
+                              * and reported by pd_scan / pd_scan_reduce_windows (PD_EINVAL). */
+
+/* Context: replaces `new SiteInfo[len+500]` per contig + zero loop (PD:4129-4145,
+ * PD:4553-4581, PD:2687-2699) and `new unsigned int[window]` (PD:715-721).  Allocates ONE
+ * int32 buffer in HBM: every contig's difference array, each slot rounded up to an 8192-cell
+ * tile, followed by one int32 tile-sum per tile; zero-filled. */
+int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out);
+int pd_destroy(pd_ctx *ctx);
+const char *pd_strerror(const pd_ctx *ctx);      /* ctx may be NULL: last pd_create failure */
+int pd_abi_version(void);
+
+/* Zero the arrays again and return to the accumulating state (a new sample / a new step). */
+int pd_reset(pd_ctx *ctx);
+
+/* Replaces the increment loop PD:449-452: +1 at beg, -1 at end in the difference arrays.
+ * Host form copies through pinned staging buffers (async H2D overlapped with the scatter
+ * kernel); device form takes a pointer that is already resident in HBM on ctx's device.
+ * Valid only before pd_scan. */
+int pd_push_intervals(pd_ctx *ctx, const pd_iv *iv, size_t n, unsigned flags);
+int pd_push_intervals_device(pd_ctx *ctx, const pd_iv *dev_iv, size_t n, unsigned flags);
+
+/* Zero-copy variant of the host form for reader threads: acquire a pinned staging slot, write
+ * up to *capacity runs into it, submit.  A slot is reusable once its scatter has completed;
+ * acquire blocks on the oldest one when all are in flight. */
+int pd_stage_acquire(pd_ctx *ctx, pd_iv **host_buf, size_t *capacity);
+int pd_stage_submit(pd_ctx *ctx, pd_iv *host_buf, size_t n, unsigned flags);
+
+/* Tuning knobs: "lmax" (owner-tile look-back in cells; longer runs take the overflow path),
+ * "sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the tile kernel). */
+int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
+
+/* Difference arrays -> per-base depth, in place (the wavefront prefix-sum sweep).
+ * wrap_bits = 18 reproduces the `unsigned Depth:18` cell (DataClass.h:85-88) used by the -a,
+ * -w<150, no-index and #.list paths; wrap_bits = 0 the `unsigned int` window cell (PD:717). */
+int pd_scan(pd_ctx *ctx, unsigned wrap_bits);
+
+/* Replaces StatChrDepthLowMEM / StatChrDepthWin (PD:329-348 / PD:295-327) for a list of
+ * CDSList entries: cover[i] = #{cells with depth >= min_dep}, sum[i] = sum of those depths.
+ * Requires pd_scan first.  cover is `int` in the reference (DataClass.h:63). */
+int pd_reduce_intervals(pd_ctx *ctx, const pd_region *regs, size_t n, uint32_t min_dep,
+                        int32_t *cover, uint64_t *sum);
+
+/* Fixed windows of `w` cells from cell 0 of every contig (the last one clipped to the contig
+ * end): replaces the synthetic 10 Mb / -w bins + StatChrDepth* (PD:3995-4049 + PD:295-348) and
+ * the -w<150 sweep (PD:4366-4389).  Window k of contig t is written at index
+ * win_off[t] + k, where win_off comes from pd_window_layout (n_contigs+1 entries, last = total).
+ *   pd_scan_reduce_windows : fused — reads the DIFFERENCE arrays once, never writes depth
+ *                            (4 B/base of HBM traffic); state stays "accumulating".
+ *   pd_reduce_windows      : from the depth arrays left by pd_scan. */
+int pd_window_layout(const pd_ctx *ctx, uint32_t w, uint64_t *win_off);
+int pd_scan_reduce_windows(pd_ctx *ctx, uint32_t w, uint32_t min_dep, unsigned wrap_bits,
+                           uint32_t *cover, uint64_t *sum);
+int pd_reduce_windows(pd_ctx *ctx, uint32_t w, uint32_t min_dep, uint32_t *cover, uint64_t *sum);
+
+/* Replaces the per-site read loop PD:4278-4281: copies depth cells [beg, beg+n) of contig tid
+ * to the host.  Requires pd_scan first. */
+int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *out);
+
+/* Test / interop access to the accumulating buffer (difference arrays + tile sums are ONE
+ * contiguous int32 allocation so that a multi-BAM sum, PD:2704-3014, is a single RCCL
+ * all-reduce / reduce-scatter of n_words int32 over xGMI, issued by the caller on the stream
+ * returned by pd_stream).  contig_off (n_contigs entries, in cells) may be NULL. */
+int pd_device_buffer(pd_ctx *ctx, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off);
+void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
+int pd_synchronize(pd_ctx *ctx);
+
+/* Per-kernel timing with HIP events recorded on the context's stream around every launch.
+ * pd_profile_get returns the accumulated milliseconds and launch count of kernel `name`
+ * ("fill", "scatter", "tile_carry", "scan", "scan_reduce_windows", "reduce_intervals",
+ * "reduce_windows"); pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
+int pd_profile(pd_ctx *ctx, int enable);
+int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDEPTH_AMD_H_ */

@@ -1,0 +1,194 @@
+"""ctypes mirror of include/pandepth_amd.h (one method per entry point, same names/arguments).
+
+Plumbing only: numpy arrays in, numpy arrays out, raw device pointers accepted for HBM-resident
+batches (e.g. torch tensors' data_ptr()).  Every failure of the C-ABI raises PdError with the
+library's own message; there is no alternative code path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+PD_PUSH_DEFAULT = 0
+PD_PUSH_SORTED = 1
+PD_TILE = 8192
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IV_DTYPE = np.dtype([("tid", "<i4"), ("beg", "<i4"), ("end", "<i4")])
+
+
+class PdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pandepth_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libpandepth_amd.so")
+
+
+def load():
+    """Load libpandepth_amd.so (built in-tree by `make -C pandepth_amd` / __graft_entry__.build)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise PdError(-2, "libpandepth_amd.so is not built (run `make -C pandepth_amd`); "
+                          "there is no CPU fallback")
+    L = ctypes.CDLL(p)
+    P, I, U, U64, SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, ctypes.c_size_t
+    sig = {
+        "pd_abi_version": (I, []),
+        "pd_create": (I, [I, ctypes.c_int32, P, ctypes.POINTER(P)]),
+        "pd_destroy": (I, [P]),
+        "pd_strerror": (ctypes.c_char_p, [P]),
+        "pd_reset": (I, [P]),
+        "pd_push_intervals": (I, [P, P, SZ, U]),
+        "pd_push_intervals_device": (I, [P, P, SZ, U]),
+        "pd_stage_acquire": (I, [P, ctypes.POINTER(P), ctypes.POINTER(SZ)]),
+        "pd_stage_submit": (I, [P, P, SZ, U]),
+        "pd_set_param": (I, [P, ctypes.c_char_p, U64]),
+        "pd_scan": (I, [P, U]),
+        "pd_reduce_intervals": (I, [P, P, SZ, ctypes.c_uint32, P, P]),
+        "pd_window_layout": (I, [P, ctypes.c_uint32, P]),
+        "pd_scan_reduce_windows": (I, [P, ctypes.c_uint32, ctypes.c_uint32, U, P, P]),
+        "pd_reduce_windows": (I, [P, ctypes.c_uint32, ctypes.c_uint32, P, P]),
+        "pd_read_depth": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, P]),
+        "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
+        "pd_stream": (P, [P]),
+        "pd_synchronize": (I, [P]),
+        "pd_profile": (I, [P, I]),
+        "pd_profile_get": (I, [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(U64)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _LIB = L
+    return L
+
+
+EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
+           "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
+           "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
+           "pd_read_depth", "pd_device_buffer", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_profile_get"]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_iv(a):
+    """(n,3) int32 array or IV_DTYPE array -> contiguous (n,3) int32."""
+    a = np.asarray(a)
+    if a.dtype == IV_DTYPE:
+        a = a.view(np.int32).reshape(-1, 3)
+    return np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 3)
+
+
+class Engine:
+    """One pd_ctx.  Method names follow the C entry points without the pd_ prefix."""
+
+    def __init__(self, contig_len, device=0):
+        self.L = load()
+        self.len = np.ascontiguousarray(contig_len, dtype=np.uint32)
+        self.n_contigs = int(self.len.size)
+        h = ctypes.c_void_p()
+        rc = self.L.pd_create(int(device), self.n_contigs, _ptr(self.len), ctypes.byref(h))
+        if rc != 0:
+            raise PdError(rc, (self.L.pd_strerror(None) or b"").decode())
+        self.h = h
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PdError(rc, (self.L.pd_strerror(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pd_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        self._ck(self.L.pd_reset(self.h))
+
+    def set_param(self, name, value):
+        self._ck(self.L.pd_set_param(self.h, name.encode(), int(value)))
+
+    def push_intervals(self, iv, flags=PD_PUSH_DEFAULT):
+        iv = as_iv(iv)
+        self._ck(self.L.pd_push_intervals(self.h, _ptr(iv), iv.shape[0], int(flags)))
+
+    def push_intervals_device(self, dev_ptr, n, flags=PD_PUSH_DEFAULT):
+        self._ck(self.L.pd_push_intervals_device(self.h, ctypes.c_void_p(int(dev_ptr)), int(n), int(flags)))
+
+    def scan(self, wrap_bits=0):
+        self._ck(self.L.pd_scan(self.h, int(wrap_bits)))
+
+    def reduce_intervals(self, regs, min_dep=1):
+        regs = np.ascontiguousarray(regs, dtype=np.int32).reshape(-1, 3)
+        n = regs.shape[0]
+        cover = np.zeros(n, dtype=np.int32)
+        tot = np.zeros(n, dtype=np.uint64)
+        self._ck(self.L.pd_reduce_intervals(self.h, _ptr(regs), n, int(min_dep), _ptr(cover), _ptr(tot)))
+        return cover, tot
+
+    def window_layout(self, w):
+        off = np.zeros(self.n_contigs + 1, dtype=np.uint64)
+        self._ck(self.L.pd_window_layout(self.h, int(w), _ptr(off)))
+        return off
+
+    def scan_reduce_windows(self, w, min_dep=1, wrap_bits=0):
+        off = self.window_layout(w)
+        n = int(off[-1])
+        cover = np.zeros(max(n, 1), dtype=np.uint32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_scan_reduce_windows(self.h, int(w), int(min_dep), int(wrap_bits), _ptr(cover), _ptr(tot)))
+        return off, cover[:n], tot[:n]
+
+    def reduce_windows(self, w, min_dep=1):
+        off = self.window_layout(w)
+        n = int(off[-1])
+        cover = np.zeros(max(n, 1), dtype=np.uint32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_reduce_windows(self.h, int(w), int(min_dep), _ptr(cover), _ptr(tot)))
+        return off, cover[:n], tot[:n]
+
+    def read_depth(self, tid, beg=0, n=None):
+        if n is None:
+            n = int(self.len[tid]) - int(beg)
+        out = np.zeros(max(int(n), 1), dtype=np.uint32)
+        self._ck(self.L.pd_read_depth(self.h, int(tid), int(beg), int(n), _ptr(out)))
+        return out[:int(n)]
+
+    def device_buffer(self):
+        p = ctypes.c_void_p()
+        nw = ctypes.c_uint64()
+        off = np.zeros(self.n_contigs, dtype=np.uint64)
+        self._ck(self.L.pd_device_buffer(self.h, ctypes.byref(p), ctypes.byref(nw), _ptr(off)))
+        return int(p.value), int(nw.value), off
+
+    def stream(self):
+        return int(self.L.pd_stream(self.h) or 0)
+
+    def synchronize(self):
+        self._ck(self.L.pd_synchronize(self.h))
+
+    def profile(self, enable=True):
+        self._ck(self.L.pd_profile(self.h, 1 if enable else 0))
+
+    def profile_get(self, name):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        self._ck(self.L.pd_profile_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)

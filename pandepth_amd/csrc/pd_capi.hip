@@ -1,0 +1,563 @@
+// pd_capi.hip — implementation of include/pandepth_amd.h on top of pd_kernels.hip.
+//
+// One context = one GPU, one compute stream, one copy stream, one int32 allocation holding all
+// contig difference arrays followed by the tile sums.  Host batches go through a small pool of
+// pinned staging slots (async H2D on the copy stream, scatter on the compute stream), so
+// reader threads overlap decode, PCIe and the scatter kernel.  No CPU fallback exists here:
+// without a gfx950 device pd_create fails.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <map>
+#include "pd_kernels.h"
+
+using namespace pdk;
+
+namespace {
+
+constexpr int N_STAGE = 8;
+constexpr size_t STAGE_CAP = (size_t)2 << 20;        // runs per staging slot (24 MiB)
+constexpr size_t DEV_BATCH_MAX = (size_t)48 << 20;   // runs per sorted device sub-batch
+constexpr uint32_t OVF_CAP = (uint32_t)DEV_BATCH_MAX;
+constexpr uint32_t LMAX_DEFAULT = 512;               // look-back bound for owner tiles (cells)
+constexpr uint32_t SAMPLE_DEFAULT = 64;              // sparse index stride (runs)
+
+std::string g_create_err;
+
+struct Stage {
+    pd_iv *host = nullptr, *dev = nullptr;
+    hipEvent_t copied = nullptr, done = nullptr;
+    int state = 0;                                   // 0 free, 1 held by caller, 2 in flight
+    uint64_t seq = 0;
+};
+
+struct ProfRec { std::string name; hipEvent_t a, b; };
+
+} // namespace
+
+struct pd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    int32_t n_contigs = 0;
+    std::vector<uint32_t> len;
+    std::vector<uint64_t> off;                       // first cell of each slot
+    uint64_t n_cells = 0, n_tiles = 0, n_words = 0;
+    int *buf = nullptr;                              // [n_cells diff | n_tiles sums | pad]
+    int *sums = nullptr, *carry = nullptr;
+    uint64_t *d_off = nullptr; uint32_t *d_len = nullptr; uint32_t *d_tile_contig = nullptr;
+    uint32_t *ub_a = nullptr, *cand_lo = nullptr;
+    BatchDesc *desc = nullptr; CheckWords *chk = nullptr;
+    uint64_t *ovf = nullptr;
+    Stage stage[N_STAGE];
+    uint64_t seq = 0;
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    int state = 0;                                   // 0 accumulating (diff), 1 depth
+    uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
+    unsigned grid_tiles = 2048;
+    bool prof = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::map<std::string, std::pair<double, uint64_t>> prof_acc;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+int fail(pd_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPOK(ctx, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+ContigTab tab_of(pd_ctx *c) { return ContigTab{c->d_off, c->d_len, c->n_contigs}; }
+
+hipEvent_t get_event(pd_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    pd_ctx *c; ProfRec r; bool on;
+    ProfScope(pd_ctx *ctx, const char *name) : c(ctx), on(ctx->prof)
+    {
+        if (on) { r.name = name; r.a = get_event(c); r.b = get_event(c); (void)hipEventRecord(r.a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(r.b, c->stream); c->prof_pending.push_back(r); }
+    }
+};
+
+int prof_collect(pd_ctx *c)
+{
+    if (c->prof_pending.empty()) return PD_OK;
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof_pending) {
+        float ms = 0.f;
+        HIPOK(c, hipEventElapsedTime(&ms, r.a, r.b));
+        auto &acc = c->prof_acc[r.name];
+        acc.first += ms; acc.second += 1;
+        c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
+    }
+    c->prof_pending.clear();
+    return PD_OK;
+}
+
+int ensure_scratch(pd_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return PD_OK;
+    if (c->scratch) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&c->scratch, want) != hipSuccess) return fail(c, PD_ENOMEM, "scratch allocation failed");
+    c->scratch_bytes = want;
+    return PD_OK;
+}
+
+int do_fill(pd_ctx *c)
+{
+    ProfScope ps(c, "fill");
+    launch_fill(c->stream, c->buf, c->n_words * 4);
+    HIPOK(c, hipMemsetAsync(c->chk, 0, sizeof(CheckWords), c->stream));
+    HIPOK(c, hipMemsetAsync(c->desc, 0, sizeof(BatchDesc), c->stream));
+    return PD_OK;
+}
+
+// scatter a device-resident batch on the compute stream
+int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags)
+{
+    if (n == 0) return PD_OK;
+    ProfScope ps(c, "scatter");
+    if (flags & PD_PUSH_SORTED) {
+        for (size_t o = 0; o < n; o += DEV_BATCH_MAX) {
+            const size_t m = n - o < DEV_BATCH_MAX ? n - o : DEV_BATCH_MAX;
+            launch_scatter_sorted(c->stream, d + o, (uint32_t)m, tab_of(c), c->lmax, c->sample, c->ub_a,
+                                  c->cand_lo, (uint32_t)c->n_tiles, c->desc, c->buf, c->sums, c->ovf,
+                                  OVF_CAP, c->chk, c->grid_tiles);
+        }
+    } else {
+        launch_scatter_atomic(c->stream, d, n, tab_of(c), c->buf, c->sums);
+    }
+    HIPOK(c, hipGetLastError());
+    return PD_OK;
+}
+
+int check_words(pd_ctx *c)
+{
+    CheckWords h;
+    HIPOK(c, hipMemcpyAsync(&h, c->chk, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (h.unsorted_batches || h.err) {
+        char m[160];
+        snprintf(m, sizeof m, "%llu batch(es) pushed with PD_PUSH_SORTED were not sorted by (tid,beg) or held "
+                 "invalid contig ids (err bits 0x%x); depth arrays are not valid",
+                 (unsigned long long)h.unsorted_batches, h.err);
+        return fail(c, PD_EINVAL, m);
+    }
+    return PD_OK;
+}
+
+// caller holds c->mu
+int stage_acquire(pd_ctx *c, int *slot)
+{
+    for (;;) {
+        int oldest = -1;
+        for (int i = 0; i < N_STAGE; ++i) {
+            Stage &s = c->stage[i];
+            if (s.state == 2 && hipEventQuery(s.done) == hipSuccess) s.state = 0;
+            if (s.state == 0) { *slot = i; s.state = 1; return PD_OK; }
+            if (s.state == 2 && (oldest < 0 || s.seq < c->stage[oldest].seq)) oldest = i;
+        }
+        if (oldest < 0) return fail(c, PD_ESTATE, "all staging slots are held by callers");
+        HIPOK(c, hipEventSynchronize(c->stage[oldest].done));
+        c->stage[oldest].state = 0;
+    }
+}
+
+int stage_submit(pd_ctx *c, int slot, size_t n, unsigned flags)
+{
+    Stage &s = c->stage[slot];
+    if (n == 0) { s.state = 0; return PD_OK; }
+    HIPOK(c, hipMemcpyAsync(s.dev, s.host, n * sizeof(pd_iv), hipMemcpyHostToDevice, c->copy_stream));
+    HIPOK(c, hipEventRecord(s.copied, c->copy_stream));
+    HIPOK(c, hipStreamWaitEvent(c->stream, s.copied, 0));
+    int rc = scatter_device(c, s.dev, n, flags);
+    if (rc) return rc;
+    HIPOK(c, hipEventRecord(s.done, c->stream));
+    s.state = 2; s.seq = ++c->seq;
+    return PD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pd_abi_version(void) { return PD_ABI_VERSION; }
+
+const char *pd_strerror(const pd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out)
+{
+    if (!out || n_contigs <= 0 || !contig_len) return fail(nullptr, PD_EINVAL, "pd_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PD_ENODEV, "pd_create: no HIP device visible (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, PD_ENODEV, "pd_create: device index out of range");
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return fail(nullptr, PD_ENODEV, "pd_create: cannot query device");
+    if (!strstr(pr.gcnArchName, "gfx950"))
+        return fail(nullptr, PD_ENODEV, std::string("pd_create: device is ") + pr.gcnArchName + ", kernels are built for gfx950 only");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PD_ENODEV, "pd_create: hipSetDevice failed");
+
+    pd_ctx *c = new pd_ctx;
+    c->device = device;
+    c->n_contigs = n_contigs;
+    c->len.assign(contig_len, contig_len + n_contigs);
+    c->off.resize((size_t)n_contigs + 1);
+    uint64_t o = 0;
+    for (int32_t i = 0; i < n_contigs; ++i) {
+        c->off[i] = o;
+        o += ((uint64_t)contig_len[i] + 1 + PD_TILE - 1) / PD_TILE * PD_TILE;   // room for the -1 at cell len
+    }
+    c->off[n_contigs] = o;
+    c->n_cells = o;
+    c->n_tiles = o / PD_TILE;
+    if (c->n_tiles >= 0xFFFFFFF0ull) { delete c; return fail(nullptr, PD_EINVAL, "pd_create: genome too large"); }
+    c->n_words = c->n_cells + (c->n_tiles + 3) / 4 * 4;
+    c->grid_tiles = (unsigned)pr.multiProcessorCount * 8;
+
+#define CREATE_OK(call)                                                                                  \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                                 \
+        std::string m_ = std::string("pd_create: ") + #call + ": " + hipGetErrorString(e_);            \
+        pd_destroy(c); return fail(nullptr, e_ == hipErrorOutOfMemory ? PD_ENOMEM : PD_EHIP, m_); } } while (0)
+
+    CREATE_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    CREATE_OK(hipMalloc(&c->buf, c->n_words * 4));
+    c->sums = c->buf + c->n_cells;
+    CREATE_OK(hipMalloc(&c->carry, (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->d_off, ((size_t)n_contigs + 1) * 8));
+    CREATE_OK(hipMalloc(&c->d_len, (size_t)n_contigs * 4));
+    CREATE_OK(hipMalloc(&c->d_tile_contig, (c->n_tiles + 1) * 4));
+    CREATE_OK(hipMalloc(&c->ub_a, (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->cand_lo, (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc)));
+    CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
+    CREATE_OK(hipMalloc(&c->ovf, (size_t)OVF_CAP * 8));
+    {
+        std::vector<uint32_t> tc(c->n_tiles + 1, 0);
+        for (int32_t i = 0; i < n_contigs; ++i)
+            for (uint64_t t = c->off[i] / PD_TILE; t < c->off[i + 1] / PD_TILE; ++t) tc[t] = (uint32_t)i;
+        CREATE_OK(hipMemcpy(c->d_tile_contig, tc.data(), (c->n_tiles + 1) * 4, hipMemcpyHostToDevice));
+        CREATE_OK(hipMemcpy(c->d_off, c->off.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice));
+        CREATE_OK(hipMemcpy(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < N_STAGE; ++i) {
+        CREATE_OK(hipEventCreateWithFlags(&c->stage[i].copied, hipEventDisableTiming));
+        CREATE_OK(hipEventCreateWithFlags(&c->stage[i].done, hipEventDisableTiming));
+    }
+#undef CREATE_OK
+    int rc = do_fill(c);
+    if (rc == PD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PD_EHIP;
+    if (rc != PD_OK) { g_create_err = c->err; pd_destroy(c); return rc; }
+    *out = c;
+    return PD_OK;
+}
+
+int pd_destroy(pd_ctx *c)
+{
+    if (!c) return PD_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (int i = 0; i < N_STAGE; ++i) {
+        if (c->stage[i].host) (void)hipHostFree(c->stage[i].host);
+        if (c->stage[i].dev) (void)hipFree(c->stage[i].dev);
+        if (c->stage[i].copied) (void)hipEventDestroy(c->stage[i].copied);
+        if (c->stage[i].done) (void)hipEventDestroy(c->stage[i].done);
+    }
+    for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    void *ptrs[] = {c->buf, c->carry, c->d_off, c->d_len, c->d_tile_contig, c->ub_a, c->cand_lo, c->desc, c->chk, c->ovf, c->scratch};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+    return PD_OK;
+}
+
+int pd_reset(pd_ctx *c)
+{
+    if (!c) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    c->state = 0;
+    return do_fill(c);
+}
+
+int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
+{
+    if (!c || !name) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(name, "lmax")) { if (value < 1 || value > PD_TILE) return fail(c, PD_EINVAL, "lmax must be in [1, tile]"); c->lmax = (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "sample must be in [1, 65536]"); c->sample = (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "grid_tiles")) { if (value < 1 || value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
+    return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
+}
+
+int pd_push_intervals_device(pd_ctx *c, const pd_iv *dev_iv, size_t n, unsigned flags)
+{
+    if (!c || (!dev_iv && n)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_push_intervals_device: depth already materialised (call pd_reset)");
+    HIPOK(c, hipSetDevice(c->device));
+    return scatter_device(c, dev_iv, n, flags);
+}
+
+int pd_stage_acquire(pd_ctx *c, pd_iv **host_buf, size_t *capacity)
+{
+    if (!c || !host_buf || !capacity) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    int slot = -1;
+    int rc = stage_acquire(c, &slot);
+    if (rc) return rc;
+    Stage &s = c->stage[slot];
+    if (!s.host) {
+        if (hipHostMalloc((void **)&s.host, STAGE_CAP * sizeof(pd_iv), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.dev, STAGE_CAP * sizeof(pd_iv)) != hipSuccess) {
+            s.state = 0;
+            return fail(c, PD_ENOMEM, "staging slot allocation failed");
+        }
+    }
+    *host_buf = s.host; *capacity = STAGE_CAP;
+    return PD_OK;
+}
+
+int pd_stage_submit(pd_ctx *c, pd_iv *host_buf, size_t n, unsigned flags)
+{
+    if (!c || !host_buf) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int slot = -1;
+    for (int i = 0; i < N_STAGE; ++i) if (c->stage[i].host == host_buf && c->stage[i].state == 1) slot = i;
+    if (slot < 0) return fail(c, PD_EINVAL, "pd_stage_submit: buffer was not handed out by pd_stage_acquire");
+    if (n > STAGE_CAP) return fail(c, PD_EINVAL, "pd_stage_submit: more runs than the slot holds");
+    if (c->state != 0) { c->stage[slot].state = 0; return fail(c, PD_ESTATE, "pd_stage_submit: depth already materialised (call pd_reset)"); }
+    HIPOK(c, hipSetDevice(c->device));
+    return stage_submit(c, slot, n, flags);
+}
+
+int pd_push_intervals(pd_ctx *c, const pd_iv *iv, size_t n, unsigned flags)
+{
+    if (!c || (!iv && n)) return PD_EINVAL;
+    for (size_t o = 0; o < n; o += STAGE_CAP) {
+        const size_t m = n - o < STAGE_CAP ? n - o : STAGE_CAP;
+        pd_iv *hb = nullptr; size_t cap = 0;
+        int rc = pd_stage_acquire(c, &hb, &cap);
+        if (rc) return rc;
+        memcpy(hb, iv + o, m * sizeof(pd_iv));
+        rc = pd_stage_submit(c, hb, m, flags);
+        if (rc) return rc;
+    }
+    return PD_OK;
+}
+
+int pd_scan(pd_ctx *c, unsigned wrap_bits)
+{
+    if (!c || wrap_bits > 32) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_scan: already scanned");
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = check_words(c);
+    if (rc) return rc;
+    const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
+    { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->carry, (uint32_t)c->n_tiles); }
+    { ProfScope ps(c, "scan"); launch_scan_write(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask); }
+    HIPOK(c, hipGetLastError());
+    c->state = 1;
+    return PD_OK;
+}
+
+int pd_window_layout(const pd_ctx *c, uint32_t w, uint64_t *win_off)
+{
+    if (!c || !win_off || w == 0) return PD_EINVAL;
+    uint64_t o = 0;
+    for (int32_t i = 0; i < c->n_contigs; ++i) { win_off[i] = o; o += ((uint64_t)c->len[i] + w - 1) / w; }
+    win_off[c->n_contigs] = o;
+    return PD_OK;
+}
+
+static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask, bool from_depth,
+                          uint32_t *cover, uint64_t *sum)
+{
+    std::vector<uint64_t> wo((size_t)c->n_contigs + 1);
+    pd_window_layout(c, w, wo.data());
+    const uint64_t nw = wo[c->n_contigs];
+    const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
+    const size_t b_sum = (size_t)nw * 8, b_cov = (size_t)nw * 4;
+    int rc = ensure_scratch(c, b_off + b_sum + b_cov + 64);
+    if (rc) return rc;
+    unsigned char *s = (unsigned char *)c->scratch;
+    uint64_t *d_wo = (uint64_t *)s;
+    unsigned long long *d_sum = (unsigned long long *)(s + b_off);
+    uint32_t *d_cov = (uint32_t *)(s + b_off + b_sum);
+    HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
+    HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));
+    if (!from_depth) { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->carry, (uint32_t)c->n_tiles); }
+    {
+        ProfScope ps(c, from_depth ? "reduce_windows" : "scan_reduce_windows");
+        TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
+        int e = launch_sweep_windows(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask, tm, w, min_dep,
+                                     d_cov, d_sum, from_depth);
+        if (e) return fail(c, PD_EHIP, "window sweep: cannot reserve LDS");
+    }
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipMemcpyAsync(cover, d_cov, b_cov, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PD_OK;
+}
+
+int pd_scan_reduce_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, unsigned wrap_bits, uint32_t *cover, uint64_t *sum)
+{
+    if (!c || !cover || !sum || w == 0 || wrap_bits > 32) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_scan_reduce_windows: depth already materialised; use pd_reduce_windows");
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = check_words(c);
+    if (rc) return rc;
+    const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
+    return windows_common(c, w, min_dep, mask, false, cover, sum);
+}
+
+int pd_reduce_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t *cover, uint64_t *sum)
+{
+    if (!c || !cover || !sum || w == 0) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 1) return fail(c, PD_ESTATE, "pd_reduce_windows: call pd_scan first");
+    HIPOK(c, hipSetDevice(c->device));
+    return windows_common(c, w, min_dep, 0xFFFFFFFFu, true, cover, sum);
+}
+
+int pd_reduce_intervals(pd_ctx *c, const pd_region *regs, size_t n, uint32_t min_dep, int32_t *cover, uint64_t *sum)
+{
+    if (!c || (n && (!regs || !cover || !sum))) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 1) return fail(c, PD_ESTATE, "pd_reduce_intervals: call pd_scan first");
+    if (n == 0) return PD_OK;
+    if (n > 0xFFFFFFF0ull) return fail(c, PD_EINVAL, "too many regions");
+    HIPOK(c, hipSetDevice(c->device));
+    constexpr uint32_t PIECE = 16384;
+    std::vector<Piece> pieces;
+    pieces.reserve(n + n / 8);
+    for (size_t i = 0; i < n; ++i) {
+        const pd_region &r = regs[i];
+        if (r.tid < 0 || r.tid >= c->n_contigs) return fail(c, PD_EINVAL, "pd_reduce_intervals: contig id out of range");
+        // cells [first-1, second), clipped to the slot (the reference reads its padding; it is zero here)
+        int64_t b = (int64_t)r.first - 1, e = r.second;
+        const int64_t slot = (int64_t)(c->off[r.tid + 1] - c->off[r.tid]);
+        if (b < 0) b = 0;
+        if (e > slot) e = slot;
+        for (int64_t p = b; p < e; p += PIECE) {
+            Piece pc; pc.start = c->off[r.tid] + (uint64_t)p;
+            pc.count = (uint32_t)((e - p) < PIECE ? (e - p) : PIECE); pc.region = (uint32_t)i;
+            pieces.push_back(pc);
+        }
+    }
+    const size_t b_p = pieces.size() * sizeof(Piece), b_sum = n * 8, b_cov = n * 4;
+    int rc = ensure_scratch(c, b_p + b_sum + b_cov + 64);
+    if (rc) return rc;
+    unsigned char *s = (unsigned char *)c->scratch;
+    unsigned long long *d_sum = (unsigned long long *)s;
+    Piece *d_p = (Piece *)(s + b_sum);
+    int *d_cov = (int *)(s + b_sum + b_p);
+    if (!pieces.empty()) HIPOK(c, hipMemcpyAsync(d_p, pieces.data(), b_p, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum, c->stream));
+    HIPOK(c, hipMemsetAsync(d_cov, 0, b_cov, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));          // pieces is a local
+    {
+        ProfScope ps(c, "reduce_intervals");
+        launch_reduce_pieces(c->stream, c->buf, d_p, (uint32_t)pieces.size(), min_dep, d_cov, d_sum);
+    }
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipMemcpyAsync(cover, d_cov, b_cov, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PD_OK;
+}
+
+int pd_read_depth(pd_ctx *c, int32_t tid, uint32_t beg, size_t n, uint32_t *out)
+{
+    if (!c || (!out && n)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 1) return fail(c, PD_ESTATE, "pd_read_depth: call pd_scan first");
+    if (tid < 0 || tid >= c->n_contigs) return fail(c, PD_EINVAL, "pd_read_depth: contig id out of range");
+    if ((uint64_t)beg + n > c->off[tid + 1] - c->off[tid]) return fail(c, PD_EINVAL, "pd_read_depth: range past the contig slot");
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipMemcpyAsync(out, c->buf + c->off[tid] + beg, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PD_OK;
+}
+
+int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off)
+{
+    if (!c) return PD_EINVAL;
+    if (dev_ptr) *dev_ptr = c->buf;
+    if (n_words) *n_words = c->n_words;
+    if (contig_off) for (int32_t i = 0; i < c->n_contigs; ++i) contig_off[i] = c->off[i];
+    return PD_OK;
+}
+
+void *pd_stream(pd_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int pd_synchronize(pd_ctx *c)
+{
+    if (!c) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->copy_stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PD_OK;
+}
+
+int pd_profile(pd_ctx *c, int enable)
+{
+    if (!c) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = prof_collect(c);
+    c->prof_acc.clear();
+    c->prof = enable != 0;
+    return rc;
+}
+
+int pd_profile_get(pd_ctx *c, const char *name, double *ms, uint64_t *launches)
+{
+    if (!c || !name) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    auto it = c->prof_acc.find(name);
+    if (ms) *ms = it == c->prof_acc.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == c->prof_acc.end() ? 0 : it->second.second;
+    return PD_OK;
+}
+
+} // extern "C"

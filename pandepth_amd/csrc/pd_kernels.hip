@@ -1,0 +1,480 @@
+// pd_kernels.hip — hand-written gfx950 kernels of the per-base depth engine.
+//
+// Everything here is HBM-bound integer work (no MFMA): a zero fill, the +1/-1 difference-array
+// scatter (owner-tile LDS accumulation with plain int4 read-modify-write flush for sorted
+// batches; device atomics for unsorted ones), the prefix-sum sweep (diff -> depth) with an
+// optional fused fixed-window reduction, and a segmented interval reduction.
+//
+// Data layout in HBM (one allocation, int32 cells):
+//   [ contig 0 slot | contig 1 slot | ... | tile sums ]
+// Every contig slot is rounded up to PD_TILE cells, so a tile belongs to exactly one contig.
+// Slot t holds the difference array d[p] (+1 at run begin, -1 at run end, runs clipped to
+// [0, len]); a contig's slot sums to zero, so ONE flat prefix sum over all slots yields every
+// contig's depth with no segment resets.  tile_sum[k] = sum of d over tile k is maintained by
+// the scatter kernels; an exclusive scan of it gives each tile's carry-in, which makes the
+// sweep a single embarrassingly parallel pass (no look-back, no inter-workgroup hand-off).
+//
+// Reference semantics restated (PD = /root/reference/src/PanDepth.cpp):
+//   scatter        == `for (; StartRead<endTmp; StartRead++) depth[..][StartRead]++`  PD:449-452
+//   scan (+wrap18) == the value a SiteInfo{unsigned Depth:18} / unsigned int cell holds PD:717, DataClass.h:85
+//   reductions     == StatChrDepthLowMEM / StatChrDepthWin / mode-6 sweep              PD:329-348, 295-327, 4366-4389
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pd_kernels.h"
+
+namespace pdk {
+
+static constexpr int WG = 256;
+static constexpr int TILE = PD_TILE;            // cells per tile (8192 -> 32 KiB of LDS)
+static_assert(TILE % (WG * 4) == 0, "tile must be a multiple of one int4 row per workgroup");
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+struct Ev { uint64_t gb, ge; bool valid, has; uint32_t len; };
+
+__device__ __forceinline__ Ev expand(const pd_iv v, const ContigTab tab)
+{
+    Ev e; e.valid = (v.tid >= 0 && v.tid < tab.n); e.has = false; e.gb = e.ge = 0; e.len = 0;
+    if (e.valid) {
+        const uint32_t len = tab.len[v.tid];
+        const uint64_t off = tab.off[v.tid];
+        uint32_t b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > len) b = len;
+        uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > len) x = len;
+        e.gb = off + b; e.ge = off + x; e.has = b < x; e.len = e.has ? x - b : 0u;
+    }
+    return e;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fill: 16 B/lane stores, grid-stride
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_fill(int4 *p, size_t n16)
+{
+    size_t i = blockIdx.x * (size_t)WG + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * WG;
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (; i < n16; i += st) p[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter, unsorted fallback: two device atomics per run (+ tile-sum atomics only when the
+// run crosses a tile boundary; inside one tile +1 and -1 cancel in the tile sum)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_scatter_atomic(const pd_iv *iv, size_t n, ContigTab tab,
+                                                       int *diff, int *sums)
+{
+    size_t i = blockIdx.x * (size_t)WG + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * WG;
+    for (; i < n; i += st) {
+        const Ev e = expand(iv[i], tab);
+        if (!e.has) continue;
+        atomicAdd(&diff[e.gb], 1);
+        atomicAdd(&diff[e.ge], -1);
+        const uint64_t tb = e.gb / TILE, te = e.ge / TILE;
+        if (tb != te) { atomicAdd(&sums[tb], 1); atomicAdd(&sums[te], -1); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter, sorted batches.  Step 1: sparse index.  One thread per sample (every S-th run):
+// because the batch is sorted by flat begin, sample values bracket where each tile's
+// candidates start and stop.  For tile t = [a, a+TILE):
+//   cand_lo[t] <= first run with gb >= a - LMAX   (look-back: short runs ending in the tile)
+//   ub_a[t+1]  >= first run with gb >= a + TILE
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint32_t S, ContigTab tab,
+                                              uint32_t lmax, uint32_t *ub_a, uint32_t *cand_lo,
+                                              uint32_t n_tiles, BatchDesc *desc)
+{
+    const uint32_t K = (n + S - 1) / S + 1;
+    const uint32_t k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    const uint64_t pk64 = (uint64_t)k * S;
+    const uint32_t pk = pk64 < n ? (uint32_t)pk64 : n;
+    const Ev last = expand(iv[n - 1], tab);
+    const uint64_t sentinel = last.gb + lmax + 1;
+    uint64_t sk;
+    if (pk < n) { const Ev e = expand(iv[pk], tab); if (!e.valid) atomicOr(&desc->err, 1u); sk = e.gb; }
+    else sk = sentinel;
+    uint64_t t_last = sentinel / TILE; if (t_last >= n_tiles) t_last = n_tiles - 1;
+    if (k == 0) {
+        const uint64_t t0 = sk / TILE;
+        desc->t_first = (uint32_t)t0;
+        if (t0 > t_last) { desc->n_active = 0; atomicOr(&desc->err, 2u); return; }   // not sorted
+        desc->n_active = (uint32_t)(t_last - t0 + 1);
+        ub_a[t0] = 0;
+        uint64_t t1 = (sk + lmax) / TILE; if (t1 > t_last) t1 = t_last;
+        for (uint64_t t = t0; t <= t1; ++t) cand_lo[t] = 0;
+        ub_a[t_last + 1] = n;
+        return;
+    }
+    const uint32_t pkm1 = (k - 1) * S;      // < n for every k >= 1
+    const Ev ep = expand(iv[pkm1], tab);
+    const uint64_t sp = ep.gb;
+    if (sk < sp) { atomicOr(&desc->err, 2u); return; }           // samples out of order
+    {   // tiles whose start a_t lies in (sp, sk]
+        uint64_t lo = sp / TILE + 1, hi = sk / TILE; if (hi > t_last + 1) hi = t_last + 1;
+        for (uint64_t t = lo; t <= hi; ++t) ub_a[t] = pk;
+    }
+    {   // tiles whose a_t - lmax lies in (sp, sk]
+        uint64_t lo = (sp + lmax) / TILE + 1, hi = (sk + lmax) / TILE; if (hi > t_last) hi = t_last;
+        for (uint64_t t = lo; t <= hi; ++t) cand_lo[t] = pkm1;
+    }
+}
+
+// Step 2: owner tiles.  A persistent grid walks the active tiles; each workgroup zeroes a
+// TILE-cell LDS window, pulls every event that lands in ITS tile from the candidate range
+// (LDS atomics), then adds the window into HBM with plain 16-byte loads/stores — no global
+// atomics on the hot path, all-zero 16-byte groups skipped.  Ends of runs longer than LMAX
+// are handed to the overflow list (applied by k_apply_overflow after this kernel).
+__global__ __launch_bounds__(WG) void k_scatter_tiles(const pd_iv *iv, uint32_t n, uint32_t n_tiles,
+                                                      ContigTab tab, uint32_t lmax,
+                                                      const uint32_t *ub_a, const uint32_t *cand_lo,
+                                                      BatchDesc *desc, int *diff, int *sums,
+                                                      uint64_t *ovf, uint32_t ovf_cap)
+{
+    __shared__ __attribute__((aligned(16))) int win[TILE];
+    __shared__ int s_sum;
+    const uint32_t t_first = desc->t_first, n_active = desc->n_active;
+    uint32_t handled = 0;
+    for (uint32_t tt = blockIdx.x; tt < n_active; tt += gridDim.x) {
+        const uint64_t t = (uint64_t)t_first + tt;
+        if (t >= n_tiles) break;
+        const uint64_t a = t * TILE;
+        int4 *w4 = reinterpret_cast<int4 *>(win);
+        for (int j = threadIdx.x; j < TILE / 4; j += WG) w4[j] = make_int4(0, 0, 0, 0);
+        if (threadIdx.x == 0) s_sum = 0;
+        __syncthreads();
+        // clamped: on a batch that was NOT sorted the index holds garbage, and the only promise
+        // then is "reported, no out-of-bounds access"
+        uint32_t hi = ub_a[t + 1]; if (hi > n) hi = n;
+        uint32_t lo = cand_lo[t]; if (lo > hi) lo = hi;
+        int net = 0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
+            const Ev e = expand(iv[i], tab);
+            const uint64_t rb = e.gb - a, re = e.ge - a;          // unsigned: below-tile wraps high
+            if (e.valid && rb < (uint64_t)TILE) {
+                ++handled;
+                if (e.has) {
+                    atomicAdd(&win[rb], 1); ++net;
+                    if (e.len > lmax) {
+                        const uint32_t slot = atomicAdd(&desc->ovf_count, 1u);
+                        if (slot < ovf_cap) ovf[slot] = e.ge; else atomicOr(&desc->err, 4u);
+                    }
+                }
+            }
+            if (e.has && e.len <= lmax && re < (uint64_t)TILE) { atomicAdd(&win[re], -1); --net; }
+        }
+        net = wave_sum(net);
+        if ((threadIdx.x & 63) == 0 && net != 0) atomicAdd(&s_sum, net);
+        __syncthreads();
+        int4 *o4 = reinterpret_cast<int4 *>(diff + a);
+        for (int j = threadIdx.x; j < TILE / 4; j += WG) {
+            const int4 w = w4[j];
+            if (w.x | w.y | w.z | w.w) {
+                int4 o = o4[j];
+                o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w;
+                o4[j] = o;
+            }
+        }
+        if (threadIdx.x == 0 && s_sum != 0) sums[t] += s_sum;
+        __syncthreads();
+    }
+    // how many runs found their owner tile: must equal the batch size if it really was sorted
+    int h = wave_sum((int)handled);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd((unsigned long long *)&desc->handled, (unsigned long long)(unsigned)h);
+}
+
+__global__ __launch_bounds__(WG) void k_apply_overflow(const uint64_t *ovf, const BatchDesc *desc,
+                                                       uint32_t ovf_cap, int *diff, int *sums)
+{
+    uint32_t n = desc->ovf_count; if (n > ovf_cap) n = ovf_cap;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        const uint64_t ge = ovf[i];
+        atomicAdd(&diff[ge], -1);
+        atomicAdd(&sums[ge / TILE], -1);
+    }
+}
+
+// Folds one batch's outcome into the context-wide check words and re-arms the descriptor.
+__global__ void k_finish_batch(BatchDesc *desc, uint64_t n_expected, CheckWords *chk)
+{
+    if (desc->handled != n_expected) chk->unsorted_batches += 1;
+    if (desc->err) chk->err |= desc->err;
+    desc->handled = 0; desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile carries: exclusive prefix sum of the tile sums (a few hundred thousand ints), one
+// workgroup of 1024 threads, chunked.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, int *carry, uint32_t n_tiles)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const int v = i < n_tiles ? sums[i] : 0;
+        int x = v;                                              // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        int pre = s_run;
+        for (int k = 0; k < wv; ++k) pre += wsum[k];
+        if (i < n_tiles) carry[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = pre + x;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the sweep.  One workgroup per tile; 4 waves x 8 rows x (64 lanes x int4): every load/store is
+// a full 1 KiB wave transaction.  Per row: in-lane scan of 4, wave scan of the 64 lane totals
+// (all 8 rows' shuffle chains are independent -> ILP), running carry across rows, then the
+// wave bases through LDS, plus the tile carry-in.
+//   MODE_WRITE : depth written back in place (8 B/base)
+//   MODE_WIN   : fused fixed-window reduction, nothing written back (4 B/base)
+//   FROM_DEPTH : input already holds depth (reduction only)
+// ------------------------------------------------------------------------------------------
+struct WinArgs {
+    uint32_t w;              // window width in cells
+    uint32_t min_dep;
+    float inv_w;
+    uint32_t *cover;         // per window (global index = win_off[contig] + k)
+    unsigned long long *sum;
+};
+
+template <bool WRITE, bool WIN, bool FROM_DEPTH>
+__global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32_t wrap_mask,
+                                              const TileMap tmap, WinArgs wa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wtot[4];
+    constexpr int ROWS = TILE / (WG * 4);                        // 8
+    const uint64_t t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int4 *p4 = reinterpret_cast<int4 *>(buf + t * TILE) + wv * (ROWS * 64) + lane;
+    int4 v[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) v[r] = p4[r * 64];
+
+    if (!FROM_DEPTH) {
+        int tot[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            v[r].y += v[r].x; v[r].z += v[r].y; v[r].w += v[r].z;
+            tot[r] = v[r].w;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { const int y = __shfl_up(tot[r], o); if (lane >= o) tot[r] += y; }
+        }
+        int run = 0;                                             // carry across this wave's rows
+        int excl[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            excl[r] = run + tot[r] - v[r].w;
+            run += __shfl(tot[r], 63);
+        }
+        if (lane == 0) wtot[wv] = run;
+        __syncthreads();
+        int base = carry[t];
+        for (int k = 0; k < wv; ++k) base += wtot[k];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int b = base + excl[r];
+            v[r].x = (int)((uint32_t)(v[r].x + b) & wrap_mask);
+            v[r].y = (int)((uint32_t)(v[r].y + b) & wrap_mask);
+            v[r].z = (int)((uint32_t)(v[r].z + b) & wrap_mask);
+            v[r].w = (int)((uint32_t)(v[r].w + b) & wrap_mask);
+        }
+    }
+    if (WRITE) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) p4[r * 64] = v[r];
+    }
+    if (WIN) {
+        // contig-local position of this tile's first cell and the contig's length
+        const uint32_t ctg = tmap.tile_contig[t];
+        const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
+        const uint32_t clen = tmap.contig_len[ctg];
+        if (local0 >= clen) return;                              // pure padding tile (uniform)
+        const uint64_t wbase = tmap.win_off[ctg];
+        const uint32_t w = wa.w;
+        const uint64_t k0 = local0 / w;                          // first window touching the tile
+        if (w >= (uint32_t)TILE && (local0 + TILE - 1) / w == k0) {
+            // whole tile inside one window (the 10 Mb bins of whole-chromosome mode)
+            int c = 0; unsigned long long s = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (local0 + pos + q < clen && d[q] >= wa.min_dep) { ++c; s += d[q]; }
+            }
+            c = wave_sum(c);
+#pragma unroll
+            for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && c) {
+                atomicAdd(&wa.cover[wbase + k0], (uint32_t)c);
+                atomicAdd(&wa.sum[wbase + k0], s);
+            }
+            return;
+        }
+        // general case: LDS accumulators for the windows overlapping this tile
+        const uint32_t nacc = (uint32_t)((local0 + TILE - 1) / w - k0 + 1);
+        unsigned long long *asum = reinterpret_cast<unsigned long long *>(smem);
+        uint32_t *acov = reinterpret_cast<uint32_t *>(smem + (size_t)nacc * 8);
+        for (uint32_t j = threadIdx.x; j < nacc; j += WG) { asum[j] = 0; acov[j] = 0; }
+        __syncthreads();
+        const uint32_t phase = (uint32_t)(local0 - k0 * w);      // offset of the tile inside window k0
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+            const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
+            const uint32_t x = pos + phase;
+            uint32_t q = (uint32_t)((float)x * wa.inv_w);
+            if ((uint64_t)q * w > x) --q;
+            if ((uint64_t)(q + 1) * w <= x) ++q;
+            uint64_t nb = (uint64_t)(q + 1) * w - phase;         // tile-local cell where window q+1 starts
+            uint32_t c = 0; unsigned long long s = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t pe = pos + e;
+                if (pe == nb) {
+                    if (c) { atomicAdd(&acov[q], c); atomicAdd(&asum[q], s); }
+                    c = 0; s = 0; ++q; nb += w;
+                }
+                if (local0 + pe < clen && d[e] >= wa.min_dep) { ++c; s += d[e]; }
+            }
+            if (c) { atomicAdd(&acov[q], c); atomicAdd(&asum[q], s); }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
+            const uint32_t c = acov[j];
+            if (!c) continue;
+            const uint64_t k = k0 + j;
+            const bool inside = (k * w >= local0) && ((k + 1) * (uint64_t)w <= local0 + TILE);
+            if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = asum[j]; }
+            else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], asum[j]); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// segmented interval reduction over the depth array: one wave per piece (a region, or a
+// <= 16384-cell slice of a long region); partial results are added into the region's slot.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_reduce_pieces(const int *depth, const Piece *pieces, uint32_t n_pieces,
+                                                      uint32_t min_dep, int *cover, unsigned long long *sum)
+{
+    const uint32_t pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= n_pieces) return;
+    const int lane = threadIdx.x & 63;
+    const Piece pc = pieces[pi];
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(depth) + pc.start;
+    int c = 0; unsigned long long s = 0;
+    for (uint32_t i = lane; i < pc.count; i += 64) {
+        const uint32_t x = d[i];
+        if (x >= min_dep) { ++c; s += x; }
+    }
+    c = wave_sum(c);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && c) { atomicAdd(&cover[pc.region], c); atomicAdd(&sum[pc.region], s); }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers (called from pd_capi.hip)
+// ------------------------------------------------------------------------------------------
+void launch_fill(hipStream_t st, void *p, size_t bytes)
+{
+    const size_t n16 = bytes / 16;
+    size_t g = (n16 + WG - 1) / WG; if (g > 4096) g = 4096; if (g == 0) g = 1;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)g), dim3(WG), 0, st, (int4 *)p, n16);
+}
+
+void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab tab, int *diff, int *sums)
+{
+    size_t g = (n + WG - 1) / WG; if (g > 8192) g = 8192; if (g == 0) return;
+    hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)g), dim3(WG), 0, st, iv, n, tab, diff, sums);
+}
+
+void launch_scatter_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
+                           uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles,
+                           BatchDesc *desc, int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap,
+                           CheckWords *chk, unsigned grid_tiles)
+{
+    if (n == 0) return;
+    const uint32_t K = (n + sample - 1) / sample + 1;
+    hipLaunchKernelGGL(k_index, dim3((K + WG - 1) / WG), dim3(WG), 0, st, iv, n, sample, tab, lmax, ub_a,
+                       cand_lo, n_tiles, desc);
+    hipLaunchKernelGGL(k_scatter_tiles, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_tiles, tab, lmax, ub_a, cand_lo, desc,
+                       diff, sums, ovf, ovf_cap);
+    hipLaunchKernelGGL(k_apply_overflow, dim3(256), dim3(WG), 0, st, ovf, desc, ovf_cap, diff, sums);
+    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, desc, (uint64_t)n, chk);
+}
+
+void launch_tile_carry(hipStream_t st, const int *sums, int *carry, uint32_t n_tiles)
+{
+    hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(1024), 0, st, sums, carry, n_tiles);
+}
+
+void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask)
+{
+    TileMap tm{}; WinArgs wa{};
+    hipLaunchKernelGGL((k_sweep<true, false, false>), dim3(n_tiles), dim3(WG), 0, st, buf, carry, wrap_mask, tm, wa);
+}
+
+static size_t win_lds_bytes(uint32_t w)
+{
+    if (w >= (uint32_t)TILE) return 2 * 12 + 16;       // at most two windows touch a tile
+    const size_t nacc = (size_t)TILE / w + 2;
+    return nacc * 12 + 16;
+}
+
+int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
+                         TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
+                         bool from_depth)
+{
+    WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = cover; wa.sum = sum;
+    const size_t lds = win_lds_bytes(w);
+    hipError_t e = hipSuccess;
+    if (from_depth) {
+        if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa);
+    } else {
+        if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, false>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa);
+    }
+    return 0;
+}
+
+void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
+                          uint32_t min_dep, int *cover, unsigned long long *sum)
+{
+    if (!n_pieces) return;
+    hipLaunchKernelGGL(k_reduce_pieces, dim3((n_pieces + 3) / 4), dim3(WG), 0, st, depth, pieces, n_pieces,
+                       min_dep, cover, sum);
+}
+
+} // namespace pdk

@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via ctypes) against the CPU oracle.
+
+Bit-exact for every integer output.  The oracle (oracle/pd_oracle.c) increments one cell per
+covered base like the reference does; the engine scatters +1/-1 and prefix-sums.
+"""
+import numpy as np
+import pytest
+
+import pd_oracle as O
+import pandepth_amd as pda
+
+pytestmark = pytest.mark.gpu
+
+TILE = 8192
+LENS = [700001, 250000, 50001, 1, 8192, 8191, 16384, 3, 100000]
+
+
+def rand_intervals(rng, lens, n, max_len=300, overhang=True):
+    tid = rng.integers(0, len(lens), n).astype(np.int32)
+    L = np.asarray(lens, dtype=np.int64)[tid]
+    beg = (rng.random(n) * (L + (40 if overhang else 0))).astype(np.int64) - (5 if overhang else 0)
+    ln = rng.integers(0, max_len, n)
+    end = beg + ln
+    return np.stack([tid, beg.astype(np.int32), end.astype(np.int32)], axis=1).astype(np.int32)
+
+
+def clip(iv, lens):
+    """What the reference's padded arrays make unobservable: clip runs to [0, len]."""
+    L = np.asarray(lens, dtype=np.int64)[iv[:, 0]]
+    out = iv.copy()
+    out[:, 1] = np.clip(iv[:, 1], 0, L)
+    out[:, 2] = np.clip(iv[:, 2], 0, L)
+    return out[out[:, 1] < out[:, 2]]
+
+
+def oracle_depth(lens, iv, wrap18=False):
+    d, off = O.depth_from_intervals(lens, clip(iv, lens), wrap18)
+    return d, off
+
+
+def check_depth(eng, lens, d, off):
+    for t, ln in enumerate(lens):
+        got = eng.read_depth(t, 0, ln)
+        exp = d[off[t]:off[t] + ln]
+        assert np.array_equal(got, exp), "contig %d differs at %s" % (t, np.nonzero(got != exp)[0][:5])
+
+
+def windows_ref(lens, d, off, w, min_dep):
+    cov, tot = [], []
+    for t, ln in enumerate(lens):
+        x = d[off[t]:off[t] + ln].astype(np.uint64)
+        for s in range(0, ln, w):
+            seg = x[s:min(s + w, ln)]
+            m = seg >= min_dep
+            cov.append(int(m.sum())); tot.append(int(seg[m].sum()))
+    return np.array(cov, dtype=np.uint32), np.array(tot, dtype=np.uint64)
+
+
+def sort_iv(iv):
+    k = np.lexsort((iv[:, 1], iv[:, 0]))
+    return iv[k]
+
+
+def test_abi_version():
+    assert pda.load().pd_abi_version() == 1
+
+
+@pytest.mark.parametrize("wrap", [0, 18])
+def test_unsorted_scatter_and_scan(wrap):
+    rng = np.random.default_rng(1)
+    iv = rand_intervals(rng, LENS, 200000)
+    d, off = oracle_depth(LENS, iv, wrap == 18)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv)
+        e.scan(wrap)
+        check_depth(e, LENS, d, off)
+
+
+def test_sorted_scatter_matches_oracle_and_atomic_path():
+    rng = np.random.default_rng(2)
+    iv = rand_intervals(rng, LENS, 300000, max_len=200)
+    long_ = rand_intervals(rng, LENS, 3000, max_len=60000)      # runs far longer than lmax
+    pile = np.tile(np.array([[0, 1000, 1150]], dtype=np.int32), (70000, 1))   # one locus, many runs
+    iv = sort_iv(np.concatenate([iv, long_, pile]))
+    d, off = oracle_depth(LENS, iv)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv, pda.PD_PUSH_SORTED)
+        e.scan(0)
+        check_depth(e, LENS, d, off)
+
+
+@pytest.mark.parametrize("sample,lmax", [(1, 1), (7, 33), (64, 512), (1000, 8192)])
+def test_sorted_scatter_index_parameters(sample, lmax):
+    rng = np.random.default_rng(3)
+    iv = sort_iv(rand_intervals(rng, LENS, 150000, max_len=700))
+    d, off = oracle_depth(LENS, iv)
+    with pda.Engine(LENS) as e:
+        e.set_param("sample", sample); e.set_param("lmax", lmax)
+        e.push_intervals(iv, pda.PD_PUSH_SORTED)
+        e.scan(0)
+        check_depth(e, LENS, d, off)
+
+
+def test_sorted_flag_on_unsorted_batch_is_reported():
+    rng = np.random.default_rng(4)
+    iv = rand_intervals(rng, LENS, 100000)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv, pda.PD_PUSH_SORTED)
+        with pytest.raises(pda.PdError):
+            e.scan(0)
+
+
+def test_multi_batch_accumulate_and_reset():
+    rng = np.random.default_rng(5)
+    a = sort_iv(rand_intervals(rng, LENS, 50000))
+    b = rand_intervals(rng, LENS, 50000)
+    c = sort_iv(rand_intervals(rng, LENS, 50000))
+    d, off = oracle_depth(LENS, np.concatenate([a, b, c]))
+    with pda.Engine(LENS) as e:
+        e.push_intervals(a, pda.PD_PUSH_SORTED)
+        e.push_intervals(b)
+        e.push_intervals(c, pda.PD_PUSH_SORTED)
+        e.scan(0)
+        check_depth(e, LENS, d, off)
+        with pytest.raises(pda.PdError):
+            e.push_intervals(a)                      # state error after scan
+        e.reset()
+        e.push_intervals(b)
+        e.scan(18)
+        d2, _ = oracle_depth(LENS, b, True)
+        check_depth(e, LENS, d2, off)
+
+
+def test_empty_and_degenerate_batches():
+    with pda.Engine([1, 5]) as e:
+        e.push_intervals(np.zeros((0, 3), dtype=np.int32))
+        e.push_intervals(np.array([[0, 0, 0], [1, 7, 9], [1, -4, -1], [0, 0, 5], [1, 4, 5]], dtype=np.int32),
+                         pda.PD_PUSH_DEFAULT)
+        e.scan(0)
+        assert list(e.read_depth(0, 0, 1)) == [1]
+        assert list(e.read_depth(1, 0, 5)) == [0, 0, 0, 0, 1]
+
+
+def test_wrap18_stack_of_262150_reads():
+    # the F2 fixture's shape: 262150 identical runs -> cell value 6 in the 18-bit paths
+    iv = np.tile(np.array([[0, 100, 110]], dtype=np.int32), (262150, 1))
+    with pda.Engine([400, 300]) as e:
+        e.push_intervals(iv, pda.PD_PUSH_SORTED)
+        e.scan(18)
+        d = e.read_depth(0, 0, 400)
+        assert d[100] == 6 and d[109] == 6 and d[99] == 0 and d[110] == 0
+    with pda.Engine([400, 300]) as e:
+        e.push_intervals(iv)
+        e.scan(0)
+        assert e.read_depth(0, 100, 1)[0] == 262150
+
+
+@pytest.mark.parametrize("min_dep", [1, 3])
+def test_reduce_intervals(min_dep):
+    rng = np.random.default_rng(6)
+    iv = rand_intervals(rng, LENS, 200000)
+    d, off = oracle_depth(LENS, iv)
+    n = 5000
+    tid = rng.integers(0, len(LENS), n)
+    L = np.asarray(LENS)[tid]
+    first = (rng.random(n) * L).astype(np.int64) + 1
+    second = np.minimum(first + rng.integers(0, 40000, n), L)
+    regs = np.stack([tid, first, second], axis=1).astype(np.int32)
+    regs[0] = [0, 1, LENS[0]]                      # a whole contig
+    regs[1] = [3, 1, 1]
+    ec, es = O.stat_regions(d, off, regs, min_dep)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv)
+        e.scan(0)
+        gc, gs = e.reduce_intervals(regs, min_dep)
+    assert np.array_equal(gc, ec) and np.array_equal(gs, es)
+
+
+@pytest.mark.parametrize("w", [1, 2, 3, 7, 100, 149, 150, 1000, 4096, 8192, 8193, 10000, 65536, 10000000])
+@pytest.mark.parametrize("wrap", [0, 18])
+def test_window_reductions(w, wrap):
+    rng = np.random.default_rng(7)
+    iv = rand_intervals(rng, LENS, 120000)
+    pile = np.tile(np.array([[1, 5000, 5100]], dtype=np.int32), (300000 if wrap else 100, 1))
+    iv = np.concatenate([iv, pile])
+    d, off = oracle_depth(LENS, iv, wrap == 18)
+    ec, es = windows_ref(LENS, d, off, w, 2)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv)
+        woff, c1, s1 = e.scan_reduce_windows(w, 2, wrap)          # fused, from the difference arrays
+        assert int(woff[-1]) == ec.size
+        assert np.array_equal(c1, ec) and np.array_equal(s1, es)
+        e.scan(wrap)
+        _, c2, s2 = e.reduce_windows(w, 2)                        # from the materialised depth
+        assert np.array_equal(c2, ec) and np.array_equal(s2, es)
+
+
+def test_profile_counters():
+    rng = np.random.default_rng(8)
+    iv = sort_iv(rand_intervals(rng, LENS, 10000))
+    with pda.Engine(LENS) as e:
+        e.profile(True)
+        e.push_intervals(iv, pda.PD_PUSH_SORTED)
+        e.scan(0)
+        ms, n = e.profile_get("scan")
+        assert n == 1 and ms > 0
+        ms, n = e.profile_get("scatter")
+        assert n == 1 and ms > 0
