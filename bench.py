@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — the depth hot path on MI355X: BASELINE.json's metric on BASELINE.json's config.
+
+A "step" is ONE whole pass of the hot path over one sample's run stream, whole-chromosome mode
+(configs[1]: 3 Gb reference, 50x short-read BAM = 10^9 alignment records of 150 bp):
+
+    pd_reset                      zero the 3.0e9-cell difference arrays            (fill kernel)
+    pd_push_intervals_device x2   +1/-1 scatter of all runs (sorted first runs through the owner-tile
+                                  kernel, the ~11 % second runs of D/I/N reads through the atomic kernel)
+    [N > 1]                       RCCL sum-reduce of the difference arrays + tile sums to rank 0
+    pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
+                                  reduction, results copied back to the host
+
+The run stream is synthetic (tools/synth.py) and is resident in HBM before the
+timed region, as the contract asks; value = records / step time.  Host-side BAM decode is NOT in
+this number (see DESIGN.md for the end-to-end figures).
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run,
+one rank per GPU, each rank holding its own sample ("one BAM per GPU", #.list mode).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+BIN = 10000000                 # whole-chromosome mode's synthetic bins (PD:3978)
+
+# algorithmic bytes per unit (SURVEY.md §8d / DESIGN.md §4)
+B_FILL_PER_CELL = 4
+B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write)
+B_SWEEP_FUSED_PER_BASE = 4
+
+
+class _DevBuf:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 3}
+
+
+def cpu_baseline(sample_records, log):
+    """Times the reference's own CPU path (oracle/_ref/pandepth_ref, built from /root/reference in
+    the dev container) on the host cores, on a bounded sample of the same workload; falls back
+    to the single-threaded C restatement (oracle/libpd_oracle.so) when the binary is absent."""
+    from tools import synth
+    ncpu = os.cpu_count() or 1
+    scale = sample_records / 1.0e9
+    names, lens = synth.genome_c2(scale=scale)
+    rec = synth.gen_records_numpy(lens, sample_records, seed=4242)
+    ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+    s2b = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
+    sample = "%d records, %.0f Mb scaled C2 genome (%d contigs), 50x, whole-chromosome mode" % (
+        sample_records, lens.sum() / 1e6, len(lens))
+    if os.access(ref, os.X_OK) and os.access(s2b, os.X_OK):
+        with tempfile.TemporaryDirectory(prefix="pdbench") as td:
+            raw, bam = os.path.join(td, "raw.bam"), os.path.join(td, "s.bam")
+            synth.write_bam(raw, names, lens, rec, procs=min(32, ncpu))
+            subprocess.run([s2b, raw, bam], check=True, stderr=subprocess.DEVNULL)
+            threads = min(36, ncpu)
+            best = None
+            for _ in range(2):                       # second run = warm page cache
+                t0 = time.perf_counter()
+                subprocess.run([ref, "-i", bam, "-o", os.path.join(td, "o"), "-t", str(threads)], check=True,
+                               stdout=subprocess.DEVNULL)
+                best = time.perf_counter() - t0
+            return {"value": sample_records / best, "unit": "records/s", "cores": threads, "kind": "reference",
+                    "sample": sample + "; pandepth_ref -t %d (BAM+BAI, warm cache, %.2f s)" % (threads, best)}
+    import pd_oracle as O
+    first, other = synth.records_to_runs(rec)
+    runs = np.concatenate([first, other])
+    t0 = time.perf_counter()
+    d, off = O.depth_from_intervals(list(lens), runs)
+    regs = np.array([[t, 1, int(l)] for t, l in enumerate(lens)], dtype=np.int32)
+    O.stat_regions(d, off, regs, 1)
+    dt = time.perf_counter() - t0
+    return {"value": sample_records / dt, "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": sample + "; oracle/pd_oracle.c increment+stat loops, no BAM decode (%.2f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
+    ap.add_argument("--cpu-sample", type=float, default=1.0e7, help="records in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pandepth_amd as pda
+    from tools import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    R = int(args.records)
+    names, lens = synth.genome_c2()
+    G = int(lens.sum())
+    eng = pda.Engine(lens.astype(np.uint32), device=local)
+    first, other = synth.gen_runs_torch(lens, R, dev, seed=42 + rank)
+    torch.cuda.synchronize()
+    n_first, n_other = int(first.shape[0]), int(other.shape[0])
+    ptr, n_words, _ = eng.device_buffer()
+    buf = torch.as_tensor(_DevBuf(ptr, n_words), device=dev) if world > 1 else None
+    wrap = 18 if world > 1 else 0        # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
+
+    def step():
+        eng.reset()
+        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED)
+        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_DEFAULT)
+        if world > 1:
+            eng.synchronize()
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            if rank != 0:
+                return None
+        return eng.scan_reduce_windows(BIN, 1, wrap)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    prof = {}
+    for k in ("fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
+              "scan_reduce_windows"):
+        ms, n = eng.profile_get(k)
+        prof[k] = (ms, n)
+    eng.profile(False)
+
+    if rank == 0:
+        # sanity: the result of the last step must account for every base that was pushed
+        woff, cover, tot = res
+        total_depth = int(tot.sum())
+        ms_step = dt / args.steps * 1e3
+        value = world * R / (dt / args.steps)
+
+        def k_entry(name, alg_bytes_per_launch):
+            ms, n = prof[name]
+            if n == 0:
+                return None
+            avg = ms / n
+            ach = alg_bytes_per_launch / (avg * 1e-3) / 1e9
+            return {"avg_ms": round(avg, 4), "launches": n, "achieved": round(ach, 1), "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg_bytes_per_launch)}
+
+        launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
+        kernels = {
+            "fill": k_entry("fill", n_words * B_FILL_PER_CELL),
+            "scatter_tiles": k_entry("scatter_tiles", n_first * B_SCATTER_PER_RUN / launches_tiles),
+            "scatter_atomic": k_entry("scatter_atomic", n_other * B_SCATTER_PER_RUN),
+            "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
+        }
+        dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])
+        kd = kernels[dom]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kd["frac"], "traffic": None,
+                    "avg_launch_ms": kd["avg_ms"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
+        cb = None
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                cb = cpu_baseline(int(args.cpu_sample), None)
+            except Exception as ex:                                # never lose the GPU line over the CPU leg
+                cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "failed", "sample": repr(ex)}
+        line = {
+            "metric": "alignment records/sec (3 Gb genome, 50x BAM, whole-chromosome mode)",
+            "value": value, "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
+                                   "whole-chromosome mode" % G,
+                       "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
+                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + (", RCCL reduce to rank 0" if world > 1 else ""),
+                       "total_depth_check": total_depth},
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cb,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

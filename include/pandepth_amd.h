@@ -129,8 +129,8 @@ int pd_synchronize(pd_ctx *ctx);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch.
  * pd_profile_get returns the accumulated milliseconds and launch count of kernel `name`
- * ("fill", "scatter", "tile_carry", "scan", "scan_reduce_windows", "reduce_intervals",
- * "reduce_windows"); pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
+ * ("fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
+ * "scan", "scan_reduce_windows", "reduce_intervals", "reduce_windows"); pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 

@@ -21,8 +21,7 @@ namespace {
 
 constexpr int N_STAGE = 8;
 constexpr size_t STAGE_CAP = (size_t)2 << 20;        // runs per staging slot (24 MiB)
-constexpr size_t DEV_BATCH_MAX = (size_t)48 << 20;   // runs per sorted device sub-batch
-constexpr uint32_t OVF_CAP = (uint32_t)DEV_BATCH_MAX;
+constexpr size_t DEV_BATCH_MAX = (size_t)256 << 20;  // runs per sorted device sub-batch (32-bit indices)
 constexpr uint32_t LMAX_DEFAULT = 512;               // look-back bound for owner tiles (cells)
 constexpr uint32_t SAMPLE_DEFAULT = 64;              // sparse index stride (runs)
 
@@ -51,7 +50,7 @@ struct pd_ctx {
     uint64_t *d_off = nullptr; uint32_t *d_len = nullptr; uint32_t *d_tile_contig = nullptr;
     uint32_t *ub_a = nullptr, *cand_lo = nullptr;
     BatchDesc *desc = nullptr; CheckWords *chk = nullptr;
-    uint64_t *ovf = nullptr;
+    uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     Stage stage[N_STAGE];
     uint64_t seq = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
@@ -141,15 +140,24 @@ int do_fill(pd_ctx *c)
 int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags)
 {
     if (n == 0) return PD_OK;
-    ProfScope ps(c, "scatter");
     if (flags & PD_PUSH_SORTED) {
         for (size_t o = 0; o < n; o += DEV_BATCH_MAX) {
-            const size_t m = n - o < DEV_BATCH_MAX ? n - o : DEV_BATCH_MAX;
-            launch_scatter_sorted(c->stream, d + o, (uint32_t)m, tab_of(c), c->lmax, c->sample, c->ub_a,
-                                  c->cand_lo, (uint32_t)c->n_tiles, c->desc, c->buf, c->sums, c->ovf,
-                                  OVF_CAP, c->chk, c->grid_tiles);
+            const uint32_t m = (uint32_t)(n - o < DEV_BATCH_MAX ? n - o : DEV_BATCH_MAX);
+            if (m > c->ovf_cap) {               // worst case: every run is longer than lmax
+                if (c->ovf) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->ovf)); c->ovf = nullptr; c->ovf_cap = 0; }
+                if (hipMalloc(&c->ovf, (size_t)m * 8) != hipSuccess) return fail(c, PD_ENOMEM, "overflow list allocation failed");
+                c->ovf_cap = m;
+            }
+            { ProfScope ps(c, "scatter_index");
+              launch_scatter_index(c->stream, d + o, m, tab_of(c), c->lmax, c->sample, c->ub_a, c->cand_lo, (uint32_t)c->n_tiles, c->desc); }
+            { ProfScope ps(c, "scatter_tiles");
+              launch_scatter_tiles(c->stream, d + o, m, tab_of(c), c->lmax, c->ub_a, c->cand_lo, (uint32_t)c->n_tiles, c->desc,
+                                   c->buf, c->sums, c->ovf, c->ovf_cap, c->grid_tiles); }
+            { ProfScope ps(c, "scatter_finish");
+              launch_scatter_finish(c->stream, m, c->desc, c->buf, c->sums, c->ovf, c->ovf_cap, c->chk); }
         }
     } else {
+        ProfScope ps(c, "scatter_atomic");
         launch_scatter_atomic(c->stream, d, n, tab_of(c), c->buf, c->sums);
     }
     HIPOK(c, hipGetLastError());
@@ -258,7 +266,6 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     CREATE_OK(hipMalloc(&c->cand_lo, (c->n_tiles + 4) * 4));
     CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc)));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
-    CREATE_OK(hipMalloc(&c->ovf, (size_t)OVF_CAP * 8));
     {
         std::vector<uint32_t> tc(c->n_tiles + 1, 0);
         for (int32_t i = 0; i < n_contigs; ++i)

@@ -39,10 +39,13 @@ struct Piece { uint64_t start; uint32_t count; uint32_t region; };
 
 void launch_fill(hipStream_t st, void *p, size_t bytes);
 void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab tab, int *diff, int *sums);
-void launch_scatter_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                           uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles,
-                           BatchDesc *desc, int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap,
-                           CheckWords *chk, unsigned grid_tiles);
+void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
+                          uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc);
+void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
+                          const uint32_t *ub_a, const uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc,
+                          int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles);
+void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
+                           const uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk);
 void launch_tile_carry(hipStream_t st, const int *sums, int *carry, uint32_t n_tiles);
 void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask);
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,

@@ -415,17 +415,25 @@ void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab 
     hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)g), dim3(WG), 0, st, iv, n, tab, diff, sums);
 }
 
-void launch_scatter_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                           uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles,
-                           BatchDesc *desc, int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap,
-                           CheckWords *chk, unsigned grid_tiles)
+void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
+                          uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc)
 {
-    if (n == 0) return;
     const uint32_t K = (n + sample - 1) / sample + 1;
     hipLaunchKernelGGL(k_index, dim3((K + WG - 1) / WG), dim3(WG), 0, st, iv, n, sample, tab, lmax, ub_a,
                        cand_lo, n_tiles, desc);
+}
+
+void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
+                          const uint32_t *ub_a, const uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc,
+                          int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles)
+{
     hipLaunchKernelGGL(k_scatter_tiles, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_tiles, tab, lmax, ub_a, cand_lo, desc,
                        diff, sums, ovf, ovf_cap);
+}
+
+void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
+                           const uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk)
+{
     hipLaunchKernelGGL(k_apply_overflow, dim3(256), dim3(WG), 0, st, ovf, desc, ovf_cap, diff, sums);
     hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, desc, (uint64_t)n, chk);
 }

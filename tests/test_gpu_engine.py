@@ -204,5 +204,5 @@ def test_profile_counters():
         e.scan(0)
         ms, n = e.profile_get("scan")
         assert n == 1 and ms > 0
-        ms, n = e.profile_get("scatter")
+        ms, n = e.profile_get("scatter_tiles")
         assert n == 1 and ms > 0
