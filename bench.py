@@ -5,8 +5,9 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
 (configs[1]: 3 Gb reference, 50x short-read BAM = 10^9 alignment records of 150 bp):
 
     pd_reset                      zero the 3.0e9-cell difference arrays            (fill kernel)
-    pd_push_intervals_device x2   +1/-1 scatter of all runs (sorted first runs through the owner-tile
-                                  kernel, the ~11 % second runs of D/I/N reads through the atomic kernel)
+    pd_push_intervals_device x2   +1/-1 scatter of all runs through the owner-tile kernel: the sorted
+                                  first-run stream, then the ~11 % second runs of D/I/N reads, which are
+                                  only nearly sorted (declared with PD_PUSH_DISORDER(max read span))
     [N > 1]                       RCCL sum-reduce of the difference arrays + tile sums to rank 0
     pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
                                   reduction, results copied back to the host
@@ -91,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
-    ap.add_argument("--cpu-sample", type=float, default=1.0e7, help="records in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=4.0e7, help="records in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -124,7 +125,7 @@ def main():
     def step():
         eng.reset()
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED)
-        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_DEFAULT)
+        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
         if world > 1:
             eng.synchronize()
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
@@ -180,8 +181,8 @@ def main():
         launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
         kernels = {
             "fill": k_entry("fill", n_words * B_FILL_PER_CELL),
-            "scatter_tiles": k_entry("scatter_tiles", n_first * B_SCATTER_PER_RUN / launches_tiles),
-            "scatter_atomic": k_entry("scatter_atomic", n_other * B_SCATTER_PER_RUN),
+            "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
+            "scatter_atomic": k_entry("scatter_atomic", 0),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
         }
         dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])

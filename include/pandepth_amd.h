@@ -62,6 +62,11 @@ typedef struct pd_region { int32_t tid, first, second; } pd_region;
                               * taken: owner-tile scatter (LDS accumulate, plain 16-byte RMW flush,
                               * no global atomics).  A broken promise is detected on the device
                               * and reported by pd_scan / pd_scan_reduce_windows (PD_EINVAL). */
+/* Nearly sorted batches (the 2nd..nth runs of reads, which trail their read's start by at most
+ * the read's reference span): OR in PD_PUSH_DISORDER(D) where D bounds how far back a run may
+ * start relative to any EARLIER run of the batch (beg_j >= beg_i - D for i < j, same contig
+ * order).  The owner tiles then widen their candidate search by D; results stay exact. */
+#define PD_PUSH_DISORDER(cells) ((((unsigned)(cells) + 255u) / 256u) << 8)
 
 /* Context: replaces `new SiteInfo[len+500]` per contig + zero loop (PD:4129-4145,
  * PD:4553-4581, PD:2687-2699) and `new unsigned int[window]` (PD:715-721).  Allocates ONE

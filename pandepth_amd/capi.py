@@ -11,6 +11,11 @@ import numpy as np
 
 PD_PUSH_DEFAULT = 0
 PD_PUSH_SORTED = 1
+
+
+def PD_PUSH_DISORDER(cells):
+    return ((int(cells) + 255) // 256) << 8
+
 PD_TILE = 8192
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -56,7 +56,7 @@ struct pd_ctx {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int state = 0;                                   // 0 accumulating (diff), 1 depth
     uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
-    unsigned grid_tiles = 2048;
+    unsigned grid_tiles = 2048; int stile = 4096; int n_cu = 256;
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -141,6 +141,8 @@ int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags)
 {
     if (n == 0) return PD_OK;
     if (flags & PD_PUSH_SORTED) {
+        const uint64_t dis64 = (uint64_t)(flags >> 8) * 256u;
+        const uint32_t disorder = dis64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)dis64;
         for (size_t o = 0; o < n; o += DEV_BATCH_MAX) {
             const uint32_t m = (uint32_t)(n - o < DEV_BATCH_MAX ? n - o : DEV_BATCH_MAX);
             if (m > c->ovf_cap) {               // worst case: every run is longer than lmax
@@ -149,9 +151,11 @@ int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags)
                 c->ovf_cap = m;
             }
             { ProfScope ps(c, "scatter_index");
-              launch_scatter_index(c->stream, d + o, m, tab_of(c), c->lmax, c->sample, c->ub_a, c->cand_lo, (uint32_t)c->n_tiles, c->desc); }
+              launch_scatter_index(c->stream, d + o, m, tab_of(c), c->lmax, disorder, c->sample, c->ub_a, c->cand_lo,
+                                   (uint32_t)(c->n_cells / c->stile), c->stile, c->desc); }
             { ProfScope ps(c, "scatter_tiles");
-              launch_scatter_tiles(c->stream, d + o, m, tab_of(c), c->lmax, c->ub_a, c->cand_lo, (uint32_t)c->n_tiles, c->desc,
+              launch_scatter_tiles(c->stream, d + o, m, tab_of(c), c->lmax, c->ub_a, c->cand_lo, c->d_tile_contig,
+                                   (uint32_t)(c->n_cells / c->stile), c->stile, c->desc,
                                    c->buf, c->sums, c->ovf, c->ovf_cap, c->grid_tiles); }
             { ProfScope ps(c, "scatter_finish");
               launch_scatter_finish(c->stream, m, c->desc, c->buf, c->sums, c->ovf, c->ovf_cap, c->chk); }
@@ -247,7 +251,8 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     c->n_tiles = o / PD_TILE;
     if (c->n_tiles >= 0xFFFFFFF0ull) { delete c; return fail(nullptr, PD_EINVAL, "pd_create: genome too large"); }
     c->n_words = c->n_cells + (c->n_tiles + 3) / 4 * 4;
-    c->grid_tiles = (unsigned)pr.multiProcessorCount * 8;
+    c->n_cu = pr.multiProcessorCount;
+    c->grid_tiles = (unsigned)c->n_cu * 8;       // 16 KiB of LDS per workgroup -> 8 resident per CU
 
 #define CREATE_OK(call)                                                                                  \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                                 \
@@ -262,8 +267,8 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     CREATE_OK(hipMalloc(&c->d_off, ((size_t)n_contigs + 1) * 8));
     CREATE_OK(hipMalloc(&c->d_len, (size_t)n_contigs * 4));
     CREATE_OK(hipMalloc(&c->d_tile_contig, (c->n_tiles + 1) * 4));
-    CREATE_OK(hipMalloc(&c->ub_a, (c->n_tiles + 4) * 4));
-    CREATE_OK(hipMalloc(&c->cand_lo, (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->ub_a, (c->n_tiles * 2 + 4) * 4));      // indexed by 4096-cell scatter tile
+    CREATE_OK(hipMalloc(&c->cand_lo, (c->n_tiles * 2 + 4) * 4));
     CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc)));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
     {
@@ -321,8 +326,12 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
 {
     if (!c || !name) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!strcmp(name, "lmax")) { if (value < 1 || value > PD_TILE) return fail(c, PD_EINVAL, "lmax must be in [1, tile]"); c->lmax = (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "lmax")) { if (value < 1 || value > 4096) return fail(c, PD_EINVAL, "lmax must be in [1, 4096]"); c->lmax = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "sample must be in [1, 65536]"); c->sample = (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "scatter_tile")) {
+        if (value != 4096 && value != 8192) return fail(c, PD_EINVAL, "scatter_tile must be 4096 or 8192");
+        c->stile = (int)value; c->grid_tiles = (unsigned)c->n_cu * (value == 4096 ? 8 : 4); return PD_OK;
+    }
     if (!strcmp(name, "grid_tiles")) { if (value < 1 || value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
@@ -416,27 +425,29 @@ static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     pd_window_layout(c, w, wo.data());
     const uint64_t nw = wo[c->n_contigs];
     const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
-    const size_t b_sum = (size_t)nw * 8, b_cov = (size_t)nw * 4;
-    int rc = ensure_scratch(c, b_off + b_sum + b_cov + 64);
+    const size_t b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
+    const size_t b_part = w >= PD_TILE ? (size_t)c->n_tiles * sizeof(TilePart) : 0;
+    int rc = ensure_scratch(c, b_off + b_sum + b_cov + b_part + 64);
     if (rc) return rc;
     unsigned char *s = (unsigned char *)c->scratch;
     uint64_t *d_wo = (uint64_t *)s;
     unsigned long long *d_sum = (unsigned long long *)(s + b_off);
     uint32_t *d_cov = (uint32_t *)(s + b_off + b_sum);
+    TilePart *d_part = (TilePart *)(s + b_off + b_sum + b_cov);
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
-    HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));
+    if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // edge windows are accumulated
     if (!from_depth) { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->carry, (uint32_t)c->n_tiles); }
     {
         ProfScope ps(c, from_depth ? "reduce_windows" : "scan_reduce_windows");
         TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
         int e = launch_sweep_windows(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask, tm, w, min_dep,
-                                     d_cov, d_sum, from_depth);
+                                     d_cov, d_sum, d_part, nw, c->n_contigs, from_depth);
         if (e) return fail(c, PD_EHIP, "window sweep: cannot reserve LDS");
     }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(c, hipMemcpyAsync(cover, d_cov, b_cov, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipMemcpyAsync(cover, d_cov, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return PD_OK;
 }

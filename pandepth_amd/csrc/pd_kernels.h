@@ -23,7 +23,8 @@ struct TileMap {              // device pointers, for the window reduction
 };
 
 struct BatchDesc {            // written by k_index, consumed by the tile kernels
-    uint64_t handled;         // runs that found their owner tile
+    uint64_t handled;         // runs that found the owner tile of their begin
+    uint64_t has, ends;       // runs with cells / ends that found their owner (tile or overflow list)
     uint32_t t_first, n_active;
     uint32_t ovf_count;
     uint32_t err;             // 1 invalid tid in a sample, 2 samples out of order, 4 overflow list full
@@ -36,13 +37,16 @@ struct CheckWords {           // context-wide, read back at pd_scan / pd_synchro
 };
 
 struct Piece { uint64_t start; uint32_t count; uint32_t region; };
+struct TilePart { uint32_t c0, c1; unsigned long long s0, s1; };   // a tile's share of windows k0, k0+1
 
 void launch_fill(hipStream_t st, void *p, size_t bytes);
 void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab tab, int *diff, int *sums);
 void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc);
+                          uint32_t disorder, uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo,
+                          uint32_t n_stiles, int stile, BatchDesc *desc);
 void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          const uint32_t *ub_a, const uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc,
+                          const uint32_t *ub_a, const uint32_t *cand_lo, const uint32_t *tile_contig,
+                          uint32_t n_stiles, int stile, BatchDesc *desc,
                           int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles);
 void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
                            const uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk);
@@ -50,7 +54,7 @@ void launch_tile_carry(hipStream_t st, const int *sums, int *carry, uint32_t n_t
 void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask);
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
-                         bool from_depth);
+                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
                           uint32_t min_dep, int *cover, unsigned long long *sum);
 

@@ -53,6 +53,20 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// inclusive prefix sum across the 64 lanes of a wave with DPP row shifts / row broadcasts (pure
+// VALU, no LDS crossbar traffic): Hillis-Steele inside each 16-lane row, then row 0->1 and
+// 2->3 (row_bcast:15), then lanes 0-31 -> 32-63 (row_bcast:31).
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------
 // fill: 16 B/lane stores, grid-stride
 // ------------------------------------------------------------------------------------------
@@ -90,43 +104,55 @@ __global__ __launch_bounds__(WG) void k_scatter_atomic(const pd_iv *iv, size_t n
 //   cand_lo[t] <= first run with gb >= a - LMAX   (look-back: short runs ending in the tile)
 //   ub_a[t+1]  >= first run with gb >= a + TILE
 // ------------------------------------------------------------------------------------------
+template <int ST>
 __global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint32_t S, ContigTab tab,
-                                              uint32_t lmax, uint32_t *ub_a, uint32_t *cand_lo,
+                                              uint32_t lmax, uint32_t dis, uint32_t *ub_a, uint32_t *cand_lo,
                                               uint32_t n_tiles, BatchDesc *desc)
 {
+    // `dis` = disorder bound D: for runs i < j of the batch, gb_j >= gb_i - D (0 = sorted).  Then
+    //   every run at index >= p_k has gb >= s_k - D,   every run at index < p_k has gb <= s_k + D,
+    // so all thresholds below just move by D; the samples themselves need not be monotone (any
+    // sample pair that brackets a threshold gives a valid, possibly looser, bound).
     const uint32_t K = (n + S - 1) / S + 1;
     const uint32_t k = blockIdx.x * WG + threadIdx.x;
     if (k >= K) return;
     const uint64_t pk64 = (uint64_t)k * S;
     const uint32_t pk = pk64 < n ? (uint32_t)pk64 : n;
     const Ev last = expand(iv[n - 1], tab);
-    const uint64_t sentinel = last.gb + lmax + 1;
-    uint64_t sk;
-    if (pk < n) { const Ev e = expand(iv[pk], tab); if (!e.valid) atomicOr(&desc->err, 1u); sk = e.gb; }
+    const int64_t D = dis, T = ST;
+    const int64_t sentinel = (int64_t)last.gb + 2 * D + lmax + 1;
+    int64_t sk;
+    if (pk < n) { const Ev e = expand(iv[pk], tab); if (!e.valid) atomicOr(&desc->err, 1u); sk = (int64_t)e.gb; }
     else sk = sentinel;
-    uint64_t t_last = sentinel / TILE; if (t_last >= n_tiles) t_last = n_tiles - 1;
+    int64_t t_last = (sentinel - D) / T; if (t_last >= (int64_t)n_tiles) t_last = (int64_t)n_tiles - 1;
+    const Ev first = expand(iv[0], tab);
+    const int64_t s0 = (int64_t)first.gb;
+    const int64_t t_first = (s0 - D) > 0 ? (s0 - D) / T : 0;
     if (k == 0) {
-        const uint64_t t0 = sk / TILE;
-        desc->t_first = (uint32_t)t0;
-        if (t0 > t_last) { desc->n_active = 0; atomicOr(&desc->err, 2u); return; }   // not sorted
-        desc->n_active = (uint32_t)(t_last - t0 + 1);
-        ub_a[t0] = 0;
-        uint64_t t1 = (sk + lmax) / TILE; if (t1 > t_last) t1 = t_last;
-        for (uint64_t t = t0; t <= t1; ++t) cand_lo[t] = 0;
+        desc->t_first = (uint32_t)t_first;
+        if (t_first > t_last) { desc->n_active = 0; atomicOr(&desc->err, 2u); return; }   // not sorted
+        desc->n_active = (uint32_t)(t_last - t_first + 1);
+        int64_t t1 = (s0 - D) >= 0 ? (s0 - D) / T : -1; if (t1 > t_last + 1) t1 = t_last + 1;
+        for (int64_t t = t_first; t <= t1; ++t) ub_a[t] = 0;
+        int64_t t2 = (s0 + lmax + D) / T; if (t2 > t_last) t2 = t_last;
+        for (int64_t t = t_first; t <= t2; ++t) cand_lo[t] = 0;
         ub_a[t_last + 1] = n;
         return;
     }
     const uint32_t pkm1 = (k - 1) * S;      // < n for every k >= 1
     const Ev ep = expand(iv[pkm1], tab);
-    const uint64_t sp = ep.gb;
-    if (sk < sp) { atomicOr(&desc->err, 2u); return; }           // samples out of order
-    {   // tiles whose start a_t lies in (sp, sk]
-        uint64_t lo = sp / TILE + 1, hi = sk / TILE; if (hi > t_last + 1) hi = t_last + 1;
-        for (uint64_t t = lo; t <= hi; ++t) ub_a[t] = pk;
+    const int64_t sp = (int64_t)ep.gb;
+    {   // tiles with a_t + D in (sp, sk]: every run at index >= p_k starts at or after a_t
+        int64_t lo = (sp - D) >= 0 ? (sp - D) / T + 1 : 0, hi = (sk - D) >= 0 ? (sk - D) / T : -1;
+        if (lo < t_first) lo = t_first;
+        if (hi > t_last + 1) hi = t_last + 1;
+        for (int64_t t = lo; t <= hi; ++t) ub_a[t] = pk;
     }
-    {   // tiles whose a_t - lmax lies in (sp, sk]
-        uint64_t lo = (sp + lmax) / TILE + 1, hi = (sk + lmax) / TILE; if (hi > t_last) hi = t_last;
-        for (uint64_t t = lo; t <= hi; ++t) cand_lo[t] = pkm1;
+    {   // tiles with a_t - lmax - D in (sp, sk]: every run at index < p_{k-1} ends before a_t
+        int64_t lo = (sp + lmax + D) / T + 1, hi = (sk + lmax + D) / T;
+        if (lo < t_first) lo = t_first;
+        if (hi > t_last) hi = t_last;
+        for (int64_t t = lo; t <= hi; ++t) cand_lo[t] = pkm1;
     }
 }
 
@@ -135,49 +161,61 @@ __global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint3
 // (LDS atomics), then adds the window into HBM with plain 16-byte loads/stores — no global
 // atomics on the hot path, all-zero 16-byte groups skipped.  Ends of runs longer than LMAX
 // are handed to the overflow list (applied by k_apply_overflow after this kernel).
+template <int ST>
 __global__ __launch_bounds__(WG) void k_scatter_tiles(const pd_iv *iv, uint32_t n, uint32_t n_tiles,
                                                       ContigTab tab, uint32_t lmax,
                                                       const uint32_t *ub_a, const uint32_t *cand_lo,
+                                                      const uint32_t *tile_contig,
                                                       BatchDesc *desc, int *diff, int *sums,
                                                       uint64_t *ovf, uint32_t ovf_cap)
 {
-    __shared__ __attribute__((aligned(16))) int win[TILE];
+    __shared__ __attribute__((aligned(16))) int win[ST];
     __shared__ int s_sum;
     const uint32_t t_first = desc->t_first, n_active = desc->n_active;
-    uint32_t handled = 0;
+    uint32_t n_beg = 0, n_has = 0, n_end = 0;
     for (uint32_t tt = blockIdx.x; tt < n_active; tt += gridDim.x) {
         const uint64_t t = (uint64_t)t_first + tt;
         if (t >= n_tiles) break;
-        const uint64_t a = t * TILE;
+        const uint64_t a = t * ST;
         int4 *w4 = reinterpret_cast<int4 *>(win);
-        for (int j = threadIdx.x; j < TILE / 4; j += WG) w4[j] = make_int4(0, 0, 0, 0);
+        for (int j = threadIdx.x; j < ST / 4; j += WG) w4[j] = make_int4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_sum = 0;
-        __syncthreads();
         // clamped: on a batch that was NOT sorted the index holds garbage, and the only promise
         // then is "reported, no out-of-bounds access"
         uint32_t hi = ub_a[t + 1]; if (hi > n) hi = n;
         uint32_t lo = cand_lo[t]; if (lo > hi) lo = hi;
+        // a scatter tile lies inside ONE contig slot, so only runs of that contig can land in it
+        const int32_t ctg = (int32_t)tile_contig[a / TILE];
+        const uint32_t clen = tab.len[ctg];
+        const int64_t rel = (int64_t)(tab.off[ctg] - a);          // slot start relative to the tile (<= 0)
+        __syncthreads();
         int net = 0;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
-            const Ev e = expand(iv[i], tab);
-            const uint64_t rb = e.gb - a, re = e.ge - a;          // unsigned: below-tile wraps high
-            if (e.valid && rb < (uint64_t)TILE) {
-                ++handled;
-                if (e.has) {
+            const pd_iv v = iv[i];
+            if (v.tid != ctg) continue;
+            uint32_t b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
+            uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+            const bool has = b < x;
+            const uint32_t len = has ? x - b : 0u;
+            const uint64_t rb = (uint64_t)(rel + b), re = (uint64_t)(rel + x);   // below-tile wraps high
+            if (rb < (uint64_t)ST) {
+                ++n_beg;
+                if (has) {
+                    ++n_has;
                     atomicAdd(&win[rb], 1); ++net;
-                    if (e.len > lmax) {
+                    if (len > lmax) {
                         const uint32_t slot = atomicAdd(&desc->ovf_count, 1u);
-                        if (slot < ovf_cap) ovf[slot] = e.ge; else atomicOr(&desc->err, 4u);
+                        if (slot < ovf_cap) { ovf[slot] = a + re; ++n_end; } else atomicOr(&desc->err, 4u);
                     }
                 }
             }
-            if (e.has && e.len <= lmax && re < (uint64_t)TILE) { atomicAdd(&win[re], -1); --net; }
+            if (has && len <= lmax && re < (uint64_t)ST) { atomicAdd(&win[re], -1); --net; ++n_end; }
         }
         net = wave_sum(net);
         if ((threadIdx.x & 63) == 0 && net != 0) atomicAdd(&s_sum, net);
         __syncthreads();
         int4 *o4 = reinterpret_cast<int4 *>(diff + a);
-        for (int j = threadIdx.x; j < TILE / 4; j += WG) {
+        for (int j = threadIdx.x; j < ST / 4; j += WG) {
             const int4 w = w4[j];
             if (w.x | w.y | w.z | w.w) {
                 int4 o = o4[j];
@@ -185,12 +223,20 @@ __global__ __launch_bounds__(WG) void k_scatter_tiles(const pd_iv *iv, uint32_t 
                 o4[j] = o;
             }
         }
-        if (threadIdx.x == 0 && s_sum != 0) sums[t] += s_sum;
+        if (threadIdx.x == 0 && s_sum != 0) {
+            if (ST == TILE) sums[t] += s_sum;                    // sole owner of this sum
+            else atomicAdd(&sums[a / TILE], s_sum);              // two scatter tiles share one sum
+        }
         __syncthreads();
     }
-    // how many runs found their owner tile: must equal the batch size if it really was sorted
-    int h = wave_sum((int)handled);
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd((unsigned long long *)&desc->handled, (unsigned long long)(unsigned)h);
+    // every run must have found the owner of its begin, and every run with cells the owner of its
+    // end (in a tile or on the overflow list); anything else means the batch broke its promise
+    const int hb = wave_sum((int)n_beg), hh = wave_sum((int)n_has), he = wave_sum((int)n_end);
+    if ((threadIdx.x & 63) == 0) {
+        if (hb) atomicAdd((unsigned long long *)&desc->handled, (unsigned long long)(unsigned)hb);
+        if (hh) atomicAdd((unsigned long long *)&desc->has, (unsigned long long)(unsigned)hh);
+        if (he) atomicAdd((unsigned long long *)&desc->ends, (unsigned long long)(unsigned)he);
+    }
 }
 
 __global__ __launch_bounds__(WG) void k_apply_overflow(const uint64_t *ovf, const BatchDesc *desc,
@@ -207,9 +253,9 @@ __global__ __launch_bounds__(WG) void k_apply_overflow(const uint64_t *ovf, cons
 // Folds one batch's outcome into the context-wide check words and re-arms the descriptor.
 __global__ void k_finish_batch(BatchDesc *desc, uint64_t n_expected, CheckWords *chk)
 {
-    if (desc->handled != n_expected) chk->unsorted_batches += 1;
+    if (desc->handled != n_expected || desc->has != desc->ends) chk->unsorted_batches += 1;
     if (desc->err) chk->err |= desc->err;
-    desc->handled = 0; desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
+    desc->handled = 0; desc->has = 0; desc->ends = 0; desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,9 +272,7 @@ __global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, int *carry
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const int v = i < n_tiles ? sums[i] : 0;
-        int x = v;                                              // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        const int x = wave_incl_scan(v);
         if (lane == 63) wsum[wv] = x;
         __syncthreads();
         int pre = s_run;
@@ -255,6 +299,7 @@ struct WinArgs {
     float inv_w;
     uint32_t *cover;         // per window (global index = win_off[contig] + k)
     unsigned long long *sum;
+    TilePart *part;          // w >= TILE: per-tile partials for the (at most two) windows it touches
 };
 
 template <bool WRITE, bool WIN, bool FROM_DEPTH>
@@ -279,16 +324,13 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
             tot[r] = v[r].w;
         }
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) { const int y = __shfl_up(tot[r], o); if (lane >= o) tot[r] += y; }
-        }
+        for (int r = 0; r < ROWS; ++r) tot[r] = wave_incl_scan(tot[r]);
         int run = 0;                                             // carry across this wave's rows
         int excl[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             excl[r] = run + tot[r] - v[r].w;
-            run += __shfl(tot[r], 63);
+            run += __builtin_amdgcn_readlane(tot[r], 63);
         }
         if (lane == 0) wtot[wv] = run;
         __syncthreads();
@@ -312,30 +354,47 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
         const uint32_t ctg = tmap.tile_contig[t];
         const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
         const uint32_t clen = tmap.contig_len[ctg];
-        if (local0 >= clen) return;                              // pure padding tile (uniform)
-        const uint64_t wbase = tmap.win_off[ctg];
         const uint32_t w = wa.w;
-        const uint64_t k0 = local0 / w;                          // first window touching the tile
-        if (w >= (uint32_t)TILE && (local0 + TILE - 1) / w == k0) {
-            // whole tile inside one window (the 10 Mb bins of whole-chromosome mode)
-            int c = 0; unsigned long long s = 0;
+        if (w >= (uint32_t)TILE) {
+            // Large windows (the 10 Mb bins of whole-chromosome mode): a tile touches at most two
+            // windows, k0 and k0+1.  Write the tile's two partial (cover, sum) pairs with plain
+            // stores; k_window_gather adds them up per window.  No atomics: with ~1200 tiles per
+            // window, same-address device atomics would serialise the whole sweep.
+            __shared__ unsigned long long red_s[4][2];
+            __shared__ int red_c[4][2];
+            int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+            if (local0 < clen) {
+                const uint64_t k0 = local0 / w;
+                const uint64_t nb = (k0 + 1) * (uint64_t)w - local0;     // tile-local start of window k0+1
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
-                const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
+                for (int r = 0; r < ROWS; ++r) {
+                    const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                    const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (local0 + pos + q < clen && d[q] >= wa.min_dep) { ++c; s += d[q]; }
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = local0 + pos + q < clen && d[q] >= wa.min_dep;
+                        if (ok) { if (pos + q < nb) { ++c0; s0 += d[q]; } else { ++c1; s1 += d[q]; } }
+                    }
+                }
             }
-            c = wave_sum(c);
+            c0 = wave_sum(c0); c1 = wave_sum(c1);
 #pragma unroll
-            for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0 && c) {
-                atomicAdd(&wa.cover[wbase + k0], (uint32_t)c);
-                atomicAdd(&wa.sum[wbase + k0], s);
+            for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+            if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                TilePart tp;
+                tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+                tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+                tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+                tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+                wa.part[t] = tp;
             }
             return;
         }
+        if (local0 >= clen) return;                              // pure padding tile (uniform)
+        const uint64_t wbase = tmap.win_off[ctg];
+        const uint64_t k0 = local0 / w;                          // first window touching the tile
         // general case: LDS accumulators for the windows overlapping this tile
         const uint32_t nacc = (uint32_t)((local0 + TILE - 1) / w - k0 + 1);
         unsigned long long *asum = reinterpret_cast<unsigned long long *>(smem);
@@ -374,6 +433,34 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
             else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], asum[j]); }
         }
     }
+}
+
+// w >= TILE: one wave per window adds up the partials of the tiles it spans (plain loads/stores).
+__global__ __launch_bounds__(WG) void k_window_gather(const TilePart *part, const TileMap tmap, int32_t n_contigs,
+                                                      uint32_t w, uint64_t n_windows, uint32_t *cover,
+                                                      unsigned long long *sum)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_windows) return;
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n_contigs;                                  // contig c with win_off[c] <= g < win_off[c+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tmap.win_off[mid] <= g) lo = mid; else hi = mid; }
+    const uint64_t k = g - tmap.win_off[lo];
+    const uint64_t coff = tmap.contig_off[lo];
+    const uint64_t clen = tmap.contig_len[lo];
+    const uint64_t b = k * w;
+    uint64_t e = b + w; if (e > clen) e = clen;
+    const uint64_t t0 = (coff + b) / TILE, t1 = (coff + e - 1) / TILE;
+    uint32_t c = 0; unsigned long long s = 0;
+    for (uint64_t t = t0 + lane; t <= t1; t += 64) {
+        const TilePart tp = part[t];
+        const uint64_t k0 = (t * TILE - coff) / w;
+        if (k0 == k) { c += tp.c0; s += tp.s0; } else { c += tp.c1; s += tp.s1; }
+    }
+    c = (uint32_t)wave_sum((int)c);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { cover[g] = c; sum[g] = s; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,19 +503,28 @@ void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab 
 }
 
 void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc)
+                          uint32_t disorder, uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo,
+                          uint32_t n_stiles, int stile, BatchDesc *desc)
 {
     const uint32_t K = (n + sample - 1) / sample + 1;
-    hipLaunchKernelGGL(k_index, dim3((K + WG - 1) / WG), dim3(WG), 0, st, iv, n, sample, tab, lmax, ub_a,
-                       cand_lo, n_tiles, desc);
+    const dim3 g((K + WG - 1) / WG), b(WG);
+    if (stile == 4096)
+        hipLaunchKernelGGL(k_index<4096>, g, b, 0, st, iv, n, sample, tab, lmax, disorder, ub_a, cand_lo, n_stiles, desc);
+    else
+        hipLaunchKernelGGL(k_index<8192>, g, b, 0, st, iv, n, sample, tab, lmax, disorder, ub_a, cand_lo, n_stiles, desc);
 }
 
 void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          const uint32_t *ub_a, const uint32_t *cand_lo, uint32_t n_tiles, BatchDesc *desc,
+                          const uint32_t *ub_a, const uint32_t *cand_lo, const uint32_t *tile_contig,
+                          uint32_t n_stiles, int stile, BatchDesc *desc,
                           int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles)
 {
-    hipLaunchKernelGGL(k_scatter_tiles, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_tiles, tab, lmax, ub_a, cand_lo, desc,
-                       diff, sums, ovf, ovf_cap);
+    if (stile == 4096)
+        hipLaunchKernelGGL(k_scatter_tiles<4096>, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_stiles, tab, lmax, ub_a,
+                           cand_lo, tile_contig, desc, diff, sums, ovf, ovf_cap);
+    else
+        hipLaunchKernelGGL(k_scatter_tiles<8192>, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_stiles, tab, lmax, ub_a,
+                           cand_lo, tile_contig, desc, diff, sums, ovf, ovf_cap);
 }
 
 void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
@@ -451,16 +547,17 @@ void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_ti
 
 static size_t win_lds_bytes(uint32_t w)
 {
-    if (w >= (uint32_t)TILE) return 2 * 12 + 16;       // at most two windows touch a tile
+    if (w >= (uint32_t)TILE) return 16;                // large windows use per-tile partials, no LDS accumulators
     const size_t nacc = (size_t)TILE / w + 2;
     return nacc * 12 + 16;
 }
 
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
-                         bool from_depth)
+                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth)
 {
     WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = cover; wa.sum = sum;
+    wa.part = part;
     const size_t lds = win_lds_bytes(w);
     hipError_t e = hipSuccess;
     if (from_depth) {
@@ -474,6 +571,9 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa);
     }
+    if (w >= (uint32_t)TILE && n_windows)
+        hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n_windows + 3) / 4)), dim3(WG), 0, st, part, tm, n_contigs,
+                           w, n_windows, cover, sum);
     return 0;
 }
 

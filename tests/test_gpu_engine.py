@@ -89,15 +89,56 @@ def test_sorted_scatter_matches_oracle_and_atomic_path():
         check_depth(e, LENS, d, off)
 
 
-@pytest.mark.parametrize("sample,lmax", [(1, 1), (7, 33), (64, 512), (1000, 8192)])
-def test_sorted_scatter_index_parameters(sample, lmax):
+@pytest.mark.parametrize("sample,lmax,stile", [(1, 1, 4096), (7, 33, 8192), (64, 512, 4096), (64, 512, 8192),
+                                               (1000, 4096, 4096), (1000, 4096, 8192)])
+def test_sorted_scatter_index_parameters(sample, lmax, stile):
     rng = np.random.default_rng(3)
     iv = sort_iv(rand_intervals(rng, LENS, 150000, max_len=700))
     d, off = oracle_depth(LENS, iv)
     with pda.Engine(LENS) as e:
-        e.set_param("sample", sample); e.set_param("lmax", lmax)
+        e.set_param("sample", sample); e.set_param("lmax", lmax); e.set_param("scatter_tile", stile)
         e.push_intervals(iv, pda.PD_PUSH_SORTED)
         e.scan(0)
+        check_depth(e, LENS, d, off)
+
+
+@pytest.mark.parametrize("D", [160, 5400, 70000])
+def test_nearly_sorted_batch_with_disorder_bound(D):
+    # runs in "file order": each read contributes 1-3 runs; later runs of a read start up to D cells
+    # after the read start, i.e. up to D cells before runs of the following reads
+    rng = np.random.default_rng(11)
+    n = 120000
+    tid = np.sort(rng.integers(0, len(LENS), n)).astype(np.int64)
+    L = np.asarray(LENS, dtype=np.int64)[tid]
+    pos = (rng.random(n) * L).astype(np.int64)
+    order = np.lexsort((pos, tid))
+    tid, pos = tid[order], pos[order]
+    runs = []
+    for k in range(3):
+        keep = rng.random(n) < (1.0 if k == 0 else 0.3)
+        shift = np.zeros(n, dtype=np.int64) if k == 0 else rng.integers(0, D - 150, n)
+        b = pos + shift
+        runs.append(np.stack([tid, b, b + rng.integers(1, 150, n), np.arange(n) * 3 + k], axis=1)[keep])
+    runs = np.concatenate(runs)
+    runs = runs[np.argsort(runs[:, 3], kind="stable")][:, :3].astype(np.int32)   # file order
+    d, off = oracle_depth(LENS, runs)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(runs, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(D))
+        e.scan(0)
+        check_depth(e, LENS, d, off)
+    for st in (4096, 8192):
+        with pda.Engine(LENS) as e:
+            e.set_param("scatter_tile", st)
+            e.push_intervals(runs, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(D))
+            e.scan(18)
+            d18, _ = oracle_depth(LENS, runs, True)
+            check_depth(e, LENS, d18, off)
+    with pda.Engine(LENS) as e:       # the same batch declared strictly sorted: either reported, or
+        e.push_intervals(runs, pda.PD_PUSH_SORTED)    # (small D, inside the index slack) still exact
+        try:
+            e.scan(0)
+        except pda.PdError:
+            return
         check_depth(e, LENS, d, off)
 
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""tools/tune_scatter.py — sweep the owner-tile scatter's knobs on the bench workload (GPU box)."""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import pandepth_amd as pda  # noqa: E402
+from tools import synth  # noqa: E402
+
+
+def main():
+    R = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(1e9)
+    dev = torch.device("cuda", 0)
+    names, lens = synth.genome_c2()
+    eng = pda.Engine(lens.astype(np.uint32), device=0)
+    first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
+    torch.cuda.synchronize()
+    nf, no = int(first.shape[0]), int(other.shape[0])
+
+    def run(tag, **params):
+        for k, v in params.items():
+            eng.set_param(k, v)
+        t_first = 0.0
+        for it in range(3):
+            if it == 1:
+                eng.profile(True)
+            eng.reset()
+            b0 = eng.profile_get("scatter_tiles")[0] if it else 0
+            eng.push_intervals_device(first.data_ptr(), nf, pda.PD_PUSH_SORTED)
+            eng.synchronize()
+            if it:
+                t_first += eng.profile_get("scatter_tiles")[0] - b0
+            eng.push_intervals_device(other.data_ptr(), no, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+            eng.synchronize()
+        ms_idx, n_idx = eng.profile_get("scatter_index")
+        ms_t, n_t = eng.profile_get("scatter_tiles")
+        ms_f, _ = eng.profile_get("scatter_finish")
+        eng.profile(False)
+        print("%-40s tiles %.3f ms/step = first %.3f + other %.3f (index %.3f finish %.3f) launches/step %d" % (
+            tag, ms_t / 2, t_first / 2, (ms_t - t_first) / 2, ms_idx / 2, ms_f / 2, n_t // 2), flush=True)
+
+    for st, gm, sample, lmax in itertools.product((4096, 8192), (1,), (64,), (512,)):
+        per_cu = 8 if st == 4096 else 4
+        run("stile=%d grid=%dx sample=%d lmax=%d" % (st, gm, sample, lmax), scatter_tile=st,
+            grid_tiles=256 * per_cu * gm, sample=sample, lmax=lmax)
+    for sample, lmax in ():
+        run("stile=4096 grid=2x sample=%d lmax=%d" % (sample, lmax), scatter_tile=4096, grid_tiles=256 * 16,
+            sample=sample, lmax=lmax)
+
+
+if __name__ == "__main__":
+    main()
