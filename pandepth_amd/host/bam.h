@@ -1,0 +1,74 @@
+// bam.h — alignment input: BAM (SAM spec §4.2) and text SAM records reduced to the five fields
+// the depth path reads (refID, pos, mapq, flag, CIGAR), plus the BAI index (§5.2) used to cut a
+// coordinate-sorted BAM into independent, record-aligned virtual-offset ranges.
+// The reference obtains all of this from htslib (sam_hdr_read / sam_read1 / sam_index_load,
+// PD:3483-3507, PD:434, PD:378); this is an independent implementation from the specification.
+#ifndef PD_BAM_H_
+#define PD_BAM_H_
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "bgzf.h"
+
+namespace pdh {
+
+struct AlnHeader {
+    std::string text;                       // @HD/@SQ/... lines
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    bool sorted_coordinate() const;         // "\tSO:coordinate" test of PD:4537-4549
+};
+
+struct AlnRec {
+    int32_t tid, pos;                       // pos 0-based
+    uint16_t flag;
+    uint8_t mapq;
+    uint32_t n_cigar;
+    const uint32_t *cigar;                  // BAM encoding: len << 4 | op ("MIDNSHP=XB"); valid until next()
+    // htslib's bam_endpos: pos + reference length, where unmapped reads and zero-length
+    // alignments count as length 1
+    int32_t endpos() const;
+};
+
+class AlnReader {
+public:
+    bool open(const std::string &path, std::string *err);
+    const AlnHeader &header() const { return hdr_; }
+    bool is_bam() const { return is_bam_; }
+    // next record; returns 1 record, 0 end of file, -1 error
+    int next(AlnRec *r);
+    uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record
+    bool seek(uint64_t voff) { return bg_.seek(voff); }
+    const std::string &error() const { return err_; }
+private:
+    bool read_bam_header();
+    bool read_sam_header();
+    int next_sam(AlnRec *r);
+    bool getline(std::string *line);
+    BgzfReader bg_;
+    AlnHeader hdr_;
+    bool is_bam_ = false;
+    std::vector<uint8_t> rec_;
+    std::vector<uint32_t> cig_;
+    std::unordered_map<std::string, int32_t> name2tid_;
+    std::string pending_line_;
+    bool have_pending_ = false;
+    std::string err_;
+};
+
+// BAI: only what range partitioning needs.
+struct BaiIndex {
+    std::vector<std::vector<uint64_t>> linear;    // per reference: 16 kb window -> smallest voffset
+    std::vector<uint64_t> ref_beg, ref_end;       // per reference: span of its chunks (0,0 if none)
+    bool load(const std::string &path, std::string *err);
+    // record-aligned split points covering [first_record_voff, EOF): about n_parts ranges of similar
+    // compressed size.  Returns the boundaries (size = parts + 1, last = UINT64_MAX).
+    std::vector<uint64_t> split(uint64_t first_record_voff, uint64_t file_size, int n_parts) const;
+};
+
+bool file_exists(const std::string &p);
+uint64_t file_size(const std::string &p);
+
+} // namespace pdh
+#endif

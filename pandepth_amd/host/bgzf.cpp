@@ -1,0 +1,217 @@
+// bgzf.cpp — see bgzf.h
+#include "bgzf.h"
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <mutex>
+
+namespace pdh {
+
+namespace {
+typedef void *(*ld_alloc_t)(void);
+typedef int (*ld_decomp_t)(void *, const void *, size_t, void *, size_t, size_t *);
+typedef void (*ld_free_t)(void *);
+ld_alloc_t g_ld_alloc = nullptr;
+ld_decomp_t g_ld_decomp = nullptr;
+ld_free_t g_ld_free = nullptr;
+std::once_flag g_ld_once;
+
+void load_libdeflate()
+{
+    const char *names[] = {"libdeflate.so.0", "libdeflate.so", "/usr/lib/x86_64-linux-gnu/libdeflate.so.0"};
+    for (const char *n : names) {
+        void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) continue;
+        g_ld_alloc = (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor");
+        g_ld_decomp = (ld_decomp_t)dlsym(h, "libdeflate_deflate_decompress");
+        g_ld_free = (ld_free_t)dlsym(h, "libdeflate_free_decompressor");
+        if (g_ld_alloc && g_ld_decomp && g_ld_free) return;
+        g_ld_alloc = nullptr; g_ld_decomp = nullptr; g_ld_free = nullptr;
+    }
+}
+} // namespace
+
+Inflater::Inflater()
+{
+    std::call_once(g_ld_once, load_libdeflate);
+    if (g_ld_alloc) ld_ = g_ld_alloc();
+    if (!ld_) {
+        z_stream *zs = new z_stream;
+        memset(zs, 0, sizeof *zs);
+        inflateInit2(zs, -15);
+        zs_ = zs;
+    }
+}
+
+Inflater::~Inflater()
+{
+    if (ld_) g_ld_free(ld_);
+    if (zs_) { inflateEnd((z_stream *)zs_); delete (z_stream *)zs_; }
+}
+
+const char *Inflater::backend()
+{
+    std::call_once(g_ld_once, load_libdeflate);
+    return g_ld_alloc ? "libdeflate" : "zlib";
+}
+
+bool Inflater::inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+    if (out_len == 0) return true;
+    if (ld_) {
+        size_t got = 0;
+        const int r = g_ld_decomp(ld_, in, in_len, out, out_len, &got);
+        return r == 0 && got == out_len;
+    }
+    z_stream *zs = (z_stream *)zs_;
+    inflateReset(zs);
+    zs->next_in = const_cast<Bytef *>(in); zs->avail_in = (uInt)in_len;
+    zs->next_out = out; zs->avail_out = (uInt)out_len;
+    const int r = inflate(zs, Z_FINISH);
+    return r == Z_STREAM_END && zs->avail_out == 0;
+}
+
+uint32_t bgzf_block_size(const uint8_t *p, size_t avail, uint32_t *data_off)
+{
+    if (avail < 18) return 0;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const uint32_t xlen = p[10] | (p[11] << 8);
+    if (avail < 12 + xlen) return 0;
+    uint32_t o = 12;
+    const uint32_t xend = 12 + xlen;
+    while (o + 4 <= xend) {
+        const uint32_t slen = p[o + 2] | (p[o + 3] << 8);
+        if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2) {
+            const uint32_t bsize = p[o + 4] | (p[o + 5] << 8);
+            if (data_off) *data_off = xend;
+            return bsize + 1;
+        }
+        o += 4 + slen;
+    }
+    return 0;
+}
+
+BgzfReader::BgzfReader() {}
+BgzfReader::~BgzfReader() { close(); }
+
+void BgzfReader::close()
+{
+    if (gz_) { gzclose((gzFile)gz_); gz_ = nullptr; }
+    if (fd_ >= 0) { ::close(fd_); fd_ = -1; }
+}
+
+bool BgzfReader::open(const std::string &path, std::string *err)
+{
+    close();
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) { if (err) *err = "cannot open " + path; return false; }
+    uint8_t h[18];
+    const ssize_t n = pread(fd_, h, sizeof h, 0);
+    is_bgzf_ = n == 18 && bgzf_block_size(h, 18, nullptr) != 0;
+    at_eof_ = false; upos_ = ulen_ = 0; cpos_ = cend_ = 0; cfile_off_ = 0; block_coff_ = next_coff_ = 0;
+    if (!is_bgzf_) {
+        // plain text or ordinary gzip: zlib's gz layer reads both transparently
+        gz_ = gzdopen(dup(fd_), "rb");
+        if (!gz_) { if (err) *err = "cannot read " + path; return false; }
+        gzbuffer((gzFile)gz_, 1 << 20);
+        ubuf_.resize(1 << 16);
+    } else {
+        cbuf_.resize(1 << 22);
+        ubuf_.resize(1 << 16);
+    }
+    return true;
+}
+
+bool BgzfReader::load_block()
+{
+    upos_ = ulen_ = 0;
+    if (at_eof_) return false;
+    if (!is_bgzf_) {
+        const int n = gzread((gzFile)gz_, ubuf_.data(), (unsigned)ubuf_.size());
+        if (n < 0) { err_ = "read error"; at_eof_ = true; return false; }
+        if (n == 0) { at_eof_ = true; return false; }
+        block_coff_ = next_coff_; next_coff_ += (uint64_t)n;      // plain offsets (no virtual offsets)
+        ulen_ = (size_t)n;
+        return true;
+    }
+    for (;;) {
+        uint32_t doff = 0;
+        uint32_t bs = cend_ - cpos_ >= 18 ? bgzf_block_size(cbuf_.data() + cpos_, cend_ - cpos_, &doff) : 0;
+        if (bs == 0 || cend_ - cpos_ < bs) {
+            // refill the read-ahead buffer starting at the current block
+            const uint64_t want_off = cfile_off_ + cpos_;
+            const ssize_t n = pread(fd_, cbuf_.data(), cbuf_.size(), (off_t)want_off);
+            if (n < 0) { err_ = "read error"; at_eof_ = true; return false; }
+            cfile_off_ = want_off; cpos_ = 0; cend_ = (size_t)n;
+            if (n == 0) { at_eof_ = true; return false; }
+            bs = bgzf_block_size(cbuf_.data(), cend_, &doff);
+            if (bs == 0 || cend_ < bs) { err_ = "truncated or corrupt BGZF block"; at_eof_ = true; return false; }
+        }
+        const uint8_t *p = cbuf_.data() + cpos_;
+        const uint32_t isize = p[bs - 4] | (p[bs - 3] << 8) | (p[bs - 2] << 16) | ((uint32_t)p[bs - 1] << 24);
+        block_coff_ = cfile_off_ + cpos_;
+        next_coff_ = block_coff_ + bs;
+        cpos_ += bs;
+        if (isize == 0) continue;                               // empty block (e.g. the EOF marker)
+        if (isize > ubuf_.size()) ubuf_.resize(isize);
+        if (!inf_.inflate_raw(p + doff, bs - doff - 8, ubuf_.data(), isize)) {
+            err_ = "corrupt BGZF block (inflate failed)"; at_eof_ = true; return false;
+        }
+        ulen_ = isize;
+        return true;
+    }
+}
+
+long BgzfReader::read(void *dst, size_t n)
+{
+    uint8_t *d = (uint8_t *)dst;
+    size_t got = 0;
+    while (got < n) {
+        if (upos_ == ulen_) { if (!load_block()) break; }
+        const size_t k = std::min(n - got, ulen_ - upos_);
+        memcpy(d + got, ubuf_.data() + upos_, k);
+        upos_ += k; got += k;
+    }
+    if (got == 0 && !err_.empty()) return -1;
+    return (long)got;
+}
+
+const uint8_t *BgzfReader::peek(size_t *avail)
+{
+    if (upos_ == ulen_) { if (!load_block()) { *avail = 0; return nullptr; } }
+    *avail = ulen_ - upos_;
+    return ubuf_.data() + upos_;
+}
+
+void BgzfReader::consume(size_t n) { upos_ += n; }
+
+bool BgzfReader::eof()
+{
+    if (upos_ < ulen_) return false;
+    return !load_block();
+}
+
+uint64_t BgzfReader::tell() const
+{
+    if (upos_ == ulen_) return next_coff_ << 16;
+    return (block_coff_ << 16) | (uint64_t)upos_;
+}
+
+bool BgzfReader::seek(uint64_t voffset)
+{
+    if (!is_bgzf_) return false;
+    const uint64_t coff = voffset >> 16;
+    const uint32_t uoff = (uint32_t)(voffset & 0xffff);
+    cfile_off_ = coff; cpos_ = cend_ = 0; at_eof_ = false; upos_ = ulen_ = 0;
+    block_coff_ = next_coff_ = coff;
+    if (uoff) {
+        if (!load_block()) return false;
+        if (uoff > ulen_) return false;
+        upos_ = uoff;
+    }
+    return true;
+}
+
+} // namespace pdh

@@ -1,0 +1,35 @@
+// engine_api.h — the depth-engine seam as a table of C function pointers with exactly the
+// signatures of include/pandepth_amd.h.  The `pandepth` binary fills it with the gfx950 library's
+// entry points (main.cpp) and nothing else; the CPU test harness under tests/ fills it with an
+// oracle-backed implementation so that the host logic (readers, read selection, region model,
+// table writer) can be checked byte-for-byte against the reference's golden files without a GPU.
+#ifndef PD_ENGINE_API_H_
+#define PD_ENGINE_API_H_
+#include "../../include/pandepth_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pd_engine_api {
+    int (*create)(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out);
+    int (*destroy)(pd_ctx *);
+    const char *(*strerror)(const pd_ctx *);
+    int (*stage_acquire)(pd_ctx *, pd_iv **, size_t *);
+    int (*stage_submit)(pd_ctx *, pd_iv *, size_t, unsigned);
+    int (*scan)(pd_ctx *, unsigned wrap_bits);
+    int (*reduce_intervals)(pd_ctx *, const pd_region *, size_t, uint32_t, int32_t *, uint64_t *);
+    int (*window_layout)(const pd_ctx *, uint32_t, uint64_t *);
+    int (*scan_reduce_windows)(pd_ctx *, uint32_t, uint32_t, unsigned, uint32_t *, uint64_t *);
+    int (*reduce_windows)(pd_ctx *, uint32_t, uint32_t, uint32_t *, uint64_t *);
+    int (*read_depth)(pd_ctx *, int32_t, uint32_t, size_t, uint32_t *);
+    int (*synchronize)(pd_ctx *);
+} pd_engine_api;
+
+/* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */
+int pandepth_main(int argc, char **argv, const pd_engine_api *api, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,15 @@
+// main.cpp — the `pandepth` executable: the reference's command line on the MI355X depth engine.
+// The engine table is bound to libpandepth_amd.so's entry points and to nothing else; without a
+// gfx950 device pd_create fails and the program exits with an error (no CPU fallback).
+#include <stdlib.h>
+#include "engine_api.h"
+
+int main(int argc, char **argv)
+{
+    static const pd_engine_api api = {
+        pd_create, pd_destroy, pd_strerror, pd_stage_acquire, pd_stage_submit, pd_scan, pd_reduce_intervals,
+        pd_window_layout, pd_scan_reduce_windows, pd_reduce_windows, pd_read_depth, pd_synchronize,
+    };
+    const char *dev = getenv("PANDEPTH_DEVICE");
+    return pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);
+}

@@ -1,0 +1,41 @@
+// options.h — the command-line surface of `pandepth` (-i -o -g -f -b -w -a -q -d -x -t -s -h;
+// -r/-c are accepted and ignored: GC content is outside this engine's scope).
+// Behaviour follows the reference's parser (PD:84-293) including its quirks: every '-' is
+// stripped from a flag, `*.list`/`*.List` expands to one input per non-empty line, -w < 1 and
+// -d < 1 clamp to 1, -o gets ".gz" appended and a trailing ".stat"/".bed" dropped later.
+#ifndef PD_OPTIONS_H_
+#define PD_OPTIONS_H_
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace pdh {
+
+struct Options {
+    std::vector<std::string> inputs;     // InStr1List
+    std::string input;                   // InStr1
+    std::string region_file;             // InStr2 (gff/gtf or bed)
+    std::string out;                     // InStr3 (with ".gz")
+    std::string feature = "CDS";
+    int mode = 0;                        // InInt2: 0 chr, 1 gff, 2 gtf, 3 bed3, 4 bed4, 5 window >= 150, 6 window < 150
+    int min_mapq = -1;                   // main() presets -1 (PD:3444): nothing is filtered unless -q is given
+    int min_dep = 1;
+    uint32_t flag_mask = 1796;
+    int threads = 3;
+    int win = 0;
+    bool site_out = false;               // -a
+    bool use_index = true;               // hidden -s clears it
+    bool gc = false;
+};
+
+// Returns the number of input files (0 => nothing to do / message already printed), like
+// bamCov_help01.  Messages go to stdout/stderr exactly as the reference prints them.
+int parse_options(int argc, char **argv, Options *o);
+void print_help();
+
+// text-file helper shared with the region parser: whole file (plain or gzip) split into lines
+// the way `while(!in.eof()) getline(in, line)` sees them
+bool read_lines(const std::string &path, std::vector<std::string> *lines);
+
+} // namespace pdh
+#endif

@@ -1,0 +1,495 @@
+// pipeline.cpp — one `pandepth` invocation: inputs -> reads the reference would count -> M/=/X
+// runs -> depth engine (through pd_engine_api) -> CoveredSite/TotalDepth -> .stat.gz tables.
+//
+// What stays on the host is everything the reference does around its depth arrays:
+//   * which cell type a mode uses (PD:4127 / PD:4413 / PD:4553 / PD:2687): uint32 for a single
+//     indexed BAM without -a and without -w<150, the 18-bit SiteInfo cell everywhere else;
+//   * which reads are fed to the increment loop: index fetch of the merged target spans widened
+//     by one base (PD:419-434), the sorted no-index stream's span cursor (PD:4608-4646), or every
+//     read (PD:4679-4711);
+//   * the table text (PD:4879-5127) and the per-site file (PD:4264-4284).
+// The increment loop itself, the statistics and the window sweep run on the engine.
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <thread>
+#include "bam.h"
+#include "engine_api.h"
+#include "options.h"
+#include "regions.h"
+#include "report.h"
+
+namespace pdh {
+
+namespace {
+
+struct Engine {
+    const pd_engine_api *api = nullptr;
+    pd_ctx *ctx = nullptr;
+    std::mutex err_mu;
+    std::string err;
+    void fail(const std::string &m) { std::lock_guard<std::mutex> lk(err_mu); if (err.empty()) err = m; }
+    bool ok() { std::lock_guard<std::mutex> lk(err_mu); return err.empty(); }
+    bool ck(int rc, const char *what)
+    {
+        if (rc == 0) return true;
+        const char *m = api->strerror(ctx);
+        fail(std::string(what) + ": " + (m ? m : "engine error"));
+        return false;
+    }
+};
+
+// Per-thread producer of run batches.  Runs that keep (tid, beg) non-decreasing go to the sorted
+// stream; the rest (later runs of multi-run reads, unsorted input) to a second stream whose
+// measured disorder decides between the owner-tile path and the atomic path.
+class RunSink {
+public:
+    explicit RunSink(Engine *e) : e_(e) {}
+    ~RunSink() { flush(); }
+    inline void emit(int32_t tid, int32_t beg, int32_t end)
+    {
+        const uint64_t key = ((uint64_t)(uint32_t)tid << 32) | (uint32_t)(beg < 0 ? 0 : beg);
+        if (key >= s_last_) {
+            if (sn_ == scap_ && !next_slot(&sbuf_, &scap_, &sn_, PD_PUSH_SORTED)) return;
+            sbuf_[sn_++] = pd_iv{tid, beg, end};
+            s_last_ = key;
+        } else {
+            if (on_ == ocap_ && !next_other()) return;
+            if (key < o_max_) {
+                const uint64_t d = (key >> 32) == (o_max_ >> 32) ? (o_max_ - key) : (uint64_t)1 << 40;
+                if (d > o_dis_) o_dis_ = d;
+            } else o_max_ = key;
+            obuf_[on_++] = pd_iv{tid, beg, end};
+        }
+    }
+    void flush()
+    {
+        if (sbuf_) { submit(sbuf_, sn_, PD_PUSH_SORTED); sbuf_ = nullptr; sn_ = scap_ = 0; s_last_ = 0; }
+        if (obuf_) { submit(obuf_, on_, other_flags()); obuf_ = nullptr; on_ = ocap_ = 0; o_max_ = 0; o_dis_ = 0; }
+    }
+private:
+    unsigned other_flags() const
+    {
+        return o_dis_ <= (1u << 20) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
+    }
+    void submit(pd_iv *b, size_t n, unsigned flags) { e_->ck(e_->api->stage_submit(e_->ctx, b, n, flags), "pd_stage_submit"); }
+    bool next_slot(pd_iv **buf, size_t *cap, size_t *n, unsigned flags)
+    {
+        if (*buf) submit(*buf, *n, flags);
+        *buf = nullptr; *n = 0; *cap = 0;
+        if (!e_->ok()) return false;
+        if (!e_->ck(e_->api->stage_acquire(e_->ctx, buf, cap), "pd_stage_acquire")) { *buf = nullptr; *cap = 0; return false; }
+        return true;
+    }
+    bool next_other()
+    {
+        const unsigned f = other_flags();
+        o_max_ = 0; o_dis_ = 0;
+        return next_slot(&obuf_, &ocap_, &on_, f);
+    }
+    Engine *e_;
+    pd_iv *sbuf_ = nullptr, *obuf_ = nullptr;
+    size_t scap_ = 0, sn_ = 0, ocap_ = 0, on_ = 0;
+    uint64_t s_last_ = 0, o_max_ = 0, o_dis_ = 0;
+};
+
+// PD:438-460: CIGAR walk with an int32 cursor; one run per M/=/X operation, D/N advance only.
+inline void emit_runs(const AlnRec &r, RunSink *sink)
+{
+    int32_t cur = r.pos;
+    for (uint32_t i = 0; i < r.n_cigar; ++i) {
+        const uint32_t op = r.cigar[i] & 0xf;
+        const int32_t len = (int32_t)(r.cigar[i] >> 4);
+        if (op == 0 || op == 7 || op == 8) { sink->emit(r.tid, cur, cur + len); cur += len; }
+        else if (op == 2 || op == 3) cur += len;
+    }
+}
+
+struct ReadFilter {
+    uint32_t flag_mask; int min_mapq; int32_t n_contigs;
+    inline bool pass(const AlnRec &r) const
+    {
+        return !(r.flag & flag_mask) && (int)r.mapq >= min_mapq && r.tid >= 0 && r.tid < n_contigs;
+    }
+};
+
+// htslib multi-region fetch of "chr:max(s-1,1)-min(e+1,len)" for every merged span (PD:419-430):
+// a read is returned when pos < region_end && endpos > region_begin0.
+struct SpanIndex {
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> per_tid;   // (begin0, end) sorted
+    std::vector<char> whole;                                         // spans cover the whole contig
+    void build(const RegionModel &rm, const AlnHeader &h, bool synthetic)
+    {
+        per_tid.assign(h.names.size(), {}); whole.assign(h.names.size(), 0);
+        for (auto &kv : rm.merged) {
+            if (kv.first < 0 || (size_t)kv.first >= h.names.size()) continue;
+            const int64_t len = h.lens[kv.first];
+            auto &v = per_tid[kv.first];
+            for (auto &se : kv.second) {
+                int64_t b = (int64_t)se.first - 1; if (b < 1) b = 1;
+                int64_t e = (int64_t)se.second + 1; if (e > len) e = len;
+                v.emplace_back((int32_t)(b - 1), (int32_t)e);
+            }
+            if (synthetic) whole[kv.first] = 1;    // bins tile [1,len] (minus at most the last base): widened, they cover every read
+        }
+    }
+    inline bool hit(const AlnRec &r) const
+    {
+        const auto &v = per_tid[r.tid];
+        if (v.empty()) return false;
+        if (whole[r.tid]) return true;
+        // spans are disjoint and ordered, so region ends increase: first span whose end is past pos
+        size_t lo = 0, hi = v.size();
+        while (lo < hi) { const size_t m = (lo + hi) / 2; if (v[m].second > r.pos) hi = m; else lo = m + 1; }
+        return lo < v.size() && r.endpos() > v[lo].first;
+    }
+};
+
+bool index_exists(const std::string &p) { return file_exists(p + ".bai") || file_exists(p + ".crai") || file_exists(p + ".csi"); }
+
+// ---- readers ---------------------------------------------------------------------------------
+bool read_indexed(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans,
+                  Engine *eng)
+{
+    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    BaiIndex bai;
+    std::string err;
+    const bool have_bai = file_exists(path + ".bai") && bai.load(path + ".bai", &err);
+    AlnReader probe;
+    if (!probe.open(path, &err)) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
+    if (!probe.is_bam()) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
+    std::vector<uint64_t> cuts;
+    int threads = o.threads < 1 ? 1 : o.threads;
+    if (have_bai && threads > 1) cuts = bai.split(probe.tell(), file_size(path), threads * 8);
+    else { cuts.push_back(probe.tell()); cuts.push_back(UINT64_MAX); }
+    const size_t n_tasks = cuts.size() - 1;
+    if ((size_t)threads > n_tasks) threads = (int)n_tasks;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        AlnReader rd;
+        std::string e2;
+        if (!rd.open(path, &e2)) { eng->fail(e2); return; }
+        RunSink sink(eng);
+        AlnRec r;
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= n_tasks || !eng->ok()) break;
+            if (!rd.seek(cuts[t])) { eng->fail("seek failed in " + path); break; }
+            const uint64_t stop = cuts[t + 1];
+            for (;;) {
+                if (rd.tell() >= stop) break;
+                const int k = rd.next(&r);
+                if (k == 0) break;
+                if (k < 0) { eng->fail(rd.error() + " (" + path + ")"); return; }
+                if (!flt.pass(r)) continue;
+                if (!spans.hit(r)) continue;
+                emit_runs(r, &sink);
+            }
+        }
+    };
+    if (threads <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < threads; ++i) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    return eng->ok();
+}
+
+// No index, header says SO:coordinate (PD:4604-4671): one cursor per contig over its merged spans.
+bool read_sorted_stream(AlnReader *rd, const Options &o, const AlnHeader &main_hdr, const RegionModel &rm, Engine *eng)
+{
+    const int32_t n = (int32_t)main_hdr.names.size();
+    std::vector<char> done(n, 1);
+    std::vector<const std::vector<std::pair<int32_t, int32_t>> *> sp(n, nullptr);
+    std::vector<size_t> cur(n, 0);
+    for (auto &kv : rm.merged) if (kv.first >= 0 && kv.first < n) { done[kv.first] = 0; sp[kv.first] = &kv.second; }
+    RunSink sink(eng);
+    AlnRec r;
+    int k;
+    while ((k = rd->next(&r)) > 0) {
+        if (r.tid < 0 || r.tid >= n) continue;       // the reference indexes EndChr[tid] here (UB for tid = -1)
+        if (done[r.tid]) continue;
+        if ((int)r.mapq < o.min_mapq) continue;
+        if (r.flag & o.flag_mask) continue;
+        const auto &v = *sp[r.tid];
+        if (r.endpos() < v[cur[r.tid]].first) continue;
+        if (r.pos > v[cur[r.tid]].second) {
+            size_t c = cur[r.tid] + 1;
+            while (c < v.size() && !(r.pos <= v[c].second)) ++c;
+            cur[r.tid] = c;
+            if (c == v.size()) {
+                done[r.tid] = 1;
+                bool all = true;
+                for (int32_t i = 0; i < n; ++i) if (!done[i]) { all = false; break; }
+                if (all) break;                      // this read is NOT counted (PD:4641-4644)
+            }
+        }
+        emit_runs(r, &sink);                         // counted even when the cursor just ran off the end
+    }
+    if (k < 0) eng->fail(rd->error());
+    return eng->ok();
+}
+
+// No index, not coordinate sorted (PD:4677-4711): every read that passes the filter.
+bool read_all(AlnReader *rd, const Options &o, const AlnHeader &main_hdr, const RegionModel &rm, Engine *eng)
+{
+    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    RunSink sink(eng);
+    AlnRec r;
+    int k;
+    while ((k = rd->next(&r)) > 0) {
+        if (!flt.pass(r)) continue;
+        if (!rm.has(r.tid)) continue;                // depth on contigs without targets is never reported
+        emit_runs(r, &sink);
+    }
+    if (k < 0) eng->fail(rd->error());
+    return eng->ok();
+}
+
+// ---- output ------------------------------------------------------------------------------------
+inline char *put_u32(char *p, uint32_t v)
+{
+    char t[12]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+
+bool write_site_depth(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng)
+{
+    GzWriter out;
+    if (!out.open(path)) { std::cerr << "open OUT File error: " << path << std::endl; return false; }
+    const size_t CH = (size_t)4 << 20;
+    std::vector<uint32_t> d(CH);
+    std::vector<char> txt;
+    for (size_t t = 0; t < hdr.names.size(); ++t) {
+        if (!rm.has((int32_t)t)) continue;
+        const std::string &nm = hdr.names[t];
+        const uint32_t len = hdr.lens[t];
+        txt.resize(CH * (nm.size() + 24));
+        for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
+            const size_t n = std::min<size_t>(CH, len - b);
+            if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) return false;
+            char *p = txt.data();
+            for (size_t j = 0; j < n; ++j) {
+                memcpy(p, nm.data(), nm.size()); p += nm.size();
+                *p++ = '\t'; p = put_u32(p, b + (uint32_t)j); *p++ = '\t'; p = put_u32(p, d[j]); *p++ = '\n';
+            }
+            out.write(txt.data(), (size_t)(p - txt.data()));
+        }
+    }
+    return out.close();
+}
+
+std::string footer(uint64_t L, uint64_t C, uint64_t D)
+{
+    return "##RegionLength: " + std::to_string(L) + "\tCoveredSite: " + std::to_string(C) + "\tCoverage(%): " +
+           fmt2(C * 100.0 / L) + "\tMeanDepth: " + fmt2(D * 1.0 / L) + "\n";
+}
+
+} // namespace
+
+} // namespace pdh
+
+using namespace pdh;
+
+extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, int device)
+{
+    Options o;
+    const int n_files = parse_options(argc, argv, &o);
+    if (n_files == 0) return 0;
+    const bool list_mode = n_files > 1;
+    if (list_mode) std::cout << "INFO: Run multi-file data " << std::endl;
+    if (o.gc) std::cerr << "Warning: GC content (-c/-r) is not computed by this engine; columns are omitted." << std::endl;
+
+    std::string path = o.input, err;
+    if (path.empty()) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
+    AlnReader first;
+    if (!first.open(path, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
+    const AlnHeader hdr = first.header();
+    if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
+
+    RegionModel rm;
+    const bool had_targets = o.mode != 0;
+    if (!build_regions(&o, hdr, &rm)) return 1;
+    const bool synthetic = o.mode == 0 || o.mode == 5 || o.mode == 6;
+    (void)had_targets;
+
+    // output names (PD:4057-4090)
+    std::string prefix = o.out.substr(0, o.out.size() - 3);
+    {
+        const size_t d = prefix.rfind('.');
+        const std::string ext = d == std::string::npos ? std::string() : prefix.substr(d + 1);
+        if (ext == "stat" || ext == "bed") prefix = prefix.substr(0, d);
+    }
+    std::string stat_path = prefix + ".gene.stat.gz";
+    std::string header_line = "#Chr\tStart\tEnd\tGeneID\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n";
+    if (o.mode == 3) { stat_path = prefix + ".bed.stat.gz"; header_line = "#Chr\tStart\tEnd\tRegionID\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
+    else if (o.mode == 4) stat_path = prefix + ".bed.stat.gz";
+    else if (o.mode == 5 || o.mode == 6) { stat_path = prefix + ".win.stat.gz"; header_line = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
+    else if (o.mode == 0) { stat_path = prefix + ".chr.stat.gz"; header_line = "#Chr\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
+    GzWriter OUT;
+    if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
+
+    Engine eng;
+    eng.api = api;
+    if (api->create(device, (int32_t)hdr.lens.size(), hdr.lens.data(), &eng.ctx) != 0) {
+        const char *m = api->strerror(nullptr);
+        std::cerr << "Error: depth engine unavailable: " << (m ? m : "?") << std::endl;
+        return 2;
+    }
+    struct CtxGuard { Engine *e; ~CtxGuard() { if (e->ctx) e->api->destroy(e->ctx); } } guard{&eng};
+
+    SpanIndex spans;
+    spans.build(rm, hdr, synthetic);
+
+    bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
+    for (const std::string &fp : o.inputs) {
+        if (index_exists(fp) && o.use_index) {
+            if (o.site_out || o.mode == 6) wrap18 = true;            // PD:4127
+            if (!read_indexed(fp, o, hdr, spans, &eng)) break;
+        } else {
+            AlnReader rd;
+            AlnReader *r = &rd;
+            if (!list_mode) r = &first;                              // already positioned after the header
+            else if (!rd.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
+            wrap18 = true;                                           // PD:4553
+            if (r->header().sorted_coordinate()) {
+                std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
+                if (!read_sorted_stream(r, o, hdr, rm, &eng)) break;
+            } else {
+                std::cout << "Warning: Can't find index file of input BAM/CRAM. PanDepth will run in No Index mode: " << fp << std::endl;
+                if (!read_all(r, o, hdr, rm, &eng)) break;
+            }
+        }
+    }
+    if (!eng.ok() || !eng.ck(api->synchronize(eng.ctx), "pd_synchronize")) {
+        std::cerr << "Error: " << eng.err << std::endl;
+        return 2;
+    }
+    const unsigned wrap_bits = wrap18 ? 18u : 0u;
+    const uint32_t min_dep = (uint32_t)o.min_dep;
+    bool scanned = false;
+    auto need_scan = [&]() -> bool {
+        if (scanned) return true;
+        scanned = true;
+        return eng.ck(api->scan(eng.ctx, wrap_bits), "pd_scan");
+    };
+    auto bail = [&]() { std::cerr << "Error: " << eng.err << std::endl; return 2; };
+
+    if (o.site_out) {
+        if (!need_scan()) return bail();
+        if (!write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng)) { if (!eng.ok()) return bail(); }
+    }
+
+    const size_t nctg = hdr.lens.size();
+    uint64_t SL = 0, SC = 0, SD = 0;
+    std::string txt;
+
+    if (o.mode == 6) {
+        // PD:4352-4394: windows straight off the cells; `for (j = 1; j < len; j += w)` drops a final
+        // 1-base window
+        const uint32_t w = (uint32_t)o.win;
+        std::vector<uint64_t> woff(nctg + 1);
+        api->window_layout(eng.ctx, w, woff.data());
+        std::vector<uint32_t> cov(woff[nctg] ? woff[nctg] : 1);
+        std::vector<uint64_t> sum(woff[nctg] ? woff[nctg] : 1);
+        const int rc = scanned ? api->reduce_windows(eng.ctx, w, min_dep, cov.data(), sum.data())
+                               : api->scan_reduce_windows(eng.ctx, w, min_dep, wrap_bits, cov.data(), sum.data());
+        if (!eng.ck(rc, "window reduction")) return bail();
+        OUT.write(header_line);
+        txt.reserve(1 << 22);
+        for (size_t t = 0; t < nctg; ++t) {
+            if (!rm.has((int32_t)t)) continue;
+            const int64_t len = hdr.lens[t];
+            for (int64_t j = 1, k = 0; j < len; j += w, ++k) {
+                int64_t end = j - 1 + w; if (end > len) end = len;
+                const int64_t L = end - j + 1;
+                const int32_t c = (int32_t)cov[woff[t] + k];
+                const int32_t d = (int32_t)sum[woff[t] + k];          // `int GeneDepth` (PD:4364)
+                txt += hdr.names[t]; txt += '\t'; txt += std::to_string(j); txt += '\t'; txt += std::to_string(end);
+                txt += '\t'; txt += std::to_string(L); txt += '\t'; txt += std::to_string(c); txt += '\t';
+                txt += std::to_string(d); txt += '\t'; txt += fmt2(c * 100.0 / L); txt += '\t'; txt += fmt2(d * 1.0 / L);
+                txt += '\n';
+                SC += (uint64_t)(int64_t)c; SL += (uint64_t)L; SD += (uint64_t)(int64_t)d;
+                if (txt.size() > (1u << 22) - 256) { OUT.write(txt); txt.clear(); }
+            }
+        }
+        OUT.write(txt);
+        OUT.write(footer(SL, SC, SD));
+        OUT.close();
+        std::cout << "INFO: Input data read done" << std::endl;
+        return 0;
+    }
+
+    if (synthetic) {
+        // modes 0 and 5: every bin is window (start-1)/width of its contig
+        const uint32_t width = o.mode == 5 ? (uint32_t)o.win : 10000000u;
+        std::vector<uint64_t> woff(nctg + 1);
+        api->window_layout(eng.ctx, width, woff.data());
+        std::vector<uint32_t> cov(woff[nctg] ? woff[nctg] : 1);
+        std::vector<uint64_t> sum(woff[nctg] ? woff[nctg] : 1);
+        const int rc = scanned ? api->reduce_windows(eng.ctx, width, min_dep, cov.data(), sum.data())
+                               : api->scan_reduce_windows(eng.ctx, width, min_dep, wrap_bits, cov.data(), sum.data());
+        if (!eng.ck(rc, "window reduction")) return bail();
+        for (auto &kv : rm.genes)
+            for (auto &g : kv.second) {
+                const uint64_t k = (uint64_t)(g.second.start - 1) / width;
+                g.second.cover = (int32_t)cov[woff[kv.first] + k];
+                g.second.depth = sum[woff[kv.first] + k];
+            }
+    } else {
+        if (!need_scan()) return bail();
+        std::vector<pd_region> regs;
+        for (auto &kv : rm.genes)
+            for (auto &g : kv.second)
+                for (auto &c : g.second.cds) regs.push_back(pd_region{kv.first, c.first, c.second});
+        std::vector<int32_t> cov(regs.size() ? regs.size() : 1);
+        std::vector<uint64_t> sum(regs.size() ? regs.size() : 1);
+        if (!eng.ck(api->reduce_intervals(eng.ctx, regs.data(), regs.size(), min_dep, cov.data(), sum.data()), "pd_reduce_intervals"))
+            return bail();
+        size_t i = 0;
+        for (auto &kv : rm.genes)
+            for (auto &g : kv.second)
+                for (size_t c = 0; c < g.second.cds.size(); ++c, ++i) { g.second.cover += cov[i]; g.second.depth += sum[i]; }
+    }
+    std::cout << "INFO: Input data read done" << std::endl;
+
+    OUT.write(header_line);
+    if (o.mode == 0) {
+        for (auto &kv : rm.genes) {
+            uint64_t L = 0, C = 0, D = 0;
+            for (auto &g : kv.second) { L += g.second.length; C += (uint64_t)(int64_t)g.second.cover; D += g.second.depth; }
+            SL += L; SC += C; SD += D;
+            OUT.write(hdr.names[kv.first] + "\t" + std::to_string(L) + "\t" + std::to_string(C) + "\t" + std::to_string(D) +
+                      "\t" + fmt2(C * 100.0 / L) + "\t" + fmt2(D * 1.0 / L) + "\n");
+        }
+    } else {
+        for (auto &kv : rm.genes) {
+            // rows by start; equal starts keep the id order of the map (PD:5032-5041)
+            std::map<int32_t, std::string> rows;
+            const std::string &chr = hdr.names[kv.first];
+            for (auto &g : kv.second) {
+                const Gene &x = g.second;
+                SC += (uint64_t)(int64_t)x.cover; SL += x.length; SD += x.depth;
+                std::string row = chr + "\t" + std::to_string(x.start) + "\t" + std::to_string(x.end) + "\t";
+                if (o.mode != 5) { row += g.first; row += '\t'; }
+                row += std::to_string(x.length) + "\t" + std::to_string(x.cover) + "\t" + std::to_string(x.depth) + "\t" +
+                       fmt2(x.cover * 100.0 / x.length) + "\t" + fmt2(x.depth * 1.0 / x.length);
+                auto it = rows.find(x.start);
+                if (it == rows.end()) rows.emplace(x.start, row);
+                else { it->second += "\n"; it->second += row; }
+            }
+            txt.clear();
+            for (auto &r : rows) { txt += r.second; txt += '\n'; if (txt.size() > (1u << 22)) { OUT.write(txt); txt.clear(); } }
+            OUT.write(txt);
+        }
+    }
+    OUT.write(footer(SL, SC, SD));
+    OUT.close();
+    return 0;
+}

@@ -1,0 +1,162 @@
+// regions.cpp — see regions.h
+#include "regions.h"
+#include <stdlib.h>
+#include <iostream>
+#include <sstream>
+
+namespace pdh {
+
+namespace {
+
+void split_any(const std::string &s, const char *delims, std::vector<std::string> *tok)
+{
+    tok->clear();
+    size_t i = s.find_first_not_of(delims);
+    while (i != std::string::npos) {
+        const size_t e = s.find_first_of(delims, i);
+        tok->push_back(s.substr(i, e == std::string::npos ? std::string::npos : e - i));
+        if (e == std::string::npos) break;
+        i = s.find_first_not_of(delims, e);
+    }
+}
+
+void erase_all(std::string *s, char c)
+{
+    size_t w = 0;
+    for (size_t r = 0; r < s->size(); ++r) if ((*s)[r] != c) (*s)[w++] = (*s)[r];
+    s->resize(w);
+}
+
+void add_entry(RegionModel *rm, int32_t tid, const std::string &id, long long start, long long end)
+{
+    Gene &g = rm->genes[tid][id];
+    const int32_t s = (int32_t)start, e = (int32_t)end;
+    if (g.cds.empty()) { g.start = s; g.end = e; }
+    else { if (g.start > s) g.start = s; if (g.end < e) g.end = e; }
+    g.length += (uint64_t)(end - start + 1);
+    g.cds.emplace_back(s, e);
+}
+
+void unknown_contig(const std::string &line)
+{
+    std::cerr << line << "Warning: This region may be incorrect.\n" << std::endl;
+}
+
+} // namespace
+
+static void merge_spans(RegionModel *rm)
+{
+    // PD:3912-3972: per contig, spans keyed by start (largest end wins), merged when the next
+    // start is <= the current end; a span starting at end+1 stays separate.
+    for (auto &kv : rm->genes) {
+        std::map<int32_t, int32_t> by_start;
+        for (auto &g : kv.second) {
+            auto it = by_start.find(g.second.start);
+            if (it == by_start.end()) by_start[g.second.start] = g.second.end;
+            else if (g.second.end > it->second) it->second = g.second.end;
+        }
+        std::vector<std::pair<int32_t, int32_t>> out;
+        for (auto &se : by_start) {
+            if (out.empty() || se.first > out.back().second) out.emplace_back(se.first, se.second);
+            else if (se.second > out.back().second) out.back().second = se.second;
+        }
+        rm->merged[kv.first] = out;
+    }
+}
+
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
+{
+    std::map<std::string, int32_t> chr2tid;
+    for (size_t i = 0; i < hdr.names.size(); ++i) chr2tid.insert({hdr.names[i], (int32_t)i});   // first name wins
+
+    if (o->mode != 0) {
+        std::vector<std::string> lines;
+        if (!read_lines(o->region_file, &lines)) {
+            std::cerr << "Error: Cannot open the GFF/GTF File: " << o->input << std::endl;
+            return false;
+        }
+        // these live across lines in the reference too: a short line re-uses the previous values
+        std::string chr, id, start_s, end_s;
+        int bstart = 0, bend = 0;
+        for (std::string &line : lines) {
+            if (line.empty()) continue;
+            if (line[0] == '#') continue;
+            if (o->mode == 1) {                                   // GFF3, PD:3557-3647
+                std::istringstream is(line);
+                std::string f2, feat, strand, attr;
+                long long s = 0, e = 0;
+                is >> chr >> f2 >> feat;
+                if (feat != o->feature) continue;
+                is >> s >> e >> f2 >> strand >> f2 >> attr;
+                std::vector<std::string> inf, kv;
+                split_any(attr, ",;", &inf);
+                if (inf.empty()) continue;
+                split_any(inf[0], "=", &kv);
+                std::string gid = kv.empty() ? std::string() : kv.back();
+                for (size_t j = 1; j < inf.size(); ++j) {
+                    split_any(inf[j], "=", &kv);
+                    if (!kv.empty() && kv[0] == "Parent") gid = kv.back();
+                }
+                auto it = chr2tid.find(chr);
+                if (it == chr2tid.end()) unknown_contig(line);
+                else add_entry(rm, it->second, gid, s, e);
+            } else if (o->mode == 2) {                            // GTF, PD:3649-3740
+                erase_all(&line, '"');
+                erase_all(&line, ';');
+                std::istringstream is(line);
+                std::string f2, feat;
+                long long s = 0, e = 0;
+                is >> chr >> f2 >> feat;
+                if (feat != o->feature) continue;
+                is >> s >> e;
+                std::vector<std::string> inf;
+                split_any(line, "\t ", &inf);
+                if (inf.size() < 10) continue;
+                auto it = chr2tid.find(chr);
+                if (it == chr2tid.end()) unknown_contig(line);
+                else add_entry(rm, it->second, inf[9], s, e);
+            } else if (o->mode == 3) {                            // BED3, PD:3741-3819
+                std::istringstream is(line);
+                is >> chr >> start_s >> end_s;
+                id = chr + "_" + start_s + "_" + end_s;
+                bstart = atoi(start_s.c_str()); bend = atoi(end_s.c_str());
+                if (bstart > bend) { std::cerr << line << "Warning: This region may be incorrect.\n" << std::endl; continue; }
+                auto it = chr2tid.find(chr);
+                if (it == chr2tid.end()) unknown_contig(line);
+                else add_entry(rm, it->second, id, bstart, bend);
+            } else if (o->mode == 4) {                            // BED4, PD:3821-3898
+                std::istringstream is(line);
+                is >> chr >> bstart >> bend >> id;
+                if (bstart > bend) { std::cerr << line << "Warning: This region may be incorrect. \n" << std::endl; continue; }
+                auto it = chr2tid.find(chr);
+                if (it == chr2tid.end()) unknown_contig(line);
+                else add_entry(rm, it->second, id, bstart, bend);
+            }
+        }
+    }
+    merge_spans(rm);
+    if (rm->merged.empty()) {
+        // no targets: whole-contig bins (PD:3974-4051)
+        int width = 10000000;
+        if (o->win == 0) o->mode = 0;
+        else if (o->win < 150) o->mode = 6;
+        else { o->mode = 5; width = o->win; }
+        for (size_t i = 0; i < hdr.names.size(); ++i) {
+            const long long len = hdr.lens[i];
+            long long start = 1, end = 2;
+            // the loop condition tests the PREVIOUS bin's end + 2: contigs shorter than 2 get no bin,
+            // and a final 1-base bin (len = k*width + 1) is never created
+            for (start = 1; end <= len; start += width) {
+                end = start + width - 1;
+                if (end > len) end = len;
+                add_entry(rm, (int32_t)i, hdr.names[i] + std::to_string(start), start, end);
+                end += 2;
+            }
+        }
+        rm->merged.clear();
+        merge_spans(rm);
+    }
+    return true;
+}
+
+} // namespace pdh

@@ -1,0 +1,36 @@
+// regions.h — the region model: GFF / GTF / BED targets or synthetic bins, grouped per contig and
+// per id, plus the merged spans that decide which reads the reference would have fetched.
+// Semantics follow PD:3547-4051 (1-based inclusive coordinates everywhere; BED is NOT converted
+// from 0-based; ids are keys of an ordered map; overlapping entries of one id double count).
+#ifndef PD_REGIONS_H_
+#define PD_REGIONS_H_
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "bam.h"
+#include "options.h"
+
+namespace pdh {
+
+struct Gene {
+    int32_t start = 0, end = 0;                       // min first / max second over the entries
+    uint64_t length = 0;                              // sum of (second - first + 1)
+    std::vector<std::pair<int32_t, int32_t>> cds;     // entries in file order
+    int32_t cover = 0;                                // filled by the pipeline
+    uint64_t depth = 0;
+};
+
+struct RegionModel {
+    std::map<int32_t, std::map<std::string, Gene>> genes;           // tid -> id -> Gene
+    std::map<int32_t, std::vector<std::pair<int32_t, int32_t>>> merged;   // tid -> sorted disjoint spans
+    bool has(int32_t tid) const { return merged.find(tid) != merged.end(); }
+};
+
+// Parses o->region_file according to o->mode (1..4); on return, if no region survived, builds the
+// synthetic bins and sets o->mode to 0 / 5 / 6 (PD:3974-4051).  Returns false on an unreadable file.
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm);
+
+} // namespace pdh
+#endif

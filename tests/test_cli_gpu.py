@@ -1,0 +1,35 @@
+"""GPU end-to-end parity: the `pandepth` binary (host side + gfx950 engine through the C-ABI)
+on every golden case — gz bytes, text, stdout and exit code identical to the reference's."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLI = os.path.join(ROOT, "pandepth_amd", "pandepth")
+MANIFEST = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("case", MANIFEST, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_pandepth_cli_byte_identical(case, threads, tmp_path):
+    assert os.access(CLI, os.X_OK), "pandepth binary not built (make -C pandepth_amd)"
+    d = os.path.join(HERE, "golden", case["fixture"])
+    args = [CLI] + case["args"] + ["-o", str(tmp_path / "o")]
+    if "-t" not in case["args"]:
+        args += ["-t", str(threads)]
+    elif threads != 1:
+        pytest.skip("case fixes -t")
+    p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
+    assert p.stdout.decode() == case["stdout"]
+    for suffix, meta in case["outputs"].items():
+        gz = (tmp_path / ("o." + suffix)).read_bytes()
+        assert hashlib.sha256(gzip.decompress(gz)).hexdigest() == meta["text_sha256"], suffix
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix + " (gz bytes)"
