@@ -19,8 +19,8 @@ using namespace pdk;
 
 namespace {
 
-constexpr int N_STAGE = 8;
-constexpr size_t STAGE_CAP = (size_t)2 << 20;        // runs per staging slot (24 MiB)
+constexpr int N_STAGE = 1024;                        // upper bound; slots are created on demand
+constexpr size_t STAGE_CAP = (size_t)1 << 18;        // runs per staging slot (3 MiB pinned + 3 MiB HBM)
 constexpr size_t DEV_BATCH_MAX = (size_t)256 << 20;  // runs per sorted device sub-batch (32-bit indices)
 constexpr uint32_t LMAX_DEFAULT = 512;               // look-back bound for owner tiles (cells)
 constexpr uint32_t SAMPLE_DEFAULT = 64;              // sparse index stride (runs)
@@ -51,7 +51,7 @@ struct pd_ctx {
     uint32_t *ub_a = nullptr, *cand_lo = nullptr;
     BatchDesc *desc = nullptr; CheckWords *chk = nullptr;
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
-    Stage stage[N_STAGE];
+    std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int state = 0;                                   // 0 accumulating (diff), 1 depth
@@ -188,11 +188,24 @@ int stage_acquire(pd_ctx *c, int *slot)
 {
     for (;;) {
         int oldest = -1;
-        for (int i = 0; i < N_STAGE; ++i) {
+        for (int i = 0; i < (int)c->stage.size(); ++i) {
             Stage &s = c->stage[i];
             if (s.state == 2 && hipEventQuery(s.done) == hipSuccess) s.state = 0;
             if (s.state == 0) { *slot = i; s.state = 1; return PD_OK; }
             if (s.state == 2 && (oldest < 0 || s.seq < c->stage[oldest].seq)) oldest = i;
+        }
+        // a new slot while the pool may still grow and fewer than 4 batches are queued on the GPU
+        int inflight = 0;
+        for (auto &s : c->stage) inflight += s.state == 2;
+        if ((int)c->stage.size() < N_STAGE && (oldest < 0 || inflight < 4)) {
+            Stage s;
+            if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+                return fail(c, PD_EHIP, "cannot create staging events");
+            s.state = 1;
+            c->stage.push_back(s);
+            *slot = (int)c->stage.size() - 1;
+            return PD_OK;
         }
         if (oldest < 0) return fail(c, PD_ESTATE, "all staging slots are held by callers");
         HIPOK(c, hipEventSynchronize(c->stage[oldest].done));
@@ -279,10 +292,6 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
         CREATE_OK(hipMemcpy(c->d_off, c->off.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice));
         CREATE_OK(hipMemcpy(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice));
     }
-    for (int i = 0; i < N_STAGE; ++i) {
-        CREATE_OK(hipEventCreateWithFlags(&c->stage[i].copied, hipEventDisableTiming));
-        CREATE_OK(hipEventCreateWithFlags(&c->stage[i].done, hipEventDisableTiming));
-    }
 #undef CREATE_OK
     int rc = do_fill(c);
     if (rc == PD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PD_EHIP;
@@ -297,7 +306,7 @@ int pd_destroy(pd_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    for (int i = 0; i < N_STAGE; ++i) {
+    for (size_t i = 0; i < c->stage.size(); ++i) {
         if (c->stage[i].host) (void)hipHostFree(c->stage[i].host);
         if (c->stage[i].dev) (void)hipFree(c->stage[i].dev);
         if (c->stage[i].copied) (void)hipEventDestroy(c->stage[i].copied);
@@ -370,7 +379,7 @@ int pd_stage_submit(pd_ctx *c, pd_iv *host_buf, size_t n, unsigned flags)
     if (!c || !host_buf) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     int slot = -1;
-    for (int i = 0; i < N_STAGE; ++i) if (c->stage[i].host == host_buf && c->stage[i].state == 1) slot = i;
+    for (int i = 0; i < (int)c->stage.size(); ++i) if (c->stage[i].host == host_buf && c->stage[i].state == 1) slot = i;
     if (slot < 0) return fail(c, PD_EINVAL, "pd_stage_submit: buffer was not handed out by pd_stage_acquire");
     if (n > STAGE_CAP) return fail(c, PD_EINVAL, "pd_stage_submit: more runs than the slot holds");
     if (c->state != 0) { c->stage[slot].state = 0; return fail(c, PD_ESTATE, "pd_stage_submit: depth already materialised (call pd_reset)"); }

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <algorithm>
+#include <map>
 
 namespace pdh {
 
@@ -280,6 +281,83 @@ bool BaiIndex::load(const std::string &path, std::string *err)
 bad:
     if (err) *err = path + ": truncated BAI index";
     return false;
+}
+
+static inline uint32_t reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+bool bai_build(const std::string &bam_path, std::string *err)
+{
+    AlnReader rd;
+    if (!rd.open(bam_path, err)) return false;
+    if (!rd.is_bam()) { if (err) *err = bam_path + " is not a BAM file"; return false; }
+    const size_t n_ref = rd.header().names.size();
+    struct Chunk { uint64_t b, e; };
+    struct Ref {
+        std::map<uint32_t, std::vector<Chunk>> bins;
+        std::vector<uint64_t> lin;
+        uint64_t off_beg = 0, off_end = 0, n_mapped = 0, n_unmapped = 0;
+        bool any = false;
+    };
+    std::vector<Ref> refs(n_ref);
+    uint64_t n_no_coor = 0;
+    AlnRec r;
+    int k;
+    int32_t last_tid = 0, last_pos = -1;
+    for (;;) {
+        const uint64_t v0 = rd.tell();
+        k = rd.next(&r);
+        if (k <= 0) break;
+        const uint64_t v1 = rd.tell();
+        if (r.tid < 0) { ++n_no_coor; continue; }
+        if ((size_t)r.tid >= n_ref) { if (err) *err = "record names a reference outside the header"; return false; }
+        if (r.tid < last_tid || (r.tid == last_tid && r.pos < last_pos)) { if (err) *err = bam_path + " is not coordinate sorted"; return false; }
+        last_tid = r.tid; last_pos = r.pos;
+        Ref &R = refs[r.tid];
+        const int64_t beg = r.pos < 0 ? 0 : r.pos;
+        int64_t end = r.endpos(); if (end <= beg) end = beg + 1;
+        const uint32_t bin = reg2bin(beg, end);
+        auto &ch = R.bins[bin];
+        if (!ch.empty() && ch.back().e == v0) ch.back().e = v1; else ch.push_back({v0, v1});
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (R.lin.size() <= w1) R.lin.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (R.lin[w] == 0) R.lin[w] = v0;
+        if (!R.any) { R.any = true; R.off_beg = v0; }
+        R.off_end = v1;
+        if (r.flag & 4) ++R.n_unmapped; else ++R.n_mapped;
+    }
+    if (k < 0) { if (err) *err = rd.error(); return false; }
+    std::vector<uint8_t> out;
+    auto p32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) out.push_back((uint8_t)(v >> (8 * i))); };
+    auto p64 = [&](uint64_t v) { for (int i = 0; i < 8; ++i) out.push_back((uint8_t)(v >> (8 * i))); };
+    out.insert(out.end(), {'B', 'A', 'I', 1});
+    p32((uint32_t)n_ref);
+    for (Ref &R : refs) {
+        p32((uint32_t)(R.bins.size() + (R.any ? 1 : 0)));
+        for (auto &b : R.bins) {
+            p32(b.first); p32((uint32_t)b.second.size());
+            for (auto &c : b.second) { p64(c.b); p64(c.e); }
+        }
+        if (R.any) { p32(37450); p32(2); p64(R.off_beg); p64(R.off_end); p64(R.n_mapped); p64(R.n_unmapped); }
+        for (size_t i = 1; i < R.lin.size(); ++i) if (R.lin[i] == 0) R.lin[i] = R.lin[i - 1];
+        p32((uint32_t)R.lin.size());
+        for (uint64_t v : R.lin) p64(v);
+    }
+    p64(n_no_coor);
+    FILE *f = fopen((bam_path + ".bai").c_str(), "wb");
+    if (!f) { if (err) *err = "cannot write " + bam_path + ".bai"; return false; }
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    if (!ok && err) *err = "short write on " + bam_path + ".bai";
+    return ok;
 }
 
 std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_parts) const

@@ -40,6 +40,7 @@ public:
     int next(AlnRec *r);
     uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record
     bool seek(uint64_t voff) { return bg_.seek(voff); }
+    void set_threads(int n) { bg_.set_threads(n); }    // sequential streams: parallel inflate read-ahead
     const std::string &error() const { return err_; }
 private:
     bool read_bam_header();
@@ -66,6 +67,11 @@ struct BaiIndex {
     // compressed size.  Returns the boundaries (size = parts + 1, last = UINT64_MAX).
     std::vector<uint64_t> split(uint64_t first_record_voff, uint64_t file_size, int n_parts) const;
 };
+
+// Builds <bam_path>.bai for a coordinate-sorted BAM (SAM spec §5.2: binning index + 16 kb linear
+// index + the 37450 metadata pseudo-bin).  A companion tool, not part of the reference's CLI: the
+// generated fixtures and benchmark inputs need an index and no samtools exists on the box.
+bool bai_build(const std::string &bam_path, std::string *err);
 
 bool file_exists(const std::string &p);
 uint64_t file_size(const std::string &p);

@@ -5,7 +5,9 @@
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 namespace pdh {
 
@@ -93,11 +95,147 @@ uint32_t bgzf_block_size(const uint8_t *p, size_t avail, uint32_t *data_off)
     return 0;
 }
 
+// ---- threaded read-ahead ------------------------------------------------------------------
+struct BgzfReader::Pipe {
+    struct Blk { uint32_t coff, csize, doff, usize; size_t uoff; };
+    struct Job {
+        std::vector<uint8_t> comp, out;
+        std::vector<Blk> blks;
+        uint64_t file_off = 0;
+        int state = 0;                    // 0 empty, 1 ready to inflate, 2 inflating, 3 done
+        bool eof = false, bad = false;
+    };
+    static constexpr size_t CHUNK = (size_t)1 << 20;
+    int fd;
+    uint64_t off;
+    std::vector<Job> jobs;
+    size_t head = 0;                      // consumer position (job sequence number)
+    size_t tail = 0;                      // reader position
+    size_t next_inflate = 0;              // next job sequence number a worker may take
+    size_t cur_blk = 0;
+    bool started_job = false;
+    bool stop = false;
+    std::mutex mu;
+    std::condition_variable cv_empty, cv_ready, cv_done;
+    std::vector<std::thread> th;
+
+    Pipe(int fd_, uint64_t start, int n) : fd(fd_), off(start), jobs((size_t)n * 3 + 2)
+    {
+        th.emplace_back([this] { reader(); });
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { worker(); });
+    }
+    ~Pipe()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_empty.notify_all(); cv_ready.notify_all(); cv_done.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void reader()
+    {
+        for (;;) {
+            Job *j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_empty.wait(lk, [&] { return stop || jobs[tail % jobs.size()].state == 0; });
+                if (stop) return;
+                j = &jobs[tail % jobs.size()];
+            }
+            j->comp.resize(CHUNK + 65536);
+            const ssize_t n = pread(fd, j->comp.data(), j->comp.size(), (off_t)off);
+            j->blks.clear(); j->eof = false; j->bad = false; j->file_off = off;
+            size_t p = 0, u = 0;
+            if (n <= 0) j->eof = true;
+            else {
+                while (p + 18 <= (size_t)n && p < CHUNK) {
+                    uint32_t doff = 0;
+                    const uint32_t bs = bgzf_block_size(j->comp.data() + p, (size_t)n - p, &doff);
+                    if (bs == 0) { if (p == 0) j->bad = true; break; }
+                    if (p + bs > (size_t)n) break;
+                    const uint8_t *q = j->comp.data() + p;
+                    const uint32_t isize = q[bs - 4] | (q[bs - 3] << 8) | (q[bs - 2] << 16) | ((uint32_t)q[bs - 1] << 24);
+                    j->blks.push_back(Blk{(uint32_t)p, bs, doff, isize, u});
+                    u += isize; p += bs;
+                }
+                if (p == 0 && !j->bad) j->bad = true;        // a partial block at end of file
+                off += p;
+            }
+            j->out.resize(u);
+            const bool last = j->eof || j->bad;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j->state = 1; ++tail;
+            }
+            cv_ready.notify_all();
+            if (last) return;
+        }
+    }
+    void worker()
+    {
+        Inflater inf;
+        for (;;) {
+            Job *j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_ready.wait(lk, [&] { return stop || (next_inflate < tail && jobs[next_inflate % jobs.size()].state == 1); });
+                if (stop) return;
+                j = &jobs[next_inflate % jobs.size()];
+                j->state = 2; ++next_inflate;
+            }
+            for (const Blk &b : j->blks)
+                if (b.usize && !inf.inflate_raw(j->comp.data() + b.coff + b.doff, b.csize - b.doff - 8, j->out.data() + b.uoff, b.usize))
+                    j->bad = true;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j->state = 3;
+            }
+            cv_done.notify_all();
+            cv_ready.notify_all();
+        }
+    }
+};
+
 BgzfReader::BgzfReader() {}
 BgzfReader::~BgzfReader() { close(); }
 
+void BgzfReader::set_threads(int n)
+{
+    if (!is_bgzf_ || n < 1 || pipe_) return;
+    pipe_ = new Pipe(fd_, next_coff_, n);
+}
+
+bool BgzfReader::load_block_threaded()
+{
+    Pipe &P = *pipe_;
+    for (;;) {
+        Pipe::Job *j;
+        {
+            std::unique_lock<std::mutex> lk(P.mu);
+            if (P.started_job && P.cur_blk >= P.jobs[P.head % P.jobs.size()].blks.size()) {
+                P.jobs[P.head % P.jobs.size()].state = 0;      // chunk fully served: recycle
+                ++P.head; P.cur_blk = 0; P.started_job = false;
+                P.cv_empty.notify_all();
+            }
+            P.cv_done.wait(lk, [&] { return P.jobs[P.head % P.jobs.size()].state == 3 && P.head < P.tail; });
+            j = &P.jobs[P.head % P.jobs.size()];
+            P.started_job = true;
+        }
+        if (j->bad) { err_ = "truncated or corrupt BGZF block"; at_eof_ = true; return false; }
+        if (j->eof) { at_eof_ = true; return false; }
+        while (P.cur_blk < j->blks.size()) {
+            const Pipe::Blk &b = j->blks[P.cur_blk++];
+            block_coff_ = j->file_off + b.coff;
+            next_coff_ = block_coff_ + b.csize;
+            if (b.usize == 0) continue;
+            udata_ = j->out.data() + b.uoff;
+            upos_ = 0; ulen_ = b.usize;
+            return true;
+        }
+    }
+}
+
 void BgzfReader::close()
 {
+    if (pipe_) { delete pipe_; pipe_ = nullptr; }
     if (gz_) { gzclose((gzFile)gz_); gz_ = nullptr; }
     if (fd_ >= 0) { ::close(fd_); fd_ = -1; }
 }
@@ -128,6 +266,8 @@ bool BgzfReader::load_block()
 {
     upos_ = ulen_ = 0;
     if (at_eof_) return false;
+    if (pipe_) return load_block_threaded();
+    udata_ = ubuf_.data();
     if (!is_bgzf_) {
         const int n = gzread((gzFile)gz_, ubuf_.data(), (unsigned)ubuf_.size());
         if (n < 0) { err_ = "read error"; at_eof_ = true; return false; }
@@ -155,7 +295,8 @@ bool BgzfReader::load_block()
         next_coff_ = block_coff_ + bs;
         cpos_ += bs;
         if (isize == 0) continue;                               // empty block (e.g. the EOF marker)
-        if (isize > ubuf_.size()) ubuf_.resize(isize);
+        if (isize > ubuf_.size()) { ubuf_.resize(isize); }
+        udata_ = ubuf_.data();
         if (!inf_.inflate_raw(p + doff, bs - doff - 8, ubuf_.data(), isize)) {
             err_ = "corrupt BGZF block (inflate failed)"; at_eof_ = true; return false;
         }
@@ -171,7 +312,7 @@ long BgzfReader::read(void *dst, size_t n)
     while (got < n) {
         if (upos_ == ulen_) { if (!load_block()) break; }
         const size_t k = std::min(n - got, ulen_ - upos_);
-        memcpy(d + got, ubuf_.data() + upos_, k);
+        memcpy(d + got, udata_ + upos_, k);
         upos_ += k; got += k;
     }
     if (got == 0 && !err_.empty()) return -1;
@@ -182,7 +323,7 @@ const uint8_t *BgzfReader::peek(size_t *avail)
 {
     if (upos_ == ulen_) { if (!load_block()) { *avail = 0; return nullptr; } }
     *avail = ulen_ - upos_;
-    return ubuf_.data() + upos_;
+    return udata_ + upos_;
 }
 
 void BgzfReader::consume(size_t n) { upos_ += n; }
@@ -201,7 +342,7 @@ uint64_t BgzfReader::tell() const
 
 bool BgzfReader::seek(uint64_t voffset)
 {
-    if (!is_bgzf_) return false;
+    if (!is_bgzf_ || pipe_) return false;
     const uint64_t coff = voffset >> 16;
     const uint32_t uoff = (uint32_t)(voffset & 0xffff);
     cfile_off_ = coff; cpos_ = cend_ = 0; at_eof_ = false; upos_ = ulen_ = 0;

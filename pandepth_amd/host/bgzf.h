@@ -51,8 +51,15 @@ public:
     void consume(size_t n);
     bool eof();
     const std::string &error() const { return err_; }
+    // Sequential streams only (no seek afterwards): inflate blocks on n helper threads ahead of the
+    // consumer (a read-ahead ring of ~1 MiB compressed chunks, served strictly in file order).
+    void set_threads(int n);
 private:
+    struct Pipe;
     bool load_block();
+    bool load_block_threaded();
+    Pipe *pipe_ = nullptr;
+    const uint8_t *udata_ = nullptr;     // current block's bytes (ubuf_ or a pipeline chunk)
     int fd_ = -1;
     bool is_bgzf_ = false;
     void *gz_ = nullptr;                 // gzFile for non-BGZF input

@@ -15,8 +15,7 @@ typedef struct pd_engine_api {
     int (*create)(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out);
     int (*destroy)(pd_ctx *);
     const char *(*strerror)(const pd_ctx *);
-    int (*stage_acquire)(pd_ctx *, pd_iv **, size_t *);
-    int (*stage_submit)(pd_ctx *, pd_iv *, size_t, unsigned);
+    int (*push_intervals)(pd_ctx *, const pd_iv *, size_t, unsigned flags);
     int (*scan)(pd_ctx *, unsigned wrap_bits);
     int (*reduce_intervals)(pd_ctx *, const pd_region *, size_t, uint32_t, int32_t *, uint64_t *);
     int (*window_layout)(const pd_ctx *, uint32_t, uint64_t *);

@@ -10,8 +10,10 @@
 //   * the table text (PD:4879-5127) and the per-site file (PD:4264-4284).
 // The increment loop itself, the statistics and the window sweep run on the engine.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -25,6 +27,20 @@
 namespace pdh {
 
 namespace {
+
+// PANDEPTH_TIMING=1: phase wall times on stderr (diagnostics only)
+struct PhaseTimer {
+    bool on = getenv("PANDEPTH_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] %-28s %8.3f s   (total %.3f s)\n", what,
+                std::chrono::duration<double>(now - last).count(), std::chrono::duration<double>(now - t0).count());
+        last = now;
+    }
+};
 
 struct Engine {
     const pd_engine_api *api = nullptr;
@@ -44,55 +60,46 @@ struct Engine {
 
 // Per-thread producer of run batches.  Runs that keep (tid, beg) non-decreasing go to the sorted
 // stream; the rest (later runs of multi-run reads, unsorted input) to a second stream whose
-// measured disorder decides between the owner-tile path and the atomic path.
+// measured disorder decides between the owner-tile path and the atomic path.  Batches are built
+// in thread-local memory and handed to pd_push_intervals, which copies them into one of the
+// engine's few pinned staging slots (the copy is ~1 % of the inflate cost and keeps the amount of
+// pinned memory independent of the number of reader threads).
 class RunSink {
 public:
-    explicit RunSink(Engine *e) : e_(e) {}
+    static constexpr size_t CAP = (size_t)1 << 18;
+    explicit RunSink(Engine *e) : e_(e) { s_.reserve(CAP); o_.reserve(CAP / 4); }
     ~RunSink() { flush(); }
     inline void emit(int32_t tid, int32_t beg, int32_t end)
     {
         const uint64_t key = ((uint64_t)(uint32_t)tid << 32) | (uint32_t)(beg < 0 ? 0 : beg);
         if (key >= s_last_) {
-            if (sn_ == scap_ && !next_slot(&sbuf_, &scap_, &sn_, PD_PUSH_SORTED)) return;
-            sbuf_[sn_++] = pd_iv{tid, beg, end};
+            s_.push_back(pd_iv{tid, beg, end});
             s_last_ = key;
+            if (s_.size() >= CAP) flush_sorted();
         } else {
-            if (on_ == ocap_ && !next_other()) return;
             if (key < o_max_) {
                 const uint64_t d = (key >> 32) == (o_max_ >> 32) ? (o_max_ - key) : (uint64_t)1 << 40;
                 if (d > o_dis_) o_dis_ = d;
             } else o_max_ = key;
-            obuf_[on_++] = pd_iv{tid, beg, end};
+            o_.push_back(pd_iv{tid, beg, end});
+            if (o_.size() >= CAP / 4) flush_other();
         }
     }
-    void flush()
-    {
-        if (sbuf_) { submit(sbuf_, sn_, PD_PUSH_SORTED); sbuf_ = nullptr; sn_ = scap_ = 0; s_last_ = 0; }
-        if (obuf_) { submit(obuf_, on_, other_flags()); obuf_ = nullptr; on_ = ocap_ = 0; o_max_ = 0; o_dis_ = 0; }
-    }
+    void flush() { flush_sorted(); flush_other(); }
 private:
-    unsigned other_flags() const
+    void flush_sorted()
     {
-        return o_dis_ <= (1u << 20) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
+        if (!s_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, s_.data(), s_.size(), PD_PUSH_SORTED), "pd_push_intervals");
+        s_.clear(); s_last_ = 0;
     }
-    void submit(pd_iv *b, size_t n, unsigned flags) { e_->ck(e_->api->stage_submit(e_->ctx, b, n, flags), "pd_stage_submit"); }
-    bool next_slot(pd_iv **buf, size_t *cap, size_t *n, unsigned flags)
+    void flush_other()
     {
-        if (*buf) submit(*buf, *n, flags);
-        *buf = nullptr; *n = 0; *cap = 0;
-        if (!e_->ok()) return false;
-        if (!e_->ck(e_->api->stage_acquire(e_->ctx, buf, cap), "pd_stage_acquire")) { *buf = nullptr; *cap = 0; return false; }
-        return true;
-    }
-    bool next_other()
-    {
-        const unsigned f = other_flags();
-        o_max_ = 0; o_dis_ = 0;
-        return next_slot(&obuf_, &ocap_, &on_, f);
+        const unsigned f = o_dis_ <= (1u << 20) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
+        if (!o_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, o_.data(), o_.size(), f), "pd_push_intervals");
+        o_.clear(); o_max_ = 0; o_dis_ = 0;
     }
     Engine *e_;
-    pd_iv *sbuf_ = nullptr, *obuf_ = nullptr;
-    size_t scap_ = 0, sn_ = 0, ocap_ = 0, on_ = 0;
+    std::vector<pd_iv> s_, o_;
     uint64_t s_last_ = 0, o_max_ = 0, o_dis_ = 0;
 };
 
@@ -168,7 +175,13 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     const size_t n_tasks = cuts.size() - 1;
     if ((size_t)threads > n_tasks) threads = (int)n_tasks;
     std::atomic<size_t> next{0};
+    std::atomic<uint64_t> n_rec{0}, busy_us{0};
     auto worker = [&]() {
+        const auto w0 = std::chrono::steady_clock::now();
+        uint64_t my_rec = 0;
+        struct Tally { std::atomic<uint64_t> &n, &us; uint64_t &mine; std::chrono::steady_clock::time_point t0;
+                       ~Tally() { n += mine; us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } }
+            tally{n_rec, busy_us, my_rec, w0};
         AlnReader rd;
         std::string e2;
         if (!rd.open(path, &e2)) { eng->fail(e2); return; }
@@ -184,6 +197,7 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
                 const int k = rd.next(&r);
                 if (k == 0) break;
                 if (k < 0) { eng->fail(rd.error() + " (" + path + ")"); return; }
+                ++my_rec;
                 if (!flt.pass(r)) continue;
                 if (!spans.hit(r)) continue;
                 emit_runs(r, &sink);
@@ -196,6 +210,9 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
         for (int i = 0; i < threads; ++i) th.emplace_back(worker);
         for (auto &t : th) t.join();
     }
+    if (getenv("PANDEPTH_TIMING"))
+        fprintf(stderr, "[timing] indexed read: %d threads, %zu ranges, %llu records, thread-seconds %.2f, inflate backend %s\n",
+                threads, n_tasks, (unsigned long long)n_rec.load(), busy_us.load() / 1e6, Inflater::backend());
     return eng->ok();
 }
 
@@ -299,6 +316,7 @@ using namespace pdh;
 
 extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, int device)
 {
+    PhaseTimer tm;
     Options o;
     const int n_files = parse_options(argc, argv, &o);
     if (n_files == 0) return 0;
@@ -313,6 +331,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     const AlnHeader hdr = first.header();
     if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
 
+    tm.mark("options + header");
     RegionModel rm;
     const bool had_targets = o.mode != 0;
     if (!build_regions(&o, hdr, &rm)) return 1;
@@ -335,6 +354,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     GzWriter OUT;
     if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
 
+    tm.mark("region model");
     Engine eng;
     eng.api = api;
     if (api->create(device, (int32_t)hdr.lens.size(), hdr.lens.data(), &eng.ctx) != 0) {
@@ -344,6 +364,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     }
     struct CtxGuard { Engine *e; ~CtxGuard() { if (e->ctx) e->api->destroy(e->ctx); } } guard{&eng};
 
+    tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
 
@@ -358,6 +379,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             if (!list_mode) r = &first;                              // already positioned after the header
             else if (!rd.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
             wrap18 = true;                                           // PD:4553
+            r->set_threads(o.threads > 1 ? (o.threads > 32 ? 32 : o.threads) : 0);
             if (r->header().sorted_coordinate()) {
                 std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
                 if (!read_sorted_stream(r, o, hdr, rm, &eng)) break;
@@ -371,6 +393,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         std::cerr << "Error: " << eng.err << std::endl;
         return 2;
     }
+    tm.mark("decode + scatter");
     const unsigned wrap_bits = wrap18 ? 18u : 0u;
     const uint32_t min_dep = (uint32_t)o.min_dep;
     bool scanned = false;
@@ -458,6 +481,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
                 for (size_t c = 0; c < g.second.cds.size(); ++c, ++i) { g.second.cover += cov[i]; g.second.depth += sum[i]; }
     }
     std::cout << "INFO: Input data read done" << std::endl;
+    tm.mark("scan + statistics");
 
     OUT.write(header_line);
     if (o.mode == 0) {
@@ -491,5 +515,6 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     }
     OUT.write(footer(SL, SC, SD));
     OUT.close();
+    tm.mark("tables");
     return 0;
 }

@@ -27,7 +27,6 @@ struct pd_ctx {
     std::string err;
 };
 
-static const size_t CAP = 1 << 14;   // small on purpose: exercises slot turnover in the host code
 
 static int o_create(int, int32_t n, const uint32_t *len, pd_ctx **out)
 {
@@ -43,8 +42,7 @@ static int o_create(int, int32_t n, const uint32_t *len, pd_ctx **out)
 }
 static int o_destroy(pd_ctx *c) { delete c; return 0; }
 static const char *o_strerror(const pd_ctx *c) { return c ? c->err.c_str() : "oracle engine"; }
-static int o_acquire(pd_ctx *, pd_iv **b, size_t *cap) { *b = (pd_iv *)malloc(CAP * sizeof(pd_iv)); *cap = CAP; return 0; }
-static int o_submit(pd_ctx *c, pd_iv *b, size_t n, unsigned flags)
+static int o_push(pd_ctx *c, const pd_iv *b, size_t n, unsigned flags)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = 0;
@@ -72,7 +70,6 @@ static int o_submit(pd_ctx *c, pd_iv *b, size_t n, unsigned flags)
         }
         pdo_add_intervals((int64_t)iv.size() / 3, iv.data(), c->depth.data(), c->off.data());
     }
-    free(b);
     return rc;
 }
 static int o_scan(pd_ctx *c, unsigned wrap)
@@ -128,7 +125,7 @@ static int o_sync(pd_ctx *) { return 0; }
 
 int main(int argc, char **argv)
 {
-    static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_acquire, o_submit, o_scan, o_reduce_intervals,
+    static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
                                       o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync};
     return pandepth_main(argc, argv, &api, 0);
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""tools/e2e_bench.py — END-TO-END wall clock of the CLI on a generated BAM (GPU box): host BAM
+decode + PCIe + kernels + table writer, next to the reference binary on the same file, with a
+byte comparison of the outputs.  Numbers from here go to DESIGN.md (they are NOT bench.py's value)."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import synth  # noqa: E402
+
+
+def main():
+    R = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(5e7)
+    modes = sys.argv[2:] or ["chr"]
+    ncpu = os.cpu_count()
+    names, lens = synth.genome_c2(scale=R / 1e9)
+    t0 = time.perf_counter()
+    rec = synth.gen_records_numpy(lens, R, seed=99)
+    td = tempfile.mkdtemp(prefix="pde2e", dir="/tmp")
+    bam = os.path.join(td, "s.bam")
+    synth.write_bam(bam, names, lens, rec, procs=min(96, ncpu), level=1, payload=True)
+    t1 = time.perf_counter()
+    subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
+    t2 = time.perf_counter()
+    print("records %d genome %.1f Mb bam %.2f GB  (generate %.1f s, index %.1f s)" % (
+        R, lens.sum() / 1e6, os.path.getsize(bam) / 1e9, t1 - t0, t2 - t1), flush=True)
+    ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+    cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
+    extra = {"chr": [], "w100": ["-w", "100"], "w1000": ["-w", "1000"], "s": ["-s"]}
+    for mode in modes:
+        suffix = "chr.stat.gz" if mode in ("chr", "s") else "win.stat.gz"
+        for t in ([8, 32, 64, 128] if mode == "chr" else [64]):
+            if t == 32 or mode != "chr":
+                subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)] + extra[mode],
+                               check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1"))
+            best = 1e9
+            for _ in range(2):
+                a = time.perf_counter()
+                subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)] + extra[mode],
+                               check=True, stdout=subprocess.DEVNULL)
+                best = min(best, time.perf_counter() - a)
+            print("pandepth(MI355X) %-6s -t %-3d  %.2f s  %.3e records/s" % (mode, t, best, R / best), flush=True)
+        if os.access(ref, os.X_OK):
+            best = 1e9
+            for _ in range(2):
+                a = time.perf_counter()
+                subprocess.run([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", "36"] + extra[mode], check=True,
+                               stdout=subprocess.DEVNULL)
+                best = min(best, time.perf_counter() - a)
+            print("pandepth_ref(CPU)  %-6s -t 36   %.2f s  %.3e records/s" % (mode, best, R / best), flush=True)
+            same = open(os.path.join(td, "mine." + suffix), "rb").read() == open(os.path.join(td, "ref." + suffix), "rb").read()
+            print("outputs byte-identical: %s" % same, flush=True)
+
+
+if __name__ == "__main__":
+    main()

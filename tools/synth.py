@@ -190,6 +190,94 @@ _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000
 _BODY = None      # set before the fork so that pool workers see the byte stream without pickling it
 
 
+def _bam_header_bytes(names, lens, sorted_header):
+    text = "@HD\tVN:1.6\tSO:%s\n" % ("coordinate" if sorted_header else "unsorted")
+    text += "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, ln) for nm, ln in zip(names, lens))
+    tb = text.encode()
+    hdr = b"BAM\x01" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(names))
+    for nm, ln in zip(names, lens):
+        nb = nm.encode() + b"\0"
+        hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(ln))
+    return hdr
+
+
+_PAY = None
+
+
+def _payload_chunk(args):
+    """records [lo, hi) with SEQ/QUAL payload -> BGZF bytes (whole records per chunk)."""
+    lo, hi, level, seed = args
+    tid, pos, kind, a, x, flags, mapq = _PAY
+    n = hi - lo
+    sl = slice(lo, hi)
+    k, aa, xx = kind[sl], a[sl], x[sl]
+    M, I, D, N, S = 0, 1, 2, 3, 4
+    ncig = np.where(k == 0, 1, np.where(k == 3, 2, 3)).astype(np.int64)
+    c0 = np.where(k == 0, (READ_LEN << 4) | M, np.where(k == 3, (xx << 4) | S, (aa << 4) | M)).astype(np.uint32)
+    op1 = np.select([k == 1, k == 2, k == 4], [D, I, N], 0)
+    c1 = np.where(k == 3, ((READ_LEN - xx) << 4) | M, (xx << 4) | op1).astype(np.uint32)
+    c2 = np.where(k == 2, ((READ_LEN - aa - xx) << 4) | M, ((READ_LEN - aa) << 4) | M).astype(np.uint32)
+    span = np.where(k == 0, READ_LEN, np.where(k == 3, READ_LEN - xx, np.where(k == 2, READ_LEN - xx, READ_LEN + xx))).astype(np.int64)
+    p64 = pos[sl].astype(np.int64)
+    SEQB, QB = (READ_LEN + 1) // 2, READ_LEN
+    fixed = 36 + 2                      # block_size + 32 + "r\0"
+    width = fixed + 12 + SEQB + QB
+    mat = np.zeros((n, width), dtype=np.uint8)
+    head = np.zeros(n, dtype=np.dtype([("bs", "<i4"), ("tid", "<i4"), ("pos", "<i4"), ("lrn", "u1"), ("mq", "u1"),
+                                       ("bin", "<u2"), ("nc", "<u2"), ("flag", "<u2"), ("lseq", "<i4"),
+                                       ("mtid", "<i4"), ("mpos", "<i4"), ("tlen", "<i4"), ("name", "S2")]))
+    head["bs"] = (34 + 4 * ncig + SEQB + QB).astype(np.int32)
+    head["tid"], head["pos"], head["lrn"], head["mq"] = tid[sl], pos[sl], 2, mapq[sl]
+    head["bin"] = _reg2bin(p64, p64 + span)
+    head["nc"], head["flag"], head["lseq"], head["mtid"], head["mpos"] = ncig, flags[sl], READ_LEN, -1, -1
+    head["name"] = b"r"
+    mat[:, :fixed] = head.view(np.uint8).reshape(n, fixed)
+    rng = np.random.default_rng(seed)
+    seq = rng.integers(0, 4, (n, SEQB * 2), dtype=np.uint8)
+    nib = np.array([1, 2, 4, 8], dtype=np.uint8)[seq]
+    seqb = (nib[:, 0::2] << 4) | nib[:, 1::2]
+    qual = np.array([37, 37, 37, 37, 37, 37, 25, 25, 11, 2], dtype=np.uint8)[rng.integers(0, 10, (n, QB))]
+    # variable part: cigar (4*ncig) then seq then qual, left-aligned after the fixed head
+    cig = np.stack([c0, c1, c2], axis=1).view(np.uint8).reshape(n, 12)
+    body = np.concatenate([cig, seqb, qual], axis=1)                  # (n, 12+SEQB+QB), cigar padded to 3 ops
+    # drop the unused cigar slots row-wise with a mask
+    col = np.arange(12 + SEQB + QB)[None, :]
+    keep = (col < (4 * ncig)[:, None]) | (col >= 12)
+    mat[:, fixed:] = body
+    full_keep = np.concatenate([np.ones((n, fixed), dtype=bool), keep], axis=1)
+    data = mat[full_keep]
+    blocks = []
+    for o in range(0, data.size, 65280):
+        blocks.append(_bgzf_block(data[o:o + 65280].tobytes(), level))
+    return b"".join(blocks)
+
+
+def _write_bam_payload(path, names, lens, rec, flags, mapq, sorted_header, level, procs):
+    global _PAY
+    tid, pos, kind, a, x = (np.asarray(rec[k]) for k in ("tid", "pos", "kind", "a", "x"))
+    n = tid.size
+    flags = np.zeros(n, dtype=np.uint16) if flags is None else np.asarray(flags, dtype=np.uint16)
+    mapq = np.full(n, 60, dtype=np.uint8) if mapq is None else np.asarray(mapq, dtype=np.uint8)
+    _PAY = (tid, pos, kind, a, x, flags, mapq)
+    hdr = _bam_header_bytes(names, lens, sorted_header)
+    step = 200000
+    tasks = [(o, min(o + step, n), level, 1000 + o // step) for o in range(0, n, step)]
+    with open(path, "wb") as f:
+        for o in range(0, len(hdr), 65280):
+            f.write(_bgzf_block(hdr[o:o + 65280], level))
+        if procs > 1 and len(tasks) > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(procs) as pool:
+                for chunk in pool.imap(_payload_chunk, tasks):
+                    f.write(chunk)
+        else:
+            for t in tasks:
+                f.write(_payload_chunk(t))
+        f.write(_BGZF_EOF)
+    _PAY = None
+    return n
+
+
 def _compress_range(args):
     lo, hi, level = args
     buf = _BODY
@@ -199,9 +287,13 @@ def _compress_range(args):
     return b"".join(out)
 
 
-def write_bam(path, names, lens, rec, flags=None, mapq=None, sorted_header=True, level=1, procs=8):
-    """Writes records (dict from gen_records_numpy) as a BAM with '*' SEQ/QUAL.  Returns the
-    number of records.  flags/mapq: optional per-record arrays (default 0 / 60)."""
+def write_bam(path, names, lens, rec, flags=None, mapq=None, sorted_header=True, level=1, procs=8, payload=False):
+    """Writes records (dict from gen_records_numpy) as a BAM.  Returns the number of records.
+    flags/mapq: optional per-record arrays (default 0 / 60).  payload=False: '*' SEQ/QUAL (tiny
+    files); payload=True: 150 random bases + 4-level binned qualities per record, so that the
+    compressed size per record (~100 B) and the inflate cost resemble a real short-read BAM."""
+    if payload:
+        return _write_bam_payload(path, names, lens, rec, flags, mapq, sorted_header, level, procs)
     tid, pos, kind, a, x = (np.asarray(rec[k]) for k in ("tid", "pos", "kind", "a", "x"))
     n = tid.size
     flags = np.zeros(n, dtype=np.uint16) if flags is None else np.asarray(flags, dtype=np.uint16)
