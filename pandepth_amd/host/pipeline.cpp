@@ -87,15 +87,17 @@ public:
     }
     void flush() { flush_sorted(); flush_other(); }
 private:
+    // PANDEPTH_DECODE_ONLY=1 (diagnostics): decode and expand, but drop the batches
+    const bool drop_ = getenv("PANDEPTH_DECODE_ONLY") != nullptr;
     void flush_sorted()
     {
-        if (!s_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, s_.data(), s_.size(), PD_PUSH_SORTED), "pd_push_intervals");
+        if (!drop_ && !s_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, s_.data(), s_.size(), PD_PUSH_SORTED), "pd_push_intervals");
         s_.clear(); s_last_ = 0;
     }
     void flush_other()
     {
         const unsigned f = o_dis_ <= (1u << 20) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
-        if (!o_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, o_.data(), o_.size(), f), "pd_push_intervals");
+        if (!drop_ && !o_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, o_.data(), o_.size(), f), "pd_push_intervals");
         o_.clear(); o_max_ = 0; o_dis_ = 0;
     }
     Engine *e_;

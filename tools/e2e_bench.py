@@ -31,10 +31,15 @@ def main():
     ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
     cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
     extra = {"chr": [], "w100": ["-w", "100"], "w1000": ["-w", "1000"], "s": ["-s"]}
+    if os.environ.get("E2E_DECODE_ONLY"):
+        for t in (8, 16, 32, 64, 128):
+            subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)], check=True,
+                           stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_DECODE_ONLY="1"))
+        return
     for mode in modes:
         suffix = "chr.stat.gz" if mode in ("chr", "s") else "win.stat.gz"
         for t in ([8, 32, 64, 128] if mode == "chr" else [64]):
-            if t == 32 or mode != "chr":
+            if True:
                 subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)] + extra[mode],
                                check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1"))
             best = 1e9
