@@ -41,12 +41,6 @@ B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write)
 B_SWEEP_FUSED_PER_BASE = 4
 
 
-class _DevBuf:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False),
-                                         "version": 3}
-
-
 def cpu_baseline(sample_records, log):
     """Times the reference's own CPU path (oracle/_ref/pandepth_ref, built from /root/reference in
     the dev container) on the host cores, on a bounded sample of the same workload; falls back
@@ -99,6 +93,7 @@ def main():
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pandepth_amd as pda
+    from pandepth_amd import multi
     from tools import synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,8 +113,8 @@ def main():
     first, other = synth.gen_runs_torch(lens, R, dev, seed=42 + rank)
     torch.cuda.synchronize()
     n_first, n_other = int(first.shape[0]), int(other.shape[0])
-    ptr, n_words, _ = eng.device_buffer()
-    buf = torch.as_tensor(_DevBuf(ptr, n_words), device=dev) if world > 1 else None
+    _, n_words, _ = eng.device_buffer()
+    buf = multi.buffer_view(eng, dev) if world > 1 else None
     wrap = 18 if world > 1 else 0        # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
 
     def step():
@@ -127,10 +122,10 @@ def main():
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
         if world > 1:
-            eng.synchronize()
-            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+            eng.synchronize()                      # the engine's stream is not torch's: order by host sync
+            is_root = multi.sum_to_root(buf, 0)
             torch.cuda.synchronize()
-            if rank != 0:
+            if not is_root:
                 return None
         return eng.scan_reduce_windows(BIN, 1, wrap)
 

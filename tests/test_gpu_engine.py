@@ -247,3 +247,25 @@ def test_profile_counters():
         assert n == 1 and ms > 0
         ms, n = e.profile_get("scatter_tiles")
         assert n == 1 and ms > 0
+
+
+def test_buffer_view_is_zero_copy_and_linear():
+    """The multi-BAM path sums accumulating buffers with a collective on a torch view of the engine's
+    memory: adding one engine's buffer into another's must equal pushing both samples into one."""
+    import torch
+    from pandepth_amd import multi
+    rng = np.random.default_rng(12)
+    a = sort_iv(rand_intervals(rng, LENS, 60000))
+    b = rand_intervals(rng, LENS, 60000)
+    d, off = oracle_depth(LENS, np.concatenate([a, b]), True)
+    with pda.Engine(LENS) as e1, pda.Engine(LENS) as e2:
+        e1.push_intervals(a, pda.PD_PUSH_SORTED)
+        e2.push_intervals(b)
+        e1.synchronize(); e2.synchronize()
+        v1 = multi.buffer_view(e1, torch.device("cuda", 0))
+        v2 = multi.buffer_view(e2, torch.device("cuda", 0))
+        assert v1.dtype == torch.int32 and v1.numel() == e1.device_buffer()[1]
+        v1 += v2                                    # what dist.reduce(SUM) does across ranks
+        torch.cuda.synchronize()
+        e1.scan(18)
+        check_depth(e1, LENS, d, off)
