@@ -4,10 +4,12 @@
 A "step" is ONE whole pass of the hot path over one sample's run stream, whole-chromosome mode
 (configs[1]: 3 Gb reference, 50x short-read BAM = 10^9 alignment records of 150 bp):
 
-    pd_reset                      zero the 3.0e9-cell difference arrays            (fill kernel)
+    pd_reset                      forget the 3.0e9 cells (per-half-tile "written" flags + tile sums; no fill:
+                                  unwritten cells count as zero until the scatter stores into them)
     pd_push_intervals_device x2   +1/-1 scatter of all runs through the owner-tile kernel: the sorted
-                                  first-run stream, then the ~11 % second runs of D/I/N reads, which are
-                                  only nearly sorted (declared with PD_PUSH_DISORDER(max read span))
+                                  first-run stream (PD_PUSH_MORE) and the ~11 % second runs of D/I/N reads,
+                                  which are only nearly sorted (PD_PUSH_DISORDER(max read span)), served by
+                                  the same passes over the tiles
     [N > 1]                       RCCL sum-reduce of the difference arrays + tile sums to rank 0
     pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
                                   reduction, results copied back to the host
@@ -41,6 +43,17 @@ B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write)
 B_SWEEP_FUSED_PER_BASE = 4
 
 
+def cpu_quota():
+    """CPUs the cgroup lets this job use (the GPU boxes cap the container below nproc)."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(sample_records, log):
     """Times the reference's own CPU path (oracle/_ref/pandepth_ref, built from /root/reference in
     the dev container) on the host cores, on a bounded sample of the same workload; falls back
@@ -66,8 +79,10 @@ def cpu_baseline(sample_records, log):
                 subprocess.run([ref, "-i", bam, "-o", os.path.join(td, "o"), "-t", str(threads)], check=True,
                                stdout=subprocess.DEVNULL)
                 best = time.perf_counter() - t0
-            return {"value": sample_records / best, "unit": "records/s", "cores": threads, "kind": "reference",
-                    "sample": sample + "; pandepth_ref -t %d (BAM+BAI, warm cache, %.2f s)" % (threads, best)}
+            return {"value": sample_records / best, "unit": "records/s", "cores": min(threads, cpu_quota()),
+                    "kind": "reference",
+                    "sample": sample + "; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads), cgroup "
+                              "quota %d CPUs, BAM+BAI, warm cache, %.2f s" % (threads, cpu_quota(), best)}
     import pd_oracle as O
     first, other = synth.records_to_runs(rec)
     runs = np.concatenate([first, other])
@@ -119,7 +134,7 @@ def main():
 
     def step():
         eng.reset()
-        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED)
+        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
         if world > 1:
             eng.synchronize()                      # the engine's stream is not torch's: order by host sync
@@ -151,7 +166,7 @@ def main():
         dt = float(tmax.item())
 
     prof = {}
-    for k in ("fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
+    for k in ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
               "scan_reduce_windows"):
         ms, n = eng.profile_get(k)
         prof[k] = (ms, n)
@@ -175,9 +190,8 @@ def main():
 
         launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
         kernels = {
-            "fill": k_entry("fill", n_words * B_FILL_PER_CELL),
+            "fill": k_entry("fill", n_words * B_FILL_PER_CELL),      # only when zeros must be materialised (N > 1)
             "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
-            "scatter_atomic": k_entry("scatter_atomic", 0),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
         }
         dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])

@@ -67,6 +67,11 @@ typedef struct pd_region { int32_t tid, first, second; } pd_region;
  * start relative to any EARLIER run of the batch (beg_j >= beg_i - D for i < j, same contig
  * order).  The owner tiles then widen their candidate search by D; results stay exact. */
 #define PD_PUSH_DISORDER(cells) ((((unsigned)(cells) + 255u) / 256u) << 8)
+/* With PD_PUSH_SORTED: another sorted batch covering the SAME genome range follows at once (a
+ * sample's first-run stream and its second-run stream); the engine defers the owner-tile pass
+ * and serves up to 4 such batches in one pass over the tiles.  The batch memory must stay valid
+ * until the next call without PD_PUSH_MORE (or pd_scan* / pd_synchronize) returns. */
+#define PD_PUSH_MORE    2u
 
 /* Context: replaces `new SiteInfo[len+500]` per contig + zero loop (PD:4129-4145,
  * PD:4553-4581, PD:2687-2699) and `new unsigned int[window]` (PD:715-721).  Allocates ONE
@@ -77,7 +82,9 @@ int pd_destroy(pd_ctx *ctx);
 const char *pd_strerror(const pd_ctx *ctx);      /* ctx may be NULL: last pd_create failure */
 int pd_abi_version(void);
 
-/* Zero the arrays again and return to the accumulating state (a new sample / a new step). */
+/* Forget every cell and return to the accumulating state (a new sample / a new step).  Nothing is
+ * filled: cells count as zero until first written (the owner-tile kernel stores into them, the
+ * sweep skips them); pd_device_buffer and the atomic path materialise the zeros on demand. */
 int pd_reset(pd_ctx *ctx);
 
 /* Replaces the increment loop PD:449-452: +1 at beg, -1 at end in the difference arrays.
@@ -134,7 +141,7 @@ int pd_synchronize(pd_ctx *ctx);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch.
  * pd_profile_get returns the accumulated milliseconds and launch count of kernel `name`
- * ("fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
+ * ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
  * "scan", "scan_reduce_windows", "reduce_intervals", "reduce_windows"); pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);

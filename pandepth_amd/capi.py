@@ -11,6 +11,7 @@ import numpy as np
 
 PD_PUSH_DEFAULT = 0
 PD_PUSH_SORTED = 1
+PD_PUSH_MORE = 2
 
 
 def PD_PUSH_DISORDER(cells):

@@ -21,7 +21,8 @@ namespace {
 
 constexpr int N_STAGE = 1024;                        // upper bound; slots are created on demand
 constexpr size_t STAGE_CAP = (size_t)1 << 18;        // runs per staging slot (3 MiB pinned + 3 MiB HBM)
-constexpr size_t DEV_BATCH_MAX = (size_t)256 << 20;  // runs per sorted device sub-batch (32-bit indices)
+constexpr size_t DEV_BATCH_MAX = 0xFFFFFF00ull;       // runs per sorted batch (32-bit run indices)
+constexpr uint64_t OVF_MAX = (uint64_t)64 << 20;     // overflow-list entries (ends of runs longer than lmax) per tile pass
 constexpr uint32_t LMAX_DEFAULT = 512;               // look-back bound for owner tiles (cells)
 constexpr uint32_t SAMPLE_DEFAULT = 64;              // sparse index stride (runs)
 
@@ -36,6 +37,8 @@ struct Stage {
 
 struct ProfRec { std::string name; hipEvent_t a, b; };
 
+struct Pending { const pd_iv *iv; uint32_t n; uint32_t disorder; int slot; };   // slot: staging slot or -1
+
 } // namespace
 
 struct pd_ctx {
@@ -46,17 +49,21 @@ struct pd_ctx {
     std::vector<uint64_t> off;                       // first cell of each slot
     uint64_t n_cells = 0, n_tiles = 0, n_words = 0;
     int *buf = nullptr;                              // [n_cells diff | n_tiles sums | pad]
-    int *sums = nullptr, *carry = nullptr;
+    int *sums = nullptr, *carry = nullptr, *bsum = nullptr;
     uint64_t *d_off = nullptr; uint32_t *d_len = nullptr; uint32_t *d_tile_contig = nullptr;
-    uint32_t *ub_a = nullptr, *cand_lo = nullptr;
-    BatchDesc *desc = nullptr; CheckWords *chk = nullptr;
+    uint32_t *ub_a[PD_MAXPEND] = {}, *cand_lo[PD_MAXPEND] = {};   // per pending batch, indexed by 4096-cell tile
+    BatchDesc *desc = nullptr; CheckWords *chk = nullptr;         // desc: PD_MAXPEND entries
+    uint8_t *hstate = nullptr; uint32_t n_half = 0;               // "written since reset" per 4096 cells
+    bool all_valid_host = false;
+    std::vector<Pending> pend;
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int state = 0;                                   // 0 accumulating (diff), 1 depth
     uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
-    unsigned grid_tiles = 2048; int stile = 4096; int n_cu = 256;
+    unsigned grid_tiles = 0;                         // 0 = sized per pass from the number of runs
+    int stile = 8192; int n_cu = 256;
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -127,40 +134,107 @@ int ensure_scratch(pd_ctx *c, size_t bytes)
     return PD_OK;
 }
 
-int do_fill(pd_ctx *c)
+// Reset = forget every cell: mark all half-tiles "not written" (the owner-tile kernel stores into
+// them without reading, the sweep reads them as zeros) and zero the tile sums.  No 12 GB fill.
+int do_reset(pd_ctx *c)
 {
-    ProfScope ps(c, "fill");
-    launch_fill(c->stream, c->buf, c->n_words * 4);
+    ProfScope ps(c, "reset");
+    HIPOK(c, hipMemsetAsync(c->hstate, 0, c->n_half, c->stream));
+    HIPOK(c, hipMemsetAsync(c->sums, 0, (c->n_words - c->n_cells) * 4, c->stream));
     HIPOK(c, hipMemsetAsync(c->chk, 0, sizeof(CheckWords), c->stream));
-    HIPOK(c, hipMemsetAsync(c->desc, 0, sizeof(BatchDesc), c->stream));
+    HIPOK(c, hipMemsetAsync(c->desc, 0, sizeof(BatchDesc) * PD_MAXPEND, c->stream));
+    c->all_valid_host = false;
     return PD_OK;
 }
 
-// scatter a device-resident batch on the compute stream
-int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags)
+// every cell readable/atomically addable: zero-fill what has not been written since the reset
+int ensure_all_valid(pd_ctx *c)
 {
+    if (c->all_valid_host) return PD_OK;
+    ProfScope ps(c, "fill");
+    launch_fill_invalid(c->stream, c->buf, c->hstate, c->n_half, c->chk, false, (unsigned)c->n_cu * 8);
+    HIPOK(c, hipGetLastError());
+    c->all_valid_host = true;
+    return PD_OK;
+}
+
+// one owner-tile pass over all pending sorted batches
+int flush_pending(pd_ctx *c)
+{
+    if (c->pend.empty()) return PD_OK;
+    uint64_t total = 0;
+    for (auto &p : c->pend) total += p.n;
+    if (total > OVF_MAX) total = OVF_MAX;     // more long runs than this in ONE pass is reported (err bit 4):
+                                              // such data belongs on the PD_PUSH_DEFAULT path
+    if (total > c->ovf_cap) {
+        if (c->ovf) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->ovf)); c->ovf = nullptr; c->ovf_cap = 0; }
+        const uint64_t cap = total;
+        if (hipMalloc(&c->ovf, (size_t)cap * 8) != hipSuccess) return fail(c, PD_ENOMEM, "overflow list allocation failed");
+        c->ovf_cap = (uint32_t)cap;
+    }
+    const uint32_t n_stiles = (uint32_t)(c->n_cells / c->stile);
+    PendSet ps{};
+    ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
+    for (int b = 0; b < ps.nb; ++b) {
+        const Pending &p = c->pend[b];
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
+        ProfScope sc(c, "scatter_index");
+        launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample, c->ub_a[b], c->cand_lo[b],
+                             n_stiles, c->stile, c->desc + b);
+    }
+    // Grid of the tile pass: measured best is ~64 K workgroups for a whole-genome pass (each walks a
+    // handful of tiles; the hardware overlaps their load/flush phases); small streaming batches
+    // touch few tiles and get a proportionally smaller grid.
+    unsigned grid = c->grid_tiles;
+    if (!grid) {
+        uint64_t all = 0;
+        for (auto &p : c->pend) all += p.n;
+        uint64_t g = all / 256;
+        if (g < (uint64_t)c->n_cu * 4) g = (uint64_t)c->n_cu * 4;
+        if (g > 65536) g = 65536;
+        grid = (unsigned)g;
+    }
+    { ProfScope sc(c, "scatter_tiles");
+      launch_scatter_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, n_stiles, c->stile, c->buf, c->sums, c->hstate,
+                           c->ovf, c->ovf_cap, c->chk, grid); }
+    { ProfScope sc(c, "scatter_finish");
+      if (!c->all_valid_host) launch_fill_invalid(c->stream, c->buf, c->hstate, c->n_half, c->chk, true, (unsigned)c->n_cu * 8);
+      launch_scatter_finish(c->stream, ps, c->buf, c->sums, c->ovf, c->ovf_cap, c->chk); }
+    HIPOK(c, hipGetLastError());
+    for (auto &p : c->pend)
+        if (p.slot >= 0) {
+            Stage &st = c->stage[p.slot];
+            HIPOK(c, hipEventRecord(st.done, c->stream));
+            st.state = 2; st.seq = ++c->seq;
+        }
+    c->pend.clear();
+    return PD_OK;
+}
+
+// scatter a device-resident batch on the compute stream; *deferred = true when a staged slot must
+// stay in flight until flush_pending records its event
+int scatter_device(pd_ctx *c, const pd_iv *d, size_t n, unsigned flags, int slot, bool *deferred)
+{
+    if (deferred) *deferred = false;
     if (n == 0) return PD_OK;
     if (flags & PD_PUSH_SORTED) {
         const uint64_t dis64 = (uint64_t)(flags >> 8) * 256u;
         const uint32_t disorder = dis64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)dis64;
         for (size_t o = 0; o < n; o += DEV_BATCH_MAX) {
             const uint32_t m = (uint32_t)(n - o < DEV_BATCH_MAX ? n - o : DEV_BATCH_MAX);
-            if (m > c->ovf_cap) {               // worst case: every run is longer than lmax
-                if (c->ovf) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->ovf)); c->ovf = nullptr; c->ovf_cap = 0; }
-                if (hipMalloc(&c->ovf, (size_t)m * 8) != hipSuccess) return fail(c, PD_ENOMEM, "overflow list allocation failed");
-                c->ovf_cap = m;
+            const bool last = o + m >= n;
+            c->pend.push_back(Pending{d + o, m, disorder, last ? slot : -1});
+            if (c->pend.size() == PD_MAXPEND || !(last && (flags & PD_PUSH_MORE))) {
+                int rc = flush_pending(c);
+                if (rc) return rc;
             }
-            { ProfScope ps(c, "scatter_index");
-              launch_scatter_index(c->stream, d + o, m, tab_of(c), c->lmax, disorder, c->sample, c->ub_a, c->cand_lo,
-                                   (uint32_t)(c->n_cells / c->stile), c->stile, c->desc); }
-            { ProfScope ps(c, "scatter_tiles");
-              launch_scatter_tiles(c->stream, d + o, m, tab_of(c), c->lmax, c->ub_a, c->cand_lo, c->d_tile_contig,
-                                   (uint32_t)(c->n_cells / c->stile), c->stile, c->desc,
-                                   c->buf, c->sums, c->ovf, c->ovf_cap, c->grid_tiles); }
-            { ProfScope ps(c, "scatter_finish");
-              launch_scatter_finish(c->stream, m, c->desc, c->buf, c->sums, c->ovf, c->ovf_cap, c->chk); }
         }
+        if (deferred) *deferred = !c->pend.empty();
     } else {
+        int rc = flush_pending(c);
+        if (rc) return rc;
+        rc = ensure_all_valid(c);
+        if (rc) return rc;
         ProfScope ps(c, "scatter_atomic");
         launch_scatter_atomic(c->stream, d, n, tab_of(c), c->buf, c->sums);
     }
@@ -174,9 +248,9 @@ int check_words(pd_ctx *c)
     HIPOK(c, hipMemcpyAsync(&h, c->chk, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     if (h.unsorted_batches || h.err) {
-        char m[160];
-        snprintf(m, sizeof m, "%llu batch(es) pushed with PD_PUSH_SORTED were not sorted by (tid,beg) or held "
-                 "invalid contig ids (err bits 0x%x); depth arrays are not valid",
+        char m[256];
+        snprintf(m, sizeof m, "%llu batch(es) pushed with PD_PUSH_SORTED were not sorted by (tid,beg), held invalid "
+                 "contig ids or too many runs longer than lmax (err bits 0x%x); depth arrays are not valid",
                  (unsigned long long)h.unsorted_batches, h.err);
         return fail(c, PD_EINVAL, m);
     }
@@ -207,7 +281,10 @@ int stage_acquire(pd_ctx *c, int *slot)
             *slot = (int)c->stage.size() - 1;
             return PD_OK;
         }
-        if (oldest < 0) return fail(c, PD_ESTATE, "all staging slots are held by callers");
+        if (oldest < 0) {
+            if (!c->pend.empty()) { int rc = flush_pending(c); if (rc) return rc; continue; }
+            return fail(c, PD_ESTATE, "all staging slots are held by callers");
+        }
         HIPOK(c, hipEventSynchronize(c->stage[oldest].done));
         c->stage[oldest].state = 0;
     }
@@ -220,10 +297,12 @@ int stage_submit(pd_ctx *c, int slot, size_t n, unsigned flags)
     HIPOK(c, hipMemcpyAsync(s.dev, s.host, n * sizeof(pd_iv), hipMemcpyHostToDevice, c->copy_stream));
     HIPOK(c, hipEventRecord(s.copied, c->copy_stream));
     HIPOK(c, hipStreamWaitEvent(c->stream, s.copied, 0));
-    int rc = scatter_device(c, s.dev, n, flags);
+    bool deferred = false;
+    int rc = scatter_device(c, s.dev, n, flags, slot, &deferred);
     if (rc) return rc;
-    HIPOK(c, hipEventRecord(s.done, c->stream));
-    s.state = 2; s.seq = ++c->seq;
+    Stage &s2 = c->stage[slot];               // (the vector may not have grown, but stay safe)
+    if (deferred) { s2.state = 3; return PD_OK; }          // event recorded by flush_pending
+    if (s2.state != 2) { HIPOK(c, hipEventRecord(s2.done, c->stream)); s2.state = 2; s2.seq = ++c->seq; }
     return PD_OK;
 }
 
@@ -265,7 +344,6 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     if (c->n_tiles >= 0xFFFFFFF0ull) { delete c; return fail(nullptr, PD_EINVAL, "pd_create: genome too large"); }
     c->n_words = c->n_cells + (c->n_tiles + 3) / 4 * 4;
     c->n_cu = pr.multiProcessorCount;
-    c->grid_tiles = (unsigned)c->n_cu * 8;       // 16 KiB of LDS per workgroup -> 8 resident per CU
 
 #define CREATE_OK(call)                                                                                  \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                                 \
@@ -277,12 +355,17 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     CREATE_OK(hipMalloc(&c->buf, c->n_words * 4));
     c->sums = c->buf + c->n_cells;
     CREATE_OK(hipMalloc(&c->carry, (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->bsum, (c->n_tiles / 1024 + 4) * 4));
     CREATE_OK(hipMalloc(&c->d_off, ((size_t)n_contigs + 1) * 8));
     CREATE_OK(hipMalloc(&c->d_len, (size_t)n_contigs * 4));
     CREATE_OK(hipMalloc(&c->d_tile_contig, (c->n_tiles + 1) * 4));
-    CREATE_OK(hipMalloc(&c->ub_a, (c->n_tiles * 2 + 4) * 4));      // indexed by 4096-cell scatter tile
-    CREATE_OK(hipMalloc(&c->cand_lo, (c->n_tiles * 2 + 4) * 4));
-    CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc)));
+    for (int b = 0; b < PD_MAXPEND; ++b) {
+        CREATE_OK(hipMalloc(&c->ub_a[b], (c->n_tiles * 2 + 4) * 4));      // indexed by 4096-cell scatter tile
+        CREATE_OK(hipMalloc(&c->cand_lo[b], (c->n_tiles * 2 + 4) * 4));
+    }
+    c->n_half = (uint32_t)(c->n_cells / PD_HALF);
+    CREATE_OK(hipMalloc(&c->hstate, c->n_half + 16));
+    CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc) * PD_MAXPEND));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
     {
         std::vector<uint32_t> tc(c->n_tiles + 1, 0);
@@ -293,7 +376,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
         CREATE_OK(hipMemcpy(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice));
     }
 #undef CREATE_OK
-    int rc = do_fill(c);
+    int rc = do_reset(c);
     if (rc == PD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PD_EHIP;
     if (rc != PD_OK) { g_create_err = c->err; pd_destroy(c); return rc; }
     *out = c;
@@ -314,7 +397,8 @@ int pd_destroy(pd_ctx *c)
     }
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    void *ptrs[] = {c->buf, c->carry, c->d_off, c->d_len, c->d_tile_contig, c->ub_a, c->cand_lo, c->desc, c->chk, c->ovf, c->scratch};
+    void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
+                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->desc, c->chk, c->ovf, c->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -327,8 +411,10 @@ int pd_reset(pd_ctx *c)
     if (!c) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc) return rc;
     c->state = 0;
-    return do_fill(c);
+    return do_reset(c);
 }
 
 int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
@@ -339,9 +425,9 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "sample must be in [1, 65536]"); c->sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "scatter_tile")) {
         if (value != 4096 && value != 8192) return fail(c, PD_EINVAL, "scatter_tile must be 4096 or 8192");
-        c->stile = (int)value; c->grid_tiles = (unsigned)c->n_cu * (value == 4096 ? 8 : 4); return PD_OK;
+        c->stile = (int)value; return PD_OK;
     }
-    if (!strcmp(name, "grid_tiles")) { if (value < 1 || value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
+    if (!strcmp(name, "grid_tiles")) { if (value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
 
@@ -351,7 +437,7 @@ int pd_push_intervals_device(pd_ctx *c, const pd_iv *dev_iv, size_t n, unsigned 
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->state != 0) return fail(c, PD_ESTATE, "pd_push_intervals_device: depth already materialised (call pd_reset)");
     HIPOK(c, hipSetDevice(c->device));
-    return scatter_device(c, dev_iv, n, flags);
+    return scatter_device(c, dev_iv, n, flags, -1, nullptr);
 }
 
 int pd_stage_acquire(pd_ctx *c, pd_iv **host_buf, size_t *capacity)
@@ -408,12 +494,16 @@ int pd_scan(pd_ctx *c, unsigned wrap_bits)
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->state != 0) return fail(c, PD_ESTATE, "pd_scan: already scanned");
     HIPOK(c, hipSetDevice(c->device));
-    int rc = check_words(c);
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    rc = check_words(c);
     if (rc) return rc;
     const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
-    { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->carry, (uint32_t)c->n_tiles); }
-    { ProfScope ps(c, "scan"); launch_scan_write(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask); }
+    { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->bsum, c->carry, (uint32_t)c->n_tiles); }
+    { ProfScope ps(c, "scan"); launch_scan_write(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask, c->hstate); }
     HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemsetAsync(c->hstate, 1, c->n_half, c->stream));     // the sweep wrote every cell
+    c->all_valid_host = true;
     c->state = 1;
     return PD_OK;
 }
@@ -446,12 +536,12 @@ static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
     if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // edge windows are accumulated
-    if (!from_depth) { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->carry, (uint32_t)c->n_tiles); }
+    if (!from_depth) { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->bsum, c->carry, (uint32_t)c->n_tiles); }
     {
         ProfScope ps(c, from_depth ? "reduce_windows" : "scan_reduce_windows");
         TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
         int e = launch_sweep_windows(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask, tm, w, min_dep,
-                                     d_cov, d_sum, d_part, nw, c->n_contigs, from_depth);
+                                     d_cov, d_sum, d_part, nw, c->n_contigs, from_depth, c->hstate);
         if (e) return fail(c, PD_EHIP, "window sweep: cannot reserve LDS");
     }
     HIPOK(c, hipGetLastError());
@@ -467,7 +557,9 @@ int pd_scan_reduce_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, unsigned wra
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->state != 0) return fail(c, PD_ESTATE, "pd_scan_reduce_windows: depth already materialised; use pd_reduce_windows");
     HIPOK(c, hipSetDevice(c->device));
-    int rc = check_words(c);
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    rc = check_words(c);
     if (rc) return rc;
     const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
     return windows_common(c, w, min_dep, mask, false, cover, sum);
@@ -545,6 +637,13 @@ int pd_read_depth(pd_ctx *c, int32_t tid, uint32_t beg, size_t n, uint32_t *out)
 int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off)
 {
     if (!c) return PD_EINVAL;
+    {   // whoever reads the raw buffer must see real zeros, not "not written since reset"
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPOK(c, hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc) return rc;
+        if (c->state == 0) { rc = ensure_all_valid(c); if (rc) return rc; }
+    }
     if (dev_ptr) *dev_ptr = c->buf;
     if (n_words) *n_words = c->n_words;
     if (contig_off) for (int32_t i = 0; i < c->n_contigs; ++i) contig_off[i] = c->off[i];
@@ -558,6 +657,8 @@ int pd_synchronize(pd_ctx *c)
     if (!c) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc) return rc;
     HIPOK(c, hipStreamSynchronize(c->copy_stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return PD_OK;

@@ -22,9 +22,11 @@ struct TileMap {              // device pointers, for the window reduction
     const uint64_t *win_off;       // first output window of each contig
 };
 
+#define PD_CNT_SLOTS 256       /* hashed counters: same-address device atomics serialise at ~12 ns */
 struct BatchDesc {            // written by k_index, consumed by the tile kernels
-    uint64_t handled;         // runs that found the owner tile of their begin
-    uint64_t has, ends;       // runs with cells / ends that found their owner (tile or overflow list)
+    uint64_t handled[PD_CNT_SLOTS];   // runs that found the owner tile of their begin
+    uint64_t has[PD_CNT_SLOTS];       // runs with cells ...
+    uint64_t ends[PD_CNT_SLOTS];      // ... and ends that found their owner (tile or overflow list)
     uint32_t t_first, n_active;
     uint32_t ovf_count;
     uint32_t err;             // 1 invalid tid in a sample, 2 samples out of order, 4 overflow list full
@@ -33,8 +35,21 @@ struct BatchDesc {            // written by k_index, consumed by the tile kernel
 struct CheckWords {           // context-wide, read back at pd_scan / pd_synchronize
     uint64_t unsorted_batches;
     uint32_t err;
+    uint32_t ovf_count;       // entries on the overflow list of the current tile pass
+    uint32_t all_valid;       // every 4096-cell half-tile has been written since the last reset
     uint32_t pad;
 };
+
+#define PD_MAXPEND 4          /* sorted batches merged into one owner-tile pass */
+#define PD_HALF 4096          /* granularity of the "written since reset" flags */
+
+struct PendBatch {            // one sorted batch of a tile pass (device pointers)
+    const pd_iv *iv;
+    const uint32_t *ub_a, *cand_lo;
+    BatchDesc *desc;
+    uint32_t n, pad;
+};
+struct PendSet { PendBatch b[PD_MAXPEND]; int nb; uint32_t lmax; };
 
 struct Piece { uint64_t start; uint32_t count; uint32_t region; };
 struct TilePart { uint32_t c0, c1; unsigned long long s0, s1; };   // a tile's share of windows k0, k0+1
@@ -44,17 +59,20 @@ void launch_scatter_atomic(hipStream_t st, const pd_iv *iv, size_t n, ContigTab 
 void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
                           uint32_t disorder, uint32_t sample, uint32_t *ub_a, uint32_t *cand_lo,
                           uint32_t n_stiles, int stile, BatchDesc *desc);
-void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          const uint32_t *ub_a, const uint32_t *cand_lo, const uint32_t *tile_contig,
-                          uint32_t n_stiles, int stile, BatchDesc *desc,
-                          int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles);
-void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
-                           const uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk);
-void launch_tile_carry(hipStream_t st, const int *sums, int *carry, uint32_t n_tiles);
-void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask);
+void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig,
+                          uint32_t n_stiles, int stile, int *diff, int *sums, uint8_t *hstate,
+                          uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk, unsigned grid_tiles);
+void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,
+                         bool only_if_overflow, unsigned grid);
+void launch_scatter_finish(hipStream_t st, const PendSet &ps, int *diff, int *sums, const uint64_t *ovf,
+                           uint32_t ovf_cap, CheckWords *chk);
+void launch_tile_carry(hipStream_t st, const int *sums, int *bsum, int *carry, uint32_t n_tiles);
+void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
+                       const uint8_t *hstate);
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
-                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth);
+                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth,
+                         const uint8_t *hstate);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
                           uint32_t min_dep, int *cover, unsigned long long *sum);
 

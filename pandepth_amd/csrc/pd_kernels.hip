@@ -156,132 +156,239 @@ __global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint3
     }
 }
 
-// Step 2: owner tiles.  A persistent grid walks the active tiles; each workgroup zeroes a
-// TILE-cell LDS window, pulls every event that lands in ITS tile from the candidate range
-// (LDS atomics), then adds the window into HBM with plain 16-byte loads/stores — no global
-// atomics on the hot path, all-zero 16-byte groups skipped.  Ends of runs longer than LMAX
-// are handed to the overflow list (applied by k_apply_overflow after this kernel).
+// Step 2: owner tiles.  A persistent grid walks the tiles the pending batches touch (up to
+// PD_MAXPEND sorted batches share ONE pass, e.g. a sample's first-run stream and its nearly sorted
+// second-run stream); each workgroup zeroes an ST-cell LDS window, pulls every event that lands in
+// ITS tile from each batch's candidate range (LDS atomics), then writes the window to HBM with
+// plain 16-byte accesses: a half-tile that has not been written since the last reset is STORED
+// (no read, no prior zero fill needed), otherwise read-modify-written with all-zero 16-byte
+// groups skipped.  No global atomics on the hot path.  Ends of runs longer than LMAX go to the
+// overflow list (applied by k_apply_overflow after this kernel).
 template <int ST>
-__global__ __launch_bounds__(WG) void k_scatter_tiles(const pd_iv *iv, uint32_t n, uint32_t n_tiles,
-                                                      ContigTab tab, uint32_t lmax,
-                                                      const uint32_t *ub_a, const uint32_t *cand_lo,
-                                                      const uint32_t *tile_contig,
-                                                      BatchDesc *desc, int *diff, int *sums,
-                                                      uint64_t *ovf, uint32_t ovf_cap)
+__global__ __launch_bounds__(WG) void k_scatter_tiles(const PendSet ps, uint32_t n_tiles, ContigTab tab,
+                                                      const uint32_t *tile_contig, int *diff, int *sums,
+                                                      uint8_t *hstate, uint64_t *ovf, uint32_t ovf_cap,
+                                                      CheckWords *chk)
 {
     __shared__ __attribute__((aligned(16))) int win[ST];
     __shared__ int s_sum;
-    const uint32_t t_first = desc->t_first, n_active = desc->n_active;
-    uint32_t n_beg = 0, n_has = 0, n_end = 0;
-    for (uint32_t tt = blockIdx.x; tt < n_active; tt += gridDim.x) {
-        const uint64_t t = (uint64_t)t_first + tt;
-        if (t >= n_tiles) break;
+    uint32_t tf[PD_MAXPEND], na[PD_MAXPEND];
+    uint32_t n_beg[PD_MAXPEND], n_has[PD_MAXPEND], n_end[PD_MAXPEND];
+    uint32_t t_lo = 0xFFFFFFFFu, t_hi = 0;
+#pragma unroll
+    for (int b = 0; b < PD_MAXPEND; ++b) {
+        n_beg[b] = n_has[b] = n_end[b] = 0; tf[b] = 0; na[b] = 0;
+        if (b < ps.nb) {
+            tf[b] = ps.b[b].desc->t_first; na[b] = ps.b[b].desc->n_active;
+            if (na[b]) { if (tf[b] < t_lo) t_lo = tf[b]; if (tf[b] + na[b] > t_hi) t_hi = tf[b] + na[b]; }
+        }
+    }
+    if (t_hi > n_tiles) t_hi = n_tiles;
+    const uint32_t lmax = ps.lmax;
+    for (uint64_t t = (uint64_t)t_lo + blockIdx.x; t < t_hi; t += gridDim.x) {
         const uint64_t a = t * ST;
         int4 *w4 = reinterpret_cast<int4 *>(win);
         for (int j = threadIdx.x; j < ST / 4; j += WG) w4[j] = make_int4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_sum = 0;
-        // clamped: on a batch that was NOT sorted the index holds garbage, and the only promise
-        // then is "reported, no out-of-bounds access"
-        uint32_t hi = ub_a[t + 1]; if (hi > n) hi = n;
-        uint32_t lo = cand_lo[t]; if (lo > hi) lo = hi;
         // a scatter tile lies inside ONE contig slot, so only runs of that contig can land in it
         const int32_t ctg = (int32_t)tile_contig[a / TILE];
         const uint32_t clen = tab.len[ctg];
         const int64_t rel = (int64_t)(tab.off[ctg] - a);          // slot start relative to the tile (<= 0)
+        const bool valid0 = hstate[a / PD_HALF] != 0;
+        const bool valid1 = ST > PD_HALF ? hstate[a / PD_HALF + 1] != 0 : valid0;
         __syncthreads();
         int net = 0;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
-            const pd_iv v = iv[i];
-            if (v.tid != ctg) continue;
-            uint32_t b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
-            uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
-            const bool has = b < x;
-            const uint32_t len = has ? x - b : 0u;
-            const uint64_t rb = (uint64_t)(rel + b), re = (uint64_t)(rel + x);   // below-tile wraps high
-            if (rb < (uint64_t)ST) {
-                ++n_beg;
-                if (has) {
-                    ++n_has;
-                    atomicAdd(&win[rb], 1); ++net;
-                    if (len > lmax) {
-                        const uint32_t slot = atomicAdd(&desc->ovf_count, 1u);
-                        if (slot < ovf_cap) { ovf[slot] = a + re; ++n_end; } else atomicOr(&desc->err, 4u);
+#pragma unroll
+        for (int b = 0; b < PD_MAXPEND; ++b) {
+            if (b >= ps.nb || t < tf[b] || t >= (uint64_t)tf[b] + na[b]) continue;
+            // clamped: on a batch that was NOT sorted the index holds garbage, and the only
+            // promise then is "reported, no out-of-bounds access"
+            const uint32_t n = ps.b[b].n;
+            uint32_t hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
+            uint32_t lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
+            const pd_iv *__restrict__ iv = ps.b[b].iv;
+            // four candidates per thread in flight: the loop is bound by load latency, not by ALU
+            constexpr int UN = 4;
+            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += UN * WG) {
+                pd_iv vv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const uint32_t i = i0 + u * WG;
+                    vv[u] = iv[i < hi ? i : hi - 1];
+                    if (i >= hi) vv[u].tid = -1;                  // never equals a contig id
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const pd_iv v = vv[u];
+                    if (v.tid != ctg) continue;
+                    uint32_t bb = v.beg < 0 ? 0u : (uint32_t)v.beg; if (bb > clen) bb = clen;
+                    uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+                    const bool has = bb < x;
+                    const uint32_t len = has ? x - bb : 0u;
+                    const uint64_t rb = (uint64_t)(rel + bb), re = (uint64_t)(rel + x);   // below-tile wraps high
+                    if (rb < (uint64_t)ST) {
+                        ++n_beg[b];
+                        if (has) {
+                            ++n_has[b];
+                            atomicAdd(&win[rb], 1); ++net;
+                            if (len > lmax) {
+                                const uint32_t slot = atomicAdd(&chk->ovf_count, 1u);
+                                if (slot < ovf_cap) { ovf[slot] = a + re; ++n_end[b]; } else atomicOr(&chk->err, 4u);
+                            }
+                        }
                     }
+                    if (has && len <= lmax && re < (uint64_t)ST) { atomicAdd(&win[re], -1); --net; ++n_end[b]; }
                 }
             }
-            if (has && len <= lmax && re < (uint64_t)ST) { atomicAdd(&win[re], -1); --net; ++n_end; }
         }
         net = wave_sum(net);
         if ((threadIdx.x & 63) == 0 && net != 0) atomicAdd(&s_sum, net);
         __syncthreads();
         int4 *o4 = reinterpret_cast<int4 *>(diff + a);
-        for (int j = threadIdx.x; j < ST / 4; j += WG) {
-            const int4 w = w4[j];
-            if (w.x | w.y | w.z | w.w) {
-                int4 o = o4[j];
-                o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w;
-                o4[j] = o;
+        constexpr int NG = ST / 4 / WG;                          // 16-byte groups per thread (4 or 8)
+        int4 w[NG], o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int j = threadIdx.x + g * WG;
+            w[g] = w4[j];
+            const bool valid = (ST > PD_HALF && j >= PD_HALF / 4) ? valid1 : valid0;
+            // read-modify-write only what was written before AND changes now; issue all loads first
+            if (valid && (w[g].x | w[g].y | w[g].z | w[g].w)) o[g] = o4[j]; else o[g] = make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int j = threadIdx.x + g * WG;
+            const bool valid = (ST > PD_HALF && j >= PD_HALF / 4) ? valid1 : valid0;
+            if (!valid || (w[g].x | w[g].y | w[g].z | w[g].w)) {
+                o[g].x += w[g].x; o[g].y += w[g].y; o[g].z += w[g].z; o[g].w += w[g].w;
+                o4[j] = o[g];                                    // first touch since reset: plain store of the window
             }
         }
-        if (threadIdx.x == 0 && s_sum != 0) {
-            if (ST == TILE) sums[t] += s_sum;                    // sole owner of this sum
-            else atomicAdd(&sums[a / TILE], s_sum);              // two scatter tiles share one sum
+        if (threadIdx.x == 0) {
+            if (!valid0) hstate[a / PD_HALF] = 1;
+            if (ST > PD_HALF && !valid1) hstate[a / PD_HALF + 1] = 1;
+            if (s_sum != 0) {
+                if (ST == TILE) sums[t] += s_sum;                // sole owner of this sum
+                else atomicAdd(&sums[a / TILE], s_sum);          // two scatter tiles share one sum
+            }
         }
         __syncthreads();
     }
     // every run must have found the owner of its begin, and every run with cells the owner of its
-    // end (in a tile or on the overflow list); anything else means the batch broke its promise
-    const int hb = wave_sum((int)n_beg), hh = wave_sum((int)n_has), he = wave_sum((int)n_end);
-    if ((threadIdx.x & 63) == 0) {
-        if (hb) atomicAdd((unsigned long long *)&desc->handled, (unsigned long long)(unsigned)hb);
-        if (hh) atomicAdd((unsigned long long *)&desc->has, (unsigned long long)(unsigned)hh);
-        if (he) atomicAdd((unsigned long long *)&desc->ends, (unsigned long long)(unsigned)he);
+    // end (in a tile or on the overflow list); anything else means the batch broke its promise.
+    // One atomic per workgroup and counter, spread over PD_CNT_SLOTS addresses.
+    __shared__ unsigned s_cnt[PD_MAXPEND][3];
+    if (threadIdx.x < PD_MAXPEND * 3) s_cnt[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PD_MAXPEND; ++b) {
+        if (b >= ps.nb) continue;
+        const int hb = wave_sum((int)n_beg[b]), hh = wave_sum((int)n_has[b]), he = wave_sum((int)n_end[b]);
+        if ((threadIdx.x & 63) == 0) {
+            if (hb) atomicAdd(&s_cnt[b][0], (unsigned)hb);
+            if (hh) atomicAdd(&s_cnt[b][1], (unsigned)hh);
+            if (he) atomicAdd(&s_cnt[b][2], (unsigned)he);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ps.nb * 3) {
+        const int b = threadIdx.x / 3, k = threadIdx.x % 3;
+        const unsigned v = s_cnt[b][k];
+        if (v) {
+            BatchDesc *desc = ps.b[b].desc;
+            unsigned long long *dst = (unsigned long long *)(k == 0 ? desc->handled : k == 1 ? desc->has : desc->ends);
+            atomicAdd(dst + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)v);
+        }
     }
 }
 
-__global__ __launch_bounds__(WG) void k_apply_overflow(const uint64_t *ovf, const BatchDesc *desc,
-                                                       uint32_t ovf_cap, int *diff, int *sums)
+// Zero-fills every half-tile that has not been written since the last reset (and marks it), so
+// that the atomic kernels may add into any cell.  With only_if_overflow it returns at once unless
+// the tile pass just put something on the overflow list.
+__global__ __launch_bounds__(WG) void k_fill_invalid(int4 *buf, uint8_t *hstate, uint32_t n_half,
+                                                     const CheckWords *chk, int only_if_overflow)
 {
-    uint32_t n = desc->ovf_count; if (n > ovf_cap) n = ovf_cap;
+    if (chk->all_valid) return;
+    if (only_if_overflow && chk->ovf_count == 0) return;
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (uint32_t h = blockIdx.x; h < n_half; h += gridDim.x) {
+        if (hstate[h]) continue;                                 // uniform per workgroup
+        int4 *p = buf + (size_t)h * (PD_HALF / 4);
+        for (int j = threadIdx.x; j < PD_HALF / 4; j += WG) p[j] = z;
+        if (threadIdx.x == 0) hstate[h] = 1;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_apply_overflow(const uint64_t *ovf, CheckWords *chk, uint32_t ovf_cap,
+                                                       int *diff, int *sums, int mark_valid)
+{
+    uint32_t n = chk->ovf_count; if (n > ovf_cap) n = ovf_cap;
     for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
         const uint64_t ge = ovf[i];
         atomicAdd(&diff[ge], -1);
         atomicAdd(&sums[ge / TILE], -1);
     }
+    // the fill that preceded this kernel ran iff the list is not empty (or unconditionally)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n > 0 || mark_valid)) chk->all_valid = 1;
 }
 
+__global__ void k_mark_all_valid(CheckWords *chk) { chk->all_valid = 1; }
+
 // Folds one batch's outcome into the context-wide check words and re-arms the descriptor.
-__global__ void k_finish_batch(BatchDesc *desc, uint64_t n_expected, CheckWords *chk)
+__global__ void k_finish_batch(const PendSet ps, CheckWords *chk)
 {
-    if (desc->handled != n_expected || desc->has != desc->ends) chk->unsorted_batches += 1;
-    if (desc->err) chk->err |= desc->err;
-    desc->handled = 0; desc->has = 0; desc->ends = 0; desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
+    for (int b = 0; b < ps.nb; ++b) {
+        BatchDesc *desc = ps.b[b].desc;
+        uint64_t handled = 0, has = 0, ends = 0;
+        for (int k = 0; k < PD_CNT_SLOTS; ++k) {
+            handled += desc->handled[k]; has += desc->has[k]; ends += desc->ends[k];
+            desc->handled[k] = 0; desc->has[k] = 0; desc->ends[k] = 0;
+        }
+        if (handled != (uint64_t)ps.b[b].n || has != ends) chk->unsorted_batches += 1;
+        if (desc->err) chk->err |= desc->err;
+        desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
+    }
+    chk->ovf_count = 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // tile carries: exclusive prefix sum of the tile sums (a few hundred thousand ints), one
 // workgroup of 1024 threads, chunked.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, int *carry, uint32_t n_tiles)
+// Two small kernels: (1) one workgroup per 1024 tile sums reduces them to a block sum; (2) every
+// workgroup re-derives its block's offset from the <= few hundred block sums and scans its block.
+__global__ __launch_bounds__(1024) void k_carry_block_sums(const int *sums, int *bsum, uint32_t n_tiles)
 {
     __shared__ int wsum[16];
-    __shared__ int s_run;
-    if (threadIdx.x == 0) s_run = 0;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < n_tiles ? sums[i] : 0;
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; bsum[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, const int *bsum, int *carry, uint32_t n_tiles)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const int v = i < n_tiles ? sums[i] : 0;
-        const int x = wave_incl_scan(v);
-        if (lane == 63) wsum[wv] = x;
-        __syncthreads();
-        int pre = s_run;
-        for (int k = 0; k < wv; ++k) pre += wsum[k];
-        if (i < n_tiles) carry[i] = pre + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_run = pre + x;
-        __syncthreads();
-    }
+    // offset of this block = sum of the block sums before it
+    int part = 0;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 1024) part += bsum[k];
+    part = wave_sum(part);
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; s_base = t; }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = i < n_tiles ? sums[i] : 0;
+    const int x = wave_incl_scan(v);
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int pre = s_base;
+    for (int k = 0; k < wv; ++k) pre += wsum[k];
+    if (i < n_tiles) carry[i] = pre + x - v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -304,7 +411,7 @@ struct WinArgs {
 
 template <bool WRITE, bool WIN, bool FROM_DEPTH>
 __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32_t wrap_mask,
-                                              const TileMap tmap, WinArgs wa)
+                                              const TileMap tmap, WinArgs wa, const uint8_t *hstate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wtot[4];
@@ -313,8 +420,16 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int4 *p4 = reinterpret_cast<int4 *>(buf + t * TILE) + wv * (ROWS * 64) + lane;
     int4 v[ROWS];
+    // a half-tile nobody has written since the reset holds stale bytes and counts as zeros; waves
+    // 0-1 cover the first 4096 cells of the tile, waves 2-3 the second (wave-uniform branch)
+    const bool live = FROM_DEPTH || hstate[t * (TILE / PD_HALF) + (wv >> 1)] != 0;
+    if (live) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) v[r] = p4[r * 64];
+        for (int r = 0; r < ROWS; ++r) v[r] = p4[r * 64];
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) v[r] = make_int4(0, 0, 0, 0);
+    }
 
     if (!FROM_DEPTH) {
         int tot[ROWS];
@@ -514,35 +629,45 @@ void launch_scatter_index(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab
         hipLaunchKernelGGL(k_index<8192>, g, b, 0, st, iv, n, sample, tab, lmax, disorder, ub_a, cand_lo, n_stiles, desc);
 }
 
-void launch_scatter_tiles(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax,
-                          const uint32_t *ub_a, const uint32_t *cand_lo, const uint32_t *tile_contig,
-                          uint32_t n_stiles, int stile, BatchDesc *desc,
-                          int *diff, int *sums, uint64_t *ovf, uint32_t ovf_cap, unsigned grid_tiles)
+void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig,
+                          uint32_t n_stiles, int stile, int *diff, int *sums, uint8_t *hstate,
+                          uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk, unsigned grid_tiles)
 {
     if (stile == 4096)
-        hipLaunchKernelGGL(k_scatter_tiles<4096>, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_stiles, tab, lmax, ub_a,
-                           cand_lo, tile_contig, desc, diff, sums, ovf, ovf_cap);
+        hipLaunchKernelGGL(k_scatter_tiles<4096>, dim3(grid_tiles), dim3(WG), 0, st, ps, n_stiles, tab, tile_contig,
+                           diff, sums, hstate, ovf, ovf_cap, chk);
     else
-        hipLaunchKernelGGL(k_scatter_tiles<8192>, dim3(grid_tiles), dim3(WG), 0, st, iv, n, n_stiles, tab, lmax, ub_a,
-                           cand_lo, tile_contig, desc, diff, sums, ovf, ovf_cap);
+        hipLaunchKernelGGL(k_scatter_tiles<8192>, dim3(grid_tiles), dim3(WG), 0, st, ps, n_stiles, tab, tile_contig,
+                           diff, sums, hstate, ovf, ovf_cap, chk);
 }
 
-void launch_scatter_finish(hipStream_t st, uint32_t n, BatchDesc *desc, int *diff, int *sums,
-                           const uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk)
+void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,
+                         bool only_if_overflow, unsigned grid)
 {
-    hipLaunchKernelGGL(k_apply_overflow, dim3(256), dim3(WG), 0, st, ovf, desc, ovf_cap, diff, sums);
-    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, desc, (uint64_t)n, chk);
+    hipLaunchKernelGGL(k_fill_invalid, dim3(grid), dim3(WG), 0, st, (int4 *)diff, hstate, n_half, chk,
+                       only_if_overflow ? 1 : 0);
+    if (!only_if_overflow) hipLaunchKernelGGL(k_mark_all_valid, dim3(1), dim3(1), 0, st, chk);
 }
 
-void launch_tile_carry(hipStream_t st, const int *sums, int *carry, uint32_t n_tiles)
+void launch_scatter_finish(hipStream_t st, const PendSet &ps, int *diff, int *sums, const uint64_t *ovf,
+                           uint32_t ovf_cap, CheckWords *chk)
 {
-    hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(1024), 0, st, sums, carry, n_tiles);
+    hipLaunchKernelGGL(k_apply_overflow, dim3(256), dim3(WG), 0, st, ovf, chk, ovf_cap, diff, sums, 0);
+    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, ps, chk);
 }
 
-void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask)
+void launch_tile_carry(hipStream_t st, const int *sums, int *bsum, int *carry, uint32_t n_tiles)
+{
+    const unsigned nb = (n_tiles + 1023) / 1024;
+    hipLaunchKernelGGL(k_carry_block_sums, dim3(nb), dim3(1024), 0, st, sums, bsum, n_tiles);
+    hipLaunchKernelGGL(k_tile_carry, dim3(nb), dim3(1024), 0, st, sums, bsum, carry, n_tiles);
+}
+
+void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
+                       const uint8_t *hstate)
 {
     TileMap tm{}; WinArgs wa{};
-    hipLaunchKernelGGL((k_sweep<true, false, false>), dim3(n_tiles), dim3(WG), 0, st, buf, carry, wrap_mask, tm, wa);
+    hipLaunchKernelGGL((k_sweep<true, false, false>), dim3(n_tiles), dim3(WG), 0, st, buf, carry, wrap_mask, tm, wa, hstate);
 }
 
 static size_t win_lds_bytes(uint32_t w)
@@ -554,7 +679,8 @@ static size_t win_lds_bytes(uint32_t w)
 
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
-                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth)
+                         TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth,
+                         const uint8_t *hstate)
 {
     WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = cover; wa.sum = sum;
     wa.part = part;
@@ -564,12 +690,12 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, true>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa);
+        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate);
     } else {
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa);
+        hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate);
     }
     if (w >= (uint32_t)TILE && n_windows)
         hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n_windows + 3) / 4)), dim3(WG), 0, st, part, tm, n_contigs,

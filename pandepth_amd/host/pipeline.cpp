@@ -96,7 +96,8 @@ private:
     }
     void flush_other()
     {
-        const unsigned f = o_dis_ <= (1u << 20) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
+        // beyond a few tiles of disorder the owner tiles would re-read too much: use the atomic kernel
+        const unsigned f = o_dis_ <= (1u << 14) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)o_dis_)) : PD_PUSH_DEFAULT;
         if (!drop_ && !o_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, o_.data(), o_.size(), f), "pd_push_intervals");
         o_.clear(); o_max_ = 0; o_dis_ = 0;
     }

@@ -142,6 +142,41 @@ def test_nearly_sorted_batch_with_disorder_bound(D):
         check_depth(e, LENS, d, off)
 
 
+def test_merged_tile_pass_and_lazy_zero():
+    """PD_PUSH_MORE: several sorted batches in one owner-tile pass; cells never written since the
+    reset must read as zero everywhere (depth, windows, the raw buffer), reset after reset."""
+    rng = np.random.default_rng(21)
+    a = sort_iv(rand_intervals(rng, LENS, 80000))
+    b = sort_iv(rand_intervals(rng, LENS, 30000, max_len=3000))          # many runs longer than lmax
+    c = sort_iv(rand_intervals(rng, [LENS[0]], 20000))                     # touches contig 0 only
+    u = rand_intervals(rng, LENS, 5000)
+    with pda.Engine(LENS) as e:
+        for rep in range(2):
+            e.push_intervals(a, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+            e.push_intervals(b, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+            e.push_intervals(c, pda.PD_PUSH_SORTED)
+            d, off = oracle_depth(LENS, np.concatenate([a, b, c]))
+            ec, es = windows_ref(LENS, d, off, 1000, 1)
+            _, c1, s1 = e.scan_reduce_windows(1000, 1, 0)
+            assert np.array_equal(c1, ec) and np.array_equal(s1, es)
+            e.push_intervals(u)                                            # atomic path after tile passes
+            d, off = oracle_depth(LENS, np.concatenate([a, b, c, u]))
+            e.scan(0)
+            check_depth(e, LENS, d, off)
+            e.reset()
+        # after a reset only one small contig is touched: everything else must still be zero
+        only = sort_iv(rand_intervals(rng, LENS[:1], 1000))
+        only[:, 0] = 6
+        only = clip(only, LENS)
+        e.push_intervals(only, pda.PD_PUSH_SORTED)
+        d, off = oracle_depth(LENS, only)
+        ec, es = windows_ref(LENS, d, off, 10000000, 1)
+        _, c1, s1 = e.scan_reduce_windows(10000000, 1, 18)
+        assert np.array_equal(c1, ec) and np.array_equal(s1, es)
+        e.scan(18)
+        check_depth(e, LENS, d, off)
+
+
 def test_sorted_flag_on_unsorted_batch_is_reported():
     rng = np.random.default_rng(4)
     iv = rand_intervals(rng, LENS, 100000)

@@ -25,31 +25,25 @@ def main():
     def run(tag, **params):
         for k, v in params.items():
             eng.set_param(k, v)
-        t_first = 0.0
         for it in range(3):
             if it == 1:
                 eng.profile(True)
             eng.reset()
-            b0 = eng.profile_get("scatter_tiles")[0] if it else 0
-            eng.push_intervals_device(first.data_ptr(), nf, pda.PD_PUSH_SORTED)
-            eng.synchronize()
-            if it:
-                t_first += eng.profile_get("scatter_tiles")[0] - b0
+            eng.push_intervals_device(first.data_ptr(), nf, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
             eng.push_intervals_device(other.data_ptr(), no, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
             eng.synchronize()
         ms_idx, n_idx = eng.profile_get("scatter_index")
         ms_t, n_t = eng.profile_get("scatter_tiles")
         ms_f, _ = eng.profile_get("scatter_finish")
         eng.profile(False)
-        print("%-40s tiles %.3f ms/step = first %.3f + other %.3f (index %.3f finish %.3f) launches/step %d" % (
-            tag, ms_t / 2, t_first / 2, (ms_t - t_first) / 2, ms_idx / 2, ms_f / 2, n_t // 2), flush=True)
+        print("%-44s tiles %.3f ms/step (index %.3f finish %.3f) launches/step %d" % (
+            tag, ms_t / 2, ms_idx / 2, ms_f / 2, n_t // 2), flush=True)
 
-    for st, gm, sample, lmax in itertools.product((4096, 8192), (1,), (64,), (512,)):
-        per_cu = 8 if st == 4096 else 4
-        run("stile=%d grid=%dx sample=%d lmax=%d" % (st, gm, sample, lmax), scatter_tile=st,
-            grid_tiles=256 * per_cu * gm, sample=sample, lmax=lmax)
-    for sample, lmax in ():
-        run("stile=4096 grid=2x sample=%d lmax=%d" % (sample, lmax), scatter_tile=4096, grid_tiles=256 * 16,
+    for st in (4096, 8192):
+        for grid in (2048, 8192, 65536, 1 << 20):
+            run("stile=%d grid=%d" % (st, grid), scatter_tile=st, grid_tiles=grid, sample=64, lmax=512)
+    for sample, lmax in ((32, 512), (128, 512), (64, 256)):
+        run("stile=4096 grid=1M sample=%d lmax=%d" % (sample, lmax), scatter_tile=4096, grid_tiles=1 << 20,
             sample=sample, lmax=lmax)
 
 
