@@ -196,8 +196,20 @@ def main():
         }
         dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])
         kd = kernels[dom]
+        # HBM bytes per launch from the PMC counters: taken from the committed rocprofv3 --pmc passes
+        # (tools/pmc_collect.sh -> profiles/*_pmc_traffic.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated
+        # there); bench.py itself never runs under a profiler
+        traffic = None
+        try:
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+            key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>"}.get(dom)
+            if key in pmc["kernels"] and R == int(1e9):
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+        except (OSError, IndexError, KeyError, ValueError):
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kd["frac"], "traffic": None,
+                    "unit": "GB/s", "frac": kd["frac"], "traffic": traffic,
                     "avg_launch_ms": kd["avg_ms"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
         cb = None
         if world == 1 and args.cpu_sample > 0:

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""tools/pmc_workload.py — the bench step (plus one write-back scan for calibration) without timing,
+meant to run under `rocprofv3 --pmc ...` (see tools/pmc_collect.sh)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import pandepth_amd as pda  # noqa: E402
+from tools import synth  # noqa: E402
+
+R = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(1e9)
+dev = torch.device("cuda", 0)
+names, lens = synth.genome_c2()
+eng = pda.Engine(lens.astype(np.uint32), device=0)
+first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
+torch.cuda.synchronize()
+for it in range(2):
+    eng.reset()
+    eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+    eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+    eng.scan_reduce_windows(10000000, 1, 0)
+    eng.scan(0)          # write-back sweep: reads AND writes every cell once = the calibration kernel
+    eng.synchronize()
+print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]))
