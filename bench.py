@@ -118,7 +118,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # PD_BENCH_FORCE_DIST=1 exercises the collective code path with a 1-rank group (single-GPU boxes)
+    use_dist = world > 1 or os.environ.get("PD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     R = int(args.records)
@@ -129,14 +133,15 @@ def main():
     torch.cuda.synchronize()
     n_first, n_other = int(first.shape[0]), int(other.shape[0])
     _, n_words, _ = eng.device_buffer()
-    buf = multi.buffer_view(eng, dev) if world > 1 else None
-    wrap = 18 if world > 1 else 0        # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
+    buf = multi.buffer_view(eng, dev) if use_dist else None
+    wrap = 18 if use_dist else 0         # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
 
     def step():
         eng.reset()
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
-        if world > 1:
+        if use_dist:
+            eng.device_buffer()                    # materialise zeros in half-tiles this sample never wrote
             eng.synchronize()                      # the engine's stream is not torch's: order by host sync
             is_root = multi.sum_to_root(buf, 0)
             torch.cuda.synchronize()
@@ -145,7 +150,7 @@ def main():
         return eng.scan_reduce_windows(BIN, 1, wrap)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
@@ -160,7 +165,7 @@ def main():
         res = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -190,11 +195,13 @@ def main():
 
         launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
         kernels = {
-            "fill": k_entry("fill", n_words * B_FILL_PER_CELL),      # only when zeros must be materialised (N > 1)
+            # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
+            "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
+                     if prof["fill"][1] else None),
             "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
         }
-        dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])
+        dom = max((k for k in kernels if kernels[k] and "frac" in kernels[k]), key=lambda k: prof[k][0])
         kd = kernels[dom]
         # HBM bytes per launch from the PMC counters: taken from the committed rocprofv3 --pmc passes
         # (tools/pmc_collect.sh -> profiles/*_pmc_traffic.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated
@@ -225,14 +232,14 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + (", RCCL reduce to rank 0" if world > 1 else ""),
+                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + (", RCCL reduce to rank 0" if use_dist else ""),
                        "total_depth_check": total_depth},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -250,7 +250,7 @@ bool BaiIndex::load(const std::string &path, std::string *err)
     auto need = [&](size_t k) { return o + k <= d.size(); };
     if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) { if (err) *err = path + " is not a BAI index"; return false; }
     const uint32_t n_ref = le32(d.data() + 4); o = 8;
-    linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0);
+    linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {});
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!need(4)) goto bad;
         {
@@ -261,9 +261,11 @@ bool BaiIndex::load(const std::string &path, std::string *err)
                 const uint32_t bin = le32(d.data() + o), n_chunk = le32(d.data() + o + 4); o += 8;
                 if (!need(16 * (size_t)n_chunk)) goto bad;
                 if (bin != 37450) {
+                    auto &v = bins[r][bin];
                     for (uint32_t c = 0; c < n_chunk; ++c) {
                         const uint64_t cb = le64(d.data() + o + 16 * c), ce = le64(d.data() + o + 16 * c + 8);
                         lo = std::min(lo, cb); hi = std::max(hi, ce);
+                        v.emplace_back(cb, ce);
                     }
                 }
                 o += 16 * (size_t)n_chunk;
@@ -358,6 +360,43 @@ bool bai_build(const std::string &bam_path, std::string *err)
     fclose(f);
     if (!ok && err) *err = "short write on " + bam_path + ".bai";
     return ok;
+}
+
+void BaiIndex::query(int32_t tid, int64_t beg0, int64_t end, std::vector<Chunk> *out) const
+{
+    if (tid < 0 || (size_t)tid >= bins.size() || beg0 >= end) return;
+    if (beg0 < 0) beg0 = 0;
+    if (end > ((int64_t)1 << 29)) end = (int64_t)1 << 29;
+    const auto &lin = linear[tid];
+    uint64_t min_off = 0;
+    if (!lin.empty()) {
+        const size_t w = (size_t)(beg0 >> 14);
+        min_off = w < lin.size() ? lin[w] : lin.back();
+    }
+    const auto &bm = bins[tid];
+    const int64_t e = end - 1;
+    auto take = [&](uint32_t bin) {
+        auto it = bm.find(bin);
+        if (it == bm.end()) return;
+        for (const Chunk &c : it->second) if (c.second > min_off) out->push_back(c);
+    };
+    take(0);
+    for (int64_t k = 1 + (beg0 >> 26); k <= 1 + (e >> 26); ++k) take((uint32_t)k);
+    for (int64_t k = 9 + (beg0 >> 23); k <= 9 + (e >> 23); ++k) take((uint32_t)k);
+    for (int64_t k = 73 + (beg0 >> 20); k <= 73 + (e >> 20); ++k) take((uint32_t)k);
+    for (int64_t k = 585 + (beg0 >> 17); k <= 585 + (e >> 17); ++k) take((uint32_t)k);
+    for (int64_t k = 4681 + (beg0 >> 14); k <= 4681 + (e >> 14); ++k) take((uint32_t)k);
+}
+
+void BaiIndex::normalise(std::vector<Chunk> *v)
+{
+    std::sort(v->begin(), v->end());
+    size_t w = 0;
+    for (size_t i = 0; i < v->size(); ++i) {
+        if (w && (*v)[i].first <= (*v)[w - 1].second) { if ((*v)[i].second > (*v)[w - 1].second) (*v)[w - 1].second = (*v)[i].second; }
+        else (*v)[w++] = (*v)[i];
+    }
+    v->resize(w);
 }
 
 std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_parts) const

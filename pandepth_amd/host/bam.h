@@ -62,7 +62,14 @@ private:
 struct BaiIndex {
     std::vector<std::vector<uint64_t>> linear;    // per reference: 16 kb window -> smallest voffset
     std::vector<uint64_t> ref_beg, ref_end;       // per reference: span of its chunks (0,0 if none)
+    typedef std::pair<uint64_t, uint64_t> Chunk;  // [begin, end) virtual offsets
+    std::vector<std::unordered_map<uint32_t, std::vector<Chunk>>> bins;   // per reference
     bool load(const std::string &path, std::string *err);
+    // file ranges that can hold reads overlapping [beg0, end) of reference tid (binning scheme of
+    // SAM spec §5.3, pruned with the linear index); appended to *out unsorted
+    void query(int32_t tid, int64_t beg0, int64_t end, std::vector<Chunk> *out) const;
+    // sorts and fuses overlapping / touching ranges
+    static void normalise(std::vector<Chunk> *v);
     // record-aligned split points covering [first_record_voff, EOF): about n_parts ranges of similar
     // compressed size.  Returns the boundaries (size = parts + 1, last = UINT64_MAX).
     std::vector<uint64_t> split(uint64_t first_record_voff, uint64_t file_size, int n_parts) const;

@@ -131,8 +131,10 @@ struct ReadFilter {
 struct SpanIndex {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> per_tid;   // (begin0, end) sorted
     std::vector<char> whole;                                         // spans cover the whole contig
-    void build(const RegionModel &rm, const AlnHeader &h, bool synthetic)
+    bool synthetic = true;                                           // whole-contig bins (modes 0/5/6)
+    void build(const RegionModel &rm, const AlnHeader &h, bool synth)
     {
+        synthetic = synth;
         per_tid.assign(h.names.size(), {}); whole.assign(h.names.size(), 0);
         for (auto &kv : rm.merged) {
             if (kv.first < 0 || (size_t)kv.first >= h.names.size()) continue;
@@ -143,7 +145,7 @@ struct SpanIndex {
                 int64_t e = (int64_t)se.second + 1; if (e > len) e = len;
                 v.emplace_back((int32_t)(b - 1), (int32_t)e);
             }
-            if (synthetic) whole[kv.first] = 1;    // bins tile [1,len] (minus at most the last base): widened, they cover every read
+            if (synth) whole[kv.first] = 1;    // bins tile [1,len] (minus at most the last base): widened, they cover every read
         }
     }
     inline bool hit(const AlnRec &r) const
@@ -171,12 +173,39 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     AlnReader probe;
     if (!probe.open(path, &err)) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
     if (!probe.is_bam()) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
-    std::vector<uint64_t> cuts;
+    // Work list: [begin, end) virtual-offset ranges, each starting at a record boundary.
+    //  * whole-genome modes: the file cut at linear-index offsets into ranges of similar size;
+    //  * GFF/BED targets: only the index chunks that can hold reads overlapping a (widened) merged
+    //    span, like the reference's multi-region iterator (PD:698-730) — most of the file is
+    //    never inflated.
+    std::vector<BaiIndex::Chunk> work;
     int threads = o.threads < 1 ? 1 : o.threads;
-    if (have_bai && threads > 1) cuts = bai.split(probe.tell(), file_size(path), threads * 8);
-    else { cuts.push_back(probe.tell()); cuts.push_back(UINT64_MAX); }
-    const size_t n_tasks = cuts.size() - 1;
-    if ((size_t)threads > n_tasks) threads = (int)n_tasks;
+    if (have_bai && !spans.synthetic) {
+        for (size_t t = 0; t < spans.per_tid.size(); ++t)
+            for (auto &sp : spans.per_tid[t]) bai.query((int32_t)t, sp.first, sp.second, &work);
+        BaiIndex::normalise(&work);
+    } else {
+        std::vector<uint64_t> cuts;
+        if (have_bai && threads > 1) cuts = bai.split(probe.tell(), file_size(path), threads * 8);
+        else { cuts.push_back(probe.tell()); cuts.push_back(UINT64_MAX); }
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) work.emplace_back(cuts[i], cuts[i + 1]);
+    }
+    // tasks = runs of consecutive ranges of similar total compressed size
+    std::vector<std::pair<size_t, size_t>> tasks;        // [first, last) into work
+    {
+        uint64_t total = 0;
+        auto csz = [&](const BaiIndex::Chunk &c) { return ((c.second == UINT64_MAX ? file_size(path) : (c.second >> 16)) - (c.first >> 16)) + 65536; };
+        for (auto &c : work) total += csz(c);
+        const uint64_t per = total / (uint64_t)(threads * 8) + 1;
+        size_t first = 0; uint64_t acc = 0;
+        for (size_t i = 0; i < work.size(); ++i) {
+            acc += csz(work[i]);
+            if (acc >= per) { tasks.emplace_back(first, i + 1); first = i + 1; acc = 0; }
+        }
+        if (first < work.size()) tasks.emplace_back(first, work.size());
+    }
+    const size_t n_tasks = tasks.size();
+    if ((size_t)threads > n_tasks) threads = n_tasks ? (int)n_tasks : 1;
     std::atomic<size_t> next{0};
     std::atomic<uint64_t> n_rec{0}, busy_us{0};
     auto worker = [&]() {
@@ -193,17 +222,19 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
         for (;;) {
             const size_t t = next.fetch_add(1);
             if (t >= n_tasks || !eng->ok()) break;
-            if (!rd.seek(cuts[t])) { eng->fail("seek failed in " + path); break; }
-            const uint64_t stop = cuts[t + 1];
-            for (;;) {
-                if (rd.tell() >= stop) break;
-                const int k = rd.next(&r);
-                if (k == 0) break;
-                if (k < 0) { eng->fail(rd.error() + " (" + path + ")"); return; }
-                ++my_rec;
-                if (!flt.pass(r)) continue;
-                if (!spans.hit(r)) continue;
-                emit_runs(r, &sink);
+            for (size_t w = tasks[t].first; w < tasks[t].second; ++w) {
+                if (!rd.seek(work[w].first)) { eng->fail("seek failed in " + path); return; }
+                const uint64_t stop = work[w].second;
+                for (;;) {
+                    if (rd.tell() >= stop) break;
+                    const int k = rd.next(&r);
+                    if (k == 0) break;
+                    if (k < 0) { eng->fail(rd.error() + " (" + path + ")"); return; }
+                    ++my_rec;
+                    if (!flt.pass(r)) continue;
+                    if (!spans.hit(r)) continue;
+                    emit_runs(r, &sink);
+                }
             }
         }
     };

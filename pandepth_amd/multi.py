@@ -28,7 +28,7 @@ def assign_samples(n_samples, rank, world):
 
 def sum_to_root(buf, root=0, group=None):
     """In-place int32 sum of every rank's buffer into `root`'s.  Returns True on the root."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM, group=group)
         return dist.get_rank(group) == root
     return True
