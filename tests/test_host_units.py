@@ -1,0 +1,98 @@
+"""Unit-level checks of the host modules through small generated files (no GPU): BGZF reader
+(plain / threaded read-ahead / seek), BAM vs SAM decoding of the same records, the BAI builder and
+the range splitter, and region-model quirks that the golden cases do not isolate."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from tools import synth  # noqa: E402
+import pd_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a", "pandepth_index"], check=True,
+                   stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness")], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(HERE, "harness", "pandepth_oracle_cli")
+
+
+def run(cli, args, cwd):
+    p = subprocess.run([cli] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    return p
+
+
+def stat(path):
+    return gzip.open(path).read().decode()
+
+
+def test_bai_builder_index_is_usable_by_split_and_matches_sequential(cli, tmp_path):
+    names, lens = synth.genome_c2(scale=0.0015)
+    rec = synth.gen_records_numpy(lens, 120000, seed=3)
+    bam = str(tmp_path / "x.bam")
+    synth.write_bam(bam, names, lens, rec, procs=1, payload=True)
+    run(cli, ["-i", "x.bam", "-o", "seq", "-t", "1"], tmp_path)           # no index: sequential stream
+    subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
+    assert os.path.getsize(bam + ".bai") > 100
+    for t in ("1", "3", "16"):
+        run(cli, ["-i", "x.bam", "-o", "idx" + t, "-t", t], tmp_path)     # indexed: range-partitioned readers
+        assert stat(tmp_path / ("idx%s.chr.stat.gz" % t)) == stat(tmp_path / "seq.chr.stat.gz")
+    first, other = synth.records_to_runs(rec)
+    d, off = O.depth_from_intervals(list(lens), np.concatenate([first, other]))
+    rows = stat(tmp_path / "seq.chr.stat.gz").strip().split("\n")[1:-1]
+    for t, row in enumerate(rows):
+        f = row.split("\t")
+        x = d[off[t]:off[t] + lens[t]]
+        assert f[0] == names[t] and int(f[2]) == int((x > 0).sum()) and int(f[3]) == int(x.sum(dtype=np.uint64))
+
+
+def test_index_build_rejects_unsorted(tmp_path):
+    names, lens = synth.genome_c2(scale=0.0015)
+    rec = synth.gen_records_numpy(lens, 2000, seed=4)
+    rec = {k: v[::-1].copy() for k, v in rec.items()}
+    bam = str(tmp_path / "u.bam")
+    synth.write_bam(bam, names, lens, rec, procs=1, sorted_header=False)
+    p = subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"not coordinate sorted" in p.stderr
+
+
+def test_sam_gz_and_bam_give_the_same_tables(cli, tmp_path, golden_dir):
+    sam = open(os.path.join(golden_dir, "f1", "f1.sam"), "rb").read()
+    (tmp_path / "a.sam").write_bytes(sam)
+    with gzip.open(tmp_path / "b.sam.gz", "wb") as f:
+        f.write(sam)
+    run(cli, ["-i", "a.sam", "-o", "a"], tmp_path)
+    run(cli, ["-i", "b.sam.gz", "-o", "b"], tmp_path)
+    assert (tmp_path / "a.chr.stat.gz").read_bytes() == (tmp_path / "b.chr.stat.gz").read_bytes()
+    exp = open(os.path.join(golden_dir, "f1", "expected", "chr_sam.chr.stat.gz"), "rb").read()
+    assert (tmp_path / "a.chr.stat.gz").read_bytes() == exp
+
+
+def test_region_quirks(cli, tmp_path):
+    # contigs: len 1 (no bin at all), len 201 with -w 200 (last 1-base bin dropped), len 400
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:one\tLN:1\n@SQ\tSN:q\tLN:201\n@SQ\tSN:r\tLN:400\n"
+    sam += "a\t0\tq\t150\t60\t60M\t*\t0\t0\t*\t*\n"        # overhangs the contig end by 8 bases
+    sam += "b\t0\tr\t1\t60\t400M\t*\t0\t0\t*\t*\n"
+    (tmp_path / "q.sam").write_text(sam)
+    run(cli, ["-i", "q.sam", "-o", "w", "-w", "200"], tmp_path)
+    rows = stat(tmp_path / "w.win.stat.gz").split("\n")
+    assert rows[1].split("\t")[:3] == ["q", "1", "200"] and rows[2].split("\t")[:3] == ["r", "1", "200"]
+    assert rows[-2].startswith("##RegionLength: 600\t")             # 200 (q, base 201 dropped) + 400; "one" absent
+    run(cli, ["-i", "q.sam", "-o", "m6", "-w", "100"], tmp_path)       # mode 6: `j < len` also drops q's base 201
+    rows = stat(tmp_path / "m6.win.stat.gz").split("\n")
+    assert [r.split("\t")[1] for r in rows[1:3]] == ["1", "101"] and rows[3].startswith("r\t1\t100")
+    # BED is 1-based inclusive, ids built from the raw strings, duplicates double count
+    (tmp_path / "r.bed").write_text("r\t010\t20\nr\t010\t20\nr\t30\t29\nzz\t1\t2\n")
+    p = run(cli, ["-i", "q.sam", "-o", "b", "-b", "r.bed"], tmp_path)
+    rows = stat(tmp_path / "b.bed.stat.gz").split("\n")
+    assert rows[1] == "r\t10\t20\tr_010_20\t22\t22\t22\t100.00\t1.00"
+    assert p.stderr.decode().count("Warning: This region may be incorrect.") == 2
