@@ -128,6 +128,7 @@ __global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint3
     const Ev first = expand(iv[0], tab);
     const int64_t s0 = (int64_t)first.gb;
     const int64_t t_first = (s0 - D) > 0 ? (s0 - D) / T : 0;
+    const int64_t sk_left = __shfl_up(sk, 1);               // every lane of the wave is still here
     if (k == 0) {
         desc->t_first = (uint32_t)t_first;
         if (t_first > t_last) { desc->n_active = 0; atomicOr(&desc->err, 2u); return; }   // not sorted
@@ -140,8 +141,13 @@ __global__ __launch_bounds__(WG) void k_index(const pd_iv *iv, uint32_t n, uint3
         return;
     }
     const uint32_t pkm1 = (k - 1) * S;      // < n for every k >= 1
-    const Ev ep = expand(iv[pkm1], tab);
-    const int64_t sp = (int64_t)ep.gb;
+    int64_t sp;
+    {
+        // the previous sample is the left neighbour's value: one scattered 12-byte load per thread
+        // instead of two (lane 0 of a wave and the thread right after the k == 0 exit load their own)
+        const bool own = (threadIdx.x & 63) == 0;
+        sp = own ? (int64_t)expand(iv[pkm1], tab).gb : sk_left;
+    }
     {   // tiles with a_t + D in (sp, sk]: every run at index >= p_k starts at or after a_t
         int64_t lo = (sp - D) >= 0 ? (sp - D) / T + 1 : 0, hi = (sk - D) >= 0 ? (sk - D) / T : -1;
         if (lo < t_first) lo = t_first;
@@ -511,10 +517,11 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
         const uint64_t wbase = tmap.win_off[ctg];
         const uint64_t k0 = local0 / w;                          // first window touching the tile
         // general case: LDS accumulators for the windows overlapping this tile
+        // one 64-bit accumulator per window: cover (<= 8192, 16 bits) in the top, depth sum
+        // (<= 8192 * 2^32 = 2^45) in the low 48 bits -> a single ds_add_u64 per lane segment
         const uint32_t nacc = (uint32_t)((local0 + TILE - 1) / w - k0 + 1);
-        unsigned long long *asum = reinterpret_cast<unsigned long long *>(smem);
-        uint32_t *acov = reinterpret_cast<uint32_t *>(smem + (size_t)nacc * 8);
-        for (uint32_t j = threadIdx.x; j < nacc; j += WG) { asum[j] = 0; acov[j] = 0; }
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem);
+        for (uint32_t j = threadIdx.x; j < nacc; j += WG) acc[j] = 0;
         __syncthreads();
         const uint32_t phase = (uint32_t)(local0 - k0 * w);      // offset of the tile inside window k0
 #pragma unroll
@@ -531,21 +538,23 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
             for (int e = 0; e < 4; ++e) {
                 const uint32_t pe = pos + e;
                 if (pe == nb) {
-                    if (c) { atomicAdd(&acov[q], c); atomicAdd(&asum[q], s); }
+                    if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | s);
                     c = 0; s = 0; ++q; nb += w;
                 }
                 if (local0 + pe < clen && d[e] >= wa.min_dep) { ++c; s += d[e]; }
             }
-            if (c) { atomicAdd(&acov[q], c); atomicAdd(&asum[q], s); }
+            if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | s);
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
-            const uint32_t c = acov[j];
+            const unsigned long long a = acc[j];
+            const uint32_t c = (uint32_t)(a >> 48);
             if (!c) continue;
+            const unsigned long long sm = a & 0xFFFFFFFFFFFFull;
             const uint64_t k = k0 + j;
             const bool inside = (k * w >= local0) && ((k + 1) * (uint64_t)w <= local0 + TILE);
-            if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = asum[j]; }
-            else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], asum[j]); }
+            if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = sm; }
+            else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], sm); }
         }
     }
 }
@@ -674,7 +683,7 @@ static size_t win_lds_bytes(uint32_t w)
 {
     if (w >= (uint32_t)TILE) return 16;                // large windows use per-tile partials, no LDS accumulators
     const size_t nacc = (size_t)TILE / w + 2;
-    return nacc * 12 + 16;
+    return nacc * 8 + 16;
 }
 
 int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_tiles, uint32_t wrap_mask,
