@@ -10,7 +10,8 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   first-run stream (PD_PUSH_MORE) and the ~11 % second runs of D/I/N reads,
                                   which are only nearly sorted (PD_PUSH_DISORDER(max read span)), served by
                                   the same passes over the tiles
-    [N > 1]                       RCCL sum-reduce of the difference arrays + tile sums to rank 0
+    [N > 1]                       RCCL sum-reduce of the difference arrays (int8 image + exception list,
+                                  pandepth_amd.multi.PackedSum) and the tile sums to rank 0
     pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
                                   reduction, results copied back to the host
 
@@ -133,7 +134,10 @@ def main():
     torch.cuda.synchronize()
     n_first, n_other = int(first.shape[0]), int(other.shape[0])
     _, n_words, _ = eng.device_buffer()
-    buf = multi.buffer_view(eng, dev) if use_dist else None
+    # N > 1: int8 transport of the difference arrays (1 B/cell on the xGMI links instead of 4);
+    # PD_BENCH_SUM=int32 selects the plain int32 reduce of the whole buffer instead
+    packed = multi.PackedSum(eng, dev) if use_dist and os.environ.get("PD_BENCH_SUM", "int8") == "int8" else None
+    buf = multi.buffer_view(eng, dev) if use_dist and packed is None else None
     wrap = 18 if use_dist else 0         # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
 
     def step():
@@ -141,10 +145,13 @@ def main():
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
         if use_dist:
-            eng.device_buffer()                    # materialise zeros in half-tiles this sample never wrote
-            eng.synchronize()                      # the engine's stream is not torch's: order by host sync
-            is_root = multi.sum_to_root(buf, 0)
-            torch.cuda.synchronize()
+            if packed is not None:
+                is_root = packed.run(0)
+            else:
+                eng.device_buffer()                # materialise zeros in half-tiles this sample never wrote
+                eng.synchronize()                  # the engine's stream is not torch's: order by host sync
+                is_root = multi.sum_to_root(buf, 0)
+                torch.cuda.synchronize()
             if not is_root:
                 return None
         return eng.scan_reduce_windows(BIN, 1, wrap)
@@ -172,7 +179,7 @@ def main():
 
     prof = {}
     for k in ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
-              "scan_reduce_windows"):
+              "scan_reduce_windows", "export_i8", "import_i8"):
         ms, n = eng.profile_get(k)
         prof[k] = (ms, n)
     eng.profile(False)
@@ -200,6 +207,8 @@ def main():
                      if prof["fill"][1] else None),
             "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
+            "export_i8": k_entry("export_i8", 5 * (n_words - (n_words - G) % 1)),     # 4 B read + 1 B written per cell
+            "import_i8": k_entry("import_i8", 5 * (n_words - (n_words - G) % 1)),     # 1 B read + 4 B written per cell
         }
         dom = max((k for k in kernels if kernels[k] and "frac" in kernels[k]), key=lambda k: prof[k][0])
         kd = kernels[dom]
@@ -232,7 +241,7 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + (", RCCL reduce to rank 0" if use_dist else ""),
+                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + ((", RCCL reduce to rank 0 (%s transport)" % ("int8" if packed else "int32")) if use_dist else ""),
                        "total_depth_check": total_depth},
             "roofline": roofline,
             "kernels": kernels,

@@ -136,6 +136,22 @@ int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *ou
  * all-reduce / reduce-scatter of n_words int32 over xGMI, issued by the caller on the stream
  * returned by pd_stream).  contig_off (n_contigs entries, in cells) may be NULL. */
 int pd_device_buffer(pd_ctx *ctx, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off);
+/* Compact transport of the difference arrays for that sum (xGMI is per-link bound; this moves
+ * 1 B/cell instead of 4).  pd_export_i8 writes one byte per cell into dev_i8 (n_cells bytes, from
+ * pd_device_layout), BIASED: d + threshold, an unsigned value in [0, 2*threshold]; cells with
+ * |d| > threshold are written as 0 (+bias) and appended to dev_exc (at most exc_cap entries;
+ * *dev_count receives the number produced — more than exc_cap is an error the caller must check).
+ * With threshold = 127 / n_ranks every byte of the sum over the ranks stays below 256, so the
+ * images may be added as int32 WORDS by an ordinary int32 sum collective (n_cells / 4 elements; no
+ * carry crosses a byte).  pd_import_i8 replaces the context's difference arrays by
+ * (byte - bias) + the given exceptions, bias = n_ranks * threshold (the tile sums are NOT touched:
+ * reduce them as int32 through pd_device_buffer's tail).  Both run on the context's stream; all
+ * pointers are device pointers on the context's GPU. */
+typedef struct pd_exc { uint64_t cell; int32_t value; int32_t pad; } pd_exc;
+int pd_device_layout(pd_ctx *ctx, uint64_t *n_cells, uint64_t *n_tile_sums);
+int pd_export_i8(pd_ctx *ctx, int threshold, void *dev_i8, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count);
+int pd_import_i8(pd_ctx *ctx, const void *dev_i8, int bias, const pd_exc *dev_exc, uint64_t n_exc);
+
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
 int pd_synchronize(pd_ctx *ctx);
 

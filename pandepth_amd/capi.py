@@ -64,6 +64,9 @@ def load():
         "pd_reduce_windows": (I, [P, ctypes.c_uint32, ctypes.c_uint32, P, P]),
         "pd_read_depth": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, P]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
+        "pd_device_layout": (I, [P, ctypes.POINTER(U64), ctypes.POINTER(U64)]),
+        "pd_export_i8": (I, [P, I, P, P, ctypes.c_uint32, P]),
+        "pd_import_i8": (I, [P, P, I, P, U64]),
         "pd_stream": (P, [P]),
         "pd_synchronize": (I, [P]),
         "pd_profile": (I, [P, I]),
@@ -79,7 +82,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_device_buffer", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -183,6 +186,19 @@ class Engine:
         off = np.zeros(self.n_contigs, dtype=np.uint64)
         self._ck(self.L.pd_device_buffer(self.h, ctypes.byref(p), ctypes.byref(nw), _ptr(off)))
         return int(p.value), int(nw.value), off
+
+    def device_layout(self):
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self._ck(self.L.pd_device_layout(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def export_i8(self, threshold, i8_ptr, exc_ptr, exc_cap, count_ptr):
+        self._ck(self.L.pd_export_i8(self.h, int(threshold), ctypes.c_void_p(int(i8_ptr)), ctypes.c_void_p(int(exc_ptr)),
+                                     int(exc_cap), ctypes.c_void_p(int(count_ptr))))
+
+    def import_i8(self, i8_ptr, bias, exc_ptr, n_exc):
+        self._ck(self.L.pd_import_i8(self.h, ctypes.c_void_p(int(i8_ptr)), int(bias),
+                                     ctypes.c_void_p(int(exc_ptr) if n_exc else 0), int(n_exc)))
 
     def stream(self):
         return int(self.L.pd_stream(self.h) or 0)

@@ -503,6 +503,7 @@ int pd_scan(pd_ctx *c, unsigned wrap_bits)
     { ProfScope ps(c, "scan"); launch_scan_write(c->stream, c->buf, c->carry, (uint32_t)c->n_tiles, mask, c->hstate); }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipMemsetAsync(c->hstate, 1, c->n_half, c->stream));     // the sweep wrote every cell
+    launch_mark_all_valid(c->stream, c->chk);
     c->all_valid_host = true;
     c->state = 1;
     return PD_OK;
@@ -647,6 +648,46 @@ int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *con
     if (dev_ptr) *dev_ptr = c->buf;
     if (n_words) *n_words = c->n_words;
     if (contig_off) for (int32_t i = 0; i < c->n_contigs; ++i) contig_off[i] = c->off[i];
+    return PD_OK;
+}
+
+int pd_device_layout(pd_ctx *c, uint64_t *n_cells, uint64_t *n_tile_sums)
+{
+    if (!c) return PD_EINVAL;
+    if (n_cells) *n_cells = c->n_cells;
+    if (n_tile_sums) *n_tile_sums = c->n_words - c->n_cells;
+    return PD_OK;
+}
+
+int pd_export_i8(pd_ctx *c, int threshold, void *dev_i8, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count)
+{
+    if (!c || !dev_i8 || !dev_count || threshold < 1 || threshold > 127 || (exc_cap && !dev_exc)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_export_i8: depth already materialised");
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    HIPOK(c, hipMemsetAsync(dev_count, 0, 4, c->stream));
+    { ProfScope ps(c, "export_i8");
+      launch_export_i8(c->stream, c->buf, c->hstate, dev_i8, c->n_cells, threshold, dev_exc, exc_cap, dev_count); }
+    HIPOK(c, hipGetLastError());
+    return PD_OK;
+}
+
+int pd_import_i8(pd_ctx *c, const void *dev_i8, int bias, const pd_exc *dev_exc, uint64_t n_exc)
+{
+    if (!c || !dev_i8 || bias < 0 || bias > 255 || (n_exc && !dev_exc)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_import_i8: depth already materialised");
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    { ProfScope ps(c, "import_i8");
+      launch_import_i8(c->stream, dev_i8, c->buf, c->n_cells, bias, dev_exc, n_exc); }
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemsetAsync(c->hstate, 1, c->n_half, c->stream));      // every cell was just written
+    c->all_valid_host = true;
+    launch_mark_all_valid(c->stream, c->chk);
     return PD_OK;
 }
 

@@ -64,6 +64,7 @@ void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, cons
                           uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk, unsigned grid_tiles);
 void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,
                          bool only_if_overflow, unsigned grid);
+void launch_mark_all_valid(hipStream_t st, CheckWords *chk);
 void launch_scatter_finish(hipStream_t st, const PendSet &ps, int *diff, int *sums, const uint64_t *ovf,
                            uint32_t ovf_cap, CheckWords *chk);
 void launch_tile_carry(hipStream_t st, const int *sums, int *bsum, int *carry, uint32_t n_tiles);
@@ -73,6 +74,10 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
                          TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth,
                          const uint8_t *hstate);
+void launch_export_i8(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells, int thr,
+                      pd_exc *exc, uint32_t cap, uint32_t *count);
+void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cells, int bias, const pd_exc *exc,
+                      uint64_t n_exc);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
                           uint32_t min_dep, int *cover, unsigned long long *sum);
 

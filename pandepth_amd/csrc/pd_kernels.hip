@@ -611,6 +611,78 @@ __global__ __launch_bounds__(WG) void k_reduce_pieces(const int *depth, const Pi
 }
 
 // ------------------------------------------------------------------------------------------
+// int8 transport of the difference arrays for the multi-sample sum (xGMI is the bottleneck there:
+// 4x fewer bytes on the links).  Cells with |d| <= thr travel as int8 (thr = 127 / world, so the
+// sum over all ranks cannot overflow); the rare others (pile-ups) travel as (cell, value)
+// exceptions and are zero in the image.  Bytes are stored BIASED (d + thr, an unsigned value in
+// [0, 2 thr]): the sum over the ranks stays below 256 in every byte, so the collective can add the
+// image as int32 words (four cells per element, no carry between bytes) at full int32 reduce
+// speed; the importer subtracts n_ranks * thr.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_export_i8(const int *diff, const uint8_t *hstate, int4 *out, uint64_t n_cells,
+                                                  int thr, pd_exc *exc, uint32_t cap, uint32_t *count)
+{
+    const uint64_t n16 = n_cells / 16;
+    for (uint64_t i = blockIdx.x * (uint64_t)WG + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * WG) {
+        const uint64_t c0 = i * 16;
+        const unsigned zb = (unsigned)thr * 0x01010101u;          // four cells of value 0
+        int4 o = make_int4((int)zb, (int)zb, (int)zb, (int)zb);
+        if (hstate[c0 / PD_HALF]) {                              // never-written half-tiles are zeros
+            const int4 *p = reinterpret_cast<const int4 *>(diff + c0);
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int4 q = p[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int x = v[k];
+                if (x > thr || x < -thr) {
+                    const uint32_t slot = atomicAdd(count, 1u);
+                    if (slot < cap) { exc[slot].cell = c0 + k; exc[slot].value = x; exc[slot].pad = 0; }
+                    x = 0;
+                }
+                w[k >> 2] |= (unsigned)((x + thr) & 0xff) << (8 * (k & 3));
+            }
+            o = make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]);
+        }
+        out[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_import_i8(const int4 *in, int *diff, uint64_t n_cells, int bias)
+{
+    const uint64_t n16 = n_cells / 16;
+    for (uint64_t i = blockIdx.x * (uint64_t)WG + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * WG) {
+        const int4 q = in[i];
+        const unsigned w[4] = {(unsigned)q.x, (unsigned)q.y, (unsigned)q.z, (unsigned)q.w};
+        int4 *p = reinterpret_cast<int4 *>(diff + i * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            p[k] = make_int4((int)(w[k] & 0xff) - bias, (int)((w[k] >> 8) & 0xff) - bias,
+                             (int)((w[k] >> 16) & 0xff) - bias, (int)(w[k] >> 24) - bias);
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_apply_exceptions(const pd_exc *exc, uint64_t n, int *diff, uint64_t n_cells)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG)
+        if (exc[i].cell < n_cells) atomicAdd(&diff[exc[i].cell], exc[i].value);
+}
+
+void launch_export_i8(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells, int thr,
+                      pd_exc *exc, uint32_t cap, uint32_t *count)
+{
+    hipLaunchKernelGGL(k_export_i8, dim3(8192), dim3(WG), 0, st, diff, hstate, (int4 *)out, n_cells, thr, exc, cap, count);
+}
+
+void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cells, int bias, const pd_exc *exc,
+                      uint64_t n_exc)
+{
+    hipLaunchKernelGGL(k_import_i8, dim3(8192), dim3(WG), 0, st, (const int4 *)in, diff, n_cells, bias);
+    if (n_exc) hipLaunchKernelGGL(k_apply_exceptions, dim3(256), dim3(WG), 0, st, exc, n_exc, diff, n_cells);
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers (called from pd_capi.hip)
 // ------------------------------------------------------------------------------------------
 void launch_fill(hipStream_t st, void *p, size_t bytes)
@@ -656,6 +728,11 @@ void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_
     hipLaunchKernelGGL(k_fill_invalid, dim3(grid), dim3(WG), 0, st, (int4 *)diff, hstate, n_half, chk,
                        only_if_overflow ? 1 : 0);
     if (!only_if_overflow) hipLaunchKernelGGL(k_mark_all_valid, dim3(1), dim3(1), 0, st, chk);
+}
+
+void launch_mark_all_valid(hipStream_t st, CheckWords *chk)
+{
+    hipLaunchKernelGGL(k_mark_all_valid, dim3(1), dim3(1), 0, st, chk);
 }
 
 void launch_scatter_finish(hipStream_t st, const PendSet &ps, int *diff, int *sums, const uint64_t *ovf,

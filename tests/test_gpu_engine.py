@@ -304,3 +304,65 @@ def test_buffer_view_is_zero_copy_and_linear():
         torch.cuda.synchronize()
         e1.scan(18)
         check_depth(e1, LENS, d, off)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_int8_transport_of_difference_arrays(world):
+    """pd_export_i8 / pd_import_i8: summing the int8 images (+ exceptions) of several samples and
+    importing the result equals pushing every sample into one context (list mode, PD:2704-3014)."""
+    import torch
+    from pandepth_amd import multi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(30 + world)
+    samples = []
+    for r in range(world):
+        iv = rand_intervals(rng, LENS, 30000)
+        if r < 2:                                                   # pile-ups beyond +-127/world: exceptions
+            iv = np.concatenate([iv, np.tile(np.array([[1, 700 + r, 900]], dtype=np.int32), (300, 1))])
+        samples.append(iv)
+    d, off = oracle_depth(LENS, np.concatenate(samples), True)
+    thr = 127 // world
+    engines = [pda.Engine(LENS) for _ in range(world)]
+    try:
+        total_i8, excs, sums = None, [], None
+        for e, iv in zip(engines, samples):
+            e.push_intervals(sort_iv(iv), pda.PD_PUSH_SORTED)
+            n_cells, n_sums = e.device_layout()
+            i8 = torch.empty(n_cells, dtype=torch.uint8, device=dev)
+            exc = torch.zeros((4096, 2), dtype=torch.int64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            e.export_i8(thr, i8.data_ptr(), exc.data_ptr(), 4096, cnt.data_ptr())
+            e.synchronize()
+            k = int(cnt.item())
+            assert k <= 4096
+            assert int(i8.max().item()) <= 2 * thr                         # biased bytes: d + thr
+            excs.append(exc[:k].clone())
+            view = multi.buffer_view(e, dev)
+            w = i8.view(torch.int32)                                        # the collective adds int32 WORDS
+            total_i8 = w.clone() if total_i8 is None else total_i8 + w
+            sums = view[n_cells:].clone() if sums is None else sums + view[n_cells:]
+        allx = torch.cat(excs, 0).contiguous()
+        assert allx.shape[0] >= 2                                     # the pile-ups did not fit int8
+        root = engines[0]
+        multi.buffer_view(root, dev)[root.device_layout()[0]:] = sums
+        torch.cuda.synchronize()
+        root.import_i8(total_i8.data_ptr(), world * thr, allx.data_ptr(), allx.shape[0])
+        root.scan(18)
+        check_depth(root, LENS, d, off)
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_packed_sum_single_rank_roundtrip():
+    import torch
+    from pandepth_amd import multi
+    rng = np.random.default_rng(41)
+    iv = np.concatenate([rand_intervals(rng, LENS, 50000), np.tile(np.array([[0, 10, 50]], dtype=np.int32), (1000, 1))])
+    d, off = oracle_depth(LENS, iv)
+    with pda.Engine(LENS) as e:
+        e.push_intervals(iv)
+        ps = multi.PackedSum(e, torch.device("cuda", 0))
+        assert ps.run(0) is True
+        e.scan(0)
+        check_depth(e, LENS, d, off)
