@@ -16,6 +16,7 @@
 #include <chrono>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include "bam.h"
@@ -310,27 +311,59 @@ inline char *put_u32(char *p, uint32_t v)
     return p;
 }
 
-bool write_site_depth(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng)
+// formats cells [b, b+n) of one contig as "name\tindex\tdepth\n" (PD:4278-4281: the index is 0-based)
+void format_sites(const std::string &nm, uint32_t b, const uint32_t *d, size_t n, std::string *out)
 {
+    out->resize(n * (nm.size() + 24));
+    char *p0 = &(*out)[0], *p = p0;
+    for (size_t j = 0; j < n; ++j) {
+        memcpy(p, nm.data(), nm.size()); p += nm.size();
+        *p++ = '\t'; p = put_u32(p, b + (uint32_t)j); *p++ = '\t'; p = put_u32(p, d[j]); *p++ = '\n';
+    }
+    out->resize((size_t)(p - p0));
+}
+
+// <prefix>.SiteDepth.gz (PD:4264-4284).  Up to PANDEPTH_SITE_PARALLEL_MIN bytes of text (default
+// 256 MiB) the file is ONE zlib stream, byte-identical to the reference's.  Larger outputs (a 3 Gb
+// genome is ~60 GB of text, ten minutes of single-threaded formatting + deflate in the reference)
+// are written as concatenated gzip members produced by the reader threads: same decompressed
+// bytes, different .gz bytes.
+bool write_site_depth(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
+{
+    uint64_t estimate = 0;
+    for (size_t t = 0; t < hdr.names.size(); ++t)
+        if (rm.has((int32_t)t)) estimate += (uint64_t)hdr.lens[t] * (hdr.names[t].size() + 12);
+    uint64_t par_min = (uint64_t)256 << 20;
+    if (const char *e = getenv("PANDEPTH_SITE_PARALLEL_MIN")) par_min = strtoull(e, nullptr, 10);
+    const size_t CH = (size_t)4 << 20;
+    if (estimate >= par_min && threads > 1) {
+        ParallelGzWriter out;
+        if (!out.open(path, threads)) { std::cerr << "open OUT File error: " << path << std::endl; return false; }
+        for (size_t t = 0; t < hdr.names.size(); ++t) {
+            if (!rm.has((int32_t)t)) continue;
+            const uint32_t len = hdr.lens[t];
+            for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
+                const size_t n = std::min<size_t>(CH, len - b);
+                auto d = std::make_shared<std::vector<uint32_t>>(n);
+                if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d->data()), "pd_read_depth")) { out.close(); return false; }
+                const std::string *nm = &hdr.names[t];
+                out.submit([d, nm, b, n](std::string *txt) { format_sites(*nm, b, d->data(), n, txt); });
+            }
+        }
+        return out.close();
+    }
     GzWriter out;
     if (!out.open(path)) { std::cerr << "open OUT File error: " << path << std::endl; return false; }
-    const size_t CH = (size_t)4 << 20;
     std::vector<uint32_t> d(CH);
-    std::vector<char> txt;
+    std::string txt;
     for (size_t t = 0; t < hdr.names.size(); ++t) {
         if (!rm.has((int32_t)t)) continue;
-        const std::string &nm = hdr.names[t];
         const uint32_t len = hdr.lens[t];
-        txt.resize(CH * (nm.size() + 24));
         for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
             const size_t n = std::min<size_t>(CH, len - b);
             if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) return false;
-            char *p = txt.data();
-            for (size_t j = 0; j < n; ++j) {
-                memcpy(p, nm.data(), nm.size()); p += nm.size();
-                *p++ = '\t'; p = put_u32(p, b + (uint32_t)j); *p++ = '\t'; p = put_u32(p, d[j]); *p++ = '\n';
-            }
-            out.write(txt.data(), (size_t)(p - txt.data()));
+            format_sites(hdr.names[t], b, d.data(), n, &txt);
+            out.write(txt);
         }
     }
     return out.close();
@@ -440,7 +473,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
 
     if (o.site_out) {
         if (!need_scan()) return bail();
-        if (!write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng)) { if (!eng.ok()) return bail(); }
+        if (!write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng, o.threads)) { if (!eng.ok()) return bail(); }
+        tm.mark("per-site file");
     }
 
     const size_t nctg = hdr.lens.size();

@@ -5,6 +5,7 @@
 #ifndef PD_REPORT_H_
 #define PD_REPORT_H_
 #include <stdint.h>
+#include <functional>
 #include <string>
 
 namespace pdh {
@@ -19,6 +20,23 @@ public:
     bool good() const { return f_ != nullptr; }
 private:
     void *f_ = nullptr;
+};
+
+// Large per-site outputs: text chunks are produced AND deflated on worker threads, each chunk
+// becoming its own gzip member; members are written in submission order.  Concatenated members are
+// one valid .gz whose decompressed content is exactly the concatenated text (the byte stream of the
+// .gz differs from a single-member file, which is why small outputs do not use this).
+class ParallelGzWriter {
+public:
+    ParallelGzWriter();
+    ~ParallelGzWriter();
+    bool open(const std::string &path, int threads);
+    // `make` fills the text of the next chunk; it runs on a worker thread
+    void submit(std::function<void(std::string *)> make);
+    bool close();
+private:
+    struct Impl;
+    Impl *p_;
 };
 
 std::string fmt2(double v);          // "%.2f"

@@ -96,3 +96,21 @@ def test_region_quirks(cli, tmp_path):
     rows = stat(tmp_path / "b.bed.stat.gz").split("\n")
     assert rows[1] == "r\t10\t20\tr_010_20\t22\t22\t22\t100.00\t1.00"
     assert p.stderr.decode().count("Warning: This region may be incorrect.") == 2
+
+
+def test_parallel_site_writer_same_text_as_single_stream(cli, tmp_path, golden_dir):
+    """Above a size threshold the per-site file is written as concatenated gzip members by several
+    threads: different .gz bytes, identical decompressed bytes (and still one valid gzip file)."""
+    d = os.path.join(golden_dir, "f3")
+    for name, env in (("serial", {}), ("par", {"PANDEPTH_SITE_PARALLEL_MIN": "1"})):
+        p = subprocess.run([cli, "-i", "tiny.bam", "-w", "100", "-a", "-t", "4", "-o", str(tmp_path / name)], cwd=d,
+                           env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-300:]
+    a = (tmp_path / "serial.SiteDepth.gz").read_bytes()
+    b = (tmp_path / "par.SiteDepth.gz").read_bytes()
+    assert a != b and gzip.decompress(a) == gzip.decompress(b)
+    assert (tmp_path / "serial.win.stat.gz").read_bytes() == (tmp_path / "par.win.stat.gz").read_bytes()
+    import hashlib, json
+    m = [e for e in json.load(open(os.path.join(golden_dir, "manifest.json"))) if e["fixture"] == "f3" and e["name"] == "w100_a"][0]
+    assert hashlib.sha256(gzip.decompress(b)).hexdigest() == m["outputs"]["SiteDepth.gz"]["text_sha256"]
+    assert hashlib.sha256(a).hexdigest() == m["outputs"]["SiteDepth.gz"]["gz_sha256"]
