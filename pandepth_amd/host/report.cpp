@@ -41,7 +41,7 @@ struct ParallelGzWriter::Impl {
     FILE *f = nullptr;
     std::vector<std::thread> th;
     std::mutex mu;
-    std::condition_variable cv_job, cv_done, cv_room;
+    std::condition_variable cv_job, cv_done;      // cv_done: a member finished OR was written
     std::deque<std::pair<uint64_t, std::function<void(std::string *)>>> jobs;
     std::map<uint64_t, std::string> done;
     uint64_t next_submit = 0, next_write = 0;
@@ -92,7 +92,6 @@ struct ParallelGzWriter::Impl {
             lk.unlock();
             if (!m.empty() && fwrite(m.data(), 1, m.size(), f) != m.size()) ok = false;
             lk.lock();
-            cv_room.notify_all();
         }
     }
 };
@@ -113,8 +112,11 @@ bool ParallelGzWriter::open(const std::string &path, int threads)
 void ParallelGzWriter::submit(std::function<void(std::string *)> make)
 {
     std::unique_lock<std::mutex> lk(p_->mu);
-    p_->drain(lk);
-    p_->cv_room.wait(lk, [&] { p_->drain(lk); return p_->next_submit - p_->next_write < p_->max_inflight; });
+    for (;;) {
+        p_->drain(lk);                                   // the submitting thread is the writer
+        if (p_->next_submit - p_->next_write < p_->max_inflight) break;
+        p_->cv_done.wait(lk);                            // woken by every finished member
+    }
     p_->jobs.emplace_back(p_->next_submit++, std::move(make));
     lk.unlock();
     p_->cv_job.notify_one();

@@ -114,3 +114,25 @@ def test_parallel_site_writer_same_text_as_single_stream(cli, tmp_path, golden_d
     m = [e for e in json.load(open(os.path.join(golden_dir, "manifest.json"))) if e["fixture"] == "f3" and e["name"] == "w100_a"][0]
     assert hashlib.sha256(gzip.decompress(b)).hexdigest() == m["outputs"]["SiteDepth.gz"]["text_sha256"]
     assert hashlib.sha256(a).hexdigest() == m["outputs"]["SiteDepth.gz"]["gz_sha256"]
+
+
+def test_parallel_site_writer_backpressure(cli, tmp_path):
+    """More chunks than the writer keeps in flight (regression: the submitter must keep draining)."""
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:30000000\nr\t0\tc\t1000\t60\t100M\t*\t0\t0\t*\t*\n"
+    (tmp_path / "big.sam").write_text(sam)
+    p = subprocess.run([cli, "-i", "big.sam", "-a", "-t", "2", "-o", "o"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    import zlib
+    d = zlib.decompressobj(31)
+    n_lines, members, tail = 0, 1, b""
+    raw = (tmp_path / "o.SiteDepth.gz").read_bytes()
+    while raw:
+        out = d.decompress(raw)
+        n_lines += out.count(b"\n")
+        if out:
+            tail = out[-40:]
+        raw = d.unused_data
+        if raw:
+            d = zlib.decompressobj(31); members += 1
+    assert n_lines == 30000000 and members >= 7 and tail.endswith(b"c\t29999999\t0\n")
