@@ -527,11 +527,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         const int rc = scanned ? api->reduce_windows(eng.ctx, width, min_dep, cov.data(), sum.data())
                                : api->scan_reduce_windows(eng.ctx, width, min_dep, wrap_bits, cov.data(), sum.data());
         if (!eng.ck(rc, "window reduction")) return bail();
-        for (auto &kv : rm.genes)
-            for (auto &g : kv.second) {
-                const uint64_t k = (uint64_t)(g.second.start - 1) / width;
-                g.second.cover = (int32_t)cov[woff[kv.first] + k];
-                g.second.depth = sum[woff[kv.first] + k];
+        for (auto &kv : rm.bins)
+            for (Bin &b : kv.second) {
+                const uint64_t k = (uint64_t)(b.start - 1) / width;
+                b.cover = (int32_t)cov[woff[kv.first] + k];
+                b.depth = sum[woff[kv.first] + k];
             }
     } else {
         if (!need_scan()) return bail();
@@ -553,12 +553,26 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
 
     OUT.write(header_line);
     if (o.mode == 0) {
-        for (auto &kv : rm.genes) {
+        for (auto &kv : rm.bins) {
             uint64_t L = 0, C = 0, D = 0;
-            for (auto &g : kv.second) { L += g.second.length; C += (uint64_t)(int64_t)g.second.cover; D += g.second.depth; }
+            for (const Bin &b : kv.second) { L += (uint64_t)(b.end - b.start + 1); C += (uint64_t)(int64_t)b.cover; D += b.depth; }
             SL += L; SC += C; SD += D;
             OUT.write(hdr.names[kv.first] + "\t" + std::to_string(L) + "\t" + std::to_string(C) + "\t" + std::to_string(D) +
                       "\t" + fmt2(C * 100.0 / L) + "\t" + fmt2(D * 1.0 / L) + "\n");
+        }
+    } else if (o.mode == 5) {
+        for (auto &kv : rm.bins) {
+            const std::string &chr = hdr.names[kv.first];
+            txt.clear();
+            for (const Bin &b : kv.second) {
+                const uint64_t L = (uint64_t)(b.end - b.start + 1);
+                SC += (uint64_t)(int64_t)b.cover; SL += L; SD += b.depth;
+                txt += chr; txt += '\t'; txt += std::to_string(b.start); txt += '\t'; txt += std::to_string(b.end); txt += '\t';
+                txt += std::to_string(L); txt += '\t'; txt += std::to_string(b.cover); txt += '\t'; txt += std::to_string(b.depth);
+                txt += '\t'; txt += fmt2(b.cover * 100.0 / L); txt += '\t'; txt += fmt2(b.depth * 1.0 / L); txt += '\n';
+                if (txt.size() > (1u << 22)) { OUT.write(txt); txt.clear(); }
+            }
+            OUT.write(txt);
         }
     } else {
         for (auto &kv : rm.genes) {

@@ -146,15 +146,19 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
             long long start = 1, end = 2;
             // the loop condition tests the PREVIOUS bin's end + 2: contigs shorter than 2 get no bin,
             // and a final 1-base bin (len = k*width + 1) is never created
+            std::vector<Bin> *v = nullptr;
+            std::vector<std::pair<int32_t, int32_t>> *m = nullptr;
             for (start = 1; end <= len; start += width) {
                 end = start + width - 1;
                 if (end > len) end = len;
-                add_entry(rm, (int32_t)i, hdr.names[i] + std::to_string(start), start, end);
+                if (!v) { v = &rm->bins[(int32_t)i]; m = &rm->merged[(int32_t)i]; }
+                Bin b; b.start = (int32_t)start; b.end = (int32_t)end;
+                v->push_back(b);
+                // merge rule of PD:3959: the next bin starts at end+1 > end, so every bin stays its own span
+                m->emplace_back((int32_t)start, (int32_t)end);
                 end += 2;
             }
         }
-        rm->merged.clear();
-        merge_spans(rm);
     }
     return true;
 }

@@ -22,8 +22,14 @@ struct Gene {
     uint64_t depth = 0;
 };
 
+struct Bin { int32_t start, end; int32_t cover = 0; uint64_t depth = 0; };   // one synthetic bin (1-based inclusive)
+
 struct RegionModel {
-    std::map<int32_t, std::map<std::string, Gene>> genes;           // tid -> id -> Gene
+    std::map<int32_t, std::map<std::string, Gene>> genes;           // tid -> id -> Gene (GFF/GTF/BED targets)
+    // whole-contig bins of modes 0/5/6, in position order.  The reference keeps them in the same
+    // id-keyed map as genes (PD:4009) but only ever reports them by start (PD:5101-5116), which
+    // for bins is this order; a vector avoids millions of map nodes for -w 1000 on a 3 Gb genome.
+    std::map<int32_t, std::vector<Bin>> bins;
     std::map<int32_t, std::vector<std::pair<int32_t, int32_t>>> merged;   // tid -> sorted disjoint spans
     bool has(int32_t tid) const { return merged.find(tid) != merged.end(); }
 };
