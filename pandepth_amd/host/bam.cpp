@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <zlib.h>
 #include <algorithm>
 #include <map>
 
@@ -362,30 +363,95 @@ bool bai_build(const std::string &bam_path, std::string *err)
     return ok;
 }
 
+bool BaiIndex::load_csi(const std::string &path, std::string *err)
+{
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) { if (err) *err = "cannot open " + path; return false; }
+    std::vector<uint8_t> d;
+    uint8_t buf[1 << 16];
+    int n;
+    while ((n = gzread(f, buf, sizeof buf)) > 0) d.insert(d.end(), buf, buf + n);
+    gzclose(f);
+    size_t o = 0;
+    auto need = [&](size_t k) { return o + k <= d.size(); };
+    if (!need(16) || memcmp(d.data(), "CSI\1", 4) != 0) { if (err) *err = path + " is not a CSI index"; return false; }
+    min_shift = (int)le32(d.data() + 4); depth = (int)le32(d.data() + 8);
+    const uint32_t l_aux = le32(d.data() + 12);
+    o = 16 + l_aux;
+    if (min_shift < 1 || min_shift > 30 || depth < 1 || depth > 9 || !need(4)) { if (err) *err = path + ": unsupported CSI parameters"; return false; }
+    const uint32_t n_ref = le32(d.data() + o); o += 4;
+    linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {}); loffset.assign(n_ref, {});
+    const uint32_t meta_bin = (uint32_t)(((1ull << (3 * (depth + 1))) - 1) / 7 + 1);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (!need(4)) goto bad;
+        {
+            const uint32_t n_bin = le32(d.data() + o); o += 4;
+            uint64_t lo = UINT64_MAX, hi = 0;
+            for (uint32_t b = 0; b < n_bin; ++b) {
+                if (!need(16)) goto bad;
+                const uint32_t bin = le32(d.data() + o);
+                const uint64_t lof = le64(d.data() + o + 4);
+                const uint32_t n_chunk = le32(d.data() + o + 12); o += 16;
+                if (!need(16 * (size_t)n_chunk)) goto bad;
+                if (bin != meta_bin) {
+                    auto &v = bins[r][bin];
+                    loffset[r][bin] = lof;
+                    for (uint32_t c = 0; c < n_chunk; ++c) {
+                        const uint64_t cb = le64(d.data() + o + 16 * c), ce = le64(d.data() + o + 16 * c + 8);
+                        lo = std::min(lo, cb); hi = std::max(hi, ce);
+                        v.emplace_back(cb, ce);
+                    }
+                }
+                o += 16 * (size_t)n_chunk;
+            }
+            if (hi) { ref_beg[r] = lo; ref_end[r] = hi; }
+        }
+    }
+    return true;
+bad:
+    if (err) *err = path + ": truncated CSI index";
+    return false;
+}
+
+bool BaiIndex::load_for(const std::string &bam_path, std::string *err)
+{
+    if (file_exists(bam_path + ".bai") && load(bam_path + ".bai", err)) return true;
+    if (file_exists(bam_path + ".csi") && load_csi(bam_path + ".csi", err)) return true;
+    return false;
+}
+
 void BaiIndex::query(int32_t tid, int64_t beg0, int64_t end, std::vector<Chunk> *out) const
 {
     if (tid < 0 || (size_t)tid >= bins.size() || beg0 >= end) return;
     if (beg0 < 0) beg0 = 0;
-    if (end > ((int64_t)1 << 29)) end = (int64_t)1 << 29;
-    const auto &lin = linear[tid];
-    uint64_t min_off = 0;
-    if (!lin.empty()) {
-        const size_t w = (size_t)(beg0 >> 14);
-        min_off = w < lin.size() ? lin[w] : lin.back();
-    }
+    const int64_t maxpos = (int64_t)1 << (min_shift + 3 * depth);
+    if (end > maxpos) end = maxpos;
+    if (beg0 >= end) return;
     const auto &bm = bins[tid];
     const int64_t e = end - 1;
-    auto take = [&](uint32_t bin) {
-        auto it = bm.find(bin);
-        if (it == bm.end()) return;
-        for (const Chunk &c : it->second) if (c.second > min_off) out->push_back(c);
-    };
-    take(0);
-    for (int64_t k = 1 + (beg0 >> 26); k <= 1 + (e >> 26); ++k) take((uint32_t)k);
-    for (int64_t k = 9 + (beg0 >> 23); k <= 9 + (e >> 23); ++k) take((uint32_t)k);
-    for (int64_t k = 73 + (beg0 >> 20); k <= 73 + (e >> 20); ++k) take((uint32_t)k);
-    for (int64_t k = 585 + (beg0 >> 17); k <= 585 + (e >> 17); ++k) take((uint32_t)k);
-    for (int64_t k = 4681 + (beg0 >> 14); k <= 4681 + (e >> 14); ++k) take((uint32_t)k);
+    // lower bound on the file offset of anything overlapping [beg0, ...): BAI's linear index, or
+    // the loffset of the smallest existing CSI bin that contains beg0
+    uint64_t min_off = 0;
+    if (!linear.empty() && !linear[tid].empty()) {
+        const auto &lin = linear[tid];
+        const size_t w = (size_t)(beg0 >> 14);
+        min_off = w < lin.size() ? lin[w] : lin.back();
+    } else if (!loffset.empty()) {
+        for (int l = depth; l >= 0; --l) {
+            const uint32_t bin = (uint32_t)(((1ull << (3 * l)) - 1) / 7 + (uint64_t)(beg0 >> (min_shift + 3 * (depth - l))));
+            auto it = loffset[tid].find(bin);
+            if (it != loffset[tid].end()) { min_off = it->second; break; }
+        }
+    }
+    for (int l = 0; l <= depth; ++l) {
+        const int sh = min_shift + 3 * (depth - l);
+        const uint64_t base = ((1ull << (3 * l)) - 1) / 7;
+        for (int64_t k = beg0 >> sh; k <= e >> sh; ++k) {
+            auto it = bm.find((uint32_t)(base + (uint64_t)k));
+            if (it == bm.end()) continue;
+            for (const Chunk &c : it->second) if (c.second > min_off) out->push_back(c);
+        }
+    }
 }
 
 void BaiIndex::normalise(std::vector<Chunk> *v)
@@ -405,6 +471,8 @@ std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_part
     for (size_t r = 0; r < linear.size(); ++r) {
         if (ref_beg[r]) cand.push_back(ref_beg[r]);
         for (uint64_t v : linear[r]) if (v) cand.push_back(v);
+        if (linear[r].empty() && r < bins.size())              // CSI: chunk begins are record starts too
+            for (auto &b : bins[r]) for (const Chunk &c : b.second) cand.push_back(c.first);
     }
     std::sort(cand.begin(), cand.end());
     cand.erase(std::unique(cand.begin(), cand.end()), cand.end());

@@ -64,7 +64,12 @@ struct BaiIndex {
     std::vector<uint64_t> ref_beg, ref_end;       // per reference: span of its chunks (0,0 if none)
     typedef std::pair<uint64_t, uint64_t> Chunk;  // [begin, end) virtual offsets
     std::vector<std::unordered_map<uint32_t, std::vector<Chunk>>> bins;   // per reference
-    bool load(const std::string &path, std::string *err);
+    int min_shift = 14, depth = 5;                // BAI's fixed scheme; CSI stores its own
+    std::vector<std::unordered_map<uint32_t, uint64_t>> loffset;          // CSI: per-bin lower bound (no linear index)
+    bool load(const std::string &path, std::string *err);       // .bai
+    bool load_csi(const std::string &path, std::string *err);   // .csi (BGZF-compressed, SAM spec CSIv1)
+    // whichever of <bam>.bai / <bam>.csi exists and parses
+    bool load_for(const std::string &bam_path, std::string *err);
     // file ranges that can hold reads overlapping [beg0, end) of reference tid (binning scheme of
     // SAM spec §5.3, pruned with the linear index); appended to *out unsorted
     void query(int32_t tid, int64_t beg0, int64_t end, std::vector<Chunk> *out) const;

@@ -170,7 +170,7 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     BaiIndex bai;
     std::string err;
-    const bool have_bai = file_exists(path + ".bai") && bai.load(path + ".bai", &err);
+    const bool have_bai = bai.load_for(path, &err);        // .bai or .csi
     AlnReader probe;
     if (!probe.open(path, &err)) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
     if (!probe.is_bam()) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }

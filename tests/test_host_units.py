@@ -136,3 +136,17 @@ def test_parallel_site_writer_backpressure(cli, tmp_path):
         if raw:
             d = zlib.decompressobj(31); members += 1
     assert n_lines == 30000000 and members >= 7 and tail.endswith(b"c\t29999999\t0\n")
+
+
+def test_csi_index_is_used_like_bai(cli, tmp_path, golden_dir):
+    """Only a .csi next to the BAM (built by htslib, committed as a fixture): indexed semantics (uint32
+    cells, region fetch) and range-partitioned readers must give the golden tables of the .bai runs."""
+    import hashlib, json, shutil
+    shutil.copy(os.path.join(golden_dir, "f3", "tiny.bam"), tmp_path / "tiny.bam")
+    shutil.copy(os.path.join(golden_dir, "f3_csi", "tiny.bam.csi"), tmp_path / "tiny.bam.csi")
+    shutil.copy(os.path.join(golden_dir, "f3", "tiny.gff"), tmp_path / "tiny.gff")
+    man = {e["name"]: e for e in json.load(open(os.path.join(golden_dir, "manifest.json"))) if e["fixture"] == "f3"}
+    for name, args, suffix in (("chr", [], "chr.stat.gz"), ("gff", ["-g", "tiny.gff"], "gene.stat.gz"), ("w1000", ["-w", "1000"], "win.stat.gz")):
+        p = run(cli, ["-i", "tiny.bam", "-o", name, "-t", "3"] + args, tmp_path)
+        assert p.stdout.decode() == man[name]["stdout"]          # no "No Index mode" warning
+        assert hashlib.sha256((tmp_path / (name + "." + suffix)).read_bytes()).hexdigest() == man[name]["outputs"][suffix]["gz_sha256"]
