@@ -318,7 +318,9 @@ __global__ __launch_bounds__(WG) void k_fill_invalid(int4 *buf, uint8_t *hstate,
     if (only_if_overflow && chk->ovf_count == 0) return;
     const int4 z = make_int4(0, 0, 0, 0);
     for (uint32_t h = blockIdx.x; h < n_half; h += gridDim.x) {
-        if (hstate[h]) continue;                                 // uniform per workgroup
+        const bool written = hstate[h] != 0;
+        __syncthreads();                 // every wave has read the flag before thread 0 may set it
+        if (written) continue;                                   // uniform per workgroup
         int4 *p = buf + (size_t)h * (PD_HALF / 4);
         for (int j = threadIdx.x; j < PD_HALF / 4; j += WG) p[j] = z;
         if (threadIdx.x == 0) hstate[h] = 1;
