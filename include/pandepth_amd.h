@@ -162,6 +162,14 @@ int pd_synchronize(pd_ctx *ctx);
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 
+/* ---- experimental (GPU-side BGZF inflate; not yet on the CLI's path) ------------
+ * Inflates every block of a BGZF image held in host memory on the GPU (one lane per block) and
+ * copies the result back; variant 0 keeps the per-block Huffman tables in LDS, 1 in global
+ * memory.  kernel_ms = average kernel time over `reps` launches.  A measuring / validation entry:
+ * the production form will keep the inflated records on the device. */
+int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
+                      size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks);
+
 #ifdef __cplusplus
 }
 #endif

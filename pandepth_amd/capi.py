@@ -67,6 +67,8 @@ def load():
         "pd_device_layout": (I, [P, ctypes.POINTER(U64), ctypes.POINTER(U64)]),
         "pd_export_i8": (I, [P, I, P, P, ctypes.c_uint32, P]),
         "pd_import_i8": (I, [P, P, I, P, U64]),
+        "pd_x_bgzf_inflate": (I, [I, P, SZ, P, SZ, ctypes.POINTER(SZ), I, I, ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(ctypes.c_uint32)]),
         "pd_stream": (P, [P]),
         "pd_synchronize": (I, [P]),
         "pd_profile": (I, [P, I]),
@@ -82,7 +84,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -96,6 +98,23 @@ def as_iv(a):
     if a.dtype == IV_DTYPE:
         a = a.view(np.int32).reshape(-1, 3)
     return np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 3)
+
+
+def bgzf_inflate(data, variant=0, reps=1, device=0, want_output=True):
+    """pd_x_bgzf_inflate: returns (bytes or None, kernel_ms, n_blocks)."""
+    L = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n = ctypes.c_size_t()
+    ms = ctypes.c_double()
+    nb = ctypes.c_uint32()
+    # first call without output to learn the size
+    cap = int(buf.size) * 12 + (1 << 20)
+    out = np.empty(cap if want_output else 1, dtype=np.uint8)
+    rc = L.pd_x_bgzf_inflate(int(device), _ptr(buf), buf.size, _ptr(out) if want_output else None, out.size if want_output else 0,
+                             ctypes.byref(n), int(variant), int(reps), ctypes.byref(ms), ctypes.byref(nb))
+    if rc != 0:
+        raise PdError(rc, "pd_x_bgzf_inflate failed")
+    return (out[:n.value].tobytes() if want_output else None), float(ms.value), int(nb.value), int(n.value)
 
 
 class Engine:

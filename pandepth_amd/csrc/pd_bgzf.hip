@@ -1,0 +1,89 @@
+// pd_bgzf.hip — GPU-side BGZF inflate (the end-to-end lever: on the GPU box the
+// host gets 16 cores, and all of the CLI's wall time is libdeflate).  A BGZF file is a sequence of
+// independent <= 64 KiB DEFLATE members, so the blocks are decoded concurrently: ONE LANE PER
+// BLOCK, the per-block Huffman tables of a wave's 64 lanes in LDS (64 x 2208 B = 138 KiB, one
+// wave per CU) or in a global scratch area (many waves per CU, table lookups through L2).  The
+// decoder itself is pd_inflate_core.h, verified against zlib on the host.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "pd_inflate_core.h"
+#include "../../include/pandepth_amd.h"
+
+namespace {
+
+struct BlkDesc { uint64_t in_off; uint64_t out_off; uint32_t in_len; uint32_t out_len; };
+
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(64) void k_inflate_blocks(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk,
+                                                       uint8_t *out, int *status, pdi::Tables *scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_blk) return;
+    pdi::Tables *t = LDS_TABLES ? reinterpret_cast<pdi::Tables *>(smem) + threadIdx.x : scratch + i;
+    const BlkDesc d = blk[i];
+    status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, *t) : 0;
+}
+
+} // namespace
+
+extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
+                                 size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks_out)
+{
+    if (!host_bgzf || !out_len) return PD_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return PD_ENODEV;
+    const uint8_t *p = (const uint8_t *)host_bgzf;
+    std::vector<BlkDesc> blks;
+    size_t o = 0; uint64_t uo = 0;
+    while (o + 18 <= n_bytes) {
+        if (p[o] != 0x1f || p[o + 1] != 0x8b || !(p[o + 3] & 4)) return PD_EINVAL;
+        const uint32_t xlen = p[o + 10] | (p[o + 11] << 8);
+        uint32_t bsize = 0;
+        for (uint32_t x = 12; x + 4 <= 12 + xlen;) {
+            const uint32_t sl = p[o + x + 2] | (p[o + x + 3] << 8);
+            if (p[o + x] == 'B' && p[o + x + 1] == 'C' && sl == 2) { bsize = (p[o + x + 4] | (p[o + x + 5] << 8)) + 1; break; }
+            x += 4 + sl;
+        }
+        if (!bsize || o + bsize > n_bytes) return PD_EINVAL;
+        const uint32_t isize = p[o + bsize - 4] | (p[o + bsize - 3] << 8) | (p[o + bsize - 2] << 16) | ((uint32_t)p[o + bsize - 1] << 24);
+        blks.push_back(BlkDesc{o + 12 + xlen, uo, bsize - 12 - xlen - 8, isize});
+        uo += isize; o += bsize;
+    }
+    *out_len = uo;
+    if (n_blocks_out) *n_blocks_out = (uint32_t)blks.size();
+    if (host_out && out_cap < uo) return PD_EINVAL;
+    uint8_t *d_in = nullptr, *d_out = nullptr; BlkDesc *d_blk = nullptr; int *d_st = nullptr; pdi::Tables *d_scr = nullptr;
+    const uint32_t nb = (uint32_t)blks.size();
+    int rc = PD_OK;
+    hipEvent_t e0, e1;
+    if (hipMalloc(&d_in, n_bytes + 16) != hipSuccess || hipMalloc(&d_out, uo + 16) != hipSuccess ||
+        hipMalloc(&d_blk, (size_t)nb * sizeof(BlkDesc) + 16) != hipSuccess || hipMalloc(&d_st, (size_t)nb * 4 + 16) != hipSuccess) rc = PD_ENOMEM;
+    if (rc == PD_OK && variant == 1 && hipMalloc(&d_scr, (size_t)nb * sizeof(pdi::Tables)) != hipSuccess) rc = PD_ENOMEM;
+#define HIPV(x) do { if ((x) != hipSuccess) rc = PD_EHIP; } while (0)
+    if (rc == PD_OK) {
+        HIPV(hipMemcpy(d_in, p, n_bytes, hipMemcpyHostToDevice));
+        HIPV(hipMemcpy(d_blk, blks.data(), (size_t)nb * sizeof(BlkDesc), hipMemcpyHostToDevice));
+        HIPV(hipEventCreate(&e0)); HIPV(hipEventCreate(&e1));
+        const size_t lds = 64 * sizeof(pdi::Tables);
+        if (variant == 0) HIPV(hipFuncSetAttribute((const void *)k_inflate_blocks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int r = 0; r < reps + 1; ++r) {
+            if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
+            if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, dim3((nb + 63) / 64), dim3(64), lds, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
+            else hipLaunchKernelGGL(k_inflate_blocks<false>, dim3((nb + 63) / 64), dim3(64), 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
+        }
+        HIPV(hipEventRecord(e1, 0));
+        if (hipEventSynchronize(e1) != hipSuccess) rc = PD_EHIP;
+        float ms = 0; HIPV(hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms = ms / (reps > 0 ? reps : 1);
+        std::vector<int> st(nb);
+        HIPV(hipMemcpy(st.data(), d_st, (size_t)nb * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nb; ++i) if (st[i] != 0) { rc = PD_EHIP; fprintf(stderr, "pd_x_bgzf_inflate: block %u failed with %d\n", i, st[i]); break; }
+        if (host_out && rc == PD_OK) HIPV(hipMemcpy(host_out, d_out, uo, hipMemcpyDeviceToHost));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_blk); (void)hipFree(d_st); if (d_scr) (void)hipFree(d_scr);
+    return rc;
+}
