@@ -162,7 +162,28 @@ int pd_synchronize(pd_ctx *ctx);
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 
-/* ---- experimental (GPU-side BGZF inflate; not yet on the CLI's path) ------------
+/* ---- GPU-side BAM decode: replaces htslib's BGZF inflate + bam_read1 on the host
+ * (the producer side of PD:434) for whole-contig modes.  The caller hands over raw BGZF bytes of
+ * record-aligned file ranges ("units", e.g. cut at index offsets); the device inflates every block
+ * (one lane per block), walks the records of every unit, filters (flag & flag_mask, mapq <
+ * min_mapq, contigs shorter than 2) and scatters the M/=/X runs exactly as pd_push_intervals would.
+ *   blob            n_bytes of BGZF data (whole blocks, any order)
+ *   blocks[k]       deflate payload [in_off, in_off+in_len) of block k inside blob, and where its
+ *                   out_len inflated bytes go inside the batch's inflated buffer (out_off)
+ *   units[u]        records START in [start, stop) of the inflated buffer; bytes up to `avail`
+ *                   belong to the unit's blocks; first_block / n_blocks index `blocks`.  Units
+ *                   must be given in file order (the first-run array is then position sorted).
+ *   unit_status[u]  OUT: 0 = counted on the device; 1 = not counted, decode this unit on the host
+ *                   (a record runs past `avail`, or a CIGAR lives in the CG tag); 2 = corrupt data
+ * Synchronous: returns when the batch has been scattered.  Experimental: opt-in from the CLI with
+ * PANDEPTH_DEVICE_DECODE=1. */
+typedef struct pd_bgzf_block { uint64_t in_off, out_off; uint32_t in_len, out_len; } pd_bgzf_block;
+typedef struct pd_bgzf_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks; } pd_bgzf_unit;
+int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
+                       const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
+                       int32_t min_mapq, int32_t *unit_status, uint64_t *n_records);
+
+/* ---- experimental measuring entry for the inflate kernel alone -------------------------------
  * Inflates every block of a BGZF image held in host memory on the GPU (one lane per block) and
  * copies the result back; variant 0 keeps the per-block Huffman tables in LDS, 1 in global
  * memory.  kernel_ms = average kernel time over `reps` launches.  A measuring / validation entry:

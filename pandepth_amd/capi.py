@@ -67,6 +67,8 @@ def load():
         "pd_device_layout": (I, [P, ctypes.POINTER(U64), ctypes.POINTER(U64)]),
         "pd_export_i8": (I, [P, I, P, P, ctypes.c_uint32, P]),
         "pd_import_i8": (I, [P, P, I, P, U64]),
+        "pd_push_bgzf_units": (I, [P, P, SZ, P, ctypes.c_uint32, P, ctypes.c_uint32, U64, ctypes.c_uint32, ctypes.c_int32, P,
+                               ctypes.POINTER(U64)]),
         "pd_x_bgzf_inflate": (I, [I, P, SZ, P, SZ, ctypes.POINTER(SZ), I, I, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_uint32)]),
         "pd_stream": (P, [P]),
@@ -84,7 +86,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_push_bgzf_units", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -218,6 +220,23 @@ class Engine:
     def import_i8(self, i8_ptr, bias, exc_ptr, n_exc):
         self._ck(self.L.pd_import_i8(self.h, ctypes.c_void_p(int(i8_ptr)), int(bias),
                                      ctypes.c_void_p(int(exc_ptr) if n_exc else 0), int(n_exc)))
+
+    def push_bgzf_units(self, blob, blocks, units, inflated_bytes, flag_mask=1796, min_mapq=-1):
+        """blocks: (n,4) uint64-compatible rows {in_off, out_off, in_len, out_len}; units: rows
+        {start, stop, avail, first_block, n_blocks}.  Returns (unit_status int32 array, n_records)."""
+        blob = np.frombuffer(blob, dtype=np.uint8)
+        bd = np.zeros(len(blocks), dtype=np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4")]))
+        for k, name in enumerate(("in_off", "out_off", "in_len", "out_len")):
+            bd[name] = [b[k] for b in blocks]
+        ud = np.zeros(len(units), dtype=np.dtype([("start", "<u8"), ("stop", "<u8"), ("avail", "<u8"), ("first_block", "<u4"),
+                                                   ("n_blocks", "<u4")]))
+        for k, name in enumerate(("start", "stop", "avail", "first_block", "n_blocks")):
+            ud[name] = [u[k] for u in units]
+        st = np.zeros(max(1, len(units)), dtype=np.int32)
+        nrec = ctypes.c_uint64()
+        self._ck(self.L.pd_push_bgzf_units(self.h, _ptr(blob), blob.size, _ptr(bd), len(blocks), _ptr(ud), len(units),
+                                           int(inflated_bytes), int(flag_mask), int(min_mapq), _ptr(st), ctypes.byref(nrec)))
+        return st[:len(units)], int(nrec.value)
 
     def stream(self):
         return int(self.L.pd_stream(self.h) or 0)

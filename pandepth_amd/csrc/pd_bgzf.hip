@@ -10,11 +10,13 @@
 #include <string.h>
 #include <vector>
 #include "pd_inflate_core.h"
+#include "pd_bamdev_core.h"
+#include "pd_kernels.h"
 #include "../../include/pandepth_amd.h"
 
 namespace {
 
-struct BlkDesc { uint64_t in_off; uint64_t out_off; uint32_t in_len; uint32_t out_len; };
+typedef pd_bgzf_block BlkDesc;      // { in_off, out_off, in_len, out_len }
 
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(64) void k_inflate_blocks(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk,
@@ -28,7 +30,113 @@ __global__ __launch_bounds__(64) void k_inflate_blocks(const uint8_t *comp, cons
     status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, *t) : 0;
 }
 
+// thread per unit: record offsets (sequential by nature: each record's length says where the next
+// starts), plus the checks that send a unit back to the host (record past the inflated bytes,
+// CIGAR in the CG tag)
+__global__ __launch_bounds__(64) void k_walk_units(const uint8_t *buf, pdb::Unit *units, uint32_t n_units,
+                                                   uint64_t *rec_off, uint64_t rec_cap, const int *blk_status,
+                                                   const uint32_t *unit_first_blk, const uint32_t *unit_n_blk)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_units) return;
+    pdb::Unit u = units[i];
+    int bad = 0;
+    for (uint32_t b = 0; b < unit_n_blk[i]; ++b) if (blk_status[unit_first_blk[i] + b] != 0) bad = 1;
+    if (bad) { u.n_rec = 0; u.status = 2; units[i] = u; return; }
+    pdb::walk_unit(buf, u, rec_off, rec_cap);
+    if (u.status == 0) {
+        for (uint32_t k = 0; k < u.n_rec; ++k) {          // long-CIGAR placeholder (SAM spec §4.2.2) -> host
+            const uint8_t *rec = buf + rec_off[u.rec_base + k];
+            if (pdb::ld16(rec + 16) == 2) {
+                const uint8_t *cg = rec + 36 + rec[12];
+                if ((pdb::ld32(cg) & 0xf) == 4 && (pdb::ld32(cg) >> 4) == pdb::ld32(rec + 20) && (pdb::ld32(cg + 4) & 0xf) == 3) { u.status = 1; break; }
+            }
+        }
+    }
+    if (u.status != 0) u.n_rec = 0;
+    units[i] = u;
+}
+
+// dense record numbering over the units that stay on the device
+__global__ void k_unit_bases(const pdb::Unit *units, uint32_t n_units, uint64_t *dense_base)
+{
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n_units; ++i) { dense_base[i] = acc; acc += units[i].n_rec; }
+    dense_base[n_units] = acc;
+}
+
+// thread per record: first run into the dense, position-sorted array; the other runs appended to
+// the batch's unordered list with ONE atomic per wave
+__global__ __launch_bounds__(256) void k_parse_records(const uint8_t *buf, const pdb::Unit *units, uint32_t n_units,
+                                                       const uint64_t *dense_base, const uint64_t *rec_off,
+                                                       pdb::Filter f, const uint32_t *contig_len, pd_iv *first,
+                                                       pd_iv *other, uint32_t other_cap, uint32_t *other_count, uint32_t *err)
+{
+    const uint64_t n = dense_base[n_units];
+    const uint64_t j = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    const bool live = j < n;
+    const uint8_t *rec = nullptr;
+    if (live) {
+        uint32_t lo = 0, hi = n_units;                  // last unit with dense_base <= j
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dense_base[mid] <= j) lo = mid; else hi = mid; }
+        rec = buf + rec_off[units[lo].rec_base + (j - dense_base[lo])];
+    }
+    uint32_t n_other = 0;
+    pd_iv fr{0, 0, 0};
+    if (live) pdb::parse_record(rec, f, contig_len, &fr, [&](pd_iv) { ++n_other; });
+    // wave-level exclusive scan of the counts, one atomic for the wave
+    uint32_t incl = n_other;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += y; }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (total) {
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(other_count, total);
+        base = __shfl(base, 0);
+    }
+    if (live) {
+        first[j] = fr;
+        if (n_other) {
+            uint32_t w = base + incl - n_other;
+            pd_iv dummy;
+            pdb::parse_record(rec, f, contig_len, &dummy, [&](pd_iv v) { if (w < other_cap) other[w] = v; else atomicOr(err, 1u); ++w; });
+        }
+    }
+}
+
 } // namespace
+
+namespace pdk {
+
+void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
+                         int *status, void *scratch)
+{
+    hipLaunchKernelGGL(k_inflate_blocks<false>, dim3((n_blk + 63) / 64), dim3(64), 0, st, comp, blk, n_blk, out, status,
+                       (pdi::Tables *)scratch);
+}
+size_t bgzf_scratch_bytes(uint32_t n_blk) { return (size_t)n_blk * sizeof(pdi::Tables); }
+
+void launch_bam_walk(hipStream_t st, const uint8_t *buf, void *units, uint32_t n_units, uint64_t *rec_off, uint64_t rec_cap,
+                     const int *blk_status, const uint32_t *unit_first_blk, const uint32_t *unit_n_blk, uint64_t *dense_base)
+{
+    hipLaunchKernelGGL(k_walk_units, dim3((n_units + 63) / 64), dim3(64), 0, st, buf, (pdb::Unit *)units, n_units, rec_off,
+                       rec_cap, blk_status, unit_first_blk, unit_n_blk);
+    hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(1), 0, st, (const pdb::Unit *)units, n_units, dense_base);
+}
+
+void launch_bam_parse(hipStream_t st, const uint8_t *buf, const void *units, uint32_t n_units, const uint64_t *dense_base,
+                      uint64_t n_rec_upper, const uint64_t *rec_off, uint32_t flag_mask, int32_t min_mapq, int32_t n_contigs,
+                      const uint32_t *contig_len, pd_iv *first, pd_iv *other, uint32_t other_cap, uint32_t *other_count,
+                      uint32_t *err)
+{
+    if (!n_rec_upper) return;
+    pdb::Filter f{flag_mask, min_mapq, n_contigs};
+    hipLaunchKernelGGL(k_parse_records, dim3((unsigned)((n_rec_upper + 255) / 256)), dim3(256), 0, st, buf,
+                       (const pdb::Unit *)units, n_units, dense_base, rec_off, f, contig_len, first, other, other_cap,
+                       other_count, err);
+}
+
+} // namespace pdk
 
 extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
                                  size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks_out)

@@ -81,5 +81,16 @@ void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cell
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
                           uint32_t min_dep, int *cover, unsigned long long *sum);
 
+// GPU-side BAM decode (pd_bgzf.hip)
+void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
+                         int *status, void *scratch);
+size_t bgzf_scratch_bytes(uint32_t n_blk);
+void launch_bam_walk(hipStream_t st, const uint8_t *buf, void *units, uint32_t n_units, uint64_t *rec_off, uint64_t rec_cap,
+                     const int *blk_status, const uint32_t *unit_first_blk, const uint32_t *unit_n_blk, uint64_t *dense_base);
+void launch_bam_parse(hipStream_t st, const uint8_t *buf, const void *units, uint32_t n_units, const uint64_t *dense_base,
+                      uint64_t n_rec_upper, const uint64_t *rec_off, uint32_t flag_mask, int32_t min_mapq, int32_t n_contigs,
+                      const uint32_t *contig_len, pd_iv *first, pd_iv *other, uint32_t other_cap, uint32_t *other_count,
+                      uint32_t *err);
+
 } // namespace pdk
 #endif
