@@ -18,16 +18,19 @@ namespace {
 
 typedef pd_bgzf_block BlkDesc;      // { in_off, out_off, in_len, out_len }
 
-template <bool LDS_TABLES>
-__global__ __launch_bounds__(64) void k_inflate_blocks(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk,
-                                                       uint8_t *out, int *status, pdi::Tables *scratch)
+// One lane per block.  The fast (one-lookup) tables of a wave's 64 lanes live in LDS (64 x 576 B =
+// 36 KiB, four waves per CU); the cold canonical arrays in a global scratch area.  LDS_FAST = false
+// keeps everything in global memory (more waves per CU, every lookup through L2).
+template <bool LDS_FAST, int WAVES_PER_SIMD = 1>
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk,
+                                                                       uint8_t *out, int *status, pdi::Tables *scratch)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ pdi::Fast s_fast[LDS_FAST ? 64 : 1];
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_blk) return;
-    pdi::Tables *t = LDS_TABLES ? reinterpret_cast<pdi::Tables *>(smem) + threadIdx.x : scratch + i;
+    pdi::Fast &tf = LDS_FAST ? s_fast[threadIdx.x] : scratch[i].fast;
     const BlkDesc d = blk[i];
-    status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, *t) : 0;
+    status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tf, scratch[i].slow) : 0;
 }
 
 // thread per unit: record offsets (sequential by nature: each record's length says where the next
@@ -111,6 +114,8 @@ namespace pdk {
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                          int *status, void *scratch)
 {
+    // measured (tools/bgzf_gpu_bench.py): with everything in global memory more waves fit a CU and the
+    // kernel is faster (30 vs 23 GB/s at 98 K blocks) than with the fast tables in LDS
     hipLaunchKernelGGL(k_inflate_blocks<false>, dim3((n_blk + 63) / 64), dim3(64), 0, st, comp, blk, n_blk, out, status,
                        (pdi::Tables *)scratch);
 }
@@ -169,18 +174,17 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
     hipEvent_t e0, e1;
     if (hipMalloc(&d_in, n_bytes + 16) != hipSuccess || hipMalloc(&d_out, uo + 16) != hipSuccess ||
         hipMalloc(&d_blk, (size_t)nb * sizeof(BlkDesc) + 16) != hipSuccess || hipMalloc(&d_st, (size_t)nb * 4 + 16) != hipSuccess) rc = PD_ENOMEM;
-    if (rc == PD_OK && variant == 1 && hipMalloc(&d_scr, (size_t)nb * sizeof(pdi::Tables)) != hipSuccess) rc = PD_ENOMEM;
+    if (rc == PD_OK && hipMalloc(&d_scr, (size_t)nb * sizeof(pdi::Tables)) != hipSuccess) rc = PD_ENOMEM;
 #define HIPV(x) do { if ((x) != hipSuccess) rc = PD_EHIP; } while (0)
     if (rc == PD_OK) {
         HIPV(hipMemcpy(d_in, p, n_bytes, hipMemcpyHostToDevice));
         HIPV(hipMemcpy(d_blk, blks.data(), (size_t)nb * sizeof(BlkDesc), hipMemcpyHostToDevice));
         HIPV(hipEventCreate(&e0)); HIPV(hipEventCreate(&e1));
-        const size_t lds = 64 * sizeof(pdi::Tables);
-        if (variant == 0) HIPV(hipFuncSetAttribute((const void *)k_inflate_blocks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int r = 0; r < reps + 1; ++r) {
             if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
-            if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, dim3((nb + 63) / 64), dim3(64), lds, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
-            else hipLaunchKernelGGL(k_inflate_blocks<false>, dim3((nb + 63) / 64), dim3(64), 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
+            const dim3 g((nb + 63) / 64), b(64);
+            if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
+            else hipLaunchKernelGGL(k_inflate_blocks<false>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
         }
         HIPV(hipEventRecord(e1, 0));
         if (hipEventSynchronize(e1) != hipSuccess) rc = PD_EHIP;

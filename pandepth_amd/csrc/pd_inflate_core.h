@@ -21,7 +21,7 @@
 
 namespace pdi {
 
-enum { LL_FAST_BITS = 9, D_FAST_BITS = 6, MAX_BITS = 15 };
+enum { LL_FAST_BITS = 8, D_FAST_BITS = 5, MAX_BITS = 15 };
 
 template <int NSYM>
 struct HuffT {                // canonical code, symbols ordered by (length, value)
@@ -31,14 +31,17 @@ struct HuffT {                // canonical code, symbols ordered by (length, val
 typedef HuffT<288> HuffLL;
 typedef HuffT<32> HuffD;      // 30 distance codes / the 19 code-length codes
 
-struct Tables {               // per-block scratch: 2208 bytes (64 lanes fit the 160 KiB LDS of a CU)
-    uint16_t ll_fast[1 << LL_FAST_BITS];   // (symbol << 4) | length, 0 = code longer than LL_FAST_BITS
-    uint16_t d_fast[1 << D_FAST_BITS];
+struct Fast {                 // hot: one lookup per symbol.  576 bytes per lane -> a wave's 64 copies fit LDS 4x per CU
+    uint16_t ll[1 << LL_FAST_BITS];        // (symbol << 4) | length, 0 = code longer than LL_FAST_BITS
+    uint16_t d[1 << D_FAST_BITS];
+};
+struct Slow {                 // cold: canonical arrays for long codes + header scratch (global memory on the GPU)
     HuffLL ll;
     HuffD d;
     uint8_t cl[320];                       // code lengths of the block being set up
     uint8_t small[32];                     // the code-length code's lengths
 };
+struct Tables { Fast fast; Slow slow; };   // host convenience
 
 struct Bits {
     const uint8_t *in;
@@ -54,8 +57,7 @@ PDI_FN void bits_refill(Bits &b)
     while (b.cnt <= 32) {
         uint32_t w;
         if (b.pos + 4 <= b.end) {
-            w = (uint32_t)b.in[b.pos] | ((uint32_t)b.in[b.pos + 1] << 8) | ((uint32_t)b.in[b.pos + 2] << 16) |
-                ((uint32_t)b.in[b.pos + 3] << 24);
+            __builtin_memcpy(&w, b.in + b.pos, 4);           // one (possibly unaligned) 32-bit load, little-endian hosts/GPUs
             b.buf |= (uint64_t)w << b.cnt; b.cnt += 32; b.pos += 4;
         } else if (b.pos < b.end) {
             b.buf |= (uint64_t)b.in[b.pos] << b.cnt; b.cnt += 8; b.pos += 1;
@@ -130,7 +132,7 @@ PDI_FN int decode(Bits &b, const H &h, const uint16_t *fast, int fast_bits)
 // Inflates one raw DEFLATE stream of exactly out_len bytes.  Returns 0 on success, a negative
 // code otherwise (-1 bad block type, -2 bad stored block, -3 bad code lengths, -4 invalid code,
 // -5 output overrun / wrong size, -6 bad distance, -7 input overrun).
-PDI_FN_NOINLINE int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &t)
+PDI_FN_NOINLINE int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Fast &tf, Slow &t)
 {
     static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,
                                        131, 163, 195, 227, 258};
@@ -157,20 +159,20 @@ PDI_FN_NOINLINE int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *o
                 for (int i = 144; i < 256; ++i) t.cl[i] = 9;
                 for (int i = 256; i < 280; ++i) t.cl[i] = 7;
                 for (int i = 280; i < 288; ++i) t.cl[i] = 8;
-                if (build(t.ll, t.ll_fast, LL_FAST_BITS, t.cl, 288) < 0) return -3;
+                if (build(t.ll, tf.ll, LL_FAST_BITS, t.cl, 288) < 0) return -3;
                 for (int i = 0; i < 30; ++i) t.cl[i] = 5;
-                if (build(t.d, t.d_fast, D_FAST_BITS, t.cl, 30) < 0) return -3;
+                if (build(t.d, tf.d, D_FAST_BITS, t.cl, 30) < 0) return -3;
             } else {
                 const int nlen = (int)bits_get(b, 5) + 257, ndist = (int)bits_get(b, 5) + 1, ncode = (int)bits_get(b, 4) + 4;
                 if (nlen > 286 || ndist > 30) return -3;
                 for (int i = 0; i < 19; ++i) t.small[i] = 0;
                 for (int i = 0; i < ncode; ++i) t.small[CLORD[i]] = (uint8_t)bits_get(b, 3);
                 // the code-length code (<= 7 bits) borrows the distance tables until they are built
-                if (build(t.d, t.d_fast, D_FAST_BITS, t.small, 19) < 0) return -3;
+                if (build(t.d, tf.d, D_FAST_BITS, t.small, 19) < 0) return -3;
                 int idx = 0;
                 uint8_t *cl = t.cl;
                 while (idx < nlen + ndist) {
-                    const int sym = decode(b, t.d, t.d_fast, D_FAST_BITS);
+                    const int sym = decode(b, t.d, tf.d, D_FAST_BITS);
                     if (sym < 0) return -4;
                     if (sym < 16) cl[idx++] = (uint8_t)sym;
                     else {
@@ -183,24 +185,27 @@ PDI_FN_NOINLINE int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *o
                     }
                 }
                 if (cl[256] == 0) return -3;                             // no end-of-block code
-                if (build(t.ll, t.ll_fast, LL_FAST_BITS, cl, nlen) < 0) return -3;
-                if (build(t.d, t.d_fast, D_FAST_BITS, cl + nlen, ndist) < 0) return -3;
+                if (build(t.ll, tf.ll, LL_FAST_BITS, cl, nlen) < 0) return -3;
+                if (build(t.d, tf.d, D_FAST_BITS, cl + nlen, ndist) < 0) return -3;
             }
             for (;;) {
-                const int sym = decode(b, t.ll, t.ll_fast, LL_FAST_BITS);
+                const int sym = decode(b, t.ll, tf.ll, LL_FAST_BITS);
                 if (sym < 0) return -4;
                 if (sym < 256) { if (o >= out_len) return -5; out[o++] = (uint8_t)sym; continue; }
                 if (sym == 256) break;
                 if (sym > 285) return -4;
                 const int ls = sym - 257;
                 const uint32_t len = LBASE[ls] + bits_get(b, LEXT[ls]);
-                const int ds = decode(b, t.d, t.d_fast, D_FAST_BITS);
+                const int ds = decode(b, t.d, tf.d, D_FAST_BITS);
                 if (ds < 0 || ds > 29) return -4;
                 const uint32_t dist = DBASE[ds] + bits_get(b, DEXT[ds]);
                 if (dist > o) return -6;
                 if (o + len > out_len) return -5;
                 const uint8_t *src = out + o - dist;
-                for (uint32_t i = 0; i < len; ++i) out[o + i] = src[i];  // forward byte copy: overlap repeats the pattern
+                uint32_t i = 0;
+                if (dist >= 4)                                          // no overlap inside a 4-byte step
+                    for (; i + 4 <= len; i += 4) { uint32_t w; __builtin_memcpy(&w, src + i, 4); __builtin_memcpy(out + o + i, &w, 4); }
+                for (; i < len; ++i) out[o + i] = src[i];               // forward byte copy: overlap repeats the pattern
                 o += len;
                 if (bits_overrun(b)) return -7;
             }

@@ -23,6 +23,9 @@ typedef struct pd_engine_api {
     int (*reduce_windows)(pd_ctx *, uint32_t, uint32_t, uint32_t *, uint64_t *);
     int (*read_depth)(pd_ctx *, int32_t, uint32_t, size_t, uint32_t *);
     int (*synchronize)(pd_ctx *);
+    /* optional (NULL = not available): GPU-side BAM decode, see pd_push_bgzf_units */
+    int (*push_bgzf_units)(pd_ctx *, const void *, size_t, const pd_bgzf_block *, uint32_t, const pd_bgzf_unit *, uint32_t,
+                           uint64_t, uint32_t, int32_t, int32_t *, uint64_t *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -9,9 +9,12 @@
 //     read (PD:4679-4711);
 //   * the table text (PD:4879-5127) and the per-site file (PD:4264-4284).
 // The increment loop itself, the statistics and the window sweep run on the engine.
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <iostream>
@@ -164,6 +167,17 @@ struct SpanIndex {
 bool index_exists(const std::string &p) { return file_exists(p + ".bai") || file_exists(p + ".crai") || file_exists(p + ".csi"); }
 
 // ---- readers ---------------------------------------------------------------------------------
+// records that START in [begin, stop) of an open BAM, through the host decoder
+bool decode_range(AlnReader &rd, uint64_t begin, uint64_t stop, const ReadFilter &flt, const struct SpanIndex &spans,
+                  RunSink *sink, uint64_t *n_rec, std::string *err);
+
+// GPU-side decode of a whole-contig-mode BAM (PANDEPTH_DEVICE_DECODE=1): the host only reads the
+// compressed bytes and cuts them into record-aligned units at index offsets; inflate, record walk,
+// filter, CIGAR walk and scatter run on the device (pd_push_bgzf_units).  Units the device hands
+// back (a record spilling past the unit's blocks, CG-tag CIGARs) are decoded on the host.
+bool read_indexed_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const struct SpanIndex &spans,
+                         const BaiIndex &bai, uint64_t first_voff, Engine *eng);
+
 bool read_indexed(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans,
                   Engine *eng)
 {
@@ -179,6 +193,8 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     //  * GFF/BED targets: only the index chunks that can hold reads overlapping a (widened) merged
     //    span, like the reference's multi-region iterator (PD:698-730) — most of the file is
     //    never inflated.
+    if (have_bai && spans.synthetic && eng->api->push_bgzf_units && getenv("PANDEPTH_DEVICE_DECODE"))
+        return read_indexed_device(path, o, main_hdr, spans, bai, probe.tell(), eng);
     std::vector<BaiIndex::Chunk> work;
     int threads = o.threads < 1 ? 1 : o.threads;
     if (have_bai && !spans.synthetic) {
@@ -219,23 +235,12 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
         std::string e2;
         if (!rd.open(path, &e2)) { eng->fail(e2); return; }
         RunSink sink(eng);
-        AlnRec r;
         for (;;) {
             const size_t t = next.fetch_add(1);
             if (t >= n_tasks || !eng->ok()) break;
             for (size_t w = tasks[t].first; w < tasks[t].second; ++w) {
-                if (!rd.seek(work[w].first)) { eng->fail("seek failed in " + path); return; }
-                const uint64_t stop = work[w].second;
-                for (;;) {
-                    if (rd.tell() >= stop) break;
-                    const int k = rd.next(&r);
-                    if (k == 0) break;
-                    if (k < 0) { eng->fail(rd.error() + " (" + path + ")"); return; }
-                    ++my_rec;
-                    if (!flt.pass(r)) continue;
-                    if (!spans.hit(r)) continue;
-                    emit_runs(r, &sink);
-                }
+                std::string e3;
+                if (!decode_range(rd, work[w].first, work[w].second, flt, spans, &sink, &my_rec, &e3)) { eng->fail(e3 + " (" + path + ")"); return; }
             }
         }
     };
@@ -248,6 +253,136 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing] indexed read: %d threads, %zu ranges, %llu records, thread-seconds %.2f, inflate backend %s\n",
                 threads, n_tasks, (unsigned long long)n_rec.load(), busy_us.load() / 1e6, Inflater::backend());
+    return eng->ok();
+}
+
+bool decode_range(AlnReader &rd, uint64_t begin, uint64_t stop, const ReadFilter &flt, const SpanIndex &spans,
+                  RunSink *sink, uint64_t *n_rec, std::string *err)
+{
+    if (!rd.seek(begin)) { *err = "seek failed"; return false; }
+    AlnRec r;
+    for (;;) {
+        if (rd.tell() >= stop) break;
+        const int k = rd.next(&r);
+        if (k == 0) break;
+        if (k < 0) { *err = rd.error(); return false; }
+        ++*n_rec;
+        if (!flt.pass(r)) continue;
+        if (!spans.hit(r)) continue;
+        emit_runs(r, sink);
+    }
+    return true;
+}
+
+bool read_indexed_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans,
+                         const BaiIndex &bai, uint64_t first_voff, Engine *eng)
+{
+    const uint64_t F = file_size(path);
+    const uint64_t unit_bytes = (uint64_t)1 << 20;
+    uint64_t batch_bytes = (uint64_t)2048 << 20;
+    if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = strtoull(e, nullptr, 10) << 20;
+    std::vector<uint64_t> cuts = bai.split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / unit_bytes + 1));
+    // batches of consecutive units
+    std::vector<std::pair<size_t, size_t>> batches;       // [first unit, last unit)
+    for (size_t u = 0; u + 1 < cuts.size();) {
+        size_t v = u + 1;
+        while (v + 1 < cuts.size() && ((cuts[v] == UINT64_MAX ? F : (cuts[v] >> 16)) - (cuts[u] >> 16)) < batch_bytes) ++v;
+        batches.emplace_back(u, v);
+        u = v;
+    }
+    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    int threads = o.threads < 1 ? 1 : o.threads;
+    if ((size_t)threads > batches.size()) threads = (int)batches.size();
+    std::atomic<size_t> next{0};
+    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0};
+    auto worker = [&]() {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { eng->fail("cannot open " + path); return; }
+        AlnReader rd;                                         // only for handed-back units
+        bool rd_open = false;
+        std::vector<uint8_t> blob;
+        std::vector<pd_bgzf_block> blocks;
+        std::vector<uint64_t> coff;                           // file offset of each scanned block
+        std::vector<pd_bgzf_unit> units;
+        std::vector<int32_t> status;
+        RunSink sink(eng);
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= batches.size() || !eng->ok()) break;
+            const size_t u0 = batches[b].first, u1 = batches[b].second;
+            const uint64_t c0 = cuts[u0] >> 16;
+            const uint64_t c_end = cuts[u1] == UINT64_MAX ? F : std::min<uint64_t>(F, (cuts[u1] >> 16) + 4 * 65536);
+            blob.resize((size_t)(c_end - c0));
+            for (size_t got = 0; got < blob.size();) {
+                const ssize_t n = pread(fd, blob.data() + got, blob.size() - got, (off_t)(c0 + got));
+                if (n <= 0) { eng->fail("read error on " + path); ::close(fd); return; }
+                got += (size_t)n;
+            }
+            blocks.clear(); coff.clear();
+            uint64_t uo = 0;
+            for (size_t p = 0; p + 18 <= blob.size();) {
+                uint32_t doff = 0;
+                const uint32_t bs = bgzf_block_size(blob.data() + p, blob.size() - p, &doff);
+                if (bs == 0 || p + bs > blob.size()) break;   // partial block at the end of the window
+                const uint8_t *q = blob.data() + p;
+                const uint32_t isize = q[bs - 4] | (q[bs - 3] << 8) | (q[bs - 2] << 16) | ((uint32_t)q[bs - 1] << 24);
+                coff.push_back(c0 + p);
+                blocks.push_back(pd_bgzf_block{p + doff, uo, bs - doff - 8, isize});
+                uo += isize; p += bs;
+            }
+            auto block_of = [&](uint64_t file_off) -> long {
+                const auto it = std::lower_bound(coff.begin(), coff.end(), file_off);
+                return it != coff.end() && *it == file_off ? (long)(it - coff.begin()) : -1;
+            };
+            units.clear();
+            bool ok = !blocks.empty();
+            for (size_t u = u0; u < u1 && ok; ++u) {
+                const long fb = block_of(cuts[u] >> 16);
+                if (fb < 0) { ok = false; break; }
+                pd_bgzf_unit un;
+                un.start = blocks[fb].out_off + (cuts[u] & 0xffff);
+                long lb;
+                if (cuts[u + 1] == UINT64_MAX) { un.stop = uo; lb = (long)blocks.size() - 1; }
+                else {
+                    const long sb = block_of(cuts[u + 1] >> 16);
+                    if (sb < 0) { ok = false; break; }
+                    un.stop = blocks[sb].out_off + (cuts[u + 1] & 0xffff);
+                    lb = std::min<long>((long)blocks.size() - 1, sb + 1);      // one spare block for the last record
+                }
+                un.avail = blocks[lb].out_off + blocks[lb].out_len;
+                un.first_block = (uint32_t)fb; un.n_blocks = (uint32_t)(lb - fb + 1);
+                units.push_back(un);
+            }
+            if (!ok) { eng->fail("index offsets of " + path + " do not match its BGZF blocks"); break; }
+            status.assign(units.size(), 0);
+            uint64_t nrec = 0;
+            if (!eng->ck(eng->api->push_bgzf_units(eng->ctx, blob.data(), blob.size(), blocks.data(), (uint32_t)blocks.size(),
+                                                   units.data(), (uint32_t)units.size(), uo, o.flag_mask, o.min_mapq, status.data(),
+                                                   &nrec), "pd_push_bgzf_units")) break;
+            n_dev += nrec;
+            for (size_t k = 0; k < units.size(); ++k) {
+                if (status[k] == 0) continue;
+                if (status[k] != 1) { eng->fail("corrupt BGZF/BAM data in " + path); break; }
+                ++n_back;
+                std::string e2;
+                if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
+                uint64_t nr = 0;
+                if (!decode_range(rd, cuts[u0 + k], cuts[u0 + k + 1], flt, spans, &sink, &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); break; }
+                n_host += nr;
+            }
+        }
+        ::close(fd);
+    };
+    if (threads <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < threads; ++i) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    if (getenv("PANDEPTH_TIMING"))
+        fprintf(stderr, "[timing] device decode: %zu batches, %zu units, %llu records on the device, %llu units (%llu records) handed back to the host\n",
+                batches.size(), cuts.size() - 1, (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(),
+                (unsigned long long)n_host.load());
     return eng->ok();
 }
 

@@ -28,7 +28,7 @@ int main(int argc, char **argv)
             const unsigned doff = 12 + xlen;
             const unsigned isize = p[bsize - 4] | (p[bsize - 3] << 8) | (p[bsize - 2] << 16) | ((unsigned)p[bsize - 1] << 24);
             std::vector<unsigned char> mine(isize + 1, 0xEE), ref(isize + 1, 0);
-            const int rc = pdi::inflate_block(p + doff, bsize - doff - 8, mine.data(), isize, *t);
+            const int rc = pdi::inflate_block(p + doff, bsize - doff - 8, mine.data(), isize, t->fast, t->slow);
             z_stream zs; memset(&zs, 0, sizeof zs); inflateInit2(&zs, -15);
             zs.next_in = (Bytef *)(p + doff); zs.avail_in = bsize - doff - 8; zs.next_out = ref.data(); zs.avail_out = isize;
             const int zr = inflate(&zs, Z_FINISH); inflateEnd(&zs);
@@ -45,7 +45,7 @@ int main(int argc, char **argv)
             std::vector<unsigned char> out(70000);
             for (int k = 0; k < 2000; ++k) {
                 c[18 + (k * 7919) % 4000] ^= (unsigned char)(1 + k % 255);
-                (void)pdi::inflate_block(c.data() + 18, 4096 - 18, out.data(), 65536, *t);
+                (void)pdi::inflate_block(c.data() + 18, 4096 - 18, out.data(), 65536, t->fast, t->slow);
             }
         }
     }

@@ -126,6 +126,6 @@ static int o_sync(pd_ctx *) { return 0; }
 int main(int argc, char **argv)
 {
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
-                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync};
+                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr};
     return pandepth_main(argc, argv, &api, 0);
 }

@@ -33,3 +33,25 @@ def test_pandepth_cli_byte_identical(case, threads, tmp_path):
         gz = (tmp_path / ("o." + suffix)).read_bytes()
         assert hashlib.sha256(gzip.decompress(gz)).hexdigest() == meta["text_sha256"], suffix
         assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix + " (gz bytes)"
+
+
+DD_CASES = [e for e in MANIFEST if "-g" not in e["args"] and "-b" not in e["args"] and "-s" not in e["args"]
+            and e["args"][1].endswith(".bam") and "noidx" not in e["args"][1] and "unsorted" not in e["args"][1]]
+
+
+@pytest.mark.parametrize("batch_mb", ["", "1"])
+@pytest.mark.parametrize("case", DD_CASES, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_pandepth_cli_device_decode_byte_identical(case, batch_mb, tmp_path):
+    """PANDEPTH_DEVICE_DECODE=1: BGZF inflate + record parsing on the GPU for the whole-contig modes."""
+    d = os.path.join(HERE, "golden", case["fixture"])
+    env = dict(os.environ, PANDEPTH_DEVICE_DECODE="1", PANDEPTH_TIMING="1")
+    if batch_mb:
+        env["PANDEPTH_DD_BATCH_MB"] = batch_mb
+    args = [CLI] + case["args"] + ["-o", str(tmp_path / "o")] + ([] if "-t" in case["args"] else ["-t", "3"])
+    p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
+    assert b"device decode:" in p.stderr
+    assert p.stdout.decode() == case["stdout"]
+    for suffix, meta in case["outputs"].items():
+        gz = (tmp_path / ("o." + suffix)).read_bytes()
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix

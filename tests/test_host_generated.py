@@ -69,15 +69,20 @@ CASES = [
 BINARIES = [
     pytest.param(os.path.join(HERE, "harness", "pandepth_oracle_cli"), id="host+oracle-engine"),
     pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth"), id="pandepth-mi355x", marks=pytest.mark.gpu),
+    pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":dd", id="pandepth-mi355x-device-decode", marks=pytest.mark.gpu),
 ]
 
 
 @pytest.mark.parametrize("cli", BINARIES)
 @pytest.mark.parametrize("name,args,suffix", CASES, ids=[c[0] for c in CASES])
 def test_generated_inputs_match_reference(data, cli, name, args, suffix):
+    env = dict(os.environ)
+    if cli.endswith(":dd"):            # GPU-side BGZF inflate + record parsing (small batches: several per file)
+        cli = cli[:-3]
+        env.update(PANDEPTH_DEVICE_DECODE="1", PANDEPTH_DD_BATCH_MB="8")
     for t in ("1", "5"):
         p = subprocess.run([cli] + args + ["-o", "mine_" + name, "-t", t], cwd=data, stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=900)
+                           stderr=subprocess.PIPE, timeout=900, env=env)
         assert p.returncode == 0, p.stderr.decode()[-400:]
         mine = {s: (data / ("mine_%s.%s" % (name, s))).read_bytes() for s in [suffix] + (["SiteDepth.gz"] if "-a" in args else [])}
         if os.access(REF, os.X_OK):

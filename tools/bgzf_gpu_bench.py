@@ -21,7 +21,7 @@ bam = os.path.join(td, "p.bam")
 synth.write_bam(bam, names, lens, rec, procs=16, payload=True, level=int(os.environ.get("BGZF_LEVEL", "6")))
 data = open(bam, "rb").read()
 print("records %d, BGZF %.1f MB" % (R, len(data) / 1e6), flush=True)
-for variant, name in ((0, "tables in LDS (1 wave/CU)"), (1, "tables in global memory")):
+for variant, name in ((0, "fast tables in LDS (4 waves/CU)"), (1, "all tables in global memory")):
     t0 = time.perf_counter()
     out, ms, nb, n = capi.bgzf_inflate(data, variant=variant, reps=3, want_output=True)
     wall = time.perf_counter() - t0
