@@ -675,6 +675,7 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->state != 0) return fail(c, PD_ESTATE, "pd_push_bgzf_units: depth already materialised (call pd_reset)");
     HIPOK(c, hipSetDevice(c->device));
+    if (getenv("PANDEPTH_TIMING")) c->prof = true;
     int rc = flush_pending(c);
     if (rc) return rc;
     // host-side unit table: capacity-based slots in the record-offset array (a record is >= 36 bytes)
@@ -703,7 +704,8 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     uint8_t *d_blob = (uint8_t *)c->dd_buf[B_BLOB], *d_inf = (uint8_t *)c->dd_buf[B_INF];
     uint64_t *d_dense = (uint64_t *)c->dd_buf[B_DENSE];
     uint32_t *d_cnt = (uint32_t *)(d_dense + n_units + 1);            // {other_count, err}
-    HIPOK(c, hipMemcpyAsync(d_blob, blob, n_bytes, hipMemcpyHostToDevice, c->stream));
+    { ProfScope ps(c, "bgzf_h2d");
+      HIPOK(c, hipMemcpyAsync(d_blob, blob, n_bytes, hipMemcpyHostToDevice, c->stream)); }
     HIPOK(c, hipMemcpyAsync(c->dd_buf[B_BLK], blocks, need[B_BLK], hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(c->dd_buf[B_UNIT], hu.data(), need[B_UNIT], hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(c->dd_buf[B_UF], ufirst.data(), need[B_UF], hipMemcpyHostToDevice, c->stream));
@@ -735,6 +737,14 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     for (uint32_t i = 0; i < n_units; ++i) unit_status[i] = hu[i].status;
     if (n_records) *n_records = n_rec;
     HIPOK(c, hipGetLastError());
+    if (getenv("PANDEPTH_TIMING")) {
+        // per-kernel event times of this batch (profiling is switched on for the call when timing is requested)
+        for (const char *k : {"bgzf_h2d", "bgzf_inflate", "bam_walk", "bam_parse", "scatter_index", "scatter_tiles", "scatter_atomic", "fill"}) {
+            prof_collect(c);
+            auto it = c->prof_acc.find(k);
+            if (it != c->prof_acc.end()) fprintf(stderr, "[timing]   device %-14s %8.2f ms total over %llu launches\n", k, it->second.first, (unsigned long long)it->second.second);
+        }
+    }
     return PD_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -278,7 +279,9 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
                          const BaiIndex &bai, uint64_t first_voff, Engine *eng)
 {
     const uint64_t F = file_size(path);
-    const uint64_t unit_bytes = (uint64_t)1 << 20;
+    // units as fine as the index allows (a thread walks one unit's records sequentially)
+    uint64_t unit_bytes = (uint64_t)256 << 10;
+    if (const char *e = getenv("PANDEPTH_DD_UNIT_KB")) unit_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 10;
     uint64_t batch_bytes = (uint64_t)2048 << 20;
     if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = strtoull(e, nullptr, 10) << 20;
     std::vector<uint64_t> cuts = bai.split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / unit_bytes + 1));
@@ -294,7 +297,8 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
     int threads = o.threads < 1 ? 1 : o.threads;
     if ((size_t)threads > batches.size()) threads = (int)batches.size();
     std::atomic<size_t> next{0};
-    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0};
+    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_scan{0}, us_push{0};
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto worker = [&]() {
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
@@ -312,12 +316,14 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
             const size_t u0 = batches[b].first, u1 = batches[b].second;
             const uint64_t c0 = cuts[u0] >> 16;
             const uint64_t c_end = cuts[u1] == UINT64_MAX ? F : std::min<uint64_t>(F, (cuts[u1] >> 16) + 4 * 65536);
+            const uint64_t t_a = now_us();
             blob.resize((size_t)(c_end - c0));
             for (size_t got = 0; got < blob.size();) {
                 const ssize_t n = pread(fd, blob.data() + got, blob.size() - got, (off_t)(c0 + got));
                 if (n <= 0) { eng->fail("read error on " + path); ::close(fd); return; }
                 got += (size_t)n;
             }
+            const uint64_t t_b = now_us();
             blocks.clear(); coff.clear();
             uint64_t uo = 0;
             for (size_t p = 0; p + 18 <= blob.size();) {
@@ -356,6 +362,9 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
             if (!ok) { eng->fail("index offsets of " + path + " do not match its BGZF blocks"); break; }
             status.assign(units.size(), 0);
             uint64_t nrec = 0;
+            const uint64_t t_c = now_us();
+            us_read += t_b - t_a; us_scan += t_c - t_b;
+            struct PushTimer { std::atomic<uint64_t> &acc; uint64_t t0; std::function<uint64_t()> now; ~PushTimer() { acc += now() - t0; } } pt{us_push, t_c, now_us};
             if (!eng->ck(eng->api->push_bgzf_units(eng->ctx, blob.data(), blob.size(), blocks.data(), (uint32_t)blocks.size(),
                                                    units.data(), (uint32_t)units.size(), uo, o.flag_mask, o.min_mapq, status.data(),
                                                    &nrec), "pd_push_bgzf_units")) break;
@@ -380,9 +389,10 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
         for (auto &t : th) t.join();
     }
     if (getenv("PANDEPTH_TIMING"))
-        fprintf(stderr, "[timing] device decode: %zu batches, %zu units, %llu records on the device, %llu units (%llu records) handed back to the host\n",
+        fprintf(stderr, "[timing] device decode: %zu batches, %zu units, %llu records on the device, %llu units (%llu records) handed back to the host; "
+                        "thread-seconds: read %.2f, block scan %.2f, pd_push_bgzf_units (incl. waiting for the GPU) %.2f\n",
                 batches.size(), cuts.size() - 1, (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(),
-                (unsigned long long)n_host.load());
+                (unsigned long long)n_host.load(), us_read.load() / 1e6, us_scan.load() / 1e6, us_push.load() / 1e6);
     return eng->ok();
 }
 

@@ -36,6 +36,20 @@ def main():
             subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)], check=True,
                            stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_DECODE_ONLY="1"))
         return
+    if os.environ.get("E2E_DEVICE_DECODE"):
+        for bmb, t in (("2048", 4),):
+            best = 1e9
+            for rep in range(2):
+                a = time.perf_counter()
+                subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "dd"), "-t", str(t)], check=True, stdout=subprocess.DEVNULL,
+                               env=dict(os.environ, PANDEPTH_DEVICE_DECODE="1", PANDEPTH_DD_BATCH_MB=bmb,
+                                        **({"PANDEPTH_TIMING": "1"} if rep == 1 else {})))
+                best = min(best, time.perf_counter() - a)
+            print("pandepth(MI355X, device decode) batch %s MB -t %d  %.2f s  %.3e records/s" % (bmb, t, best, R / best), flush=True)
+        subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "hd"), "-t", "32"], check=True, stdout=subprocess.DEVNULL)
+        print("device-decode output == host-decode output:",
+              open(os.path.join(td, "dd.chr.stat.gz"), "rb").read() == open(os.path.join(td, "hd.chr.stat.gz"), "rb").read(), flush=True)
+        return
     for mode in modes:
         suffix = "chr.stat.gz" if mode in ("chr", "s") else "win.stat.gz"
         for t in ([8, 32, 64, 128] if mode == "chr" else [16]):
