@@ -545,10 +545,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
 
     tm.mark("options + header");
     RegionModel rm;
-    const bool had_targets = o.mode != 0;
     if (!build_regions(&o, hdr, &rm)) return 1;
     const bool synthetic = o.mode == 0 || o.mode == 5 || o.mode == 6;
-    (void)had_targets;
 
     // output names (PD:4057-4090)
     std::string prefix = o.out.substr(0, o.out.size() - 3);
