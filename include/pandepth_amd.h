@@ -136,6 +136,12 @@ int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *ou
  * all-reduce / reduce-scatter of n_words int32 over xGMI, issued by the caller on the stream
  * returned by pd_stream).  contig_off (n_contigs entries, in cells) may be NULL. */
 int pd_device_buffer(pd_ctx *ctx, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off);
+/* Single-process form of the same sum (the CLI's `#.list` over several GPUs, one context per GPU):
+ * dst += src, difference arrays and tile sums, chunk by chunk through a peer copy over xGMI and an
+ * add kernel on dst's GPU.  Both contexts must describe the same contigs and be accumulating. */
+int pd_device_count(int *n);
+int pd_accumulate_from(pd_ctx *dst, pd_ctx *src);
+
 /* Compact transport of the difference arrays for that sum (xGMI is per-link bound; this moves
  * 1 B/cell instead of 4).  pd_export_i8 writes one byte per cell into dev_i8 (n_cells bytes, from
  * pd_device_layout), BIASED: d + threshold, an unsigned value in [0, 2*threshold]; cells with

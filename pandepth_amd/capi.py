@@ -64,6 +64,8 @@ def load():
         "pd_reduce_windows": (I, [P, ctypes.c_uint32, ctypes.c_uint32, P, P]),
         "pd_read_depth": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, P]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
+        "pd_device_count": (I, [ctypes.POINTER(I)]),
+        "pd_accumulate_from": (I, [P, P]),
         "pd_device_layout": (I, [P, ctypes.POINTER(U64), ctypes.POINTER(U64)]),
         "pd_export_i8": (I, [P, I, P, P, ctypes.c_uint32, P]),
         "pd_import_i8": (I, [P, P, I, P, U64]),
@@ -86,7 +88,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_device_buffer", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_push_bgzf_units", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_read_depth", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_push_bgzf_units", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -207,6 +209,9 @@ class Engine:
         off = np.zeros(self.n_contigs, dtype=np.uint64)
         self._ck(self.L.pd_device_buffer(self.h, ctypes.byref(p), ctypes.byref(nw), _ptr(off)))
         return int(p.value), int(nw.value), off
+
+    def accumulate_from(self, other):
+        self._ck(self.L.pd_accumulate_from(self.h, other.h))
 
     def device_layout(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()

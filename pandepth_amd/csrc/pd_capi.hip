@@ -748,6 +748,58 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     return PD_OK;
 }
 
+int pd_device_count(int *n)
+{
+    if (!n) return PD_EINVAL;
+    int k = 0;
+    if (hipGetDeviceCount(&k) != hipSuccess) k = 0;
+    *n = k;
+    return k > 0 ? PD_OK : PD_ENODEV;
+}
+
+int pd_accumulate_from(pd_ctx *dst, pd_ctx *src)
+{
+    if (!dst || !src || dst == src) return PD_EINVAL;
+    // lock both contexts in address order
+    std::unique_lock<std::mutex> l1(dst < src ? dst->mu : src->mu), l2(dst < src ? src->mu : dst->mu);
+    if (dst->n_words != src->n_words || dst->n_contigs != src->n_contigs || dst->len != src->len)
+        return fail(dst, PD_EINVAL, "pd_accumulate_from: the contexts describe different contigs");
+    if (dst->state != 0 || src->state != 0) return fail(dst, PD_ESTATE, "pd_accumulate_from: both contexts must be accumulating");
+    // materialise the source (zeros where nothing was written) and finish its work
+    HIPOK(src, hipSetDevice(src->device));
+    int rc = flush_pending(src);
+    if (rc) { dst->err = src->err; return rc; }
+    rc = check_words(src);
+    if (rc) { dst->err = src->err; return rc; }
+    rc = ensure_all_valid(src);
+    if (rc) { dst->err = src->err; return rc; }
+    HIPOK(src, hipStreamSynchronize(src->copy_stream));
+    HIPOK(src, hipStreamSynchronize(src->stream));
+    HIPOK(dst, hipSetDevice(dst->device));
+    rc = flush_pending(dst);
+    if (rc) return rc;
+    rc = ensure_all_valid(dst);
+    if (rc) return rc;
+    const size_t CH = (size_t)64 << 20;                               // words per chunk (256 MiB)
+    rc = ensure_scratch(dst, CH * 4);
+    if (rc) return rc;
+    if (dst->device != src->device) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, dst->device, src->device);
+        if (can) (void)hipDeviceEnablePeerAccess(src->device, 0);    // already enabled is fine
+        (void)hipGetLastError();
+    }
+    for (size_t o = 0; o < dst->n_words; o += CH) {
+        const size_t n = dst->n_words - o < CH ? dst->n_words - o : CH;
+        HIPOK(dst, hipMemcpyPeerAsync(dst->scratch, dst->device, src->buf + o, src->device, n * 4, dst->stream));
+        ProfScope ps(dst, "accumulate_from");
+        launch_add_i32(dst->stream, dst->buf + o, (const int *)dst->scratch, n);
+    }
+    HIPOK(dst, hipGetLastError());
+    HIPOK(dst, hipStreamSynchronize(dst->stream));
+    return PD_OK;
+}
+
 int pd_device_layout(pd_ctx *c, uint64_t *n_cells, uint64_t *n_tile_sums)
 {
     if (!c) return PD_EINVAL;

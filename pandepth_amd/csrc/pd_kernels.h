@@ -74,6 +74,7 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
                          TileMap tm, uint32_t w, uint32_t min_dep, uint32_t *cover, unsigned long long *sum,
                          TilePart *part, uint64_t n_windows, int32_t n_contigs, bool from_depth,
                          const uint8_t *hstate);
+void launch_add_i32(hipStream_t st, int *dst, const int *src, size_t n_words);
 void launch_export_i8(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells, int thr,
                       pd_exc *exc, uint32_t cap, uint32_t *count);
 void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cells, int bias, const pd_exc *exc,

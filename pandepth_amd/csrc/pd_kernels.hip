@@ -671,6 +671,24 @@ __global__ __launch_bounds__(WG) void k_apply_exceptions(const pd_exc *exc, uint
         if (exc[i].cell < n_cells) atomicAdd(&diff[exc[i].cell], exc[i].value);
 }
 
+__global__ __launch_bounds__(WG) void k_add_i32(int4 *dst, const int4 *src, size_t n16)
+{
+    size_t i = blockIdx.x * (size_t)WG + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * WG;
+    for (; i < n16; i += st) {
+        int4 a = dst[i]; const int4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+
+void launch_add_i32(hipStream_t st, int *dst, const int *src, size_t n_words)
+{
+    const size_t n16 = n_words / 4;
+    size_t g = (n16 + WG - 1) / WG; if (g > 8192) g = 8192; if (!g) return;
+    hipLaunchKernelGGL(k_add_i32, dim3((unsigned)g), dim3(WG), 0, st, (int4 *)dst, (const int4 *)src, n16);
+}
+
 void launch_export_i8(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells, int thr,
                       pd_exc *exc, uint32_t cap, uint32_t *count)
 {

@@ -26,6 +26,9 @@ typedef struct pd_engine_api {
     /* optional (NULL = not available): GPU-side BAM decode, see pd_push_bgzf_units */
     int (*push_bgzf_units)(pd_ctx *, const void *, size_t, const pd_bgzf_block *, uint32_t, const pd_bgzf_unit *, uint32_t,
                            uint64_t, uint32_t, int32_t, int32_t *, uint64_t *);
+    /* optional (NULL = one context only): several GPUs in one process for `#.list` inputs */
+    int (*device_count)(int *);
+    int (*accumulate_from)(pd_ctx *dst, pd_ctx *src);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -565,43 +565,85 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
 
     tm.mark("region model");
-    Engine eng;
-    eng.api = api;
-    if (api->create(device, (int32_t)hdr.lens.size(), hdr.lens.data(), &eng.ctx) != 0) {
-        const char *m = api->strerror(nullptr);
-        std::cerr << "Error: depth engine unavailable: " << (m ? m : "?") << std::endl;
-        return 2;
+    // One context per GPU.  A `#.list` input is sharded one file per GPU (round robin) when the engine
+    // offers several devices; the contexts are summed into the first one before the statistics
+    // (difference arrays are linear: PD:2704-3014 accumulates every file into one array).
+    int n_dev = 1, n_ctx = 1;
+    if (list_mode && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
+        n_ctx = n_dev;
+        if (const char *e = getenv("PANDEPTH_GPUS")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
+        if (n_ctx > n_files) n_ctx = n_files;
     }
-    struct CtxGuard { Engine *e; ~CtxGuard() { if (e->ctx) e->api->destroy(e->ctx); } } guard{&eng};
-
+    std::vector<std::unique_ptr<Engine>> engs;
+    struct CtxGuard { std::vector<std::unique_ptr<Engine>> *v; ~CtxGuard() { for (auto &e : *v) if (e->ctx) e->api->destroy(e->ctx); } } guard{&engs};
+    for (int k = 0; k < n_ctx; ++k) {
+        engs.emplace_back(new Engine);
+        engs.back()->api = api;
+        if (api->create((device + k) % n_dev, (int32_t)hdr.lens.size(), hdr.lens.data(), &engs.back()->ctx) != 0) {
+            const char *m = api->strerror(nullptr);
+            std::cerr << "Error: depth engine unavailable: " << (m ? m : "?") << std::endl;
+            return 2;
+        }
+    }
+    Engine &eng = *engs[0];
     tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
 
+    // Classify the inputs in list order first: the reference prints its "No Index mode" warnings in
+    // that order (it reads the files one after another), whatever order the GPUs finish in.
+    struct Input { std::string path; int kind; };                  // 0 indexed, 1 sorted stream, 2 every read
+    std::vector<Input> inputs;
     bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
     for (const std::string &fp : o.inputs) {
         if (index_exists(fp) && o.use_index) {
             if (o.site_out || o.mode == 6) wrap18 = true;            // PD:4127
-            if (!read_indexed(fp, o, hdr, spans, &eng)) break;
-        } else {
+            inputs.push_back({fp, 0});
+            continue;
+        }
+        wrap18 = true;                                               // PD:4553
+        bool sorted = false;
+        if (!list_mode) sorted = first.header().sorted_coordinate();
+        else {
+            AlnReader probe;
+            if (!probe.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
+            sorted = probe.header().sorted_coordinate();
+        }
+        if (sorted) std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
+        else std::cout << "Warning: Can't find index file of input BAM/CRAM. PanDepth will run in No Index mode: " << fp << std::endl;
+        inputs.push_back({fp, sorted ? 1 : 2});
+    }
+    Options o_part = o;
+    if (n_ctx > 1) o_part.threads = std::max(1, o.threads / n_ctx);
+    auto run_inputs = [&](int k) {
+        Engine *e = engs[k].get();
+        for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
+            const Input &in = inputs[i];
+            if (in.kind == 0) { if (!read_indexed(in.path, o_part, hdr, spans, e)) return; continue; }
             AlnReader rd;
             AlnReader *r = &rd;
+            std::string e2;
             if (!list_mode) r = &first;                              // already positioned after the header
-            else if (!rd.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
-            wrap18 = true;                                           // PD:4553
-            r->set_threads(o.threads > 1 ? (o.threads > 32 ? 32 : o.threads) : 0);
-            if (r->header().sorted_coordinate()) {
-                std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
-                if (!read_sorted_stream(r, o, hdr, rm, &eng)) break;
-            } else {
-                std::cout << "Warning: Can't find index file of input BAM/CRAM. PanDepth will run in No Index mode: " << fp << std::endl;
-                if (!read_all(r, o, hdr, rm, &eng)) break;
-            }
+            else if (!rd.open(in.path, &e2)) { e->fail("cannot open " + in.path); return; }
+            r->set_threads(o_part.threads > 1 ? (o_part.threads > 32 ? 32 : o_part.threads) : 0);
+            if (!(in.kind == 1 ? read_sorted_stream(r, o_part, hdr, rm, e) : read_all(r, o_part, hdr, rm, e))) return;
+        }
+    };
+    if (n_ctx == 1) run_inputs(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < n_ctx; ++k) th.emplace_back(run_inputs, k);
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!engs[k]->ok() || !engs[k]->ck(api->synchronize(engs[k]->ctx), "pd_synchronize")) {
+            std::cerr << "Error: " << engs[k]->err << std::endl;
+            return 2;
         }
     }
-    if (!eng.ok() || !eng.ck(api->synchronize(eng.ctx), "pd_synchronize")) {
-        std::cerr << "Error: " << eng.err << std::endl;
-        return 2;
+    for (int k = 1; k < n_ctx; ++k) {
+        if (!eng.ck(api->accumulate_from(eng.ctx, engs[k]->ctx), "pd_accumulate_from")) { std::cerr << "Error: " << eng.err << std::endl; return 2; }
+        api->destroy(engs[k]->ctx); engs[k]->ctx = nullptr;
     }
     tm.mark("decode + scatter");
     const unsigned wrap_bits = wrap18 ? 18u : 0u;

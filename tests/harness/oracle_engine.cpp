@@ -122,10 +122,19 @@ static int o_read_depth(pd_ctx *c, int32_t t, uint32_t beg, size_t n, uint32_t *
     return 0;
 }
 static int o_sync(pd_ctx *) { return 0; }
+// several "GPUs" for the list-mode driver: as many as PANDEPTH_FAKE_GPUS says (default 1)
+static int o_device_count(int *n) { const char *e = getenv("PANDEPTH_FAKE_GPUS"); *n = e ? atoi(e) : 1; return 0; }
+static int o_accumulate_from(pd_ctx *dst, pd_ctx *src)
+{
+    if (dst->scanned || src->scanned || dst->depth.size() != src->depth.size()) { dst->err = "accumulate_from: bad state"; return -4; }
+    // per-base counts are additive exactly like difference arrays
+    for (size_t i = 0; i < dst->depth.size(); ++i) dst->depth[i] += src->depth[i];
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
-                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr};
+                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from};
     return pandepth_main(argc, argv, &api, 0);
 }

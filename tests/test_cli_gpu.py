@@ -55,3 +55,16 @@ def test_pandepth_cli_device_decode_byte_identical(case, batch_mb, tmp_path):
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()
         assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix
+
+
+@pytest.mark.parametrize("case", [e for e in MANIFEST if ".list" in e["args"][1]], ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_pandepth_cli_list_over_two_contexts(case, tmp_path):
+    """PANDEPTH_GPUS=2 on a one-GPU box: two contexts (sharing the GPU), pd_accumulate_from at the end."""
+    d = os.path.join(HERE, "golden", case["fixture"])
+    p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANDEPTH_GPUS="2"))
+    assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
+    assert p.stdout.decode() == case["stdout"]
+    for suffix, meta in case["outputs"].items():
+        gz = (tmp_path / ("o." + suffix)).read_bytes()
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix

@@ -366,3 +366,24 @@ def test_packed_sum_single_rank_roundtrip():
         assert ps.run(0) is True
         e.scan(0)
         check_depth(e, LENS, d, off)
+
+
+def test_accumulate_from_equals_pushing_into_one_context():
+    rng = np.random.default_rng(51)
+    a = sort_iv(rand_intervals(rng, LENS, 70000))
+    b = rand_intervals(rng, LENS, 30000)
+    c = sort_iv(rand_intervals(rng, LENS[:2], 20000))          # leaves most of e3 unwritten
+    d, off = oracle_depth(LENS, np.concatenate([a, b, c]), True)
+    with pda.Engine(LENS) as e1, pda.Engine(LENS) as e2, pda.Engine(LENS) as e3:
+        e1.push_intervals(a, pda.PD_PUSH_SORTED)
+        e2.push_intervals(b)
+        e3.push_intervals(c, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)     # still pending when summed
+        e1.accumulate_from(e2)
+        e1.accumulate_from(e3)
+        e1.scan(18)
+        check_depth(e1, LENS, d, off)
+        with pytest.raises(pda.PdError):
+            e2.accumulate_from(e1)                                # e1 is no longer accumulating
+    with pda.Engine(LENS) as e1, pda.Engine([5, 7]) as e2:
+        with pytest.raises(pda.PdError):
+            e1.accumulate_from(e2)

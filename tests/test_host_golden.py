@@ -23,12 +23,13 @@ def harness():
     return os.path.join(HERE, "harness", "pandepth_oracle_cli")
 
 
-def run_case(cli, case, tmp_path, threads):
+def run_case(cli, case, tmp_path, threads, env=None):
     d = os.path.join(HERE, "golden", case["fixture"])
     args = [cli] + case["args"] + ["-o", str(tmp_path / "o")]
     if "-t" not in case["args"]:
         args += ["-t", str(threads)]
-    p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
@@ -46,6 +47,14 @@ def test_host_pipeline_byte_identical(harness, case, tmp_path):
                          ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_host_pipeline_parallel_readers(harness, case, tmp_path):
     run_case(harness, case, tmp_path, 4)
+
+
+@pytest.mark.parametrize("gpus", ["2", "3"])
+@pytest.mark.parametrize("case", [e for e in MANIFEST if ".list" in e["args"][1]], ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_list_mode_sharded_over_several_contexts(harness, case, gpus, tmp_path):
+    """`#.list` with one engine context per (stand-in) GPU: files round-robin over the contexts,
+    contexts summed before the statistics; output and stdout exactly as with one context."""
+    run_case(harness, case, tmp_path, 4, env={"PANDEPTH_FAKE_GPUS": gpus})
 
 
 def test_cli_messages(harness, tmp_path):
