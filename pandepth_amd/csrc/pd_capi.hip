@@ -59,6 +59,7 @@ struct pd_ctx {
     std::vector<Pending> pend;
     // GPU-side BAM decode: device buffers grown on demand (index = purpose)
     void *dd_buf[12] = {}; size_t dd_cap[12] = {};
+    std::mutex dd_mu; hipStream_t dd_stream = nullptr; hipEvent_t dd_ev[6] = {}; double dd_ms[4] = {}; uint64_t dd_batches = 0;
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
@@ -404,6 +405,8 @@ int pd_destroy(pd_ctx *c)
                     c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->desc, c->chk, c->ovf, c->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->dd_buf) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->dd_ev) if (e) (void)hipEventDestroy(e);
+    if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -655,16 +658,6 @@ int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *con
     return PD_OK;
 }
 
-static int dd_ensure(pd_ctx *c, int k, size_t bytes)
-{
-    if (bytes <= c->dd_cap[k]) return PD_OK;
-    if (c->dd_buf[k]) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->dd_buf[k])); c->dd_buf[k] = nullptr; c->dd_cap[k] = 0; }
-    const size_t want = bytes + bytes / 8 + 4096;
-    if (hipMalloc(&c->dd_buf[k], want) != hipSuccess) return fail(c, PD_ENOMEM, "device-decode buffer allocation failed");
-    c->dd_cap[k] = want;
-    return PD_OK;
-}
-
 int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
                        const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
                        int32_t min_mapq, int32_t *unit_status, uint64_t *n_records)
@@ -672,12 +665,15 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     if (!c || !blob || !blocks || !units || !unit_status) return PD_EINVAL;
     if (n_records) *n_records = 0;
     if (n_units == 0 || n_blocks == 0) return PD_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (c->state != 0) return fail(c, PD_ESTATE, "pd_push_bgzf_units: depth already materialised (call pd_reset)");
-    HIPOK(c, hipSetDevice(c->device));
-    if (getenv("PANDEPTH_TIMING")) c->prof = true;
-    int rc = flush_pending(c);
-    if (rc) return rc;
+    // Phase 1 (inflate, record walk, parse) works only on the decode buffers and runs on its own stream
+    // under its own lock, so that pd_push_intervals callers (host-decoded ranges of the same file) keep
+    // scattering meanwhile; only phase 2 (the scatter of this batch's runs) takes the context lock.
+    std::unique_lock<std::mutex> dl(c->dd_mu);
+    auto dd_fail = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(c->mu); return fail(c, code, msg); };
+#define HIPDD(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return dd_fail(PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+    HIPDD(hipSetDevice(c->device));
+    if (!c->dd_stream) HIPDD(hipStreamCreateWithFlags(&c->dd_stream, hipStreamNonBlocking));
+    hipStream_t st = c->dd_stream;
     // host-side unit table: capacity-based slots in the record-offset array (a record is >= 36 bytes)
     std::vector<pdb::Unit> hu(n_units);
     std::vector<uint32_t> ufirst(n_units), unblk(n_units);
@@ -685,66 +681,81 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     for (uint32_t i = 0; i < n_units; ++i) {
         const pd_bgzf_unit &u = units[i];
         if (u.start > u.avail || u.start > u.stop || u.avail > inflated_bytes || (uint64_t)u.first_block + u.n_blocks > n_blocks)
-            return fail(c, PD_EINVAL, "pd_push_bgzf_units: unit outside the inflated buffer");
+            return dd_fail(PD_EINVAL, "pd_push_bgzf_units: unit outside the inflated buffer");
         hu[i].start = u.start; hu[i].stop = u.stop; hu[i].avail = u.avail; hu[i].rec_base = rec_cap; hu[i].n_rec = 0; hu[i].status = 0;
         rec_cap += (u.avail - u.start) / 36 + 1;
         ufirst[i] = u.first_block; unblk[i] = u.n_blocks;
     }
     for (uint32_t b = 0; b < n_blocks; ++b)
         if (blocks[b].in_off + blocks[b].in_len > n_bytes || blocks[b].out_off + blocks[b].out_len > inflated_bytes)
-            return fail(c, PD_EINVAL, "pd_push_bgzf_units: block outside its buffer");
-    if (rec_cap > 0xFFFFFF00ull) return fail(c, PD_EINVAL, "pd_push_bgzf_units: batch too large");
+            return dd_fail(PD_EINVAL, "pd_push_bgzf_units: block outside its buffer");
+    if (rec_cap > 0xFFFFFF00ull) return dd_fail(PD_EINVAL, "pd_push_bgzf_units: batch too large");
     const size_t other_cap = (size_t)rec_cap / 2 + 1024;
     enum { B_BLOB, B_INF, B_BLK, B_BST, B_UNIT, B_UF, B_UN, B_ROFF, B_DENSE, B_FIRST, B_OTHER, B_TAB };
     const size_t need[12] = {n_bytes + 16, (size_t)inflated_bytes + 64, (size_t)n_blocks * sizeof(pd_bgzf_block), (size_t)n_blocks * 4,
                              (size_t)n_units * sizeof(pdb::Unit), (size_t)n_units * 4, (size_t)n_units * 4, (size_t)rec_cap * 8,
                              ((size_t)n_units + 1) * 8 + 16, (size_t)rec_cap * sizeof(pd_iv), other_cap * sizeof(pd_iv),
                              bgzf_scratch_bytes(n_blocks)};
-    for (int k = 0; k < 12; ++k) { rc = dd_ensure(c, k, need[k]); if (rc) return rc; }
+    for (int k = 0; k < 12; ++k) {
+        if (need[k] <= c->dd_cap[k]) continue;
+        if (c->dd_buf[k]) { HIPDD(hipStreamSynchronize(st)); HIPDD(hipFree(c->dd_buf[k])); c->dd_buf[k] = nullptr; c->dd_cap[k] = 0; }
+        const size_t want = need[k] + need[k] / 8 + 4096;
+        if (hipMalloc(&c->dd_buf[k], want) != hipSuccess) return dd_fail(PD_ENOMEM, "device-decode buffer allocation failed");
+        c->dd_cap[k] = want;
+    }
+    if (!c->dd_ev[0]) for (int k = 0; k < 6; ++k) HIPDD(hipEventCreate(&c->dd_ev[k]));
     uint8_t *d_blob = (uint8_t *)c->dd_buf[B_BLOB], *d_inf = (uint8_t *)c->dd_buf[B_INF];
     uint64_t *d_dense = (uint64_t *)c->dd_buf[B_DENSE];
     uint32_t *d_cnt = (uint32_t *)(d_dense + n_units + 1);            // {other_count, err}
-    { ProfScope ps(c, "bgzf_h2d");
-      HIPOK(c, hipMemcpyAsync(d_blob, blob, n_bytes, hipMemcpyHostToDevice, c->stream)); }
-    HIPOK(c, hipMemcpyAsync(c->dd_buf[B_BLK], blocks, need[B_BLK], hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(c->dd_buf[B_UNIT], hu.data(), need[B_UNIT], hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(c->dd_buf[B_UF], ufirst.data(), need[B_UF], hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(c->dd_buf[B_UN], unblk.data(), need[B_UN], hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
-    { ProfScope ps(c, "bgzf_inflate");
-      launch_bgzf_inflate(c->stream, d_blob, (const pd_bgzf_block *)c->dd_buf[B_BLK], n_blocks, d_inf, (int *)c->dd_buf[B_BST], c->dd_buf[B_TAB]); }
-    { ProfScope ps(c, "bam_walk");
-      launch_bam_walk(c->stream, d_inf, c->dd_buf[B_UNIT], n_units, (uint64_t *)c->dd_buf[B_ROFF], rec_cap, (const int *)c->dd_buf[B_BST],
-                      (const uint32_t *)c->dd_buf[B_UF], (const uint32_t *)c->dd_buf[B_UN], d_dense); }
+    HIPDD(hipEventRecord(c->dd_ev[0], st));
+    HIPDD(hipMemcpyAsync(d_blob, blob, n_bytes, hipMemcpyHostToDevice, st));
+    HIPDD(hipMemcpyAsync(c->dd_buf[B_BLK], blocks, need[B_BLK], hipMemcpyHostToDevice, st));
+    HIPDD(hipMemcpyAsync(c->dd_buf[B_UNIT], hu.data(), need[B_UNIT], hipMemcpyHostToDevice, st));
+    HIPDD(hipMemcpyAsync(c->dd_buf[B_UF], ufirst.data(), need[B_UF], hipMemcpyHostToDevice, st));
+    HIPDD(hipMemcpyAsync(c->dd_buf[B_UN], unblk.data(), need[B_UN], hipMemcpyHostToDevice, st));
+    HIPDD(hipMemsetAsync(d_cnt, 0, 8, st));
+    HIPDD(hipEventRecord(c->dd_ev[1], st));
+    launch_bgzf_inflate(st, d_blob, (const pd_bgzf_block *)c->dd_buf[B_BLK], n_blocks, d_inf, (int *)c->dd_buf[B_BST], c->dd_buf[B_TAB]);
+    HIPDD(hipEventRecord(c->dd_ev[2], st));
+    launch_bam_walk(st, d_inf, c->dd_buf[B_UNIT], n_units, (uint64_t *)c->dd_buf[B_ROFF], rec_cap, (const int *)c->dd_buf[B_BST],
+                    (const uint32_t *)c->dd_buf[B_UF], (const uint32_t *)c->dd_buf[B_UN], d_dense);
+    HIPDD(hipEventRecord(c->dd_ev[3], st));
     uint64_t n_rec = 0;
-    HIPOK(c, hipMemcpyAsync(&n_rec, d_dense + n_units, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(c, hipStreamSynchronize(c->stream));                        // also: the host arrays above may go
+    HIPDD(hipMemcpyAsync(&n_rec, d_dense + n_units, 8, hipMemcpyDeviceToHost, st));
+    HIPDD(hipStreamSynchronize(st));                                  // also: the host arrays above may go
+    uint32_t cnt[2] = {0, 0};
     if (n_rec) {
-        { ProfScope ps(c, "bam_parse");
-          launch_bam_parse(c->stream, d_inf, c->dd_buf[B_UNIT], n_units, d_dense, n_rec, (const uint64_t *)c->dd_buf[B_ROFF], flag_mask,
-                           min_mapq, c->n_contigs, c->d_len, (pd_iv *)c->dd_buf[B_FIRST], (pd_iv *)c->dd_buf[B_OTHER],
-                           (uint32_t)other_cap, d_cnt, d_cnt + 1); }
-        uint32_t cnt[2] = {0, 0};
-        HIPOK(c, hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(c, hipStreamSynchronize(c->stream));
-        if (cnt[1] || cnt[0] > other_cap) return fail(c, PD_EINVAL, "pd_push_bgzf_units: more than one extra run per two records on average; decode this input on the host");
-        rc = scatter_device(c, (const pd_iv *)c->dd_buf[B_FIRST], (size_t)n_rec, PD_PUSH_SORTED, -1, nullptr);
+        launch_bam_parse(st, d_inf, c->dd_buf[B_UNIT], n_units, d_dense, n_rec, (const uint64_t *)c->dd_buf[B_ROFF], flag_mask,
+                         min_mapq, c->n_contigs, c->d_len, (pd_iv *)c->dd_buf[B_FIRST], (pd_iv *)c->dd_buf[B_OTHER],
+                         (uint32_t)other_cap, d_cnt, d_cnt + 1);
+        HIPDD(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPDD(hipEventRecord(c->dd_ev[4], st));
+    HIPDD(hipMemcpyAsync(hu.data(), c->dd_buf[B_UNIT], need[B_UNIT], hipMemcpyDeviceToHost, st));
+    HIPDD(hipStreamSynchronize(st));
+    HIPDD(hipGetLastError());
+    if (cnt[1] || cnt[0] > other_cap)
+        return dd_fail(PD_EINVAL, "pd_push_bgzf_units: more than one extra run per two records on average; decode this input on the host");
+    for (int k = 0; k < 4; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, c->dd_ev[k], c->dd_ev[k + 1]) == hipSuccess) c->dd_ms[k] += ms; }
+    c->dd_batches += 1;
+    // Phase 2: scatter this batch's runs (first runs: dense and position sorted; the rest: atomics)
+    if (n_rec) {
+        std::unique_lock<std::mutex> lk(c->mu);
+        if (c->state != 0) return fail(c, PD_ESTATE, "pd_push_bgzf_units: depth already materialised (call pd_reset)");
+        HIPOK(c, hipSetDevice(c->device));
+        int rc = scatter_device(c, (const pd_iv *)c->dd_buf[B_FIRST], (size_t)n_rec, PD_PUSH_SORTED, -1, nullptr);
         if (rc) return rc;
         if (cnt[0]) { rc = scatter_device(c, (const pd_iv *)c->dd_buf[B_OTHER], cnt[0], PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
+        HIPOK(c, hipEventRecord(c->dd_ev[5], c->stream));
+        lk.unlock();                                                  // other pushers may go on; the decode buffers stay ours
+        HIPDD(hipEventSynchronize(c->dd_ev[5]));
     }
-    HIPOK(c, hipMemcpyAsync(hu.data(), c->dd_buf[B_UNIT], need[B_UNIT], hipMemcpyDeviceToHost, c->stream));
-    HIPOK(c, hipStreamSynchronize(c->stream));
     for (uint32_t i = 0; i < n_units; ++i) unit_status[i] = hu[i].status;
     if (n_records) *n_records = n_rec;
-    HIPOK(c, hipGetLastError());
-    if (getenv("PANDEPTH_TIMING")) {
-        // per-kernel event times of this batch (profiling is switched on for the call when timing is requested)
-        for (const char *k : {"bgzf_h2d", "bgzf_inflate", "bam_walk", "bam_parse", "scatter_index", "scatter_tiles", "scatter_atomic", "fill"}) {
-            prof_collect(c);
-            auto it = c->prof_acc.find(k);
-            if (it != c->prof_acc.end()) fprintf(stderr, "[timing]   device %-14s %8.2f ms total over %llu launches\n", k, it->second.first, (unsigned long long)it->second.second);
-        }
-    }
+    if (getenv("PANDEPTH_TIMING"))
+        fprintf(stderr, "[timing]   device decode so far: %llu batches, H2D %.1f ms, inflate %.1f ms, walk %.1f ms, parse %.1f ms\n",
+                (unsigned long long)c->dd_batches, c->dd_ms[0], c->dd_ms[1], c->dd_ms[2], c->dd_ms[3]);
+#undef HIPDD
     return PD_OK;
 }
 

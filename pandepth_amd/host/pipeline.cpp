@@ -279,27 +279,55 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
                          const BaiIndex &bai, uint64_t first_voff, Engine *eng)
 {
     const uint64_t F = file_size(path);
-    // units as fine as the index allows (a thread walks one unit's records sequentially)
+    // units as fine as the index allows (a device thread walks one unit's records sequentially)
     uint64_t unit_bytes = (uint64_t)256 << 10;
     if (const char *e = getenv("PANDEPTH_DD_UNIT_KB")) unit_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 10;
     uint64_t batch_bytes = (uint64_t)2048 << 20;
     if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = strtoull(e, nullptr, 10) << 20;
-    std::vector<uint64_t> cuts = bai.split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / unit_bytes + 1));
-    // batches of consecutive units
-    std::vector<std::pair<size_t, size_t>> batches;       // [first unit, last unit)
-    for (size_t u = 0; u + 1 < cuts.size();) {
-        size_t v = u + 1;
-        while (v + 1 < cuts.size() && ((cuts[v] == UINT64_MAX ? F : (cuts[v] >> 16)) - (cuts[u] >> 16)) < batch_bytes) ++v;
-        batches.emplace_back(u, v);
-        u = v;
-    }
-    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    const std::vector<uint64_t> cuts = bai.split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / unit_bytes + 1));
+    const size_t n_units = cuts.size() - 1;
+    auto coff_of = [&](size_t u) { return cuts[u] == UINT64_MAX ? F : (cuts[u] >> 16); };
+    // Heterogeneous schedule over ONE list of units: device feeders take large batches from the
+    // front (the inflate kernel wants ~100 K blocks per launch), host decoders take small ranges from
+    // the back (libdeflate on the remaining threads); they meet somewhere in the middle.
     int threads = o.threads < 1 ? 1 : o.threads;
-    if ((size_t)threads > batches.size()) threads = (int)batches.size();
-    std::atomic<size_t> next{0};
-    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_scan{0}, us_push{0};
+    int feeders = 2;
+    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
+    if (feeders > threads) feeders = threads;
+    const int host_workers = threads - feeders;
+    std::mutex qmu;
+    size_t front = 0, back = n_units;
+    auto take_front = [&](size_t *u0, size_t *u1) -> bool {
+        std::lock_guard<std::mutex> lk(qmu);
+        if (front >= back) return false;
+        size_t v = front + 1;
+        while (v < back && coff_of(v) - coff_of(front) < batch_bytes) ++v;
+        *u0 = front; *u1 = v; front = v;
+        return true;
+    };
+    auto take_back = [&](size_t *u0, size_t *u1) -> bool {
+        std::lock_guard<std::mutex> lk(qmu);
+        if (front >= back) return false;
+        const size_t n = std::min<size_t>(8, back - front);
+        *u1 = back; *u0 = back - n; back -= n;
+        return true;
+    };
+    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, n_batches{0}, us_read{0}, us_scan{0}, us_push{0};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto worker = [&]() {
+    auto host_worker = [&]() {
+        AlnReader rd;
+        std::string e2;
+        if (!rd.open(path, &e2)) { eng->fail(e2); return; }
+        RunSink sink(eng);
+        size_t u0, u1;
+        while (eng->ok() && take_back(&u0, &u1)) {
+            uint64_t nr = 0;
+            if (!decode_range(rd, cuts[u0], cuts[u1], flt, spans, &sink, &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); return; }
+            n_host += nr;
+        }
+    };
+    auto feeder = [&]() {
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
         AlnReader rd;                                         // only for handed-back units
@@ -310,10 +338,9 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
         std::vector<pd_bgzf_unit> units;
         std::vector<int32_t> status;
         RunSink sink(eng);
-        for (;;) {
-            const size_t b = next.fetch_add(1);
-            if (b >= batches.size() || !eng->ok()) break;
-            const size_t u0 = batches[b].first, u1 = batches[b].second;
+        size_t u0, u1;
+        while (eng->ok() && take_front(&u0, &u1)) {
+            ++n_batches;
             const uint64_t c0 = cuts[u0] >> 16;
             const uint64_t c_end = cuts[u1] == UINT64_MAX ? F : std::min<uint64_t>(F, (cuts[u1] >> 16) + 4 * 65536);
             const uint64_t t_a = now_us();
@@ -364,10 +391,11 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
             uint64_t nrec = 0;
             const uint64_t t_c = now_us();
             us_read += t_b - t_a; us_scan += t_c - t_b;
-            struct PushTimer { std::atomic<uint64_t> &acc; uint64_t t0; std::function<uint64_t()> now; ~PushTimer() { acc += now() - t0; } } pt{us_push, t_c, now_us};
-            if (!eng->ck(eng->api->push_bgzf_units(eng->ctx, blob.data(), blob.size(), blocks.data(), (uint32_t)blocks.size(),
-                                                   units.data(), (uint32_t)units.size(), uo, o.flag_mask, o.min_mapq, status.data(),
-                                                   &nrec), "pd_push_bgzf_units")) break;
+            const bool pushed = eng->ck(eng->api->push_bgzf_units(eng->ctx, blob.data(), blob.size(), blocks.data(), (uint32_t)blocks.size(),
+                                                                units.data(), (uint32_t)units.size(), uo, o.flag_mask, o.min_mapq,
+                                                                status.data(), &nrec), "pd_push_bgzf_units");
+            us_push += now_us() - t_c;
+            if (!pushed) break;
             n_dev += nrec;
             for (size_t k = 0; k < units.size(); ++k) {
                 if (status[k] == 0) continue;
@@ -382,17 +410,17 @@ bool read_indexed_device(const std::string &path, const Options &o, const AlnHea
         }
         ::close(fd);
     };
-    if (threads <= 1) worker();
-    else {
+    {
         std::vector<std::thread> th;
-        for (int i = 0; i < threads; ++i) th.emplace_back(worker);
+        for (int i = 0; i < feeders; ++i) th.emplace_back(feeder);
+        for (int i = 0; i < host_workers; ++i) th.emplace_back(host_worker);
         for (auto &t : th) t.join();
     }
     if (getenv("PANDEPTH_TIMING"))
-        fprintf(stderr, "[timing] device decode: %zu batches, %zu units, %llu records on the device, %llu units (%llu records) handed back to the host; "
-                        "thread-seconds: read %.2f, block scan %.2f, pd_push_bgzf_units (incl. waiting for the GPU) %.2f\n",
-                batches.size(), cuts.size() - 1, (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(),
-                (unsigned long long)n_host.load(), us_read.load() / 1e6, us_scan.load() / 1e6, us_push.load() / 1e6);
+        fprintf(stderr, "[timing] device decode: %zu units; device: %llu batches, %llu records (%llu units handed back); host decoders (%d threads): %llu records; "
+                        "feeder thread-seconds: read %.2f, block scan %.2f, pd_push_bgzf_units %.2f\n",
+                n_units, (unsigned long long)n_batches.load(), (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(),
+                host_workers, (unsigned long long)n_host.load(), us_read.load() / 1e6, us_scan.load() / 1e6, us_push.load() / 1e6);
     return eng->ok();
 }
 

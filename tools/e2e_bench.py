@@ -37,7 +37,7 @@ def main():
                            stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_DECODE_ONLY="1"))
         return
     if os.environ.get("E2E_DEVICE_DECODE"):
-        for bmb, t in (("2048", 4),):
+        for bmb, t in (("2048", 2), ("1024", 16), ("2048", 16), ("2048", 32)):
             best = 1e9
             for rep in range(2):
                 a = time.perf_counter()
