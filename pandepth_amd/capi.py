@@ -111,8 +111,12 @@ def bgzf_inflate(data, variant=0, reps=1, device=0, want_output=True):
     n = ctypes.c_size_t()
     ms = ctypes.c_double()
     nb = ctypes.c_uint32()
-    # first call without output to learn the size
-    cap = int(buf.size) * 12 + (1 << 20)
+    # exact output size from the ISIZE trailers of the blocks
+    cap, o = 64, 0
+    while o + 18 <= buf.size:
+        bs = int(buf[o + 16]) + (int(buf[o + 17]) << 8) + 1
+        cap += int.from_bytes(bytes(buf[o + bs - 4:o + bs]), "little")
+        o += bs
     out = np.empty(cap if want_output else 1, dtype=np.uint8)
     rc = L.pd_x_bgzf_inflate(int(device), _ptr(buf), buf.size, _ptr(out) if want_output else None, out.size if want_output else 0,
                              ctypes.byref(n), int(variant), int(reps), ctypes.byref(ms), ctypes.byref(nb))
