@@ -10,10 +10,16 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   first-run stream (PD_PUSH_MORE) and the ~11 % second runs of D/I/N reads,
                                   which are only nearly sorted (PD_PUSH_DISORDER(max read span)), served by
                                   the same passes over the tiles
-    [N > 1]                       RCCL sum-reduce of the difference arrays (int8 image + exception list,
-                                  pandepth_amd.multi.PackedSum) and the tile sums to rank 0
     pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
                                   reduction, results copied back to the host
+    [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pandepth_amd.multi.SlicedSum):
+                                  4-bit image (pd_export_i4), all-to-all over RCCL so that every xGMI link of a
+                                  GPU carries 1/N of it at once, every rank sums + sweeps its 1/N of the tiles
+                                  (pd_slice_sweep_i4), rank 0 adds the per-tile partials up per bin
+                                  (pd_gather_windows).  Steps are software-pipelined: sample k+1 is scattered
+                                  while sample k's image is on the links; the timed region still contains K
+                                  complete steps (fill and drain included).  PD_BENCH_SUM=int8|int32 select
+                                  the older reduce-to-rank-0 forms, PD_BENCH_PIPELINE=0 the unpipelined order.
 
 The run stream is synthetic (tools/synth.py) and is resident in HBM before the
 timed region, as the contract asks; value = records / step time.  Host-side BAM decode is NOT in
@@ -134,16 +140,43 @@ def main():
     torch.cuda.synchronize()
     n_first, n_other = int(first.shape[0]), int(other.shape[0])
     _, n_words, _ = eng.device_buffer()
+    n_cells = eng.device_layout()[0]
     # N > 1: int8 transport of the difference arrays (1 B/cell on the xGMI links instead of 4);
     # PD_BENCH_SUM=int32 selects the plain int32 reduce of the whole buffer instead
-    packed = multi.PackedSum(eng, dev) if use_dist and os.environ.get("PD_BENCH_SUM", "int8") == "int8" else None
-    buf = multi.buffer_view(eng, dev) if use_dist and packed is None else None
+    sum_mode = os.environ.get("PD_BENCH_SUM", "sliced") if use_dist else None
+    sliced = multi.SlicedSum(eng, dev) if sum_mode == "sliced" else None
+    packed = multi.PackedSum(eng, dev) if sum_mode == "int8" else None
+    buf = multi.buffer_view(eng, dev) if sum_mode == "int32" else None
+    pipelined = sliced is not None and os.environ.get("PD_BENCH_PIPELINE", "1") == "1"
     wrap = 18 if use_dist else 0         # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
 
-    def step():
+    def scatter():
         eng.reset()
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+
+    def run_steps(k):
+        """k complete steps; returns the last step's result (rank 0)"""
+        res = None
+        if sliced is None:
+            for _ in range(k):
+                res = step()
+        elif not pipelined:
+            for _ in range(k):
+                scatter()
+                res = sliced.run(BIN, 1, wrap, 0)
+        else:
+            for i in range(k):
+                scatter()
+                sliced.start(i % 2)
+                if i:
+                    res = sliced.finish((i - 1) % 2, BIN, 1, wrap, 0)
+            if k:
+                res = sliced.finish((k - 1) % 2, BIN, 1, wrap, 0)
+        return res
+
+    def step():
+        scatter()
         if use_dist:
             if packed is not None:
                 is_root = packed.run(0)
@@ -162,14 +195,11 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     eng.profile(True)
     t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -179,7 +209,7 @@ def main():
 
     prof = {}
     for k in ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
-              "scan_reduce_windows", "export_i8", "import_i8"):
+              "scan_reduce_windows", "export_i8", "import_i8", "export_i4", "slice_sweep", "gather_windows"):
         ms, n = eng.profile_get(k)
         prof[k] = (ms, n)
     eng.profile(False)
@@ -209,6 +239,9 @@ def main():
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
             "export_i8": k_entry("export_i8", 5 * (n_words - (n_words - G) % 1)),     # 4 B read + 1 B written per cell
             "import_i8": k_entry("import_i8", 5 * (n_words - (n_words - G) % 1)),     # 1 B read + 4 B written per cell
+            "export_i4": k_entry("export_i4", 4.5 * n_cells),                        # 4 B read + 4 bits written per cell
+            # per rank: `world` nibble images of 1/world of the cells = n_cells / 2 bytes read, nothing written
+            "slice_sweep": k_entry("slice_sweep", 0.5 * n_cells),
         }
         dom = max((k for k in kernels if kernels[k] and "frac" in kernels[k]), key=lambda k: prof[k][0])
         kd = kernels[dom]
@@ -241,7 +274,9 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + ((", RCCL reduce to rank 0 (%s transport)" % ("int8" if packed else "int32")) if use_dist else ""),
+                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + ((", " + {
+                           "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
+                           "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),
                        "total_depth_check": total_depth},
             "roofline": roofline,
             "kernels": kernels,

@@ -158,6 +158,38 @@ int pd_device_layout(pd_ctx *ctx, uint64_t *n_cells, uint64_t *n_tile_sums);
 int pd_export_i8(pd_ctx *ctx, int threshold, void *dev_i8, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count);
 int pd_import_i8(pd_ctx *ctx, const void *dev_i8, int bias, const pd_exc *dev_exc, uint64_t n_exc);
 
+/* Sliced form of the multi-BAM sum (PD:2704-3014) for point-to-point xGMI: instead of funnelling
+ * every rank's image into one GPU, every rank keeps ONE contiguous range of tiles ("slice") of the
+ * summed arrays.  The images travel once, directly between the pairs (an all-to-all: every link of
+ * the GPU carries 1/n_ranks of the image at the same time), as 4-bit cells; nothing is added on
+ * the wire, so the value range does not shrink with the number of ranks.
+ *   pd_export_i4      one nibble per cell into dev_i4 (n_cells / 2 bytes; cell 2k in the low
+ *                     nibble of byte k), BIASED: d + 8 in [0, 15]; cells outside [-8, 7] are
+ *                     written as 0 (+bias) and appended to dev_exc as in pd_export_i8.
+ *   pd_slice_sweep_i4 the receiving side, for the tiles [tile_first, tile_first + tile_count) of the
+ *                     buffer (8192 cells each), in ONE fused kernel: adds the n_parts images of that
+ *                     range (part j at dev_parts + j * part_stride, tile_count * 4096 bytes each,
+ *                     16-byte aligned) and the exceptions (block j at dev_exc + j * exc_stride entries,
+ *                     dev_exc_counts[j] of them used; entries outside the range are ignored;
+ *                     dev_exc_counts may be NULL), prefix-sums them with the carries derived from
+ *                     dev_tile_sums (ALL tiles, already summed over the ranks), applies the wrap and
+ *                     reduces windows of w >= 8192 cells to per-tile partials: PD_TILE_PARTIAL_BYTES
+ *                     per tile at dev_partials, entry 0 = tile_first.  The summed arrays are never
+ *                     materialised; none of the context's accumulating state is touched.
+ *   pd_gather_windows on the root: adds the partials of all tiles (gathered from the ranks, in tile
+ *                     order) to the windows of pd_window_layout(w); same results as
+ *                     pd_scan_reduce_windows on a context holding the sum of all samples.
+ * All pointers except cover/sum are device pointers on the context's GPU; the kernels run on the
+ * context's stream. */
+#define PD_TILE_CELLS 8192
+#define PD_TILE_PARTIAL_BYTES 24
+int pd_export_i4(pd_ctx *ctx, void *dev_i4, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count);
+int pd_slice_sweep_i4(pd_ctx *ctx, const void *dev_parts, uint32_t n_parts, uint64_t part_stride,
+                      uint64_t tile_first, uint64_t tile_count, const int32_t *dev_tile_sums,
+                      const pd_exc *dev_exc, uint64_t exc_stride, const int32_t *dev_exc_counts,
+                      uint32_t w, uint32_t min_dep, unsigned wrap_bits, void *dev_partials);
+int pd_gather_windows(pd_ctx *ctx, const void *dev_partials, uint32_t w, uint32_t *cover, uint64_t *sum);
+
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
 int pd_synchronize(pd_ctx *ctx);
 

@@ -69,6 +69,10 @@ def load():
         "pd_device_layout": (I, [P, ctypes.POINTER(U64), ctypes.POINTER(U64)]),
         "pd_export_i8": (I, [P, I, P, P, ctypes.c_uint32, P]),
         "pd_import_i8": (I, [P, P, I, P, U64]),
+        "pd_export_i4": (I, [P, P, P, ctypes.c_uint32, P]),
+        "pd_slice_sweep_i4": (I, [P, P, ctypes.c_uint32, U64, U64, U64, P, P, U64, P, ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_uint, P]),
+        "pd_gather_windows": (I, [P, P, ctypes.c_uint32, P, P]),
         "pd_push_bgzf_units": (I, [P, P, SZ, P, ctypes.c_uint32, P, ctypes.c_uint32, U64, ctypes.c_uint32, ctypes.c_int32, P,
                                ctypes.POINTER(U64)]),
         "pd_x_bgzf_inflate": (I, [I, P, SZ, P, SZ, ctypes.POINTER(SZ), I, I, ctypes.POINTER(ctypes.c_double),
@@ -88,7 +92,8 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_push_bgzf_units", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_read_depth", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
+           "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -229,6 +234,26 @@ class Engine:
     def import_i8(self, i8_ptr, bias, exc_ptr, n_exc):
         self._ck(self.L.pd_import_i8(self.h, ctypes.c_void_p(int(i8_ptr)), int(bias),
                                      ctypes.c_void_p(int(exc_ptr) if n_exc else 0), int(n_exc)))
+
+    def export_i4(self, i4_ptr, exc_ptr, exc_cap, count_ptr):
+        self._ck(self.L.pd_export_i4(self.h, ctypes.c_void_p(int(i4_ptr)), ctypes.c_void_p(int(exc_ptr)), int(exc_cap),
+                                     ctypes.c_void_p(int(count_ptr))))
+
+    def slice_sweep_i4(self, parts_ptr, n_parts, part_stride, tile_first, tile_count, tile_sums_ptr, exc_ptr, exc_stride,
+                       exc_counts_ptr, w, min_dep, wrap_bits, partials_ptr):
+        self._ck(self.L.pd_slice_sweep_i4(self.h, ctypes.c_void_p(int(parts_ptr)), int(n_parts), int(part_stride),
+                                          int(tile_first), int(tile_count), ctypes.c_void_p(int(tile_sums_ptr)),
+                                          ctypes.c_void_p(int(exc_ptr) or None), int(exc_stride),
+                                          ctypes.c_void_p(int(exc_counts_ptr) or None), int(w), int(min_dep),
+                                          int(wrap_bits), ctypes.c_void_p(int(partials_ptr))))
+
+    def gather_windows(self, partials_ptr, w):
+        off = self.window_layout(w)
+        n = int(off[-1])
+        cover = np.zeros(max(n, 1), dtype=np.uint32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_gather_windows(self.h, ctypes.c_void_p(int(partials_ptr)), int(w), _ptr(cover), _ptr(tot)))
+        return off, cover[:n], tot[:n]
 
     def push_bgzf_units(self, blob, blocks, units, inflated_bytes, flag_mask=1796, min_mapq=-1):
         """blocks: (n,4) uint64-compatible rows {in_off, out_off, in_len, out_len}; units: rows

@@ -55,6 +55,7 @@ struct pd_ctx {
     uint32_t *ub_a[PD_MAXPEND] = {}, *cand_lo[PD_MAXPEND] = {};   // per pending batch, indexed by 4096-cell tile
     BatchDesc *desc = nullptr; CheckWords *chk = nullptr;         // desc: PD_MAXPEND entries
     uint8_t *hstate = nullptr; uint32_t n_half = 0;               // "written since reset" per 4096 cells
+    uint8_t *slice_flags = nullptr;                               // pd_slice_sweep_i4: tiles that own exceptions
     bool all_valid_host = false;
     std::vector<Pending> pend;
     // GPU-side BAM decode: device buffers grown on demand (index = purpose)
@@ -369,6 +370,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     }
     c->n_half = (uint32_t)(c->n_cells / PD_HALF);
     CREATE_OK(hipMalloc(&c->hstate, c->n_half + 16));
+    CREATE_OK(hipMalloc(&c->slice_flags, c->n_tiles + 16));
     CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc) * PD_MAXPEND));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
     {
@@ -402,7 +404,7 @@ int pd_destroy(pd_ctx *c)
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
-                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->desc, c->chk, c->ovf, c->scratch};
+                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->desc, c->chk, c->ovf, c->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->dd_buf) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->dd_ev) if (e) (void)hipEventDestroy(e);
@@ -848,6 +850,75 @@ int pd_import_i8(pd_ctx *c, const void *dev_i8, int bias, const pd_exc *dev_exc,
     HIPOK(c, hipMemsetAsync(c->hstate, 1, c->n_half, c->stream));      // every cell was just written
     c->all_valid_host = true;
     launch_mark_all_valid(c->stream, c->chk);
+    return PD_OK;
+}
+
+static_assert(sizeof(TilePart) == PD_TILE_PARTIAL_BYTES, "pd_gather_windows' partial layout");
+static_assert(PD_TILE == PD_TILE_CELLS, "tile size in the public header");
+
+int pd_export_i4(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count)
+{
+    if (!c || !dev_i4 || !dev_count || (exc_cap && !dev_exc)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != 0) return fail(c, PD_ESTATE, "pd_export_i4: depth already materialised");
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    HIPOK(c, hipMemsetAsync(dev_count, 0, 4, c->stream));
+    { ProfScope ps(c, "export_i4");
+      launch_export_i4(c->stream, c->buf, c->hstate, dev_i4, c->n_cells, dev_exc, exc_cap, dev_count); }
+    HIPOK(c, hipGetLastError());
+    return PD_OK;
+}
+
+int pd_slice_sweep_i4(pd_ctx *c, const void *dev_parts, uint32_t n_parts, uint64_t part_stride, uint64_t tile_first,
+                      uint64_t tile_count, const int32_t *dev_tile_sums, const pd_exc *dev_exc, uint64_t exc_stride,
+                      const int32_t *dev_exc_counts, uint32_t w, uint32_t min_dep, unsigned wrap_bits, void *dev_partials)
+{
+    if (!c || !dev_parts || !n_parts || !dev_tile_sums || !dev_partials || wrap_bits > 32) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (w < PD_TILE) return fail(c, PD_EINVAL, "pd_slice_sweep_i4: windows narrower than a tile are not sliced");
+    if (tile_first > c->n_tiles || tile_count > c->n_tiles - tile_first)
+        return fail(c, PD_EINVAL, "pd_slice_sweep_i4: tile range outside the buffer");
+    if (n_parts > 1 && part_stride < tile_count * (PD_TILE / 2)) return fail(c, PD_EINVAL, "pd_slice_sweep_i4: parts overlap");
+    if (((uintptr_t)dev_parts | part_stride) & 15) return fail(c, PD_EINVAL, "pd_slice_sweep_i4: parts must be 16-byte aligned");
+    HIPOK(c, hipSetDevice(c->device));
+    const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
+    { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, dev_tile_sums, c->bsum, c->carry, (uint32_t)c->n_tiles); }
+    { ProfScope ps(c, "slice_sweep");
+      TileMap tm{c->d_tile_contig, c->d_off, c->d_len, nullptr};
+      launch_sweep_i4(c->stream, dev_parts, n_parts, part_stride, (uint32_t)tile_first, (uint32_t)tile_count, dev_exc, exc_stride,
+                      dev_exc_counts, c->slice_flags, c->carry, mask, tm, w, min_dep, (TilePart *)dev_partials); }
+    HIPOK(c, hipGetLastError());
+    return PD_OK;
+}
+
+int pd_gather_windows(pd_ctx *c, const void *dev_partials, uint32_t w, uint32_t *cover, uint64_t *sum)
+{
+    if (!c || !dev_partials || !cover || !sum) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (w < PD_TILE) return fail(c, PD_EINVAL, "pd_gather_windows: windows narrower than a tile are not sliced");
+    HIPOK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> wo((size_t)c->n_contigs + 1);
+    pd_window_layout(c, w, wo.data());
+    const uint64_t nw = wo[c->n_contigs];
+    const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
+    const size_t b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
+    int rc = ensure_scratch(c, b_off + b_sum + b_cov + 64);
+    if (rc) return rc;
+    unsigned char *s = (unsigned char *)c->scratch;
+    uint64_t *d_wo = (uint64_t *)s;
+    unsigned long long *d_sum = (unsigned long long *)(s + b_off);
+    uint32_t *d_cov = (uint32_t *)(s + b_off + b_sum);
+    HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
+    { ProfScope ps(c, "gather_windows");
+      TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
+      launch_window_gather(c->stream, (const TilePart *)dev_partials, tm, c->n_contigs, w, nw, d_cov, d_sum); }
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipMemcpyAsync(cover, d_cov, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
     return PD_OK;
 }
 

@@ -79,6 +79,13 @@ void launch_export_i8(hipStream_t st, const int *diff, const uint8_t *hstate, vo
                       pd_exc *exc, uint32_t cap, uint32_t *count);
 void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cells, int bias, const pd_exc *exc,
                       uint64_t n_exc);
+void launch_export_i4(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells,
+                      pd_exc *exc, uint32_t cap, uint32_t *count);
+void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
+                     uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags,
+                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part);
+void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
+                          uint64_t n_windows, uint32_t *cover, unsigned long long *sum);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,
                           uint32_t min_dep, int *cover, unsigned long long *sum);
 

@@ -671,6 +671,158 @@ __global__ __launch_bounds__(WG) void k_apply_exceptions(const pd_exc *exc, uint
         if (exc[i].cell < n_cells) atomicAdd(&diff[exc[i].cell], exc[i].value);
 }
 
+// ------------------------------------------------------------------------------------------
+// 4-bit transport for the SLICED sum: the images are exchanged pairwise (all-to-all) and added on
+// the receiving GPU in int32, so a nibble (d + 8) per cell is enough whatever the number of ranks.
+// ------------------------------------------------------------------------------------------
+// one workgroup per tile and step; every load is a full 1 KiB wave transaction (lane-contiguous
+// int4), every store 128 contiguous bytes (one ushort = 4 cells per lane)
+__global__ __launch_bounds__(WG) void k_export_i4(const int *diff, const uint8_t *hstate, unsigned short *out,
+                                                       uint32_t n_tiles, pd_exc *exc, uint32_t cap, uint32_t *count)
+{
+    constexpr int ROWS = TILE / (WG * 4);                        // 8
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t cw = (uint64_t)t * TILE + (uint64_t)wv * (ROWS * 256);       // first cell of this wave
+        unsigned short *o = out + cw / 4 + lane;
+        if (!hstate[(uint64_t)t * (TILE / PD_HALF) + (wv >> 1)]) {                   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) o[r * 64] = 0x8888;
+            continue;
+        }
+        const int4 *p4 = reinterpret_cast<const int4 *>(diff + cw) + lane;
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) v[r] = p4[r * 64];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            int x[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+            unsigned w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (x[k] > 7 || x[k] < -8) {
+                    const uint32_t slot = atomicAdd(count, 1u);
+                    if (slot < cap) { exc[slot].cell = cw + r * 256 + lane * 4 + k; exc[slot].value = x[k]; exc[slot].pad = 0; }
+                    x[k] = 0;
+                }
+                w |= (unsigned)((x[k] + 8) & 0xf) << (4 * k);
+            }
+            o[r * 64] = (unsigned short)w;
+        }
+    }
+}
+
+// marks the tiles of the slice [tile0, tile0 + n_tiles) that own an exception of any part (blockIdx.y)
+__global__ __launch_bounds__(WG) void k_flag_exception_tiles(const pd_exc *exc, uint64_t exc_stride, const int32_t *counts,
+                                                             uint64_t tile0, uint64_t n_tiles, uint8_t *flags)
+{
+    const uint32_t j = blockIdx.y;
+    uint64_t n = counts[j] < 0 ? 0 : (uint64_t)counts[j];
+    if (n > exc_stride) n = exc_stride;
+    const pd_exc *e = exc + (uint64_t)j * exc_stride;
+    for (uint64_t i = blockIdx.x * (uint64_t)WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        const uint64_t t = e[i].cell / TILE;
+        if (t >= tile0 && t - tile0 < n_tiles) flags[t - tile0] = 1;
+    }
+}
+
+// The receiving side of the sliced sum, fused: one workgroup per tile of the slice reads the tile's
+// 4 KiB of every part (one 16-byte load per lane and part = the lane's 32 consecutive cells), adds
+// them in registers, prefix-sums (32 cells in the lane, one wave scan of the lane totals, wave bases
+// through LDS, tile carry), wraps, and reduces the tile's share of the (at most two) windows of
+// w >= TILE cells it touches.  No int32 copy of the summed arrays ever exists.  Tiles that own
+// exceptions (rare: pile-ups) patch them in through LDS.
+struct I4Src {
+    const uint8_t *parts; uint64_t stride; uint32_t n_parts;
+    const uint8_t *flags;                     // per tile of the slice, or null
+    const pd_exc *exc; uint64_t exc_stride; const int32_t *counts;
+};
+
+__global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
+                                                 uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0)
+{
+    __shared__ int wtot[4];
+    __shared__ int patch[TILE];
+    __shared__ unsigned long long red_s[4][2];
+    __shared__ int red_c[4][2];
+    const uint32_t i = blockIdx.x;
+    const uint64_t t = (uint64_t)i + tile0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int a[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a[k] = -8 * (int)src.n_parts;
+    const uint8_t *p = src.parts + (uint64_t)i * (TILE / 2) + (uint64_t)tid * 16;
+    // the parts are added as packed bytes (even / odd nibbles of each word widened to bytes: up to
+    // 16 parts fit, 15 * 16 < 256) and only then spread into the 32 int accumulators
+    for (uint32_t j0 = 0; j0 < src.n_parts; j0 += 16) {
+        unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        const uint32_t j1 = j0 + 16 < src.n_parts ? j0 + 16 : src.n_parts;
+        for (uint32_t j = j0; j < j1; ++j) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(p + (uint64_t)j * src.stride);
+            const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { lo[m] += wd[m] & 0x0F0F0F0Fu; hi[m] += (wd[m] >> 4) & 0x0F0F0F0Fu; }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                a[8 * m + 2 * b] += (int)((lo[m] >> (8 * b)) & 0xff);
+                a[8 * m + 2 * b + 1] += (int)((hi[m] >> (8 * b)) & 0xff);
+            }
+    }
+    if (src.flags && src.flags[i]) {                             // workgroup-uniform
+        for (int k = tid; k < TILE; k += WG) patch[k] = 0;
+        __syncthreads();
+        for (uint32_t j = 0; j < src.n_parts; ++j) {
+            uint64_t n = src.counts[j] < 0 ? 0 : (uint64_t)src.counts[j];
+            if (n > src.exc_stride) n = src.exc_stride;
+            const pd_exc *e = src.exc + (uint64_t)j * src.exc_stride;
+            for (uint64_t x = tid; x < n; x += WG)
+                if (e[x].cell / TILE == t) atomicAdd(&patch[e[x].cell % TILE], e[x].value);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] += patch[tid * 32 + k];
+    }
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { run += a[k]; a[k] = run; }
+    const int incl = wave_incl_scan(run);
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int base = carry[t] + incl - run;
+    for (int k = 0; k < wv; ++k) base += wtot[k];
+
+    const uint32_t ctg = tmap.tile_contig[t];
+    const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
+    const uint32_t clen = tmap.contig_len[ctg];
+    int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+    if (local0 < clen) {
+        const uint64_t k0 = local0 / w;
+        const uint64_t nb = (k0 + 1) * (uint64_t)w - local0;     // tile-local start of window k0+1
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const uint32_t pos = (uint32_t)(tid * 32 + k);
+            const uint32_t d = (uint32_t)(a[k] + base) & wrap_mask;
+            if (local0 + pos < clen && d >= min_dep) { if (pos < nb) { ++c0; s0 += d; } else { ++c1; s1 += d; } }
+        }
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        TilePart tp;
+        tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+        tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+        tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+        tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+        part[i] = tp;
+    }
+}
+
 __global__ __launch_bounds__(WG) void k_add_i32(int4 *dst, const int4 *src, size_t n16)
 {
     size_t i = blockIdx.x * (size_t)WG + threadIdx.x;
@@ -700,6 +852,36 @@ void launch_import_i8(hipStream_t st, const void *in, int *diff, uint64_t n_cell
 {
     hipLaunchKernelGGL(k_import_i8, dim3(8192), dim3(WG), 0, st, (const int4 *)in, diff, n_cells, bias);
     if (n_exc) hipLaunchKernelGGL(k_apply_exceptions, dim3(256), dim3(WG), 0, st, exc, n_exc, diff, n_cells);
+}
+
+void launch_export_i4(hipStream_t st, const int *diff, const uint8_t *hstate, void *out, uint64_t n_cells,
+                      pd_exc *exc, uint32_t cap, uint32_t *count)
+{
+    hipLaunchKernelGGL(k_export_i4, dim3(16384), dim3(WG), 0, st, diff, hstate, (unsigned short *)out,
+                       (uint32_t)(n_cells / TILE), exc, cap, count);
+}
+
+void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
+                     uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags,
+                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part)
+{
+    if (!tile_count) return;
+    const bool with_exc = exc && exc_counts && exc_stride && flags;
+    if (with_exc) {
+        (void)hipMemsetAsync(flags, 0, tile_count, st);
+        hipLaunchKernelGGL(k_flag_exception_tiles, dim3(64, n_parts), dim3(WG), 0, st, exc, exc_stride, exc_counts,
+                           (uint64_t)tile_first, (uint64_t)tile_count, flags);
+    }
+    I4Src src{(const uint8_t *)parts, stride, n_parts, with_exc ? flags : nullptr, exc, exc_stride, exc_counts};
+    hipLaunchKernelGGL(k_sweep_i4, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
+}
+
+void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
+                          uint64_t n_windows, uint32_t *cover, unsigned long long *sum)
+{
+    if (!n_windows) return;
+    hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n_windows + 3) / 4)), dim3(WG), 0, st, part, tm, n_contigs,
+                       w, n_windows, cover, sum);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -98,3 +98,136 @@ class PackedSum:
             e.import_i8(self.i8.data_ptr(), self.world * self.threshold, self.exc.data_ptr(), n_exc if self.world == 1 else 0)
             e.synchronize()
         return is_root
+
+
+TILE = 8192                    # include/pandepth_amd.h PD_TILE_CELLS
+PART_BYTES = 24                # PD_TILE_PARTIAL_BYTES
+
+
+class SlicedSum:
+    """Multi-sample sum shaped for point-to-point xGMI (whole-chromosome / wide-window mode): no GPU
+    ever receives everybody's arrays.  Rank r keeps the tiles [r * slice_tiles, (r + 1) * slice_tiles):
+
+        start    export   4-bit image of this rank's difference arrays (+ exception block)   pd_export_i4
+                 exchange all-to-all of the image: every pair of GPUs moves 1/world of it over its
+                          own link, all links at once; all-reduce of the int32 tile sums (+ the
+                          exception counts), all-gather of the (64 Ki-entry) exception blocks
+        finish   sweep    one fused kernel: sum of the `world` images of the slice, prefix sum with
+                          carries from the summed tile sums, 18-bit wrap, window partials pd_slice_sweep_i4
+                 gather   24 B per tile to the root, which adds them up per window       pd_gather_windows
+
+    start() only enqueues (the collectives are asynchronous), so a caller with several samples per
+    rank can scatter sample k+1 while sample k's image is on the links: `depth` slots of buffers.
+    With stream_mode "engine" torch runs on the context's own HIP stream (ExternalStream), so kernels
+    and collectives are ordered on the device and the host never waits in between; "sync" orders
+    them with host synchronisation instead."""
+
+    EXC_BLOCK = 1 << 16
+
+    def __init__(self, engine, device, group=None, sums=None, depth=2, stream_mode=None):
+        self.e, self.dev, self.group = engine, torch.device(device), group
+        self.dist = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank = dist.get_rank(group) if self.dist else 0
+        n_cells, n_sums = engine.device_layout()
+        self.n_cells, self.n_sums = n_cells, n_sums
+        self.n_tiles = n_cells // TILE
+        self.slice_tiles = max(1, -(-self.n_tiles // self.world))
+        self.slice_bytes = self.slice_tiles * (TILE // 2)
+        self.tile_first = min(self.rank * self.slice_tiles, self.n_tiles)
+        self.tile_count = min(self.slice_tiles, self.n_tiles - self.tile_first)
+        self.sums = sums if sums is not None else buffer_view(engine, device)[n_cells:]
+        if stream_mode is None:
+            stream_mode = "engine" if self.dev.type == "cuda" else "sync"
+        self.stream_mode = stream_mode
+        self._ext = torch.cuda.ExternalStream(engine.stream(), device=self.dev) if stream_mode == "engine" else None
+        W, B = self.world, self.EXC_BLOCK
+        kw = dict(device=self.dev)
+        self.slots = []
+        with self._stream():
+            for _ in range(depth):
+                self.slots.append(dict(
+                    send=torch.zeros(W * self.slice_bytes, dtype=torch.uint8, **kw),      # tail beyond n_cells / 2 stays 0
+                    recv=torch.empty(W * self.slice_bytes, dtype=torch.uint8, **kw),
+                    meta=torch.zeros(n_sums + W, dtype=torch.int32, **kw),               # tile sums | exception counts
+                    exc=torch.zeros((B, 2), dtype=torch.int64, **kw),                    # pd_exc = {u64 cell; i32 value; i32 pad}
+                    exc_all=torch.zeros((W * B, 2), dtype=torch.int64, **kw),
+                    count=torch.zeros(1, dtype=torch.int32, **kw), works=None))
+            self.part_mine = torch.zeros(self.slice_tiles * PART_BYTES, dtype=torch.uint8, **kw)
+            self.part_all = torch.zeros(W * self.slice_tiles * PART_BYTES, dtype=torch.uint8, **kw)
+        self._sync_all()
+
+    # -- ordering between the context's stream and torch's ------------------------------------
+    def _stream(self):
+        import contextlib
+        return torch.cuda.stream(self._ext) if self._ext is not None else contextlib.nullcontext()
+
+    def _sync_all(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def _engine_then_torch(self):
+        if self._ext is None:
+            self.e.synchronize()
+
+    def _torch_then_engine(self):
+        if self._ext is None:
+            self._sync_all()
+
+    # -- protocol -----------------------------------------------------------------------------
+    def start(self, slot=0):
+        """Packs this rank's arrays and puts them on the links; returns immediately.  The
+        context may be reset and refilled right after."""
+        s, W = self.slots[slot], self.world
+        with self._stream():
+            self.e.export_i4(s["send"].data_ptr(), s["exc"].data_ptr(), self.EXC_BLOCK, s["count"].data_ptr())
+            self._engine_then_torch()
+            meta = s["meta"]
+            meta[:self.n_sums].copy_(self.sums)
+            meta[self.n_sums:].zero_()
+            meta[self.n_sums + self.rank:self.n_sums + self.rank + 1].copy_(s["count"])
+            if self.dist:
+                s["works"] = [
+                    dist.all_to_all_single(s["recv"], s["send"], group=self.group, async_op=True),
+                    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                    dist.all_gather_into_tensor(s["exc_all"], s["exc"], group=self.group, async_op=True)]
+            else:
+                s["recv"].copy_(s["send"])
+                s["exc_all"].copy_(s["exc"])
+                s["works"] = []
+            if self._ext is None:
+                self._sync_all()          # "sync" mode: the context's next kernels must not overtake the copies above
+
+    def finish(self, slot=0, w=10000000, min_dep=1, wrap_bits=18, root=0):
+        """Completes the sum started in `slot`.  Returns (win_off, cover, depth_sum) on the root —
+        the results pd_scan_reduce_windows gives on a context holding every sample — else None."""
+        s, W = self.slots[slot], self.world
+        with self._stream():
+            for wk in s["works"]:
+                wk.wait()
+            s["works"] = None
+            self._torch_then_engine()
+            meta = s["meta"]
+            self.e.slice_sweep_i4(s["recv"].data_ptr(), W, self.slice_bytes, self.tile_first, self.tile_count,
+                                  meta.data_ptr(), s["exc_all"].data_ptr(), self.EXC_BLOCK,
+                                  meta.data_ptr() + 4 * self.n_sums, w, min_dep, wrap_bits, self.part_mine.data_ptr())
+            self._engine_then_torch()
+            is_root = self.rank == root
+            if self.dist:
+                chunks = list(self.part_all.view(W, -1).unbind(0)) if is_root else None
+                dist.gather(self.part_mine, chunks, dst=root, group=self.group)
+            else:
+                self.part_all.copy_(self.part_mine)
+            res = None
+            if is_root:
+                self._torch_then_engine()
+                res = self.e.gather_windows(self.part_all.data_ptr(), w)
+            counts = meta[self.n_sums:].tolist()
+            if max(counts) > self.EXC_BLOCK:
+                raise RuntimeError("a sample has %d cells outside the 4-bit range (block of %d): use PackedSum / sum_to_root"
+                                   % (max(counts), self.EXC_BLOCK))
+            return res
+
+    def run(self, w=10000000, min_dep=1, wrap_bits=18, root=0):
+        self.start(0)
+        return self.finish(0, w, min_dep, wrap_bits, root)

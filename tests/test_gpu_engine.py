@@ -387,3 +387,132 @@ def test_accumulate_from_equals_pushing_into_one_context():
     with pda.Engine(LENS) as e1, pda.Engine([5, 7]) as e2:
         with pytest.raises(pda.PdError):
             e1.accumulate_from(e2)
+
+
+# ---------------------------------------------------------------------------------------------
+# sliced multi-sample sum: 4-bit images exchanged pairwise, every rank sweeps its own slice
+# ---------------------------------------------------------------------------------------------
+def _sliced_samples(rng, world, n=30000):
+    samples = []
+    for r in range(world):
+        iv = rand_intervals(rng, LENS, n)
+        if r < 2:                                                   # pile-ups beyond the nibble range: exceptions,
+            iv = np.concatenate([iv, np.tile(np.array([[1, 700 + r, 900]], dtype=np.int32), (300, 1)),
+                                 np.tile(np.array([[0, 8190, 8200 + r]], dtype=np.int32), (40, 1))])   # ... across a tile edge
+        samples.append(iv)
+    return samples
+
+
+@pytest.mark.parametrize("world,w,min_dep", [(2, 10000, 1), (3, 8192, 3), (8, 10000000, 1), (5, 250000, 2)])
+def test_sliced_sum_kernels_manual_exchange(world, w, min_dep):
+    """pd_export_i4 -> (the all-to-all, done here by slicing tensors) -> pd_slice_sweep_i4 on every
+    "rank" -> pd_gather_windows on the root  ==  pd_scan_reduce_windows(18-bit) on one context that
+    received every sample (list mode, PD:2704-3014), and == the oracle's per-base increments."""
+    import torch
+    from pandepth_amd import multi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(70 + world)
+    samples = _sliced_samples(rng, world)
+    d, off = oracle_depth(LENS, np.concatenate(samples), True)
+    cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
+    B = 4096
+    engines = [pda.Engine(LENS) for _ in range(world)]
+    try:
+        n_cells, n_sums = engines[0].device_layout()
+        n_tiles = n_cells // TILE
+        st = -(-n_tiles // world)
+        sb = st * (TILE // 2)
+        sends, excs, counts, sums = [], [], [], None
+        for e, iv in zip(engines, samples):
+            e.push_intervals(sort_iv(iv), pda.PD_PUSH_SORTED)
+            send = torch.zeros(world * sb, dtype=torch.uint8, device=dev)
+            exc = torch.zeros((B, 2), dtype=torch.int64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            e.export_i4(send.data_ptr(), exc.data_ptr(), B, cnt.data_ptr())
+            e.synchronize()
+            assert 0 <= int(cnt.item()) <= B
+            sends.append(send); excs.append(exc); counts.append(int(cnt.item()))
+            tail = multi.buffer_view(e, dev)[n_cells:]
+            sums = tail.clone() if sums is None else sums + tail
+        assert sum(counts) >= 2
+        exc_all = torch.cat(excs, 0).contiguous()
+        cnt_all = torch.tensor(counts, dtype=torch.int32, device=dev)
+        part_all = torch.zeros(world * st * 24, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for r, e in enumerate(engines):
+            t0 = min(r * st, n_tiles); tc = min(st, n_tiles - t0)
+            recv = torch.cat([s[r * sb:(r + 1) * sb] for s in sends]).contiguous()
+            torch.cuda.synchronize()
+            e.slice_sweep_i4(recv.data_ptr(), world, sb, t0, tc, sums.data_ptr(), exc_all.data_ptr(), B, cnt_all.data_ptr(),
+                             w, min_dep, 18, part_all.data_ptr() + t0 * 24)
+            e.synchronize()
+        woff, cover, tot = engines[0].gather_windows(part_all.data_ptr(), w)
+        assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
+        # and the engine's own single-context result
+        with pda.Engine(LENS) as one:
+            for iv in samples:
+                one.push_intervals(iv)
+            woff1, cover1, tot1 = one.scan_reduce_windows(w, min_dep, 18)
+        assert np.array_equal(woff, woff1) and np.array_equal(cover, cover1) and np.array_equal(tot, tot1)
+        with pytest.raises(pda.PdError):
+            engines[0].slice_sweep_i4(sends[0].data_ptr(), 1, sb, 0, 1, sums.data_ptr(), 0, 0, 0, 100, 1, 18,
+                                      part_all.data_ptr())                           # w < 8192 is not sliced
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.parametrize("mode", ["engine", "sync"])
+def test_sliced_sum_single_rank(mode):
+    import torch
+    from pandepth_amd import multi
+    rng = np.random.default_rng(81)
+    iv = np.concatenate([rand_intervals(rng, LENS, 50000), np.tile(np.array([[0, 10, 50]], dtype=np.int32), (1000, 1))])
+    d, off = oracle_depth(LENS, iv, True)
+    with pda.Engine(LENS) as e:
+        ss = multi.SlicedSum(e, torch.device("cuda", 0), stream_mode=mode)
+        for rep in range(2):                                  # slots are reusable; the context is reset in between
+            e.reset()
+            e.push_intervals(iv)
+            ss.start(rep)
+            e.reset()                                         # the image is on its way: the context is free again
+            woff, cover, tot = ss.finish(rep, 10000, 1, 18)
+            cov_ref, tot_ref = windows_ref(LENS, d, off, 10000, 1)
+            assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
+
+
+def test_sliced_sum_one_rank_rccl_group(tmp_path):
+    """The collective code path (all_to_all_single / all_reduce / all_gather / gather over RCCL) with a
+    1-rank group, two samples in flight; run in a child process that owns the process group."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
+import pandepth_amd as pda
+from pandepth_amd import multi
+from test_gpu_engine import LENS, rand_intervals, oracle_depth, windows_ref
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29877", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(91)
+ivs = [np.concatenate([rand_intervals(rng, LENS, 40000), np.tile(np.array([[0, 10 + k, 50]], dtype=np.int32), (500, 1))]) for k in range(3)]
+with pda.Engine(LENS) as e:
+    ss = multi.SlicedSum(e, torch.device("cuda", 0))
+    assert ss.stream_mode == "engine"
+    res = []
+    for k, iv in enumerate(ivs):                    # software pipeline: start(k), then finish(k - 1)
+        e.reset(); e.push_intervals(iv); ss.start(k %% 2)
+        if k: res.append(ss.finish((k - 1) %% 2, 10000, 1, 18))
+    res.append(ss.finish((len(ivs) - 1) %% 2, 10000, 1, 18))
+    for iv, (woff, cover, tot) in zip(ivs, res):
+        d, off = oracle_depth(LENS, iv, True)
+        c, t = windows_ref(LENS, d, off, 10000, 1)
+        assert np.array_equal(cover, c) and np.array_equal(tot, t)
+dist.destroy_process_group()
+print("SLICED-RCCL-OK")
+''' % (root, root, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SLICED-RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
