@@ -175,8 +175,8 @@ def main():
                 res = sliced.finish((k - 1) % 2, BIN, 1, wrap, 0)
         return res
 
-    def step():
-        scatter()
+    def sum_to_rank0():
+        """the older forms: everybody's arrays into rank 0, which sweeps them"""
         if use_dist:
             if packed is not None:
                 is_root = packed.run(0)
@@ -189,12 +189,28 @@ def main():
                 return None
         return eng.scan_reduce_windows(BIN, 1, wrap)
 
+    def step():
+        scatter()
+        return sum_to_rank0()
+
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
 
+    selfcheck = None
+    if use_dist:
+        # the multi-GPU sum against what it must equal: depth sums are additive, so the bins of the summed
+        # result (rank 0) = the sum over ranks of each rank's own single-GPU bins (no wrap below 2^18)
+        scatter()
+        own = torch.from_numpy(eng.scan_reduce_windows(BIN, 1, wrap)[2].astype(np.int64)).to(dev)
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+        got = sliced.run(BIN, 1, wrap, 0) if sliced is not None else sum_to_rank0()
+        if rank == 0:
+            selfcheck = bool(np.array_equal(got[2].astype(np.int64), own.cpu().numpy()))
+            if not selfcheck:
+                raise SystemExit("multi-GPU sum (%s) disagrees with the sum of the per-rank results" % sum_mode)
     run_steps(args.warmup)
     barrier()
     eng.profile(True)
@@ -277,7 +293,7 @@ def main():
                        "cells": int(n_words), "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
                            "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),
-                       "total_depth_check": total_depth},
+                       "total_depth_check": total_depth, "multi_gpu_sum_selfcheck": selfcheck},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cb,

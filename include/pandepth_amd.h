@@ -101,7 +101,8 @@ int pd_stage_acquire(pd_ctx *ctx, pd_iv **host_buf, size_t *capacity);
 int pd_stage_submit(pd_ctx *ctx, pd_iv *host_buf, size_t n, unsigned flags);
 
 /* Tuning knobs: "lmax" (owner-tile look-back in cells; longer runs take the overflow path),
- * "sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the tile kernel). */
+ * "sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the tile kernel),
+ * "accumulate_packed" (pd_accumulate_from's transport, default 1). */
 int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
 
 /* Difference arrays -> per-base depth, in place (the wavefront prefix-sum sweep).
@@ -138,7 +139,10 @@ int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *ou
 int pd_device_buffer(pd_ctx *ctx, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off);
 /* Single-process form of the same sum (the CLI's `#.list` over several GPUs, one context per GPU):
  * dst += src, difference arrays and tile sums, chunk by chunk through a peer copy over xGMI and an
- * add kernel on dst's GPU.  Both contexts must describe the same contigs and be accumulating. */
+ * add kernel on dst's GPU.  Both contexts must describe the same contigs and be accumulating.
+ * Transport: the source packs its cells to nibbles (d + 8, pd_export_i4's image) + an exception list on
+ * its own GPU, so 1/8 of the int32 bytes cross the link; more than 2^20 cells outside [-8, 7], or
+ * pd_set_param(dst, "accumulate_packed", 0), selects plain int32 chunks. */
 int pd_device_count(int *n);
 int pd_accumulate_from(pd_ctx *dst, pd_ctx *src);
 

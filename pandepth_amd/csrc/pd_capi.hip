@@ -56,6 +56,7 @@ struct pd_ctx {
     BatchDesc *desc = nullptr; CheckWords *chk = nullptr;         // desc: PD_MAXPEND entries
     uint8_t *hstate = nullptr; uint32_t n_half = 0;               // "written since reset" per 4096 cells
     uint8_t *slice_flags = nullptr;                               // pd_slice_sweep_i4: tiles that own exceptions
+    bool accumulate_packed = true;                                // pd_accumulate_from: 4-bit transport
     bool all_valid_host = false;
     std::vector<Pending> pend;
     // GPU-side BAM decode: device buffers grown on demand (index = purpose)
@@ -437,6 +438,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
         c->stile = (int)value; return PD_OK;
     }
     if (!strcmp(name, "grid_tiles")) { if (value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
+    if (!strcmp(name, "accumulate_packed")) { c->accumulate_packed = value != 0; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
 
@@ -778,14 +780,43 @@ int pd_accumulate_from(pd_ctx *dst, pd_ctx *src)
     if (dst->n_words != src->n_words || dst->n_contigs != src->n_contigs || dst->len != src->len)
         return fail(dst, PD_EINVAL, "pd_accumulate_from: the contexts describe different contigs");
     if (dst->state != 0 || src->state != 0) return fail(dst, PD_ESTATE, "pd_accumulate_from: both contexts must be accumulating");
-    // materialise the source (zeros where nothing was written) and finish its work
     HIPOK(src, hipSetDevice(src->device));
     int rc = flush_pending(src);
     if (rc) { dst->err = src->err; return rc; }
     rc = check_words(src);
     if (rc) { dst->err = src->err; return rc; }
-    rc = ensure_all_valid(src);
-    if (rc) { dst->err = src->err; return rc; }
+    if (dst->device != src->device) {
+        HIPOK(dst, hipSetDevice(dst->device));
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, dst->device, src->device);
+        if (can) (void)hipDeviceEnablePeerAccess(src->device, 0);    // already enabled is fine
+        (void)hipGetLastError();
+        HIPOK(src, hipSetDevice(src->device));
+    }
+    // Packed transport (default): the source packs its cells to nibbles (d + 8) + an exception list
+    // on its own GPU — 1.5 GB instead of 12 GB over the link for a 3 Gb genome; never-written
+    // half-tiles need no fill.  More than EXC_CAP cells outside [-8, 7]: the int32 path below.
+    constexpr uint32_t EXC_CAP = 1u << 20;
+    const size_t img_bytes = dst->n_cells / 2, exc_bytes = (size_t)EXC_CAP * sizeof(pd_exc);
+    bool packed = dst->accumulate_packed;
+    uint32_t n_exc = 0;
+    if (packed) {
+        rc = ensure_scratch(src, 16 + exc_bytes + img_bytes);
+        if (rc) { dst->err = src->err; return rc; }
+        unsigned char *ss = (unsigned char *)src->scratch;
+        HIPOK(src, hipMemsetAsync(ss, 0, 16, src->stream));
+        { ProfScope ps(src, "export_i4");
+          launch_export_i4(src->stream, src->buf, src->hstate, ss + 16 + exc_bytes, src->n_cells, (pd_exc *)(ss + 16), EXC_CAP,
+                           (uint32_t *)ss); }
+        HIPOK(src, hipMemcpyAsync(&n_exc, ss, 4, hipMemcpyDeviceToHost, src->stream));
+        HIPOK(src, hipStreamSynchronize(src->stream));
+        if (n_exc > EXC_CAP) packed = false;
+    }
+    if (!packed) {
+        // int32 transport: materialise the source (zeros where nothing was written)
+        rc = ensure_all_valid(src);
+        if (rc) { dst->err = src->err; return rc; }
+    }
     HIPOK(src, hipStreamSynchronize(src->copy_stream));
     HIPOK(src, hipStreamSynchronize(src->stream));
     HIPOK(dst, hipSetDevice(dst->device));
@@ -794,19 +825,34 @@ int pd_accumulate_from(pd_ctx *dst, pd_ctx *src)
     rc = ensure_all_valid(dst);
     if (rc) return rc;
     const size_t CH = (size_t)64 << 20;                               // words per chunk (256 MiB)
-    rc = ensure_scratch(dst, CH * 4);
-    if (rc) return rc;
-    if (dst->device != src->device) {
-        int can = 0;
-        (void)hipDeviceCanAccessPeer(&can, dst->device, src->device);
-        if (can) (void)hipDeviceEnablePeerAccess(src->device, 0);    // already enabled is fine
-        (void)hipGetLastError();
-    }
-    for (size_t o = 0; o < dst->n_words; o += CH) {
-        const size_t n = dst->n_words - o < CH ? dst->n_words - o : CH;
-        HIPOK(dst, hipMemcpyPeerAsync(dst->scratch, dst->device, src->buf + o, src->device, n * 4, dst->stream));
-        ProfScope ps(dst, "accumulate_from");
-        launch_add_i32(dst->stream, dst->buf + o, (const int *)dst->scratch, n);
+    if (packed) {
+        const unsigned char *ss = (const unsigned char *)src->scratch;
+        const size_t CHB = CH * 4;                                    // image bytes per chunk = 512 Mi cells
+        rc = ensure_scratch(dst, CHB + (size_t)n_exc * sizeof(pd_exc) + 64);
+        if (rc) return rc;
+        unsigned char *ds = (unsigned char *)dst->scratch;
+        pd_exc *d_exc = (pd_exc *)(ds + CHB);
+        if (n_exc) HIPOK(dst, hipMemcpyPeerAsync(d_exc, dst->device, ss + 16, src->device, (size_t)n_exc * sizeof(pd_exc), dst->stream));
+        for (size_t o = 0; o < img_bytes; o += CHB) {
+            const size_t n = img_bytes - o < CHB ? img_bytes - o : CHB;
+            HIPOK(dst, hipMemcpyPeerAsync(ds, dst->device, ss + 16 + exc_bytes + o, src->device, n, dst->stream));
+            ProfScope ps(dst, "accumulate_from");
+            const bool last = o + CHB >= img_bytes;
+            launch_add_i4(dst->stream, dst->buf + o * 2, ds, (uint32_t)(n / (PD_TILE / 2)), d_exc, last ? n_exc : 0, dst->n_cells, dst->buf);
+        }
+        // the int32 tile sums travel as they are (4 B per 8192 cells)
+        const size_t n_sum_words = dst->n_words - dst->n_cells;
+        HIPOK(dst, hipMemcpyPeerAsync(ds, dst->device, src->sums, src->device, n_sum_words * 4, dst->stream));
+        launch_add_i32(dst->stream, dst->sums, (const int *)ds, n_sum_words);
+    } else {
+        rc = ensure_scratch(dst, CH * 4);
+        if (rc) return rc;
+        for (size_t o = 0; o < dst->n_words; o += CH) {
+            const size_t n = dst->n_words - o < CH ? dst->n_words - o : CH;
+            HIPOK(dst, hipMemcpyPeerAsync(dst->scratch, dst->device, src->buf + o, src->device, n * 4, dst->stream));
+            ProfScope ps(dst, "accumulate_from");
+            launch_add_i32(dst->stream, dst->buf + o, (const int *)dst->scratch, n);
+        }
     }
     HIPOK(dst, hipGetLastError());
     HIPOK(dst, hipStreamSynchronize(dst->stream));

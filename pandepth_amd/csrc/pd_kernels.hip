@@ -712,6 +712,31 @@ __global__ __launch_bounds__(WG) void k_export_i4(const int *diff, const uint8_t
     }
 }
 
+// dst += (nibble - 8) for the tiles [0, n_tiles) of a chunk: the single-process form of the sum
+// (pd_accumulate_from).  Same row layout as k_export_i4: lane-contiguous int4 RMW of the cells, one
+// ushort (4 cells) of the image per lane and row.
+__global__ __launch_bounds__(WG) void k_add_i4(int *dst, const unsigned short *img, uint32_t n_tiles)
+{
+    constexpr int ROWS = TILE / (WG * 4);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t cw = (uint64_t)t * TILE + (uint64_t)wv * (ROWS * 256);
+        const unsigned short *q = img + cw / 4 + lane;
+        int4 *p4 = reinterpret_cast<int4 *>(dst + cw) + lane;
+        unsigned short h[ROWS];
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { h[r] = q[r * 64]; v[r] = p4[r * 64]; }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const unsigned w = h[r];
+            v[r].x += (int)(w & 0xf) - 8; v[r].y += (int)((w >> 4) & 0xf) - 8;
+            v[r].z += (int)((w >> 8) & 0xf) - 8; v[r].w += (int)(w >> 12) - 8;
+            p4[r * 64] = v[r];
+        }
+    }
+}
+
 // marks the tiles of the slice [tile0, tile0 + n_tiles) that own an exception of any part (blockIdx.y)
 __global__ __launch_bounds__(WG) void k_flag_exception_tiles(const pd_exc *exc, uint64_t exc_stride, const int32_t *counts,
                                                              uint64_t tile0, uint64_t n_tiles, uint8_t *flags)
@@ -859,6 +884,16 @@ void launch_export_i4(hipStream_t st, const int *diff, const uint8_t *hstate, vo
 {
     hipLaunchKernelGGL(k_export_i4, dim3(16384), dim3(WG), 0, st, diff, hstate, (unsigned short *)out,
                        (uint32_t)(n_cells / TILE), exc, cap, count);
+}
+
+void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, const pd_exc *exc, uint64_t n_exc,
+                   uint64_t n_cells_total, int *dst_base)
+{
+    if (n_tiles) {
+        unsigned g = n_tiles < 16384 ? n_tiles : 16384;
+        hipLaunchKernelGGL(k_add_i4, dim3(g), dim3(WG), 0, st, dst, (const unsigned short *)img, n_tiles);
+    }
+    if (n_exc) hipLaunchKernelGGL(k_apply_exceptions, dim3(256), dim3(WG), 0, st, exc, n_exc, dst_base, n_cells_total);
 }
 
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,

@@ -110,8 +110,10 @@ class SlicedSum:
 
         start    export   4-bit image of this rank's difference arrays (+ exception block)   pd_export_i4
                  exchange all-to-all of the image: every pair of GPUs moves 1/world of it over its
-                          own link, all links at once; all-reduce of the int32 tile sums (+ the
-                          exception counts), all-gather of the (64 Ki-entry) exception blocks
+                          own link, all links at once (grouped send/recv in messages of at most
+                          MSG_BYTES: RCCL 2.26.6 silently drops the second half of a send/recv
+                          larger than 1 GiB — tools/rccl_large_message_check.py); all-reduce of the int32 tile sums
+                          (+ the exception counts), all-gather of the exception blocks
         finish   sweep    one fused kernel: sum of the `world` images of the slice, prefix sum with
                           carries from the summed tile sums, 18-bit wrap, window partials pd_slice_sweep_i4
                  gather   24 B per tile to the root, which adds them up per window       pd_gather_windows
@@ -122,9 +124,10 @@ class SlicedSum:
     and collectives are ordered on the device and the host never waits in between; "sync" orders
     them with host synchronisation instead."""
 
-    EXC_BLOCK = 1 << 16
+    EXC_BLOCK = 1 << 18
+    MSG_BYTES = 1 << 28
 
-    def __init__(self, engine, device, group=None, sums=None, depth=2, stream_mode=None):
+    def __init__(self, engine, device, group=None, sums=None, depth=2, stream_mode=None, self_via_collective=False):
         self.e, self.dev, self.group = engine, torch.device(device), group
         self.dist = dist.is_initialized()
         self.world = dist.get_world_size(group) if self.dist else 1
@@ -140,6 +143,7 @@ class SlicedSum:
         if stream_mode is None:
             stream_mode = "engine" if self.dev.type == "cuda" else "sync"
         self.stream_mode = stream_mode
+        self.self_via_collective = self_via_collective      # tests: route this rank's own part through send/recv too
         self._ext = torch.cuda.ExternalStream(engine.stream(), device=self.dev) if stream_mode == "engine" else None
         W, B = self.world, self.EXC_BLOCK
         kw = dict(device=self.dev)
@@ -186,17 +190,35 @@ class SlicedSum:
             meta[:self.n_sums].copy_(self.sums)
             meta[self.n_sums:].zero_()
             meta[self.n_sums + self.rank:self.n_sums + self.rank + 1].copy_(s["count"])
+            s["works"] = self._exchange(s["send"], s["recv"])
             if self.dist:
-                s["works"] = [
-                    dist.all_to_all_single(s["recv"], s["send"], group=self.group, async_op=True),
+                s["works"] += [
                     dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
                     dist.all_gather_into_tensor(s["exc_all"], s["exc"], group=self.group, async_op=True)]
             else:
-                s["recv"].copy_(s["send"])
                 s["exc_all"].copy_(s["exc"])
-                s["works"] = []
             if self._ext is None:
                 self._sync_all()          # "sync" mode: the context's next kernels must not overtake the copies above
+
+    def _exchange(self, send, recv):
+        """recv[p] <- rank p's send[self.rank], for every p: the all-to-all, as one group of
+        send/recv pairs per MSG_BYTES of slice.  Returns the pending work handles."""
+        W, sb = self.world, self.slice_bytes
+        rs, rr = send.view(W, sb), recv.view(W, sb)
+        peers = [p for p in range(W) if p != self.rank or (self.dist and self.self_via_collective)]
+        if self.rank not in peers:
+            rr[self.rank].copy_(rs[self.rank])
+        works = []
+        if peers:
+            to_global = (lambda p: dist.get_global_rank(self.group, p)) if self.group is not None else (lambda p: p)
+            for c0 in range(0, sb, self.MSG_BYTES):
+                c1 = min(sb, c0 + self.MSG_BYTES)
+                ops = []
+                for p in peers:
+                    ops.append(dist.P2POp(dist.isend, rs[p][c0:c1], to_global(p), group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, rr[p][c0:c1], to_global(p), group=self.group))
+                works += dist.batch_isend_irecv(ops)
+        return works
 
     def finish(self, slot=0, w=10000000, min_dep=1, wrap_bits=18, root=0):
         """Completes the sum started in `slot`.  Returns (win_off, cover, depth_sum) on the root —

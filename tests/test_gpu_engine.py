@@ -368,13 +368,17 @@ def test_packed_sum_single_rank_roundtrip():
         check_depth(e, LENS, d, off)
 
 
-def test_accumulate_from_equals_pushing_into_one_context():
+@pytest.mark.parametrize("packed", [1, 0])
+def test_accumulate_from_equals_pushing_into_one_context(packed):
+    """packed=1: 4-bit transport (nibble image + exception list, the pile-ups below), 0: int32 chunks"""
     rng = np.random.default_rng(51)
     a = sort_iv(rand_intervals(rng, LENS, 70000))
-    b = rand_intervals(rng, LENS, 30000)
+    b = np.concatenate([rand_intervals(rng, LENS, 30000), np.tile(np.array([[0, 8190, 8200]], dtype=np.int32), (300, 1)),
+                        np.tile(np.array([[8, 99990, 100000]], dtype=np.int32), (20, 1))])
     c = sort_iv(rand_intervals(rng, LENS[:2], 20000))          # leaves most of e3 unwritten
     d, off = oracle_depth(LENS, np.concatenate([a, b, c]), True)
     with pda.Engine(LENS) as e1, pda.Engine(LENS) as e2, pda.Engine(LENS) as e3:
+        e1.set_param("accumulate_packed", packed)
         e1.push_intervals(a, pda.PD_PUSH_SORTED)
         e2.push_intervals(b)
         e3.push_intervals(c, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)     # still pending when summed
@@ -482,7 +486,7 @@ def test_sliced_sum_single_rank(mode):
 
 
 def test_sliced_sum_one_rank_rccl_group(tmp_path):
-    """The collective code path (all_to_all_single / all_reduce / all_gather / gather over RCCL) with a
+    """The collective code path (grouped isend/irecv, all_reduce, all_gather, gather over RCCL) with a
     1-rank group, two samples in flight; run in a child process that owns the process group."""
     import subprocess
     import sys
@@ -500,7 +504,8 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 rng = np.random.default_rng(91)
 ivs = [np.concatenate([rand_intervals(rng, LENS, 40000), np.tile(np.array([[0, 10 + k, 50]], dtype=np.int32), (500, 1))]) for k in range(3)]
 with pda.Engine(LENS) as e:
-    ss = multi.SlicedSum(e, torch.device("cuda", 0))
+    multi.SlicedSum.MSG_BYTES = 1 << 16           # several grouped send/recv rounds per exchange
+    ss = multi.SlicedSum(e, torch.device("cuda", 0), self_via_collective=True)      # the rank's own part goes through RCCL too
     assert ss.stream_mode == "engine"
     res = []
     for k, iv in enumerate(ivs):                    # software pipeline: start(k), then finish(k - 1)

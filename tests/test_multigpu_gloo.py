@@ -310,6 +310,8 @@ def _worker_sliced(rank, world, port, out, lens, pipelined):
 
         buf = np.zeros(n_cells + n_cells // TILE, dtype=np.int32)
         eng = FakeSliceEngine(buf, n_cells, lens)
+        if pipelined:
+            multi.SlicedSum.MSG_BYTES = 8192            # several send/recv groups per exchange
         ss = multi.SlicedSum(eng, "cpu", sums=torch.from_numpy(buf)[n_cells:])
         assert ss.stream_mode == "sync" and ss.slice_tiles * world >= n_cells // TILE
         for s in ss.slots:
