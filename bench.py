@@ -6,12 +6,19 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
 
     pd_reset                      forget the 3.0e9 cells (per-half-tile "written" flags + tile sums; no fill:
                                   unwritten cells count as zero until the scatter stores into them)
-    pd_push_intervals_device x2   +1/-1 scatter of all runs through the owner-tile kernel: the sorted
-                                  first-run stream (PD_PUSH_MORE) and the ~11 % second runs of D/I/N reads,
-                                  which are only nearly sorted (PD_PUSH_DISORDER(max read span)), served by
-                                  the same passes over the tiles
-    pd_scan_reduce_windows        prefix-sum sweep fused with the 10 Mb-bin CoveredSite/TotalDepth
-                                  reduction, results copied back to the host
+    pd_push_intervals_device x2   the sample's two run streams: the sorted first runs and the ~11 % second
+                                  runs of D/I/N reads, which are only nearly sorted
+                                  (PD_PUSH_DISORDER(max read span)); both deferred (PD_PUSH_MORE)
+    pd_scan_reduce_windows        10 Mb-bin CoveredSite/TotalDepth, results copied back to the host.
+                                  N = 1 (default, "direct_windows"): ONE pass over the runs — each tile's
+                                  difference window is built in LDS (+1/-1 scatter), its carry-in counted
+                                  from the same candidate runs, prefix-summed and reduced on the spot; the
+                                  difference arrays never reach HBM (k_direct_tiles).
+                                  PD_BENCH_PATH=arrays (and always for N > 1): the general path — owner-tile
+                                  scatter into the int32 difference arrays in HBM (k_scatter_tiles), then the
+                                  prefix-sum sweep fused with the bin reduction (k_sweep).  A few steps of it
+                                  are also run after the timed region: their kernel figures are reported under
+                                  "arrays_path" and their results must equal the direct path's.
     [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pandepth_amd.multi.SlicedSum):
                                   4-bit image (pd_export_i4), all-to-all over RCCL so that every xGMI link of a
                                   GPU carries 1/N of it at once, every rank sums + sweeps its 1/N of the tiles
@@ -48,6 +55,7 @@ BIN = 10000000                 # whole-chromosome mode's synthetic bins (PD:3978
 B_FILL_PER_CELL = 4
 B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write)
 B_SWEEP_FUSED_PER_BASE = 4
+B_RUN = 12                     # one packed (tid, beg, end) run
 
 
 def cpu_quota():
@@ -149,11 +157,14 @@ def main():
     buf = multi.buffer_view(eng, dev) if sum_mode == "int32" else None
     pipelined = sliced is not None and os.environ.get("PD_BENCH_PIPELINE", "1") == "1"
     wrap = 18 if use_dist else 0         # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
+    direct = not use_dist and os.environ.get("PD_BENCH_PATH", "direct") == "direct"
+    eng.set_param("direct_windows", 1 if direct else 0)
 
     def scatter():
         eng.reset()
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
-        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN)
+                                  | (pda.PD_PUSH_MORE if direct else 0))
 
     def run_steps(k):
         """k complete steps; returns the last step's result (rank 0)"""
@@ -223,12 +234,32 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    prof = {}
-    for k in ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
-              "scan_reduce_windows", "export_i8", "import_i8", "export_i4", "slice_sweep", "gather_windows"):
-        ms, n = eng.profile_get(k)
-        prof[k] = (ms, n)
+    PROF_KEYS = ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
+                 "scan_reduce_windows", "export_i8", "import_i8", "export_i4", "slice_sweep", "gather_windows", "direct_tiles")
+    prof = {k: eng.profile_get(k) for k in PROF_KEYS}
     eng.profile(False)
+
+    # the general (materialising) path next to the direct one: a few untimed-for-`value` steps, same inputs
+    arrays_path = None
+    if direct:
+        ASTEPS = 3
+        direct = False
+        eng.set_param("direct_windows", 0)
+        step()
+        eng.synchronize()
+        eng.profile(True)
+        ta = time.perf_counter()
+        for _ in range(ASTEPS):
+            res_a = step()
+        eng.synchronize()
+        ta = time.perf_counter() - ta
+        prof_a = {k: eng.profile_get(k) for k in PROF_KEYS}
+        eng.profile(False)
+        same = bool(np.array_equal(res_a[1], res[1]) and np.array_equal(res_a[2], res[2]))
+        if not same:
+            raise SystemExit("direct path and materialising path disagree")
+        arrays_path = {"ms_per_step": ta / ASTEPS * 1e3, "steps": ASTEPS, "equals_direct": same, "prof": prof_a}
+        direct = True
 
     if rank == 0:
         # sanity: the result of the last step must account for every base that was pushed
@@ -246,8 +277,27 @@ def main():
             return {"avg_ms": round(avg, 4), "launches": n, "achieved": round(ach, 1), "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg_bytes_per_launch)}
 
+        def entries(prof, steps):
+            launches_tiles = max(1, prof["scatter_tiles"][1] // steps)
+            return {
+                "scatter_tiles": k_entry2(prof, "scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
+                "scan_reduce_windows": k_entry2(prof, "scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE)}
+
+        def k_entry2(pr, name, alg):
+            ms, n = pr[name]
+            if n == 0:
+                return None
+            avg = ms / n
+            ach = alg / (avg * 1e-3) / 1e9
+            return {"avg_ms": round(avg, 4), "launches": n, "achieved": round(ach, 1), "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg)}
+
+        if arrays_path is not None:
+            arrays_path["kernels"] = entries(arrays_path.pop("prof"), arrays_path["steps"])
         launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
         kernels = {
+            # the direct path's only big kernel: reads every run once (12 B), writes 24 B per tile
+            "direct_tiles": k_entry("direct_tiles", (n_first + n_other) * B_RUN + (n_cells // 8192) * 24),
             # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
             "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
                      if prof["fill"][1] else None),
@@ -268,7 +318,8 @@ def main():
         try:
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-            key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>"}.get(dom)
+            key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
+                   "direct_tiles": "k_direct_tiles"}.get(dom)
             if key in pmc["kernels"] and R == int(1e9):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, IndexError, KeyError, ValueError):
@@ -290,12 +341,14 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "parallelism": "1 BAM per GPU" + ((", " + {
+                       "cells": int(n_words), "path": "direct (difference windows stay in LDS)" if direct else "arrays (difference arrays in HBM)",
+                       "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
                            "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),
                        "total_depth_check": total_depth, "multi_gpu_sum_selfcheck": selfcheck},
             "roofline": roofline,
             "kernels": kernels,
+            "arrays_path": arrays_path,
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)

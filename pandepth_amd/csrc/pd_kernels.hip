@@ -308,6 +308,448 @@ __global__ __launch_bounds__(WG) void k_scatter_tiles(const PendSet ps, uint32_t
     }
 }
 
+// The DIRECT whole-sample path (windows of >= TILE cells, i.e. whole-chromosome mode): when every
+// run of the sample is still pending as sorted batches and the context holds nothing else, the
+// difference array never needs to exist in HBM.  One workgroup per tile builds the tile's
+// difference window in LDS exactly as k_scatter_tiles does, but instead of flushing it:
+//   * the carry into the tile — the depth just before its first cell — is counted from the same
+//     candidates: runs that begin before the tile and end at or after its first cell (every such
+//     run is among the candidates as long as no run is longer than the look-back `lmax`; longer
+//     runs are counted in *n_long and the caller falls back to the materialising path);
+//   * the window is prefix-summed from LDS (same row layout / wave scans as k_sweep), wrapped, and
+//     reduced to the tile's share of the (at most two) windows it touches.
+// HBM traffic: the runs, once (+ the look-back overlap), and 24 bytes per tile.  No inter-workgroup
+// dependency, no atomics outside LDS.
+// One candidate run of the direct pass; per-lane counters (summed over the wave by the caller).
+struct DirectCnt { uint32_t n_beg; int open; int carry; };
+
+__device__ __forceinline__ void direct_candidate(const pd_iv v, int32_t ctg, uint32_t clen, uint32_t p0, unsigned *win,
+                                                 DirectCnt &c)
+{
+    constexpr uint32_t ST = TILE;
+    uint32_t bb = v.beg < 0 ? 0u : (uint32_t)v.beg; if (bb > clen) bb = clen;
+    uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+    // tile-relative begin / end in 32-bit arithmetic: a position before the tile wraps to a huge value
+    // (candidates lie within lmax + D cells of the tile, far from 2^32)
+    const uint32_t sb = bb - p0, se = x - p0;
+    if (v.tid == ctg) {
+        if (bb < x) {
+            if (sb < ST) {
+                atomicAdd(&win[sb >> 1], 1u + (sb & 1u) * 0xFFFFu);
+                ++c.n_beg; ++c.open;
+            }
+            if (se < ST) {
+                atomicSub(&win[se >> 1], 1u + (se & 1u) * 0xFFFFu);
+                --c.open;
+            }
+            if (bb < p0 && x >= p0) ++c.carry;                    // covers the cell just before the tile
+        } else if (sb < ST) {
+            ++c.n_beg;                                            // an empty run still has an owner
+        }
+    }
+}
+
+template <int UN, int WPE>
+__global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint32_t n_tiles, ContigTab tab,
+                                                        const uint32_t *tile_contig, uint32_t wrap_mask, uint32_t w,
+                                                        uint32_t min_dep, TilePart *part, uint32_t *n_long,
+                                                        uint32_t *heavy_list, uint32_t *heavy_count)
+{
+    constexpr int ST = TILE;
+    constexpr int ROWS = TILE / (WG * 4);                        // 8
+    // two signed 16-bit counters per word, kept as ONE 32-bit sum 65536 * H + L: half the LDS of an
+    // int window, twice the resident workgroups.  L = sign-extended low half and H = (word - L) >> 16
+    // are exact while both stay within +-32767, which holds when the tile has fewer candidates than
+    // that; heavier tiles (pile-ups) go on the heavy list and are done by k_direct_tiles_heavy with
+    // an int window.
+    __shared__ __attribute__((aligned(16))) unsigned win[ST / 2];
+    __shared__ int s_carry;
+    __shared__ int wtot[4];
+    __shared__ unsigned long long red_s[4][2];
+    __shared__ int red_c[4][2];
+    __shared__ uint32_t s_lo[PD_MAXPEND], s_hi[PD_MAXPEND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // summed over the batches: begins that found their owner tile; runs with cells whose begin was owned
+    // minus ends that were owned (must cancel: a run that reaches into a tile without being one of its
+    // candidates — longer than the look-back — leaves its end unowned, so this also catches long runs)
+    uint32_t n_beg = 0; int open = 0;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t a = t * ST;
+        if (threadIdx.x < PD_MAXPEND) {
+            const int b = threadIdx.x;
+            uint32_t lo = 0, hi = 0;
+            if (b < ps.nb) {
+                const uint32_t tf = ps.b[b].desc->t_first, na = ps.b[b].desc->n_active;
+                if (t >= tf && t < (uint64_t)tf + na) {
+                    const uint32_t n = ps.b[b].n;
+                    hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
+                    lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
+                }
+            }
+            s_lo[b] = lo; s_hi[b] = hi;
+        }
+        uint4 *w4 = reinterpret_cast<uint4 *>(win);
+        for (int j = threadIdx.x; j < ST / 8; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) s_carry = 0;
+        const int32_t ctg = (int32_t)tile_contig[t];
+        const uint32_t clen = tab.len[ctg];
+        const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);         // tile start inside the contig (slots are < 2^32 cells)
+        __syncthreads();
+        uint32_t cand = 0;
+        for (int b = 0; b < ps.nb; ++b) cand += s_hi[b] - s_lo[b];
+        if (cand > 32000u) {                                      // workgroup-uniform
+            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
+            __syncthreads();
+            continue;
+        }
+        DirectCnt cnt{0u, 0, 0};
+#pragma unroll 1
+        for (int b = 0; b < ps.nb; ++b) {
+            const uint32_t lo = s_lo[b], hi = s_hi[b];
+            if (lo >= hi) continue;
+            const pd_iv *__restrict__ iv = ps.b[b].iv;
+            uint32_t i = lo;                                      // uniform
+            // full chunks: scalar base + constant per-lane offsets, no bounds tests
+            for (; i + UN * WG <= hi; i += UN * WG) {
+                const pd_iv *__restrict__ p = iv + i;
+                pd_iv vv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) vv[u] = p[threadIdx.x + u * WG];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) direct_candidate(vv[u], ctg, clen, p0, win, cnt);
+            }
+            if (i < hi) {                                         // the tail chunk
+                const pd_iv *__restrict__ p = iv + i;
+                const uint32_t left = hi - i;
+                pd_iv vv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const uint32_t j = threadIdx.x + u * WG;
+                    vv[u] = p[j < left ? j : left - 1];
+                    if (j >= left) vv[u].tid = -1;                // never equals a contig id
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) direct_candidate(vv[u], ctg, clen, p0, win, cnt);
+            }
+        }
+        n_beg += cnt.n_beg; open += cnt.open;
+        const int carry = wave_sum(cnt.carry);
+        if (lane == 0 && carry != 0) atomicAdd(&s_carry, carry);
+        __syncthreads();
+        // ---- prefix sum of the window, straight from LDS (k_sweep's layout) ----
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint2 q = reinterpret_cast<const uint2 *>(win)[wv * (ROWS * 64) + r * 64 + lane];
+            const int l0 = (int)(short)(q.x & 0xffffu), l1 = (int)(short)(q.y & 0xffffu);
+            v[r] = make_int4(l0, ((int)q.x - l0) >> 16, l1, ((int)q.y - l1) >> 16);
+        }
+        int tot[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            v[r].y += v[r].x; v[r].z += v[r].y; v[r].w += v[r].z;
+            tot[r] = v[r].w;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) tot[r] = wave_incl_scan(tot[r]);
+        int run = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int e = run + tot[r] - v[r].w;                  // exclusive prefix of this lane's group in the wave
+            run += __builtin_amdgcn_readlane(tot[r], 63);
+            tot[r] = e;
+        }
+        if (lane == 0) wtot[wv] = run;
+        __syncthreads();
+        int base = s_carry;
+        for (int k = 0; k < wv; ++k) base += wtot[k];
+        // ---- the tile's share of windows k0 and k0 + 1 ----
+        const uint64_t local0 = p0;
+        int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+        if (local0 < clen) {
+            const uint64_t k0 = local0 / w;
+            const uint64_t nb64 = (k0 + 1) * (uint64_t)w - local0;   // tile-local start of window k0+1
+            const uint32_t nb = nb64 > (uint64_t)ST ? (uint32_t)ST : (uint32_t)nb64;
+            const uint64_t left = (uint64_t)clen - local0;           // cells of the contig from the tile start on
+            const uint32_t lim = left > (uint64_t)ST ? (uint32_t)ST : (uint32_t)left;
+            const uint64_t dmax = (uint64_t)(uint32_t)s_carry + cand;     // no depth in this tile exceeds carry + begins
+            if (nb >= (uint32_t)ST && lim >= (uint32_t)ST && min_dep <= 1u && dmax < (1u << 27) && dmax <= wrap_mask) {
+                // the common tile — inside one window, inside the contig, no wrap possible, threshold <= 1:
+                // the depths need not be formed: sum = sum of the local prefixes + 4 x base per row,
+                // covered cells = those whose local prefix differs from -base (all of them for threshold 0)
+                uint32_t s32 = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int bsum = base + tot[r];
+                    s32 += (uint32_t)(v[r].x + v[r].y + v[r].z + v[r].w) + 4u * (uint32_t)bsum;
+                    if (min_dep) {
+                        const int z = -bsum;
+                        c0 += (v[r].x != z ? 1 : 0) + (v[r].y != z ? 1 : 0) + (v[r].z != z ? 1 : 0) + (v[r].w != z ? 1 : 0);
+                    } else c0 += 4;
+                }
+                s0 = s32;
+            } else if (nb >= (uint32_t)ST && lim >= (uint32_t)ST && dmax < (1u << 27)) {
+                // the common tile: inside one window and inside the contig — no position tests; no depth
+                // exceeds carry + begins in the tile < 2^27, so a lane's 32 cells add up in 32 bits
+                uint32_t s32 = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int bsum = base + tot[r];
+                    const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
+                                           (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = d[q] >= min_dep;
+                        c0 += ok ? 1 : 0;
+                        s32 += ok ? d[q] : 0u;
+                    }
+                }
+                s0 = s32;
+            } else if (nb >= (uint32_t)ST && lim >= (uint32_t)ST) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int bsum = base + tot[r];
+                    const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
+                                           (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = d[q] >= min_dep;
+                        c0 += ok ? 1 : 0;
+                        s0 += ok ? d[q] : 0u;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int bsum = base + tot[r];
+                    const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                    const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
+                                           (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = pos + q < lim && d[q] >= min_dep;
+                        if (ok) { if (pos + q < nb) { ++c0; s0 += d[q]; } else { ++c1; s1 += d[q]; } }
+                    }
+                }
+            }
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            TilePart tp;
+            tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+            tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+            tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+            tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+            part[t] = tp;
+        }
+        __syncthreads();
+    }
+    // every begin and every end must have found its owner tile: totals over all batches go to batch 0's
+    // counters (k_finish_direct compares sums, which is as strict: no run can be counted twice)
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const int hb = wave_sum((int)n_beg), ho = wave_sum(open);
+        if (lane == 0) {
+            if (hb) atomicAdd(&s_cnt[0], (unsigned)hb);
+            if (ho) atomicAdd(&s_cnt[1], (unsigned)ho);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BatchDesc *desc = ps.b[0].desc;
+        if (s_cnt[0]) atomicAdd((unsigned long long *)desc->handled + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)s_cnt[0]);
+        // signed total of (owned begins with cells) - (owned ends), as a 64-bit two's complement sum in `has`
+        if (s_cnt[1]) atomicAdd((unsigned long long *)desc->has + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)(long long)(int)s_cnt[1]);
+    }
+    (void)n_long;
+}
+
+__global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uint32_t n_tiles, ContigTab tab,
+                                                     const uint32_t *tile_contig, uint32_t wrap_mask, uint32_t w,
+                                                     uint32_t min_dep, TilePart *part, uint32_t *n_long,
+                                                     const uint32_t *heavy_list, const uint32_t *heavy_count)
+{
+    constexpr int ST = TILE;
+    constexpr int ROWS = TILE / (WG * 4);                        // 8
+    __shared__ __attribute__((aligned(16))) int win[ST];
+    __shared__ int s_carry;
+    __shared__ int wtot[4];
+    __shared__ unsigned long long red_s[4][2];
+    __shared__ int red_c[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t tf[PD_MAXPEND], na[PD_MAXPEND];
+    uint32_t n_beg[PD_MAXPEND], n_has[PD_MAXPEND], n_end[PD_MAXPEND];
+    uint32_t longs = 0;
+#pragma unroll
+    for (int b = 0; b < PD_MAXPEND; ++b) {
+        n_beg[b] = n_has[b] = n_end[b] = 0; tf[b] = 0; na[b] = 0;
+        if (b < ps.nb) { tf[b] = ps.b[b].desc->t_first; na[b] = ps.b[b].desc->n_active; }
+    }
+    const uint32_t lmax = ps.lmax;
+    const uint32_t n_heavy = *heavy_count < n_tiles ? *heavy_count : n_tiles;
+    for (uint32_t hi_ = blockIdx.x; hi_ < n_heavy; hi_ += gridDim.x) {
+        const uint64_t t = heavy_list[hi_];
+        const uint64_t a = t * ST;
+        int4 *w4 = reinterpret_cast<int4 *>(win);
+        for (int j = threadIdx.x; j < ST / 4; j += WG) w4[j] = make_int4(0, 0, 0, 0);
+        if (threadIdx.x == 0) s_carry = 0;
+        const int32_t ctg = (int32_t)tile_contig[t];
+        const uint32_t clen = tab.len[ctg];
+        const int64_t rel = (int64_t)(tab.off[ctg] - a);          // slot start relative to the tile (<= 0)
+        __syncthreads();
+        int carry = 0;
+#pragma unroll
+        for (int b = 0; b < PD_MAXPEND; ++b) {
+            if (b >= ps.nb || t < tf[b] || t >= (uint64_t)tf[b] + na[b]) continue;
+            const uint32_t n = ps.b[b].n;
+            uint32_t hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
+            uint32_t lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
+            const pd_iv *__restrict__ iv = ps.b[b].iv;
+            constexpr int UN = 4;
+            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += UN * WG) {
+                pd_iv vv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const uint32_t i = i0 + u * WG;
+                    vv[u] = iv[i < hi ? i : hi - 1];
+                    if (i >= hi) vv[u].tid = -1;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const pd_iv v = vv[u];
+                    if (v.tid != ctg) continue;
+                    uint32_t bb = v.beg < 0 ? 0u : (uint32_t)v.beg; if (bb > clen) bb = clen;
+                    uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+                    const bool has = bb < x;
+                    const int64_t sb = rel + (int64_t)bb, se = rel + (int64_t)x;     // tile-relative begin / end
+                    if (sb >= 0 && sb < ST) {
+                        ++n_beg[b];
+                        if (has) { ++n_has[b]; atomicAdd(&win[sb], 1); if (x - bb > lmax) ++longs; }
+                    }
+                    if (has) {
+                        if (se >= 0 && se < ST) { atomicAdd(&win[se], -1); ++n_end[b]; }
+                        if (sb < 0 && se >= 0) ++carry;           // covers the cell just before the tile
+                    }
+                }
+            }
+        }
+        carry = wave_sum(carry);
+        if (lane == 0 && carry != 0) atomicAdd(&s_carry, carry);
+        __syncthreads();
+        // ---- prefix sum of the window, straight from LDS (k_sweep's layout) ----
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) v[r] = w4[wv * (ROWS * 64) + r * 64 + lane];
+        int tot[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            v[r].y += v[r].x; v[r].z += v[r].y; v[r].w += v[r].z;
+            tot[r] = v[r].w;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) tot[r] = wave_incl_scan(tot[r]);
+        int run = 0;
+        int excl[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            excl[r] = run + tot[r] - v[r].w;
+            run += __builtin_amdgcn_readlane(tot[r], 63);
+        }
+        if (lane == 0) wtot[wv] = run;
+        __syncthreads();
+        int base = s_carry;
+        for (int k = 0; k < wv; ++k) base += wtot[k];
+        // ---- the tile's share of windows k0 and k0 + 1 ----
+        const uint64_t local0 = a - tab.off[ctg];
+        int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+        if (local0 < clen) {
+            const uint64_t k0 = local0 / w;
+            const uint64_t nb = (k0 + 1) * (uint64_t)w - local0;     // tile-local start of window k0+1
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int bsum = base + excl[r];
+                const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
+                                       (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = local0 + pos + q < clen && d[q] >= min_dep;
+                    if (ok) { if (pos + q < nb) { ++c0; s0 += d[q]; } else { ++c1; s1 += d[q]; } }
+                }
+            }
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            TilePart tp;
+            tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+            tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+            tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+            tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+            part[t] = tp;
+        }
+        __syncthreads();
+    }
+    // the same accounting as k_scatter_tiles: every begin and every end must have found its owner tile
+    __shared__ unsigned s_cnt[PD_MAXPEND][3];
+    __shared__ unsigned s_long;
+    if (threadIdx.x < PD_MAXPEND * 3) s_cnt[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PD_MAXPEND; ++b) {
+        if (b >= ps.nb) continue;
+        const int hb = wave_sum((int)n_beg[b]), hh = wave_sum((int)n_has[b]), he = wave_sum((int)n_end[b]);
+        if (lane == 0) {
+            if (hb) atomicAdd(&s_cnt[b][0], (unsigned)hb);
+            if (hh) atomicAdd(&s_cnt[b][1], (unsigned)hh);
+            if (he) atomicAdd(&s_cnt[b][2], (unsigned)he);
+        }
+    }
+    const int hl = wave_sum((int)longs);
+    if (lane == 0 && hl) atomicAdd(&s_long, (unsigned)hl);
+    __syncthreads();
+    if (threadIdx.x < ps.nb * 3) {
+        const int b = threadIdx.x / 3, k = threadIdx.x % 3;
+        const unsigned v = s_cnt[b][k];
+        if (v) {
+            BatchDesc *desc = ps.b[b].desc;
+            unsigned long long *dst = (unsigned long long *)(k == 0 ? desc->handled : k == 1 ? desc->has : desc->ends);
+            atomicAdd(dst + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)v);
+        }
+    }
+    if (threadIdx.x == 0 && s_long) atomicAdd(n_long, s_long);
+}
+
+// Outcome of a direct pass: *fail = 1 unless every batch was complete and sorted and no run was
+// longer than the look-back; re-arms the descriptors (the batches stay pending for the fallback).
+__global__ void k_finish_direct(const PendSet ps, const uint32_t *n_long, uint32_t *fail)
+{
+    uint32_t bad = *n_long != 0;
+    uint64_t handled = 0, has = 0, ends = 0, n = 0;
+    for (int b = 0; b < ps.nb; ++b) {
+        BatchDesc *desc = ps.b[b].desc;
+        for (int k = 0; k < PD_CNT_SLOTS; ++k) {
+            handled += desc->handled[k]; has += desc->has[k]; ends += desc->ends[k];
+            desc->handled[k] = 0; desc->has[k] = 0; desc->ends[k] = 0;
+        }
+        n += ps.b[b].n;
+        if (desc->err) bad = 1;
+        desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
+    }
+    if (handled != n || has != ends) bad = 1;
+    *fail = bad;
+}
+
 // Zero-fills every half-tile that has not been written since the last reset (and marks it), so
 // that the atomic kernels may add into any cell.  With only_if_overflow it returns at once unless
 // the tile pass just put something on the overflow list.
@@ -957,6 +1399,24 @@ void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, cons
     else
         hipLaunchKernelGGL(k_scatter_tiles<8192>, dim3(grid_tiles), dim3(WG), 0, st, ps, n_stiles, tab, tile_contig,
                            diff, sums, hstate, ovf, ovf_cap, chk);
+}
+
+void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
+                         uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, uint32_t *n_long, uint32_t *fail,
+                         uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un)
+{
+#define PD_DIRECT(UN_, WPE_) hipLaunchKernelGGL((k_direct_tiles<UN_, WPE_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, \
+                                                tile_contig, wrap_mask, w, min_dep, part, n_long, heavy_list, heavy_count)
+    switch (un) {                       // tuning knob "direct_un": loads in flight per thread + 100 x waves-per-SIMD target
+    case 404: PD_DIRECT(4, 4); break;   // (measured on the bench sample: 504 3.4-3.6 ms, 508 3.3-3.6, 404 3.7, 408 3.7)
+    case 408: PD_DIRECT(8, 4); break;
+    case 508: PD_DIRECT(8, 5); break;
+    default: PD_DIRECT(4, 5); break;
+    }
+#undef PD_DIRECT
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(1024), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, w, min_dep,
+                       part, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count);
+    hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 
 void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,

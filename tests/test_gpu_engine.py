@@ -521,3 +521,111 @@ print("SLICED-RCCL-OK")
 ''' % (root, root, root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SLICED-RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------------------------------------
+# direct whole-sample path: pending sorted batches -> windows, difference arrays never materialised
+# ---------------------------------------------------------------------------------------------
+def _split_streams(rng, lens, n, max_len=300):
+    """a sample as the host produces it: the sorted first-run stream and a nearly sorted second-run stream"""
+    first = sort_iv(rand_intervals(rng, lens, n, max_len=max_len))
+    k = rng.random(first.shape[0]) < 0.2                      # every fifth read has a second run after a gap
+    gap = rng.integers(1, 400, int(k.sum())).astype(np.int32)
+    other = first[k].copy()
+    other[:, 1] = first[k][:, 2] + gap
+    other[:, 2] = other[:, 1] + rng.integers(1, max_len, other.shape[0]).astype(np.int32)
+    return first, other
+
+
+@pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (250000, 0, 18), (10000000, 1, 0)])
+def test_direct_windows_equal_oracle(w, min_dep, wrap):
+    rng = np.random.default_rng(300 + w % 97)
+    first, other = _split_streams(rng, LENS, 80000)
+    pile = np.tile(np.array([[0, 8190, 8200]], dtype=np.int32), (1000, 1))      # a pile-up across a tile edge
+    first = sort_iv(np.concatenate([first, pile]))
+    d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
+    cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        for rep in range(2):
+            e.reset()
+            e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+            woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+            assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
+            with pytest.raises(pda.PdError, match="direct"):
+                e.scan(wrap)                                      # the arrays never received the sample
+            with pytest.raises(pda.PdError):
+                e.push_intervals(first)
+        # the same calls without the parameter take the materialising path and agree
+        e.set_param("direct_windows", 0)
+        e.reset()
+        e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff2, cover2, tot2 = e.scan_reduce_windows(w, min_dep, wrap)
+        assert np.array_equal(cover2, cov_ref) and np.array_equal(tot2, tot_ref)
+        e.scan(wrap)
+        check_depth(e, LENS, d, off)
+
+
+def test_direct_windows_device_batches_and_wrap():
+    """device-resident batches (the bench's form) and a pile deeper than 2^18 (carry counts > 18 bits)"""
+    import torch
+    rng = np.random.default_rng(311)
+    first, other = _split_streams(rng, LENS, 60000)
+    pile = np.tile(np.array([[1, 100, 30000]], dtype=np.int32), (1, 1))
+    deep = np.tile(np.array([[0, 20000, 20100]], dtype=np.int32), (262150, 1))
+    first = sort_iv(np.concatenate([first, deep]))
+    d, off = oracle_depth(LENS, np.concatenate([first, other]), True)
+    cov_ref, tot_ref = windows_ref(LENS, d, off, 10000, 1)
+    dev = torch.device("cuda", 0)
+    tf, to = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
+    torch.cuda.synchronize()
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        e.push_intervals_device(tf.data_ptr(), tf.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        e.push_intervals_device(to.data_ptr(), to.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff, cover, tot = e.scan_reduce_windows(10000, 1, 18)
+        assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
+    del pile
+
+
+def test_direct_windows_fall_back():
+    """runs longer than the look-back, narrow windows, and a context that already holds data take the
+    materialising path (same results, state stays accumulating); a batch that is not sorted is reported"""
+    rng = np.random.default_rng(321)
+    first, other = _split_streams(rng, LENS, 50000)
+    long_runs = np.array([[0, 1000, 60000], [0, 300000, 302000], [8, 10, 99000]], dtype=np.int32)   # > lmax = 512
+    first_l = sort_iv(np.concatenate([first, long_runs]))
+    d, off = oracle_depth(LENS, np.concatenate([first_l, other]), False)
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        e.push_intervals(first_l, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff, cover, tot = e.scan_reduce_windows(10000, 1, 0)
+        c, t = windows_ref(LENS, d, off, 10000, 1)
+        assert np.array_equal(cover, c) and np.array_equal(tot, t)
+        e.scan(0)                                             # fell back: the arrays hold the sample
+        check_depth(e, LENS, d, off)
+        # narrow windows
+        d2, off2 = oracle_depth(LENS, np.concatenate([first, other]), False)
+        e.reset()
+        e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff, cover, tot = e.scan_reduce_windows(100, 1, 0)
+        c, t = windows_ref(LENS, d2, off2, 100, 1)
+        assert np.array_equal(cover, c) and np.array_equal(tot, t)
+        e.scan(0)
+        check_depth(e, LENS, d2, off2)
+        # something already materialised before the deferred batches
+        e.reset()
+        e.push_intervals(other)
+        e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        woff, cover, tot = e.scan_reduce_windows(10000, 1, 0)
+        c, t = windows_ref(LENS, d2, off2, 10000, 1)
+        assert np.array_equal(cover, c) and np.array_equal(tot, t)
+        # a broken promise is still an error
+        e.reset()
+        e.push_intervals(first[::-1].copy(), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        with pytest.raises(pda.PdError):
+            e.scan_reduce_windows(10000, 1, 0)
