@@ -102,7 +102,8 @@ int pd_stage_submit(pd_ctx *ctx, pd_iv *host_buf, size_t n, unsigned flags);
 
 /* Tuning knobs: "lmax" (owner-tile look-back in cells; longer runs take the overflow path),
  * "sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the tile kernel),
- * "accumulate_packed" (pd_accumulate_from's transport, default 1). */
+ * "accumulate_packed" (pd_accumulate_from's transport, default 1), "direct_windows" (default 0, see
+ * pd_scan_reduce_windows), "direct_un" (tuning variant of the direct kernel). */
 int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
 
 /* Difference arrays -> per-base depth, in place (the wavefront prefix-sum sweep).
@@ -122,6 +123,16 @@ int pd_reduce_intervals(pd_ctx *ctx, const pd_region *regs, size_t n, uint32_t m
  * win_off[t] + k, where win_off comes from pd_window_layout (n_contigs+1 entries, last = total).
  *   pd_scan_reduce_windows : fused — reads the DIFFERENCE arrays once, never writes depth
  *                            (4 B/base of HBM traffic); state stays "accumulating".
+ *                            With pd_set_param(ctx, "direct_windows", 1), w >= 8192, a context that
+ *                            holds nothing since pd_reset and a sample that is entirely DEFERRED
+ *                            (every batch pushed with PD_PUSH_SORTED | PD_PUSH_MORE, at most 4), the
+ *                            difference arrays are never materialised at all: one pass over the runs
+ *                            builds each tile's window in LDS, counts its carry-in from the same runs,
+ *                            prefix-sums and reduces it (12 B/run of HBM traffic, results identical).
+ *                            The sample is then CONSUMED: the arrays stay empty and every call except
+ *                            pd_reset / pd_destroy fails with PD_ESTATE.  Runs longer than the
+ *                            look-back ("lmax") or a batch that is not sorted make the call fall back
+ *                            to the materialising path on its own.
  *   pd_reduce_windows      : from the depth arrays left by pd_scan. */
 int pd_window_layout(const pd_ctx *ctx, uint32_t w, uint64_t *win_off);
 int pd_scan_reduce_windows(pd_ctx *ctx, uint32_t w, uint32_t min_dep, unsigned wrap_bits,

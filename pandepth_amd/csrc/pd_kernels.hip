@@ -1414,7 +1414,7 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     default: PD_DIRECT(4, 5); break;
     }
 #undef PD_DIRECT
-    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(1024), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, w, min_dep,
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, w, min_dep,
                        part, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count);
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }

@@ -25,4 +25,14 @@ for it in range(2):
     eng.scan_reduce_windows(10000000, 1, 0)
     eng.scan(0)          # write-back sweep: reads AND writes every cell once = the calibration kernel
     eng.synchronize()
+# the direct window path (k_direct_tiles): both streams deferred, difference arrays never materialised
+eng.set_param("direct_windows", 1)
+for it in range(2):
+    eng.reset()
+    eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+    eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+    eng.scan_reduce_windows(10000000, 1, 0)
+    eng.synchronize()
+eng.set_param("direct_windows", 0)
+eng.reset()
 print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]))
