@@ -123,7 +123,7 @@ int pd_reduce_intervals(pd_ctx *ctx, const pd_region *regs, size_t n, uint32_t m
  * win_off[t] + k, where win_off comes from pd_window_layout (n_contigs+1 entries, last = total).
  *   pd_scan_reduce_windows : fused — reads the DIFFERENCE arrays once, never writes depth
  *                            (4 B/base of HBM traffic); state stays "accumulating".
- *                            With pd_set_param(ctx, "direct_windows", 1), w >= 8192, a context that
+ *                            With pd_set_param(ctx, "direct_windows", 1), w >= 64, a context that
  *                            holds nothing since pd_reset and a sample that is entirely DEFERRED
  *                            (every batch pushed with PD_PUSH_SORTED | PD_PUSH_MORE, at most 4), the
  *                            difference arrays are never materialised at all: one pass over the runs

@@ -607,6 +607,7 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
     HIPOK(c, hipMemsetAsync(c->direct_words, 0, 16, c->stream));
+    if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // edge windows are accumulated
     const uint32_t n_stiles = (uint32_t)c->n_tiles;
     PendSet ps{};
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
@@ -629,11 +630,13 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     }
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_tiles");
-      launch_direct_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part,
-                          c->direct_words, c->direct_words + 1, c->direct_words + 4, c->direct_words + 2, grid, c->direct_un); }
-    { ProfScope sc(c, "gather_windows");
-      TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
-      launch_window_gather(c->stream, d_part, tm, c->n_contigs, w, nw, d_cov, d_sum); }
+      launch_direct_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part, d_wo,
+                          d_cov, d_sum, c->direct_words, c->direct_words + 1, c->direct_words + 4, c->direct_words + 2, grid, c->direct_un); }
+    if (w >= PD_TILE) {
+        ProfScope sc(c, "gather_windows");
+        TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
+        launch_window_gather(c->stream, d_part, tm, c->n_contigs, w, nw, d_cov, d_sum);
+    }
     HIPOK(c, hipGetLastError());
     uint32_t words[2] = {0, 0};
     HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));
@@ -659,7 +662,7 @@ int pd_scan_reduce_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, unsigned wra
     std::lock_guard<std::mutex> lk(c->mu);
     if (int rs = need_state(c, 0, "pd_scan_reduce_windows")) return rs;
     HIPOK(c, hipSetDevice(c->device));
-    if (c->direct_windows && c->pristine && !c->pend.empty() && w >= PD_TILE && c->stile == PD_TILE) {
+    if (c->direct_windows && c->pristine && !c->pend.empty() && w >= 64 && c->stile == PD_TILE) {
         const uint32_t m = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
         bool done = false;
         int rd = direct_windows(c, w, min_dep, m, cover, sum, &done);

@@ -63,7 +63,8 @@ void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, cons
                           uint32_t n_stiles, int stile, int *diff, int *sums, uint8_t *hstate,
                           uint64_t *ovf, uint32_t ovf_cap, CheckWords *chk, unsigned grid_tiles);
 void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
-                         uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, uint32_t *n_long, uint32_t *fail,
+                         uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, const uint64_t *win_off,
+                         uint32_t *cover, unsigned long long *sum, uint32_t *n_long, uint32_t *fail,
                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
 void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,
                          bool only_if_overflow, unsigned grid);

@@ -320,6 +320,66 @@ __global__ __launch_bounds__(WG) void k_scatter_tiles(const PendSet ps, uint32_t
 //     reduced to the tile's share of the (at most two) windows it touches.
 // HBM traffic: the runs, once (+ the look-back overlap), and 24 bytes per tile.  No inter-workgroup
 // dependency, no atomics outside LDS.
+struct WinArgs {
+    uint32_t w;              // window width in cells
+    uint32_t min_dep;
+    float inv_w;
+    uint32_t *cover;         // per window (global index = win_off[contig] + k)
+    unsigned long long *sum;
+    TilePart *part;          // w >= TILE: per-tile partials for the (at most two) windows it touches
+};
+
+// Narrow windows (64 <= w < TILE) for the direct kernels: k_sweep's LDS accumulators (one packed
+// 64-bit word per window overlapping the tile: cover in the top 16 bits, depth sum below), fed from
+// the registers that hold the tile's local prefix sums.  Called by the whole workgroup.
+template <int ROWS>
+__device__ __forceinline__ void direct_small_windows(const int4 (&v)[ROWS], const int (&rowex)[ROWS], int base,
+                                                     uint32_t wrap_mask, uint32_t local0, uint32_t clen, const WinArgs &wa,
+                                                     uint64_t wbase, unsigned long long *acc)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t w = wa.w;
+    const uint32_t k0 = local0 / w;                              // first window touching the tile
+    const uint32_t nacc = (uint32_t)(((uint64_t)local0 + TILE - 1) / w - k0 + 1);
+    for (uint32_t j = threadIdx.x; j < nacc; j += WG) acc[j] = 0;
+    __syncthreads();
+    const uint32_t phase = local0 - k0 * w;                      // offset of the tile inside window k0
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int bsum = base + rowex[r];
+        const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+        const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
+                               (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
+        const uint32_t x = pos + phase;
+        uint32_t q = (uint32_t)((float)x * wa.inv_w);
+        if ((uint64_t)q * w > x) --q;
+        if ((uint64_t)(q + 1) * w <= x) ++q;
+        uint64_t nb = (uint64_t)(q + 1) * w - phase;             // tile-local cell where window q+1 starts
+        uint32_t c = 0; unsigned long long sm = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t pe = pos + e;
+            if (pe == nb) {
+                if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | sm);
+                c = 0; sm = 0; ++q; nb += w;
+            }
+            if ((uint64_t)local0 + pe < clen && d[e] >= wa.min_dep) { ++c; sm += d[e]; }
+        }
+        if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | sm);
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
+        const unsigned long long a = acc[j];
+        const uint32_t c = (uint32_t)(a >> 48);
+        if (!c) continue;
+        const unsigned long long sm = a & 0xFFFFFFFFFFFFull;
+        const uint64_t k = (uint64_t)k0 + j;
+        const bool inside = (k * w >= local0) && ((k + 1) * (uint64_t)w <= (uint64_t)local0 + TILE);
+        if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = sm; }
+        else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], sm); }
+    }
+}
+
 // One candidate run of the direct pass; per-lane counters (summed over the wave by the caller).
 struct DirectCnt { uint32_t n_beg; int open; int carry; };
 
@@ -349,12 +409,20 @@ __device__ __forceinline__ void direct_candidate(const pd_iv v, int32_t ctg, uin
     }
 }
 
-template <int UN, int WPE>
+struct DirectWide { static constexpr bool narrow = false; uint32_t w, min_dep; TilePart *part; };
+struct DirectNarrow { static constexpr bool narrow = true; WinArgs wa; const uint64_t *win_off; };
+
+// A = DirectWide: windows >= TILE, per-tile partials (the bench's instantiation);
+// A = DirectNarrow: 64 <= w < TILE, LDS accumulators, results straight into the window arrays.
+template <int UN, int WPE, class A>
 __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint32_t n_tiles, ContigTab tab,
-                                                        const uint32_t *tile_contig, uint32_t wrap_mask, uint32_t w,
-                                                        uint32_t min_dep, TilePart *part, uint32_t *n_long,
-                                                        uint32_t *heavy_list, uint32_t *heavy_count)
+                                                        const uint32_t *tile_contig, uint32_t wrap_mask, const A args,
+                                                        uint32_t *n_long, uint32_t *heavy_list, uint32_t *heavy_count)
 {
+    constexpr bool NARROW = A::narrow;
+    uint32_t w, min_dep; TilePart *part = nullptr;
+    if constexpr (NARROW) { w = args.wa.w; min_dep = args.wa.min_dep; } else { w = args.w; min_dep = args.min_dep; part = args.part; }
+    __shared__ unsigned long long acc[NARROW ? TILE / 64 + 2 : 1];
     constexpr int ST = TILE;
     constexpr int ROWS = TILE / (WG * 4);                        // 8
     // two signed 16-bit counters per word, kept as ONE 32-bit sum 65536 * H + L: half the LDS of an
@@ -463,6 +531,11 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
         __syncthreads();
         int base = s_carry;
         for (int k = 0; k < wv; ++k) base += wtot[k];
+        if constexpr (NARROW) {                                   // narrow windows: LDS accumulators
+            if (p0 < clen) direct_small_windows<ROWS>(v, tot, base, wrap_mask, p0, clen, args.wa, args.win_off[ctg], acc);
+            __syncthreads();
+            continue;
+        }
         // ---- the tile's share of windows k0 and k0 + 1 ----
         const uint64_t local0 = p0;
         int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
@@ -571,10 +644,13 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
 }
 
 __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uint32_t n_tiles, ContigTab tab,
-                                                     const uint32_t *tile_contig, uint32_t wrap_mask, uint32_t w,
-                                                     uint32_t min_dep, TilePart *part, uint32_t *n_long,
+                                                     const uint32_t *tile_contig, uint32_t wrap_mask, const WinArgs wa,
+                                                     const uint64_t *win_off, uint32_t *n_long,
                                                      const uint32_t *heavy_list, const uint32_t *heavy_count)
 {
+    const uint32_t w = wa.w, min_dep = wa.min_dep;
+    TilePart *const part = wa.part;
+    __shared__ unsigned long long acc[TILE / 64 + 2];
     constexpr int ST = TILE;
     constexpr int ROWS = TILE / (WG * 4);                        // 8
     __shared__ __attribute__((aligned(16))) int win[ST];
@@ -665,6 +741,12 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
         __syncthreads();
         int base = s_carry;
         for (int k = 0; k < wv; ++k) base += wtot[k];
+        if (w < (uint32_t)ST) {                                   // narrow windows: LDS accumulators (uniform branch)
+            const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);
+            if (p0 < clen) direct_small_windows<ROWS>(v, excl, base, wrap_mask, p0, clen, wa, win_off[ctg], acc);
+            __syncthreads();
+            continue;
+        }
         // ---- the tile's share of windows k0 and k0 + 1 ----
         const uint64_t local0 = a - tab.off[ctg];
         int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
@@ -850,14 +932,6 @@ __global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, const int 
 //   MODE_WIN   : fused fixed-window reduction, nothing written back (4 B/base)
 //   FROM_DEPTH : input already holds depth (reduction only)
 // ------------------------------------------------------------------------------------------
-struct WinArgs {
-    uint32_t w;              // window width in cells
-    uint32_t min_dep;
-    float inv_w;
-    uint32_t *cover;         // per window (global index = win_off[contig] + k)
-    unsigned long long *sum;
-    TilePart *part;          // w >= TILE: per-tile partials for the (at most two) windows it touches
-};
 
 template <bool WRITE, bool WIN, bool FROM_DEPTH>
 __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32_t wrap_mask,
@@ -1402,20 +1476,27 @@ void launch_scatter_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, cons
 }
 
 void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
-                         uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, uint32_t *n_long, uint32_t *fail,
+                         uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, const uint64_t *win_off,
+                         uint32_t *cover, unsigned long long *sum, uint32_t *n_long, uint32_t *fail,
                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un)
 {
-#define PD_DIRECT(UN_, WPE_) hipLaunchKernelGGL((k_direct_tiles<UN_, WPE_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, \
-                                                tile_contig, wrap_mask, w, min_dep, part, n_long, heavy_list, heavy_count)
-    switch (un) {                       // tuning knob "direct_un": loads in flight per thread + 100 x waves-per-SIMD target
+    WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = cover; wa.sum = sum; wa.part = part;
+    const DirectWide dw{w, min_dep, part};
+    const DirectNarrow dn{wa, win_off};
+#define PD_DIRECT(UN_, WPE_) hipLaunchKernelGGL((k_direct_tiles<UN_, WPE_, DirectWide>), dim3(grid_tiles), dim3(WG), 0, st, ps, \
+                                                n_tiles, tab, tile_contig, wrap_mask, dw, n_long, heavy_list, heavy_count)
+    if (w < (uint32_t)TILE)
+        hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
+                           wrap_mask, dn, n_long, heavy_list, heavy_count);
+    else switch (un) {                       // tuning knob "direct_un": loads in flight per thread + 100 x waves-per-SIMD target
     case 404: PD_DIRECT(4, 4); break;   // (measured on the bench sample: 504 3.4-3.6 ms, 508 3.3-3.6, 404 3.7, 408 3.7)
     case 408: PD_DIRECT(8, 4); break;
     case 508: PD_DIRECT(8, 5); break;
     default: PD_DIRECT(4, 5); break;
     }
 #undef PD_DIRECT
-    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, w, min_dep,
-                       part, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count);
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,
+                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count);
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 

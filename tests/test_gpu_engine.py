@@ -537,7 +537,8 @@ def _split_streams(rng, lens, n, max_len=300):
     return first, other
 
 
-@pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (250000, 0, 18), (10000000, 1, 0)])
+@pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (250000, 0, 18), (10000000, 1, 0),
+                                             (100, 1, 0), (1000, 2, 18), (64, 1, 0), (5000, 0, 18), (8191, 1, 0)])
 def test_direct_windows_equal_oracle(w, min_dep, wrap):
     rng = np.random.default_rng(300 + w % 97)
     first, other = _split_streams(rng, LENS, 80000)
@@ -607,13 +608,13 @@ def test_direct_windows_fall_back():
         assert np.array_equal(cover, c) and np.array_equal(tot, t)
         e.scan(0)                                             # fell back: the arrays hold the sample
         check_depth(e, LENS, d, off)
-        # narrow windows
+        # windows narrower than 64 cells
         d2, off2 = oracle_depth(LENS, np.concatenate([first, other]), False)
         e.reset()
         e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
-        woff, cover, tot = e.scan_reduce_windows(100, 1, 0)
-        c, t = windows_ref(LENS, d2, off2, 100, 1)
+        woff, cover, tot = e.scan_reduce_windows(50, 1, 0)
+        c, t = windows_ref(LENS, d2, off2, 50, 1)
         assert np.array_equal(cover, c) and np.array_equal(tot, t)
         e.scan(0)
         check_depth(e, LENS, d2, off2)
