@@ -1,0 +1,588 @@
+// pgzip.cpp — see pgzip.h.  Stage 2 below re-states what zlib's deflate does AFTER the LZ77 parse
+// (trees.c of zlib 1.2.11 / 1.2.12, as published): same block boundaries, same Huffman codes, same
+// bits.  It is test-pinned against the system zlib on every golden table and on generated text.
+#include "pgzip.h"
+
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "../csrc/pd_inflate_core.h"
+
+namespace pgz {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// symbols: literal = byte value; match = (len << 16) | dist, len 3..258, dist 1..32768
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t Sym;
+inline bool is_match(Sym s) { return s >= 65536u; }
+inline uint32_t sym_len(Sym s) { return is_match(s) ? (s >> 16) : 1u; }
+
+const int LENGTH_CODES = 29, LITERALS = 256, L_CODES = 286, D_CODES = 30, BL_CODES = 19, HEAP_SIZE = 2 * L_CODES + 1;
+const int MAX_BITS = 15, MAX_BL_BITS = 7, END_BLOCK = 256, REP_3_6 = 16, REPZ_3_10 = 17, REPZ_11_138 = 18;
+const uint32_t LIT_BUFSIZE = 1u << (8 + 6);           // memLevel 8: a block is flushed at LIT_BUFSIZE - 1 symbols
+
+const int extra_lbits[LENGTH_CODES] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const int extra_dbits[D_CODES] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const int extra_blbits[BL_CODES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 7};
+const uint8_t bl_order[BL_CODES] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Ct { uint16_t freq, code, dad, len; };
+
+struct Static {
+    Ct ltree[L_CODES + 2], dtree[D_CODES];
+    uint8_t dist_code[512], length_code[256];
+    int base_length[LENGTH_CODES], base_dist[D_CODES];
+    Static();
+};
+
+unsigned bi_reverse(unsigned code, int len)
+{
+    unsigned res = 0;
+    do { res |= code & 1; code >>= 1; res <<= 1; } while (--len > 0);
+    return res >> 1;
+}
+
+void gen_codes(Ct *tree, int max_code, const uint16_t *bl_count)
+{
+    uint16_t next_code[MAX_BITS + 1];
+    unsigned code = 0;
+    for (int bits = 1; bits <= MAX_BITS; ++bits) { code = (code + bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
+    for (int n = 0; n <= max_code; ++n) {
+        const int len = tree[n].len;
+        if (len == 0) continue;
+        tree[n].code = (uint16_t)bi_reverse(next_code[len]++, len);
+    }
+}
+
+Static::Static()
+{
+    int length = 0, code;
+    for (code = 0; code < LENGTH_CODES - 1; ++code) {
+        base_length[code] = length;
+        for (int n = 0; n < (1 << extra_lbits[code]); ++n) length_code[length++] = (uint8_t)code;
+    }
+    base_length[code] = 0;                               // code 28 (length 258) carries no extra bits
+    length_code[length - 1] = (uint8_t)code;
+    int dist = 0;
+    for (code = 0; code < 16; ++code) {
+        base_dist[code] = dist;
+        for (int n = 0; n < (1 << extra_dbits[code]); ++n) dist_code[dist++] = (uint8_t)code;
+    }
+    dist >>= 7;                                          // from now on all distances are divided by 128
+    for (; code < D_CODES; ++code) {
+        base_dist[code] = dist << 7;
+        for (int n = 0; n < (1 << (extra_dbits[code] - 7)); ++n) dist_code[256 + dist++] = (uint8_t)code;
+    }
+    uint16_t bl_count[MAX_BITS + 1] = {0};
+    int n = 0;
+    while (n <= 143) { ltree[n++].len = 8; bl_count[8]++; }
+    while (n <= 255) { ltree[n++].len = 9; bl_count[9]++; }
+    while (n <= 279) { ltree[n++].len = 7; bl_count[7]++; }
+    while (n <= 287) { ltree[n++].len = 8; bl_count[8]++; }
+    gen_codes(ltree, L_CODES + 1, bl_count);
+    for (n = 0; n < D_CODES; ++n) { dtree[n].len = 5; dtree[n].code = (uint16_t)bi_reverse((unsigned)n, 5); }
+}
+const Static ST;
+
+inline int d_code(unsigned dist) { return dist < 256 ? ST.dist_code[dist] : ST.dist_code[256 + (dist >> 7)]; }
+
+struct TreeDesc { Ct *dyn; const Ct *stat; const int *extra; int extra_base, elems, max_length, max_code; };
+
+// ---------------------------------------------------------------------------------------------
+// stage 2: blocks, trees, bits
+// ---------------------------------------------------------------------------------------------
+class BlockWriter {
+public:
+    explicit BlockWriter(std::vector<uint8_t> &out) : out_(out) { init_block(); }
+    bool add(Sym s)
+    {
+        syms_.push_back(s);
+        if (is_match(s)) {
+            const unsigned lc = (s >> 16) - 3, dist = (s & 0xffff) - 1;
+            ltree_[ST.length_code[lc] + LITERALS + 1].freq++;
+            dtree_[d_code(dist)].freq++;
+            span_ += (s >> 16);
+        } else {
+            ltree_[s].freq++;
+            span_ += 1;
+        }
+        if (syms_.size() == LIT_BUFSIZE - 1) return flush_block(false);
+        return true;
+    }
+    bool finish()
+    {
+        if (!flush_block(true)) return false;
+        // bi_windup
+        if (bi_valid_ > 8) { out_.push_back((uint8_t)bi_buf_); out_.push_back((uint8_t)(bi_buf_ >> 8)); }
+        else if (bi_valid_ > 0) out_.push_back((uint8_t)bi_buf_);
+        bi_buf_ = 0; bi_valid_ = 0;
+        return true;
+    }
+
+private:
+    std::vector<uint8_t> &out_;
+    std::vector<Sym> syms_;
+    uint64_t span_ = 0;                                  // input bytes covered by the buffered symbols
+    Ct ltree_[HEAP_SIZE], dtree_[2 * D_CODES + 1], bltree_[2 * BL_CODES + 1];
+    uint16_t bl_count_[MAX_BITS + 1];
+    int heap_[2 * L_CODES + 1], heap_len_ = 0, heap_max_ = 0;
+    uint8_t depth_[2 * L_CODES + 1];
+    unsigned long opt_len_ = 0, static_len_ = 0;
+    uint16_t bi_buf_ = 0; int bi_valid_ = 0;
+
+    void init_block()
+    {
+        for (int n = 0; n < L_CODES; ++n) ltree_[n].freq = 0;
+        for (int n = 0; n < D_CODES; ++n) dtree_[n].freq = 0;
+        for (int n = 0; n < BL_CODES; ++n) bltree_[n].freq = 0;
+        ltree_[END_BLOCK].freq = 1;
+        opt_len_ = static_len_ = 0;
+        syms_.clear(); span_ = 0;
+    }
+    void send_bits(unsigned value, int length)
+    {
+        // 16-bit bit buffer, least significant bit first
+        if (bi_valid_ > 16 - length) {
+            bi_buf_ |= (uint16_t)(value << bi_valid_);
+            out_.push_back((uint8_t)bi_buf_); out_.push_back((uint8_t)(bi_buf_ >> 8));
+            bi_buf_ = (uint16_t)(value >> (16 - bi_valid_));
+            bi_valid_ += length - 16;
+        } else {
+            bi_buf_ |= (uint16_t)(value << bi_valid_);
+            bi_valid_ += length;
+        }
+    }
+    void send_code(int c, const Ct *tree) { send_bits(tree[c].code, tree[c].len); }
+
+    bool smaller(const Ct *tree, int n, int m) const
+    {
+        return tree[n].freq < tree[m].freq || (tree[n].freq == tree[m].freq && depth_[n] <= depth_[m]);
+    }
+    void pqdownheap(const Ct *tree, int k)
+    {
+        const int v = heap_[k];
+        int j = k << 1;
+        while (j <= heap_len_) {
+            if (j < heap_len_ && smaller(tree, heap_[j + 1], heap_[j])) ++j;
+            if (smaller(tree, v, heap_[j])) break;
+            heap_[k] = heap_[j]; k = j;
+            j <<= 1;
+        }
+        heap_[k] = v;
+    }
+    void gen_bitlen(TreeDesc &d)
+    {
+        Ct *tree = d.dyn;
+        const int max_code = d.max_code, base = d.extra_base, max_length = d.max_length;
+        int h, overflow = 0;
+        for (int bits = 0; bits <= MAX_BITS; ++bits) bl_count_[bits] = 0;
+        tree[heap_[heap_max_]].len = 0;                  // root of the heap
+        for (h = heap_max_ + 1; h < HEAP_SIZE; ++h) {
+            const int n = heap_[h];
+            int bits = tree[tree[n].dad].len + 1;
+            if (bits > max_length) { bits = max_length; ++overflow; }
+            tree[n].len = (uint16_t)bits;
+            if (n > max_code) continue;                  // not a leaf node
+            bl_count_[bits]++;
+            int xbits = 0;
+            if (n >= base) xbits = d.extra[n - base];
+            const unsigned long f = tree[n].freq;
+            opt_len_ += f * (unsigned long)(bits + xbits);
+            if (d.stat) static_len_ += f * (unsigned long)(d.stat[n].len + xbits);
+        }
+        if (overflow == 0) return;
+        do {                                             // find the first bit length which could increase
+            int bits = max_length - 1;
+            while (bl_count_[bits] == 0) --bits;
+            bl_count_[bits]--;
+            bl_count_[bits + 1] += 2;
+            bl_count_[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (int bits = max_length; bits != 0; --bits) {
+            int n = bl_count_[bits];
+            while (n != 0) {
+                const int m = heap_[--h];
+                if (m > max_code) continue;
+                if (tree[m].len != (unsigned)bits) {
+                    opt_len_ += ((unsigned long)bits - tree[m].len) * tree[m].freq;
+                    tree[m].len = (uint16_t)bits;
+                }
+                --n;
+            }
+        }
+    }
+    void build_tree(TreeDesc &d)
+    {
+        Ct *tree = d.dyn;
+        const int elems = d.elems;
+        int max_code = -1, node;
+        heap_len_ = 0; heap_max_ = HEAP_SIZE;
+        for (int n = 0; n < elems; ++n) {
+            if (tree[n].freq != 0) { heap_[++heap_len_] = max_code = n; depth_[n] = 0; }
+            else tree[n].len = 0;
+        }
+        while (heap_len_ < 2) {                          // force at least two codes of non zero frequency
+            node = heap_[++heap_len_] = (max_code < 2 ? ++max_code : 0);
+            tree[node].freq = 1;
+            depth_[node] = 0;
+            opt_len_--;
+            if (d.stat) static_len_ -= d.stat[node].len;
+        }
+        d.max_code = max_code;
+        for (int n = heap_len_ / 2; n >= 1; --n) pqdownheap(tree, n);
+        node = elems;
+        do {
+            const int n = heap_[1];
+            heap_[1] = heap_[heap_len_--];
+            pqdownheap(tree, 1);
+            const int m = heap_[1];
+            heap_[--heap_max_] = n;
+            heap_[--heap_max_] = m;
+            tree[node].freq = (uint16_t)(tree[n].freq + tree[m].freq);
+            depth_[node] = (uint8_t)((depth_[n] >= depth_[m] ? depth_[n] : depth_[m]) + 1);
+            tree[n].dad = tree[m].dad = (uint16_t)node;
+            heap_[1] = node++;
+            pqdownheap(tree, 1);
+        } while (heap_len_ >= 2);
+        heap_[--heap_max_] = heap_[1];
+        gen_bitlen(d);
+        gen_codes(tree, max_code, bl_count_);
+    }
+    void scan_tree(Ct *tree, int max_code)
+    {
+        int prevlen = -1, nextlen = tree[0].len, count = 0, max_count = 7, min_count = 4;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        tree[max_code + 1].len = 0xffff;                 // guard
+        for (int n = 0; n <= max_code; ++n) {
+            const int curlen = nextlen; nextlen = tree[n + 1].len;
+            if (++count < max_count && curlen == nextlen) continue;
+            else if (count < min_count) bltree_[curlen].freq += (uint16_t)count;
+            else if (curlen != 0) { if (curlen != prevlen) bltree_[curlen].freq++; bltree_[REP_3_6].freq++; }
+            else if (count <= 10) bltree_[REPZ_3_10].freq++;
+            else bltree_[REPZ_11_138].freq++;
+            count = 0; prevlen = curlen;
+            if (nextlen == 0) { max_count = 138; min_count = 3; }
+            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+            else { max_count = 7; min_count = 4; }
+        }
+    }
+    void send_tree(Ct *tree, int max_code)
+    {
+        int prevlen = -1, nextlen = tree[0].len, count = 0, max_count = 7, min_count = 4;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        for (int n = 0; n <= max_code; ++n) {
+            const int curlen = nextlen; nextlen = tree[n + 1].len;
+            if (++count < max_count && curlen == nextlen) continue;
+            else if (count < min_count) { do { send_code(curlen, bltree_); } while (--count != 0); }
+            else if (curlen != 0) {
+                if (curlen != prevlen) { send_code(curlen, bltree_); --count; }
+                send_code(REP_3_6, bltree_); send_bits((unsigned)(count - 3), 2);
+            } else if (count <= 10) { send_code(REPZ_3_10, bltree_); send_bits((unsigned)(count - 3), 3); }
+            else { send_code(REPZ_11_138, bltree_); send_bits((unsigned)(count - 11), 7); }
+            count = 0; prevlen = curlen;
+            if (nextlen == 0) { max_count = 138; min_count = 3; }
+            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+            else { max_count = 7; min_count = 4; }
+        }
+    }
+    void compress_block(const Ct *ltree, const Ct *dtree)
+    {
+        for (const Sym s : syms_) {
+            if (!is_match(s)) { send_code((int)s, ltree); continue; }
+            unsigned lc = (s >> 16) - 3, dist = (s & 0xffff) - 1;
+            int code = ST.length_code[lc];
+            send_code(code + LITERALS + 1, ltree);
+            int extra = extra_lbits[code];
+            if (extra != 0) { lc -= (unsigned)ST.base_length[code]; send_bits(lc, extra); }
+            code = d_code(dist);
+            send_code(code, dtree);
+            extra = extra_dbits[code];
+            if (extra != 0) { dist -= (unsigned)ST.base_dist[code]; send_bits(dist, extra); }
+        }
+        send_code(END_BLOCK, ltree);
+    }
+    bool flush_block(bool last)
+    {
+        TreeDesc ld{ltree_, ST.ltree, extra_lbits, LITERALS + 1, L_CODES, MAX_BITS, 0};
+        TreeDesc dd{dtree_, ST.dtree, extra_dbits, 0, D_CODES, MAX_BITS, 0};
+        TreeDesc bd{bltree_, nullptr, extra_blbits, 0, BL_CODES, MAX_BL_BITS, 0};
+        build_tree(ld);
+        build_tree(dd);
+        // build_bl_tree
+        scan_tree(ltree_, ld.max_code);
+        scan_tree(dtree_, dd.max_code);
+        build_tree(bd);
+        int max_blindex;
+        for (max_blindex = BL_CODES - 1; max_blindex >= 3; --max_blindex)
+            if (bltree_[bl_order[max_blindex]].len != 0) break;
+        opt_len_ += 3 * ((unsigned long)max_blindex + 1) + 5 + 5 + 4;
+        unsigned long opt_lenb = (opt_len_ + 3 + 7) >> 3;
+        const unsigned long static_lenb = (static_len_ + 3 + 7) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        if (span_ + 4 <= opt_lenb) return false;         // zlib would store this block (incompressible data): not re-stated
+        if (static_lenb == opt_lenb) {
+            send_bits((1u << 1) + (last ? 1u : 0u), 3);  // STATIC_TREES
+            compress_block(ST.ltree, ST.dtree);
+        } else {
+            send_bits((2u << 1) + (last ? 1u : 0u), 3);  // DYN_TREES
+            const int lcodes = ld.max_code + 1, dcodes = dd.max_code + 1, blcodes = max_blindex + 1;
+            send_bits((unsigned)(lcodes - 257), 5);
+            send_bits((unsigned)(dcodes - 1), 5);
+            send_bits((unsigned)(blcodes - 4), 4);
+            for (int rank = 0; rank < blcodes; ++rank) send_bits(bltree_[bl_order[rank]].len, 3);
+            send_tree(ltree_, lcodes - 1);
+            send_tree(dtree_, dcodes - 1);
+            compress_block(ltree_, dtree_);
+        }
+        init_block();
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// stage 1: zlib's own parse of one chunk, read back as symbols
+// ---------------------------------------------------------------------------------------------
+bool parse_symbols(const uint8_t *in, size_t in_len, std::vector<Sym> &syms)
+{
+    using namespace pdi;
+    static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,
+                                       131, 163, 195, 227, 258};
+    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537,
+                                       2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    if (in_len > 0xFFFFFFF0u) return false;
+    Tables tb;
+    Fast &tf = tb.fast; Slow &t = tb.slow;
+    Bits b; b.in = in; b.pos = 0; b.end = (uint32_t)in_len; b.buf = 0; b.cnt = 0;
+    for (;;) {
+        const uint32_t last = bits_get(b, 1), type = bits_get(b, 2);
+        if (type == 1) {
+            for (int i = 0; i < 144; ++i) t.cl[i] = 8;
+            for (int i = 144; i < 256; ++i) t.cl[i] = 9;
+            for (int i = 256; i < 280; ++i) t.cl[i] = 7;
+            for (int i = 280; i < 288; ++i) t.cl[i] = 8;
+            if (build(t.ll, tf.ll, LL_FAST_BITS, t.cl, 288) < 0) return false;
+            for (int i = 0; i < 30; ++i) t.cl[i] = 5;
+            if (build(t.d, tf.d, D_FAST_BITS, t.cl, 30) < 0) return false;
+        } else if (type == 2) {
+            const int nlen = (int)bits_get(b, 5) + 257, ndist = (int)bits_get(b, 5) + 1, ncode = (int)bits_get(b, 4) + 4;
+            if (nlen > 286 || ndist > 30) return false;
+            for (int i = 0; i < 19; ++i) t.small[i] = 0;
+            for (int i = 0; i < ncode; ++i) t.small[CLORD[i]] = (uint8_t)bits_get(b, 3);
+            if (build(t.d, tf.d, D_FAST_BITS, t.small, 19) < 0) return false;
+            int idx = 0;
+            uint8_t *cl = t.cl;
+            while (idx < nlen + ndist) {
+                const int sym = decode(b, t.d, tf.d, D_FAST_BITS);
+                if (sym < 0) return false;
+                if (sym < 16) cl[idx++] = (uint8_t)sym;
+                else {
+                    int rep; uint8_t val = 0;
+                    if (sym == 16) { if (idx == 0) return false; val = cl[idx - 1]; rep = 3 + (int)bits_get(b, 2); }
+                    else if (sym == 17) rep = 3 + (int)bits_get(b, 3);
+                    else rep = 11 + (int)bits_get(b, 7);
+                    if (idx + rep > nlen + ndist) return false;
+                    while (rep--) cl[idx++] = val;
+                }
+            }
+            if (build(t.ll, tf.ll, LL_FAST_BITS, cl, nlen) < 0) return false;
+            if (build(t.d, tf.d, D_FAST_BITS, cl + nlen, ndist) < 0) return false;
+        } else return false;                             // a stored block: zlib found the chunk incompressible
+        for (;;) {
+            const int sym = decode(b, t.ll, tf.ll, LL_FAST_BITS);
+            if (sym < 0 || sym > 285) return false;
+            if (sym < 256) { syms.push_back((Sym)sym); continue; }
+            if (sym == 256) break;
+            static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+            static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+            const int ls = sym - 257;
+            const uint32_t len = LBASE[ls] + bits_get(b, LEXT[ls]);
+            const int ds = decode(b, t.d, tf.d, D_FAST_BITS);
+            if (ds < 0 || ds > 29) return false;
+            const uint32_t dist = DBASE[ds] + bits_get(b, DEXT[ds]);
+            syms.push_back((len << 16) | dist);
+            if (bits_overrun(b)) return false;
+        }
+        if (bits_overrun(b)) return false;
+        if (last) break;
+    }
+    return true;
+}
+
+struct Chunk {
+    size_t start = 0, end = 0, tail_end = 0;
+    std::vector<Sym> syms;           // zlib's parse of [start, tail_end), primed with the 32 KiB before start
+    uint32_t crc = 0;                // of [start, end)
+    bool ok = false, done = false;
+};
+
+void run_chunk(const uint8_t *data, Chunk &c)
+{
+    c.ok = false;
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+    if (c.start > 0) {
+        const size_t dl = c.start < 32768 ? c.start : 32768;
+        if (deflateSetDictionary(&z, data + c.start - dl, (uInt)dl) != Z_OK) { deflateEnd(&z); return; }
+    }
+    const size_t n = c.tail_end - c.start;
+    std::vector<uint8_t> raw(deflateBound(&z, (uLong)n) + 64);
+    z.next_in = const_cast<Bytef *>(data + c.start); z.avail_in = (uInt)n;
+    z.next_out = raw.data(); z.avail_out = (uInt)raw.size();
+    const int rc = deflate(&z, Z_FINISH);
+    const size_t produced = raw.size() - z.avail_out;
+    deflateEnd(&z);
+    if (rc != Z_STREAM_END) return;
+    c.syms.reserve(n / 3 + 16);
+    if (!parse_symbols(raw.data(), produced, c.syms)) return;
+    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + c.start, (uInt)(c.end - c.start));
+    c.ok = true;
+}
+
+} // namespace
+
+bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p)
+{
+    if (threads < 1) threads = 1;
+    const size_t CH = p.chunk < 65536 ? 65536 : p.chunk;
+    const size_t TAIL = p.tail < 2048 ? 2048 : p.tail;
+    const size_t MARGIN = 1024;                           // zlib's look-ahead near the artificial end of a chunk
+    if (CH > 0x40000000u || TAIL > CH / 2) return false;
+    const size_t n_chunks = n == 0 ? 1 : (n + CH - 1) / CH;
+    std::vector<Chunk> chunks(n_chunks);
+    for (size_t i = 0; i < n_chunks; ++i) {
+        chunks[i].start = i * CH;
+        chunks[i].end = std::min(n, (i + 1) * CH);
+        chunks[i].tail_end = std::min(n, chunks[i].end + TAIL);
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    size_t consumed = 0;                                  // chunks the encoder has finished with (guarded by mu)
+    bool abort_all = false;
+    const size_t AHEAD = (size_t)threads * 4 + 2;
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_chunks) return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort_all || i < consumed + AHEAD; });
+                if (abort_all) return;
+            }
+            run_chunk(data, chunks[i]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                chunks[i].done = true;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    const size_t n_workers = std::min<size_t>((size_t)threads, n_chunks);
+    for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+
+    std::vector<uint8_t> body;
+    body.reserve(n / 4 + 1024);
+    static const uint8_t HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};      // gz header: deflate, no flags, mtime 0, xfl 0, OS unix
+    body.insert(body.end(), HDR, HDR + 10);
+    BlockWriter bw(body);
+    bool ok = true;
+    size_t pos = 0;                                       // every byte before pos is encoded
+    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+    auto wait_for = [&](size_t i) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return chunks[i].done; });
+    };
+    for (size_t i = 0; i < n_chunks && ok; ++i) {
+        wait_for(i);
+        Chunk &a = chunks[i];
+        if (!a.ok) { ok = false; break; }
+        crc = (uint32_t)crc32_combine(crc, a.crc, (z_off_t)(a.end - a.start));
+        // where this chunk's symbols are taken up to
+        size_t stop = n;                                  // exclusive; n = "to the very end"
+        const bool to_end = a.tail_end == n;
+        if (!to_end) {
+            wait_for(i + 1);
+            Chunk &b = chunks[i + 1];
+            if (!b.ok) { ok = false; break; }
+            // match ends of b inside a's tail
+            std::vector<size_t> bends;
+            size_t q = b.start;
+            for (const Sym s : b.syms) {
+                q += sym_len(s);
+                if (q + MARGIN > a.tail_end) break;
+                if (is_match(s)) bends.push_back(q);
+            }
+            // first match end of a (beyond pos and b.start) that b shares
+            size_t qa = a.start, k = 0;
+            stop = 0;
+            for (const Sym s : a.syms) {
+                qa += sym_len(s);
+                if (qa + MARGIN > a.tail_end) break;
+                if (!is_match(s) || qa <= b.start || qa <= pos) continue;
+                while (k < bends.size() && bends[k] < qa) ++k;
+                if (k < bends.size() && bends[k] == qa) { stop = qa; break; }
+            }
+            if (stop == 0) { ok = false; break; }          // the two parses did not meet inside the tail
+        }
+        // feed a's symbols covering [pos, stop)
+        size_t qa = a.start;
+        for (const Sym s : a.syms) {
+            if (qa >= stop) break;
+            if (qa >= pos) {
+                if (!bw.add(s)) { ok = false; break; }
+            } else if (qa + sym_len(s) > pos) { ok = false; break; }         // pos is not a symbol boundary of this parse
+            qa += sym_len(s);
+        }
+        if (!ok) break;
+        if (stop == n ? qa != n : qa != stop) { ok = false; break; }
+        pos = qa;
+        a.syms.clear(); a.syms.shrink_to_fit();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = i + 1;
+        }
+        cv.notify_all();
+        if (to_end) {
+            // the rest of the text was inside this chunk's tail: later chunks only add their checksums
+            for (size_t j = i + 1; j < n_chunks; ++j) {
+                wait_for(j);
+                if (!chunks[j].ok) { ok = false; break; }
+                crc = (uint32_t)crc32_combine(crc, chunks[j].crc, (z_off_t)(chunks[j].end - chunks[j].start));
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = j + 1;
+            }
+            cv.notify_all();
+            break;
+        }
+    }
+    if (ok) ok = pos == n && bw.finish();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true; consumed = n_chunks + AHEAD;
+    }
+    cv.notify_all();
+    for (auto &t : pool) t.join();
+    if (!ok) return false;
+    for (int k = 0; k < 4; ++k) body.push_back((uint8_t)(crc >> (8 * k)));
+    for (int k = 0; k < 4; ++k) body.push_back((uint8_t)((uint32_t)n >> (8 * k)));   // ISIZE = length mod 2^32
+    out.insert(out.end(), body.begin(), body.end());
+    return true;
+}
+
+bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out)
+{
+    return gzip_identical(data, n, threads, out, Params());
+}
+
+} // namespace pgz

@@ -1,0 +1,36 @@
+// pgzip.h — the byte stream of `gzopen(path, "wb")` + gzwrite + gzclose (zlib 1.2.x: deflate level 6,
+// default strategy, memLevel 8, gzip wrapper with mtime 0 / OS 3), produced with several threads.
+//
+// The reference writes every table through one zlib gz stream (include/gzstream.c:46-67), so its
+// .gz bytes are a function of the text; a 3 Gb `-w 100` table is 1.2 GB of text and a minute of
+// single-threaded deflate.  zlib's output factors into two stages:
+//   1. the LZ77 parse (deflate_slow: hash chains, lazy matching) — all of the time, and a function
+//      of the preceding 32 KiB only;
+//   2. block splitting (every 16383 symbols) + Huffman trees + bit packing — cheap, but sequential.
+// Stage 1 runs on worker threads, each calling zlib ITSELF on one chunk of the text primed with the
+// previous 32 KiB as dictionary (raw deflate), and reading the symbols back out of zlib's output;
+// neighbouring chunks overlap by a tail and are stitched where both parses emit a match ending at
+// the same position (from there on zlib's state is a function of the window alone).  Stage 2 is
+// re-stated here (RFC 1951 + the choices zlib's trees.c makes: heap order and tie-breaks of the
+// Huffman construction, length-limit repair, run-length coding of the code lengths, fixed vs
+// dynamic choice), and is checked against zlib byte for byte by tests/test_pgzip.py.
+// Whenever a case outside the re-statement shows up (a block zlib would store, chunks that do not
+// re-synchronise) the function returns false and the caller uses zlib's own serial stream.
+#ifndef PD_PGZIP_H_
+#define PD_PGZIP_H_
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+
+namespace pgz {
+
+// Appends the complete .gz file image of `data` to `out`.  Returns false (out untouched) when the
+// parallel form does not apply; the result, when produced, equals zlib's.
+bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out);
+
+// tuning / tests
+struct Params { size_t chunk = (size_t)1 << 20; size_t tail = (size_t)1 << 14; };
+bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p);
+
+} // namespace pgz
+#endif

@@ -526,6 +526,7 @@ bool write_site_depth(const std::string &path, const AlnHeader &hdr, const Regio
         return out.close();
     }
     GzWriter out;
+    out.set_threads(threads);                            // one stream, the reference's bytes, deflated on all threads
     if (!out.open(path)) { std::cerr << "open OUT File error: " << path << std::endl; return false; }
     std::vector<uint32_t> d(CH);
     std::string txt;
@@ -590,6 +591,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     else if (o.mode == 5 || o.mode == 6) { stat_path = prefix + ".win.stat.gz"; header_line = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
     else if (o.mode == 0) { stat_path = prefix + ".chr.stat.gz"; header_line = "#Chr\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
     GzWriter OUT;
+    OUT.set_threads(o.threads);                          // large tables: same bytes, LZ77 parse on all threads (host/pgzip.h)
     if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
 
     tm.mark("region model");
@@ -780,9 +782,9 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             for (const Bin &b : kv.second) {
                 const uint64_t L = (uint64_t)(b.end - b.start + 1);
                 SC += (uint64_t)(int64_t)b.cover; SL += L; SD += b.depth;
-                txt += chr; txt += '\t'; txt += std::to_string(b.start); txt += '\t'; txt += std::to_string(b.end); txt += '\t';
-                txt += std::to_string(L); txt += '\t'; txt += std::to_string(b.cover); txt += '\t'; txt += std::to_string(b.depth);
-                txt += '\t'; txt += fmt2(b.cover * 100.0 / L); txt += '\t'; txt += fmt2(b.depth * 1.0 / L); txt += '\n';
+                txt += chr; txt += '\t'; append_i64(&txt, b.start); txt += '\t'; append_i64(&txt, b.end); txt += '\t';
+                append_u64(&txt, L); txt += '\t'; append_i64(&txt, b.cover); txt += '\t'; append_u64(&txt, b.depth);
+                txt += '\t'; append_fmt2(&txt, b.cover * 100.0 / L); txt += '\t'; append_fmt2(&txt, b.depth * 1.0 / L); txt += '\n';
                 if (txt.size() > (1u << 22)) { OUT.write(txt); txt.clear(); }
             }
             OUT.write(txt);
@@ -809,7 +811,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
     }
     OUT.write(footer(SL, SC, SD));
+    tm.mark("table text");
     OUT.close();
-    tm.mark("tables");
+    tm.mark("table gzip");
     return 0;
 }

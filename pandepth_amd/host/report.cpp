@@ -1,6 +1,8 @@
 // report.cpp — see report.h
 #include "report.h"
+#include "pgzip.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 #include <condition_variable>
@@ -15,6 +17,11 @@ namespace pdh {
 bool GzWriter::open(const std::string &path)
 {
     close();
+    path_ = path;
+    if (threads_ > 1) {
+        fp_ = fopen(path.c_str(), "wb");                 // created now, like gzopen would; filled at close()
+        return fp_ != nullptr;
+    }
     f_ = gzopen(path.c_str(), "wb");
     if (f_) gzbuffer((gzFile)f_, 1 << 18);
     return f_ != nullptr;
@@ -22,6 +29,7 @@ bool GzWriter::open(const std::string &path)
 
 void GzWriter::write(const char *p, size_t n)
 {
+    if (fp_) { text_.append(p, n); return; }
     while (n) {
         const unsigned k = n > (1u << 30) ? (1u << 30) : (unsigned)n;
         gzwrite((gzFile)f_, p, k);
@@ -31,6 +39,36 @@ void GzWriter::write(const char *p, size_t n)
 
 bool GzWriter::close()
 {
+    if (fp_) {
+        FILE *fp = (FILE *)fp_;
+        fp_ = nullptr;
+        size_t pgz_min = (size_t)1 << 20;
+        if (const char *e = getenv("PANDEPTH_PGZ_MIN")) pgz_min = (size_t)strtoull(e, nullptr, 10);
+        std::vector<uint8_t> img;
+        bool ok;
+        if (text_.size() >= pgz_min && pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img)) {
+            ok = fwrite(img.data(), 1, img.size(), fp) == img.size();
+            ok = fclose(fp) == 0 && ok;
+        } else {
+            // zlib's own stream (small texts; data pgz does not re-state, e.g. incompressible blocks)
+            fclose(fp);
+            gzFile g = gzopen(path_.c_str(), "wb");
+            ok = g != nullptr;
+            if (g) {
+                gzbuffer(g, 1 << 18);
+                const char *p = text_.data();
+                size_t n = text_.size();
+                while (n) {
+                    const unsigned k = n > (1u << 30) ? (1u << 30) : (unsigned)n;
+                    if (gzwrite(g, p, k) != (int)k) { ok = false; break; }
+                    p += k; n -= k;
+                }
+                ok = gzclose(g) == Z_OK && ok;
+            }
+        }
+        std::string().swap(text_);
+        return ok;
+    }
     if (!f_) return true;
     const int r = gzclose((gzFile)f_);
     f_ = nullptr;
@@ -145,11 +183,65 @@ bool ParallelGzWriter::close()
     return p_->ok;
 }
 
+// printf("%.2f") for the finite non-negative doubles the tables hold, without printf: v = M * 2^e exactly, so
+// v * 100 = (M * 100) >> -e with an exact remainder, rounded half-to-even on the exact binary value — what
+// glibc's correctly rounded printf does.  Anything else (negative, non-finite, >= 2^52) goes through snprintf.
+size_t fmt2_to(char *out, double v)
+{
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    if ((bits >> 63) || be == 0x7ff || be >= 1023 + 52) return (size_t)snprintf(out, 64, "%.2f", v);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e;                                               // v = m * 2^e
+    if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
+    const uint64_t n = m * 100;                          // < 2^60
+    const int sh = -e;                                   // >= 1 here (v < 2^52)
+    uint64_t q;
+    if (sh >= 64) q = 0;                                 // n < 2^60 is below half of 2^sh
+    else {
+        q = n >> sh;
+        const uint64_t rem = n & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) ++q;
+    }
+    const uint64_t ip = q / 100;
+    const unsigned fp = (unsigned)(q % 100);
+    char tmp[24];
+    int k = 0;
+    uint64_t x = ip;
+    do { tmp[k++] = (char)('0' + x % 10); x /= 10; } while (x);
+    size_t o = 0;
+    while (k) out[o++] = tmp[--k];
+    out[o++] = '.'; out[o++] = (char)('0' + fp / 10); out[o++] = (char)('0' + fp % 10);
+    out[o] = 0;
+    return o;
+}
+
 std::string fmt2(double v)
 {
     char b[64];
-    snprintf(b, sizeof b, "%.2f", v);
-    return b;
+    const size_t n = fmt2_to(b, v);
+    return std::string(b, n);
+}
+
+void append_u64(std::string *s, uint64_t x)
+{
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + x % 10); x /= 10; } while (x);
+    while (k) s->push_back(tmp[--k]);
+}
+
+void append_i64(std::string *s, int64_t x)
+{
+    if (x < 0) { s->push_back('-'); append_u64(s, (uint64_t)0 - (uint64_t)x); } else append_u64(s, (uint64_t)x);
+}
+
+void append_fmt2(std::string *s, double v)
+{
+    char b[64];
+    const size_t n = fmt2_to(b, v);
+    s->append(b, n);
 }
 
 } // namespace pdh

@@ -14,12 +14,19 @@ class GzWriter {
 public:
     ~GzWriter() { close(); }
     bool open(const std::string &path);
+    // threads > 1: the text is collected and deflated at close() by pgz::gzip_identical (host/pgzip.h) —
+    // the SAME bytes as the single zlib stream, with the LZ77 parse spread over the threads; texts
+    // below PANDEPTH_PGZ_MIN bytes (default 1 MiB), and texts pgz declines, take zlib's serial stream
+    void set_threads(int threads) { threads_ = threads; }
     void write(const char *p, size_t n);
     void write(const std::string &s) { write(s.data(), s.size()); }
     bool close();
-    bool good() const { return f_ != nullptr; }
+    bool good() const { return f_ != nullptr || fp_ != nullptr; }
 private:
-    void *f_ = nullptr;
+    void *f_ = nullptr;          // gzFile: streaming mode
+    void *fp_ = nullptr;         // FILE*: collecting mode
+    int threads_ = 1;
+    std::string path_, text_;
 };
 
 // Large per-site outputs: text chunks are produced AND deflated on worker threads, each chunk
@@ -39,7 +46,11 @@ private:
     Impl *p_;
 };
 
-std::string fmt2(double v);          // "%.2f"
+std::string fmt2(double v);          // "%.2f" (exact, without printf for the values tables hold)
+size_t fmt2_to(char *out, double v); // out >= 64 bytes; returns the length
+void append_fmt2(std::string *s, double v);
+void append_u64(std::string *s, uint64_t x);
+void append_i64(std::string *s, int64_t x);
 
 } // namespace pdh
 #endif

@@ -1,0 +1,58 @@
+// tests/harness/pgzip_check.cpp — TEST INFRASTRUCTURE: pgz::gzip_identical against the system zlib's gzopen/gzwrite/gzclose
+// on a file's bytes.  usage: pgzip_check <file> [threads chunk tail]  -> prints "identical" / where the streams diverge.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../pandepth_amd/host/pgzip.h"
+
+static std::vector<uint8_t> slurp(const char *path)
+{
+    std::vector<uint8_t> v;
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    uint8_t buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + k);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: pgzip_check <file> [threads chunk tail]\n"); return 2; }
+    const std::vector<uint8_t> data = slurp(argv[1]);
+    const int threads = argc > 2 ? atoi(argv[2]) : 4;
+    pgz::Params p;
+    if (argc > 3) p.chunk = (size_t)atoll(argv[3]);
+    if (argc > 4) p.tail = (size_t)atoll(argv[4]);
+    // the reference stream: the way GzWriter (and the reference's gzstream) writes
+    char tmp[] = "/tmp/pgzcheckXXXXXX";
+    const int fd = mkstemp(tmp);
+    if (fd < 0) { perror("mkstemp"); return 2; }
+    close(fd);
+    const auto t0 = std::chrono::steady_clock::now();
+    gzFile g = gzopen(tmp, "wb");
+    gzbuffer(g, 1 << 18);
+    for (size_t o = 0; o < data.size(); o += 100000) gzwrite(g, data.data() + o, (unsigned)std::min<size_t>(100000, data.size() - o));
+    gzclose(g);
+    const auto t1 = std::chrono::steady_clock::now();
+    const std::vector<uint8_t> ref = slurp(tmp);
+    unlink(tmp);
+    std::vector<uint8_t> out;
+    const bool ok = pgz::gzip_identical(data.data(), data.size(), threads, out, p);
+    const auto t2 = std::chrono::steady_clock::now();
+    const double ts = std::chrono::duration<double>(t1 - t0).count(), tp = std::chrono::duration<double>(t2 - t1).count();
+    if (!ok) { printf("declined (%zu bytes, zlib %.3f s)\n", data.size(), ts); return 3; }
+    if (out == ref) { printf("identical %zu -> %zu bytes, zlib %.3f s, parallel(%d) %.3f s\n", data.size(), ref.size(), ts, threads, tp); return 0; }
+    size_t i = 0;
+    while (i < out.size() && i < ref.size() && out[i] == ref[i]) ++i;
+    printf("DIFFERENT at byte %zu (sizes %zu vs %zu)\n", i, out.size(), ref.size());
+    return 1;
+}
