@@ -6,10 +6,12 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <atomic>
-#include <condition_variable>
-#include <mutex>
+#include <functional>
 #include <thread>
 
 #include "../csrc/pd_inflate_core.h"
@@ -98,36 +100,39 @@ struct TreeDesc { Ct *dyn; const Ct *stat; const int *extra; int extra_base, ele
 // ---------------------------------------------------------------------------------------------
 // stage 2: blocks, trees, bits
 // ---------------------------------------------------------------------------------------------
-class BlockWriter {
+// One deflate block: the symbols zlib would have had in its buffer when it flushed.  The bits start at bit 0 of
+// `out`; *nbits is their number (the caller splices blocks together at arbitrary bit offsets).
+class BlockEncoder {
 public:
-    explicit BlockWriter(std::vector<uint8_t> &out) : out_(out) { init_block(); }
-    bool add(Sym s)
+    // false: zlib would have STORED this block (incompressible data) — not re-stated
+    bool encode(const Sym *syms, size_t n, bool last, std::vector<uint8_t> *out, uint64_t *nbits)
     {
-        syms_.push_back(s);
-        if (is_match(s)) {
-            const unsigned lc = (s >> 16) - 3, dist = (s & 0xffff) - 1;
-            ltree_[ST.length_code[lc] + LITERALS + 1].freq++;
-            dtree_[d_code(dist)].freq++;
-            span_ += (s >> 16);
-        } else {
-            ltree_[s].freq++;
-            span_ += 1;
+        out_.clear();
+        bi_buf_ = 0; bi_valid_ = 0;
+        init_block();
+        syms_.assign(syms, syms + n);
+        for (size_t i = 0; i < n; ++i) {
+            const Sym s = syms[i];
+            if (is_match(s)) {
+                const unsigned lc = (s >> 16) - 3, dist = (s & 0xffff) - 1;
+                ltree_[ST.length_code[lc] + LITERALS + 1].freq++;
+                dtree_[d_code(dist)].freq++;
+                span_ += (s >> 16);
+            } else {
+                ltree_[s].freq++;
+                span_ += 1;
+            }
         }
-        if (syms_.size() == LIT_BUFSIZE - 1) return flush_block(false);
-        return true;
-    }
-    bool finish()
-    {
-        if (!flush_block(true)) return false;
-        // bi_windup
+        if (!flush_block(last)) return false;
+        *nbits = (uint64_t)out_.size() * 8 + (uint64_t)bi_valid_;
         if (bi_valid_ > 8) { out_.push_back((uint8_t)bi_buf_); out_.push_back((uint8_t)(bi_buf_ >> 8)); }
         else if (bi_valid_ > 0) out_.push_back((uint8_t)bi_buf_);
-        bi_buf_ = 0; bi_valid_ = 0;
+        out->swap(out_);
         return true;
     }
 
 private:
-    std::vector<uint8_t> &out_;
+    std::vector<uint8_t> out_;
     std::vector<Sym> syms_;
     uint64_t span_ = 0;                                  // input bytes covered by the buffered symbols
     Ct ltree_[HEAP_SIZE], dtree_[2 * D_CODES + 1], bltree_[2 * BL_CODES + 1];
@@ -342,7 +347,6 @@ private:
             send_tree(dtree_, dcodes - 1);
             compress_block(ltree_, dtree_);
         }
-        init_block();
         return true;
     }
 };
@@ -418,25 +422,28 @@ bool parse_symbols(const uint8_t *in, size_t in_len, std::vector<Sym> &syms)
 }
 
 struct Chunk {
-    size_t start = 0, end = 0, tail_end = 0;
+    uint64_t start = 0, end = 0, tail_end = 0;   // absolute text positions
     std::vector<Sym> syms;           // zlib's parse of [start, tail_end), primed with the 32 KiB before start
     uint32_t crc = 0;                // of [start, end)
-    bool ok = false, done = false;
+    bool ok = false;
 };
 
-void run_chunk(const uint8_t *data, Chunk &c)
+// `text` holds the absolute range [base, ...)
+void run_chunk(const uint8_t *text, uint64_t base, Chunk &c)
 {
     c.ok = false;
+    c.syms.clear();
     z_stream z;
     memset(&z, 0, sizeof z);
     if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+    const uint8_t *p = text + (c.start - base);
     if (c.start > 0) {
-        const size_t dl = c.start < 32768 ? c.start : 32768;
-        if (deflateSetDictionary(&z, data + c.start - dl, (uInt)dl) != Z_OK) { deflateEnd(&z); return; }
+        const uint64_t dl = c.start < 32768 ? c.start : 32768;
+        if (deflateSetDictionary(&z, p - dl, (uInt)dl) != Z_OK) { deflateEnd(&z); return; }
     }
-    const size_t n = c.tail_end - c.start;
+    const size_t n = (size_t)(c.tail_end - c.start);
     std::vector<uint8_t> raw(deflateBound(&z, (uLong)n) + 64);
-    z.next_in = const_cast<Bytef *>(data + c.start); z.avail_in = (uInt)n;
+    z.next_in = const_cast<Bytef *>(p); z.avail_in = (uInt)n;
     z.next_out = raw.data(); z.avail_out = (uInt)raw.size();
     const int rc = deflate(&z, Z_FINISH);
     const size_t produced = raw.size() - z.avail_out;
@@ -444,139 +451,234 @@ void run_chunk(const uint8_t *data, Chunk &c)
     if (rc != Z_STREAM_END) return;
     c.syms.reserve(n / 3 + 16);
     if (!parse_symbols(raw.data(), produced, c.syms)) return;
-    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + c.start, (uInt)(c.end - c.start));
+    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)(c.end - c.start));
     c.ok = true;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// fork-join over [0, n): the calling thread takes part
+void parallel_for(int threads, size_t n, const std::function<void(size_t)> &fn)
+{
+    if (n == 0) return;
+    std::atomic<size_t> next{0};
+    auto body = [&] { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) return; fn(i); } };
+    std::vector<std::thread> pool;
+    const size_t extra = std::min<size_t>(threads > 1 ? (size_t)threads - 1 : 0, n - 1);
+    for (size_t t = 0; t < extra; ++t) pool.emplace_back(body);
+    body();
+    for (auto &t : pool) t.join();
 }
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------
+// the stream: text in, .gz bytes out, in batches of chunks
+// ---------------------------------------------------------------------------------------------
+struct Stream::Impl {
+    int threads = 1;
+    uint64_t CH = 1 << 20, TAIL = 1 << 16;
+    uint64_t batch_bytes = (uint64_t)96 << 20;
+    std::function<bool(const uint8_t *, size_t)> sink;
+    bool failed = false, finished = false, header_done = false;
+    std::vector<uint8_t> buf;        // text [base, base + buf.size())
+    uint64_t base = 0, total = 0;
+    uint64_t pos = 0;                // every byte before pos is covered by emitted symbols
+    uint64_t next_chunk = 0;         // first chunk (on the absolute grid) not yet stitched
+    bool have_carry = false; Chunk carry;   // parse of chunk next_chunk, made as the look-ahead of the previous batch
+    std::vector<Sym> pending;        // stitched symbols not yet in a block (< LIT_BUFSIZE - 1 between batches)
+    uint32_t crc = 0;
+    // output bit splicing
+    std::vector<uint8_t> out; uint8_t part = 0; int part_bits = 0;
+
+    void put_bits(const uint8_t *p, uint64_t nbits)
+    {
+        const size_t nbytes = (size_t)((nbits + 7) / 8);
+        if (part_bits == 0) {
+            const size_t whole = (size_t)(nbits / 8);
+            out.insert(out.end(), p, p + whole);
+            if (nbits & 7) { part = (uint8_t)(p[whole] & ((1u << (nbits & 7)) - 1)); part_bits = (int)(nbits & 7); }
+            return;
+        }
+        unsigned acc = part; int have = part_bits;           // `have` low bits of acc are valid, have < 8
+        uint64_t left = nbits;
+        for (size_t i = 0; i < nbytes; ++i) {
+            const int take = left >= 8 ? 8 : (int)left;
+            acc |= (unsigned)(p[i] & ((1u << take) - 1)) << have;
+            have += take; left -= (uint64_t)take;
+            if (have >= 8) { out.push_back((uint8_t)acc); acc >>= 8; have -= 8; }
+        }
+        part = (uint8_t)acc; part_bits = have;
+    }
+    bool flush_out(bool final)
+    {
+        if (final && part_bits) { out.push_back(part); part = 0; part_bits = 0; }
+        if (out.empty()) return true;
+        const bool ok = sink(out.data(), out.size());
+        out.clear();
+        return ok;
+    }
+
+    // stitches and emits everything that can be decided with the text seen so far (all of it when final)
+    bool run(bool final)
+    {
+        if (!header_done) {
+            static const uint8_t HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};      // deflate, no flags, mtime 0, xfl 0, OS unix
+            out.insert(out.end(), HDR, HDR + 10);
+            crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            header_done = true;
+        }
+        const uint64_t avail = base + buf.size();            // == total
+        const uint64_t MARGIN = 1024;                        // zlib's look-ahead near the artificial end of a chunk
+        // chunks that can be parsed now: tail inside the text (or final)
+        uint64_t c_hi = next_chunk;                           // exclusive
+        if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
+        else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
+        if (!final && c_hi < next_chunk + 2) return true;     // a stitch needs a chunk and its successor
+        const size_t nc = (size_t)(c_hi - next_chunk);
+        std::vector<Chunk> chunks(nc);
+        for (size_t k = 0; k < nc; ++k) {
+            const uint64_t i = next_chunk + k;
+            chunks[k].start = i * CH;
+            chunks[k].end = final ? std::min<uint64_t>(total, (i + 1) * CH) : (i + 1) * CH;
+            chunks[k].tail_end = final ? std::min<uint64_t>(total, chunks[k].end + TAIL) : chunks[k].end + TAIL;
+        }
+        size_t first_new = 0;
+        if (have_carry && nc) { chunks[0].syms.swap(carry.syms); chunks[0].crc = carry.crc; chunks[0].ok = carry.ok;
+                                chunks[0].tail_end = carry.tail_end; chunks[0].end = carry.end; first_new = 1; have_carry = false; }
+        const double tp0 = now_s();
+        parallel_for(threads, nc - first_new, [&](size_t k) { run_chunk(buf.data(), base, chunks[first_new + k]); });
+        const double tp1 = now_s();
+        for (auto &c : chunks) if (!c.ok) return false;
+        // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position
+        const size_t n_stitch = final ? nc : (nc ? nc - 1 : 0);   // the last parsed chunk waits for its successor unless final
+        std::vector<Sym> syms;
+        syms.swap(pending);
+        bool ended = false;
+        for (size_t k = 0; k < n_stitch && !ended; ++k) {
+            Chunk &a = chunks[k];
+            crc = (uint32_t)crc32_combine(crc, a.crc, (z_off_t)(a.end - a.start));
+            uint64_t stop;
+            const bool to_end = final && a.tail_end == total;
+            if (to_end) stop = total;
+            else {
+                const Chunk &b = chunks[k + 1];
+                std::vector<uint64_t> bends;
+                uint64_t q = b.start;
+                for (const Sym s : b.syms) {
+                    q += sym_len(s);
+                    if (q + MARGIN > a.tail_end) break;
+                    if (is_match(s)) bends.push_back(q);
+                }
+                uint64_t qa = a.start; size_t j = 0;
+                stop = 0;
+                for (const Sym s : a.syms) {
+                    qa += sym_len(s);
+                    if (qa + MARGIN > a.tail_end) break;
+                    if (!is_match(s) || qa <= b.start || qa <= pos) continue;
+                    while (j < bends.size() && bends[j] < qa) ++j;
+                    if (j < bends.size() && bends[j] == qa) { stop = qa; break; }
+                }
+                if (stop == 0) return false;                  // the two parses did not meet inside the tail
+            }
+            uint64_t qa = a.start;
+            for (const Sym s : a.syms) {
+                if (qa >= stop) break;
+                if (qa >= pos) syms.push_back(s);
+                else if (qa + sym_len(s) > pos) return false; // pos is not a symbol boundary of this parse
+                qa += sym_len(s);
+            }
+            if (qa != stop) return false;
+            pos = qa;
+            if (to_end) {
+                for (size_t r = k + 1; r < nc; ++r) crc = (uint32_t)crc32_combine(crc, chunks[r].crc, (z_off_t)(chunks[r].end - chunks[r].start));
+                ended = true;
+            }
+        }
+        if (final && pos != total) return false;
+        if (!final && nc) { carry = std::move(chunks[nc - 1]); have_carry = true; }
+        next_chunk += n_stitch;
+        if (final) next_chunk = c_hi;
+        // blocks: every LIT_BUFSIZE - 1 symbols; at the end the remainder (possibly empty) closes the stream
+        const double tp2 = now_s();
+        const size_t BS = LIT_BUFSIZE - 1;
+        const size_t full = syms.size() / BS;
+        const size_t nblocks = full + (final ? 1 : 0);
+        std::vector<std::vector<uint8_t>> bytes(nblocks);
+        std::vector<uint64_t> nbits(nblocks, 0);
+        std::vector<char> good(nblocks, 1);
+        parallel_for(threads, nblocks, [&](size_t b) {
+            BlockEncoder enc;
+            const size_t lo = b * BS, hi = b < full ? lo + BS : syms.size();
+            good[b] = enc.encode(syms.data() + lo, hi - lo, final && b + 1 == nblocks, &bytes[b], &nbits[b]) ? 1 : 0;
+        });
+        const double tp3 = now_s();
+        for (size_t b = 0; b < nblocks; ++b) {
+            if (!good[b]) return false;
+            put_bits(bytes[b].data(), nbits[b]);
+        }
+        const double tp4 = now_s();
+        if (!final) pending.assign(syms.begin() + (std::ptrdiff_t)(full * BS), syms.end());
+        if (final) {
+            if (part_bits) { out.push_back(part); part = 0; part_bits = 0; }
+            for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(crc >> (8 * k)));
+            for (int k = 0; k < 4; ++k) out.push_back((uint8_t)((uint32_t)total >> (8 * k)));   // ISIZE = length mod 2^32
+        }
+        if (!flush_out(final)) return false;
+        if (getenv("PGZ_DEBUG"))
+            fprintf(stderr, "[pgz] round: %zu chunks, %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, nblocks,
+                    tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
+        // forget the text nobody needs any more: everything before the dictionary of the next chunk to parse
+        if (!final) {
+            const uint64_t keep_from_chunk = next_chunk + (have_carry ? 1 : 0);
+            const uint64_t keep = keep_from_chunk * CH > 32768 ? keep_from_chunk * CH - 32768 : 0;
+            if (keep > base) { buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)(keep - base)); base = keep; }
+        }
+        return true;
+    }
+};
+
+Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p) : p_(new Impl)
+{
+    p_->threads = threads < 1 ? 1 : threads;
+    p_->sink = std::move(sink);
+    p_->CH = p.chunk < 65536 ? 65536 : p.chunk;
+    p_->TAIL = p.tail < 2048 ? 2048 : p.tail;
+    if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
+    if (p.batch) p_->batch_bytes = p.batch;
+}
+Stream::~Stream() { delete p_; }
+
+bool Stream::write(const void *data, size_t n)
+{
+    if (p_->failed || p_->finished) return false;
+    const uint8_t *q = (const uint8_t *)data;
+    const size_t limit = (size_t)(p_->batch_bytes + 2 * p_->CH + p_->TAIL);
+    while (n) {
+        const size_t have = p_->buf.size();
+        const size_t k = std::min(n, have < limit ? limit - have : (size_t)p_->CH);
+        p_->buf.insert(p_->buf.end(), q, q + k);
+        p_->total += k; q += k; n -= k;
+        if (p_->buf.size() >= limit && !p_->run(false)) { p_->failed = true; return false; }
+    }
+    return true;
+}
+
+bool Stream::finish()
+{
+    if (p_->failed || p_->finished) return false;
+    p_->finished = true;
+    if (!p_->run(true)) { p_->failed = true; return false; }
+    return true;
+}
+
 bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p)
 {
-    if (threads < 1) threads = 1;
-    const size_t CH = p.chunk < 65536 ? 65536 : p.chunk;
-    const size_t TAIL = p.tail < 2048 ? 2048 : p.tail;
-    const size_t MARGIN = 1024;                           // zlib's look-ahead near the artificial end of a chunk
-    if (CH > 0x40000000u || TAIL > CH / 2) return false;
-    const size_t n_chunks = n == 0 ? 1 : (n + CH - 1) / CH;
-    std::vector<Chunk> chunks(n_chunks);
-    for (size_t i = 0; i < n_chunks; ++i) {
-        chunks[i].start = i * CH;
-        chunks[i].end = std::min(n, (i + 1) * CH);
-        chunks[i].tail_end = std::min(n, chunks[i].end + TAIL);
-    }
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<size_t> next{0};
-    size_t consumed = 0;                                  // chunks the encoder has finished with (guarded by mu)
-    bool abort_all = false;
-    const size_t AHEAD = (size_t)threads * 4 + 2;
-    auto worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= n_chunks) return;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return abort_all || i < consumed + AHEAD; });
-                if (abort_all) return;
-            }
-            run_chunk(data, chunks[i]);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                chunks[i].done = true;
-            }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    const size_t n_workers = std::min<size_t>((size_t)threads, n_chunks);
-    for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-
-    std::vector<uint8_t> body;
-    body.reserve(n / 4 + 1024);
-    static const uint8_t HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};      // gz header: deflate, no flags, mtime 0, xfl 0, OS unix
-    body.insert(body.end(), HDR, HDR + 10);
-    BlockWriter bw(body);
-    bool ok = true;
-    size_t pos = 0;                                       // every byte before pos is encoded
-    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-    auto wait_for = [&](size_t i) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return chunks[i].done; });
-    };
-    for (size_t i = 0; i < n_chunks && ok; ++i) {
-        wait_for(i);
-        Chunk &a = chunks[i];
-        if (!a.ok) { ok = false; break; }
-        crc = (uint32_t)crc32_combine(crc, a.crc, (z_off_t)(a.end - a.start));
-        // where this chunk's symbols are taken up to
-        size_t stop = n;                                  // exclusive; n = "to the very end"
-        const bool to_end = a.tail_end == n;
-        if (!to_end) {
-            wait_for(i + 1);
-            Chunk &b = chunks[i + 1];
-            if (!b.ok) { ok = false; break; }
-            // match ends of b inside a's tail
-            std::vector<size_t> bends;
-            size_t q = b.start;
-            for (const Sym s : b.syms) {
-                q += sym_len(s);
-                if (q + MARGIN > a.tail_end) break;
-                if (is_match(s)) bends.push_back(q);
-            }
-            // first match end of a (beyond pos and b.start) that b shares
-            size_t qa = a.start, k = 0;
-            stop = 0;
-            for (const Sym s : a.syms) {
-                qa += sym_len(s);
-                if (qa + MARGIN > a.tail_end) break;
-                if (!is_match(s) || qa <= b.start || qa <= pos) continue;
-                while (k < bends.size() && bends[k] < qa) ++k;
-                if (k < bends.size() && bends[k] == qa) { stop = qa; break; }
-            }
-            if (stop == 0) { ok = false; break; }          // the two parses did not meet inside the tail
-        }
-        // feed a's symbols covering [pos, stop)
-        size_t qa = a.start;
-        for (const Sym s : a.syms) {
-            if (qa >= stop) break;
-            if (qa >= pos) {
-                if (!bw.add(s)) { ok = false; break; }
-            } else if (qa + sym_len(s) > pos) { ok = false; break; }         // pos is not a symbol boundary of this parse
-            qa += sym_len(s);
-        }
-        if (!ok) break;
-        if (stop == n ? qa != n : qa != stop) { ok = false; break; }
-        pos = qa;
-        a.syms.clear(); a.syms.shrink_to_fit();
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            consumed = i + 1;
-        }
-        cv.notify_all();
-        if (to_end) {
-            // the rest of the text was inside this chunk's tail: later chunks only add their checksums
-            for (size_t j = i + 1; j < n_chunks; ++j) {
-                wait_for(j);
-                if (!chunks[j].ok) { ok = false; break; }
-                crc = (uint32_t)crc32_combine(crc, chunks[j].crc, (z_off_t)(chunks[j].end - chunks[j].start));
-                std::lock_guard<std::mutex> lk(mu);
-                consumed = j + 1;
-            }
-            cv.notify_all();
-            break;
-        }
-    }
-    if (ok) ok = pos == n && bw.finish();
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        abort_all = true; consumed = n_chunks + AHEAD;
-    }
-    cv.notify_all();
-    for (auto &t : pool) t.join();
-    if (!ok) return false;
-    for (int k = 0; k < 4; ++k) body.push_back((uint8_t)(crc >> (8 * k)));
-    for (int k = 0; k < 4; ++k) body.push_back((uint8_t)((uint32_t)n >> (8 * k)));   // ISIZE = length mod 2^32
-    out.insert(out.end(), body.begin(), body.end());
+    std::vector<uint8_t> img;
+    img.reserve(n / 4 + 1024);
+    Stream st(threads, [&](const uint8_t *b, size_t k) { img.insert(img.end(), b, b + k); return true; }, p);
+    if (!st.write(data, n) || !st.finish()) return false;
+    out.insert(out.end(), img.begin(), img.end());
     return true;
 }
 

@@ -20,16 +20,38 @@
 #define PD_PGZIP_H_
 #include <stddef.h>
 #include <stdint.h>
+#include <functional>
 #include <vector>
 
 namespace pgz {
+
+struct Params {
+    size_t chunk = (size_t)1 << 20;      // text per zlib call
+    size_t tail = (size_t)1 << 16;       // overlap in which neighbouring parses must meet
+    size_t batch = 0;                    // text buffered between rounds (0 = 96 MiB)
+};
+
+// Streaming form: text in, the .gz file's bytes out through `sink`, in rounds of `batch` bytes (bounded
+// memory: a 3 Gb per-site file is 60 GB of text).  write()/finish() return false when the parallel form
+// stops applying (or the sink fails); the bytes already handed to the sink are then a prefix of zlib's
+// stream and the caller must start the file over with zlib itself.
+class Stream {
+public:
+    Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p = Params());
+    ~Stream();
+    bool write(const void *data, size_t n);
+    bool finish();
+private:
+    struct Impl;
+    Impl *p_;
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+};
 
 // Appends the complete .gz file image of `data` to `out`.  Returns false (out untouched) when the
 // parallel form does not apply; the result, when produced, equals zlib's.
 bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out);
 
-// tuning / tests
-struct Params { size_t chunk = (size_t)1 << 20; size_t tail = (size_t)1 << 14; };
 bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p);
 
 } // namespace pgz

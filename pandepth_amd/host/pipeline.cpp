@@ -28,6 +28,7 @@
 #include "options.h"
 #include "regions.h"
 #include "report.h"
+#include "pgzip.h"
 
 namespace pdh {
 
@@ -496,13 +497,59 @@ void format_sites(const std::string &nm, uint32_t b, const uint32_t *d, size_t n
     out->resize((size_t)(p - p0));
 }
 
-// <prefix>.SiteDepth.gz (PD:4264-4284).  Up to PANDEPTH_SITE_PARALLEL_MIN bytes of text (default
-// 256 MiB) the file is ONE zlib stream, byte-identical to the reference's.  Larger outputs (a 3 Gb
-// genome is ~60 GB of text, ten minutes of single-threaded formatting + deflate in the reference)
-// are written as concatenated gzip members produced by the reader threads: same decompressed
-// bytes, different .gz bytes.
+// <prefix>.SiteDepth.gz (PD:4264-4284), byte-identical to the reference's single zlib stream at any size, on all
+// threads: 4 M-cell blocks are read back, formatted in parallel slices and fed, in order, to pgz::Stream
+// (host/pgzip.h), which deflates them with zlib's own parse spread over the threads and bounded memory.
+// Returns 1 done, 0 the parallel form declined (nothing usable written), -1 error.
+int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
+{
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { std::cerr << "open OUT File error: " << path << std::endl; return -1; }
+    bool io_ok = true;
+    int rc = 1;
+    {
+        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; });
+        const size_t CH = (size_t)4 << 20;
+        std::vector<uint32_t> d(CH);
+        const int nt = threads < 1 ? 1 : threads;
+        std::vector<std::string> parts((size_t)nt);
+        for (size_t t = 0; t < hdr.names.size() && rc == 1; ++t) {
+            if (!rm.has((int32_t)t)) continue;
+            const uint32_t len = hdr.lens[t];
+            for (uint32_t b = 0; b < len && rc == 1; b += (uint32_t)CH) {
+                const size_t n = std::min<size_t>(CH, len - b);
+                if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) { rc = -1; break; }
+                const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+                std::vector<std::thread> th;
+                for (int k = 1; k < nt; ++k) {
+                    const size_t lo = std::min(n, per * (size_t)k), hi = std::min(n, lo + per);
+                    th.emplace_back([&, k, lo, hi] { format_sites(hdr.names[t], b + (uint32_t)lo, d.data() + lo, hi - lo, &parts[(size_t)k]); });
+                }
+                format_sites(hdr.names[t], b, d.data(), std::min(n, per), &parts[0]);
+                for (auto &x : th) x.join();
+                for (int k = 0; k < nt && rc == 1; ++k)
+                    if (!parts[(size_t)k].empty() && !st.write(parts[(size_t)k].data(), parts[(size_t)k].size())) rc = io_ok ? 0 : -1;
+            }
+        }
+        if (rc == 1 && !st.finish()) rc = io_ok ? 0 : -1;
+    }
+    if (fclose(fp) != 0 && rc == 1) rc = -1;
+    return rc;
+}
+
+// <prefix>.SiteDepth.gz: the byte-identical parallel stream above; if pgz declines (text it does not
+// re-state, which depth tables never produced in testing) the file is started over — as ONE zlib stream
+// below PANDEPTH_SITE_PARALLEL_MIN bytes of text (default 256 MiB), as concatenated gzip members produced by
+// the reader threads above it (same decompressed bytes, different .gz bytes).  PANDEPTH_SITE_IDENTICAL=0
+// skips the first attempt.
 bool write_site_depth(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
 {
+    const char *ident = getenv("PANDEPTH_SITE_IDENTICAL");
+    if (threads > 1 && !(ident && ident[0] == '0')) {
+        const int r = write_site_depth_identical(path, hdr, rm, eng, threads);
+        if (r == 1) return true;
+        if (r < 0) return false;
+    }
     uint64_t estimate = 0;
     for (size_t t = 0; t < hdr.names.size(); ++t)
         if (rm.has((int32_t)t)) estimate += (uint64_t)hdr.lens[t] * (hdr.names[t].size() + 12);

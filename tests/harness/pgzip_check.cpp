@@ -1,5 +1,5 @@
 // tests/harness/pgzip_check.cpp — TEST INFRASTRUCTURE: pgz::gzip_identical against the system zlib's gzopen/gzwrite/gzclose
-// on a file's bytes.  usage: pgzip_check <file> [threads chunk tail]  -> prints "identical" / where the streams diverge.
+// on a file's bytes.  usage: pgzip_check <file> [threads chunk tail batch]  -> prints "identical" / where the streams diverge.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,12 +26,13 @@ static std::vector<uint8_t> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: pgzip_check <file> [threads chunk tail]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: pgzip_check <file> [threads chunk tail batch]\n"); return 2; }
     const std::vector<uint8_t> data = slurp(argv[1]);
     const int threads = argc > 2 ? atoi(argv[2]) : 4;
     pgz::Params p;
     if (argc > 3) p.chunk = (size_t)atoll(argv[3]);
     if (argc > 4) p.tail = (size_t)atoll(argv[4]);
+    if (argc > 5) p.batch = (size_t)atoll(argv[5]);
     // the reference stream: the way GzWriter (and the reference's gzstream) writes
     char tmp[] = "/tmp/pgzcheckXXXXXX";
     const int fd = mkstemp(tmp);

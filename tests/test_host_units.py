@@ -99,10 +99,11 @@ def test_region_quirks(cli, tmp_path):
 
 
 def test_parallel_site_writer_same_text_as_single_stream(cli, tmp_path, golden_dir):
-    """Above a size threshold the per-site file is written as concatenated gzip members by several
-    threads: different .gz bytes, identical decompressed bytes (and still one valid gzip file)."""
+    """The per-site file is the reference's single zlib stream, byte for byte, also when it is produced on several
+    threads (pgz::Stream).  The fallback for text pgz declines — concatenated gzip members above a size threshold — has
+    different .gz bytes, identical decompressed bytes (and is still one valid gzip file)."""
     d = os.path.join(golden_dir, "f3")
-    for name, env in (("serial", {}), ("par", {"PANDEPTH_SITE_PARALLEL_MIN": "1"})):
+    for name, env in (("serial", {}), ("par", {"PANDEPTH_SITE_IDENTICAL": "0", "PANDEPTH_SITE_PARALLEL_MIN": "1"})):
         p = subprocess.run([cli, "-i", "tiny.bam", "-w", "100", "-a", "-t", "4", "-o", str(tmp_path / name)], cwd=d,
                            env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-300:]
@@ -121,7 +122,7 @@ def test_parallel_site_writer_backpressure(cli, tmp_path):
     sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:30000000\nr\t0\tc\t1000\t60\t100M\t*\t0\t0\t*\t*\n"
     (tmp_path / "big.sam").write_text(sam)
     p = subprocess.run([cli, "-i", "big.sam", "-a", "-t", "2", "-o", "o"], cwd=tmp_path, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=300)
+                       stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, PANDEPTH_SITE_IDENTICAL="0"))
     assert p.returncode == 0, p.stderr.decode()[-300:]
     import zlib
     d = zlib.decompressobj(31)
@@ -136,6 +137,25 @@ def test_parallel_site_writer_backpressure(cli, tmp_path):
         if raw:
             d = zlib.decompressobj(31); members += 1
     assert n_lines == 30000000 and members >= 7 and tail.endswith(b"c\t29999999\t0\n")
+
+
+def test_site_writer_identical_stream_at_size(cli, tmp_path):
+    """30 M per-site lines (~400 MB of text, several pgz rounds with PANDEPTH-independent defaults): the file written on 4
+    threads equals, byte for byte, the single zlib stream of the same text"""
+    import zlib
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:30000000\n" + "".join(
+        "r%d\t0\tc\t%d\t60\t100M\t*\t0\t0\t*\t*\n" % (i, 1000 + 37 * i) for i in range(20000))
+    (tmp_path / "big.sam").write_text(sam)
+    p = subprocess.run([cli, "-i", "big.sam", "-a", "-t", "4", "-o", "o"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    raw = (tmp_path / "o.SiteDepth.gz").read_bytes()
+    text = gzip.decompress(raw)
+    assert text.count(b"\n") == 30000000 and text.endswith(b"c\t29999999\t0\n")
+    co = zlib.compressobj(-1, zlib.DEFLATED, 31, 8, zlib.Z_DEFAULT_STRATEGY)
+    ref = co.compress(text) + co.flush()
+    # zlib.compressobj writes OS = 3 and mtime 0 like gzopen: the whole file must match
+    assert raw == ref
 
 
 def test_csi_index_is_used_like_bai(cli, tmp_path, golden_dir):

@@ -83,9 +83,10 @@ def main():
                         h.update(blk)
                     pz.wait()
                     hs.append(h.hexdigest())
-                print("SiteDepth.gz sizes %d / %d bytes, decompressed content identical: %s" % (
+                gz_same = subprocess.run(["cmp", "-s", os.path.join(td, "mine.SiteDepth.gz"), os.path.join(td, "ref.SiteDepth.gz")]).returncode == 0
+                print("SiteDepth.gz sizes %d / %d bytes, decompressed content identical: %s, .gz bytes identical: %s" % (
                     os.path.getsize(os.path.join(td, "mine.SiteDepth.gz")), os.path.getsize(os.path.join(td, "ref.SiteDepth.gz")),
-                    hs[0] == hs[1]), flush=True)
+                    hs[0] == hs[1], gz_same), flush=True)
 
 
 if __name__ == "__main__":
