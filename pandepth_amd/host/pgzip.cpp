@@ -493,21 +493,39 @@ struct Stream::Impl {
 
     void put_bits(const uint8_t *p, uint64_t nbits)
     {
-        const size_t nbytes = (size_t)((nbits + 7) / 8);
         if (part_bits == 0) {
             const size_t whole = (size_t)(nbits / 8);
             out.insert(out.end(), p, p + whole);
             if (nbits & 7) { part = (uint8_t)(p[whole] & ((1u << (nbits & 7)) - 1)); part_bits = (int)(nbits & 7); }
             return;
         }
-        unsigned acc = part; int have = part_bits;           // `have` low bits of acc are valid, have < 8
-        uint64_t left = nbits;
-        for (size_t i = 0; i < nbytes; ++i) {
-            const int take = left >= 8 ? 8 : (int)left;
-            acc |= (unsigned)(p[i] & ((1u << take) - 1)) << have;
-            have += take; left -= (uint64_t)take;
-            if (have >= 8) { out.push_back((uint8_t)acc); acc >>= 8; have -= 8; }
+        // unaligned: shift whole 64-bit words
+        const int sh = part_bits;                            // 1..7
+        const size_t whole = (size_t)(nbits / 8), old = out.size();
+        const unsigned tailbits = (unsigned)(nbits & 7);
+        out.resize(old + whole + 9);
+        uint8_t *o = out.data() + old;
+        uint64_t carry = part;                               // low `sh` bits valid
+        size_t i = 0;
+        for (; i + 8 <= whole; i += 8) {
+            uint64_t w;
+            memcpy(&w, p + i, 8);
+            const uint64_t v = carry | (w << sh);
+            memcpy(o + i, &v, 8);
+            carry = w >> (64 - sh);
         }
+        unsigned acc = (unsigned)carry; int have = sh;
+        size_t produced = i;
+        for (; i < whole; ++i) {
+            acc |= (unsigned)p[i] << have;
+            o[produced++] = (uint8_t)acc; acc >>= 8;
+        }
+        if (tailbits) {
+            acc |= (unsigned)(p[whole] & ((1u << tailbits) - 1)) << have;
+            have += (int)tailbits;
+            if (have >= 8) { o[produced++] = (uint8_t)acc; acc >>= 8; have -= 8; }
+        }
+        out.resize(old + produced);
         part = (uint8_t)acc; part_bits = have;
     }
     bool flush_out(bool final)
@@ -553,16 +571,24 @@ struct Stream::Impl {
         // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position
         const size_t n_stitch = final ? nc : (nc ? nc - 1 : 0);   // the last parsed chunk waits for its successor unless final
         std::vector<Sym> syms;
-        syms.swap(pending);
+        {
+            size_t cap = pending.size();
+            for (size_t k = 0; k < n_stitch; ++k) cap += chunks[k].syms.size();
+            syms.reserve(cap);
+            syms.insert(syms.end(), pending.begin(), pending.end());
+            pending.clear();
+        }
         bool ended = false;
         for (size_t k = 0; k < n_stitch && !ended; ++k) {
             Chunk &a = chunks[k];
             crc = (uint32_t)crc32_combine(crc, a.crc, (z_off_t)(a.end - a.start));
             uint64_t stop;
+            size_t i_stop = a.syms.size();                    // index of the first symbol NOT taken from a
             const bool to_end = final && a.tail_end == total;
             if (to_end) stop = total;
             else {
                 const Chunk &b = chunks[k + 1];
+                // match ends of b inside a's tail (b's parse starts at b.start: only its first symbols are walked)
                 std::vector<uint64_t> bends;
                 uint64_t q = b.start;
                 for (const Sym s : b.syms) {
@@ -570,26 +596,30 @@ struct Stream::Impl {
                     if (q + MARGIN > a.tail_end) break;
                     if (is_match(s)) bends.push_back(q);
                 }
-                uint64_t qa = a.start; size_t j = 0;
+                // a's symbols in the tail, walked BACKWARDS from its end (a's parse covers [start, tail_end) exactly):
+                // the earliest match end beyond b.start (and pos) that b shares
+                uint64_t qe = a.tail_end;                     // end position of symbol i - 1 ... start of symbol i
                 stop = 0;
-                for (const Sym s : a.syms) {
-                    qa += sym_len(s);
-                    if (qa + MARGIN > a.tail_end) break;
-                    if (!is_match(s) || qa <= b.start || qa <= pos) continue;
-                    while (j < bends.size() && bends[j] < qa) ++j;
-                    if (j < bends.size() && bends[j] == qa) { stop = qa; break; }
+                size_t j = bends.size();
+                for (size_t i = a.syms.size(); i-- > 0;) {
+                    // symbol i covers [qe - len, qe)
+                    const Sym sy = a.syms[i];
+                    if (qe <= b.start || qe <= pos) break;
+                    if (is_match(sy) && qe + MARGIN <= a.tail_end) {
+                        while (j > 0 && bends[j - 1] > qe) --j;
+                        if (j > 0 && bends[j - 1] == qe) { stop = qe; i_stop = i + 1; }   // keep going: an earlier one is better
+                    }
+                    qe -= sym_len(sy);
                 }
                 if (stop == 0) return false;                  // the two parses did not meet inside the tail
             }
+            // first symbol of a at pos: walked from the front (pos lies within a tail's length of a.start)
             uint64_t qa = a.start;
-            for (const Sym s : a.syms) {
-                if (qa >= stop) break;
-                if (qa >= pos) syms.push_back(s);
-                else if (qa + sym_len(s) > pos) return false; // pos is not a symbol boundary of this parse
-                qa += sym_len(s);
-            }
-            if (qa != stop) return false;
-            pos = qa;
+            size_t i_first = 0;
+            while (i_first < i_stop && qa < pos) { qa += sym_len(a.syms[i_first]); ++i_first; }
+            if (qa != pos) return false;                       // pos is not a symbol boundary of this parse
+            syms.insert(syms.end(), a.syms.begin() + (std::ptrdiff_t)i_first, a.syms.begin() + (std::ptrdiff_t)i_stop);
+            pos = stop;
             if (to_end) {
                 for (size_t r = k + 1; r < nc; ++r) crc = (uint32_t)crc32_combine(crc, chunks[r].crc, (z_off_t)(chunks[r].end - chunks[r].start));
                 ended = true;
