@@ -22,6 +22,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
 #include <thread>
 #include "bam.h"
 #include "engine_api.h"
@@ -509,28 +511,58 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
     int rc = 1;
     {
         pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; });
+        // producer: read-back + formatting of the next blocks (a quarter of the threads) while the consumer deflates
         const size_t CH = (size_t)4 << 20;
-        std::vector<uint32_t> d(CH);
-        const int nt = threads < 1 ? 1 : threads;
-        std::vector<std::string> parts((size_t)nt);
-        for (size_t t = 0; t < hdr.names.size() && rc == 1; ++t) {
-            if (!rm.has((int32_t)t)) continue;
-            const uint32_t len = hdr.lens[t];
-            for (uint32_t b = 0; b < len && rc == 1; b += (uint32_t)CH) {
-                const size_t n = std::min<size_t>(CH, len - b);
-                if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) { rc = -1; break; }
-                const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
-                std::vector<std::thread> th;
-                for (int k = 1; k < nt; ++k) {
-                    const size_t lo = std::min(n, per * (size_t)k), hi = std::min(n, lo + per);
-                    th.emplace_back([&, k, lo, hi] { format_sites(hdr.names[t], b + (uint32_t)lo, d.data() + lo, hi - lo, &parts[(size_t)k]); });
+        const int nt = std::max(1, threads / 4);
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::vector<std::string>> q;              // each entry: one block's slices, in order
+        bool done = false, stop = false, prod_ok = true;
+        std::thread producer([&] {
+            std::vector<uint32_t> d(CH);
+            for (size_t t = 0; t < hdr.names.size(); ++t) {
+                if (!rm.has((int32_t)t)) continue;
+                const uint32_t len = hdr.lens[t];
+                for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
+                    const size_t n = std::min<size_t>(CH, len - b);
+                    if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) { prod_ok = false; goto out; }
+                    {
+                        std::vector<std::string> parts((size_t)nt);
+                        const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+                        std::vector<std::thread> th;
+                        for (int k = 1; k < nt; ++k) {
+                            const size_t lo = std::min(n, per * (size_t)k), hi = std::min(n, lo + per);
+                            th.emplace_back([&, k, lo, hi] { format_sites(hdr.names[t], b + (uint32_t)lo, d.data() + lo, hi - lo, &parts[(size_t)k]); });
+                        }
+                        format_sites(hdr.names[t], b, d.data(), std::min(n, per), &parts[0]);
+                        for (auto &x : th) x.join();
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || q.size() < 2; });
+                        if (stop) goto out;
+                        q.push_back(std::move(parts));
+                    }
+                    cv.notify_all();
                 }
-                format_sites(hdr.names[t], b, d.data(), std::min(n, per), &parts[0]);
-                for (auto &x : th) x.join();
-                for (int k = 0; k < nt && rc == 1; ++k)
-                    if (!parts[(size_t)k].empty() && !st.write(parts[(size_t)k].data(), parts[(size_t)k].size())) rc = io_ok ? 0 : -1;
             }
+        out:
+            { std::lock_guard<std::mutex> lk(mu); done = true; }
+            cv.notify_all();
+        });
+        for (;;) {
+            std::vector<std::string> parts;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done || !q.empty(); });
+                if (q.empty()) break;
+                parts = std::move(q.front()); q.pop_front();
+            }
+            cv.notify_all();
+            for (auto &p : parts)
+                if (rc == 1 && !p.empty() && !st.write(p.data(), p.size())) rc = io_ok ? 0 : -1;
+            if (rc != 1) { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); break; }
         }
+        producer.join();
+        if (!prod_ok) rc = -1;
         if (rc == 1 && !st.finish()) rc = io_ok ? 0 : -1;
     }
     if (fclose(fp) != 0 && rc == 1) rc = -1;

@@ -20,7 +20,21 @@ bam = os.path.join(td, "f.bam")
 synth.write_bam(bam, names, lens, rec, procs=16, payload=False)
 subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
 cli, ref = os.path.join(ROOT, "pandepth_amd", "pandepth"), os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
-for tag, extra, suffix in (("chr", [], "chr.stat.gz"), ("w1000", ["-w", "1000"], "win.stat.gz"), ("chr_s", ["-s"], "chr.stat.gz")):
+# configs[2]'s annotation shape: 33 688 transcripts / 175 274 CDS rows, exon length log-normal
+import numpy as np  # noqa: E402
+rng = np.random.default_rng(3)
+per_tx = np.full(33688, 175274 // 33688); per_tx[:175274 - per_tx.sum()] += 1
+chrom = rng.choice(12, 33688, p=lens[:12] / lens[:12].sum())
+gff = os.path.join(td, "c3.gff")
+with open(gff, "w") as fh:
+    for t in range(33688):
+        c = int(chrom[t]); s0 = int(rng.integers(1, lens[c] - 200000))
+        for e in range(int(per_tx[t])):
+            el = int(min(5000, max(30, rng.lognormal(np.log(150), 0.7))))
+            fh.write("%s\tsynth\tCDS\t%d\t%d\t.\t+\t0\tID=cds%d.%d;Parent=tx%05d\n" % (names[c], s0, s0 + el - 1, t, e, t))
+            s0 += el + int(rng.integers(80, 3000))
+for tag, extra, suffix in (("chr", [], "chr.stat.gz"), ("w1000", ["-w", "1000"], "win.stat.gz"), ("chr_s", ["-s"], "chr.stat.gz"),
+                           ("gff", ["-g", gff], "gene.stat.gz")):
     t0 = time.perf_counter()
     subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "m_" + tag), "-t", "16"] + extra, check=True, stdout=subprocess.DEVNULL, timeout=280)
     t1 = time.perf_counter()
