@@ -451,6 +451,34 @@ def run(args, cwd="."):
     cover, tot = stat_regions(depth, off, np.array(reg, dtype=np.int32).reshape(-1, 3), o["d"])
     for k, (t, gid) in enumerate(owner):
         genes[t][gid].cover += int(cover[k]); genes[t][gid].depth += int(tot[k])
+    if not wrap:
+        # PD:676-786 + PD:295-309: the indexed uint32 path walks the merged spans of a contig in windows
+        # [MeMStart, MeMEnd] (10 Mb of spans each; MeMEnd = last span end + 1, clipped to the contig length) and gives a
+        # window's cells only to the genes with GeneStart < MeMEnd and GeneEnd >= MeMStart ("<=" when the window is a single
+        # position).  A gene whose span starts on the contig's last base is selected by no window unless its window
+        # starts there too: it keeps cover 0 / depth 0.
+        for t in sorted(genes):
+            spans, clen = merged[t], lens[t]
+            wins = []
+            ms = max(1, spans[0][0]); me = min(ms + 10000000 - 1, clen)
+            for k, (s0, e0) in enumerate(spans):
+                end = min(e0 + 1, clen)
+                last = k + 1 == len(spans)
+                if end >= me or last:
+                    me = end
+                    wins.append((ms, me))
+                    if not last:
+                        ms = spans[k + 1][0]
+                        if ms - 150 > me:
+                            ms -= 150
+                    me = min(ms + 10000000, clen)
+            for g in genes[t].values():
+                sel = False
+                for (a, b) in wins:
+                    out_ = (g.start >= b or g.end < a) if b != a else (g.start > b or g.end < a)
+                    sel = sel or not out_
+                if not sel:
+                    g.cover = 0; g.depth = 0
 
     if mode == 0:
         txt = "#Chr\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"

@@ -841,6 +841,49 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         for (auto &kv : rm.genes)
             for (auto &g : kv.second)
                 for (size_t c = 0; c < g.second.cds.size(); ++c, ++i) { g.second.cover += cov[i]; g.second.depth += sum[i]; }
+        // The indexed uint32 path of the reference (ProDealChrBambai, PD:676-786) walks each contig's merged gene
+        // spans in windows [MeMStart, MeMEnd] and gives a window's statistics to the genes with
+        // GeneStart < MeMEnd && GeneEnd >= MeMStart (PD:299-303; <= when the window is a single position, PD:305-308).
+        // A window ends at (last span end + 1) clipped to the contig length, so a gene that STARTS on the last base of
+        // its contig is selected by no window — it keeps cover 0 / depth 0 — unless its window also starts there.
+        if (!wrap18) {
+            for (auto &kv : rm.genes) {
+                const int64_t clen = (int64_t)hdr.lens[(size_t)kv.first];
+                auto mit = rm.merged.find(kv.first);
+                if (mit == rm.merged.end() || mit->second.empty()) continue;
+                const auto &spans = mit->second;
+                bool any_at_end = false;
+                for (auto &g : kv.second) if ((int64_t)g.second.start >= clen) { any_at_end = true; break; }
+                if (!any_at_end) continue;                              // the only genes this can concern
+                std::vector<std::pair<int64_t, int64_t>> wins;          // the reference's windows on this contig
+                int64_t ms = spans[0].first < 1 ? 1 : spans[0].first;
+                int64_t me = std::min<int64_t>(ms + 10000000 - 1, clen);
+                for (size_t k = 0; k < spans.size(); ++k) {
+                    const int64_t end = std::min<int64_t>((int64_t)spans[k].second + 1, clen);
+                    const bool last = k + 1 == spans.size();
+                    if (end >= me || last) {
+                        me = end;
+                        wins.emplace_back(ms, me);
+                        if (!last) {
+                            ms = spans[k + 1].first;
+                            if (ms - 150 > me) ms -= 150;
+                        }
+                        me = std::min<int64_t>(ms + 10000000, clen);
+                    }
+                }
+                for (auto &g : kv.second) {
+                    Gene &x = g.second;
+                    if ((int64_t)x.start < clen) continue;
+                    bool selected = false;
+                    for (auto &w : wins) {
+                        const bool out = w.second != w.first ? ((int64_t)x.start >= w.second || (int64_t)x.end < w.first)
+                                                             : ((int64_t)x.start > w.second || (int64_t)x.end < w.first);
+                        if (!out) { selected = true; break; }
+                    }
+                    if (!selected) { x.cover = 0; x.depth = 0; }
+                }
+            }
+        }
     }
     std::cout << "INFO: Input data read done" << std::endl;
     tm.mark("scan + statistics");

@@ -351,6 +351,59 @@ F3_CASES = [
     ("w100_a", ["-i", "tiny.bam", "-w", "100", "-a"]),
 ]
 
+# ---------------------------------------------------------------------------------------------
+# F4: last-base targets.  The reference's indexed path (ProDealChrBambai, PD:676-786) hands a window's statistics
+# to the genes with GeneStart < MeMEnd (PD:299-303), and MeMEnd is clipped to the contig length: a target that STARTS
+# on the last base of its contig gets no statistics there (found by tools/fuzz_vs_ref.py), while the SiteInfo paths
+# (-a, no index, list) count it.
+# ---------------------------------------------------------------------------------------------
+F4_CONTIGS = [("k2", 2), ("k201", 201), ("k37", 37), ("k500", 500)]
+
+
+def build_f4(d):
+    os.makedirs(d, exist_ok=True)
+    rng = random.Random(404)
+    recs = []
+    for i in range(900):
+        ci = rng.randrange(len(F4_CONTIGS))
+        ln = F4_CONTIGS[ci][1]
+        span = rng.randint(1, min(ln, 60))
+        pos1 = rng.randint(1, ln - span + 1)
+        if rng.random() < 0.3:
+            pos1 = ln - span + 1                        # pile reads onto the contig ends
+        recs.append((ci, pos1, rng.choice([0, 16, 0, 16, 1024]), rng.choice([0, 30, 60]), "%dM" % span))
+    srt = sorted(range(len(recs)), key=lambda k: (recs[k][0], recs[k][1], k))
+    sam = sam_header(F4_CONTIGS, True)
+    for k in srt:
+        ci, pos1, flag, mapq, cig = recs[k]
+        sam += sam_line(k, flag, F4_CONTIGS[ci][0], pos1, mapq, cig)
+    write(os.path.join(d, "e.sam"), sam)
+    to_bam(os.path.join(d, "e.sam"), os.path.join(d, "e.bam"), True)
+    shutil.copy(os.path.join(d, "e.bam"), os.path.join(d, "e_noidx.bam"))
+    write(os.path.join(d, "e.list"), "e.bam\ne_noidx.bam\n")
+    write(os.path.join(d, "e.bed"), "\n".join([
+        "k2\t2\t2\tlastbase", "k2\t1\t2\tboth", "k201\t201\t201\tend201", "k201\t150\t201\ttail", "k201\t1\t10\thead",
+        "k37\t37\t37\talone",                       # the only target of its contig: its window starts there, it is counted
+        "k500\t10\t40\ta", "k500\t500\t500\tz", "k500\t499\t500\ty"]) + "\n")
+    write(os.path.join(d, "e.gff"), "\n".join([
+        "k2\ts\tCDS\t2\t2\t.\t+\t0\tID=a;Parent=g_last", "k201\ts\tCDS\t201\t201\t.\t+\t0\tID=b;Parent=g_end",
+        "k201\ts\tCDS\t20\t80\t.\t+\t0\tID=c;Parent=g_mid", "k500\ts\tCDS\t500\t500\t.\t-\t0\tID=d;Parent=g_z",
+        "k500\ts\tCDS\t100\t200\t.\t-\t0\tID=e;Parent=g_z", "k37\ts\tCDS\t37\t37\t.\t+\t0\tID=f;Parent=g_alone"]) + "\n")
+
+
+F4_CASES = [
+    ("bed4", ["-i", "e.bam", "-b", "e.bed"]),
+    ("bed4_a", ["-i", "e.bam", "-b", "e.bed", "-a"]),
+    ("bed4_noidx", ["-i", "e_noidx.bam", "-b", "e.bed"]),
+    ("bed4_s", ["-i", "e.bam", "-b", "e.bed", "-s"]),
+    ("bed4_list", ["-i", "e.list", "-b", "e.bed"]),
+    ("gff", ["-i", "e.bam", "-g", "e.gff"]),
+    ("gff_sam", ["-i", "e.sam", "-g", "e.gff"]),
+    ("chr", ["-i", "e.bam"]),
+    ("w10", ["-i", "e.bam", "-w", "10"]),
+    ("w200", ["-i", "e.bam", "-w", "200"]),
+]
+
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
 
 
@@ -386,7 +439,7 @@ def main():
         sys.exit("build the reference oracle first: make -C oracle ref")
     manifest = []
     for fx, build, cases in (("f1", build_f1, F1_CASES), ("f2", build_f2, F2_CASES),
-                             ("f3", build_f3, F3_CASES)):
+                             ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES)):
         d = os.path.join(HERE, fx)
         build(d)
         run_cases(fx, d, cases, manifest)

@@ -82,7 +82,16 @@ static int o_scan(pd_ctx *c, unsigned wrap)
 static int o_reduce_intervals(pd_ctx *c, const pd_region *r, size_t n, uint32_t md, int32_t *cov, uint64_t *sum)
 {
     if (!c->scanned) { c->err = "scan first"; return -4; }
-    pdo_stat_regions(c->depth.data(), c->off.data(), (int64_t)n, (const int32_t *)r, md, cov, sum);
+    // like pd_reduce_intervals: cells clipped to the contig (the product clips runs to [0, len], so the cells a region
+    // reaches beyond the contig end hold zero; the oracle's arrays are contiguous, the next contig starts there)
+    std::vector<pd_region> rr(r, r + n);
+    for (auto &x : rr) {
+        const int64_t len = (int64_t)c->len[(size_t)x.tid];
+        if (x.second > len) x.second = (int32_t)len;
+        if (x.first < 1) x.first = 1;
+        if (x.first > x.second + 1) x.first = x.second + 1;
+    }
+    pdo_stat_regions(c->depth.data(), c->off.data(), (int64_t)n, (const int32_t *)rr.data(), md, cov, sum);
     return 0;
 }
 static int o_layout(const pd_ctx *c, uint32_t w, uint64_t *wo)

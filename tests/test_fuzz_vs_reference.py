@@ -1,0 +1,25 @@
+"""Differential fuzzing of the host pipeline (CPU oracle engine) against the compiled reference, when it is present
+(dev container: oracle/_ref/pandepth_ref built from /root/reference): tools/fuzz_vs_ref.py generates small SAM / BAM /
+BAM+BAI / #.list inputs, GFF / GTF / BED3 / BED4 files with the quirks real files have (comments, blank lines, unknown
+contigs, start > end, duplicate ids, odd attribute orders, leading zeros, spaces for tabs) and random option mixes, and
+compares exit code, stdout and every output file byte for byte.  This is how the last-base target rule of the reference's
+indexed path was found (tests/golden/f4).  Skipped where the reference binary does not exist (GPU box, CI)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+
+
+@pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
+@pytest.mark.parametrize("seed", [101, 102])
+def test_random_inputs_match_the_reference(seed):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), str(seed), "60"], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""tools/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
+compiled reference (oracle/_ref/pandepth_ref): random small SAM inputs, region files with the quirks real files have, random
+option mixes.  Compares exit code, stdout and every output file byte for byte.  Needs /root/reference's build (dev container).
+usage: fuzz_vs_ref.py [seed] [cases]"""
+import glob
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+CLI = os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")
+
+
+def gen_sam(rng, sorted_hdr):
+    ncontig = rng.randrange(1, 5)
+    lens = [rng.choice([1, 2, 37, 101, 201, 500, 1001, 2500, 10001]) for _ in range(ncontig)]
+    names = ["c%d" % i if rng.random() < 0.8 else "chr_%s" % "xyzw"[i] for i in range(ncontig)]
+    out = ["@HD\tVN:1.6\tSO:%s" % ("coordinate" if sorted_hdr else rng.choice(["unsorted", "queryname", "unknown"]))]
+    for n, l in zip(names, lens):
+        out.append("@SQ\tSN:%s\tLN:%d" % (n, l))
+    reads = []
+    for i in range(rng.randrange(0, 400)):
+        t = rng.randrange(ncontig)
+        L = lens[t]
+        pos = rng.randrange(1, L + 1)
+        ops = []
+        for _ in range(rng.randrange(1, 6)):
+            op = rng.choice("MMMMIDNS=XH")
+            ops.append((rng.randrange(1, 40 if op != "N" else 300), op))
+        if ops[0][1] in "DN" and rng.random() < 0.7:
+            ops[0] = (ops[0][0], "M")
+        # alignments stay inside the contig, as every aligner's do (the reference lets overhanging reads write into the
+        # +500 cells of padding behind each contig and reports them for regions that reach beyond the contig end: invalid
+        # input on both counts, not reproduced)
+        rlen = sum(n for n, o in ops if o in "MDN=X")
+        if pos + rlen - 1 > L:
+            if rng.random() < 0.5 and rlen <= L:
+                pos = rng.randrange(1, L - rlen + 2)
+            else:
+                pos = min(pos, L)
+                ops = [(rng.randrange(1, L - pos + 2), "M")]
+        cigar = "".join("%d%s" % o for o in ops)
+        qlen = sum(n for n, o in ops if o in "MIS=X")
+        flag = rng.choice([0, 16, 0, 16, 256, 512, 1024, 2048, 4, 99, 147, 1040])
+        mapq = rng.choice([0, 1, 10, 20, 30, 60, 255])
+        seq = "A" * qlen if qlen else "*"
+        reads.append((t, pos, "r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s" % (i, flag, names[t], pos, mapq, cigar, seq, "I" * qlen if qlen else "*")))
+    if sorted_hdr:
+        reads.sort(key=lambda r: (r[0], r[1]))
+    else:
+        rng.shuffle(reads)
+    if rng.random() < 0.3:
+        reads.append((99, 0, "u1\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII"))
+    return "\n".join(out + [r[2] for r in reads]) + "\n", names, lens
+
+
+def gen_regions(rng, names, lens, kind):
+    lines = []
+    n = rng.randrange(1, 40)
+    for i in range(n):
+        t = rng.randrange(len(names))
+        nm = names[t] if rng.random() < 0.93 else "nochr"
+        # inside the contig: beyond its end the reference reads its padding (zeros for one input, uninitialised heap in
+        # list mode) — undefined input, not reproduced
+        a = rng.randrange(1, lens[t] + 1); b = min(lens[t], a + rng.randrange(0, 400))
+        if rng.random() < 0.05:
+            a, b = b, a                                  # start > end (BED: warned and skipped; GFF/GTF: taken as they are)
+        if kind == "gff":
+            feat = rng.choice(["CDS", "CDS", "CDS", "exon", "gene", "mRNA"])
+            gid = "g%d" % rng.randrange(0, max(1, n // 3))
+            attr = rng.choice(["ID=c%d;Parent=%s" % (i, gid), "Parent=%s;ID=c%d" % (gid, i), "ID=%s" % gid, "Parent=%s,%sb" % (gid, gid),
+                               "Name=x;Parent=%s;Note=a=b" % gid, "%s" % gid, "ID=c%d;Parent=%s;" % (i, gid)])
+            lines.append("%s\tsrc\t%s\t%d\t%d\t.\t%s\t%s\t%s" % (nm, feat, a, b, rng.choice("+-."), rng.choice("012."), attr))
+        elif kind == "gtf":
+            feat = rng.choice(["CDS", "CDS", "exon", "gene"])
+            gid = "G%d" % rng.randrange(0, max(1, n // 3))
+            lines.append('%s\tsrc\t%s\t%d\t%d\t.\t+\t0\tgene_id "%s"; transcript_id "%s.1";' % (nm, feat, a, b, gid, gid))
+        elif kind == "bed3":
+            sep = rng.choice(["\t", "\t", " "])
+            lines.append(sep.join([nm, ("%d" % a) if rng.random() < 0.9 else "0%d" % a, "%d" % b]))
+        else:
+            lines.append("\t".join([nm, "%d" % a, "%d" % b, "id%d" % rng.randrange(0, max(1, n // 2))]))
+        if rng.random() < 0.05:
+            lines.append("")
+        if rng.random() < 0.05:
+            lines.append("# a comment")
+    return "\n".join(lines) + ("\n" if rng.random() < 0.9 else "")
+
+
+S2B = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
+
+
+def one_case(rng, td):
+    sorted_hdr = rng.random() < 0.75
+    sam, names, lens = gen_sam(rng, sorted_hdr)
+    open(os.path.join(td, "x.sam"), "w").write(sam)
+    args = ["-i", "x.sam"]
+    form = rng.choice(["sam", "bam+bai", "bam+bai", "bam", "list"])
+    if form.startswith("bam") and os.access(S2B, os.X_OK):
+        indexed = form == "bam+bai" and sorted_hdr
+        r = subprocess.run([S2B, "x.sam", "x.bam"] + ([] if indexed else ["noindex"]), cwd=td, capture_output=True)
+        if r.returncode == 0:
+            args = ["-i", "x.bam"]
+    elif form == "list" and os.access(S2B, os.X_OK):
+        # two or three files with the same contigs (list mode takes them from the first): other reads, mixed formats
+        files = ["x.sam"]
+        hdr = [l for l in sam.split("\n") if l.startswith("@")]
+        for k in range(rng.randrange(1, 3)):
+            other, _, _ = gen_sam(rng, sorted_hdr)
+            body = [l for l in other.split("\n") if l and not l.startswith("@")]
+            ok = []
+            for l in body:                               # keep the reads that fit THESE contigs
+                f = l.split("\t")
+                if f[2] in names:
+                    L = lens[names.index(f[2])]
+                    import re
+                    rl = sum(int(n) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", f[5]) if o in "MDN=X")
+                    if int(f[3]) + rl - 1 <= L:
+                        ok.append(l)
+            if sorted_hdr:
+                ok.sort(key=lambda l: (names.index(l.split("\t")[2]), int(l.split("\t")[3])))
+            fn = "y%d.sam" % k
+            open(os.path.join(td, fn), "w").write("\n".join(hdr + ok) + "\n")
+            if rng.random() < 0.5:
+                r = subprocess.run([S2B, fn, "y%d.bam" % k] + ([] if sorted_hdr and rng.random() < 0.7 else ["noindex"]), cwd=td, capture_output=True)
+                if r.returncode == 0:
+                    fn = "y%d.bam" % k
+            files.append(fn)
+        open(os.path.join(td, "in.list"), "w").write("\n".join(files) + "\n")
+        args = ["-i", "in.list"]
+    mode = rng.choice(["chr", "chr", "w", "w", "gff", "gtf", "bed3", "bed4"])
+    if mode == "w":
+        args += ["-w", str(rng.choice([1, 2, 7, 50, 100, 149, 150, 151, 200, 1000, 0, -3]))]
+    elif mode in ("gff", "gtf"):
+        open(os.path.join(td, "r." + mode), "w").write(gen_regions(rng, names, lens, mode))
+        args += ["-g", "r." + mode]
+        if rng.random() < 0.3:
+            args += ["-f", rng.choice(["exon", "CDS", "gene"])]
+    elif mode in ("bed3", "bed4"):
+        open(os.path.join(td, "r.bed"), "w").write(gen_regions(rng, names, lens, mode))
+        args += ["-b", "r.bed"]
+    if rng.random() < 0.3:
+        args += ["-a"]
+    if rng.random() < 0.3:
+        args += ["-q", str(rng.choice([0, 1, 10, 20, 61]))]
+    if rng.random() < 0.3:
+        args += ["-d", str(rng.choice([0, 1, 2, 5, 50]))]
+    if rng.random() < 0.3:
+        args += ["-x", str(rng.choice([0, 4, 1024, 1796, 3844]))]
+    if rng.random() < 0.15:
+        args += ["-s"]
+    if rng.random() < 0.5:
+        args += ["-t", str(rng.choice([1, 2, 5]))]
+    return args
+
+
+def run(exe, args, td, prefix):
+    p = subprocess.run([exe] + args + ["-o", prefix], cwd=td, capture_output=True, timeout=120)
+    files = {}
+    for f in sorted(glob.glob(os.path.join(td, prefix + ".*"))):
+        files[os.path.basename(f)[len(prefix):]] = open(f, "rb").read()
+    return p.returncode, p.stdout, files
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    rng = random.Random(seed)
+    bad = skipped = 0
+    for k in range(cases):
+        td = tempfile.mkdtemp(prefix="fz", dir="/tmp")
+        args = one_case(rng, td)
+        try:
+            r_rc, r_out, r_files = run(REF, args, td, "ref")
+        except subprocess.TimeoutExpired:
+            skipped += 1; shutil.rmtree(td); continue
+        if r_rc < 0:                                    # the reference itself crashed on this input
+            skipped += 1; shutil.rmtree(td); continue
+        m_rc, m_out, m_files = run(CLI, args, td, "mine")
+        same = r_rc == m_rc and r_out == m_out and r_files == m_files
+        if not same:
+            bad += 1
+            keep = "/tmp/fuzzbad_%d_%d" % (seed, k)
+            shutil.rmtree(keep, ignore_errors=True)
+            shutil.copytree(td, keep)
+            what = "rc %d/%d" % (r_rc, m_rc) if r_rc != m_rc else "stdout" if r_out != m_out else "files " + ",".join(
+                sorted(set(r_files) ^ set(m_files)) or [f for f in r_files if r_files[f] != m_files[f]])
+            print("MISMATCH case %d: %s  args %s  -> %s" % (k, what, " ".join(args), keep), flush=True)
+        shutil.rmtree(td)
+    print("seed %d: %d cases, %d mismatches, %d skipped (reference crashed / hung)" % (seed, cases, bad, skipped))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
