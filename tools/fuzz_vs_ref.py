@@ -16,9 +16,16 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
 CLI = os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")
 
 
+BIG = False         # fuzz_vs_ref.py <seed> <cases> big: contigs of 11-32 Mb, reads and targets clustered around the 10 Mb steps
+                    # of the reference's indexed window walk (PD:676-786)
+
+
 def gen_sam(rng, sorted_hdr):
     ncontig = rng.randrange(1, 5)
     lens = [rng.choice([1, 2, 37, 101, 201, 500, 1001, 2500, 10001]) for _ in range(ncontig)]
+    if BIG:
+        ncontig = rng.randrange(1, 3)
+        lens = [rng.choice([11000000, 20000001, 25000000, 32000000, 10000150]) for _ in range(ncontig)]
     names = ["c%d" % i if rng.random() < 0.8 else "chr_%s" % "xyzw"[i] for i in range(ncontig)]
     out = ["@HD\tVN:1.6\tSO:%s" % ("coordinate" if sorted_hdr else rng.choice(["unsorted", "queryname", "unknown"]))]
     for n, l in zip(names, lens):
@@ -28,6 +35,9 @@ def gen_sam(rng, sorted_hdr):
         t = rng.randrange(ncontig)
         L = lens[t]
         pos = rng.randrange(1, L + 1)
+        if BIG and rng.random() < 0.85:                   # near a 10 Mb step (or the contig end)
+            c = rng.choice([10000000, 20000000, 30000000, L, 10000000 + rng.randrange(-400, 400)])
+            pos = min(L, max(1, c + rng.randrange(-700, 700)))
         ops = []
         for _ in range(rng.randrange(1, 6)):
             op = rng.choice("MMMMIDNS=XH")
@@ -68,6 +78,9 @@ def gen_regions(rng, names, lens, kind):
         # inside the contig: beyond its end the reference reads its padding (zeros for one input, uninitialised heap in
         # list mode) — undefined input, not reproduced
         a = rng.randrange(1, lens[t] + 1); b = min(lens[t], a + rng.randrange(0, 400))
+        if BIG and rng.random() < 0.9:
+            c = rng.choice([10000000, 20000000, 30000000, lens[t], rng.choice([1, 50, 200])])
+            a = min(lens[t], max(1, c + rng.randrange(-900, 900))); b = min(lens[t], a + rng.randrange(0, 700))
         if rng.random() < 0.05:
             a, b = b, a                                  # start > end (BED: warned and skipped; GFF/GTF: taken as they are)
         if kind == "gff":
@@ -168,8 +181,10 @@ def run(exe, args, td, prefix):
 
 
 def main():
+    global BIG
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     rng = random.Random(seed)
     bad = skipped = 0
     for k in range(cases):
