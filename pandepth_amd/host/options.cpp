@@ -101,14 +101,16 @@ int parse_options(int argc, char **argv, Options *o)
         } else if (flag == "o") { if (!arg(&o->out)) return 0; }
         else if (flag == "c") o->gc = true;
         else if (flag == "a") o->site_out = true;
-        else if (flag == "r") { if (!arg(&v)) return 0; }
+        else if (flag == "r") { if (!arg(&o->reference)) return 0; }
         else if (flag == "f") { if (!arg(&o->feature)) return 0; }
         else if (flag == "x") { if (!arg(&v)) return 0; o->flag_mask = (uint32_t)atoi(v.c_str()); }
         else if (flag == "g") {
             if (!arg(&v)) return 0;
             o->region_file = v;
             std::vector<std::string> ls;
-            if (!read_lines(v, &ls)) { std::cerr << "Error: Failed to open the file: " << v << std::endl; return 0; }
+            // a file that cannot be opened does not trip the reference's `INGFF.fail()` check (PD:154-158, its gzstream
+            // reports nothing): it reads no line and ends in the format message below
+            (void)read_lines(v, &ls);
             // sniff the first 167 lines: the LAST line mentioning Parent / transcript_id decides (PD:162-181)
             for (size_t k = 0; k < ls.size() && k < 167; ++k) {
                 const std::string &t = ls[k];
@@ -137,7 +139,9 @@ int parse_options(int argc, char **argv, Options *o)
     if (bed_count != 0 && o->region_file.empty()) {
         o->region_file = bed_list[0];
         std::vector<std::string> ls;
-        if (!read_lines(o->region_file, &ls)) { std::cerr << "Error: Failed to open BED file: " << o->region_file << std::endl; return 0; }
+        // an unreadable file does not trip the reference's `!LISTTT.good()` (PD:268-273, its gzstream reports nothing):
+        // it is an empty BED3 list, and an empty target list falls back to whole-chromosome mode
+        (void)read_lines(o->region_file, &ls);
         std::vector<std::string> t1, t2;
         split_ws(ls.size() > 0 ? ls[0] : std::string(), &t1);
         split_ws(ls.size() > 1 ? ls[1] : std::string(), &t2);

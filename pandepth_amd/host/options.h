@@ -22,6 +22,7 @@ struct Options {
     int min_dep = 1;
     uint32_t flag_mask = 1796;
     int threads = 3;
+    std::string reference;            // -r (only its presence matters here: GC columns are not computed)
     int win = 0;
     bool site_out = false;               // -a
     bool use_index = true;               // hidden -s clears it

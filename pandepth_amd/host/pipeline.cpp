@@ -642,7 +642,6 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (n_files == 0) return 0;
     const bool list_mode = n_files > 1;
     if (list_mode) std::cout << "INFO: Run multi-file data " << std::endl;
-    if (o.gc) std::cerr << "Warning: GC content (-c/-r) is not computed by this engine; columns are omitted." << std::endl;
 
     std::string path = o.input, err;
     if (path.empty()) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
@@ -650,6 +649,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (!first.open(path, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
     const AlnHeader hdr = first.header();
     if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
+    if (o.gc) {
+        // PD:3510-3532 (PD:2068-2090 for lists): -c needs -r, checked once the first input's header has been read
+        if (o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }
+        std::cerr << "Warning: GC content (-c/-r) is not computed by this engine; columns are omitted." << std::endl;
+    }
 
     tm.mark("options + header");
     RegionModel rm;

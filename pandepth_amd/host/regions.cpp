@@ -71,10 +71,9 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
 
     if (o->mode != 0) {
         std::vector<std::string> lines;
-        if (!read_lines(o->region_file, &lines)) {
-            std::cerr << "Error: Cannot open the GFF/GTF File: " << o->input << std::endl;
-            return false;
-        }
+        // PD:3550-3555 tests `!LIST.good()`, which the reference's gzstream never sets for a file it could not open: the
+        // target list is then simply empty (and an empty list falls back to whole-chromosome mode below)
+        (void)read_lines(o->region_file, &lines);
         // these live across lines in the reference too: a short line re-uses the previous values
         std::string chr, id, start_s, end_s;
         int bstart = 0, bend = 0;

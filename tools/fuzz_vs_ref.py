@@ -2,7 +2,7 @@
 """tools/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
 compiled reference (oracle/_ref/pandepth_ref): random small SAM inputs, region files with the quirks real files have, random
 option mixes.  Compares exit code, stdout and every output file byte for byte.  Needs /root/reference's build (dev container).
-usage: fuzz_vs_ref.py [seed] [cases]"""
+usage: fuzz_vs_ref.py [seed] [cases] [big | args]"""
 import glob
 import os
 import random
@@ -180,11 +180,51 @@ def run(exe, args, td, prefix):
     return p.returncode, p.stdout, files
 
 
+def args_mode(seed, cases):
+    """random argv over the golden fixture f1: flags in any order, missing values, unknown flags, unreadable files; compares
+    exit code, stderr, stdout (the usage text counts as equal: this build does not list cram/paf) and every output file"""
+    rng = random.Random(seed)
+    d = os.path.join(ROOT, "tests", "golden", "f1")
+    flags = ["-i", "-o", "-g", "-f", "-b", "-w", "-a", "-q", "-d", "-x", "-t", "-h", "-s", "-c", "-r", "-z", "--help", "-W", "-I", "-O"]
+    vals = ["f1.bam", "f1.sam", "f1.gff", "f1.gtf", "f1.bed3", "f1.bed4", "f1_3.list", "missing.bam", "100", "0", "-5", "abc", "1e3", "CDS",
+            "exon", "", "3.7", "200", "1796", "60"]
+    bad = 0
+    for k in range(cases):
+        args = []
+        if rng.random() < 0.8:
+            args += ["-i", rng.choice(["f1.bam", "f1.sam", "f1_3.list", "missing.bam"])]
+        for _ in range(rng.randrange(0, 7)):
+            args.append(rng.choice(flags))
+            if rng.random() < 0.75:
+                args.append(rng.choice(vals))
+        td = tempfile.mkdtemp(prefix="af", dir="/tmp")
+        res = []
+        for exe, pre in ((REF, "r"), (CLI, "m")):
+            full = [exe] + args + ([] if "-o" in args else ["-o", os.path.join(td, pre)])
+            try:
+                p = subprocess.run(full, cwd=d, capture_output=True, timeout=60)
+            except subprocess.TimeoutExpired:
+                res.append(None); continue
+            files = {os.path.basename(f)[1:]: open(f, "rb").read() for f in glob.glob(os.path.join(td, pre + ".*"))}
+            out = b"<usage>" if p.stdout.startswith(b"Usage: pandepth") else p.stdout
+            res.append((p.returncode, out, p.stderr.replace(pre.encode() + b".", b"X."), files))
+        shutil.rmtree(td)
+        if res[0] is None or res[0][0] < 0:
+            continue
+        if res[0] != res[1]:
+            bad += 1
+            print("MISMATCH argv case %d: %s\n  ref %r\n  mine %r" % (k, " ".join(args), res[0][:3], res[1][:3] if res[1] else None), flush=True)
+    print("seed %d: %d argv cases, %d mismatches" % (seed, cases, bad))
+    return 1 if bad else 0
+
+
 def main():
     global BIG
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+    if len(sys.argv) > 3 and sys.argv[3] == "args":
+        return args_mode(seed, cases)
     rng = random.Random(seed)
     bad = skipped = 0
     for k in range(cases):
