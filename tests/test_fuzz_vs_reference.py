@@ -42,3 +42,11 @@ def test_large_contigs_around_the_reference_window_steps():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "41", "12", "big"], capture_output=True, text=True,
                        timeout=1800)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
+def test_messy_target_files_match_the_reference():
+    """Windows line endings, extra columns, runs of spaces, truncated BED lines (the reference re-uses the previous line's values)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "51", "60", "messy"], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]

@@ -2,7 +2,7 @@
 """tools/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
 compiled reference (oracle/_ref/pandepth_ref): random small SAM inputs, region files with the quirks real files have, random
 option mixes.  Compares exit code, stdout and every output file byte for byte.  Needs /root/reference's build (dev container).
-usage: fuzz_vs_ref.py [seed] [cases] [big | args]"""
+usage: fuzz_vs_ref.py [seed] [cases] [big | args | messy]"""
 import glob
 import os
 import random
@@ -16,6 +16,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
 CLI = os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")
 
 
+MESSY = False       # fuzz_vs_ref.py <seed> <cases> messy: truncated lines, CRLF, extra columns, runs of spaces in the target files
 BIG = False         # fuzz_vs_ref.py <seed> <cases> big: contigs of 11-32 Mb, reads and targets clustered around the 10 Mb steps
                     # of the reference's indexed window walk (PD:676-786)
 
@@ -58,6 +59,11 @@ def gen_sam(rng, sorted_hdr):
         qlen = sum(n for n, o in ops if o in "MIS=X")
         flag = rng.choice([0, 16, 0, 16, 256, 512, 1024, 2048, 4, 99, 147, 1040])
         mapq = rng.choice([0, 1, 10, 20, 30, 60, 255])
+        if flag & 4:
+            # an unmapped read carries no alignment (SAM spec: CIGAR "*").  With a CIGAR, and -x letting it through, the
+            # reference's indexed path counts it only inside the 10 Mb window that fetched it by its first base
+            # (htslib's end position of an unmapped read is pos + 1): an inconsistent record, not generated, not reproduced
+            cigar, qlen = "*", 4
         seq = "A" * qlen if qlen else "*"
         reads.append((t, pos, "r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s" % (i, flag, names[t], pos, mapq, cigar, seq, "I" * qlen if qlen else "*")))
     if sorted_hdr:
@@ -81,8 +87,10 @@ def gen_regions(rng, names, lens, kind):
         if BIG and rng.random() < 0.9:
             c = rng.choice([10000000, 20000000, 30000000, lens[t], rng.choice([1, 50, 200])])
             a = min(lens[t], max(1, c + rng.randrange(-900, 900))); b = min(lens[t], a + rng.randrange(0, 700))
-        if rng.random() < 0.05:
-            a, b = b, a                                  # start > end (BED: warned and skipped; GFF/GTF: taken as they are)
+        if rng.random() < 0.05 and kind.startswith("bed"):
+            a, b = b, a                                  # start > end: BED rows are warned about and skipped (PD:3754-3758).  GFF/GTF
+                                                         # rows are taken as they are and turn into reversed merged spans whose region
+                                                         # fetch is garbage-in: not generated, not reproduced
         if kind == "gff":
             feat = rng.choice(["CDS", "CDS", "CDS", "exon", "gene", "mRNA"])
             gid = "g%d" % rng.randrange(0, max(1, n // 3))
@@ -98,6 +106,19 @@ def gen_regions(rng, names, lens, kind):
             lines.append(sep.join([nm, ("%d" % a) if rng.random() < 0.9 else "0%d" % a, "%d" % b]))
         else:
             lines.append("\t".join([nm, "%d" % a, "%d" % b, "id%d" % rng.randrange(0, max(1, n // 2))]))
+        if MESSY:
+            u = rng.random()
+            if u < 0.04 and kind.startswith("bed"):      # a truncated BED line (the reference re-uses what the previous line left;
+                                                         # a GFF/GTF line without its attribute column indexes past the end of a vector)
+                cols = lines[-1].split("\t")
+                keep = 3 if kind.startswith("bed") else 5     # the coordinates stay on the line: values re-used from another
+                lines[-1] = "\t".join(cols[:rng.randrange(min(keep, len(cols)), len(cols) + 1)])   # contig's line reach beyond this one's end
+            elif u < 0.08:
+                lines[-1] += "\r"                        # a Windows line ending
+            elif u < 0.12:
+                lines[-1] += "\textra\t7"                # more columns than needed
+            elif u < 0.15:
+                lines[-1] = lines[-1].replace("\t", "  ", 1)
         if rng.random() < 0.05:
             lines.append("")
         if rng.random() < 0.05:
@@ -219,10 +240,11 @@ def args_mode(seed, cases):
 
 
 def main():
-    global BIG
+    global BIG, MESSY
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+    MESSY = len(sys.argv) > 3 and sys.argv[3] == "messy"
     if len(sys.argv) > 3 and sys.argv[3] == "args":
         return args_mode(seed, cases)
     rng = random.Random(seed)
