@@ -47,7 +47,20 @@ int main(int argc, char **argv)
     const std::vector<uint8_t> ref = slurp(tmp);
     unlink(tmp);
     std::vector<uint8_t> out;
-    const bool ok = pgz::gzip_identical(data.data(), data.size(), threads, out, p);
+    bool ok;
+    if (getenv("PGZ_PIECES")) {
+        // the streaming interface, fed in pieces of irregular size (as the per-site writer does)
+        pgz::Stream st(threads, [&](const uint8_t *b, size_t k) { out.insert(out.end(), b, b + k); return true; }, p);
+        unsigned long long x = 88172645463325252ull;
+        ok = true;
+        for (size_t o = 0; o < data.size() && ok;) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const size_t k = std::min<size_t>(data.size() - o, 1 + (size_t)(x % (x % 5 == 0 ? 3000000 : 70000)));
+            ok = st.write(data.data() + o, k);
+            o += k;
+        }
+        ok = ok && st.finish();
+    } else ok = pgz::gzip_identical(data.data(), data.size(), threads, out, p);
     const auto t2 = std::chrono::steady_clock::now();
     const double ts = std::chrono::duration<double>(t1 - t0).count(), tp = std::chrono::duration<double>(t2 - t1).count();
     if (!ok) { printf("declined (%zu bytes, zlib %.3f s)\n", data.size(), ts); return 3; }

@@ -69,6 +69,16 @@ def test_generated_tables_stitched_across_chunks(check, tmp_path, cfg):
         assert verdict(check, p, *cfg) == "identical", name
 
 
+def test_streaming_interface_in_irregular_pieces(check, tmp_path):
+    """pgz::Stream fed with writes of 1 byte .. 3 MB and rounds of 2 MB: same bytes as one zlib stream"""
+    p = tmp_path / "s.txt"
+    p.write_bytes(site_table(900000, 21) + window_table(60000, 22))
+    for cfg in ((4, 65536, 4096, 2000000), (3, 262144, 16384, 1), (8,)):
+        r = subprocess.run([check, str(p)] + [str(c) for c in cfg], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, PGZ_PIECES="1"))
+        assert r.stdout.split()[0] == "identical", r.stdout
+
+
 def test_edge_cases(check, tmp_path):
     cases = {
         "empty": (b"", "identical"),
