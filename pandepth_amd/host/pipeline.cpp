@@ -835,7 +835,9 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
         SL += tot.L; SC += tot.C; SD += tot.D;
         OUT.write(footer(SL, SC, SD));
+        tm.mark("scan + statistics + table text");
         OUT.close();
+        tm.mark("table gzip");
         std::cout << "INFO: Input data read done" << std::endl;
         return 0;
     }
