@@ -171,13 +171,27 @@ def one_case(rng, td):
     if mode == "w":
         args += ["-w", str(rng.choice([1, 2, 7, 50, 100, 149, 150, 151, 200, 1000, 0, -3]))]
     elif mode in ("gff", "gtf"):
-        open(os.path.join(td, "r." + mode), "w").write(gen_regions(rng, names, lens, mode))
-        args += ["-g", "r." + mode]
+        fn = "r." + mode
+        text = gen_regions(rng, names, lens, mode)
+        if rng.random() < 0.2:                            # the reference reads its target files through gzstream
+            import gzip
+            fn += ".gz"
+            gzip.open(os.path.join(td, fn), "wb").write(text.encode())
+        else:
+            open(os.path.join(td, fn), "w").write(text)
+        args += ["-g", fn]
         if rng.random() < 0.3:
             args += ["-f", rng.choice(["exon", "CDS", "gene"])]
     elif mode in ("bed3", "bed4"):
-        open(os.path.join(td, "r.bed"), "w").write(gen_regions(rng, names, lens, mode))
-        args += ["-b", "r.bed"]
+        fn = "r.bed"
+        text = gen_regions(rng, names, lens, mode)
+        if rng.random() < 0.2:
+            import gzip
+            fn += ".gz"
+            gzip.open(os.path.join(td, fn), "wb").write(text.encode())
+        else:
+            open(os.path.join(td, fn), "w").write(text)
+        args += ["-b", fn]
     if rng.random() < 0.3:
         args += ["-a"]
     if rng.random() < 0.3:
