@@ -41,8 +41,12 @@ def gen_sam(rng, sorted_hdr):
             pos = min(L, max(1, c + rng.randrange(-700, 700)))
         ops = []
         for _ in range(rng.randrange(1, 6)):
-            op = rng.choice("MMMMIDNS=XH")
+            op = rng.choice("MMMMIDNS=XHP")
             ops.append((rng.randrange(1, 40 if op != "N" else 300), op))
+        if BIG and rng.random() < 0.02 and L > 300000:
+            # more than 65535 CIGAR operations: BAM keeps the CIGAR in the CG:B,I tag (SAM spec 4.2.2)
+            ops = [(1, "M"), (1, "D")] * rng.randrange(33000, 36000)
+            pos = min(pos, L - 80000)
         if ops[0][1] in "DN" and rng.random() < 0.7:
             ops[0] = (ops[0][0], "M")
         # alignments stay inside the contig, as every aligner's do (the reference lets overhanging reads write into the
