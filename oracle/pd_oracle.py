@@ -357,7 +357,7 @@ def _select_sorted_stream(r, merged, flag_mask, min_mapq):  # PD:4608-4646
 
 def run(args, cwd="."):
     """Replay `pandepth <args>`; returns {suffix: text} for every file the reference writes."""
-    o = {"i": None, "g": None, "b": None, "f": "CDS", "w": 0, "a": False, "q": -1, "d": 1,
+    o = {"i": None, "g": None, "b": None, "f": "CDS", "w": None, "a": False, "q": -1, "d": 1,
          "x": 1796, "s": False}
     k = 0
     while k < len(args):
@@ -369,7 +369,8 @@ def run(args, cwd="."):
         else:
             o[f] = args[k + 1]; k += 1
         k += 1
-    o["w"] = max(o["w"], 1) if o["w"] != 0 else 0
+    # PD:211-215: a given -w below 1 is warned about and becomes 1 (so `-w 0` is still window mode); not given = 0
+    o["w"] = 0 if o["w"] is None else max(o["w"], 1)
     o["d"] = max(o["d"], 1)
     path = os.path.join(cwd, o["i"])
     is_list = path.endswith(".list") or path.endswith(".List")
@@ -426,8 +427,10 @@ def run(args, cwd="."):
         out["SiteDepth.gz"] = "".join(rows)
 
     def footer(L, C, D):
-        cov = C * 100.0 / L if L else float("nan")
-        mean = D * 1.0 / L if L else float("nan")
+        if not L:      # PD:5122 divides 0.0 by 0.0: x86 SSE gives the NaN with the sign bit set, printf prints "-nan"
+            return "##RegionLength: 0\tCoveredSite: %d\tCoverage(%%): -nan\tMeanDepth: -nan\n" % C
+        cov = C * 100.0 / L
+        mean = D * 1.0 / L
         return "##RegionLength: %d\tCoveredSite: %d\tCoverage(%%): %.2f\tMeanDepth: %.2f\n" % (L, C, cov, mean)
 
     SL = SC = SD = 0

@@ -50,3 +50,12 @@ def test_messy_target_files_match_the_reference():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "51", "60", "messy"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
+def test_oracle_restatement_matches_the_reference_on_random_inputs():
+    """oracle/pd_oracle.py itself (the checker of the GPU tests) against the reference binary: table and per-site texts"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "61", "80", "oracle"], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]

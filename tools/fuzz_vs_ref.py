@@ -2,7 +2,7 @@
 """tools/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
 compiled reference (oracle/_ref/pandepth_ref): random small SAM inputs, region files with the quirks real files have, random
 option mixes.  Compares exit code, stdout and every output file byte for byte.  Needs /root/reference's build (dev container).
-usage: fuzz_vs_ref.py [seed] [cases] [big | args | messy]"""
+usage: fuzz_vs_ref.py [seed] [cases] [big | args | messy | oracle]"""
 import glob
 import os
 import random
@@ -257,6 +257,39 @@ def args_mode(seed, cases):
     return 1 if bad else 0
 
 
+def oracle_mode(seed, cases):
+    """the Python/C restatement (oracle/pd_oracle.py: run()) against the reference binary on the same random inputs: every
+    output file's TEXT (the oracle does not deflate)"""
+    import gzip
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pd_oracle as O
+    rng = random.Random(seed)
+    bad = skipped = 0
+    for k in range(cases):
+        td = tempfile.mkdtemp(prefix="fo", dir="/tmp")
+        args = one_case(rng, td)
+        try:
+            p = subprocess.run([REF] + args + ["-o", "ref"], cwd=td, capture_output=True, timeout=120)
+        except subprocess.TimeoutExpired:
+            skipped += 1; shutil.rmtree(td); continue
+        if p.returncode < 0:
+            skipped += 1; shutil.rmtree(td); continue
+        ref = {os.path.basename(x)[4:]: gzip.decompress(open(x, "rb").read()).decode() for x in glob.glob(os.path.join(td, "ref.*"))}
+        try:
+            mine = O.run(args + ["-o", "x"], cwd=td)
+        except Exception as e:                                   # noqa: BLE001 - reported as a mismatch
+            mine = {"error": repr(e)}
+        if mine != ref:
+            bad += 1
+            keep = "/tmp/oraclebad_%d_%d" % (seed, k)
+            shutil.rmtree(keep, ignore_errors=True)
+            shutil.copytree(td, keep)
+            print("ORACLE MISMATCH case %d: %s -> %s" % (k, " ".join(args), keep), flush=True)
+        shutil.rmtree(td)
+    print("seed %d: %d oracle cases, %d mismatches, %d skipped" % (seed, cases, bad, skipped))
+    return 1 if bad else 0
+
+
 def main():
     global BIG, MESSY
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -265,6 +298,8 @@ def main():
     MESSY = len(sys.argv) > 3 and sys.argv[3] == "messy"
     if len(sys.argv) > 3 and sys.argv[3] == "args":
         return args_mode(seed, cases)
+    if len(sys.argv) > 3 and sys.argv[3] == "oracle":
+        return oracle_mode(seed, cases)
     rng = random.Random(seed)
     bad = skipped = 0
     for k in range(cases):
