@@ -20,7 +20,8 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   are also run after the timed region: their kernel figures are reported under
                                   "arrays_path" and their results must equal the direct path's.
     [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pandepth_amd.multi.SlicedSum):
-                                  4-bit image (pd_export_i4), all-to-all over RCCL so that every xGMI link of a
+                                  4-bit image (pd_export_i4; packed straight from the tile windows in LDS, the arrays
+                                  are not written on any rank), all-to-all over RCCL so that every xGMI link of a
                                   GPU carries 1/N of it at once, every rank sums + sweeps its 1/N of the tiles
                                   (pd_slice_sweep_i4), rank 0 adds the per-tile partials up per bin
                                   (pd_gather_windows).  Steps are software-pipelined: sample k+1 is scattered
@@ -157,7 +158,9 @@ def main():
     buf = multi.buffer_view(eng, dev) if sum_mode == "int32" else None
     pipelined = sliced is not None and os.environ.get("PD_BENCH_PIPELINE", "1") == "1"
     wrap = 18 if use_dist else 0         # #.list mode keeps 18-bit cells (PD:2687-2699); single BAM + index: uint32
-    direct = not use_dist and os.environ.get("PD_BENCH_PATH", "direct") == "direct"
+    # N > 1 with the sliced sum: the same deferred pushes, and pd_export_i4 packs the tile windows straight from LDS
+    # (no arrays on any rank); the reduce-to-rank-0 forms need the arrays
+    direct = os.environ.get("PD_BENCH_PATH", "direct") == "direct" and (not use_dist or sliced is not None)
     eng.set_param("direct_windows", 1 if direct else 0)
 
     def scatter():
@@ -217,6 +220,8 @@ def main():
         scatter()
         own = torch.from_numpy(eng.scan_reduce_windows(BIN, 1, wrap)[2].astype(np.int64)).to(dev)
         dist.all_reduce(own, op=dist.ReduceOp.SUM)
+        if direct:
+            scatter()                              # the direct window call consumed the sample
         got = sliced.run(BIN, 1, wrap, 0) if sliced is not None else sum_to_rank0()
         if rank == 0:
             selfcheck = bool(np.array_equal(got[2].astype(np.int64), own.cpu().numpy()))
@@ -235,13 +240,14 @@ def main():
         dt = float(tmax.item())
 
     PROF_KEYS = ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
-                 "scan_reduce_windows", "export_i8", "import_i8", "export_i4", "slice_sweep", "gather_windows", "direct_tiles")
+                 "scan_reduce_windows", "export_i8", "import_i8", "export_i4", "slice_sweep", "gather_windows", "direct_tiles",
+                 "direct_export")
     prof = {k: eng.profile_get(k) for k in PROF_KEYS}
     eng.profile(False)
 
     # the general (materialising) path next to the direct one: a few untimed-for-`value` steps, same inputs
     arrays_path = None
-    if direct:
+    if direct and not use_dist:
         ASTEPS = 3
         direct = False
         eng.set_param("direct_windows", 0)
@@ -298,6 +304,8 @@ def main():
         kernels = {
             # the direct path's only big kernel: reads every run once (12 B), writes 24 B per tile
             "direct_tiles": k_entry("direct_tiles", (n_first + n_other) * B_RUN + (n_cells // 8192) * 24),
+            # N > 1: the runs read once, the 4-bit image (n_cells / 2 bytes) and the tile sums written
+            "direct_export": k_entry("direct_export", (n_first + n_other) * B_RUN + n_cells // 2 + (n_cells // 8192) * 4),
             # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
             "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
                      if prof["fill"][1] else None),
@@ -342,7 +350,8 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "path": "direct (difference windows stay in LDS)" if direct else "arrays (difference arrays in HBM)",
+                       "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else ")")) if direct
+                               else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
                            "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),

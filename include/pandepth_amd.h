@@ -180,7 +180,11 @@ int pd_import_i8(pd_ctx *ctx, const void *dev_i8, int bias, const pd_exc *dev_ex
  * the wire, so the value range does not shrink with the number of ranks.
  *   pd_export_i4      one nibble per cell into dev_i4 (n_cells / 2 bytes; cell 2k in the low
  *                     nibble of byte k), BIASED: d + 8 in [0, 15]; cells outside [-8, 7] are
- *                     written as 0 (+bias) and appended to dev_exc as in pd_export_i8.
+ *                     written as 0 (+bias) and appended to dev_exc as in pd_export_i8.  With
+ *                     "direct_windows" set, a pristine context and an entirely deferred sample
+ *                     (see pd_scan_reduce_windows) the image, the exceptions and the tile sums
+ *                     come straight from the tile windows in LDS — same bytes, the difference
+ *                     arrays are never written; the sample is then consumed (pd_reset next).
  *   pd_slice_sweep_i4 the receiving side, for the tiles [tile_first, tile_first + tile_count) of the
  *                     buffer (8192 cells each), in ONE fused kernel: adds the n_parts images of that
  *                     range (part j at dev_parts + j * part_stride, tile_count * 4096 bytes each,

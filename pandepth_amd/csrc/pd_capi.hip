@@ -1003,12 +1003,70 @@ int pd_import_i8(pd_ctx *c, const void *dev_i8, int bias, const pd_exc *dev_exc,
 static_assert(sizeof(TilePart) == PD_TILE_PARTIAL_BYTES, "pd_gather_windows' partial layout");
 static_assert(PD_TILE == PD_TILE_CELLS, "tile size in the public header");
 
+// pd_export_i4 without the arrays ("direct_windows", sample entirely deferred, context pristine): the tile windows leave
+// as the 4-bit image straight from LDS (k_direct_tiles<DirectExport>), the tile sums are written beside it.  *done = false
+// (tile sums re-zeroed, batches still pending) when a tile was too heavy, a run too long or a batch not sorted.
+static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count, bool *done)
+{
+    *done = false;
+    HIPOK(c, hipMemsetAsync(dev_count, 0, 4, c->stream));
+    HIPOK(c, hipMemsetAsync(c->direct_words, 0, 16, c->stream));
+    PendSet ps{};
+    ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
+    uint64_t all = 0;
+    for (int b = 0; b < ps.nb; ++b) {
+        const Pending &p = c->pend[b];
+        all += p.n;
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
+        ProfScope sc(c, "scatter_index");
+        launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample < 256 ? 256 : c->sample, c->ub_a[b],
+                             c->cand_lo[b], (uint32_t)c->n_tiles, PD_TILE, c->desc + b);
+    }
+    unsigned grid = c->grid_tiles;
+    if (!grid) {
+        uint64_t g = all / 256;
+        if (g < (uint64_t)c->n_cu * 4) g = (uint64_t)c->n_cu * 4;
+        if (g > 65536) g = 65536;
+        grid = (unsigned)g;
+    }
+    if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
+    { ProfScope sc(c, "direct_export");
+      launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
+                           c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 4, c->direct_words + 2, grid); }
+    HIPOK(c, hipGetLastError());
+    uint32_t words[2] = {0, 0};
+    HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (words[1]) {
+        HIPOK(c, hipMemsetAsync(c->sums, 0, (c->n_words - c->n_cells) * 4, c->stream));      // the kernel wrote them
+        char m[160];
+        snprintf(m, sizeof m, "direct export declined (heavy tiles / long runs: %u); the materialising path was used", words[0]);
+        c->err = m;                                          // informational: the call still succeeds
+        return PD_OK;
+    }
+    for (auto &p : c->pend)
+        if (p.slot >= 0) {
+            Stage &st = c->stage[p.slot];
+            HIPOK(c, hipEventRecord(st.done, c->stream));
+            st.state = 2; st.seq = ++c->seq;
+        }
+    c->pend.clear();
+    c->state = 2;
+    *done = true;
+    return PD_OK;
+}
+
 int pd_export_i4(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_cap, uint32_t *dev_count)
 {
     if (!c || !dev_i4 || !dev_count || (exc_cap && !dev_exc)) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     if (int rs = need_state(c, 0, "pd_export_i4")) return rs;
     HIPOK(c, hipSetDevice(c->device));
+    if (c->direct_windows && c->pristine && !c->pend.empty() && c->stile == PD_TILE) {
+        bool done = false;
+        const int rd = direct_export(c, dev_i4, dev_exc, exc_cap, dev_count, &done);
+        if (rd || done) return rd;
+    }
     int rc = flush_pending(c);
     if (rc) return rc;
     HIPOK(c, hipMemsetAsync(dev_count, 0, 4, c->stream));

@@ -66,6 +66,9 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
                          uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, const uint64_t *win_off,
                          uint32_t *cover, unsigned long long *sum, uint32_t *n_long, uint32_t *fail,
                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
+void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
+                          void *img, pd_exc *exc, uint32_t cap, uint32_t *count, int *sums, uint32_t *n_long, uint32_t *fail,
+                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles);
 void launch_fill_invalid(hipStream_t st, int *diff, uint8_t *hstate, uint32_t n_half, CheckWords *chk,
                          bool only_if_overflow, unsigned grid);
 void launch_mark_all_valid(hipStream_t st, CheckWords *chk);

@@ -409,19 +409,26 @@ __device__ __forceinline__ void direct_candidate(const pd_iv v, int32_t ctg, uin
     }
 }
 
-struct DirectWide { static constexpr bool narrow = false; uint32_t w, min_dep; TilePart *part; };
-struct DirectNarrow { static constexpr bool narrow = true; WinArgs wa; const uint64_t *win_off; };
+struct DirectWide { static constexpr bool narrow = false, exporting = false; uint32_t w, min_dep; TilePart *part; };
+struct DirectNarrow { static constexpr bool narrow = true, exporting = false; WinArgs wa; const uint64_t *win_off; };
+struct DirectExport {                  // the multi-GPU sum's 4-bit image straight from the tile windows (pd_export_i4)
+    static constexpr bool narrow = false, exporting = true;
+    unsigned short *img; pd_exc *exc; uint32_t cap; uint32_t *count; int *sums;
+};
 
 // A = DirectWide: windows >= TILE, per-tile partials (the bench's instantiation);
-// A = DirectNarrow: 64 <= w < TILE, LDS accumulators, results straight into the window arrays.
+// A = DirectNarrow: 64 <= w < TILE, LDS accumulators, results straight into the window arrays;
+// A = DirectExport: no statistics — the tile's difference window leaves as nibbles (k_export_i4's image), its cells
+//                   outside [-8, 7] as exceptions, its sum as the tile sum: what a rank puts on the links.
 template <int UN, int WPE, class A>
 __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const A args,
                                                         uint32_t *n_long, uint32_t *heavy_list, uint32_t *heavy_count)
 {
-    constexpr bool NARROW = A::narrow;
-    uint32_t w, min_dep; TilePart *part = nullptr;
-    if constexpr (NARROW) { w = args.wa.w; min_dep = args.wa.min_dep; } else { w = args.w; min_dep = args.min_dep; part = args.part; }
+    constexpr bool NARROW = A::narrow, EXPORT = A::exporting;
+    uint32_t w = (uint32_t)TILE, min_dep = 1; TilePart *part = nullptr;
+    if constexpr (NARROW) { w = args.wa.w; min_dep = args.wa.min_dep; }
+    else if constexpr (!EXPORT) { w = args.w; min_dep = args.min_dep; part = args.part; }
     __shared__ unsigned long long acc[NARROW ? TILE / 64 + 2 : 1];
     constexpr int ST = TILE;
     constexpr int ROWS = TILE / (WG * 4);                        // 8
@@ -504,6 +511,36 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
         const int carry = wave_sum(cnt.carry);
         if (lane == 0 && carry != 0) atomicAdd(&s_carry, carry);
         __syncthreads();
+        if constexpr (EXPORT) {
+            // k_export_i4's layout: one ushort (4 cells, nibble d + 8) per lane and row, 128 contiguous bytes per wave store
+            const uint64_t cw = a + (uint64_t)wv * (ROWS * 256);
+            unsigned short *o = args.img + cw / 4 + lane;
+            int tsum = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint2 q = reinterpret_cast<const uint2 *>(win)[wv * (ROWS * 64) + r * 64 + lane];
+                const int l0 = (int)(short)(q.x & 0xffffu), l1 = (int)(short)(q.y & 0xffffu);
+                int x[4] = {l0, ((int)q.x - l0) >> 16, l1, ((int)q.y - l1) >> 16};
+                unsigned wb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tsum += x[k];
+                    if (x[k] > 7 || x[k] < -8) {
+                        const uint32_t slot = atomicAdd(args.count, 1u);
+                        if (slot < args.cap) { args.exc[slot].cell = cw + (uint64_t)(r * 256 + lane * 4 + k); args.exc[slot].value = x[k]; args.exc[slot].pad = 0; }
+                        x[k] = 0;
+                    }
+                    wb |= (unsigned)((x[k] + 8) & 0xf) << (4 * k);
+                }
+                o[r * 64] = (unsigned short)wb;
+            }
+            tsum = wave_sum(tsum);
+            if (lane == 0) wtot[wv] = tsum;
+            __syncthreads();
+            if (threadIdx.x == 0) args.sums[t] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            __syncthreads();
+            continue;
+        }
         // ---- prefix sum of the window, straight from LDS (k_sweep's layout) ----
         int4 v[ROWS];
 #pragma unroll
@@ -646,7 +683,8 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
 __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                      const uint32_t *tile_contig, uint32_t wrap_mask, const WinArgs wa,
                                                      const uint64_t *win_off, uint32_t *n_long,
-                                                     const uint32_t *heavy_list, const uint32_t *heavy_count)
+                                                     const uint32_t *heavy_list, const uint32_t *heavy_count,
+                                                     const DirectExport ex)          // ex.img != null: export instead of statistics
 {
     const uint32_t w = wa.w, min_dep = wa.min_dep;
     TilePart *const part = wa.part;
@@ -718,6 +756,34 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
         carry = wave_sum(carry);
         if (lane == 0 && carry != 0) atomicAdd(&s_carry, carry);
         __syncthreads();
+        if (ex.img) {                                             // workgroup-uniform: the window leaves as nibbles (k_export_i4's layout)
+            const uint64_t cw = a + (uint64_t)wv * (ROWS * 256);
+            unsigned short *o = ex.img + cw / 4 + lane;
+            int tsum = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
+                int x[4] = {q.x, q.y, q.z, q.w};
+                unsigned wb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tsum += x[k];
+                    if (x[k] > 7 || x[k] < -8) {
+                        const uint32_t slot = atomicAdd(ex.count, 1u);
+                        if (slot < ex.cap) { ex.exc[slot].cell = cw + (uint64_t)(r * 256 + lane * 4 + k); ex.exc[slot].value = x[k]; ex.exc[slot].pad = 0; }
+                        x[k] = 0;
+                    }
+                    wb |= (unsigned)((x[k] + 8) & 0xf) << (4 * k);
+                }
+                o[r * 64] = (unsigned short)wb;
+            }
+            tsum = wave_sum(tsum);
+            if (lane == 0) wtot[wv] = tsum;
+            __syncthreads();
+            if (threadIdx.x == 0) ex.sums[t] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            __syncthreads();
+            continue;
+        }
         // ---- prefix sum of the window, straight from LDS (k_sweep's layout) ----
         int4 v[ROWS];
 #pragma unroll
@@ -1496,7 +1562,21 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     }
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,
-                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count);
+                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{});
+    hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
+}
+
+void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
+                          void *img, pd_exc *exc, uint32_t cap, uint32_t *count, int *sums, uint32_t *n_long, uint32_t *fail,
+                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
+{
+    const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
+    hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectExport>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
+                       0xFFFFFFFFu, de, n_long, heavy_list, heavy_count);
+    // tiles with more than 32 000 candidates: the int-window kernel exports them
+    WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa,
+                       (const uint64_t *)nullptr, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de);
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 

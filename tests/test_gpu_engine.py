@@ -630,3 +630,62 @@ def test_direct_windows_fall_back():
         e.push_intervals(first[::-1].copy(), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         with pytest.raises(pda.PdError):
             e.scan_reduce_windows(10000, 1, 0)
+
+
+def test_direct_export_equals_export_of_the_arrays():
+    """pd_export_i4 on a deferred sample ("direct_windows"): image, exception set and tile sums straight from the tile windows
+    must equal what the materialising path exports; runs the sliced finish on them too"""
+    import torch
+    from pandepth_amd import multi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(401)
+    first, other = _split_streams(rng, LENS, 90000)
+    first = sort_iv(np.concatenate([first, np.tile(np.array([[1, 700, 900]], dtype=np.int32), (300, 1)),
+                                    np.tile(np.array([[0, 8190, 8200]], dtype=np.int32), (40, 1)),         # exceptions, one across a tile edge
+                                    np.tile(np.array([[0, 300000, 300100]], dtype=np.int32), (40000, 1))]))  # > 32 000 candidates: a heavy tile
+    B = 8192
+
+    def export(direct):
+        e = pda.Engine(LENS)
+        e.set_param("direct_windows", 1 if direct else 0)
+        more = pda.PD_PUSH_MORE if direct else 0
+        e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        e.push_intervals(other, pda.PD_PUSH_SORTED | more | pda.PD_PUSH_DISORDER(800))
+        n_cells, n_sums = e.device_layout()
+        img = torch.zeros(n_cells // 2, dtype=torch.uint8, device=dev)
+        exc = torch.zeros((B, 2), dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.export_i4(img.data_ptr(), exc.data_ptr(), B, cnt.data_ptr())
+        e.synchronize()
+        k = int(cnt.item())
+        sums = multi.buffer_view(e, dev)[n_cells:].clone() if not direct else None
+        return e, img, exc[:k].cpu().numpy(), sums
+
+    ea, img_a, exc_a, sums_a = export(False)
+    ed, img_d, exc_d, _ = export(True)
+    try:
+        assert torch.equal(img_a, img_d)
+        key = lambda x: sorted(map(tuple, x.tolist()))
+        assert len(exc_a) >= 2 and key(exc_a) == key(exc_d)
+        with pytest.raises(pda.PdError, match="direct"):
+            ed.scan(0)                                            # consumed: the arrays hold nothing
+        # tile sums: the direct kernel writes them where the scatter kernels keep theirs; checked through the sliced finish,
+        # which derives every carry from them
+        ss = multi.SlicedSum(ea, dev)
+        ss.start(0)
+        ref = ss.finish(0, 10000, 1, 18)
+        ed.reset()
+        sd = multi.SlicedSum(ed, dev)                             # (before the pushes: its buffer view flushes what is pending)
+        ed.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        sd.start(0)
+        with pytest.raises(pda.PdError, match="direct"):
+            ed.scan(0)                                            # start() took the direct export
+        got = sd.finish(0, 10000, 1, 18)
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+        d, off = oracle_depth(LENS, np.concatenate([first, other]), True)
+        c, t = windows_ref(LENS, d, off, 10000, 1)
+        assert np.array_equal(got[1], c) and np.array_equal(got[2], t)
+    finally:
+        ea.close(); ed.close()
