@@ -77,11 +77,12 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
         // these live across lines in the reference too: a short line re-uses the previous values
         std::string chr, id, start_s, end_s;
         int bstart = 0, bend = 0;
+        std::istringstream is;
         for (std::string &line : lines) {
             if (line.empty()) continue;
             if (line[0] == '#') continue;
             if (o->mode == 1) {                                   // GFF3, PD:3557-3647
-                std::istringstream is(line);
+                is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 std::string f2, feat, strand, attr;
                 long long s = 0, e = 0;
                 is >> chr >> f2 >> feat;
@@ -102,7 +103,7 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
             } else if (o->mode == 2) {                            // GTF, PD:3649-3740
                 erase_all(&line, '"');
                 erase_all(&line, ';');
-                std::istringstream is(line);
+                is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 std::string f2, feat;
                 long long s = 0, e = 0;
                 is >> chr >> f2 >> feat;
@@ -115,7 +116,7 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
                 if (it == chr2tid.end()) unknown_contig(line);
                 else add_entry(rm, it->second, inf[9], s, e);
             } else if (o->mode == 3) {                            // BED3, PD:3741-3819
-                std::istringstream is(line);
+                is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 is >> chr >> start_s >> end_s;
                 id = chr + "_" + start_s + "_" + end_s;
                 bstart = atoi(start_s.c_str()); bend = atoi(end_s.c_str());
@@ -124,7 +125,7 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
                 if (it == chr2tid.end()) unknown_contig(line);
                 else add_entry(rm, it->second, id, bstart, bend);
             } else if (o->mode == 4) {                            // BED4, PD:3821-3898
-                std::istringstream is(line);
+                is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 is >> chr >> bstart >> bend >> id;
                 if (bstart > bend) { std::cerr << line << "Warning: This region may be incorrect. \n" << std::endl; continue; }
                 auto it = chr2tid.find(chr);
