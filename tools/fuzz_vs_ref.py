@@ -223,7 +223,12 @@ def args_mode(seed, cases):
     """random argv over the golden fixture f1: flags in any order, missing values, unknown flags, unreadable files; compares
     exit code, stderr, stdout (the usage text counts as equal: this build does not list cram/paf) and every output file"""
     rng = random.Random(seed)
-    d = os.path.join(ROOT, "tests", "golden", "f1")
+    # a scratch COPY of the fixture: `-o <value>` writes next to the inputs
+    d = tempfile.mkdtemp(prefix="af1", dir="/tmp")
+    src = os.path.join(ROOT, "tests", "golden", "f1")
+    for fn in os.listdir(src):
+        if os.path.isfile(os.path.join(src, fn)):
+            shutil.copy(os.path.join(src, fn), d)
     flags = ["-i", "-o", "-g", "-f", "-b", "-w", "-a", "-q", "-d", "-x", "-t", "-h", "-s", "-c", "-r", "-z", "--help", "-W", "-I", "-O"]
     vals = ["f1.bam", "f1.sam", "f1.gff", "f1.gtf", "f1.bed3", "f1.bed4", "f1_3.list", "missing.bam", "100", "0", "-5", "abc", "1e3", "CDS",
             "exon", "", "3.7", "200", "1796", "60"]
@@ -253,6 +258,7 @@ def args_mode(seed, cases):
         if res[0] != res[1]:
             bad += 1
             print("MISMATCH argv case %d: %s\n  ref %r\n  mine %r" % (k, " ".join(args), res[0][:3], res[1][:3] if res[1] else None), flush=True)
+    shutil.rmtree(d, ignore_errors=True)
     print("seed %d: %d argv cases, %d mismatches" % (seed, cases, bad))
     return 1 if bad else 0
 
