@@ -148,13 +148,13 @@ int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *ou
  * all-reduce / reduce-scatter of n_words int32 over xGMI, issued by the caller on the stream
  * returned by pd_stream).  contig_off (n_contigs entries, in cells) may be NULL. */
 int pd_device_buffer(pd_ctx *ctx, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off);
+int pd_device_count(int *n);                      /* usable gfx950 devices */
 /* Single-process form of the same sum (the CLI's `#.list` over several GPUs, one context per GPU):
  * dst += src, difference arrays and tile sums, chunk by chunk through a peer copy over xGMI and an
  * add kernel on dst's GPU.  Both contexts must describe the same contigs and be accumulating.
  * Transport: the source packs its cells to nibbles (d + 8, pd_export_i4's image) + an exception list on
  * its own GPU, so 1/8 of the int32 bytes cross the link; more than 2^20 cells outside [-8, 7], or
  * pd_set_param(dst, "accumulate_packed", 0), selects plain int32 chunks. */
-int pd_device_count(int *n);
 int pd_accumulate_from(pd_ctx *dst, pd_ctx *src);
 
 /* Compact transport of the difference arrays for that sum (xGMI is per-link bound; this moves
@@ -215,7 +215,9 @@ int pd_synchronize(pd_ctx *ctx);
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch.
  * pd_profile_get returns the accumulated milliseconds and launch count of kernel `name`
  * ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scatter_atomic", "tile_carry",
- * "scan", "scan_reduce_windows", "reduce_intervals", "reduce_windows"); pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
+ * "scan", "scan_reduce_windows", "reduce_intervals", "reduce_windows", "direct_tiles", "direct_export",
+ * "export_i4", "export_i8", "import_i8", "slice_sweep", "gather_windows", "accumulate_from");
+ * pd_profile(ctx, 0/1) switches it (and clears the accumulators). */
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 

@@ -178,17 +178,71 @@ def endpos(r, i):
 # region model  (PD:3547-4051)
 # --------------------------------------------------------------------------------------------
 class Gene:
-    __slots__ = ("start", "end", "length", "cds", "cover", "depth")
+    __slots__ = ("start", "end", "length", "cds", "cover", "depth", "gc")
 
     def __init__(self, s, e):
         self.start, self.end, self.length, self.cds = s, e, e - s + 1, [(s, e)]
         self.cover, self.depth = 0, 0
+        self.gc = 0
+
+
+_GC = None                                                  # {tid: bytes} while a -c run builds its regions
+
+
+def read_fasta(path, chrmap):
+    """PD:3506-3529 (klib kseq records): '>' or '@' starts a record, the name ends at the first white space, sequence
+    lines are joined until a line starts with '>', '@' or '+'; '+' opens a quality block as long as the sequence.
+    Returns {tid: sequence}; a name the header does not know becomes contig 0 IN `chrmap` (map::operator[]), and the
+    first sequence claiming an id wins."""
+    raw = open(path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    lines = raw.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    seqs, k, n = {}, 0, len(lines)
+    while k < n and not (lines[k][:1] in (b">", b"@")):    # (the reader would also accept a marker in mid-line here)
+        k += 1
+    while k < n:
+        name = lines[k][1:].split()[0].decode() if lines[k][1:].split() else ""
+        k += 1
+        parts = []
+        while k < n and lines[k][:1] not in (b">", b"@", b"+"):
+            ln = lines[k]
+            if len(ln) > 1 and ln.endswith(b"\r"):
+                ln = ln[:-1]
+            parts.append(ln)
+            k += 1
+        seq = b"".join(parts)
+        if k < n and lines[k][:1] == b"+":
+            k += 1
+            q = 0
+            while k < n and q < len(seq):
+                ln = lines[k]
+                if len(ln) > 1 and ln.endswith(b"\r"):
+                    ln = ln[:-1]
+                q += len(ln)
+                k += 1
+            if q != len(seq):
+                break                                       # truncated quality: the reader stops here
+            while k < n and not (lines[k][:1] in (b">", b"@")):
+                k += 1
+        tid = chrmap.setdefault(name, 0)
+        seqs.setdefault(tid, seq)
+    return seqs
+
+
+def _gc_count(tid, s, e):                                   # PD:3536-3538 + the loops `for (ii = Start-1; ii < End; ii++)`
+    b = _GC.get(tid, b"")[max(s - 1, 0):max(e, 0)]
+    return b.count(b"C") + b.count(b"c") + b.count(b"G") + b.count(b"g")
 
 
 def _add(genes, tid, gid, s, e):
     g = genes.setdefault(tid, {})
     if gid not in g:
         g[gid] = Gene(s, e)
+        if _GC is not None:                                 # only the entry that creates the id is counted (PD:3605-3611)
+            g[gid].gc = _gc_count(tid, s, e)
     else:
         x = g[gid]
         x.start = min(x.start, s); x.end = max(x.end, e)
@@ -202,10 +256,13 @@ def _lines(path):
     return raw.decode().split("\n")
 
 
-def parse_regions(path, mode, names, feature):
+def parse_regions(path, mode, names, feature, chrmap=None):
     """mode 1 GFF, 2 GTF, 3 BED3, 4 BED4.  Plain well-formed inputs only."""
     genes = {}
-    chrmap = {n: i for i, n in enumerate(names)}
+    if chrmap is None:
+        chrmap = {}
+        for i, n in enumerate(names):
+            chrmap.setdefault(n, i)
     for line in _lines(path):
         if not line or line[0] == "#":
             continue
@@ -358,11 +415,11 @@ def _select_sorted_stream(r, merged, flag_mask, min_mapq):  # PD:4608-4646
 def run(args, cwd="."):
     """Replay `pandepth <args>`; returns {suffix: text} for every file the reference writes."""
     o = {"i": None, "g": None, "b": None, "f": "CDS", "w": None, "a": False, "q": -1, "d": 1,
-         "x": 1796, "s": False}
+         "x": 1796, "s": False, "c": False, "r": None}
     k = 0
     while k < len(args):
         f = args[k].replace("-", "")
-        if f in ("a", "s"):
+        if f in ("a", "s", "c"):
             o[f] = True
         elif f in ("w", "q", "d", "x", "t"):
             o[f] = int(args[k + 1]); k += 1
@@ -384,7 +441,22 @@ def run(args, cwd="."):
         mode = _sniff_gff(os.path.join(cwd, o["g"]))
     elif o["b"]:
         mode = _sniff_bed(os.path.join(cwd, o["b"]))
-    genes = parse_regions(os.path.join(cwd, o["g"] or o["b"]), mode, names, o["f"]) if mode else {}
+    global _GC
+    chrmap = {}
+    for i, n in enumerate(names):
+        chrmap.setdefault(n, i)
+    if o["c"] and not o["r"]:
+        return {}                                           # PD:3530-3533: "lack reference sequence", exit 0, no output
+    gc = bool(o["c"])
+    _GC = read_fasta(os.path.join(cwd, o["r"]), chrmap) if gc else None
+    try:
+        return _run(o, cwd, files, is_list, first, names, lens, mode, chrmap, gc)
+    finally:
+        _GC = None
+
+
+def _run(o, cwd, files, is_list, first, names, lens, mode, chrmap, gc):
+    genes = parse_regions(os.path.join(cwd, o["g"] or o["b"]), mode, names, o["f"], chrmap) if mode else {}
     merged = merge_regions(genes)
     if not merged:
         if o["w"] == 0:
@@ -426,14 +498,23 @@ def run(args, cwd="."):
             rows.append("".join("%s\t%d\t%d\n" % (names[t], j, d[j]) for j in range(lens[t])))
         out["SiteDepth.gz"] = "".join(rows)
 
-    def footer(L, C, D):
+    def footer(L, C, D, G=0):
         if not L:      # PD:5122 divides 0.0 by 0.0: x86 SSE gives the NaN with the sign bit set, printf prints "-nan"
-            return "##RegionLength: 0\tCoveredSite: %d\tCoverage(%%): -nan\tMeanDepth: -nan\n" % C
+            return "##RegionLength: 0\tCoveredSite: %d\t%sCoverage(%%): -nan\tMeanDepth: -nan\n" % (
+                C, "GC(%): -nan\t" if gc else "")
         cov = C * 100.0 / L
         mean = D * 1.0 / L
-        return "##RegionLength: %d\tCoveredSite: %d\tCoverage(%%): %.2f\tMeanDepth: %.2f\n" % (L, C, cov, mean)
+        return "##RegionLength: %d\tCoveredSite: %d\t%sCoverage(%%): %.2f\tMeanDepth: %.2f\n" % (
+            L, C, "GC(%%): %.2f\t" % (G * 100.0 / L) if gc else "", cov, mean)      # PD:5005
 
-    SL = SC = SD = 0
+    def gccol(G, L):                                        # the extra column sits after TotalDepth (PD:4095-4114)
+        return "%.2f\t" % (G * 100.0 / L) if gc else ""
+
+    hgc = "GC(%)\t" if gc else ""
+    SL = SC = SD = SG = 0
+    if mode == 6 and gc:
+        # PD:4097 drops the sequences before PD:4327 indexes them: the reference prints whatever memory follows
+        raise NotImplementedError("-c with -w < 150: the reference's GC column is read from freed memory")
     if mode == 6:
         txt = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"
         for t in sorted(merged):
@@ -484,22 +565,23 @@ def run(args, cwd="."):
                     g.cover = 0; g.depth = 0
 
     if mode == 0:
-        txt = "#Chr\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"
+        txt = "#Chr\tLength\tCoveredSite\tTotalDepth\t%sCoverage(%%)\tMeanDepth\n" % hgc
         for t in sorted(genes):
             L = sum(g.length for g in genes[t].values())
             C = sum(g.cover for g in genes[t].values())
             D = sum(g.depth for g in genes[t].values())
-            txt += "%s\t%d\t%d\t%d\t%.2f\t%.2f\n" % (names[t], L, C, D, C * 100.0 / L, D * 1.0 / L)
-            SL += L; SC += C; SD += D
-        out["chr.stat.gz"] = txt + footer(SL, SC, SD)
+            G = sum(g.gc for g in genes[t].values())
+            txt += "%s\t%d\t%d\t%d\t%s%.2f\t%.2f\n" % (names[t], L, C, D, gccol(G, L), C * 100.0 / L, D * 1.0 / L)
+            SL += L; SC += C; SD += D; SG += G
+        out["chr.stat.gz"] = txt + footer(SL, SC, SD, SG)
         return out
 
     if mode == 5:
-        txt = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"
+        txt = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\t%sCoverage(%%)\tMeanDepth\n" % hgc
         suffix = "win.stat.gz"
     else:
-        txt = "#Chr\tStart\tEnd\t%s\tLength\tCoveredSite\tTotalDepth\tCoverage(%%)\tMeanDepth\n" % (
-            "RegionID" if mode == 3 else "GeneID")
+        txt = "#Chr\tStart\tEnd\t%s\tLength\tCoveredSite\tTotalDepth\t%sCoverage(%%)\tMeanDepth\n" % (
+            "RegionID" if mode == 3 else "GeneID", hgc)
         suffix = "bed.stat.gz" if mode in (3, 4) else "gene.stat.gz"
     for t in sorted(genes):
         ids = sorted(genes[t], key=lambda s: s.encode())
@@ -507,9 +589,9 @@ def run(args, cwd="."):
         for gid in ids:
             g = genes[t][gid]
             mid = "" if mode == 5 else gid + "\t"
-            txt += "%s\t%d\t%d\t%s%d\t%d\t%d\t%.2f\t%.2f\n" % (
-                names[t], g.start, g.end, mid, g.length, g.cover, g.depth,
+            txt += "%s\t%d\t%d\t%s%d\t%d\t%d\t%s%.2f\t%.2f\n" % (
+                names[t], g.start, g.end, mid, g.length, g.cover, g.depth, gccol(g.gc, g.length),
                 g.cover * 100.0 / g.length, g.depth * 1.0 / g.length)
-            SL += g.length; SC += g.cover; SD += g.depth
-    out[suffix] = txt + footer(SL, SC, SD)
+            SL += g.length; SC += g.cover; SD += g.depth; SG += g.gc
+    out[suffix] = txt + footer(SL, SC, SD, SG)
     return out

@@ -1,0 +1,32 @@
+// fasta.h — the reference sequence behind `-c -r ref.fa[.gz]`: the GC(%) column of every table.
+// The reference loads the whole file with klib's kseq reader into one string per contig id
+// (PD:3506-3529, PD:2067-2090 for lists) and counts C/c/G/g (PD:3536-3538).  Restated here with the
+// reader's observable rules: records start at '>' or '@', the name ends at the first white space, sequence
+// lines are concatenated (one trailing '\r' per line dropped) until a line starts with '>', '@' or '+';
+// '+' starts a FASTQ quality block of the same length.  Two quirks of the caller are kept:
+//   * a sequence name the alignment header does not know is looked up with `map::operator[]`, which
+//     ENTERS it into the name table as contig 0 — target rows naming it then land on contig 0;
+//   * the first sequence that claims a contig id wins.
+// Positions a sequence does not cover count as "not G/C" (the reference reads past its string there).
+#ifndef PD_FASTA_H_
+#define PD_FASTA_H_
+#include <stdint.h>
+#include <map>
+#include <string>
+
+namespace pdh {
+
+struct RefSeqs {
+    std::map<int32_t, std::string> seq;     // contig id -> bases
+    bool loaded = false;                    // RefIn
+    // number of C/c/G/g among the 1-based inclusive positions [first, last] of contig tid
+    uint64_t gc(int32_t tid, int64_t first, int64_t last) const;
+    void clear() { seq.clear(); }
+};
+
+// false when the file cannot be opened (the reference never returns from that: its reader spins on a
+// NULL gzFile); chr2tid gains the unknown names (-> 0)
+bool load_reference(const std::string &path, std::map<std::string, int32_t> *chr2tid, RefSeqs *out);
+
+} // namespace pdh
+#endif

@@ -1,5 +1,4 @@
-// options.h — the command-line surface of `pandepth` (-i -o -g -f -b -w -a -q -d -x -t -s -h;
-// -r/-c are accepted and ignored: GC content is outside this engine's scope).
+// options.h — the command-line surface of `pandepth` (-i -o -g -f -b -w -a -q -d -x -t -s -c -r -h).
 // Behaviour follows the reference's parser (PD:84-293) including its quirks: every '-' is
 // stripped from a flag, `*.list`/`*.List` expands to one input per non-empty line, -w < 1 and
 // -d < 1 clamp to 1, -o gets ".gz" appended and a trailing ".stat"/".bed" dropped later.
@@ -22,7 +21,7 @@ struct Options {
     int min_dep = 1;
     uint32_t flag_mask = 1796;
     int threads = 3;
-    std::string reference;            // -r (only its presence matters here: GC columns are not computed)
+    std::string reference;            // -r: FASTA behind -c's GC(%) column (host/fasta.h)
     int win = 0;
     bool site_out = false;               // -a
     bool use_index = true;               // hidden -s clears it

@@ -622,7 +622,7 @@ bool write_site_depth(const std::string &path, const AlnHeader &hdr, const Regio
     return out.close();
 }
 
-struct RowSums { uint64_t L = 0, C = 0, D = 0; };
+struct RowSums { uint64_t L = 0, C = 0, D = 0, G = 0; };
 
 // Rows [0, n) of one contig's table, formatted by up to `threads` threads in contiguous slices (3e7 rows for -w 100 on a
 // 3 Gb genome) and written in order.  `row(k, txt, sums)` appends row k and adds its three totals.
@@ -641,12 +641,14 @@ void write_rows(GzWriter &out, size_t n, int threads, RowSums *tot, F row)
     for (size_t s = 1; s < T; ++s) th.emplace_back(work, s);
     work(0);
     for (auto &x : th) x.join();
-    for (size_t s = 0; s < T; ++s) { out.write(txt[s]); tot->L += sums[s].L; tot->C += sums[s].C; tot->D += sums[s].D; }
+    for (size_t s = 0; s < T; ++s) { out.write(txt[s]); tot->L += sums[s].L; tot->C += sums[s].C; tot->D += sums[s].D; tot->G += sums[s].G; }
 }
 
-std::string footer(uint64_t L, uint64_t C, uint64_t D)
+// gc_sum < 0: no GC column (PD:5122); otherwise PD:5005
+std::string footer(uint64_t L, uint64_t C, uint64_t D, int64_t gc_sum = -1)
 {
-    return "##RegionLength: " + std::to_string(L) + "\tCoveredSite: " + std::to_string(C) + "\tCoverage(%): " +
+    return "##RegionLength: " + std::to_string(L) + "\tCoveredSite: " + std::to_string(C) +
+           (gc_sum >= 0 ? "\tGC(%): " + fmt2((uint64_t)gc_sum * 100.0 / L) : std::string()) + "\tCoverage(%): " +
            fmt2(C * 100.0 / L) + "\tMeanDepth: " + fmt2(D * 1.0 / L) + "\n";
 }
 
@@ -674,12 +676,18 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (o.gc) {
         // PD:3510-3532 (PD:2068-2090 for lists): -c needs -r, checked once the first input's header has been read
         if (o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }
-        std::cerr << "Warning: GC content (-c/-r) is not computed by this engine; columns are omitted." << std::endl;
     }
 
     tm.mark("options + header");
     RegionModel rm;
-    if (!build_regions(&o, hdr, &rm)) return 1;
+    RefSeqs ref;                                         // -c -r: the GC(%) column (PD:3506-3538); host-side text work
+    if (!build_regions(&o, hdr, &rm, o.gc ? &ref : nullptr, o.threads)) {
+        // the reference's reader never returns from a NULL gzFile; an error is the usable answer
+        std::cerr << "Error: Cannot open the reference sequence file: " << o.reference << std::endl;
+        return 1;
+    }
+    const bool gc = ref.loaded;
+    if (gc && o.mode != 6) ref.clear();                  // PD:4095-4097 (the bins and genes hold their counts by now)
     const bool synthetic = o.mode == 0 || o.mode == 5 || o.mode == 6;
 
     // output names (PD:4057-4090)
@@ -695,6 +703,10 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     else if (o.mode == 4) stat_path = prefix + ".bed.stat.gz";
     else if (o.mode == 5 || o.mode == 6) { stat_path = prefix + ".win.stat.gz"; header_line = "#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
     else if (o.mode == 0) { stat_path = prefix + ".chr.stat.gz"; header_line = "#Chr\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"; }
+    if (gc) {                                            // PD:4095-4114: one more column, after TotalDepth
+        const size_t at = header_line.find("\tCoverage(%)");
+        header_line.insert(at, "\tGC(%)");
+    }
     GzWriter OUT;
     OUT.set_threads(o.threads);                          // large tables: same bytes, LZ77 parse on all threads (host/pgzip.h)
     if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
@@ -798,7 +810,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     }
 
     const size_t nctg = hdr.lens.size();
-    uint64_t SL = 0, SC = 0, SD = 0;
+    uint64_t SL = 0, SC = 0, SD = 0, SG = 0;
     std::string txt;
 
     if (o.mode == 6) {
@@ -828,13 +840,21 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
                 const int32_t d = (int32_t)sum[base + k];             // `int GeneDepth` (PD:4364)
                 *row += nm; *row += '\t'; append_i64(row, j); *row += '\t'; append_i64(row, end);
                 *row += '\t'; append_i64(row, L); *row += '\t'; append_i64(row, c); *row += '\t';
-                append_i64(row, d); *row += '\t'; append_fmt2(row, c * 100.0 / L); *row += '\t'; append_fmt2(row, d * 1.0 / L);
+                append_i64(row, d); *row += '\t';
+                if (gc) {
+                    // PD:4327-4332.  The reference has dropped its sequences by now (PD:4097) and counts whatever
+                    // memory follows an empty string; the window's real G/C count is written here instead.
+                    const int32_t g = (int32_t)ref.gc((int32_t)t, j, end);
+                    append_fmt2(row, g * 100.0 / L); *row += '\t';
+                    rs->G += (uint64_t)(int64_t)g;
+                }
+                append_fmt2(row, c * 100.0 / L); *row += '\t'; append_fmt2(row, d * 1.0 / L);
                 *row += '\n';
                 rs->C += (uint64_t)(int64_t)c; rs->L += (uint64_t)L; rs->D += (uint64_t)(int64_t)d;
             });
         }
         SL += tot.L; SC += tot.C; SD += tot.D;
-        OUT.write(footer(SL, SC, SD));
+        OUT.write(footer(SL, SC, SD, gc ? (int64_t)tot.G : -1));
         tm.mark("scan + statistics + table text");
         OUT.close();
         tm.mark("table gzip");
@@ -922,11 +942,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     OUT.write(header_line);
     if (o.mode == 0) {
         for (auto &kv : rm.bins) {
-            uint64_t L = 0, C = 0, D = 0;
-            for (const Bin &b : kv.second) { L += (uint64_t)(b.end - b.start + 1); C += (uint64_t)(int64_t)b.cover; D += b.depth; }
-            SL += L; SC += C; SD += D;
+            uint64_t L = 0, C = 0, D = 0, G = 0;
+            for (const Bin &b : kv.second) { L += (uint64_t)(b.end - b.start + 1); C += (uint64_t)(int64_t)b.cover; D += b.depth; G += (uint64_t)(int64_t)b.gc; }
+            SL += L; SC += C; SD += D; SG += G;
             OUT.write(hdr.names[kv.first] + "\t" + std::to_string(L) + "\t" + std::to_string(C) + "\t" + std::to_string(D) +
-                      "\t" + fmt2(C * 100.0 / L) + "\t" + fmt2(D * 1.0 / L) + "\n");
+                      "\t" + (gc ? fmt2(G * 100.0 / L) + "\t" : std::string()) + fmt2(C * 100.0 / L) + "\t" + fmt2(D * 1.0 / L) + "\n");
         }
     } else if (o.mode == 5) {
         RowSums tot;
@@ -936,13 +956,14 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             write_rows(OUT, bins.size(), o.threads, &tot, [&](size_t k, std::string *row, RowSums *rs) {
                 const Bin &b = bins[k];
                 const uint64_t L = (uint64_t)(b.end - b.start + 1);
-                rs->C += (uint64_t)(int64_t)b.cover; rs->L += L; rs->D += b.depth;
+                rs->C += (uint64_t)(int64_t)b.cover; rs->L += L; rs->D += b.depth; rs->G += (uint64_t)(int64_t)b.gc;
                 *row += chr; *row += '\t'; append_i64(row, b.start); *row += '\t'; append_i64(row, b.end); *row += '\t';
                 append_u64(row, L); *row += '\t'; append_i64(row, b.cover); *row += '\t'; append_u64(row, b.depth);
+                if (gc) { *row += '\t'; append_fmt2(row, b.gc * 100.0 / L); }
                 *row += '\t'; append_fmt2(row, b.cover * 100.0 / L); *row += '\t'; append_fmt2(row, b.depth * 1.0 / L); *row += '\n';
             });
         }
-        SL += tot.L; SC += tot.C; SD += tot.D;
+        SL += tot.L; SC += tot.C; SD += tot.D; SG += tot.G;
     } else {
         for (auto &kv : rm.genes) {
             // rows by start; equal starts keep the id order of the map (PD:5032-5041)
@@ -950,11 +971,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             const std::string &chr = hdr.names[kv.first];
             for (auto &g : kv.second) {
                 const Gene &x = g.second;
-                SC += (uint64_t)(int64_t)x.cover; SL += x.length; SD += x.depth;
+                SC += (uint64_t)(int64_t)x.cover; SL += x.length; SD += x.depth; SG += (uint64_t)(int64_t)x.gc;
                 std::string row = chr + "\t" + std::to_string(x.start) + "\t" + std::to_string(x.end) + "\t";
                 if (o.mode != 5) { row += g.first; row += '\t'; }
                 row += std::to_string(x.length) + "\t" + std::to_string(x.cover) + "\t" + std::to_string(x.depth) + "\t" +
-                       fmt2(x.cover * 100.0 / x.length) + "\t" + fmt2(x.depth * 1.0 / x.length);
+                       (gc ? fmt2(x.gc * 100.0 / x.length) + "\t" : std::string()) + fmt2(x.cover * 100.0 / x.length) + "\t" + fmt2(x.depth * 1.0 / x.length);
                 auto it = rows.find(x.start);
                 if (it == rows.end()) rows.emplace(x.start, row);
                 else { it->second += "\n"; it->second += row; }
@@ -964,7 +985,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             OUT.write(txt);
         }
     }
-    OUT.write(footer(SL, SC, SD));
+    OUT.write(footer(SL, SC, SD, gc ? (int64_t)SG : -1));
     tm.mark("table text");
     OUT.close();
     tm.mark("table gzip");

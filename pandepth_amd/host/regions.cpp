@@ -1,8 +1,10 @@
 // regions.cpp — see regions.h
 #include "regions.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 namespace pdh {
 
@@ -27,11 +29,16 @@ void erase_all(std::string *s, char c)
     s->resize(w);
 }
 
+const RefSeqs *g_ref = nullptr;            // set for the duration of one build_regions call
+
 void add_entry(RegionModel *rm, int32_t tid, const std::string &id, long long start, long long end)
 {
     Gene &g = rm->genes[tid][id];
     const int32_t s = (int32_t)start, e = (int32_t)end;
-    if (g.cds.empty()) { g.start = s; g.end = e; }
+    if (g.cds.empty()) {
+        g.start = s; g.end = e;
+        if (g_ref) g.gc = (int32_t)g_ref->gc(tid, (int32_t)start, (int32_t)end);      // `for (int ii = Start-1; ii < End; ii++)`
+    }
     else { if (g.start > s) g.start = s; if (g.end < e) g.end = e; }
     g.length += (uint64_t)(end - start + 1);
     g.cds.emplace_back(s, e);
@@ -64,10 +71,12 @@ static void merge_spans(RegionModel *rm)
     }
 }
 
-bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref, int threads)
 {
     std::map<std::string, int32_t> chr2tid;
     for (size_t i = 0; i < hdr.names.size(); ++i) chr2tid.insert({hdr.names[i], (int32_t)i});   // first name wins
+    if (ref && !load_reference(o->reference, &chr2tid, ref)) return false;
+    struct RefScope { RefScope(const RefSeqs *r) { g_ref = r; } ~RefScope() { g_ref = nullptr; } } ref_scope(ref);
 
     if (o->mode != 0) {
         std::vector<std::string> lines;
@@ -158,6 +167,21 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm)
                 m->emplace_back((int32_t)start, (int32_t)end);
                 end += 2;
             }
+        }
+        if (ref) {
+            // PD:4017-4023: every bin counts its own bases; whole-genome passes, so spread over the threads
+            std::vector<Bin *> all;
+            for (auto &kv : rm->bins) for (Bin &b : kv.second) all.push_back(&b);
+            std::vector<int32_t> tid_of;
+            for (auto &kv : rm->bins) tid_of.insert(tid_of.end(), kv.second.size(), kv.first);
+            const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), all.size()));
+            auto work = [&](size_t s) {
+                for (size_t k = s; k < all.size(); k += T) all[k]->gc = (int32_t)ref->gc(tid_of[k], all[k]->start, all[k]->end);
+            };
+            std::vector<std::thread> th;
+            for (size_t s = 1; s < T; ++s) th.emplace_back(work, s);
+            work(0);
+            for (auto &x : th) x.join();
         }
     }
     return true;

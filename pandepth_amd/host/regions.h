@@ -11,6 +11,7 @@
 #include <vector>
 #include "bam.h"
 #include "options.h"
+#include "fasta.h"
 
 namespace pdh {
 
@@ -20,9 +21,11 @@ struct Gene {
     std::vector<std::pair<int32_t, int32_t>> cds;     // entries in file order
     int32_t cover = 0;                                // filled by the pipeline
     uint64_t depth = 0;
+    int32_t gc = 0;                                   // -c: G/C bases of the entry that CREATED the id (PD:3605-3611: later
+                                                      // entries of the same id add to length but never to GeneGCGC)
 };
 
-struct Bin { int32_t start, end; int32_t cover = 0; uint64_t depth = 0; };   // one synthetic bin (1-based inclusive)
+struct Bin { int32_t start, end; int32_t cover = 0; uint64_t depth = 0; int32_t gc = 0; };   // one synthetic bin (1-based inclusive)
 
 struct RegionModel {
     std::map<int32_t, std::map<std::string, Gene>> genes;           // tid -> id -> Gene (GFF/GTF/BED targets)
@@ -35,8 +38,10 @@ struct RegionModel {
 };
 
 // Parses o->region_file according to o->mode (1..4); on return, if no region survived, builds the
-// synthetic bins and sets o->mode to 0 / 5 / 6 (PD:3974-4051).  Returns false on an unreadable file.
-bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm);
+// synthetic bins and sets o->mode to 0 / 5 / 6 (PD:3974-4051).  With `ref` (-c -r) the sequences are loaded first
+// (their names join the contig-name table, see fasta.h) and every gene / bin gets its G/C count.
+// Returns false on an unreadable reference file.
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref = nullptr, int threads = 1);
 
 } // namespace pdh
 #endif

@@ -13,6 +13,7 @@ manifest with sha256 of the gz bytes and of the decompressed text).  No referenc
 copied.  Re-running this script must reproduce the committed files bit for bit.
 
     python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py f5         # regenerate the named fixtures only
 """
 import gzip
 import hashlib
@@ -404,6 +405,83 @@ F4_CASES = [
     ("w200", ["-i", "e.bam", "-w", "200"]),
 ]
 
+# ---------------------------------------------------------------------------------------------
+# F5: the GC(%) column (-c -r): FASTA with lower case / N / comments / CRLF / blank lines / a gzip copy, a sequence
+# name the BAM header does not know (it becomes contig 0 in the reference's name table), multi-entry ids (only the
+# entry that creates an id is counted)
+# ---------------------------------------------------------------------------------------------
+F5_CONTIGS = [("g1", 1500), ("g2", 700), ("g3", 1), ("g4", 301)]
+
+
+def build_f5(d):
+    os.makedirs(d, exist_ok=True)
+    rng = random.Random(505)
+    recs = []
+    for i in range(1200):
+        ci = rng.choice([0, 0, 1, 3])
+        ln = F5_CONTIGS[ci][1]
+        cig = rng.choice(["40M", "15M3D25M", "8S32M", "20M60N20M", "25M2I13M", "40="])
+        span = cigar_ref_span(cig)
+        pos1 = rng.randint(1, ln - span + 1)
+        recs.append((ci, pos1, rng.choice([0, 16, 0, 16, 1024, 256]), rng.choice([0, 20, 60]), cig))
+    for nm, sel in (("c", recs), ("c2", recs[:500])):
+        srt = sorted(range(len(sel)), key=lambda k: (sel[k][0], sel[k][1], k))
+        sam = sam_header(F5_CONTIGS, True)
+        for k in srt:
+            ci, pos1, flag, mapq, cig = sel[k]
+            sam += sam_line(k, flag, F5_CONTIGS[ci][0], pos1, mapq, cig)
+        write(os.path.join(d, nm + ".sam"), sam)
+        to_bam(os.path.join(d, nm + ".sam"), os.path.join(d, nm + ".bam"), True)
+    os.remove(os.path.join(d, "c2.sam"))
+    shutil.copy(os.path.join(d, "c.bam"), os.path.join(d, "c_noidx.bam"))
+    write(os.path.join(d, "c.list"), "c.bam\nc2.bam\n")
+    fa = ""
+    for name, ln in F5_CONTIGS + [("extra", 90)]:
+        seq = "".join(rng.choice("ACGTACGTacgtNnRY") for _ in range(ln + (25 if name == "g2" else 0)))   # g2: longer than its contig
+        fa += ">%s%s\n" % (name, {"g1": " primary assembly", "g2": "\tlen=700"}.get(name, ""))
+        width = {"g1": 60, "g2": 70, "g3": 60, "g4": 50, "extra": 30}[name]
+        for k in range(0, len(seq), width):
+            fa += seq[k:k + width] + ("\r\n" if name == "g4" else "\n")
+            if name == "g1" and k == 600:
+                fa += "\n"                                # an empty line inside a record
+    with open(os.path.join(d, "c.fa"), "wb") as f:
+        f.write(fa.encode())
+    with open(os.path.join(d, "c.fa.gz"), "wb") as f:
+        f.write(gzip.compress(fa.encode(), mtime=0))
+    write(os.path.join(d, "c.gff"), "\n".join([
+        "g1\ts\tCDS\t100\t180\t.\t+\t0\tID=a;Parent=t1", "g1\ts\tCDS\t300\t420\t.\t+\t0\tID=b;Parent=t1",
+        "g1\ts\tCDS\t1400\t1500\t.\t+\t0\tID=c;Parent=t2", "g1\ts\texon\t90\t200\t.\t+\t.\tID=x;Parent=t1",
+        "g2\ts\tCDS\t1\t700\t.\t-\t0\tID=d;Parent=u1", "g2\ts\tCDS\t650\t700\t.\t-\t0\tID=e;Parent=u1",
+        "g4\ts\tCDS\t10\t300\t.\t+\t0\tID=f;Parent=v1", "extra\ts\tCDS\t5\t60\t.\t+\t0\tID=g;Parent=w1",
+        "nowhere\ts\tCDS\t5\t60\t.\t+\t0\tID=h;Parent=w2"]) + "\n")
+    write(os.path.join(d, "c.gtf"), "\n".join([
+        'g1\ts\tCDS\t100\t180\t.\t+\t0\tgene_id "G1"; transcript_id "T1";',
+        'g1\ts\tCDS\t300\t420\t.\t+\t0\tgene_id "G1"; transcript_id "T1";',
+        'g2\ts\tCDS\t20\t90\t.\t-\t0\tgene_id "G2"; transcript_id "T2";']) + "\n")
+    write(os.path.join(d, "c.bed3"), "g1\t1\t1500\ng1\t700\t800\ng2\t350\t350\nextra\t10\t20\ng4\t1\t301\n")
+    write(os.path.join(d, "c.bed4"), "g1\t1\t100\tA\ng1\t500\t900\tA\ng1\t50\t60\tB\ng2\t1\t700\tC\ng4\t100\t200\tD\n")
+
+
+F5_CASES = [
+    ("chr", ["-i", "c.bam", "-c", "-r", "c.fa"]),
+    ("chr_gz", ["-i", "c.bam", "-c", "-r", "c.fa.gz"]),
+    ("chr_sam", ["-i", "c.sam", "-c", "-r", "c.fa"]),
+    ("chr_noidx", ["-i", "c_noidx.bam", "-c", "-r", "c.fa"]),
+    ("chr_s_a", ["-i", "c.bam", "-s", "-a", "-c", "-r", "c.fa"]),
+    ("chr_list", ["-i", "c.list", "-c", "-r", "c.fa"]),
+    ("w150", ["-i", "c.bam", "-w", "150", "-c", "-r", "c.fa"]),
+    ("w400_d5", ["-i", "c.bam", "-w", "400", "-d", "5", "-c", "-r", "c.fa.gz"]),
+    ("w250_list", ["-i", "c.list", "-w", "250", "-c", "-r", "c.fa"]),
+    ("gff", ["-i", "c.bam", "-g", "c.gff", "-c", "-r", "c.fa"]),
+    ("gff_exon", ["-i", "c.bam", "-g", "c.gff", "-f", "exon", "-c", "-r", "c.fa"]),
+    ("gff_list_a", ["-i", "c.list", "-g", "c.gff", "-a", "-c", "-r", "c.fa"]),
+    ("gtf", ["-i", "c.bam", "-g", "c.gtf", "-c", "-r", "c.fa"]),
+    ("bed3", ["-i", "c.bam", "-b", "c.bed3", "-c", "-r", "c.fa"]),
+    ("bed4", ["-i", "c.bam", "-b", "c.bed4", "-c", "-r", "c.fa", "-q", "20"]),
+    ("bed4_noidx", ["-i", "c_noidx.bam", "-b", "c.bed4", "-c", "-r", "c.fa"]),
+    ("r_only", ["-i", "c.bam", "-r", "c.fa"]),                    # -r without -c: no GC column
+]
+
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
 
 
@@ -438,8 +516,13 @@ def main():
     if not (os.path.exists(REF) and os.path.exists(SAM2BAM)):
         sys.exit("build the reference oracle first: make -C oracle ref")
     manifest = []
+    only = sys.argv[1:]                                  # e.g. `make_golden.py f5`: rebuild these, keep the other entries
+    if only:
+        manifest = [e for e in json.load(open(os.path.join(HERE, "manifest.json"))) if e["fixture"] not in only]
     for fx, build, cases in (("f1", build_f1, F1_CASES), ("f2", build_f2, F2_CASES),
-                             ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES)):
+                             ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES), ("f5", build_f5, F5_CASES)):
+        if only and fx not in only:
+            continue
         d = os.path.join(HERE, fx)
         build(d)
         run_cases(fx, d, cases, manifest)

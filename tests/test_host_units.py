@@ -170,3 +170,42 @@ def test_csi_index_is_used_like_bai(cli, tmp_path, golden_dir):
         p = run(cli, ["-i", "tiny.bam", "-o", name, "-t", "3"] + args, tmp_path)
         assert p.stdout.decode() == man[name]["stdout"]          # no "No Index mode" warning
         assert hashlib.sha256((tmp_path / (name + "." + suffix)).read_bytes()).hexdigest() == man[name]["outputs"][suffix]["gz_sha256"]
+
+
+def test_gc_column_of_small_windows_is_the_real_count(cli, tmp_path, golden_dir):
+    """-c with -w < 150: the reference frees its sequences before the sweep reads them (PD:4097 / PD:4327) and prints
+    heap contents; here the column holds the window's G/C count.  Every other column equals the run without -c, and the
+    per-window counts add up to the whole-chromosome table's (which IS pinned against the reference, fixture f5)."""
+    f5 = os.path.join(golden_dir, "f5")
+    for fn in ("c.bam", "c.bam.bai", "c.fa"):
+        os.symlink(os.path.join(f5, fn), tmp_path / fn)
+    run(cli, ["-i", "c.bam", "-o", "g", "-w", "100", "-c", "-r", "c.fa"], tmp_path)
+    run(cli, ["-i", "c.bam", "-o", "n", "-w", "100"], tmp_path)
+    g = [l.split("\t") for l in stat(tmp_path / "g.win.stat.gz").strip().split("\n")]
+    n = [l.split("\t") for l in stat(tmp_path / "n.win.stat.gz").strip().split("\n")]
+    assert g[0][6] == "GC(%)" and [x[:6] + x[7:] for x in g[:-1]] == n[:-1]
+    seqs, name = {}, None
+    for line in open(os.path.join(f5, "c.fa"), "rb").read().decode().split("\n"):
+        line = line.rstrip("\r")
+        if line.startswith(">"):
+            name = line[1:].split()[0]; seqs[name] = ""
+        elif name:
+            seqs[name] += line
+    total = 0
+    for row in g[1:-1]:
+        s = seqs[row[0]][int(row[1]) - 1:int(row[2])]
+        cnt = sum(s.count(c) for c in "CcGg")
+        total += cnt
+        assert row[6] == "%.2f" % (cnt * 100.0 / int(row[3]))
+    L = sum(int(r[3]) for r in g[1:-1])
+    assert g[-1][2] == "GC(%%): %.2f" % (total * 100.0 / L)
+
+
+def test_gc_needs_a_readable_reference(cli, tmp_path, golden_dir):
+    f5 = os.path.join(golden_dir, "f5")
+    os.symlink(os.path.join(f5, "c.bam"), tmp_path / "c.bam")
+    p = subprocess.run([cli, "-i", "c.bam", "-o", "x", "-c", "-r", "missing.fa"], cwd=tmp_path, capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"Cannot open the reference sequence file" in p.stderr     # (the reference spins forever here)
+    p = subprocess.run([cli, "-i", "c.bam", "-o", "x", "-c"], cwd=tmp_path, capture_output=True, timeout=60)
+    assert p.returncode == 0 and b"lack reference sequence (-r) for GC parse" in p.stderr    # PD:3530-3533
+    assert not os.path.exists(tmp_path / "x.chr.stat.gz")

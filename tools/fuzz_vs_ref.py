@@ -130,6 +130,48 @@ def gen_regions(rng, names, lens, kind):
     return "\n".join(lines) + ("\n" if rng.random() < 0.9 else "")
 
 
+def gen_fasta(rng, names, lens):
+    """-r for -c: every contig present and at least as long as the header says (beyond a sequence's end, and for a contig
+    without a sequence, the reference indexes past its string — undefined, not generated); lower case, N / IUPAC codes,
+    header comments, CRLF, blank lines, FASTQ-style records, a second record of the same name (the first wins), names
+    the alignment header does not know (they become contig 0 in the name table — fixture f5 pins what target rows naming them do; here they are names no target row uses, placed after contig 0's own record, or
+    contig 0 would get a foreign, possibly shorter sequence)."""
+    recs = []
+    order = list(range(len(names)))
+    if rng.random() < 0.5:
+        rng.shuffle(order)
+    for t in order:
+        L = lens[t] + rng.choice([0, 0, 0, 1, 37])
+        alpha = rng.choice(["ACGT", "ACGTacgt", "ACGTNacgtnRYKM", "GGCCAT", "at"])
+        if L > 200000:
+            blocks = ["".join(rng.choice(alpha) for _ in range(1000)) for _ in range(8)]
+            seq = "".join(rng.choice(blocks) for _ in range(L // 1000 + 1))[:L]
+        else:
+            seq = "".join(rng.choice(alpha) for _ in range(L))
+        recs.append((names[t], seq))
+        if rng.random() < 0.1:
+            recs.append((names[t], "G" * min(L, 50)))           # a later record of the same name is ignored
+    if rng.random() < 0.3:
+        k0 = [i for i, r in enumerate(recs) if r[0] == names[0]][0]
+        recs.insert(rng.randrange(k0 + 1, len(recs) + 1), (rng.choice(["alien", "other"]), "ACGT" * rng.randrange(1, 30)))
+    eol = rng.choice(["\n", "\n", "\n", "\r\n"])
+    out = []
+    for name, seq in recs:
+        if len(seq) < 5000 and rng.random() < 0.1:
+            out.append("@%s%s%s%s+%s%s%s" % (name, rng.choice(["", " q"]), eol, seq + eol if seq else eol, eol,
+                                         "".join(rng.choice("@>+IIIF#") for _ in seq), eol))
+            continue
+        w = rng.choice([50, 60, 70, 80, 1000, 10 ** 9])
+        body = eol.join(seq[k:k + w] for k in range(0, len(seq), w))
+        if rng.random() < 0.1 and len(seq) > w:
+            body = body.replace(eol, eol + "\n", 1)              # an empty line inside the record
+        out.append(">%s%s%s%s%s" % (name, rng.choice(["", "", " some comment", "\tx=1"]), eol, body, eol))
+    text = "".join(out)
+    if rng.random() < 0.1 and text.endswith(eol):
+        text = text[:-len(eol)]                             # no line end after the last line of the file
+    return text
+
+
 S2B = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
 
 
@@ -208,6 +250,21 @@ def one_case(rng, td):
         args += ["-s"]
     if rng.random() < 0.5:
         args += ["-t", str(rng.choice([1, 2, 5]))]
+    # -c -r: the GC(%) column.  Not with a window below 150: the reference frees its sequences before that sweep reads them
+    # (PD:4097 / PD:4327) and prints what the heap holds.
+    small_w = "-w" in args and int(args[args.index("-w") + 1]) < 150
+    if rng.random() < 0.25 and not small_w:
+        import gzip
+        fa = gen_fasta(rng, names, lens)
+        fn = "genome.fa"
+        if rng.random() < 0.25:
+            fn += ".gz"
+            gzip.open(os.path.join(td, fn), "wb", compresslevel=1).write(fa.encode())
+        else:
+            open(os.path.join(td, fn), "wb").write(fa.encode())
+        args += ["-r", fn] + (["-c"] if rng.random() < 0.9 else [])
+    elif rng.random() < 0.03:
+        args += ["-c"]                                    # -c without -r: the message, rc 0, no output
     return args
 
 
