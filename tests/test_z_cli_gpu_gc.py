@@ -1,0 +1,34 @@
+"""GPU end-to-end parity of the GC(%) column cases (fixture f5: `-c -r ref.fa`): the same three checks as
+tests/test_cli_gpu.py — plain, GPU-side BAM decode, `#.list` over two contexts — on the cases that carry the extra column.
+Kept in a file that sorts last: these cases were added after the last GPU run of their round."""
+import os
+
+import pytest
+
+import test_cli_gpu as T
+
+pytestmark = pytest.mark.gpu
+
+F5 = [e for e in T.ALL_CASES if e["fixture"] == "f5"]
+ID = dict(ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("case", F5, **ID)
+def test_gc_cases_byte_identical(case, threads, tmp_path):
+    T.test_pandepth_cli_byte_identical(case, threads, tmp_path)
+
+
+DD = [e for e in F5 if "-g" not in e["args"] and "-b" not in e["args"] and "-s" not in e["args"]
+      and e["args"][1].endswith(".bam") and "noidx" not in e["args"][1]]
+
+
+@pytest.mark.parametrize("batch_mb", ["", "1"])
+@pytest.mark.parametrize("case", DD, **ID)
+def test_gc_cases_device_decode_byte_identical(case, batch_mb, tmp_path):
+    T.test_pandepth_cli_device_decode_byte_identical(case, batch_mb, tmp_path)
+
+
+@pytest.mark.parametrize("case", [e for e in F5 if ".list" in e["args"][1]], **ID)
+def test_gc_cases_list_over_two_contexts(case, tmp_path):
+    T.test_pandepth_cli_list_over_two_contexts(case, tmp_path)
