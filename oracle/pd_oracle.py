@@ -189,7 +189,7 @@ class Gene:
 _GC = None                                                  # {tid: bytes} while a -c run builds its regions
 
 
-def read_fasta(path, chrmap):
+def read_fasta(path, chrmap, keep_all=False):
     """PD:3506-3529 (klib kseq records): '>' or '@' starts a record, the name ends at the first white space, sequence
     lines are joined until a line starts with '>', '@' or '+'; '+' opens a quality block as long as the sequence.
     Returns {tid: sequence}; a name the header does not know becomes contig 0 IN `chrmap` (map::operator[]), and the
@@ -227,9 +227,12 @@ def read_fasta(path, chrmap):
                 break                                       # truncated quality: the reader stops here
             while k < n and not (lines[k][:1] in (b">", b"@")):
                 k += 1
+        if keep_all:
+            seqs.setdefault("all", []).append((name, seq))
+            continue
         tid = chrmap.setdefault(name, 0)
         seqs.setdefault(tid, seq)
-    return seqs
+    return seqs.get("all", []) if keep_all else seqs
 
 
 def _gc_count(tid, s, e):                                   # PD:3536-3538 + the loops `for (ii = Start-1; ii < End; ii++)`
@@ -433,6 +436,8 @@ def run(args, cwd="."):
     is_list = path.endswith(".list") or path.endswith(".List")
     files = [os.path.join(cwd, l) for l in _lines(path) if l] if is_list else [path]
     is_list = len(files) > 1
+    if is_paf(files[0]):                                    # PD:3466-3479: the first input's extension decides
+        return _run_paf_front(o, cwd, files, is_list)
     first = read_alignments(files[0])
     names, lens = first.names, first.lens
 
@@ -455,7 +460,78 @@ def run(args, cwd="."):
         _GC = None
 
 
-def _run(o, cwd, files, is_list, first, names, lens, mode, chrmap, gc):
+def is_paf(path):
+    if path.endswith(".gz"):
+        path = path[:-3]
+    return path.endswith(".paf") or path.endswith(".PAF")
+
+
+def _run_paf_front(o, cwd, files, is_list):
+    """paf_main (PD:852-2024): targets from -r's records (ids in file order, the GC column then always on) or from
+    columns 6/7 of the first file; depth from [tstart-1, tend) or the cg:Z: walk; 18-bit cells; the shared tables."""
+    global _GC
+    if o["c"] and not o["r"]:
+        return {}                                           # PD:909-913
+    names, lens, chrmap, seqs = [], [], {}, {}
+    if o["r"]:
+        tmp = {}
+        raw = read_fasta(os.path.join(cwd, o["r"]), tmp, keep_all=True)
+        for tid, (nm, sq) in enumerate(raw):
+            chrmap[nm] = tid; names.append(nm); lens.append(len(sq)); seqs[tid] = sq
+    else:
+        for line in _lines(files[0]):
+            f = line.split()
+            if len(f) >= 7 and f[5] not in chrmap:          # (well-formed lines only)
+                chrmap[f[5]] = len(names); names.append(f[5]); lens.append(int(f[6]))
+    mode = 0
+    if o["g"]:
+        mode = _sniff_gff(os.path.join(cwd, o["g"]))
+    elif o["b"]:
+        mode = _sniff_bed(os.path.join(cwd, o["b"]))
+    gc = bool(o["r"])
+    if gc and not o["c"]:
+        raise NotImplementedError("PAF with -r but without -c: the reference counts G/C in strings it never filled")
+    _GC = seqs if gc else None
+    try:
+        return _run(o, cwd, files, is_list, None, names, lens, mode, chrmap, gc, paf=True)
+    finally:
+        _GC = None
+
+
+def _paf_depth(files, o, chrmap, depth, off, lens):           # PD:1532-1616
+    for fp in files:
+        for line in _lines(fp):
+            if not line:
+                continue
+            if (o["x"] & 0x100) and "tp:A:S" in line:
+                continue
+            f = line.replace("\t", " ").split(" ")
+            f = [x for x in f if x]
+            tid = chrmap.setdefault(f[5], 0)
+            if int(f[11]) < o["q"]:
+                continue
+            s, e = int(f[7]), int(f[8])
+            if s > e:
+                s, e = e, s
+            cg = [k for k, x in enumerate(f) if x.startswith("cg:Z:")]
+            base = int(off[tid])
+            if cg and cg[0] > 1:
+                n = ""
+                for ch in f[cg[0]][5:]:
+                    if ch.isdigit():
+                        n += ch
+                        continue
+                    k = int(n); n = ""
+                    if ch in "M=X":
+                        depth[base + s:base + s + k] += 1       # (inside the target for the inputs replayed here)
+                        s += k
+                    elif ch in "DN":
+                        s += k
+            else:
+                depth[base + max(s - 1, 0):base + e] += 1
+
+
+def _run(o, cwd, files, is_list, first, names, lens, mode, chrmap, gc, paf=False):
     genes = parse_regions(os.path.join(cwd, o["g"] or o["b"]), mode, names, o["f"], chrmap) if mode else {}
     merged = merge_regions(genes)
     if not merged:
@@ -471,7 +547,10 @@ def _run(o, cwd, files, is_list, first, names, lens, mode, chrmap, gc):
     off = contig_offsets(lens)
     depth = np.zeros(int(off[-1]), dtype=np.uint32)
     wrap = is_list
-    for fp in files:
+    if paf:
+        _paf_depth(files, o, chrmap, depth, off, lens)
+        wrap = True
+    for fp in ([] if paf else files):
         r = first if fp == files[0] else read_alignments(fp)
         has_index = any(os.path.exists(fp + e) for e in (".bai", ".csi", ".crai")) and not o["s"]
         if has_index:

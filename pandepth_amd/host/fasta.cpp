@@ -45,13 +45,12 @@ struct Bytes {
 
 } // namespace
 
-bool load_reference(const std::string &path, std::map<std::string, int32_t> *chr2tid, RefSeqs *out)
+bool read_fasta_records(const std::string &path, const std::function<void(const std::string &, std::string &)> &rec)
 {
     gzFile g = gzopen(path.c_str(), "r");
     if (!g) return false;
     gzbuffer(g, 1u << 20);
     Bytes in(g);
-    out->loaded = true;
     int last = 0;                                        // header character already consumed
     std::string name, seq, qual;
     for (;;) {
@@ -89,15 +88,23 @@ bool load_reference(const std::string &path, std::map<std::string, int32_t> *chr
             }
         }
         if (!ok) break;                                  // kseq_read < 0 ends the caller's loop
+        rec(name, seq);
+    }
+    gzclose(g);
+    return true;
+}
+
+bool load_reference(const std::string &path, std::map<std::string, int32_t> *chr2tid, RefSeqs *out)
+{
+    out->loaded = true;
+    return read_fasta_records(path, [&](const std::string &name, std::string &seq) {
         const size_t z = seq.find('\0');                 // `string seqBB = seq->seq.s` stops at a NUL
         if (z != std::string::npos) seq.resize(z);
         auto it = chr2tid->find(name);
         int32_t id = 0;
         if (it == chr2tid->end()) (*chr2tid)[name] = 0; else id = it->second;
-        out->seq.insert({id, seq});                      // first claim wins
-    }
-    gzclose(g);
-    return true;
+        if (out->seq.find(id) == out->seq.end()) out->seq.emplace(id, std::move(seq));      // first claim wins
+    });
 }
 
 uint64_t RefSeqs::gc(int32_t tid, int64_t first, int64_t last) const

@@ -11,6 +11,7 @@
 #ifndef PD_FASTA_H_
 #define PD_FASTA_H_
 #include <stdint.h>
+#include <functional>
 #include <map>
 #include <string>
 
@@ -23,6 +24,10 @@ struct RefSeqs {
     uint64_t gc(int32_t tid, int64_t first, int64_t last) const;
     void clear() { seq.clear(); }
 };
+
+// every record of a FASTA/FASTQ file (plain or gzip) in file order: rec(name, sequence); the callback may move from the
+// sequence.  false when the file cannot be opened.
+bool read_fasta_records(const std::string &path, const std::function<void(const std::string &, std::string &)> &rec);
 
 // false when the file cannot be opened (the reference never returns from that: its reader spins on a
 // NULL gzFile); chr2tid gains the unknown names (-> 0)

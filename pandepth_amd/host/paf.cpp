@@ -1,0 +1,155 @@
+// paf.cpp — see paf.h
+#include "paf.h"
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include <sstream>
+#include <vector>
+
+namespace pdh {
+
+namespace {
+
+// lines of a plain or gzip file, the way `while (!in.eof()) getline(in, line)` sees them, without holding the file
+struct GzLines {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t beg = 0, end = 0;
+    bool eof = false;
+    explicit GzLines(const std::string &path) : buf((size_t)1 << 20)
+    {
+        f = gzopen(path.c_str(), "rb");
+        if (f) gzbuffer(f, 1u << 20);
+    }
+    ~GzLines() { if (f) gzclose(f); }
+    bool next(std::string *line)
+    {
+        line->clear();
+        if (!f) return false;
+        bool any = false;
+        for (;;) {
+            if (beg >= end) {
+                if (eof) return any;
+                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                if (n <= 0) { eof = true; return any; }
+                beg = 0; end = (size_t)n;
+            }
+            any = true;
+            const char *p = (const char *)memchr(buf.data() + beg, '\n', end - beg);
+            if (p) { line->append(buf.data() + beg, (size_t)(p - (buf.data() + beg))); beg = (size_t)(p - buf.data()) + 1; return true; }
+            line->append(buf.data() + beg, end - beg);
+            beg = end;
+        }
+    }
+};
+
+void split_ws(const std::string &s, std::vector<std::pair<const char *, size_t>> *tok)
+{
+    tok->clear();
+    const char *p = s.data(), *e = p + s.size();
+    while (p < e) {
+        while (p < e && (*p == ' ' || *p == '\t')) ++p;
+        if (p >= e) break;
+        const char *b = p;
+        while (p < e && *p != ' ' && *p != '\t') ++p;
+        tok->emplace_back(b, (size_t)(p - b));
+    }
+}
+
+} // namespace
+
+bool is_paf_path(const std::string &path)
+{
+    auto ext_of = [](const std::string &p) { const size_t d = p.rfind('.'); return d == std::string::npos ? std::string() : p.substr(d + 1); };
+    std::string ext = ext_of(path);
+    if (ext == "gz") ext = ext_of(path.substr(0, path.rfind('.')));
+    return ext == "paf" || ext == "PAF";
+}
+
+bool paf_targets(const Options &o, AlnHeader *hdr, std::map<std::string, int32_t> *chr2tid, RefSeqs *ref)
+{
+    hdr->names.clear(); hdr->lens.clear(); chr2tid->clear();
+    if (!o.reference.empty()) {
+        // PD:873-907: one target per FASTA record, ids in file order; a repeated name keeps both targets and the
+        // name points at the later one.  (Without -c the reference still switches its GC column on and then counts
+        // in strings it never filled; the sequences are kept here either way and the column is real.)
+        ref->loaded = true;
+        return read_fasta_records(o.reference, [&](const std::string &name, std::string &seq) {
+            const int32_t id = (int32_t)hdr->names.size();
+            (*chr2tid)[name] = id;
+            hdr->names.push_back(name);
+            hdr->lens.push_back((uint32_t)seq.size());
+            const size_t z = seq.find('\0');
+            if (z != std::string::npos) seq.resize(z);
+            ref->seq.emplace(id, std::move(seq));
+        });
+    }
+    // PD:917-942: columns 6 and 7 of the first file; a short line re-uses what the previous line left in the variables
+    GzLines in(o.input);
+    std::string line, t1, t2, t3, t4, t5, chr;
+    int len = 0;
+    std::istringstream is;
+    while (in.next(&line)) {
+        if (line.empty()) continue;
+        is.clear(); is.str(line);
+        is >> t1 >> t2 >> t3 >> t4 >> t5 >> chr >> len;
+        if (chr2tid->find(chr) == chr2tid->end()) {
+            (*chr2tid)[chr] = (int32_t)hdr->names.size();
+            hdr->names.push_back(chr);
+            hdr->lens.push_back((uint32_t)len);
+        }
+    }
+    return true;
+}
+
+bool read_paf(const std::string &path, const Options &o, std::map<std::string, int32_t> *chr2tid, RunEmitter *out, uint64_t *n_records)
+{
+    GzLines in(path);
+    std::string line, key;
+    std::vector<std::pair<const char *, size_t>> f;
+    const bool skip_secondary = (o.flag_mask & 0x100u) != 0;
+    while (in.next(&line)) {
+        if (line.empty()) continue;
+        if (skip_secondary && line.find("tp:A:S") != std::string::npos) continue;
+        split_ws(line, &f);
+        if (f.size() < 12) continue;
+        key.assign(f[5].first, f[5].second);
+        auto it = chr2tid->find(key);
+        int32_t tid = 0;
+        if (it == chr2tid->end()) (*chr2tid)[key] = 0; else tid = it->second;
+        auto num = [&](size_t k) { char tmp[32]; const size_t n = f[k].second < 31 ? f[k].second : 31; memcpy(tmp, f[k].first, n); tmp[n] = 0; return atoi(tmp); };
+        if (num(11) < o.min_mapq) continue;
+        int32_t s = num(7), e = num(8);
+        if (s > e) { const int32_t t = s; s = e; e = t; }
+        size_t cg = 0;
+        for (size_t k = 0; k < f.size(); ++k) if (f[k].second >= 5 && memcmp(f[k].first, "cg:Z:", 5) == 0) { cg = k; break; }
+        if (cg > 1) {
+            // PD:806-833 + PD:1585-1608: <number><op> pairs; M/=/X are runs, D/N advance, everything else is ignored
+            const char *p = f[cg].first + 5, *pe = f[cg].first + f[cg].second;
+            struct Op { int32_t n; char c; };
+            std::vector<Op> ops;
+            bool ok = true;
+            while (p < pe) {
+                if (!(*p >= '0' && *p <= '9')) { ok = false; break; }
+                int64_t v = 0;
+                while (p < pe && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 0x7fffffffLL) { ok = false; break; } ++p; }
+                if (!ok) break;
+                ops.push_back(Op{(int32_t)v, p < pe ? *p : '\0'});
+                ++p;
+            }
+            if (!ok) continue;
+            ++*n_records;
+            int32_t cur = s;
+            for (const Op &x : ops) {
+                if (x.c == 'M' || x.c == '=' || x.c == 'X') { out->emit(tid, cur, cur + x.n); cur += x.n; }
+                else if (x.c == 'D' || x.c == 'N') cur += x.n;
+            }
+        } else {
+            ++*n_records;
+            if (e > s - 1) out->emit(tid, s - 1, e);
+        }
+    }
+    return true;
+}
+
+} // namespace pdh

@@ -29,6 +29,7 @@
 #include "engine_api.h"
 #include "options.h"
 #include "regions.h"
+#include "paf.h"
 #include "report.h"
 #include "pgzip.h"
 
@@ -669,19 +670,31 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
 
     std::string path = o.input, err;
     if (path.empty()) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
+    const bool paf = is_paf_path(path);                  // PD:3466-3479 / PD:3420-3432: the first input's extension decides
     AlnReader first;
-    if (!first.open(path, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
-    const AlnHeader hdr = first.header();
-    if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
-    if (o.gc) {
-        // PD:3510-3532 (PD:2068-2090 for lists): -c needs -r, checked once the first input's header has been read
-        if (o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }
-    }
-
-    tm.mark("options + header");
-    RegionModel rm;
+    AlnHeader hdr;
     RefSeqs ref;                                         // -c -r: the GC(%) column (PD:3506-3538); host-side text work
-    if (!build_regions(&o, hdr, &rm, o.gc ? &ref : nullptr, o.threads)) {
+    std::map<std::string, int32_t> paf_names;            // PAF: target name -> id (grows while records are read, PD:1559)
+    bool regions_ok = true;
+    RegionModel rm;
+    if (paf) {
+        std::cout << (list_mode ? "INFO: Run PAF format data " : "INFO: Run paf Format data ") << std::endl;
+        if (o.gc && o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }   // PD:909-913
+        regions_ok = paf_targets(o, &hdr, &paf_names, &ref);
+        tm.mark("options + targets");
+        if (regions_ok) regions_ok = build_regions(&o, hdr, &rm, ref.loaded ? &ref : nullptr, o.threads, &paf_names);
+    } else {
+        if (!first.open(path, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
+        hdr = first.header();
+        if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
+        if (o.gc) {
+            // PD:3510-3532 (PD:2068-2090 for lists): -c needs -r, checked once the first input's header has been read
+            if (o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }
+        }
+        tm.mark("options + header");
+        regions_ok = build_regions(&o, hdr, &rm, o.gc ? &ref : nullptr, o.threads);
+    }
+    if (!regions_ok) {
         // the reference's reader never returns from a NULL gzFile; an error is the usable answer
         std::cerr << "Error: Cannot open the reference sequence file: " << o.reference << std::endl;
         return 1;
@@ -712,11 +725,20 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (!OUT.open(stat_path)) { std::cerr << "open OUT File error: " << stat_path << std::endl; return 0; }
 
     tm.mark("region model");
+    if (paf && hdr.names.empty()) {
+        // an empty (or unreadable: the reference's gzstream reports nothing) first file: no targets, empty tables
+        if (o.site_out) { GzWriter s; if (s.open(prefix + ".SiteDepth.gz")) s.close(); }
+        OUT.write(header_line);
+        std::cout << "INFO: Input data read done" << std::endl;
+        OUT.write(footer(0, 0, 0, gc ? 0 : -1));
+        OUT.close();
+        return 0;
+    }
     // One context per GPU.  A `#.list` input is sharded one file per GPU (round robin) when the engine
     // offers several devices; the contexts are summed into the first one before the statistics
     // (difference arrays are linear: PD:2704-3014 accumulates every file into one array).
     int n_dev = 1, n_ctx = 1;
-    if (list_mode && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
+    if (list_mode && !paf && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
         n_ctx = n_dev;
         if (const char *e = getenv("PANDEPTH_GPUS")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
         if (n_ctx > n_files) n_ctx = n_files;
@@ -737,50 +759,65 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
 
-    // Classify the inputs in list order first: the reference prints its "No Index mode" warnings in
-    // that order (it reads the files one after another), whatever order the GPUs finish in.
-    struct Input { std::string path; int kind; };                  // 0 indexed, 1 sorted stream, 2 every read
-    std::vector<Input> inputs;
     bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
-    for (const std::string &fp : o.inputs) {
-        if (index_exists(fp) && o.use_index) {
-            if (o.site_out || o.mode == 6) wrap18 = true;            // PD:4127
-            inputs.push_back({fp, 0});
-            continue;
+    if (paf) {
+        // PD:1532-1616: every file of the list, line by line, into the same 18-bit arrays.  PAF lines come in query order,
+        // so most runs take the sink's unordered stream (device atomics); text parsing, not the scatter, is the cost.
+        wrap18 = true;
+        struct SinkEmitter : RunEmitter {
+            RunSink sink;
+            explicit SinkEmitter(Engine *e) : sink(e) {}
+            void emit(int32_t tid, int32_t beg, int32_t end) override { sink.emit(tid, beg, end); }
+        } em(&eng);
+        uint64_t n_rec = 0;
+        for (const std::string &fp : o.inputs) read_paf(fp, o, &paf_names, &em, &n_rec);
+        em.sink.flush();
+        if (tm.on) fprintf(stderr, "[timing] paf: %llu records\n", (unsigned long long)n_rec);
+    } else {
+        // Classify the inputs in list order first: the reference prints its "No Index mode" warnings in
+        // that order (it reads the files one after another), whatever order the GPUs finish in.
+        struct Input { std::string path; int kind; };                  // 0 indexed, 1 sorted stream, 2 every read
+        std::vector<Input> inputs;
+        for (const std::string &fp : o.inputs) {
+            if (index_exists(fp) && o.use_index) {
+                if (o.site_out || o.mode == 6) wrap18 = true;            // PD:4127
+                inputs.push_back({fp, 0});
+                continue;
+            }
+            wrap18 = true;                                               // PD:4553
+            bool sorted = false;
+            if (!list_mode) sorted = first.header().sorted_coordinate();
+            else {
+                AlnReader probe;
+                if (!probe.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
+                sorted = probe.header().sorted_coordinate();
+            }
+            if (sorted) std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
+            else std::cout << "Warning: Can't find index file of input BAM/CRAM. PanDepth will run in No Index mode: " << fp << std::endl;
+            inputs.push_back({fp, sorted ? 1 : 2});
         }
-        wrap18 = true;                                               // PD:4553
-        bool sorted = false;
-        if (!list_mode) sorted = first.header().sorted_coordinate();
+        Options o_part = o;
+        if (n_ctx > 1) o_part.threads = std::max(1, o.threads / n_ctx);
+        auto run_inputs = [&](int k) {
+            Engine *e = engs[k].get();
+            for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
+                const Input &in = inputs[i];
+                if (in.kind == 0) { if (!read_indexed(in.path, o_part, hdr, spans, e)) return; continue; }
+                AlnReader rd;
+                AlnReader *r = &rd;
+                std::string e2;
+                if (!list_mode) r = &first;                              // already positioned after the header
+                else if (!rd.open(in.path, &e2)) { e->fail("cannot open " + in.path); return; }
+                r->set_threads(o_part.threads > 1 ? (o_part.threads > 32 ? 32 : o_part.threads) : 0);
+                if (!(in.kind == 1 ? read_sorted_stream(r, o_part, hdr, rm, e) : read_all(r, o_part, hdr, rm, e))) return;
+            }
+        };
+        if (n_ctx == 1) run_inputs(0);
         else {
-            AlnReader probe;
-            if (!probe.open(fp, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << fp << std::endl; continue; }
-            sorted = probe.header().sorted_coordinate();
+            std::vector<std::thread> th;
+            for (int k = 0; k < n_ctx; ++k) th.emplace_back(run_inputs, k);
+            for (auto &t : th) t.join();
         }
-        if (sorted) std::cout << "Warning: PanDepth will run in No Index mode: " << fp << std::endl;
-        else std::cout << "Warning: Can't find index file of input BAM/CRAM. PanDepth will run in No Index mode: " << fp << std::endl;
-        inputs.push_back({fp, sorted ? 1 : 2});
-    }
-    Options o_part = o;
-    if (n_ctx > 1) o_part.threads = std::max(1, o.threads / n_ctx);
-    auto run_inputs = [&](int k) {
-        Engine *e = engs[k].get();
-        for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
-            const Input &in = inputs[i];
-            if (in.kind == 0) { if (!read_indexed(in.path, o_part, hdr, spans, e)) return; continue; }
-            AlnReader rd;
-            AlnReader *r = &rd;
-            std::string e2;
-            if (!list_mode) r = &first;                              // already positioned after the header
-            else if (!rd.open(in.path, &e2)) { e->fail("cannot open " + in.path); return; }
-            r->set_threads(o_part.threads > 1 ? (o_part.threads > 32 ? 32 : o_part.threads) : 0);
-            if (!(in.kind == 1 ? read_sorted_stream(r, o_part, hdr, rm, e) : read_all(r, o_part, hdr, rm, e))) return;
-        }
-    };
-    if (n_ctx == 1) run_inputs(0);
-    else {
-        std::vector<std::thread> th;
-        for (int k = 0; k < n_ctx; ++k) th.emplace_back(run_inputs, k);
-        for (auto &t : th) t.join();
     }
     for (int k = 0; k < n_ctx; ++k) {
         if (!engs[k]->ok() || !engs[k]->ck(api->synchronize(engs[k]->ctx), "pd_synchronize")) {

@@ -71,11 +71,15 @@ static void merge_spans(RegionModel *rm)
     }
 }
 
-bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref, int threads)
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref, int threads,
+                   const std::map<std::string, int32_t> *names)
 {
     std::map<std::string, int32_t> chr2tid;
-    for (size_t i = 0; i < hdr.names.size(); ++i) chr2tid.insert({hdr.names[i], (int32_t)i});   // first name wins
-    if (ref && !load_reference(o->reference, &chr2tid, ref)) return false;
+    if (names) chr2tid = *names;
+    else {
+        for (size_t i = 0; i < hdr.names.size(); ++i) chr2tid.insert({hdr.names[i], (int32_t)i});   // first name wins
+        if (ref && !load_reference(o->reference, &chr2tid, ref)) return false;
+    }
     struct RefScope { RefScope(const RefSeqs *r) { g_ref = r; } ~RefScope() { g_ref = nullptr; } } ref_scope(ref);
 
     if (o->mode != 0) {

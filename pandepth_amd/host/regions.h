@@ -40,8 +40,9 @@ struct RegionModel {
 // Parses o->region_file according to o->mode (1..4); on return, if no region survived, builds the
 // synthetic bins and sets o->mode to 0 / 5 / 6 (PD:3974-4051).  With `ref` (-c -r) the sequences are loaded first
 // (their names join the contig-name table, see fasta.h) and every gene / bin gets its G/C count.
-// Returns false on an unreadable reference file.
-bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref = nullptr, int threads = 1);
+// Returns false on an unreadable reference file.  `names` (PAF input): a ready name table; `ref` is then already loaded.
+bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *ref = nullptr, int threads = 1,
+                   const std::map<std::string, int32_t> *names = nullptr);
 
 } // namespace pdh
 #endif

@@ -482,6 +482,78 @@ F5_CASES = [
     ("r_only", ["-i", "c.bam", "-r", "c.fa"]),                    # -r without -c: no GC column
 ]
 
+# ---------------------------------------------------------------------------------------------
+# F6: PAF input (paf_main, PD:852-2024): targets from the first file or from -r, cg:Z: walks vs plain target spans,
+# reversed coordinates, tp:A:S lines and -x, -q on column 12, a list of files, gzip input, a name only a later file knows
+# ---------------------------------------------------------------------------------------------
+F6_TARGETS = [("ctgA", 3000), ("ctgB", 800), ("ctgC", 1), ("ctgD", 151)]
+
+
+def f6_paf(seed, n, targets):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        name, L = rng.choice([t for t in targets if t[1] >= 2])
+        a = rng.randrange(0, L); b = min(L, a + rng.randrange(1, 700))
+        tags = ["tp:A:%s" % rng.choice("PPPS"), "cm:i:%d" % rng.randrange(100)]
+        if i % 2:
+            rem, ops = b - a, []
+            while rem > 0:
+                k = min(rem, rng.randrange(1, 250)); ops.append("%d%s" % (k, rng.choice("MMM=XDN"))); rem -= k
+                if rng.random() < 0.3:
+                    ops.append("%d%s" % (rng.randrange(1, 30), rng.choice("IS")))
+            tags.append("cg:Z:" + "".join(ops))
+            s, e = a, b
+        else:
+            s, e = max(a, 1), max(b, 1)
+        if i % 17 == 0:
+            s, e = e, s
+        out.append("\t".join(["q%d" % i, "4000", "5", "800", rng.choice("+-"), name, str(L), str(s), str(e),
+                               str(abs(e - s)), str(abs(e - s) + 7), str(rng.choice([0, 10, 60]))] + tags))
+    return "\n".join(out) + "\n"
+
+
+def build_f6(d):
+    os.makedirs(d, exist_ok=True)
+    rng = random.Random(606)
+    write(os.path.join(d, "p.paf"), f6_paf(61, 260, F6_TARGETS))
+    with open(os.path.join(d, "p2.paf.gz"), "wb") as f:
+        # the second file also names a target the first never mentions: it is looked up with operator[] -> target 0
+        extra = "qx\t900\t0\t300\t+\tnovel\t500\t100\t400\t300\t300\t60\ttp:A:P\n"
+        f.write(gzip.compress((f6_paf(62, 120, F6_TARGETS[:2]) + extra).encode(), mtime=0))
+    write(os.path.join(d, "p.list"), "p.paf\np2.paf.gz\n")
+    fa = ""
+    for name, ln in [F6_TARGETS[1], F6_TARGETS[0], F6_TARGETS[3], F6_TARGETS[2]]:       # ids follow the FASTA order
+        seq = "".join(rng.choice("ACGTacgtNn") for _ in range(ln))
+        fa += ">%s\n" % name + "".join(seq[k:k + 80] + "\n" for k in range(0, ln, 80))
+    write(os.path.join(d, "p.fa"), fa)
+    write(os.path.join(d, "p.gff"), "\n".join([
+        "ctgA\ts\tCDS\t100\t400\t.\t+\t0\tID=a;Parent=m1", "ctgA\ts\tCDS\t900\t1500\t.\t+\t0\tID=b;Parent=m1",
+        "ctgA\ts\tCDS\t2990\t3000\t.\t+\t0\tID=c;Parent=m2", "ctgB\ts\tCDS\t1\t800\t.\t-\t0\tID=d;Parent=n1",
+        "ctgD\ts\tCDS\t151\t151\t.\t-\t0\tID=e;Parent=o1", "ctgD\ts\tCDS\t5\t60\t.\t-\t0\tID=f;Parent=o2"]) + "\n")
+    write(os.path.join(d, "p.bed3"), "ctgA\t1\t3000\nctgA\t1200\t1300\nctgB\t400\t400\nctgD\t1\t151\n")
+    write(os.path.join(d, "p.bed4"), "ctgA\t1\t100\tA\nctgA\t2000\t2500\tA\nctgB\t1\t800\tB\nctgD\t100\t151\tD\n")
+
+
+F6_CASES = [
+    ("chr", ["-i", "p.paf"]),
+    ("chr_gz_x0", ["-i", "p2.paf.gz", "-x", "0"]),
+    ("chr_list", ["-i", "p.list"]),
+    ("chr_q20_a", ["-i", "p.paf", "-q", "20", "-a"]),
+    ("w100", ["-i", "p.paf", "-w", "100"]),
+    ("w500_d3", ["-i", "p.paf", "-w", "500", "-d", "3"]),
+    ("w150_list_x0", ["-i", "p.list", "-w", "150", "-x", "0"]),
+    ("gff", ["-i", "p.paf", "-g", "p.gff"]),
+    ("gff_list_a", ["-i", "p.list", "-g", "p.gff", "-a"]),
+    ("bed3", ["-i", "p.paf", "-b", "p.bed3"]),
+    ("bed4", ["-i", "p.paf", "-b", "p.bed4", "-d", "2"]),
+    ("gc_chr", ["-i", "p.paf", "-r", "p.fa", "-c"]),
+    ("gc_w300", ["-i", "p.paf", "-r", "p.fa", "-c", "-w", "300"]),
+    ("gc_gff", ["-i", "p.paf", "-r", "p.fa", "-c", "-g", "p.gff"]),
+    ("gc_bed3_list", ["-i", "p.list", "-r", "p.fa", "-c", "-b", "p.bed3"]),
+    ("c_without_r", ["-i", "p.paf", "-c"]),
+]
+
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
 
 
@@ -520,7 +592,8 @@ def main():
     if only:
         manifest = [e for e in json.load(open(os.path.join(HERE, "manifest.json"))) if e["fixture"] not in only]
     for fx, build, cases in (("f1", build_f1, F1_CASES), ("f2", build_f2, F2_CASES),
-                             ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES), ("f5", build_f5, F5_CASES)):
+                             ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES), ("f5", build_f5, F5_CASES),
+                             ("f6", build_f6, F6_CASES)):
         if only and fx not in only:
             continue
         d = os.path.join(HERE, fx)

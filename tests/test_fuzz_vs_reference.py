@@ -59,3 +59,17 @@ def test_oracle_restatement_matches_the_reference_on_random_inputs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "61", "80", "oracle"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
+def test_paf_inputs_match_the_reference():
+    """PAF front end (paf_main): targets from the first file or from -r, cg:Z: walks, reversed coordinates, tp:A:S / -x,
+    -q on column 12, lists, gzip, GFF / BED targets, GC columns"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "71", "150", "paf"], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "72", "60", "oracle-paf"], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]

@@ -209,3 +209,23 @@ def test_gc_needs_a_readable_reference(cli, tmp_path, golden_dir):
     p = subprocess.run([cli, "-i", "c.bam", "-o", "x", "-c"], cwd=tmp_path, capture_output=True, timeout=60)
     assert p.returncode == 0 and b"lack reference sequence (-r) for GC parse" in p.stderr    # PD:3530-3533
     assert not os.path.exists(tmp_path / "x.chr.stat.gz")
+
+
+def test_paf_lines_the_reference_cannot_answer(cli, tmp_path):
+    """tstart = 0 without a cg:Z: tag (the reference starts one cell BEFORE its array), a line with fewer than 12 columns
+    (it indexes past its vector) and a cg:Z: value without a number (std::stoi throws): the first is clipped to the
+    target, the other two lines are skipped; everything else on the file is counted."""
+    good = ["q1\t100\t0\t50\t+\ttg\t300\t0\t50\t50\t50\t60\ttp:A:P",                     # cells [0, 50) after clipping -1
+            "q2\t100\t0\t50\t+\ttg\t300\t100\t160\t60\t60\t60\ttp:A:P\tcg:Z:30M10D20M",   # [100,130) + [140,160)
+            "q3\t100\t0\t50\t+\ttg\t300\t10\t20",                                            # short line
+            "q4\t100\t0\t50\t+\ttg\t300\t200\t260\t60\t60\t60\ttp:A:P\tcg:Z:M30"]          # malformed cg
+    (tmp_path / "u.paf").write_text("\n".join(good) + "\n")
+    p = run(cli, ["-i", "u.paf", "-o", "u", "-a"], tmp_path)
+    assert p.stdout.decode() == "INFO: Run paf Format data \nINFO: Input data read done\n"
+    d = [int(l.split("\t")[2]) for l in stat(tmp_path / "u.SiteDepth.gz").strip().split("\n")]
+    want = [0] * 300
+    for a, b in ((0, 50), (100, 130), (140, 160)):
+        for k in range(a, b):
+            want[k] += 1
+    assert d == want
+    assert stat(tmp_path / "u.chr.stat.gz").split("\n")[1] == "tg\t300\t100\t100\t33.33\t0.33"

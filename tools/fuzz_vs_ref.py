@@ -172,6 +172,104 @@ def gen_fasta(rng, names, lens):
     return text
 
 
+def gen_paf(rng, targets, n):
+    """PAF lines on the given (name, length) targets.  Inside what the reference defines: at least 12 columns, target
+    coordinates within the target (+ its 500 cells of padding are never relied on), tstart >= 1 for lines without a
+    cg:Z: tag (it starts counting one cell before tstart), well-formed cg:Z: values."""
+    out = []
+    big = [t for t in targets if t[1] >= 2]
+    for i in range(n):
+        name, L = rng.choice(big)
+        a = rng.randrange(0, L); b = min(L, a + rng.randrange(1, 900))
+        cols = ["q%d" % i, "5000", "10", "900", rng.choice("+-"), name, str(L)]
+        tags = ["tp:A:%s" % rng.choice("PPPSI"), "cm:i:%d" % rng.randrange(100)]
+        if rng.random() < 0.5:
+            rem, ops = b - a, []
+            while rem > 0:
+                k = min(rem, rng.randrange(1, 300)); ops.append("%d%s" % (k, rng.choice("MMMM=XDN"))); rem -= k
+                if rng.random() < 0.3:
+                    ops.append("%d%s" % (rng.randrange(1, 40), rng.choice("IISH")))
+            tags.insert(rng.randrange(len(tags) + 1), "cg:Z:" + "".join(ops))
+            s, e = a, b
+        else:
+            s, e = max(a, 1), max(b, 1)
+        if rng.random() < 0.05:
+            s, e = e, s                                       # reversed coordinates are swapped back (PD:1570-1575)
+        cols += [str(s), str(e), str(abs(e - s)), str(abs(e - s) + rng.randrange(50)), str(rng.choice([0, 1, 20, 60, 255]))]
+        sep = "\t" if rng.random() < 0.95 else " "
+        out.append(sep.join(cols + tags))
+        if rng.random() < 0.03:
+            out.append("")
+    return "\n".join(out) + ("\n" if rng.random() < 0.9 else "")
+
+
+def paf_case(rng, td):
+    import gzip
+    nt = rng.randrange(1, 5)
+    targets = [("t%d" % k if rng.random() < 0.8 else "ctg_%d" % k, rng.choice([1, 2, 37, 150, 151, 600, 2500, 5000])) for k in range(nt)]
+    if all(L < 2 for _, L in targets):
+        targets.append(("tx", 800))
+    names, lens = [t[0] for t in targets], [t[1] for t in targets]
+
+    def put(fn, text):
+        if rng.random() < 0.25:
+            fn += ".gz"
+            gzip.open(os.path.join(td, fn), "wb", compresslevel=1).write(text.encode())
+        else:
+            open(os.path.join(td, fn), "w").write(text)
+        return fn
+    first = put("a.paf", gen_paf(rng, targets, rng.randrange(0, 300)))
+    args = ["-i", first]
+    if rng.random() < 0.25:
+        files = [first] + [put("b%d.paf" % k, gen_paf(rng, targets, rng.randrange(1, 200))) for k in range(rng.randrange(1, 3))]
+        open(os.path.join(td, "p.list"), "w").write("\n".join(files) + "\n")
+        args = ["-i", "p.list"]
+    use_ref = rng.random() < 0.35
+    if use_ref:
+        # targets then come from the FASTA records (ids in file order); every PAF target is present with its length
+        order = list(range(nt + (len(targets) - nt)))
+        rng.shuffle(order)
+        fa = "".join(">%s\n%s\n" % (names[t], "".join(rng.choice("ACGTacgtN") for _ in range(lens[t]))) for t in order)
+        if rng.random() < 0.3:
+            fa += ">spare\nACGTACGTAC\n"
+        put_name = "genome.fa"
+        open(os.path.join(td, put_name), "w").write(fa)
+        args += ["-r", put_name, "-c"]                        # (-r without -c: its GC column reads strings it never filled)
+        names = [names[t] for t in order]; lens = [lens[t] for t in order]
+    mode = rng.choice(["chr", "chr", "w", "w", "gff", "bed3", "bed4"])
+    if mode == "w":
+        ws = [150, 151, 200, 1000, 5000] if use_ref else [1, 7, 50, 100, 149, 150, 151, 200, 1000, 0]
+        args += ["-w", str(rng.choice(ws))]
+    elif mode in ("gff", "bed3", "bed4"):
+        # every target keeps at least one target row: a target without rows gets a 500-cell array in the reference and
+        # its alignments run off the end of it
+        text = gen_regions(rng, names, lens, mode).rstrip("\n").split("\n")
+        for nm, L in zip(names, lens):
+            a = rng.randrange(1, L + 1); b = rng.randrange(a, L + 1)
+            if mode == "gff":
+                text.append("%s\tsrc\tCDS\t%d\t%d\t.\t+\t0\tID=k;Parent=keep_%s" % (nm, a, b, nm))
+            elif mode == "bed3":
+                text.append("%s\t%d\t%d" % (nm, a, b))
+            else:
+                text.append("%s\t%d\t%d\tkeep_%s" % (nm, a, b, nm))
+        rng.shuffle(text)
+        if mode == "bed4":
+            text = [l for l in text if len(l.split()) == 4] or text
+        fn = put("r." + ("gff" if mode == "gff" else "bed"), "\n".join(text) + "\n")
+        args += ["-g" if mode == "gff" else "-b", fn]
+    if rng.random() < 0.3:
+        args += ["-a"]
+    if rng.random() < 0.3:
+        args += ["-q", str(rng.choice([0, 1, 20, 61]))]
+    if rng.random() < 0.3:
+        args += ["-d", str(rng.choice([0, 1, 2, 5]))]
+    if rng.random() < 0.4:
+        args += ["-x", str(rng.choice([0, 256, 1796, 4]))]
+    if rng.random() < 0.3:
+        args += ["-t", str(rng.choice([1, 4]))]
+    return args
+
+
 S2B = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
 
 
@@ -320,7 +418,7 @@ def args_mode(seed, cases):
     return 1 if bad else 0
 
 
-def oracle_mode(seed, cases):
+def oracle_mode(seed, cases, paf=False):
     """the Python/C restatement (oracle/pd_oracle.py: run()) against the reference binary on the same random inputs: every
     output file's TEXT (the oracle does not deflate)"""
     import gzip
@@ -330,7 +428,7 @@ def oracle_mode(seed, cases):
     bad = skipped = 0
     for k in range(cases):
         td = tempfile.mkdtemp(prefix="fo", dir="/tmp")
-        args = one_case(rng, td)
+        args = paf_case(rng, td) if paf else one_case(rng, td)
         try:
             p = subprocess.run([REF] + args + ["-o", "ref"], cwd=td, capture_output=True, timeout=120)
         except subprocess.TimeoutExpired:
@@ -357,17 +455,18 @@ def main():
     global BIG, MESSY
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    PAF = len(sys.argv) > 3 and sys.argv[3] == "paf"
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     MESSY = len(sys.argv) > 3 and sys.argv[3] == "messy"
     if len(sys.argv) > 3 and sys.argv[3] == "args":
         return args_mode(seed, cases)
-    if len(sys.argv) > 3 and sys.argv[3] == "oracle":
-        return oracle_mode(seed, cases)
+    if len(sys.argv) > 3 and sys.argv[3] in ("oracle", "oracle-paf"):
+        return oracle_mode(seed, cases, sys.argv[3] == "oracle-paf")
     rng = random.Random(seed)
     bad = skipped = 0
     for k in range(cases):
         td = tempfile.mkdtemp(prefix="fz", dir="/tmp")
-        args = one_case(rng, td)
+        args = paf_case(rng, td) if PAF else one_case(rng, td)
         try:
             r_rc, r_out, r_files = run(REF, args, td, "ref")
         except subprocess.TimeoutExpired:
