@@ -29,15 +29,13 @@ void erase_all(std::string *s, char c)
     s->resize(w);
 }
 
-const RefSeqs *g_ref = nullptr;            // set for the duration of one build_regions call
-
-void add_entry(RegionModel *rm, int32_t tid, const std::string &id, long long start, long long end)
+void add_entry(RegionModel *rm, const RefSeqs *ref, int32_t tid, const std::string &id, long long start, long long end)
 {
     Gene &g = rm->genes[tid][id];
     const int32_t s = (int32_t)start, e = (int32_t)end;
     if (g.cds.empty()) {
         g.start = s; g.end = e;
-        if (g_ref) g.gc = (int32_t)g_ref->gc(tid, (int32_t)start, (int32_t)end);      // `for (int ii = Start-1; ii < End; ii++)`
+        if (ref) g.gc = (int32_t)ref->gc(tid, (int32_t)start, (int32_t)end);      // `for (int ii = Start-1; ii < End; ii++)`
     }
     else { if (g.start > s) g.start = s; if (g.end < e) g.end = e; }
     g.length += (uint64_t)(end - start + 1);
@@ -80,7 +78,6 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *r
         for (size_t i = 0; i < hdr.names.size(); ++i) chr2tid.insert({hdr.names[i], (int32_t)i});   // first name wins
         if (ref && !load_reference(o->reference, &chr2tid, ref)) return false;
     }
-    struct RefScope { RefScope(const RefSeqs *r) { g_ref = r; } ~RefScope() { g_ref = nullptr; } } ref_scope(ref);
 
     if (o->mode != 0) {
         std::vector<std::string> lines;
@@ -112,7 +109,7 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *r
                 }
                 auto it = chr2tid.find(chr);
                 if (it == chr2tid.end()) unknown_contig(line);
-                else add_entry(rm, it->second, gid, s, e);
+                else add_entry(rm, ref, it->second, gid, s, e);
             } else if (o->mode == 2) {                            // GTF, PD:3649-3740
                 erase_all(&line, '"');
                 erase_all(&line, ';');
@@ -127,7 +124,7 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *r
                 if (inf.size() < 10) continue;
                 auto it = chr2tid.find(chr);
                 if (it == chr2tid.end()) unknown_contig(line);
-                else add_entry(rm, it->second, inf[9], s, e);
+                else add_entry(rm, ref, it->second, inf[9], s, e);
             } else if (o->mode == 3) {                            // BED3, PD:3741-3819
                 is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 is >> chr >> start_s >> end_s;
@@ -136,14 +133,14 @@ bool build_regions(Options *o, const AlnHeader &hdr, RegionModel *rm, RefSeqs *r
                 if (bstart > bend) { std::cerr << line << "Warning: This region may be incorrect.\n" << std::endl; continue; }
                 auto it = chr2tid.find(chr);
                 if (it == chr2tid.end()) unknown_contig(line);
-                else add_entry(rm, it->second, id, bstart, bend);
+                else add_entry(rm, ref, it->second, id, bstart, bend);
             } else if (o->mode == 4) {                            // BED4, PD:3821-3898
                 is.clear(); is.str(line);                    // one stream object for all lines (constructing one per line costs ~1 us)
                 is >> chr >> bstart >> bend >> id;
                 if (bstart > bend) { std::cerr << line << "Warning: This region may be incorrect. \n" << std::endl; continue; }
                 auto it = chr2tid.find(chr);
                 if (it == chr2tid.end()) unknown_contig(line);
-                else add_entry(rm, it->second, id, bstart, bend);
+                else add_entry(rm, ref, it->second, id, bstart, bend);
             }
         }
     }
