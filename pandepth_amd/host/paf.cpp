@@ -1,9 +1,11 @@
 // paf.cpp — see paf.h
 #include "paf.h"
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
-#include <sstream>
+#include <fcntl.h>
+#include <unistd.h>
 #include <vector>
 
 namespace pdh {
@@ -16,21 +18,29 @@ struct GzLines {
     std::vector<char> buf;
     size_t beg = 0, end = 0;
     bool eof = false;
-    explicit GzLines(const std::string &path) : buf((size_t)1 << 20)
+    int fd = -1;                                     // plain files bypass zlib's copy
+    explicit GzLines(const std::string &path) : buf((size_t)4 << 20)
     {
-        f = gzopen(path.c_str(), "rb");
-        if (f) gzbuffer(f, 1u << 20);
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            f = gzdopen(fd, "rb");
+            if (f) { gzbuffer(f, 1u << 20); fd = -1; } else { close(fd); fd = -1; }
+        }
     }
-    ~GzLines() { if (f) gzclose(f); }
+    ~GzLines() { if (f) gzclose(f); if (fd >= 0) close(fd); }
+    int fill() { return f ? gzread(f, buf.data(), (unsigned)buf.size()) : (int)read(fd, buf.data(), buf.size()); }
     bool next(std::string *line)
     {
         line->clear();
-        if (!f) return false;
+        if (!f && fd < 0) return false;
         bool any = false;
         for (;;) {
             if (beg >= end) {
                 if (eof) return any;
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                const int n = fill();
                 if (n <= 0) { eof = true; return any; }
                 beg = 0; end = (size_t)n;
             }
@@ -86,13 +96,32 @@ bool paf_targets(const Options &o, AlnHeader *hdr, std::map<std::string, int32_t
     }
     // PD:917-942: columns 6 and 7 of the first file; a short line re-uses what the previous line left in the variables
     GzLines in(o.input);
-    std::string line, t1, t2, t3, t4, t5, chr;
+    std::string line, chr;
     int len = 0;
-    std::istringstream is;
     while (in.next(&line)) {
         if (line.empty()) continue;
-        is.clear(); is.str(line);
-        is >> t1 >> t2 >> t3 >> t4 >> t5 >> chr >> len;
+        // `isone >> tmp1 >> tmp2 >> tmp3 >> tmp4 >> tmp5 >> chr >> chrlength`: tokens between white space; what a short
+        // line does not reach keeps its previous value; the number is read the way num_get reads an int
+        const char *p = line.data(), *e = p + line.size();
+        int k = 0;
+        for (; k < 7; ++k) {
+            while (p < e && isspace((unsigned char)*p)) ++p;
+            if (p >= e) break;
+            const char *b = p;
+            if (k == 6) {
+                const char *q = p;
+                bool neg = false;
+                if (q < e && (*q == '+' || *q == '-')) { neg = *q == '-'; ++q; }
+                const char *d0 = q;
+                long long v = 0;
+                while (q < e && *q >= '0' && *q <= '9') { if (v < (1LL << 40)) v = v * 10 + (*q - '0'); ++q; }
+                if (q == d0) len = 0;                      // no digits: failbit, and C++11 stores 0
+                else { if (neg) v = -v; len = v > 2147483647LL ? 2147483647 : v < -2147483648LL ? (int)-2147483648LL : (int)v; }
+                break;
+            }
+            while (p < e && !isspace((unsigned char)*p)) ++p;
+            if (k == 5) chr.assign(b, (size_t)(p - b));
+        }
         if (chr2tid->find(chr) == chr2tid->end()) {
             (*chr2tid)[chr] = (int32_t)hdr->names.size();
             hdr->names.push_back(chr);
