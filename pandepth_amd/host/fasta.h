@@ -17,17 +17,27 @@
 
 namespace pdh {
 
+// All sequences live in ONE arena (a 3 Gb genome is one 3 GB allocation, sized from the file for plain FASTA: no
+// per-contig regrowth, no copies between buffers, one set of page faults); a contig is an (offset, length) span of it.
 struct RefSeqs {
-    std::map<int32_t, std::string> seq;     // contig id -> bases
     bool loaded = false;                    // RefIn
     // number of C/c/G/g among the 1-based inclusive positions [first, last] of contig tid
     uint64_t gc(int32_t tid, int64_t first, int64_t last) const;
-    void clear() { seq.clear(); }
+    // the reader appends a record's bases to arena(); claim() then binds [off, off+n) to tid, or — when tid already has a
+    // sequence (the first claim wins) — drops them again and returns false
+    std::string *arena() { return &arena_; }
+    bool claim(int32_t tid, size_t off, size_t n);
+    size_t n_seqs() const { return span_.size(); }
+    void clear() { std::string().swap(arena_); span_.clear(); }
+private:
+    std::string arena_;
+    std::map<int32_t, std::pair<size_t, size_t>> span_;
 };
 
-// every record of a FASTA/FASTQ file (plain or gzip) in file order: rec(name, sequence); the callback may move from the
-// sequence.  false when the file cannot be opened.
-bool read_fasta_records(const std::string &path, const std::function<void(const std::string &, std::string &)> &rec);
+// every record of a FASTA/FASTQ file (plain or gzip) in file order: the bases are APPENDED to *dst (reserved from the file
+// size for plain files) and rec(name, offset, length) is told where; rec may shrink *dst back to `offset`.
+// false when the file cannot be opened.
+bool read_fasta_records(const std::string &path, std::string *dst, const std::function<void(const std::string &, size_t, size_t)> &rec);
 
 // false when the file cannot be opened (the reference never returns from that: its reader spins on a
 // NULL gzFile); chr2tid gains the unknown names (-> 0)

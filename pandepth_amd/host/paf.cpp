@@ -84,14 +84,14 @@ bool paf_targets(const Options &o, AlnHeader *hdr, std::map<std::string, int32_t
         // name points at the later one.  (Without -c the reference still switches its GC column on and then counts
         // in strings it never filled; the sequences are kept here either way and the column is real.)
         ref->loaded = true;
-        return read_fasta_records(o.reference, [&](const std::string &name, std::string &seq) {
+        std::string *arena = ref->arena();
+        return read_fasta_records(o.reference, arena, [&](const std::string &name, size_t off, size_t n) {
             const int32_t id = (int32_t)hdr->names.size();
             (*chr2tid)[name] = id;
             hdr->names.push_back(name);
-            hdr->lens.push_back((uint32_t)seq.size());
-            const size_t z = seq.find('\0');
-            if (z != std::string::npos) seq.resize(z);
-            ref->seq.emplace(id, std::move(seq));
+            hdr->lens.push_back((uint32_t)n);
+            const void *z = memchr(arena->data() + off, 0, n);
+            ref->claim(id, off, z ? (size_t)((const char *)z - (arena->data() + off)) : n);
         });
     }
     // PD:917-942: columns 6 and 7 of the first file; a short line re-uses what the previous line left in the variables
