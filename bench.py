@@ -99,6 +99,7 @@ def cpu_baseline(sample_records, log):
                     "kind": "reference",
                     "sample": sample + "; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads), cgroup "
                               "quota %d CPUs, BAM+BAI, warm cache, %.2f s" % (threads, cpu_quota(), best)}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the checker's directory is on the path for this leg only
     import pd_oracle as O
     first, other = synth.records_to_runs(rec)
     runs = np.concatenate([first, other])
@@ -122,7 +123,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pandepth_amd as pda
     from pandepth_amd import multi
     from tools import synth

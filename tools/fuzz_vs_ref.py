@@ -13,7 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
-CLI = os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")
+CLI = os.environ.get("FUZZ_CLI") or os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")     # FUZZ_CLI: a copy of the harness binary, so that rebuilding the tree does not disturb a running campaign
 
 
 MESSY = False       # fuzz_vs_ref.py <seed> <cases> messy: truncated lines, CRLF, extra columns, runs of spaces in the target files
