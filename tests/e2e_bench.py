@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/e2e_bench.py — END-TO-END wall clock of the CLI on a generated BAM (GPU box): host BAM
+"""tests/e2e_bench.py — END-TO-END wall clock of the CLI on a generated BAM (GPU box): host BAM
 decode + PCIe + kernels + table writer, next to the reference binary on the same file, with a
 byte comparison of the outputs.  Numbers from here go to DESIGN.md (they are NOT bench.py's value)."""
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/e2e_fullsize.py — the CLI on a FULL-SIZE reference (3.0 Gb, 512 contigs) with a thin read set:
+"""tests/e2e_fullsize.py — the CLI on a FULL-SIZE reference (3.0 Gb, 512 contigs) with a thin read set:
 checks the 3 Gb code paths end to end (12 GB context, index arrays, 3e6-window tables) against the
 reference binary, byte for byte."""
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
+"""tests/fuzz_vs_ref.py — differential fuzzing of the host pipeline (on the CPU oracle engine, tests/harness) against the
 compiled reference (oracle/_ref/pandepth_ref): random small SAM inputs, region files with the quirks real files have, random
 option mixes.  Compares exit code, stdout and every output file byte for byte.  Needs /root/reference's build (dev container).
 usage: fuzz_vs_ref.py [seed] [cases] [big | args | messy | oracle]"""

@@ -355,7 +355,7 @@ F3_CASES = [
 # ---------------------------------------------------------------------------------------------
 # F4: last-base targets.  The reference's indexed path (ProDealChrBambai, PD:676-786) hands a window's statistics
 # to the genes with GeneStart < MeMEnd (PD:299-303), and MeMEnd is clipped to the contig length: a target that STARTS
-# on the last base of its contig gets no statistics there (found by tools/fuzz_vs_ref.py), while the SiteInfo paths
+# on the last base of its contig gets no statistics there (found by tests/fuzz_vs_ref.py), while the SiteInfo paths
 # (-a, no index, list) count it.
 # ---------------------------------------------------------------------------------------------
 F4_CONTIGS = [("k2", 2), ("k201", 201), ("k37", 37), ("k500", 500)]

@@ -1,5 +1,5 @@
 """Differential fuzzing of the host pipeline (CPU oracle engine) against the compiled reference, when it is present
-(dev container: oracle/_ref/pandepth_ref built from /root/reference): tools/fuzz_vs_ref.py generates small SAM / BAM /
+(dev container: oracle/_ref/pandepth_ref built from /root/reference): tests/fuzz_vs_ref.py generates small SAM / BAM /
 BAM+BAI / #.list inputs, GFF / GTF / BED3 / BED4 files with the quirks real files have (comments, blank lines, unknown
 contigs, start > end, duplicate ids, odd attribute orders, leading zeros, spaces for tabs) and random option mixes, and
 compares exit code, stdout and every output file byte for byte.  This is how the last-base target rule of the reference's
@@ -20,7 +20,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
 def test_random_inputs_match_the_reference(seed):
     subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), str(seed), "150"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), str(seed), "150"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
 
@@ -31,7 +31,7 @@ def test_random_command_lines_match_the_reference():
     (which the reference treats as empty lists), -c without -r"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "7", "200", "args"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "7", "200", "args"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
 
@@ -39,7 +39,7 @@ def test_random_command_lines_match_the_reference():
 @pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
 def test_large_contigs_around_the_reference_window_steps():
     """contigs of 10-32 Mb with reads and targets clustered around the 10 Mb steps of the reference's indexed window walk"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "41", "3", "big"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "41", "3", "big"], capture_output=True, text=True,
                        timeout=1800)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
 
@@ -47,7 +47,7 @@ def test_large_contigs_around_the_reference_window_steps():
 @pytest.mark.skipif(not os.access(REF, os.X_OK), reason="needs the compiled reference (dev container only)")
 def test_messy_target_files_match_the_reference():
     """Windows line endings, extra columns, runs of spaces, truncated BED lines (the reference re-uses the previous line's values)"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "51", "150", "messy"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "51", "150", "messy"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
 
@@ -56,7 +56,7 @@ def test_messy_target_files_match_the_reference():
 def test_oracle_restatement_matches_the_reference_on_random_inputs():
     """oracle/pd_oracle.py itself (the checker of the GPU tests) against the reference binary: table and per-site texts"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "61", "80", "oracle"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "61", "80", "oracle"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
 
@@ -67,9 +67,9 @@ def test_paf_inputs_match_the_reference():
     -q on column 12, lists, gzip, GFF / BED targets, GC columns"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "71", "150", "paf"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "71", "150", "paf"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_ref.py"), "72", "60", "oracle-paf"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_vs_ref.py"), "72", "60", "oracle-paf"], capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
