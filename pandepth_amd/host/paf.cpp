@@ -7,6 +7,12 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <vector>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace pdh {
 
@@ -31,7 +37,12 @@ struct GzLines {
         }
     }
     ~GzLines() { if (f) gzclose(f); if (fd >= 0) close(fd); }
-    int fill() { return f ? gzread(f, buf.data(), (unsigned)buf.size()) : (int)read(fd, buf.data(), buf.size()); }
+    int fill() { return read_raw(buf.data(), buf.size()); }
+    int read_raw(char *dst, size_t n)
+    {
+        if (n > ((size_t)1 << 30)) n = (size_t)1 << 30;
+        return f ? gzread(f, dst, (unsigned)n) : (int)read(fd, dst, n);
+    }
     bool next(std::string *line)
     {
         line->clear();
@@ -52,19 +63,6 @@ struct GzLines {
         }
     }
 };
-
-void split_ws(const std::string &s, std::vector<std::pair<const char *, size_t>> *tok)
-{
-    tok->clear();
-    const char *p = s.data(), *e = p + s.size();
-    while (p < e) {
-        while (p < e && (*p == ' ' || *p == '\t')) ++p;
-        if (p >= e) break;
-        const char *b = p;
-        while (p < e && *p != ' ' && *p != '\t') ++p;
-        tok->emplace_back(b, (size_t)(p - b));
-    }
-}
 
 } // namespace
 
@@ -131,53 +129,144 @@ bool paf_targets(const Options &o, AlnHeader *hdr, std::map<std::string, int32_t
     return true;
 }
 
-bool read_paf(const std::string &path, const Options &o, std::map<std::string, int32_t> *chr2tid, RunEmitter *out, uint64_t *n_records)
-{
-    GzLines in(path);
-    std::string line, key;
+namespace {
+
+// one PAF line -> runs (PD:1549-1612)
+struct LineParser {
+    const Options &o;
+    const std::map<std::string, int32_t> &tab;
+    RunEmitter *out;
+    uint64_t n_records = 0;
+    const bool skip_secondary;
     std::vector<std::pair<const char *, size_t>> f;
-    const bool skip_secondary = (o.flag_mask & 0x100u) != 0;
-    while (in.next(&line)) {
-        if (line.empty()) continue;
-        if (skip_secondary && line.find("tp:A:S") != std::string::npos) continue;
-        split_ws(line, &f);
-        if (f.size() < 12) continue;
+    std::string key;
+    struct Op { int32_t n; char c; };
+    std::vector<Op> ops;
+    LineParser(const Options &opt, const std::map<std::string, int32_t> &t, RunEmitter *e)
+        : o(opt), tab(t), out(e), skip_secondary((opt.flag_mask & 0x100u) != 0) {}
+
+    void line(const char *b, const char *e)
+    {
+        if (b == e) return;
+        if (skip_secondary && memmem(b, (size_t)(e - b), "tp:A:S", 6)) return;
+        f.clear();
+        for (const char *p = b; p < e;) {
+            while (p < e && (*p == ' ' || *p == '\t')) ++p;
+            if (p >= e) break;
+            const char *t = p;
+            while (p < e && *p != ' ' && *p != '\t') ++p;
+            f.emplace_back(t, (size_t)(p - t));
+        }
+        if (f.size() < 12) return;
+        // the reference looks the name up with operator[]: a name the table does not know is ENTERED as target 0 — the
+        // same answer as not finding it, so the table stays read-only here (and may be shared by parser threads)
         key.assign(f[5].first, f[5].second);
-        auto it = chr2tid->find(key);
-        int32_t tid = 0;
-        if (it == chr2tid->end()) (*chr2tid)[key] = 0; else tid = it->second;
+        auto it = tab.find(key);
+        const int32_t tid = it == tab.end() ? 0 : it->second;
         auto num = [&](size_t k) { char tmp[32]; const size_t n = f[k].second < 31 ? f[k].second : 31; memcpy(tmp, f[k].first, n); tmp[n] = 0; return atoi(tmp); };
-        if (num(11) < o.min_mapq) continue;
-        int32_t s = num(7), e = num(8);
-        if (s > e) { const int32_t t = s; s = e; e = t; }
+        if (num(11) < o.min_mapq) return;
+        int32_t s = num(7), en = num(8);
+        if (s > en) { const int32_t t = s; s = en; en = t; }
         size_t cg = 0;
         for (size_t k = 0; k < f.size(); ++k) if (f[k].second >= 5 && memcmp(f[k].first, "cg:Z:", 5) == 0) { cg = k; break; }
         if (cg > 1) {
             // PD:806-833 + PD:1585-1608: <number><op> pairs; M/=/X are runs, D/N advance, everything else is ignored
             const char *p = f[cg].first + 5, *pe = f[cg].first + f[cg].second;
-            struct Op { int32_t n; char c; };
-            std::vector<Op> ops;
-            bool ok = true;
+            ops.clear();
             while (p < pe) {
-                if (!(*p >= '0' && *p <= '9')) { ok = false; break; }
+                if (!(*p >= '0' && *p <= '9')) return;
                 int64_t v = 0;
-                while (p < pe && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 0x7fffffffLL) { ok = false; break; } ++p; }
-                if (!ok) break;
+                while (p < pe && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 0x7fffffffLL) return; ++p; }
                 ops.push_back(Op{(int32_t)v, p < pe ? *p : '\0'});
                 ++p;
             }
-            if (!ok) continue;
-            ++*n_records;
+            ++n_records;
             int32_t cur = s;
             for (const Op &x : ops) {
                 if (x.c == 'M' || x.c == '=' || x.c == 'X') { out->emit(tid, cur, cur + x.n); cur += x.n; }
                 else if (x.c == 'D' || x.c == 'N') cur += x.n;
             }
         } else {
-            ++*n_records;
-            if (e > s - 1) out->emit(tid, s - 1, e);
+            ++n_records;
+            if (en > s - 1) out->emit(tid, s - 1, en);
         }
     }
+    void block(const char *b, const char *e)
+    {
+        while (b < e) {
+            const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+            if (!nl) nl = e;
+            line(b, nl);
+            b = nl + 1;
+        }
+    }
+};
+
+} // namespace
+
+bool read_paf(const std::string &path, const Options &o, const std::map<std::string, int32_t> &chr2tid,
+              const std::function<std::unique_ptr<RunEmitter>()> &make_emitter, int threads, uint64_t *n_records)
+{
+    GzLines in(path);
+    if (!in.f && in.fd < 0) return true;                   // (the reference's gzstream reports nothing either)
+    // The reader cuts the byte stream into blocks of whole lines; parser threads (each with its own emitter) take them.
+    constexpr size_t BLOCK = (size_t)8 << 20;
+    const int T = std::max(1, std::min(threads, 16));
+    std::mutex mu;
+    std::condition_variable cv_put, cv_get;
+    std::deque<std::vector<char>> queue;
+    bool done = false;
+    std::atomic<uint64_t> total{0};
+    auto worker = [&]() {
+        std::unique_ptr<RunEmitter> em = make_emitter();
+        LineParser lp(o, chr2tid, em.get());
+        for (;;) {
+            std::vector<char> blk;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_get.wait(lk, [&] { return done || !queue.empty(); });
+                if (queue.empty()) break;
+                blk.swap(queue.front()); queue.pop_front();
+            }
+            cv_put.notify_one();
+            lp.block(blk.data(), blk.data() + blk.size());
+        }
+        total += lp.n_records;
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k) th.emplace_back(worker);
+    std::vector<char> carry;
+    for (;;) {
+        std::vector<char> blk(carry.size() + BLOCK);
+        if (!carry.empty()) memcpy(blk.data(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        bool eof = false;
+        while (have < blk.size()) {
+            const int n = in.read_raw(blk.data() + have, blk.size() - have);
+            if (n <= 0) { eof = true; break; }
+            have += (size_t)n;
+        }
+        size_t cut = have;
+        if (!eof) {                                        // keep the unfinished last line for the next block
+            while (cut > 0 && blk[cut - 1] != '\n') --cut;
+            if (cut == 0) { carry.assign(blk.begin(), blk.begin() + have); if (carry.size() > ((size_t)1 << 30)) eof = true; else continue; }
+            carry.assign(blk.begin() + cut, blk.begin() + have);
+        }
+        blk.resize(cut);
+        if (!blk.empty()) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_put.wait(lk, [&] { return queue.size() < (size_t)T * 2; });
+            queue.emplace_back(std::move(blk));
+            lk.unlock();
+            cv_get.notify_one();
+        }
+        if (eof) break;
+    }
+    { std::lock_guard<std::mutex> lk(mu); done = true; }
+    cv_get.notify_all();
+    for (auto &t : th) t.join();
+    *n_records += total.load();
     return true;
 }
 

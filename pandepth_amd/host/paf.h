@@ -11,7 +11,9 @@
 #ifndef PD_PAF_H_
 #define PD_PAF_H_
 #include <stdint.h>
+#include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include "bam.h"
 #include "fasta.h"
@@ -27,11 +29,12 @@ bool paf_targets(const Options &o, AlnHeader *hdr, std::map<std::string, int32_t
 
 struct RunEmitter { virtual void emit(int32_t tid, int32_t beg, int32_t end) = 0; virtual ~RunEmitter() {} };
 
-// Streams one PAF file (plain or gzip) into `out`; n_records counts the lines that were walked.
+// Streams one PAF file (plain or gzip): the reader cuts it into blocks of whole lines, up to `threads` parser threads
+// (each with an emitter of its own from make_emitter) turn them into runs; n_records counts the lines that were walked.
 // Lines with fewer than 12 columns, or a cg:Z: value that does not parse, are skipped (the reference indexes past its
 // vector / dies in std::stoi there).
-bool read_paf(const std::string &path, const Options &o, std::map<std::string, int32_t> *chr2tid, RunEmitter *out,
-              uint64_t *n_records);
+bool read_paf(const std::string &path, const Options &o, const std::map<std::string, int32_t> &chr2tid,
+              const std::function<std::unique_ptr<RunEmitter>()> &make_emitter, int threads, uint64_t *n_records);
 
 } // namespace pdh
 #endif

@@ -768,10 +768,10 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             RunSink sink;
             explicit SinkEmitter(Engine *e) : sink(e) {}
             void emit(int32_t tid, int32_t beg, int32_t end) override { sink.emit(tid, beg, end); }
-        } em(&eng);
+        };                                                 // (a sink flushes what it holds when it goes away)
         uint64_t n_rec = 0;
-        for (const std::string &fp : o.inputs) read_paf(fp, o, &paf_names, &em, &n_rec);
-        em.sink.flush();
+        for (const std::string &fp : o.inputs)
+            read_paf(fp, o, paf_names, [&]() { return std::unique_ptr<RunEmitter>(new SinkEmitter(&eng)); }, o.threads, &n_rec);
         if (tm.on) fprintf(stderr, "[timing] paf: %llu records\n", (unsigned long long)n_rec);
     } else {
         // Classify the inputs in list order first: the reference prints its "No Index mode" warnings in
