@@ -6,6 +6,8 @@
  * is installed; the binary lands in oracle/_ref/ and is never used by the product path.
  *
  *   usage: sam2bam in.sam out.bam [noindex]
+ *          sam2bam in.sam|in.bam out.cram [noindex] [ref=genome.fa]     CRAM 3.0; without ref= the file is written
+ *                                                                      reference-free (CRAM_OPT_NO_REF)
  */
 #include <stdio.h>
 #include <string.h>
@@ -18,8 +20,20 @@ int main(int argc, char **argv)
     if (!in) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
     sam_hdr_t *hdr = sam_hdr_read(in);
     if (!hdr) { fprintf(stderr, "cannot read header of %s\n", argv[1]); return 1; }
-    samFile *out = sam_open(argv[2], "wb");
+    const size_t ol = strlen(argv[2]);
+    const int cram = ol > 5 && strcmp(argv[2] + ol - 5, ".cram") == 0;
+    int noindex = 0;
+    const char *ref = NULL;
+    for (int k = 3; k < argc; ++k) {
+        if (strcmp(argv[k], "noindex") == 0) noindex = 1;
+        else if (strncmp(argv[k], "ref=", 4) == 0) ref = argv[k] + 4;
+    }
+    samFile *out = sam_open(argv[2], cram ? "wc" : "wb");
     if (!out) { fprintf(stderr, "cannot open %s for writing\n", argv[2]); return 1; }
+    if (cram) {
+        if (ref) { if (hts_set_fai_filename(out, ref) < 0) { fprintf(stderr, "cannot use reference %s\n", ref); return 1; } }
+        else hts_set_opt(out, CRAM_OPT_NO_REF, 1);
+    }
     if (sam_hdr_write(out, hdr) < 0) { fprintf(stderr, "header write failed\n"); return 1; }
     bam1_t *rec = bam_init1();
     long n = 0;
@@ -33,7 +47,7 @@ int main(int argc, char **argv)
     sam_hdr_destroy(hdr);
     sam_close(in);
     if (sam_close(out) < 0) { fprintf(stderr, "close failed\n"); return 1; }
-    if (argc < 4 || strcmp(argv[3], "noindex") != 0) {
+    if (!noindex) {
         if (sam_index_build(argv[2], 0) < 0) { fprintf(stderr, "index build failed\n"); return 1; }
     }
     fprintf(stderr, "sam2bam: %ld records\n", n);

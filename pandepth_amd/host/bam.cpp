@@ -40,6 +40,13 @@ int32_t AlnRec::endpos() const
 
 bool AlnReader::open(const std::string &path, std::string *err)
 {
+    is_cram_ = CramReader::is_cram(path);
+    if (is_cram_) {
+        is_bam_ = false;
+        if (cram_.open(path, &hdr_, &err_)) return true;
+        if (err) *err = err_;
+        return false;
+    }
     if (!bg_.open(path, err)) return false;
     size_t av = 0;
     const uint8_t *p = bg_.peek(&av);
@@ -173,6 +180,7 @@ int AlnReader::next_sam(AlnRec *r)
 
 int AlnReader::next(AlnRec *r)
 {
+    if (is_cram_) { const int k = cram_.next(r); if (k < 0) err_ = cram_.error(); return k; }
     if (!is_bam_) return next_sam(r);
     size_t av = 0;
     const uint8_t *p = bg_.peek(&av);

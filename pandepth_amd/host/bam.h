@@ -1,4 +1,4 @@
-// bam.h — alignment input: BAM (SAM spec §4.2) and text SAM records reduced to the five fields
+// bam.h — alignment input: BAM (SAM spec §4.2), text SAM and CRAM 3.0 (cram.h) records reduced to the five fields
 // the depth path reads (refID, pos, mapq, flag, CIGAR), plus the BAI index (§5.2) used to cut a
 // coordinate-sorted BAM into independent, record-aligned virtual-offset ranges.
 // The reference obtains all of this from htslib (sam_hdr_read / sam_read1 / sam_index_load,
@@ -10,6 +10,7 @@
 #include <unordered_map>
 #include <vector>
 #include "bgzf.h"
+#include "cram.h"
 
 namespace pdh {
 
@@ -36,6 +37,7 @@ public:
     bool open(const std::string &path, std::string *err);
     const AlnHeader &header() const { return hdr_; }
     bool is_bam() const { return is_bam_; }
+    bool is_cram() const { return is_cram_; }        // CRAM 3.0 (host/cram.h): sequential reading only
     // next record; returns 1 record, 0 end of file, -1 error
     int next(AlnRec *r);
     uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record
@@ -49,7 +51,8 @@ private:
     bool getline(std::string *line);
     BgzfReader bg_;
     AlnHeader hdr_;
-    bool is_bam_ = false;
+    bool is_bam_ = false, is_cram_ = false;
+    CramReader cram_;
     std::vector<uint8_t> rec_;
     std::vector<uint32_t> cig_;
     std::unordered_map<std::string, int32_t> name2tid_;

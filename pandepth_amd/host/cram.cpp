@@ -1,0 +1,636 @@
+// cram.cpp — see cram.h.  Section numbers refer to the CRAM format specification, version 3.0.
+#include "cram.h"
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include <map>
+#include <memory>
+#include "bam.h"
+
+namespace pdh {
+
+namespace {
+
+// ---- byte cursor with the variable-length integers of §2.3 ------------------------------------------------------
+struct Cur {
+    const uint8_t *p, *e;
+    bool ok = true;
+    Cur(const uint8_t *b, size_t n) : p(b), e(b + n) {}
+    int u8() { if (p >= e) { ok = false; return 0; } return *p++; }
+    int32_t itf8()
+    {
+        const int b0 = u8();
+        if (b0 < 0x80) return b0;
+        if (b0 < 0xc0) return ((b0 & 0x3f) << 8) | u8();
+        if (b0 < 0xe0) { const int b1 = u8(), b2 = u8(); return ((b0 & 0x1f) << 16) | (b1 << 8) | b2; }
+        if (b0 < 0xf0) { const int b1 = u8(), b2 = u8(), b3 = u8(); return ((b0 & 0x0f) << 24) | (b1 << 16) | (b2 << 8) | b3; }
+        const uint32_t b1 = (uint32_t)u8(), b2 = (uint32_t)u8(), b3 = (uint32_t)u8(), b4 = (uint32_t)u8();
+        return (int32_t)((((uint32_t)b0 & 0x0f) << 28) | (b1 << 20) | (b2 << 12) | (b3 << 4) | (b4 & 0x0f));
+    }
+    int64_t ltf8()
+    {
+        const int b0 = u8();
+        int extra = 0;
+        while (extra < 8 && (b0 & (0x80 >> extra))) ++extra;
+        uint64_t v = extra >= 7 ? 0 : (uint64_t)(b0 & (0xff >> (extra + 1)));
+        for (int k = 0; k < extra; ++k) v = (v << 8) | (uint64_t)u8();
+        return (int64_t)v;
+    }
+    uint32_t u32le() { uint32_t v = 0; for (int k = 0; k < 4; ++k) v |= (uint32_t)u8() << (8 * k); return v; }
+    const uint8_t *take(size_t n) { if ((size_t)(e - p) < n) { ok = false; p = e; return nullptr; } const uint8_t *r = p; p += n; return r; }
+    size_t left() const { return (size_t)(e - p); }
+};
+
+// ---- rANS 4x8 (§ "rANS codec"): four interleaved 32-bit states, 12-bit frequencies ------------------------------------
+bool rans_read_freqs(Cur &c, uint16_t F[256], uint16_t C[256], uint8_t *lookup)
+{
+    memset(F, 0, 512); memset(C, 0, 512);
+    int rle = 0, x = 0;
+    int j = c.u8();
+    do {
+        int f = c.u8();
+        if (f >= 128) f = ((f & 127) << 8) | c.u8();
+        F[j] = (uint16_t)f; C[j] = (uint16_t)x;
+        if (x + f > 4096 || !c.ok) return false;
+        memset(lookup + x, j, (size_t)f);
+        x += f;
+        if (!rle && c.p < c.e && j + 1 == *c.p) { j = c.u8(); rle = c.u8(); }
+        else if (rle) { --rle; ++j; }
+        else j = c.u8();
+    } while (j && c.ok);
+    return c.ok;
+}
+
+bool rans_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out)
+{
+    Cur c(in, n_in);
+    const int order = c.u8();
+    const uint32_t csize = c.u32le(), osize = c.u32le();
+    (void)csize;
+    if (!c.ok || osize > ((uint32_t)1 << 30)) return false;
+    out->assign(osize, 0);
+    if (osize == 0) return true;
+    uint8_t *o = out->data();
+    auto renorm = [&](uint32_t &R) { while (R < (1u << 23) && c.p < c.e) R = (R << 8) | *c.p++; };
+    if (order == 0) {
+        uint16_t F[256], C[256];
+        std::vector<uint8_t> lookup(4096, 0);
+        if (!rans_read_freqs(c, F, C, lookup.data())) return false;
+        uint32_t R[4];
+        for (int k = 0; k < 4; ++k) R[k] = c.u32le();
+        if (!c.ok) return false;
+        const size_t n4 = osize & ~(size_t)3;
+        for (size_t i = 0; i < n4; i += 4)
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t m = R[k] & 0xfff;
+                const uint8_t s = lookup[m];
+                o[i + k] = s;
+                R[k] = F[s] * (R[k] >> 12) + m - C[s];
+                renorm(R[k]);
+            }
+        for (size_t i = n4, k = 0; i < osize; ++i, ++k) {
+            const uint32_t m = R[k] & 0xfff;
+            const uint8_t s = lookup[m];
+            o[i] = s;
+            R[k] = F[s] * (R[k] >> 12) + m - C[s];
+            renorm(R[k]);
+        }
+        return true;
+    }
+    if (order != 1) return false;
+    // order 1: one frequency table per preceding symbol
+    std::vector<uint16_t> F(256 * 256, 0), Cm(256 * 256, 0);
+    std::vector<uint8_t> lookup((size_t)256 * 4096, 0);
+    {
+        int rle_i = 0;
+        int i = c.u8();
+        do {
+            if (!rans_read_freqs(c, &F[(size_t)i * 256], &Cm[(size_t)i * 256], &lookup[(size_t)i * 4096])) return false;
+            if (!rle_i && c.p < c.e && i + 1 == *c.p) { i = c.u8(); rle_i = c.u8(); }
+            else if (rle_i) { --rle_i; ++i; }
+            else i = c.u8();
+        } while (i && c.ok);
+    }
+    uint32_t R[4];
+    for (int k = 0; k < 4; ++k) R[k] = c.u32le();
+    if (!c.ok) return false;
+    const size_t q = osize >> 2;
+    size_t idx[4] = {0, q, 2 * q, 3 * q};
+    int last[4] = {0, 0, 0, 0};
+    for (; idx[0] < q; ) {
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = R[k] & 0xfff;
+            const size_t ctx = (size_t)last[k];
+            const uint8_t s = lookup[ctx * 4096 + m];
+            o[idx[k]++] = s;
+            R[k] = F[ctx * 256 + s] * (R[k] >> 12) + m - Cm[ctx * 256 + s];
+            renorm(R[k]);
+            last[k] = s;
+        }
+    }
+    for (; idx[3] < osize; ) {
+        const uint32_t m = R[3] & 0xfff;
+        const size_t ctx = (size_t)last[3];
+        const uint8_t s = lookup[ctx * 4096 + m];
+        o[idx[3]++] = s;
+        R[3] = F[ctx * 256 + s] * (R[3] >> 12) + m - Cm[ctx * 256 + s];
+        renorm(R[3]);
+        last[3] = s;
+    }
+    return true;
+}
+
+// ---- blocks (§8.1) ------------------------------------------------------------------------------------------------
+struct Block {
+    int method = 0, type = 0;
+    int32_t id = 0;
+    std::vector<uint8_t> data;
+};
+
+bool read_block(Cur &c, Block *b, std::string *err)
+{
+    b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
+    const int32_t csize = c.itf8(), rsize = c.itf8();
+    if (!c.ok || csize < 0 || rsize < 0) { *err = "truncated CRAM block header"; return false; }
+    const uint8_t *d = c.take((size_t)csize);
+    c.take(4);                                           // CRC32
+    if (!c.ok) { *err = "truncated CRAM block"; return false; }
+    if (getenv("PANDEPTH_CRAM_DEBUG")) fprintf(stderr, "[cram] block method %d%s type %d id %d %d -> %d bytes\n", b->method,
+                                               b->method == 4 && csize > 0 ? (d[0] ? " (order 1)" : " (order 0)") : "", b->type, b->id, csize, rsize);
+    switch (b->method) {
+    case 0: b->data.assign(d, d + csize); return true;
+    case 1: {
+        b->data.assign((size_t)rsize, 0);
+        z_stream z; memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 15 + 32) != Z_OK) { *err = "zlib init failed"; return false; }
+        z.next_in = const_cast<Bytef *>(d); z.avail_in = (uInt)csize;
+        z.next_out = b->data.data(); z.avail_out = (uInt)rsize;
+        const int rc = inflate(&z, Z_FINISH);
+        inflateEnd(&z);
+        if (rc != Z_STREAM_END && !(rc == Z_OK && z.avail_out == 0) && !(rc == Z_BUF_ERROR && z.avail_out == 0)) { *err = "corrupt gzip block in CRAM"; return false; }
+        return true;
+    }
+    case 4:
+        if (!rans_decode(d, (size_t)csize, &b->data) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS block in CRAM"; return false; }
+        return true;
+    default:
+        *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma / CRAM 3.1 codecs)";
+        return false;
+    }
+}
+
+// ---- encodings (§13) ------------------------------------------------------------------------------------------------
+struct Enc {
+    int codec = 0;                         // 0 NULL 1 EXTERNAL 3 HUFFMAN 4 BYTE_ARRAY_LEN 5 BYTE_ARRAY_STOP 6 BETA 7 SUBEXP 9 GAMMA
+    int32_t ext = 0, offset = 0, bits = 0;
+    uint8_t stop = 0;
+    std::vector<int32_t> sym, len, code;   // HUFFMAN: sorted by (length, symbol), canonical codes
+    std::unique_ptr<Enc> a, b;             // BYTE_ARRAY_LEN: lengths, values
+};
+
+bool parse_enc(Cur &c, Enc *e)
+{
+    e->codec = c.itf8();
+    const int32_t plen = c.itf8();
+    if (!c.ok || plen < 0) return false;
+    const uint8_t *pp = c.take((size_t)plen);
+    if (!c.ok) return false;
+    Cur p(pp, (size_t)plen);
+    switch (e->codec) {
+    case 0: return true;
+    case 1: e->ext = p.itf8(); return p.ok;
+    case 3: {
+        const int32_t n = p.itf8();
+        std::vector<int32_t> s, l;
+        for (int32_t k = 0; k < n; ++k) s.push_back(p.itf8());
+        const int32_t m = p.itf8();
+        for (int32_t k = 0; k < m; ++k) l.push_back(p.itf8());
+        if (!p.ok || n != m || n <= 0) return false;
+        std::vector<int> ord((size_t)n);
+        for (int k = 0; k < n; ++k) ord[(size_t)k] = k;
+        for (int i = 1; i < n; ++i)                       // insertion sort by (length, symbol): alphabets are tiny
+            for (int j = i; j > 0; --j) {
+                const int x = ord[(size_t)j - 1], y = ord[(size_t)j];
+                if (l[(size_t)x] > l[(size_t)y] || (l[(size_t)x] == l[(size_t)y] && s[(size_t)x] > s[(size_t)y])) std::swap(ord[(size_t)j - 1], ord[(size_t)j]); else break;
+            }
+        int32_t code = 0, prev = l[(size_t)ord[0]];
+        for (int k = 0; k < n; ++k) {
+            const int32_t L = l[(size_t)ord[(size_t)k]];
+            code <<= (L - prev); prev = L;
+            e->sym.push_back(s[(size_t)ord[(size_t)k]]); e->len.push_back(L); e->code.push_back(code);
+            ++code;
+        }
+        return true;
+    }
+    case 4:
+        e->a.reset(new Enc); e->b.reset(new Enc);
+        return parse_enc(p, e->a.get()) && parse_enc(p, e->b.get());
+    case 5: e->stop = (uint8_t)p.u8(); e->ext = p.itf8(); return p.ok;
+    case 6: e->offset = p.itf8(); e->bits = p.itf8(); return p.ok;
+    case 7: e->offset = p.itf8(); e->bits = p.itf8(); return p.ok;      // bits = k
+    case 9: e->offset = p.itf8(); return p.ok;
+    default: return false;                                 // GOLOMB / GOLOMB_RICE: never written by htslib
+    }
+}
+
+// ---- one slice's data: the core bit stream and the external byte streams -------------------------------------------------
+struct SliceData {
+    const uint8_t *core = nullptr; size_t core_n = 0, bitpos = 0;
+    struct Ext { const uint8_t *p, *e; };
+    std::map<int32_t, Ext> ext;
+    bool ok = true;
+
+    uint32_t bits(int n)
+    {
+        uint32_t v = 0;
+        for (int k = 0; k < n; ++k) {
+            const size_t byte = bitpos >> 3;
+            if (byte >= core_n) { ok = false; return 0; }
+            v = (v << 1) | ((core[byte] >> (7 - (bitpos & 7))) & 1u);
+            ++bitpos;
+        }
+        return v;
+    }
+    Ext *find(int32_t id) { auto it = ext.find(id); if (it == ext.end()) { ok = false; return nullptr; } return &it->second; }
+
+    int32_t get_int(const Enc *e)
+    {
+        if (!e) { ok = false; return 0; }
+        switch (e->codec) {
+        case 1: { Ext *x = find(e->ext); if (!x) return 0; Cur c(x->p, (size_t)(x->e - x->p)); const int32_t v = c.itf8(); if (!c.ok) ok = false; x->p = c.p; return v; }
+        case 3: {
+            const size_t n = e->sym.size();
+            if (n == 1 && e->len[0] == 0) return e->sym[0];
+            int32_t code = 0, have = 0;
+            for (size_t k = 0; k < n; ) {
+                const int32_t need = e->len[k] - have;
+                code = (int32_t)(((uint32_t)code << need) | bits(need)); have += need;
+                for (; k < n && e->len[k] == have; ++k) if (e->code[k] == code) return e->sym[k];
+                if (!ok) return 0;
+            }
+            ok = false; return 0;
+        }
+        case 6: return (int32_t)bits(e->bits) - e->offset;
+        case 7: {
+            int i = 0;
+            while (ok && bits(1)) ++i;
+            int32_t v;
+            if (i == 0) v = (int32_t)bits(e->bits);
+            else { const int b = i + e->bits - 1; v = (int32_t)((1u << b) | bits(b)); }
+            return v - e->offset;
+        }
+        case 9: {
+            int n = 0;
+            while (ok && !bits(1)) ++n;
+            return (int32_t)((1u << n) | bits(n)) - e->offset;
+        }
+        default: ok = false; return 0;
+        }
+    }
+    int get_byte(const Enc *e)
+    {
+        if (!e) { ok = false; return 0; }
+        if (e->codec == 1) { Ext *x = find(e->ext); if (!x) return 0; if (x->p >= x->e) { ok = false; return 0; } return *x->p++; }
+        return get_int(e) & 0xff;
+    }
+    void skip_bytes(const Enc *e, int32_t n)                // n values of a byte series
+    {
+        if (n <= 0) return;
+        if (!e) { ok = false; return; }
+        if (e->codec == 1) { Ext *x = find(e->ext); if (!x) return; if ((int64_t)(x->e - x->p) < n) { ok = false; x->p = x->e; } else x->p += n; return; }
+        for (int32_t k = 0; k < n && ok; ++k) (void)get_int(e);
+    }
+    int32_t skip_array(const Enc *e)                         // one byte array; returns its length
+    {
+        if (!e) { ok = false; return 0; }
+        if (e->codec == 4) { const int32_t n = get_int(e->a.get()); if (n < 0) { ok = false; return 0; } skip_bytes(e->b.get(), n); return n; }
+        if (e->codec == 5) {
+            Ext *x = find(e->ext); if (!x) return 0;
+            const uint8_t *q = (const uint8_t *)memchr(x->p, e->stop, (size_t)(x->e - x->p));
+            if (!q) { ok = false; return 0; }
+            const int32_t n = (int32_t)(q - x->p);
+            x->p = q + 1;
+            return n;
+        }
+        ok = false; return 0;
+    }
+};
+
+inline uint16_t key2(char a, char b) { return (uint16_t)(((uint8_t)a << 8) | (uint8_t)b); }
+
+struct CompHeader {
+    bool rn = true, ap_delta = true;
+    std::vector<std::vector<int32_t>> td;                  // tag dictionary: lines of tag keys
+    std::map<uint16_t, Enc> ds;
+    std::map<int32_t, Enc> tags;
+    const Enc *get(char a, char b) const { auto it = ds.find(key2(a, b)); return it == ds.end() ? nullptr : &it->second; }
+};
+
+bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader *h)
+{
+    Cur c(d.data(), d.size());
+    {   // preservation map
+        const int32_t size = c.itf8();
+        if (!c.ok || size < 0) return false;
+        const uint8_t *pp = c.take((size_t)size);
+        if (!c.ok) return false;
+        Cur p(pp, (size_t)size);
+        const int32_t n = p.itf8();
+        for (int32_t k = 0; k < n && p.ok; ++k) {
+            const int a = p.u8(), b = p.u8();
+            if (a == 'R' && b == 'N') h->rn = p.u8() != 0;
+            else if (a == 'A' && b == 'P') h->ap_delta = p.u8() != 0;
+            else if (a == 'R' && b == 'R') p.u8();
+            else if (a == 'S' && b == 'M') p.take(5);
+            else if (a == 'T' && b == 'D') {
+                const int32_t len = p.itf8();
+                const uint8_t *t = p.take(len < 0 ? 0 : (size_t)len);
+                if (!p.ok) return false;
+                std::vector<int32_t> line;
+                for (int32_t i = 0; i < len; ) {
+                    if (t[i] == 0) { h->td.push_back(line); line.clear(); ++i; continue; }
+                    if (i + 3 > len) return false;
+                    line.push_back((t[i] << 16) | (t[i + 1] << 8) | t[i + 2]);
+                    i += 3;
+                }
+                if (!line.empty()) h->td.push_back(line);
+            } else return false;
+        }
+        if (!p.ok) return false;
+    }
+    {   // data series encodings
+        const int32_t size = c.itf8();
+        if (!c.ok || size < 0) return false;
+        const uint8_t *pp = c.take((size_t)size);
+        if (!c.ok) return false;
+        Cur p(pp, (size_t)size);
+        const int32_t n = p.itf8();
+        for (int32_t k = 0; k < n; ++k) {
+            const int a = p.u8(), b = p.u8();
+            Enc e;
+            if (!p.ok || !parse_enc(p, &e)) return false;
+            h->ds[key2((char)a, (char)b)] = std::move(e);
+        }
+    }
+    {   // tag encodings
+        const int32_t size = c.itf8();
+        if (!c.ok || size < 0) return false;
+        const uint8_t *pp = c.take((size_t)size);
+        if (!c.ok) return false;
+        Cur p(pp, (size_t)size);
+        const int32_t n = p.itf8();
+        for (int32_t k = 0; k < n; ++k) {
+            const int32_t key = p.itf8();
+            Enc e;
+            if (!p.ok || !parse_enc(p, &e)) return false;
+            h->tags[key] = std::move(e);
+        }
+    }
+    return true;
+}
+
+int fgetc_itf8(FILE *f, int32_t *v)
+{
+    uint8_t b[5];
+    const int c0 = fgetc(f);
+    if (c0 == EOF) return -1;
+    b[0] = (uint8_t)c0;
+    const int extra = b[0] < 0x80 ? 0 : b[0] < 0xc0 ? 1 : b[0] < 0xe0 ? 2 : b[0] < 0xf0 ? 3 : 4;
+    if (extra && fread(b + 1, 1, (size_t)extra, f) != (size_t)extra) return -1;
+    Cur c(b, (size_t)extra + 1);
+    *v = c.itf8();
+    return 0;
+}
+
+int fgetc_ltf8(FILE *f, int64_t *v)
+{
+    uint8_t b[9];
+    const int c0 = fgetc(f);
+    if (c0 == EOF) return -1;
+    b[0] = (uint8_t)c0;
+    int extra = 0;
+    while (extra < 8 && (b[0] & (0x80 >> extra))) ++extra;
+    if (extra && fread(b + 1, 1, (size_t)extra, f) != (size_t)extra) return -1;
+    Cur c(b, (size_t)extra + 1);
+    *v = c.ltf8();
+    return 0;
+}
+
+struct ContainerHeader { int32_t length = 0, ref = 0, start = 0, span = 0, n_rec = 0, n_blocks = 0; std::vector<int32_t> landmarks; };
+
+// 1 ok, 0 clean end of file, -1 truncated
+int read_container_header(FILE *f, ContainerHeader *h)
+{
+    uint8_t l[4];
+    const size_t got = fread(l, 1, 4, f);
+    if (got == 0) return 0;
+    if (got != 4) return -1;
+    h->length = (int32_t)((uint32_t)l[0] | ((uint32_t)l[1] << 8) | ((uint32_t)l[2] << 16) | ((uint32_t)l[3] << 24));
+    int64_t t;
+    int32_t n = 0;
+    if (fgetc_itf8(f, &h->ref) || fgetc_itf8(f, &h->start) || fgetc_itf8(f, &h->span) || fgetc_itf8(f, &h->n_rec) ||
+        fgetc_ltf8(f, &t) || fgetc_ltf8(f, &t) || fgetc_itf8(f, &h->n_blocks) || fgetc_itf8(f, &n)) return -1;
+    h->landmarks.clear();
+    for (int32_t k = 0; k < n; ++k) { int32_t v; if (fgetc_itf8(f, &v)) return -1; h->landmarks.push_back(v); }
+    if (fread(l, 1, 4, f) != 4) return -1;                 // CRC32
+    return h->length < 0 ? -1 : 1;
+}
+
+} // namespace
+
+bool CramReader::is_cram(const std::string &path)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char m[4] = {0, 0, 0, 0};
+    const size_t n = fread(m, 1, 4, f);
+    fclose(f);
+    return n == 4 && memcmp(m, "CRAM", 4) == 0;
+}
+
+void CramReader::close() { if (f_) { fclose(f_); f_ = nullptr; } }
+
+bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
+{
+    close();
+    err_.clear(); eof_ = false; recs_.clear(); cigs_.clear(); cur_ = 0;
+    auto bad = [&](const std::string &m) { err_ = m; if (err) *err = m; close(); return false; };
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) return bad("cannot open " + path);
+    uint8_t def[26];
+    if (fread(def, 1, 26, f_) != 26 || memcmp(def, "CRAM", 4) != 0) return bad("not a CRAM file: " + path);
+    if (def[4] != 3 || def[5] != 0) return bad("CRAM version " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 only): " + path);
+    // §6: the first container holds the SAM header
+    ContainerHeader ch;
+    if (read_container_header(f_, &ch) != 1) return bad("truncated CRAM header container: " + path);
+    std::vector<uint8_t> body((size_t)ch.length);
+    if (ch.length && fread(body.data(), 1, body.size(), f_) != body.size()) return bad("truncated CRAM header container: " + path);
+    Cur c(body.data(), body.size());
+    Block b;
+    std::string e2;
+    if (!read_block(c, &b, &e2)) return bad(e2);
+    if (b.type != 0 || b.data.size() < 4) return bad("CRAM header block missing: " + path);
+    const uint32_t l_text = (uint32_t)b.data[0] | ((uint32_t)b.data[1] << 8) | ((uint32_t)b.data[2] << 16) | ((uint32_t)b.data[3] << 24);
+    if ((size_t)l_text + 4 > b.data.size()) return bad("CRAM header text truncated: " + path);
+    hdr->text.assign((const char *)b.data.data() + 4, l_text);
+    const size_t z = hdr->text.find('\0');
+    if (z != std::string::npos) hdr->text.resize(z);
+    hdr->names.clear(); hdr->lens.clear();
+    size_t p = 0;
+    while (p < hdr->text.size()) {
+        size_t nl = hdr->text.find('\n', p);
+        if (nl == std::string::npos) nl = hdr->text.size();
+        if (nl - p >= 3 && hdr->text.compare(p, 3, "@SQ") == 0) {
+            std::string name; long long len = 0;
+            size_t q = p;
+            while (q < nl) {
+                size_t t = hdr->text.find('\t', q);
+                if (t == std::string::npos || t > nl) t = nl;
+                if (t - q > 3 && hdr->text.compare(q, 3, "SN:") == 0) name = hdr->text.substr(q + 3, t - q - 3);
+                else if (t - q > 3 && hdr->text.compare(q, 3, "LN:") == 0) len = atoll(hdr->text.substr(q + 3, t - q - 3).c_str());
+                q = t + 1;
+            }
+            hdr->names.push_back(name); hdr->lens.push_back((uint32_t)len);
+        }
+        p = nl + 1;
+    }
+    return true;
+}
+
+bool CramReader::load_container()
+{
+    recs_.clear(); cigs_.clear(); cur_ = 0;
+    for (;;) {
+        ContainerHeader ch;
+        const int rc = read_container_header(f_, &ch);
+        if (rc == 0) { eof_ = true; return true; }
+        if (rc < 0) return fail("truncated CRAM container header");
+        std::vector<uint8_t> body((size_t)ch.length);
+        if (ch.length && fread(body.data(), 1, body.size(), f_) != body.size()) return fail("truncated CRAM container");
+        if (ch.n_rec == 0) continue;                       // the end-of-file container (or an empty one)
+        Cur c(body.data(), body.size());
+        Block cb;
+        std::string e2;
+        if (!read_block(c, &cb, &e2)) return fail(e2);
+        if (cb.type != 1) return fail("CRAM compression header missing");
+        CompHeader H;
+        if (!parse_comp_header(cb.data, &H)) return fail("CRAM compression header uses an encoding this reader does not know");
+        if (getenv("PANDEPTH_CRAM_DEBUG")) {
+            fprintf(stderr, "[cram] container ref %d n_rec %d rn %d ap_delta %d td %zu\n", ch.ref, ch.n_rec, (int)H.rn, (int)H.ap_delta, H.td.size());
+            for (auto &kv : H.ds) fprintf(stderr, "[cram]   %c%c codec %d ext %d%s\n", kv.first >> 8, kv.first & 0xff, kv.second.codec, kv.second.ext,
+                                          kv.second.codec == 3 ? (kv.second.sym.size() == 1 ? " (const)" : " (huffman)") : "");
+            for (auto &kv : H.tags) fprintf(stderr, "[cram]   tag %c%c%c codec %d ext %d\n", kv.first >> 16, (kv.first >> 8) & 0xff, kv.first & 0xff, kv.second.codec, kv.second.ext);
+        }
+        const Enc *BF = H.get('B', 'F'), *CF = H.get('C', 'F'), *RI = H.get('R', 'I'), *RL = H.get('R', 'L'), *AP = H.get('A', 'P'),
+                  *RG = H.get('R', 'G'), *RN = H.get('R', 'N'), *MF = H.get('M', 'F'), *NS = H.get('N', 'S'), *NP = H.get('N', 'P'),
+                  *TS = H.get('T', 'S'), *NF = H.get('N', 'F'), *TL = H.get('T', 'L'), *FN = H.get('F', 'N'), *FC = H.get('F', 'C'),
+                  *FP = H.get('F', 'P'), *DL = H.get('D', 'L'), *BB = H.get('B', 'B'), *QQ = H.get('Q', 'Q'), *BS = H.get('B', 'S'),
+                  *IN = H.get('I', 'N'), *RS = H.get('R', 'S'), *PD = H.get('P', 'D'), *HC = H.get('H', 'C'), *SC = H.get('S', 'C'),
+                  *MQ = H.get('M', 'Q'), *BA = H.get('B', 'A'), *QS = H.get('Q', 'S');
+        while (c.left() > 0) {
+            // §8.5 slice header, then its blocks
+            Block sh;
+            if (!read_block(c, &sh, &e2)) return fail(e2);
+            if (sh.type != 2) return fail("CRAM slice header expected");
+            Cur s(sh.data.data(), sh.data.size());
+            const int32_t ref = s.itf8(), start = s.itf8();
+            s.itf8();                                       // span
+            const int32_t n_rec = s.itf8();
+            s.ltf8();                                       // record counter
+            const int32_t n_blocks = s.itf8();
+            if (!s.ok || n_rec < 0 || n_blocks < 0) return fail("corrupt CRAM slice header");
+            std::vector<Block> blocks((size_t)n_blocks);
+            SliceData sd;
+            for (int32_t k = 0; k < n_blocks; ++k) {
+                if (!read_block(c, &blocks[(size_t)k], &e2)) return fail(e2);
+                Block &b = blocks[(size_t)k];
+                if (b.type == 5) { sd.core = b.data.data(); sd.core_n = b.data.size(); }
+                else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{b.data.data(), b.data.data() + b.data.size()};
+            }
+            int32_t prev_ap = start;
+            for (int32_t r = 0; r < n_rec; ++r) {
+                // §10: the record
+                const int32_t bf = sd.get_int(BF), cf = sd.get_int(CF);
+                int32_t ri = ref;
+                if (ref == -2) ri = sd.get_int(RI);
+                const int32_t rl = sd.get_int(RL);
+                int32_t ap = sd.get_int(AP);
+                if (H.ap_delta) { prev_ap += ap; ap = prev_ap; }
+                sd.get_int(RG);
+                if (H.rn) sd.skip_array(RN);
+                if (cf & 2) {
+                    sd.get_int(MF);
+                    if (!H.rn) sd.skip_array(RN);
+                    sd.get_int(NS); sd.get_int(NP); sd.get_int(TS);
+                } else if (cf & 4) sd.get_int(NF);
+                const int32_t tl = sd.get_int(TL);
+                if (!sd.ok) return fail("corrupt CRAM record");
+                if (tl >= 0 && (size_t)tl < H.td.size())
+                    for (int32_t key : H.td[(size_t)tl]) {
+                        auto it = H.tags.find(key);
+                        if (it == H.tags.end()) return fail("CRAM tag without an encoding");
+                        sd.skip_array(&it->second);
+                    }
+                else if (!H.td.empty() || tl != 0) return fail("corrupt CRAM tag line");
+                Rec rec{ri, ap - 1, (uint16_t)bf, 0, (uint32_t)cigs_.size(), 0};
+                auto op = [&](uint32_t code, int32_t len) {
+                    if (len <= 0) return;
+                    if (cigs_.size() > rec.cig_off && (cigs_.back() & 0xf) == code) cigs_.back() += (uint32_t)len << 4;
+                    else cigs_.push_back(((uint32_t)len << 4) | code);
+                };
+                if (!(bf & 4)) {
+                    // §10.6: read features -> the CIGAR shape (M 0, I 1, D 2, N 3, S 4, H 5, P 6)
+                    const int32_t fn = sd.get_int(FN);
+                    int32_t prev = 0, seq_pos = 1;
+                    for (int32_t k = 0; k < fn && sd.ok; ++k) {
+                        const int fc = sd.get_byte(FC);
+                        const int32_t pos = prev + sd.get_int(FP);
+                        prev = pos;
+                        if (pos > seq_pos) { op(0, pos - seq_pos); seq_pos = pos; }
+                        switch (fc) {
+                        case 'S': { const int32_t n = sd.skip_array(SC); op(4, n); seq_pos += n; break; }
+                        case 'X': sd.get_byte(BS); op(0, 1); ++seq_pos; break;
+                        case 'D': op(2, sd.get_int(DL)); break;
+                        case 'I': { const int32_t n = sd.skip_array(IN); op(1, n); seq_pos += n; break; }
+                        case 'i': sd.get_byte(BA); op(1, 1); ++seq_pos; break;
+                        case 'b': { const int32_t n = sd.skip_array(BB); op(0, n); seq_pos += n; break; }
+                        case 'q': sd.skip_array(QQ); break;
+                        case 'B': sd.get_byte(BA); sd.get_byte(QS); op(0, 1); ++seq_pos; break;
+                        case 'Q': sd.get_byte(QS); break;
+                        case 'H': op(5, sd.get_int(HC)); break;
+                        case 'P': op(6, sd.get_int(PD)); break;
+                        case 'N': op(3, sd.get_int(RS)); break;
+                        default: return fail("unknown CRAM read feature");
+                        }
+                    }
+                    if (seq_pos <= rl) op(0, rl - seq_pos + 1);
+                    rec.mapq = (uint8_t)sd.get_int(MQ);
+                    if (cf & 1) sd.skip_bytes(QS, rl);
+                } else {
+                    sd.skip_bytes(BA, rl);
+                    if (cf & 1) sd.skip_bytes(QS, rl);
+                }
+                if (!sd.ok) return fail("corrupt CRAM record (record " + std::to_string(r) + " of its slice)");
+                rec.n_cig = (uint32_t)cigs_.size() - rec.cig_off;
+                recs_.push_back(rec);
+            }
+        }
+        if (!recs_.empty()) return true;
+    }
+}
+
+int CramReader::next(AlnRec *r)
+{
+    if (!f_) return -1;
+    while (cur_ >= recs_.size()) {
+        if (eof_) return 0;
+        if (!load_container()) return -1;
+        if (eof_ && recs_.empty()) return 0;
+    }
+    const Rec &x = recs_[cur_++];
+    r->tid = x.tid; r->pos = x.pos; r->flag = x.flag; r->mapq = x.mapq;
+    r->n_cigar = x.n_cig; r->cigar = cigs_.data() + x.cig_off;
+    return 1;
+}
+
+} // namespace pdh

@@ -192,6 +192,21 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     const bool have_bai = bai.load_for(path, &err);        // .bai or .csi
     AlnReader probe;
     if (!probe.open(path, &err)) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
+    if (probe.is_cram()) {
+        // CRAM with a .crai next to it: the reads the reference's index fetch would return (PD:419-434), found by walking
+        // the file in order (containers are decoded whole; the .crai itself is not consulted)
+        RunSink sink(eng);
+        AlnRec r;
+        uint64_t n = 0;
+        int k;
+        while ((k = probe.next(&r)) == 1) {
+            ++n;
+            if (flt.pass(r) && spans.hit(r)) emit_runs(r, &sink);
+        }
+        if (k < 0) { eng->fail(probe.error() + " (" + path + ")"); return false; }
+        if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing] cram (indexed selection, sequential): %llu records\n", (unsigned long long)n);
+        return true;
+    }
     if (!probe.is_bam()) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
     // Work list: [begin, end) virtual-offset ranges, each starting at a record boundary.
     //  * whole-genome modes: the file cut at linear-index offsets into ranges of similar size;
@@ -687,6 +702,23 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         if (!first.open(path, &err)) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
         hdr = first.header();
         if (hdr.names.empty()) { std::cerr << "Error: Failed to read the header for the BAM/CRAM file: " << path << std::endl; return 1; }
+        if (first.is_cram() && !o.reference.empty()) {
+            // PD:3486-3492 hands -r to htslib for CRAM input, and htslib then trusts the FASTA over the header: an @SQ
+            // whose LN differs from the indexed sequence's length is rewritten to the FASTA's (cram_io.c
+            // sanitise_SQ_lines).  Plain-text FASTA only (its faidx cannot index a gzip file, and nothing changes then).
+            std::map<std::string, uint32_t> fa_len;
+            std::string scratch;
+            bool plain = false;
+            { FILE *fp = fopen(o.reference.c_str(), "rb"); if (fp) { const int c0 = fgetc(fp), c1 = fgetc(fp); plain = !(c0 == 0x1f && c1 == 0x8b) && c0 != EOF; fclose(fp); } }
+            if (plain && read_fasta_records(o.reference, &scratch, [&](const std::string &name, size_t off, size_t n) {
+                    fa_len.insert({name, (uint32_t)n});          // the first record of a name is the indexed one
+                    scratch.resize(off);
+                }))
+                for (size_t i = 0; i < hdr.names.size(); ++i) {
+                    auto it = fa_len.find(hdr.names[i]);
+                    if (it != fa_len.end()) hdr.lens[i] = it->second;
+                }
+        }
         if (o.gc) {
             // PD:3510-3532 (PD:2068-2090 for lists): -c needs -r, checked once the first input's header has been read
             if (o.reference.empty()) { std::cerr << "Error: lack reference sequence (-r) for GC parse" << std::endl; return 0; }

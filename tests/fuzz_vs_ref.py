@@ -130,7 +130,7 @@ def gen_regions(rng, names, lens, kind):
     return "\n".join(lines) + ("\n" if rng.random() < 0.9 else "")
 
 
-def gen_fasta(rng, names, lens):
+def gen_fasta(rng, names, lens, plain=False):
     """-r for -c: every contig present and at least as long as the header says (beyond a sequence's end, and for a contig
     without a sequence, the reference indexes past its string — undefined, not generated); lower case, N / IUPAC codes,
     header comments, CRLF, blank lines, FASTQ-style records, a second record of the same name (the first wins), names
@@ -154,16 +154,16 @@ def gen_fasta(rng, names, lens):
     if rng.random() < 0.3:
         k0 = [i for i, r in enumerate(recs) if r[0] == names[0]][0]
         recs.insert(rng.randrange(k0 + 1, len(recs) + 1), (rng.choice(["alien", "other"]), "ACGT" * rng.randrange(1, 30)))
-    eol = rng.choice(["\n", "\n", "\n", "\r\n"])
+    eol = "\n" if plain else rng.choice(["\n", "\n", "\n", "\r\n"])
     out = []
     for name, seq in recs:
-        if len(seq) < 5000 and rng.random() < 0.1:
+        if not plain and len(seq) < 5000 and rng.random() < 0.1:
             out.append("@%s%s%s%s+%s%s%s" % (name, rng.choice(["", " q"]), eol, seq + eol if seq else eol, eol,
                                          "".join(rng.choice("@>+IIIF#") for _ in seq), eol))
             continue
         w = rng.choice([50, 60, 70, 80, 1000, 10 ** 9])
         body = eol.join(seq[k:k + w] for k in range(0, len(seq), w))
-        if rng.random() < 0.1 and len(seq) > w:
+        if not plain and rng.random() < 0.1 and len(seq) > w:
             body = body.replace(eol, eol + "\n", 1)              # an empty line inside the record
         out.append(">%s%s%s%s%s" % (name, rng.choice(["", "", " some comment", "\tx=1"]), eol, body, eol))
     text = "".join(out)
@@ -278,8 +278,15 @@ def one_case(rng, td):
     sam, names, lens = gen_sam(rng, sorted_hdr)
     open(os.path.join(td, "x.sam"), "w").write(sam)
     args = ["-i", "x.sam"]
-    form = rng.choice(["sam", "bam+bai", "bam+bai", "bam", "list"])
-    if form.startswith("bam") and os.access(S2B, os.X_OK):
+    form = rng.choice(["sam", "bam+bai", "bam+bai", "bam", "list", "cram", "cram+crai"])
+    if form.startswith("cram") and os.access(S2B, os.X_OK):
+        # CRAM 3.0 written reference-free by the reference's own htslib; with a .crai next to it the reference takes its
+        # indexed path
+        indexed = form == "cram+crai" and sorted_hdr
+        r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]), cwd=td, capture_output=True)
+        if r.returncode == 0:
+            args = ["-i", "x.cram"]
+    elif form.startswith("bam") and os.access(S2B, os.X_OK):
         indexed = form == "bam+bai" and sorted_hdr
         r = subprocess.run([S2B, "x.sam", "x.bam"] + ([] if indexed else ["noindex"]), cwd=td, capture_output=True)
         if r.returncode == 0:
@@ -305,9 +312,10 @@ def one_case(rng, td):
             fn = "y%d.sam" % k
             open(os.path.join(td, fn), "w").write("\n".join(hdr + ok) + "\n")
             if rng.random() < 0.5:
-                r = subprocess.run([S2B, fn, "y%d.bam" % k] + ([] if sorted_hdr and rng.random() < 0.7 else ["noindex"]), cwd=td, capture_output=True)
+                ext = rng.choice(["bam", "bam", "cram"])
+                r = subprocess.run([S2B, fn, "y%d.%s" % (k, ext)] + ([] if sorted_hdr and rng.random() < 0.7 else ["noindex"]), cwd=td, capture_output=True)
                 if r.returncode == 0:
-                    fn = "y%d.bam" % k
+                    fn = "y%d.%s" % (k, ext)
             files.append(fn)
         open(os.path.join(td, "in.list"), "w").write("\n".join(files) + "\n")
         args = ["-i", "in.list"]
@@ -353,9 +361,12 @@ def one_case(rng, td):
     small_w = "-w" in args and int(args[args.index("-w") + 1]) < 150
     if rng.random() < 0.25 and not small_w:
         import gzip
-        fa = gen_fasta(rng, names, lens)
+        # CRAM input: -r also goes to htslib's faidx, which wants an indexable file (uniform lines, no FASTQ records, not
+        # gzip) and then lets the FASTA's sequence lengths override the header's LN values
+        cram = args[1].endswith(".cram") or (args[1].endswith(".list") and open(os.path.join(td, args[1])).read().split("\n")[0].endswith(".cram"))
+        fa = gen_fasta(rng, names, lens, plain=cram)
         fn = "genome.fa"
-        if rng.random() < 0.25:
+        if rng.random() < 0.25 and not cram:
             fn += ".gz"
             gzip.open(os.path.join(td, fn), "wb", compresslevel=1).write(fa.encode())
         else:
