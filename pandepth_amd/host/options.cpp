@@ -12,7 +12,7 @@ void print_help()
     std::cout <<
         "Usage: pandepth -i in.bam [-g gene.gff | -b region.bed] -o outPrefix\n"
         " Input/Output options:\n"
-        "   -i    <str>     input of sam/bam/paf or #.list file (cram is not read)\n"
+        "   -i    <str>     input of sam/bam/cram/paf or #.list file\n"
         "   -o    <str>     prefix of output file\n"
         " Target options:\n"
         "   -g    <str>     input gff/gtf file for gene region\n"
@@ -26,7 +26,7 @@ void print_help()
         "   -x    <int>     exclude reads with any of the bits in FLAG set [1796]\n"
         " Other options:\n"
         "   -t    <int>     number of host reader threads [3]\n"
-        "   -r    <str>     reference genome file for GC parse (and the target table of paf input)\n"
+        "   -r    <str>     reference genome file for GC parse (cram is decoded without it)\n"
         "   -c              enable the calculation of GC content (requires -r)\n"
         "   -h              show this help [MI355X engine, PanDepth v2.26 compatible]\n"
         "\n";

@@ -554,6 +554,102 @@ F6_CASES = [
     ("c_without_r", ["-i", "p.paf", "-c"]),
 ]
 
+# ---------------------------------------------------------------------------------------------
+# F7: CRAM 3.0 input written by the reference's own htslib (oracle/_ref/sam2bam ... out.cram): reference-free and
+# reference-based files, with and without .crai, multi-reference slices (tiny contigs), bases + qualities + tags +
+# mate fields in the records, a list mixing CRAM and BAM, and -r next to a CRAM (htslib then takes the contig
+# lengths from the FASTA)
+# ---------------------------------------------------------------------------------------------
+F7_CONTIGS = [("k1", 4000), ("k2", 900), ("k3", 1), ("k4", 250)]
+
+
+def build_f7(d):
+    os.makedirs(d, exist_ok=True)
+    rng = random.Random(707)
+    ref = {nm: "".join(rng.choice("ACGT") for _ in range(ln)) for nm, ln in F7_CONTIGS}
+    recs = []
+    for i in range(1500):
+        ci = rng.choice([0, 0, 0, 1, 3])
+        nm, L = F7_CONTIGS[ci]
+        ops = []
+        k = rng.randrange(1, 5)
+        for j in range(k):
+            ops.append((rng.randrange(5, 50), "M"))
+            if j < k - 1:
+                ops.append((rng.randrange(1, 25), rng.choice("IDNX=")))
+        if rng.random() < 0.3:
+            ops.insert(0, (rng.randrange(1, 15), "S"))
+        if rng.random() < 0.2:
+            ops.append((rng.randrange(1, 15), "S"))
+        if rng.random() < 0.1:
+            ops.insert(0, (rng.randrange(1, 9), "H"))
+        span = sum(n for n, o in ops if o in "MDN=X")
+        if span >= L:
+            continue
+        pos = rng.randrange(1, L - span + 1)
+        seq, rp = [], pos - 1
+        for n, o in ops:
+            if o in "M=X":
+                for t in range(n):
+                    b = ref[nm][rp + t]
+                    if o == "X" or (o == "M" and rng.random() < 0.04):
+                        b = rng.choice([x for x in "ACGT" if x != b])
+                    seq.append(b)
+                rp += n
+            elif o in "IS":
+                seq += [rng.choice("ACGTN") for _ in range(n)]
+            elif o in "DN":
+                rp += n
+        seq = "".join(seq)
+        qual = "".join(chr(33 + rng.randrange(2, 41)) for _ in seq)
+        flag = rng.choice([0, 16, 99, 147, 83, 163, 256, 1024, 0, 16])
+        mate = ("=", pos + rng.randrange(0, 200), rng.randrange(-300, 300)) if flag & 1 else ("*", 0, 0)
+        tags = rng.choice(["", "\tNM:i:%d" % rng.randrange(9), "\tRG:Z:g1\tAS:i:%d" % rng.randrange(200)])
+        recs.append((ci, pos, "r%d\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s%s" % (
+            i, flag, nm, pos, rng.choice([0, 10, 60]), "".join("%d%s" % x for x in ops), mate[0], mate[1], mate[2], seq, qual, tags)))
+    recs.append((99, 0, "u1\t77\t*\t0\t0\t*\t*\t0\t0\tACGTACGT\tIIIIIIII"))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in F7_CONTIGS) + "@RG\tID:g1\tSM:x\n"
+    write(os.path.join(d, "m.sam"), hdr + "\n".join(r[2] for r in recs) + "\n")
+    # the FASTA handed to -r is LONGER than k2 says: with CRAM input htslib rewrites the header's LN from it
+    fa = ""
+    for nm, ln in F7_CONTIGS:
+        sq = ref[nm] + ("ACGTT" * 5 if nm == "k2" else "")
+        fa += ">%s\n" % nm + "".join(sq[k:k + 60] + "\n" for k in range(0, len(sq), 60))
+    write(os.path.join(d, "m.fa"), fa)
+    write(os.path.join(d, "m_exact.fa"), "".join(">%s\n" % nm + "".join(ref[nm][k:k + 60] + "\n" for k in range(0, ln, 60)) for nm, ln in F7_CONTIGS))
+    subprocess.run([SAM2BAM, "m.sam", "m.cram"], cwd=d, check=True, stderr=subprocess.DEVNULL)                       # reference-free + .crai
+    subprocess.run([SAM2BAM, "m.sam", "m_noidx.cram", "noindex"], cwd=d, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([SAM2BAM, "m.sam", "m_ref.cram", "ref=m_exact.fa"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # reference-based
+    for junk in ("m_exact.fa.fai",):
+        if os.path.exists(os.path.join(d, junk)):
+            os.remove(os.path.join(d, junk))
+    to_bam(os.path.join(d, "m.sam"), os.path.join(d, "m.bam"), True)
+    write(os.path.join(d, "m.list"), "m.cram\nm.bam\nm_noidx.cram\n")
+    write(os.path.join(d, "m.gff"), "\n".join([
+        "k1\ts\tCDS\t100\t700\t.\t+\t0\tID=a;Parent=t1", "k1\ts\tCDS\t1500\t1900\t.\t+\t0\tID=b;Parent=t1",
+        "k1\ts\tCDS\t3990\t4000\t.\t+\t0\tID=c;Parent=t2", "k2\ts\tCDS\t1\t900\t.\t-\t0\tID=d;Parent=u1",
+        "k4\ts\tCDS\t20\t250\t.\t-\t0\tID=e;Parent=v1"]) + "\n")
+    write(os.path.join(d, "m.bed4"), "k1\t1\t400\tA\nk1\t2000\t3000\tA\nk2\t1\t900\tB\nk4\t100\t250\tD\n")
+
+
+F7_CASES = [
+    ("chr", ["-i", "m.cram"]),
+    ("chr_noidx", ["-i", "m_noidx.cram"]),
+    ("chr_refbased", ["-i", "m_ref.cram"]),
+    ("chr_s", ["-i", "m.cram", "-s"]),
+    ("chr_q20_x0", ["-i", "m.cram", "-q", "20", "-x", "0"]),
+    ("w100_a", ["-i", "m.cram", "-w", "100", "-a"]),
+    ("w500", ["-i", "m_noidx.cram", "-w", "500", "-d", "3"]),
+    ("gff", ["-i", "m.cram", "-g", "m.gff"]),
+    ("gff_noidx", ["-i", "m_noidx.cram", "-g", "m.gff"]),
+    ("bed4_a", ["-i", "m_ref.cram", "-b", "m.bed4", "-a"]),
+    ("list", ["-i", "m.list"]),
+    ("list_gff", ["-i", "m.list", "-g", "m.gff"]),
+    ("r_overrides_ln", ["-i", "m.cram", "-r", "m.fa"]),
+    ("gc", ["-i", "m.cram", "-r", "m.fa", "-c", "-w", "300"]),
+]
+
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
 
 
@@ -593,7 +689,7 @@ def main():
         manifest = [e for e in json.load(open(os.path.join(HERE, "manifest.json"))) if e["fixture"] not in only]
     for fx, build, cases in (("f1", build_f1, F1_CASES), ("f2", build_f2, F2_CASES),
                              ("f3", build_f3, F3_CASES), ("f4", build_f4, F4_CASES), ("f5", build_f5, F5_CASES),
-                             ("f6", build_f6, F6_CASES)):
+                             ("f6", build_f6, F6_CASES), ("f7", build_f7, F7_CASES)):
         if only and fx not in only:
             continue
         d = os.path.join(HERE, fx)

@@ -14,9 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CLI = os.path.join(ROOT, "pandepth_amd", "pandepth")
 ALL_CASES = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
-# fixtures f5 (GC columns) and f6 (PAF input) run from tests/test_z_cli_gpu_late.py, after everything else: they were added
+# fixtures f5 (GC columns), f6 (PAF input) and f7 (CRAM input) run from tests/test_z_cli_gpu_late.py, after everything else: they were added
 # when the round's GPU budget was already spent, and the round-end run stops at the first failure
-MANIFEST = [e for e in ALL_CASES if e["fixture"] not in ("f5", "f6")]
+MANIFEST = [e for e in ALL_CASES if e["fixture"] not in ("f5", "f6", "f7")]
 
 
 @pytest.mark.parametrize("threads", [1, 4])

@@ -1,0 +1,63 @@
+"""CRAM 3.0 input (pandepth_amd/host/cram.cpp): the reader against the SAM text of the committed fixture files (any box),
+against freshly generated files written by the reference's htslib (dev container only), and its error paths."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+S2B = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
+F7 = os.path.join(HERE, "golden", "f7")
+
+
+@pytest.fixture(scope="module")
+def chk():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "cram_check", "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(HERE, "harness", "cram_check")
+
+
+def records(chk, path):
+    p = subprocess.run([chk, path], capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    out = []
+    for line in p.stdout.decode().split("\n"):
+        f = line.split("\t")
+        if len(f) == 5 and int(f[2]) & 4:
+            f[3] = "-"                                   # CRAM stores no mapping quality for reads flagged unmapped
+        out.append("\t".join(f))
+    return out
+
+
+@pytest.mark.parametrize("name", ["m.cram", "m_noidx.cram", "m_ref.cram"])
+def test_reader_returns_the_records_of_the_sam_text(chk, name):
+    """reference-free and reference-based files, bases / qualities / tags / mate fields present, multi-reference slices"""
+    want = records(chk, os.path.join(F7, "m.sam"))
+    assert len(want) > 1400
+    assert records(chk, os.path.join(F7, name)) == want
+
+
+def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
+    good = open(os.path.join(F7, "m.cram"), "rb").read()
+    cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
+    cases = {"v21.cram": good[:4] + b"\x02\x01" + good[6:], "v31.cram": good[:4] + b"\x03\x01" + good[6:],
+             "cut_header.cram": good[:40], "cut_body.cram": good[:len(good) // 2],
+             "flipped.cram": good[:3000] + bytes(b ^ 0x5a for b in good[3000:3400]) + good[3400:]}
+    for fn, data in cases.items():
+        (tmp_path / fn).write_bytes(data)
+        p = subprocess.run([chk, str(tmp_path / fn)], capture_output=True, timeout=60)
+        assert p.returncode in (0, 1), (fn, p.returncode)          # never a signal
+        if fn.startswith("v"):
+            assert p.returncode == 1 and b"is not supported (3.0 only)" in p.stderr
+        if fn.startswith("cut"):
+            assert p.returncode == 1
+        q = subprocess.run([cli, "-i", fn, "-o", "o"], cwd=tmp_path, capture_output=True, timeout=60)
+        assert q.returncode >= 0, (fn, q.returncode)
+
+
+@pytest.mark.skipif(not os.access(S2B, os.X_OK), reason="needs the reference's htslib (dev container only)")
+def test_generated_crams_match_their_sam_text(chk):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "cram_vs_sam.py"), "11", "25"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-1500:]

@@ -1,4 +1,4 @@
-"""GPU end-to-end parity of the GC(%) column cases (fixture f5: `-c -r ref.fa`) and of PAF input (fixture f6): the same
+"""GPU end-to-end parity of the GC(%) column cases (fixture f5: `-c -r ref.fa`) and of PAF input (fixture f6) and CRAM input (fixture f7): the same
 three checks as tests/test_cli_gpu.py — plain, GPU-side BAM decode, `#.list` over two contexts.
 Kept in a file that sorts last: these cases were added after the last GPU run of their round."""
 import os
@@ -9,7 +9,7 @@ import test_cli_gpu as T
 
 pytestmark = pytest.mark.gpu
 
-F5 = [e for e in T.ALL_CASES if e["fixture"] in ("f5", "f6")]
+F5 = [e for e in T.ALL_CASES if e["fixture"] in ("f5", "f6", "f7")]
 ID = dict(ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 
 
