@@ -144,17 +144,34 @@ bool rans_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out)
 struct Block {
     int method = 0, type = 0;
     int32_t id = 0;
+    const uint8_t *comp = nullptr;         // the compressed bytes inside the container body
+    int32_t csize = 0, rsize = 0;
+    bool ready = false;                    // data holds the uncompressed bytes
     std::vector<uint8_t> data;
 };
 
-bool read_block(Cur &c, Block *b, std::string *err)
+bool inflate_block(Block *b, std::string *err);
+
+// lazy = true: only the block header is parsed; inflate_block() runs when somebody needs the bytes (the external blocks
+// of series the depth path never reads — qualities, names, bases, tags — are never decompressed)
+bool read_block(Cur &c, Block *b, std::string *err, bool lazy = false)
 {
     b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
-    const int32_t csize = c.itf8(), rsize = c.itf8();
-    if (!c.ok || csize < 0 || rsize < 0) { *err = "truncated CRAM block header"; return false; }
-    const uint8_t *d = c.take((size_t)csize);
+    b->csize = c.itf8(); b->rsize = c.itf8();
+    if (!c.ok || b->csize < 0 || b->rsize < 0) { *err = "truncated CRAM block header"; return false; }
+    b->comp = c.take((size_t)b->csize);
     c.take(4);                                           // CRC32
     if (!c.ok) { *err = "truncated CRAM block"; return false; }
+    b->ready = false;
+    return lazy ? true : inflate_block(b, err);
+}
+
+bool inflate_block(Block *b, std::string *err)
+{
+    if (b->ready) return true;
+    b->ready = true;
+    const uint8_t *d = b->comp;
+    const int32_t csize = b->csize, rsize = b->rsize;
     if (getenv("PANDEPTH_CRAM_DEBUG")) fprintf(stderr, "[cram] block method %d%s type %d id %d %d -> %d bytes\n", b->method,
                                                b->method == 4 && csize > 0 ? (d[0] ? " (order 1)" : " (order 0)") : "", b->type, b->id, csize, rsize);
     switch (b->method) {
@@ -236,9 +253,10 @@ bool parse_enc(Cur &c, Enc *e)
 // ---- one slice's data: the core bit stream and the external byte streams -------------------------------------------------
 struct SliceData {
     const uint8_t *core = nullptr; size_t core_n = 0, bitpos = 0;
-    struct Ext { const uint8_t *p, *e; };
+    struct Ext { Block *blk; int64_t pos; const uint8_t *p, *e; };      // p/e valid once the block is inflated
     std::map<int32_t, Ext> ext;
     bool ok = true;
+    std::string err;
 
     uint32_t bits(int n)
     {
@@ -251,7 +269,19 @@ struct SliceData {
         }
         return v;
     }
-    Ext *find(int32_t id) { auto it = ext.find(id); if (it == ext.end()) { ok = false; return nullptr; } return &it->second; }
+    // an external stream whose BYTES are needed: inflated on first use; earlier pointer-only skips are applied now
+    Ext *find(int32_t id)
+    {
+        auto it = ext.find(id);
+        if (it == ext.end()) { ok = false; return nullptr; }
+        Ext &x = it->second;
+        if (!x.p) {
+            if (!inflate_block(x.blk, &err)) { ok = false; return nullptr; }
+            x.p = x.blk->data.data(); x.e = x.p + x.blk->data.size();
+            if (x.pos > (int64_t)x.blk->data.size()) { ok = false; x.p = x.e; } else x.p += x.pos;
+        }
+        return &x;
+    }
 
     int32_t get_int(const Enc *e)
     {
@@ -297,7 +327,14 @@ struct SliceData {
     {
         if (n <= 0) return;
         if (!e) { ok = false; return; }
-        if (e->codec == 1) { Ext *x = find(e->ext); if (!x) return; if ((int64_t)(x->e - x->p) < n) { ok = false; x->p = x->e; } else x->p += n; return; }
+        if (e->codec == 1) {
+            auto it = ext.find(e->ext);
+            if (it == ext.end()) { ok = false; return; }
+            Ext &x = it->second;
+            if (x.p) { if ((int64_t)(x.e - x.p) < n) { ok = false; x.p = x.e; } else x.p += n; }
+            else { x.pos += n; if (x.pos > (int64_t)x.blk->rsize) ok = false; }        // no bytes needed: the block stays compressed
+            return;
+        }
         for (int32_t k = 0; k < n && ok; ++k) (void)get_int(e);
     }
     int32_t skip_array(const Enc *e)                         // one byte array; returns its length
@@ -387,6 +424,61 @@ bool parse_comp_header(const std::vector<uint8_t> &d, CompHeader *h)
         }
     }
     return true;
+}
+
+// Which data series have to be walked at all.  Every external block is a byte stream of its own, so a series whose
+// encoding touches neither the core bit stream nor a block that a NEEDED series reads can be left alone: its block is
+// never decompressed (qualities, names, bases, tags, mate fields — most of the file).  Needed: what gives flag, contig,
+// position, mapping quality and the feature list (BF CF RI RL AP FN FC FP DL RS HC PD MQ + the lengths of SC IN BB).
+struct EncUse { bool core = false; std::vector<int32_t> ids; };
+
+void enc_use(const Enc *e, EncUse *u)
+{
+    if (!e) return;
+    switch (e->codec) {
+    case 1: case 5: u->ids.push_back(e->ext); break;
+    case 3: if (!(e->sym.size() == 1 && e->len[0] == 0)) u->core = true; break;
+    case 4: enc_use(e->a.get(), u); enc_use(e->b.get(), u); break;
+    case 6: case 7: case 9: u->core = true; break;
+    default: break;
+    }
+}
+
+struct Walk {
+    std::map<uint16_t, bool> ds;              // optional series -> must be consumed
+    std::map<int32_t, bool> tag;
+    bool any_tag = false;
+    bool operator()(char a, char b) const { auto it = ds.find(key2(a, b)); return it == ds.end() ? true : it->second; }
+};
+
+Walk plan_walk(const CompHeader &H)
+{
+    static const char *NEEDED[] = {"BF", "CF", "RI", "RL", "AP", "FN", "FC", "FP", "DL", "RS", "HC", "PD", "MQ", "SC", "IN", "BB"};
+    static const char *OPTIONAL[] = {"RG", "RN", "MF", "NS", "NP", "TS", "NF", "TL", "QQ", "BS", "BA", "QS"};
+    std::vector<int32_t> ids;
+    auto touches = [&](const EncUse &u) { for (int32_t a : u.ids) for (int32_t b : ids) if (a == b) return true; return false; };
+    for (const char *k : NEEDED) { EncUse u; enc_use(H.get(k[0], k[1]), &u); ids.insert(ids.end(), u.ids.begin(), u.ids.end()); }
+    Walk w;
+    for (const char *k : OPTIONAL) w.ds[key2(k[0], k[1])] = false;
+    for (auto &kv : H.tags) w.tag[kv.first] = false;
+    for (bool changed = true; changed; ) {
+        changed = false;
+        for (const char *k : OPTIONAL) {
+            bool &keep = w.ds[key2(k[0], k[1])];
+            if (keep) continue;
+            EncUse u; enc_use(H.get(k[0], k[1]), &u);
+            if (u.core || touches(u)) { keep = true; changed = true; ids.insert(ids.end(), u.ids.begin(), u.ids.end()); }
+        }
+        for (auto &kv : H.tags) {
+            bool &keep = w.tag[kv.first];
+            if (keep) continue;
+            EncUse u; enc_use(&kv.second, &u);
+            if (u.core || touches(u)) { keep = true; changed = true; ids.insert(ids.end(), u.ids.begin(), u.ids.end()); }
+        }
+    }
+    for (auto &kv : w.tag) w.any_tag = w.any_tag || kv.second;
+    if (w.any_tag) w.ds[key2('T', 'L')] = true;             // the tag line says which tags a record carries
+    return w;
 }
 
 int fgetc_itf8(FILE *f, int32_t *v)
@@ -521,6 +613,9 @@ bool CramReader::load_container()
                                           kv.second.codec == 3 ? (kv.second.sym.size() == 1 ? " (const)" : " (huffman)") : "");
             for (auto &kv : H.tags) fprintf(stderr, "[cram]   tag %c%c%c codec %d ext %d\n", kv.first >> 16, (kv.first >> 8) & 0xff, kv.first & 0xff, kv.second.codec, kv.second.ext);
         }
+        const Walk W = plan_walk(H);
+        const bool wRG = W('R', 'G'), wRN = W('R', 'N'), wMF = W('M', 'F'), wNS = W('N', 'S'), wNP = W('N', 'P'), wTS = W('T', 'S'),
+                   wNF = W('N', 'F'), wTL = W('T', 'L'), wQQ = W('Q', 'Q'), wBS = W('B', 'S'), wBA = W('B', 'A'), wQS = W('Q', 'S');
         const Enc *BF = H.get('B', 'F'), *CF = H.get('C', 'F'), *RI = H.get('R', 'I'), *RL = H.get('R', 'L'), *AP = H.get('A', 'P'),
                   *RG = H.get('R', 'G'), *RN = H.get('R', 'N'), *MF = H.get('M', 'F'), *NS = H.get('N', 'S'), *NP = H.get('N', 'P'),
                   *TS = H.get('T', 'S'), *NF = H.get('N', 'F'), *TL = H.get('T', 'L'), *FN = H.get('F', 'N'), *FC = H.get('F', 'C'),
@@ -542,10 +637,10 @@ bool CramReader::load_container()
             std::vector<Block> blocks((size_t)n_blocks);
             SliceData sd;
             for (int32_t k = 0; k < n_blocks; ++k) {
-                if (!read_block(c, &blocks[(size_t)k], &e2)) return fail(e2);
+                if (!read_block(c, &blocks[(size_t)k], &e2, true)) return fail(e2);
                 Block &b = blocks[(size_t)k];
-                if (b.type == 5) { sd.core = b.data.data(); sd.core_n = b.data.size(); }
-                else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{b.data.data(), b.data.data() + b.data.size()};
+                if (b.type == 5) { if (!inflate_block(&b, &e2)) return fail(e2); sd.core = b.data.data(); sd.core_n = b.data.size(); }
+                else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{&b, 0, nullptr, nullptr};
             }
             int32_t prev_ap = start;
             for (int32_t r = 0; r < n_rec; ++r) {
@@ -556,20 +651,23 @@ bool CramReader::load_container()
                 const int32_t rl = sd.get_int(RL);
                 int32_t ap = sd.get_int(AP);
                 if (H.ap_delta) { prev_ap += ap; ap = prev_ap; }
-                sd.get_int(RG);
-                if (H.rn) sd.skip_array(RN);
+                if (wRG) sd.get_int(RG);
+                if (H.rn && wRN) sd.skip_array(RN);
                 if (cf & 2) {
-                    sd.get_int(MF);
-                    if (!H.rn) sd.skip_array(RN);
-                    sd.get_int(NS); sd.get_int(NP); sd.get_int(TS);
-                } else if (cf & 4) sd.get_int(NF);
-                const int32_t tl = sd.get_int(TL);
+                    if (wMF) sd.get_int(MF);
+                    if (!H.rn && wRN) sd.skip_array(RN);
+                    if (wNS) sd.get_int(NS);
+                    if (wNP) sd.get_int(NP);
+                    if (wTS) sd.get_int(TS);
+                } else if ((cf & 4) && wNF) sd.get_int(NF);
+                const int32_t tl = wTL ? sd.get_int(TL) : 0;
                 if (!sd.ok) return fail("corrupt CRAM record");
-                if (tl >= 0 && (size_t)tl < H.td.size())
+                if (!W.any_tag) {}
+                else if (tl >= 0 && (size_t)tl < H.td.size())
                     for (int32_t key : H.td[(size_t)tl]) {
                         auto it = H.tags.find(key);
                         if (it == H.tags.end()) return fail("CRAM tag without an encoding");
-                        sd.skip_array(&it->second);
+                        if (W.tag.at(key)) sd.skip_array(&it->second);
                     }
                 else if (!H.td.empty() || tl != 0) return fail("corrupt CRAM tag line");
                 Rec rec{ri, ap - 1, (uint16_t)bf, 0, (uint32_t)cigs_.size(), 0};
@@ -589,14 +687,14 @@ bool CramReader::load_container()
                         if (pos > seq_pos) { op(0, pos - seq_pos); seq_pos = pos; }
                         switch (fc) {
                         case 'S': { const int32_t n = sd.skip_array(SC); op(4, n); seq_pos += n; break; }
-                        case 'X': sd.get_byte(BS); op(0, 1); ++seq_pos; break;
+                        case 'X': if (wBS) sd.get_byte(BS); op(0, 1); ++seq_pos; break;
                         case 'D': op(2, sd.get_int(DL)); break;
                         case 'I': { const int32_t n = sd.skip_array(IN); op(1, n); seq_pos += n; break; }
-                        case 'i': sd.get_byte(BA); op(1, 1); ++seq_pos; break;
+                        case 'i': if (wBA) sd.get_byte(BA); op(1, 1); ++seq_pos; break;
                         case 'b': { const int32_t n = sd.skip_array(BB); op(0, n); seq_pos += n; break; }
-                        case 'q': sd.skip_array(QQ); break;
-                        case 'B': sd.get_byte(BA); sd.get_byte(QS); op(0, 1); ++seq_pos; break;
-                        case 'Q': sd.get_byte(QS); break;
+                        case 'q': if (wQQ) sd.skip_array(QQ); break;
+                        case 'B': if (wBA) sd.get_byte(BA); if (wQS) sd.get_byte(QS); op(0, 1); ++seq_pos; break;
+                        case 'Q': if (wQS) sd.get_byte(QS); break;
                         case 'H': op(5, sd.get_int(HC)); break;
                         case 'P': op(6, sd.get_int(PD)); break;
                         case 'N': op(3, sd.get_int(RS)); break;
@@ -605,12 +703,12 @@ bool CramReader::load_container()
                     }
                     if (seq_pos <= rl) op(0, rl - seq_pos + 1);
                     rec.mapq = (uint8_t)sd.get_int(MQ);
-                    if (cf & 1) sd.skip_bytes(QS, rl);
+                    if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
                 } else {
-                    sd.skip_bytes(BA, rl);
-                    if (cf & 1) sd.skip_bytes(QS, rl);
+                    if (wBA) sd.skip_bytes(BA, rl);
+                    if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
                 }
-                if (!sd.ok) return fail("corrupt CRAM record (record " + std::to_string(r) + " of its slice)");
+                if (!sd.ok) return fail(!sd.err.empty() ? sd.err : "corrupt CRAM record (record " + std::to_string(r) + " of its slice)");
                 rec.n_cig = (uint32_t)cigs_.size() - rec.cig_off;
                 recs_.push_back(rec);
             }
