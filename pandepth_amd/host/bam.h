@@ -42,7 +42,7 @@ public:
     int next(AlnRec *r);
     uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record
     bool seek(uint64_t voff) { return bg_.seek(voff); }
-    void set_threads(int n) { bg_.set_threads(n); }    // sequential streams: parallel inflate read-ahead
+    void set_threads(int n) { if (is_cram_) cram_.set_threads(n); else bg_.set_threads(n); }    // sequential streams: parallel inflate read-ahead
     const std::string &error() const { return err_; }
 private:
     bool read_bam_header();

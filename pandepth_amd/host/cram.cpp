@@ -540,12 +540,12 @@ bool CramReader::is_cram(const std::string &path)
     return n == 4 && memcmp(m, "CRAM", 4) == 0;
 }
 
-void CramReader::close() { if (f_) { fclose(f_); f_ = nullptr; } }
+void CramReader::close() { ahead_.clear(); if (f_) { fclose(f_); f_ = nullptr; } }
 
 bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
 {
     close();
-    err_.clear(); eof_ = false; recs_.clear(); cigs_.clear(); cur_ = 0;
+    err_.clear(); eof_ = false; ahead_.clear(); cur_batch_ = Batch(); cur_ = 0;
     auto bad = [&](const std::string &m) { err_ = m; if (err) *err = m; close(); return false; };
     f_ = fopen(path.c_str(), "rb");
     if (!f_) return bad("cannot open " + path);
@@ -589,145 +589,171 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
     return true;
 }
 
-bool CramReader::load_container()
+namespace {
+
+// one container body (everything after the container header) -> its records
+bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out)
 {
-    recs_.clear(); cigs_.clear(); cur_ = 0;
+    typedef CramReader::Rec Rec;
+    auto bad = [&](const std::string &m) { if (out->err.empty()) out->err = m; return false; };
+    Cur c(body.data(), body.size());
+    Block cb;
+    std::string e2;
+    if (!read_block(c, &cb, &e2)) return bad(e2);
+    if (cb.type != 1) return bad("CRAM compression header missing");
+    CompHeader H;
+    if (!parse_comp_header(cb.data, &H)) return bad("CRAM compression header uses an encoding this reader does not know");
+    if (getenv("PANDEPTH_CRAM_DEBUG")) {
+        fprintf(stderr, "[cram] container ref %d n_rec %d rn %d ap_delta %d td %zu\n", 0, 0, (int)H.rn, (int)H.ap_delta, H.td.size());
+        for (auto &kv : H.ds) fprintf(stderr, "[cram]   %c%c codec %d ext %d%s\n", kv.first >> 8, kv.first & 0xff, kv.second.codec, kv.second.ext,
+                                      kv.second.codec == 3 ? (kv.second.sym.size() == 1 ? " (const)" : " (huffman)") : "");
+        for (auto &kv : H.tags) fprintf(stderr, "[cram]   tag %c%c%c codec %d ext %d\n", kv.first >> 16, (kv.first >> 8) & 0xff, kv.first & 0xff, kv.second.codec, kv.second.ext);
+    }
+    const Walk W = plan_walk(H);
+    const bool wRG = W('R', 'G'), wRN = W('R', 'N'), wMF = W('M', 'F'), wNS = W('N', 'S'), wNP = W('N', 'P'), wTS = W('T', 'S'),
+               wNF = W('N', 'F'), wTL = W('T', 'L'), wQQ = W('Q', 'Q'), wBS = W('B', 'S'), wBA = W('B', 'A'), wQS = W('Q', 'S');
+    const Enc *BF = H.get('B', 'F'), *CF = H.get('C', 'F'), *RI = H.get('R', 'I'), *RL = H.get('R', 'L'), *AP = H.get('A', 'P'),
+              *RG = H.get('R', 'G'), *RN = H.get('R', 'N'), *MF = H.get('M', 'F'), *NS = H.get('N', 'S'), *NP = H.get('N', 'P'),
+              *TS = H.get('T', 'S'), *NF = H.get('N', 'F'), *TL = H.get('T', 'L'), *FN = H.get('F', 'N'), *FC = H.get('F', 'C'),
+              *FP = H.get('F', 'P'), *DL = H.get('D', 'L'), *BB = H.get('B', 'B'), *QQ = H.get('Q', 'Q'), *BS = H.get('B', 'S'),
+              *IN = H.get('I', 'N'), *RS = H.get('R', 'S'), *PD = H.get('P', 'D'), *HC = H.get('H', 'C'), *SC = H.get('S', 'C'),
+              *MQ = H.get('M', 'Q'), *BA = H.get('B', 'A'), *QS = H.get('Q', 'S');
+    while (c.left() > 0) {
+        // §8.5 slice header, then its blocks
+        Block sh;
+        if (!read_block(c, &sh, &e2)) return bad(e2);
+        if (sh.type != 2) return bad("CRAM slice header expected");
+        Cur s(sh.data.data(), sh.data.size());
+        const int32_t ref = s.itf8(), start = s.itf8();
+        s.itf8();                                       // span
+        const int32_t n_rec = s.itf8();
+        s.ltf8();                                       // record counter
+        const int32_t n_blocks = s.itf8();
+        if (!s.ok || n_rec < 0 || n_blocks < 0) return bad("corrupt CRAM slice header");
+        std::vector<Block> blocks((size_t)n_blocks);
+        SliceData sd;
+        for (int32_t k = 0; k < n_blocks; ++k) {
+            if (!read_block(c, &blocks[(size_t)k], &e2, true)) return bad(e2);
+            Block &b = blocks[(size_t)k];
+            if (b.type == 5) { if (!inflate_block(&b, &e2)) return bad(e2); sd.core = b.data.data(); sd.core_n = b.data.size(); }
+            else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{&b, 0, nullptr, nullptr};
+        }
+        int32_t prev_ap = start;
+        for (int32_t r = 0; r < n_rec; ++r) {
+            // §10: the record
+            const int32_t bf = sd.get_int(BF), cf = sd.get_int(CF);
+            int32_t ri = ref;
+            if (ref == -2) ri = sd.get_int(RI);
+            const int32_t rl = sd.get_int(RL);
+            int32_t ap = sd.get_int(AP);
+            if (H.ap_delta) { prev_ap += ap; ap = prev_ap; }
+            if (wRG) sd.get_int(RG);
+            if (H.rn && wRN) sd.skip_array(RN);
+            if (cf & 2) {
+                if (wMF) sd.get_int(MF);
+                if (!H.rn && wRN) sd.skip_array(RN);
+                if (wNS) sd.get_int(NS);
+                if (wNP) sd.get_int(NP);
+                if (wTS) sd.get_int(TS);
+            } else if ((cf & 4) && wNF) sd.get_int(NF);
+            const int32_t tl = wTL ? sd.get_int(TL) : 0;
+            if (!sd.ok) return bad("corrupt CRAM record");
+            if (!W.any_tag) {}
+            else if (tl >= 0 && (size_t)tl < H.td.size())
+                for (int32_t key : H.td[(size_t)tl]) {
+                    auto it = H.tags.find(key);
+                    if (it == H.tags.end()) return bad("CRAM tag without an encoding");
+                    if (W.tag.at(key)) sd.skip_array(&it->second);
+                }
+            else if (!H.td.empty() || tl != 0) return bad("corrupt CRAM tag line");
+            Rec rec{ri, ap - 1, (uint16_t)bf, 0, (uint32_t)out->cigs.size(), 0};
+            auto op = [&](uint32_t code, int32_t len) {
+                if (len <= 0) return;
+                if (out->cigs.size() > rec.cig_off && (out->cigs.back() & 0xf) == code) out->cigs.back() += (uint32_t)len << 4;
+                else out->cigs.push_back(((uint32_t)len << 4) | code);
+            };
+            if (!(bf & 4)) {
+                // §10.6: read features -> the CIGAR shape (M 0, I 1, D 2, N 3, S 4, H 5, P 6)
+                const int32_t fn = sd.get_int(FN);
+                int32_t prev = 0, seq_pos = 1;
+                for (int32_t k = 0; k < fn && sd.ok; ++k) {
+                    const int fc = sd.get_byte(FC);
+                    const int32_t pos = prev + sd.get_int(FP);
+                    prev = pos;
+                    if (pos > seq_pos) { op(0, pos - seq_pos); seq_pos = pos; }
+                    switch (fc) {
+                    case 'S': { const int32_t n = sd.skip_array(SC); op(4, n); seq_pos += n; break; }
+                    case 'X': if (wBS) sd.get_byte(BS); op(0, 1); ++seq_pos; break;
+                    case 'D': op(2, sd.get_int(DL)); break;
+                    case 'I': { const int32_t n = sd.skip_array(IN); op(1, n); seq_pos += n; break; }
+                    case 'i': if (wBA) sd.get_byte(BA); op(1, 1); ++seq_pos; break;
+                    case 'b': { const int32_t n = sd.skip_array(BB); op(0, n); seq_pos += n; break; }
+                    case 'q': if (wQQ) sd.skip_array(QQ); break;
+                    case 'B': if (wBA) sd.get_byte(BA); if (wQS) sd.get_byte(QS); op(0, 1); ++seq_pos; break;
+                    case 'Q': if (wQS) sd.get_byte(QS); break;
+                    case 'H': op(5, sd.get_int(HC)); break;
+                    case 'P': op(6, sd.get_int(PD)); break;
+                    case 'N': op(3, sd.get_int(RS)); break;
+                    default: return bad("unknown CRAM read feature");
+                    }
+                }
+                if (seq_pos <= rl) op(0, rl - seq_pos + 1);
+                rec.mapq = (uint8_t)sd.get_int(MQ);
+                if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
+            } else {
+                if (wBA) sd.skip_bytes(BA, rl);
+                if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
+            }
+            if (!sd.ok) return bad(!sd.err.empty() ? sd.err : "corrupt CRAM record (record " + std::to_string(r) + " of its slice)");
+            rec.n_cig = (uint32_t)out->cigs.size() - rec.cig_off;
+            out->recs.push_back(rec);
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+bool CramReader::read_body(std::vector<uint8_t> *body)
+{
     for (;;) {
         ContainerHeader ch;
         const int rc = read_container_header(f_, &ch);
-        if (rc == 0) { eof_ = true; return true; }
-        if (rc < 0) return fail("truncated CRAM container header");
-        std::vector<uint8_t> body((size_t)ch.length);
-        if (ch.length && fread(body.data(), 1, body.size(), f_) != body.size()) return fail("truncated CRAM container");
+        if (rc == 0) { eof_ = true; return false; }
+        if (rc < 0) { eof_ = true; return fail("truncated CRAM container header"); }
+        body->resize((size_t)ch.length);
+        if (ch.length && fread(body->data(), 1, body->size(), f_) != body->size()) { eof_ = true; return fail("truncated CRAM container"); }
         if (ch.n_rec == 0) continue;                       // the end-of-file container (or an empty one)
-        Cur c(body.data(), body.size());
-        Block cb;
-        std::string e2;
-        if (!read_block(c, &cb, &e2)) return fail(e2);
-        if (cb.type != 1) return fail("CRAM compression header missing");
-        CompHeader H;
-        if (!parse_comp_header(cb.data, &H)) return fail("CRAM compression header uses an encoding this reader does not know");
-        if (getenv("PANDEPTH_CRAM_DEBUG")) {
-            fprintf(stderr, "[cram] container ref %d n_rec %d rn %d ap_delta %d td %zu\n", ch.ref, ch.n_rec, (int)H.rn, (int)H.ap_delta, H.td.size());
-            for (auto &kv : H.ds) fprintf(stderr, "[cram]   %c%c codec %d ext %d%s\n", kv.first >> 8, kv.first & 0xff, kv.second.codec, kv.second.ext,
-                                          kv.second.codec == 3 ? (kv.second.sym.size() == 1 ? " (const)" : " (huffman)") : "");
-            for (auto &kv : H.tags) fprintf(stderr, "[cram]   tag %c%c%c codec %d ext %d\n", kv.first >> 16, (kv.first >> 8) & 0xff, kv.first & 0xff, kv.second.codec, kv.second.ext);
-        }
-        const Walk W = plan_walk(H);
-        const bool wRG = W('R', 'G'), wRN = W('R', 'N'), wMF = W('M', 'F'), wNS = W('N', 'S'), wNP = W('N', 'P'), wTS = W('T', 'S'),
-                   wNF = W('N', 'F'), wTL = W('T', 'L'), wQQ = W('Q', 'Q'), wBS = W('B', 'S'), wBA = W('B', 'A'), wQS = W('Q', 'S');
-        const Enc *BF = H.get('B', 'F'), *CF = H.get('C', 'F'), *RI = H.get('R', 'I'), *RL = H.get('R', 'L'), *AP = H.get('A', 'P'),
-                  *RG = H.get('R', 'G'), *RN = H.get('R', 'N'), *MF = H.get('M', 'F'), *NS = H.get('N', 'S'), *NP = H.get('N', 'P'),
-                  *TS = H.get('T', 'S'), *NF = H.get('N', 'F'), *TL = H.get('T', 'L'), *FN = H.get('F', 'N'), *FC = H.get('F', 'C'),
-                  *FP = H.get('F', 'P'), *DL = H.get('D', 'L'), *BB = H.get('B', 'B'), *QQ = H.get('Q', 'Q'), *BS = H.get('B', 'S'),
-                  *IN = H.get('I', 'N'), *RS = H.get('R', 'S'), *PD = H.get('P', 'D'), *HC = H.get('H', 'C'), *SC = H.get('S', 'C'),
-                  *MQ = H.get('M', 'Q'), *BA = H.get('B', 'A'), *QS = H.get('Q', 'S');
-        while (c.left() > 0) {
-            // §8.5 slice header, then its blocks
-            Block sh;
-            if (!read_block(c, &sh, &e2)) return fail(e2);
-            if (sh.type != 2) return fail("CRAM slice header expected");
-            Cur s(sh.data.data(), sh.data.size());
-            const int32_t ref = s.itf8(), start = s.itf8();
-            s.itf8();                                       // span
-            const int32_t n_rec = s.itf8();
-            s.ltf8();                                       // record counter
-            const int32_t n_blocks = s.itf8();
-            if (!s.ok || n_rec < 0 || n_blocks < 0) return fail("corrupt CRAM slice header");
-            std::vector<Block> blocks((size_t)n_blocks);
-            SliceData sd;
-            for (int32_t k = 0; k < n_blocks; ++k) {
-                if (!read_block(c, &blocks[(size_t)k], &e2, true)) return fail(e2);
-                Block &b = blocks[(size_t)k];
-                if (b.type == 5) { if (!inflate_block(&b, &e2)) return fail(e2); sd.core = b.data.data(); sd.core_n = b.data.size(); }
-                else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{&b, 0, nullptr, nullptr};
-            }
-            int32_t prev_ap = start;
-            for (int32_t r = 0; r < n_rec; ++r) {
-                // §10: the record
-                const int32_t bf = sd.get_int(BF), cf = sd.get_int(CF);
-                int32_t ri = ref;
-                if (ref == -2) ri = sd.get_int(RI);
-                const int32_t rl = sd.get_int(RL);
-                int32_t ap = sd.get_int(AP);
-                if (H.ap_delta) { prev_ap += ap; ap = prev_ap; }
-                if (wRG) sd.get_int(RG);
-                if (H.rn && wRN) sd.skip_array(RN);
-                if (cf & 2) {
-                    if (wMF) sd.get_int(MF);
-                    if (!H.rn && wRN) sd.skip_array(RN);
-                    if (wNS) sd.get_int(NS);
-                    if (wNP) sd.get_int(NP);
-                    if (wTS) sd.get_int(TS);
-                } else if ((cf & 4) && wNF) sd.get_int(NF);
-                const int32_t tl = wTL ? sd.get_int(TL) : 0;
-                if (!sd.ok) return fail("corrupt CRAM record");
-                if (!W.any_tag) {}
-                else if (tl >= 0 && (size_t)tl < H.td.size())
-                    for (int32_t key : H.td[(size_t)tl]) {
-                        auto it = H.tags.find(key);
-                        if (it == H.tags.end()) return fail("CRAM tag without an encoding");
-                        if (W.tag.at(key)) sd.skip_array(&it->second);
-                    }
-                else if (!H.td.empty() || tl != 0) return fail("corrupt CRAM tag line");
-                Rec rec{ri, ap - 1, (uint16_t)bf, 0, (uint32_t)cigs_.size(), 0};
-                auto op = [&](uint32_t code, int32_t len) {
-                    if (len <= 0) return;
-                    if (cigs_.size() > rec.cig_off && (cigs_.back() & 0xf) == code) cigs_.back() += (uint32_t)len << 4;
-                    else cigs_.push_back(((uint32_t)len << 4) | code);
-                };
-                if (!(bf & 4)) {
-                    // §10.6: read features -> the CIGAR shape (M 0, I 1, D 2, N 3, S 4, H 5, P 6)
-                    const int32_t fn = sd.get_int(FN);
-                    int32_t prev = 0, seq_pos = 1;
-                    for (int32_t k = 0; k < fn && sd.ok; ++k) {
-                        const int fc = sd.get_byte(FC);
-                        const int32_t pos = prev + sd.get_int(FP);
-                        prev = pos;
-                        if (pos > seq_pos) { op(0, pos - seq_pos); seq_pos = pos; }
-                        switch (fc) {
-                        case 'S': { const int32_t n = sd.skip_array(SC); op(4, n); seq_pos += n; break; }
-                        case 'X': if (wBS) sd.get_byte(BS); op(0, 1); ++seq_pos; break;
-                        case 'D': op(2, sd.get_int(DL)); break;
-                        case 'I': { const int32_t n = sd.skip_array(IN); op(1, n); seq_pos += n; break; }
-                        case 'i': if (wBA) sd.get_byte(BA); op(1, 1); ++seq_pos; break;
-                        case 'b': { const int32_t n = sd.skip_array(BB); op(0, n); seq_pos += n; break; }
-                        case 'q': if (wQQ) sd.skip_array(QQ); break;
-                        case 'B': if (wBA) sd.get_byte(BA); if (wQS) sd.get_byte(QS); op(0, 1); ++seq_pos; break;
-                        case 'Q': if (wQS) sd.get_byte(QS); break;
-                        case 'H': op(5, sd.get_int(HC)); break;
-                        case 'P': op(6, sd.get_int(PD)); break;
-                        case 'N': op(3, sd.get_int(RS)); break;
-                        default: return fail("unknown CRAM read feature");
-                        }
-                    }
-                    if (seq_pos <= rl) op(0, rl - seq_pos + 1);
-                    rec.mapq = (uint8_t)sd.get_int(MQ);
-                    if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
-                } else {
-                    if (wBA) sd.skip_bytes(BA, rl);
-                    if ((cf & 1) && wQS) sd.skip_bytes(QS, rl);
-                }
-                if (!sd.ok) return fail(!sd.err.empty() ? sd.err : "corrupt CRAM record (record " + std::to_string(r) + " of its slice)");
-                rec.n_cig = (uint32_t)cigs_.size() - rec.cig_off;
-                recs_.push_back(rec);
-            }
-        }
-        if (!recs_.empty()) return true;
+        return true;
     }
 }
 
 int CramReader::next(AlnRec *r)
 {
     if (!f_) return -1;
-    while (cur_ >= recs_.size()) {
-        if (eof_) return 0;
-        if (!load_container()) return -1;
-        if (eof_ && recs_.empty()) return 0;
+    while (cur_ >= cur_batch_.recs.size()) {
+        // keep up to threads_ containers in flight (one decoder thread each), hand them back in file order
+        while (!eof_ && ahead_.size() < (size_t)threads_) {
+            std::vector<uint8_t> body;
+            if (!read_body(&body)) break;
+            if (threads_ == 1) {
+                std::promise<Batch> p;
+                Batch b;
+                decode_container(body, &b);
+                p.set_value(std::move(b));
+                ahead_.push_back(p.get_future());
+            } else
+                ahead_.push_back(std::async(std::launch::async, [](std::vector<uint8_t> bytes) { Batch b; decode_container(bytes, &b); return b; }, std::move(body)));
+        }
+        if (ahead_.empty()) return err_.empty() ? 0 : -1;
+        cur_batch_ = ahead_.front().get();
+        ahead_.pop_front();
+        cur_ = 0;
+        if (!cur_batch_.err.empty()) { fail(cur_batch_.err); return -1; }
     }
-    const Rec &x = recs_[cur_++];
+    const Rec &x = cur_batch_.recs[cur_++];
     r->tid = x.tid; r->pos = x.pos; r->flag = x.flag; r->mapq = x.mapq;
-    r->n_cigar = x.n_cig; r->cigar = cigs_.data() + x.cig_off;
+    r->n_cigar = x.n_cig; r->cigar = cur_batch_.cigs.data() + x.cig_off;
     return 1;
 }
 

@@ -11,6 +11,8 @@
 #define PD_CRAM_H_
 #include <stdint.h>
 #include <stdio.h>
+#include <deque>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -28,15 +30,20 @@ public:
     // next record: 1 record, 0 end of file, -1 error (error() has the text)
     int next(AlnRec *r);
     const std::string &error() const { return err_; }
+    // containers are independent: with n > 1 up to n of them are decoded ahead on helper threads (records still come
+    // back in file order)
+    void set_threads(int n) { threads_ = n < 1 ? 1 : n > 64 ? 64 : n; }
     void close();
-private:
     struct Rec { int32_t tid, pos; uint16_t flag; uint8_t mapq; uint32_t cig_off, n_cig; };
-    bool load_container();                       // decodes the next data container into recs_
+    struct Batch { std::vector<Rec> recs; std::vector<uint32_t> cigs; std::string err; };      // one container
+private:
+    bool read_body(std::vector<uint8_t> *body);  // the next container that holds records; false at end of file / error
     bool fail(const std::string &m) { if (err_.empty()) err_ = m; return false; }
     FILE *f_ = nullptr;
     bool eof_ = false;
-    std::vector<Rec> recs_;
-    std::vector<uint32_t> cigs_;
+    int threads_ = 1;
+    std::deque<std::future<Batch>> ahead_;
+    Batch cur_batch_;
     size_t cur_ = 0;
     std::string err_;
 };

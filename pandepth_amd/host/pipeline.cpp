@@ -199,6 +199,7 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
         AlnRec r;
         uint64_t n = 0;
         int k;
+        probe.set_threads(o.threads);                        // containers decoded ahead on helper threads
         while ((k = probe.next(&r)) == 1) {
             ++n;
             if (flt.pass(r) && spans.hit(r)) emit_runs(r, &sink);
