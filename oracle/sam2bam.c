@@ -8,8 +8,11 @@
  *   usage: sam2bam in.sam out.bam [noindex]
  *          sam2bam in.sam|in.bam out.cram [noindex] [ref=genome.fa]     CRAM 3.0; without ref= the file is written
  *                                                                      reference-free (CRAM_OPT_NO_REF)
+ *                  [sps=N] records per slice  [spc=N] slices per container  [multiseq] multi-reference slices
+ *                  [embedref] (with ref=) the reference bases travel inside the slices
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "sam.h"
 
@@ -22,17 +25,25 @@ int main(int argc, char **argv)
     if (!hdr) { fprintf(stderr, "cannot read header of %s\n", argv[1]); return 1; }
     const size_t ol = strlen(argv[2]);
     const int cram = ol > 5 && strcmp(argv[2] + ol - 5, ".cram") == 0;
-    int noindex = 0;
+    int noindex = 0, sps = 0, spc = 0, multiseq = 0, embedref = 0;
     const char *ref = NULL;
     for (int k = 3; k < argc; ++k) {
         if (strcmp(argv[k], "noindex") == 0) noindex = 1;
         else if (strncmp(argv[k], "ref=", 4) == 0) ref = argv[k] + 4;
+        else if (strncmp(argv[k], "sps=", 4) == 0) sps = atoi(argv[k] + 4);
+        else if (strncmp(argv[k], "spc=", 4) == 0) spc = atoi(argv[k] + 4);
+        else if (strcmp(argv[k], "multiseq") == 0) multiseq = 1;
+        else if (strcmp(argv[k], "embedref") == 0) embedref = 1;
     }
     samFile *out = sam_open(argv[2], cram ? "wc" : "wb");
     if (!out) { fprintf(stderr, "cannot open %s for writing\n", argv[2]); return 1; }
     if (cram) {
         if (ref) { if (hts_set_fai_filename(out, ref) < 0) { fprintf(stderr, "cannot use reference %s\n", ref); return 1; } }
         else hts_set_opt(out, CRAM_OPT_NO_REF, 1);
+        if (sps > 0) hts_set_opt(out, CRAM_OPT_SEQS_PER_SLICE, sps);
+        if (spc > 0) hts_set_opt(out, CRAM_OPT_SLICES_PER_CONTAINER, spc);
+        if (multiseq) hts_set_opt(out, CRAM_OPT_MULTI_SEQ_PER_SLICE, 1);
+        if (embedref && ref) hts_set_opt(out, CRAM_OPT_EMBED_REF, 1);
     }
     if (sam_hdr_write(out, hdr) < 0) { fprintf(stderr, "header write failed\n"); return 1; }
     bam1_t *rec = bam_init1();

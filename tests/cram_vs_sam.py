@@ -3,7 +3,8 @@
 Differential test of the product's CRAM 3.0 reader (pandepth_amd/host/cram.cpp) against the SAM text a CRAM was written
 from: random alignments (CIGARs with M I D N S H = X, bases with mismatches, qualities, tags, mate fields, unmapped
 reads, tiny and large contigs -> single- and multi-reference slices, up to 120 000 records -> several containers, raw /
-gzip / rANS order-0 / order-1 blocks) are written as CRAM by htslib — reference-free or against a FASTA — and
+gzip / rANS order-0 / order-1 blocks; 1 to 10 000 records per slice, several slices per container, forced
+multi-reference slices, embedded reference) are written as CRAM by htslib — reference-free or against a FASTA — and
 tests/harness/cram_check must print the same (tid, pos, flag, mapq, reference-consuming CIGAR shape) for both files.
 (mapq of reads flagged unmapped is not compared: CRAM does not store it.)
 
@@ -82,11 +83,15 @@ for k in range(cases):
         open('t.fa','w').write(''.join('>%s\n%s\n'%(nm,sq) for nm,sq in ref.items()))
         if os.path.exists('t.fa.fai'): os.remove('t.fa.fai')
         args.append('ref=t.fa')
+    if rng.random()<0.4: args.append('sps=%d'%rng.choice([1,7,100,1000]))
+    if rng.random()<0.4: args.append('spc=%d'%rng.choice([2,3,10]))
+    if rng.random()<0.2: args.append('multiseq')
+    if useref and rng.random()<0.3: args.append('embedref')
     p=subprocess.run(args,capture_output=True)
     if p.returncode: print('case',k,'s2b failed',p.stderr.decode()[-200:]); continue
     a=subprocess.run([CHK,'t.cram'],capture_output=True); b=subprocess.run([CHK,'t.sam'],capture_output=True)
     if a.returncode or norm(a.stdout.decode())!=norm(b.stdout.decode()):
-        bad+=1; print('MISMATCH case',k,'n',n,'seq',with_seq,'sorted',sorted_,'ref',useref,a.stderr.decode()[-200:]); 
+        bad+=1; print('MISMATCH case',k,'n',n,'seq',with_seq,'sorted',sorted_,'ref',useref,' '.join(args[4:]),a.stderr.decode()[-200:]); 
         os.system('cp t.sam /tmp/crambad_%d_%d.sam; cp t.cram /tmp/crambad_%d_%d.cram'%(seed,k,seed,k))
 import shutil
 shutil.rmtree(WORK,ignore_errors=True)
