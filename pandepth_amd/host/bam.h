@@ -38,6 +38,7 @@ public:
     const AlnHeader &header() const { return hdr_; }
     bool is_bam() const { return is_bam_; }
     bool is_cram() const { return is_cram_; }        // CRAM 3.0 (host/cram.h): sequential reading only
+    CramReader &cram() { return cram_; }
     // next record; returns 1 record, 0 end of file, -1 error
     int next(AlnRec *r);
     uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record

@@ -721,9 +721,16 @@ bool CramReader::read_body(std::vector<uint8_t> *body)
         const int rc = read_container_header(f_, &ch);
         if (rc == 0) { eof_ = true; return false; }
         if (rc < 0) { eof_ = true; return fail("truncated CRAM container header"); }
+        if (keep_ && ch.n_rec > 0 && ch.ref != -2 &&
+            (ch.ref < 0 || !keep_(ch.ref, (int64_t)ch.start - 1, (int64_t)ch.start - 1 + (ch.span > 0 ? ch.span : 1)))) {
+            if (fseeko(f_, (off_t)ch.length, SEEK_CUR) != 0) { eof_ = true; return fail("seek failed in CRAM file"); }
+            ++n_skipped_;
+            continue;
+        }
         body->resize((size_t)ch.length);
         if (ch.length && fread(body->data(), 1, body->size(), f_) != body->size()) { eof_ = true; return fail("truncated CRAM container"); }
         if (ch.n_rec == 0) continue;                       // the end-of-file container (or an empty one)
+        ++n_read_;
         return true;
     }
 }

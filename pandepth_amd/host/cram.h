@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <deque>
+#include <functional>
 #include <future>
 #include <string>
 #include <vector>
@@ -33,6 +34,12 @@ public:
     // containers are independent: with n > 1 up to n of them are decoded ahead on helper threads (records still come
     // back in file order)
     void set_threads(int n) { threads_ = n < 1 ? 1 : n > 64 ? 64 : n; }
+    // Region reads without the .crai: a container header names its contig and the stretch its reads cover (§7), so
+    // containers the predicate rejects are stepped over unread.  keep(ref, start0, end): [start0, end) 0-based.
+    // Multi-reference containers (ref -2) are always decoded, unmapped ones (ref -1) never once a predicate is set.
+    void set_container_filter(std::function<bool(int32_t, int64_t, int64_t)> keep) { keep_ = std::move(keep); }
+    uint64_t containers_read() const { return n_read_; }
+    uint64_t containers_skipped() const { return n_skipped_; }
     void close();
     struct Rec { int32_t tid, pos; uint16_t flag; uint8_t mapq; uint32_t cig_off, n_cig; };
     struct Batch { std::vector<Rec> recs; std::vector<uint32_t> cigs; std::string err; };      // one container
@@ -42,6 +49,8 @@ private:
     FILE *f_ = nullptr;
     bool eof_ = false;
     int threads_ = 1;
+    std::function<bool(int32_t, int64_t, int64_t)> keep_;
+    uint64_t n_read_ = 0, n_skipped_ = 0;
     std::deque<std::future<Batch>> ahead_;
     Batch cur_batch_;
     size_t cur_ = 0;

@@ -200,12 +200,22 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
         uint64_t n = 0;
         int k;
         probe.set_threads(o.threads);                        // containers decoded ahead on helper threads
+        if (!spans.synthetic)
+            // GFF / BED targets: only containers whose stretch meets a (widened) merged span can hold selected reads
+            probe.cram().set_container_filter([&spans](int32_t tid, int64_t b0, int64_t e) {
+                if (tid < 0 || (size_t)tid >= spans.per_tid.size()) return false;
+                for (auto &sp : spans.per_tid[(size_t)tid])
+                    if ((int64_t)sp.first < e + 2 && (int64_t)sp.second > b0 - 2) return true;
+                return false;
+            });
         while ((k = probe.next(&r)) == 1) {
             ++n;
             if (flt.pass(r) && spans.hit(r)) emit_runs(r, &sink);
         }
         if (k < 0) { eng->fail(probe.error() + " (" + path + ")"); return false; }
-        if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing] cram (indexed selection, sequential): %llu records\n", (unsigned long long)n);
+        if (getenv("PANDEPTH_TIMING"))
+            fprintf(stderr, "[timing] cram (indexed selection): %llu records, %llu containers decoded, %llu stepped over\n", (unsigned long long)n,
+                    (unsigned long long)probe.cram().containers_read(), (unsigned long long)probe.cram().containers_skipped());
         return true;
     }
     if (!probe.is_bam()) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }

@@ -61,3 +61,37 @@ def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
 def test_generated_crams_match_their_sam_text(chk):
     r = subprocess.run([sys.executable, os.path.join(HERE, "cram_vs_sam.py"), "11", "11"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.skipif(not os.access(S2B, os.X_OK), reason="needs the reference's htslib and binary (dev container only)")
+def test_target_regions_step_over_containers_and_still_match_the_reference(chk, tmp_path):
+    """a CRAM of many small containers + .crai, BED targets on a few places: containers whose stretch meets no (widened)
+    target are never read, and the table is the reference's byte for byte"""
+    import random
+    rng = random.Random(5)
+    contigs = [("u1", 200000), ("u2", 60000)]
+    recs = []
+    for i in range(6000):
+        ci = rng.randrange(2)
+        L = contigs[ci][1]
+        cig = rng.choice(["100M", "40M200N60M", "10S90M", "50M5D50M", "30M3I67M"])
+        span = sum(int(n) for n, o in __import__("re").findall(r"(\d+)([MDN])", cig))
+        pos = rng.randrange(1, L - span)
+        recs.append((ci, pos, "r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t*\t*" % (i, rng.choice([0, 16, 1024]), contigs[ci][0], pos, rng.choice([0, 30, 60]), cig)))
+    recs.sort()
+    sam = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "\n".join(r[2] for r in recs) + "\n"
+    (tmp_path / "t.sam").write_text(sam)
+    subprocess.run([S2B, "t.sam", "t.cram", "sps=100"], cwd=tmp_path, check=True, capture_output=True)
+    (tmp_path / "t.bed").write_text("u1\t5000\t5600\tA\nu1\t150000\t150100\tB\nu2\t1\t300\tC\nu2\t59000\t60000\tD\n")
+    cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
+    ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+    for extra in ([], ["-a"], ["-q", "20"]):
+        m = subprocess.run([cli, "-i", "t.cram", "-b", "t.bed", "-o", "m", "-t", "3"] + extra, cwd=tmp_path, capture_output=True,
+                           env=dict(os.environ, PANDEPTH_TIMING="1"), timeout=120)
+        r = subprocess.run([ref, "-i", "t.cram", "-b", "t.bed", "-o", "r", "-t", "3"] + extra, cwd=tmp_path, capture_output=True, timeout=120)
+        assert m.returncode == 0 and r.returncode == 0 and m.stdout == r.stdout
+        line = [l for l in m.stderr.decode().split("\n") if "containers decoded" in l][0]
+        decoded, skipped = int(line.split(" containers decoded")[0].split()[-1]), int(line.split(" stepped over")[0].split()[-1])
+        assert skipped > 40 and decoded < 15, line
+        for suffix in ("bed.stat.gz",) + (("SiteDepth.gz",) if extra == ["-a"] else ()):
+            assert (tmp_path / ("m." + suffix)).read_bytes() == (tmp_path / ("r." + suffix)).read_bytes(), suffix
