@@ -10,6 +10,7 @@
  *                                                                      reference-free (CRAM_OPT_NO_REF)
  *                  [sps=N] records per slice  [spc=N] slices per container  [multiseq] multi-reference slices
  *                  [embedref] (with ref=) the reference bases travel inside the slices
+ *                  [fmt=cram,version=3.1,small ...] an htslib format string instead of plain CRAM 3.0
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,7 +27,7 @@ int main(int argc, char **argv)
     const size_t ol = strlen(argv[2]);
     const int cram = ol > 5 && strcmp(argv[2] + ol - 5, ".cram") == 0;
     int noindex = 0, sps = 0, spc = 0, multiseq = 0, embedref = 0;
-    const char *ref = NULL;
+    const char *ref = NULL, *fmtstr = NULL;
     for (int k = 3; k < argc; ++k) {
         if (strcmp(argv[k], "noindex") == 0) noindex = 1;
         else if (strncmp(argv[k], "ref=", 4) == 0) ref = argv[k] + 4;
@@ -34,8 +35,12 @@ int main(int argc, char **argv)
         else if (strncmp(argv[k], "spc=", 4) == 0) spc = atoi(argv[k] + 4);
         else if (strcmp(argv[k], "multiseq") == 0) multiseq = 1;
         else if (strcmp(argv[k], "embedref") == 0) embedref = 1;
+        else if (strncmp(argv[k], "fmt=", 4) == 0) fmtstr = argv[k] + 4;
     }
-    samFile *out = sam_open(argv[2], cram ? "wc" : "wb");
+    htsFormat fmt;
+    memset(&fmt, 0, sizeof fmt);
+    if (fmtstr && hts_parse_format(&fmt, fmtstr) < 0) { fprintf(stderr, "bad format string %s\n", fmtstr); return 1; }
+    samFile *out = fmtstr ? sam_open_format(argv[2], "wc", &fmt) : sam_open(argv[2], cram ? "wc" : "wb");
     if (!out) { fprintf(stderr, "cannot open %s for writing\n", argv[2]); return 1; }
     if (cram) {
         if (ref) { if (hts_set_fai_filename(out, ref) < 0) { fprintf(stderr, "cannot use reference %s\n", ref); return 1; } }

@@ -140,6 +140,210 @@ bool rans_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out)
     return true;
 }
 
+// ---- rANS Nx16 (CRAM 3.1, block method 5): N = 4 or 32 interleaved states renormalised 16 bits at a time, 12- or
+// 10-bit frequencies, with the byte-stream transforms around it (stripe, bit packing, run lengths, stored) ------------------
+struct Cur7 : Cur {
+    using Cur::Cur;
+    uint32_t u7() { uint32_t v = 0; int c; int n = 0; do { c = u8(); v = (v << 7) | (uint32_t)(c & 0x7f); } while ((c & 0x80) && ok && ++n < 6); return v; }
+};
+
+bool nx16_alphabet(Cur7 &c, bool A[256])
+{
+    memset(A, 0, 256);
+    int rle = 0, j = c.u8();
+    do {
+        A[j] = true;
+        if (!rle && c.p < c.e && j + 1 == *c.p) { j = c.u8(); rle = c.u8(); }
+        else if (rle) { --rle; ++j; }
+        else j = c.u8();
+    } while (j && j < 256 && c.ok);
+    return c.ok;
+}
+
+// scales a row of frequencies whose sum is a smaller power of two up to 1 << bits and fills its lookup
+bool nx16_finish_row(uint32_t *F, uint32_t *C, uint8_t *lookup, int bits)
+{
+    uint32_t tot = 0;
+    for (int j = 0; j < 256; ++j) tot += F[j];
+    if (tot == 0) return true;
+    const uint32_t want = 1u << bits;
+    if (tot > want) return false;
+    int shift = 0;
+    while ((tot << shift) < want) ++shift;
+    if ((tot << shift) != want) return false;
+    uint32_t x = 0;
+    for (int j = 0; j < 256; ++j) {
+        F[j] <<= shift; C[j] = x;
+        if (F[j]) memset(lookup + x, j, F[j]);
+        x += F[j];
+    }
+    return true;
+}
+
+bool nx16_order0(Cur7 &c, uint8_t *o, size_t osize, int N)
+{
+    bool A[256];
+    if (!nx16_alphabet(c, A)) return false;
+    uint32_t F[256] = {0}, C[256] = {0};
+    for (int j = 0; j < 256; ++j) if (A[j]) F[j] = c.u7();
+    std::vector<uint8_t> lookup(4096, 0);
+    if (!c.ok || !nx16_finish_row(F, C, lookup.data(), 12)) return false;
+    uint32_t R[32];
+    for (int k = 0; k < N; ++k) R[k] = c.u32le();
+    if (!c.ok) return false;
+    for (size_t i = 0; i < osize; ++i) {
+        uint32_t &r = R[i % (size_t)N];
+        const uint32_t m = r & 0xfff;
+        const uint8_t s = lookup[m];
+        o[i] = s;
+        r = F[s] * (r >> 12) + m - C[s];
+        if (r < (1u << 15) && c.e - c.p >= 2) { r = (r << 16) | (uint32_t)c.p[0] | ((uint32_t)c.p[1] << 8); c.p += 2; }
+    }
+    return true;
+}
+
+bool nx16_order1(Cur7 &c, uint8_t *o, size_t osize, int N)
+{
+    const int comp = c.u8();
+    const int bits = comp >> 4;
+    if (!c.ok || bits < 8 || bits > 12) return false;
+    std::vector<uint8_t> table;
+    Cur7 t(c.p, (size_t)(c.e - c.p));
+    if (comp & 1) {                                       // the frequency table is itself order-0 compressed
+        const uint32_t usz = c.u7(), csz = c.u7();
+        const uint8_t *tp = c.take(csz);
+        if (!c.ok) return false;
+        table.assign(usz, 0);
+        Cur7 tc(tp, csz);
+        if (!nx16_order0(tc, table.data(), usz, 4)) return false;
+        t = Cur7(table.data(), table.size());
+    }
+    bool A[256];
+    if (!nx16_alphabet(t, A)) return false;
+    const size_t W = (size_t)1 << bits;
+    std::vector<uint32_t> F(256 * 256, 0), C(256 * 256, 0);
+    std::vector<uint8_t> lookup(256 * W, 0);
+    for (int i = 0; i < 256; ++i) {
+        if (!A[i]) continue;
+        int run = 0;
+        uint32_t *Fi = &F[(size_t)i * 256];
+        for (int j = 0; j < 256; ++j) {
+            if (!A[j]) continue;
+            if (run) { --run; continue; }
+            Fi[j] = t.u7();
+            if (Fi[j] == 0) run = t.u8();
+        }
+        if (!t.ok || !nx16_finish_row(Fi, &C[(size_t)i * 256], &lookup[(size_t)i * W], bits)) return false;
+    }
+    if (!(comp & 1)) c.p = t.p;                             // the table was read in place
+    uint32_t R[32];
+    for (int k = 0; k < N; ++k) R[k] = c.u32le();
+    if (!c.ok) return false;
+    const size_t q = osize / (size_t)N;
+    size_t idx[32];
+    int last[32];
+    for (int k = 0; k < N; ++k) { idx[k] = (size_t)k * q; last[k] = 0; }
+    const uint32_t mask = (uint32_t)W - 1;
+    auto step = [&](int k) {
+        uint32_t &r = R[k];
+        const uint32_t m = r & mask;
+        const size_t ctx = (size_t)last[k];
+        const uint8_t s = lookup[ctx * W + m];
+        o[idx[k]++] = s;
+        r = F[ctx * 256 + s] * (r >> bits) + m - C[ctx * 256 + s];
+        if (r < (1u << 15) && c.e - c.p >= 2) { r = (r << 16) | (uint32_t)c.p[0] | ((uint32_t)c.p[1] << 8); c.p += 2; }
+        last[k] = s;
+    };
+    for (size_t i = 0; i < q; ++i) for (int k = 0; k < N; ++k) step(k);
+    while (idx[N - 1] < osize) step(N - 1);
+    return true;
+}
+
+bool nx16_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out, size_t known_size, bool have_size, int depth)
+{
+    if (depth > 3 || n_in == 0) { out->clear(); return n_in == 0 && known_size == 0; }
+    Cur7 c(in, n_in);
+    const int flags = c.u8();
+    if (getenv("PANDEPTH_CRAM_DEBUG")) fprintf(stderr, "[cram]   nx16 flags 0x%02x in %zu depth %d\n", flags, n_in, depth);
+    const bool order1 = flags & 0x01, x32 = flags & 0x04, stripe = flags & 0x08, nosz = flags & 0x10, cat = flags & 0x20, rle = flags & 0x40, pack = flags & 0x80;
+    size_t osize = known_size;
+    if (!nosz) osize = c.u7(); else if (!have_size) return false;
+    if (!c.ok || osize > ((size_t)1 << 30)) return false;
+    if (stripe) {
+        const int n = c.u8();
+        if (n <= 0) return false;
+        std::vector<uint32_t> clen((size_t)n);
+        for (int k = 0; k < n; ++k) clen[(size_t)k] = c.u7();
+        out->assign(osize, 0);
+        for (int k = 0; k < n; ++k) {
+            const size_t ulen = osize / (size_t)n + ((osize % (size_t)n) > (size_t)k ? 1 : 0);
+            const uint8_t *sp = c.take(clen[(size_t)k]);
+            if (!c.ok) return false;
+            std::vector<uint8_t> sub;
+            if (!nx16_decode(sp, clen[(size_t)k], &sub, ulen, true, depth + 1) || sub.size() != ulen) return false;
+            for (size_t i = 0; i < ulen; ++i) (*out)[i * (size_t)n + (size_t)k] = sub[i];
+        }
+        return true;
+    }
+    // transforms announce themselves before the entropy-coded bytes, outermost first
+    uint8_t pmap[256]; int psym = 0; size_t unpacked = 0;
+    if (pack) {
+        psym = c.u8();
+        if (psym == 0) psym = 256;
+        for (int k = 0; k < psym && k < 256; ++k) pmap[k] = (uint8_t)c.u8();
+        unpacked = osize;
+        osize = c.u7();
+    }
+    std::vector<uint8_t> rmeta; size_t unrle = 0;
+    if (rle) {
+        const uint32_t umeta = c.u7();
+        const uint32_t rlen = c.u7();
+        if (umeta & 1) { const uint8_t *mp = c.take(umeta / 2); if (!c.ok) return false; rmeta.assign(mp, mp + umeta / 2); }
+        else {
+            const uint32_t cmeta = c.u7();
+            const uint8_t *mp = c.take(cmeta);
+            if (!c.ok) return false;
+            rmeta.assign(umeta / 2, 0);
+            Cur7 mc(mp, cmeta);
+            if (!nx16_order0(mc, rmeta.data(), rmeta.size(), x32 ? 32 : 4)) return false;      // the meta stream follows the block's interleave
+        }
+        unrle = osize;
+        osize = rlen;
+    }
+    if (!c.ok || osize > ((size_t)1 << 30)) return false;
+    std::vector<uint8_t> cur(osize, 0);
+    if (cat) { const uint8_t *d = c.take(osize); if (!c.ok) return false; if (osize) memcpy(cur.data(), d, osize); }
+    else if (osize) { if (!(order1 ? nx16_order1(c, cur.data(), osize, x32 ? 32 : 4) : nx16_order0(c, cur.data(), osize, x32 ? 32 : 4))) return false; }
+    if (rle) {
+        // meta: the symbols that carry run lengths, then the lengths (uint7) in order of appearance
+        Cur7 m(rmeta.data(), rmeta.size());
+        int ns = m.u8();
+        if (ns == 0) ns = 256;
+        bool has[256] = {false};
+        for (int k = 0; k < ns; ++k) has[m.u8()] = true;
+        std::vector<uint8_t> o2;
+        o2.reserve(unrle);
+        for (size_t i = 0; i < cur.size(); ++i) {
+            const uint8_t b = cur[i];
+            o2.push_back(b);
+            if (has[b]) { const uint32_t run = m.u7(); if (o2.size() + run > unrle) return false; o2.insert(o2.end(), run, b); }
+        }
+        if (!m.ok || o2.size() != unrle) return false;
+        cur.swap(o2);
+    }
+    if (pack) {
+        std::vector<uint8_t> o2(unpacked, 0);
+        if (psym <= 1) memset(o2.data(), pmap[0], unpacked);
+        else if (psym <= 2) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 3) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 3] >> (i & 7)) & 1]; } }
+        else if (psym <= 4) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 2) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 2] >> ((i & 3) * 2)) & 3]; } }
+        else if (psym <= 16) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 1) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 1] >> ((i & 1) * 4)) & 15]; } }
+        else { if (cur.size() != unpacked) return false; o2 = cur; }
+        cur.swap(o2);
+    }
+    out->swap(cur);
+    return true;
+}
+
 // ---- blocks (§8.1) ------------------------------------------------------------------------------------------------
 struct Block {
     int method = 0, type = 0;
@@ -190,8 +394,11 @@ bool inflate_block(Block *b, std::string *err)
     case 4:
         if (!rans_decode(d, (size_t)csize, &b->data) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS block in CRAM"; return false; }
         return true;
+    case 5:
+        if (!nx16_decode(d, (size_t)csize, &b->data, 0, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS Nx16 block in CRAM"; return false; }
+        return true;
     default:
-        *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma / CRAM 3.1 codecs)";
+        *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma / adaptive arithmetic coder)";
         return false;
     }
 }
@@ -551,7 +758,7 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
     if (!f_) return bad("cannot open " + path);
     uint8_t def[26];
     if (fread(def, 1, 26, f_) != 26 || memcmp(def, "CRAM", 4) != 0) return bad("not a CRAM file: " + path);
-    if (def[4] != 3 || def[5] != 0) return bad("CRAM version " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 only): " + path);
+    if (def[4] != 3 || def[5] > 1) return bad("CRAM version " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 and 3.1 only): " + path);
     // §6: the first container holds the SAM header
     ContainerHeader ch;
     if (read_container_header(f_, &ch) != 1) return bad("truncated CRAM header container: " + path);

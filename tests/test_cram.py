@@ -1,4 +1,4 @@
-"""CRAM 3.0 input (pandepth_amd/host/cram.cpp): the reader against the SAM text of the committed fixture files (any box),
+"""CRAM 3.0 / 3.1 input (pandepth_amd/host/cram.cpp): the reader against the SAM text of the committed fixture files (any box),
 against freshly generated files written by the reference's htslib (dev container only), and its error paths."""
 import os
 import subprocess
@@ -42,7 +42,7 @@ def test_reader_returns_the_records_of_the_sam_text(chk, name):
 def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
     good = open(os.path.join(F7, "m.cram"), "rb").read()
     cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
-    cases = {"v21.cram": good[:4] + b"\x02\x01" + good[6:], "v31.cram": good[:4] + b"\x03\x01" + good[6:],
+    cases = {"v21.cram": good[:4] + b"\x02\x01" + good[6:], "v32.cram": good[:4] + b"\x03\x02" + good[6:],
              "cut_header.cram": good[:40], "cut_body.cram": good[:len(good) // 2],
              "flipped.cram": good[:3000] + bytes(b ^ 0x5a for b in good[3000:3400]) + good[3400:]}
     for fn, data in cases.items():
@@ -50,7 +50,7 @@ def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
         p = subprocess.run([chk, str(tmp_path / fn)], capture_output=True, timeout=60)
         assert p.returncode in (0, 1), (fn, p.returncode)          # never a signal
         if fn.startswith("v"):
-            assert p.returncode == 1 and b"is not supported (3.0 only)" in p.stderr
+            assert p.returncode == 1 and b"is not supported (3.0 and 3.1 only)" in p.stderr
         if fn.startswith("cut"):
             assert p.returncode == 1
         q = subprocess.run([cli, "-i", fn, "-o", "o"], cwd=tmp_path, capture_output=True, timeout=60)
@@ -95,3 +95,12 @@ def test_target_regions_step_over_containers_and_still_match_the_reference(chk, 
         assert skipped > 40 and decoded < 15, line
         for suffix in ("bed.stat.gz",) + (("SiteDepth.gz",) if extra == ["-a"] else ()):
             assert (tmp_path / ("m." + suffix)).read_bytes() == (tmp_path / ("r." + suffix)).read_bytes(), suffix
+
+
+@pytest.mark.skipif(not os.access(S2B, os.X_OK), reason="needs the reference's libhts.a (dev container only)")
+def test_rans_nx16_decoder_against_the_htscodecs_encoder():
+    """CRAM 3.1's block codec: every transform combination round-trips through the encoder bundled in the reference's htslib"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "nx16_check"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HERE, "harness", "nx16_check")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-1500:]
