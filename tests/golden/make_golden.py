@@ -621,6 +621,7 @@ def build_f7(d):
     subprocess.run([SAM2BAM, "m.sam", "m.cram"], cwd=d, check=True, stderr=subprocess.DEVNULL)                       # reference-free + .crai
     subprocess.run([SAM2BAM, "m.sam", "m_noidx.cram", "noindex"], cwd=d, check=True, stderr=subprocess.DEVNULL)
     subprocess.run([SAM2BAM, "m.sam", "m_ref.cram", "ref=m_exact.fa"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # reference-based
+    subprocess.run([SAM2BAM, "m.sam", "m_v31.cram", "fmt=cram,version=3.1"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # CRAM 3.1 (rANS Nx16)
     for junk in ("m_exact.fa.fai",):
         if os.path.exists(os.path.join(d, junk)):
             os.remove(os.path.join(d, junk))
@@ -648,6 +649,8 @@ F7_CASES = [
     ("list_gff", ["-i", "m.list", "-g", "m.gff"]),
     ("r_overrides_ln", ["-i", "m.cram", "-r", "m.fa"]),
     ("gc", ["-i", "m.cram", "-r", "m.fa", "-c", "-w", "300"]),
+    ("chr_v31", ["-i", "m_v31.cram"]),
+    ("bed4_v31", ["-i", "m_v31.cram", "-b", "m.bed4"]),
 ]
 
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed
