@@ -283,7 +283,8 @@ def one_case(rng, td):
         # CRAM 3.0 written reference-free by the reference's own htslib; with a .crai next to it the reference takes its
         # indexed path
         indexed = form == "cram+crai" and sorted_hdr
-        r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]), cwd=td, capture_output=True)
+        r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]) + (["fmt=cram,version=3.1"] if rng.random() < 0.4 else [])
+                           + (["sps=%d" % rng.choice([3, 50])] if rng.random() < 0.3 else []), cwd=td, capture_output=True)
         if r.returncode == 0:
             args = ["-i", "x.cram"]
     elif form.startswith("bam") and os.access(S2B, os.X_OK):
