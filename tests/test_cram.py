@@ -104,3 +104,10 @@ def test_rans_nx16_decoder_against_the_htscodecs_encoder():
     subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "nx16_check"], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HERE, "harness", "nx16_check")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-1500:]
+
+
+def test_core_bit_stream_codecs_and_varints(chk):
+    """BETA / GAMMA / SUBEXP / canonical HUFFMAN on hand-made bit strings, ITF8 / LTF8 at their length boundaries"""
+    subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "cram_bits_check"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HERE, "harness", "cram_bits_check")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "0 failures", r.stdout
