@@ -57,8 +57,8 @@ bool rans_read_freqs(Cur &c, uint16_t F[256], uint16_t C[256], uint8_t *lookup)
         if (!rle && c.p < c.e && j + 1 == *c.p) { j = c.u8(); rle = c.u8(); }
         else if (rle) { --rle; ++j; }
         else j = c.u8();
-    } while (j && c.ok);
-    return c.ok;
+    } while (j && j < 256 && c.ok);
+    return c.ok && j < 256;
 }
 
 bool rans_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out)
@@ -109,7 +109,8 @@ bool rans_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out)
             if (!rle_i && c.p < c.e && i + 1 == *c.p) { i = c.u8(); rle_i = c.u8(); }
             else if (rle_i) { --rle_i; ++i; }
             else i = c.u8();
-        } while (i && c.ok);
+        } while (i && i < 256 && c.ok);
+        if (i >= 256) return false;
     }
     uint32_t R[4];
     for (int k = 0; k < 4; ++k) R[k] = c.u32le();
@@ -430,6 +431,7 @@ bool parse_enc(Cur &c, Enc *e)
         const int32_t m = p.itf8();
         for (int32_t k = 0; k < m; ++k) l.push_back(p.itf8());
         if (!p.ok || n != m || n <= 0) return false;
+        for (int32_t x : l) if (x < 0 || x > 31) return false;
         std::vector<int> ord((size_t)n);
         for (int k = 0; k < n; ++k) ord[(size_t)k] = k;
         for (int i = 1; i < n; ++i)                       // insertion sort by (length, symbol): alphabets are tiny
@@ -507,18 +509,19 @@ struct SliceData {
             }
             ok = false; return 0;
         }
-        case 6: return (int32_t)bits(e->bits) - e->offset;
+        case 6: if (e->bits < 0 || e->bits > 32) { ok = false; return 0; } return (int32_t)bits(e->bits) - e->offset;
         case 7: {
             int i = 0;
             while (ok && bits(1)) ++i;
             int32_t v;
             if (i == 0) v = (int32_t)bits(e->bits);
-            else { const int b = i + e->bits - 1; v = (int32_t)((1u << b) | bits(b)); }
+            else { const int b = i + e->bits - 1; if (b < 0 || b > 30) { ok = false; return 0; } v = (int32_t)((1u << b) | bits(b)); }
             return v - e->offset;
         }
         case 9: {
             int n = 0;
             while (ok && !bits(1)) ++n;
+            if (n > 30) { ok = false; return 0; }
             return (int32_t)((1u << n) | bits(n)) - e->offset;
         }
         default: ok = false; return 0;
