@@ -61,6 +61,7 @@ bool AlnReader::read_bam_header()
     uint8_t b[8];
     if (!bg_.read_exact(b, 8)) { err_ = "truncated BAM header"; return false; }
     const uint32_t l_text = le32(b + 4);
+    if (l_text > 0x7fffffffu) { err_ = "damaged BAM header (text length)"; return false; }      // int32 in the specification
     hdr_.text.resize(l_text);
     if (l_text && !bg_.read_exact(&hdr_.text[0], l_text)) { err_ = "truncated BAM header"; return false; }
     const std::string::size_type z = hdr_.text.find('\0');
@@ -70,6 +71,7 @@ bool AlnReader::read_bam_header()
     for (uint32_t i = 0; i < n_ref; ++i) {
         if (!bg_.read_exact(b, 4)) { err_ = "truncated BAM header"; return false; }
         const uint32_t l_name = le32(b);
+        if (l_name > (1u << 20)) { err_ = "damaged BAM header (reference name length)"; return false; }
         std::string nm(l_name, '\0');
         if (l_name && !bg_.read_exact(&nm[0], l_name)) { err_ = "truncated BAM header"; return false; }
         if (!nm.empty() && nm.back() == '\0') nm.pop_back();
@@ -259,6 +261,7 @@ bool BaiIndex::load(const std::string &path, std::string *err)
     auto need = [&](size_t k) { return o + k <= d.size(); };
     if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) { if (err) *err = path + " is not a BAI index"; return false; }
     const uint32_t n_ref = le32(d.data() + 4); o = 8;
+    if ((size_t)n_ref > (d.size() - 8) / 8) { if (err) *err = path + ": damaged BAI index (reference count)"; return false; }   // 8 bytes per reference at least
     linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {});
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!need(4)) goto bad;
@@ -388,6 +391,7 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err)
     o = 16 + l_aux;
     if (min_shift < 1 || min_shift > 30 || depth < 1 || depth > 9 || !need(4)) { if (err) *err = path + ": unsupported CSI parameters"; return false; }
     const uint32_t n_ref = le32(d.data() + o); o += 4;
+    if ((size_t)n_ref > (d.size() - o) / 4 + 1) { if (err) *err = path + ": damaged CSI index (reference count)"; return false; }  // 4 bytes per reference at least
     linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {}); loffset.assign(n_ref, {});
     const uint32_t meta_bin = (uint32_t)(((1ull << (3 * (depth + 1))) - 1) / 7 + 1);
     for (uint32_t r = 0; r < n_ref; ++r) {
