@@ -229,3 +229,23 @@ def test_paf_lines_the_reference_cannot_answer(cli, tmp_path):
             want[k] += 1
     assert d == want
     assert stat(tmp_path / "u.chr.stat.gz").split("\n")[1] == "tg\t300\t100\t100\t33.33\t0.33"
+
+
+def test_damaged_index_is_not_trusted(cli, tmp_path, golden_dir):
+    """a .bai whose reference count has a flipped high byte (it asked for 64 GB once): the file is read without it, the
+    reads the indexed path selects are the same, so is the table"""
+    f1 = os.path.join(golden_dir, "f1")
+    for fn in ("f1.bam", "f1.gff"):
+        os.symlink(os.path.join(f1, fn), tmp_path / fn)
+    bai = bytearray(open(os.path.join(f1, "f1.bam.bai"), "rb").read())
+    (tmp_path / "good").mkdir()
+    os.symlink(os.path.join(f1, "f1.bam"), tmp_path / "good" / "f1.bam")
+    os.symlink(os.path.join(f1, "f1.gff"), tmp_path / "good" / "f1.gff")
+    (tmp_path / "good" / "f1.bam.bai").write_bytes(bytes(bai))
+    bai[7] = 160
+    (tmp_path / "f1.bam.bai").write_bytes(bytes(bai))
+    for extra in ([], ["-g", "f1.gff"]):
+        run(cli, ["-i", "f1.bam", "-o", "o", "-t", "3"] + extra, tmp_path)
+        run(cli, ["-i", "f1.bam", "-o", "o", "-t", "3"] + extra, tmp_path / "good")
+        name = "o.gene.stat.gz" if extra else "o.chr.stat.gz"
+        assert (tmp_path / name).read_bytes() == (tmp_path / "good" / name).read_bytes()
