@@ -284,7 +284,11 @@ def one_case(rng, td):
         # indexed path
         indexed = form == "cram+crai" and sorted_hdr
         r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]) + (["fmt=cram,version=3.1"] if rng.random() < 0.4 else [])
-                           + (["sps=%d" % rng.choice([3, 50])] if rng.random() < 0.3 else []), cwd=td, capture_output=True)
+                           + (["sps=%d" % rng.choice([3, 50])] if rng.random() < 0.3 and not indexed else []), cwd=td, capture_output=True)
+        # (tiny slices only without a .crai: htslib's slice lookup, cram_index_query, walks back only while the PREVIOUS slice
+        # still reaches the target, so with a .crai and GFF / BED targets the reference misses a read from an earlier slice
+        # that spans into the target — it finds that read in the same data written as BAM, and so does this reader in the
+        # CRAM; tests/test_cram.py pins that)
         if r.returncode == 0:
             args = ["-i", "x.cram"]
     elif form.startswith("bam") and os.access(S2B, os.X_OK):
