@@ -115,11 +115,10 @@ def test_core_bit_stream_codecs_and_varints(chk):
 
 @pytest.mark.skipif(not os.access(S2B, os.X_OK), reason="needs the reference's htslib and binary (dev container only)")
 def test_region_reads_of_a_cram_are_the_reads_of_the_same_data_as_bam(chk, tmp_path):
-    """Declared deviation.  With a .crai and GFF / BED targets, htslib finds the first slice to read by walking back from
-    the target only while the previous slice's end still reaches it (cram_index_query); a read in a still earlier slice
-    whose alignment spans into the target (long N gaps; easy to provoke with tiny slices) is never returned, so the
-    reference reports less depth for the CRAM than for the same records written as BAM.  This reader selects reads per
-    record, so its CRAM answer is the reference's BAM answer."""
+    """Declared deviation.  With a .crai and GFF / BED targets, htslib's slice lookup (cram_index_query) does not return a
+    read that sits in an earlier slice and spans into the target across slices that end before it (long N gaps; easy to
+    provoke with tiny slices), so the reference reports less depth for the CRAM than for the same records written as
+    BAM.  This reader selects reads per record, so its CRAM answer is the reference's BAM answer."""
     import random
     rng = random.Random(9)
     L = 6000
