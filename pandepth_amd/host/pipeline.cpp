@@ -717,6 +717,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             // PD:3486-3492 hands -r to htslib for CRAM input, and htslib then trusts the FASTA over the header: an @SQ
             // whose LN differs from the indexed sequence's length is rewritten to the FASTA's (cram_io.c
             // sanitise_SQ_lines).  Plain-text FASTA only (its faidx cannot index a gzip file, and nothing changes then).
+            // Not detected: a plain FASTA that faidx refuses to index (ragged line lengths, blank lines inside a record).
             std::map<std::string, uint32_t> fa_len;
             std::string scratch;
             bool plain = false;
