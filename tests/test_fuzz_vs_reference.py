@@ -1,6 +1,6 @@
 """Differential fuzzing of the host pipeline (CPU oracle engine) against the compiled reference, when it is present
 (dev container: oracle/_ref/pandepth_ref built from /root/reference): tests/fuzz_vs_ref.py generates small SAM / BAM /
-BAM+BAI / #.list inputs, GFF / GTF / BED3 / BED4 files with the quirks real files have (comments, blank lines, unknown
+BAM+BAI / CRAM 3.0 and 3.1 (+CRAI) / PAF / #.list inputs, GFF / GTF / BED3 / BED4 files with the quirks real files have (comments, blank lines, unknown
 contigs, start > end, duplicate ids, odd attribute orders, leading zeros, spaces for tabs) and random option mixes, and
 compares exit code, stdout and every output file byte for byte.  This is how the last-base target rule of the reference's
 indexed path was found (tests/golden/f4).  Skipped where the reference binary does not exist (GPU box, CI)."""
