@@ -345,6 +345,133 @@ bool nx16_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out, size
     return true;
 }
 
+// ---- adaptive arithmetic coder (CRAM 3.1, block method 6): a byte-wise range coder over adaptive frequency models, order
+// 0 or 1, optionally with run lengths modelled beside the symbols, inside the same stripe / pack / stored framing ---------
+struct RangeDec {
+    const uint8_t *p, *e;
+    uint32_t range = 0xffffffffu, code = 0;
+    bool ok = true;
+    RangeDec(const uint8_t *b, const uint8_t *end) : p(b), e(end)
+    {
+        if (e - p < 5) { ok = false; p = e; return; }
+        for (int k = 0; k < 5; ++k) code = (code << 8) | *p++;      // the first byte is the encoder's carry cache
+    }
+    uint32_t freq(uint32_t tot) { range /= tot; if (!range) { ok = false; return 0; } return code / range; }
+    void decode(uint32_t cum, uint32_t f)
+    {
+        code -= cum * range;
+        range *= f;
+        while (range < (1u << 24)) { if (p >= e) { ok = false; return; } code = (code << 8) | *p++; range <<= 8; }
+    }
+};
+
+template <int NSYM> struct AdaptModel {
+    static constexpr uint32_t MAXF = (1u << 16) - 17, STEP = 16;
+    uint32_t tot;
+    struct SF { uint16_t f, s; } v[NSYM + 2];            // v[0] is a sentinel that outranks everything, v[NSYM + 1] ends the list
+    void init(int max_sym)
+    {
+        v[0].f = (uint16_t)MAXF; v[0].s = 0;
+        for (int i = 0; i < NSYM; ++i) { v[i + 1].s = (uint16_t)i; v[i + 1].f = i < max_sym ? 1 : 0; }
+        v[NSYM + 1].f = 0; v[NSYM + 1].s = 0;
+        tot = (uint32_t)max_sym;
+    }
+    int get(RangeDec &rc)
+    {
+        const uint32_t fr = rc.freq(tot);
+        if (!rc.ok || fr > MAXF) { rc.ok = false; return 0; }
+        int k = 1;
+        uint32_t acc = 0;
+        while (k <= NSYM && (acc += v[k].f) <= fr) ++k;
+        if (k > NSYM) { rc.ok = false; return 0; }
+        acc -= v[k].f;
+        rc.decode(acc, v[k].f);
+        v[k].f = (uint16_t)(v[k].f + STEP); tot += STEP;
+        if (tot > MAXF) { tot = 0; for (int j = 1; j <= NSYM && v[j].f; ++j) { v[j].f = (uint16_t)(v[j].f - (v[j].f >> 1)); tot += v[j].f; } }
+        if (v[k].f > v[k - 1].f) { const SF t = v[k]; v[k] = v[k - 1]; v[k - 1] = t; return t.s; }      // kept roughly sorted
+        return v[k].s;
+    }
+};
+
+bool arith_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out, size_t known_size, bool have_size, int depth)
+{
+    if (depth > 3 || n_in == 0) { out->clear(); return n_in == 0 && known_size == 0; }
+    Cur7 c(in, n_in);
+    const int flags = c.u8();
+    const bool order1 = flags & 0x01, ext = flags & 0x04, stripe = flags & 0x08, nosz = flags & 0x10, cat = flags & 0x20, rle = flags & 0x40, pack = flags & 0x80;
+    size_t osize = known_size;
+    if (!nosz) osize = c.u7(); else if (!have_size) return false;
+    if (!c.ok || osize > ((size_t)1 << 30) || ext || (flags & 0x02)) return false;         // EXT = bzip2 inside; order 2 does not exist
+    if (stripe) {
+        const int n = c.u8();
+        if (n <= 0) return false;
+        std::vector<uint32_t> clen((size_t)n);
+        for (int k = 0; k < n; ++k) clen[(size_t)k] = c.u7();
+        out->assign(osize, 0);
+        for (int k = 0; k < n; ++k) {
+            const size_t ulen = osize / (size_t)n + ((osize % (size_t)n) > (size_t)k ? 1 : 0);
+            const uint8_t *sp = c.take(clen[(size_t)k]);
+            if (!c.ok) return false;
+            std::vector<uint8_t> sub;
+            if (!arith_decode(sp, clen[(size_t)k], &sub, ulen, true, depth + 1) || sub.size() != ulen) return false;
+            for (size_t i = 0; i < ulen; ++i) (*out)[i * (size_t)n + (size_t)k] = sub[i];
+        }
+        return true;
+    }
+    uint8_t pmap[256]; int psym = 0; size_t unpacked = 0;
+    if (pack) {
+        psym = c.u8();
+        if (psym == 0) psym = 256;
+        for (int k = 0; k < psym && k < 256; ++k) pmap[k] = (uint8_t)c.u8();
+        unpacked = osize;
+        osize = c.u7();
+    }
+    if (!c.ok || osize > ((size_t)1 << 30)) return false;
+    std::vector<uint8_t> cur(osize, 0);
+    if (cat) { const uint8_t *d = c.take(osize); if (!c.ok) return false; if (osize) memcpy(cur.data(), d, osize); }
+    else if (osize) {
+        int m = c.u8();
+        if (m == 0) m = 256;
+        RangeDec rc(c.p, c.e);
+        typedef AdaptModel<256> BM;
+        typedef AdaptModel<258> RM;
+        std::vector<BM> bm(order1 ? 256 : 1);
+        for (BM &x : bm) x.init(m);
+        std::vector<RM> rm;
+        if (rle) { rm.resize(258); for (RM &x : rm) x.init(4); }
+        int last = 0;
+        for (size_t i = 0; i < osize && rc.ok; ++i) {
+            const int s = bm[order1 ? (size_t)last : 0].get(rc);
+            cur[i] = (uint8_t)s;
+            last = s;
+            if (rle) {
+                // the run that follows the symbol: parts of 0..3, a part of 3 says "more follows"; the context moves from the
+                // symbol to 256, 257 and stays there
+                uint32_t run = 0, part;
+                int rctx = s;
+                do {
+                    part = (uint32_t)rm[(size_t)rctx].get(rc);
+                    if (rctx == s) rctx = 256; else if (rctx < 257) ++rctx;
+                    run += part;
+                } while (part == 3 && rc.ok && run < ((uint32_t)1 << 30));
+                for (uint32_t j = 0; j < run && i + 1 < osize; ++j) cur[++i] = (uint8_t)s;
+            }
+        }
+        if (!rc.ok) return false;
+    }
+    if (pack) {
+        std::vector<uint8_t> o2(unpacked, 0);
+        if (psym <= 1) memset(o2.data(), pmap[0], unpacked);
+        else if (psym <= 2) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 3) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 3] >> (i & 7)) & 1]; } }
+        else if (psym <= 4) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 2) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 2] >> ((i & 3) * 2)) & 3]; } }
+        else if (psym <= 16) { for (size_t i = 0; i < unpacked; ++i) { if ((i >> 1) >= cur.size()) return false; o2[i] = pmap[(cur[i >> 1] >> ((i & 1) * 4)) & 15]; } }
+        else { if (cur.size() != unpacked) return false; o2 = cur; }
+        cur.swap(o2);
+    }
+    out->swap(cur);
+    return true;
+}
+
 // ---- blocks (§8.1) ------------------------------------------------------------------------------------------------
 struct Block {
     int method = 0, type = 0;
@@ -398,8 +525,11 @@ bool inflate_block(Block *b, std::string *err)
     case 5:
         if (!nx16_decode(d, (size_t)csize, &b->data, 0, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS Nx16 block in CRAM"; return false; }
         return true;
+    case 6:
+        if (!arith_decode(d, (size_t)csize, &b->data, 0, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt or unsupported (bzip2 inside) arithmetic-coded block in CRAM"; return false; }
+        return true;
     default:
-        *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma / adaptive arithmetic coder)";
+        *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma; fqzcomp and the name tokeniser only hold qualities and names)";
         return false;
     }
 }

@@ -2,13 +2,14 @@
 // reference-consuming shape of the alignment).  The reference gets CRAM from htslib (PD:3486-3492 sets the decoder to
 // FLAG | RNAME | POS | MAPQ | CIGAR); this is an independent reader written from the CRAM 3.0 specification
 // (samtools/hts-specs CRAMv3 and CRAMcodecs): file definition, containers, blocks (raw / gzip / rANS 4x8 order 0 and 1 /
-// rANS Nx16 with its stripe, pack, run-length and stored transforms — the codec CRAM 3.1 uses for the series read here), the
+// rANS Nx16 with its stripe, pack, run-length and stored transforms and the adaptive arithmetic coder — the codecs CRAM 3.1
+// uses for the series read here), the
 // compression header (preservation map, data-series and tag encodings: EXTERNAL, HUFFMAN, BYTE_ARRAY_LEN,
 // BYTE_ARRAY_STOP, BETA, GAMMA, SUBEXP, NULL), slices (single- and multi-reference, delta-coded positions) and the
 // record layout.  A CRAM record stores no CIGAR: it is rebuilt from the read features (§10.6 of the specification),
 // which needs no reference sequence — only positions matter here, so `-r` is not required for decoding.
-// Not read: CRAM 2.x; bzip2 / lzma / adaptive-arithmetic blocks (the reference's own htslib build cannot write the
-// profiles that use them); fqzcomp and name-tokeniser blocks only ever hold qualities and names, which are never inflated.
+// Not read: CRAM 2.x; bzip2 / lzma blocks (and arithmetic-coder blocks that wrap bzip2): the reference's own htslib build
+// has neither library; fqzcomp and name-tokeniser blocks only ever hold qualities and names, which are never inflated.
 #ifndef PD_CRAM_H_
 #define PD_CRAM_H_
 #include <stdint.h>

@@ -99,7 +99,8 @@ def test_target_regions_step_over_containers_and_still_match_the_reference(chk, 
 
 @pytest.mark.skipif(not os.access(S2B, os.X_OK), reason="needs the reference's libhts.a (dev container only)")
 def test_rans_nx16_decoder_against_the_htscodecs_encoder():
-    """CRAM 3.1's block codec: every transform combination round-trips through the encoder bundled in the reference's htslib"""
+    """CRAM 3.1's block codecs (rANS Nx16, adaptive arithmetic coder): every transform combination round-trips through the
+    encoders bundled in the reference's htslib"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", os.path.join(HERE, "harness"), "nx16_check"], check=True, stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HERE, "harness", "nx16_check")], capture_output=True, text=True, timeout=600)
