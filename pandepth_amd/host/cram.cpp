@@ -268,7 +268,8 @@ bool nx16_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out, size
     if (getenv("PANDEPTH_CRAM_DEBUG")) fprintf(stderr, "[cram]   nx16 flags 0x%02x in %zu depth %d\n", flags, n_in, depth);
     const bool order1 = flags & 0x01, x32 = flags & 0x04, stripe = flags & 0x08, nosz = flags & 0x10, cat = flags & 0x20, rle = flags & 0x40, pack = flags & 0x80;
     size_t osize = known_size;
-    if (!nosz) osize = c.u7(); else if (!have_size) return false;
+    if (!nosz) { osize = c.u7(); if (!have_size && known_size && osize != known_size) return false; }     // (the block header's size, when the caller has one)
+    else if (!have_size) return false;
     if (!c.ok || osize > ((size_t)1 << 30)) return false;
     if (stripe) {
         const int n = c.u8();
@@ -400,7 +401,8 @@ bool arith_decode(const uint8_t *in, size_t n_in, std::vector<uint8_t> *out, siz
     const int flags = c.u8();
     const bool order1 = flags & 0x01, ext = flags & 0x04, stripe = flags & 0x08, nosz = flags & 0x10, cat = flags & 0x20, rle = flags & 0x40, pack = flags & 0x80;
     size_t osize = known_size;
-    if (!nosz) osize = c.u7(); else if (!have_size) return false;
+    if (!nosz) { osize = c.u7(); if (!have_size && known_size && osize != known_size) return false; }     // (the block header's size, when the caller has one)
+    else if (!have_size) return false;
     if (!c.ok || osize > ((size_t)1 << 30) || ext || (flags & 0x02)) return false;         // EXT = bzip2 inside; order 2 does not exist
     if (stripe) {
         const int n = c.u8();
@@ -523,10 +525,10 @@ bool inflate_block(Block *b, std::string *err)
         if (!rans_decode(d, (size_t)csize, &b->data) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS block in CRAM"; return false; }
         return true;
     case 5:
-        if (!nx16_decode(d, (size_t)csize, &b->data, 0, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS Nx16 block in CRAM"; return false; }
+        if (!nx16_decode(d, (size_t)csize, &b->data, (size_t)rsize, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt rANS Nx16 block in CRAM"; return false; }
         return true;
     case 6:
-        if (!arith_decode(d, (size_t)csize, &b->data, 0, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt or unsupported (bzip2 inside) arithmetic-coded block in CRAM"; return false; }
+        if (!arith_decode(d, (size_t)csize, &b->data, (size_t)rsize, false, 0) || b->data.size() != (size_t)rsize) { *err = "corrupt or unsupported (bzip2 inside) arithmetic-coded block in CRAM"; return false; }
         return true;
     default:
         *err = "CRAM block compression method " + std::to_string(b->method) + " is not supported (bzip2 / lzma; fqzcomp and the name tokeniser only hold qualities and names)";
