@@ -488,13 +488,14 @@ bool inflate_block(Block *b, std::string *err);
 
 // lazy = true: only the block header is parsed; inflate_block() runs when somebody needs the bytes (the external blocks
 // of series the depth path never reads — qualities, names, bases, tags — are never decompressed)
-bool read_block(Cur &c, Block *b, std::string *err, bool lazy = false)
+// CRAM 2.1 differs from 3.0 in framing only: no CRC32 after container headers and blocks, 32-bit record counters
+bool read_block(Cur &c, Block *b, std::string *err, bool lazy = false, bool v2 = false)
 {
     b->method = c.u8(); b->type = c.u8(); b->id = c.itf8();
     b->csize = c.itf8(); b->rsize = c.itf8();
     if (!c.ok || b->csize < 0 || b->rsize < 0) { *err = "truncated CRAM block header"; return false; }
     b->comp = c.take((size_t)b->csize);
-    c.take(4);                                           // CRC32
+    if (!v2) c.take(4);                                  // CRC32
     if (!c.ok) { *err = "truncated CRAM block"; return false; }
     b->ready = false;
     return lazy ? true : inflate_block(b, err);
@@ -853,7 +854,7 @@ int fgetc_ltf8(FILE *f, int64_t *v)
 struct ContainerHeader { int32_t length = 0, ref = 0, start = 0, span = 0, n_rec = 0, n_blocks = 0; std::vector<int32_t> landmarks; };
 
 // 1 ok, 0 clean end of file, -1 truncated
-int read_container_header(FILE *f, ContainerHeader *h)
+int read_container_header(FILE *f, ContainerHeader *h, bool v2)
 {
     uint8_t l[4];
     const size_t got = fread(l, 1, 4, f);
@@ -862,11 +863,12 @@ int read_container_header(FILE *f, ContainerHeader *h)
     h->length = (int32_t)((uint32_t)l[0] | ((uint32_t)l[1] << 8) | ((uint32_t)l[2] << 16) | ((uint32_t)l[3] << 24));
     int64_t t;
     int32_t n = 0;
+    int32_t t32;
     if (fgetc_itf8(f, &h->ref) || fgetc_itf8(f, &h->start) || fgetc_itf8(f, &h->span) || fgetc_itf8(f, &h->n_rec) ||
-        fgetc_ltf8(f, &t) || fgetc_ltf8(f, &t) || fgetc_itf8(f, &h->n_blocks) || fgetc_itf8(f, &n)) return -1;
+        (v2 ? fgetc_itf8(f, &t32) : fgetc_ltf8(f, &t)) || fgetc_ltf8(f, &t) || fgetc_itf8(f, &h->n_blocks) || fgetc_itf8(f, &n)) return -1;
     h->landmarks.clear();
     for (int32_t k = 0; k < n; ++k) { int32_t v; if (fgetc_itf8(f, &v)) return -1; h->landmarks.push_back(v); }
-    if (fread(l, 1, 4, f) != 4) return -1;                 // CRC32
+    if (!v2 && fread(l, 1, 4, f) != 4) return -1;          // CRC32
     return h->length < 0 ? -1 : 1;
 }
 
@@ -893,16 +895,30 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
     if (!f_) return bad("cannot open " + path);
     uint8_t def[26];
     if (fread(def, 1, 26, f_) != 26 || memcmp(def, "CRAM", 4) != 0) return bad("not a CRAM file: " + path);
-    if (def[4] != 3 || def[5] > 1) return bad("CRAM version " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 and 3.1 only): " + path);
+    if (!((def[4] == 3 && def[5] <= 1) || (def[4] == 2 && def[5] == 1))) return bad("CRAM version " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (2.1, 3.0 and 3.1 only): " + path);
     // §6: the first container holds the SAM header
     ContainerHeader ch;
-    if (read_container_header(f_, &ch) != 1) return bad("truncated CRAM header container: " + path);
-    std::vector<uint8_t> body((size_t)ch.length);
-    if (ch.length && fread(body.data(), 1, body.size(), f_) != body.size()) return bad("truncated CRAM header container: " + path);
-    Cur c(body.data(), body.size());
+    v2_ = def[4] == 2;
+    if (read_container_header(f_, &ch, v2_) != 1) return bad("truncated CRAM header container: " + path);
+    // The header block is read from the file itself, not from `length` bytes of container body: writers of CRAM 2.1 files
+    // state a container length a few bytes short of the (padded) block, and htslib reads it this way too.
     Block b;
     std::string e2;
-    if (!read_block(c, &b, &e2)) return bad(e2);
+    std::vector<uint8_t> raw;
+    {
+        uint8_t mt[2];
+        int32_t id = 0, csize = 0, rsize = 0;
+        const long at = ftell(f_);
+        if (fread(mt, 1, 2, f_) != 2 || fgetc_itf8(f_, &id) || fgetc_itf8(f_, &csize) || fgetc_itf8(f_, &rsize) || csize < 0 || rsize < 0)
+            return bad("truncated CRAM header block: " + path);
+        raw.resize((size_t)csize);
+        if (csize && fread(raw.data(), 1, raw.size(), f_) != raw.size()) return bad("truncated CRAM header block: " + path);
+        if (!v2_) { uint8_t crc[4]; if (fread(crc, 1, 4, f_) != 4) return bad("truncated CRAM header block: " + path); }
+        b.method = mt[0]; b.type = mt[1]; b.id = id; b.comp = raw.data(); b.csize = csize; b.rsize = rsize;
+        if (!inflate_block(&b, &e2)) return bad(e2);
+        const long used = ftell(f_) - at;
+        if ((long)ch.length > used && fseek(f_, (long)ch.length - used, SEEK_CUR) != 0) return bad("truncated CRAM header container: " + path);
+    }
     if (b.type != 0 || b.data.size() < 4) return bad("CRAM header block missing: " + path);
     const uint32_t l_text = (uint32_t)b.data[0] | ((uint32_t)b.data[1] << 8) | ((uint32_t)b.data[2] << 16) | ((uint32_t)b.data[3] << 24);
     if ((size_t)l_text + 4 > b.data.size()) return bad("CRAM header text truncated: " + path);
@@ -934,14 +950,14 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
 namespace {
 
 // one container body (everything after the container header) -> its records
-bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out)
+bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out, bool v2)
 {
     typedef CramReader::Rec Rec;
     auto bad = [&](const std::string &m) { if (out->err.empty()) out->err = m; return false; };
     Cur c(body.data(), body.size());
     Block cb;
     std::string e2;
-    if (!read_block(c, &cb, &e2)) return bad(e2);
+    if (!read_block(c, &cb, &e2, false, v2)) return bad(e2);
     if (cb.type != 1) return bad("CRAM compression header missing");
     CompHeader H;
     if (!parse_comp_header(cb.data, &H)) return bad("CRAM compression header uses an encoding this reader does not know");
@@ -963,19 +979,19 @@ bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out)
     while (c.left() > 0) {
         // §8.5 slice header, then its blocks
         Block sh;
-        if (!read_block(c, &sh, &e2)) return bad(e2);
+        if (!read_block(c, &sh, &e2, false, v2)) return bad(e2);
         if (sh.type != 2) return bad("CRAM slice header expected");
         Cur s(sh.data.data(), sh.data.size());
         const int32_t ref = s.itf8(), start = s.itf8();
         s.itf8();                                       // span
         const int32_t n_rec = s.itf8();
-        s.ltf8();                                       // record counter
+        if (v2) s.itf8(); else s.ltf8();               // record counter
         const int32_t n_blocks = s.itf8();
         if (!s.ok || n_rec < 0 || n_blocks < 0) return bad("corrupt CRAM slice header");
         std::vector<Block> blocks((size_t)n_blocks);
         SliceData sd;
         for (int32_t k = 0; k < n_blocks; ++k) {
-            if (!read_block(c, &blocks[(size_t)k], &e2, true)) return bad(e2);
+            if (!read_block(c, &blocks[(size_t)k], &e2, true, v2)) return bad(e2);
             Block &b = blocks[(size_t)k];
             if (b.type == 5) { if (!inflate_block(&b, &e2)) return bad(e2); sd.core = b.data.data(); sd.core_n = b.data.size(); }
             else if (b.type == 4) sd.ext[b.id] = SliceData::Ext{&b, 0, nullptr, nullptr};
@@ -1060,7 +1076,7 @@ bool CramReader::read_body(std::vector<uint8_t> *body)
 {
     for (;;) {
         ContainerHeader ch;
-        const int rc = read_container_header(f_, &ch);
+        const int rc = read_container_header(f_, &ch, v2_);
         if (rc == 0) { eof_ = true; return false; }
         if (rc < 0) { eof_ = true; return fail("truncated CRAM container header"); }
         if (keep_ && ch.n_rec > 0 && ch.ref != -2 &&
@@ -1088,11 +1104,11 @@ int CramReader::next(AlnRec *r)
             if (threads_ == 1) {
                 std::promise<Batch> p;
                 Batch b;
-                decode_container(body, &b);
+                decode_container(body, &b, v2_);
                 p.set_value(std::move(b));
                 ahead_.push_back(p.get_future());
             } else
-                ahead_.push_back(std::async(std::launch::async, [](std::vector<uint8_t> bytes) { Batch b; decode_container(bytes, &b); return b; }, std::move(body)));
+                ahead_.push_back(std::async(std::launch::async, [](std::vector<uint8_t> bytes, bool v2) { Batch b; decode_container(bytes, &b, v2); return b; }, std::move(body), v2_));
         }
         if (ahead_.empty()) return err_.empty() ? 0 : -1;
         cur_batch_ = ahead_.front().get();

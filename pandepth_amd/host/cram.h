@@ -1,4 +1,4 @@
-// cram.h — CRAM 3.0 / 3.1 input reduced to the five fields the depth path reads (refID, pos, mapq, flag and the
+// cram.h — CRAM 2.1 / 3.0 / 3.1 input reduced to the five fields the depth path reads (refID, pos, mapq, flag and the
 // reference-consuming shape of the alignment).  The reference gets CRAM from htslib (PD:3486-3492 sets the decoder to
 // FLAG | RNAME | POS | MAPQ | CIGAR); this is an independent reader written from the CRAM 3.0 specification
 // (samtools/hts-specs CRAMv3 and CRAMcodecs): file definition, containers, blocks (raw / gzip / rANS 4x8 order 0 and 1 /
@@ -8,7 +8,7 @@
 // BYTE_ARRAY_STOP, BETA, GAMMA, SUBEXP, NULL), slices (single- and multi-reference, delta-coded positions) and the
 // record layout.  A CRAM record stores no CIGAR: it is rebuilt from the read features (§10.6 of the specification),
 // which needs no reference sequence — only positions matter here, so `-r` is not required for decoding.
-// Not read: CRAM 2.x; bzip2 / lzma blocks (and arithmetic-coder blocks that wrap bzip2): the reference's own htslib build
+// Not read: CRAM 1.0 / 2.0; bzip2 / lzma blocks (and arithmetic-coder blocks that wrap bzip2): the reference's own htslib build
 // has neither library; fqzcomp and name-tokeniser blocks only ever hold qualities and names, which are never inflated.
 #ifndef PD_CRAM_H_
 #define PD_CRAM_H_
@@ -50,7 +50,7 @@ private:
     bool read_body(std::vector<uint8_t> *body);  // the next container that holds records; false at end of file / error
     bool fail(const std::string &m) { if (err_.empty()) err_ = m; return false; }
     FILE *f_ = nullptr;
-    bool eof_ = false;
+    bool eof_ = false, v2_ = false;          // v2_: CRAM 2.1 framing (no CRC32 fields, 32-bit record counters)
     int threads_ = 1;
     std::function<bool(int32_t, int64_t, int64_t)> keep_;
     uint64_t n_read_ = 0, n_skipped_ = 0;

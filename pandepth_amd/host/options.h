@@ -1,5 +1,5 @@
 // options.h — the command-line surface of `pandepth` (-i -o -g -f -b -w -a -q -d -x -t -s -c -r -h);
-// -i takes SAM / BAM / CRAM 3.0-3.1 / PAF files or a #.list of them.
+// -i takes SAM / BAM / CRAM 2.1 / 3.0 / 3.1 / PAF files or a #.list of them.
 // Behaviour follows the reference's parser (PD:84-293) including its quirks: every '-' is
 // stripped from a flag, `*.list`/`*.List` expands to one input per non-empty line, -w < 1 and
 // -d < 1 clamp to 1, -o gets ".gz" appended and a trailing ".stat"/".bed" dropped later.

@@ -87,7 +87,9 @@ for k in range(cases):
     if rng.random()<0.4: args.append('spc=%d'%rng.choice([2,3,10]))
     if rng.random()<0.2: args.append('multiseq')
     if useref and rng.random()<0.3: args.append('embedref')
-    if rng.random()<0.5: args.append('fmt=cram,version=3.1'+rng.choice(['',',fast',',normal',',level=1',',level=9']))    # rANS Nx16 blocks
+    u=rng.random()
+    if u<0.45: args.append('fmt=cram,version=3.1'+rng.choice(['',',fast',',normal',',level=1',',level=9']))    # rANS Nx16 blocks
+    elif u<0.6: args.append('fmt=cram,version=2.1')                                                       # the older framing
     p=subprocess.run(args,capture_output=True)
     if p.returncode: print('case',k,'s2b failed',p.stderr.decode()[-200:]); continue
     a=subprocess.run([CHK,'t.cram'],capture_output=True); b=subprocess.run([CHK,'t.sam'],capture_output=True)

@@ -283,7 +283,7 @@ def one_case(rng, td):
         # CRAM 3.0 written reference-free by the reference's own htslib; with a .crai next to it the reference takes its
         # indexed path
         indexed = form == "cram+crai" and sorted_hdr
-        r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]) + (["fmt=cram,version=3.1"] if rng.random() < 0.4 else [])
+        r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]) + ([rng.choice(["fmt=cram,version=3.1", "fmt=cram,version=3.1", "fmt=cram,version=2.1"])] if rng.random() < 0.5 else [])
                            + (["sps=%d" % rng.choice([3, 50])] if rng.random() < 0.3 and not indexed else []), cwd=td, capture_output=True)
         # (tiny slices only without a .crai: htslib's slice lookup, cram_index_query, walks back only while the PREVIOUS slice
         # still reaches the target, so with a .crai and GFF / BED targets the reference misses a read from an earlier slice

@@ -1,4 +1,4 @@
-"""CRAM 3.0 / 3.1 input (pandepth_amd/host/cram.cpp): the reader against the SAM text of the committed fixture files (any box),
+"""CRAM 2.1 / 3.0 / 3.1 input (pandepth_amd/host/cram.cpp): the reader against the SAM text of the committed fixture files (any box),
 against freshly generated files written by the reference's htslib (dev container only), and its error paths."""
 import os
 import subprocess
@@ -42,7 +42,7 @@ def test_reader_returns_the_records_of_the_sam_text(chk, name):
 def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
     good = open(os.path.join(F7, "m.cram"), "rb").read()
     cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
-    cases = {"v21.cram": good[:4] + b"\x02\x01" + good[6:], "v32.cram": good[:4] + b"\x03\x02" + good[6:],
+    cases = {"v20.cram": good[:4] + b"\x02\x00" + good[6:], "v32.cram": good[:4] + b"\x03\x02" + good[6:],
              "cut_header.cram": good[:40], "cut_body.cram": good[:len(good) // 2],
              "flipped.cram": good[:3000] + bytes(b ^ 0x5a for b in good[3000:3400]) + good[3400:]}
     for fn, data in cases.items():
@@ -50,7 +50,7 @@ def test_unsupported_and_damaged_files_are_errors_not_crashes(chk, tmp_path):
         p = subprocess.run([chk, str(tmp_path / fn)], capture_output=True, timeout=60)
         assert p.returncode in (0, 1), (fn, p.returncode)          # never a signal
         if fn.startswith("v"):
-            assert p.returncode == 1 and b"is not supported (3.0 and 3.1 only)" in p.stderr
+            assert p.returncode == 1 and b"is not supported (2.1, 3.0 and 3.1 only)" in p.stderr
         if fn.startswith("cut"):
             assert p.returncode == 1
         q = subprocess.run([cli, "-i", fn, "-o", "o"], cwd=tmp_path, capture_output=True, timeout=60)
