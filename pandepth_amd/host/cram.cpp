@@ -899,6 +899,7 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
     // §6: the first container holds the SAM header
     ContainerHeader ch;
     v2_ = def[4] == 2;
+    fsize_ = file_size(path);
     if (read_container_header(f_, &ch, v2_) != 1) return bad("truncated CRAM header container: " + path);
     // The header block is read from the file itself, not from `length` bytes of container body: writers of CRAM 2.1 files
     // state a container length a few bytes short of the (padded) block, and htslib reads it this way too.
@@ -911,6 +912,7 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
         const long at = ftell(f_);
         if (fread(mt, 1, 2, f_) != 2 || fgetc_itf8(f_, &id) || fgetc_itf8(f_, &csize) || fgetc_itf8(f_, &rsize) || csize < 0 || rsize < 0)
             return bad("truncated CRAM header block: " + path);
+        if ((uint64_t)csize > file_size(path) || (uint64_t)rsize > ((uint64_t)1 << 31)) return bad("damaged CRAM header block: " + path);
         raw.resize((size_t)csize);
         if (csize && fread(raw.data(), 1, raw.size(), f_) != raw.size()) return bad("truncated CRAM header block: " + path);
         if (!v2_) { uint8_t crc[4]; if (fread(crc, 1, 4, f_) != 4) return bad("truncated CRAM header block: " + path); }
@@ -1085,6 +1087,7 @@ bool CramReader::read_body(std::vector<uint8_t> *body)
             ++n_skipped_;
             continue;
         }
+        if ((uint64_t)ch.length > fsize_) { eof_ = true; return fail("truncated CRAM container"); }      // longer than the file: do not size a buffer from it
         body->resize((size_t)ch.length);
         if (ch.length && fread(body->data(), 1, body->size(), f_) != body->size()) { eof_ = true; return fail("truncated CRAM container"); }
         if (ch.n_rec == 0) continue;                       // the end-of-file container (or an empty one)

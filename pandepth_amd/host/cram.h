@@ -52,6 +52,7 @@ private:
     FILE *f_ = nullptr;
     bool eof_ = false, v2_ = false;          // v2_: CRAM 2.1 framing (no CRC32 fields, 32-bit record counters)
     int threads_ = 1;
+    uint64_t fsize_ = 0;
     std::function<bool(int32_t, int64_t, int64_t)> keep_;
     uint64_t n_read_ = 0, n_skipped_ = 0;
     std::deque<std::future<Batch>> ahead_;
