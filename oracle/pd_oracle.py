@@ -123,7 +123,7 @@ _CIG = {c: i for i, c in enumerate("MIDNSHP=XB")}
 def _cram_text(path):
     """CRAM decoding is NOT restated here (the product's reader is pinned against the SAM text by tests/test_cram.py and
     against the reference's outputs by the golden cases): a .cram input is replaced by the SAM it was written from, which
-    the fixtures keep next to it as <stem>.sam (m_noidx.cram, m_ref.cram, m_v31.cram -> m.sam)."""
+    the fixtures keep next to it as <stem>.sam (m_noidx.cram, m_ref.cram, m_v31.cram, m_v21.cram -> m.sam)."""
     stem = path[:-5]
     for cand in (stem + ".sam", os.path.join(os.path.dirname(stem), os.path.basename(stem).split("_")[0] + ".sam")):
         if os.path.exists(cand):

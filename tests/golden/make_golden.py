@@ -622,6 +622,7 @@ def build_f7(d):
     subprocess.run([SAM2BAM, "m.sam", "m_noidx.cram", "noindex"], cwd=d, check=True, stderr=subprocess.DEVNULL)
     subprocess.run([SAM2BAM, "m.sam", "m_ref.cram", "ref=m_exact.fa"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # reference-based
     subprocess.run([SAM2BAM, "m.sam", "m_v31.cram", "fmt=cram,version=3.1"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # CRAM 3.1 (rANS Nx16)
+    subprocess.run([SAM2BAM, "m.sam", "m_v21.cram", "noindex", "fmt=cram,version=2.1"], cwd=d, check=True, stderr=subprocess.DEVNULL)  # CRAM 2.1 framing
     for junk in ("m_exact.fa.fai",):
         if os.path.exists(os.path.join(d, junk)):
             os.remove(os.path.join(d, junk))
@@ -651,6 +652,7 @@ F7_CASES = [
     ("gc", ["-i", "m.cram", "-r", "m.fa", "-c", "-w", "300"]),
     ("chr_v31", ["-i", "m_v31.cram"]),
     ("bed4_v31", ["-i", "m_v31.cram", "-b", "m.bed4"]),
+    ("chr_v21", ["-i", "m_v21.cram"]),
 ]
 
 BIG_OUTPUT = 400000   # decompressed bytes above which only hashes are committed

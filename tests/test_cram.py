@@ -31,7 +31,7 @@ def records(chk, path):
     return out
 
 
-@pytest.mark.parametrize("name", ["m.cram", "m_noidx.cram", "m_ref.cram", "m_v31.cram"])
+@pytest.mark.parametrize("name", ["m.cram", "m_noidx.cram", "m_ref.cram", "m_v31.cram", "m_v21.cram"])
 def test_reader_returns_the_records_of_the_sam_text(chk, name):
     """reference-free and reference-based files, bases / qualities / tags / mate fields present, multi-reference slices"""
     want = records(chk, os.path.join(F7, "m.sam"))
