@@ -43,7 +43,7 @@ def test_host_pipeline_byte_identical(harness, case, tmp_path):
     run_case(harness, case, tmp_path, 1)
 
 
-@pytest.mark.parametrize("case", [e for e in MANIFEST if e["fixture"] == "f3" or e["name"] in ("gff_a", "list3", "w100")],
+@pytest.mark.parametrize("case", [e for e in MANIFEST if e["fixture"] in ("f3", "f6", "f7") or e["name"] in ("gff_a", "list3", "w100")],
                          ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_host_pipeline_parallel_readers(harness, case, tmp_path):
     run_case(harness, case, tmp_path, 4)
