@@ -2,6 +2,7 @@
 // record of a SAM / BAM (AlnReader) or CRAM (CramReader) file, one line each, so that the CRAM reader can be compared
 // with the SAM text the CRAM was made from.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include "../../pandepth_amd/host/bam.h"
 #include "../../pandepth_amd/host/cram.h"
@@ -25,6 +26,7 @@ int main(int argc, char **argv)
     if (CramReader::is_cram(argv[1])) {
         CramReader c; AlnHeader h;
         if (!c.open(argv[1], &h, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (argc > 2) c.set_threads(atoi(argv[2]));            // containers decoded ahead on helper threads
         for (size_t i = 0; i < h.names.size(); ++i) printf("@%s\t%u\n", h.names[i].c_str(), h.lens[i]);
         int rc; while ((rc = c.next(&r)) == 1) dump(r);
         if (rc < 0) { fprintf(stderr, "error: %s\n", c.error().c_str()); return 1; }
