@@ -196,6 +196,7 @@ int AlnReader::next(AlnRec *r)
     } else {
         if (!bg_.read_exact(szb, 4)) { err_ = "truncated BAM record"; return -1; }
         bs = le32(szb);
+        if (bs < 32 || bs > (1u << 30)) { err_ = "corrupt BAM record"; return -1; }     // before anything is sized from it
         if (rec_.size() < bs) rec_.resize(bs);
         if (!bg_.read_exact(rec_.data(), bs)) { err_ = "truncated BAM record"; return -1; }
         rec = rec_.data();
@@ -212,8 +213,11 @@ int AlnReader::next(AlnRec *r)
     // CIGARs with > 65535 operations are stored in the CG:B,I tag behind a <l_seq>S<ref_len>N
     // placeholder (SAM spec §4.2.2); long reads need this.
     const uint32_t l_seq = le32(rec + 16);
-    if (n_cigar == 2 && (le32(cg) & 0xf) == 4 && (le32(cg) >> 4) == l_seq && (le32(cg + 4) & 0xf) == 3) {
-        const uint8_t *aux = cg + 8 + (l_seq + 1) / 2 + l_seq, *end = rec + bs;
+    // htslib's test (bam_tag2cigar): any CIGAR whose first operation is <l_seq>S on a placed read (tid, pos >= 0), and a
+    // CG tag of type B,I or B,i with at least n_cigar entries; the fake CIGAR is kept when no such tag exists.
+    if (n_cigar >= 1 && r->tid >= 0 && r->pos >= 0 && (le32(cg) & 0xf) == 4 && (le32(cg) >> 4) == l_seq) {
+        const uint8_t *aux = cg + 4 * (size_t)n_cigar + (l_seq + 1) / 2 + (size_t)l_seq, *end = rec + bs;
+        if (aux > end) aux = end;
         while (aux + 3 <= end) {
             const char t0 = (char)aux[0], t1 = (char)aux[1], ty = (char)aux[2];
             aux += 3;
@@ -227,7 +231,9 @@ int AlnReader::next(AlnRec *r)
                 const char st = (char)aux[0];
                 const uint32_t cnt = le32(aux + 1);
                 const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-                if (t0 == 'C' && t1 == 'G' && st == 'I' && aux + 5 + 4 * (size_t)cnt <= end) {
+                if (t0 == 'C' && t1 == 'G') {
+                    // the first CG tag decides (bam_aux_get): wrong subtype or too short means "keep the fake CIGAR"
+                    if (!((st == 'I' || st == 'i') && cnt >= n_cigar && cnt < (1u << 29) && aux + 5 + 4 * (size_t)cnt <= end)) break;
                     cig_.resize(cnt);
                     for (uint32_t i = 0; i < cnt; ++i) cig_[i] = le32(aux + 5 + 4 * i);
                     r->n_cigar = cnt; r->cigar = cig_.data();

@@ -86,7 +86,11 @@ uint32_t bgzf_block_size(const uint8_t *p, size_t avail, uint32_t *data_off)
     while (o + 4 <= xend) {
         const uint32_t slen = p[o + 2] | (p[o + 3] << 8);
         if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2) {
+            if (o + 6 > xend) return 0;                          // the BC payload itself must lie inside the extra field
             const uint32_t bsize = p[o + 4] | (p[o + 5] << 8);
+            // a block holds its header, the extra field and the 8-byte CRC32/ISIZE trailer: callers compute
+            // bs - data_off - 8 and read p[bs - 4 ..], so anything shorter is a corrupt block (0), not a size
+            if (bsize + 1 < xend + 8) return 0;
             if (data_off) *data_off = xend;
             return bsize + 1;
         }

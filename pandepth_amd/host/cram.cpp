@@ -164,17 +164,24 @@ bool nx16_alphabet(Cur7 &c, bool A[256])
 // scales a row of frequencies whose sum is a smaller power of two up to 1 << bits and fills its lookup
 bool nx16_finish_row(uint32_t *F, uint32_t *C, uint8_t *lookup, int bits)
 {
-    uint32_t tot = 0;
-    for (int j = 0; j < 256; ++j) tot += F[j];
-    if (tot == 0) return true;
+    // every frequency comes straight from the file (a uint7 of up to 32 bits): bound each one and add them up in
+    // 64 bits, so that a crafted row cannot wrap the sum back to a legal total and drive the memset below past the table
     const uint32_t want = 1u << bits;
-    if (tot > want) return false;
+    uint64_t tot64 = 0;
+    for (int j = 0; j < 256; ++j) {
+        if (F[j] > want) return false;
+        tot64 += F[j];
+        if (tot64 > want) return false;
+    }
+    const uint32_t tot = (uint32_t)tot64;
+    if (tot == 0) return true;
     int shift = 0;
     while ((tot << shift) < want) ++shift;
     if ((tot << shift) != want) return false;
     uint32_t x = 0;
     for (int j = 0; j < 256; ++j) {
         F[j] <<= shift; C[j] = x;
+        if (F[j] > want - x) return false;
         if (F[j]) memset(lookup + x, j, F[j]);
         x += F[j];
     }
@@ -952,7 +959,22 @@ bool CramReader::open(const std::string &path, AlnHeader *hdr, std::string *err)
 namespace {
 
 // one container body (everything after the container header) -> its records
+bool decode_container_unchecked(const std::vector<uint8_t> &body, CramReader::Batch *out, bool v2);
+
+// Sizes inside a container (block sizes, table sizes, record counts) are file-declared; whatever slips past the
+// explicit bounds ends as std::bad_alloc / std::length_error.  On a helper thread that would reach future::get()
+// uncaught and end the process, so it is turned into the reader's ordinary "corrupt CRAM" error here.
 bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out, bool v2)
+{
+    try { return decode_container_unchecked(body, out, v2); }
+    catch (const std::exception &e) {
+        out->recs.clear(); out->cigs.clear();
+        if (out->err.empty()) out->err = std::string("corrupt CRAM container (") + e.what() + ")";
+        return false;
+    }
+}
+
+bool decode_container_unchecked(const std::vector<uint8_t> &body, CramReader::Batch *out, bool v2)
 {
     typedef CramReader::Rec Rec;
     auto bad = [&](const std::string &m) { if (out->err.empty()) out->err = m; return false; };
@@ -990,6 +1012,9 @@ bool decode_container(const std::vector<uint8_t> &body, CramReader::Batch *out, 
         if (v2) s.itf8(); else s.ltf8();               // record counter
         const int32_t n_blocks = s.itf8();
         if (!s.ok || n_rec < 0 || n_blocks < 0) return bad("corrupt CRAM slice header");
+        // counts come from the file: a block takes at least 6 bytes of the container, and a slice of more than 2^24
+        // records is not something any writer produces (htslib: 10 000) — nothing below is sized from a larger number
+        if ((size_t)n_blocks > c.left() / 6 + 1 || n_rec > (1 << 24)) return bad("corrupt CRAM slice header");
         std::vector<Block> blocks((size_t)n_blocks);
         SliceData sd;
         for (int32_t k = 0; k < n_blocks; ++k) {

@@ -50,6 +50,24 @@ int main() {
                 if (!ok) { ++bad; printf("FAIL arith order 0x%02x kind %d len %zu (stream flags 0x%02x, %u bytes)\n", o, kind, len, c[0], osz); }
                 free(c);
             }
+    // crafted order-0 streams whose uint7 frequencies wrap a 32-bit sum back to 4096 (F[1] = 0x80000000, F[2] = 0x80001000):
+    // the decoder used to memset 2 GiB past its 4096-byte table; every single frequency and the running total are bounded now
+    {
+        auto u7 = [](std::vector<uint8_t> &v, uint32_t x) { uint8_t t[5]; int k = 0; do { t[k++] = x & 0x7f; x >>= 7; } while (x); while (k--) v.push_back(t[k] | (k ? 0x80 : 0)); };
+        for (int variant = 0; variant < 3; ++variant) {
+            std::vector<uint8_t> st;
+            st.push_back(0x00);                                    // flags: order 0, 4-way, no transforms
+            u7(st, 64);                                            // uncompressed size
+            st.push_back(1); st.push_back(2); st.push_back(0);     // alphabet {1, 2}
+            if (variant == 0) { u7(st, 0x80000000u); u7(st, 0x80001000u); }
+            else if (variant == 1) { u7(st, 0xFFFFFFFFu); u7(st, 4097u); }
+            else { u7(st, 5000u); u7(st, 0xFFFFF000u - 904u); }
+            for (int k = 0; k < 64; ++k) st.push_back((uint8_t)(rng() & 0xff));
+            std::vector<uint8_t> out;
+            ++n;
+            if (pdh::nx16_decode(st.data(), st.size(), &out, 0, false, 0)) { ++bad; printf("FAIL wrapped frequency sum accepted (variant %d)\n", variant); }
+        }
+    }
     printf("%d cases, %d failures\n", n, bad);
     return bad != 0;
 }
