@@ -10,6 +10,7 @@
 #include <string.h>
 #include <vector>
 #include "pd_inflate_core.h"
+#include "pd_inflate_wave.h"
 #include "pd_bamdev_core.h"
 #include "pd_kernels.h"
 #include "../../include/pandepth_amd.h"
@@ -17,6 +18,7 @@
 namespace {
 
 typedef pd_bgzf_block BlkDesc;      // { in_off, out_off, in_len, out_len }
+#define PD_WAVE_TOKENS (65536 / 3 + 64)
 
 // One lane per block.  The fast (one-lookup) tables of a wave's 64 lanes live in LDS (64 x 576 B =
 // 36 KiB, four waves per CU); the cold canonical arrays in a global scratch area.  LDS_FAST = false
@@ -31,6 +33,27 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
     pdi::Fast &tf = LDS_FAST ? s_fast[threadIdx.x] : scratch[i].fast;
     const BlkDesc d = blk[i];
     status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tf, scratch[i].slow) : 0;
+}
+
+// One WAVE per BGZF member (pd_inflate_wave.h): persistent one-wave workgroups take members from an atomic counter;
+// Huffman tables in LDS (10.7 KiB per wave), match tokens in a per-workgroup slice of global scratch.
+__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
+                                                     pdw::Token *tok_scratch, uint32_t *next)
+{
+    __shared__ pdw::Tables T;
+    __shared__ uint32_t s_i;
+    pdw::Token *tok = tok_scratch + (size_t)blockIdx.x * PD_WAVE_TOKENS;
+    for (;;) {
+        if (threadIdx.x == 0) s_i = atomicAdd(next, 1u);
+        __syncthreads();
+        const uint32_t i = s_i;
+        __syncthreads();
+        if (i >= n_blk) return;
+        const BlkDesc d = blk[i];
+        int rc = 0;
+        if (d.out_len) rc = pdw::inflate_block<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
+        if (threadIdx.x == 0) status[i] = rc;
+    }
 }
 
 // thread per unit: record offsets (sequential by nature: each record's length says where the next
@@ -111,6 +134,19 @@ __global__ __launch_bounds__(256) void k_parse_records(const uint8_t *buf, const
 
 namespace pdk {
 
+// the wave-cooperative decoder: n_wg persistent one-wave workgroups; `scratch` = bgzf_wave_scratch_bytes(n_wg) bytes
+void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
+                              int *status, void *scratch, unsigned n_wg)
+{
+    if (!n_blk) return;
+    if (n_wg > n_blk) n_wg = n_blk;
+    uint32_t *counter = (uint32_t *)scratch;
+    (void)hipMemsetAsync(counter, 0, 64, st);
+    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status,
+                       (pdw::Token *)((uint8_t *)scratch + 64), counter);
+}
+size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return 64 + (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token); }
+
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                          int *status, void *scratch)
 {
@@ -172,9 +208,17 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
     const uint32_t nb = (uint32_t)blks.size();
     int rc = PD_OK;
     hipEvent_t e0, e1;
+    // variant >= 2: the wave-cooperative decoder with (variant >> 4, default 16) persistent waves per CU
+    unsigned n_wg = 0;
+    if (variant >= 2) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, device) != hipSuccess) return PD_ENODEV;
+        const unsigned per_cu = (variant >> 4) ? (unsigned)(variant >> 4) : 16u;
+        n_wg = (unsigned)pr.multiProcessorCount * per_cu;
+    }
     if (hipMalloc(&d_in, n_bytes + 16) != hipSuccess || hipMalloc(&d_out, uo + 16) != hipSuccess ||
         hipMalloc(&d_blk, (size_t)nb * sizeof(BlkDesc) + 16) != hipSuccess || hipMalloc(&d_st, (size_t)nb * 4 + 16) != hipSuccess) rc = PD_ENOMEM;
-    if (rc == PD_OK && hipMalloc(&d_scr, (size_t)nb * sizeof(pdi::Tables)) != hipSuccess) rc = PD_ENOMEM;
+    if (rc == PD_OK && hipMalloc(&d_scr, variant >= 2 ? pdk::bgzf_wave_scratch_bytes(n_wg) : (size_t)nb * sizeof(pdi::Tables)) != hipSuccess) rc = PD_ENOMEM;
 #define HIPV(x) do { if ((x) != hipSuccess) rc = PD_EHIP; } while (0)
     if (rc == PD_OK) {
         HIPV(hipMemcpy(d_in, p, n_bytes, hipMemcpyHostToDevice));
@@ -183,7 +227,8 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
         for (int r = 0; r < reps + 1; ++r) {
             if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
             const dim3 g((nb + 63) / 64), b(64);
-            if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
+            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg);
+            else if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
             else hipLaunchKernelGGL(k_inflate_blocks<false>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
         }
         HIPV(hipEventRecord(e1, 0));

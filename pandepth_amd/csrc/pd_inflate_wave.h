@@ -1,0 +1,631 @@
+// pd_inflate_wave.h — WAVE-COOPERATIVE raw DEFLATE (RFC 1951) decoder for one BGZF block: one 64-lane
+// wavefront per block, all 64 lanes decoding the SAME block at once.
+//
+// Huffman decoding is serial by nature (a symbol's length says where the next one starts), so the wave
+// decodes SPECULATIVELY and then synchronises:
+//   * the compressed bits of a deflate block are cut into 64 subsequences of S bits; lane l decodes
+//     subsequence l starting at a guessed bit position (lane 0's start is the true one);
+//   * a Huffman decoder started at a wrong position falls back onto the true symbol boundaries after a few
+//     symbols (self-synchronisation), so most lanes END at the true position even when they started wrong.
+//     Round after round every lane takes the end of its left neighbour as its start and re-decodes if that
+//     changed; by induction lanes 0..k are exact after round k, and in practice all lanes agree after 2-3
+//     rounds.  No output is written while speculating: a round only counts the bytes a subsequence emits;
+//   * an exclusive wave scan of those counts gives every lane its output offset; a last pass writes the
+//     literals and copies the matches.  A match may read bytes another lane of the same pass has not written
+//     yet, so the pass runs in rounds: a lane stalls at a match whose source is not final — final = below the
+//     frontier F (the write cursor of the first unfinished lane at the start of the round) or inside the
+//     lane's own region — and the first unfinished lane never stalls, so at most 64 rounds are needed.
+// Table construction (canonical codes -> two-level lookup tables: a 10-bit / 8-bit root plus sub-tables for
+// longer codes, one or two LDS lookups per symbol) is lane-parallel as well.
+//
+// The SAME source compiles for gfx950 (class W = the hardware wave: ballots, DPP / shuffles, LDS) and for the
+// host (class W = 64 emulated lanes in a loop), where tests/harness/inflate_wave_check.cpp compares it with
+// zlib on every block of the test files before it runs on a GPU.  Code outside W::each() is wave-uniform
+// (every lane computes the same values); code inside runs per lane; collectives are W:: functions.
+//
+// Anything this decoder does not want to judge (incomplete Huffman codes other than the usual "one distance
+// code", sub-table overflow) returns PD_W_HOST: the caller hands that block's unit back to the host decoder.
+// Every loop is bounded by the input / output sizes: corrupt data ends in an error code, never in a hang or
+// an out-of-bounds write.
+#ifndef PD_INFLATE_WAVE_H_
+#define PD_INFLATE_WAVE_H_
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define PW_FN __host__ __device__ __forceinline__
+#else
+#define PW_FN inline
+#endif
+
+namespace pdw {
+
+enum { LL_ROOT = 10, LL_SUBCAP = 320, D_ROOT = 8, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
+enum { PD_W_OK = 0, PD_W_HOST = 1 };      // negative values: corrupt stream (same codes as pd_inflate_core.h)
+enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2, KIND_BAD = 3 };
+enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };
+
+// Table entry: [3:0] code length in bits (sub-table pointer: index width)  [5:4] kind  [6] sub-table pointer
+//              [15:8] literal byte / number of extra bits  [31:16] base value / sub-table offset
+struct Tables {
+    uint32_t ll[(1 << LL_ROOT) + LL_SUBCAP];
+    uint32_t d[(1 << D_ROOT) + D_SUBCAP];
+    uint16_t sorted[320];                 // symbols ordered by (code length, symbol)
+    uint32_t work[160];                   // table building: uint16 rank[320] (position of a symbol inside its length class);
+                                          // phase 3: bdst[64] | bend[64] (destination range of every match of the current batch)
+    uint8_t cl[320];                      // code lengths of the deflate block being set up
+    PW_FN uint16_t *rank() { return reinterpret_cast<uint16_t *>(work); }
+    PW_FN uint32_t *bdst() { return work; }
+    PW_FN uint32_t *bend() { return work + 64; }
+};
+
+struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
+    uint64_t blocks = 0, dblocks = 0, steps = 0, sync_rounds = 0, emit_rounds = 0, sym_true = 0, sym_decoded = 0, lanes_redecoded = 0;
+    uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0;
+};
+
+PW_FN uint64_t ld64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+PW_FN void st64(uint8_t *p, uint64_t w) { __builtin_memcpy(p, &w, 8); }
+PW_FN uint32_t bitrev32(uint32_t x)
+{
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+#endif
+}
+PW_FN uint32_t bitrev(uint32_t x, int n) { return n ? bitrev32(x) >> (32 - n) : 0u; }
+PW_FN uint32_t peek_bits(const uint8_t *in, uint32_t q) { return (uint32_t)(ld64(in + (q >> 3)) >> (q & 7)); }   // >= 32 valid bits
+
+template <int MODE> PW_FN uint32_t make_entry(uint32_t sym, uint32_t len)
+{
+    if (MODE == 0) {                      // literal / length alphabet
+        if (sym < 256) return len | (KIND_LIT << 4) | (sym << 8);
+        if (sym == 256) return len | (KIND_EOB << 4);
+        if (sym > 285) return KIND_BAD << 4;
+        const uint32_t ls = sym - 257;
+        uint32_t ext = 0, base = 3 + ls;
+        if (ls == 28) base = 258;
+        else if (ls >= 8) { ext = (ls >> 2) - 1; base = ((4 + (ls & 3)) << ext) + 3; }
+        return len | (KIND_LEN << 4) | (ext << 8) | (base << 16);
+    }
+    if (MODE == 1) {                      // distance alphabet
+        if (sym > 29) return KIND_BAD << 4;
+        uint32_t ext = 0, base = sym + 1;
+        if (sym >= 4) { ext = (sym >> 1) - 1; base = ((2 + (sym & 1)) << ext) + 1; }
+        return len | (KIND_LEN << 4) | (ext << 8) | (base << 16);
+    }
+    return len | (KIND_LIT << 4) | (sym << 8);     // the code-length code
+}
+
+// Canonical Huffman code -> lookup table `tab` (root of 2^ROOT entries + sub-tables for longer codes).
+// Returns 0, PD_W_HOST (incomplete code / sub-table area too small) or -3 (over-subscribed, no codes).
+template <class W, int ROOT, int SUBCAP, int MODE>
+PW_FN int build_table(uint32_t *tab, const uint8_t *cl, int n, uint16_t *sorted, uint16_t *rank)
+{
+    typedef typename W::template Var<uint32_t> U;
+    uint32_t count[16], first[16], offs[16];                 // wave-uniform; only ever indexed by unrolled constants
+#pragma unroll
+    for (int v = 0; v < 16; ++v) count[v] = 0;
+    // class sizes and every symbol's position inside its class, by ballots (symbol order is kept inside a class)
+    for (int b = 0; b < n; b += 64) {
+        U L;
+        W::each([&](int l) { const int s = b + l; L[l] = s < n ? cl[s] : 0u; });
+#pragma unroll
+        for (int v = 1; v <= 15; ++v) {
+            const uint64_t m = W::ballot_eq(L, (uint32_t)v);
+            if (m) {
+                const uint32_t c0 = count[v];
+                W::each([&](int l) { if (L[l] == (uint32_t)v) rank[b + l] = (uint16_t)(c0 + W::prefix_count(m, l)); });
+                count[v] += (uint32_t)__builtin_popcountll(m);
+            }
+        }
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int v = 1; v <= 15; ++v) total += count[v];
+    if (total == 0) {
+        if (MODE != 1) return -3;
+        W::each([&](int l) { for (uint32_t i = l; i < (1u << ROOT); i += 64) tab[i] = KIND_BAD << 4; });   // a block without matches
+        W::sync();
+        return 0;
+    }
+    int left = 1;
+#pragma unroll
+    for (int v = 1; v <= 15; ++v) { left <<= 1; left -= (int)count[v]; if (left < 0) return -3; }
+    // incomplete codes: only "one distance code of one bit" is decoded here (zlib accepts exactly that)
+    if (left > 0 && !(MODE == 1 && total == 1 && count[1] == 1)) return PD_W_HOST;
+    {
+        uint32_t code = 0, off = 0;
+#pragma unroll
+        for (int v = 1; v <= 15; ++v) { code = (code + (v > 1 ? count[v - 1] : 0u)) << 1; first[v] = code; offs[v] = off; off += count[v]; }
+    }
+    first[0] = offs[0] = 0;
+    W::sync();
+    W::each([&](int l) {
+        for (int s = l; s < n; s += 64) {
+            const uint32_t len = cl[s];
+            if (!len) continue;
+            uint32_t o = 0;
+#pragma unroll
+            for (int v = 1; v <= 15; ++v) if (len == (uint32_t)v) o = offs[v];
+            sorted[o + rank[s]] = (uint16_t)s;
+        }
+    });
+    W::sync();
+    // root: every index asks which code (of at most ROOT bits) its bits start with
+    W::each([&](int l) {
+        for (uint32_t i = l; i < (1u << ROOT); i += 64) {
+            const uint32_t rc = bitrev(i, ROOT);
+            uint32_t flen = 0, fidx = 0;
+#pragma unroll
+            for (int v = 1; v <= ROOT; ++v) {
+                const uint32_t c = rc >> (ROOT - v);
+                if (!flen && c >= first[v] && c - first[v] < count[v]) { flen = (uint32_t)v; fidx = offs[v] + (c - first[v]); }
+            }
+            tab[i] = flen ? make_entry<MODE>(sorted[fidx], flen) : (uint32_t)(KIND_BAD << 4);
+        }
+    });
+    uint32_t n_long = 0;
+#pragma unroll
+    for (int v = ROOT + 1; v <= 15; ++v) n_long += count[v];
+    if (n_long) {
+        // ROOT-bit prefixes (most significant bit first) pmin .. 2^ROOT - 1 lead to codes longer than ROOT bits; the
+        // sub-table of a prefix is indexed by as many further bits as its longest code needs
+        const uint32_t pmin = first[ROOT] + count[ROOT];
+        const uint32_t np = (1u << ROOT) - pmin;
+        const uint32_t ch = (np + 63) / 64;
+        auto sub_bits = [&](uint32_t P) -> uint32_t {
+            uint32_t sb = 0;
+#pragma unroll
+            for (int v = ROOT + 1; v <= 15; ++v)
+                if (count[v] && P >= (first[v] >> (v - ROOT)) && P <= ((first[v] + count[v] - 1) >> (v - ROOT))) sb = (uint32_t)(v - ROOT);
+            return sb;
+        };
+        U size;
+        W::each([&](int l) {
+            uint32_t s = 0;
+            for (uint32_t j = 0; j < ch; ++j) {
+                const uint32_t P = pmin + (uint32_t)l * ch + j;
+                if (P < (1u << ROOT)) { const uint32_t sb = sub_bits(P); if (sb) s += 1u << sb; }
+            }
+            size[l] = s;
+        });
+        uint32_t sub_total = 0;
+        const U ex = W::excl_scan(size, &sub_total);
+        if (sub_total > (uint32_t)SUBCAP) return PD_W_HOST;
+        W::each([&](int l) {
+            uint32_t run = (1u << ROOT) + ex[l];
+            for (uint32_t j = 0; j < ch; ++j) {
+                const uint32_t P = pmin + (uint32_t)l * ch + j;
+                if (P >= (1u << ROOT)) break;
+                const uint32_t sb = sub_bits(P);
+                if (!sb) continue;
+                tab[bitrev(P, ROOT)] = sb | (KIND_BAD << 4) | 0x40u | (run << 16);
+                run += 1u << sb;
+            }
+        });
+        W::sync();
+        const uint32_t t0 = total - n_long;
+        W::each([&](int l) {
+            for (uint32_t t = t0 + (uint32_t)l; t < total; t += 64) {
+                const uint32_t sym = sorted[t];
+                const uint32_t len = cl[sym];
+                uint32_t code = 0;
+#pragma unroll
+                for (int v = ROOT + 1; v <= 15; ++v) if (len == (uint32_t)v) code = first[v] + (t - offs[v]);
+                const uint32_t lowbits = len - ROOT;
+                const uint32_t e = tab[bitrev(code >> lowbits, ROOT)];
+                const uint32_t off = e >> 16, sb = e & 15;
+                const uint32_t r = bitrev(code & ((1u << lowbits) - 1), (int)lowbits);
+                const uint32_t ent = make_entry<MODE>(sym, len);
+                for (uint32_t k = 0; k < (1u << (sb - lowbits)); ++k) tab[off + r + (k << lowbits)] = ent;
+            }
+        });
+    }
+    W::sync();
+    return 0;
+}
+
+struct Sym { uint32_t kind, val, dist, used; };
+
+// One literal/length symbol (with its distance) at bit position q.  Reads at most 8 bytes from in + q / 8.
+// Straight-line on purpose (the lanes of a wave sit on different symbols): the distance lookup is done for every
+// symbol and ignored unless a length was decoded; only the rare second-level lookups branch.
+PW_FN Sym decode_sym(const Tables &T, const uint8_t *in, uint32_t q)
+{
+    uint64_t w = ld64(in + (q >> 3)) >> (q & 7);                          // >= 57 valid bits; a symbol needs <= 48
+    uint32_t e = T.ll[(uint32_t)w & ((1u << LL_ROOT) - 1)];
+    if (e & 0x40u) e = T.ll[(e >> 16) + (((uint32_t)w >> LL_ROOT) & ((1u << (e & 15)) - 1))];
+    const uint32_t n = e & 15, kind = (e >> 4) & 3;
+    const bool is_len = kind == KIND_LEN;
+    w >>= n;
+    const uint32_t ext = is_len ? (e >> 8) & 0xff : 0u;
+    const uint32_t lenv = (e >> 16) + ((uint32_t)w & ((1u << ext) - 1));
+    w >>= ext;
+    uint32_t f = T.d[(uint32_t)w & ((1u << D_ROOT) - 1)];
+    if (is_len && (f & 0x40u)) f = T.d[(f >> 16) + (((uint32_t)w >> D_ROOT) & ((1u << (f & 15)) - 1))];
+    const uint32_t dn = f & 15, dext = (f >> 8) & 0xff;
+    const uint32_t dist = (f >> 16) + ((uint32_t)(w >> dn) & ((1u << dext) - 1));
+    Sym s;
+    s.kind = is_len && ((f >> 4) & 3) != KIND_LEN ? (uint32_t)KIND_BAD : kind;
+    s.val = is_len ? lenv : (e >> 8) & 0xff;
+    s.dist = is_len ? dist : 0u;
+    s.used = n + (is_len ? ext + dn + dext : 0u);
+    return s;
+}
+
+// Phase 1 state of one lane.  The speculative pass over a subsequence runs from bit p until the first symbol boundary
+// at or after `bound` (or a stop: end of block, invalid code, end of input); nothing is written: e = where it ended,
+// n = bytes it would emit, m = matches among its symbols.
+// Three checkpoints (S/8, S/4, S/2 bits into the subsequence) remember where the previous pass of this lane crossed
+// them: a re-decode from a corrected start that crosses a checkpoint at the SAME bit has merged with the previous
+// pass (from a common symbol boundary on, two passes are identical), so it stops there and keeps the old tail.
+struct SubCount {
+    uint32_t e, n, m, f, ns;                     // results of the last complete pass
+    uint32_t cp0, cp1, cp2, co0, co1, co2, cm0, cm1, cm2;
+    uint32_t q, out, nm, stage, next_t;          // the pass in progress
+};
+
+PW_FN void count_begin(SubCount &c, uint32_t p, uint32_t nominal, uint32_t S)
+{
+    c.q = p; c.out = 0; c.nm = 0; c.stage = 0; c.next_t = nominal + (S >> 3); c.ns = 0;
+}
+
+// one symbol of the pass in progress; returns false when the pass is over
+// (lim = min(bound, in_bits): a pass that stops at lim before reaching its bound ran out of input)
+PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t nominal, uint32_t S, uint32_t bound, uint32_t lim, bool have_prev, SubCount &c)
+{
+    uint32_t flag = 0;
+    const uint32_t q = c.q;
+    bool stop = q >= lim;
+    if (stop && q < bound) flag = F_OVERRUN;
+    if (!stop && q >= c.next_t) {                                         // crossing a checkpoint (3 times per pass)
+        // (every field is read into a value first: selecting between the fields' ADDRESSES would pin the state in memory)
+        const uint32_t st = c.stage, cp0 = c.cp0, cp1 = c.cp1, cp2 = c.cp2, co0 = c.co0, co1 = c.co1, co2 = c.co2, cm0 = c.cm0, cm1 = c.cm1,
+                       cm2 = c.cm2, out = c.out, nm = c.nm;
+        const bool s0 = st == 0, s1 = st == 1;
+        const uint32_t old_p = s0 ? cp0 : s1 ? cp1 : cp2;
+        if (have_prev && old_p == q) {
+            // same tail as before; the counts remembered beyond this point were relative to the old start
+            const uint32_t d_o = out - (s0 ? co0 : s1 ? co1 : co2);
+            const uint32_t d_m = nm - (s0 ? cm0 : s1 ? cm1 : cm2);
+            c.co0 = co0 + (s0 ? d_o : 0u); c.cm0 = cm0 + (s0 ? d_m : 0u);
+            c.co1 = co1 + (s0 || s1 ? d_o : 0u); c.cm1 = cm1 + (s0 || s1 ? d_m : 0u);
+            c.co2 = co2 + d_o; c.cm2 = cm2 + d_m;
+            c.n += d_o; c.m += d_m;
+            return false;                                                 // e, f and the later checkpoints stay
+        }
+        c.cp0 = s0 ? q : cp0; c.co0 = s0 ? out : co0; c.cm0 = s0 ? nm : cm0;
+        c.cp1 = s1 ? q : cp1; c.co1 = s1 ? out : co1; c.cm1 = s1 ? nm : cm1;
+        const bool s2 = !s0 && !s1;
+        c.cp2 = s2 ? q : cp2; c.co2 = s2 ? out : co2; c.cm2 = s2 ? nm : cm2;
+        c.next_t = s0 ? nominal + (S >> 2) : s1 ? nominal + (S >> 1) : 0xFFFFFFFFu;
+        c.stage = st + 1;
+    }
+    if (!stop) {
+        const Sym s = decode_sym(T, in, q);
+        const bool bad = s.kind == KIND_BAD, eob = s.kind == KIND_EOB;
+        c.q = q + (bad ? 0u : s.used);
+        c.ns += bad ? 0u : 1u;
+        c.out += bad ? 0u : s.kind == KIND_LIT ? 1u : s.kind == KIND_LEN ? s.val : 0u;
+        c.nm += !bad && s.kind == KIND_LEN ? 1u : 0u;
+        flag = bad ? (uint32_t)F_INVALID : eob ? (uint32_t)F_EOB : 0u;
+        stop = bad || eob;
+    }
+    if (!stop) return true;
+    // the pass ran to its end: a checkpoint it did not reach must not stay behind for the next comparison
+    const uint32_t st = c.stage;
+    c.cp0 = st <= 0 ? 0xFFFFFFFFu : c.cp0;
+    c.cp1 = st <= 1 ? 0xFFFFFFFFu : c.cp1;
+    c.cp2 = st <= 2 ? 0xFFFFFFFFu : c.cp2;
+    c.e = c.q; c.f = flag; c.n = c.out; c.m = c.nm;
+    return false;
+}
+
+// A match waiting to be copied: out[dst .. dst+len) = out[dst-dist ..] (positions inside the member's output).
+struct Token { uint32_t dst; uint32_t len_dist; };             // len_dist = len | dist << 16
+
+// The compressed data of one deflate block (Huffman tables already in T), starting at bit q_io.  On success the
+// block's end-of-block code has been consumed: q_io is the bit after it, o_io the output position.
+// `tok` = scratch for out_len / 3 + 64 tokens (global memory on the GPU).
+template <class W>
+PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8_t *out, uint32_t out_len, uint32_t &o_io, Tables &T,
+                      Token *tok, Stats *st)
+{
+    typedef typename W::template Var<uint32_t> U;
+    uint32_t base = q_io, o = o_io;
+    const uint32_t max_steps = in_bits / 64 + 2;
+    for (uint32_t step = 0; step < max_steps; ++step) {
+        // subsequence width: the rest of the BGZF payload spread over the wave — a block that fills its BGZF member
+        // (the usual case) is ONE superstep; wide subsequences also re-synchronise inside themselves more often
+        uint32_t S = (in_bits - base + 63) / 64;
+        if (S < 64) S = 64;
+        typename W::template Var<SubCount> c;
+        U p, need, bound;
+        W::each([&](int l) {
+            bound[l] = base + (uint32_t)(l + 1) * S;
+            p[l] = base + (uint32_t)l * S;
+            need[l] = 1;
+            SubCount &x = c[l];
+            x.e = x.n = x.m = x.f = x.ns = 0;
+            x.cp0 = x.cp1 = x.cp2 = 0xFFFFFFFFu;
+            x.co0 = x.co1 = x.co2 = x.cm0 = x.cm1 = x.cm2 = 0;
+            x.q = x.out = x.nm = x.stage = x.next_t = 0;
+        });
+        // ---- phase 1: speculate and synchronise (nothing is written) ----
+        uint32_t kend = 64;
+        for (int round = 0;; ++round) {
+            if (round > 66) return -9;
+            // a wave-uniform loop around one predicated symbol step per lane (lanes run out at different trips)
+            U act;
+            W::each([&](int l) { act[l] = need[l]; if (need[l]) count_begin(c[l], p[l], base + (uint32_t)l * S, S); });
+            uint32_t trips = 0;
+            while (W::ballot_ne(act, 0u)) {
+                if (++trips > 2 * S + 64) return -9;
+                W::each([&](int l) {
+                    if (act[l]) act[l] = count_step(T, in, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l]);
+                });
+            }
+            if (st) { st->sync_rounds++; st->wave_iters_sync += trips;
+                      W::each([&](int l) { if (need[l]) { st->sym_decoded += c[l].ns; st->lanes_redecoded++; } }); }
+            U e, f;
+            W::each([&](int l) { e[l] = c[l].e; f[l] = c[l].f; });
+            const U pe = W::shift_up1(e, base);
+            W::each([&](int l) { const uint32_t np = l == 0 ? base : pe[l]; need[l] = np != p[l]; p[l] = np; });
+            const uint64_t nm = W::ballot_ne(need, 0u);
+            const int settled = nm ? __builtin_ctzll(nm) : 64;            // lanes [0, settled) started at their true position
+            const uint64_t sm = W::ballot_ne(f, 0u) & (settled >= 64 ? ~0ull : ((1ull << settled) - 1));
+            if (sm) { kend = (uint32_t)__builtin_ctzll(sm); break; }      // the block (or the valid data) ends in lane kend
+            if (!nm) break;
+        }
+        const uint32_t n_valid = kend < 64 ? kend + 1 : 64;
+        U e, n, m;
+        W::each([&](int l) { e[l] = c[l].e; n[l] = (uint32_t)l < n_valid ? c[l].n : 0u; m[l] = (uint32_t)l < n_valid ? c[l].m : 0u; });
+        if (kend < 64) {
+            U f;
+            W::each([&](int l) { f[l] = c[l].f; });
+            const uint32_t fk = W::bcast(f, (int)kend);
+            if (fk & F_INVALID) return -4;
+            if (fk & F_OVERRUN) return -7;
+        }
+        uint32_t total = 0, n_tok = 0;
+        const U ex = W::excl_scan(n, &total);
+        const U exm = W::excl_scan(m, &n_tok);
+        if (total > out_len - o) return -5;
+        if (n_tok > out_len / 3 + 1) return -5;                          // (cannot happen: a match emits >= 3 bytes)
+        if (st) st->steps++;
+        // ---- phase 2: every lane writes its literals and lists its matches, in output order (no lane waits) ----
+        U err, q2, w2, t2, act2;
+        W::each([&](int l) { err[l] = 0; q2[l] = p[l]; w2[l] = o + ex[l]; t2[l] = exm[l]; act2[l] = (uint32_t)l < n_valid; });
+        {
+            uint32_t trips = 0;
+            while (W::ballot_ne(act2, 0u)) {
+                if (++trips > 2 * S + 64) return -9;
+                W::each([&](int l) {
+                    if (!act2[l]) return;
+                    if (q2[l] >= bound[l]) { act2[l] = 0; return; }
+                    const Sym s = decode_sym(T, in, q2[l]);
+                    const uint32_t wl = w2[l];
+                    if (st) st->sym_true++;
+                    if (s.kind == KIND_LIT) { out[wl] = (uint8_t)s.val; w2[l] = wl + 1; }
+                    else if (s.kind == KIND_LEN) {
+                        if (s.dist > wl) { err[l] = 6; act2[l] = 0; return; }
+                        tok[t2[l]].dst = wl; tok[t2[l]].len_dist = s.val | (s.dist << 16); t2[l] += 1;
+                        w2[l] = wl + s.val;
+                    } else { act2[l] = 0; return; }                       // end of block
+                    q2[l] += s.used;
+                });
+            }
+            if (st) { st->wave_iters_emit += trips; st->matches += n_tok; }
+        }
+        if (W::ballot_ne(err, 0u)) return -6;
+        W::fence();
+        // ---- phase 3: the matches, 64 CONSECUTIVE ones at a time, one per lane.  Neighbouring matches rarely depend
+        // on each other (they copy from about a record back), so a batch takes one or two rounds: a lane copies once the
+        // earlier matches of the batch that overlap its source are done (the exact set, as a lane mask); everything before
+        // the batch — literals of phase 2, earlier batches — is final.  The lowest unfinished lane is always ready.
+        for (uint32_t b0 = 0; b0 < n_tok; b0 += 64) {
+            U dst, len, dist, dep_lo, dep_hi, valid;
+            W::each([&](int l) {
+                const uint32_t i = b0 + (uint32_t)l;
+                valid[l] = i < n_tok;
+                dst[l] = len[l] = dist[l] = 0;
+                if (valid[l]) { const Token k = tok[i]; dst[l] = k.dst; len[l] = k.len_dist & 0xffff; dist[l] = k.len_dist >> 16; }
+                T.bdst()[l] = valid[l] ? dst[l] : 0xFFFFFFFFu;
+                T.bend()[l] = valid[l] ? dst[l] + len[l] : 0xFFFFFFFFu;
+            });
+            W::sync();
+            const uint32_t d0 = W::bcast(dst, 0);
+            W::each([&](int l) {
+                dep_lo[l] = 1; dep_hi[l] = 0;                              // empty
+                if (!valid[l] || l == 0) return;
+                const uint32_t src = dst[l] - dist[l];
+                const uint32_t send = src + (len[l] < dist[l] ? len[l] : dist[l]);
+                if (send <= d0) return;                                   // the source ends before the batch's first match
+                int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
+                const int i_lo = lo;
+                lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
+                dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
+            });
+            uint64_t done = W::ballot_eq(valid, 0u);
+            for (int round = 0; done != ~0ull; ++round) {
+                if (round > 64) return -9;
+                U ready;
+                W::each([&](int l) {
+                    ready[l] = 0;
+                    if ((done >> l) & 1) return;
+                    uint64_t dm = 0;
+                    if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
+                    if (dm & ~done) return;
+                    ready[l] = 1;
+                    const uint32_t d = dist[l], n_ = len[l], wl = dst[l], src = wl - d;
+                    uint32_t i = 0;
+                    if (d >= 8) for (; i + 8 <= n_; i += 8) st64(out + wl + i, ld64(out + src + i));
+                    for (; i < n_; ++i) out[wl + i] = out[src + i];
+                    if (st) st->copy_iters += n_ / 8 + (n_ & 7);
+                });
+                W::fence();
+                done |= W::ballot_ne(ready, 0u);
+                if (st) st->emit_rounds++;
+            }
+            if (st) st->batches++;
+            W::sync();
+        }
+        o += total;
+        if (kend < 64) { q_io = W::bcast(e, (int)kend); o_io = o; return 0; }
+        base = W::bcast(e, 63);
+    }
+    return -9;
+}
+
+// One whole BGZF member payload (raw DEFLATE) of exactly out_len bytes.  Returns 0, PD_W_HOST or a negative error.
+// `in` must be readable for 8 bytes past in_len (a BGZF payload is followed by its 8-byte trailer).
+template <class W>
+PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st)
+{
+    static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    if (in_len > (1u << 17) || out_len > (1u << 16)) return PD_W_HOST;        // not a BGZF member: 16-bit token fields
+    const uint32_t in_bits = in_len * 8;
+    uint32_t q = 0, o = 0;
+    if (st) st->blocks++;
+    for (int guard = 0; guard < 70000; ++guard) {
+        if (q + 3 > in_bits) return -7;
+        const uint32_t hdr = peek_bits(in, q) & 7; q += 3;
+        const uint32_t last = hdr & 1, type = hdr >> 1;
+        if (st) st->dblocks++;
+        if (type == 0) {                                                  // stored: the wave copies the bytes
+            q = (q + 7) & ~7u;
+            if (q + 32 > in_bits) return -7;
+            const uint32_t w = peek_bits(in, q); q += 32;
+            const uint32_t len = w & 0xffff, nlen = w >> 16;
+            if ((len ^ 0xffff) != nlen) return -2;
+            if (len > out_len - o) return -5;
+            if ((uint64_t)q + (uint64_t)len * 8 > in_bits) return -7;
+            const uint8_t *src = in + (q >> 3);
+            uint8_t *dst = out + o;
+            W::each([&](int l) { for (uint32_t i = l; i < len; i += 64) dst[i] = src[i]; });
+            W::sync();
+            q += len * 8; o += len;
+        } else if (type == 3) return -1;
+        else {
+            uint32_t nlen = 288, ndist = 32;
+            if (type == 1) {
+                W::each([&](int l) {
+                    for (int s = l; s < 320; s += 64) T.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                });
+                W::sync();
+            } else {
+                if (q + 14 > in_bits) return -7;
+                const uint32_t h = peek_bits(in, q); q += 14;
+                nlen = (h & 31) + 257; ndist = ((h >> 5) & 31) + 1;
+                const uint32_t ncode = ((h >> 10) & 15) + 4;
+                if (nlen > 286 || ndist > 30) return -3;
+                if (q + ncode * 3 > in_bits) return -7;
+                W::each([&](int l) { if (l < 19) T.cl[l] = 0; });
+                W::sync();
+                {
+                    const uint64_t w64 = ld64(in + (q >> 3)) >> (q & 7);   // 19 x 3 = 57 bits
+                    W::each([&](int l) { if ((uint32_t)l < ncode) T.cl[CLORD[l]] = (uint8_t)((w64 >> (3 * l)) & 7); });
+                    q += ncode * 3;
+                }
+                W::sync();
+                int rc = build_table<W, 7, 0, 2>(T.d, T.cl, 19, T.sorted, T.rank());       // borrows the distance table's space
+                if (rc) return rc < 0 ? -3 : rc;
+                // the code lengths themselves: a short serial stream (every lane runs it, lane 0 stores)
+                uint32_t idx = 0, prev = 0;
+                const uint32_t want = nlen + ndist;
+                while (idx < want) {
+                    if (q >= in_bits) return -7;
+                    uint32_t w = peek_bits(in, q);
+                    const uint32_t e = T.d[w & 127];
+                    const uint32_t n = e & 15;
+                    if (!n || ((e >> 4) & 3) != KIND_LIT) return -4;
+                    const uint32_t sym = (e >> 8) & 0xff;
+                    w >>= n; q += n;
+                    if (st) st->hdr_syms++;
+                    uint32_t rep = 1, val = sym;
+                    if (sym == 16) { if (idx == 0) return -3; val = prev; rep = 3 + (w & 3); q += 2; }
+                    else if (sym == 17) { val = 0; rep = 3 + (w & 7); q += 3; }
+                    else if (sym == 18) { val = 0; rep = 11 + (w & 127); q += 7; }
+                    if (idx + rep > want) return -3;
+                    W::each([&](int l) { if ((uint32_t)l < rep) T.cl[idx + (uint32_t)l] = (uint8_t)val; });   // rep <= 138: up to 3 stores per lane
+                    if (rep > 64) W::each([&](int l) { for (uint32_t k = 64 + (uint32_t)l; k < rep; k += 64) T.cl[idx + k] = (uint8_t)val; });
+                    idx += rep; prev = val;
+                }
+                if (q > in_bits) return -7;
+                W::sync();
+                if (W::uniform_u8(&T.cl[256]) == 0) return -3;             // no end-of-block code
+            }
+            int rc = build_table<W, LL_ROOT, LL_SUBCAP, 0>(T.ll, T.cl, (int)nlen, T.sorted, T.rank());
+            if (rc) return rc;
+            rc = build_table<W, D_ROOT, D_SUBCAP, 1>(T.d, T.cl + nlen, (int)ndist, T.sorted, T.rank());
+            if (rc) return rc;
+            rc = decode_body<W>(in, in_bits, q, out, out_len, o, T, tok, st);
+            if (rc) return rc;
+        }
+        if (last) break;
+    }
+    return o == out_len ? 0 : -5;
+}
+
+// ---- the two wave implementations -------------------------------------------------------------------------------
+struct HostWave {                         // 64 emulated lanes
+    template <class T> struct Var { T v[64]; T &operator[](int l) { return v[l]; } const T &operator[](int l) const { return v[l]; } };
+    template <class F> static void each(F f) { for (int l = 0; l < 64; ++l) f(l); }
+    static void sync() {}
+    static void fence() {}
+    static uint64_t ballot_eq(const Var<uint32_t> &x, uint32_t v) { uint64_t m = 0; for (int l = 0; l < 64; ++l) if (x.v[l] == v) m |= 1ull << l; return m; }
+    static uint64_t ballot_ne(const Var<uint32_t> &x, uint32_t v) { uint64_t m = 0; for (int l = 0; l < 64; ++l) if (x.v[l] != v) m |= 1ull << l; return m; }
+    static uint32_t prefix_count(uint64_t m, int l) { return (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1)); }
+    static Var<uint32_t> excl_scan(const Var<uint32_t> &x, uint32_t *total) { Var<uint32_t> r; uint32_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; a += x.v[l]; } *total = a; return r; }
+    static Var<uint32_t> shift_up1(const Var<uint32_t> &x, uint32_t fill) { Var<uint32_t> r; r.v[0] = fill; for (int l = 1; l < 64; ++l) r.v[l] = x.v[l - 1]; return r; }
+    static uint32_t bcast(const Var<uint32_t> &x, int lane) { return x.v[lane]; }
+    static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
+    static uint32_t uniform_u8(const uint8_t *p) { return *p; }
+};
+
+#if defined(__HIPCC__)
+struct DevWave {                          // the hardware wavefront (one wave per workgroup)
+    template <class T> struct Var { T v; __device__ T &operator[](int) { return v; } __device__ const T &operator[](int) const { return v; } };
+    template <class F> __device__ static __forceinline__ void each(F f) { f((int)(threadIdx.x & 63)); }
+    __device__ static __forceinline__ void sync() { __syncthreads(); }
+    __device__ static __forceinline__ void fence() { asm volatile("" ::: "memory"); }   // compiler-only: the wave issues in order
+    __device__ static __forceinline__ uint64_t ballot_eq(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v == v); }
+    __device__ static __forceinline__ uint64_t ballot_ne(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v != v); }
+    __device__ static __forceinline__ uint32_t prefix_count(uint64_t m, int) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+    __device__ static __forceinline__ Var<uint32_t> excl_scan(const Var<uint32_t> &x, uint32_t *total)
+    {
+        int s = (int)x.v;
+        s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);
+        s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);
+        s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);
+        s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);
+        s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);
+        s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);
+        *total = (uint32_t)__builtin_amdgcn_readlane(s, 63);
+        Var<uint32_t> r; r.v = (uint32_t)s - x.v; return r;
+    }
+    __device__ static __forceinline__ Var<uint32_t> shift_up1(const Var<uint32_t> &x, uint32_t fill)
+    {
+        Var<uint32_t> r; const uint32_t y = (uint32_t)__shfl_up((int)x.v, 1); r.v = (threadIdx.x & 63) ? y : fill; return r;
+    }
+    __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
+    __device__ static __forceinline__ uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip)
+    {
+        uint32_t m = skip.v ? 0xFFFFFFFFu : x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y < m ? y : m; }
+        return m;
+    }
+    __device__ static __forceinline__ uint32_t uniform_u8(const uint8_t *p) { return *p; }
+};
+#endif
+
+} // namespace pdw
+#endif

@@ -102,6 +102,9 @@ void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces,
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                          int *status, void *scratch);
 size_t bgzf_scratch_bytes(uint32_t n_blk);
+void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
+                              int *status, void *scratch, unsigned n_wg);
+size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 void launch_bam_walk(hipStream_t st, const uint8_t *buf, void *units, uint32_t n_units, uint64_t *rec_off, uint64_t rec_cap,
                      const int *blk_status, const uint32_t *unit_first_blk, const uint32_t *unit_n_blk, uint64_t *dense_base);
 void launch_bam_parse(hipStream_t st, const uint8_t *buf, const void *units, uint32_t n_units, const uint64_t *dense_base,

@@ -37,6 +37,17 @@ def test_decoder_equals_zlib_on_host(generated):
     assert b" 0 mismatches" in p.stdout
 
 
+def test_wave_decoder_equals_zlib_on_host(generated):
+    """pd_inflate_wave.h (one wave per BGZF member: speculative parallel Huffman decode, token list, batched match
+    copies) with its 64 lanes emulated on the host: every block type / strategy / level on generated streams, every
+    block of the fixture and payload BAMs, and mutated streams (an error or zlib's bytes, never past the output)."""
+    exe = os.path.join(HERE, "harness", "inflate_wave_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(HERE, "harness", "inflate_wave_check.cpp"), "-lz", "-o", exe], check=True)
+    p = subprocess.run([exe, "-g", "-f", "2"] + FIX + generated, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, (p.stdout.decode()[-400:], p.stderr.decode()[-400:])
+    assert b" 0 failures" in p.stdout and b" 0 mismatches" in p.stdout
+
+
 @pytest.mark.gpu
 def test_decoder_equals_zlib_on_gpu(generated):
     import gzip
@@ -44,6 +55,6 @@ def test_decoder_equals_zlib_on_gpu(generated):
     for path in FIX + generated:
         data = open(path, "rb").read()
         ref = gzip.decompress(data)
-        for variant in (0, 1):
+        for variant in (0, 1, 2):            # 2 = the wave-cooperative decoder (pd_inflate_wave.h)
             out, ms, nb, n = capi.bgzf_inflate(data, variant=variant, reps=1)
             assert n == len(ref) and out == ref, (path, variant)

@@ -21,7 +21,12 @@ bam = os.path.join(td, "p.bam")
 synth.write_bam(bam, names, lens, rec, procs=16, payload=True, level=int(os.environ.get("BGZF_LEVEL", "6")))
 data = open(bam, "rb").read()
 print("records %d, BGZF %.1f MB" % (R, len(data) / 1e6), flush=True)
-for variant, name in ((0, "fast tables in LDS (4 waves/CU)"), (1, "all tables in global memory")):
+VARIANTS = [(1, "lane per block, tables in global memory")] + [
+    (2 + (w << 4), "wave per block, %d waves/CU" % w) for w in (8, 12, 14, 16)]
+if os.environ.get("BGZF_VARIANTS"):
+    keep = set(int(x) for x in os.environ["BGZF_VARIANTS"].split(","))
+    VARIANTS = [v for v in VARIANTS if v[0] in keep]
+for variant, name in VARIANTS:
     t0 = time.perf_counter()
     out, ms, nb, n = capi.bgzf_inflate(data, variant=variant, reps=3, want_output=True)
     wall = time.perf_counter() - t0
@@ -34,5 +39,5 @@ for variant, name in ((0, "fast tables in LDS (4 waves/CU)"), (1, "all tables in
         if out[uo:uo + len(raw)] != raw:
             bad += 1
         uo += len(raw); o += bs
-    print("%-28s %d blocks, %.1f MB out: kernel %.2f ms = %.1f GB/s out (%.1f GB/s in), verified-bad %d, call wall %.2f s" % (
+    print("%-40s %d blocks, %.1f MB out: kernel %.2f ms = %.1f GB/s out (%.1f GB/s in), verified-bad %d, call wall %.2f s" % (
         name, nb, n / 1e6, ms, n / ms / 1e6, len(data) / ms / 1e6, bad, wall), flush=True)
