@@ -35,24 +35,20 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
     status[i] = d.out_len ? pdi::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tf, scratch[i].slow) : 0;
 }
 
-// One WAVE per BGZF member (pd_inflate_wave.h): persistent one-wave workgroups take members from an atomic counter;
-// Huffman tables in LDS (10.7 KiB per wave), match tokens in a per-workgroup slice of global scratch.
+// One WAVE per BGZF member (pd_inflate_wave.h): persistent one-wave workgroups walk the members with a grid stride
+// (members of a BAM are alike, so a static split balances); Huffman tables in LDS (9 KiB per wave), match tokens in a
+// per-workgroup slice of global scratch.
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
-                                                     pdw::Token *tok_scratch, uint32_t *next)
+                                                     pdw::Token *tok_scratch)
 {
     __shared__ pdw::Tables T;
-    __shared__ uint32_t s_i;
     pdw::Token *tok = tok_scratch + (size_t)blockIdx.x * PD_WAVE_TOKENS;
-    for (;;) {
-        if (threadIdx.x == 0) s_i = atomicAdd(next, 1u);
-        __syncthreads();
-        const uint32_t i = s_i;
-        __syncthreads();
-        if (i >= n_blk) return;
+    for (uint32_t i = blockIdx.x; i < n_blk; i += gridDim.x) {
         const BlkDesc d = blk[i];
         int rc = 0;
         if (d.out_len) rc = pdw::inflate_block<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
         if (threadIdx.x == 0) status[i] = rc;
+        __syncthreads();
     }
 }
 
@@ -140,12 +136,9 @@ void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf
 {
     if (!n_blk) return;
     if (n_wg > n_blk) n_wg = n_blk;
-    uint32_t *counter = (uint32_t *)scratch;
-    (void)hipMemsetAsync(counter, 0, 64, st);
-    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status,
-                       (pdw::Token *)((uint8_t *)scratch + 64), counter);
+    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch);
 }
-size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return 64 + (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token); }
+size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token) + 64; }
 
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                          int *status, void *scratch)

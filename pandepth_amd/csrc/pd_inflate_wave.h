@@ -38,6 +38,13 @@
 #define PW_FN inline
 #endif
 
+#ifndef PW_MARK
+#define PW_MARK(code, val) do { } while (0)     /* development hooks (tools/ubench/wave_debug.hip): progress marks, */
+#endif
+#ifndef PW_TICK
+#define PW_TICK(phase) do { } while (0)         /* cycles since the previous tick are charged to `phase` */
+#endif
+
 namespace pdw {
 
 enum { LL_ROOT = 10, LL_SUBCAP = 320, D_ROOT = 8, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
@@ -232,12 +239,33 @@ PW_FN int build_table(uint32_t *tab, const uint8_t *cl, int n, uint16_t *sorted,
 
 struct Sym { uint32_t kind, val, dist, used; };
 
-// One literal/length symbol (with its distance) at bit position q.  Reads at most 8 bytes from in + q / 8.
+// A lane's view of the compressed bits: 16 bytes (cur | nxt) starting at byte `base` of the stream plus the next 8
+// (`ahead`), loaded one step before they are needed — the load is issued when the window moves on, and the window
+// moves on only every 64 bits (several symbols), so no symbol waits for memory.  Reads stay below in + lim.
+struct BitWin { uint64_t cur, nxt, ahead; uint32_t base; };
+
+PW_FN uint64_t win_load(const uint8_t *in, uint32_t at, uint32_t lim) { return at + 8 <= lim ? ld64(in + at) : 0ull; }
+PW_FN void win_init(BitWin &b, const uint8_t *in, uint32_t q, uint32_t lim)
+{
+    b.base = q >> 3;
+    b.cur = win_load(in, b.base, lim); b.nxt = win_load(in, b.base + 8, lim); b.ahead = win_load(in, b.base + 16, lim);
+}
+// 64 bits starting at bit q (q >= 8 * base; at most 64 bits beyond the window start after the caller's last step)
+PW_FN uint64_t win_bits(BitWin &b, const uint8_t *in, uint32_t q, uint32_t lim)
+{
+    uint32_t off = q - 8 * b.base;
+    if (off >= 64) {                                                      // moved past `cur` (a symbol is <= 48 bits: at most once)
+        b.cur = b.nxt; b.nxt = b.ahead; b.base += 8; off -= 64;
+        b.ahead = win_load(in, b.base + 16, lim);
+    }
+    return off ? (b.cur >> off) | (b.nxt << (64 - off)) : b.cur;
+}
+
+// One literal/length symbol (with its distance) from the 64 bits `w` that start at its first bit (<= 48 are used).
 // Straight-line on purpose (the lanes of a wave sit on different symbols): the distance lookup is done for every
 // symbol and ignored unless a length was decoded; only the rare second-level lookups branch.
-PW_FN Sym decode_sym(const Tables &T, const uint8_t *in, uint32_t q)
+PW_FN Sym decode_sym(const Tables &T, uint64_t w)
 {
-    uint64_t w = ld64(in + (q >> 3)) >> (q & 7);                          // >= 57 valid bits; a symbol needs <= 48
     uint32_t e = T.ll[(uint32_t)w & ((1u << LL_ROOT) - 1)];
     if (e & 0x40u) e = T.ll[(e >> 16) + (((uint32_t)w >> LL_ROOT) & ((1u << (e & 15)) - 1))];
     const uint32_t n = e & 15, kind = (e >> 4) & 3;
@@ -268,16 +296,19 @@ struct SubCount {
     uint32_t e, n, m, f, ns;                     // results of the last complete pass
     uint32_t cp0, cp1, cp2, co0, co1, co2, cm0, cm1, cm2;
     uint32_t q, out, nm, stage, next_t;          // the pass in progress
+    BitWin win;
 };
 
-PW_FN void count_begin(SubCount &c, uint32_t p, uint32_t nominal, uint32_t S)
+PW_FN void count_begin(SubCount &c, const uint8_t *in, uint32_t in_lim, uint32_t p, uint32_t nominal, uint32_t S)
 {
     c.q = p; c.out = 0; c.nm = 0; c.stage = 0; c.next_t = nominal + (S >> 3); c.ns = 0;
+    win_init(c.win, in, p, in_lim);
 }
 
 // one symbol of the pass in progress; returns false when the pass is over
 // (lim = min(bound, in_bits): a pass that stops at lim before reaching its bound ran out of input)
-PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t nominal, uint32_t S, uint32_t bound, uint32_t lim, bool have_prev, SubCount &c)
+PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint32_t nominal, uint32_t S, uint32_t bound, uint32_t lim, bool have_prev,
+                      SubCount &c)
 {
     uint32_t flag = 0;
     const uint32_t q = c.q;
@@ -307,7 +338,7 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t nominal, uint
         c.stage = st + 1;
     }
     if (!stop) {
-        const Sym s = decode_sym(T, in, q);
+        const Sym s = decode_sym(T, win_bits(c.win, in, q, in_lim));
         const bool bad = s.kind == KIND_BAD, eob = s.kind == KIND_EOB;
         c.q = q + (bad ? 0u : s.used);
         c.ns += bad ? 0u : 1u;
@@ -326,6 +357,79 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t nominal, uint
     return false;
 }
 
+PW_FN uint32_t ld32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+PW_FN void st32(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+PW_FN void st16(uint8_t *p, uint32_t w) { const uint16_t h = (uint16_t)w; __builtin_memcpy(p, &h, 2); }
+
+// exactly n (1..8) low bytes of v, as at most two (overlapping) stores
+PW_FN void store_bytes(uint8_t *p, uint64_t v, uint32_t n)
+{
+    if (n >= 8) st64(p, v);
+    else if (n >= 4) { st32(p, (uint32_t)v); st32(p + n - 4, (uint32_t)(v >> (8 * (n - 4)))); }
+    else if (n >= 2) { st16(p, (uint32_t)v); st16(p + n - 2, (uint32_t)(v >> (8 * (n - 2)))); }
+    else p[0] = (uint8_t)v;
+}
+
+// out[dst .. dst+len) = the LZ77 copy from `dist` back.  Every source byte below dst exists already.  Written so that a
+// match costs ONE memory round trip, not one per chunk: loads of a group are issued before its stores (the hardware
+// keeps a wave's accesses in order, the dependency is only through registers), a tail is an overlapping 8-byte store
+// that ends exactly at dst+len, short periods (dist < 8) are expanded in registers, and a long overlapping match
+// (8 <= dist < len) proceeds in generations of `dist` bytes.  May READ up to 7 bytes past its source (never stores
+// them): the output buffer is padded by 8 bytes.
+PW_FN void copy_match(uint8_t *out, uint32_t dst, uint32_t dist, uint32_t len)
+{
+    uint8_t *d = out + dst;
+    const uint8_t *s = d - dist;
+    if (dist < 8) {
+        // period < 8: the first 8 bytes of the periodic sequence, then each next chunk's phase moves on by 8 mod dist
+        const uint64_t raw = ld64(s);
+        uint64_t pat = 0;
+        uint32_t ph = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pat |= ((raw >> (8 * ph)) & 0xff) << (8 * k); ph = ph + 1 == dist ? 0 : ph + 1; }
+        // pat = bytes 0..7 of the sequence; byte j of the sequence = raw byte (j mod dist); rotate by (8 mod dist) per chunk
+        const uint32_t step = 8 % dist;                                   // dist 1,2,4: 0 (the same chunk again and again)
+        uint32_t i = 0, phase = 0;                                        // phase = (8 * chunk) mod dist
+        for (; i < len; i += 8) {
+            uint64_t v = pat;
+            if (phase) {                                                  // sequence bytes phase .. phase+7
+                v = 0; uint32_t q = phase;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v |= ((raw >> (8 * q)) & 0xff) << (8 * k); q = q + 1 == dist ? 0 : q + 1; }
+            }
+            store_bytes(d + i, v, len - i);
+            phase += step; if (phase >= dist) phase -= dist;
+        }
+        return;
+    }
+    // generations: [0, g) reads only bytes that existed before this match; each next generation reads the previous one
+    uint32_t done = 0;
+    while (done < len) {
+        const uint32_t g = len - done < dist ? len - done : dist;         // bytes of this generation (>= 1)
+        const uint8_t *sg = s + done;
+        uint8_t *dg = d + done;
+        if (g < 8) {                                                      // (only as the tail of an overlapping match or len < 8)
+            store_bytes(dg, ld64(sg), g);
+        } else {
+            uint32_t i = 0;
+            for (; i + 32 <= g; i += 32) {                                // four loads in flight, then four stores
+                const uint64_t a = ld64(sg + i), b = ld64(sg + i + 8), c = ld64(sg + i + 16), e = ld64(sg + i + 24);
+                st64(dg + i, a); st64(dg + i + 8, b); st64(dg + i + 16, c); st64(dg + i + 24, e);
+            }
+            const uint32_t r = g - i;                                     // 0..31 left: up to three chunks + an overlapping last one
+            if (r) {
+                const uint64_t a = ld64(sg + i), b = r > 8 ? ld64(sg + i + 8) : 0, c = r > 16 ? ld64(sg + i + 16) : 0;
+                const uint64_t t = ld64(sg + g - 8);                      // the last 8 bytes of the generation (g >= 8)
+                if (r >= 8) st64(dg + i, a);
+                if (r >= 16) st64(dg + i + 8, b);
+                if (r >= 24) st64(dg + i + 16, c);
+                st64(dg + g - 8, t);
+            }
+        }
+        done += g;
+    }
+}
+
 // A match waiting to be copied: out[dst .. dst+len) = out[dst-dist ..] (positions inside the member's output).
 struct Token { uint32_t dst; uint32_t len_dist; };             // len_dist = len | dist << 16
 
@@ -339,6 +443,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
     typedef typename W::template Var<uint32_t> U;
     uint32_t base = q_io, o = o_io;
     const uint32_t max_steps = in_bits / 64 + 2;
+    const uint32_t in_lim = in_bits / 8 + 8;                              // readable bytes: the payload and its 8-byte trailer
     for (uint32_t step = 0; step < max_steps; ++step) {
         // subsequence width: the rest of the BGZF payload spread over the wave — a block that fills its BGZF member
         // (the usual case) is ONE superstep; wide subsequences also re-synchronise inside themselves more often
@@ -360,14 +465,15 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         uint32_t kend = 64;
         for (int round = 0;; ++round) {
             if (round > 66) return -9;
+            PW_MARK(30, (uint32_t)round);
             // a wave-uniform loop around one predicated symbol step per lane (lanes run out at different trips)
             U act;
-            W::each([&](int l) { act[l] = need[l]; if (need[l]) count_begin(c[l], p[l], base + (uint32_t)l * S, S); });
+            W::each([&](int l) { act[l] = need[l]; if (need[l]) count_begin(c[l], in, in_lim, p[l], base + (uint32_t)l * S, S); });
             uint32_t trips = 0;
             while (W::ballot_ne(act, 0u)) {
                 if (++trips > 2 * S + 64) return -9;
                 W::each([&](int l) {
-                    if (act[l]) act[l] = count_step(T, in, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l]);
+                    if (act[l]) act[l] = count_step(T, in, in_lim, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l]);
                 });
             }
             if (st) { st->sync_rounds++; st->wave_iters_sync += trips;
@@ -398,9 +504,15 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         if (total > out_len - o) return -5;
         if (n_tok > out_len / 3 + 1) return -5;                          // (cannot happen: a match emits >= 3 bytes)
         if (st) st->steps++;
+        PW_MARK(40, total);
+        PW_TICK(2);
         // ---- phase 2: every lane writes its literals and lists its matches, in output order (no lane waits) ----
         U err, q2, w2, t2, act2;
-        W::each([&](int l) { err[l] = 0; q2[l] = p[l]; w2[l] = o + ex[l]; t2[l] = exm[l]; act2[l] = (uint32_t)l < n_valid; });
+        typename W::template Var<BitWin> bw;
+        W::each([&](int l) {
+            err[l] = 0; q2[l] = p[l]; w2[l] = o + ex[l]; t2[l] = exm[l]; act2[l] = (uint32_t)l < n_valid;
+            if (act2[l]) win_init(bw[l], in, p[l], in_lim); else { bw[l].cur = bw[l].nxt = bw[l].ahead = 0; bw[l].base = 0; }
+        });
         {
             uint32_t trips = 0;
             while (W::ballot_ne(act2, 0u)) {
@@ -408,7 +520,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 W::each([&](int l) {
                     if (!act2[l]) return;
                     if (q2[l] >= bound[l]) { act2[l] = 0; return; }
-                    const Sym s = decode_sym(T, in, q2[l]);
+                    const Sym s = decode_sym(T, win_bits(bw[l], in, q2[l], in_lim));
                     const uint32_t wl = w2[l];
                     if (st) st->sym_true++;
                     if (s.kind == KIND_LIT) { out[wl] = (uint8_t)s.val; w2[l] = wl + 1; }
@@ -424,17 +536,21 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         }
         if (W::ballot_ne(err, 0u)) return -6;
         W::fence();
+        PW_TICK(3);
         // ---- phase 3: the matches, 64 CONSECUTIVE ones at a time, one per lane.  Neighbouring matches rarely depend
         // on each other (they copy from about a record back), so a batch takes one or two rounds: a lane copies once the
         // earlier matches of the batch that overlap its source are done (the exact set, as a lane mask); everything before
         // the batch — literals of phase 2, earlier batches — is final.  The lowest unfinished lane is always ready.
+        U nx_dst, nx_ld;                                                  // the next batch's tokens are fetched a batch ahead
+        W::each([&](int l) { nx_dst[l] = nx_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
         for (uint32_t b0 = 0; b0 < n_tok; b0 += 64) {
+            PW_MARK(50, b0);
             U dst, len, dist, dep_lo, dep_hi, valid;
             W::each([&](int l) {
                 const uint32_t i = b0 + (uint32_t)l;
                 valid[l] = i < n_tok;
-                dst[l] = len[l] = dist[l] = 0;
-                if (valid[l]) { const Token k = tok[i]; dst[l] = k.dst; len[l] = k.len_dist & 0xffff; dist[l] = k.len_dist >> 16; }
+                dst[l] = valid[l] ? nx_dst[l] : 0u; len[l] = valid[l] ? nx_ld[l] & 0xffff : 0u; dist[l] = valid[l] ? nx_ld[l] >> 16 : 0u;
+                if (i + 64 < n_tok) { const Token k = tok[i + 64]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; }
                 T.bdst()[l] = valid[l] ? dst[l] : 0xFFFFFFFFu;
                 T.bend()[l] = valid[l] ? dst[l] + len[l] : 0xFFFFFFFFu;
             });
@@ -464,11 +580,8 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
                     if (dm & ~done) return;
                     ready[l] = 1;
-                    const uint32_t d = dist[l], n_ = len[l], wl = dst[l], src = wl - d;
-                    uint32_t i = 0;
-                    if (d >= 8) for (; i + 8 <= n_; i += 8) st64(out + wl + i, ld64(out + src + i));
-                    for (; i < n_; ++i) out[wl + i] = out[src + i];
-                    if (st) st->copy_iters += n_ / 8 + (n_ & 7);
+                    copy_match(out, dst[l], dist[l], len[l]);
+                    if (st) st->copy_iters += (len[l] + 31) / 32;
                 });
                 W::fence();
                 done |= W::ballot_ne(ready, 0u);
@@ -477,6 +590,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
             if (st) st->batches++;
             W::sync();
         }
+        PW_TICK(4);
         o += total;
         if (kend < 64) { q_io = W::bcast(e, (int)kend); o_io = o; return 0; }
         base = W::bcast(e, 63);
@@ -498,6 +612,8 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
         if (q + 3 > in_bits) return -7;
         const uint32_t hdr = peek_bits(in, q) & 7; q += 3;
         const uint32_t last = hdr & 1, type = hdr >> 1;
+        PW_MARK(10 + type, q);
+        PW_TICK(5);
         if (st) st->dblocks++;
         if (type == 0) {                                                  // stored: the wave copies the bytes
             q = (q + 7) & ~7u;
@@ -535,14 +651,30 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                     q += ncode * 3;
                 }
                 W::sync();
-                int rc = build_table<W, 7, 0, 2>(T.d, T.cl, 19, T.sorted, T.rank());       // borrows the distance table's space
+                PW_MARK(15, ncode);
+                int rc = build_table<W, 7, 0, 2>(T.d, T.cl, 19, T.sorted, T.rank());
+                PW_MARK(16, (uint32_t)rc);
+                PW_TICK(1);       // borrows the distance table's space
                 if (rc) return rc < 0 ? -3 : rc;
-                // the code lengths themselves: a short serial stream (every lane runs it, lane 0 stores)
+                // the code lengths themselves: a short serial stream (every lane runs it, lane l stores).  Its bytes are
+                // fetched ONCE: lane l holds the 8 bytes at l * 8 of a 512-byte window, and the bit buffer is fed by
+                // readlane (a register access) instead of a dependent memory load per symbol
                 uint32_t idx = 0, prev = 0;
                 const uint32_t want = nlen + ndist;
+                uint32_t wbase = q >> 3;                                   // byte position of the window in `in`
+                typename W::template Var<uint64_t> hw;
+                W::each([&](int l) { const uint32_t at = wbase + 8u * (uint32_t)l; hw[l] = at <= in_len ? ld64(in + at) : 0ull; });
                 while (idx < want) {
                     if (q >= in_bits) return -7;
-                    uint32_t w = peek_bits(in, q);
+                    uint32_t r = q - 8 * wbase;                            // bit offset inside the window
+                    if (r > 62 * 64) {                                     // (a header longer than the window: move it)
+                        wbase = q >> 3;
+                        W::each([&](int l) { const uint32_t at = wbase + 8u * (uint32_t)l; hw[l] = at <= in_len ? ld64(in + at) : 0ull; });
+                        r = q - 8 * wbase;
+                    }
+                    const uint32_t k = r >> 6, sh = r & 63;
+                    const uint64_t a = W::bcast64(hw, (int)k), b = W::bcast64(hw, (int)k + 1);
+                    uint32_t w = (uint32_t)(sh ? (a >> sh) | (b << (64 - sh)) : a);
                     const uint32_t e = T.d[w & 127];
                     const uint32_t n = e & 15;
                     if (!n || ((e >> 4) & 3) != KIND_LIT) return -4;
@@ -554,23 +686,32 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                     else if (sym == 17) { val = 0; rep = 3 + (w & 7); q += 3; }
                     else if (sym == 18) { val = 0; rep = 11 + (w & 127); q += 7; }
                     if (idx + rep > want) return -3;
-                    W::each([&](int l) { if ((uint32_t)l < rep) T.cl[idx + (uint32_t)l] = (uint8_t)val; });   // rep <= 138: up to 3 stores per lane
-                    if (rep > 64) W::each([&](int l) { for (uint32_t k = 64 + (uint32_t)l; k < rep; k += 64) T.cl[idx + k] = (uint8_t)val; });
+                    W::each([&](int l) { for (uint32_t j = (uint32_t)l; j < rep; j += 64) T.cl[idx + j] = (uint8_t)val; });   // rep <= 138
                     idx += rep; prev = val;
                 }
                 if (q > in_bits) return -7;
                 W::sync();
                 if (W::uniform_u8(&T.cl[256]) == 0) return -3;             // no end-of-block code
             }
+            PW_MARK(20, nlen);
+            PW_TICK(0);
             int rc = build_table<W, LL_ROOT, LL_SUBCAP, 0>(T.ll, T.cl, (int)nlen, T.sorted, T.rank());
+            PW_MARK(21, (uint32_t)rc);
             if (rc) return rc;
             rc = build_table<W, D_ROOT, D_SUBCAP, 1>(T.d, T.cl + nlen, (int)ndist, T.sorted, T.rank());
             if (rc) return rc;
+            PW_MARK(22, (uint32_t)rc);
+            PW_TICK(1);
             rc = decode_body<W>(in, in_bits, q, out, out_len, o, T, tok, st);
+            PW_MARK(23, (uint32_t)rc);
             if (rc) return rc;
+            PW_MARK(24, last);
         }
+        PW_MARK(25, last);
         if (last) break;
+        PW_MARK(26, q);
     }
+    PW_MARK(27, o);
     return o == out_len ? 0 : -5;
 }
 
@@ -586,6 +727,7 @@ struct HostWave {                         // 64 emulated lanes
     static Var<uint32_t> excl_scan(const Var<uint32_t> &x, uint32_t *total) { Var<uint32_t> r; uint32_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; a += x.v[l]; } *total = a; return r; }
     static Var<uint32_t> shift_up1(const Var<uint32_t> &x, uint32_t fill) { Var<uint32_t> r; r.v[0] = fill; for (int l = 1; l < 64; ++l) r.v[l] = x.v[l - 1]; return r; }
     static uint32_t bcast(const Var<uint32_t> &x, int lane) { return x.v[lane]; }
+    static uint64_t bcast64(const Var<uint64_t> &x, int lane) { return x.v[lane]; }
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
 };
@@ -616,6 +758,12 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         Var<uint32_t> r; const uint32_t y = (uint32_t)__shfl_up((int)x.v, 1); r.v = (threadIdx.x & 63) ? y : fill; return r;
     }
     __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
+    __device__ static __forceinline__ uint64_t bcast64(const Var<uint64_t> &x, int lane)        // lane must be wave-uniform
+    {
+        const int sl = __builtin_amdgcn_readfirstlane(lane);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x.v, sl), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x.v >> 32), sl);
+        return ((uint64_t)hi << 32) | lo;
+    }
     __device__ static __forceinline__ uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip)
     {
         uint32_t m = skip.v ? 0xFFFFFFFFu : x.v;

@@ -1,0 +1,91 @@
+// tools/ubench/wave_debug.hip — DEVELOPMENT TOOL (not product code): runs pd_inflate_wave.h on the GPU over the
+// members of a BGZF file with host-visible progress marks and a polling watchdog, and compares with zlib.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wave_debug.hip -lz -o tools/ubench/wave_debug
+//   wave_debug file.bam [n_wg] [max_blocks] [seconds]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <vector>
+#define PW_MARK(code, val) do { if (g_dbg && (threadIdx.x & 63) == 0) { g_dbg[blockIdx.x * 8 + 0] = (code); g_dbg[blockIdx.x * 8 + 1] = (val); g_dbg[blockIdx.x * 8 + 2] += 1; } } while (0)
+__device__ volatile unsigned *g_dbg;
+__device__ unsigned long long g_ticks[8];
+__device__ long long g_last[16384];
+#define PW_TICK(phase) do { if ((threadIdx.x & 63) == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_ticks[phase], (unsigned long long)(now_ - g_last[blockIdx.x])); g_last[blockIdx.x] = now_; } } while (0)
+#include "../../pandepth_amd/csrc/pd_inflate_wave.h"
+struct Blk { unsigned long long in_off, out_off; unsigned in_len, out_len; };
+#define NTOK (65536 / 3 + 64)
+__global__ __launch_bounds__(64) void k_dbg(const uint8_t *comp, const Blk *blk, unsigned n_blk, uint8_t *out, int *status, pdw::Token *tok_scratch,
+                                            unsigned *next, volatile unsigned *dbg)
+{
+    __shared__ pdw::Tables T;
+    __shared__ unsigned s_i;
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg = dbg;
+    pdw::Token *tok = tok_scratch + (size_t)blockIdx.x * NTOK;
+    for (unsigned i = blockIdx.x; i < n_blk; i += gridDim.x) {
+        if (threadIdx.x == 0 && dbg) { dbg[blockIdx.x * 8 + 3] = i; dbg[blockIdx.x * 8 + 4] = 1; }
+        const Blk d = blk[i];
+        int rc = 0;
+        if (threadIdx.x == 0) g_last[blockIdx.x] = wall_clock64();
+        if (d.out_len) rc = pdw::inflate_block<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
+        PW_TICK(6);
+        if (threadIdx.x == 0) { status[i] = rc; if (dbg) dbg[blockIdx.x * 8 + 4] = 2; }
+        __syncthreads();
+    }
+}
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    unsigned n_wg = argc > 2 ? atoi(argv[2]) : 1, max_blocks = argc > 3 ? atoi(argv[3]) : 1000000; int secs = argc > 4 ? atoi(argv[4]) : 10;
+    FILE *f = fopen(argv[1], "rb"); if (!f) return 2;
+    std::vector<unsigned char> d; unsigned char buf[1 << 16]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    std::vector<Blk> blks; size_t o = 0; unsigned long long uo = 0;
+    while (o + 18 <= d.size() && blks.size() < max_blocks) {
+        const unsigned char *p = d.data() + o;
+        const unsigned xlen = p[10] | (p[11] << 8), bsize = (p[16] | (p[17] << 8)) + 1;
+        const unsigned isize = p[bsize - 4] | (p[bsize - 3] << 8) | (p[bsize - 2] << 16) | ((unsigned)p[bsize - 1] << 24);
+        blks.push_back(Blk{o + 12 + xlen, uo, bsize - 12 - xlen - 8, isize}); uo += isize; o += bsize;
+    }
+    const unsigned nb = blks.size();
+    if (n_wg > nb) n_wg = nb;
+    uint8_t *d_in, *d_out; Blk *d_blk; int *d_st; pdw::Token *d_tok; unsigned *d_next; unsigned *h_dbg;
+    hipMalloc(&d_in, d.size() + 16); hipMalloc(&d_out, uo + 16); hipMalloc(&d_blk, nb * sizeof(Blk)); hipMalloc(&d_st, nb * 4 + 4);
+    hipMalloc(&d_tok, (size_t)n_wg * NTOK * sizeof(pdw::Token)); hipMalloc(&d_next, 64);
+    hipHostMalloc(&h_dbg, n_wg * 32, hipHostMallocMapped); memset(h_dbg, 0, n_wg * 32);
+    hipMemcpy(d_in, d.data(), d.size(), hipMemcpyHostToDevice); hipMemcpy(d_blk, blks.data(), nb * sizeof(Blk), hipMemcpyHostToDevice);
+    hipMemset(d_next, 0, 64); hipMemset(d_st, 0xff, nb * 4); hipMemset(d_out, 0xEE, uo);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    const bool marks = getenv("MARKS") != nullptr;
+    hipLaunchKernelGGL(k_dbg, dim3(n_wg), dim3(64), 0, 0, d_in, d_blk, nb, d_out, d_st, d_tok, d_next, marks ? (volatile unsigned *)h_dbg : (volatile unsigned *)nullptr);
+    hipEventRecord(e1, 0);
+    bool done = false;
+    for (int t = 0; t < secs * 10; ++t) { if (hipEventQuery(e1) == hipSuccess) { done = true; break; } usleep(100000); }
+    if (!done) {
+        printf("NOT FINISHED after %d s; progress of the first workgroups (mark code, value, count, member, state):\n", secs);
+        for (unsigned w = 0; w < n_wg && w < 16; ++w) printf("  wg %u: mark %u val %u count %u member %u state %u exec after the decoder %08x%08x (flag/rc %u)\n", w, h_dbg[w * 8], h_dbg[w * 8 + 1], h_dbg[w * 8 + 2], h_dbg[w * 8 + 3], h_dbg[w * 8 + 4], h_dbg[w * 8 + 6], h_dbg[w * 8 + 5], h_dbg[w * 8 + 7]);
+        fflush(stdout); _exit(3);
+    }
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<int> st(nb); std::vector<unsigned char> out(uo + 1);
+    hipMemcpy(st.data(), d_st, nb * 4, hipMemcpyDeviceToHost); hipMemcpy(out.data(), d_out, uo, hipMemcpyDeviceToHost);
+    unsigned bad = 0, badst = 0;
+    for (unsigned i = 0; i < nb; ++i) {
+        if (st[i] != 0) { if (badst < 5) printf("member %u status %d\n", i, st[i]); ++badst; continue; }
+        std::vector<unsigned char> ref(blks[i].out_len + 1);
+        z_stream zs; memset(&zs, 0, sizeof zs); inflateInit2(&zs, -15);
+        zs.next_in = d.data() + blks[i].in_off; zs.avail_in = blks[i].in_len; zs.next_out = ref.data(); zs.avail_out = blks[i].out_len;
+        inflate(&zs, Z_FINISH); inflateEnd(&zs);
+        if (memcmp(ref.data(), out.data() + blks[i].out_off, blks[i].out_len)) { if (bad < 5) { unsigned k = 0; while (ref[k] == out[blks[i].out_off + k]) ++k; printf("member %u differs at byte %u of %u\n", i, k, blks[i].out_len); } ++bad; }
+    }
+    { unsigned long long t[8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), sizeof t);
+      double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)t[k];
+      const char *nm[8] = {"code-length stream", "table build", "phase 1 (speculate+sync)", "phase 2 (literals+tokens)", "phase 3 (match copies)", "block header", "tail", "-"};
+      for (int k = 0; k < 7; ++k) printf("   %-28s %6.1f %%   %.0f ticks per member\n", nm[k], 100.0 * t[k] / (tot > 0 ? tot : 1), (double)t[k] / nb); }
+    printf("%u members, %.1f MB out, kernel %.3f ms = %.1f GB/s; bad status %u, mismatching %u\n", nb, uo / 1e6, ms, uo / ms / 1e6, badst, bad);
+    return bad || badst;
+}
