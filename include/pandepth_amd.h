@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+#define PD_ABI_VERSION 2
 
 enum {
     PD_OK = 0,
@@ -210,6 +210,9 @@ int pd_slice_sweep_i4(pd_ctx *ctx, const void *dev_parts, uint32_t n_parts, uint
 int pd_gather_windows(pd_ctx *ctx, const void *dev_partials, uint32_t w, uint32_t *cover, uint64_t *sum);
 
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
+/* Waits for everything queued.  Deferred batches (PD_PUSH_MORE) are scattered first — except that with "direct_windows"
+ * set a whole deferred sample in an otherwise empty context stays deferred (its memory must then stay valid until the
+ * statistics call that consumes it, or pd_reset). */
 int pd_synchronize(pd_ctx *ctx);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch.
@@ -241,6 +244,50 @@ typedef struct pd_bgzf_unit { uint64_t start, stop, avail; uint32_t first_block,
 int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
                        const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
                        int32_t min_mapq, int32_t *unit_status, uint64_t *n_records);
+
+/* ---- GPU-side BAM decode, asynchronous batches (the CLI's default input path for BAM files) --------------------
+ * Replaces the producer side of the seam as well — htslib's bgzf_read / bam_read1 and the filter + CIGAR walk of
+ * PD:434-460 — so that the host only reads compressed bytes.  A BATCH is a set of whole BGZF members plus UNITS:
+ * stretches [start, stop) of the batch's inflated bytes whose records are to be counted; a unit's first record
+ * starts at `start` (an index offset), or, with PD_UNIT_GUESS, at the first record boundary at or after `start`,
+ * which the device finds itself (no-index streams; the caller checks res->first_start against the previous batch's
+ * res->next_start).  Per batch, on one of the context's decode streams: H2D of the members (from pinned memory
+ * handed out by pd_decode_acquire) -> inflate, one WAVE per member (speculative parallel Huffman decoding, see
+ * csrc/pd_inflate_wave.h) -> record boundaries, one wave per 64 KiB (csrc/pd_bamwalk.h) -> filter (flag, mapq,
+ * contigs with targets, optionally htslib's region test against `spans`) + CIGAR walk -> the batch's runs, dense and
+ * in file order, in HBM.  pd_decode_end concatenates the batches by `order` and leaves the sample DEFERRED exactly
+ * as pd_push_intervals_device(.., PD_PUSH_SORTED | PD_PUSH_MORE) would: the statistics calls then take the direct
+ * path (pd_set_param "direct_windows") or materialise the arrays.  Units the device does not finish are handed back:
+ *   unit_status[u] 0 counted; 1 decode it on the host (a record runs past the unit's bytes, a CIGAR lives in the CG
+ *   tag, a Huffman code this decoder leaves to zlib); 2 corrupt data.
+ * pd_decode_acquire / submit may be called from several threads (one batch each); submit returns when the batch's
+ * runs are in HBM — batches of different threads overlap on the device. */
+#define PD_UNIT_GUESS 1u
+typedef struct pd_decode_cfg {
+    uint32_t flag_mask; int32_t min_mapq;
+    const uint8_t *contig_on;       /* n_contigs flags: count reads of this contig (NULL: contigs of >= 2 bases, PD:4000) */
+    const uint32_t *span_off;       /* -g / -b: spans of contig t are [span_off[t], span_off[t+1]) ...                   */
+    const int32_t *spans;           /* ... pairs (begin0, end), sorted, disjoint (PD:419-434); NULL: every read          */
+    int32_t sorted;                 /* the file is coordinate sorted (first runs form a position-sorted stream)          */
+} pd_decode_cfg;
+typedef struct pd_decode_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks, flags, pad; } pd_decode_unit;
+typedef struct pd_decode_batch {
+    void *host_buf; size_t n_bytes;                              /* from pd_decode_acquire: whole BGZF members           */
+    const pd_bgzf_block *blocks; uint32_t n_blocks; uint32_t pad;
+    uint64_t inflated_bytes;
+    const pd_decode_unit *units; uint32_t n_units; uint32_t pad2;
+    uint64_t order;                                              /* file position of the batch                           */
+} pd_decode_batch;
+typedef struct pd_decode_result {
+    uint64_t n_reads, n_first, n_other;    /* records seen in the units that were counted; first runs; other runs       */
+    uint64_t first_start, next_start;      /* unit 0: first record it owns / first record start >= its stop (~0: none)   */
+    double ms_h2d, ms_inflate, ms_walk, ms_emit;
+} pd_decode_result;
+int pd_decode_begin(pd_ctx *ctx, const pd_decode_cfg *cfg);
+int pd_decode_acquire(pd_ctx *ctx, size_t bytes, void **host_buf);
+int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_status, pd_decode_result *res);
+int pd_decode_end(pd_ctx *ctx);
+int pd_decode_abort(pd_ctx *ctx);          /* forget the batches decoded since pd_decode_begin (nothing is counted) */
 
 /* ---- experimental measuring entry for the inflate kernel alone -------------------------------
  * Inflates every block of a BGZF image held in host memory on the GPU (one lane per block) and

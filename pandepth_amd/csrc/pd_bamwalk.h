@@ -1,0 +1,239 @@
+// pd_bamwalk.h — finding and parsing BAM records in inflated bytes with a whole wavefront, replacing the one-thread-
+// per-unit walk of round 1.  Restates PD:434-460 (filter + CIGAR walk) on raw BAM bytes (SAM spec §4.2): block_size,
+// refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen at fixed offsets, the CIGAR
+// after the read name.
+//
+// Records form a chain (each record's length says where the next one starts), so a stretch of the inflated stream is
+// walked SPECULATIVELY, like the Huffman streams in pd_inflate_wave.h:
+//   * a SEGMENT is up to 64 KiB whose first record start is known (an index offset) or guessed; lane l of the wave owns
+//     the records that start in the l-th KiB;
+//   * every lane looks for the first position in its KiB that passes a strict record-header test (sizes consistent with
+//     each other, ids inside the header's tables, a NUL where the name ends, and the same for the record it points to),
+//     and walks from there to the end of its KiB;
+//   * the true start of lane l is where the chain of lanes 0..l-1 ends = the prefix maximum of their end positions; lanes
+//     whose guess was different walk again, until nothing changes.  A stable state is the exact chain by induction from
+//     lane 0, whatever the guesses were: the header test only makes it come quickly.  A segment whose own start was a
+//     guess is checked the same way against the segments before it (k_walk_finish), and redone with the corrected start.
+// Pass 1 counts what every lane will emit (reads that pass the filter; their M/=/X runs), pass 2 writes the runs to
+// dense arrays: the first run of every read in file order (position sorted for a coordinate-sorted BAM), the other runs
+// behind them in the same order.
+//
+// The same source compiles for gfx950 and for the host (tests/harness/bamwalk_check.cpp compares it with the host reader).
+#ifndef PD_BAMWALK_H_
+#define PD_BAMWALK_H_
+#include <stdint.h>
+#include "pd_inflate_wave.h"              // PW_FN, the wave classes
+#include "../../include/pandepth_amd.h"
+
+namespace pdb2 {
+
+enum { SUB = 1024, SEG_BYTES = 64 * SUB };
+enum { WF_BAD = 1, WF_MORE = 2, WF_HOST = 4 };     // corrupt record / record runs past the batch / CIGAR in the CG tag
+static const uint64_t NONE = ~0ull, STOPPED = 1ull << 62;
+
+struct Cfg {                              // wave-uniform
+    const uint8_t *buf; uint64_t avail;   // the batch's inflated bytes
+    int32_t n_ref; const uint32_t *contig_len; const uint8_t *contig_on;      // contig_on[tid] != 0: the contig has targets
+    uint32_t flag_mask; int32_t min_mapq;
+    const uint32_t *span_off; const int32_t *spans;                            // -g / -b: (begin0, end) per contig, sorted; or null
+};
+
+struct Seg {
+    uint64_t begin, end;                  // records STARTING in [begin, end) belong to the segment
+    uint64_t hint;                        // its first record start (>= begin) when known, else NONE
+    uint64_t avail;                       // end of the unit's inflated bytes (a record must end at or before it)
+    uint32_t unit_first, n_rec;           // first segment of its unit (nothing before it to be checked against); OUT: records it owns
+    // results
+    uint64_t used_start, e_last;          // where lane 0 started; first record start >= end (0: no record seen)
+    uint32_t n_first, n_other, flags, max_span;
+    uint64_t base_first, base_other;      // written by k_walk_finish: where the segment's runs go
+};
+struct LaneOut { uint64_t start; uint32_t n_first, n_other; };
+
+PW_FN uint32_t rd32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+PW_FN uint32_t rd16(const uint8_t *p) { uint16_t w; __builtin_memcpy(&w, p, 2); return w; }
+
+// strict header test of a candidate record start (everything it reads lies below avail)
+PW_FN bool plausible(const Cfg &c, uint64_t p, int depth)
+{
+    for (int k = 0; k < depth; ++k) {
+        if (p + 36 > c.avail) return k > 0;                               // cannot look further: what was seen was consistent
+        const uint8_t *r = c.buf + p;
+        const uint32_t bs = rd32(r);
+        if (bs < 34 || bs > (1u << 27)) return false;
+        const int32_t tid = (int32_t)rd32(r + 4), pos = (int32_t)rd32(r + 8);
+        if (tid < -1 || tid >= c.n_ref || pos < -1) return false;
+        const uint32_t l_name = r[12], n_cig = rd16(r + 16), l_seq = rd32(r + 20);
+        const int32_t ntid = (int32_t)rd32(r + 24), npos = (int32_t)rd32(r + 28);
+        if (l_name < 1 || l_seq > (1u << 27) || ntid < -1 || ntid >= c.n_ref || npos < -1) return false;
+        if ((uint64_t)32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) return false;
+        if (tid >= 0 && pos >= 0 && (uint32_t)pos > c.contig_len[tid]) return false;
+        if (p + 36 + l_name <= c.avail && r[36 + l_name - 1] != 0) return false;             // the name ends with NUL
+        p += 4 + (uint64_t)bs;
+    }
+    return true;
+}
+
+struct Rec { int32_t tid, pos; uint32_t keep, n_cig; const uint8_t *cig; uint32_t flags, unmapped; };
+
+// header of the record at p (p + 36 <= avail, block size already validated by the caller) + the filter
+PW_FN Rec open_record(const Cfg &c, uint64_t p, uint32_t bs)
+{
+    const uint8_t *r = c.buf + p;
+    Rec x;
+    x.tid = (int32_t)rd32(r + 4); x.pos = (int32_t)rd32(r + 8);
+    const uint32_t l_name = r[12], mapq = r[13], flag = rd16(r + 18), l_seq = rd32(r + 20);
+    x.n_cig = rd16(r + 16); x.cig = r + 36 + l_name; x.flags = 0; x.unmapped = flag & 4;
+    x.keep = !(flag & c.flag_mask) && (int32_t)mapq >= c.min_mapq && x.tid >= 0 && x.tid < c.n_ref;
+    if (x.keep && !c.contig_on[x.tid]) x.keep = 0;
+    if ((uint64_t)32 + l_name + 4ull * x.n_cig > bs) { x.keep = 0; x.flags = WF_BAD; }      // the host reader fails such a record
+    // CIGAR kept in the CG tag (htslib: first operation <l_seq>S on a placed read): the host decodes that unit
+    else if (x.n_cig >= 1 && x.tid >= 0 && x.pos >= 0 && (rd32(x.cig) & 0xf) == 4 && (rd32(x.cig) >> 4) == l_seq && x.keep) x.flags = WF_HOST;
+    return x;
+}
+
+// M/=/X runs of one kept record; emit(first?, beg, end).  Returns the reference end position.
+template <class F> PW_FN int32_t walk_cigar(const Rec &x, F emit)
+{
+    int32_t cur = x.pos;
+    bool first_done = false, moved = false;
+    for (uint32_t i = 0; i < x.n_cig; ++i) {
+        const uint32_t cg = rd32(x.cig + 4 * i), op = cg & 0xf;
+        const int32_t len = (int32_t)(cg >> 4);
+        if (op == 0 || op == 7 || op == 8) {
+            emit(!first_done && !moved, cur, cur + len);
+            first_done = true; cur += len;
+        } else if (op == 2 || op == 3) { cur += len; moved = true; }
+    }
+    return cur;
+}
+
+// htslib's multi-region test for -g / -b (PD:419-434): pos < span end && endpos > span begin0 for some widened span
+PW_FN bool span_hit(const Cfg &c, int32_t tid, int32_t pos, int32_t endpos)
+{
+    uint32_t lo = c.span_off[tid], hi = c.span_off[tid + 1];
+    const uint32_t top = hi;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (c.spans[2 * m + 1] > pos) hi = m; else lo = m + 1; }
+    return lo < top && endpos > c.spans[2 * lo];
+}
+
+struct LaneWalk { uint64_t e; uint32_t n_first, n_other, flags, max_span, n_rec; };
+
+// records starting in [s, b): counts (emit == false) or runs written at first[of..] / other[oo..] (emit == true)
+template <bool EMIT>
+PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_iv *other, uint64_t of, uint64_t oo)
+{
+    LaneWalk w; w.e = s; w.n_first = w.n_other = w.flags = w.max_span = w.n_rec = 0;
+    uint64_t p = s;
+    for (uint32_t guard = 0; p < b && guard < SUB / 36 + 2; ++guard) {
+        // a record that cannot be finished here stops the chain: nothing after it may be taken for a record start
+        if (p + 36 > c.avail) { w.flags |= WF_MORE; p = STOPPED; break; }
+        const uint32_t bs = rd32(c.buf + p);
+        if (bs < 32 || bs > (1u << 29)) { w.flags |= WF_BAD; p = STOPPED; break; }
+        if (p + 4 + (uint64_t)bs > c.avail) { w.flags |= WF_MORE; p = STOPPED; break; }
+        const Rec x = open_record(c, p, bs);
+        w.flags |= x.flags; ++w.n_rec;
+        if (x.keep && !x.flags) {
+            bool take = true;
+            if (c.spans) {                                               // endpos first: the filter needs it
+                // htslib's bam_endpos: unmapped reads and alignments without reference bases count as one base
+                const int32_t endpos = x.unmapped || !x.n_cig ? x.pos + 1 : walk_cigar(x, [](bool, int32_t, int32_t) {});
+                take = span_hit(c, x.tid, x.pos, endpos > x.pos ? endpos : x.pos + 1);
+            }
+            if (take) {
+                uint32_t nf = 0, no = 0, span = 0;
+                walk_cigar(x, [&](bool is_first, int32_t beg, int32_t end) {
+                    if (is_first) { if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end}; nf = 1; }
+                    else { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; const uint32_t d = (uint32_t)(beg - x.pos); if (d > span) span = d; }
+                });
+                w.n_first += nf; w.n_other += no;
+                if (span > w.max_span) w.max_span = span;
+            }
+        }
+        p += 4 + (uint64_t)bs;
+    }
+    w.e = p;
+    return w;
+}
+
+// pass 1: one wave, one segment.  lanes[64] receives every lane's start and counts for pass 2.
+template <class W>
+PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
+{
+    Cfg c = cfg; c.avail = sg.avail;
+    typedef typename W::template Var<uint64_t> U64;
+    typedef typename W::template Var<uint32_t> U;
+    U64 a, b, s, e;
+    U nf, no, fl, ms, need, nr;
+    const uint64_t hint = sg.hint;
+    W::each([&](int l) {
+        a[l] = sg.begin + (uint64_t)l * SUB; b[l] = a[l] + SUB < sg.end ? a[l] + SUB : sg.end;
+        if (a[l] >= sg.end) { a[l] = b[l] = sg.end; }
+        // the guess: first plausible header in the lane's KiB (lane 0 of a segment whose start is known: that)
+        uint64_t g = NONE;
+        if (l == 0 && hint != NONE) g = hint;
+        else for (uint64_t p = a[l]; p < b[l]; ++p) if (plausible(c, p, 3)) { g = p; break; }
+        s[l] = g; need[l] = 1; e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = 0;
+    });
+    for (int round = 0; round < 70; ++round) {
+        W::each([&](int l) {
+            if (!need[l]) return;
+            e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = 0;
+            if (s[l] == NONE) return;                                     // nothing known to start here: no information
+            if (s[l] >= b[l]) { e[l] = s[l]; return; }                     // the chain passes over this lane's KiB
+            const LaneWalk w = walk_lane<false>(c, s[l], b[l], nullptr, nullptr, 0, 0);
+            e[l] = w.e; nf[l] = w.n_first; no[l] = w.n_other; fl[l] = w.flags; ms[l] = w.max_span; nr[l] = w.n_rec;
+        });
+        // where the chain of the lanes before l ends = prefix maximum of their ends
+        const U64 pm = W::excl_scan_max64(e);
+        W::each([&](int l) {
+            uint64_t t = s[l];
+            if (l > 0 && pm[l] != 0) t = pm[l];                           // (0: no lane before this one knows anything — keep the guess)
+            need[l] = t != s[l]; s[l] = t;
+        });
+        if (!W::ballot_ne(need, 0u)) break;
+    }
+    uint32_t tf = 0, to = 0;
+    const U ef = W::excl_scan(nf, &tf);
+    const U eo = W::excl_scan(no, &to);
+    uint32_t tr = 0;
+    const U er = W::excl_scan(nr, &tr);
+    (void)ef; (void)eo; (void)er;
+    const uint64_t flags = W::ballot_ne(fl, 0u);
+    uint32_t allf = 0, mspan = 0;
+    if (flags) allf = W::reduce_or(fl);
+    mspan = W::reduce_max(ms);
+    const uint64_t last_e = W::reduce_max64(e);
+    U64 own;
+    W::each([&](int l) { own[l] = s[l] != NONE && s[l] < b[l] ? s[l] : NONE; });
+    const uint64_t first_start = W::reduce_min64(own);                   // the first record the segment owns (NONE: none starts here)
+    W::each([&](int l) {
+        lanes[l].start = s[l]; lanes[l].n_first = nf[l]; lanes[l].n_other = no[l];
+        if (l == 0) {
+            sg.used_start = first_start; sg.e_last = last_e; sg.n_first = tf; sg.n_other = to; sg.flags = allf; sg.max_span = mspan; sg.n_rec = tr;
+        }
+    });
+}
+
+// pass 2: the same lanes write their runs; sg.base_first / base_other say where the segment's runs go
+template <class W>
+PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_iv *first, pd_iv *other)
+{
+    Cfg c = cfg; c.avail = sg.avail;
+    typedef typename W::template Var<uint32_t> U;
+    U nf, no;
+    W::each([&](int l) { nf[l] = lanes[l].n_first; no[l] = lanes[l].n_other; });
+    uint32_t tf = 0, to = 0;
+    const U ef = W::excl_scan(nf, &tf);
+    const U eo = W::excl_scan(no, &to);
+    W::each([&](int l) {
+        const uint64_t a = sg.begin + (uint64_t)l * SUB;
+        uint64_t b = a + SUB < sg.end ? a + SUB : sg.end;
+        const uint64_t s = lanes[l].start;
+        if (a >= sg.end || s == NONE || s >= b || (nf[l] | no[l]) == 0) return;
+        (void)walk_lane<true>(c, s, b, first, other, sg.base_first + ef[l], sg.base_other + eo[l]);
+    });
+}
+
+} // namespace pdb2
+#endif

@@ -11,7 +11,7 @@
 #include <vector>
 #include "pd_inflate_core.h"
 #include "pd_inflate_wave.h"
-#include "pd_bamdev_core.h"
+#include "pd_bamwalk.h"
 #include "pd_kernels.h"
 #include "../../include/pandepth_amd.h"
 
@@ -52,78 +52,25 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const 
     }
 }
 
-// thread per unit: record offsets (sequential by nature: each record's length says where the next
-// starts), plus the checks that send a unit back to the host (record past the inflated bytes,
-// CIGAR in the CG tag)
-__global__ __launch_bounds__(64) void k_walk_units(const uint8_t *buf, pdb::Unit *units, uint32_t n_units,
-                                                   uint64_t *rec_off, uint64_t rec_cap, const int *blk_status,
-                                                   const uint32_t *unit_first_blk, const uint32_t *unit_n_blk)
+// The record chain of the inflated bytes, one wave per <= 64 KiB segment (pd_bamwalk.h): pass 1 finds every lane's first
+// record and counts what it will emit; `only` (or null) lists the segments to (re)do.
+__global__ __launch_bounds__(64) void k_walk_segments(const pdb2::Cfg cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes,
+                                                      const uint32_t *only, uint32_t n_only)
 {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_units) return;
-    pdb::Unit u = units[i];
-    int bad = 0;
-    for (uint32_t b = 0; b < unit_n_blk[i]; ++b) if (blk_status[unit_first_blk[i] + b] != 0) bad = 1;
-    if (bad) { u.n_rec = 0; u.status = 2; units[i] = u; return; }
-    pdb::walk_unit(buf, u, rec_off, rec_cap);
-    if (u.status == 0) {
-        for (uint32_t k = 0; k < u.n_rec; ++k) {          // long-CIGAR placeholder (SAM spec §4.2.2) -> host
-            const uint8_t *rec = buf + rec_off[u.rec_base + k];
-            if (pdb::ld16(rec + 16) == 2) {
-                const uint8_t *cg = rec + 36 + rec[12];
-                if ((pdb::ld32(cg) & 0xf) == 4 && (pdb::ld32(cg) >> 4) == pdb::ld32(rec + 20) && (pdb::ld32(cg + 4) & 0xf) == 3) { u.status = 1; break; }
-            }
-        }
-    }
-    if (u.status != 0) u.n_rec = 0;
-    units[i] = u;
+    const uint32_t k = blockIdx.x;
+    if (k >= (only ? n_only : n_seg)) return;
+    const uint32_t j = only ? only[k] : k;
+    pdb2::walk_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64);
 }
 
-// dense record numbering over the units that stay on the device
-__global__ void k_unit_bases(const pdb::Unit *units, uint32_t n_units, uint64_t *dense_base)
+// pass 2: the runs, at the offsets the host gave every segment (base_first / base_other)
+__global__ __launch_bounds__(64) void k_emit_segments(const pdb2::Cfg cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
+                                                      pd_iv *first, pd_iv *other)
 {
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < n_units; ++i) { dense_base[i] = acc; acc += units[i].n_rec; }
-    dense_base[n_units] = acc;
-}
-
-// thread per record: first run into the dense, position-sorted array; the other runs appended to
-// the batch's unordered list with ONE atomic per wave
-__global__ __launch_bounds__(256) void k_parse_records(const uint8_t *buf, const pdb::Unit *units, uint32_t n_units,
-                                                       const uint64_t *dense_base, const uint64_t *rec_off,
-                                                       pdb::Filter f, const uint32_t *contig_len, pd_iv *first,
-                                                       pd_iv *other, uint32_t other_cap, uint32_t *other_count, uint32_t *err)
-{
-    const uint64_t n = dense_base[n_units];
-    const uint64_t j = blockIdx.x * (uint64_t)256 + threadIdx.x;
-    const bool live = j < n;
-    const uint8_t *rec = nullptr;
-    if (live) {
-        uint32_t lo = 0, hi = n_units;                  // last unit with dense_base <= j
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dense_base[mid] <= j) lo = mid; else hi = mid; }
-        rec = buf + rec_off[units[lo].rec_base + (j - dense_base[lo])];
-    }
-    uint32_t n_other = 0;
-    pd_iv fr{0, 0, 0};
-    if (live) pdb::parse_record(rec, f, contig_len, &fr, [&](pd_iv) { ++n_other; });
-    // wave-level exclusive scan of the counts, one atomic for the wave
-    uint32_t incl = n_other;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += y; }
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t base = 0;
-    if (total) {
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(other_count, total);
-        base = __shfl(base, 0);
-    }
-    if (live) {
-        first[j] = fr;
-        if (n_other) {
-            uint32_t w = base + incl - n_other;
-            pd_iv dummy;
-            pdb::parse_record(rec, f, contig_len, &dummy, [&](pd_iv v) { if (w < other_cap) other[w] = v; else atomicOr(err, 1u); ++w; });
-        }
-    }
+    const uint32_t j = blockIdx.x;
+    if (j >= n_seg) return;
+    if ((segs[j].n_first | segs[j].n_other) == 0) return;
+    pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other);
 }
 
 } // namespace
@@ -140,6 +87,20 @@ void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf
 }
 size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token) + 64; }
 
+void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes,
+                          const uint32_t *only, uint32_t n_only)
+{
+    const uint32_t n = only ? n_only : n_seg;
+    if (!n) return;
+    hipLaunchKernelGGL(k_walk_segments, dim3(n), dim3(64), 0, st, cfg, segs, n_seg, lanes, only, n_only);
+}
+void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
+                          pd_iv *first, pd_iv *other)
+{
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_emit_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, first, other);
+}
+
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                          int *status, void *scratch)
 {
@@ -149,26 +110,6 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_bloc
                        (pdi::Tables *)scratch);
 }
 size_t bgzf_scratch_bytes(uint32_t n_blk) { return (size_t)n_blk * sizeof(pdi::Tables); }
-
-void launch_bam_walk(hipStream_t st, const uint8_t *buf, void *units, uint32_t n_units, uint64_t *rec_off, uint64_t rec_cap,
-                     const int *blk_status, const uint32_t *unit_first_blk, const uint32_t *unit_n_blk, uint64_t *dense_base)
-{
-    hipLaunchKernelGGL(k_walk_units, dim3((n_units + 63) / 64), dim3(64), 0, st, buf, (pdb::Unit *)units, n_units, rec_off,
-                       rec_cap, blk_status, unit_first_blk, unit_n_blk);
-    hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(1), 0, st, (const pdb::Unit *)units, n_units, dense_base);
-}
-
-void launch_bam_parse(hipStream_t st, const uint8_t *buf, const void *units, uint32_t n_units, const uint64_t *dense_base,
-                      uint64_t n_rec_upper, const uint64_t *rec_off, uint32_t flag_mask, int32_t min_mapq, int32_t n_contigs,
-                      const uint32_t *contig_len, pd_iv *first, pd_iv *other, uint32_t other_cap, uint32_t *other_count,
-                      uint32_t *err)
-{
-    if (!n_rec_upper) return;
-    pdb::Filter f{flag_mask, min_mapq, n_contigs};
-    hipLaunchKernelGGL(k_parse_records, dim3((unsigned)((n_rec_upper + 255) / 256)), dim3(256), 0, st, buf,
-                       (const pdb::Unit *)units, n_units, dense_base, rec_off, f, contig_len, first, other, other_cap,
-                       other_count, err);
-}
 
 } // namespace pdk
 

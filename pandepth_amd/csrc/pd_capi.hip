@@ -14,7 +14,10 @@
 #include <vector>
 #include <map>
 #include "pd_kernels.h"
-#include "pd_bamdev_core.h"
+#include "pd_bamwalk.h"
+#include <condition_variable>
+#include <algorithm>
+#include <atomic>
 
 using namespace pdk;
 
@@ -63,9 +66,23 @@ struct pd_ctx {
     int direct_un = 4;
     bool all_valid_host = false;
     std::vector<Pending> pend;
-    // GPU-side BAM decode: device buffers grown on demand (index = purpose)
-    void *dd_buf[12] = {}; size_t dd_cap[12] = {};
-    std::mutex dd_mu; hipStream_t dd_stream = nullptr; hipEvent_t dd_ev[6] = {}; double dd_ms[4] = {}; uint64_t dd_batches = 0;
+    // ---- device decode (pd_decode_*): a few batch slots, each with its own stream and buffers ----
+    struct DecSlot {
+        bool busy = false;
+        hipStream_t st = nullptr;
+        hipEvent_t ev[6] = {};
+        uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
+        void *d[7] = {}; size_t cap[7] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list
+        void *d_tok = nullptr;                                    // wave scratch (match tokens)
+    };
+    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; uint32_t max_span; };
+    static constexpr int N_DEC = 3;
+    DecSlot dec[N_DEC];
+    std::mutex dec_mu; std::condition_variable dec_cv;
+    bool dec_open = false;
+    pd_decode_cfg dec_cfg{}; uint8_t *d_contig_on = nullptr; uint32_t *d_span_off = nullptr; int32_t *d_spans = nullptr;
+    std::vector<RunSeg> run_segs;
+    pd_iv *run_first = nullptr, *run_other = nullptr;             // the concatenated sample (owned until the next reset)
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
@@ -425,9 +442,16 @@ int pd_destroy(pd_ctx *c)
     void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
                     c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->direct_words, c->desc, c->chk, c->ovf, c->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (void *p : c->dd_buf) if (p) (void)hipFree(p);
-    for (hipEvent_t e : c->dd_ev) if (e) (void)hipEventDestroy(e);
-    if (c->dd_stream) (void)hipStreamDestroy(c->dd_stream);
+    for (auto &sl : c->dec) {
+        if (sl.st) (void)hipStreamSynchronize(sl.st);
+        if (sl.h_blob) (void)hipHostFree(sl.h_blob);
+        for (void *p : sl.d) if (p) (void)hipFree(p);
+        if (sl.d_tok) (void)hipFree(sl.d_tok);
+        for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+    }
+    for (auto &r : c->run_segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); }
+    for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -442,7 +466,13 @@ int pd_reset(pd_ctx *c)
     int rc = flush_pending(c);
     if (rc) return rc;
     c->state = 0;
-    return do_reset(c);
+    rc = do_reset(c);
+    if (rc == PD_OK && (c->run_first || c->run_other)) {          // the decoded sample's runs go with it
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
+        if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+    }
+    return rc;
 }
 
 int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
@@ -761,6 +791,280 @@ int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *con
     return PD_OK;
 }
 
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// GPU-side BAM decode in asynchronous batches (include/pandepth_amd.h: pd_decode_*)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG, DS_LANE, DS_ONLY };
+
+int dec_fail(pd_ctx *c, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(c->mu); return fail(c, code, msg); }
+
+#define HIPDEC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return dec_fail(c, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int dec_ensure(pd_ctx *c, pd_ctx::DecSlot &sl, int k, size_t bytes)
+{
+    if (bytes <= sl.cap[k]) return PD_OK;
+    if (sl.d[k]) { HIPDEC(hipStreamSynchronize(sl.st)); HIPDEC(hipFree(sl.d[k])); sl.d[k] = nullptr; sl.cap[k] = 0; }
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&sl.d[k], want) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode buffer allocation failed");
+    sl.cap[k] = want;
+    return PD_OK;
+}
+
+// the host side of a batch after pass 1: is every guessed segment start the one the chain before it arrives at?
+// (per unit; corrected hints for the ones that are not) + the running output offsets
+uint32_t dec_finish(std::vector<pdb2::Seg> &segs, std::vector<uint32_t> *redo)
+{
+    uint64_t E = 0;
+    redo->clear();
+    for (size_t j = 0; j < segs.size(); ++j) {
+        pdb2::Seg &s = segs[j];
+        if (s.unit_first) E = 0;
+        else {
+            const bool none_expected = E >= s.end;
+            const bool ok = none_expected ? s.used_start == pdb2::NONE : s.used_start == E;
+            if (!ok) { s.hint = E; redo->push_back((uint32_t)j); }
+        }
+        if (s.e_last > E) E = s.e_last;
+    }
+    return (uint32_t)redo->size();
+}
+
+} // namespace
+
+extern "C" {
+
+int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
+{
+    if (!c || !cfg) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rs = need_state(c, 0, "pd_decode_begin")) return rs;
+    HIPOK(c, hipSetDevice(c->device));
+    c->dec_cfg = *cfg;
+    std::vector<uint8_t> on((size_t)c->n_contigs, 1);
+    for (int32_t t = 0; t < c->n_contigs; ++t) on[(size_t)t] = cfg->contig_on ? (cfg->contig_on[t] != 0) : (c->len[(size_t)t] >= 2);
+    if (!c->d_contig_on && hipMalloc(&c->d_contig_on, (size_t)c->n_contigs + 16) != hipSuccess) return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed");
+    HIPOK(c, hipMemcpy(c->d_contig_on, on.data(), on.size(), hipMemcpyHostToDevice));
+    if (c->d_span_off) { (void)hipFree(c->d_span_off); c->d_span_off = nullptr; }
+    if (c->d_spans) { (void)hipFree(c->d_spans); c->d_spans = nullptr; }
+    if (cfg->span_off && cfg->spans) {
+        const size_t ns = cfg->span_off[c->n_contigs];
+        if (hipMalloc(&c->d_span_off, ((size_t)c->n_contigs + 1) * 4) != hipSuccess || hipMalloc(&c->d_spans, ns * 8 + 16) != hipSuccess)
+            return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed");
+        HIPOK(c, hipMemcpy(c->d_span_off, cfg->span_off, ((size_t)c->n_contigs + 1) * 4, hipMemcpyHostToDevice));
+        if (ns) HIPOK(c, hipMemcpy(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice));
+    }
+    c->dec_cfg.contig_on = nullptr; c->dec_cfg.span_off = nullptr; c->dec_cfg.spans = nullptr;      // (the caller's arrays are not kept)
+    c->dec_open = true;
+    return PD_OK;
+}
+
+int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
+{
+    if (!c || !host_buf) return PD_EINVAL;
+    *host_buf = nullptr;
+    std::unique_lock<std::mutex> lk(c->dec_mu);
+    if (!c->dec_open) return dec_fail(c, PD_ESTATE, "pd_decode_acquire: call pd_decode_begin first");
+    pd_ctx::DecSlot *sl = nullptr;
+    c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; });
+    sl->busy = true;
+    lk.unlock();
+    if (hipSetDevice(c->device) != hipSuccess) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); }
+    if (bytes + 64 > sl->h_cap) {
+        if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
+        const size_t want = std::max<size_t>(bytes + 64, (size_t)64 << 20);
+        if (hipHostMalloc((void **)&sl->h_blob, want, hipHostMallocDefault) != hipSuccess) {
+            { std::lock_guard<std::mutex> l2(c->dec_mu); sl->busy = false; }
+            c->dec_cv.notify_one();
+            return dec_fail(c, PD_ENOMEM, "pinned batch buffer allocation failed");
+        }
+        sl->h_cap = want;
+    }
+    *host_buf = sl->h_blob;
+    return PD_OK;
+}
+
+int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status, pd_decode_result *res)
+{
+    if (!c || !bt || !bt->host_buf || !unit_status) return PD_EINVAL;
+    pd_ctx::DecSlot *slp = nullptr;
+    for (auto &x : c->dec) if (x.h_blob == bt->host_buf && x.busy) slp = &x;
+    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_submit: buffer was not handed out by pd_decode_acquire");
+    pd_ctx::DecSlot &sl = *slp;
+    struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; } c->dec_cv.notify_one(); } } rel{c, slp};
+    if (res) memset(res, 0, sizeof *res);
+    if (res) res->first_start = res->next_start = ~0ull;
+    for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
+    if (!bt->n_units || !bt->n_blocks) return PD_OK;
+    if (bt->n_bytes + 64 > sl.h_cap) return dec_fail(c, PD_EINVAL, "pd_decode_submit: more bytes than were acquired");
+    HIPDEC(hipSetDevice(c->device));
+    if (!sl.st) {
+        HIPDEC(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        for (auto &e : sl.ev) HIPDEC(hipEventCreate(&e));
+    }
+    // ---- segments of every unit (host) ----
+    std::vector<pdb2::Seg> segs;
+    std::vector<uint32_t> seg0(bt->n_units + 1, 0);
+    for (uint32_t u = 0; u < bt->n_units; ++u) {
+        const pd_decode_unit &un = bt->units[u];
+        if (un.start > un.stop || un.start > un.avail || un.avail > bt->inflated_bytes || (uint64_t)un.first_block + un.n_blocks > bt->n_blocks)
+            return dec_fail(c, PD_EINVAL, "pd_decode_submit: unit outside the inflated buffer");
+        seg0[u] = (uint32_t)segs.size();
+        for (uint64_t b = un.start; b < un.stop; b += pdb2::SEG_BYTES) {
+            pdb2::Seg s; memset(&s, 0, sizeof s);
+            s.begin = b; s.end = std::min<uint64_t>(b + pdb2::SEG_BYTES, un.stop); s.avail = un.avail;
+            s.unit_first = b == un.start;
+            s.hint = (b == un.start && !(un.flags & PD_UNIT_GUESS)) ? un.start : pdb2::NONE;
+            segs.push_back(s);
+        }
+    }
+    seg0[bt->n_units] = (uint32_t)segs.size();
+    for (uint32_t b = 0; b < bt->n_blocks; ++b)
+        if (bt->blocks[b].in_off + bt->blocks[b].in_len + 8 > bt->n_bytes + 8 || bt->blocks[b].out_off + bt->blocks[b].out_len > bt->inflated_bytes)
+            return dec_fail(c, PD_EINVAL, "pd_decode_submit: block outside its buffer");
+    const uint32_t n_seg = (uint32_t)segs.size();
+    if (!n_seg) return PD_OK;
+    const unsigned n_wg = (unsigned)c->n_cu * 16u;
+    int rc;
+    if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
+        (rc = dec_ensure(c, sl, DS_BLK, (size_t)bt->n_blocks * sizeof(pd_bgzf_block))) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
+        (rc = dec_ensure(c, sl, DS_SEG, (size_t)n_seg * sizeof(pdb2::Seg))) || (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
+        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16))) return rc;
+    if (!sl.d_tok && hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
+    hipStream_t st = sl.st;
+    uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF];
+    pdb2::Seg *d_seg = (pdb2::Seg *)sl.d[DS_SEG];
+    pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
+    pdb2::Cfg cfg;
+    cfg.buf = d_inf; cfg.avail = bt->inflated_bytes; cfg.n_ref = c->n_contigs; cfg.contig_len = c->d_len; cfg.contig_on = c->d_contig_on;
+    cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans;
+    // ---- H2D, inflate, pass 1 ----
+    HIPDEC(hipEventRecord(sl.ev[0], st));
+    HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes, hipMemcpyHostToDevice, st));
+    HIPDEC(hipMemsetAsync(d_blob + bt->n_bytes, 0, 64, st));
+    HIPDEC(hipMemcpyAsync(sl.d[DS_BLK], bt->blocks, (size_t)bt->n_blocks * sizeof(pd_bgzf_block), hipMemcpyHostToDevice, st));
+    HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+    HIPDEC(hipEventRecord(sl.ev[1], st));
+    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg);
+    HIPDEC(hipEventRecord(sl.ev[2], st));
+    launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, 0);
+    std::vector<int> bst(bt->n_blocks);
+    HIPDEC(hipMemcpyAsync(bst.data(), sl.d[DS_ST], (size_t)bt->n_blocks * 4, hipMemcpyDeviceToHost, st));
+    HIPDEC(hipMemcpyAsync(segs.data(), d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+    HIPDEC(hipEventRecord(sl.ev[3], st));
+    HIPDEC(hipStreamSynchronize(st));
+    HIPDEC(hipGetLastError());
+    // ---- the chain across segments; segments whose guess was wrong walk again from the corrected start ----
+    std::vector<uint32_t> redo;
+    for (int round = 0; dec_finish(segs, &redo) > 0; ++round) {
+        if (round >= 4) { for (uint32_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
+        for (uint32_t j : redo) HIPDEC(hipMemcpyAsync(&d_seg[j].hint, &segs[j].hint, 8, hipMemcpyHostToDevice, st));
+        HIPDEC(hipMemcpyAsync(sl.d[DS_ONLY], redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
+        launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, (const uint32_t *)sl.d[DS_ONLY], (uint32_t)redo.size());
+        HIPDEC(hipMemcpyAsync(segs.data(), d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+        HIPDEC(hipStreamSynchronize(st));
+    }
+    // ---- unit outcomes; units handed back emit nothing ----
+    uint64_t nf = 0, no = 0, nrec = 0; uint32_t max_span = 0;
+    for (uint32_t u = 0; u < bt->n_units; ++u) {
+        int stt = 0;
+        const pd_decode_unit &un = bt->units[u];
+        for (uint32_t b = 0; b < un.n_blocks; ++b) { const int v = bst[un.first_block + b]; if (v < 0) stt = 2; else if (v > 0 && stt == 0) stt = 1; }
+        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
+            if (segs[j].flags & pdb2::WF_BAD) stt = 2;
+            else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && stt == 0) stt = 1;
+        }
+        unit_status[u] = stt;
+        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
+            if (stt) { segs[j].n_first = segs[j].n_other = 0; } else nrec += segs[j].n_rec;
+            segs[j].base_first = nf; segs[j].base_other = no; nf += segs[j].n_first; no += segs[j].n_other;
+            if (!stt && segs[j].max_span > max_span) max_span = segs[j].max_span;
+        }
+    }
+    if (res) {
+        res->n_first = nf; res->n_other = no; res->n_reads = nrec;
+        uint64_t fs = ~0ull, E = 0;
+        for (uint32_t j = seg0[0]; j < seg0[1]; ++j) { if (fs == ~0ull && segs[j].used_start != pdb2::NONE) fs = segs[j].used_start; if (segs[j].e_last > E) E = segs[j].e_last; }
+        res->first_start = fs; res->next_start = E ? E : ~0ull;
+    }
+    // ---- pass 2: the runs ----
+    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, max_span};
+    if (nf + no) {
+        if (nf && hipMalloc(&rs.first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+        if (no && hipMalloc(&rs.other, (size_t)no * sizeof(pd_iv)) != hipSuccess) { if (rs.first) (void)hipFree(rs.first); return dec_fail(c, PD_ENOMEM, "run array allocation failed"); }
+        HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+        launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other);
+    }
+    HIPDEC(hipEventRecord(sl.ev[4], st));
+    HIPDEC(hipStreamSynchronize(st));
+    HIPDEC(hipGetLastError());
+    if (res) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) res->ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) res->ms_inflate = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) res->ms_walk = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]) == hipSuccess) res->ms_emit = ms;
+    }
+    if (nf + no) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
+    return PD_OK;
+}
+
+int pd_decode_end(pd_ctx *c)
+{
+    if (!c) return PD_EINVAL;
+    {   // every batch has returned (submit is synchronous per caller); wait for stragglers that still hold a slot
+        std::unique_lock<std::mutex> lk(c->dec_mu);
+        c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });
+        c->dec_open = false;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rs = need_state(c, 0, "pd_decode_end")) return rs;
+    HIPOK(c, hipSetDevice(c->device));
+    std::vector<pd_ctx::RunSeg> segs;
+    { std::lock_guard<std::mutex> l2(c->dec_mu); segs.swap(c->run_segs); }
+    std::sort(segs.begin(), segs.end(), [](const pd_ctx::RunSeg &a, const pd_ctx::RunSeg &b) { return a.order < b.order; });
+    uint64_t nf = 0, no = 0; uint32_t span = 0;
+    for (auto &r : segs) { nf += r.n_first; no += r.n_other; if (r.max_span > span) span = r.max_span; }
+    auto drop = [&]() { for (auto &r : segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); } };
+    if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
+    if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+    if (nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
+    if (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
+    uint64_t of = 0, oo = 0;
+    for (auto &r : segs) {
+        if (r.n_first) HIPOK(c, hipMemcpyAsync(c->run_first + of, r.first, (size_t)r.n_first * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
+        if (r.n_other) HIPOK(c, hipMemcpyAsync(c->run_other + oo, r.other, (size_t)r.n_other * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
+        of += r.n_first; oo += r.n_other;
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    drop();
+    // the sample, deferred: first runs position sorted (a coordinate-sorted file), the others trail their read's start by
+    // at most `span` cells; an unsorted file, or reads spanning more than a few tiles, take the atomic path
+    const bool sorted = c->dec_cfg.sorted != 0;
+    int rc = PD_OK;
+    if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | (no && span <= (1u << 14) ? PD_PUSH_MORE : 0u)) : PD_PUSH_DEFAULT, -1, nullptr);
+    if (rc == PD_OK && no)
+        rc = scatter_device(c, c->run_other, (size_t)no, sorted && span <= (1u << 14) ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(span + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
+    return rc;
+}
+
+int pd_decode_abort(pd_ctx *c)
+{
+    if (!c) return PD_EINVAL;
+    std::unique_lock<std::mutex> lk(c->dec_mu);
+    c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });
+    c->dec_open = false;
+    (void)hipSetDevice(c->device);
+    for (auto &r : c->run_segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); }
+    c->run_segs.clear();
+    return PD_OK;
+}
+
+// The synchronous single-batch form (round 1's entry point, kept for its callers): one batch through the pipeline
+// above, its runs scattered at once (first runs: owner tiles; the others: atomics).
 int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
                        const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
                        int32_t min_mapq, int32_t *unit_status, uint64_t *n_records)
@@ -768,99 +1072,42 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     if (!c || !blob || !blocks || !units || !unit_status) return PD_EINVAL;
     if (n_records) *n_records = 0;
     if (n_units == 0 || n_blocks == 0) return PD_OK;
-    // Phase 1 (inflate, record walk, parse) works only on the decode buffers and runs on its own stream
-    // under its own lock, so that pd_push_intervals callers (host-decoded ranges of the same file) keep
-    // scattering meanwhile; only phase 2 (the scatter of this batch's runs) takes the context lock.
-    std::unique_lock<std::mutex> dl(c->dd_mu);
-    auto dd_fail = [&](int code, const std::string &msg) { std::lock_guard<std::mutex> lk(c->mu); return fail(c, code, msg); };
-#define HIPDD(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return dd_fail(PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-    HIPDD(hipSetDevice(c->device));
-    if (!c->dd_stream) HIPDD(hipStreamCreateWithFlags(&c->dd_stream, hipStreamNonBlocking));
-    hipStream_t st = c->dd_stream;
-    // host-side unit table: capacity-based slots in the record-offset array (a record is >= 36 bytes)
-    std::vector<pdb::Unit> hu(n_units);
-    std::vector<uint32_t> ufirst(n_units), unblk(n_units);
-    uint64_t rec_cap = 0;
-    for (uint32_t i = 0; i < n_units; ++i) {
-        const pd_bgzf_unit &u = units[i];
-        if (u.start > u.avail || u.start > u.stop || u.avail > inflated_bytes || (uint64_t)u.first_block + u.n_blocks > n_blocks)
-            return dd_fail(PD_EINVAL, "pd_push_bgzf_units: unit outside the inflated buffer");
-        hu[i].start = u.start; hu[i].stop = u.stop; hu[i].avail = u.avail; hu[i].rec_base = rec_cap; hu[i].n_rec = 0; hu[i].status = 0;
-        rec_cap += (u.avail - u.start) / 36 + 1;
-        ufirst[i] = u.first_block; unblk[i] = u.n_blocks;
+    pd_decode_cfg cfg{}; cfg.flag_mask = flag_mask; cfg.min_mapq = min_mapq; cfg.sorted = 1;
+    int rc = pd_decode_begin(c, &cfg);
+    if (rc) return rc;
+    void *hb = nullptr;
+    if ((rc = pd_decode_acquire(c, n_bytes, &hb))) return rc;
+    memcpy(hb, blob, n_bytes);
+    std::vector<pd_decode_unit> du(n_units);
+    for (uint32_t u = 0; u < n_units; ++u) du[u] = pd_decode_unit{units[u].start, units[u].stop, units[u].avail, units[u].first_block, units[u].n_blocks, 0, 0};
+    static std::atomic<uint64_t> key{0};
+    pd_decode_batch bt{}; bt.host_buf = hb; bt.n_bytes = n_bytes; bt.blocks = blocks; bt.n_blocks = n_blocks; bt.inflated_bytes = inflated_bytes;
+    bt.units = du.data(); bt.n_units = n_units; bt.order = ((uint64_t)1 << 63) + key.fetch_add(1);
+    pd_decode_result res;
+    if ((rc = pd_decode_submit(c, &bt, unit_status, &res))) return rc;
+    if (n_records) *n_records = res.n_reads;
+    pd_ctx::RunSeg mine{0, nullptr, 0, nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(c->dec_mu);
+        for (size_t i = 0; i < c->run_segs.size(); ++i)
+            if (c->run_segs[i].order == bt.order) { mine = c->run_segs[i]; c->run_segs.erase(c->run_segs.begin() + (long)i); break; }
     }
-    for (uint32_t b = 0; b < n_blocks; ++b)
-        if (blocks[b].in_off + blocks[b].in_len > n_bytes || blocks[b].out_off + blocks[b].out_len > inflated_bytes)
-            return dd_fail(PD_EINVAL, "pd_push_bgzf_units: block outside its buffer");
-    if (rec_cap > 0xFFFFFF00ull) return dd_fail(PD_EINVAL, "pd_push_bgzf_units: batch too large");
-    const size_t other_cap = (size_t)rec_cap / 2 + 1024;
-    enum { B_BLOB, B_INF, B_BLK, B_BST, B_UNIT, B_UF, B_UN, B_ROFF, B_DENSE, B_FIRST, B_OTHER, B_TAB };
-    const size_t need[12] = {n_bytes + 16, (size_t)inflated_bytes + 64, (size_t)n_blocks * sizeof(pd_bgzf_block), (size_t)n_blocks * 4,
-                             (size_t)n_units * sizeof(pdb::Unit), (size_t)n_units * 4, (size_t)n_units * 4, (size_t)rec_cap * 8,
-                             ((size_t)n_units + 1) * 8 + 16, (size_t)rec_cap * sizeof(pd_iv), other_cap * sizeof(pd_iv),
-                             bgzf_scratch_bytes(n_blocks)};
-    for (int k = 0; k < 12; ++k) {
-        if (need[k] <= c->dd_cap[k]) continue;
-        if (c->dd_buf[k]) { HIPDD(hipStreamSynchronize(st)); HIPDD(hipFree(c->dd_buf[k])); c->dd_buf[k] = nullptr; c->dd_cap[k] = 0; }
-        const size_t want = need[k] + need[k] / 8 + 4096;
-        if (hipMalloc(&c->dd_buf[k], want) != hipSuccess) return dd_fail(PD_ENOMEM, "device-decode buffer allocation failed");
-        c->dd_cap[k] = want;
-    }
-    if (!c->dd_ev[0]) for (int k = 0; k < 6; ++k) HIPDD(hipEventCreate(&c->dd_ev[k]));
-    uint8_t *d_blob = (uint8_t *)c->dd_buf[B_BLOB], *d_inf = (uint8_t *)c->dd_buf[B_INF];
-    uint64_t *d_dense = (uint64_t *)c->dd_buf[B_DENSE];
-    uint32_t *d_cnt = (uint32_t *)(d_dense + n_units + 1);            // {other_count, err}
-    HIPDD(hipEventRecord(c->dd_ev[0], st));
-    HIPDD(hipMemcpyAsync(d_blob, blob, n_bytes, hipMemcpyHostToDevice, st));
-    HIPDD(hipMemcpyAsync(c->dd_buf[B_BLK], blocks, need[B_BLK], hipMemcpyHostToDevice, st));
-    HIPDD(hipMemcpyAsync(c->dd_buf[B_UNIT], hu.data(), need[B_UNIT], hipMemcpyHostToDevice, st));
-    HIPDD(hipMemcpyAsync(c->dd_buf[B_UF], ufirst.data(), need[B_UF], hipMemcpyHostToDevice, st));
-    HIPDD(hipMemcpyAsync(c->dd_buf[B_UN], unblk.data(), need[B_UN], hipMemcpyHostToDevice, st));
-    HIPDD(hipMemsetAsync(d_cnt, 0, 8, st));
-    HIPDD(hipEventRecord(c->dd_ev[1], st));
-    launch_bgzf_inflate(st, d_blob, (const pd_bgzf_block *)c->dd_buf[B_BLK], n_blocks, d_inf, (int *)c->dd_buf[B_BST], c->dd_buf[B_TAB]);
-    HIPDD(hipEventRecord(c->dd_ev[2], st));
-    launch_bam_walk(st, d_inf, c->dd_buf[B_UNIT], n_units, (uint64_t *)c->dd_buf[B_ROFF], rec_cap, (const int *)c->dd_buf[B_BST],
-                    (const uint32_t *)c->dd_buf[B_UF], (const uint32_t *)c->dd_buf[B_UN], d_dense);
-    HIPDD(hipEventRecord(c->dd_ev[3], st));
-    uint64_t n_rec = 0;
-    HIPDD(hipMemcpyAsync(&n_rec, d_dense + n_units, 8, hipMemcpyDeviceToHost, st));
-    HIPDD(hipStreamSynchronize(st));                                  // also: the host arrays above may go
-    uint32_t cnt[2] = {0, 0};
-    if (n_rec) {
-        launch_bam_parse(st, d_inf, c->dd_buf[B_UNIT], n_units, d_dense, n_rec, (const uint64_t *)c->dd_buf[B_ROFF], flag_mask,
-                         min_mapq, c->n_contigs, c->d_len, (pd_iv *)c->dd_buf[B_FIRST], (pd_iv *)c->dd_buf[B_OTHER],
-                         (uint32_t)other_cap, d_cnt, d_cnt + 1);
-        HIPDD(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
-    }
-    HIPDD(hipEventRecord(c->dd_ev[4], st));
-    HIPDD(hipMemcpyAsync(hu.data(), c->dd_buf[B_UNIT], need[B_UNIT], hipMemcpyDeviceToHost, st));
-    HIPDD(hipStreamSynchronize(st));
-    HIPDD(hipGetLastError());
-    if (cnt[1] || cnt[0] > other_cap)
-        return dd_fail(PD_EINVAL, "pd_push_bgzf_units: more than one extra run per two records on average; decode this input on the host");
-    for (int k = 0; k < 4; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, c->dd_ev[k], c->dd_ev[k + 1]) == hipSuccess) c->dd_ms[k] += ms; }
-    c->dd_batches += 1;
-    // Phase 2: scatter this batch's runs (first runs: dense and position sorted; the rest: atomics)
-    if (n_rec) {
+    if (mine.n_first + mine.n_other) {
         std::unique_lock<std::mutex> lk(c->mu);
         if (int rs = need_state(c, 0, "pd_push_bgzf_units")) return rs;
         HIPOK(c, hipSetDevice(c->device));
-        int rc = scatter_device(c, (const pd_iv *)c->dd_buf[B_FIRST], (size_t)n_rec, PD_PUSH_SORTED, -1, nullptr);
-        if (rc) return rc;
-        if (cnt[0]) { rc = scatter_device(c, (const pd_iv *)c->dd_buf[B_OTHER], cnt[0], PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
-        HIPOK(c, hipEventRecord(c->dd_ev[5], c->stream));
-        lk.unlock();                                                  // other pushers may go on; the decode buffers stay ours
-        HIPDD(hipEventSynchronize(c->dd_ev[5]));
+        if (mine.n_first) { rc = scatter_device(c, mine.first, (size_t)mine.n_first, PD_PUSH_SORTED, -1, nullptr); if (rc) return rc; }
+        if (mine.n_other) { rc = scatter_device(c, mine.other, (size_t)mine.n_other, PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        if (mine.first) (void)hipFree(mine.first);
+        if (mine.other) (void)hipFree(mine.other);
     }
-    for (uint32_t i = 0; i < n_units; ++i) unit_status[i] = hu[i].status;
-    if (n_records) *n_records = n_rec;
-    if (getenv("PANDEPTH_TIMING"))
-        fprintf(stderr, "[timing]   device decode so far: %llu batches, H2D %.1f ms, inflate %.1f ms, walk %.1f ms, parse %.1f ms\n",
-                (unsigned long long)c->dd_batches, c->dd_ms[0], c->dd_ms[1], c->dd_ms[2], c->dd_ms[3]);
-#undef HIPDD
     return PD_OK;
 }
+
+} // extern "C"
+
+extern "C" {
 
 int pd_device_count(int *n)
 {
@@ -1134,7 +1381,9 @@ int pd_synchronize(pd_ctx *c)
     if (!c) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPOK(c, hipSetDevice(c->device));
-    int rc = flush_pending(c);
+    // a whole deferred sample in an otherwise empty context stays deferred when the direct window path may still take it
+    const bool keep_deferred = c->direct_windows && c->pristine && !c->pend.empty() && c->state == 0;
+    int rc = keep_deferred ? PD_OK : flush_pending(c);
     if (rc) return rc;
     HIPOK(c, hipStreamSynchronize(c->copy_stream));
     HIPOK(c, hipStreamSynchronize(c->stream));

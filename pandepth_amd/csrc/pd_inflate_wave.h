@@ -730,6 +730,11 @@ struct HostWave {                         // 64 emulated lanes
     static uint64_t bcast64(const Var<uint64_t> &x, int lane) { return x.v[lane]; }
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
+    static Var<uint64_t> excl_scan_max64(const Var<uint64_t> &x) { Var<uint64_t> r; uint64_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; if (x.v[l] > a) a = x.v[l]; } return r; }
+    static uint32_t reduce_or(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) a |= x.v[l]; return a; }
+    static uint32_t reduce_max(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
+    static uint64_t reduce_max64(const Var<uint64_t> &x) { uint64_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
+    static uint64_t reduce_min64(const Var<uint64_t> &x) { uint64_t a = ~0ull; for (int l = 0; l < 64; ++l) if (x.v[l] < a) a = x.v[l]; return a; }
 };
 
 #if defined(__HIPCC__)
@@ -772,6 +777,53 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         return m;
     }
     __device__ static __forceinline__ uint32_t uniform_u8(const uint8_t *p) { return *p; }
+    __device__ static __forceinline__ uint64_t shfl_up64(uint64_t v, int d)
+    {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ static __forceinline__ uint64_t shfl_xor64(uint64_t v, int d)
+    {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ static __forceinline__ Var<uint64_t> excl_scan_max64(const Var<uint64_t> &x)
+    {
+        const int lane = (int)(threadIdx.x & 63);
+        uint64_t m = x.v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = shfl_up64(m, d); if (lane >= d && y > m) m = y; }
+        const uint64_t up = shfl_up64(m, 1);
+        Var<uint64_t> r; r.v = lane ? up : 0ull; return r;
+    }
+    __device__ static __forceinline__ uint32_t reduce_or(const Var<uint32_t> &x)
+    {
+        uint32_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o);
+        return m;
+    }
+    __device__ static __forceinline__ uint32_t reduce_max(const Var<uint32_t> &x)
+    {
+        uint32_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
+        return m;
+    }
+    __device__ static __forceinline__ uint64_t reduce_max64(const Var<uint64_t> &x)
+    {
+        uint64_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint64_t y = shfl_xor64(m, o); m = y > m ? y : m; }
+        return m;
+    }
+    __device__ static __forceinline__ uint64_t reduce_min64(const Var<uint64_t> &x)
+    {
+        uint64_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint64_t y = shfl_xor64(m, o); m = y < m ? y : m; }
+        return m;
+    }
 };
 #endif
 

@@ -105,12 +105,14 @@ size_t bgzf_scratch_bytes(uint32_t n_blk);
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
                               int *status, void *scratch, unsigned n_wg);
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
-void launch_bam_walk(hipStream_t st, const uint8_t *buf, void *units, uint32_t n_units, uint64_t *rec_off, uint64_t rec_cap,
-                     const int *blk_status, const uint32_t *unit_first_blk, const uint32_t *unit_n_blk, uint64_t *dense_base);
-void launch_bam_parse(hipStream_t st, const uint8_t *buf, const void *units, uint32_t n_units, const uint64_t *dense_base,
-                      uint64_t n_rec_upper, const uint64_t *rec_off, uint32_t flag_mask, int32_t min_mapq, int32_t n_contigs,
-                      const uint32_t *contig_len, pd_iv *first, pd_iv *other, uint32_t other_cap, uint32_t *other_count,
-                      uint32_t *err);
-
 } // namespace pdk
+
+// the record walk of the device decode path (pd_bamwalk.h)
+namespace pdb2 { struct Cfg; struct Seg; struct LaneOut; }
+namespace pdk {
+void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes,
+                          const uint32_t *only, uint32_t n_only);
+void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
+                          pd_iv *first, pd_iv *other);
+}
 #endif

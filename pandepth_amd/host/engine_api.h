@@ -29,6 +29,13 @@ typedef struct pd_engine_api {
     /* optional (NULL = one context only): several GPUs in one process for `#.list` inputs */
     int (*device_count)(int *);
     int (*accumulate_from)(pd_ctx *dst, pd_ctx *src);
+    /* optional (NULL = the host decodes): GPU-side BAM decode in asynchronous batches, see pd_decode_* */
+    int (*decode_begin)(pd_ctx *, const pd_decode_cfg *);
+    int (*decode_acquire)(pd_ctx *, size_t, void **);
+    int (*decode_submit)(pd_ctx *, const pd_decode_batch *, int32_t *, pd_decode_result *);
+    int (*decode_end)(pd_ctx *);
+    int (*decode_abort)(pd_ctx *);
+    int (*set_param)(pd_ctx *, const char *, uint64_t);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -9,6 +9,7 @@ int main(int argc, char **argv)
     static const pd_engine_api api = {
         pd_create, pd_destroy, pd_strerror, pd_push_intervals, pd_scan, pd_reduce_intervals,
         pd_window_layout, pd_scan_reduce_windows, pd_reduce_windows, pd_read_depth, pd_synchronize, pd_push_bgzf_units, pd_device_count, pd_accumulate_from,
+        pd_decode_begin, pd_decode_acquire, pd_decode_submit, pd_decode_end, pd_decode_abort, pd_set_param,
     };
     const char *dev = getenv("PANDEPTH_DEVICE");
     return pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);

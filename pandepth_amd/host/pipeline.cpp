@@ -176,15 +176,12 @@ bool index_exists(const std::string &p) { return file_exists(p + ".bai") || file
 bool decode_range(AlnReader &rd, uint64_t begin, uint64_t stop, const ReadFilter &flt, const struct SpanIndex &spans,
                   RunSink *sink, uint64_t *n_rec, std::string *err);
 
-// GPU-side decode of a whole-contig-mode BAM (PANDEPTH_DEVICE_DECODE=1): the host only reads the
-// compressed bytes and cuts them into record-aligned units at index offsets; inflate, record walk,
-// filter, CIGAR walk and scatter run on the device (pd_push_bgzf_units).  Units the device hands
-// back (a record spilling past the unit's blocks, CG-tag CIGARs) are decoded on the host.
-bool read_indexed_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const struct SpanIndex &spans,
-                         const BaiIndex &bai, uint64_t first_voff, Engine *eng);
+struct DevRange;
+int read_bam_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans, const RegionModel &rm,
+                    int kind, uint64_t first_voff, const BaiIndex *bai, bool sorted, Engine *eng);
 
 bool read_indexed(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans,
-                  Engine *eng)
+                  Engine *eng, const RegionModel *rm = nullptr)
 {
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     BaiIndex bai;
@@ -224,8 +221,10 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     //  * GFF/BED targets: only the index chunks that can hold reads overlapping a (widened) merged
     //    span, like the reference's multi-region iterator (PD:698-730) — most of the file is
     //    never inflated.
-    if (have_bai && spans.synthetic && eng->api->push_bgzf_units && getenv("PANDEPTH_DEVICE_DECODE"))
-        return read_indexed_device(path, o, main_hdr, spans, bai, probe.tell(), eng);
+    if (have_bai && rm) {
+        const int r = read_bam_device(path, o, main_hdr, spans, *rm, 0, probe.tell(), &bai, probe.header().sorted_coordinate(), eng);
+        if (r != 0) return r > 0;
+    }
     std::vector<BaiIndex::Chunk> work;
     int threads = o.threads < 1 ? 1 : o.threads;
     if (have_bai && !spans.synthetic) {
@@ -305,153 +304,238 @@ bool decode_range(AlnReader &rd, uint64_t begin, uint64_t stop, const ReadFilter
     return true;
 }
 
-bool read_indexed_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans,
-                         const BaiIndex &bai, uint64_t first_voff, Engine *eng)
+// ---- GPU-side decode (the default for BAM input) -----------------------------------------------------------------
+// The host only READS: compressed bytes go from the page cache straight into the engine's pinned batch buffers, BGZF
+// member boundaries are found from the 18-byte headers, and pd_decode_submit does the rest on the device (inflate, one
+// wave per member; record boundaries; filter; CIGAR walk; runs resident in HBM).  Three input shapes:
+//   * indexed, whole-contig modes: the file is cut at index offsets (record boundaries) into batches of ~96 MB;
+//   * indexed, GFF / BED targets: the index chunks that can hold reads overlapping a (widened) merged span (the
+//     reference's multi-region iterator, PD:698-730) become the units of the batches; the region test runs on the device;
+//   * no index (whole-contig modes): the file is cut at arbitrary offsets, every batch finds its first BGZF member by
+//     the member signature and its first record on the device (PD_UNIT_GUESS); afterwards batch k's "next record" must
+//     be batch k+1's "first record" (compared as virtual offsets), otherwise the input is decoded on the host instead.
+// Units the device hands back (a record longer than the spare members, CIGARs in the CG tag) are decoded by the host
+// reader.  Returns 1 done, 0 not applicable / declined (nothing was counted: the caller uses the host path), -1 error.
+struct DevRange { uint64_t vbeg, vend; };                  // one unit: records starting in [vbeg, vend) (virtual offsets; vend UINT64_MAX = EOF)
+
+int read_bam_device(const std::string &path, const Options &o, const AlnHeader &main_hdr, const SpanIndex &spans, const RegionModel &rm,
+                    int kind, uint64_t first_voff, const BaiIndex *bai, bool sorted, Engine *eng)
 {
+    const pd_engine_api *api = eng->api;
+    if (!api->decode_begin || !api->decode_acquire || !api->decode_submit || !api->decode_end || !api->decode_abort) return 0;
+    if (const char *e = getenv("PANDEPTH_DEVICE_DECODE")) if (e[0] == '0') return 0;
+    if (kind != 0 && !spans.synthetic) return 0;            // the no-index span cursor (PD:4608-4646) stays on the host
     const uint64_t F = file_size(path);
-    // units as fine as the index allows (a device thread walks one unit's records sequentially)
-    uint64_t unit_bytes = (uint64_t)256 << 10;
-    if (const char *e = getenv("PANDEPTH_DD_UNIT_KB")) unit_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 10;
-    uint64_t batch_bytes = (uint64_t)2048 << 20;
-    if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = strtoull(e, nullptr, 10) << 20;
-    const std::vector<uint64_t> cuts = bai.split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / unit_bytes + 1));
-    const size_t n_units = cuts.size() - 1;
-    auto coff_of = [&](size_t u) { return cuts[u] == UINT64_MAX ? F : (cuts[u] >> 16); };
-    // Heterogeneous schedule over ONE list of units: device feeders take large batches from the
-    // front (the inflate kernel wants ~100 K blocks per launch), host decoders take small ranges from
-    // the back (libdeflate on the remaining threads); they meet somewhere in the middle.
-    int threads = o.threads < 1 ? 1 : o.threads;
-    int feeders = 2;
-    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
-    if (feeders > threads) feeders = threads;
-    const int host_workers = threads - feeders;
-    std::mutex qmu;
-    size_t front = 0, back = n_units;
-    auto take_front = [&](size_t *u0, size_t *u1) -> bool {
-        std::lock_guard<std::mutex> lk(qmu);
-        if (front >= back) return false;
-        size_t v = front + 1;
-        while (v < back && coff_of(v) - coff_of(front) < batch_bytes) ++v;
-        *u0 = front; *u1 = v; front = v;
-        return true;
-    };
-    auto take_back = [&](size_t *u0, size_t *u1) -> bool {
-        std::lock_guard<std::mutex> lk(qmu);
-        if (front >= back) return false;
-        const size_t n = std::min<size_t>(8, back - front);
-        *u1 = back; *u0 = back - n; back -= n;
-        return true;
-    };
-    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
-    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, n_batches{0}, us_read{0}, us_scan{0}, us_push{0};
-    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto host_worker = [&]() {
-        AlnReader rd;
-        std::string e2;
-        if (!rd.open(path, &e2)) { eng->fail(e2); return; }
-        RunSink sink(eng);
-        size_t u0, u1;
-        while (eng->ok() && take_back(&u0, &u1)) {
-            uint64_t nr = 0;
-            if (!decode_range(rd, cuts[u0], cuts[u1], flt, spans, &sink, &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); return; }
-            n_host += nr;
+    if (F < 28) return 0;
+    const uint64_t SPARE = 5 * 65536;                        // bytes read past a unit's end so that its last record can finish
+    uint64_t batch_bytes = (uint64_t)96 << 20;
+    if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+    // ---- the work list: batches of units ----
+    std::vector<std::vector<DevRange>> batches;
+    const bool guess = kind != 0;
+    if (!guess) {
+        std::vector<BaiIndex::Chunk> work;
+        if (!spans.synthetic) {
+            for (size_t t = 0; t < spans.per_tid.size(); ++t)
+                for (auto &sp : spans.per_tid[t]) bai->query((int32_t)t, sp.first, sp.second, &work);
+            BaiIndex::normalise(&work);
+        } else {
+            const std::vector<uint64_t> cuts = bai->split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / batch_bytes + 1));
+            for (size_t i = 0; i + 1 < cuts.size(); ++i) work.emplace_back(cuts[i], cuts[i + 1]);
         }
-    };
+        uint64_t acc = 0;
+        for (auto &c : work) {
+            const uint64_t sz = ((c.second == UINT64_MAX ? F : (c.second >> 16)) - (c.first >> 16)) + SPARE;
+            if (batches.empty() || acc + sz > batch_bytes) { batches.emplace_back(); acc = 0; }
+            batches.back().push_back(DevRange{c.first, c.second});
+            acc += sz;
+        }
+    } else {
+        for (uint64_t a = first_voff >> 16; a < F; a += batch_bytes) batches.push_back({DevRange{a == (first_voff >> 16) ? first_voff : (a << 16), UINT64_MAX}});
+    }
+    if (batches.empty()) return 1;
+    // ---- configuration: who is counted ----
+    std::vector<uint8_t> on(main_hdr.names.size(), 0);
+    for (size_t t = 0; t < on.size(); ++t) on[t] = rm.has((int32_t)t) ? 1 : 0;
+    std::vector<uint32_t> soff; std::vector<int32_t> sflat;
+    pd_decode_cfg cfg{};
+    cfg.flag_mask = o.flag_mask; cfg.min_mapq = o.min_mapq; cfg.contig_on = on.data(); cfg.sorted = sorted ? 1 : 0;
+    if (!spans.synthetic) {
+        soff.assign(on.size() + 1, 0);
+        for (size_t t = 0; t < on.size(); ++t) {
+            soff[t] = (uint32_t)(sflat.size() / 2);
+            if (t < spans.per_tid.size()) for (auto &sp : spans.per_tid[t]) { sflat.push_back(sp.first); sflat.push_back(sp.second); }
+            on[t] = t < spans.per_tid.size() && !spans.per_tid[t].empty();
+        }
+        soff[on.size()] = (uint32_t)(sflat.size() / 2);
+        if (sflat.empty()) sflat.push_back(0);
+        cfg.span_off = soff.data(); cfg.spans = sflat.data();
+    }
+    if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
+
+    const size_t n_batches = batches.size();
+    std::atomic<size_t> next{0};
+    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_submit{0};
+    std::atomic<int> declined{0};
+    std::vector<uint64_t> chain_first(n_batches, UINT64_MAX), chain_next(n_batches, UINT64_MAX);   // no-index: virtual offsets
+    double ms_sum[4] = {0, 0, 0, 0}; std::mutex ms_mu;
+    ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto feeder = [&]() {
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
-        AlnReader rd;                                         // only for handed-back units
-        bool rd_open = false;
-        std::vector<uint8_t> blob;
+        AlnReader rd; bool rd_open = false;                  // only for handed-back units
         std::vector<pd_bgzf_block> blocks;
-        std::vector<uint64_t> coff;                           // file offset of each scanned block
-        std::vector<pd_bgzf_unit> units;
+        std::vector<uint64_t> bfile;                         // file offset of every scanned member
+        std::vector<pd_decode_unit> units;
         std::vector<int32_t> status;
-        RunSink sink(eng);
-        size_t u0, u1;
-        while (eng->ok() && take_front(&u0, &u1)) {
-            ++n_batches;
-            const uint64_t c0 = cuts[u0] >> 16;
-            const uint64_t c_end = cuts[u1] == UINT64_MAX ? F : std::min<uint64_t>(F, (cuts[u1] >> 16) + 4 * 65536);
+        std::unique_ptr<RunSink> sink;
+        for (;;) {
+            const size_t bi = next.fetch_add(1);
+            if (bi >= n_batches || !eng->ok() || declined.load()) break;
+            const std::vector<DevRange> &rs = batches[bi];
+            // bytes to read: every unit's members + spare
+            std::vector<std::pair<uint64_t, uint64_t>> fr;   // file ranges
+            uint64_t total = 0;
+            for (auto &r : rs) {
+                uint64_t a = r.vbeg >> 16, b = r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16);
+                b = std::min(F, b + SPARE);
+                if (guess && bi > 0) a = r.vbeg >> 16;       // arbitrary offset: the first member is found below
+                fr.emplace_back(a, b); total += b - a;
+            }
+            void *hb = nullptr;
+            if (!eng->ck(api->decode_acquire(eng->ctx, (size_t)total + 64, &hb), "pd_decode_acquire")) break;
+            uint8_t *buf = (uint8_t *)hb;
             const uint64_t t_a = now_us();
-            blob.resize((size_t)(c_end - c0));
-            for (size_t got = 0; got < blob.size();) {
-                const ssize_t n = pread(fd, blob.data() + got, blob.size() - got, (off_t)(c0 + got));
-                if (n <= 0) { eng->fail("read error on " + path); ::close(fd); return; }
-                got += (size_t)n;
+            blocks.clear(); bfile.clear(); units.clear();
+            uint64_t pos = 0, uo = 0; bool bad = false;
+            for (size_t k = 0; k < rs.size() && !bad; ++k) {
+                const uint64_t a = fr[k].first, b = fr[k].second;
+                for (uint64_t got = 0; got < b - a;) {
+                    const ssize_t n = pread(fd, buf + pos + got, (size_t)(b - a - got), (off_t)(a + got));
+                    if (n <= 0) { eng->fail("read error on " + path); bad = true; break; }
+                    got += (uint64_t)n;
+                }
+                if (bad) break;
+                const uint8_t *w = buf + pos; const uint64_t wn = b - a;
+                uint64_t p = 0;
+                if (guess && bi > 0) {
+                    // the first member at or after this arbitrary offset: the member signature, confirmed by the two that follow
+                    bool found = false;
+                    for (; p + 18 <= wn && p < 3 * 65536; ++p) {
+                        if (w[p] != 0x1f || w[p + 1] != 0x8b || w[p + 2] != 8 || !(w[p + 3] & 4)) continue;
+                        uint64_t q = p; int okc = 0;
+                        for (; okc < 3 && q + 18 <= wn; ++okc) { uint32_t d0 = 0; const uint32_t bs = bgzf_block_size(w + q, wn - q, &d0); if (!bs) break; q += bs; }
+                        if (okc == 3 || (okc > 0 && q + 18 > wn)) { found = true; break; }
+                    }
+                    if (!found) { declined = 1; bad = true; break; }
+                }
+                const size_t b0 = blocks.size();
+                const uint64_t own_end = guess ? std::min(F, (rs[k].vbeg >> 16) + batch_bytes) : 0;      // members starting before this belong to the batch
+                long stop_blk = -1;
+                for (; p + 18 <= wn;) {
+                    uint32_t doff = 0;
+                    const uint32_t bs = bgzf_block_size(w + p, wn - p, &doff);
+                    if (bs == 0 || p + bs > wn) break;       // partial member at the end of the window
+                    const uint32_t isize = w[p + bs - 4] | (w[p + bs - 3] << 8) | (w[p + bs - 2] << 16) | ((uint32_t)w[p + bs - 1] << 24);
+                    if (guess && stop_blk < 0 && a + p >= own_end) stop_blk = (long)blocks.size();
+                    bfile.push_back(a + p);
+                    blocks.push_back(pd_bgzf_block{pos + p + doff, uo, bs - doff - 8, isize});
+                    uo += isize; p += bs;
+                }
+                if (blocks.size() == b0) { if (guess) { continue; } eng->fail("index offsets of " + path + " do not match its BGZF blocks"); bad = true; break; }
+                pd_decode_unit un{};
+                un.first_block = (uint32_t)b0; un.n_blocks = (uint32_t)(blocks.size() - b0);
+                un.avail = uo;
+                if (guess) {
+                    un.start = blocks[b0].out_off + (bi == 0 ? (rs[k].vbeg & 0xffff) : 0);
+                    un.flags = bi == 0 ? 0 : PD_UNIT_GUESS;
+                    un.stop = stop_blk >= 0 ? blocks[(size_t)stop_blk].out_off : uo;
+                } else {
+                    if (bfile[b0] != (rs[k].vbeg >> 16)) { eng->fail("index offsets of " + path + " do not match its BGZF blocks"); bad = true; break; }
+                    un.start = blocks[b0].out_off + (rs[k].vbeg & 0xffff);
+                    if (rs[k].vend == UINT64_MAX) un.stop = uo;
+                    else {
+                        const auto it = std::lower_bound(bfile.begin() + (long)b0, bfile.end(), rs[k].vend >> 16);
+                        if (it == bfile.end() || *it != (rs[k].vend >> 16)) {
+                            if ((rs[k].vend >> 16) >= F || (rs[k].vend & 0xffff) == 0) un.stop = uo;     // an offset at the very end of the file
+                            else { eng->fail("index offsets of " + path + " do not match its BGZF blocks"); bad = true; break; }
+                        } else un.stop = blocks[(size_t)(it - bfile.begin())].out_off + (rs[k].vend & 0xffff);
+                    }
+                }
+                if (un.start > un.stop) un.start = un.stop;
+                units.push_back(un);
+                pos += wn;
             }
             const uint64_t t_b = now_us();
-            blocks.clear(); coff.clear();
-            uint64_t uo = 0;
-            for (size_t p = 0; p + 18 <= blob.size();) {
-                uint32_t doff = 0;
-                const uint32_t bs = bgzf_block_size(blob.data() + p, blob.size() - p, &doff);
-                if (bs == 0 || p + bs > blob.size()) break;   // partial block at the end of the window
-                const uint8_t *q = blob.data() + p;
-                const uint32_t isize = q[bs - 4] | (q[bs - 3] << 8) | (q[bs - 2] << 16) | ((uint32_t)q[bs - 1] << 24);
-                coff.push_back(c0 + p);
-                blocks.push_back(pd_bgzf_block{p + doff, uo, bs - doff - 8, isize});
-                uo += isize; p += bs;
+            us_read += t_b - t_a;
+            if (bad || units.empty()) {
+                // nothing to do for this batch: hand the buffer back with an empty submit
+                pd_decode_batch e{}; e.host_buf = hb; int32_t dummy = 0; api->decode_submit(eng->ctx, &e, &dummy, nullptr);
+                if (bad) break; else continue;
             }
-            auto block_of = [&](uint64_t file_off) -> long {
-                const auto it = std::lower_bound(coff.begin(), coff.end(), file_off);
-                return it != coff.end() && *it == file_off ? (long)(it - coff.begin()) : -1;
-            };
-            units.clear();
-            bool ok = !blocks.empty();
-            for (size_t u = u0; u < u1 && ok; ++u) {
-                const long fb = block_of(cuts[u] >> 16);
-                if (fb < 0) { ok = false; break; }
-                pd_bgzf_unit un;
-                un.start = blocks[fb].out_off + (cuts[u] & 0xffff);
-                long lb;
-                if (cuts[u + 1] == UINT64_MAX) { un.stop = uo; lb = (long)blocks.size() - 1; }
-                else {
-                    const long sb = block_of(cuts[u + 1] >> 16);
-                    if (sb < 0) { ok = false; break; }
-                    un.stop = blocks[sb].out_off + (cuts[u + 1] & 0xffff);
-                    lb = std::min<long>((long)blocks.size() - 1, sb + 1);      // one spare block for the last record
-                }
-                un.avail = blocks[lb].out_off + blocks[lb].out_len;
-                un.first_block = (uint32_t)fb; un.n_blocks = (uint32_t)(lb - fb + 1);
-                units.push_back(un);
-            }
-            if (!ok) { eng->fail("index offsets of " + path + " do not match its BGZF blocks"); break; }
             status.assign(units.size(), 0);
-            uint64_t nrec = 0;
-            const uint64_t t_c = now_us();
-            us_read += t_b - t_a; us_scan += t_c - t_b;
-            const bool pushed = eng->ck(eng->api->push_bgzf_units(eng->ctx, blob.data(), blob.size(), blocks.data(), (uint32_t)blocks.size(),
-                                                                units.data(), (uint32_t)units.size(), uo, o.flag_mask, o.min_mapq,
-                                                                status.data(), &nrec), "pd_push_bgzf_units");
-            us_push += now_us() - t_c;
-            if (!pushed) break;
-            n_dev += nrec;
-            for (size_t k = 0; k < units.size(); ++k) {
-                if (status[k] == 0) continue;
-                if (status[k] != 1) { eng->fail("corrupt BGZF/BAM data in " + path); break; }
-                ++n_back;
-                std::string e2;
-                if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
-                uint64_t nr = 0;
-                if (!decode_range(rd, cuts[u0 + k], cuts[u0 + k + 1], flt, spans, &sink, &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); break; }
-                n_host += nr;
+            pd_decode_batch bt{}; bt.host_buf = hb; bt.n_bytes = (size_t)pos; bt.blocks = blocks.data(); bt.n_blocks = (uint32_t)blocks.size();
+            bt.inflated_bytes = uo; bt.units = units.data(); bt.n_units = (uint32_t)units.size(); bt.order = bi;
+            pd_decode_result res;
+            const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
+            us_submit += now_us() - t_b;
+            if (!ok) break;
+            n_dev += res.n_reads;
+            { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
+            auto voff_of = [&](uint64_t u) -> uint64_t {      // inflated offset of the batch -> virtual file offset
+                if (u == UINT64_MAX) return UINT64_MAX;
+                size_t lo = 0, hi = blocks.size();
+                while (hi - lo > 1) { const size_t m = (lo + hi) / 2; if (blocks[m].out_off <= u) lo = m; else hi = m; }
+                // the end of a member is the start of the next one
+                while (lo + 1 < blocks.size() && u >= blocks[lo].out_off + blocks[lo].out_len) ++lo;
+                if (u >= blocks[lo].out_off + blocks[lo].out_len) return UINT64_MAX - 1;          // past everything this batch saw
+                return (bfile[lo] << 16) | (u - blocks[lo].out_off);
+            };
+            if (guess) {
+                if (status[0] != 0) { declined = 1; break; }
+                chain_first[bi] = bi == 0 ? first_voff : voff_of(res.first_start);
+                chain_next[bi] = voff_of(res.next_start);
+            } else {
+                for (size_t k = 0; k < units.size(); ++k) {
+                    if (status[k] == 0) continue;
+                    if (status[k] != 1) { eng->fail("corrupt BGZF/BAM data in " + path); break; }
+                    ++n_back;
+                    std::string e2;
+                    if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
+                    if (!sink) sink.reset(new RunSink(eng));
+                    uint64_t nr = 0;
+                    if (!decode_range(rd, rs[k].vbeg, rs[k].vend, flt, spans, sink.get(), &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); break; }
+                    n_host += nr;
+                }
             }
         }
         ::close(fd);
     };
+    int feeders = std::min<int>(std::max(1, o.threads), 6);
+    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
+    if ((size_t)feeders > n_batches) feeders = (int)n_batches;
     {
         std::vector<std::thread> th;
-        for (int i = 0; i < feeders; ++i) th.emplace_back(feeder);
-        for (int i = 0; i < host_workers; ++i) th.emplace_back(host_worker);
+        for (int i = 1; i < feeders; ++i) th.emplace_back(feeder);
+        feeder();
         for (auto &t : th) t.join();
     }
+    if (guess && eng->ok() && !declined.load()) {
+        // the record chain across the batches (virtual offsets; the end of a member equals the start of the next one)
+        for (size_t k = 0; k + 1 < n_batches; ++k)
+            if (chain_next[k] != chain_first[k + 1] || chain_next[k] >= UINT64_MAX - 1) { declined = 1; break; }
+    }
     if (getenv("PANDEPTH_TIMING"))
-        fprintf(stderr, "[timing] device decode: %zu units; device: %llu batches, %llu records (%llu units handed back); host decoders (%d threads): %llu records; "
-                        "feeder thread-seconds: read %.2f, block scan %.2f, pd_push_bgzf_units %.2f\n",
-                n_units, (unsigned long long)n_batches.load(), (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(),
-                host_workers, (unsigned long long)n_host.load(), us_read.load() / 1e6, us_scan.load() / 1e6, us_push.load() / 1e6);
-    return eng->ok();
+        fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders, %llu records on the device, %llu units handed back (%llu records on the host)%s; "
+                        "feeder thread-seconds: read+scan %.2f, submit %.2f; device ms summed over batches: H2D %.1f, inflate %.1f, walk %.1f, emit %.1f\n",
+                n_batches, guess ? "no index: guessed starts" : spans.synthetic ? "index cuts" : "index chunks of the targets", feeders,
+                (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(), (unsigned long long)n_host.load(), declined.load() ? " — DECLINED" : "",
+                us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3]);
+    if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
+    if (declined.load()) { api->decode_abort(eng->ctx); return 0; }          // nothing of this input has been counted
+    if (!eng->ck(api->decode_end(eng->ctx), "pd_decode_end")) return -1;
+    return 1;
 }
 
 // No index, header says SO:coordinate (PD:4604-4671): one cursor per contig over its merged spans.
@@ -799,6 +883,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
     }
     Engine &eng = *engs[0];
+    // whole-contig statistics straight from the runs when a sample ends up resident and deferred (pd_scan_reduce_windows)
+    if (api->set_param) for (auto &e : engs) api->set_param(e->ctx, "direct_windows", 1);
     tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
@@ -846,12 +932,19 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             Engine *e = engs[k].get();
             for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
                 const Input &in = inputs[i];
-                if (in.kind == 0) { if (!read_indexed(in.path, o_part, hdr, spans, e)) return; continue; }
+                if (in.kind == 0) { if (!read_indexed(in.path, o_part, hdr, spans, e, &rm)) return; continue; }
                 AlnReader rd;
                 AlnReader *r = &rd;
                 std::string e2;
                 if (!list_mode) r = &first;                              // already positioned after the header
                 else if (!rd.open(in.path, &e2)) { e->fail("cannot open " + in.path); return; }
+                if (r->is_bam()) {
+                    // whole-contig modes: the device decodes the stream (every read of a contig with targets is counted on
+                    // all three of the reference's paths there); 0 = not applicable or declined, nothing counted yet
+                    const int d = read_bam_device(in.path, o_part, hdr, spans, rm, in.kind, r->tell(), nullptr, in.kind == 1, e);
+                    if (d > 0) continue;
+                    if (d < 0) return;
+                }
                 r->set_threads(o_part.threads > 1 ? (o_part.threads > 32 ? 32 : o_part.threads) : 0);
                 if (!(in.kind == 1 ? read_sorted_stream(r, o_part, hdr, rm, e) : read_all(r, o_part, hdr, rm, e))) return;
             }

@@ -38,22 +38,37 @@ def test_pandepth_cli_byte_identical(case, threads, tmp_path):
         assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix + " (gz bytes)"
 
 
-DD_CASES = [e for e in MANIFEST if "-g" not in e["args"] and "-b" not in e["args"] and "-s" not in e["args"]
-            and e["args"][1].endswith(".bam") and "noidx" not in e["args"][1] and "unsorted" not in e["args"][1]]
+BAM_CASES = [e for e in MANIFEST if e["args"][1].endswith(".bam")]
 
 
-@pytest.mark.parametrize("batch_mb", ["", "1"])
-@pytest.mark.parametrize("case", DD_CASES, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
-def test_pandepth_cli_device_decode_byte_identical(case, batch_mb, tmp_path):
-    """PANDEPTH_DEVICE_DECODE=1: BGZF inflate + record parsing on the GPU for the whole-contig modes."""
+@pytest.mark.parametrize("case", BAM_CASES, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_pandepth_cli_device_decode_is_the_default(case, tmp_path):
+    """BAM input is decoded on the GPU (BGZF inflate, record boundaries, filter, CIGAR walk) in every mode that has
+    a device form: whole-contig modes with or without an index, GFF / BED targets with an index.  The timing line says so."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_DEVICE_DECODE="1", PANDEPTH_TIMING="1")
-    if batch_mb:
-        env["PANDEPTH_DD_BATCH_MB"] = batch_mb
+    env = dict(os.environ, PANDEPTH_TIMING="1")
     args = [CLI] + case["args"] + ["-o", str(tmp_path / "o")] + ([] if "-t" in case["args"] else ["-t", "3"])
     p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
-    assert b"device decode:" in p.stderr
+    no_index = "-s" in case["args"] or "noidx" in case["args"][1] or "unsorted" in case["args"][1]
+    targets = "-g" in case["args"] or "-b" in case["args"]
+    if case["outputs"] and not (no_index and targets):
+        assert b"device decode:" in p.stderr, p.stderr.decode()[-800:]
+    assert p.stdout.decode() == case["stdout"]
+    for suffix, meta in case["outputs"].items():
+        gz = (tmp_path / ("o." + suffix)).read_bytes()
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix
+
+
+@pytest.mark.parametrize("case", BAM_CASES[::3], ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
+def test_pandepth_cli_host_decode_byte_identical(case, tmp_path):
+    """PANDEPTH_DEVICE_DECODE=0: the host readers (libdeflate + pd_push_intervals) still give the same bytes."""
+    d = os.path.join(HERE, "golden", case["fixture"])
+    env = dict(os.environ, PANDEPTH_DEVICE_DECODE="0", PANDEPTH_TIMING="1")
+    args = [CLI] + case["args"] + ["-o", str(tmp_path / "o")] + ([] if "-t" in case["args"] else ["-t", "3"])
+    p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
+    assert b"device decode:" not in p.stderr
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()

@@ -62,7 +62,7 @@ def sort_iv(iv):
 
 
 def test_abi_version():
-    assert pda.load().pd_abi_version() == 1
+    assert pda.load().pd_abi_version() == 2
 
 
 @pytest.mark.parametrize("wrap", [0, 18])

@@ -69,7 +69,8 @@ CASES = [
 BINARIES = [
     pytest.param(os.path.join(HERE, "harness", "pandepth_oracle_cli"), id="host+oracle-engine"),
     pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth"), id="pandepth-mi355x", marks=pytest.mark.gpu),
-    pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":dd", id="pandepth-mi355x-device-decode", marks=pytest.mark.gpu),
+    pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":dd", id="pandepth-mi355x-small-batches", marks=pytest.mark.gpu),
+    pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":host", id="pandepth-mi355x-host-decode", marks=pytest.mark.gpu),
 ]
 
 
@@ -77,9 +78,13 @@ BINARIES = [
 @pytest.mark.parametrize("name,args,suffix", CASES, ids=[c[0] for c in CASES])
 def test_generated_inputs_match_reference(data, cli, name, args, suffix):
     env = dict(os.environ)
-    if cli.endswith(":dd"):            # GPU-side BGZF inflate + record parsing (small batches: several per file)
+    # the pandepth binary decodes BAM on the GPU by default (inflate, record boundaries, filter, CIGAR walk)
+    if cli.endswith(":dd"):            # ... in small batches: several per file, several feeder threads
         cli = cli[:-3]
-        env.update(PANDEPTH_DEVICE_DECODE="1", PANDEPTH_DD_BATCH_MB="8")
+        env.update(PANDEPTH_DD_BATCH_MB="2")
+    elif cli.endswith(":host"):        # ... or not at all: the host readers (libdeflate) feed pd_push_intervals
+        cli = cli[:-5]
+        env.update(PANDEPTH_DEVICE_DECODE="0")
     for t in ("1", "5"):
         p = subprocess.run([cli] + args + ["-o", "mine_" + name, "-t", t], cwd=data, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=900, env=env)
