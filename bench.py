@@ -30,8 +30,12 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   the older reduce-to-rank-0 forms, PD_BENCH_PIPELINE=0 the unpipelined order.
 
 The run stream is synthetic (tools/synth.py) and is resident in HBM before the
-timed region, as the contract asks; value = records / step time.  Host-side BAM decode is NOT in
-this number (see DESIGN.md for the end-to-end figures).
+timed region, as the contract asks; value = records / step time, on the kernel the `pandepth`
+executable itself runs for this mode (its GPU decoder leaves the sample's runs resident and deferred,
+then pd_scan_reduce_windows takes the direct path).  BAM decode is NOT in `value`; it IS in the
+"e2e" object of the same JSON line: the executable and the reference binary on one payload BAM
+generated on this box (tools/bamgen), process wall clock, outputs compared byte for byte.  The
+reference's run there is also the contract's "cpu_baseline".
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run,
 one rank per GPU, each rank holding its own sample ("one BAM per GPU", #.list mode).
@@ -70,46 +74,70 @@ def cpu_quota():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(sample_records, log):
-    """Times the reference's own CPU path (oracle/_ref/pandepth_ref, built from /root/reference in
-    the dev container) on the host cores, on a bounded sample of the same workload; falls back
-    to the single-threaded C restatement (oracle/libpd_oracle.so) when the binary is absent."""
-    from tools import synth
-    ncpu = os.cpu_count() or 1
-    scale = sample_records / 1.0e9
-    names, lens = synth.genome_c2(scale=scale)
-    rec = synth.gen_records_numpy(lens, sample_records, seed=4242)
+def _best_wall(cmd, reps, env=None):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, timeout=1800)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def e2e_leg(records):
+    """END TO END, product path: the `pandepth` executable (GPU-side BGZF inflate + record parsing + the direct window
+    kernel) and the reference binary on the SAME coordinate-sorted BAM with SEQ/QUAL/tag payload, written here by
+    tools/bamgen (libdeflate level 6, BAI alongside), whole-chromosome mode, process wall clock (exec to exit, warm page
+    cache, best of 3 / 2), outputs compared byte for byte.  Returns (e2e object, cpu_baseline object).
+    The reference run is the contract's cpu_baseline (kind "reference"): its own multithreaded CPU path on this box's
+    host cores, the file being the bounded sample of configs[1]."""
+    gen = os.path.join(ROOT, "tools", "bamgen")
+    if not os.access(gen, os.X_OK):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tools", "bamgen.cpp"), "-lz", "-ldl", "-o", gen], check=True)
+    cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
     ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
-    s2b = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
-    sample = "%d records, %.0f Mb scaled C2 genome (%d contigs), 50x, whole-chromosome mode" % (
-        sample_records, lens.sum() / 1e6, len(lens))
-    if os.access(ref, os.X_OK) and os.access(s2b, os.X_OK):
-        with tempfile.TemporaryDirectory(prefix="pdbench") as td:
-            raw, bam = os.path.join(td, "raw.bam"), os.path.join(td, "s.bam")
-            synth.write_bam(raw, names, lens, rec, procs=min(32, ncpu))
-            subprocess.run([s2b, raw, bam], check=True, stderr=subprocess.DEVNULL)
-            threads = min(36, ncpu)
-            best = None
-            for _ in range(2):                       # second run = warm page cache
-                t0 = time.perf_counter()
-                subprocess.run([ref, "-i", bam, "-o", os.path.join(td, "o"), "-t", str(threads)], check=True,
-                               stdout=subprocess.DEVNULL)
-                best = time.perf_counter() - t0
-            return {"value": sample_records / best, "unit": "records/s", "cores": min(threads, cpu_quota()),
-                    "kind": "reference",
-                    "sample": sample + "; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads), cgroup "
-                              "quota %d CPUs, BAM+BAI, warm cache, %.2f s" % (threads, cpu_quota(), best)}
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the checker's directory is on the path for this leg only
-    import pd_oracle as O
-    first, other = synth.records_to_runs(rec)
-    runs = np.concatenate([first, other])
-    t0 = time.perf_counter()
-    d, off = O.depth_from_intervals(list(lens), runs)
-    regs = np.array([[t, 1, int(l)] for t, l in enumerate(lens)], dtype=np.int32)
-    O.stat_regions(d, off, regs, 1)
-    dt = time.perf_counter() - t0
-    return {"value": sample_records / dt, "unit": "records/s", "cores": 1, "kind": "port",
-            "sample": sample + "; oracle/pd_oracle.c increment+stat loops, no BAM decode (%.2f s)" % dt}
+    quota = cpu_quota()
+    td = tempfile.mkdtemp(prefix="pde2e", dir="/tmp")
+    bam = os.path.join(td, "s.bam")
+    try:
+        t0 = time.perf_counter()
+        g = subprocess.run([gen, "-o", bam, "-n", str(int(records)), "-t", str(min(32, os.cpu_count() or 1))], check=True,
+                           stderr=subprocess.PIPE, timeout=1800)
+        t_gen = time.perf_counter() - t0
+        size = os.path.getsize(bam)
+        threads = max(4, min(16, quota))
+        mine = os.path.join(td, "mine")
+        w_dev = _best_wall([cli, "-i", bam, "-o", mine, "-t", str(threads)], 3)
+        w_host = _best_wall([cli, "-i", bam, "-o", os.path.join(td, "host"), "-t", str(threads)], 1,
+                            env=dict(os.environ, PANDEPTH_DEVICE_DECODE="0"))
+        e2e = {
+            "records": int(records), "bam_bytes": size, "bam_bytes_per_record": round(size / records, 1),
+            "bam": "tools/bamgen: coordinate-sorted, 150-base reads with names, SEQ from a synthetic reference, binned QUAL, "
+                   "NM/MD/AS/XS/RG tags; BGZF by libdeflate level 6; .bai alongside (" + g.stderr.decode().strip().replace("bamgen: ", "") +
+                   "; generated in %.0f s)" % t_gen,
+            "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache",
+            "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads,
+                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_tiles; host only reads the file"},
+            "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
+                                     "path": "PANDEPTH_DEVICE_DECODE=0: libdeflate on the host threads + pd_push_intervals"},
+            "cpu_quota": quota, "host_cpus": os.cpu_count(),
+        }
+        cb = None
+        if os.access(ref, os.X_OK):
+            rthreads = 36
+            w_ref = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", str(rthreads)], 2)
+            same = open(mine + ".chr.stat.gz", "rb").read() == open(os.path.join(td, "ref.chr.stat.gz"), "rb").read()
+            e2e["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": records / w_ref, "threads": rthreads}
+            e2e["byte_identical"] = same
+            e2e["speedup_vs_reference"] = round(w_ref / w_dev, 2)
+            cb = {"value": records / w_ref, "unit": "records/s", "cores": min(rthreads, quota), "kind": "reference",
+                  "sample": "%d records of the configs[1] workload with payload (%.2f GB BAM, %.0f B/record compressed), BAM+BAI, warm "
+                            "cache; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads) on a cgroup quota of %d CPUs, "
+                            "%.2f s wall" % (records, size / 1e9, size / records, rthreads, quota, w_ref)}
+        return e2e, cb
+    finally:
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():
@@ -118,7 +146,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
-    ap.add_argument("--cpu-sample", type=float, default=4.0e7, help="records in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--e2e-records", type=float, default=1.0e8,
+                    help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -322,10 +351,11 @@ def main():
         # HBM bytes per launch from the PMC counters: taken from the committed rocprofv3 --pmc passes
         # (tools/pmc_collect.sh -> profiles/*_pmc_traffic.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated
         # there); bench.py itself never runs under a profiler
-        traffic = None
+        traffic, pmc_file = None, ""
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+            pmc = json.load(open(pmc_file))
             key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
                    "direct_tiles": "k_direct_tiles<4, 5>"}.get(dom)
             key = next((k for k in pmc["kernels"] if key and k.startswith(key.rstrip(">"))), None)    # template arguments may grow
@@ -333,14 +363,20 @@ def main():
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, IndexError, KeyError, ValueError):
             traffic = None
+        # `traffic` is a live PMC measurement or null; this run is not under a profiler, so the committed figure is
+        # reported beside it with its source, never as if it had been measured here
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kd["frac"], "traffic": traffic,
+                    "unit": "GB/s", "frac": kd["frac"], "traffic": None,
+                    "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)}
+                                             if traffic else None),
                     "avg_launch_ms": kd["avg_ms"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
-        cb = None
-        if world == 1 and args.cpu_sample > 0:
+        cb, e2e = None, None
+        if world == 1 and args.e2e_records > 0:
             try:
-                cb = cpu_baseline(int(args.cpu_sample), None)
-            except Exception as ex:                                # never lose the GPU line over the CPU leg
+                eng.close()                                        # the CLI makes its own context on this GPU
+                e2e, cb = e2e_leg(int(args.e2e_records))
+            except Exception as ex:                                # never lose the GPU line over this leg
+                e2e = {"failed": repr(ex)}
                 cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "failed", "sample": repr(ex)}
         line = {
             "metric": "alignment records/sec (3 Gb genome, 50x BAM, whole-chromosome mode)",
@@ -350,7 +386,7 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else ")")) if direct
+                       "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)")) if direct
                                else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
@@ -359,13 +395,15 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "arrays_path": arrays_path,
+            "e2e": e2e,
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng.h:
+        eng.close()
 
 
 if __name__ == "__main__":

@@ -269,6 +269,7 @@ typedef struct pd_decode_cfg {
     const uint32_t *span_off;       /* -g / -b: spans of contig t are [span_off[t], span_off[t+1]) ...                   */
     const int32_t *spans;           /* ... pairs (begin0, end), sorted, disjoint (PD:419-434); NULL: every read          */
     int32_t sorted;                 /* the file is coordinate sorted (first runs form a position-sorted stream)          */
+    uint64_t bytes_hint;            /* about how many compressed bytes will be submitted (sizes the run arena; 0 = unknown) */
 } pd_decode_cfg;
 typedef struct pd_decode_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks, flags, pad; } pd_decode_unit;
 typedef struct pd_decode_batch {

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 
 using namespace pdk;
 
@@ -76,7 +77,8 @@ struct pd_ctx {
         void *d_tok = nullptr;                                    // wave scratch (match tokens)
     };
     struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; uint32_t max_span; };
-    static constexpr int N_DEC = 3;
+    static constexpr int N_DEC = 6;
+    uint8_t *arena = nullptr; size_t arena_cap = 0; std::atomic<size_t> arena_used{0};   // the batches' run arrays (bump allocated)
     DecSlot dec[N_DEC];
     std::mutex dec_mu; std::condition_variable dec_cv;
     bool dec_open = false;
@@ -450,8 +452,12 @@ int pd_destroy(pd_ctx *c)
         for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.st) (void)hipStreamDestroy(sl.st);
     }
-    for (auto &r : c->run_segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); }
-    for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other}) if (p) (void)hipFree(p);
+    for (auto &r : c->run_segs) {
+        const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+        if (r.first && !ina(r.first)) (void)hipFree(r.first);
+        if (r.other && !ina(r.other)) (void)hipFree(r.other);
+    }
+    for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->arena}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -800,6 +806,11 @@ namespace {
 
 enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG, DS_LANE, DS_ONLY };
 
+// PANDEPTH_TIMING=1: where the host side of the decode path spends its time (thread-microseconds, summed)
+std::atomic<uint64_t> g_dec_us[8];
+inline uint64_t dec_now() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct DecTimer { int k; uint64_t t0; explicit DecTimer(int k_) : k(k_), t0(dec_now()) {} ~DecTimer() { g_dec_us[k] += dec_now() - t0; } };
+
 int dec_fail(pd_ctx *c, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(c->mu); return fail(c, code, msg); }
 
 #define HIPDEC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return dec_fail(c, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -858,6 +869,14 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (ns) HIPOK(c, hipMemcpy(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice));
     }
     c->dec_cfg.contig_on = nullptr; c->dec_cfg.span_off = nullptr; c->dec_cfg.spans = nullptr;      // (the caller's arrays are not kept)
+    // one arena for the batches' run arrays (a hipMalloc per batch waits for the other streams): about half the compressed
+    // bytes is plenty for short reads (12 B per run against >= 30 B of BGZF per record); what does not fit is allocated singly
+    const size_t want = cfg->bytes_hint ? (size_t)(cfg->bytes_hint / 2) + ((size_t)16 << 20) : (size_t)256 << 20;
+    if (c->arena_cap < want) {
+        if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_cap = 0; }
+        if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
+    }
+    c->arena_used = 0;
     c->dec_open = true;
     return PD_OK;
 }
@@ -869,13 +888,14 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     std::unique_lock<std::mutex> lk(c->dec_mu);
     if (!c->dec_open) return dec_fail(c, PD_ESTATE, "pd_decode_acquire: call pd_decode_begin first");
     pd_ctx::DecSlot *sl = nullptr;
-    c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; });
+    { DecTimer tw(0); c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; }); }
     sl->busy = true;
     lk.unlock();
+    DecTimer ta(1);
     if (hipSetDevice(c->device) != hipSuccess) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); }
     if (bytes + 64 > sl->h_cap) {
         if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
-        const size_t want = std::max<size_t>(bytes + 64, (size_t)64 << 20);
+        const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20);
         if (hipHostMalloc((void **)&sl->h_blob, want, hipHostMallocDefault) != hipSuccess) {
             { std::lock_guard<std::mutex> l2(c->dec_mu); sl->busy = false; }
             c->dec_cv.notify_one();
@@ -929,11 +949,14 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     if (!n_seg) return PD_OK;
     const unsigned n_wg = (unsigned)c->n_cu * 16u;
     int rc;
+    uint64_t t_mark = dec_now();
+    auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - t_mark; t_mark = n; };
     if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
         (rc = dec_ensure(c, sl, DS_BLK, (size_t)bt->n_blocks * sizeof(pd_bgzf_block))) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
         (rc = dec_ensure(c, sl, DS_SEG, (size_t)n_seg * sizeof(pdb2::Seg))) || (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
         (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16))) return rc;
     if (!sl.d_tok && hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
+    lap(2);                                                               // device buffers
     hipStream_t st = sl.st;
     uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF];
     pdb2::Seg *d_seg = (pdb2::Seg *)sl.d[DS_SEG];
@@ -957,6 +980,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     HIPDEC(hipEventRecord(sl.ev[3], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    lap(3);                                                               // H2D + inflate + pass 1 (waiting)
     // ---- the chain across segments; segments whose guess was wrong walk again from the corrected start ----
     std::vector<uint32_t> redo;
     for (int round = 0; dec_finish(segs, &redo) > 0; ++round) {
@@ -992,15 +1016,24 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     }
     // ---- pass 2: the runs ----
     pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, max_span};
+    lap(4);                                                               // host: chain check, unit outcomes
     if (nf + no) {
-        if (nf && hipMalloc(&rs.first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
-        if (no && hipMalloc(&rs.other, (size_t)no * sizeof(pd_iv)) != hipSuccess) { if (rs.first) (void)hipFree(rs.first); return dec_fail(c, PD_ENOMEM, "run array allocation failed"); }
+        auto grab = [&](uint64_t n, pd_iv **out) -> bool {
+            const size_t bytes = ((size_t)n * sizeof(pd_iv) + 255) & ~(size_t)255;
+            const size_t at = c->arena_used.fetch_add(bytes);
+            if (at + bytes <= c->arena_cap) { *out = (pd_iv *)(c->arena + at); return true; }
+            return hipMalloc(out, bytes) == hipSuccess;
+        };
+        if (nf && !grab(nf, &rs.first)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+        if (no && !grab(no, &rs.other)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
         HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+        lap(5);                                                           // run array allocation
         launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other);
     }
     HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    lap(6);                                                               // pass 2 (waiting)
     if (res) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) res->ms_h2d = ms;
@@ -1028,7 +1061,8 @@ int pd_decode_end(pd_ctx *c)
     std::sort(segs.begin(), segs.end(), [](const pd_ctx::RunSeg &a, const pd_ctx::RunSeg &b) { return a.order < b.order; });
     uint64_t nf = 0, no = 0; uint32_t span = 0;
     for (auto &r : segs) { nf += r.n_first; no += r.n_other; if (r.max_span > span) span = r.max_span; }
-    auto drop = [&]() { for (auto &r : segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); } };
+    auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+    auto drop = [&]() { for (auto &r : segs) { if (r.first && !in_arena(r.first)) (void)hipFree(r.first); if (r.other && !in_arena(r.other)) (void)hipFree(r.other); } };
     if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
     if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
     if (nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
@@ -1044,6 +1078,10 @@ int pd_decode_end(pd_ctx *c)
     // the sample, deferred: first runs position sorted (a coordinate-sorted file), the others trail their read's start by
     // at most `span` cells; an unsorted file, or reads spanning more than a few tiles, take the atomic path
     const bool sorted = c->dec_cfg.sorted != 0;
+    if (getenv("PANDEPTH_TIMING"))
+        fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
+                        "host chain check %.3f, run arrays %.3f, wait emit %.3f; %zu batches\n", g_dec_us[0] / 1e6, g_dec_us[1] / 1e6, g_dec_us[2] / 1e6,
+                g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, segs.size());
     int rc = PD_OK;
     if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | (no && span <= (1u << 14) ? PD_PUSH_MORE : 0u)) : PD_PUSH_DEFAULT, -1, nullptr);
     if (rc == PD_OK && no)
@@ -1058,7 +1096,8 @@ int pd_decode_abort(pd_ctx *c)
     c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });
     c->dec_open = false;
     (void)hipSetDevice(c->device);
-    for (auto &r : c->run_segs) { if (r.first) (void)hipFree(r.first); if (r.other) (void)hipFree(r.other); }
+    auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+    for (auto &r : c->run_segs) { if (r.first && !in_arena(r.first)) (void)hipFree(r.first); if (r.other && !in_arena(r.other)) (void)hipFree(r.other); }
     c->run_segs.clear();
     return PD_OK;
 }
@@ -1099,8 +1138,9 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
         if (mine.n_first) { rc = scatter_device(c, mine.first, (size_t)mine.n_first, PD_PUSH_SORTED, -1, nullptr); if (rc) return rc; }
         if (mine.n_other) { rc = scatter_device(c, mine.other, (size_t)mine.n_other, PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
         HIPOK(c, hipStreamSynchronize(c->stream));
-        if (mine.first) (void)hipFree(mine.first);
-        if (mine.other) (void)hipFree(mine.other);
+        const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+        if (mine.first && !ina(mine.first)) (void)hipFree(mine.first);
+        if (mine.other && !ina(mine.other)) (void)hipFree(mine.other);
     }
     return PD_OK;
 }

@@ -1,7 +1,9 @@
 // main.cpp — the `pandepth` executable: the reference's command line on the MI355X depth engine.
 // The engine table is bound to libpandepth_amd.so's entry points and to nothing else; without a
 // gfx950 device pd_create fails and the program exits with an error (no CPU fallback).
+#include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include "engine_api.h"
 
 int main(int argc, char **argv)
@@ -12,5 +14,10 @@ int main(int argc, char **argv)
         pd_decode_begin, pd_decode_acquire, pd_decode_submit, pd_decode_end, pd_decode_abort, pd_set_param,
     };
     const char *dev = getenv("PANDEPTH_DEVICE");
-    return pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);
+    // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
+    // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory
+    setenv("PANDEPTH_KEEP_CONTEXT", "1", 1);
+    const int rc = pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);
+    fflush(stdout); fflush(stderr);
+    _exit(rc);
 }

@@ -328,7 +328,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     const uint64_t F = file_size(path);
     if (F < 28) return 0;
     const uint64_t SPARE = 5 * 65536;                        // bytes read past a unit's end so that its last record can finish
-    uint64_t batch_bytes = (uint64_t)96 << 20;
+    uint64_t batch_bytes = (uint64_t)32 << 20;
     if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     // ---- the work list: batches of units ----
     std::vector<std::vector<DevRange>> batches;
@@ -360,6 +360,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     std::vector<uint32_t> soff; std::vector<int32_t> sflat;
     pd_decode_cfg cfg{};
     cfg.flag_mask = o.flag_mask; cfg.min_mapq = o.min_mapq; cfg.contig_on = on.data(); cfg.sorted = sorted ? 1 : 0;
+    { uint64_t b = 0; for (auto &v : batches) for (auto &r : v) b += ((r.vend == UINT64_MAX ? F : (r.vend >> 16)) - (r.vbeg >> 16)) + 65536; cfg.bytes_hint = std::min(b, 2 * F); }
     if (!spans.synthetic) {
         soff.assign(on.size() + 1, 0);
         for (size_t t = 0; t < on.size(); ++t) {
@@ -534,7 +535,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3]);
     if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
     if (declined.load()) { api->decode_abort(eng->ctx); return 0; }          // nothing of this input has been counted
+    const uint64_t t_e = now_us();
     if (!eng->ck(api->decode_end(eng->ctx), "pd_decode_end")) return -1;
+    if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing]   pd_decode_end (concatenate the batches' runs) %.3f s\n", (now_us() - t_e) / 1e6);
     return 1;
 }
 
@@ -872,7 +875,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         if (n_ctx > n_files) n_ctx = n_files;
     }
     std::vector<std::unique_ptr<Engine>> engs;
-    struct CtxGuard { std::vector<std::unique_ptr<Engine>> *v; ~CtxGuard() { for (auto &e : *v) if (e->ctx) e->api->destroy(e->ctx); } } guard{&engs};
+    // (the executable leaves without tearing the engine down — the process is about to end; library users of pandepth_main keep the destroy)
+    struct CtxGuard { std::vector<std::unique_ptr<Engine>> *v; ~CtxGuard() { if (getenv("PANDEPTH_KEEP_CONTEXT")) return; for (auto &e : *v) if (e->ctx) e->api->destroy(e->ctx); } } guard{&engs};
     for (int k = 0; k < n_ctx; ++k) {
         engs.emplace_back(new Engine);
         engs.back()->api = api;
