@@ -1063,8 +1063,14 @@ int pd_decode_end(pd_ctx *c)
     for (auto &r : segs) { nf += r.n_first; no += r.n_other; if (r.max_span > span) span = r.max_span; }
     auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
     auto drop = [&]() { for (auto &r : segs) { if (r.first && !in_arena(r.first)) (void)hipFree(r.first); if (r.other && !in_arena(r.other)) (void)hipFree(r.other); } };
-    if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
-    if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+    if (c->run_first || c->run_other) {
+        // an earlier sample of this context (#.list: one file after another) may still be deferred on these arrays
+        int rf = flush_pending(c);
+        if (rf) { drop(); return rf; }
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
+        if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+    }
     if (nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
     if (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
     uint64_t of = 0, oo = 0;

@@ -1,5 +1,5 @@
 """GPU end-to-end parity of the GC(%) column cases (fixture f5: `-c -r ref.fa`) and of PAF input (fixture f6) and CRAM input (fixture f7): the same
-three checks as tests/test_cli_gpu.py — plain, GPU-side BAM decode, `#.list` over two contexts.
+checks as tests/test_cli_gpu.py — plain (BAM input is decoded on the GPU), host decode, `#.list` over two contexts.
 Kept in a file that sorts last: these cases were added after the last GPU run of their round."""
 import os
 
@@ -19,14 +19,17 @@ def test_gc_cases_byte_identical(case, threads, tmp_path):
     T.test_pandepth_cli_byte_identical(case, threads, tmp_path)
 
 
-DD = [e for e in F5 if "-g" not in e["args"] and "-b" not in e["args"] and "-s" not in e["args"]
-      and e["args"][1].endswith(".bam") and "noidx" not in e["args"][1]]
+BAM = [e for e in F5 if e["args"][1].endswith(".bam")]
 
 
-@pytest.mark.parametrize("batch_mb", ["", "1"])
-@pytest.mark.parametrize("case", DD, **ID)
-def test_gc_cases_device_decode_byte_identical(case, batch_mb, tmp_path):
-    T.test_pandepth_cli_device_decode_byte_identical(case, batch_mb, tmp_path)
+@pytest.mark.parametrize("case", BAM, **ID)
+def test_gc_cases_device_decode_is_the_default(case, tmp_path):
+    T.test_pandepth_cli_device_decode_is_the_default(case, tmp_path)
+
+
+@pytest.mark.parametrize("case", BAM[::2], **ID)
+def test_gc_cases_host_decode_byte_identical(case, tmp_path):
+    T.test_pandepth_cli_host_decode_byte_identical(case, tmp_path)
 
 
 @pytest.mark.parametrize("case", [e for e in F5 if ".list" in e["args"][1]], **ID)
