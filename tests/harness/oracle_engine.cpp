@@ -10,6 +10,9 @@
 #include <string>
 #include <vector>
 #include "../../pandepth_amd/host/engine_api.h"
+#include "../../pandepth_amd/csrc/pd_inflate_wave.h"       // the product's device decode cores, their 64 lanes emulated on the host
+#include "../../pandepth_amd/csrc/pd_bamwalk.h"
+#include <algorithm>
 
 extern "C" {
 void pdo_add_intervals(int64_t n, const int32_t *iv, uint32_t *depth, const int64_t *contig_off);
@@ -25,6 +28,13 @@ struct pd_ctx {
     bool scanned = false;
     std::mutex mu;
     std::string err;
+    // decode_*: the same batch protocol as libpandepth_amd.so's, run with the product's cores (pd_inflate_wave.h,
+    // pd_bamwalk.h) in host emulation, so that the CPU suite drives the feeder of host/pipeline.cpp too
+    pd_decode_cfg dcfg{}; std::vector<uint8_t> on; std::vector<uint32_t> soff; std::vector<int32_t> spans;
+    struct Buf { std::vector<uint8_t> b; bool busy = false; };
+    std::vector<Buf *> bufs;
+    struct Runs { uint64_t order; std::vector<pd_iv> first, other; };
+    std::vector<Runs> runs;
 };
 
 
@@ -141,9 +151,120 @@ static int o_accumulate_from(pd_ctx *dst, pd_ctx *src)
     return 0;
 }
 
+// ---- decode_*: pd_decode_begin / acquire / submit / end / abort on the CPU -------------------------------------
+static int o_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->dcfg = *cfg;
+    const size_t n = c->len.size();
+    c->on.assign(n, 1);
+    for (size_t t = 0; t < n; ++t) c->on[t] = cfg->contig_on ? cfg->contig_on[t] != 0 : c->len[t] >= 2;
+    c->soff.clear(); c->spans.clear();
+    if (cfg->span_off && cfg->spans) { c->soff.assign(cfg->span_off, cfg->span_off + n + 1); c->spans.assign(cfg->spans, cfg->spans + 2 * (size_t)cfg->span_off[n]); c->spans.push_back(0); }
+    c->runs.clear();
+    return 0;
+}
+static int o_decode_acquire(pd_ctx *c, size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    pd_ctx::Buf *b = nullptr;
+    for (auto *x : c->bufs) if (!x->busy) { b = x; break; }
+    if (!b) { b = new pd_ctx::Buf; c->bufs.push_back(b); }
+    b->busy = true; b->b.resize(bytes + 64);
+    *out = b->b.data();
+    return 0;
+}
+static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status, pd_decode_result *res)
+{
+    pd_ctx::Buf *mine = nullptr;
+    { std::lock_guard<std::mutex> lk(c->mu); for (auto *x : c->bufs) if (x->busy && x->b.data() == bt->host_buf) mine = x; }
+    if (!mine) { c->err = "submit: unknown buffer"; return -1; }
+    struct Rel { pd_ctx *c; pd_ctx::Buf *b; ~Rel() { std::lock_guard<std::mutex> lk(c->mu); b->busy = false; } } rel{c, mine};
+    if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
+    if (!bt->n_units || !bt->n_blocks) return 0;
+    const uint8_t *blob = (const uint8_t *)bt->host_buf;
+    std::vector<uint8_t> inf((size_t)bt->inflated_bytes + 256, 0);
+    std::vector<int> bst(bt->n_blocks, 0);
+    static thread_local pdw::Tables T;
+    static thread_local std::vector<pdw::Token> tok(65536 / 3 + 64);
+    for (uint32_t b = 0; b < bt->n_blocks; ++b) {
+        const pd_bgzf_block &d = bt->blocks[b];
+        if (d.out_len) bst[b] = pdw::inflate_block<pdw::HostWave>(blob + d.in_off, d.in_len, inf.data() + d.out_off, d.out_len, T, tok.data(), nullptr);
+    }
+    pdb2::Cfg cfg;
+    cfg.buf = inf.data(); cfg.avail = bt->inflated_bytes; cfg.n_ref = (int32_t)c->len.size(); cfg.contig_len = c->len.data(); cfg.contig_on = c->on.data();
+    cfg.flag_mask = c->dcfg.flag_mask; cfg.min_mapq = c->dcfg.min_mapq;
+    cfg.span_off = c->soff.empty() ? nullptr : c->soff.data(); cfg.spans = c->soff.empty() ? nullptr : c->spans.data();
+    std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0(bt->n_units + 1, 0);
+    for (uint32_t u = 0; u < bt->n_units; ++u) {
+        const pd_decode_unit &un = bt->units[u];
+        seg0[u] = (uint32_t)segs.size();
+        for (uint64_t b = un.start; b < un.stop; b += pdb2::SEG_BYTES) {
+            pdb2::Seg s; memset(&s, 0, sizeof s);
+            s.begin = b; s.end = std::min<uint64_t>(b + pdb2::SEG_BYTES, un.stop); s.avail = un.avail; s.unit_first = b == un.start;
+            s.hint = (b == un.start && !(un.flags & PD_UNIT_GUESS)) ? un.start : pdb2::NONE;
+            segs.push_back(s);
+        }
+    }
+    seg0[bt->n_units] = (uint32_t)segs.size();
+    std::vector<pdb2::LaneOut> lanes(segs.size() * 64);
+    for (size_t j = 0; j < segs.size(); ++j) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
+    for (int round = 0; round < 5; ++round) {                   // the chain across segments (pd_capi.hip: dec_finish)
+        uint64_t E = 0; std::vector<size_t> redo;
+        for (size_t j = 0; j < segs.size(); ++j) {
+            pdb2::Seg &s = segs[j];
+            if (s.unit_first) E = 0;
+            else { const bool none = E >= s.end; if (!(none ? s.used_start == pdb2::NONE : s.used_start == E)) { s.hint = E; redo.push_back(j); } }
+            if (s.e_last > E) E = s.e_last;
+        }
+        if (redo.empty()) break;
+        if (round == 4) { for (size_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
+        for (size_t j : redo) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
+    }
+    uint64_t nf = 0, no = 0, nrec = 0;
+    for (uint32_t u = 0; u < bt->n_units; ++u) {
+        int st = 0;
+        const pd_decode_unit &un = bt->units[u];
+        for (uint32_t b = 0; b < un.n_blocks; ++b) { const int v = bst[un.first_block + b]; if (v < 0) st = 2; else if (v > 0 && !st) st = 1; }
+        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) { if (segs[j].flags & pdb2::WF_BAD) st = 2; else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && !st) st = 1; }
+        status[u] = st;
+        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
+            if (st) segs[j].n_first = segs[j].n_other = 0; else nrec += segs[j].n_rec;
+            segs[j].base_first = nf; segs[j].base_other = no; nf += segs[j].n_first; no += segs[j].n_other;
+        }
+    }
+    if (res) {
+        res->n_first = nf; res->n_other = no; res->n_reads = nrec;
+        uint64_t fs = ~0ull, E = 0;
+        for (uint32_t j = seg0[0]; j < seg0[1]; ++j) { if (fs == ~0ull && segs[j].used_start != pdb2::NONE) fs = segs[j].used_start; if (segs[j].e_last > E) E = segs[j].e_last; }
+        res->first_start = fs; res->next_start = E ? E : ~0ull;
+    }
+    pd_ctx::Runs r; r.order = bt->order; r.first.resize(nf + 1); r.other.resize(no + 1);
+    for (size_t j = 0; j < segs.size(); ++j) if (segs[j].n_first | segs[j].n_other) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data());
+    r.first.resize(nf); r.other.resize(no);
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->runs.push_back(std::move(r));
+    return 0;
+}
+static int o_decode_end(pd_ctx *c)
+{
+    std::vector<pd_ctx::Runs> rs;
+    { std::lock_guard<std::mutex> lk(c->mu); rs.swap(c->runs); }
+    std::sort(rs.begin(), rs.end(), [](const pd_ctx::Runs &a, const pd_ctx::Runs &b) { return a.order < b.order; });
+    std::vector<pd_iv> first, other;
+    for (auto &r : rs) { first.insert(first.end(), r.first.begin(), r.first.end()); other.insert(other.end(), r.other.begin(), r.other.end()); }
+    // the product pushes the first runs as a SORTED batch when the file is coordinate sorted: hold it to that promise
+    int rc = first.empty() ? 0 : o_push(c, first.data(), first.size(), c->dcfg.sorted ? PD_PUSH_SORTED : PD_PUSH_DEFAULT);
+    if (!rc && !other.empty()) rc = o_push(c, other.data(), other.size(), PD_PUSH_DEFAULT);
+    return rc;
+}
+static int o_decode_abort(pd_ctx *c) { std::lock_guard<std::mutex> lk(c->mu); c->runs.clear(); return 0; }
+static int o_set_param(pd_ctx *, const char *, uint64_t) { return 0; }
+
 int main(int argc, char **argv)
 {
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
-                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from};
+                                      o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from,
+                                      o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param};
     return pandepth_main(argc, argv, &api, 0);
 }

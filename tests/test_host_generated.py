@@ -68,6 +68,8 @@ CASES = [
 
 BINARIES = [
     pytest.param(os.path.join(HERE, "harness", "pandepth_oracle_cli"), id="host+oracle-engine"),
+    pytest.param(os.path.join(HERE, "harness", "pandepth_oracle_cli") + ":dd", id="host+oracle-engine-small-batches"),
+    pytest.param(os.path.join(HERE, "harness", "pandepth_oracle_cli") + ":host", id="host+oracle-engine-host-decode"),
     pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth"), id="pandepth-mi355x", marks=pytest.mark.gpu),
     pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":dd", id="pandepth-mi355x-small-batches", marks=pytest.mark.gpu),
     pytest.param(os.path.join(ROOT, "pandepth_amd", "pandepth") + ":host", id="pandepth-mi355x-host-decode", marks=pytest.mark.gpu),
