@@ -6,8 +6,8 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
 
     pd_reset                      forget the 3.0e9 cells (per-half-tile "written" flags + tile sums; no fill:
                                   unwritten cells count as zero until the scatter stores into them)
-    pd_push_intervals_device x2   the sample's two run streams: the sorted first runs and the ~11 % second
-                                  runs of D/I/N reads, which are only nearly sorted
+    pd_push_intervals_device x2   the sample's two run streams, as the product's GPU decoder leaves them: the sorted
+                                  first runs and the ~11 % later runs of D/I/N reads, which are only nearly sorted
                                   (PD_PUSH_DISORDER(max read span)); both deferred (PD_PUSH_MORE)
     pd_scan_reduce_windows        10 Mb-bin CoveredSite/TotalDepth, results copied back to the host.
                                   N = 1 (default, "direct_windows"): ONE pass over the runs — each tile's
@@ -174,9 +174,11 @@ def main():
     names, lens = synth.genome_c2()
     G = int(lens.sum())
     eng = pda.Engine(lens.astype(np.uint32), device=local)
+    # the two run streams the product's GPU decoder leaves in HBM (pd_decode_end): every read's first run (position sorted)
+    # and its later runs (D / I / N reads), which trail the sorted order by at most the longest gap
     first, other = synth.gen_runs_torch(lens, R, dev, seed=42 + rank)
     torch.cuda.synchronize()
-    n_first, n_other = int(first.shape[0]), int(other.shape[0])
+    n_first, n_other, n_far = int(first.shape[0]), int(other.shape[0]), 0
     _, n_words, _ = eng.device_buffer()
     n_cells = eng.device_layout()[0]
     # N > 1: int8 transport of the difference arrays (1 B/cell on the xGMI links instead of 4);
@@ -315,7 +317,7 @@ def main():
         def entries(prof, steps):
             launches_tiles = max(1, prof["scatter_tiles"][1] // steps)
             return {
-                "scatter_tiles": k_entry2(prof, "scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
+                "scatter_tiles": k_entry2(prof, "scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
                 "scan_reduce_windows": k_entry2(prof, "scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE)}
 
         def k_entry2(pr, name, alg):
@@ -332,13 +334,13 @@ def main():
         launches_tiles = max(1, prof["scatter_tiles"][1] // args.steps)
         kernels = {
             # the direct path's only big kernel: reads every run once (12 B), writes 24 B per tile
-            "direct_tiles": k_entry("direct_tiles", (n_first + n_other) * B_RUN + (n_cells // 8192) * 24),
+            "direct_tiles": k_entry("direct_tiles", (n_first + n_other + n_far) * B_RUN + (n_cells // 8192) * 24),
             # N > 1: the runs read once, the 4-bit image (n_cells / 2 bytes) and the tile sums written
-            "direct_export": k_entry("direct_export", (n_first + n_other) * B_RUN + n_cells // 2 + (n_cells // 8192) * 4),
+            "direct_export": k_entry("direct_export", (n_first + n_other + n_far) * B_RUN + n_cells // 2 + (n_cells // 8192) * 4),
             # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
             "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
                      if prof["fill"][1] else None),
-            "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other) * B_SCATTER_PER_RUN / launches_tiles),
+            "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
             "export_i8": k_entry("export_i8", 5 * (n_words - (n_words - G) % 1)),     # 4 B read + 1 B written per cell
             "import_i8": k_entry("import_i8", 5 * (n_words - (n_words - G) % 1)),     # 1 B read + 4 B written per cell

@@ -28,6 +28,9 @@
 namespace pdb2 {
 
 enum { SUB = 1024, SEG_BYTES = 64 * SUB };
+// Later runs of a read that begin more than Cfg::near_span bases after its start may go to a separate ("far") stream.  Measured
+// on the 50x sample a third stream costs the tile kernels more (per-batch bookkeeping in every tile) than its tighter disorder
+// bound saves, so the split is off by default (near_span = 0xFFFFFFFF) and every later run goes to the one "other" stream.
 enum { WF_BAD = 1, WF_MORE = 2, WF_HOST = 4 };     // corrupt record / record runs past the batch / CIGAR in the CG tag
 static const uint64_t NONE = ~0ull, STOPPED = 1ull << 62;
 
@@ -36,6 +39,7 @@ struct Cfg {                              // wave-uniform
     int32_t n_ref; const uint32_t *contig_len; const uint8_t *contig_on;      // contig_on[tid] != 0: the contig has targets
     uint32_t flag_mask; int32_t min_mapq;
     const uint32_t *span_off; const int32_t *spans;                            // -g / -b: (begin0, end) per contig, sorted; or null
+    uint32_t near_span;
 };
 
 struct Seg {
@@ -45,10 +49,11 @@ struct Seg {
     uint32_t unit_first, n_rec;           // first segment of its unit (nothing before it to be checked against); OUT: records it owns
     // results
     uint64_t used_start, e_last;          // where lane 0 started; first record start >= end (0: no record seen)
-    uint32_t n_first, n_other, flags, max_span;
-    uint64_t base_first, base_other;      // written by k_walk_finish: where the segment's runs go
+    uint32_t n_first, n_other, flags, max_span;   // n_other: near runs; n_far: runs that begin > NEAR_SPAN after their read's start
+    uint32_t n_far, pad2;
+    uint64_t base_first, base_other, base_far;    // written by the host between the passes: where the segment's runs go
 };
-struct LaneOut { uint64_t start; uint32_t n_first, n_other; };
+struct LaneOut { uint64_t start; uint32_t n_first, n_other, n_far, pad; };
 
 PW_FN uint32_t rd32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 PW_FN uint32_t rd16(const uint8_t *p) { uint16_t w; __builtin_memcpy(&w, p, 2); return w; }
@@ -117,13 +122,13 @@ PW_FN bool span_hit(const Cfg &c, int32_t tid, int32_t pos, int32_t endpos)
     return lo < top && endpos > c.spans[2 * lo];
 }
 
-struct LaneWalk { uint64_t e; uint32_t n_first, n_other, flags, max_span, n_rec; };
+struct LaneWalk { uint64_t e; uint32_t n_first, n_other, n_far, flags, max_span, n_rec; };
 
 // records starting in [s, b): counts (emit == false) or runs written at first[of..] / other[oo..] (emit == true)
 template <bool EMIT>
-PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_iv *other, uint64_t of, uint64_t oo)
+PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_iv *other, pd_iv *far, uint64_t of, uint64_t oo, uint64_t ofar)
 {
-    LaneWalk w; w.e = s; w.n_first = w.n_other = w.flags = w.max_span = w.n_rec = 0;
+    LaneWalk w; w.e = s; w.n_first = w.n_other = w.n_far = w.flags = w.max_span = w.n_rec = 0;
     uint64_t p = s;
     for (uint32_t guard = 0; p < b && guard < SUB / 36 + 2; ++guard) {
         // a record that cannot be finished here stops the chain: nothing after it may be taken for a record start
@@ -141,12 +146,15 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
                 take = span_hit(c, x.tid, x.pos, endpos > x.pos ? endpos : x.pos + 1);
             }
             if (take) {
-                uint32_t nf = 0, no = 0, span = 0;
+                uint32_t nf = 0, no = 0, nfar = 0, span = 0;
                 walk_cigar(x, [&](bool is_first, int32_t beg, int32_t end) {
-                    if (is_first) { if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end}; nf = 1; }
-                    else { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; const uint32_t d = (uint32_t)(beg - x.pos); if (d > span) span = d; }
+                    if (is_first) { if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end}; nf = 1; return; }
+                    const uint32_t d = (uint32_t)(beg - x.pos);
+                    if (d > span) span = d;
+                    if (d <= c.near_span) { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; }
+                    else { if (EMIT) far[ofar + w.n_far + nfar] = pd_iv{x.tid, beg, end}; ++nfar; }
                 });
-                w.n_first += nf; w.n_other += no;
+                w.n_first += nf; w.n_other += no; w.n_far += nfar;
                 if (span > w.max_span) w.max_span = span;
             }
         }
@@ -164,7 +172,7 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
     typedef typename W::template Var<uint64_t> U64;
     typedef typename W::template Var<uint32_t> U;
     U64 a, b, s, e;
-    U nf, no, fl, ms, need, nr;
+    U nf, no, fl, ms, need, nr, nfar;
     const uint64_t hint = sg.hint;
     W::each([&](int l) {
         a[l] = sg.begin + (uint64_t)l * SUB; b[l] = a[l] + SUB < sg.end ? a[l] + SUB : sg.end;
@@ -173,16 +181,16 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
         uint64_t g = NONE;
         if (l == 0 && hint != NONE) g = hint;
         else for (uint64_t p = a[l]; p < b[l]; ++p) if (plausible(c, p, 3)) { g = p; break; }
-        s[l] = g; need[l] = 1; e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = 0;
+        s[l] = g; need[l] = 1; e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = nfar[l] = 0;
     });
     for (int round = 0; round < 70; ++round) {
         W::each([&](int l) {
             if (!need[l]) return;
-            e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = 0;
+            e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = nfar[l] = 0;
             if (s[l] == NONE) return;                                     // nothing known to start here: no information
             if (s[l] >= b[l]) { e[l] = s[l]; return; }                     // the chain passes over this lane's KiB
-            const LaneWalk w = walk_lane<false>(c, s[l], b[l], nullptr, nullptr, 0, 0);
-            e[l] = w.e; nf[l] = w.n_first; no[l] = w.n_other; fl[l] = w.flags; ms[l] = w.max_span; nr[l] = w.n_rec;
+            const LaneWalk w = walk_lane<false>(c, s[l], b[l], nullptr, nullptr, nullptr, 0, 0, 0);
+            e[l] = w.e; nf[l] = w.n_first; no[l] = w.n_other; fl[l] = w.flags; ms[l] = w.max_span; nr[l] = w.n_rec; nfar[l] = w.n_far;
         });
         // where the chain of the lanes before l ends = prefix maximum of their ends
         const U64 pm = W::excl_scan_max64(e);
@@ -196,9 +204,10 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
     uint32_t tf = 0, to = 0;
     const U ef = W::excl_scan(nf, &tf);
     const U eo = W::excl_scan(no, &to);
-    uint32_t tr = 0;
+    uint32_t tr = 0, tfar = 0;
     const U er = W::excl_scan(nr, &tr);
-    (void)ef; (void)eo; (void)er;
+    const U efar = W::excl_scan(nfar, &tfar);
+    (void)ef; (void)eo; (void)er; (void)efar;
     const uint64_t flags = W::ballot_ne(fl, 0u);
     uint32_t allf = 0, mspan = 0;
     if (flags) allf = W::reduce_or(fl);
@@ -208,30 +217,31 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
     W::each([&](int l) { own[l] = s[l] != NONE && s[l] < b[l] ? s[l] : NONE; });
     const uint64_t first_start = W::reduce_min64(own);                   // the first record the segment owns (NONE: none starts here)
     W::each([&](int l) {
-        lanes[l].start = s[l]; lanes[l].n_first = nf[l]; lanes[l].n_other = no[l];
+        lanes[l].start = s[l]; lanes[l].n_first = nf[l]; lanes[l].n_other = no[l]; lanes[l].n_far = nfar[l]; lanes[l].pad = 0;
         if (l == 0) {
-            sg.used_start = first_start; sg.e_last = last_e; sg.n_first = tf; sg.n_other = to; sg.flags = allf; sg.max_span = mspan; sg.n_rec = tr;
+            sg.used_start = first_start; sg.e_last = last_e; sg.n_first = tf; sg.n_other = to; sg.flags = allf; sg.max_span = mspan; sg.n_rec = tr; sg.n_far = tfar;
         }
     });
 }
 
 // pass 2: the same lanes write their runs; sg.base_first / base_other say where the segment's runs go
 template <class W>
-PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_iv *first, pd_iv *other)
+PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_iv *first, pd_iv *other, pd_iv *far)
 {
     Cfg c = cfg; c.avail = sg.avail;
     typedef typename W::template Var<uint32_t> U;
-    U nf, no;
-    W::each([&](int l) { nf[l] = lanes[l].n_first; no[l] = lanes[l].n_other; });
-    uint32_t tf = 0, to = 0;
+    U nf, no, nfar;
+    W::each([&](int l) { nf[l] = lanes[l].n_first; no[l] = lanes[l].n_other; nfar[l] = lanes[l].n_far; });
+    uint32_t tf = 0, to = 0, tfar = 0;
     const U ef = W::excl_scan(nf, &tf);
     const U eo = W::excl_scan(no, &to);
+    const U efar = W::excl_scan(nfar, &tfar);
     W::each([&](int l) {
         const uint64_t a = sg.begin + (uint64_t)l * SUB;
         uint64_t b = a + SUB < sg.end ? a + SUB : sg.end;
         const uint64_t s = lanes[l].start;
-        if (a >= sg.end || s == NONE || s >= b || (nf[l] | no[l]) == 0) return;
-        (void)walk_lane<true>(c, s, b, first, other, sg.base_first + ef[l], sg.base_other + eo[l]);
+        if (a >= sg.end || s == NONE || s >= b || (nf[l] | no[l] | nfar[l]) == 0) return;
+        (void)walk_lane<true>(c, s, b, first, other, far, sg.base_first + ef[l], sg.base_other + eo[l], sg.base_far + efar[l]);
     });
 }
 

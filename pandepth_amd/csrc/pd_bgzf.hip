@@ -65,12 +65,12 @@ __global__ __launch_bounds__(64) void k_walk_segments(const pdb2::Cfg cfg, pdb2:
 
 // pass 2: the runs, at the offsets the host gave every segment (base_first / base_other)
 __global__ __launch_bounds__(64) void k_emit_segments(const pdb2::Cfg cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                                                      pd_iv *first, pd_iv *other)
+                                                      pd_iv *first, pd_iv *other, pd_iv *far)
 {
     const uint32_t j = blockIdx.x;
     if (j >= n_seg) return;
-    if ((segs[j].n_first | segs[j].n_other) == 0) return;
-    pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other);
+    if ((segs[j].n_first | segs[j].n_other | segs[j].n_far) == 0) return;
+    pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other, far);
 }
 
 } // namespace
@@ -95,10 +95,10 @@ void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs,
     hipLaunchKernelGGL(k_walk_segments, dim3(n), dim3(64), 0, st, cfg, segs, n_seg, lanes, only, n_only);
 }
 void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                          pd_iv *first, pd_iv *other)
+                          pd_iv *first, pd_iv *other, pd_iv *far)
 {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_emit_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, first, other);
+    hipLaunchKernelGGL(k_emit_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, first, other, far);
 }
 
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,

@@ -76,15 +76,16 @@ struct pd_ctx {
         void *d[7] = {}; size_t cap[7] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list
         void *d_tok = nullptr;                                    // wave scratch (match tokens)
     };
-    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; uint32_t max_span; };
+    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; };
     static constexpr int N_DEC = 6;
     uint8_t *arena = nullptr; size_t arena_cap = 0; std::atomic<size_t> arena_used{0};   // the batches' run arrays (bump allocated)
     DecSlot dec[N_DEC];
     std::mutex dec_mu; std::condition_variable dec_cv;
     bool dec_open = false;
+    uint32_t dec_near_span = 0xFFFFFFFFu;                         // "decode_near_span": split the later runs into two streams (off)
     pd_decode_cfg dec_cfg{}; uint8_t *d_contig_on = nullptr; uint32_t *d_span_off = nullptr; int32_t *d_spans = nullptr;
     std::vector<RunSeg> run_segs;
-    pd_iv *run_first = nullptr, *run_other = nullptr;             // the concatenated sample (owned until the next reset)
+    pd_iv *run_first = nullptr, *run_other = nullptr, *run_far = nullptr;   // the concatenated sample (owned until the next reset)
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
@@ -408,7 +409,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     c->n_half = (uint32_t)(c->n_cells / PD_HALF);
     CREATE_OK(hipMalloc(&c->hstate, c->n_half + 16));
     CREATE_OK(hipMalloc(&c->slice_flags, c->n_tiles + 16));
-    CREATE_OK(hipMalloc(&c->direct_words, 16 + (c->n_tiles + 4) * 4));
+    CREATE_OK(hipMalloc(&c->direct_words, 64 + (c->n_tiles + 4) * 4));       // [n_long, fail, heavy_count, diagnostics ... | heavy tile list at +16]
     CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc) * PD_MAXPEND));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
     {
@@ -456,8 +457,9 @@ int pd_destroy(pd_ctx *c)
         const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
         if (r.first && !ina(r.first)) (void)hipFree(r.first);
         if (r.other && !ina(r.other)) (void)hipFree(r.other);
+        if (r.far && !ina(r.far)) (void)hipFree(r.far);
     }
-    for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->arena}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -473,10 +475,9 @@ int pd_reset(pd_ctx *c)
     if (rc) return rc;
     c->state = 0;
     rc = do_reset(c);
-    if (rc == PD_OK && (c->run_first || c->run_other)) {          // the decoded sample's runs go with it
+    if (rc == PD_OK && (c->run_first || c->run_other || c->run_far)) {          // the decoded sample's runs go with it
         HIPOK(c, hipStreamSynchronize(c->stream));
-        if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
-        if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+        for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
     }
     return rc;
 }
@@ -495,6 +496,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "accumulate_packed")) { c->accumulate_packed = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_windows")) { c->direct_windows = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
+    if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
 
@@ -642,7 +644,7 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     TilePart *d_part = (TilePart *)(s + b_off + b_sum + b_cov);
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
-    HIPOK(c, hipMemsetAsync(c->direct_words, 0, 16, c->stream));
+    HIPOK(c, hipMemsetAsync(c->direct_words, 0, 64, c->stream));
     if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // edge windows are accumulated
     const uint32_t n_stiles = (uint32_t)c->n_tiles;
     PendSet ps{};
@@ -667,19 +669,24 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_tiles");
       launch_direct_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part, d_wo,
-                          d_cov, d_sum, c->direct_words, c->direct_words + 1, c->direct_words + 4, c->direct_words + 2, grid, c->direct_un); }
+                          d_cov, d_sum, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid, c->direct_un); }
     if (w >= PD_TILE) {
         ProfScope sc(c, "gather_windows");
         TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
         launch_window_gather(c->stream, d_part, tm, c->n_contigs, w, nw, d_cov, d_sum);
     }
     HIPOK(c, hipGetLastError());
-    uint32_t words[2] = {0, 0};
-    HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t words[12] = {0};
+    HIPOK(c, hipMemcpyAsync(words, c->direct_words, 48, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipMemcpyAsync(cover, d_cov, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
-    if (words[1]) return PD_OK;                          // not applicable: batches stay pending
+    if (words[1]) {                                      // not applicable: batches stay pending
+        if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing]   direct window path declined: begins owned %llu of %llu runs, runs with cells %u vs ends owned %u (difference), index error bits 0x%x, "
+                            "long runs %u: the arrays are materialised\n", (unsigned long long)words[3] | ((unsigned long long)words[4] << 32),
+                    (unsigned long long)words[5] | ((unsigned long long)words[6] << 32), words[7], words[8], words[9], words[10]);
+        return PD_OK;
+    }
     for (auto &p : c->pend)
         if (p.slot >= 0) {
             Stage &st = c->stage[p.slot];
@@ -963,7 +970,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
     pdb2::Cfg cfg;
     cfg.buf = d_inf; cfg.avail = bt->inflated_bytes; cfg.n_ref = c->n_contigs; cfg.contig_len = c->d_len; cfg.contig_on = c->d_contig_on;
-    cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans;
+    cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans; cfg.near_span = c->dec_near_span;
     // ---- H2D, inflate, pass 1 ----
     HIPDEC(hipEventRecord(sl.ev[0], st));
     HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes, hipMemcpyHostToDevice, st));
@@ -992,7 +999,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         HIPDEC(hipStreamSynchronize(st));
     }
     // ---- unit outcomes; units handed back emit nothing ----
-    uint64_t nf = 0, no = 0, nrec = 0; uint32_t max_span = 0;
+    uint64_t nf = 0, no = 0, nfar = 0, nrec = 0; uint32_t max_span = 0;
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         int stt = 0;
         const pd_decode_unit &un = bt->units[u];
@@ -1003,21 +1010,22 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         }
         unit_status[u] = stt;
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
-            if (stt) { segs[j].n_first = segs[j].n_other = 0; } else nrec += segs[j].n_rec;
-            segs[j].base_first = nf; segs[j].base_other = no; nf += segs[j].n_first; no += segs[j].n_other;
+            if (stt) { segs[j].n_first = segs[j].n_other = segs[j].n_far = 0; } else nrec += segs[j].n_rec;
+            segs[j].base_first = nf; segs[j].base_other = no; segs[j].base_far = nfar;
+            nf += segs[j].n_first; no += segs[j].n_other; nfar += segs[j].n_far;
             if (!stt && segs[j].max_span > max_span) max_span = segs[j].max_span;
         }
     }
     if (res) {
-        res->n_first = nf; res->n_other = no; res->n_reads = nrec;
+        res->n_first = nf; res->n_other = no + nfar; res->n_reads = nrec;
         uint64_t fs = ~0ull, E = 0;
         for (uint32_t j = seg0[0]; j < seg0[1]; ++j) { if (fs == ~0ull && segs[j].used_start != pdb2::NONE) fs = segs[j].used_start; if (segs[j].e_last > E) E = segs[j].e_last; }
         res->first_start = fs; res->next_start = E ? E : ~0ull;
     }
     // ---- pass 2: the runs ----
-    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, max_span};
+    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, nullptr, nfar, max_span};
     lap(4);                                                               // host: chain check, unit outcomes
-    if (nf + no) {
+    if (nf + no + nfar) {
         auto grab = [&](uint64_t n, pd_iv **out) -> bool {
             const size_t bytes = ((size_t)n * sizeof(pd_iv) + 255) & ~(size_t)255;
             const size_t at = c->arena_used.fetch_add(bytes);
@@ -1026,9 +1034,10 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         };
         if (nf && !grab(nf, &rs.first)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
         if (no && !grab(no, &rs.other)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+        if (nfar && !grab(nfar, &rs.far)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
         HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
         lap(5);                                                           // run array allocation
-        launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other);
+        launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far);
     }
     HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
@@ -1041,7 +1050,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) res->ms_walk = ms;
         if (hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]) == hipSuccess) res->ms_emit = ms;
     }
-    if (nf + no) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
+    if (nf + no + nfar) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
     return PD_OK;
 }
 
@@ -1059,39 +1068,46 @@ int pd_decode_end(pd_ctx *c)
     std::vector<pd_ctx::RunSeg> segs;
     { std::lock_guard<std::mutex> l2(c->dec_mu); segs.swap(c->run_segs); }
     std::sort(segs.begin(), segs.end(), [](const pd_ctx::RunSeg &a, const pd_ctx::RunSeg &b) { return a.order < b.order; });
-    uint64_t nf = 0, no = 0; uint32_t span = 0;
-    for (auto &r : segs) { nf += r.n_first; no += r.n_other; if (r.max_span > span) span = r.max_span; }
+    uint64_t nf = 0, no = 0, nfar = 0; uint32_t span = 0;
+    for (auto &r : segs) { nf += r.n_first; no += r.n_other; nfar += r.n_far; if (r.max_span > span) span = r.max_span; }
     auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
-    auto drop = [&]() { for (auto &r : segs) { if (r.first && !in_arena(r.first)) (void)hipFree(r.first); if (r.other && !in_arena(r.other)) (void)hipFree(r.other); } };
-    if (c->run_first || c->run_other) {
+    auto drop = [&]() { for (auto &r : segs) for (pd_iv *q : {r.first, r.other, r.far}) if (q && !in_arena(q)) (void)hipFree(q); };
+    if (c->run_first || c->run_other || c->run_far) {
         // an earlier sample of this context (#.list: one file after another) may still be deferred on these arrays
         int rf = flush_pending(c);
         if (rf) { drop(); return rf; }
         HIPOK(c, hipStreamSynchronize(c->stream));
-        if (c->run_first) { (void)hipFree(c->run_first); c->run_first = nullptr; }
-        if (c->run_other) { (void)hipFree(c->run_other); c->run_other = nullptr; }
+        for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
     }
-    if (nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
-    if (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
-    uint64_t of = 0, oo = 0;
+    if ((nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) || (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) ||
+        (nfar && hipMalloc(&c->run_far, (size_t)nfar * sizeof(pd_iv)) != hipSuccess)) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
+    uint64_t of = 0, oo = 0, ofar = 0;
     for (auto &r : segs) {
         if (r.n_first) HIPOK(c, hipMemcpyAsync(c->run_first + of, r.first, (size_t)r.n_first * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
         if (r.n_other) HIPOK(c, hipMemcpyAsync(c->run_other + oo, r.other, (size_t)r.n_other * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
-        of += r.n_first; oo += r.n_other;
+        if (r.n_far) HIPOK(c, hipMemcpyAsync(c->run_far + ofar, r.far, (size_t)r.n_far * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
+        of += r.n_first; oo += r.n_other; ofar += r.n_far;
     }
     HIPOK(c, hipStreamSynchronize(c->stream));
     drop();
-    // the sample, deferred: first runs position sorted (a coordinate-sorted file), the others trail their read's start by
-    // at most `span` cells; an unsorted file, or reads spanning more than a few tiles, take the atomic path
+    // the sample, deferred, as up to three streams in file order: every read's first run (position sorted for a
+    // coordinate-sorted file: exact tile bounds), its later runs that begin within NEAR_SPAN bases of its start (they trail
+    // the sorted order by at most that), and the few that follow a long gap (N operations: they trail by up to `span`).
+    // An unsorted file, or gaps of more than a few tiles, take the atomic path.
     const bool sorted = c->dec_cfg.sorted != 0;
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
-                        "host chain check %.3f, run arrays %.3f, wait emit %.3f; %zu batches\n", g_dec_us[0] / 1e6, g_dec_us[1] / 1e6, g_dec_us[2] / 1e6,
-                g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, segs.size());
+                        "host chain check %.3f, run arrays %.3f, wait emit %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u)\n", g_dec_us[0] / 1e6,
+                g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, segs.size(),
+                (unsigned long long)nf, (unsigned long long)no, (unsigned long long)nfar, span);
     int rc = PD_OK;
-    if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | (no && span <= (1u << 14) ? PD_PUSH_MORE : 0u)) : PD_PUSH_DEFAULT, -1, nullptr);
-    if (rc == PD_OK && no)
-        rc = scatter_device(c, c->run_other, (size_t)no, sorted && span <= (1u << 14) ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(span + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
+    // disorder of a stream = how far its runs may trail the sorted order: the near stream by near_span (when the split is on,
+    // otherwise by the longest gap seen, like the far stream)
+    const uint32_t near_dis = nfar ? (c->dec_near_span < span ? c->dec_near_span : span) : span;
+    const bool near_sorted = sorted && near_dis <= (1u << 14), far_sorted = sorted && span <= (1u << 14);
+    if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE) : PD_PUSH_DEFAULT, -1, nullptr);
+    if (rc == PD_OK && no) rc = scatter_device(c, c->run_other, (size_t)no, near_sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(near_dis + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
+    if (rc == PD_OK && nfar) rc = scatter_device(c, c->run_far, (size_t)nfar, far_sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(span + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
     return rc;
 }
 
@@ -1103,7 +1119,7 @@ int pd_decode_abort(pd_ctx *c)
     c->dec_open = false;
     (void)hipSetDevice(c->device);
     auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
-    for (auto &r : c->run_segs) { if (r.first && !in_arena(r.first)) (void)hipFree(r.first); if (r.other && !in_arena(r.other)) (void)hipFree(r.other); }
+    for (auto &r : c->run_segs) for (pd_iv *q : {r.first, r.other, r.far}) if (q && !in_arena(q)) (void)hipFree(q);
     c->run_segs.clear();
     return PD_OK;
 }
@@ -1131,22 +1147,22 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     pd_decode_result res;
     if ((rc = pd_decode_submit(c, &bt, unit_status, &res))) return rc;
     if (n_records) *n_records = res.n_reads;
-    pd_ctx::RunSeg mine{0, nullptr, 0, nullptr, 0, 0};
+    pd_ctx::RunSeg mine{0, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     {
         std::lock_guard<std::mutex> lk(c->dec_mu);
         for (size_t i = 0; i < c->run_segs.size(); ++i)
             if (c->run_segs[i].order == bt.order) { mine = c->run_segs[i]; c->run_segs.erase(c->run_segs.begin() + (long)i); break; }
     }
-    if (mine.n_first + mine.n_other) {
+    if (mine.n_first + mine.n_other + mine.n_far) {
         std::unique_lock<std::mutex> lk(c->mu);
         if (int rs = need_state(c, 0, "pd_push_bgzf_units")) return rs;
         HIPOK(c, hipSetDevice(c->device));
         if (mine.n_first) { rc = scatter_device(c, mine.first, (size_t)mine.n_first, PD_PUSH_SORTED, -1, nullptr); if (rc) return rc; }
         if (mine.n_other) { rc = scatter_device(c, mine.other, (size_t)mine.n_other, PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
+        if (mine.n_far) { rc = scatter_device(c, mine.far, (size_t)mine.n_far, PD_PUSH_DEFAULT, -1, nullptr); if (rc) return rc; }
         HIPOK(c, hipStreamSynchronize(c->stream));
         const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
-        if (mine.first && !ina(mine.first)) (void)hipFree(mine.first);
-        if (mine.other && !ina(mine.other)) (void)hipFree(mine.other);
+        for (pd_iv *q : {mine.first, mine.other, mine.far}) if (q && !ina(q)) (void)hipFree(q);
     }
     return PD_OK;
 }
@@ -1303,7 +1319,7 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
 {
     *done = false;
     HIPOK(c, hipMemsetAsync(dev_count, 0, 4, c->stream));
-    HIPOK(c, hipMemsetAsync(c->direct_words, 0, 16, c->stream));
+    HIPOK(c, hipMemsetAsync(c->direct_words, 0, 64, c->stream));
     PendSet ps{};
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     uint64_t all = 0;
@@ -1325,7 +1341,7 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_export");
       launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
-                           c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 4, c->direct_words + 2, grid); }
+                           c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
     HIPOK(c, hipGetLastError());
     uint32_t words[2] = {0, 0};
     HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));

@@ -113,6 +113,6 @@ namespace pdk {
 void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes,
                           const uint32_t *only, uint32_t n_only);
 void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                          pd_iv *first, pd_iv *other);
+                          pd_iv *first, pd_iv *other, pd_iv *far);
 }
 #endif

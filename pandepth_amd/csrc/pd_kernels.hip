@@ -882,7 +882,7 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
 // longer than the look-back; re-arms the descriptors (the batches stay pending for the fallback).
 __global__ void k_finish_direct(const PendSet ps, const uint32_t *n_long, uint32_t *fail)
 {
-    uint32_t bad = *n_long != 0;
+    uint32_t bad = *n_long != 0, errs = 0;
     uint64_t handled = 0, has = 0, ends = 0, n = 0;
     for (int b = 0; b < ps.nb; ++b) {
         BatchDesc *desc = ps.b[b].desc;
@@ -892,10 +892,16 @@ __global__ void k_finish_direct(const PendSet ps, const uint32_t *n_long, uint32
         }
         n += ps.b[b].n;
         if (desc->err) bad = 1;
+        errs |= desc->err;
         desc->ovf_count = 0; desc->err = 0; desc->t_first = 0; desc->n_active = 0;
     }
     if (handled != n || has != ends) bad = 1;
     *fail = bad;
+    if (bad) {                                   // why (read by the host for its diagnostics): fail + 2 .. fail + 9
+        const uint32_t err = errs;
+        fail[2] = (uint32_t)handled; fail[3] = (uint32_t)(handled >> 32); fail[4] = (uint32_t)n; fail[5] = (uint32_t)(n >> 32);
+        fail[6] = (uint32_t)has; fail[7] = (uint32_t)ends; fail[8] = err; fail[9] = *n_long;
+    }
 }
 
 // Zero-fills every half-tile that has not been written since the last reset (and marks it), so

@@ -28,9 +28,9 @@ static bool gunzip_all(const char *path, std::vector<uint8_t> &out)
 
 // the host side of a batch: validate the chain across segments, give every segment its output offsets.
 // Returns the number of segments that must be walked again (their hint has been corrected).
-static int finish(std::vector<Seg> &segs, uint64_t *tot_first, uint64_t *tot_other, uint32_t *flags, uint32_t *max_span)
+static int finish(std::vector<Seg> &segs, uint64_t *tot_first, uint64_t *tot_other, uint64_t *tot_far, uint32_t *flags, uint32_t *max_span)
 {
-    int bad = 0; uint64_t E = 0, f = 0, o = 0; *flags = 0; *max_span = 0;
+    int bad = 0; uint64_t E = 0, f = 0, o = 0, fr = 0; *flags = 0; *max_span = 0;
     for (auto &s : segs) {
         if (s.unit_first) E = 0;
         else {
@@ -39,22 +39,23 @@ static int finish(std::vector<Seg> &segs, uint64_t *tot_first, uint64_t *tot_oth
             if (!ok) { s.hint = E; ++bad; }
         }
         if (s.e_last > E) E = s.e_last;
-        s.base_first = f; s.base_other = o; f += s.n_first; o += s.n_other;
+        s.base_first = f; s.base_other = o; s.base_far = fr; f += s.n_first; o += s.n_other; fr += s.n_far;
         *flags |= s.flags; if (s.max_span > *max_span) *max_span = s.max_span;
     }
-    *tot_first = f; *tot_other = o;
+    *tot_first = f; *tot_other = o; *tot_far = fr;
     return bad;
 }
 
 int main(int argc, char **argv)
 {
-    uint32_t mask = 1796; int mapq = 0; bool guess_all = true; int seg_kb = 64;
+    uint32_t mask = 1796, near_span = 0xFFFFFFFFu; int mapq = 0; bool guess_all = true; int seg_kb = 64;
     int bad_files = 0;
     for (int a = 1; a < argc; ++a) {
         if (!strcmp(argv[a], "-x")) { mask = (uint32_t)atoi(argv[++a]); continue; }
         if (!strcmp(argv[a], "-q")) { mapq = atoi(argv[++a]); continue; }
         if (!strcmp(argv[a], "-noguess")) { guess_all = false; continue; }
         if (!strcmp(argv[a], "-seg")) { seg_kb = atoi(argv[++a]); continue; }
+        if (!strcmp(argv[a], "-near")) { near_span = (uint32_t)atoi(argv[++a]); continue; }
         const char *path = argv[a];
         std::vector<uint8_t> d;
         if (!gunzip_all(path, d)) { fprintf(stderr, "cannot read %s\n", path); return 2; }
@@ -81,7 +82,7 @@ int main(int argc, char **argv)
         for (uint32_t i = 0; i < n_ref; ++i) { const uint32_t ln = rd32(d.data() + o); o += 4 + ln; lens[i] = rd32(d.data() + o); o += 4; }
         d.resize(d.size() + 64, 0);
         Cfg c; c.buf = d.data(); c.avail = d.size() - 64; c.n_ref = (int32_t)n_ref; c.contig_len = lens.data(); c.contig_on = on.data();
-        c.flag_mask = mask; c.min_mapq = mapq; c.span_off = nullptr; c.spans = nullptr;
+        c.flag_mask = mask; c.min_mapq = mapq; c.span_off = nullptr; c.spans = nullptr; c.near_span = near_span;
         std::vector<Seg> segs;
         const uint64_t SB = (uint64_t)seg_kb * 1024;
         for (uint64_t b = o; b < c.avail; b += SB) {
@@ -92,20 +93,24 @@ int main(int argc, char **argv)
         if (segs.empty()) { printf("%s: no records\n", path); continue; }
         std::vector<LaneOut> lanes(segs.size() * 64);
         for (size_t j = 0; j < segs.size(); ++j) walk_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64]);
-        uint64_t tf = 0, to = 0; uint32_t fl = 0, ms = 0; int redo = 0, rounds = 0;
-        while ((redo = finish(segs, &tf, &to, &fl, &ms)) > 0 && rounds < 4) {
+        uint64_t tf = 0, to = 0, tfar = 0; uint32_t fl = 0, ms = 0; int redo = 0, rounds = 0;
+        while ((redo = finish(segs, &tf, &to, &tfar, &fl, &ms)) > 0 && rounds < 4) {
             ++rounds;
             for (size_t j = 0; j < segs.size(); ++j) if (segs[j].hint != NONE && !segs[j].unit_first && segs[j].used_start != segs[j].hint && !(segs[j].hint >= segs[j].end && segs[j].used_start == NONE))
                 walk_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64]);
         }
         (void)guess_all;
-        std::vector<pd_iv> first(tf + 1), other(to + 1);
-        for (size_t j = 0; j < segs.size(); ++j) emit_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64], first.data(), other.data());
+        std::vector<pd_iv> first(tf + 1), other(to + 1), far(tfar + 1);
+        for (size_t j = 0; j < segs.size(); ++j) emit_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64], first.data(), other.data(), far.data());
         std::vector<Run> got_first, got_other;
         for (uint64_t i = 0; i < tf; ++i) got_first.push_back(Run(first[i].tid, first[i].beg, first[i].end));
         for (uint64_t i = 0; i < to; ++i) got_other.push_back(Run(other[i].tid, other[i].beg, other[i].end));
+        for (uint64_t i = 0; i < tfar; ++i) got_other.push_back(Run(far[i].tid, far[i].beg, far[i].end));
         const bool same_first = got_first == exp_first;                  // file order
+        // the later runs come out as two streams (near / far from their read's start), each in file order: same multiset
+        std::sort(got_other.begin(), got_other.end()); std::sort(exp_other.begin(), exp_other.end());
         const bool same_other = got_other == exp_other;
+        to += tfar;
         printf("%s: %llu records, %zu segments (%d corrected in %d extra rounds), first runs %llu (expected %zu) %s, other runs %llu (expected %zu) %s, flags %u, max span %u\n",
                path, (unsigned long long)n_rec, segs.size(), redo, rounds, (unsigned long long)tf, exp_first.size(), same_first ? "identical" : "DIFFERENT",
                (unsigned long long)to, exp_other.size(), same_other ? "identical" : "DIFFERENT", fl, ms);

@@ -33,7 +33,7 @@ struct pd_ctx {
     pd_decode_cfg dcfg{}; std::vector<uint8_t> on; std::vector<uint32_t> soff; std::vector<int32_t> spans;
     struct Buf { std::vector<uint8_t> b; bool busy = false; };
     std::vector<Buf *> bufs;
-    struct Runs { uint64_t order; std::vector<pd_iv> first, other; };
+    struct Runs { uint64_t order; std::vector<pd_iv> first, other, far; };
     std::vector<Runs> runs;
 };
 
@@ -195,6 +195,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     cfg.buf = inf.data(); cfg.avail = bt->inflated_bytes; cfg.n_ref = (int32_t)c->len.size(); cfg.contig_len = c->len.data(); cfg.contig_on = c->on.data();
     cfg.flag_mask = c->dcfg.flag_mask; cfg.min_mapq = c->dcfg.min_mapq;
     cfg.span_off = c->soff.empty() ? nullptr : c->soff.data(); cfg.spans = c->soff.empty() ? nullptr : c->spans.data();
+    cfg.near_span = getenv("PANDEPTH_TEST_NEAR_SPAN") ? (uint32_t)atoi(getenv("PANDEPTH_TEST_NEAR_SPAN")) : 0xFFFFFFFFu;
     std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0(bt->n_units + 1, 0);
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         const pd_decode_unit &un = bt->units[u];
@@ -221,7 +222,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
         if (round == 4) { for (size_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
         for (size_t j : redo) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
     }
-    uint64_t nf = 0, no = 0, nrec = 0;
+    uint64_t nf = 0, no = 0, nfar = 0, nrec = 0;
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         int st = 0;
         const pd_decode_unit &un = bt->units[u];
@@ -229,19 +230,20 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) { if (segs[j].flags & pdb2::WF_BAD) st = 2; else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && !st) st = 1; }
         status[u] = st;
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
-            if (st) segs[j].n_first = segs[j].n_other = 0; else nrec += segs[j].n_rec;
-            segs[j].base_first = nf; segs[j].base_other = no; nf += segs[j].n_first; no += segs[j].n_other;
+            if (st) segs[j].n_first = segs[j].n_other = segs[j].n_far = 0; else nrec += segs[j].n_rec;
+            segs[j].base_first = nf; segs[j].base_other = no; segs[j].base_far = nfar; nf += segs[j].n_first; no += segs[j].n_other; nfar += segs[j].n_far;
         }
     }
     if (res) {
-        res->n_first = nf; res->n_other = no; res->n_reads = nrec;
+        res->n_first = nf; res->n_other = no + nfar; res->n_reads = nrec;
         uint64_t fs = ~0ull, E = 0;
         for (uint32_t j = seg0[0]; j < seg0[1]; ++j) { if (fs == ~0ull && segs[j].used_start != pdb2::NONE) fs = segs[j].used_start; if (segs[j].e_last > E) E = segs[j].e_last; }
         res->first_start = fs; res->next_start = E ? E : ~0ull;
     }
-    pd_ctx::Runs r; r.order = bt->order; r.first.resize(nf + 1); r.other.resize(no + 1);
-    for (size_t j = 0; j < segs.size(); ++j) if (segs[j].n_first | segs[j].n_other) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data());
-    r.first.resize(nf); r.other.resize(no);
+    pd_ctx::Runs r; r.order = bt->order; r.first.resize(nf + 1); r.other.resize(no + 1); r.far.resize(nfar + 1);
+    for (size_t j = 0; j < segs.size(); ++j)
+        if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data());
+    r.first.resize(nf); r.other.resize(no); r.far.resize(nfar);
     std::lock_guard<std::mutex> lk(c->mu);
     c->runs.push_back(std::move(r));
     return 0;
@@ -251,11 +253,13 @@ static int o_decode_end(pd_ctx *c)
     std::vector<pd_ctx::Runs> rs;
     { std::lock_guard<std::mutex> lk(c->mu); rs.swap(c->runs); }
     std::sort(rs.begin(), rs.end(), [](const pd_ctx::Runs &a, const pd_ctx::Runs &b) { return a.order < b.order; });
-    std::vector<pd_iv> first, other;
-    for (auto &r : rs) { first.insert(first.end(), r.first.begin(), r.first.end()); other.insert(other.end(), r.other.begin(), r.other.end()); }
+    std::vector<pd_iv> first, other, far;
+    for (auto &r : rs) { first.insert(first.end(), r.first.begin(), r.first.end()); other.insert(other.end(), r.other.begin(), r.other.end()); far.insert(far.end(), r.far.begin(), r.far.end()); }
     // the product pushes the first runs as a SORTED batch when the file is coordinate sorted: hold it to that promise
     int rc = first.empty() ? 0 : o_push(c, first.data(), first.size(), c->dcfg.sorted ? PD_PUSH_SORTED : PD_PUSH_DEFAULT);
-    if (!rc && !other.empty()) rc = o_push(c, other.data(), other.size(), PD_PUSH_DEFAULT);
+    // ... and the near stream as sorted within NEAR_SPAN cells, as the product promises the engine
+    if (!rc && !other.empty()) rc = o_push(c, other.data(), other.size(), (c->dcfg.sorted && getenv("PANDEPTH_TEST_NEAR_SPAN")) ? (PD_PUSH_SORTED | PD_PUSH_DISORDER((unsigned)atoi(getenv("PANDEPTH_TEST_NEAR_SPAN")))) : PD_PUSH_DEFAULT);
+    if (!rc && !far.empty()) rc = o_push(c, far.data(), far.size(), PD_PUSH_DEFAULT);
     return rc;
 }
 static int o_decode_abort(pd_ctx *c) { std::lock_guard<std::mutex> lk(c->mu); c->runs.clear(); return 0; }

@@ -99,3 +99,106 @@ def test_fullsize_properties(sample):
     load(s, times=2)
     _, covd, totd = eng.scan_reduce_windows(BIN, 1, 0)
     assert np.array_equal(covd, cov) and np.array_equal(totd, 2 * tot)
+
+
+def load3(s):
+    """three deferred streams (first / near / far runs): what the product's GPU decoder emits with "decode_near_span" set"""
+    eng, pda, synth = s["eng"], s["pda"], s["synth"]
+    if "near" not in s:
+        torch = s["torch"]
+        other = s["other"]
+        # the same seeded generator, asked for the split streams (near: second runs within NEAR_SPAN of their read's start)
+        first, near, far = synth.gen_runs_torch(s["lens"], int(1e9), torch.device("cuda", 0), seed=4242, split=True)
+        assert int(first.shape[0]) == int(s["first"].shape[0]) and int(near.shape[0]) + int(far.shape[0]) == int(other.shape[0])
+        s["near"], s["far"] = near, far
+        del first
+        torch.cuda.synchronize()              # the engine reads these on its own stream
+    eng.reset()
+    eng.push_intervals_device(s["first"].data_ptr(), int(s["first"].shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+    eng.push_intervals_device(s["near"].data_ptr(), int(s["near"].shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(synth.NEAR_SPAN))
+    eng.push_intervals_device(s["far"].data_ptr(), int(s["far"].shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+
+
+def test_fullsize_direct_path(sample):
+    """The direct window path (k_direct_tiles: no difference arrays in HBM; what the pandepth executable runs in
+    whole-chromosome mode) at full size: mass conservation, and the same tables as the atomic path, for 10 Mb bins,
+    1 kb windows (narrow instantiation) and the 18-bit wrap."""
+    s = sample
+    eng = s["eng"]
+    load(s, flags_sorted=False)
+    eng.set_param("direct_windows", 0)
+    _, cov_a, tot_a = eng.scan_reduce_windows(BIN, 1, 0)
+    w1off, c1_a, t1_a = eng.scan_reduce_windows(1000, 1, 0)
+    eng.set_param("direct_windows", 1)
+    try:
+        for w, wrap, ec, et in ((BIN, 0, cov_a, tot_a), (BIN, 18, cov_a, tot_a), (1000, 0, c1_a, t1_a)):
+            load3(s)
+            _, cov, tot = eng.scan_reduce_windows(w, 1, wrap)
+            # the direct call consumed the sample: the arrays are still empty
+            with pytest.raises(s["pda"].PdError):
+                eng.scan(0)
+            assert int(tot.sum()) == s["mass"]
+            assert np.array_equal(cov, ec) and np.array_equal(tot, et), (w, wrap)
+    finally:
+        eng.set_param("direct_windows", 0)
+
+
+def test_fullsize_gff_config(sample):
+    """configs[2] at full size: a synthetic annotation of 33 688 transcripts / 175 274 CDS entries (README:128) on the 1e9-record
+    sample: pd_reduce_intervals against sums of pd_read_depth slices for sampled entries, and against window statistics for
+    entries laid exactly on windows; -d 5 against a threshold applied to the same cells."""
+    s = sample
+    eng, lens = s["eng"], s["lens"]
+    rng = np.random.default_rng(33688)
+    n_tr, n_cds = 33688, 175274
+    per = rng.multinomial(n_cds - n_tr, np.ones(n_tr) / n_tr) + 1
+    tid = rng.choice(12, n_tr, p=lens[:12] / lens[:12].sum())
+    regs = np.zeros((n_cds, 3), dtype=np.int32)
+    k = 0
+    for t in range(n_tr):
+        start = int(rng.integers(1, lens[tid[t]] - 40000))
+        for _ in range(per[t]):
+            ln = int(np.clip(rng.lognormal(np.log(150), 0.7), 30, 3000))
+            regs[k] = (tid[t], start, start + ln - 1)
+            start += ln + int(rng.integers(50, 1500))
+            k += 1
+    load(s)
+    eng.scan(18)
+    c, t = eng.reduce_intervals(regs, 1)
+    c5, t5 = eng.reduce_intervals(regs, 5)
+    assert np.all(c5 <= c) and np.all(t5 <= t) and int(c.sum()) > 0
+    for i in rng.choice(n_cds, 400, replace=False):
+        tt, a, b = int(regs[i, 0]), int(regs[i, 1]), int(regs[i, 2])
+        cells = eng.read_depth(tt, a - 1, b - a + 1).astype(np.int64)
+        assert int(c[i]) == int((cells >= 1).sum()) and int(t[i]) == int(cells.sum())
+        assert int(c5[i]) == int((cells >= 5).sum()) and int(t5[i]) == int(cells[cells >= 5].sum())
+    # total over all entries == total over the same cells counted with multiplicity
+    assert int(t.sum()) == sum(int(x) for x in t)
+
+
+def test_fullsize_w100_config(sample):
+    """configs[3] at full size: -w 100 fused (from the difference arrays) and from the depth arrays give the same 3.0e7
+    windows; they add up to the -w 1000 windows and to the 10 Mb bins; the per-site read-back of a whole chromosome adds
+    up to its windows (the -a stream is those cells, one line each)."""
+    s = sample
+    eng, lens = s["eng"], s["lens"]
+    load(s)
+    woff, cov, tot = eng.scan_reduce_windows(BIN, 1, 18)
+    w1, c1, t1 = eng.scan_reduce_windows(1000, 1, 18)
+    w100, c100, t100 = eng.scan_reduce_windows(100, 1, 18)
+    eng.scan(18)
+    _, d100, e100 = eng.reduce_windows(100, 1)
+    assert np.array_equal(d100, c100) and np.array_equal(e100, t100)
+    assert int(t100.sum()) == s["mass"] == int(tot.sum())
+    for t in (0, 7, 11, 40):
+        a = c100[w100[t]:w100[t + 1]].astype(np.int64); b = t100[w100[t]:w100[t + 1]].astype(np.int64)
+        n1 = int(w1[t + 1] - w1[t])
+        pad = n1 * 10 - a.size
+        a = np.concatenate([a, np.zeros(pad, dtype=np.int64)]).reshape(n1, 10).sum(1)
+        b = np.concatenate([b, np.zeros(pad, dtype=np.int64)]).reshape(n1, 10).sum(1)
+        assert np.array_equal(a, c1[w1[t]:w1[t + 1]].astype(np.int64)) and np.array_equal(b, t1[w1[t]:w1[t + 1]].astype(np.int64))
+    t = 7                                                                 # a whole chromosome's per-site cells (-a)
+    cells = eng.read_depth(t, 0, int(lens[t])).astype(np.int64)
+    n = cells.size // 100 * 100
+    assert np.array_equal(cells[:n].reshape(-1, 100).sum(1), t100[w100[t]:w100[t] + n // 100].astype(np.int64))
+    assert np.array_equal((cells[:n].reshape(-1, 100) >= 1).sum(1), c100[w100[t]:w100[t] + n // 100].astype(np.int64))

@@ -107,16 +107,21 @@ def records_to_runs(rec):
 # ------------------------------------------------------------------------------------------------
 # torch generator (bench: the whole stream is produced in HBM)
 # ------------------------------------------------------------------------------------------------
-def gen_runs_torch(lens, n_records, device, seed=42):
+NEAR_SPAN = 1024      # pd_bamwalk.h: later runs of a read that begin within this many bases of its start
+
+
+def gen_runs_torch(lens, n_records, device, seed=42, split=False):
     """Same workload definition as gen_records_numpy + records_to_runs, generated on `device`.
-    Returns (sorted_runs int32 (n,3), other_runs int32 (m,3)) as torch tensors."""
+    Returns (sorted_runs int32 (n,3), other_runs int32 (m,3)) as torch tensors; with split=True the other runs come
+    as the two streams the product's decoder emits: (near, far) = second runs that begin within NEAR_SPAN bases of
+    their read's start / after a longer gap (N operations)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rng = np.random.default_rng(seed)
     per = records_per_contig(lens, n_records)
     first = torch.empty((int(n_records), 3), dtype=torch.int32, device=device)
-    others = []
+    others, fars = [], []
     o = 0
     for t, (ln, n) in enumerate(zip(lens, per)):
         n = int(n)
@@ -155,10 +160,17 @@ def gen_runs_torch(lens, n_records, device, seed=42):
         second_len = torch.where(kind == 2, READ_LEN - a - x, READ_LEN - a)
         b2 = (pos + a + gap)[two]
         oth = torch.stack([torch.full_like(b2, t), b2, b2 + second_len[two]], dim=1)
-        others.append(oth)
+        if split:
+            isfar = ((a + gap) > NEAR_SPAN)[two]
+            others.append(oth[~isfar]); fars.append(oth[isfar])
+        else:
+            others.append(oth)
         o += n
         del r, kind, a, xr, x, first_len, two, gap, second_len, b2, pos
     other = torch.cat(others, 0).contiguous() if others else torch.empty((0, 3), dtype=torch.int32, device=device)
+    if split:
+        far = torch.cat(fars, 0).contiguous() if fars else torch.empty((0, 3), dtype=torch.int32, device=device)
+        return first[:o].contiguous(), other, far
     return first[:o].contiguous(), other
 
 
