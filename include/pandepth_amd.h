@@ -209,6 +209,23 @@ int pd_slice_sweep_i4(pd_ctx *ctx, const void *dev_parts, uint32_t n_parts, uint
                       uint32_t w, uint32_t min_dep, unsigned wrap_bits, void *dev_partials);
 int pd_gather_windows(pd_ctx *ctx, const void *dev_partials, uint32_t w, uint32_t *cover, uint64_t *sum);
 
+/* ---- the same sliced sum with RCCL called from inside the library (replaces SURVEY §8(b)'s pd_allreduce_diff(ctx, ncclComm_t,
+ * root): no GPU ever receives everybody's arrays).  One pd_comm per rank = per context = per GPU; the ranks may be threads of one
+ * process (pd_comm_init_all: ncclCommInitAll over the contexts' devices — the CLI's `#.list` mode) or processes
+ * (pd_comm_unique_id on one of them, the 128 bytes handed to the others by whatever launcher there is, pd_comm_init on each).
+ * pd_sliced_window_sum is COLLECTIVE — every rank calls it, in one process from one thread per rank — and does, on each context's
+ * stream: pd_export_i4 -> grouped ncclSend / ncclRecv of the 1/n slices between all pairs (messages of <= 256 MiB) ->
+ * ncclAllReduce of the int32 tile sums + ncclAllGather of the exception blocks -> pd_slice_sweep_i4 on the rank's slice ->
+ * 24 B per tile to `root` -> pd_gather_windows there.  Windows of w >= 8192 cells (whole-chromosome mode, PD:2704-3014 + PD:3978). */
+typedef struct pd_comm pd_comm;
+#define PD_UNIQUE_ID_BYTES 128
+int pd_comm_unique_id(void *id128);
+int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm **out);
+int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms);
+int pd_comm_destroy(pd_comm *comm);
+const char *pd_comm_strerror(const pd_comm *comm);
+int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
+
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
 /* Waits for everything queued.  Deferred batches (PD_PUSH_MORE) are scattered first — except that with "direct_windows"
  * set a whole deferred sample in an otherwise empty context stays deferred (its memory must then stay valid until the

@@ -6,6 +6,8 @@
 // reader threads overlap decode, PCIe and the scatter kernel.  No CPU fallback exists here:
 // without a gfx950 device pd_create fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1473,6 +1475,208 @@ int pd_profile_get(pd_ctx *c, const char *name, double *ms, uint64_t *launches)
     auto it = c->prof_acc.find(name);
     if (ms) *ms = it == c->prof_acc.end() ? 0.0 : it->second.first;
     if (launches) *launches = it == c->prof_acc.end() ? 0 : it->second.second;
+    return PD_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-sample sum over several GPUs with RCCL called from here (include/pandepth_amd.h: pd_comm_*, pd_sliced_window_sum):
+// the C++ form of pandepth_amd/multi.py's SlicedSum, for the CLI's `#.list` mode and for any host that is not Python.
+// ---------------------------------------------------------------------------------------------------------------
+struct pd_comm {
+    pd_ctx *ctx = nullptr;
+    ncclComm_t nccl = nullptr;
+    int rank = 0, world = 1;
+    uint64_t n_tiles = 0, slice_tiles = 0, slice_bytes = 0, tile_first = 0, tile_count = 0, n_sums = 0;
+    uint8_t *send = nullptr, *recv = nullptr, *part_mine = nullptr, *part_all = nullptr;
+    int32_t *meta = nullptr;
+    pd_exc *exc = nullptr, *exc_all = nullptr;
+    uint32_t *count = nullptr;
+    std::string err;
+};
+
+namespace {
+// RCCL is loaded on first use (dlopen): librccl.so is half a gigabyte of code objects that a single-GPU run never needs,
+// and the executable's start-up time is part of its end-to-end figure.
+struct Rccl {
+    void *h = nullptr;
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclAllReduce) AllReduce = nullptr;
+    decltype(&::ncclAllGather) AllGather = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *p : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) if ((r.h = dlopen(p, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.h) return;
+#define PD_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
+        PD_SYM(GetUniqueId); PD_SYM(CommInitRank); PD_SYM(CommInitAll); PD_SYM(CommDestroy); PD_SYM(GroupStart); PD_SYM(GroupEnd);
+        PD_SYM(Send); PD_SYM(Recv); PD_SYM(AllReduce); PD_SYM(AllGather); PD_SYM(GetErrorString);
+#undef PD_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce &&
+               r.AllGather && r.GetErrorString;
+    });
+    return r;
+}
+constexpr uint32_t COMM_EXC_BLOCK = 1u << 18;       // exceptions (cells outside the 4-bit range) per rank
+constexpr size_t COMM_MSG_BYTES = (size_t)1 << 28;  // RCCL 2.26 delivers only the first half of a send/recv above 1 GiB: stay far below
+
+int comm_fail(pd_comm *m, int code, const std::string &msg) { m->err = msg; if (m->ctx) { std::lock_guard<std::mutex> lk(m->ctx->mu); m->ctx->err = msg; } return code; }
+#define NCCLOK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); } while (0)
+#define HIPCM(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int comm_setup(pd_comm *m)
+{
+    pd_ctx *c = m->ctx;
+    m->n_tiles = c->n_tiles; m->n_sums = c->n_words - c->n_cells;
+    m->slice_tiles = std::max<uint64_t>(1, (m->n_tiles + (uint64_t)m->world - 1) / (uint64_t)m->world);
+    m->slice_bytes = m->slice_tiles * (PD_TILE / 2);
+    m->tile_first = std::min<uint64_t>((uint64_t)m->rank * m->slice_tiles, m->n_tiles);
+    m->tile_count = std::min<uint64_t>(m->slice_tiles, m->n_tiles - m->tile_first);
+    const size_t W = (size_t)m->world;
+    HIPCM(m, hipSetDevice(c->device));
+    if (hipMalloc(&m->send, W * m->slice_bytes + 256) != hipSuccess || hipMalloc(&m->recv, W * m->slice_bytes + 256) != hipSuccess ||
+        hipMalloc(&m->meta, (m->n_sums + W + 16) * 4) != hipSuccess || hipMalloc(&m->exc, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess ||
+        hipMalloc(&m->exc_all, W * COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess || hipMalloc(&m->count, 64) != hipSuccess ||
+        hipMalloc(&m->part_mine, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess ||
+        hipMalloc(&m->part_all, W * m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess)
+        return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
+    HIPCM(m, hipMemsetAsync(m->send, 0, W * m->slice_bytes + 256, c->stream));          // the tail beyond n_cells / 2 stays zero
+    HIPCM(m, hipMemsetAsync(m->exc, 0, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), c->stream));
+    HIPCM(m, hipMemsetAsync(m->part_mine, 0, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64, c->stream));
+    HIPCM(m, hipStreamSynchronize(c->stream));
+    return PD_OK;
+}
+} // namespace
+
+extern "C" {
+
+int pd_comm_unique_id(void *id128)
+{
+    if (!id128) return PD_EINVAL;
+    if (!rccl().ok) return PD_ENODEV;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return PD_EHIP;
+    static_assert(sizeof(id) == PD_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id128, &id, sizeof id);
+    return PD_OK;
+}
+
+int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm **out)
+{
+    if (!ctx || !id128 || !out || rank < 0 || rank >= n_ranks) return PD_EINVAL;
+    *out = nullptr;
+    if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
+    pd_comm *m = new pd_comm; m->ctx = ctx; m->rank = rank; m->world = n_ranks;
+    ncclUniqueId id; memcpy(&id, id128, sizeof id);
+    if (hipSetDevice(ctx->device) != hipSuccess || rccl().CommInitRank(&m->nccl, n_ranks, id, rank) != ncclSuccess) {
+        { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: ncclCommInitRank failed"; }
+        delete m; return PD_EHIP;
+    }
+    const int rc = comm_setup(m);
+    if (rc) { pd_comm_destroy(m); return rc; }
+    *out = m;
+    return PD_OK;
+}
+
+int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms)
+{
+    if (!ctxs || !comms || n < 1) return PD_EINVAL;
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) { if (!ctxs[i]) return PD_EINVAL; devs[(size_t)i] = ctxs[i]->device; comms[i] = nullptr; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (devs[(size_t)i] == devs[(size_t)j]) {
+        std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
+    if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
+    std::vector<ncclComm_t> nc((size_t)n, nullptr);
+    if (rccl().CommInitAll(nc.data(), n, devs.data()) != ncclSuccess) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "ncclCommInitAll failed"; return PD_EHIP; }
+    int rc = PD_OK;
+    for (int i = 0; i < n; ++i) {
+        pd_comm *m = new pd_comm; m->ctx = ctxs[i]; m->rank = i; m->world = n; m->nccl = nc[(size_t)i];
+        comms[i] = m;
+        if (rc == PD_OK) rc = comm_setup(m);
+    }
+    if (rc) for (int i = 0; i < n; ++i) { pd_comm_destroy(comms[i]); comms[i] = nullptr; }
+    return rc;
+}
+
+int pd_comm_destroy(pd_comm *m)
+{
+    if (!m) return PD_OK;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->nccl) (void)rccl().CommDestroy(m->nccl);
+    for (void *p : {(void *)m->send, (void *)m->recv, (void *)m->meta, (void *)m->exc, (void *)m->exc_all, (void *)m->count, (void *)m->part_mine, (void *)m->part_all})
+        if (p) (void)hipFree(p);
+    delete m;
+    return PD_OK;
+}
+
+const char *pd_comm_strerror(const pd_comm *m) { return m ? m->err.c_str() : ""; }
+
+// Collective: every rank calls it (in one process: one thread per rank).  On `root`, cover / sum receive what
+// pd_scan_reduce_windows would give on a context holding the sum of all ranks' samples (windows of w >= 8192 cells).
+int pd_sliced_window_sum(pd_comm *m, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
+{
+    if (!m || root < 0 || root >= m->world || w < PD_TILE || wrap_bits > 32) return PD_EINVAL;
+    if (m->rank == root && (!cover || !sum)) return PD_EINVAL;
+    pd_ctx *c = m->ctx;
+    const size_t W = (size_t)m->world, sb = (size_t)m->slice_bytes;
+    HIPCM(m, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // 1. this rank's 4-bit image (straight from the tile windows in LDS when the sample is still deferred)
+    int rc = pd_export_i4(c, m->send, m->exc, COMM_EXC_BLOCK, m->count);
+    if (rc) return comm_fail(m, rc, std::string("pd_export_i4: ") + c->err);
+    HIPCM(m, hipMemcpyAsync(m->meta, c->sums, (size_t)m->n_sums * 4, hipMemcpyDeviceToDevice, st));
+    HIPCM(m, hipMemsetAsync(m->meta + m->n_sums, 0, W * 4, st));
+    HIPCM(m, hipMemcpyAsync(m->meta + m->n_sums + m->rank, m->count, 4, hipMemcpyDeviceToDevice, st));
+    // 2. the all-to-all: every pair of GPUs moves 1/world of the image over its own xGMI link, all links at once
+    HIPCM(m, hipMemcpyAsync(m->recv + (size_t)m->rank * sb, m->send + (size_t)m->rank * sb, sb, hipMemcpyDeviceToDevice, st));
+    for (size_t c0 = 0; c0 < sb && W > 1; c0 += COMM_MSG_BYTES) {
+        const size_t n = std::min(COMM_MSG_BYTES, sb - c0);
+        NCCLOK(m, rccl().GroupStart());
+        for (int p = 0; p < m->world; ++p) {
+            if (p == m->rank) continue;
+            NCCLOK(m, rccl().Send(m->send + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, st));
+            NCCLOK(m, rccl().Recv(m->recv + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, st));
+        }
+        NCCLOK(m, rccl().GroupEnd());
+    }
+    // 3. tile sums (+ exception counts) summed over the ranks; everybody's exception block to everybody
+    NCCLOK(m, rccl().AllReduce(m->meta, m->meta, (size_t)m->n_sums + W, ncclInt32, ncclSum, m->nccl, st));
+    NCCLOK(m, rccl().AllGather(m->exc, m->exc_all, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), ncclUint8, m->nccl, st));
+    // 4. this rank's slice: sum of the images, prefix sum, wrap, per-tile partials of the windows
+    rc = pd_slice_sweep_i4(c, m->recv, (uint32_t)W, sb, m->tile_first, m->tile_count, m->meta, m->exc_all, COMM_EXC_BLOCK, m->meta + m->n_sums, w, min_dep,
+                           wrap_bits, m->part_mine);
+    if (rc) return comm_fail(m, rc, std::string("pd_slice_sweep_i4: ") + c->err);
+    // 5. 24 bytes per tile to the root
+    const size_t pb = (size_t)m->slice_tiles * PD_TILE_PARTIAL_BYTES;
+    if (m->rank == root) HIPCM(m, hipMemcpyAsync(m->part_all + (size_t)root * pb, m->part_mine, pb, hipMemcpyDeviceToDevice, st));
+    if (W > 1) {
+        NCCLOK(m, rccl().GroupStart());
+        if (m->rank == root) { for (int p = 0; p < m->world; ++p) if (p != root) NCCLOK(m, rccl().Recv(m->part_all + (size_t)p * pb, pb, ncclUint8, p, m->nccl, st)); }
+        else NCCLOK(m, rccl().Send(m->part_mine, pb, ncclUint8, root, m->nccl, st));
+        NCCLOK(m, rccl().GroupEnd());
+    }
+    std::vector<int32_t> counts(W);
+    HIPCM(m, hipMemcpyAsync(counts.data(), m->meta + m->n_sums, W * 4, hipMemcpyDeviceToHost, st));
+    HIPCM(m, hipStreamSynchronize(st));
+    for (int32_t k : counts) if (k < 0 || (uint32_t)k > COMM_EXC_BLOCK) return comm_fail(m, PD_EINVAL, "a sample has more cells outside the 4-bit range than the exception block holds; use pd_accumulate_from");
+    if (m->rank == root) {
+        rc = pd_gather_windows(c, m->part_all, w, cover, sum);
+        if (rc) return comm_fail(m, rc, std::string("pd_gather_windows: ") + c->err);
+    }
     return PD_OK;
 }
 
