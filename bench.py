@@ -184,7 +184,15 @@ def main():
     # N > 1: int8 transport of the difference arrays (1 B/cell on the xGMI links instead of 4);
     # PD_BENCH_SUM=int32 selects the plain int32 reduce of the whole buffer instead
     sum_mode = os.environ.get("PD_BENCH_SUM", "sliced") if use_dist else None
-    sliced = multi.SlicedSum(eng, dev) if sum_mode == "sliced" else None
+    # "sliced": RCCL called inside the library (pd_comm_init + pd_sliced_sum_start / _finish; torch.distributed only hands the
+    # 128-byte unique id round);  "sliced_torch": the same protocol with the collectives issued from torch.distributed
+    sliced = None
+    if sum_mode == "sliced":
+        ids = [pda.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        sliced = pda.Comm(eng, ids[0], rank, world)
+    elif sum_mode == "sliced_torch":
+        sliced = multi.SlicedSum(eng, dev)
     packed = multi.PackedSum(eng, dev) if sum_mode == "int8" else None
     buf = multi.buffer_view(eng, dev) if sum_mode == "int32" else None
     pipelined = sliced is not None and os.environ.get("PD_BENCH_PIPELINE", "1") == "1"
@@ -391,7 +399,8 @@ def main():
                        "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)")) if direct
                                else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
-                           "sliced": "sliced sum: 4-bit all-to-all over RCCL, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
+                           "sliced": "sliced sum behind the C-ABI (pd_sliced_sum_start / _finish: RCCL grouped send/recv of 4-bit slices issued by the library), every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
+                           "sliced_torch": "sliced sum: 4-bit all-to-all issued from torch.distributed, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
                            "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),
                        "total_depth_check": total_depth, "multi_gpu_sum_selfcheck": selfcheck},
             "roofline": roofline,

@@ -225,6 +225,13 @@ int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms);
 int pd_comm_destroy(pd_comm *comm);
 const char *pd_comm_strerror(const pd_comm *comm);
 int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
+/* The same in two halves, with two slots of exchange buffers (slot 0 or 1), for a caller with several samples per rank:
+ * pd_sliced_sum_start only enqueues (pack on the context's stream, the collectives on the communicator's own stream, ordered
+ * by events), so the context can be reset and sample k+1 scattered while sample k's image is on the xGMI links;
+ * pd_sliced_sum_finish completes a started slot and blocks until this rank's part is done.  All ranks make the same calls in
+ * the same order.  pd_sliced_window_sum = start(0) + finish(0). */
+int pd_sliced_sum_start(pd_comm *comm, int slot);
+int pd_sliced_sum_finish(pd_comm *comm, int slot, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
 
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
 /* Waits for everything queued.  Deferred batches (PD_PUSH_MORE) are scattered first — except that with "direct_windows"

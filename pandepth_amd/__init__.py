@@ -5,6 +5,6 @@ hand-written gfx950 HIP kernels, plus the C++ host side (`pandepth` CLI).  This 
 the thin ctypes mirror of that ABI used by tests and bench.py.  It never falls back to a CPU
 implementation: if the library is missing or no gfx950 device is present, it raises.
 """
-from .capi import Engine, PdError, lib_path, load, PD_PUSH_SORTED, PD_PUSH_DEFAULT, PD_PUSH_DISORDER, PD_PUSH_MORE  # noqa: F401
+from .capi import Comm, comm_unique_id, Engine, PdError, lib_path, load, PD_PUSH_SORTED, PD_PUSH_DEFAULT, PD_PUSH_DISORDER, PD_PUSH_MORE  # noqa: F401
 
 __version__ = "0.1.0"

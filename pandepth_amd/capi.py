@@ -73,6 +73,14 @@ def load():
         "pd_slice_sweep_i4": (I, [P, P, ctypes.c_uint32, U64, U64, U64, P, P, U64, P, ctypes.c_uint32, ctypes.c_uint32,
                                   ctypes.c_uint, P]),
         "pd_gather_windows": (I, [P, P, ctypes.c_uint32, P, P]),
+        "pd_comm_unique_id": (I, [P]),
+        "pd_comm_init": (I, [P, P, I, I, ctypes.POINTER(P)]),
+        "pd_comm_init_all": (I, [ctypes.POINTER(P), I, ctypes.POINTER(P)]),
+        "pd_comm_destroy": (I, [P]),
+        "pd_comm_strerror": (ctypes.c_char_p, [P]),
+        "pd_sliced_window_sum": (I, [P, ctypes.c_uint32, ctypes.c_uint32, U, I, P, P]),
+        "pd_sliced_sum_start": (I, [P, I]),
+        "pd_sliced_sum_finish": (I, [P, I, ctypes.c_uint32, ctypes.c_uint32, U, I, P, P]),
         "pd_push_bgzf_units": (I, [P, P, SZ, P, ctypes.c_uint32, P, ctypes.c_uint32, U64, ctypes.c_uint32, ctypes.c_int32, P,
                                ctypes.POINTER(U64)]),
         "pd_x_bgzf_inflate": (I, [I, P, SZ, P, SZ, ctypes.POINTER(SZ), I, I, ctypes.POINTER(ctypes.c_double),
@@ -94,7 +102,7 @@ EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
            "pd_read_depth", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
-           "pd_comm_strerror", "pd_sliced_window_sum", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -129,6 +137,60 @@ def bgzf_inflate(data, variant=0, reps=1, device=0, want_output=True):
     if rc != 0:
         raise PdError(rc, "pd_x_bgzf_inflate failed")
     return (out[:n.value].tobytes() if want_output else None), float(ms.value), int(nb.value), int(n.value)
+
+
+PD_UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """pd_comm_unique_id: the 128 bytes one rank makes and every rank passes to Comm()."""
+    b = ctypes.create_string_buffer(PD_UNIQUE_ID_BYTES)
+    rc = load().pd_comm_unique_id(b)
+    if rc != 0:
+        raise PdError(rc, "pd_comm_unique_id failed (librccl?)")
+    return b.raw
+
+
+class Comm:
+    """One pd_comm: this rank's end of the RCCL sliced sum (the collectives are issued inside the library)."""
+
+    def __init__(self, engine, unique_id, rank, world):
+        self.L, self.e, self.rank, self.world = engine.L, engine, int(rank), int(world)
+        h = ctypes.c_void_p()
+        rc = self.L.pd_comm_init(engine.h, ctypes.c_char_p(bytes(unique_id)), self.rank, self.world, ctypes.byref(h))
+        if rc != 0:
+            raise PdError(rc, (self.L.pd_strerror(engine.h) or b"").decode())
+        self.h = h
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PdError(rc, (self.L.pd_comm_strerror(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pd_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def start(self, slot=0):
+        self._ck(self.L.pd_sliced_sum_start(self.h, int(slot)))
+
+    def finish(self, slot=0, w=10000000, min_dep=1, wrap_bits=18, root=0):
+        """(win_off, cover, depth_sum) on the root, else None."""
+        if self.rank != root:
+            self._ck(self.L.pd_sliced_sum_finish(self.h, int(slot), int(w), int(min_dep), int(wrap_bits), int(root), None, None))
+            return None
+        off = self.e.window_layout(w)
+        n = int(off[-1])
+        cover = np.zeros(max(n, 1), dtype=np.uint32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_sliced_sum_finish(self.h, int(slot), int(w), int(min_dep), int(wrap_bits), int(root), _ptr(cover), _ptr(tot)))
+        return off, cover[:n], tot[:n]
+
+    def run(self, w=10000000, min_dep=1, wrap_bits=18, root=0):
+        self.start(0)
+        return self.finish(0, w, min_dep, wrap_bits, root)
 
 
 class Engine:

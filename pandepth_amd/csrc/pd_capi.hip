@@ -1489,10 +1489,18 @@ struct pd_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, world = 1;
     uint64_t n_tiles = 0, slice_tiles = 0, slice_bytes = 0, tile_first = 0, tile_count = 0, n_sums = 0;
-    uint8_t *send = nullptr, *recv = nullptr, *part_mine = nullptr, *part_all = nullptr;
-    int32_t *meta = nullptr;
-    pd_exc *exc = nullptr, *exc_all = nullptr;
-    uint32_t *count = nullptr;
+    // two slots of exchange buffers: sample k+1 is scattered and packed while sample k's image is on the links
+    struct Slot {
+        uint8_t *send = nullptr, *recv = nullptr;
+        int32_t *meta = nullptr;                  // tile sums | exception counts per rank
+        pd_exc *exc = nullptr, *exc_all = nullptr;
+        uint32_t *count = nullptr;
+        hipEvent_t packed = nullptr, landed = nullptr;
+        bool busy = false;
+    } slot[2];
+    uint8_t *part_mine = nullptr, *part_all = nullptr;
+    hipStream_t links = nullptr;                  // every RCCL call is issued on this stream, ordered against the context's by events
+    hipEvent_t swept = nullptr, gathered = nullptr;
     std::string err;
 };
 
@@ -1547,14 +1555,22 @@ int comm_setup(pd_comm *m)
     m->tile_count = std::min<uint64_t>(m->slice_tiles, m->n_tiles - m->tile_first);
     const size_t W = (size_t)m->world;
     HIPCM(m, hipSetDevice(c->device));
-    if (hipMalloc(&m->send, W * m->slice_bytes + 256) != hipSuccess || hipMalloc(&m->recv, W * m->slice_bytes + 256) != hipSuccess ||
-        hipMalloc(&m->meta, (m->n_sums + W + 16) * 4) != hipSuccess || hipMalloc(&m->exc, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess ||
-        hipMalloc(&m->exc_all, W * COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess || hipMalloc(&m->count, 64) != hipSuccess ||
-        hipMalloc(&m->part_mine, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess ||
+    HIPCM(m, hipStreamCreateWithFlags(&m->links, hipStreamNonBlocking));
+    HIPCM(m, hipEventCreateWithFlags(&m->swept, hipEventDisableTiming));
+    HIPCM(m, hipEventCreateWithFlags(&m->gathered, hipEventDisableTiming));
+    for (pd_comm::Slot &s : m->slot) {
+        if (hipMalloc(&s.send, W * m->slice_bytes + 256) != hipSuccess || hipMalloc(&s.recv, W * m->slice_bytes + 256) != hipSuccess ||
+            hipMalloc(&s.meta, (m->n_sums + W + 16) * 4) != hipSuccess || hipMalloc(&s.exc, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess ||
+            hipMalloc(&s.exc_all, W * COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess || hipMalloc(&s.count, 64) != hipSuccess)
+            return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
+        HIPCM(m, hipEventCreateWithFlags(&s.packed, hipEventDisableTiming));
+        HIPCM(m, hipEventCreateWithFlags(&s.landed, hipEventDisableTiming));
+        HIPCM(m, hipMemsetAsync(s.send, 0, W * m->slice_bytes + 256, c->stream));          // the tail beyond n_cells / 2 stays zero
+        HIPCM(m, hipMemsetAsync(s.exc, 0, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), c->stream));
+    }
+    if (hipMalloc(&m->part_mine, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess ||
         hipMalloc(&m->part_all, W * m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess)
         return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
-    HIPCM(m, hipMemsetAsync(m->send, 0, W * m->slice_bytes + 256, c->stream));          // the tail beyond n_cells / 2 stays zero
-    HIPCM(m, hipMemsetAsync(m->exc, 0, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), c->stream));
     HIPCM(m, hipMemsetAsync(m->part_mine, 0, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64, c->stream));
     HIPCM(m, hipStreamSynchronize(c->stream));
     return PD_OK;
@@ -1615,69 +1631,113 @@ int pd_comm_destroy(pd_comm *m)
 {
     if (!m) return PD_OK;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->links) (void)hipStreamSynchronize(m->links);
     if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
     if (m->nccl) (void)rccl().CommDestroy(m->nccl);
-    for (void *p : {(void *)m->send, (void *)m->recv, (void *)m->meta, (void *)m->exc, (void *)m->exc_all, (void *)m->count, (void *)m->part_mine, (void *)m->part_all})
-        if (p) (void)hipFree(p);
+    for (pd_comm::Slot &s : m->slot) {
+        for (void *p : {(void *)s.send, (void *)s.recv, (void *)s.meta, (void *)s.exc, (void *)s.exc_all, (void *)s.count}) if (p) (void)hipFree(p);
+        if (s.packed) (void)hipEventDestroy(s.packed);
+        if (s.landed) (void)hipEventDestroy(s.landed);
+    }
+    if (m->part_mine) (void)hipFree(m->part_mine);
+    if (m->part_all) (void)hipFree(m->part_all);
+    if (m->swept) (void)hipEventDestroy(m->swept);
+    if (m->gathered) (void)hipEventDestroy(m->gathered);
+    if (m->links) (void)hipStreamDestroy(m->links);
     delete m;
     return PD_OK;
 }
 
 const char *pd_comm_strerror(const pd_comm *m) { return m ? m->err.c_str() : ""; }
 
-// Collective: every rank calls it (in one process: one thread per rank).  On `root`, cover / sum receive what
-// pd_scan_reduce_windows would give on a context holding the sum of all ranks' samples (windows of w >= 8192 cells).
-int pd_sliced_window_sum(pd_comm *m, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
+// Collective, first half: packs the context's sample (pd_export_i4) into `slot` and puts it on the links.  Only enqueues: the
+// context may be reset and refilled right away, and the other slot may be started before this one is finished.
+int pd_sliced_sum_start(pd_comm *m, int slot)
 {
-    if (!m || root < 0 || root >= m->world || w < PD_TILE || wrap_bits > 32) return PD_EINVAL;
-    if (m->rank == root && (!cover || !sum)) return PD_EINVAL;
+    if (!m || slot < 0 || slot > 1) return PD_EINVAL;
+    pd_comm::Slot &s = m->slot[slot];
+    if (s.busy) return comm_fail(m, PD_EINVAL, "pd_sliced_sum_start: the slot has not been finished");
     pd_ctx *c = m->ctx;
     const size_t W = (size_t)m->world, sb = (size_t)m->slice_bytes;
     HIPCM(m, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    // 1. this rank's 4-bit image (straight from the tile windows in LDS when the sample is still deferred)
-    int rc = pd_export_i4(c, m->send, m->exc, COMM_EXC_BLOCK, m->count);
+    hipStream_t st = c->stream, ln = m->links;
+    // 1. this rank's 4-bit image (straight from the tile windows in LDS when the sample is still deferred), its own slice in place
+    int rc = pd_export_i4(c, s.send, s.exc, COMM_EXC_BLOCK, s.count);
     if (rc) return comm_fail(m, rc, std::string("pd_export_i4: ") + c->err);
-    HIPCM(m, hipMemcpyAsync(m->meta, c->sums, (size_t)m->n_sums * 4, hipMemcpyDeviceToDevice, st));
-    HIPCM(m, hipMemsetAsync(m->meta + m->n_sums, 0, W * 4, st));
-    HIPCM(m, hipMemcpyAsync(m->meta + m->n_sums + m->rank, m->count, 4, hipMemcpyDeviceToDevice, st));
+    HIPCM(m, hipMemcpyAsync(s.meta, c->sums, (size_t)m->n_sums * 4, hipMemcpyDeviceToDevice, st));
+    HIPCM(m, hipMemsetAsync(s.meta + m->n_sums, 0, W * 4, st));
+    HIPCM(m, hipMemcpyAsync(s.meta + m->n_sums + m->rank, s.count, 4, hipMemcpyDeviceToDevice, st));
+    HIPCM(m, hipMemcpyAsync(s.recv + (size_t)m->rank * sb, s.send + (size_t)m->rank * sb, sb, hipMemcpyDeviceToDevice, st));
+    HIPCM(m, hipEventRecord(s.packed, st));
+    HIPCM(m, hipStreamWaitEvent(ln, s.packed, 0));
     // 2. the all-to-all: every pair of GPUs moves 1/world of the image over its own xGMI link, all links at once
-    HIPCM(m, hipMemcpyAsync(m->recv + (size_t)m->rank * sb, m->send + (size_t)m->rank * sb, sb, hipMemcpyDeviceToDevice, st));
     for (size_t c0 = 0; c0 < sb && W > 1; c0 += COMM_MSG_BYTES) {
         const size_t n = std::min(COMM_MSG_BYTES, sb - c0);
         NCCLOK(m, rccl().GroupStart());
         for (int p = 0; p < m->world; ++p) {
             if (p == m->rank) continue;
-            NCCLOK(m, rccl().Send(m->send + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, st));
-            NCCLOK(m, rccl().Recv(m->recv + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, st));
+            NCCLOK(m, rccl().Send(s.send + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
+            NCCLOK(m, rccl().Recv(s.recv + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
         }
         NCCLOK(m, rccl().GroupEnd());
     }
     // 3. tile sums (+ exception counts) summed over the ranks; everybody's exception block to everybody
-    NCCLOK(m, rccl().AllReduce(m->meta, m->meta, (size_t)m->n_sums + W, ncclInt32, ncclSum, m->nccl, st));
-    NCCLOK(m, rccl().AllGather(m->exc, m->exc_all, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), ncclUint8, m->nccl, st));
+    NCCLOK(m, rccl().AllReduce(s.meta, s.meta, (size_t)m->n_sums + W, ncclInt32, ncclSum, m->nccl, ln));
+    NCCLOK(m, rccl().AllGather(s.exc, s.exc_all, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), ncclUint8, m->nccl, ln));
+    HIPCM(m, hipEventRecord(s.landed, ln));
+    s.busy = true;
+    return PD_OK;
+}
+
+// Collective, second half: on `root`, cover / sum receive what pd_scan_reduce_windows would give on a context holding the sum
+// of all ranks' samples started in `slot` (windows of w >= 8192 cells).  Blocks until this rank's part is complete.
+int pd_sliced_sum_finish(pd_comm *m, int slot, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
+{
+    if (!m || slot < 0 || slot > 1 || root < 0 || root >= m->world || w < PD_TILE || wrap_bits > 32) return PD_EINVAL;
+    if (m->rank == root && (!cover || !sum)) return PD_EINVAL;
+    pd_comm::Slot &s = m->slot[slot];
+    if (!s.busy) return comm_fail(m, PD_EINVAL, "pd_sliced_sum_finish: the slot has not been started");
+    s.busy = false;
+    pd_ctx *c = m->ctx;
+    const size_t W = (size_t)m->world, sb = (size_t)m->slice_bytes;
+    HIPCM(m, hipSetDevice(c->device));
+    hipStream_t st = c->stream, ln = m->links;
     // 4. this rank's slice: sum of the images, prefix sum, wrap, per-tile partials of the windows
-    rc = pd_slice_sweep_i4(c, m->recv, (uint32_t)W, sb, m->tile_first, m->tile_count, m->meta, m->exc_all, COMM_EXC_BLOCK, m->meta + m->n_sums, w, min_dep,
-                           wrap_bits, m->part_mine);
+    HIPCM(m, hipStreamWaitEvent(st, s.landed, 0));
+    int rc = pd_slice_sweep_i4(c, s.recv, (uint32_t)W, sb, m->tile_first, m->tile_count, s.meta, s.exc_all, COMM_EXC_BLOCK, s.meta + m->n_sums, w, min_dep,
+                               wrap_bits, m->part_mine);
     if (rc) return comm_fail(m, rc, std::string("pd_slice_sweep_i4: ") + c->err);
     // 5. 24 bytes per tile to the root
     const size_t pb = (size_t)m->slice_tiles * PD_TILE_PARTIAL_BYTES;
     if (m->rank == root) HIPCM(m, hipMemcpyAsync(m->part_all + (size_t)root * pb, m->part_mine, pb, hipMemcpyDeviceToDevice, st));
     if (W > 1) {
+        HIPCM(m, hipEventRecord(m->swept, st));
+        HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
         NCCLOK(m, rccl().GroupStart());
-        if (m->rank == root) { for (int p = 0; p < m->world; ++p) if (p != root) NCCLOK(m, rccl().Recv(m->part_all + (size_t)p * pb, pb, ncclUint8, p, m->nccl, st)); }
-        else NCCLOK(m, rccl().Send(m->part_mine, pb, ncclUint8, root, m->nccl, st));
+        if (m->rank == root) { for (int p = 0; p < m->world; ++p) if (p != root) NCCLOK(m, rccl().Recv(m->part_all + (size_t)p * pb, pb, ncclUint8, p, m->nccl, ln)); }
+        else NCCLOK(m, rccl().Send(m->part_mine, pb, ncclUint8, root, m->nccl, ln));
         NCCLOK(m, rccl().GroupEnd());
+        HIPCM(m, hipEventRecord(m->gathered, ln));
+        HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
     }
     std::vector<int32_t> counts(W);
-    HIPCM(m, hipMemcpyAsync(counts.data(), m->meta + m->n_sums, W * 4, hipMemcpyDeviceToHost, st));
+    HIPCM(m, hipMemcpyAsync(counts.data(), s.meta + m->n_sums, W * 4, hipMemcpyDeviceToHost, st));
     HIPCM(m, hipStreamSynchronize(st));
-    for (int32_t k : counts) if (k < 0 || (uint32_t)k > COMM_EXC_BLOCK) return comm_fail(m, PD_EINVAL, "a sample has more cells outside the 4-bit range than the exception block holds; use pd_accumulate_from");
+    for (int32_t k : counts) if (k < 0 || (uint32_t)k > COMM_EXC_BLOCK)
+        return comm_fail(m, PD_EINVAL, "a sample has more cells outside the 4-bit range than the exception block holds; use pd_accumulate_from (the executable: PANDEPTH_NO_RCCL=1)");
     if (m->rank == root) {
         rc = pd_gather_windows(c, m->part_all, w, cover, sum);
         if (rc) return comm_fail(m, rc, std::string("pd_gather_windows: ") + c->err);
     }
     return PD_OK;
+}
+
+int pd_sliced_window_sum(pd_comm *m, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
+{
+    if (!m || root < 0 || root >= m->world || w < PD_TILE || wrap_bits > 32) return PD_EINVAL;
+    if (m->rank == root && (!cover || !sum)) return PD_EINVAL;
+    const int rc = pd_sliced_sum_start(m, 0);
+    return rc ? rc : pd_sliced_sum_finish(m, 0, w, min_dep, wrap_bits, root, cover, sum);
 }
 
 } // extern "C"

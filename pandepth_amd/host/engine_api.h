@@ -36,6 +36,11 @@ typedef struct pd_engine_api {
     int (*decode_end)(pd_ctx *);
     int (*decode_abort)(pd_ctx *);
     int (*set_param)(pd_ctx *, const char *, uint64_t);
+    /* optional (NULL = contexts are added into the first one): the RCCL sliced sum between one context per GPU, see pd_comm_* */
+    int (*comm_init_all)(pd_ctx **, int, pd_comm **);
+    int (*sliced_window_sum)(pd_comm *, uint32_t, uint32_t, unsigned, int, uint32_t *, uint64_t *);
+    int (*comm_destroy)(pd_comm *);
+    const char *(*comm_strerror)(const pd_comm *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

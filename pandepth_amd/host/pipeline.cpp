@@ -966,20 +966,55 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             return 2;
         }
     }
-    for (int k = 1; k < n_ctx; ++k) {
-        if (!eng.ck(api->accumulate_from(eng.ctx, engs[k]->ctx), "pd_accumulate_from")) { std::cerr << "Error: " << eng.err << std::endl; return 2; }
-        api->destroy(engs[k]->ctx); engs[k]->ctx = nullptr;
-    }
     tm.mark("decode + scatter");
     const unsigned wrap_bits = wrap18 ? 18u : 0u;
     const uint32_t min_dep = (uint32_t)o.min_dep;
+    // Several GPUs hold one partial sample each.  Wide-window statistics are summed in slices over RCCL (pd_sliced_window_sum:
+    // every GPU receives 1/n of the others' 4-bit images, no GPU ever holds everybody's arrays); whatever needs the summed
+    // cells themselves (per-site output, annotation intervals, narrow windows) adds the contexts into the first one.
+    bool merged = n_ctx == 1 && !getenv("PANDEPTH_FORCE_RCCL");      // (the variable: a 1-rank communicator, so that single-GPU boxes test this path)
+    auto merge_contexts = [&]() -> bool {
+        if (merged) return true;
+        merged = true;
+        for (int k = 1; k < n_ctx; ++k) {
+            if (!eng.ck(api->accumulate_from(eng.ctx, engs[k]->ctx), "pd_accumulate_from")) return false;
+            api->destroy(engs[k]->ctx); engs[k]->ctx = nullptr;
+        }
+        return true;
+    };
     bool scanned = false;
     auto need_scan = [&]() -> bool {
         if (scanned) return true;
+        if (!merge_contexts()) return false;
         scanned = true;
         return eng.ck(api->scan(eng.ctx, wrap_bits), "pd_scan");
     };
     auto bail = [&]() { std::cerr << "Error: " << eng.err << std::endl; return 2; };
+    // cover / depth sum of every window of `width` cells (pd_window_layout order), whichever way the sample is held
+    auto window_stats = [&](uint32_t width, uint32_t *cov, uint64_t *sum) -> bool {
+        if (!merged && !scanned && width >= PD_TILE_CELLS && n_ctx <= n_dev && api->comm_init_all && api->sliced_window_sum && !getenv("PANDEPTH_NO_RCCL")) {
+            std::vector<pd_ctx *> ctxs;
+            for (auto &e : engs) ctxs.push_back(e->ctx);
+            std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
+            if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) == 0) {
+                std::vector<int> rcs((size_t)n_ctx, 0);
+                std::vector<std::thread> th;
+                for (int k = 0; k < n_ctx; ++k)
+                    th.emplace_back([&, k]() { rcs[(size_t)k] = api->sliced_window_sum(comms[(size_t)k], width, min_dep, wrap_bits, 0, k == 0 ? cov : nullptr, k == 0 ? sum : nullptr); });
+                for (auto &t : th) t.join();
+                bool ok = true;
+                for (int k = 0; k < n_ctx; ++k)
+                    if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string("pd_sliced_window_sum: ") + (m ? m : "?")); }
+                if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
+                if (tm.on) fprintf(stderr, "[timing] window statistics summed over %d GPUs in slices (RCCL)\n", n_ctx);
+                return ok;
+            }
+            if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
+        }
+        if (!merge_contexts()) return false;
+        const int rc = scanned ? api->reduce_windows(eng.ctx, width, min_dep, cov, sum) : api->scan_reduce_windows(eng.ctx, width, min_dep, wrap_bits, cov, sum);
+        return eng.ck(rc, "window reduction");
+    };
 
     if (o.site_out) {
         if (!need_scan()) return bail();
@@ -999,9 +1034,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         api->window_layout(eng.ctx, w, woff.data());
         std::vector<uint32_t> cov(woff[nctg] ? woff[nctg] : 1);
         std::vector<uint64_t> sum(woff[nctg] ? woff[nctg] : 1);
-        const int rc = scanned ? api->reduce_windows(eng.ctx, w, min_dep, cov.data(), sum.data())
-                               : api->scan_reduce_windows(eng.ctx, w, min_dep, wrap_bits, cov.data(), sum.data());
-        if (!eng.ck(rc, "window reduction")) return bail();
+        if (!window_stats(w, cov.data(), sum.data())) return bail();
         OUT.write(header_line);
         RowSums tot;
         for (size_t t = 0; t < nctg; ++t) {
@@ -1047,9 +1080,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         api->window_layout(eng.ctx, width, woff.data());
         std::vector<uint32_t> cov(woff[nctg] ? woff[nctg] : 1);
         std::vector<uint64_t> sum(woff[nctg] ? woff[nctg] : 1);
-        const int rc = scanned ? api->reduce_windows(eng.ctx, width, min_dep, cov.data(), sum.data())
-                               : api->scan_reduce_windows(eng.ctx, width, min_dep, wrap_bits, cov.data(), sum.data());
-        if (!eng.ck(rc, "window reduction")) return bail();
+        if (!window_stats(width, cov.data(), sum.data())) return bail();
         for (auto &kv : rm.bins)
             for (Bin &b : kv.second) {
                 const uint64_t k = (uint64_t)(b.start - 1) / width;
