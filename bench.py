@@ -78,7 +78,9 @@ def _best_wall(cmd, reps, env=None):
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, timeout=1800)
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1800)
+        if p.returncode != 0:
+            raise RuntimeError("%s: exit %d: %s" % (os.path.basename(cmd[0]), p.returncode, p.stderr.decode(errors="replace")[-600:]))
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return best
@@ -412,6 +414,8 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
+        if isinstance(sliced, pda.Comm):
+            sliced.close()                      # the communicator goes before the context it belongs to and before the process group
         dist.destroy_process_group()
     if eng.h:
         eng.close()

@@ -168,7 +168,8 @@ class Comm:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.pd_comm_destroy(self.h)
+            if getattr(self.e, "h", None):          # (a context that is already gone took its stream along: nothing left to release safely)
+                self.L.pd_comm_destroy(self.h)
             self.h = None
 
     __del__ = close

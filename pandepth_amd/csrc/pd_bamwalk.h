@@ -245,5 +245,38 @@ PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_
     });
 }
 
+// The host side after pass 1 (and after every repeat): is every segment's speculated first record the one the chain of
+// the segments before it arrives at?  Segments that are not get the right start as their hint and their index in `redo`
+// (they walk again).  A segment right after one that must walk again cannot be checked in this round — the end of its
+// predecessor's chain is not known yet — and is taken at its word until the next round; the segments after it are
+// checked against ITS chain, so an isolated wrong guess costs one repeat, not one repeat per segment behind it.
+// A confirmed chain that stops inside a unit ends the unit: its remaining segments are marked WF_BAD (a record that
+// cannot be one) or WF_MORE (a hand-over to the host: the record runs past the bytes, a CIGAR in the CG tag).
+// Returns the number of segments to walk again; 0 = every start is confirmed.
+template <class Vec, class Redo>
+inline uint32_t check_chain(Vec &segs, Redo *redo)
+{
+    redo->clear();
+    uint64_t E = 0;
+    bool known = true;
+    uint32_t dead = 0;                                   // flags for the rest of a unit whose chain has stopped
+    for (size_t j = 0; j < segs.size(); ++j) {
+        Seg &s = segs[j];
+        bool confirmed = true;
+        if (s.unit_first) { E = 0; known = true; dead = 0; }
+        else if (dead) { s.flags = dead; s.n_first = s.n_other = s.n_far = s.n_rec = 0; continue; }
+        else if (known) {
+            const bool none_expected = E >= s.end;
+            const bool ok = none_expected ? s.used_start == NONE : s.used_start == E;
+            if (!ok) { s.hint = E; redo->push_back((uint32_t)j); known = false; continue; }       // its own e_last is stale
+        } else confirmed = false;
+        if (confirmed) {
+            if (s.e_last > E) E = s.e_last;
+            if (E >= STOPPED) dead = (s.flags & WF_BAD) || !(s.flags & (WF_MORE | WF_HOST)) ? (uint32_t)WF_BAD : (uint32_t)WF_MORE;
+        } else if (s.e_last != 0 && s.e_last < STOPPED) { E = s.e_last; known = true; }          // taken at its word for this round
+    }
+    return (uint32_t)redo->size();
+}
+
 } // namespace pdb2
 #endif

@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <iostream>
+#include <fcntl.h>
+#include <unistd.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -834,24 +837,8 @@ int dec_ensure(pd_ctx *c, pd_ctx::DecSlot &sl, int k, size_t bytes)
     return PD_OK;
 }
 
-// the host side of a batch after pass 1: is every guessed segment start the one the chain before it arrives at?
-// (per unit; corrected hints for the ones that are not) + the running output offsets
-uint32_t dec_finish(std::vector<pdb2::Seg> &segs, std::vector<uint32_t> *redo)
-{
-    uint64_t E = 0;
-    redo->clear();
-    for (size_t j = 0; j < segs.size(); ++j) {
-        pdb2::Seg &s = segs[j];
-        if (s.unit_first) E = 0;
-        else {
-            const bool none_expected = E >= s.end;
-            const bool ok = none_expected ? s.used_start == pdb2::NONE : s.used_start == E;
-            if (!ok) { s.hint = E; redo->push_back((uint32_t)j); }
-        }
-        if (s.e_last > E) E = s.e_last;
-    }
-    return (uint32_t)redo->size();
-}
+// the host side of a batch after pass 1: pdb2::check_chain (pd_bamwalk.h)
+uint32_t dec_finish(std::vector<pdb2::Seg> &segs, std::vector<uint32_t> *redo) { return pdb2::check_chain(segs, redo); }
 
 } // namespace
 
@@ -993,7 +980,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     // ---- the chain across segments; segments whose guess was wrong walk again from the corrected start ----
     std::vector<uint32_t> redo;
     for (int round = 0; dec_finish(segs, &redo) > 0; ++round) {
-        if (round >= 4) { for (uint32_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
+        if (round >= 24) { for (uint32_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
         for (uint32_t j : redo) HIPDEC(hipMemcpyAsync(&d_seg[j].hint, &segs[j].hint, 8, hipMemcpyHostToDevice, st));
         HIPDEC(hipMemcpyAsync(sl.d[DS_ONLY], redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
         launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, (const uint32_t *)sl.d[DS_ONLY], (uint32_t)redo.size());
@@ -1007,7 +994,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         const pd_decode_unit &un = bt->units[u];
         for (uint32_t b = 0; b < un.n_blocks; ++b) { const int v = bst[un.first_block + b]; if (v < 0) stt = 2; else if (v > 0 && stt == 0) stt = 1; }
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
-            if (segs[j].flags & pdb2::WF_BAD) stt = 2;
+            if (segs[j].flags & pdb2::WF_BAD) { if (stt != 2) stt = 3; }
             else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && stt == 0) stt = 1;
         }
         unit_status[u] = stt;
@@ -1538,6 +1525,23 @@ Rccl &rccl()
     });
     return r;
 }
+// RCCL 2.27 prints a version banner on stdout when a communicator is made, whatever NCCL_DEBUG says; the executable's stdout
+// is part of its contract (compared byte for byte with the reference's).  While a communicator is being made, and unless the
+// user asked RCCL to talk (NCCL_DEBUG set), file descriptor 1 points at /dev/null.  Callers make communicators at a quiet point.
+struct QuietStdout {
+    int saved = -1;
+    QuietStdout()
+    {
+        if (getenv("NCCL_DEBUG")) return;
+        fflush(stdout); std::cout.flush();          // (the banner comes through std::cout, which may not share stdio's buffer)
+        const int nul = open("/dev/null", O_WRONLY);
+        if (nul < 0) return;
+        saved = dup(1);
+        if (saved >= 0) dup2(nul, 1);
+        close(nul);
+    }
+    ~QuietStdout() { if (saved >= 0) { fflush(stdout); std::cout.flush(); dup2(saved, 1); close(saved); } }
+};
 constexpr uint32_t COMM_EXC_BLOCK = 1u << 18;       // exceptions (cells outside the 4-bit range) per rank
 constexpr size_t COMM_MSG_BYTES = (size_t)1 << 28;  // RCCL 2.26 delivers only the first half of a send/recv above 1 GiB: stay far below
 
@@ -1597,7 +1601,9 @@ int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm 
     if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
     pd_comm *m = new pd_comm; m->ctx = ctx; m->rank = rank; m->world = n_ranks;
     ncclUniqueId id; memcpy(&id, id128, sizeof id);
-    if (hipSetDevice(ctx->device) != hipSuccess || rccl().CommInitRank(&m->nccl, n_ranks, id, rank) != ncclSuccess) {
+    bool made;
+    { QuietStdout q; made = hipSetDevice(ctx->device) == hipSuccess && rccl().CommInitRank(&m->nccl, n_ranks, id, rank) == ncclSuccess; }
+    if (!made) {
         { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: ncclCommInitRank failed"; }
         delete m; return PD_EHIP;
     }
@@ -1616,7 +1622,9 @@ int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms)
         std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
     if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
-    if (rccl().CommInitAll(nc.data(), n, devs.data()) != ncclSuccess) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "ncclCommInitAll failed"; return PD_EHIP; }
+    bool made;
+    { QuietStdout q; made = rccl().CommInitAll(nc.data(), n, devs.data()) == ncclSuccess; }
+    if (!made) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "ncclCommInitAll failed"; return PD_EHIP; }
     int rc = PD_OK;
     for (int i = 0; i < n; ++i) {
         pd_comm *m = new pd_comm; m->ctx = ctxs[i]; m->rank = i; m->world = n; m->nccl = nc[(size_t)i];

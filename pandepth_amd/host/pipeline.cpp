@@ -500,7 +500,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             } else {
                 for (size_t k = 0; k < units.size(); ++k) {
                     if (status[k] == 0) continue;
-                    if (status[k] != 1) { eng->fail("corrupt BGZF/BAM data in " + path); break; }
+                    if (status[k] == 2) { eng->fail("corrupt BGZF data in " + path); break; }
+                    // 1: the device leaves this unit to the host; 3: it could not follow the record chain — the host reader
+                    // below goes through the same bytes and says what is wrong with them, if anything is
                     ++n_back;
                     std::string e2;
                     if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
@@ -996,6 +998,14 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             std::vector<pd_ctx *> ctxs;
             for (auto &e : engs) ctxs.push_back(e->ctx);
             std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
+            // RCCL announces itself on stdout (a version banner, from whichever thread first gets there); this program's stdout
+            // is compared byte for byte with the reference's, and nothing of ours is printed until the sum is done
+            struct Quiet {
+                int saved = -1;
+                Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
+                ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
+            };
+            std::unique_ptr<Quiet> quiet(getenv("PANDEPTH_RCCL_VERBOSE") ? nullptr : new Quiet);
             if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) == 0) {
                 std::vector<int> rcs((size_t)n_ctx, 0);
                 std::vector<std::thread> th;
@@ -1006,6 +1016,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
                 for (int k = 0; k < n_ctx; ++k)
                     if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string("pd_sliced_window_sum: ") + (m ? m : "?")); }
                 if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
+                quiet.reset();
                 if (tm.on) fprintf(stderr, "[timing] window statistics summed over %d GPUs in slices (RCCL)\n", n_ctx);
                 return ok;
             }

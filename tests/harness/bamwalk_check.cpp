@@ -26,24 +26,15 @@ static bool gunzip_all(const char *path, std::vector<uint8_t> &out)
     return true;
 }
 
-// the host side of a batch: validate the chain across segments, give every segment its output offsets.
-// Returns the number of segments that must be walked again (their hint has been corrected).
-static int finish(std::vector<Seg> &segs, uint64_t *tot_first, uint64_t *tot_other, uint64_t *tot_far, uint32_t *flags, uint32_t *max_span)
+// every segment's output offsets and the totals, once the chain is confirmed (pdb2::check_chain)
+static void offsets(std::vector<Seg> &segs, uint64_t *tot_first, uint64_t *tot_other, uint64_t *tot_far, uint32_t *flags, uint32_t *max_span)
 {
-    int bad = 0; uint64_t E = 0, f = 0, o = 0, fr = 0; *flags = 0; *max_span = 0;
+    uint64_t f = 0, o = 0, fr = 0; *flags = 0; *max_span = 0;
     for (auto &s : segs) {
-        if (s.unit_first) E = 0;
-        else {
-            const bool none_expected = E >= s.end;
-            const bool ok = none_expected ? s.used_start == NONE : s.used_start == E;
-            if (!ok) { s.hint = E; ++bad; }
-        }
-        if (s.e_last > E) E = s.e_last;
         s.base_first = f; s.base_other = o; s.base_far = fr; f += s.n_first; o += s.n_other; fr += s.n_far;
         *flags |= s.flags; if (s.max_span > *max_span) *max_span = s.max_span;
     }
     *tot_first = f; *tot_other = o; *tot_far = fr;
-    return bad;
 }
 
 int main(int argc, char **argv)
@@ -93,12 +84,13 @@ int main(int argc, char **argv)
         if (segs.empty()) { printf("%s: no records\n", path); continue; }
         std::vector<LaneOut> lanes(segs.size() * 64);
         for (size_t j = 0; j < segs.size(); ++j) walk_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64]);
-        uint64_t tf = 0, to = 0, tfar = 0; uint32_t fl = 0, ms = 0; int redo = 0, rounds = 0;
-        while ((redo = finish(segs, &tf, &to, &tfar, &fl, &ms)) > 0 && rounds < 4) {
+        uint64_t tf = 0, to = 0, tfar = 0; uint32_t fl = 0, ms = 0; int rounds = 0;
+        std::vector<uint32_t> redo;
+        while (check_chain(segs, &redo) > 0 && rounds < 24) {
             ++rounds;
-            for (size_t j = 0; j < segs.size(); ++j) if (segs[j].hint != NONE && !segs[j].unit_first && segs[j].used_start != segs[j].hint && !(segs[j].hint >= segs[j].end && segs[j].used_start == NONE))
-                walk_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64]);
+            for (uint32_t j : redo) walk_segment<pdw::HostWave>(c, segs[j], &lanes[(size_t)j * 64]);
         }
+        offsets(segs, &tf, &to, &tfar, &fl, &ms);
         (void)guess_all;
         std::vector<pd_iv> first(tf + 1), other(to + 1), far(tfar + 1);
         for (size_t j = 0; j < segs.size(); ++j) emit_segment<pdw::HostWave>(c, segs[j], &lanes[j * 64], first.data(), other.data(), far.data());
@@ -112,7 +104,7 @@ int main(int argc, char **argv)
         const bool same_other = got_other == exp_other;
         to += tfar;
         printf("%s: %llu records, %zu segments (%d corrected in %d extra rounds), first runs %llu (expected %zu) %s, other runs %llu (expected %zu) %s, flags %u, max span %u\n",
-               path, (unsigned long long)n_rec, segs.size(), redo, rounds, (unsigned long long)tf, exp_first.size(), same_first ? "identical" : "DIFFERENT",
+               path, (unsigned long long)n_rec, segs.size(), (int)redo.size(), rounds, (unsigned long long)tf, exp_first.size(), same_first ? "identical" : "DIFFERENT",
                (unsigned long long)to, exp_other.size(), same_other ? "identical" : "DIFFERENT", fl, ms);
         if (!same_first || !same_other || fl) ++bad_files;
     }

@@ -1,0 +1,111 @@
+// tests/harness/chain_check.cpp — TEST INFRASTRUCTURE: pdb2::check_chain (pandepth_amd/csrc/pd_bamwalk.h), the host half of
+// the speculative record walk, against a model walker: a unit of back-to-back records of known sizes, cut in segments; the
+// first walk of a segment "guesses" (right, or wrong at chosen segments: a false start a few bytes early whose chain stops,
+// or one that lands on a later true record); a repeated walk follows the hint it is given — into garbage if the hint is.
+// Checks: the loop ends with every segment confirmed at the true chain; with short records an isolated wrong guess costs ONE
+// repeat whatever comes behind it and k wrong guesses in a row at most k + 1 (records longer than a segment leave segments
+// without any start between two guesses, which then count as neighbours: a few more); a stopped confirmed chain ends the unit.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <random>
+#include <set>
+#include <vector>
+#include "../../pandepth_amd/csrc/pd_bamwalk.h"
+
+struct Model {
+    std::vector<uint64_t> rec;                    // true record starts, ascending; rec.back() = end of the last record
+    uint64_t stop_at = ~0ull;                     // a true record that cannot be walked (corrupt / hand-over)
+    uint32_t stop_flag = 0;
+    // walks segment s from `start` (NONE = nothing known): fills used_start / e_last / flags as walk_segment does
+    void walk(pdb2::Seg &s, uint64_t start) const
+    {
+        s.flags = 0; s.n_rec = 0;
+        if (start == pdb2::NONE) { s.used_start = pdb2::NONE; s.e_last = 0; return; }
+        if (start >= s.end) { s.used_start = pdb2::NONE; s.e_last = start; return; }
+        s.used_start = start;
+        auto it = std::lower_bound(rec.begin(), rec.end(), start);
+        if (it == rec.end() || *it != start) { s.e_last = pdb2::STOPPED; s.flags = pdb2::WF_MORE; return; }     // not a record: its "size" runs off
+        uint64_t p = start;
+        while (p < s.end) {
+            if (p == stop_at) { s.e_last = pdb2::STOPPED; s.flags |= stop_flag; return; }
+            ++it; ++s.n_rec;
+            if (it == rec.end()) { s.e_last = pdb2::STOPPED; s.flags |= pdb2::WF_MORE; return; }
+            p = *it;
+        }
+        s.e_last = p;
+    }
+    uint64_t first_in(uint64_t a, uint64_t b) const { auto it = std::lower_bound(rec.begin(), rec.end(), a); return it != rec.end() && *it < b && it + 1 != rec.end() ? *it : pdb2::NONE; }
+};
+
+static int run_case(const Model &m, uint64_t seg_bytes, const std::set<size_t> &wrong_early, const std::set<size_t> &wrong_late, int max_rounds, const char *what)
+{
+    std::vector<pdb2::Seg> segs;
+    const uint64_t stop = m.rec[m.rec.size() - 1];
+    for (uint64_t b = m.rec[0]; b < stop; b += seg_bytes) {
+        pdb2::Seg s{}; s.begin = b; s.end = std::min(b + seg_bytes, stop); s.avail = stop; s.unit_first = b == m.rec[0]; s.hint = s.unit_first ? b : pdb2::NONE;
+        segs.push_back(s);
+    }
+    for (size_t j = 0; j < segs.size(); ++j) {
+        uint64_t g = segs[j].unit_first ? segs[j].begin : m.first_in(segs[j].begin, segs[j].end);
+        if (wrong_early.count(j) && g != pdb2::NONE && g >= segs[j].begin + 2) g -= 2;               // a false start: not a record
+        if (wrong_late.count(j)) { const uint64_t h = g == pdb2::NONE ? pdb2::NONE : m.first_in(g + 1, segs[j].end); if (h != pdb2::NONE) g = h; }   // skips a record
+        if (wrong_late.count(j) && g == pdb2::NONE) g = segs[j].begin + 1;                           // a start where none is (inside a long record)
+        m.walk(segs[j], g);
+    }
+    std::vector<uint32_t> redo;
+    int rounds = 0;
+    while (pdb2::check_chain(segs, &redo) > 0) {
+        if (++rounds > 64) { fprintf(stderr, "%s: no convergence\n", what); return 1; }
+        if (getenv("CHAIN_DBG") && !strcmp(getenv("CHAIN_DBG"), what)) { fprintf(stderr, "round %d redo:", rounds); for (uint32_t j : redo) fprintf(stderr, " %u(hint %lld, used %lld)", j, (long long)segs[j].hint, (long long)segs[j].used_start); fprintf(stderr, "\n"); }
+        for (uint32_t j : redo) m.walk(segs[j], segs[j].hint);
+    }
+    if (rounds > max_rounds) { fprintf(stderr, "%s: %d rounds (at most %d expected)\n", what, rounds, max_rounds); return 1; }
+    // the confirmed chain is the true one up to the stop
+    uint64_t n = 0; bool dead = false;
+    for (size_t j = 0; j < segs.size(); ++j) {
+        const pdb2::Seg &s = segs[j];
+        if (dead) { if (!(s.flags & (pdb2::WF_BAD | pdb2::WF_MORE))) { fprintf(stderr, "%s: segment %zu after the stop carries no flag\n", what, j); return 1; } continue; }
+        const uint64_t want = m.first_in(s.begin, s.end);
+        const uint64_t lastrec = m.rec[m.rec.size() - 2];
+        const uint64_t w2 = (want != pdb2::NONE) ? want : (s.begin <= lastrec && lastrec < s.end ? lastrec : pdb2::NONE);
+        if (s.used_start != w2) { fprintf(stderr, "%s: segment %zu starts at %llu, the chain says %llu\n", what, j, (unsigned long long)s.used_start, (unsigned long long)w2); return 1; }
+        n += s.n_rec;
+        if (s.e_last >= pdb2::STOPPED) dead = true;
+    }
+    (void)n;
+    return 0;
+}
+
+int main()
+{
+    std::mt19937_64 rng(3);
+    int bad = 0, cases = 0;
+    for (int rep = 0; rep < 300; ++rep) {
+        Model m;
+        uint64_t p = 1000 + rng() % 5000;
+        const bool long_reads = rep % 3 == 2;
+        const size_t nrec = 2000 + rng() % 3000;
+        for (size_t i = 0; i < nrec; ++i) { m.rec.push_back(p); p += long_reads ? 200 + rng() % 300000 : 200 + rng() % 400; }
+        m.rec.push_back(p);
+        const uint64_t seg = 65536;
+        const size_t nseg = (size_t)((p - m.rec[0] + seg - 1) / seg);
+        if (nseg < 12) continue;
+        char what[128];
+        // every guess right: no repeats
+        snprintf(what, sizeof what, "rep %d clean", rep); bad += run_case(m, seg, {}, {}, 0, what); ++cases;
+        // isolated wrong guesses (at least two segments apart): one repeat
+        { std::set<size_t> e, l; for (size_t j = 2; j + 1 < nseg; j += 3 + rng() % 5) ((rng() & 1) ? e : l).insert(j);
+          snprintf(what, sizeof what, "rep %d isolated", rep); bad += run_case(m, seg, e, l, long_reads ? 8 : 1, what); ++cases; }
+        // k wrong guesses in a row: at most k + 1 repeats
+        { const size_t k = 2 + rng() % 6, j0 = 1 + rng() % (nseg - k - 1); std::set<size_t> e, l; for (size_t j = j0; j < j0 + k; ++j) ((rng() & 1) ? e : l).insert(j);
+          snprintf(what, sizeof what, "rep %d run of %zu", rep, k); bad += run_case(m, seg, e, l, long_reads ? (int)k + 8 : (int)k + 1, what); ++cases; }
+        // a record that cannot be walked in the middle: the unit ends there, with or without wrong guesses around it
+        { Model c = m; c.stop_at = m.rec[nrec / 2]; c.stop_flag = (rep & 1) ? pdb2::WF_BAD : pdb2::WF_HOST;
+          std::set<size_t> e; for (size_t j = 3; j + 1 < nseg; j += 4) e.insert(j);
+          snprintf(what, sizeof what, "rep %d stop", rep); bad += run_case(c, seg, e, {}, long_reads ? 8 : 1, what); ++cases; }
+    }
+    printf("chain_check: %d cases, %d failures\n", cases, bad);
+    return bad ? 1 : 0;
+}

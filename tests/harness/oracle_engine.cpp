@@ -210,25 +210,19 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     seg0[bt->n_units] = (uint32_t)segs.size();
     std::vector<pdb2::LaneOut> lanes(segs.size() * 64);
     for (size_t j = 0; j < segs.size(); ++j) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
-    for (int round = 0; round < 5; ++round) {                   // the chain across segments (pd_capi.hip: dec_finish)
-        uint64_t E = 0; std::vector<size_t> redo;
-        for (size_t j = 0; j < segs.size(); ++j) {
-            pdb2::Seg &s = segs[j];
-            if (s.unit_first) E = 0;
-            else { const bool none = E >= s.end; if (!(none ? s.used_start == pdb2::NONE : s.used_start == E)) { s.hint = E; redo.push_back(j); } }
-            if (s.e_last > E) E = s.e_last;
-        }
-        if (redo.empty()) break;
-        if (round == 4) { for (size_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
-        for (size_t j : redo) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
+    std::vector<uint32_t> redo;                                  // the chain across segments, as pd_decode_submit does it
+    for (int round = 0; pdb2::check_chain(segs, &redo) > 0; ++round) {
+        if (round >= 24) { for (uint32_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
+        for (uint32_t j : redo) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[(size_t)j * 64]);
     }
     uint64_t nf = 0, no = 0, nfar = 0, nrec = 0;
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         int st = 0;
         const pd_decode_unit &un = bt->units[u];
         for (uint32_t b = 0; b < un.n_blocks; ++b) { const int v = bst[un.first_block + b]; if (v < 0) st = 2; else if (v > 0 && !st) st = 1; }
-        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) { if (segs[j].flags & pdb2::WF_BAD) st = 2; else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && !st) st = 1; }
+        for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) { if (segs[j].flags & pdb2::WF_BAD) { if (st != 2) st = 3; } else if ((segs[j].flags & (pdb2::WF_MORE | pdb2::WF_HOST)) && !st) st = 1; }
         status[u] = st;
+
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
             if (st) segs[j].n_first = segs[j].n_other = segs[j].n_far = 0; else nrec += segs[j].n_rec;
             segs[j].base_first = nf; segs[j].base_other = no; segs[j].base_far = nfar; nf += segs[j].n_first; no += segs[j].n_other; nfar += segs[j].n_far;
