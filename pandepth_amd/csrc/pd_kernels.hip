@@ -392,21 +392,16 @@ __device__ __forceinline__ void direct_candidate(const pd_iv v, int32_t ctg, uin
     // tile-relative begin / end in 32-bit arithmetic: a position before the tile wraps to a huge value
     // (candidates lie within lmax + D cells of the tile, far from 2^32)
     const uint32_t sb = bb - p0, se = x - p0;
-    if (v.tid == ctg) {
-        if (bb < x) {
-            if (sb < ST) {
-                atomicAdd(&win[sb >> 1], 1u + (sb & 1u) * 0xFFFFu);
-                ++c.n_beg; ++c.open;
-            }
-            if (se < ST) {
-                atomicSub(&win[se >> 1], 1u + (se & 1u) * 0xFFFFu);
-                --c.open;
-            }
-            if (bb < p0 && x >= p0) ++c.carry;                    // covers the cell just before the tile
-        } else if (sb < ST) {
-            ++c.n_beg;                                            // an empty run still has an owner
-        }
-    }
+    const bool mine = v.tid == ctg, nonempty = bb < x;
+    const bool pb = mine && sb < ST;                              // owns the begin (an empty run still has an owner)
+    const bool eb = pb && nonempty, ee = mine && nonempty && se < ST;
+    if (eb) atomicAdd(&win[sb >> 1], 1u + (sb & 1u) * 0xFFFFu);
+    if (ee) atomicSub(&win[se >> 1], 1u + (se & 1u) * 0xFFFFu);
+    // selects of values, not increments under the conditions: conditional increments of the three counters were
+    // compiled to ONE indexed read-modify-write of a scratch slot (12 bytes of private memory in every direct kernel)
+    c.n_beg += pb ? 1u : 0u;
+    c.open += (eb ? 1 : 0) - (ee ? 1 : 0);
+    c.carry += (mine && nonempty && bb < p0 && x >= p0) ? 1 : 0;  // covers the cell just before the tile
 }
 
 struct DirectWide { static constexpr bool narrow = false, exporting = false; uint32_t w, min_dep; TilePart *part; };
@@ -678,6 +673,285 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
         if (s_cnt[1]) atomicAdd((unsigned long long *)desc->has + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)(long long)(int)s_cnt[1]);
     }
     (void)n_long;
+}
+
+// wave totals through the DPP scan (no LDS crossbar): the last lane holds the sum
+__device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
+// k_direct_wide3 — the wide-window (w >= TILE) direct kernel, second form.  Same results as k_direct_tiles<.., DirectWide>
+// (TilePart per tile, owner / open counters for k_finish_direct, heavy list); the SIMDs were 65 % busy with vector ALU work
+// in that kernel (SQ_ACTIVE_INST_VALU), so this one does the same job in fewer instructions:
+//   * SPLIT-HALF window: word j of the 16 KB window holds cell j in its low and cell j + TILE/2 in its high 16 bits (the
+//     same "one 32-bit sum 65536 * H + L" arithmetic).  Both half-tiles go through the prefix sum in the SAME registers —
+//     additions are linear in that packing — so the scan is over 4096 words, not 8192 cells: 4 row scans per lane, not 8;
+//     the halves are only taken apart where depths are formed.  The event address is a mask and a shift.
+//   * covered cells are counted with wave ballots of the compare masks (scalar popcounts), not per-lane adds + a reduction;
+//     the remaining wave totals go through the DPP scan instead of the LDS crossbar.
+//   * tiles that are not at a contig's first cell and lie entirely inside it skip the clamps of run begin / end — they cannot
+//     change which cells of the tile a run touches; owner / open / carry counts are ballots accumulated in scalar registers.
+//   * the tail chunk of a candidate range issues its loads together, as before, and skips the empty load slots.
+template <int UN, int WPE>
+__global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
+                                                        const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
+                                                        uint32_t *heavy_list, uint32_t *heavy_count, uint32_t run_len)
+{
+    const uint32_t w = args.w, min_dep = args.min_dep; TilePart *const part = args.part;
+    constexpr uint32_t ST = TILE, HT = TILE / 2;                 // cells per tile, per half-tile (= words of the window)
+    constexpr int ROWS = (int)(HT / (WG * 4));                   // 4 rows of 4 words per lane
+    __shared__ __attribute__((aligned(16))) unsigned win[HT];
+    __shared__ int s_carry;
+    __shared__ int wtot[4];
+    __shared__ unsigned long long red_s[4][2];
+    __shared__ int red_c[4][2];
+    __shared__ uint32_t s_lo[PD_MAXPEND], s_hi[PD_MAXPEND];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t n_beg_s = 0; int open_s = 0;                        // owner / open counts: wave-uniform (scalar popcounts of compare masks)
+    (void)run_len;
+    // the batches' active tile ranges and run arrays do not change from tile to tile; the candidate bounds of the NEXT tile
+    // are fetched while this one is worked on (two dependent loads off the critical path)
+    __shared__ uint32_t s_tf[PD_MAXPEND], s_te[PD_MAXPEND], s_n[PD_MAXPEND];
+    __shared__ const pd_iv *s_iv[PD_MAXPEND];
+    if (threadIdx.x < PD_MAXPEND) {
+        const int b = threadIdx.x;
+        uint32_t tf = 0, na = 0, n = 0; const pd_iv *ivp = nullptr;
+        if (b < ps.nb) { tf = ps.b[b].desc->t_first; na = ps.b[b].desc->n_active; n = ps.b[b].n; ivp = ps.b[b].iv; }
+        s_tf[b] = tf; s_te[b] = tf + na; s_n[b] = n; s_iv[b] = ivp;
+    }
+    __syncthreads();
+    auto bounds = [&](const uint64_t t, uint32_t &lo, uint32_t &hi) {       // threads < PD_MAXPEND: batch threadIdx.x, tile t
+        lo = 0; hi = 0;
+        const int b = threadIdx.x;
+        if (b < ps.nb && t < n_tiles && t >= s_tf[b] && t < s_te[b]) {
+            const uint32_t n = s_n[b];
+            hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
+            lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
+        }
+    };
+    uint32_t nlo = 0, nhi = 0;
+    if (threadIdx.x < PD_MAXPEND) bounds(blockIdx.x, nlo, nhi);
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t a = t * ST;
+        if (threadIdx.x < PD_MAXPEND) { s_lo[threadIdx.x] = nlo; s_hi[threadIdx.x] = nhi; }
+        uint4 *w4 = reinterpret_cast<uint4 *>(win);
+        for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) s_carry = 0;
+        const int32_t ctg = (int32_t)tile_contig[t];
+        const uint32_t clen = tab.len[ctg];
+        const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);         // tile start inside the contig (slots are < 2^32 cells)
+        __syncthreads();
+        if (threadIdx.x < PD_MAXPEND) bounds(t + gridDim.x, nlo, nhi);
+        uint32_t cand = 0;
+        for (int b = 0; b < ps.nb; ++b) cand += s_hi[b] - s_lo[b];
+        if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
+            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
+            __syncthreads();
+            continue;
+        }
+        const bool interior = p0 > 0u && clen < 0x7FFFFFFFu && clen > p0 && clen - p0 >= ST;
+        int carry_s = 0;                                          // wave-uniform
+        // one candidate.  The predicates are single compares whose wave masks (ballots of the compares themselves: no
+        // extra vector work) are combined and counted in scalar registers; only the two LDS events are per-lane work.
+#define PD_B(x) __builtin_amdgcn_ballot_w64(x)
+        auto one = [&](const pd_iv v, const bool fast) {
+            uint32_t sb, se;
+            unsigned long long m_ne, m_cov;
+            bool nonempty;
+            if (fast) {
+                sb = (uint32_t)v.beg - p0; se = (uint32_t)v.end - p0;
+                nonempty = v.beg < v.end;
+                m_ne = PD_B(v.beg < v.end);
+                m_cov = PD_B(v.beg < (int32_t)p0) & PD_B(v.end >= (int32_t)p0);   // begins before the tile, reaches its first cell or further
+            } else {
+                uint32_t bb = v.beg < 0 ? 0u : (uint32_t)v.beg; if (bb > clen) bb = clen;
+                uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+                sb = bb - p0; se = x - p0;
+                nonempty = bb < x;
+                m_ne = PD_B(bb < x);
+                m_cov = PD_B(bb < p0) & PD_B(x >= p0);
+            }
+            const unsigned long long m_mine = PD_B(v.tid == ctg), m_sb = PD_B(sb < ST), m_se = PD_B(se < ST);
+            const unsigned long long m_pb = m_mine & m_sb;        // owns the begin (an empty run still has an owner)
+            const unsigned long long m_eb = m_pb & m_ne, m_ee = m_mine & m_ne & m_se;
+            if (v.tid == ctg && nonempty) {
+                if (sb < ST) atomicAdd(&win[sb & (HT - 1u)], 1u + (sb >> 12) * 0xFFFFu);
+                if (se < ST) atomicSub(&win[se & (HT - 1u)], 1u + (se >> 12) * 0xFFFFu);
+            }
+            n_beg_s += (uint32_t)__builtin_popcountll(m_pb);
+            open_s += __builtin_popcountll(m_eb) - __builtin_popcountll(m_ee);
+            carry_s += __builtin_popcountll(m_mine & m_ne & m_cov);
+        };
+#undef PD_B
+        // chunks of UN x WG candidates, stream after stream; the loads of chunk k + 1 (same stream or the next one) are in
+        // flight while chunk k is worked on
+        {
+            auto load_chunk = [&](pd_iv (&dst)[UN], const int b, const uint32_t i) {
+                const pd_iv *__restrict__ p = s_iv[b];
+                const uint32_t last = s_hi[b] - 1u;
+#pragma unroll
+                for (int k = 0; k < UN; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = p[j < last ? j : last]; }
+            };
+            int b = 0;
+            while (b < ps.nb && s_lo[b] >= s_hi[b]) ++b;
+            uint32_t i = b < ps.nb ? s_lo[b] : 0u;
+            pd_iv cur[UN];
+            if (b < ps.nb) load_chunk(cur, b, i);
+#pragma unroll 1
+            while (b < ps.nb) {
+                int nb2 = b; uint32_t ni = i + UN * WG;
+                if (ni >= s_hi[b]) { nb2 = b + 1; while (nb2 < ps.nb && s_lo[nb2] >= s_hi[nb2]) ++nb2; ni = nb2 < ps.nb ? s_lo[nb2] : 0u; }
+                pd_iv nx[UN];
+                if (nb2 < ps.nb) load_chunk(nx, nb2, ni);
+                const uint32_t left = s_hi[b] - i;
+                if (left >= UN * WG) {
+                    if (interior) {
+#pragma unroll
+                        for (int k = 0; k < UN; ++k) one(cur[k], true);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < UN; ++k) one(cur[k], false);
+                    }
+                } else {                                          // the tail chunk of a stream: empty slots skipped
+                    const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) if (k < nu) {
+                        pd_iv v = cur[k];
+                        if (threadIdx.x + k * WG >= left) v.tid = -1;       // never equals a contig id
+                        one(v, interior);
+                    }
+                }
+                if (nb2 < ps.nb) {
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) cur[k] = nx[k];
+                }
+                b = nb2; i = ni;
+            }
+        }
+        if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
+        __syncthreads();
+        // ---- prefix sum of the packed window: both half-tiles at once ----
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
+            v[r] = make_int4((int)q.x, (int)q.x + (int)q.y, 0, 0);
+            v[r].z = v[r].y + (int)q.z; v[r].w = v[r].z + (int)q.w;
+        }
+        int ex[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) ex[r] = wave_incl_scan(v[r].w);
+        int run = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int e = run + ex[r] - v[r].w;                   // exclusive prefix of this lane's group in the wave
+            run += __builtin_amdgcn_readlane(ex[r], 63);
+            ex[r] = e;
+        }
+        if (lane == 0) wtot[wv] = run;
+        __syncthreads();
+        int basep = 0;                                            // packed: words of the waves before this one
+        for (int k = 0; k < wv; ++k) basep += wtot[k];
+        const int totp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        const int tl = (int)(short)(totp & 0xffff);               // begins - ends over the low half-tile
+        const int carry_l = s_carry, carry_h = carry_l + tl;      // depth just before cell 0 / cell HT of the tile
+        // ---- the tile's share of windows k0 and k0 + 1 ----
+        const uint64_t local0 = p0;
+        int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+        bool uniform_counts = false;                              // c0 is a wave count (ballots), s0 a 32-bit lane sum
+        if (local0 < clen) {
+            const uint64_t k0 = local0 / w;
+            const uint64_t nb64 = (k0 + 1) * (uint64_t)w - local0;   // tile-local start of window k0+1
+            const uint32_t nb = nb64 > (uint64_t)ST ? ST : (uint32_t)nb64;
+            const uint64_t left = (uint64_t)clen - local0;
+            const uint32_t lim = left > (uint64_t)ST ? ST : (uint32_t)left;
+            const uint64_t dmax = (uint64_t)(uint32_t)carry_l + cand;     // no depth in this tile exceeds carry + begins
+            if (nb >= ST && lim >= ST && min_dep <= 1u && dmax < (1u << 27) && dmax <= wrap_mask) {
+                // the common tile — inside one window, inside the contig, no wrap possible, threshold <= 1: the sum is the
+                // sum of the local prefixes + 16 x (carry_l + carry_h) per lane; a cell is covered unless its prefix = -carry
+                int sl = 0; int cnt = 0;
+                const int zl = -carry_l, zh = -carry_h;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        sl += L + H;
+                        if (min_dep) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(L != zl)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(H != zh));
+                    }
+                }
+                c0 = min_dep ? cnt : (int)(ROWS * 8 * 64);
+                s0 = (uint32_t)sl + (uint32_t)(ROWS * 4) * ((uint32_t)carry_l + (uint32_t)carry_h);
+                uniform_counts = true;
+            } else if (nb >= ST && lim >= ST && dmax < (1u << 27)) {
+                uint32_t s32 = 0; int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        const uint32_t dl = (uint32_t)(L + carry_l) & wrap_mask, dh = (uint32_t)(H + carry_h) & wrap_mask;
+                        const bool okl = dl >= min_dep, okh = dh >= min_dep;
+                        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(okl)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(okh));
+                        s32 += (okl ? dl : 0u) + (okh ? dh : 0u);
+                    }
+                }
+                c0 = cnt; s0 = s32; uniform_counts = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        const uint32_t dl = (uint32_t)(L + carry_l) & wrap_mask, dh = (uint32_t)(H + carry_h) & wrap_mask;
+                        const uint32_t pl = pos + q, ph = pl + HT;
+                        if (pl < lim && dl >= min_dep) { if (pl < nb) { ++c0; s0 += dl; } else { ++c1; s1 += dl; } }
+                        if (ph < lim && dh >= min_dep) { if (ph < nb) { ++c0; s0 += dh; } else { ++c1; s1 += dh; } }
+                    }
+                }
+            }
+        }
+        if (uniform_counts) {                                     // workgroup-uniform
+            const uint32_t s32 = (uint32_t)s0;
+            const unsigned long long lo16 = (unsigned long long)(uint32_t)wave_total((int)(s32 & 0xffffu));
+            const unsigned long long hi16 = (unsigned long long)(uint32_t)wave_total((int)(s32 >> 16));
+            s0 = (hi16 << 16) + lo16;
+        } else {
+            c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        }
+        if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            TilePart tp;
+            tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+            tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+            tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+            tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+            part[t] = tp;
+        }
+        __syncthreads();
+    }
+    // every begin and every end must have found its owner tile (k_finish_direct compares the sums over all batches)
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        if (n_beg_s) atomicAdd(&s_cnt[0], n_beg_s);
+        if (open_s) atomicAdd(&s_cnt[1], (unsigned)open_s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BatchDesc *desc = ps.b[0].desc;
+        if (s_cnt[0]) atomicAdd((unsigned long long *)desc->handled + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd((unsigned long long *)desc->has + (blockIdx.x & (PD_CNT_SLOTS - 1)), (unsigned long long)(long long)(int)s_cnt[1]);
+    }
 }
 
 __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uint32_t n_tiles, ContigTab tab,
@@ -1560,11 +1834,35 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     if (w < (uint32_t)TILE)
         hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
                            wrap_mask, dn, n_long, heavy_list, heavy_count);
+    else if (un == 0 || un >= 3000) {                   // second form (k_direct_wide3): run length x 10000 + 3000 + 100 x waves-per-SIMD target + loads in flight per thread
+        const uint32_t run_len = un >= 10000 ? (uint32_t)(un / 10000) : 1u;
+        const uint64_t n_runs = ((uint64_t)n_tiles + run_len - 1) / run_len;
+        const unsigned g3 = grid_tiles > n_runs ? (unsigned)n_runs : grid_tiles;
+#define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_>), dim3(g3), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, run_len)
+        switch (un % 10000) {                // (measured on the bench sample, ms: 3602 3.08-3.11, 3504 3.10-3.28, 3503 3.2, 3702 3.3, 3502 3.4, 3404 3.6-3.8, 3801 3.6; first form 3.52-3.60)
+        case 3404: PD_DIRECT3(4, 4); break;
+        case 3502: PD_DIRECT3(2, 5); break;
+        case 3503: PD_DIRECT3(3, 5); break;
+        case 3602: PD_DIRECT3(2, 6); break;
+        case 3702: PD_DIRECT3(2, 7); break;
+        case 3802: PD_DIRECT3(2, 8); break;
+        case 3801: PD_DIRECT3(1, 8); break;
+        case 3601: PD_DIRECT3(1, 6); break;
+        case 3603: PD_DIRECT3(3, 6); break;
+        case 3604: PD_DIRECT3(4, 6); break;
+        case 3804: PD_DIRECT3(4, 8); break;
+        case 3508: PD_DIRECT3(8, 5); break;
+        case 3608: PD_DIRECT3(8, 6); break;
+        case 3504: PD_DIRECT3(4, 5); break;
+        default: PD_DIRECT3(2, 6); break;
+        }
+#undef PD_DIRECT3
+    }
     else switch (un) {                       // tuning knob "direct_un": loads in flight per thread + 100 x waves-per-SIMD target
     case 404: PD_DIRECT(4, 4); break;   // (measured on the bench sample: 504 3.4-3.6 ms, 508 3.3-3.6, 404 3.7, 408 3.7)
     case 408: PD_DIRECT(8, 4); break;
     case 508: PD_DIRECT(8, 5); break;
-    default: PD_DIRECT(4, 5); break;
+    default: PD_DIRECT(4, 5); break;         // 504 (or any other value below 3000): the first form
     }
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,

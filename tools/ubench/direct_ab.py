@@ -1,0 +1,48 @@
+"""A/B of the direct wide-window kernels on the bench sample (one process, one data set): per variant of the
+"direct_un" knob the context's own event time of the direct_tiles section, and equality of the tables with the default's."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import pandepth_amd as pda
+from tools import synth
+dev = torch.device("cuda", 0)
+names, lens = synth.genome_c2()
+eng = pda.Engine(lens.astype(np.uint32), device=0)
+R = int(float(os.environ.get("R", "1e9")))
+first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
+torch.cuda.synchronize()
+eng.set_param("direct_windows", 1)
+def scatter():
+    eng.reset()
+    eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+    eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN) | pda.PD_PUSH_MORE)
+CASES = [(10000000, 1, 0), (10000000, 1, 18), (10000000, 3, 0), (8192, 1, 0), (250000, 2, 18), (10000000, 0, 0)]
+ref = {}
+variants = [int(x) for x in os.environ.get("VARIANTS", "0,2404,2304,2408,2406,0").split(",")]
+for v in variants:
+    eng.set_param("direct_un", v)
+    ok = True
+    for c in CASES:
+        scatter()
+        _, cov, tot = eng.scan_reduce_windows(*c)
+        if c not in ref: ref[c] = (cov.copy(), tot.copy())
+        elif not (np.array_equal(cov, ref[c][0]) and np.array_equal(tot, ref[c][1])):
+            ok = False
+            bad = np.nonzero((cov != ref[c][0]) | (tot != ref[c][1]))[0]
+            print("variant", v, "case", c, "DIFFERS at", bad.size, "windows, first", bad[:5].tolist(), tot[bad[:3]].tolist(), ref[c][1][bad[:3]].tolist(), cov[bad[:3]].tolist(), ref[c][0][bad[:3]].tolist())
+    for _ in range(2):
+        scatter(); eng.scan_reduce_windows(10000000, 1, 0)
+    eng.synchronize()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    N = 10
+    for _ in range(N):
+        scatter(); eng.scan_reduce_windows(10000000, 1, 0)
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / N * 1e3
+    ms, n = eng.profile_get("direct_tiles")
+    ims, inn = eng.profile_get("scatter_index")
+    eng.profile(False)
+    print("variant %5d: direct_tiles %.3f ms/launch (%d), index %.3f ms/step, step wall %.3f ms, tables %s" % (v, ms / max(n, 1), n, ims / N, dt, "equal" if ok else "DIFFERENT"), flush=True)

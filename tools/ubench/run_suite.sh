@@ -1,5 +1,4 @@
-# GPU box: the whole -m gpu suite, then bench.py (short) with the e2e leg
-mkdir -p gpurun_out/r2f; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-(timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -15) > gpurun_out/r2f/pytest.log
-true
-tail -5 gpurun_out/r2f/pytest.log; tail -3 gpurun_out/r2f/bench.err; cat gpurun_out/r2f/bench.json | cut -c1-1500
+# GPU box: the whole -m gpu suite
+mkdir -p gpurun_out/r2s; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+(timeout 1700 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -25) > gpurun_out/r2s/pytest.log
+tail -12 gpurun_out/r2s/pytest.log | cut -c1-600
