@@ -39,6 +39,15 @@ reference's run there is also the contract's "cpu_baseline".
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run,
 one rank per GPU, each rank holding its own sample ("one BAM per GPU", #.list mode).
+
+--config gff | w100a: the same contract line for BASELINE.json's other two full-size configurations on the same sample
+(they are parity-test cases, tests/test_gpu_fullsize.py; these legs give their kernels a measured roofline):
+    gff    configs[2], `-g` with 33 688 transcripts / 175 274 CDS entries: owner-tile scatter INTO the difference arrays
+           (k_scatter_tiles), write-back prefix sum (pd_scan: k_sweep reads and writes every cell), interval statistics
+           (pd_reduce_intervals: k_reduce_pieces)
+    w100a  configs[3], `-w 100 -a`: scatter, write-back prefix sum with the 18-bit wrap (the per-site file needs the cells),
+           100-base windows off the depth (pd_reduce_windows: 3.0e7 windows); the read-back of the cells for the per-site
+           text (pd_read_depth, PCIe) is timed separately ("site_readback") — host side, not in `value`
 """
 import argparse
 import json
@@ -58,7 +67,8 @@ BIN = 10000000                 # whole-chromosome mode's synthetic bins (PD:3978
 
 # algorithmic bytes per unit (SURVEY.md §8d / DESIGN.md §4)
 B_FILL_PER_CELL = 4
-B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write)
+B_SCATTER_PER_RUN = 12         # owner-tile scatter: every run read once ...
+B_SCATTER_PER_CELL = 4         # ... and every cell of the difference arrays written once (after pd_reset half-tiles are stored, not read)
 B_SWEEP_FUSED_PER_BASE = 4
 B_RUN = 12                     # one packed (tid, beg, end) run
 
@@ -142,6 +152,130 @@ def e2e_leg(records):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def config_leg(args, which, eng, pda, synth, torch, dist, first, other, lens, rank, world, use_dist):
+    """configs[2] / configs[3] on the bench sample: K timed steps of that configuration's device work, one JSON line."""
+    G = int(lens.sum())
+    n_first, n_other = int(first.shape[0]), int(other.shape[0])
+    n_runs = n_first + n_other
+    R = int(args.records)
+    n_cells = eng.device_layout()[0]
+    eng.set_param("direct_windows", 0)
+    regs, region_bases = None, 0
+    if which == "gff":
+        # synthetic annotation of configs[2] (README:128): 33 688 transcripts / 175 274 CDS entries, exon length log-normal
+        rng = np.random.default_rng(3)
+        per_tx = np.full(33688, 175274 // 33688); per_tx[:175274 - per_tx.sum()] += 1
+        chrom = rng.choice(12, 33688, p=lens[:12] / lens[:12].sum())
+        rl = []
+        for t in range(33688):
+            c = int(chrom[t]); s0 = int(rng.integers(1, lens[c] - 200000))
+            for _ in range(int(per_tx[t])):
+                el = int(min(5000, max(30, rng.lognormal(np.log(150), 0.7))))
+                rl.append((c, s0, s0 + el - 1)); s0 += el + int(rng.integers(80, 3000))
+        regs = np.array(rl, dtype=np.int32)
+        region_bases = int((regs[:, 2] - regs[:, 1] + 1).sum())
+
+    def step():
+        eng.reset()
+        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
+        if which == "gff":
+            eng.scan(0)                                          # indexed single BAM: uint32 cells (PD:676-786)
+            return eng.reduce_intervals(regs, 1)
+        eng.scan(18)                                             # -a: SiteInfo cells (PD:4127)
+        return eng.reduce_windows(100, 1)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=first.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    keys = ("reset", "fill", "scatter_index", "scatter_tiles", "scatter_finish", "scan", "reduce_intervals", "reduce_windows")
+    prof = {k: eng.profile_get(k) for k in keys}
+    eng.profile(False)
+    site = None
+    if which == "w100a" and rank == 0:
+        # the per-site text needs every cell on the host: the largest contig's cells over PCIe (pageable destination)
+        t1 = time.perf_counter()
+        d = eng.read_depth(0, 0, int(lens[0]))
+        t1 = time.perf_counter() - t1
+        site = {"what": "pd_read_depth of Chr01 (%d cells, 4 B each) into a pageable host buffer" % int(lens[0]), "seconds": round(t1, 4),
+                "GBps": round(4 * int(lens[0]) / t1 / 1e9, 2), "cells_sum_check": int(d.astype(np.uint64).sum())}
+    if rank != 0:
+        return None
+
+    def ent(name, alg):
+        ms, n = prof[name]
+        if not n:
+            return None
+        avg = ms / n
+        return {"avg_ms": round(avg, 4), "launches": n, "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "unit": "GB/s",
+                "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg)}
+    lt = max(1, prof["scatter_tiles"][1] // args.steps)
+    kernels = {
+        # every run read once (12 B), every cell of the arrays written once (4 B)
+        "scatter_tiles": ent("scatter_tiles", (n_runs * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / lt),
+        # write-back prefix sum: every cell read and written once
+        "scan": ent("scan", 8 * n_cells),
+    }
+    if which == "gff":
+        kernels["reduce_intervals"] = ent("reduce_intervals", 4 * region_bases + 24 * len(regs))
+    else:
+        kernels["reduce_windows"] = ent("reduce_windows", 4 * G + 12 * (G // 100))
+    dom = max((k for k in kernels if kernels[k]), key=lambda k: prof[k][0])
+    kd = kernels[dom]
+    traffic, pmc_file = None, ""
+    try:
+        import glob
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        pmc = json.load(open(pmc_file))
+        want = {"scatter_tiles": "k_scatter_tiles<8192", "scan": "k_sweep<true, false, false"}.get(dom)
+        key = next((k for k in pmc["kernels"] if want and k.startswith(want)), None)
+        if key and R == int(1e9):
+            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+    except (OSError, IndexError, KeyError, ValueError):
+        traffic = None
+    if which == "gff":
+        cov, tot = res
+        check = {"regions": int(len(regs)), "region_bases": region_bases, "depth_sum_over_regions": int(np.asarray(tot, dtype=np.uint64).sum())}
+        metric = "alignment records/sec (3 Gb genome, 50x BAM, -g annotation mode: 33688 transcripts / 175274 CDS)"
+        workload = "configs[2]: the configs[1] sample + a synthetic annotation of 33 688 transcripts / 175 274 CDS entries (%d bases)" % region_bases
+    else:
+        woff, cov, tot = res
+        check = {"windows": int(len(tot)), "depth_sum_over_windows": int(np.asarray(tot, dtype=np.uint64).sum())}
+        metric = "alignment records/sec (3 Gb genome, 50x BAM, -w 100 -a mode)"
+        workload = "configs[3]: the configs[1] sample, 100-base windows (%d of them) + per-site cells kept for the per-site file" % len(tot)
+    return {
+        "metric": metric, "value": world * R / (dt / args.steps), "unit": "records/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": workload, "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other, "cells": int(n_cells),
+                   "path": "arrays (difference arrays in HBM, prefix sum written back)", "parallelism": "replicas" if world > 1 else "1 GPU",
+                   "check": check},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kd["frac"],
+                     "traffic": None,
+                     "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)} if traffic else None),
+                     "avg_launch_ms": kd["avg_ms"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]},
+        "kernels": kernels, "site_readback": site,
+        "cpu_baseline": {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
+                         "sample": "not timed in this leg: the reference's run is timed by the default (--config chr) invocation's e2e leg"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +284,19 @@ def main():
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
     ap.add_argument("--e2e-records", type=float, default=1.0e8,
                     help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip)")
+    ap.add_argument("--config", choices=["chr", "gff", "w100a"], default="chr",
+                    help="chr = configs[1] (BASELINE.json's metric; default); gff = configs[2]; w100a = configs[3]")
     args = ap.parse_args()
+
+    # the contract: rank 0 prints ONE JSON line on stdout.  Libraries loaded below write there too (RCCL announces its version
+    # when a communicator is made): file descriptor 1 is pointed at stderr for the life of the process and the line goes to
+    # the real stdout through emit().
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
     import torch
     import torch.distributed as dist
@@ -181,6 +327,15 @@ def main():
     first, other = synth.gen_runs_torch(lens, R, dev, seed=42 + rank)
     torch.cuda.synchronize()
     n_first, n_other, n_far = int(first.shape[0]), int(other.shape[0]), 0
+    if args.config != "chr":
+        line = config_leg(args, args.config, eng, pda, synth, torch, dist, first, other, lens, rank, world, use_dist)
+        if rank == 0:
+            emit(line)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        eng.close()
+        return
     _, n_words, _ = eng.device_buffer()
     n_cells = eng.device_layout()[0]
     # N > 1: int8 transport of the difference arrays (1 B/cell on the xGMI links instead of 4);
@@ -327,7 +482,7 @@ def main():
         def entries(prof, steps):
             launches_tiles = max(1, prof["scatter_tiles"][1] // steps)
             return {
-                "scatter_tiles": k_entry2(prof, "scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
+                "scatter_tiles": k_entry2(prof, "scatter_tiles", ((n_first + n_other + n_far) * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / launches_tiles),
                 "scan_reduce_windows": k_entry2(prof, "scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE)}
 
         def k_entry2(pr, name, alg):
@@ -350,7 +505,7 @@ def main():
             # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
             "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
                      if prof["fill"][1] else None),
-            "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
+            "scatter_tiles": k_entry("scatter_tiles", ((n_first + n_other + n_far) * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / launches_tiles),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
             "export_i8": k_entry("export_i8", 5 * (n_words - (n_words - G) % 1)),     # 4 B read + 1 B written per cell
             "import_i8": k_entry("import_i8", 5 * (n_words - (n_words - G) % 1)),     # 1 B read + 4 B written per cell
@@ -369,7 +524,7 @@ def main():
             pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
             pmc = json.load(open(pmc_file))
             key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
-                   "direct_tiles": "k_direct_tiles<4, 5>"}.get(dom)
+                   "direct_tiles": "k_direct_wide3<"}.get(dom)
             key = next((k for k in pmc["kernels"] if key and k.startswith(key.rstrip(">"))), None)    # template arguments may grow
             if key and R == int(1e9):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
@@ -411,7 +566,7 @@ def main():
             "e2e": e2e,
             "cpu_baseline": cb,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         dist.barrier()
         if isinstance(sliced, pda.Comm):

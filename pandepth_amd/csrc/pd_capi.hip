@@ -69,7 +69,7 @@ struct pd_ctx {
     bool direct_windows = false;                                  // pd_scan_reduce_windows may consume deferred batches in place
     bool pristine = true;                                         // nothing materialised in the arrays since the last reset
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
-    int direct_un = 4;
+    int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
     bool all_valid_host = false;
     std::vector<Pending> pend;
     // ---- device decode (pd_decode_*): a few batch slots, each with its own stream and buffers ----

@@ -17,8 +17,12 @@ int main(int argc, char **argv)
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
     // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory
-    setenv("PANDEPTH_KEEP_CONTEXT", "1", 1);
+    // (PANDEPTH_ORDERLY_EXIT=1: tear everything down and return — a profiler attached to the process writes its files from an
+    // exit handler, which _exit would skip)
+    const bool orderly = getenv("PANDEPTH_ORDERLY_EXIT") != nullptr;
+    if (!orderly) setenv("PANDEPTH_KEEP_CONTEXT", "1", 1);
     const int rc = pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);
     fflush(stdout); fflush(stderr);
+    if (orderly) return rc;
     _exit(rc);
 }
