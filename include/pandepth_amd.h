@@ -142,6 +142,11 @@ int pd_reduce_windows(pd_ctx *ctx, uint32_t w, uint32_t min_dep, uint32_t *cover
 /* Replaces the per-site read loop PD:4278-4281: copies depth cells [beg, beg+n) of contig tid
  * to the host.  Requires pd_scan first. */
 int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *out);
+/* Per-site rows formatted on the device (PD:4278-4281, 4750-4753, 3031-3034): after pd_scan, the text
+ * "<name>\t<index>\t<depth>\n" for cells [beg, beg + n) of contig tid (index = the 0-based cell number the reference prints),
+ * written to `text` (a host buffer of `cap` bytes; n * (name_len + 23) always suffices), *n_bytes = its length.  What
+ * crosses PCIe is the text the gzip stage consumes, not 4-byte cells to be formatted by host threads.  n <= 2^27 per call. */
+int pd_format_sites(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, char *text, size_t cap, size_t *n_bytes);
 
 /* Test / interop access to the accumulating buffer (difference arrays + tile sums are ONE
  * contiguous int32 allocation so that a multi-BAM sum, PD:2704-3014, is a single RCCL

@@ -793,6 +793,42 @@ int pd_read_depth(pd_ctx *c, int32_t tid, uint32_t beg, size_t n, uint32_t *out)
     return PD_OK;
 }
 
+int pd_format_sites(pd_ctx *c, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, char *text, size_t cap, size_t *n_bytes)
+{
+    if (!c || !n_bytes || (!text && cap) || (!name && name_len)) return PD_EINVAL;
+    *n_bytes = 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rs = need_state(c, 1, "pd_format_sites")) return rs;
+    if (tid < 0 || tid >= c->n_contigs) return fail(c, PD_EINVAL, "pd_format_sites: contig id out of range");
+    if ((uint64_t)beg + n > c->off[tid + 1] - c->off[tid]) return fail(c, PD_EINVAL, "pd_format_sites: range past the contig slot");
+    if (name_len > 4096 || n > ((size_t)1 << 27)) return fail(c, PD_EINVAL, "pd_format_sites: at most 2^27 cells per call and 4096 bytes of name");
+    if (n == 0) return PD_OK;
+    HIPOK(c, hipSetDevice(c->device));
+    const uint32_t nb = pdk::site_rows_blocks(n);
+    const size_t b_name = (name_len + 15) / 16 * 16 + 16, b_cnt = ((size_t)nb * 4 + 15) / 16 * 16, b_off = ((size_t)nb + 1) * 8;
+    const size_t worst = n * (name_len + 23);                  // name + 2 tabs + newline + 2 x 10 digits
+    int rc = ensure_scratch(c, b_name + b_cnt + b_off + worst + 64);
+    if (rc) return rc;
+    unsigned char *s = (unsigned char *)c->scratch;
+    char *d_name = (char *)s; uint32_t *d_cnt = (uint32_t *)(s + b_name); uint64_t *d_off = (uint64_t *)(s + b_name + b_cnt);
+    char *d_text = (char *)(s + b_name + b_cnt + b_off);
+    ProfScope ps(c, "format_sites");
+    if (name_len) HIPOK(c, hipMemcpyAsync(d_name, name, name_len, hipMemcpyHostToDevice, c->stream));
+    const uint32_t *depth = (const uint32_t *)(c->buf + c->off[tid] + beg);
+    pdk::launch_site_rows(c->stream, depth, beg, n, (uint32_t)name_len, d_name, d_cnt, d_off, d_text, false);
+    uint64_t total = 0;
+    HIPOK(c, hipMemcpyAsync(&total, d_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    HIPOK(c, hipGetLastError());
+    if (total > cap) return fail(c, PD_EINVAL, "pd_format_sites: the text buffer is too small");
+    pdk::launch_site_rows(c->stream, depth, beg, n, (uint32_t)name_len, d_name, d_cnt, d_off, d_text, true);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemcpyAsync(text, d_text, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    *n_bytes = (size_t)total;
+    return PD_OK;
+}
+
 int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *contig_off)
 {
     if (!c) return PD_EINVAL;

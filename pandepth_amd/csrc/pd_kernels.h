@@ -107,6 +107,13 @@ void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 } // namespace pdk
 
+// per-site text rows (pd_format.hip)
+namespace pdk {
+uint32_t site_rows_blocks(uint64_t n);
+void launch_site_rows(hipStream_t st, const uint32_t *depth, uint32_t first_index, uint64_t n, uint32_t name_len, const char *dev_name,
+                      uint32_t *blk_bytes, uint64_t *blk_off, char *text, bool write);
+}
+
 // the record walk of the device decode path (pd_bamwalk.h)
 namespace pdb2 { struct Cfg; struct Seg; struct LaneOut; }
 namespace pdk {

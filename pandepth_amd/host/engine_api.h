@@ -41,6 +41,8 @@ typedef struct pd_engine_api {
     int (*sliced_window_sum)(pd_comm *, uint32_t, uint32_t, unsigned, int, uint32_t *, uint64_t *);
     int (*comm_destroy)(pd_comm *);
     const char *(*comm_strerror)(const pd_comm *);
+    /* optional (NULL = the host formats the cells it reads back): per-site rows formatted by the engine, see pd_format_sites */
+    int (*format_sites)(pd_ctx *, int32_t, uint32_t, size_t, const char *, size_t, char *, size_t, size_t *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

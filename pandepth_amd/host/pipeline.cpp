@@ -641,6 +641,22 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                 const uint32_t len = hdr.lens[t];
                 for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
                     const size_t n = std::min<size_t>(CH, len - b);
+                    if (eng->api->format_sites) {
+                        // the engine formats the rows where the cells are; one block of text comes back
+                        std::vector<std::string> parts(1);
+                        const std::string &nm = hdr.names[t];
+                        parts[0].resize(n * (nm.size() + 23));
+                        size_t got = 0;
+                        if (!eng->ck(eng->api->format_sites(eng->ctx, (int32_t)t, b, n, nm.data(), nm.size(), &parts[0][0], parts[0].size(), &got), "pd_format_sites")) { prod_ok = false; goto out; }
+                        parts[0].resize(got);
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || q.size() < 2; });
+                        if (stop) goto out;
+                        q.push_back(std::move(parts));
+                        lk.unlock();
+                        cv.notify_all();
+                        continue;
+                    }
                     if (!eng->ck(eng->api->read_depth(eng->ctx, (int32_t)t, b, n, d.data()), "pd_read_depth")) { prod_ok = false; goto out; }
                     {
                         std::vector<std::string> parts((size_t)nt);

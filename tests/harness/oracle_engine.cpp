@@ -264,6 +264,6 @@ int main(int argc, char **argv)
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
                                       o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from,
                                       o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param,
-                                      nullptr, nullptr, nullptr, nullptr};
+                                      nullptr, nullptr, nullptr, nullptr, nullptr};
     return pandepth_main(argc, argv, &api, 0);
 }

@@ -689,3 +689,37 @@ def test_direct_export_equals_export_of_the_arrays():
         assert np.array_equal(got[1], c) and np.array_equal(got[2], t)
     finally:
         ea.close(); ed.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# per-site rows formatted on the device (pd_format_sites)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wrap", [0, 18])
+def test_format_sites_equals_host_formatting(wrap):
+    """pd_format_sites == "<name>\\t<index>\\t<depth>\\n" (PD:4278-4281) of the cells pd_read_depth returns: ranges that
+    start and end inside workgroup blocks, single cells, indices whose digit count changes inside the range, deep pile-ups
+    (6-digit depths), names of 1 and 40 bytes, and the error cases."""
+    rng = np.random.default_rng(77)
+    lens = np.array([1200000, 50000, 9, 1], dtype=np.uint32)
+    iv = np.concatenate([rand_intervals(rng, lens, 60000), np.tile(np.array([[0, 99990, 100020]], dtype=np.int32), (150000, 1)),
+                         np.tile(np.array([[2, 0, 9]], dtype=np.int32), (7, 1))])
+    with pda.Engine(lens) as e:
+        e.push_intervals(iv)
+        e.scan(wrap)
+        for tid, beg, n, name in ((0, 0, 1, "c"), (0, 0, 4095, "chr1"), (0, 1, 4096, "chr1"), (0, 9, 4097, "Chr01"), (0, 99000, 2000, "x" * 40),
+                                  (0, 999990, 100000, "chr1"), (0, 0, 1200000, "Chr01"), (1, 49999, 1, "scaffold_77"), (2, 0, 9, "s"), (3, 0, 1, "t"),
+                                  (1, 0, 0, "empty")):
+            d = e.read_depth(tid, beg, n)
+            want = "".join("%s\t%d\t%d\n" % (name, beg + j, int(d[j])) for j in range(n)).encode() if n <= 200000 else \
+                   b"".join(("%s\t%d\t%d\n" % (name, beg + j, int(d[j]))).encode() for j in range(n))
+            got = e.format_sites(tid, beg, n, name)
+            assert got == want, (tid, beg, n, name, len(got), len(want))
+        assert int(e.read_depth(0, 99995, 1)[0]) >= 150000 or wrap == 18
+        with pytest.raises(pda.PdError):
+            e.format_sites(9, 0, 1, "x")
+        with pytest.raises(pda.PdError):
+            e.format_sites(1, 57340, 10, "x")                   # past the contig's slot (50 001 cells rounded up to 57 344)
+    with pda.Engine(lens) as e:
+        e.push_intervals(iv)
+        with pytest.raises(pda.PdError):
+            e.format_sites(0, 0, 10, "x")                       # before pd_scan: the cells are not depths yet
