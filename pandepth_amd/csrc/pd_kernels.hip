@@ -693,7 +693,7 @@ __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readl
 template <int UN, int WPE>
 __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
-                                                        uint32_t *heavy_list, uint32_t *heavy_count, uint32_t run_len)
+                                                        uint32_t *heavy_list, uint32_t *heavy_count)
 {
     const uint32_t w = args.w, min_dep = args.min_dep; TilePart *const part = args.part;
     constexpr uint32_t ST = TILE, HT = TILE / 2;                 // cells per tile, per half-tile (= words of the window)
@@ -706,7 +706,6 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
     __shared__ uint32_t s_lo[PD_MAXPEND], s_hi[PD_MAXPEND];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t n_beg_s = 0; int open_s = 0;                        // owner / open counts: wave-uniform (scalar popcounts of compare masks)
-    (void)run_len;
     // the batches' active tile ranges and run arrays do not change from tile to tile; the candidate bounds of the NEXT tile
     // are fetched while this one is worked on (two dependent loads off the critical path)
     __shared__ uint32_t s_tf[PD_MAXPEND], s_te[PD_MAXPEND], s_n[PD_MAXPEND];
@@ -936,7 +935,8 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
             part[t] = tp;
         }
-        __syncthreads();
+        // (no barrier here: everything the next tile overwrites — bounds, window, carry, wave totals, partials — is last read
+        // before one of the three barriers that precede the overwriting store)
     }
     // every begin and every end must have found its owner tile (k_finish_direct compares the sums over all batches)
     __shared__ unsigned s_cnt[2];
@@ -1834,25 +1834,13 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     if (w < (uint32_t)TILE)
         hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
                            wrap_mask, dn, n_long, heavy_list, heavy_count);
-    else if (un == 0 || un >= 3000) {                   // second form (k_direct_wide3): run length x 10000 + 3000 + 100 x waves-per-SIMD target + loads in flight per thread
-        const uint32_t run_len = un >= 10000 ? (uint32_t)(un / 10000) : 1u;
-        const uint64_t n_runs = ((uint64_t)n_tiles + run_len - 1) / run_len;
-        const unsigned g3 = grid_tiles > n_runs ? (unsigned)n_runs : grid_tiles;
-#define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_>), dim3(g3), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, run_len)
-        switch (un % 10000) {                // (measured on the bench sample, ms: 3602 3.08-3.11, 3504 3.10-3.28, 3503 3.2, 3702 3.3, 3502 3.4, 3404 3.6-3.8, 3801 3.6; first form 3.52-3.60)
+    else if (un == 0 || un >= 3000) {        // second form (k_direct_wide3): 3000 + 100 x waves-per-SIMD target + loads in flight per thread
+#define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count)
+        // measured on the bench sample (ms; variants that were tried and are no longer compiled included): <2, 6> 3.08-3.13,
+        // <4, 5> 3.10-3.28, <3, 5> 3.2, <2, 7> 3.3, <2, 5> 3.4, <4, 4> 3.6-3.8, <1, 8> 3.6, <2, 8> 4.1 (spills), <4, 6> 3.5
+        // (spills); first form 3.52-3.69.  Grids of 16 K .. 262 K workgroups: within 2 %.
+        switch (un) {
         case 3404: PD_DIRECT3(4, 4); break;
-        case 3502: PD_DIRECT3(2, 5); break;
-        case 3503: PD_DIRECT3(3, 5); break;
-        case 3602: PD_DIRECT3(2, 6); break;
-        case 3702: PD_DIRECT3(2, 7); break;
-        case 3802: PD_DIRECT3(2, 8); break;
-        case 3801: PD_DIRECT3(1, 8); break;
-        case 3601: PD_DIRECT3(1, 6); break;
-        case 3603: PD_DIRECT3(3, 6); break;
-        case 3604: PD_DIRECT3(4, 6); break;
-        case 3804: PD_DIRECT3(4, 8); break;
-        case 3508: PD_DIRECT3(8, 5); break;
-        case 3608: PD_DIRECT3(8, 6); break;
         case 3504: PD_DIRECT3(4, 5); break;
         default: PD_DIRECT3(2, 6); break;
         }

@@ -20,8 +20,10 @@ def scatter():
     eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN) | pda.PD_PUSH_MORE)
 CASES = [(10000000, 1, 0), (10000000, 1, 18), (10000000, 3, 0), (8192, 1, 0), (250000, 2, 18), (10000000, 0, 0)]
 ref = {}
-variants = [int(x) for x in os.environ.get("VARIANTS", "0,2404,2304,2408,2406,0").split(",")]
-for v in variants:
+variants = [x for x in os.environ.get("VARIANTS", "0").split(",")]
+for vs in variants:
+    v = int(vs.split("@")[0])
+    eng.set_param("grid_tiles", int(vs.split("@")[1]) if "@" in vs else 0)
     eng.set_param("direct_un", v)
     ok = True
     for c in CASES:
@@ -45,4 +47,4 @@ for v in variants:
     ms, n = eng.profile_get("direct_tiles")
     ims, inn = eng.profile_get("scatter_index")
     eng.profile(False)
-    print("variant %5d: direct_tiles %.3f ms/launch (%d), index %.3f ms/step, step wall %.3f ms, tables %s" % (v, ms / max(n, 1), n, ims / N, dt, "equal" if ok else "DIFFERENT"), flush=True)
+    print("variant %5d grid %s: direct_tiles %.3f ms/launch (%d), index %.3f ms/step, step wall %.3f ms, tables %s" % (v, vs.split("@")[1] if "@" in vs else "auto", ms / max(n, 1), n, ims / N, dt, "equal" if ok else "DIFFERENT"), flush=True)

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out/e2et; cd /tmp && export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/e2et
+mkdir -p /tmp/e2e && cd /tmp/e2e && timeout 300 $GRAFT_REPO_ROOT/tools/bamgen -o s.bam -n 40000000 -t 32 2>&1 | tail -1
+P=$GRAFT_REPO_ROOT/pandepth_amd/pandepth
+for T in 1 2 6; do echo "feeders $T"; PANDEPTH_DD_THREADS=$T PANDEPTH_TIMING=1 $P -i s.bam -o m -t 16 2>&1 | grep -E "device decode|decode \+ scatter|engine create" | cut -c1-400; done
