@@ -53,8 +53,10 @@ struct Seg {
     uint32_t n_far, pad2;
     uint64_t base_first, base_other, base_far;    // written by the host between the passes: where the segment's runs go
 };
+static const int SCAN = 64;               // positions of the header search tested per step (one group of loads)
 struct LaneOut { uint64_t start; uint32_t n_first, n_other, n_far, pad; };
 
+PW_FN int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 PW_FN uint32_t rd32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 PW_FN uint32_t rd16(const uint8_t *p) { uint16_t w; __builtin_memcpy(&w, p, 2); return w; }
 
@@ -180,7 +182,39 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
         // the guess: first plausible header in the lane's KiB (lane 0 of a segment whose start is known: that)
         uint64_t g = NONE;
         if (l == 0 && hint != NONE) g = hint;
-        else for (uint64_t p = a[l]; p < b[l]; ++p) if (plausible(c, p, 3)) { g = p; break; }
+        else {
+            // SCAN positions per step from dwords held in registers: the integer fields of a header that have a range (block
+            // size, reference ids, sequence length, positions >= -1) reject nearly every position without touching memory
+            // again; the survivors of a step are a bit mask per lane and get the full three-records-deep test one per loop
+            // trip, every lane its own — so the wave's trip count is the LARGEST number of survivors a lane has to try, not
+            // the number of positions at which ANY lane has one (the per-position form ran the deep test ~50 times per
+            // step for the wave: 0.42 ms per 200 MB batch, ten times the record walk itself).
+            for (uint64_t p = a[l]; p < b[l] && g == NONE; p += SCAN) {
+                uint32_t d[SCAN / 4 + 9];
+#pragma unroll
+                for (int j = 0; j < SCAN / 4 + 9; ++j) d[j] = p + 4 * j + 4 <= c.avail + 32 ? rd32(c.buf + p + 4 * j) : 0u;   // (buffers carry >= 64 bytes of slack)
+                const uint32_t lim = b[l] - p < (uint64_t)SCAN ? (uint32_t)(b[l] - p) : (uint32_t)SCAN;
+                uint64_t cand = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < (uint32_t)SCAN; ++k) {
+                    const uint32_t sh = (k & 3) * 8, j = k >> 2;
+                    auto fld = [&](uint32_t q) { return sh ? (d[j + q] >> sh) | (d[j + q + 1] << (32 - sh)) : d[j + q]; };   // dword at byte p + k + 4 q
+                    const bool ok = fld(0) - 34u <= (1u << 27) - 34u              // block size
+                                    && fld(1) + 1u <= (uint32_t)c.n_ref           // refID in -1 .. n_ref - 1
+                                    && (int32_t)fld(2) >= -1                      // pos
+                                    && (fld(3) & 0xffu) != 0u                     // l_read_name >= 1
+                                    && fld(5) <= (1u << 27)                       // l_seq
+                                    && fld(6) + 1u <= (uint32_t)c.n_ref           // next refID
+                                    && (int32_t)fld(7) >= -1;                     // next pos
+                    cand |= (uint64_t)(ok && k < lim) << k;
+                }
+                while (cand != 0 && g == NONE) {
+                    const uint32_t k = (uint32_t)ctz64(cand);
+                    cand &= cand - 1;
+                    if (plausible(c, p + k, 3)) g = p + k;
+                }
+            }
+        }
         s[l] = g; need[l] = 1; e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = nfar[l] = 0;
     });
     for (int round = 0; round < 70; ++round) {
