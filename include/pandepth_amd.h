@@ -300,6 +300,9 @@ typedef struct pd_decode_cfg {
     const int32_t *spans;           /* ... pairs (begin0, end), sorted, disjoint (PD:419-434); NULL: every read          */
     int32_t sorted;                 /* the file is coordinate sorted (first runs form a position-sorted stream)          */
     uint64_t bytes_hint;            /* about how many compressed bytes will be submitted (sizes the run arena; 0 = unknown) */
+    uint64_t batch_bytes;           /* largest pd_decode_acquire the caller will make and how many batches it will have in  */
+    uint32_t batches_in_flight, pad;/* flight (0 = unknown): pd_decode_begin then pins that many buffers up front, from ONE  */
+                                    /* thread — six threads pinning at once took 75-100 ms each, alone 4-5 ms              */
 } pd_decode_cfg;
 typedef struct pd_decode_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks, flags, pad; } pd_decode_unit;
 typedef struct pd_decode_batch {

@@ -366,6 +366,9 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 {
     if (!out || n_contigs <= 0 || !contig_len) return fail(nullptr, PD_EINVAL, "pd_create: bad arguments");
     *out = nullptr;
+    const bool tm_on = getenv("PANDEPTH_TIMING") != nullptr;
+    const auto tm_t0 = std::chrono::steady_clock::now();
+    auto tm_mark = [&](const char *what) { if (tm_on) fprintf(stderr, "[timing]   pd_create: %-28s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tm_t0).count()); };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, PD_ENODEV, "pd_create: no HIP device visible (this engine has no CPU fallback)");
@@ -375,6 +378,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     if (!strstr(pr.gcnArchName, "gfx950"))
         return fail(nullptr, PD_ENODEV, std::string("pd_create: device is ") + pr.gcnArchName + ", kernels are built for gfx950 only");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PD_ENODEV, "pd_create: hipSetDevice failed");
+    tm_mark("runtime up, device chosen");
 
     pd_ctx *c = new pd_ctx;
     c->device = device;
@@ -400,7 +404,9 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 
     CREATE_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    tm_mark("streams");
     CREATE_OK(hipMalloc(&c->buf, c->n_words * 4));
+    tm_mark("cell buffer");
     c->sums = c->buf + c->n_cells;
     CREATE_OK(hipMalloc(&c->carry, (c->n_tiles + 4) * 4));
     CREATE_OK(hipMalloc(&c->bsum, (c->n_tiles / 1024 + 4) * 4));
@@ -426,8 +432,10 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
         CREATE_OK(hipMemcpy(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice));
     }
 #undef CREATE_OK
+    tm_mark("other buffers + tables");
     int rc = do_reset(c);
     if (rc == PD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PD_EHIP;
+    tm_mark("first reset (kernels loaded)");
     if (rc != PD_OK) { g_create_err = c->err; pd_destroy(c); return rc; }
     *out = c;
     return PD_OK;
@@ -863,9 +871,12 @@ int dec_fail(pd_ctx *c, int code, const std::string &msg) { std::lock_guard<std:
 
 #define HIPDEC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return dec_fail(c, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
+std::mutex g_alloc_mu;                   // pinned / device allocations of the decode slots, one at a time
+
 int dec_ensure(pd_ctx *c, pd_ctx::DecSlot &sl, int k, size_t bytes)
 {
     if (bytes <= sl.cap[k]) return PD_OK;
+    std::lock_guard<std::mutex> al(g_alloc_mu);
     if (sl.d[k]) { HIPDEC(hipStreamSynchronize(sl.st)); HIPDEC(hipFree(sl.d[k])); sl.d[k] = nullptr; sl.cap[k] = 0; }
     const size_t want = bytes + bytes / 8 + 4096;
     if (hipMalloc(&sl.d[k], want) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode buffer allocation failed");
@@ -909,6 +920,17 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
     }
     c->arena_used = 0;
+    if (cfg->batch_bytes && cfg->batches_in_flight) {
+        DecTimer ta(1);
+        const size_t want = std::max<size_t>((size_t)cfg->batch_bytes + 128, (size_t)8 << 20);
+        uint32_t k = 0;
+        for (auto &sl : c->dec) {
+            if (k++ >= cfg->batches_in_flight) break;
+            if (sl.h_cap >= want) continue;
+            if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
+            if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+        }
+    }
     c->dec_open = true;
     return PD_OK;
 }
@@ -923,11 +945,14 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     { DecTimer tw(0); c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; }); }
     sl->busy = true;
     lk.unlock();
+    { DecTimer tsd(7); if (hipSetDevice(c->device) != hipSuccess) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); } }
     DecTimer ta(1);
-    if (hipSetDevice(c->device) != hipSuccess) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); }
+    if (false) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); }
     if (bytes + 64 > sl->h_cap) {
         if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
         const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20);
+        // one allocation at a time: six feeders pinning their first buffers at once took 75-100 ms EACH (4-5 ms alone)
+        std::lock_guard<std::mutex> al(g_alloc_mu);
         if (hipHostMalloc((void **)&sl->h_blob, want, hipHostMallocDefault) != hipSuccess) {
             { std::lock_guard<std::mutex> l2(c->dec_mu); sl->busy = false; }
             c->dec_cv.notify_one();
@@ -987,7 +1012,10 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         (rc = dec_ensure(c, sl, DS_BLK, (size_t)bt->n_blocks * sizeof(pd_bgzf_block))) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
         (rc = dec_ensure(c, sl, DS_SEG, (size_t)n_seg * sizeof(pdb2::Seg))) || (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
         (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16))) return rc;
-    if (!sl.d_tok && hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
+    if (!sl.d_tok) {
+        std::lock_guard<std::mutex> al(g_alloc_mu);
+        if (hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
+    }
     lap(2);                                                               // device buffers
     hipStream_t st = sl.st;
     uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF];
@@ -1122,8 +1150,8 @@ int pd_decode_end(pd_ctx *c)
     const bool sorted = c->dec_cfg.sorted != 0;
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
-                        "host chain check %.3f, run arrays %.3f, wait emit %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u)\n", g_dec_us[0] / 1e6,
-                g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, segs.size(),
+                        "host chain check %.3f, run arrays %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u)\n", g_dec_us[0] / 1e6,
+                g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, g_dec_us[7] / 1e6, segs.size(),
                 (unsigned long long)nf, (unsigned long long)no, (unsigned long long)nfar, span);
     int rc = PD_OK;
     // disorder of a stream = how far its runs may trail the sorted order: the near stream by near_span (when the split is on,

@@ -372,6 +372,14 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         if (sflat.empty()) sflat.push_back(0);
         cfg.span_off = soff.data(); cfg.spans = sflat.data();
     }
+    int feeders = std::min<int>(std::max(1, o.threads), 6);
+    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
+    if ((size_t)feeders > batches.size()) feeders = (int)batches.size();
+    {   // the largest batch the feeders will ask a buffer for
+        uint64_t mx = 0;
+        for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + SPARE); t += b - a; } mx = std::max(mx, t); }
+        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
+    }
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
     const size_t n_batches = batches.size();
@@ -515,9 +523,6 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         }
         ::close(fd);
     };
-    int feeders = std::min<int>(std::max(1, o.threads), 6);
-    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
-    if ((size_t)feeders > n_batches) feeders = (int)n_batches;
     {
         std::vector<std::thread> th;
         for (int i = 1; i < feeders; ++i) th.emplace_back(feeder);
