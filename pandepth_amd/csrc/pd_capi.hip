@@ -342,6 +342,7 @@ int stage_submit(pd_ctx *c, int slot, size_t n, unsigned flags)
 {
     Stage &s = c->stage[slot];
     if (n == 0) { s.state = 0; return PD_OK; }
+    if (!c->copy_stream) HIPOK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPOK(c, hipMemcpyAsync(s.dev, s.host, n * sizeof(pd_iv), hipMemcpyHostToDevice, c->copy_stream));
     HIPOK(c, hipEventRecord(s.copied, c->copy_stream));
     HIPOK(c, hipStreamWaitEvent(c->stream, s.copied, 0));
@@ -403,7 +404,8 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
         pd_destroy(c); return fail(nullptr, e_ == hipErrorOutOfMemory ? PD_ENOMEM : PD_EHIP, m_); } } while (0)
 
     CREATE_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // (the copy stream of the host staging path is made by its first user: a queue costs ~15 ms, and the device-decode path
+    // of the executable never stages runs from the host)
     tm_mark("streams");
     CREATE_OK(hipMalloc(&c->buf, c->n_words * 4));
     tm_mark("cell buffer");
@@ -1278,7 +1280,7 @@ int pd_accumulate_from(pd_ctx *dst, pd_ctx *src)
         rc = ensure_all_valid(src);
         if (rc) { dst->err = src->err; return rc; }
     }
-    HIPOK(src, hipStreamSynchronize(src->copy_stream));
+    if (src->copy_stream) HIPOK(src, hipStreamSynchronize(src->copy_stream));
     HIPOK(src, hipStreamSynchronize(src->stream));
     HIPOK(dst, hipSetDevice(dst->device));
     rc = flush_pending(dst);
@@ -1500,7 +1502,7 @@ int pd_synchronize(pd_ctx *c)
     const bool keep_deferred = c->direct_windows && c->pristine && !c->pend.empty() && c->state == 0;
     int rc = keep_deferred ? PD_OK : flush_pending(c);
     if (rc) return rc;
-    HIPOK(c, hipStreamSynchronize(c->copy_stream));
+    if (c->copy_stream) HIPOK(c, hipStreamSynchronize(c->copy_stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return PD_OK;
 }
