@@ -132,7 +132,7 @@ def e2e_leg(records):
                    "; generated in %.0f s)" % t_gen,
             "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache",
             "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads,
-                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_tiles; host only reads the file"},
+                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_wide3; host only reads the file"},
             "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
                                      "path": "PANDEPTH_DEVICE_DECODE=0: libdeflate on the host threads + pd_push_intervals"},
             "cpu_quota": quota, "host_cpus": os.cpu_count(),
