@@ -178,6 +178,11 @@ def config_leg(args, which, eng, pda, synth, torch, dist, first, other, lens, ra
         regs = np.array(rl, dtype=np.int32)
         region_bases = int((regs[:, 2] - regs[:, 1] + 1).sum())
 
+    win_out = None
+    if which == "w100a":
+        nw = int(eng.window_layout(100)[-1])
+        win_out = (np.zeros(nw, dtype=np.uint32), np.zeros(nw, dtype=np.uint64))
+
     def step():
         eng.reset()
         eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
@@ -186,7 +191,7 @@ def config_leg(args, which, eng, pda, synth, torch, dist, first, other, lens, ra
             eng.scan(0)                                          # indexed single BAM: uint32 cells (PD:676-786)
             return eng.reduce_intervals(regs, 1)
         eng.scan(18)                                             # -a: SiteInfo cells (PD:4127)
-        return eng.reduce_windows(100, 1)
+        return eng.reduce_windows(100, 1, out=win_out)           # 3.0e7 windows into the caller's arrays, as the executable does
 
     def barrier():
         if use_dist:

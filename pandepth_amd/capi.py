@@ -262,11 +262,17 @@ class Engine:
         self._ck(self.L.pd_scan_reduce_windows(self.h, int(w), int(min_dep), int(wrap_bits), _ptr(cover), _ptr(tot)))
         return off, cover[:n], tot[:n]
 
-    def reduce_windows(self, w, min_dep=1):
+    def reduce_windows(self, w, min_dep=1, out=None):
+        """out = (cover uint32 array, sum uint64 array) of at least pd_window_layout(w)[-1] entries to receive the results (a caller
+        with millions of windows keeps its arrays: fresh pages cost more than the copy)."""
         off = self.window_layout(w)
         n = int(off[-1])
-        cover = np.zeros(max(n, 1), dtype=np.uint32)
-        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        if out is not None:
+            cover, tot = out
+            assert cover.dtype == np.uint32 and tot.dtype == np.uint64 and cover.size >= n and tot.size >= n
+        else:
+            cover = np.zeros(max(n, 1), dtype=np.uint32)
+            tot = np.zeros(max(n, 1), dtype=np.uint64)
         self._ck(self.L.pd_reduce_windows(self.h, int(w), int(min_dep), _ptr(cover), _ptr(tot)))
         return off, cover[:n], tot[:n]
 

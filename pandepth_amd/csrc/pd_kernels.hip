@@ -690,10 +690,10 @@ __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readl
 //   * tiles that are not at a contig's first cell and lie entirely inside it skip the clamps of run begin / end — they cannot
 //     change which cells of the tile a run touches; owner / open / carry counts are ballots accumulated in scalar registers.
 //   * the tail chunk of a candidate range issues its loads together, as before, and skips the empty load slots.
-template <int UN, int WPE>
+template <int UN, int WPE, bool EXPORT>
 __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
-                                                        uint32_t *heavy_list, uint32_t *heavy_count)
+                                                        uint32_t *heavy_list, uint32_t *heavy_count, const DirectExport ex)
 {
     const uint32_t w = args.w, min_dep = args.min_dep; TilePart *const part = args.part;
     constexpr uint32_t ST = TILE, HT = TILE / 2;                 // cells per tile, per half-tile (= words of the window)
@@ -827,6 +827,48 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         }
         if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
         __syncthreads();
+        if constexpr (EXPORT) {                                   // the multi-GPU sum's 4-bit image (pd_export_i4)
+            // k_export_i4's layout: one ushort per 4 cells (nibble d + 8), 128 contiguous bytes per wave store; the low
+            // half-tile's cells sit in the low 16 bits of the window's words, the high half-tile's in the high 16 bits
+            unsigned short *o_lo = ex.img + a / 4 + (uint64_t)(wv * (ROWS * 64) + lane), *o_hi = o_lo + HT / 4;
+            int tsum = 0;                                         // packed: sum over the lane's words
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
+                const unsigned wq[4] = {q.x, q.y, q.z, q.w};
+                unsigned wl = 0, wh = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tsum += (int)wq[k];
+                    int xl = (int)(short)(wq[k] & 0xffffu), xh = ((int)wq[k] - xl) >> 16;
+                    const uint64_t cell = a + (uint64_t)(wv * (ROWS * 256) + r * 256 + lane * 4 + k);
+                    if (xl > 7 || xl < -8) {
+                        const uint32_t slot = atomicAdd(ex.count, 1u);
+                        if (slot < ex.cap) { ex.exc[slot].cell = cell; ex.exc[slot].value = xl; ex.exc[slot].pad = 0; }
+                        xl = 0;
+                    }
+                    if (xh > 7 || xh < -8) {
+                        const uint32_t slot = atomicAdd(ex.count, 1u);
+                        if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
+                        xh = 0;
+                    }
+                    wl |= (unsigned)((xl + 8) & 0xf) << (4 * k);
+                    wh |= (unsigned)((xh + 8) & 0xf) << (4 * k);
+                }
+                o_lo[r * 64] = (unsigned short)wl;
+                o_hi[r * 64] = (unsigned short)wh;
+            }
+            tsum = wave_total(tsum);                              // packed 65536 * H + L over the wave (|H|, |L| <= 32 000)
+            if (lane == 0) wtot[wv] = tsum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+                const int tl2 = (int)(short)(tp & 0xffff);
+                ex.sums[t] = tl2 + ((tp - tl2) >> 16);
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- prefix sum of the packed window: both half-tiles at once ----
         int4 v[ROWS];
 #pragma unroll
@@ -1835,7 +1877,7 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
         hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
                            wrap_mask, dn, n_long, heavy_list, heavy_count);
     else if (un == 0 || un >= 3000) {        // second form (k_direct_wide3): 3000 + 100 x waves-per-SIMD target + loads in flight per thread
-#define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count)
+#define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_, false>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
         // measured on the bench sample (ms; variants that were tried and are no longer compiled included): <2, 6> 3.08-3.13,
         // <4, 5> 3.10-3.28, <3, 5> 3.2, <2, 7> 3.3, <2, 5> 3.4, <4, 4> 3.6-3.8, <1, 8> 3.6, <2, 8> 4.1 (spills), <4, 6> 3.5
         // (spills); first form 3.52-3.69.  Grids of 16 K .. 262 K workgroups: within 2 %.
@@ -1863,8 +1905,10 @@ void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, cons
                           uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
 {
     const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
-    hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectExport>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
-                       0xFFFFFFFFu, de, n_long, heavy_list, heavy_count);
+    // the second form of the direct kernel with its export branch (the first form's export instantiation — 128 VGPRs and
+    // 160 bytes of spills — took 5.2 ms per sample)
+    hipLaunchKernelGGL((k_direct_wide3<2, 5, true>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+                       DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
     // tiles with more than 32 000 candidates: the int-window kernel exports them
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa,
