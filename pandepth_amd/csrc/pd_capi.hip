@@ -69,6 +69,7 @@ struct pd_ctx {
     bool direct_windows = false;                                  // pd_scan_reduce_windows may consume deferred batches in place
     bool pristine = true;                                         // nothing materialised in the arrays since the last reset
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
+    uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
     int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
     bool all_valid_host = false;
     std::vector<Pending> pend;
@@ -511,6 +512,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "accumulate_packed")) { c->accumulate_packed = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_windows")) { c->direct_windows = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
+    if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
@@ -671,7 +673,7 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
         ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
         ProfScope sc(c, "scatter_index");
         // a 4x sparser index than the arrays path's: measured neutral for the tile kernel, 0.43 -> 0.13 ms of index
-        launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample < 256 ? 256 : c->sample, c->ub_a[b],
+        launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->direct_sample, c->ub_a[b],
                              c->cand_lo[b], n_stiles, PD_TILE, c->desc + b);
     }
     unsigned grid = c->grid_tiles;

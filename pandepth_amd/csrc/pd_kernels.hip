@@ -690,6 +690,12 @@ __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readl
 //   * tiles that are not at a contig's first cell and lie entirely inside it skip the clamps of run begin / end — they cannot
 //     change which cells of the tile a run touches; owner / open / carry counts are ballots accumulated in scalar registers.
 //   * the tail chunk of a candidate range issues its loads together, as before, and skips the empty load slots.
+#ifdef PD_WIDE3_TICKS                     /* development build only (tools/ubench/wide3_ticks.sh): shader-clock cycles per phase of a tile, summed over waves */
+__device__ unsigned long long g_wide3_ticks[16];
+#define W3_TICK(k) do { const long long now_ = (long long)clock64(); tk[k] += now_ - t_prev; t_prev = now_; } while (0)
+#else
+#define W3_TICK(k) do { } while (0)
+#endif
 template <int UN, int WPE, bool EXPORT>
 __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
@@ -728,6 +734,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
     };
     uint32_t nlo = 0, nhi = 0;
     if (threadIdx.x < PD_MAXPEND) bounds(blockIdx.x, nlo, nhi);
+#ifdef PD_WIDE3_TICKS
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (long long)clock64();
+#endif
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t a = t * ST;
         if (threadIdx.x < PD_MAXPEND) { s_lo[threadIdx.x] = nlo; s_hi[threadIdx.x] = nhi; }
@@ -737,7 +746,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         const int32_t ctg = (int32_t)tile_contig[t];
         const uint32_t clen = tab.len[ctg];
         const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);         // tile start inside the contig (slots are < 2^32 cells)
+        W3_TICK(0);                                               // bounds to LDS, window zeroed
         __syncthreads();
+        W3_TICK(1);                                               // barrier 1
         if (threadIdx.x < PD_MAXPEND) bounds(t + gridDim.x, nlo, nhi);
         uint32_t cand = 0;
         for (int b = 0; b < ps.nb; ++b) cand += s_hi[b] - s_lo[b];
@@ -826,7 +837,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             }
         }
         if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
+        W3_TICK(2);                                               // candidates
         __syncthreads();
+        W3_TICK(3);                                               // barrier 2
         if constexpr (EXPORT) {                                   // the multi-GPU sum's 4-bit image (pd_export_i4)
             // k_export_i4's layout: one ushort per 4 cells (nibble d + 8), 128 contiguous bytes per wave store; the low
             // half-tile's cells sit in the low 16 bits of the window's words, the high half-tile's in the high 16 bits
@@ -888,7 +901,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             ex[r] = e;
         }
         if (lane == 0) wtot[wv] = run;
+        W3_TICK(4);                                               // window read + scans
         __syncthreads();
+        W3_TICK(5);                                               // barrier 3
         int basep = 0;                                            // packed: words of the waves before this one
         for (int k = 0; k < wv; ++k) basep += wtot[k];
         const int totp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
@@ -968,7 +983,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
         }
         if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+        W3_TICK(6);                                               // statistics
         __syncthreads();
+        W3_TICK(7);                                               // barrier 4
         if (threadIdx.x == 0) {
             TilePart tp;
             tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
@@ -980,6 +997,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         // (no barrier here: everything the next tile overwrites — bounds, window, carry, wave totals, partials — is last read
         // before one of the three barriers that precede the overwriting store)
     }
+#ifdef PD_WIDE3_TICKS
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_wide3_ticks[k], (unsigned long long)tk[k]);
+#endif
     // every begin and every end must have found its owner tile (k_finish_direct compares the sums over all batches)
     __shared__ unsigned s_cnt[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -1992,3 +2012,12 @@ void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces,
 }
 
 } // namespace pdk
+
+#ifdef PD_WIDE3_TICKS
+extern "C" int pd_x_wide3_ticks(unsigned long long *out16)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdk::g_wide3_ticks), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pdk::g_wide3_ticks), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -22,8 +22,11 @@ CASES = [(10000000, 1, 0), (10000000, 1, 18), (10000000, 3, 0), (8192, 1, 0), (2
 ref = {}
 variants = [x for x in os.environ.get("VARIANTS", "0").split(",")]
 for vs in variants:
-    v = int(vs.split("@")[0])
+    v = int(vs.split("@")[0].split("/")[0])
     eng.set_param("grid_tiles", int(vs.split("@")[1]) if "@" in vs else 0)
+    opts = vs.split("/")[1:]                                  # /s64 = direct_sample 64, /l160 = lmax 160
+    eng.set_param("direct_sample", next((int(o[1:]) for o in opts if o[0] == "s"), 256))
+    eng.set_param("lmax", next((int(o[1:]) for o in opts if o[0] == "l"), 512))
     eng.set_param("direct_un", v)
     ok = True
     for c in CASES:
@@ -47,4 +50,4 @@ for vs in variants:
     ms, n = eng.profile_get("direct_tiles")
     ims, inn = eng.profile_get("scatter_index")
     eng.profile(False)
-    print("variant %5d grid %s: direct_tiles %.3f ms/launch (%d), index %.3f ms/step, step wall %.3f ms, tables %s" % (v, vs.split("@")[1] if "@" in vs else "auto", ms / max(n, 1), n, ims / N, dt, "equal" if ok else "DIFFERENT"), flush=True)
+    print("variant %5d %s grid %s: direct_tiles %.3f ms/launch (%d), index %.3f ms/step, step wall %.3f ms, tables %s" % (v, "/".join(opts), vs.split("@")[1] if "@" in vs else "auto", ms / max(n, 1), n, ims / N, dt, "equal" if ok else "DIFFERENT"), flush=True)
