@@ -222,7 +222,7 @@ int pd_gather_windows(pd_ctx *ctx, const void *dev_partials, uint32_t w, uint32_
  * stream: pd_export_i4 -> grouped ncclSend / ncclRecv of the 1/n slices between all pairs (messages of <= 256 MiB) ->
  * ncclAllReduce of the int32 tile sums + ncclAllGather of the exception blocks -> pd_slice_sweep_i4 on the rank's slice ->
  * 24 B per tile to `root` -> pd_gather_windows there.  Windows of w >= 8192 cells (whole-chromosome mode, PD:2704-3014 + PD:3978). */
-typedef struct pd_comm pd_comm;
+typedef struct pd_comm pd_comm;          /* belongs to its context: pd_comm_destroy before pd_destroy */
 #define PD_UNIQUE_ID_BYTES 128
 int pd_comm_unique_id(void *id128);
 int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm **out);
