@@ -331,6 +331,7 @@ def test_int8_transport_of_difference_arrays(world):
             i8 = torch.empty(n_cells, dtype=torch.uint8, device=dev)
             exc = torch.zeros((4096, 2), dtype=torch.int64, device=dev)
             cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                                  # the engine writes these on ITS stream: torch's fills must be done
             e.export_i8(thr, i8.data_ptr(), exc.data_ptr(), 4096, cnt.data_ptr())
             e.synchronize()
             k = int(cnt.item())
@@ -432,6 +433,7 @@ def test_sliced_sum_kernels_manual_exchange(world, w, min_dep):
             send = torch.zeros(world * sb, dtype=torch.uint8, device=dev)
             exc = torch.zeros((B, 2), dtype=torch.int64, device=dev)
             cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                                  # the engine writes these on ITS stream: torch's fills must be done
             e.export_i4(send.data_ptr(), exc.data_ptr(), B, cnt.data_ptr())
             e.synchronize()
             assert 0 <= int(cnt.item()) <= B
