@@ -67,8 +67,9 @@ BIN = 10000000                 # whole-chromosome mode's synthetic bins (PD:3978
 
 # algorithmic bytes per unit (SURVEY.md §8d / DESIGN.md §4)
 B_FILL_PER_CELL = 4
-B_SCATTER_PER_RUN = 12         # owner-tile scatter: every run read once ...
-B_SCATTER_PER_CELL = 4         # ... and every cell of the difference arrays written once (after pd_reset half-tiles are stored, not read)
+B_SCATTER_PER_RUN = 28         # 12 B run + 2 x (4 B read + 4 B write) — the contract's algorithmic figure for the scatter
+B_SCATTER_ONCE_PER_RUN = 12    # what the owner-tile kernel must move at least: every run read once ...
+B_SCATTER_ONCE_PER_CELL = 4    # ... and every cell of the difference arrays written once (after pd_reset half-tiles are stored, not read)
 B_SWEEP_FUSED_PER_BASE = 4
 B_RUN = 12                     # one packed (tid, beg, end) run
 
@@ -235,11 +236,15 @@ def config_leg(args, which, eng, pda, synth, torch, dist, first, other, lens, ra
                 "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg)}
     lt = max(1, prof["scatter_tiles"][1] // args.steps)
     kernels = {
-        # every run read once (12 B), every cell of the arrays written once (4 B)
-        "scatter_tiles": ent("scatter_tiles", (n_runs * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / lt),
+        # SURVEY §8(d)'s 28 B per run; "store_once" beside it: runs read once + every cell written once (what the kernel must move)
+        "scatter_tiles": ent("scatter_tiles", n_runs * B_SCATTER_PER_RUN / lt),
         # write-back prefix sum: every cell read and written once
         "scan": ent("scan", 8 * n_cells),
     }
+    if kernels["scatter_tiles"]:
+        once = (n_runs * B_SCATTER_ONCE_PER_RUN + n_cells * B_SCATTER_ONCE_PER_CELL) / lt
+        kernels["scatter_tiles"]["store_once_bytes"] = int(once)
+        kernels["scatter_tiles"]["store_once_frac"] = round(once / (kernels["scatter_tiles"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if which == "gff":
         kernels["reduce_intervals"] = ent("reduce_intervals", 4 * region_bases + 24 * len(regs))
     else:
@@ -490,7 +495,7 @@ def main():
         def entries(prof, steps):
             launches_tiles = max(1, prof["scatter_tiles"][1] // steps)
             return {
-                "scatter_tiles": k_entry2(prof, "scatter_tiles", ((n_first + n_other + n_far) * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / launches_tiles),
+                "scatter_tiles": k_entry2(prof, "scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
                 "scan_reduce_windows": k_entry2(prof, "scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE)}
 
         def k_entry2(pr, name, alg):
@@ -513,7 +518,7 @@ def main():
             # on-demand zero fill of never-written half-tiles (multi-GPU reduce only): bytes depend on the sample
             "fill": ({"avg_ms": round(prof["fill"][0] / prof["fill"][1], 4), "launches": prof["fill"][1]}
                      if prof["fill"][1] else None),
-            "scatter_tiles": k_entry("scatter_tiles", ((n_first + n_other + n_far) * B_SCATTER_PER_RUN + n_cells * B_SCATTER_PER_CELL) / launches_tiles),
+            "scatter_tiles": k_entry("scatter_tiles", (n_first + n_other + n_far) * B_SCATTER_PER_RUN / launches_tiles),
             "scan_reduce_windows": k_entry("scan_reduce_windows", G * B_SWEEP_FUSED_PER_BASE),
             "export_i8": k_entry("export_i8", 5 * (n_words - (n_words - G) % 1)),     # 4 B read + 1 B written per cell
             "import_i8": k_entry("import_i8", 5 * (n_words - (n_words - G) % 1)),     # 1 B read + 4 B written per cell
