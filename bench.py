@@ -13,13 +13,14 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   N = 1 (default, "direct_windows"): ONE pass over the runs — each tile's
                                   difference window is built in LDS (+1/-1 scatter), its carry-in counted
                                   from the same candidate runs, prefix-summed and reduced on the spot; the
-                                  difference arrays never reach HBM (k_direct_tiles).
+                                  difference arrays never reach HBM (k_direct_wide3).
                                   PD_BENCH_PATH=arrays (and always for N > 1): the general path — owner-tile
                                   scatter into the int32 difference arrays in HBM (k_scatter_tiles), then the
                                   prefix-sum sweep fused with the bin reduction (k_sweep).  A few steps of it
                                   are also run after the timed region: their kernel figures are reported under
                                   "arrays_path" and their results must equal the direct path's.
-    [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pandepth_amd.multi.SlicedSum):
+    [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pd_comm_init + pd_sliced_sum_start / _finish:
+                                  RCCL issued inside the library; PD_BENCH_SUM=sliced_torch: pandepth_amd.multi.SlicedSum):
                                   4-bit image (pd_export_i4; packed straight from the tile windows in LDS, the arrays
                                   are not written on any rank), all-to-all over RCCL so that every xGMI link of a
                                   GPU carries 1/N of it at once, every rank sums + sweeps its 1/N of the tiles

@@ -253,10 +253,11 @@ int pd_synchronize(pd_ctx *ctx);
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 
-/* ---- GPU-side BAM decode: replaces htslib's BGZF inflate + bam_read1 on the host
+/* ---- GPU-side BAM decode, the one-call synchronous form (round 1's entry point, kept on top of
+ * the pd_decode_* path below): replaces htslib's BGZF inflate + bam_read1 on the host
  * (the producer side of PD:434) for whole-contig modes.  The caller hands over raw BGZF bytes of
  * record-aligned file ranges ("units", e.g. cut at index offsets); the device inflates every block
- * (one lane per block), walks the records of every unit, filters (flag & flag_mask, mapq <
+ * (one wave per block), walks the records of every unit, filters (flag & flag_mask, mapq <
  * min_mapq, contigs shorter than 2) and scatters the M/=/X runs exactly as pd_push_intervals would.
  *   blob            n_bytes of BGZF data (whole blocks, any order)
  *   blocks[k]       deflate payload [in_off, in_off+in_len) of block k inside blob, and where its
@@ -266,8 +267,7 @@ int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches
  *                   must be given in file order (the first-run array is then position sorted).
  *   unit_status[u]  OUT: 0 = counted on the device; 1 = not counted, decode this unit on the host
  *                   (a record runs past `avail`, or a CIGAR lives in the CG tag); 2 = corrupt data
- * Synchronous: returns when the batch has been scattered.  Experimental: opt-in from the CLI with
- * PANDEPTH_DEVICE_DECODE=1. */
+ * Synchronous: returns when the batch has been scattered.  The executable uses pd_decode_* (below). */
 typedef struct pd_bgzf_block { uint64_t in_off, out_off; uint32_t in_len, out_len; } pd_bgzf_block;
 typedef struct pd_bgzf_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks; } pd_bgzf_unit;
 int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
