@@ -546,11 +546,26 @@ def main():
             traffic = None
         # `traffic` is a live PMC measurement or null; this run is not under a profiler, so the committed figure is
         # reported beside it with its source, never as if it had been measured here
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command (profiles/): an
+        # independent clock on the launch; bench.py itself never runs under a profiler
+        rocprof_avg = None
+        try:
+            import csv
+            import glob
+            kf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
+            want = {"direct_tiles": "k_direct_wide3<", "scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
+                    "direct_export": "k_direct_wide3<"}.get(dom)
+            for row in csv.DictReader(open(kf)):
+                if want and want in row["Name"]:
+                    rocprof_avg = {"avg_launch_ms": round(float(row["AverageNs"]) / 1e6, 4), "calls": int(row["Calls"]), "source": "profiles/" + os.path.basename(kf)}
+                    break
+        except (OSError, IndexError, KeyError, ValueError):
+            rocprof_avg = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kd["frac"], "traffic": None,
                     "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)}
                                              if traffic else None),
-                    "avg_launch_ms": kd["avg_ms"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
+                    "avg_launch_ms": kd["avg_ms"], "avg_launch_ms_rocprof": rocprof_avg, "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
         cb, e2e = None, None
         if world == 1 and args.e2e_records > 0:
             try:
