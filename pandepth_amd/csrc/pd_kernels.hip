@@ -1909,10 +1909,8 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
 #undef PD_DIRECT3
     }
     else switch (un) {                       // tuning knob "direct_un": loads in flight per thread + 100 x waves-per-SIMD target
-    case 404: PD_DIRECT(4, 4); break;   // (measured on the bench sample: 504 3.4-3.6 ms, 508 3.3-3.6, 404 3.7, 408 3.7)
-    case 408: PD_DIRECT(8, 4); break;
-    case 508: PD_DIRECT(8, 5); break;
-    default: PD_DIRECT(4, 5); break;         // 504 (or any other value below 3000): the first form
+    default: PD_DIRECT(4, 5); break;         // 504 (or any other value below 3000): the first form, kept as the cross-check of the second
+                                             // (measured on the bench sample, ms: <4, 5> 3.5-3.7; its other variants <8, 5> 3.3-3.6, <4, 4> 3.7, <8, 4> 3.7 are no longer compiled)
     }
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,

@@ -725,3 +725,32 @@ def test_format_sites_equals_host_formatting(wrap):
         e.push_intervals(iv)
         with pytest.raises(pda.PdError):
             e.format_sites(0, 0, 10, "x")                       # before pd_scan: the cells are not depths yet
+
+
+@pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (10000000, 0, 0), (16384, 1, 18)])
+def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
+    """Both forms of the wide-window direct kernel (k_direct_wide3, the default; k_direct_tiles<.., DirectWide>, "direct_un" 504)
+    against the oracle on a sample with everything a tile can meet: a pile-up of 40 000 runs in one tile (> 32 000 candidates: the
+    int-window kernel takes that tile), runs that start before cell 0 or end past their contig (clamps: the first and last tiles
+    of a contig are not "interior"), empty runs (they still have an owner), runs ending exactly on tile edges, a contig of one tile
+    and one of a single cell."""
+    rng = np.random.default_rng(4100 + w % 89)
+    first, other = _split_streams(rng, LENS, 60000)
+    L0 = int(LENS[0])
+    hard = np.array([[0, -5, 40], [0, -1, 1], [0, 0, 0], [0, 8192, 8192], [0, 8000, 8192], [0, 8192, 16384], [0, L0 - 10, L0 + 7], [0, L0 - 1, L0],
+                     [0, L0, L0 + 3], [1, -3, 5000], [1, 100, 100]], dtype=np.int32)
+    pile = np.tile(np.array([[0, 300000, 300100]], dtype=np.int32), (40000, 1))
+    first = sort_iv(np.concatenate([first, hard, pile]))
+    d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
+    cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        for form in (0, 504, 3504, 3404):
+            e.set_param("direct_un", form)
+            e.reset()
+            e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+            woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+            assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref), form
+            with pytest.raises(pda.PdError, match="direct"):
+                e.scan(wrap)                                      # consumed by the direct path, whichever form
