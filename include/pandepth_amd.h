@@ -316,6 +316,13 @@ typedef struct pd_decode_result {
     uint64_t n_reads, n_first, n_other;    /* records seen in the units that were counted; first runs; other runs       */
     uint64_t first_start, next_start;      /* unit 0: first record it owns / first record start >= its stop (~0: none)   */
     double ms_h2d, ms_inflate, ms_walk, ms_emit;
+    /* order of the batch's first runs (key = tid << 32 | begin; file order): unsorted = 1 when a key is smaller than the one
+     * before it; first_key / last_key for the check across batches (valid when n_first > 0).  A file whose header says
+     * SO:coordinate but whose records are not in that order must not go on as a sorted stream: the caller abandons the
+     * device pass (pd_decode_abort) and reads such a file the way the reference does; pd_decode_end, for its part, pushes
+     * the first runs as PD_PUSH_DEFAULT when it sees a violation. */
+    uint64_t first_key, last_key;
+    uint32_t unsorted, pad;
 } pd_decode_result;
 int pd_decode_begin(pd_ctx *ctx, const pd_decode_cfg *cfg);
 int pd_decode_acquire(pd_ctx *ctx, size_t bytes, void **host_buf);

@@ -107,10 +107,12 @@ template <class F> PW_FN int32_t walk_cigar(const Rec &x, F emit)
     for (uint32_t i = 0; i < x.n_cig; ++i) {
         const uint32_t cg = rd32(x.cig + 4 * i), op = cg & 0xf;
         const int32_t len = (int32_t)(cg >> 4);
+        // (the reference's int cursor wraps on corrupt lengths; here the wrap is spelled out in unsigned arithmetic)
+        const int32_t nxt = (int32_t)((uint32_t)cur + (uint32_t)len);
         if (op == 0 || op == 7 || op == 8) {
-            emit(!first_done && !moved, cur, cur + len);
-            first_done = true; cur += len;
-        } else if (op == 2 || op == 3) { cur += len; moved = true; }
+            emit(!first_done && !moved, cur, nxt);
+            first_done = true; cur = nxt;
+        } else if (op == 2 || op == 3) { cur = nxt; moved = true; }
     }
     return cur;
 }
@@ -151,7 +153,7 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
                 uint32_t nf = 0, no = 0, nfar = 0, span = 0;
                 walk_cigar(x, [&](bool is_first, int32_t beg, int32_t end) {
                     if (is_first) { if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end}; nf = 1; return; }
-                    const uint32_t d = (uint32_t)(beg - x.pos);
+                    const uint32_t d = (uint32_t)beg - (uint32_t)x.pos;
                     if (d > span) span = d;
                     if (d <= c.near_span) { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; }
                     else { if (EMIT) far[ofar + w.n_far + nfar] = pd_iv{x.tid, beg, end}; ++nfar; }

@@ -73,9 +73,28 @@ __global__ __launch_bounds__(64) void k_emit_segments(const pdb2::Cfg cfg, const
     pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other, far);
 }
 
+// are the first runs of a batch in (tid, begin) order?  out[0] = 1 if not; out[2..3] / out[4..5] = first / last key
+__global__ __launch_bounds__(256) void k_runs_sorted(const pd_iv *runs, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = ((uint64_t)(uint32_t)runs[i].tid << 32) | (uint32_t)runs[i].beg;
+    if (i > 0) {
+        const uint64_t kp = ((uint64_t)(uint32_t)runs[i - 1].tid << 32) | (uint32_t)runs[i - 1].beg;
+        if (k < kp) out[0] = 1;
+    } else { out[2] = (uint32_t)k; out[3] = (uint32_t)(k >> 32); }
+    if (i + 1 == n) { out[4] = (uint32_t)k; out[5] = (uint32_t)(k >> 32); }
+}
+
 } // namespace
 
 namespace pdk {
+
+void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t *out)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_runs_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, runs, n, out);
+}
 
 // the wave-cooperative decoder: n_wg persistent one-wave workgroups; `scratch` = bgzf_wave_scratch_bytes(n_wg) bytes
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,

@@ -82,7 +82,7 @@ struct pd_ctx {
         void *d[7] = {}; size_t cap[7] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list
         void *d_tok = nullptr;                                    // wave scratch (match tokens)
     };
-    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; };
+    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; uint32_t unsorted; uint64_t first_key, last_key; };
     static constexpr int N_DEC = 6;
     uint8_t *arena = nullptr; size_t arena_cap = 0; std::atomic<size_t> arena_used{0};   // the batches' run arrays (bump allocated)
     DecSlot dec[N_DEC];
@@ -1080,7 +1080,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         res->first_start = fs; res->next_start = E ? E : ~0ull;
     }
     // ---- pass 2: the runs ----
-    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, nullptr, nfar, max_span};
+    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, nullptr, nfar, max_span, 0u, 0ull, 0ull};
     lap(4);                                                               // host: chain check, unit outcomes
     if (nf + no + nfar) {
         auto grab = [&](uint64_t n, pd_iv **out) -> bool {
@@ -1096,9 +1096,20 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         lap(5);                                                           // run array allocation
         launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far);
     }
+    // are the first runs in (tid, begin) order, as the header's SO:coordinate promises?  (DS_ONLY is free again: 6 words)
+    uint32_t order_words[6] = {0, 0, 0, 0, 0, 0};
+    if (nf) {
+        HIPDEC(hipMemsetAsync(sl.d[DS_ONLY], 0, 24, st));
+        launch_runs_sorted(st, rs.first, nf, (uint32_t *)sl.d[DS_ONLY]);
+        HIPDEC(hipMemcpyAsync(order_words, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
+    }
     HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    rs.unsorted = order_words[0];
+    rs.first_key = (uint64_t)order_words[2] | ((uint64_t)order_words[3] << 32);
+    rs.last_key = (uint64_t)order_words[4] | ((uint64_t)order_words[5] << 32);
+    if (res) { res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key; }
     lap(6);                                                               // pass 2 (waiting)
     if (res) {
         float ms = 0;
@@ -1151,7 +1162,15 @@ int pd_decode_end(pd_ctx *c)
     // coordinate-sorted file: exact tile bounds), its later runs that begin within NEAR_SPAN bases of its start (they trail
     // the sorted order by at most that), and the few that follow a long gap (N operations: they trail by up to `span`).
     // An unsorted file, or gaps of more than a few tiles, take the atomic path.
-    const bool sorted = c->dec_cfg.sorted != 0;
+    bool sorted = c->dec_cfg.sorted != 0;
+    if (sorted) {                                        // ... and only if the records really are in that order (the header may lie)
+        uint64_t prev = 0; bool have = false;
+        for (auto &r : segs) {
+            if (!r.n_first) continue;
+            if (r.unsorted || (have && r.first_key < prev)) { sorted = false; break; }
+            prev = r.last_key; have = true;
+        }
+    }
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
                         "host chain check %.3f, run arrays %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u)\n", g_dec_us[0] / 1e6,

@@ -121,5 +121,6 @@ void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs,
                           const uint32_t *only, uint32_t n_only);
 void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
                           pd_iv *first, pd_iv *other, pd_iv *far);
+void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t *out);
 }
 #endif

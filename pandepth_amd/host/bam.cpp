@@ -29,13 +29,13 @@ int32_t AlnRec::endpos() const
     if (!(flag & 4) && n_cigar > 0) {
         for (uint32_t i = 0; i < n_cigar; ++i) {
             const uint32_t op = cigar[i] & 0xf;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(cigar[i] >> 4);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen = (int32_t)((uint32_t)rlen + (cigar[i] >> 4));   // wraps like the reference's int on corrupt lengths, without UB
         }
     } else {
         rlen = 1;
     }
     if (rlen == 0) rlen = 1;
-    return pos + rlen;
+    return (int32_t)((uint32_t)pos + (uint32_t)rlen);
 }
 
 bool AlnReader::open(const std::string &path, std::string *err)

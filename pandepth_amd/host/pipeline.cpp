@@ -122,8 +122,9 @@ inline void emit_runs(const AlnRec &r, RunSink *sink)
     for (uint32_t i = 0; i < r.n_cigar; ++i) {
         const uint32_t op = r.cigar[i] & 0xf;
         const int32_t len = (int32_t)(r.cigar[i] >> 4);
-        if (op == 0 || op == 7 || op == 8) { sink->emit(r.tid, cur, cur + len); cur += len; }
-        else if (op == 2 || op == 3) cur += len;
+        const int32_t nxt = (int32_t)((uint32_t)cur + (uint32_t)len);      // the int cursor's wrap on corrupt lengths, spelled out
+        if (op == 0 || op == 7 || op == 8) { sink->emit(r.tid, cur, nxt); cur = nxt; }
+        else if (op == 2 || op == 3) cur = nxt;
     }
 }
 
@@ -387,6 +388,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_submit{0};
     std::atomic<int> declined{0};
     std::vector<uint64_t> chain_first(n_batches, UINT64_MAX), chain_next(n_batches, UINT64_MAX);   // no-index: virtual offsets
+    std::vector<uint64_t> key_first(n_batches, 0), key_last(n_batches, 0);                         // order of the first runs across batches
+    std::vector<uint8_t> key_have(n_batches, 0);
+    std::atomic<int> order_broken{0};
     double ms_sum[4] = {0, 0, 0, 0}; std::mutex ms_mu;
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -491,6 +495,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             us_submit += now_us() - t_b;
             if (!ok) break;
             n_dev += res.n_reads;
+            if (res.n_first) { key_first[bi] = res.first_key; key_last[bi] = res.last_key; key_have[bi] = 1; if (res.unsorted) order_broken = 1; }
             { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
             auto voff_of = [&](uint64_t u) -> uint64_t {      // inflated offset of the batch -> virtual file offset
                 if (u == UINT64_MAX) return UINT64_MAX;
@@ -533,6 +538,17 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         // the record chain across the batches (virtual offsets; the end of a member equals the start of the next one)
         for (size_t k = 0; k + 1 < n_batches; ++k)
             if (chain_next[k] != chain_first[k + 1] || chain_next[k] >= UINT64_MAX - 1) { declined = 1; break; }
+    }
+    if (sorted && eng->ok() && !declined.load()) {
+        // the header said SO:coordinate; a file whose records are not in that order is read on the host, the reference's way
+        // (its no-index cursor, PD:4604-4671, depends on the order the records come in)
+        uint64_t prev = 0; bool have = false;
+        for (size_t k = 0; k < n_batches && !order_broken.load(); ++k) {
+            if (!key_have[k]) continue;
+            if (have && key_first[k] < prev) order_broken = 1;
+            prev = key_last[k]; have = true;
+        }
+        if (order_broken.load()) declined = 1;
     }
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders, %llu records on the device, %llu units handed back (%llu records on the host)%s; "

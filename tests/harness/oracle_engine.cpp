@@ -238,6 +238,11 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     for (size_t j = 0; j < segs.size(); ++j)
         if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data());
     r.first.resize(nf); r.other.resize(no); r.far.resize(nfar);
+    if (res && nf) {                                             // order of the first runs, as pd_decode_submit reports it
+        auto key = [](const pd_iv &v) { return ((uint64_t)(uint32_t)v.tid << 32) | (uint32_t)v.beg; };
+        res->first_key = key(r.first[0]); res->last_key = key(r.first[nf - 1]); res->unsorted = 0;
+        for (uint64_t i = 1; i < nf; ++i) if (key(r.first[i]) < key(r.first[i - 1])) { res->unsorted = 1; break; }
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     c->runs.push_back(std::move(r));
     return 0;

@@ -35,6 +35,12 @@ def data(tmp_path_factory):
     bam = str(d / "g.bam")
     synth.write_bam(bam, names, lens, rec, flags=flags, mapq=mapq, procs=2, payload=True)
     subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
+    # a file whose header says SO:coordinate although two blocks of records have changed places (two sorted files
+    # concatenated look like this): no index can exist for it; the reference reads it with its no-index cursor, whose
+    # result depends on the order the records come in — the device decoder must notice and leave the file to the host reader
+    idx = np.arange(n)
+    idx[40000:43000], idx[200000:203000] = idx[200000:203000].copy(), idx[40000:43000].copy()
+    synth.write_bam(str(d / "l.bam"), names, lens, {k: v[idx] for k, v in rec.items()}, flags=flags[idx], mapq=mapq[idx], procs=1, payload=True)
     # annotation: 300 transcripts of 1-5 CDS, plus a BED of 400 regions
     g, b = ["##gff-version 3"], []
     for t in range(300):
@@ -63,6 +69,8 @@ CASES = [
     ("bed", ["-i", "g.bam", "-b", "g.bed", "-d", "3"], "bed.stat.gz"),
     ("noindex", ["-i", "g.bam", "-s"], "chr.stat.gz"),
     ("noindex_gff", ["-i", "g.bam", "-s", "-g", "g.gff"], "gene.stat.gz"),
+    ("header_lies", ["-i", "l.bam"], "chr.stat.gz"),
+    ("header_lies_w", ["-i", "l.bam", "-w", "5000", "-q", "20"], "win.stat.gz"),
 ]
 
 
