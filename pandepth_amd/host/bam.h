@@ -44,7 +44,7 @@ public:
     uint64_t tell() const { return bg_.tell(); }       // BAM only: virtual offset of the next record
     bool seek(uint64_t voff) { return bg_.seek(voff); }
     void set_threads(int n) { if (is_cram_) cram_.set_threads(n); else bg_.set_threads(n); }    // sequential streams: parallel inflate read-ahead
-    const std::string &error() const { return err_; }
+    const std::string &error() const { static const std::string generic = "corrupt BGZF/BAM data"; return err_.empty() ? generic : err_; }
 private:
     bool read_bam_header();
     bool read_sam_header();
