@@ -21,7 +21,7 @@ BIG = False         # fuzz_vs_ref.py <seed> <cases> big: contigs of 11-32 Mb, re
                     # of the reference's indexed window walk (PD:676-786)
 
 
-def gen_sam(rng, sorted_hdr):
+def gen_sam(rng, sorted_hdr, lie=False):
     ncontig = rng.randrange(1, 5)
     lens = [rng.choice([1, 2, 37, 101, 201, 500, 1001, 2500, 10001]) for _ in range(ncontig)]
     if BIG:
@@ -72,6 +72,12 @@ def gen_sam(rng, sorted_hdr):
         reads.append((t, pos, "r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s" % (i, flag, names[t], pos, mapq, cigar, seq, "I" * qlen if qlen else "*")))
     if sorted_hdr:
         reads.sort(key=lambda r: (r[0], r[1]))
+        if lie and len(reads) > 8:
+            # the header keeps saying SO:coordinate, but two blocks of records change places (what concatenating two sorted
+            # files gives): only possible without an index; the reference reads such a file with its no-index cursor
+            a = rng.randrange(0, len(reads) // 2); b = rng.randrange(len(reads) // 2, len(reads) - 1)
+            k = rng.randrange(1, min(len(reads) // 2 - a, len(reads) - b, 40) + 1)
+            reads[a:a + k], reads[b:b + k] = reads[b:b + k], reads[a:a + k]
     else:
         rng.shuffle(reads)
     if rng.random() < 0.3:
@@ -275,14 +281,15 @@ S2B = os.path.join(ROOT, "oracle", "_ref", "sam2bam")
 
 def one_case(rng, td):
     sorted_hdr = rng.random() < 0.75
-    sam, names, lens = gen_sam(rng, sorted_hdr)
+    lie = sorted_hdr and rng.random() < 0.2
+    sam, names, lens = gen_sam(rng, sorted_hdr, lie)
     open(os.path.join(td, "x.sam"), "w").write(sam)
     args = ["-i", "x.sam"]
     form = rng.choice(["sam", "bam+bai", "bam+bai", "bam", "list", "cram", "cram+crai"])
     if form.startswith("cram") and os.access(S2B, os.X_OK):
         # CRAM 3.0 written reference-free by the reference's own htslib; with a .crai next to it the reference takes its
         # indexed path
-        indexed = form == "cram+crai" and sorted_hdr
+        indexed = form == "cram+crai" and sorted_hdr and not lie
         r = subprocess.run([S2B, "x.sam", "x.cram"] + ([] if indexed else ["noindex"]) + ([rng.choice(["fmt=cram,version=3.1", "fmt=cram,version=3.1", "fmt=cram,version=2.1"])] if rng.random() < 0.5 else [])
                            + (["sps=%d" % rng.choice([3, 50])] if rng.random() < 0.3 and not indexed else []), cwd=td, capture_output=True)
         # (tiny slices only without a .crai: htslib's slice lookup, cram_index_query, walks back only while the PREVIOUS slice
@@ -292,7 +299,7 @@ def one_case(rng, td):
         if r.returncode == 0:
             args = ["-i", "x.cram"]
     elif form.startswith("bam") and os.access(S2B, os.X_OK):
-        indexed = form == "bam+bai" and sorted_hdr
+        indexed = form == "bam+bai" and sorted_hdr and not lie
         r = subprocess.run([S2B, "x.sam", "x.bam"] + ([] if indexed else ["noindex"]), cwd=td, capture_output=True)
         if r.returncode == 0:
             args = ["-i", "x.bam"]
