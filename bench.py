@@ -151,6 +151,9 @@ def e2e_leg(records):
                   "sample": "%d records of the configs[1] workload with payload (%.2f GB BAM, %.0f B/record compressed), BAM+BAI, warm "
                             "cache; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads) on a cgroup quota of %d CPUs, "
                             "%.2f s wall" % (records, size / 1e9, size / records, rthreads, quota, w_ref)}
+        if cb is None:
+            cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
+                  "sample": "oracle/_ref/pandepth_ref is not built on this box (oracle/Makefile needs /root/reference): the reference was not timed"}
         return e2e, cb
     finally:
         import shutil
@@ -566,7 +569,8 @@ def main():
                     "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)}
                                              if traffic else None),
                     "avg_launch_ms": kd["avg_ms"], "avg_launch_ms_rocprof": rocprof_avg, "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
-        cb, e2e = None, None
+        cb, e2e = {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
+                   "sample": "not timed: the end-to-end leg runs on rank 0 of a 1-GPU invocation with --e2e-records > 0"}, None
         if world == 1 and args.e2e_records > 0:
             try:
                 eng.close()                                        # the CLI makes its own context on this GPU
