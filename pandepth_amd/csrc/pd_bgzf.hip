@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const 
     for (uint32_t i = blockIdx.x; i < n_blk; i += gridDim.x) {
         const BlkDesc d = blk[i];
         int rc = 0;
-        if (d.out_len) rc = pdw::inflate_block<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
+        // inflate + the CRC-32 of the output against the member's trailer (an empty member still has one: 0)
+        rc = pdw::inflate_member<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
         if (threadIdx.x == 0) status[i] = rc;
         __syncthreads();
     }

@@ -715,6 +715,69 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     return o == out_len ? 0 : -5;
 }
 
+// ---- CRC-32 of a member's inflated bytes (RFC 1952; htslib checks it for every BGZF block it reads, so a flipped bit that
+// still inflates must not go unnoticed here either).  One wave, lane l takes bytes [1024 l, 1024 (l + 1)): the register
+// update is linear over GF(2) — R(s, data) = R(s, zeros) ^ R(0, data), and running over n zero bytes is the multiplication
+// by x^(8n) modulo the CRC polynomial — so every lane runs its KiB from a zero register through a 256-entry table, shifts its
+// result past the bytes behind it with that multiplication, and the wave XORs the 64 results with the shifted start value.
+static const uint32_t CRC_POLY = 0xEDB88320u;                            // reflected: bit 31 is the coefficient of x^0
+PW_FN uint32_t crc_mul(uint32_t a, uint32_t b)                            // a(x) b(x) mod P(x)
+{
+    uint32_t p = 0;
+    for (int k = 0; k < 32; ++k) {
+        p ^= b & (0u - ((a >> (31 - k)) & 1u));
+        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
+    }
+    return p;
+}
+PW_FN uint32_t crc_shift(uint32_t v, uint32_t n_bytes)                    // v(x) x^(8 n) mod P(x), n < 2^17
+{
+    uint32_t e = 0x80000000u, p = 0x00800000u;                             // x^0, x^8
+    for (int j = 0; j < 17; ++j) {
+        if ((n_bytes >> j) & 1u) e = crc_mul(e, p);
+        p = crc_mul(p, p);
+    }
+    return crc_mul(e, v);
+}
+template <class W>
+PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 256 words of LDS */)
+{
+    typedef typename W::template Var<uint32_t> U;
+    W::each([&](int l) {
+        for (int k = 0; k < 4; ++k) {
+            uint32_t c = (uint32_t)(l * 4 + k);
+            for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1u)));
+            tab[l * 4 + k] = c;
+        }
+    });
+    W::sync();
+    U part;
+    W::each([&](int l) {
+        const uint32_t a = (uint32_t)l * 1024u;
+        const uint32_t b = a + 1024u < n ? a + 1024u : n;
+        uint32_t r = 0;
+        for (uint32_t i = a; i < b; ++i) r = tab[(r ^ data[i]) & 0xffu] ^ (r >> 8);
+        part[l] = a < n ? crc_shift(r, n - b) : 0u;
+    });
+    const uint32_t body = W::reduce_xor(part);
+    W::sync();                                                            // (the table's LDS is the caller's again)
+    return body ^ crc_shift(0xFFFFFFFFu, n) ^ 0xFFFFFFFFu;
+}
+
+// A whole BGZF member: inflate, then the CRC-32 of the output against the member's trailer (the 4 bytes behind the payload).
+// Returns 0, PD_W_HOST, a negative inflate error, or -20: the bytes inflate but are not the bytes that were compressed.
+template <class W>
+PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st)
+{
+    if (out_len) {                                                        // (an empty member — the EOF marker — has nothing to inflate)
+        const int rc = inflate_block<W>(in, in_len, out, out_len, T, tok, st);
+        if (rc) return rc;
+    }
+    W::fence();
+    uint32_t want; __builtin_memcpy(&want, in + in_len, 4);
+    return crc32_wave<W>(out, out_len, T.ll) == want ? 0 : -20;
+}
+
 // ---- the two wave implementations -------------------------------------------------------------------------------
 struct HostWave {                         // 64 emulated lanes
     template <class T> struct Var { T v[64]; T &operator[](int l) { return v[l]; } const T &operator[](int l) const { return v[l]; } };
@@ -732,6 +795,7 @@ struct HostWave {                         // 64 emulated lanes
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
     static Var<uint64_t> excl_scan_max64(const Var<uint64_t> &x) { Var<uint64_t> r; uint64_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; if (x.v[l] > a) a = x.v[l]; } return r; }
     static uint32_t reduce_or(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) a |= x.v[l]; return a; }
+    static uint32_t reduce_xor(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) a ^= x.v[l]; return a; }
     static uint32_t reduce_max(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
     static uint64_t reduce_max64(const Var<uint64_t> &x) { uint64_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
     static uint64_t reduce_min64(const Var<uint64_t> &x) { uint64_t a = ~0ull; for (int l = 0; l < 64; ++l) if (x.v[l] < a) a = x.v[l]; return a; }
@@ -801,6 +865,13 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         uint32_t m = x.v;
 #pragma unroll
         for (int o = 32; o; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o);
+        return m;
+    }
+    __device__ static __forceinline__ uint32_t reduce_xor(const Var<uint32_t> &x)
+    {
+        uint32_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m ^= (uint32_t)__shfl_xor((int)m, o);
         return m;
     }
     __device__ static __forceinline__ uint32_t reduce_max(const Var<uint32_t> &x)

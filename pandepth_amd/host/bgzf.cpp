@@ -15,6 +15,8 @@ namespace {
 typedef void *(*ld_alloc_t)(void);
 typedef int (*ld_decomp_t)(void *, const void *, size_t, void *, size_t, size_t *);
 typedef void (*ld_free_t)(void *);
+typedef uint32_t (*ld_crc32_t)(uint32_t, const void *, size_t);
+ld_crc32_t g_ld_crc32 = nullptr;
 ld_alloc_t g_ld_alloc = nullptr;
 ld_decomp_t g_ld_decomp = nullptr;
 ld_free_t g_ld_free = nullptr;
@@ -29,6 +31,7 @@ void load_libdeflate()
         g_ld_alloc = (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor");
         g_ld_decomp = (ld_decomp_t)dlsym(h, "libdeflate_deflate_decompress");
         g_ld_free = (ld_free_t)dlsym(h, "libdeflate_free_decompressor");
+        g_ld_crc32 = (ld_crc32_t)dlsym(h, "libdeflate_crc32");
         if (g_ld_alloc && g_ld_decomp && g_ld_free) return;
         g_ld_alloc = nullptr; g_ld_decomp = nullptr; g_ld_free = nullptr;
     }
@@ -73,6 +76,17 @@ bool Inflater::inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_
     zs->next_out = out; zs->avail_out = (uInt)out_len;
     const int r = inflate(zs, Z_FINISH);
     return r == Z_STREAM_END && zs->avail_out == 0;
+}
+
+// a whole BGZF member: the payload must inflate to exactly out_len bytes AND those bytes must have the CRC-32 stored behind
+// the payload (RFC 1952; htslib's bgzf_read_block checks it too: a flipped bit that still inflates is a corrupt block)
+bool Inflater::inflate_member(const uint8_t *payload, size_t in_len, uint8_t *out, size_t out_len)
+{
+    if (!inflate_raw(payload, in_len, out, out_len)) return false;
+    const uint8_t *t = payload + in_len;
+    const uint32_t want = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t got = g_ld_crc32 ? g_ld_crc32(0, out, out_len) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)out_len);
+    return got == want;
 }
 
 uint32_t bgzf_block_size(const uint8_t *p, size_t avail, uint32_t *data_off)
@@ -186,7 +200,7 @@ struct BgzfReader::Pipe {
                 j->state = 2; ++next_inflate;
             }
             for (const Blk &b : j->blks)
-                if (b.usize && !inf.inflate_raw(j->comp.data() + b.coff + b.doff, b.csize - b.doff - 8, j->out.data() + b.uoff, b.usize))
+                if (!inf.inflate_member(j->comp.data() + b.coff + b.doff, b.csize - b.doff - 8, j->out.data() + b.uoff, b.usize))
                     j->bad = true;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -301,7 +315,7 @@ bool BgzfReader::load_block()
         if (isize == 0) continue;                               // empty block (e.g. the EOF marker)
         if (isize > ubuf_.size()) { ubuf_.resize(isize); }
         udata_ = ubuf_.data();
-        if (!inf_.inflate_raw(p + doff, bs - doff - 8, ubuf_.data(), isize)) {
+        if (!inf_.inflate_member(p + doff, bs - doff - 8, ubuf_.data(), isize)) {
             err_ = "corrupt BGZF block (inflate failed)"; at_eof_ = true; return false;
         }
         ulen_ = isize;

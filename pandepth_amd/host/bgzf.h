@@ -19,6 +19,7 @@ public:
     ~Inflater();
     // inflates exactly out_len bytes; returns false on corrupt data
     bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
+    bool inflate_member(const uint8_t *payload, size_t in_len, uint8_t *out, size_t out_len);     // + the CRC-32 behind the payload
     static const char *backend();
 private:
     void *ld_ = nullptr;      // libdeflate decompressor

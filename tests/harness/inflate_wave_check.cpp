@@ -97,6 +97,16 @@ static int generated()
             run(d, "records");
         }
     }
+    // the wave CRC-32 against zlib's, every length class (empty, partial first KiB, exact KiBs, the 64 KiB maximum)
+    for (size_t len : {0ul, 1ul, 2ul, 1023ul, 1024ul, 1025ul, 2048ul, 4097ul, 30000ul, 65535ul, 65536ul})
+        for (int rep = 0; rep < 3; ++rep) {
+            std::vector<unsigned char> d(len + 8);
+            for (auto &x : d) x = rep == 0 ? 0 : rep == 1 ? 0xff : (unsigned char)rng();
+            const uint32_t mine = pdw::crc32_wave<pdw::HostWave>(d.data(), (uint32_t)len, g_T.ll);
+            const uint32_t ref = (uint32_t)crc32(crc32(0L, Z_NULL, 0), d.data(), (uInt)len);
+            if (mine != ref) { fprintf(stderr, "crc32_wave: length %zu fill %d: %08x, zlib %08x\n", len, rep, mine, ref); ++bad; }
+            ++n;
+        }
     printf("generated: %d streams, %d failures\n", n, bad);
     return bad;
 }
@@ -131,6 +141,17 @@ int main(int argc, char **argv)
             const unsigned isize = p[bsize - 4] | (p[bsize - 3] << 8) | (p[bsize - 2] << 16) | ((unsigned)p[bsize - 1] << 24);
             char what[256]; snprintf(what, sizeof what, "%s: block at %zu (csize %u, isize %u)", path, o, bsize, isize);
             if (check_stream(p + doff, bsize - doff - 8, isize, what, true)) ++bad;
+            {   // the whole member with its CRC-32; one flipped output-affecting bit in the trailer must be noticed
+                std::vector<unsigned char> mem(p + doff, p + bsize); mem.resize(mem.size() + 16, 0);
+                std::vector<unsigned char> o2(isize + 9);
+                int r = pdw::inflate_member<pdw::HostWave>(mem.data(), bsize - doff - 8, o2.data(), isize, g_T, g_tok, nullptr);
+                if (r != 0 && r != pdw::PD_W_HOST) { fprintf(stderr, "%s: inflate_member rc %d\n", what, r); ++bad; }
+                if (r == 0) {
+                    mem[bsize - doff - 8] ^= 0x10;             // the stored CRC
+                    r = pdw::inflate_member<pdw::HostWave>(mem.data(), bsize - doff - 8, o2.data(), isize, g_T, g_tok, nullptr);
+                    if (r != -20) { fprintf(stderr, "%s: a wrong CRC-32 went unnoticed (rc %d)\n", what, r); ++bad; }
+                }
+            }
             for (int k = 0; k < fuzz; ++k) {
                 std::vector<unsigned char> c(p + doff, p + bsize - 8);
                 const int flips = 1 + (int)(rng() % 3);

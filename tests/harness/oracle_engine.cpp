@@ -189,7 +189,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     static thread_local std::vector<pdw::Token> tok(65536 / 3 + 64);
     for (uint32_t b = 0; b < bt->n_blocks; ++b) {
         const pd_bgzf_block &d = bt->blocks[b];
-        if (d.out_len) bst[b] = pdw::inflate_block<pdw::HostWave>(blob + d.in_off, d.in_len, inf.data() + d.out_off, d.out_len, T, tok.data(), nullptr);
+        bst[b] = pdw::inflate_member<pdw::HostWave>(blob + d.in_off, d.in_len, inf.data() + d.out_off, d.out_len, T, tok.data(), nullptr);
     }
     pdb2::Cfg cfg;
     cfg.buf = inf.data(); cfg.avail = bt->inflated_bytes; cfg.n_ref = (int32_t)c->len.size(); cfg.contig_len = c->len.data(); cfg.contig_on = c->on.data();
