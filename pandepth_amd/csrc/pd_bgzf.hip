@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
 // (members of a BAM are alike, so a static split balances); Huffman tables in LDS (9 KiB per wave), match tokens in a
 // per-workgroup slice of global scratch.
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
-                                                     pdw::Token *tok_scratch)
+                                                     pdw::Token *tok_scratch, int check_crc)
 {
     __shared__ pdw::Tables T;
     pdw::Token *tok = tok_scratch + (size_t)blockIdx.x * PD_WAVE_TOKENS;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const 
         const BlkDesc d = blk[i];
         int rc = 0;
         // inflate + the CRC-32 of the output against the member's trailer (an empty member still has one: 0)
-        rc = pdw::inflate_member<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr);
+        rc = pdw::inflate_member<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr, check_crc != 0);
         if (threadIdx.x == 0) status[i] = rc;
         __syncthreads();
     }
@@ -99,11 +99,11 @@ void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t 
 
 // the wave-cooperative decoder: n_wg persistent one-wave workgroups; `scratch` = bgzf_wave_scratch_bytes(n_wg) bytes
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg)
+                              int *status, void *scratch, unsigned n_wg, bool check_crc)
 {
     if (!n_blk) return;
     if (n_wg > n_blk) n_wg = n_blk;
-    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch);
+    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch, check_crc ? 1 : 0);
 }
 size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token) + 64; }
 
@@ -162,8 +162,10 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
     const uint32_t nb = (uint32_t)blks.size();
     int rc = PD_OK;
     hipEvent_t e0, e1;
-    // variant >= 2: the wave-cooperative decoder with (variant >> 4, default 16) persistent waves per CU
+    // variant >= 2: the wave-cooperative decoder with ((variant >> 4) & 0xff, default 16) persistent waves per CU; + 0x8000: without the CRC-32 check
     unsigned n_wg = 0;
+    const bool no_crc = (variant & 0x8000) != 0;
+    variant &= 0x7fff;
     if (variant >= 2) {
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, device) != hipSuccess) return PD_ENODEV;
@@ -181,7 +183,7 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
         for (int r = 0; r < reps + 1; ++r) {
             if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
             const dim3 g((nb + 63) / 64), b(64);
-            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg);
+            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg, !no_crc);
             else if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
             else hipLaunchKernelGGL(k_inflate_blocks<false>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
         }

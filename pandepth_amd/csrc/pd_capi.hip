@@ -69,6 +69,7 @@ struct pd_ctx {
     bool direct_windows = false;                                  // pd_scan_reduce_windows may consume deferred batches in place
     bool pristine = true;                                         // nothing materialised in the arrays since the last reset
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
+    bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
     uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
     int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
     bool all_valid_host = false;
@@ -513,6 +514,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_windows")) { c->direct_windows = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
@@ -1035,7 +1037,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     HIPDEC(hipMemcpyAsync(sl.d[DS_BLK], bt->blocks, (size_t)bt->n_blocks * sizeof(pd_bgzf_block), hipMemcpyHostToDevice, st));
     HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
     HIPDEC(hipEventRecord(sl.ev[1], st));
-    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg);
+    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc);
     HIPDEC(hipEventRecord(sl.ev[2], st));
     launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, 0);
     std::vector<int> bst(bt->n_blocks);

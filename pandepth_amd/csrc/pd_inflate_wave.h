@@ -755,8 +755,20 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 256 
     W::each([&](int l) {
         const uint32_t a = (uint32_t)l * 1024u;
         const uint32_t b = a + 1024u < n ? a + 1024u : n;
-        uint32_t r = 0;
-        for (uint32_t i = a; i < b; ++i) r = tab[(r ^ data[i]) & 0xffu] ^ (r >> 8);
+        uint32_t r = 0, i = a;
+        // 16 bytes per load (a byte per load made every step a cache miss: 64 lanes x 16 waves stream 1 000 different lines)
+        for (; i + 16 <= b; i += 16) {
+            uint32_t w[4]; __builtin_memcpy(w, data + i, 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = w[k];
+                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
+                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
+                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
+                r = tab[(r ^ x) & 0xffu] ^ (r >> 8);
+            }
+        }
+        for (; i < b; ++i) r = tab[(r ^ data[i]) & 0xffu] ^ (r >> 8);
         part[l] = a < n ? crc_shift(r, n - b) : 0u;
     });
     const uint32_t body = W::reduce_xor(part);
@@ -767,12 +779,13 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 256 
 // A whole BGZF member: inflate, then the CRC-32 of the output against the member's trailer (the 4 bytes behind the payload).
 // Returns 0, PD_W_HOST, a negative inflate error, or -20: the bytes inflate but are not the bytes that were compressed.
 template <class W>
-PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st)
+PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st, bool check_crc = true)
 {
     if (out_len) {                                                        // (an empty member — the EOF marker — has nothing to inflate)
         const int rc = inflate_block<W>(in, in_len, out, out_len, T, tok, st);
         if (rc) return rc;
     }
+    if (!check_crc) return 0;
     W::fence();
     uint32_t want; __builtin_memcpy(&want, in + in_len, 4);
     return crc32_wave<W>(out, out_len, T.ll) == want ? 0 : -20;

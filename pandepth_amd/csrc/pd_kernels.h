@@ -103,7 +103,7 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_bloc
                          int *status, void *scratch);
 size_t bgzf_scratch_bytes(uint32_t n_blk);
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg);
+                              int *status, void *scratch, unsigned n_wg, bool check_crc);
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 } // namespace pdk
 

@@ -22,7 +22,8 @@ synth.write_bam(bam, names, lens, rec, procs=16, payload=True, level=int(os.envi
 data = open(bam, "rb").read()
 print("records %d, BGZF %.1f MB" % (R, len(data) / 1e6), flush=True)
 VARIANTS = [(1, "lane per block, tables in global memory")] + [
-    (2 + (w << 4), "wave per block, %d waves/CU" % w) for w in (8, 12, 14, 16, 20)]
+    (2 + (w << 4), "wave per block, %d waves/CU" % w) for w in (8, 12, 14, 16, 20)] + [
+    (2 + (16 << 4) + 0x8000, "wave per block, 16 waves/CU, CRC-32 check off")]
 if os.environ.get("BGZF_VARIANTS"):
     keep = set(int(x) for x in os.environ["BGZF_VARIANTS"].split(","))
     VARIANTS = [v for v in VARIANTS if v[0] in keep]
