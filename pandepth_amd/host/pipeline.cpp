@@ -456,6 +456,11 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                     blocks.push_back(pd_bgzf_block{pos + p + doff, uo, bs - doff - 8, isize});
                     uo += isize; p += bs;
                 }
+                {   // the member scan must have covered what this unit owns: stopping earlier means a member header that is not one
+                    // (or a file that ends inside a member) — the host reader goes through such a file and says what is wrong
+                    const uint64_t need = guess ? own_end : (rs[k].vend == UINT64_MAX ? F : std::min(F, rs[k].vend >> 16));
+                    if (a + p < need) { declined = 1; bad = true; break; }
+                }
                 if (blocks.size() == b0) { if (guess) { continue; } eng->fail("index offsets of " + path + " do not match its BGZF blocks"); bad = true; break; }
                 pd_decode_unit un{};
                 un.first_block = (uint32_t)b0; un.n_blocks = (uint32_t)(blocks.size() - b0);
