@@ -288,8 +288,9 @@ int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_b
  * as pd_push_intervals_device(.., PD_PUSH_SORTED | PD_PUSH_MORE) would: the statistics calls then take the direct
  * path (pd_set_param "direct_windows") or materialise the arrays.  Units the device does not finish are handed back:
  *   unit_status[u] 0 counted; 1 decode it on the host (a record runs past the unit's bytes, a CIGAR lives in the CG
- *   tag, a Huffman code this decoder leaves to zlib); 2 corrupt data (a member does not inflate); 3 the record
- *   chain could not be followed: decode the unit on the host, which reports the corruption if it is one.
+ *   tag, a Huffman code this decoder leaves to zlib); 2 a member read for the unit does not inflate or fails
+ *   its CRC-32; 3 the record chain could not be followed: in both cases decode the unit on the host, which reads only what the
+ *   unit needs and reports the corruption if it is one.
  * pd_decode_acquire / submit may be called from several threads (one batch each); submit returns when the batch's
  * runs are in HBM — batches of different threads overlap on the device. */
 #define PD_UNIT_GUESS 1u

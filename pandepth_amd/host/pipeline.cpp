@@ -518,9 +518,10 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             } else {
                 for (size_t k = 0; k < units.size(); ++k) {
                     if (status[k] == 0) continue;
-                    if (status[k] == 2) { eng->fail("corrupt BGZF data in " + path); break; }
-                    // 1: the device leaves this unit to the host; 3: it could not follow the record chain — the host reader
-                    // below goes through the same bytes and says what is wrong with them, if anything is
+                    // 1: the device leaves this unit to the host; 2: one of the members read for it does not inflate or fails its
+                    // CRC-32 — possibly one of the spare members behind the unit that no record of it needs; 3: it could not follow
+                    // the record chain.  In every case the host reader goes through exactly the bytes the unit needs and says what
+                    // is wrong with them, if anything is
                     ++n_back;
                     std::string e2;
                     if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
