@@ -364,7 +364,16 @@ def main():
     if sum_mode == "sliced":
         ids = [pda.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        sliced = pda.Comm(eng, ids[0], rank, world)
+        try:
+            sliced = pda.Comm(eng, ids[0], rank, world)
+        except pda.PdError as e:               # say why and let every rank take the torch.distributed form of the same protocol
+            sys.stderr.write("[bench] rank %d: pd_comm_init failed (%s)\n" % (rank, e))
+        ok = torch.tensor([0 if sliced is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if sliced is not None:
+                sliced.close()
+            sliced, sum_mode = multi.SlicedSum(eng, dev), "sliced_torch"
     elif sum_mode == "sliced_torch":
         sliced = multi.SlicedSum(eng, dev)
     packed = multi.PackedSum(eng, dev) if sum_mode == "int8" else None
