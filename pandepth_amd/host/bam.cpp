@@ -483,7 +483,7 @@ void BaiIndex::normalise(std::vector<Chunk> *v)
     v->resize(w);
 }
 
-std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_parts) const
+std::vector<uint64_t> BaiIndex::record_starts() const
 {
     std::vector<uint64_t> cand;
     for (size_t r = 0; r < linear.size(); ++r) {
@@ -494,6 +494,12 @@ std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_part
     }
     std::sort(cand.begin(), cand.end());
     cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    return cand;
+}
+
+std::vector<uint64_t> BaiIndex::split(uint64_t first, uint64_t fsize, int n_parts) const
+{
+    const std::vector<uint64_t> cand = record_starts();
     std::vector<uint64_t> out;
     out.push_back(first);
     if (n_parts < 1) n_parts = 1;

@@ -82,6 +82,9 @@ struct BaiIndex {
     // record-aligned split points covering [first_record_voff, EOF): about n_parts ranges of similar
     // compressed size.  Returns the boundaries (size = parts + 1, last = UINT64_MAX).
     std::vector<uint64_t> split(uint64_t first_record_voff, uint64_t file_size, int n_parts) const;
+    // every virtual offset the index names that is the start of a record (linear-index entries, first chunk of each
+    // reference; CSI: chunk begins), sorted
+    std::vector<uint64_t> record_starts() const;
 };
 
 // Builds <bam_path>.bai for a coordinate-sorted BAM (SAM spec §5.2: binning index + 16 kb linear

@@ -329,6 +329,12 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     const uint64_t F = file_size(path);
     if (F < 28) return 0;
     const uint64_t SPARE = 5 * 65536;                        // bytes read past a unit's end so that its last record can finish
+    // An index chunk ends where its last record ends (SAM spec 5.1.3: chunk_end is the virtual offset behind it), so a unit
+    // made of chunks needs the member its end offset points into and nothing behind it; members are at most 64 KiB.  With
+    // thousands of small targets the tail is most of what is read: 5 x 64 KiB behind each of 33 688 genes is 11 GB.
+    // (An index whose chunk ends are not record ends: the last record runs past the unit's bytes, the unit goes to the host.)
+    const bool chunk_units = kind == 0 && !spans.synthetic;
+    auto spare_of = [&](uint64_t vend) -> uint64_t { return !chunk_units || vend == UINT64_MAX ? SPARE : (vend & 0xffff) ? 65536 : 0; };
     uint64_t batch_bytes = (uint64_t)32 << 20;
     if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     // ---- the work list: batches of units ----
@@ -340,13 +346,45 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             for (size_t t = 0; t < spans.per_tid.size(); ++t)
                 for (auto &sp : spans.per_tid[t]) bai->query((int32_t)t, sp.first, sp.second, &work);
             BaiIndex::normalise(&work);
+            // Chunks are disjoint in virtual offsets but neighbours share members (two exons of a gene lie in one or two
+            // members), and a unit reads the whole member its end lies in: a chunk that begins within 64 KiB of the previous
+            // one's end joins it.  The records in between meet no span (the index would have named them), and the span test drops
+            // them like it does inside a chunk.  Fewer bytes are read and inflated, never more.
+            const uint64_t unit_cap = std::max<uint64_t>(batch_bytes / 4, (uint64_t)1 << 20);
+            size_t w = 0;
+            for (size_t i = 0; i < work.size(); ++i) {
+                if (w && work[i].second != UINT64_MAX && (work[i].first >> 16) <= (work[w - 1].second >> 16) + 65536 &&
+                    (work[i].second >> 16) - (work[w - 1].first >> 16) <= unit_cap) work[w - 1].second = work[i].second;
+                else work[w++] = work[i];
+            }
+            work.resize(w);
+            // and a chunk larger than a batch (a target that is a whole chromosome) is cut at record starts the index names
+            bool big = false;
+            for (auto &c : work) if ((c.second == UINT64_MAX ? F : (c.second >> 16)) - (c.first >> 16) > batch_bytes) big = true;
+            if (big) {
+                const std::vector<uint64_t> starts = bai->record_starts();
+                std::vector<BaiIndex::Chunk> cut;
+                for (auto &c : work) {
+                    uint64_t a = c.first;
+                    const uint64_t stop = c.second;
+                    auto it = std::upper_bound(starts.begin(), starts.end(), a);
+                    while ((stop == UINT64_MAX ? F : (stop >> 16)) - (a >> 16) > batch_bytes) {
+                        it = std::lower_bound(it, starts.end(), ((a >> 16) + batch_bytes / 2) << 16);
+                        if (it == starts.end() || *it >= stop) break;
+                        cut.emplace_back(a, *it);
+                        a = *it;
+                    }
+                    cut.emplace_back(a, stop);
+                }
+                work.swap(cut);
+            }
         } else {
             const std::vector<uint64_t> cuts = bai->split(first_voff, F, (int)std::min<uint64_t>(1u << 20, F / batch_bytes + 1));
             for (size_t i = 0; i + 1 < cuts.size(); ++i) work.emplace_back(cuts[i], cuts[i + 1]);
         }
         uint64_t acc = 0;
         for (auto &c : work) {
-            const uint64_t sz = ((c.second == UINT64_MAX ? F : (c.second >> 16)) - (c.first >> 16)) + SPARE;
+            const uint64_t sz = ((c.second == UINT64_MAX ? F : (c.second >> 16)) - (c.first >> 16)) + spare_of(c.second);
             if (batches.empty() || acc + sz > batch_bytes) { batches.emplace_back(); acc = 0; }
             batches.back().push_back(DevRange{c.first, c.second});
             acc += sz;
@@ -378,7 +416,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     if ((size_t)feeders > batches.size()) feeders = (int)batches.size();
     {   // the largest batch the feeders will ask a buffer for
         uint64_t mx = 0;
-        for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + SPARE); t += b - a; } mx = std::max(mx, t); }
+        for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + spare_of(r.vend)); t += b - a; } mx = std::max(mx, t); }
         cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
     }
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
@@ -412,7 +450,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             uint64_t total = 0;
             for (auto &r : rs) {
                 uint64_t a = r.vbeg >> 16, b = r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16);
-                b = std::min(F, b + SPARE);
+                b = std::min(F, b + spare_of(r.vend));
                 if (guess && bi > 0) a = r.vbeg >> 16;       // arbitrary offset: the first member is found below
                 fr.emplace_back(a, b); total += b - a;
             }

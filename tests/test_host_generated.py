@@ -56,6 +56,11 @@ def data(tmp_path_factory):
         b.append("%s\t%d\t%d" % (names[ci], s, min(int(lens[ci]), s + int(rng.integers(1, 5000)))))
     (d / "g.gff").write_text("\n".join(g) + "\n")
     (d / "g.bed").write_text("\n".join(b) + "\n")
+    # targets that are whole chromosomes (index chunks larger than a device batch are cut at record starts the index
+    # names) next to neighbouring small ones (chunks that share BGZF members become one unit)
+    wb = ["%s\t0\t%d\tall%d" % (names[ci], lens[ci], ci) for ci in (0, 1, 2, 5)]
+    wb += ["%s\t%d\t%d\tnear%d" % (names[7], 20000 + 700 * k, 20000 + 700 * k + 300, k) for k in range(40)]
+    (d / "w.bed").write_text("\n".join(wb) + "\n")
     return d
 
 
@@ -67,6 +72,8 @@ CASES = [
     ("gff", ["-i", "g.bam", "-g", "g.gff"], "gene.stat.gz"),
     ("gff_a", ["-i", "g.bam", "-g", "g.gff", "-a"], "gene.stat.gz"),
     ("bed", ["-i", "g.bam", "-b", "g.bed", "-d", "3"], "bed.stat.gz"),
+    ("bed_whole", ["-i", "g.bam", "-b", "w.bed"], "bed.stat.gz"),
+    ("bed_whole_a", ["-i", "g.bam", "-b", "w.bed", "-a", "-q", "20"], "bed.stat.gz"),
     ("noindex", ["-i", "g.bam", "-s"], "chr.stat.gz"),
     ("noindex_gff", ["-i", "g.bam", "-s", "-g", "g.gff"], "gene.stat.gz"),
     ("header_lies", ["-i", "l.bam"], "chr.stat.gz"),
