@@ -339,6 +339,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     // ---- the work list: batches of units ----
     std::vector<std::vector<DevRange>> batches;
+    std::vector<BaiIndex::Chunk> orig;                       // region fetch: the index chunks as the host reader visits them
     const bool guess = kind != 0;
     if (!guess) {
         std::vector<BaiIndex::Chunk> work;
@@ -346,6 +347,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             for (size_t t = 0; t < spans.per_tid.size(); ++t)
                 for (auto &sp : spans.per_tid[t]) bai->query((int32_t)t, sp.first, sp.second, &work);
             BaiIndex::normalise(&work);
+            orig = work;
             // Chunks are disjoint in virtual offsets but neighbours share members (two exons of a gene lie in one or two
             // members), and a unit reads the whole member its end lies in: a chunk that begins within 64 KiB of the previous
             // one's end joins it.  The records in between meet no span (the index would have named them), and the span test drops
@@ -358,6 +360,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 else work[w++] = work[i];
             }
             work.resize(w);
+            if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing] region fetch: %zu index chunks in %zu units\n", orig.size(), work.size());
             // and a chunk larger than a batch (a target that is a whole chromosome) is cut at record starts the index names
             bool big = false;
             for (auto &c : work) if ((c.second == UINT64_MAX ? F : (c.second >> 16)) - (c.first >> 16) > batch_bytes) big = true;
@@ -564,9 +567,20 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                     std::string e2;
                     if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
                     if (!sink) sink.reset(new RunSink(eng));
-                    uint64_t nr = 0;
-                    if (!decode_range(rd, rs[k].vbeg, rs[k].vend, flt, spans, sink.get(), &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); break; }
-                    n_host += nr;
+                    // (a unit made of several chunks goes back chunk by chunk: what lies between them is not the host reader's
+                    // business, damaged or not)
+                    bool ok2 = true;
+                    auto host_range = [&](uint64_t a, uint64_t b) {
+                        uint64_t nr = 0;
+                        if (!decode_range(rd, a, b, flt, spans, sink.get(), &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); ok2 = false; }
+                        n_host += nr;
+                    };
+                    if (orig.empty()) host_range(rs[k].vbeg, rs[k].vend);
+                    else
+                        for (auto it = std::upper_bound(orig.begin(), orig.end(), rs[k].vbeg, [](uint64_t v, const BaiIndex::Chunk &c) { return v < c.second; });
+                             ok2 && it != orig.end() && it->first < rs[k].vend; ++it)
+                            host_range(std::max(it->first, rs[k].vbeg), std::min(it->second, rs[k].vend));
+                    if (!ok2) break;
                 }
             }
         }

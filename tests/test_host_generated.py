@@ -120,3 +120,111 @@ def test_generated_inputs_match_reference(data, cli, name, args, suffix):
             for s, got in mine.items():
                 assert gzip.decompress(got).decode() == exp[s], "%s differs (-t %s)" % (s, t)
             break
+
+
+def _members_and_record_starts(bam_bytes):
+    """BGZF member offsets of a BAM, and for every record (tid, pos, index of the member it starts in)"""
+    import struct
+    import zlib
+    offs, chunks, p = [], [], 0
+    while p < len(bam_bytes):
+        xlen = struct.unpack_from("<H", bam_bytes, p + 10)[0]
+        bsize = struct.unpack_from("<H", bam_bytes, p + 16)[0] + 1          # generator and fixtures: BC is the only extra field
+        offs.append(p)
+        chunks.append(zlib.decompress(bam_bytes[p + 12 + xlen:p + bsize - 8], -15))
+        p += bsize
+    starts = np.cumsum([0] + [len(c) for c in chunks])
+    data = b"".join(chunks)
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    q = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, q)[0]; q += 4
+    for _ in range(n_ref):
+        q += 4 + struct.unpack_from("<i", data, q)[0] + 4
+    recs = []
+    while q + 4 <= len(data):
+        bs = struct.unpack_from("<i", data, q)[0]
+        tid, pos = struct.unpack_from("<ii", data, q + 4)
+        recs.append((tid, pos, int(np.searchsorted(starts, q, side="right") - 1)))
+        q += 4 + bs
+    return offs, recs
+
+
+def _bai_chunks(bai_bytes, tid, beg0, end):
+    """chunks of a .bai that can hold reads overlapping [beg0, end) of reference tid (SAM spec 5.3), pruned with the linear index"""
+    import struct
+    p = 8
+    for r in range(tid + 1):
+        bins = {}
+        n_bin = struct.unpack_from("<i", bai_bytes, p)[0]; p += 4
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", bai_bytes, p); p += 8
+            bins[b] = [struct.unpack_from("<QQ", bai_bytes, p + 16 * k) for k in range(n_chunk)]
+            p += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", bai_bytes, p)[0]; p += 4
+        lin = struct.unpack_from("<%dQ" % n_intv, bai_bytes, p); p += 8 * n_intv
+    want = [0]
+    e = end - 1
+    for sh, off in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        want += range(off + (beg0 >> sh), off + (e >> sh) + 1)
+    min_off = lin[beg0 >> 14] if (beg0 >> 14) < len(lin) else 0
+    return [c for b in want for c in bins.get(b, []) if c[1] > min_off]
+
+
+def test_damage_between_target_chunks_is_nobodys_business(data):
+    """Target chunks a member or two apart: the device path reads them as ONE unit, gaps included (fewer bytes than a tail
+    behind every chunk); the host reader and the reference's iterator visit the chunks only.  A damaged member in a gap must not
+    change the outcome — the unit goes back to the host reader chunk by chunk — and damage inside a chunk is an error on both."""
+    import random
+    names, lens = synth.genome_c2(scale=0.0004)
+    rec = synth.gen_records_numpy(lens, 40000, seed=3)
+    synth.write_bam(str(data / "thin.bam"), names, lens, rec, procs=1, payload=True)
+    subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), str(data / "thin.bam")], check=True)
+    bam = (data / "thin.bam").read_bytes()
+    offs, _ = _members_and_record_starts(bam)
+    rng = random.Random(1)
+    targets = []
+    for t in range(40):
+        ci = rng.randrange(12)
+        s0 = rng.randrange(1, int(lens[ci]) - 3000)
+        targets.append((ci, s0, s0 + rng.randrange(50, 900)))
+    (data / "gap.bed").write_text("".join("%s\t%d\t%d\tt%d\n" % (names[ci], b - 1, e, k) for k, (ci, b, e) in enumerate(targets)))
+    bai = (data / "thin.bam.bai").read_bytes()
+    chunks = sorted(c for ci, b, e in targets for c in _bai_chunks(bai, ci, max(0, b - 2), e + 1))
+    used = np.zeros(len(offs), bool)                                 # members some chunk reads
+    for cb, ce in chunks:
+        lo = int(np.searchsorted(offs, cb >> 16, side="right") - 1)
+        hi = int(np.searchsorted(offs, ce >> 16, side="right") - 1)
+        used[lo:hi + (1 if ce & 0xffff else 0)] = True
+    gaps = [m for m in range(1, len(offs) - 1) if not used[m] and used[:m].any() and used[m + 1:].any() and
+            offs[int(np.flatnonzero(used[m:])[0]) + m] - offs[m] <= 40000]
+    assert gaps, "this input should have unread members between chunks"
+    inside = [int(m) for m in np.flatnonzero(used)[::max(1, int(used.sum()) // 3)][:3]]
+    cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
+    work = data / "gapcase"
+    work.mkdir()
+    os.symlink(data / "gap.bed", work / "gap.bed")
+    (work / "m.bam.bai").write_bytes(bai)
+    outcomes = {}
+    for m in gaps[:4] + inside:
+        b = bytearray(bam)
+        b[(offs[m] + 18 + offs[m + 1] - 8) // 2] ^= 0x10             # inside the member's deflate stream
+        (work / "m.bam").write_bytes(bytes(b))
+        got = []
+        for env in ({"PANDEPTH_DD_BATCH_MB": "2", "PANDEPTH_TIMING": "1"}, {"PANDEPTH_DEVICE_DECODE": "0"}):
+            p = subprocess.run([cli, "-i", "m.bam", "-b", "gap.bed", "-o", "o", "-t", "3"], cwd=work, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+            f = work / "o.bed.stat.gz"
+            got.append((p.returncode, f.read_bytes() if p.returncode == 0 and f.exists() else None))
+            if f.exists():
+                f.unlink()
+            if "PANDEPTH_TIMING" in env:
+                line = [x for x in p.stderr.decode().splitlines() if "region fetch:" in x][0].split()
+                assert int(line[-2]) < int(line[-6]), "chunks should have been joined: " + " ".join(line)
+        assert got[0] == got[1], "member %d: device path rc %d, host path rc %d" % (m, got[0][0], got[1][0])
+        outcomes[m] = got[1][0]
+    assert any(outcomes[m] == 0 for m in gaps[:4]) and any(outcomes[m] != 0 for m in inside), outcomes
+    if os.access(REF, os.X_OK):                                      # the undamaged answer, for the cases that went through
+        subprocess.run([REF, "-i", "thin.bam", "-b", "gap.bed", "-o", "gap_ref"], cwd=data, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        (work / "m.bam").write_bytes(bam)
+        subprocess.run([cli, "-i", "m.bam", "-b", "gap.bed", "-o", "o"], cwd=work, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert (work / "o.bed.stat.gz").read_bytes() == (data / "gap_ref.bed.stat.gz").read_bytes()
