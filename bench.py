@@ -36,7 +36,8 @@ executable itself runs for this mode (its GPU decoder leaves the sample's runs r
 then pd_scan_reduce_windows takes the direct path).  BAM decode is NOT in `value`; it IS in the
 "e2e" object of the same JSON line: the executable and the reference binary on one payload BAM
 generated on this box (tools/bamgen), process wall clock, outputs compared byte for byte.  The
-reference's run there is also the contract's "cpu_baseline".
+reference's run there is also the contract's "cpu_baseline".  e2e["annotation"] is the same pair of executables
+in `-g` mode on that BAM (configs[2]'s annotation density: index-driven fetch of the targets' chunks, decoded on the GPU).
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run,
 one rank per GPU, each rank holding its own sample ("one BAM per GPU", #.list mode).
@@ -101,6 +102,80 @@ def _best_wall(cmd, reps, env=None):
     return best
 
 
+def _bam_contigs(path):
+    """(names, lengths) from a BAM's header (its first BGZF members)"""
+    import struct
+    import zlib
+    data = b""
+    with open(path, "rb") as f:
+        for _ in range(64):
+            h = f.read(12)
+            if len(h) < 12:
+                break
+            xlen = struct.unpack_from("<H", h, 10)[0]
+            extra = f.read(xlen)
+            bsize = struct.unpack_from("<H", extra, 4)[0] + 1
+            body = f.read(bsize - 12 - xlen)
+            data += zlib.decompress(body[:-8], -15)
+            if len(data) >= 12:
+                l_text = struct.unpack_from("<i", data, 4)[0]
+                if len(data) >= 12 + l_text:
+                    n_ref = struct.unpack_from("<i", data, 8 + l_text)[0]
+                    q, names, lens, ok = 12 + l_text, [], [], True
+                    for _ in range(n_ref):
+                        if q + 4 > len(data):
+                            ok = False
+                            break
+                        l_name = struct.unpack_from("<i", data, q)[0]
+                        if q + 8 + l_name > len(data):
+                            ok = False
+                            break
+                        names.append(data[q + 4:q + 4 + l_name - 1].decode())
+                        lens.append(struct.unpack_from("<i", data, q + 4 + l_name)[0])
+                        q += 8 + l_name
+                    if ok:
+                        return names, lens
+    raise RuntimeError("BAM header not found in the first members of " + path)
+
+
+def e2e_annotation(td, bam, cli, ref, threads, records):
+    """configs[2] end to end on the same BAM: a synthetic annotation of SURVEY.md 8(d) C3's shape and density (33 688
+    transcripts / 175 274 CDS rows per 3.0 Gb, on the twelve largest contigs), `pandepth -g` (index-driven fetch of the targets' chunks, decoded on the
+    GPU) against the reference binary, gene.stat.gz compared byte for byte."""
+    names, lens = _bam_contigs(bam)
+    big = sorted(range(len(lens)), key=lambda i: -lens[i])[:12]
+    big = [i for i in big if lens[i] > 400000]
+    rng = np.random.default_rng(3)
+    # the same density as 33 688 transcripts / 175 274 CDS rows on 3.0 Gb: the generated BAM covers a scaled genome at 50x
+    G = float(sum(lens))
+    n_tx = max(100, int(round(33688 * G / 3.0e9)))
+    n_cds = int(round(n_tx * 175274 / 33688))
+    per_tx = np.full(n_tx, n_cds // n_tx)
+    per_tx[:n_cds - int(per_tx.sum())] += 1
+    w = np.array([lens[i] for i in big], dtype=np.float64)
+    chrom = rng.choice(len(big), n_tx, p=w / w.sum())
+    gff = os.path.join(td, "c3.gff")
+    with open(gff, "w") as fh:
+        for t in range(n_tx):
+            c = big[int(chrom[t])]
+            s0 = int(rng.integers(1, lens[c] - 200000))
+            for e in range(int(per_tx[t])):
+                el = int(min(5000, max(30, rng.lognormal(np.log(150), 0.7))))
+                fh.write("%s\tsynth\tCDS\t%d\t%d\t.\t+\t0\tID=cds%d.%d;Parent=tx%05d\n" % (names[c], s0, s0 + el - 1, t, e, t))
+                s0 += el + int(rng.integers(80, 3000))
+    mine = os.path.join(td, "mine_g")
+    w_dev = _best_wall([cli, "-i", bam, "-g", gff, "-o", mine, "-t", str(threads)], 2)
+    out = {"mode": "pandepth -i s.bam -g c3.gff -o out -t N: %d transcripts / %d CDS rows on a %.2f Gb genome (the density of "
+                   "33 688 / 175 274 on 3.0 Gb)" % (n_tx, n_cds, G / 1e9),
+           "pandepth": {"wall_s": round(w_dev, 4), "records_in_file_per_s": records / w_dev, "threads": threads}}
+    if os.access(ref, os.X_OK):
+        w_ref = _best_wall([ref, "-i", bam, "-g", gff, "-o", os.path.join(td, "ref_g"), "-t", "36"], 1)
+        out["reference"] = {"wall_s": round(w_ref, 4), "threads": 36}
+        out["byte_identical"] = open(mine + ".gene.stat.gz", "rb").read() == open(os.path.join(td, "ref_g.gene.stat.gz"), "rb").read()
+        out["speedup_vs_reference"] = round(w_ref / w_dev, 2)
+    return out
+
+
 def e2e_leg(records):
     """END TO END, product path: the `pandepth` executable (GPU-side BGZF inflate + record parsing + the direct window
     kernel) and the reference binary on the SAME coordinate-sorted BAM with SEQ/QUAL/tag payload, written here by
@@ -151,6 +226,11 @@ def e2e_leg(records):
                   "sample": "%d records of the configs[1] workload with payload (%.2f GB BAM, %.0f B/record compressed), BAM+BAI, warm "
                             "cache; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads) on a cgroup quota of %d CPUs, "
                             "%.2f s wall" % (records, size / 1e9, size / records, rthreads, quota, w_ref)}
+        if os.environ.get("PD_BENCH_E2E_ANNOTATION", "1") == "1":
+            try:                                    # an extra: whatever goes wrong here must not cost the line its e2e object
+                e2e["annotation"] = e2e_annotation(td, bam, cli, ref, threads, records)
+            except Exception as ex:                 # noqa: BLE001
+                e2e["annotation"] = {"failed": repr(ex)[:300]}
         if cb is None:
             cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
                   "sample": "oracle/_ref/pandepth_ref is not built on this box (oracle/Makefile needs /root/reference): the reference was not timed"}
