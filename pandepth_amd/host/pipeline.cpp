@@ -432,18 +432,18 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     std::vector<uint64_t> key_first(n_batches, 0), key_last(n_batches, 0);                         // order of the first runs across batches
     std::vector<uint8_t> key_have(n_batches, 0);
     std::atomic<int> order_broken{0};
+    std::vector<std::pair<uint64_t, uint64_t>> backlog;                                            // handed-back units: [begin, stop) virtual offsets for the host reader
+    std::mutex back_mu;
     double ms_sum[4] = {0, 0, 0, 0}; std::mutex ms_mu;
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto feeder = [&]() {
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
-        AlnReader rd; bool rd_open = false;                  // only for handed-back units
         std::vector<pd_bgzf_block> blocks;
         std::vector<uint64_t> bfile;                         // file offset of every scanned member
         std::vector<pd_decode_unit> units;
         std::vector<int32_t> status;
-        std::unique_ptr<RunSink> sink;
         for (;;) {
             const size_t bi = next.fetch_add(1);
             if (bi >= n_batches || !eng->ok() || declined.load()) break;
@@ -563,24 +563,18 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                     // CRC-32 — possibly one of the spare members behind the unit that no record of it needs; 3: it could not follow
                     // the record chain.  In every case the host reader goes through exactly the bytes the unit needs and says what
                     // is wrong with them, if anything is
-                    ++n_back;
-                    std::string e2;
-                    if (!rd_open) { if (!rd.open(path, &e2)) { eng->fail(e2); break; } rd_open = true; }
-                    if (!sink) sink.reset(new RunSink(eng));
+                    // It is only NOTED here: the pass can still be declined (a member scan that stops short in another batch, an
+                    // SO:coordinate header that does not hold), and a declined pass must not have counted anything — the host reader
+                    // then goes through the whole file.  The backlog is decoded after those checks, before pd_decode_end.
                     // (a unit made of several chunks goes back chunk by chunk: what lies between them is not the host reader's
                     // business, damaged or not)
-                    bool ok2 = true;
-                    auto host_range = [&](uint64_t a, uint64_t b) {
-                        uint64_t nr = 0;
-                        if (!decode_range(rd, a, b, flt, spans, sink.get(), &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); ok2 = false; }
-                        n_host += nr;
-                    };
-                    if (orig.empty()) host_range(rs[k].vbeg, rs[k].vend);
+                    ++n_back;
+                    std::lock_guard<std::mutex> lk(back_mu);
+                    if (orig.empty()) backlog.emplace_back(rs[k].vbeg, rs[k].vend);
                     else
                         for (auto it = std::upper_bound(orig.begin(), orig.end(), rs[k].vbeg, [](uint64_t v, const BaiIndex::Chunk &c) { return v < c.second; });
-                             ok2 && it != orig.end() && it->first < rs[k].vend; ++it)
-                            host_range(std::max(it->first, rs[k].vbeg), std::min(it->second, rs[k].vend));
-                    if (!ok2) break;
+                             it != orig.end() && it->first < rs[k].vend; ++it)
+                            backlog.emplace_back(std::max(it->first, rs[k].vbeg), std::min(it->second, rs[k].vend));
                 }
             }
         }
@@ -616,6 +610,30 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3]);
     if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
     if (declined.load()) { api->decode_abort(eng->ctx); return 0; }          // nothing of this input has been counted
+    if (!backlog.empty()) {
+        // the units the device handed back, now that the pass stands: the host reader goes through exactly the bytes each of
+        // them needs and says what is wrong with them, if anything is
+        std::sort(backlog.begin(), backlog.end());
+        std::atomic<size_t> nb{0};
+        auto host_worker = [&]() {
+            AlnReader rd; std::string e2;
+            if (!rd.open(path, &e2)) { eng->fail(e2); return; }
+            RunSink sink(eng);
+            for (;;) {
+                const size_t i = nb.fetch_add(1);
+                if (i >= backlog.size() || !eng->ok()) break;
+                uint64_t nr = 0;
+                if (!decode_range(rd, backlog[i].first, backlog[i].second, flt, spans, &sink, &nr, &e2)) { eng->fail(e2 + " (" + path + ")"); break; }
+                n_host += nr;
+            }
+        };
+        const int nt = (int)std::min<size_t>((size_t)std::max(1, o.threads), backlog.size());
+        std::vector<std::thread> th;
+        for (int i = 1; i < nt; ++i) th.emplace_back(host_worker);
+        host_worker();
+        for (auto &t : th) t.join();
+        if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
+    }
     const uint64_t t_e = now_us();
     if (!eng->ck(api->decode_end(eng->ctx), "pd_decode_end")) return -1;
     if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing]   pd_decode_end (concatenate the batches' runs) %.3f s\n", (now_us() - t_e) / 1e6);
