@@ -67,7 +67,7 @@ PW_FN bool plausible(const Cfg &c, uint64_t p, int depth)
         if (p + 36 > c.avail) return k > 0;                               // cannot look further: what was seen was consistent
         const uint8_t *r = c.buf + p;
         const uint32_t bs = rd32(r);
-        if (bs < 34 || bs > (1u << 27)) return false;
+        if (bs < 33 || bs > (1u << 27)) return false;                         // 32 fixed bytes + a name of at least its NUL
         const int32_t tid = (int32_t)rd32(r + 4), pos = (int32_t)rd32(r + 8);
         if (tid < -1 || tid >= c.n_ref || pos < -1) return false;
         const uint32_t l_name = r[12], n_cig = rd16(r + 16), l_seq = rd32(r + 20);
@@ -146,8 +146,11 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
             bool take = true;
             if (c.spans) {                                               // endpos first: the filter needs it
                 // htslib's bam_endpos: unmapped reads and alignments without reference bases count as one base
-                const int32_t endpos = x.unmapped || !x.n_cig ? x.pos + 1 : walk_cigar(x, [](bool, int32_t, int32_t) {});
-                take = span_hit(c, x.tid, x.pos, endpos > x.pos ? endpos : x.pos + 1);
+                // (pos + reference length in the reference's wrapping int arithmetic, like the host reader's AlnRec::endpos:
+                // only a reference length of zero becomes one base — corrupt lengths that wrap select the same reads on both paths)
+                const int32_t one = (int32_t)((uint32_t)x.pos + 1u);
+                const int32_t endpos = x.unmapped || !x.n_cig ? one : walk_cigar(x, [](bool, int32_t, int32_t) {});
+                take = span_hit(c, x.tid, x.pos, endpos == x.pos ? one : endpos);
             }
             if (take) {
                 uint32_t nf = 0, no = 0, nfar = 0, span = 0;
@@ -201,7 +204,7 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
                 for (uint32_t k = 0; k < (uint32_t)SCAN; ++k) {
                     const uint32_t sh = (k & 3) * 8, j = k >> 2;
                     auto fld = [&](uint32_t q) { return sh ? (d[j + q] >> sh) | (d[j + q + 1] << (32 - sh)) : d[j + q]; };   // dword at byte p + k + 4 q
-                    const bool ok = fld(0) - 34u <= (1u << 27) - 34u              // block size
+                    const bool ok = fld(0) - 33u <= (1u << 27) - 33u              // block size
                                     && fld(1) + 1u <= (uint32_t)c.n_ref           // refID in -1 .. n_ref - 1
                                     && (int32_t)fld(2) >= -1                      // pos
                                     && (fld(3) & 0xffu) != 0u                     // l_read_name >= 1

@@ -951,9 +951,15 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     { DecTimer tw(0); c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; }); }
     sl->busy = true;
     lk.unlock();
-    { DecTimer tsd(7); if (hipSetDevice(c->device) != hipSuccess) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); } }
+    {
+        DecTimer tsd(7);
+        if (hipSetDevice(c->device) != hipSuccess) {
+            { std::lock_guard<std::mutex> l2(c->dec_mu); sl->busy = false; }
+            c->dec_cv.notify_one();
+            return dec_fail(c, PD_EHIP, "hipSetDevice failed");
+        }
+    }
     DecTimer ta(1);
-    if (false) { sl->busy = false; c->dec_cv.notify_one(); return dec_fail(c, PD_EHIP, "hipSetDevice failed"); }
     if (bytes + 64 > sl->h_cap) {
         if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
         const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20);
@@ -974,7 +980,10 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
 {
     if (!c || !bt || !bt->host_buf || !unit_status) return PD_EINVAL;
     pd_ctx::DecSlot *slp = nullptr;
-    for (auto &x : c->dec) if (x.h_blob == bt->host_buf && x.busy) slp = &x;
+    {   // (other feeders may be in pd_decode_acquire, re-allocating THEIR slots' pinned buffers: look the slot up under the lock)
+        std::lock_guard<std::mutex> l0(c->dec_mu);
+        for (auto &x : c->dec) if (x.busy && x.h_blob == bt->host_buf) slp = &x;
+    }
     if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_submit: buffer was not handed out by pd_decode_acquire");
     pd_ctx::DecSlot &sl = *slp;
     struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; } c->dec_cv.notify_one(); } } rel{c, slp};
@@ -1083,6 +1092,11 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     }
     // ---- pass 2: the runs ----
     pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, nullptr, nfar, max_span, 0u, 0ull, 0ull};
+    // run arrays taken outside the arena belong to this call until the batch is listed: every early return gives them back
+    struct RunGuard {
+        pd_ctx *c; pd_ctx::RunSeg *r; bool keep = false;
+        ~RunGuard() { if (keep) return; for (pd_iv *q : {r->first, r->other, r->far}) if (q && !(c->arena && (const uint8_t *)q >= c->arena && (const uint8_t *)q < c->arena + c->arena_cap)) (void)hipFree(q); }
+    } run_guard{c, &rs};
     lap(4);                                                               // host: chain check, unit outcomes
     if (nf + no + nfar) {
         auto grab = [&](uint64_t n, pd_iv **out) -> bool {
@@ -1091,9 +1105,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
             if (at + bytes <= c->arena_cap) { *out = (pd_iv *)(c->arena + at); return true; }
             return hipMalloc(out, bytes) == hipSuccess;
         };
-        if (nf && !grab(nf, &rs.first)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
-        if (no && !grab(no, &rs.other)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
-        if (nfar && !grab(nfar, &rs.far)) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+        if ((nf && !grab(nf, &rs.first)) || (no && !grab(no, &rs.other)) || (nfar && !grab(nfar, &rs.far))) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
         HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
         lap(5);                                                           // run array allocation
         launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far);
@@ -1121,6 +1133,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         if (hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]) == hipSuccess) res->ms_emit = ms;
     }
     if (nf + no + nfar) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
+    run_guard.keep = true;
     return PD_OK;
 }
 
@@ -1214,6 +1227,9 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     pd_decode_cfg cfg{}; cfg.flag_mask = flag_mask; cfg.min_mapq = min_mapq; cfg.sorted = 1;
     int rc = pd_decode_begin(c, &cfg);
     if (rc) return rc;
+    // the session this call opens is closed on every path out of it (its batch is taken out of the list below, so the
+    // abort drops nothing that was counted)
+    struct Close { pd_ctx *c; ~Close() { (void)pd_decode_abort(c); } } close_session{c};
     void *hb = nullptr;
     if ((rc = pd_decode_acquire(c, n_bytes, &hb))) return rc;
     memcpy(hb, blob, n_bytes);
