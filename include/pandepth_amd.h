@@ -40,7 +40,8 @@ enum {
     PD_ENODEV = -2,   /* no usable gfx950 device / HIP runtime failure  */
     PD_ENOMEM = -3,   /* device or pinned-host allocation failed       */
     PD_ESTATE = -4,   /* call not valid in the context's current state */
-    PD_EHIP   = -5    /* a HIP call failed; see pd_strerror            */
+    PD_EHIP   = -5,   /* a HIP call failed; see pd_strerror            */
+    PD_ERANGE = -6    /* the data does not fit this path's packed form; nothing was lost: take the general path (see pd_sliced_sum_finish) */
 };
 
 typedef struct pd_ctx pd_ctx;
@@ -189,7 +190,10 @@ int pd_import_i8(pd_ctx *ctx, const void *dev_i8, int bias, const pd_exc *dev_ex
  *                     "direct_windows" set, a pristine context and an entirely deferred sample
  *                     (see pd_scan_reduce_windows) the image, the exceptions and the tile sums
  *                     come straight from the tile windows in LDS — same bytes, the difference
- *                     arrays are never written; the sample is then consumed (pd_reset next).
+ *                     arrays are never written.  An export READS the sample: it stays deferred (a later
+ *                     pd_scan / pd_accumulate_from materialises it as usual; pd_reset forgets it).  An
+ *                     export that produces more than exc_cap exceptions always leaves the sample in the
+ *                     difference arrays (never "half exported").
  *   pd_slice_sweep_i4 the receiving side, for the tiles [tile_first, tile_first + tile_count) of the
  *                     buffer (8192 cells each), in ONE fused kernel: adds the n_parts images of that
  *                     range (part j at dev_parts + j * part_stride, tile_count * 4096 bytes each,
@@ -234,7 +238,11 @@ int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned w
  * pd_sliced_sum_start only enqueues (pack on the context's stream, the collectives on the communicator's own stream, ordered
  * by events), so the context can be reset and sample k+1 scattered while sample k's image is on the xGMI links;
  * pd_sliced_sum_finish completes a started slot and blocks until this rank's part is done.  All ranks make the same calls in
- * the same order.  pd_sliced_window_sum = start(0) + finish(0). */
+ * the same order.  pd_sliced_window_sum = start(0) + finish(0).
+ * PD_ERANGE (from finish, on EVERY rank alike — the counts are all-reduced): some rank's sample has more cells outside the
+ * 4-bit range than the exception block holds (2^18: amplicon or very deep data).  No sample was consumed; sum the contexts
+ * with pd_accumulate_from (one process) or reduce pd_device_buffer (several) instead — the reference handles such data
+ * (PD:2704-3014), so must the caller. */
 int pd_sliced_sum_start(pd_comm *comm, int slot);
 int pd_sliced_sum_finish(pd_comm *comm, int slot, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
 

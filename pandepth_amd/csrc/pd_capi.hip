@@ -68,6 +68,7 @@ struct pd_ctx {
     bool accumulate_packed = true;                                // pd_accumulate_from: 4-bit transport
     bool direct_windows = false;                                  // pd_scan_reduce_windows may consume deferred batches in place
     bool pristine = true;                                         // nothing materialised in the arrays since the last reset
+    bool sums_stale = false;                                      // the tile sums hold what a direct export wrote while the sample is still deferred
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
     bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
     uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
@@ -192,6 +193,7 @@ int do_reset(pd_ctx *c)
     HIPOK(c, hipMemsetAsync(c->desc, 0, sizeof(BatchDesc) * PD_MAXPEND, c->stream));
     c->all_valid_host = false;
     c->pristine = true;
+    c->sums_stale = false;
     return PD_OK;
 }
 
@@ -210,6 +212,10 @@ int ensure_all_valid(pd_ctx *c)
 int flush_pending(pd_ctx *c)
 {
     if (c->pend.empty()) return PD_OK;
+    if (c->sums_stale) {                      // a direct export wrote this (still deferred) sample's tile sums; the scatter adds to them
+        HIPOK(c, hipMemsetAsync(c->sums, 0, (c->n_words - c->n_cells) * 4, c->stream));
+        c->sums_stale = false;
+    }
     c->pristine = false;
     uint64_t total = 0;
     for (auto &p : c->pend) total += p.n;
@@ -488,10 +494,17 @@ int pd_reset(pd_ctx *c)
     if (!c) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPOK(c, hipSetDevice(c->device));
-    int rc = flush_pending(c);
-    if (rc) return rc;
+    // deferred batches are forgotten with everything else (they used to be scattered first, a whole-genome pass for nothing);
+    // their staging slots are free once the stream has passed this point
+    for (auto &p : c->pend)
+        if (p.slot >= 0) {
+            Stage &st = c->stage[p.slot];
+            HIPOK(c, hipEventRecord(st.done, c->stream));
+            st.state = 2; st.seq = ++c->seq;
+        }
+    c->pend.clear();
     c->state = 0;
-    rc = do_reset(c);
+    int rc = do_reset(c);
     if (rc == PD_OK && (c->run_first || c->run_other || c->run_far)) {          // the decoded sample's runs go with it
         HIPOK(c, hipStreamSynchronize(c->stream));
         for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
@@ -1437,24 +1450,27 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
       launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
                            c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
     HIPOK(c, hipGetLastError());
-    uint32_t words[2] = {0, 0};
+    uint32_t words[2] = {0, 0}, n_exc = 0;
     HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipMemcpyAsync(&n_exc, dev_count, 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
+    // more cells outside the 4-bit range than the caller's exception block holds (amplicon / very deep data): the image is
+    // not usable, and the sample must stay whole for whatever the caller does instead — it is materialised below like any
+    // other declined export, the arrays keep it
+    if (n_exc > exc_cap) words[1] = 1;
     if (words[1]) {
         HIPOK(c, hipMemsetAsync(c->sums, 0, (c->n_words - c->n_cells) * 4, c->stream));      // the kernel wrote them
+        c->sums_stale = false;
         char m[160];
-        snprintf(m, sizeof m, "direct export declined (heavy tiles / long runs: %u); the materialising path was used", words[0]);
+        snprintf(m, sizeof m, "direct export declined (heavy tiles / long runs: %u; cells outside the 4-bit range: %u); the materialising path was used", words[0], n_exc);
         c->err = m;                                          // informational: the call still succeeds
         return PD_OK;
     }
-    for (auto &p : c->pend)
-        if (p.slot >= 0) {
-            Stage &st = c->stage[p.slot];
-            HIPOK(c, hipEventRecord(st.done, c->stream));
-            st.state = 2; st.seq = ++c->seq;
-        }
-    c->pend.clear();
-    c->state = 2;
+    // The sample STAYS deferred: an export reads it.  (A caller that finds out later that the image is of no use — another
+    // rank's sample did not fit its exception block, pd_sliced_sum_finish -> PD_ERANGE — still has every context's sample and
+    // adds them up the general way.)  The tile sums now hold this sample's sums although the arrays hold nothing:
+    // flush_pending zeroes them before it scatters, pd_reset forgets them with everything else.
+    c->sums_stale = true;
     *done = true;
     return PD_OK;
 }
@@ -1612,14 +1628,17 @@ struct Rccl {
     decltype(&::ncclAllReduce) AllReduce = nullptr;
     decltype(&::ncclAllGather) AllGather = nullptr;
     decltype(&::ncclGetErrorString) GetErrorString = nullptr;
-    bool ok = false;
+    bool ok = false, alt = false;
 };
 Rccl &rccl()
 {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *p : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) if ((r.h = dlopen(p, RTLD_NOW | RTLD_GLOBAL))) break;
+        // PANDEPTH_RCCL_LIB names another library with RCCL's entry points (tests: a loopback transport between contexts that
+        // share one GPU, tests/harness/loopback_nccl.hip — the only way to run N > 1 ranks of this code on a 1-GPU box)
+        if (const char *alt = getenv("PANDEPTH_RCCL_LIB")) { if (alt[0]) r.h = dlopen(alt, RTLD_NOW | RTLD_LOCAL); if (r.h) r.alt = true; }
+        if (!r.h) for (const char *p : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) if ((r.h = dlopen(p, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!r.h) return;
 #define PD_SYM(name) r.name = (decltype(r.name))dlsym(r.h, "nccl" #name)
         PD_SYM(GetUniqueId); PD_SYM(CommInitRank); PD_SYM(CommInitAll); PD_SYM(CommDestroy); PD_SYM(GroupStart); PD_SYM(GroupEnd);
@@ -1723,8 +1742,9 @@ int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms)
     if (!ctxs || !comms || n < 1) return PD_EINVAL;
     std::vector<int> devs((size_t)n);
     for (int i = 0; i < n; ++i) { if (!ctxs[i]) return PD_EINVAL; devs[(size_t)i] = ctxs[i]->device; comms[i] = nullptr; }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (devs[(size_t)i] == devs[(size_t)j]) {
-        std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
+    if (!rccl().alt)
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (devs[(size_t)i] == devs[(size_t)j]) {
+            std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
     if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
     bool made;
@@ -1836,8 +1856,11 @@ int pd_sliced_sum_finish(pd_comm *m, int slot, uint32_t w, uint32_t min_dep, uns
     std::vector<int32_t> counts(W);
     HIPCM(m, hipMemcpyAsync(counts.data(), s.meta + m->n_sums, W * 4, hipMemcpyDeviceToHost, st));
     HIPCM(m, hipStreamSynchronize(st));
+    // (every rank holds the same all-reduced counts, so every rank leaves here with the same code; the samples are intact —
+    // an export that overflows never consumes a deferred sample, it leaves it in the rank's difference arrays)
     for (int32_t k : counts) if (k < 0 || (uint32_t)k > COMM_EXC_BLOCK)
-        return comm_fail(m, PD_EINVAL, "a sample has more cells outside the 4-bit range than the exception block holds; use pd_accumulate_from (the executable: PANDEPTH_NO_RCCL=1)");
+        return comm_fail(m, PD_ERANGE, "a sample has more cells outside the 4-bit range than the exception block holds: the sliced sum does not apply, "
+                                       "every context still holds its sample (pd_accumulate_from adds them up)");
     if (m->rank == root) {
         rc = pd_gather_windows(c, m->part_all, w, cover, sum);
         if (rc) return comm_fail(m, rc, std::string("pd_gather_windows: ") + c->err);

@@ -1107,7 +1107,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     auto bail = [&]() { std::cerr << "Error: " << eng.err << std::endl; return 2; };
     // cover / depth sum of every window of `width` cells (pd_window_layout order), whichever way the sample is held
     auto window_stats = [&](uint32_t width, uint32_t *cov, uint64_t *sum) -> bool {
-        if (!merged && !scanned && width >= PD_TILE_CELLS && n_ctx <= n_dev && api->comm_init_all && api->sliced_window_sum && !getenv("PANDEPTH_NO_RCCL")) {
+        if (!merged && !scanned && width >= PD_TILE_CELLS && (n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) && api->comm_init_all && api->sliced_window_sum && !getenv("PANDEPTH_NO_RCCL")) {
             std::vector<pd_ctx *> ctxs;
             for (auto &e : engs) ctxs.push_back(e->ctx);
             std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
@@ -1125,14 +1125,20 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
                 for (int k = 0; k < n_ctx; ++k)
                     th.emplace_back([&, k]() { rcs[(size_t)k] = api->sliced_window_sum(comms[(size_t)k], width, min_dep, wrap_bits, 0, k == 0 ? cov : nullptr, k == 0 ? sum : nullptr); });
                 for (auto &t : th) t.join();
-                bool ok = true;
-                for (int k = 0; k < n_ctx; ++k)
+                // PD_ERANGE (-6) on every rank: a sample with more cells outside the 4-bit image's range than the exception block
+                // holds (amplicon, very deep RNA-seq).  Nothing was consumed; the contexts are added into the first one instead.
+                bool ok = true, too_wide = true;
+                for (int k = 0; k < n_ctx; ++k) if (rcs[(size_t)k] != PD_ERANGE) too_wide = false;
+                for (int k = 0; k < n_ctx && !too_wide; ++k)
                     if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string("pd_sliced_window_sum: ") + (m ? m : "?")); }
                 if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
                 quiet.reset();
-                if (tm.on) fprintf(stderr, "[timing] window statistics summed over %d GPUs in slices (RCCL)\n", n_ctx);
-                return ok;
-            }
+                if (!too_wide) {
+                    if (tm.on) fprintf(stderr, "[timing] window statistics summed over %d GPUs in slices (RCCL)\n", n_ctx);
+                    return ok;
+                }
+                if (tm.on) fprintf(stderr, "[timing] the samples do not fit the sliced sum's 4-bit images: the contexts are added into GPU %d instead\n", device);
+            } else
             if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
         }
         if (!merge_contexts()) return false;

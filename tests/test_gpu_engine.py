@@ -670,8 +670,12 @@ def test_direct_export_equals_export_of_the_arrays():
         assert torch.equal(img_a, img_d)
         key = lambda x: sorted(map(tuple, x.tolist()))
         assert len(exc_a) >= 2 and key(exc_a) == key(exc_d)
-        with pytest.raises(pda.PdError, match="direct"):
-            ed.scan(0)                                            # consumed: the arrays hold nothing
+        # an export READS the sample: it is still deferred, and materialises like any other (the tile sums the export kernel
+        # wrote are dropped first)
+        d0, off0 = oracle_depth(LENS, np.concatenate([first, other]), False)
+        ed.scan(0)
+        for t in (0, len(LENS) - 1):
+            assert np.array_equal(ed.read_depth(t, 0, int(LENS[t])), d0[off0[t]:off0[t] + LENS[t]])
         # tile sums: the direct kernel writes them where the scatter kernels keep theirs; checked through the sliced finish,
         # which derives every carry from them
         ss = multi.SlicedSum(ea, dev)
@@ -681,11 +685,11 @@ def test_direct_export_equals_export_of_the_arrays():
         sd = multi.SlicedSum(ed, dev)                             # (before the pushes: its buffer view flushes what is pending)
         ed.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
-        sd.start(0)
-        with pytest.raises(pda.PdError, match="direct"):
-            ed.scan(0)                                            # start() took the direct export
+        sd.start(0)                                               # takes the direct export
         got = sd.finish(0, 10000, 1, 18)
         assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+        w2 = ed.scan_reduce_windows(10000, 1, 18)                 # ... which left the sample where it was
+        assert np.array_equal(ref[1], w2[1]) and np.array_equal(ref[2], w2[2])
         d, off = oracle_depth(LENS, np.concatenate([first, other]), True)
         c, t = windows_ref(LENS, d, off, 10000, 1)
         assert np.array_equal(got[1], c) and np.array_equal(got[2], t)
