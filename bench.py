@@ -87,19 +87,41 @@ def cpu_quota():
     return os.cpu_count() or 1
 
 
-def _best_wall(cmd, reps, env=None):
-    best = None
+def _best_wall(cmd, reps, env=None, want_stderr=False):
+    """best wall time (exec to exit) of `reps` runs; with want_stderr also the stderr text of that run"""
+    best, err = None, ""
     for k in range(reps):
         if k:
             time.sleep(1.0)       # the executable leaves without freeing its HBM (the driver reclaims it): a process started
                                   # right behind it waits for that in its own runtime start-up (0.09 -> 0.26 s of pd_create)
         t0 = time.perf_counter()
-        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1800)
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=3600)
         if p.returncode != 0:
             raise RuntimeError("%s: exit %d: %s" % (os.path.basename(cmd[0]), p.returncode, p.stderr.decode(errors="replace")[-600:]))
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return best
+        if best is None or dt < best:
+            best, err = dt, p.stderr.decode(errors="replace")
+    return (best, err) if want_stderr else best
+
+
+def parse_timing(err):
+    """PANDEPTH_TIMING=1 lines of one run -> {phase: seconds} + the device-decode totals (diagnostics printed by the executable:
+    host/pipeline.cpp PhaseTimer and read_bam_device)"""
+    import re
+    ph, dec = {}, None
+    for ln in err.splitlines():
+        m = re.match(r"\[timing\] (\S.*?)\s+([0-9.]+) s   \(total ([0-9.]+) s\)", ln)
+        if m:
+            ph[m.group(1).strip()] = float(m.group(2))
+            ph["total_in_main"] = float(m.group(3))
+        m = re.search(r"device decode: (\d+) batches .*?(\d+) feeders, (\d+) records on the device, (\d+) units handed back \((\d+) records on the host\).*?"
+                      r"device ms summed over batches: H2D ([0-9.]+), inflate ([0-9.]+), walk ([0-9.]+), emit ([0-9.]+); bytes: compressed (\d+), inflated (\d+)", ln)
+        if m:
+            dec = {"batches": int(m.group(1)), "feeders": int(m.group(2)), "records_on_device": int(m.group(3)), "units_handed_back": int(m.group(4)),
+                   "records_on_host": int(m.group(5)), "device_ms_summed": {"h2d": float(m.group(6)), "inflate": float(m.group(7)), "walk": float(m.group(8)),
+                                                                             "emit": float(m.group(9))},
+                   "compressed_bytes": int(m.group(10)), "inflated_bytes": int(m.group(11))}
+    return ph, dec
 
 
 def _bam_contigs(path):
@@ -169,18 +191,45 @@ def e2e_annotation(td, bam, cli, ref, threads, records):
                    "33 688 / 175 274 on 3.0 Gb)" % (n_tx, n_cds, G / 1e9),
            "pandepth": {"wall_s": round(w_dev, 4), "records_in_file_per_s": records / w_dev, "threads": threads}}
     if os.access(ref, os.X_OK):
-        w_ref = _best_wall([ref, "-i", bam, "-g", gff, "-o", os.path.join(td, "ref_g"), "-t", "36"], 1)
+        w_ref = _best_wall([ref, "-i", bam, "-g", gff, "-o", os.path.join(td, "ref_g"), "-t", "36"], 2)
         out["reference"] = {"wall_s": round(w_ref, 4), "threads": 36}
         out["byte_identical"] = open(mine + ".gene.stat.gz", "rb").read() == open(os.path.join(td, "ref_g.gene.stat.gz"), "rb").read()
         out["speedup_vs_reference"] = round(w_ref / w_dev, 2)
     return out
 
 
-def e2e_leg(records):
+PCIE_PEAK_GBS = 64.0           # PCIe Gen5 x16, one direction, raw (MI355X_MICROARCH.md: host link); ~55 GB/s is what a pinned H2D copy reaches
+
+
+def e2e_site_windows(td, gen, cli, ref, threads, records=20000000):
+    """configs[3] end to end: `-w 100 -a` on a generated BAM (default 2e7 records / 60 Mb: 6e7 per-site lines, 0.9 GB of text),
+    the product executable against the reference binary, win.stat.gz AND SiteDepth.gz compared byte for byte."""
+    bam = os.path.join(td, "w.bam")
+    g = subprocess.run([gen, "-o", bam, "-n", str(int(records)), "-t", str(min(32, os.cpu_count() or 1))], check=True, stderr=subprocess.PIPE, timeout=1800)
+    mine = os.path.join(td, "mine_w")
+    w_dev, err = _best_wall([cli, "-i", bam, "-w", "100", "-a", "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
+    ph, _ = parse_timing(err)
+    out = {"mode": "pandepth -i w.bam -w 100 -a -o out -t N (" + g.stderr.decode().strip().replace("bamgen: ", "") + ")", "records": int(records),
+           "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads, "phases_s": ph}}
+    if os.access(ref, os.X_OK):
+        w_ref = _best_wall([ref, "-i", bam, "-w", "100", "-a", "-o", os.path.join(td, "ref_w"), "-t", "36"], 1)
+        out["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": records / w_ref, "threads": 36}
+        same = {}
+        for suf in ("win.stat.gz", "SiteDepth.gz"):
+            same[suf] = open(mine + "." + suf, "rb").read() == open(os.path.join(td, "ref_w." + suf), "rb").read()
+        out["byte_identical"] = all(same.values())
+        out["byte_identical_files"] = same
+        out["site_depth_gz_bytes"] = os.path.getsize(mine + ".SiteDepth.gz")
+        out["speedup_vs_reference"] = round(w_ref / w_dev, 2)
+    os.remove(bam)
+    return out
+
+
+def e2e_leg(records, site_records):
     """END TO END, product path: the `pandepth` executable (GPU-side BGZF inflate + record parsing + the direct window
     kernel) and the reference binary on the SAME coordinate-sorted BAM with SEQ/QUAL/tag payload, written here by
     tools/bamgen (libdeflate level 6, BAI alongside), whole-chromosome mode, process wall clock (exec to exit, warm page
-    cache, best of 3 / 2), outputs compared byte for byte.  Returns (e2e object, cpu_baseline object).
+    cache, best of 2 for both), outputs compared byte for byte.  Returns (e2e object, cpu_baseline object).
     The reference run is the contract's cpu_baseline (kind "reference"): its own multithreaded CPU path on this box's
     host cores, the file being the bounded sample of configs[1]."""
     gen = os.path.join(ROOT, "tools", "bamgen")
@@ -192,28 +241,49 @@ def e2e_leg(records):
     td = tempfile.mkdtemp(prefix="pde2e", dir="/tmp")
     bam = os.path.join(td, "s.bam")
     try:
+        # room for the file (~53 B per record) beside what the box already holds: a smaller sample rather than a failed leg
+        free = os.statvfs(td).f_bavail * os.statvfs(td).f_frsize
+        asked = int(records)
+        while records > 2e7 and records * 56 > 0.8 * free:
+            records = int(records // 2)
         t0 = time.perf_counter()
         g = subprocess.run([gen, "-o", bam, "-n", str(int(records)), "-t", str(min(32, os.cpu_count() or 1))], check=True,
-                           stderr=subprocess.PIPE, timeout=1800)
+                           stderr=subprocess.PIPE, timeout=3600)
         t_gen = time.perf_counter() - t0
         size = os.path.getsize(bam)
         threads = max(4, min(16, quota))
         mine = os.path.join(td, "mine")
-        w_dev = _best_wall([cli, "-i", bam, "-o", mine, "-t", str(threads)], 3)
+        w_dev, err = _best_wall([cli, "-i", bam, "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
+        ph, dec = parse_timing(err)
         w_host = _best_wall([cli, "-i", bam, "-o", os.path.join(td, "host"), "-t", str(threads)], 1,
                             env=dict(os.environ, PANDEPTH_DEVICE_DECODE="0"))
         e2e = {
-            "records": int(records), "bam_bytes": size, "bam_bytes_per_record": round(size / records, 1),
+            "records": int(records), "records_asked": asked, "bam_bytes": size, "bam_bytes_per_record": round(size / records, 1),
             "bam": "tools/bamgen: coordinate-sorted, 150-base reads with names, SEQ from a synthetic reference, binned QUAL, "
                    "NM/MD/AS/XS/RG tags; BGZF by libdeflate level 6; .bai alongside (" + g.stderr.decode().strip().replace("bamgen: ", "") +
                    "; generated in %.0f s)" % t_gen,
-            "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache",
+            "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache, best of 2 runs for both executables",
             "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads,
-                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_wide3; host only reads the file"},
+                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_wide3; host only reads the file",
+                         "phases_s": ph, "device_decode": dec},
             "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
                                      "path": "PANDEPTH_DEVICE_DECODE=0: libdeflate on the host threads + pd_push_intervals"},
             "cpu_quota": quota, "host_cpus": os.cpu_count(),
         }
+        # what bounds the end-to-end run: the compressed bytes cross PCIe once (host page cache -> pinned buffer -> HBM), the
+        # inflated bytes are produced by k_inflate_wave; both rates over the "decode + scatter" phase of the timed run
+        t_dec = ph.get("decode + scatter")
+        if dec and t_dec:
+            e2e["roofline"] = {
+                "phase": "decode + scatter", "seconds": t_dec,
+                "compressed_GBps": round(dec["compressed_bytes"] / t_dec / 1e9, 2), "pcie_peak_GBps": PCIE_PEAK_GBS,
+                "frac_pcie": round(dec["compressed_bytes"] / t_dec / 1e9 / PCIE_PEAK_GBS, 3),
+                "inflated_GBps": round(dec["inflated_bytes"] / t_dec / 1e9, 1),
+                "inflate_kernel_busy_s_summed_over_streams": round(dec["device_ms_summed"]["inflate"] / 1e3, 3),
+                "inflate_kernel_GBps_in_situ": round(dec["inflated_bytes"] / (dec["device_ms_summed"]["inflate"] / 1e3) / 1e9, 1) if dec["device_ms_summed"]["inflate"] else None,
+                "note": "inflate_kernel_GBps_in_situ = inflated bytes / sum of the batches' inflate-kernel times (batches of different feeders "
+                        "overlap on the device, so the wall-clock rate inflated_GBps can exceed it); isolated kernel rate: profiles/",
+            }
         cb = None
         if os.access(ref, os.X_OK):
             rthreads = 36
@@ -231,6 +301,12 @@ def e2e_leg(records):
                 e2e["annotation"] = e2e_annotation(td, bam, cli, ref, threads, records)
             except Exception as ex:                 # noqa: BLE001
                 e2e["annotation"] = {"failed": repr(ex)[:300]}
+        os.remove(bam)
+        if site_records > 0:
+            try:
+                e2e["site_windows"] = e2e_site_windows(td, gen, cli, ref, threads, site_records)
+            except Exception as ex:                 # noqa: BLE001
+                e2e["site_windows"] = {"failed": repr(ex)[:300]}
         if cb is None:
             cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
                   "sample": "oracle/_ref/pandepth_ref is not built on this box (oracle/Makefile needs /root/reference): the reference was not timed"}
@@ -379,8 +455,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
-    ap.add_argument("--e2e-records", type=float, default=1.0e8,
-                    help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip)")
+    ap.add_argument("--e2e-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_RECORDS", "3.0e8")),
+                    help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip; "
+                         "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write)")
+    ap.add_argument("--e2e-site-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_SITE_RECORDS", "2.0e7")),
+                    help="records of the `-w 100 -a` end-to-end pair (configs[3]; 0 = skip)")
     ap.add_argument("--config", choices=["chr", "gff", "w100a"], default="chr",
                     help="chr = configs[1] (BASELINE.json's metric; default); gff = configs[2]; w100a = configs[3]")
     args = ap.parse_args()
@@ -660,13 +739,37 @@ def main():
                     "avg_launch_ms": kd["avg_ms"], "avg_launch_ms_rocprof": rocprof_avg, "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
         cb, e2e = {"value": None, "unit": "records/s", "cores": 0, "kind": "reference",
                    "sample": "not timed: the end-to-end leg runs on rank 0 of a 1-GPU invocation with --e2e-records > 0"}, None
+        # configs[2] and configs[3] on the same resident sample, three steps each after the timed region (their kernels are
+        # the general path's: scatter into the arrays, write-back sweep, interval / narrow-window reductions); `--config gff |
+        # w100a` runs either as a contract line of its own
+        configs = None
+        if world == 1 and not use_dist and os.environ.get("PD_BENCH_CONFIG_LEGS", "1") == "1":
+            configs = {}
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup = 3, 1
+            for which in ("gff", "w100a"):
+                try:
+                    ln = config_leg(sub, which, eng, pda, synth, torch, dist, first, other, lens, rank, world, use_dist)
+                    configs[which] = {k: ln[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "kernels", "site_readback")}
+                    configs[which]["workload"] = ln["config"]["workload"]
+                    configs[which]["check"] = ln["config"]["check"]
+                except Exception as ex:                            # noqa: BLE001 — an extra must not cost the line
+                    configs[which] = {"failed": repr(ex)[:300]}
         if world == 1 and args.e2e_records > 0:
             try:
                 eng.close()                                        # the CLI makes its own context on this GPU
-                e2e, cb = e2e_leg(int(args.e2e_records))
+                del first, other                                   # ... and the bench sample's 13 GB of runs go too
+                torch.cuda.empty_cache()
+                e2e, cb = e2e_leg(int(args.e2e_records), int(args.e2e_site_records))
             except Exception as ex:                                # never lose the GPU line over this leg
                 e2e = {"failed": repr(ex)}
                 cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "failed", "sample": repr(ex)}
+        if configs is not None and isinstance(e2e, dict):
+            # the same two configurations end to end (executable vs reference binary on a generated BAM, bytes compared)
+            if "gff" in configs and "annotation" in e2e:
+                configs["gff"]["e2e"] = e2e["annotation"]
+            if "w100a" in configs and "site_windows" in e2e:
+                configs["w100a"]["e2e"] = e2e["site_windows"]
         line = {
             "metric": "alignment records/sec (3 Gb genome, 50x BAM, whole-chromosome mode)",
             "value": value, "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -685,6 +788,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "arrays_path": arrays_path,
+            "configs": configs,
             "e2e": e2e,
             "cpu_baseline": cb,
         }

@@ -426,7 +426,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
 
     const size_t n_batches = batches.size();
     std::atomic<size_t> next{0};
-    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_submit{0};
+    std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_submit{0}, b_comp{0}, b_inf{0};
     std::atomic<int> declined{0};
     std::vector<uint64_t> chain_first(n_batches, UINT64_MAX), chain_next(n_batches, UINT64_MAX);   // no-index: virtual offsets
     std::vector<uint64_t> key_first(n_batches, 0), key_last(n_batches, 0);                         // order of the first runs across batches
@@ -540,7 +540,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
             us_submit += now_us() - t_b;
             if (!ok) break;
-            n_dev += res.n_reads;
+            n_dev += res.n_reads; b_comp += pos; b_inf += uo;
             if (res.n_first) { key_first[bi] = res.first_key; key_last[bi] = res.last_key; key_have[bi] = 1; if (res.unsorted) order_broken = 1; }
             { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
             auto voff_of = [&](uint64_t u) -> uint64_t {      // inflated offset of the batch -> virtual file offset
@@ -604,10 +604,11 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     }
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders, %llu records on the device, %llu units handed back (%llu records on the host)%s; "
-                        "feeder thread-seconds: read+scan %.2f, submit %.2f; device ms summed over batches: H2D %.1f, inflate %.1f, walk %.1f, emit %.1f\n",
+                        "feeder thread-seconds: read+scan %.2f, submit %.2f; device ms summed over batches: H2D %.1f, inflate %.1f, walk %.1f, emit %.1f; "
+                        "bytes: compressed %llu, inflated %llu\n",
                 n_batches, guess ? "no index: guessed starts" : spans.synthetic ? "index cuts" : "index chunks of the targets", feeders,
                 (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(), (unsigned long long)n_host.load(), declined.load() ? " — DECLINED" : "",
-                us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3]);
+                us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3], (unsigned long long)b_comp.load(), (unsigned long long)b_inf.load());
     if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
     if (declined.load()) { api->decode_abort(eng->ctx); return 0; }          // nothing of this input has been counted
     if (!backlog.empty()) {

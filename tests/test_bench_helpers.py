@@ -20,3 +20,18 @@ def test_bam_contigs_reads_a_header_that_spans_members(tmp_path):
     got_names, got_lens = bench._bam_contigs(bam)
     assert got_names == names
     assert got_lens == [int(x) for x in lens]
+
+
+def test_parse_timing_reads_the_executables_diagnostics():
+    """bench.py's e2e.phases_s / e2e.roofline come from the PANDEPTH_TIMING lines of the timed run (host/pipeline.cpp)."""
+    import bench
+    err = ("[timing] options + header                0.002 s   (total 0.002 s)\n"
+           "[timing] engine create                   0.093 s   (total 0.101 s)\n"
+           "[timing] device decode: 498 batches (index cuts), 6 feeders, 300000000 records on the device, 0 units handed back (0 records on the host); "
+           "feeder thread-seconds: read+scan 1.20, submit 3.10; device ms summed over batches: H2D 400.5, inflate 3000.2, walk 90.1, emit 40.0; "
+           "bytes: compressed 15900000000, inflated 99000000000\n"
+           "[timing] decode + scatter                0.745 s   (total 0.846 s)\n")
+    ph, dec = bench.parse_timing(err)
+    assert ph["engine create"] == 0.093 and ph["decode + scatter"] == 0.745 and ph["total_in_main"] == 0.846
+    assert dec["batches"] == 498 and dec["feeders"] == 6 and dec["records_on_device"] == 300000000
+    assert dec["device_ms_summed"]["inflate"] == 3000.2 and dec["inflated_bytes"] == 99000000000 and dec["compressed_bytes"] == 15900000000
