@@ -44,6 +44,9 @@ def sample(r, k, n=20000):
     return np.concatenate([iv, np.tile(np.array([[0, 10 + k + r, 50]], dtype=np.int32), (500, 1)),
                            np.tile(np.array([[0, 8190, 8200 + r]], dtype=np.int32), (40, 1)),
                            np.tile(np.array([[1, 16380 + r, 16390 + r]], dtype=np.int32), (30, 1))])
+_b = np.repeat(np.arange(1000, 451000, 3, dtype=np.int32), 10)
+OVER = np.ascontiguousarray(np.stack([np.zeros_like(_b), _b, _b + 100], axis=1))
+assert int(LENS[0]) > 452000
 results, errors = {}, []
 def rank_main(rank):
     try:
@@ -61,12 +64,12 @@ def rank_main(rank):
                 e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
                 res.append(c.run(8192, 2, 18, 0))
             elif mode == "overflow":
-                # more cells outside the 4-bit range than the exception block holds (2^18): ten reads start on every base of
-                # 300 000 bases on rank 0 -> every rank gets PD_ERANGE, no sample is consumed, the contexts still add up
+                # more cells outside the 4-bit range than the exception block holds (2^18): ten reads start on every third base
+                # of 450 000 bases on rank 0 (+10 at 150 000 cells, -10 at 150 000 others: the ends fall on another residue, nothing
+                # cancels) -> every rank gets PD_ERANGE, no sample is consumed, the contexts still add up
                 e.set_param("direct_windows", 1)
                 if rank == 0:
-                    b = np.repeat(np.arange(1000, 301000, dtype=np.int32), 10)
-                    iv = np.stack([np.zeros_like(b), b, b + 100], axis=1)
+                    iv = OVER
                 else:
                     iv = sample(rank, 0); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
                 e.push_intervals(np.ascontiguousarray(iv), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
@@ -100,10 +103,8 @@ if mode == "pipeline":
 else:
     for r in range(world):
         assert results[r][0] == -6, (r, results[r][0])            # PD_ERANGE on every rank
-    b = np.repeat(np.arange(1000, 301000, dtype=np.int32), 10)
-    iv0 = np.stack([np.zeros_like(b), b, b + 100], axis=1)
     for r in range(world):
-        iv = iv0 if r == 0 else sample(r, 0)
+        iv = OVER if r == 0 else sample(r, 0)
         d, off = oracle_depth(LENS, iv, True)
         cov, tot = windows_ref(LENS, d, off, 8192, 1)
         assert np.array_equal(results[r][1][1], cov) and np.array_equal(results[r][1][2], tot), r
