@@ -543,10 +543,19 @@ def main():
     # (no arrays on any rank); the reduce-to-rank-0 forms need the arrays
     direct = os.environ.get("PD_BENCH_PATH", "direct") == "direct" and (not use_dist or sliced is not None)
     eng.set_param("direct_windows", 1 if direct else 0)
+    # the sorted stream in the engine's compact form (pd_runs_create: 8 bytes per run + exact tile bounds) — what pd_decode_end
+    # leaves for the whole-contig modes (PD_DECODE_COMPACT), made once before the timed region like the rest of the resident input
+    runs8 = None
+    if direct and os.environ.get("PD_BENCH_COMPACT", "1") == "1":
+        runs8 = eng.runs_create(first.data_ptr(), n_first)
+    used_compact = runs8 is not None
 
     def scatter():
         eng.reset()
-        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        if runs8 is not None and direct:
+            eng.push_runs(runs8, pda.PD_PUSH_MORE)
+        else:
+            eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN)
                                   | (pda.PD_PUSH_MORE if direct else 0))
 
@@ -757,6 +766,8 @@ def main():
                     configs[which] = {"failed": repr(ex)[:300]}
         if world == 1 and args.e2e_records > 0:
             try:
+                if runs8 is not None:
+                    eng.reset(); eng.runs_destroy(runs8); runs8 = None
                 eng.close()                                        # the CLI makes its own context on this GPU
                 del first, other                                   # ... and the bench sample's 13 GB of runs go too
                 torch.cuda.empty_cache()
@@ -778,7 +789,8 @@ def main():
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)")) if direct
+                       "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)") +
+                                (" — sorted stream resident in the compact form (8 B/run, exact tile bounds), as pd_decode_end leaves it" if used_compact else "")) if direct
                                else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum behind the C-ABI (pd_sliced_sum_start / _finish: RCCL grouped send/recv of 4-bit slices issued by the library), every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
@@ -799,6 +811,8 @@ def main():
             sliced.close()                      # the communicator goes before the context it belongs to and before the process group
         dist.destroy_process_group()
     if eng.h:
+        if runs8 is not None:
+            eng.reset(); eng.runs_destroy(runs8)
         eng.close()
 
 

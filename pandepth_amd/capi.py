@@ -54,6 +54,9 @@ def load():
         "pd_reset": (I, [P]),
         "pd_push_intervals": (I, [P, P, SZ, U]),
         "pd_push_intervals_device": (I, [P, P, SZ, U]),
+        "pd_runs_create": (I, [P, P, SZ, ctypes.POINTER(P)]),
+        "pd_runs_destroy": (I, [P]),
+        "pd_push_runs": (I, [P, P, U]),
         "pd_stage_acquire": (I, [P, ctypes.POINTER(P), ctypes.POINTER(SZ)]),
         "pd_stage_submit": (I, [P, P, SZ, U]),
         "pd_set_param": (I, [P, ctypes.c_char_p, U64]),
@@ -99,7 +102,7 @@ def load():
 
 
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
-           "pd_push_intervals_device", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
+           "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
            "pd_read_depth", "pd_format_sites", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
@@ -237,6 +240,18 @@ class Engine:
 
     def push_intervals_device(self, dev_ptr, n, flags=PD_PUSH_DEFAULT):
         self._ck(self.L.pd_push_intervals_device(self.h, ctypes.c_void_p(int(dev_ptr)), int(n), int(flags)))
+
+    def runs_create(self, dev_ptr, n):
+        """A device-resident batch sorted by (tid, beg) as a compact sample (pd_runs_create); PdError(-1) if it is not sorted."""
+        h = ctypes.c_void_p()
+        self._ck(self.L.pd_runs_create(self.h, ctypes.c_void_p(int(dev_ptr)), int(n), ctypes.byref(h)))
+        return h
+
+    def runs_destroy(self, runs):
+        self._ck(self.L.pd_runs_destroy(runs))
+
+    def push_runs(self, runs, flags=PD_PUSH_MORE):
+        self._ck(self.L.pd_push_runs(self.h, runs, int(flags)))
 
     def scan(self, wrap_bits=0):
         self._ck(self.L.pd_scan(self.h, int(wrap_bits)))

@@ -47,9 +47,18 @@ struct Stage {
 
 struct ProfRec { std::string name; hipEvent_t a, b; };
 
-struct Pending { const pd_iv *iv; uint32_t n; uint32_t disorder; int slot; };   // slot: staging slot or -1
+struct Pending { const pd_iv *iv; uint32_t n; uint32_t disorder; int slot; pd_runs *cr = nullptr; };   // slot: staging slot or -1; cr: a compact sample (iv NULL until expanded)
 
 } // namespace
+
+// a sorted sample in the compact form (include/pandepth_amd.h: pd_runs_create)
+struct pd_runs {
+    pd_ctx *ctx = nullptr;
+    Run8 *r8 = nullptr; uint32_t n = 0;
+    uint32_t *tile_first = nullptr, *look_first = nullptr;      // n_tiles + 1 entries each
+    uint32_t lmax = 0; uint32_t n_long = 0;
+    pd_iv *iv12 = nullptr;                                       // the expanded copy, made on first need
+};
 
 struct pd_ctx {
     int device = 0;
@@ -94,6 +103,7 @@ struct pd_ctx {
     pd_decode_cfg dec_cfg{}; uint8_t *d_contig_on = nullptr; uint32_t *d_span_off = nullptr; int32_t *d_spans = nullptr;
     std::vector<RunSeg> run_segs;
     pd_iv *run_first = nullptr, *run_other = nullptr, *run_far = nullptr;   // the concatenated sample (owned until the next reset)
+    pd_runs *dec_runs = nullptr;                                  // ... its first runs as a compact sample (PD_DECODE_COMPACT)
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
@@ -208,10 +218,26 @@ int ensure_all_valid(pd_ctx *c)
     return PD_OK;
 }
 
+// a compact pending batch that has to take a path that reads 12-byte runs: expanded once (the copy stays with the sample)
+int expand_compact(pd_ctx *c, Pending &p)
+{
+    if (!p.cr || p.iv) return PD_OK;
+    pd_runs *r = p.cr;
+    if (!r->iv12) {
+        if (hipMalloc(&r->iv12, (size_t)r->n * sizeof(pd_iv)) != hipSuccess) return fail(c, PD_ENOMEM, "compact sample: allocation of the expanded runs failed");
+        ProfScope ps(c, "expand_runs");
+        launch_expand_runs(c->stream, r->r8, r->tile_first, c->d_tile_contig, (uint32_t)c->n_tiles, r->iv12);
+        HIPOK(c, hipGetLastError());
+    }
+    p.iv = r->iv12;
+    return PD_OK;
+}
+
 // one owner-tile pass over all pending sorted batches
 int flush_pending(pd_ctx *c)
 {
     if (c->pend.empty()) return PD_OK;
+    for (auto &p : c->pend) { const int re = expand_compact(c, p); if (re) return re; }
     if (c->sums_stale) {                      // a direct export wrote this (still deferred) sample's tile sums; the scatter adds to them
         HIPOK(c, hipMemsetAsync(c->sums, 0, (c->n_words - c->n_cells) * 4, c->stream));
         c->sums_stale = false;
@@ -232,7 +258,7 @@ int flush_pending(pd_ctx *c)
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
         ProfScope sc(c, "scatter_index");
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample, c->ub_a[b], c->cand_lo[b],
                              n_stiles, c->stile, c->desc + b);
@@ -451,6 +477,9 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     return PD_OK;
 }
 
+static void runs_free(pd_runs *r);
+static int runs_make(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out);
+
 int pd_destroy(pd_ctx *c)
 {
     if (!c) return PD_OK;
@@ -483,6 +512,7 @@ int pd_destroy(pd_ctx *c)
         if (r.far && !ina(r.far)) (void)hipFree(r.far);
     }
     for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
+    runs_free(c->dec_runs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -505,9 +535,10 @@ int pd_reset(pd_ctx *c)
     c->pend.clear();
     c->state = 0;
     int rc = do_reset(c);
-    if (rc == PD_OK && (c->run_first || c->run_other || c->run_far)) {          // the decoded sample's runs go with it
+    if (rc == PD_OK && (c->run_first || c->run_other || c->run_far || c->dec_runs)) {          // the decoded sample's runs go with it
         HIPOK(c, hipStreamSynchronize(c->stream));
         for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        runs_free(c->dec_runs); c->dec_runs = nullptr;
     }
     return rc;
 }
@@ -530,6 +561,78 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
+}
+
+static void runs_free(pd_runs *r)
+{
+    if (!r) return;
+    for (void *q : {(void *)r->r8, (void *)r->tile_first, (void *)r->look_first, (void *)r->iv12}) if (q) (void)hipFree(q);
+    delete r;
+}
+
+// caller holds c->mu and has set the device
+static int runs_make(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out)
+{
+    *out = nullptr;
+    if (n == 0 || n > DEV_BATCH_MAX) return fail(c, PD_EINVAL, "pd_runs_create: between 1 and 2^32 - 256 runs");
+    pd_runs *r = new pd_runs;
+    r->ctx = c; r->n = (uint32_t)n; r->lmax = c->lmax;
+    uint32_t *words = nullptr;
+    const size_t nt = (size_t)c->n_tiles + 1;
+    if (hipMalloc(&r->r8, n * sizeof(Run8)) != hipSuccess || hipMalloc(&r->tile_first, nt * 4 + 16) != hipSuccess ||
+        hipMalloc(&r->look_first, nt * 4 + 16) != hipSuccess || hipMalloc(&words, 16) != hipSuccess) {
+        (void)hipGetLastError(); runs_free(r); if (words) (void)hipFree(words);
+        return fail(c, PD_ENOMEM, "pd_runs_create: allocation failed");
+    }
+    uint32_t h[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(words, 0, 16, c->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(c, "compact_runs");
+        launch_compact_runs(c->stream, dev_iv, r->n, tab_of(c), c->d_tile_contig, r->lmax, (uint32_t)c->n_tiles, r->r8, r->tile_first, r->look_first, words);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(words);
+    if (e != hipSuccess) { runs_free(r); return fail(c, PD_EHIP, std::string("pd_runs_create: ") + hipGetErrorString(e)); }
+    if (h[0]) { runs_free(r); return fail(c, PD_EINVAL, "pd_runs_create: the batch is not sorted by (tid, beg), or holds a contig id out of range"); }
+    r->n_long = h[1];
+    *out = r;
+    return PD_OK;
+}
+
+int pd_runs_create(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out)
+{
+    if (!c || !dev_iv || !out) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    return runs_make(c, dev_iv, n, out);
+}
+
+int pd_runs_destroy(pd_runs *r)
+{
+    if (!r) return PD_OK;
+    pd_ctx *c = r->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    for (auto &p : c->pend) if (p.cr == r) return fail(c, PD_ESTATE, "pd_runs_destroy: the sample is still deferred on its context (pd_reset first)");
+    (void)hipStreamSynchronize(c->stream);
+    runs_free(r);
+    return PD_OK;
+}
+
+int pd_push_runs(pd_ctx *c, const pd_runs *runs, unsigned flags)
+{
+    if (!c || !runs || runs->ctx != c || (flags & ~PD_PUSH_MORE)) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rs = need_state(c, 0, "pd_push_runs")) return rs;
+    HIPOK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);                 // a compact sample is the first batch of its pass
+    if (rc) return rc;
+    Pending p{nullptr, runs->n, 0u, -1};
+    p.cr = const_cast<pd_runs *>(runs);
+    c->pend.push_back(p);
+    return (flags & PD_PUSH_MORE) ? PD_OK : flush_pending(c);
 }
 
 int pd_push_intervals_device(pd_ctx *c, const pd_iv *dev_iv, size_t n, unsigned flags)
@@ -682,10 +785,20 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     PendSet ps{};
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     uint64_t all = 0;
+    // a compact sample serves wide windows as batch 0 (k_direct_wide3's C8 form); anywhere else it goes on as 12-byte runs
+    for (int b = 0; b < ps.nb; ++b) {
+        Pending &p = c->pend[b];
+        if (p.cr && !p.iv && (b != 0 || w < PD_TILE || p.cr->n_long)) { const int re = expand_compact(c, p); if (re) return re; }
+    }
     for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
         all += p.n;
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
+        if (p.cr && !p.iv) {
+            ps.b[b] = PendBatch{nullptr, p.cr->tile_first, p.cr->look_first, c->desc + b, p.n, 0, p.cr->r8};
+            launch_desc_all_tiles(c->stream, c->desc + b, (uint32_t)c->n_tiles);
+            continue;
+        }
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
         ProfScope sc(c, "scatter_index");
         // a 4x sparser index than the arrays path's: measured neutral for the tile kernel, 0.43 -> 0.13 ms of index
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->direct_sample, c->ub_a[b],
@@ -1168,12 +1281,13 @@ int pd_decode_end(pd_ctx *c)
     for (auto &r : segs) { nf += r.n_first; no += r.n_other; nfar += r.n_far; if (r.max_span > span) span = r.max_span; }
     auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
     auto drop = [&]() { for (auto &r : segs) for (pd_iv *q : {r.first, r.other, r.far}) if (q && !in_arena(q)) (void)hipFree(q); };
-    if (c->run_first || c->run_other || c->run_far) {
+    if (c->run_first || c->run_other || c->run_far || c->dec_runs) {
         // an earlier sample of this context (#.list: one file after another) may still be deferred on these arrays
         int rf = flush_pending(c);
         if (rf) { drop(); return rf; }
         HIPOK(c, hipStreamSynchronize(c->stream));
         for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        runs_free(c->dec_runs); c->dec_runs = nullptr;
     }
     if ((nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) || (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) ||
         (nfar && hipMalloc(&c->run_far, (size_t)nfar * sizeof(pd_iv)) != hipSuccess)) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
@@ -1209,6 +1323,19 @@ int pd_decode_end(pd_ctx *c)
     // otherwise by the longest gap seen, like the far stream)
     const uint32_t near_dis = nfar ? (c->dec_near_span < span ? c->dec_near_span : span) : span;
     const bool near_sorted = sorted && near_dis <= (1u << 14), far_sorted = sorted && span <= (1u << 14);
+    if (nf && sorted && (c->dec_cfg.flags & PD_DECODE_COMPACT) && c->pend.empty() && nf <= DEV_BATCH_MAX) {
+        // the whole-contig modes: the first runs stay as a compact sample (8 bytes per run + exact tile bounds; the conversion
+        // reads the 12-byte runs once and checks their order again), the 12-byte copy goes
+        pd_runs *r = nullptr;
+        if (runs_make(c, c->run_first, (size_t)nf, &r) == PD_OK) {
+            (void)hipFree(c->run_first); c->run_first = nullptr;
+            c->dec_runs = r;
+            Pending p{nullptr, r->n, 0u, -1};
+            p.cr = r;
+            c->pend.push_back(p);
+            nf = 0;
+        }
+    }
     if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE) : PD_PUSH_DEFAULT, -1, nullptr);
     if (rc == PD_OK && no) rc = scatter_device(c, c->run_other, (size_t)no, near_sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(near_dis + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
     if (rc == PD_OK && nfar) rc = scatter_device(c, c->run_far, (size_t)nfar, far_sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(span + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
@@ -1431,9 +1558,18 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     uint64_t all = 0;
     for (int b = 0; b < ps.nb; ++b) {
+        Pending &p = c->pend[b];
+        if (p.cr && !p.iv && (b != 0 || p.cr->n_long)) { const int re = expand_compact(c, p); if (re) return re; }
+    }
+    for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
         all += p.n;
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
+        if (p.cr && !p.iv) {
+            ps.b[b] = PendBatch{nullptr, p.cr->tile_first, p.cr->look_first, c->desc + b, p.n, 0, p.cr->r8};
+            launch_desc_all_tiles(c->stream, c->desc + b, (uint32_t)c->n_tiles);
+            continue;
+        }
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
         ProfScope sc(c, "scatter_index");
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample < 256 ? 256 : c->sample, c->ub_a[b],
                              c->cand_lo[b], (uint32_t)c->n_tiles, PD_TILE, c->desc + b);

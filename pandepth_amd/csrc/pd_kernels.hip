@@ -696,7 +696,13 @@ __device__ unsigned long long g_wide3_ticks[16];
 #else
 #define W3_TICK(k) do { } while (0)
 #endif
-template <int UN, int WPE, bool EXPORT>
+//   * C8 (round 3): batch 0 of the set is a COMPACT sample (Run8, pd_runs_create): 8 bytes per run, coordinates clamped when
+//     the sample was made, and EXACT tile bounds — a tile's own runs are [tile_first[t], tile_first[t + 1]), every one of them
+//     begins in the tile (no owner test, the owner count is an index difference), and the look-back candidates before them are
+//     exactly the runs of the same contig that begin within lmax cells of the tile.  No contig compare, no clamps, no empty-run
+//     test (a run without cells adds and subtracts at the same cell): 13 vector instructions per run instead of 26, a third
+//     fewer bytes, no candidates that belong to other tiles.  UN8 = its loads in flight per thread.
+template <int UN, int WPE, bool EXPORT, bool C8 = false, int UN8 = 4>
 __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
                                                         uint32_t *heavy_list, uint32_t *heavy_count, const DirectExport ex)
@@ -710,6 +716,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
     __shared__ uint32_t s_lo[PD_MAXPEND], s_hi[PD_MAXPEND];
+    __shared__ uint32_t s_mid;                                   // C8: first run that begins in the tile (tile_first[t])
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t n_beg_s = 0; int open_s = 0;                        // owner / open counts: wave-uniform (scalar popcounts of compare masks)
     // the batches' active tile ranges and run arrays do not change from tile to tile; the candidate bounds of the NEXT tile
@@ -732,14 +739,22 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
         }
     };
-    uint32_t nlo = 0, nhi = 0;
+    uint32_t nlo = 0, nhi = 0, nmid = 0;
+    auto mid_of = [&](const uint64_t t, const uint32_t lo, const uint32_t hi) -> uint32_t {   // thread 0, compact batch: tile_first[t], inside [lo, hi]
+        if (t >= n_tiles) return 0u;
+        uint32_t m = ps.b[0].ub_a[t];
+        if (m < lo) m = lo;
+        return m > hi ? hi : m;
+    };
     if (threadIdx.x < PD_MAXPEND) bounds(blockIdx.x, nlo, nhi);
+    if (C8 && threadIdx.x == 0) nmid = mid_of(blockIdx.x, nlo, nhi);
 #ifdef PD_WIDE3_TICKS
     long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (long long)clock64();
 #endif
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t a = t * ST;
         if (threadIdx.x < PD_MAXPEND) { s_lo[threadIdx.x] = nlo; s_hi[threadIdx.x] = nhi; }
+        if (C8 && threadIdx.x == 0) s_mid = nmid;
         uint4 *w4 = reinterpret_cast<uint4 *>(win);
         for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x == 0) s_carry = 0;
@@ -750,6 +765,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         __syncthreads();
         W3_TICK(1);                                               // barrier 1
         if (threadIdx.x < PD_MAXPEND) bounds(t + gridDim.x, nlo, nhi);
+        if (C8 && threadIdx.x == 0) nmid = mid_of(t + gridDim.x, nlo, nhi);
         uint32_t cand = 0;
         for (int b = 0; b < ps.nb; ++b) cand += s_hi[b] - s_lo[b];
         if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
@@ -791,6 +807,58 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             carry_s += __builtin_popcountll(m_mine & m_ne & m_cov);
         };
 #undef PD_B
+        if constexpr (C8) {
+            // ---- the compact stream: [lo, mid) may end in the tile, [mid, hi) begin in it.  One event pair per run:
+            //   sb = b - p0 (mod 2^32): < ST exactly for the tile's own runs;  se = sb + len: < ST when the end lies in the tile;
+            //   se < len exactly when the run begins before the tile and reaches its first cell or further (the carry-in).
+            const uint32_t lo = s_lo[0], hi = s_hi[0];
+            if (wv == 0) { const uint32_t own = hi - s_mid; n_beg_s += own; open_s += (int)own; }
+            const Run8 *__restrict__ p = ps.b[0].r8;
+            constexpr uint32_t C = UN8 * WG;
+            auto load8 = [&](uint2 (&dst)[UN8], const uint32_t i) {
+                const uint32_t last = hi - 1u;
+#pragma unroll
+                for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (j < last ? j : last)); }
+            };
+            int ends_s = 0;
+            auto ev8 = [&](const uint32_t b, const uint32_t len) {
+                const uint32_t sb = b - p0, se = sb + len;
+                const unsigned long long m_e = __builtin_amdgcn_ballot_w64(se < ST), m_c = __builtin_amdgcn_ballot_w64(se < len);
+                if (sb < ST) atomicAdd(&win[sb & (HT - 1u)], 1u + (sb >> 12) * 0xFFFFu);
+                if (se < ST) atomicSub(&win[se & (HT - 1u)], 1u + (se >> 12) * 0xFFFFu);
+                ends_s += __builtin_popcountll(m_e);
+                carry_s += __builtin_popcountll(m_c);
+            };
+            auto work8 = [&](const uint2 (&c)[UN8], const uint32_t i) {
+                const uint32_t left = hi - i;
+                if (left >= C) {
+#pragma unroll
+                    for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
+                } else {                                          // the tail chunk: slots past the end become runs outside the tile
+                    const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
+#pragma unroll
+                    for (int k = 0; k < UN8; ++k) if (k < nu) {
+                        const bool in = threadIdx.x + k * WG < left;
+                        ev8(in ? c[k].x : p0 + ST, in ? c[k].y : 0u);
+                    }
+                }
+            };
+            if (lo < hi) {
+                uint2 A[UN8], B[UN8];
+                uint32_t i = lo;
+                load8(A, i);
+#pragma unroll 1
+                for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
+                    if (i + C < hi) load8(B, i + C);
+                    work8(A, i);
+                    i += C; if (i >= hi) break;
+                    if (i + C < hi) load8(A, i + C);
+                    work8(B, i);
+                    i += C; if (i >= hi) break;
+                }
+            }
+            open_s -= ends_s;
+        }
         // chunks of UN x WG candidates, stream after stream; the loads of chunk k + 1 (same stream or the next one) are in
         // flight while chunk k is worked on
         {
@@ -800,7 +868,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
 #pragma unroll
                 for (int k = 0; k < UN; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = p[j < last ? j : last]; }
             };
-            int b = 0;
+            int b = C8 ? 1 : 0;
             while (b < ps.nb && s_lo[b] >= s_hi[b]) ++b;
             uint32_t i = b < ps.nb ? s_lo[b] : 0u;
             pd_iv cur[UN];
@@ -841,35 +909,55 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         __syncthreads();
         W3_TICK(3);                                               // barrier 2
         if constexpr (EXPORT) {                                   // the multi-GPU sum's 4-bit image (pd_export_i4)
-            // k_export_i4's layout: one ushort per 4 cells (nibble d + 8), 128 contiguous bytes per wave store; the low
-            // half-tile's cells sit in the low 16 bits of the window's words, the high half-tile's in the high 16 bits
-            unsigned short *o_lo = ex.img + a / 4 + (uint64_t)(wv * (ROWS * 64) + lane), *o_hi = o_lo + HT / 4;
+            // k_export_i4's layout: one nibble (d + 8) per cell, cell 2k in the low half of byte k.  A lane packs the 4 cells of
+            // each of its 4 rows to 16 bits per half-tile; the 8 halfwords go through the wave's OWN part of the window (its
+            // words are in registers by then, nobody else touches them before the next tile's barrier) and come back as one
+            // 16-byte piece per lane — lanes 0..31 the wave's 512 bytes of the low half-tile's image, lanes 32..63 those of
+            // the high half-tile's — so a wave stores its 1 KiB with ONE 16-byte store per lane (it was eight 2-byte stores).
             int tsum = 0;                                         // packed: sum over the lane's words
+            unsigned short hw[2 * ROWS];
+            uint4 q4[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) q4[r] = w4[wv * (ROWS * 64) + r * 64 + lane];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-                const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
-                const unsigned wq[4] = {q.x, q.y, q.z, q.w};
+                const unsigned wq[4] = {q4[r].x, q4[r].y, q4[r].z, q4[r].w};
                 unsigned wl = 0, wh = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     tsum += (int)wq[k];
                     int xl = (int)(short)(wq[k] & 0xffffu), xh = ((int)wq[k] - xl) >> 16;
-                    const uint64_t cell = a + (uint64_t)(wv * (ROWS * 256) + r * 256 + lane * 4 + k);
-                    if (xl > 7 || xl < -8) {
-                        const uint32_t slot = atomicAdd(ex.count, 1u);
-                        if (slot < ex.cap) { ex.exc[slot].cell = cell; ex.exc[slot].value = xl; ex.exc[slot].pad = 0; }
-                        xl = 0;
-                    }
-                    if (xh > 7 || xh < -8) {
-                        const uint32_t slot = atomicAdd(ex.count, 1u);
-                        if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
-                        xh = 0;
+                    if ((unsigned)(xl + 8) > 15u || (unsigned)(xh + 8) > 15u) {        // rare: a cell outside [-8, 7]
+                        const uint64_t cell = a + (uint64_t)(wv * (ROWS * 256) + r * 256 + lane * 4 + k);
+                        if ((unsigned)(xl + 8) > 15u) {
+                            const uint32_t slot = atomicAdd(ex.count, 1u);
+                            if (slot < ex.cap) { ex.exc[slot].cell = cell; ex.exc[slot].value = xl; ex.exc[slot].pad = 0; }
+                            xl = 0;
+                        }
+                        if ((unsigned)(xh + 8) > 15u) {
+                            const uint32_t slot = atomicAdd(ex.count, 1u);
+                            if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
+                            xh = 0;
+                        }
                     }
                     wl |= (unsigned)((xl + 8) & 0xf) << (4 * k);
                     wh |= (unsigned)((xh + 8) & 0xf) << (4 * k);
                 }
-                o_lo[r * 64] = (unsigned short)wl;
-                o_hi[r * 64] = (unsigned short)wh;
+                hw[r] = (unsigned short)wl; hw[ROWS + r] = (unsigned short)wh;
+            }
+            {
+                // staging: halfword index r * 64 + lane of the low image, ROWS * 64 + the same of the high image (1 KiB per wave)
+                unsigned short *stg = reinterpret_cast<unsigned short *>(win + wv * (ROWS * 256));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the window reads above are complete (registers) before the overwrite
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) { stg[r * 64 + lane] = hw[r]; stg[ROWS * 64 + r * 64 + lane] = hw[ROWS + r]; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 piece = reinterpret_cast<const uint4 *>(stg)[lane];
+                // lanes 0..31: low half-tile, bytes [a / 2 + wv * 512, + 512); lanes 32..63: high half-tile, HT / 2 bytes further
+                unsigned char *img = reinterpret_cast<unsigned char *>(ex.img);
+                const uint64_t at = a / 2 + (uint64_t)wv * (ROWS * 128) + (lane < 32 ? (uint64_t)lane * 16 : (uint64_t)(HT / 2) + (uint64_t)(lane - 32) * 16);
+                *reinterpret_cast<uint4 *>(img + at) = piece;
             }
             tsum = wave_total(tsum);                              // packed 65536 * H + L over the wave (|H|, |L| <= 32 000)
             if (lane == 0) wtot[wv] = tsum;
@@ -1061,13 +1149,15 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
             uint32_t hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
             uint32_t lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
             const pd_iv *__restrict__ iv = ps.b[b].iv;
+            const Run8 *__restrict__ r8 = ps.b[b].r8;             // a compact batch: the tile's contig, coordinates inside it
             constexpr int UN = 4;
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += UN * WG) {
                 pd_iv vv[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
                     const uint32_t i = i0 + u * WG;
-                    vv[u] = iv[i < hi ? i : hi - 1];
+                    if (r8) { const Run8 r = r8[i < hi ? i : hi - 1]; vv[u] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
+                    else vv[u] = iv[i < hi ? i : hi - 1];
                     if (i >= hi) vv[u].tid = -1;
                 }
 #pragma unroll
@@ -1213,6 +1303,80 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
     }
     if (threadIdx.x == 0 && s_long) atomicAdd(n_long, s_long);
 }
+
+// ------------------------------------------------------------------------------------------
+// compact samples (pd_runs_create / pd_push_runs)
+// ------------------------------------------------------------------------------------------
+// One pass over a batch that is promised to be sorted by flat begin: the runs leave as Run8 (clamped begin inside the contig,
+// length), every tile learns the index of its first run (exact: thread i writes the tiles between its predecessor's and its
+// own), the same with the threshold moved back by lmax for the look-back bound, and the promise is CHECKED (words[0] != 0:
+// an invalid contig id or a run that begins before its predecessor; words[1]: runs longer than lmax, whose ends the look-back
+// would miss — such a sample is not used in this form).
+__global__ __launch_bounds__(WG) void k_compact_runs(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax, uint32_t n_tiles,
+                                                     Run8 *out, uint32_t *tile_first, uint32_t *look_first, uint32_t *words)
+{
+    const uint64_t i64 = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint32_t i = i64 < n ? (uint32_t)i64 : n - 1;
+    auto flat = [&](const pd_iv v, uint32_t &b, uint32_t &len, bool &valid) -> uint64_t {
+        valid = v.tid >= 0 && v.tid < tab.n;
+        b = 0; len = 0;
+        if (!valid) return 0;
+        const uint32_t clen = tab.len[v.tid];
+        b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
+        uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+        len = x > b ? x - b : 0u;
+        return tab.off[v.tid] + b;
+    };
+    uint32_t b, len; bool valid;
+    const uint64_t gb = flat(iv[i], b, len, valid);
+    // the predecessor's flat begin: the left lane's value, except for a wave's first lane
+    uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(gb >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)gb, 1);
+    bool pvalid = __shfl_up((int)valid, 1) != 0;
+    if ((threadIdx.x & 63) == 0 && i > 0) { uint32_t pb, pl; prev = flat(iv[i - 1], pb, pl, pvalid); }
+    if (i64 >= n) return;
+    if (!valid || (i > 0 && (!pvalid || gb < prev))) atomicOr(&words[0], 1u);
+    if (len > lmax) atomicAdd(&words[1], 1u);
+    out[i] = Run8{b, len};
+    const uint64_t T = (uint64_t)TILE;
+    const int64_t t_hi = (int64_t)(gb / T), t_lo = i > 0 ? (int64_t)(prev / T) : -1;
+    for (int64_t t = t_lo + 1; t <= t_hi && t <= (int64_t)n_tiles; ++t) tile_first[t] = i;
+    int64_t l_hi = (int64_t)((gb + lmax) / T), l_lo = i > 0 ? (int64_t)((prev + lmax) / T) : -1;
+    if (l_hi > (int64_t)n_tiles) l_hi = n_tiles;
+    if (l_lo > (int64_t)n_tiles) l_lo = n_tiles;
+    for (int64_t t = l_lo + 1; t <= l_hi; ++t) look_first[t] = i;
+    if (i == n - 1) {
+        for (int64_t t = t_hi + 1; t <= (int64_t)n_tiles; ++t) tile_first[t] = n;
+        for (int64_t t = l_hi + 1; t <= (int64_t)n_tiles; ++t) look_first[t] = n;
+    }
+}
+
+// the look-back never reaches into the previous contig (its runs would be read with the wrong origin): not before the first
+// run of the tile's own contig, whose slot starts on a tile boundary
+__global__ __launch_bounds__(WG) void k_compact_clip(const uint32_t *tile_first, uint32_t *look_first, const uint32_t *tile_contig,
+                                                     ContigTab tab, uint32_t n_tiles)
+{
+    const uint32_t t = blockIdx.x * WG + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t t0 = (uint32_t)(tab.off[tile_contig[t]] / (uint64_t)TILE);
+    const uint32_t f = tile_first[t0], m = tile_first[t];
+    uint32_t l = look_first[t];
+    if (l < f) l = f;
+    if (l > m) l = m;
+    look_first[t] = l;
+}
+
+// the reverse (a compact sample that has to take the general path after all): 12-byte runs, tile by tile
+__global__ __launch_bounds__(WG) void k_expand_runs(const Run8 *r8, const uint32_t *tile_first, const uint32_t *tile_contig,
+                                                    uint32_t n_tiles, pd_iv *out)
+{
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t lo = tile_first[t], hi = tile_first[t + 1];
+        const int32_t ctg = (int32_t)tile_contig[t];
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) { const Run8 r = r8[i]; out[i] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
+    }
+}
+
+__global__ void k_desc_all_tiles(BatchDesc *desc, uint32_t n_tiles) { desc->t_first = 0; desc->n_active = n_tiles; }
 
 // Outcome of a direct pass: *fail = 1 unless every batch was complete and sorted and no run was
 // longer than the look-back; re-arms the descriptors (the batches stay pending for the fallback).
@@ -1896,6 +2060,22 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     if (w < (uint32_t)TILE)
         hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
                            wrap_mask, dn, n_long, heavy_list, heavy_count);
+    else if (ps.nb > 0 && ps.b[0].r8) {      // batch 0 is a compact sample: the C8 instantiations (un: 100 x waves-per-SIMD target + 10 x loads in
+                                             // flight per thread of the compact stream + loads per thread of the other streams; 0 = default)
+#define PD_DIRECT8(UN_, WPE_, UN8_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_, false, true, UN8_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
+        switch (un) {
+        case 622: PD_DIRECT8(2, 6, 2); break;
+        case 642: PD_DIRECT8(2, 6, 4); break;
+        case 542: PD_DIRECT8(2, 5, 4); break;
+        case 582: PD_DIRECT8(2, 5, 8); break;
+        case 742: PD_DIRECT8(2, 7, 4); break;
+        case 842: PD_DIRECT8(2, 8, 4); break;
+        case 822: PD_DIRECT8(2, 8, 2); break;
+        case 641: PD_DIRECT8(1, 6, 4); break;
+        default: PD_DIRECT8(2, 6, 4); break;
+        }
+#undef PD_DIRECT8
+    }
     else if (un == 0 || un >= 3000) {        // second form (k_direct_wide3): 3000 + 100 x waves-per-SIMD target + loads in flight per thread
 #define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_, false>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
         // measured on the bench sample (ms; variants that were tried and are no longer compiled included): <2, 6> 3.08-3.13,
@@ -1918,6 +2098,24 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 
+void launch_compact_runs(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, const uint32_t *tile_contig, uint32_t lmax,
+                         uint32_t n_tiles, Run8 *out, uint32_t *tile_first, uint32_t *look_first, uint32_t *words)
+{
+    hipLaunchKernelGGL(k_compact_runs, dim3((unsigned)(((uint64_t)n + WG - 1) / WG)), dim3(WG), 0, st, iv, n, tab, lmax, n_tiles, out, tile_first,
+                       look_first, words);
+    hipLaunchKernelGGL(k_compact_clip, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const uint32_t *)tile_first, look_first, tile_contig, tab, n_tiles);
+}
+
+void launch_expand_runs(hipStream_t st, const Run8 *r8, const uint32_t *tile_first, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
+{
+    hipLaunchKernelGGL(k_expand_runs, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, r8, tile_first, tile_contig, n_tiles, out);
+}
+
+void launch_desc_all_tiles(hipStream_t st, BatchDesc *desc, uint32_t n_tiles)
+{
+    hipLaunchKernelGGL(k_desc_all_tiles, dim3(1), dim3(1), 0, st, desc, n_tiles);
+}
+
 void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
                           void *img, pd_exc *exc, uint32_t cap, uint32_t *count, int *sums, uint32_t *n_long, uint32_t *fail,
                           uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
@@ -1925,8 +2123,12 @@ void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, cons
     const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
     // the second form of the direct kernel with its export branch (the first form's export instantiation — 128 VGPRs and
     // 160 bytes of spills — took 5.2 ms per sample)
-    hipLaunchKernelGGL((k_direct_wide3<2, 5, true>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
-                       DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
+    if (ps.nb > 0 && ps.b[0].r8)
+        hipLaunchKernelGGL((k_direct_wide3<2, 5, true, true, 4>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+                           DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
+    else
+        hipLaunchKernelGGL((k_direct_wide3<2, 5, true>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+                           DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
     // tiles with more than 32 000 candidates: the int-window kernel exports them
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa,

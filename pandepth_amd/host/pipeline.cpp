@@ -402,6 +402,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     std::vector<uint32_t> soff; std::vector<int32_t> sflat;
     pd_decode_cfg cfg{};
     cfg.flag_mask = o.flag_mask; cfg.min_mapq = o.min_mapq; cfg.contig_on = on.data(); cfg.sorted = sorted ? 1 : 0;
+    // whole-contig statistics over windows of >= 8192 cells (mode 0's 10 Mb bins, -w >= 8192) read the sample once, in the
+    // engine's compact form; every other mode needs the arrays and keeps 12-byte runs
+    if (spans.synthetic && !o.site_out && (o.mode == 0 || (o.mode == 5 && o.win >= 8192))) cfg.flags |= PD_DECODE_COMPACT;
     { uint64_t b = 0; for (auto &v : batches) for (auto &r : v) b += ((r.vend == UINT64_MAX ? F : (r.vend >> 16)) - (r.vbeg >> 16)) + 65536; cfg.bytes_hint = std::min(b, 2 * F); }
     if (!spans.synthetic) {
         soff.assign(on.size() + 1, 0);

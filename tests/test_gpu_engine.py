@@ -758,3 +758,151 @@ def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
             assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref), form
             with pytest.raises(pda.PdError, match="direct"):
                 e.scan(wrap)                                      # consumed by the direct path, whichever form
+
+
+# ---------------------------------------------------------------------------------------------
+# compact samples (pd_runs_create / pd_push_runs): 8-byte runs + exact tile bounds, k_direct_wide3's C8 form
+# ---------------------------------------------------------------------------------------------
+def _hard_sample(seed, n=60000, long_run=False):
+    rng = np.random.default_rng(seed)
+    first, other = _split_streams(rng, LENS, n)
+    L0 = int(LENS[0])
+    hard = np.array([[0, -5, 40], [0, -1, 1], [0, 0, 0], [0, 8192, 8192], [0, 8000, 8192], [0, 8192, 16384], [0, 8191, 8193], [0, 16383, 16384],
+                     [0, L0 - 10, L0 + 7], [0, L0 - 1, L0], [0, L0, L0 + 3], [0, L0 + 5, L0 + 9], [1, -3, 5000], [1, 100, 100], [1, 90, 80],
+                     [4, 0, 8192], [4, 8191, 8192], [5, 0, 8191], [6, 8000, 8400], [7, 0, 3], [3, 0, 1]], dtype=np.int32)
+    pile = np.tile(np.array([[0, 300000, 300100]], dtype=np.int32), (40000, 1))
+    extra = [hard, pile]
+    if long_run:
+        extra.append(np.array([[0, 50000, 53000], [6, 100, 9000]], dtype=np.int32))      # longer than the look-back (512)
+    return sort_iv(np.concatenate([first] + extra)), other
+
+
+@pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (10000000, 0, 0), (16384, 1, 18), (250000, 2, 0)])
+def test_compact_sample_agrees_with_oracle_on_hard_tiles(w, min_dep, wrap):
+    """The compact form of the sorted stream through every compiled C8 variant of the wide direct kernel, against the oracle:
+    the pile-up tile (int-window kernel reading Run8), runs clipped at both ends of a contig, empty and reversed runs, ends on
+    tile edges, contigs of exactly one tile / one cell / 8191 cells, a second (12-byte, nearly sorted) stream beside it."""
+    import torch
+    dev = torch.device("cuda", 0)
+    first, other = _hard_sample(5100 + w % 97)
+    d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
+    cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
+    ft = torch.from_numpy(first).to(dev)
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        runs = e.runs_create(ft.data_ptr(), first.shape[0])
+        for un in (0, 622, 642, 542, 582, 742, 842, 822, 641):
+            e.set_param("direct_un", un)
+            e.reset()
+            e.push_runs(runs, pda.PD_PUSH_MORE)
+            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+            woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+            assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref), un
+        e.set_param("direct_un", 0)
+        # alone (no second stream), and pushed without PD_PUSH_MORE (scattered at once: the expanded copy)
+        d1, off1 = oracle_depth(LENS, first, wrap == 18)
+        c1, t1 = windows_ref(LENS, d1, off1, w, min_dep)
+        for flags in (pda.PD_PUSH_MORE, 0):
+            e.reset()
+            e.push_runs(runs, flags)
+            woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+            assert np.array_equal(cover, c1) and np.array_equal(tot, t1), flags
+        e.reset()
+        e.runs_destroy(runs)
+
+
+def test_compact_sample_takes_every_other_path_expanded():
+    """Whatever cannot read Run8 — narrow windows, pd_scan + per-base reads, a sample with runs longer than the look-back, an export
+    after such a sample — gets the 12-byte form back and the same answers; an unsorted batch is refused."""
+    import torch
+    dev = torch.device("cuda", 0)
+    first, other = _hard_sample(77)
+    both = np.concatenate([first, other])
+    ft = torch.from_numpy(first).to(dev)
+    with pda.Engine(LENS) as e:
+        e.set_param("direct_windows", 1)
+        runs = e.runs_create(ft.data_ptr(), first.shape[0])
+        for w, md, wrap in ((100, 1, 0), (1000, 2, 18), (64, 1, 0), (8191, 1, 0)):
+            d, off = oracle_depth(LENS, both, wrap == 18)
+            cr, tr = windows_ref(LENS, d, off, w, md)
+            e.reset()
+            e.push_runs(runs, pda.PD_PUSH_MORE)
+            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+            woff, cover, tot = e.scan_reduce_windows(w, md, wrap)
+            assert np.array_equal(cover, cr) and np.array_equal(tot, tr), (w, md, wrap)
+        d, off = oracle_depth(LENS, both, False)
+        e.reset()
+        e.push_runs(runs, pda.PD_PUSH_MORE)
+        e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        e.scan(0)
+        for t in range(len(LENS)):
+            assert np.array_equal(e.read_depth(t, 0, int(LENS[t])), d[off[t]:off[t] + LENS[t]]), t
+        e.reset()
+        e.runs_destroy(runs)
+        # runs longer than the look-back: the compact form is made, but the wide path expands it (and then declines to the arrays)
+        fl, ol = _hard_sample(78, long_run=True)
+        flt = torch.from_numpy(fl).to(dev)
+        runs = e.runs_create(flt.data_ptr(), fl.shape[0])
+        d, off = oracle_depth(LENS, np.concatenate([fl, ol]), True)
+        cr, tr = windows_ref(LENS, d, off, 10000, 1)
+        e.push_runs(runs, pda.PD_PUSH_MORE)
+        e.push_intervals(ol, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff, cover, tot = e.scan_reduce_windows(10000, 1, 18)
+        assert np.array_equal(cover, cr) and np.array_equal(tot, tr)
+        e.reset()
+        e.runs_destroy(runs)
+        # not sorted / a contig id out of range: refused, nothing is kept
+        bad = first.copy(); bad[[1000, 30000]] = bad[[30000, 1000]]
+        bt = torch.from_numpy(bad).to(dev)
+        with pytest.raises(pda.PdError, match="not sorted"):
+            e.runs_create(bt.data_ptr(), bad.shape[0])
+        bad = first.copy(); bad[500, 0] = len(LENS)
+        bt = torch.from_numpy(bad).to(dev)
+        with pytest.raises(pda.PdError):
+            e.runs_create(bt.data_ptr(), bad.shape[0])
+
+
+def test_compact_export_equals_export_of_the_arrays():
+    """pd_export_i4 on a compact deferred sample (the C8 export instantiation, 16-byte image stores): image, exception set and
+    tile sums equal to what the materialising path exports; the sample stays deferred."""
+    import torch
+    from pandepth_amd import multi
+    dev = torch.device("cuda", 0)
+    first, other = _hard_sample(402)
+    ft = torch.from_numpy(first).to(dev)
+    B = 8192
+
+    def export(e):
+        n_cells, n_sums = e.device_layout()
+        img = torch.zeros(n_cells // 2, dtype=torch.uint8, device=dev)
+        exc = torch.zeros((B, 2), dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.export_i4(img.data_ptr(), exc.data_ptr(), B, cnt.data_ptr())
+        e.synchronize()
+        return img, exc[:int(cnt.item())].cpu().numpy()
+
+    with pda.Engine(LENS) as ea, pda.Engine(LENS) as ed:
+        ea.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        ea.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(800))
+        img_a, exc_a = export(ea)
+        ed.set_param("direct_windows", 1)
+        runs = ed.runs_create(ft.data_ptr(), first.shape[0])
+        ed.push_runs(runs, pda.PD_PUSH_MORE)
+        ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        img_d, exc_d = export(ed)
+        assert torch.equal(img_a, img_d)
+        key = lambda x: sorted(map(tuple, x.tolist()))
+        assert len(exc_a) >= 2 and key(exc_a) == key(exc_d)
+        # tile sums through the sliced finish, and the sample is still there afterwards
+        ss = multi.SlicedSum(ea, dev); ss.start(0); ref = ss.finish(0, 10000, 1, 18)
+        sd = multi.SlicedSum(ed, dev)
+        ed.reset()
+        ed.push_runs(runs, pda.PD_PUSH_MORE)
+        ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        sd.start(0); got = sd.finish(0, 10000, 1, 18)
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+        w2 = ed.scan_reduce_windows(10000, 1, 18)
+        assert np.array_equal(ref[1], w2[1]) and np.array_equal(ref[2], w2[2])
+        ed.reset()
+        ed.runs_destroy(runs)
