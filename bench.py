@@ -543,19 +543,19 @@ def main():
     # (no arrays on any rank); the reduce-to-rank-0 forms need the arrays
     direct = os.environ.get("PD_BENCH_PATH", "direct") == "direct" and (not use_dist or sliced is not None)
     eng.set_param("direct_windows", 1 if direct else 0)
-    # the sorted stream in the engine's compact form (pd_runs_create: 8 bytes per run + exact tile bounds) — what pd_decode_end
+    # the sample in the engine's compact form (pd_runs_create: 8 bytes per run, bucketed, exact bounds) — what pd_decode_end
     # leaves for the whole-contig modes (PD_DECODE_COMPACT), made once before the timed region like the rest of the resident input
     runs8 = None
     if direct and os.environ.get("PD_BENCH_COMPACT", "1") == "1":
-        runs8 = eng.runs_create(first.data_ptr(), n_first)
+        runs8 = eng.runs_create(first.data_ptr(), n_first, other.data_ptr(), n_other)
     used_compact = runs8 is not None
 
     def scatter():
         eng.reset()
         if runs8 is not None and direct:
             eng.push_runs(runs8, pda.PD_PUSH_MORE)
-        else:
-            eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+            return
+        eng.push_intervals_device(first.data_ptr(), n_first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         eng.push_intervals_device(other.data_ptr(), n_other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN)
                                   | (pda.PD_PUSH_MORE if direct else 0))
 
@@ -790,7 +790,7 @@ def main():
                                    "whole-chromosome mode" % G,
                        "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
                        "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)") +
-                                (" — sorted stream resident in the compact form (8 B/run, exact tile bounds), as pd_decode_end leaves it" if used_compact else "")) if direct
+                                (" — sample resident in the compact form (8 B/run, grouped by 512-cell bucket with exact bounds), as pd_decode_end leaves it" if used_compact else "")) if direct
                                else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
                            "sliced": "sliced sum behind the C-ABI (pd_sliced_sum_start / _finish: RCCL grouped send/recv of 4-bit slices issued by the library), every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),

@@ -95,18 +95,20 @@ int pd_reset(pd_ctx *ctx);
 int pd_push_intervals(pd_ctx *ctx, const pd_iv *iv, size_t n, unsigned flags);
 int pd_push_intervals_device(pd_ctx *ctx, const pd_iv *dev_iv, size_t n, unsigned flags);
 
-/* A sorted sample kept in the engine's COMPACT form (what the GPU decoder leaves for the whole-contig modes): 8 bytes per
- * run — begin inside its contig, already clipped to [0, len] as PD:449-452's cells are, and length — the contig implied by
- * the run's place, plus the exact index of every 8192-cell tile's first run.  The direct window path (pd_scan_reduce_windows
- * with "direct_windows", windows of >= 8192 cells; pd_export_i4) then reads a third fewer bytes, tests no contig ids and no
- * bounds, and visits no run that belongs to another tile.  pd_runs_create converts a device-resident batch that is sorted by
- * (tid, beg) in ONE pass and CHECKS the order while it does (PD_EINVAL: not sorted / a contig id out of range: push the
- * batch the ordinary way); the object belongs to ctx, stays valid across pd_reset, and must be destroyed before ctx.
- * pd_push_runs defers it exactly like pd_push_intervals_device(.., PD_PUSH_SORTED | PD_PUSH_MORE) (flags: 0 or
- * PD_PUSH_MORE; it becomes the first batch of the pass); whatever cannot use the compact form (narrow windows, pd_scan, runs
- * longer than the look-back) expands it to 12-byte runs first — same results, never an error. */
+/* A whole sample kept in the engine's COMPACT form (what the GPU decoder leaves for the whole-contig modes): 8 bytes per
+ * run — begin inside its contig, already clipped to [0, len] as PD:449-452's cells are, and length — grouped by bucket of
+ * 512 cells (the "lmax" look-back bound) with the exact index of every bucket's first run, the contig implied by the run's
+ * place.  The direct window path (pd_scan_reduce_windows with "direct_windows", windows of >= 8192 cells; pd_export_i4)
+ * then reads a third fewer bytes, tests no contig ids and no bounds, and visits only a tile's own runs and those of the one
+ * bucket before it.  pd_runs_create takes the sample as the decoder has it — `dev_sorted`, sorted by (tid, beg) (every read's
+ * first run; the order is CHECKED: PD_EINVAL if it does not hold or a contig id is out of range — push such runs the ordinary
+ * way), and `dev_other` in any order (the later runs of reads with deletions / skips; may be NULL / 0) — and makes it in a
+ * few passes over the runs; both arrays may be freed afterwards.  The object belongs to ctx, stays valid across pd_reset, and
+ * is destroyed before ctx.  pd_push_runs defers it like pd_push_intervals_device(.., PD_PUSH_SORTED | PD_PUSH_MORE) (flags:
+ * 0 or PD_PUSH_MORE); whatever cannot use the compact form (narrow windows, pd_scan, other batches pushed beside it, a sample
+ * with runs longer than a bucket) expands it to 12-byte runs first — same results, never an error. */
 typedef struct pd_runs pd_runs;
-int pd_runs_create(pd_ctx *ctx, const pd_iv *dev_iv, size_t n, pd_runs **out);
+int pd_runs_create(pd_ctx *ctx, const pd_iv *dev_sorted, size_t n_sorted, const pd_iv *dev_other, size_t n_other, pd_runs **out);
 int pd_runs_destroy(pd_runs *runs);
 int pd_push_runs(pd_ctx *ctx, const pd_runs *runs, unsigned flags);
 
@@ -328,8 +330,8 @@ typedef struct pd_decode_cfg {
     uint32_t batches_in_flight, flags;/* flight (0 = unknown): pd_decode_begin then pins that many buffers up front, from ONE */
                                     /* thread — six threads pinning at once took 75-100 ms each, alone 4-5 ms              */
                                     /* flags: PD_DECODE_COMPACT — the caller will ask for whole-contig statistics                */
-                                    /* (pd_scan_reduce_windows, w >= 8192): pd_decode_end leaves a sorted file's first runs as a   */
-                                    /* compact sample (pd_runs) instead of 12-byte runs                                            */
+                                    /* (pd_scan_reduce_windows, w >= 8192): pd_decode_end leaves a sorted file's runs as ONE        */
+                                    /* compact sample (pd_runs) instead of 12-byte arrays                                          */
 } pd_decode_cfg;
 #define PD_DECODE_COMPACT 1u
 typedef struct pd_decode_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks, flags, pad; } pd_decode_unit;

@@ -54,7 +54,7 @@ def load():
         "pd_reset": (I, [P]),
         "pd_push_intervals": (I, [P, P, SZ, U]),
         "pd_push_intervals_device": (I, [P, P, SZ, U]),
-        "pd_runs_create": (I, [P, P, SZ, ctypes.POINTER(P)]),
+        "pd_runs_create": (I, [P, P, SZ, P, SZ, ctypes.POINTER(P)]),
         "pd_runs_destroy": (I, [P]),
         "pd_push_runs": (I, [P, P, U]),
         "pd_stage_acquire": (I, [P, ctypes.POINTER(P), ctypes.POINTER(SZ)]),
@@ -241,10 +241,12 @@ class Engine:
     def push_intervals_device(self, dev_ptr, n, flags=PD_PUSH_DEFAULT):
         self._ck(self.L.pd_push_intervals_device(self.h, ctypes.c_void_p(int(dev_ptr)), int(n), int(flags)))
 
-    def runs_create(self, dev_ptr, n):
-        """A device-resident batch sorted by (tid, beg) as a compact sample (pd_runs_create); PdError(-1) if it is not sorted."""
+    def runs_create(self, sorted_ptr, n_sorted, other_ptr=0, n_other=0):
+        """A device-resident sample — runs sorted by (tid, beg) + further runs in any order — as ONE compact sample
+        (pd_runs_create); PdError(-1) if the first batch is not sorted."""
         h = ctypes.c_void_p()
-        self._ck(self.L.pd_runs_create(self.h, ctypes.c_void_p(int(dev_ptr)), int(n), ctypes.byref(h)))
+        self._ck(self.L.pd_runs_create(self.h, ctypes.c_void_p(int(sorted_ptr)), int(n_sorted), ctypes.c_void_p(int(other_ptr)) if n_other else None,
+                                       int(n_other), ctypes.byref(h)))
         return h
 
     def runs_destroy(self, runs):

@@ -51,13 +51,15 @@ struct Pending { const pd_iv *iv; uint32_t n; uint32_t disorder; int slot; pd_ru
 
 } // namespace
 
-// a sorted sample in the compact form (include/pandepth_amd.h: pd_runs_create)
+// a whole sample in the compact form (include/pandepth_amd.h: pd_runs_create; layout: C8Sample in pd_kernels.h)
 struct pd_runs {
     pd_ctx *ctx = nullptr;
     Run8 *r8 = nullptr; uint32_t n = 0;
-    uint32_t *tile_first = nullptr, *look_first = nullptr;      // n_tiles + 1 entries each
-    uint32_t lmax = 0; uint32_t n_long = 0;
+    uint32_t *bstart = nullptr;                                  // (n_tiles << bshift) + 1 entries
+    uint32_t bshift = 4;                                         // 16 buckets of 512 cells per tile
+    uint32_t n_long = 0;                                         // runs longer than a bucket: the direct kernels cannot use the sample
     pd_iv *iv12 = nullptr;                                       // the expanded copy, made on first need
+    C8Sample view() const { return C8Sample{r8, bstart, bshift, n}; }
 };
 
 struct pd_ctx {
@@ -218,7 +220,8 @@ int ensure_all_valid(pd_ctx *c)
     return PD_OK;
 }
 
-// a compact pending batch that has to take a path that reads 12-byte runs: expanded once (the copy stays with the sample)
+// a compact pending sample that has to take a path that reads 12-byte runs: expanded once (the copy stays with the sample).
+// Inside a bucket the runs are in no particular order: the batch is sorted up to one bucket's cells of disorder.
 int expand_compact(pd_ctx *c, Pending &p)
 {
     if (!p.cr || p.iv) return PD_OK;
@@ -226,10 +229,11 @@ int expand_compact(pd_ctx *c, Pending &p)
     if (!r->iv12) {
         if (hipMalloc(&r->iv12, (size_t)r->n * sizeof(pd_iv)) != hipSuccess) return fail(c, PD_ENOMEM, "compact sample: allocation of the expanded runs failed");
         ProfScope ps(c, "expand_runs");
-        launch_expand_runs(c->stream, r->r8, r->tile_first, c->d_tile_contig, (uint32_t)c->n_tiles, r->iv12);
+        launch_c8_expand(c->stream, r->view(), c->d_tile_contig, (uint32_t)c->n_tiles, r->iv12);
         HIPOK(c, hipGetLastError());
     }
     p.iv = r->iv12;
+    p.disorder = (uint32_t)PD_TILE >> r->bshift;
     return PD_OK;
 }
 
@@ -258,7 +262,7 @@ int flush_pending(pd_ctx *c)
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
         ProfScope sc(c, "scatter_index");
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample, c->ub_a[b], c->cand_lo[b],
                              n_stiles, c->stile, c->desc + b);
@@ -478,7 +482,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 }
 
 static void runs_free(pd_runs *r);
-static int runs_make(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out);
+static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out);
 
 int pd_destroy(pd_ctx *c)
 {
@@ -566,47 +570,69 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
 static void runs_free(pd_runs *r)
 {
     if (!r) return;
-    for (void *q : {(void *)r->r8, (void *)r->tile_first, (void *)r->look_first, (void *)r->iv12}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)r->r8, (void *)r->bstart, (void *)r->iv12}) if (q) (void)hipFree(q);
     delete r;
 }
 
-// caller holds c->mu and has set the device
-static int runs_make(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out)
+// caller holds c->mu and has set the device.  `sorted` must be sorted by (tid, beg) — checked; the `others` may be in any order.
+static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out)
 {
     *out = nullptr;
+    size_t n = n_sorted;
+    for (int k = 0; k < n_arr; ++k) n += n_others[k];
     if (n == 0 || n > DEV_BATCH_MAX) return fail(c, PD_EINVAL, "pd_runs_create: between 1 and 2^32 - 256 runs");
+    if (n_arr > 2) return PD_EINVAL;
     pd_runs *r = new pd_runs;
-    r->ctx = c; r->n = (uint32_t)n; r->lmax = c->lmax;
-    uint32_t *words = nullptr;
-    const size_t nt = (size_t)c->n_tiles + 1;
-    if (hipMalloc(&r->r8, n * sizeof(Run8)) != hipSuccess || hipMalloc(&r->tile_first, nt * 4 + 16) != hipSuccess ||
-        hipMalloc(&r->look_first, nt * 4 + 16) != hipSuccess || hipMalloc(&words, 16) != hipSuccess) {
-        (void)hipGetLastError(); runs_free(r); if (words) (void)hipFree(words);
+    r->ctx = c; r->n = (uint32_t)n;
+    // buckets as wide as the look-back bound ("lmax", a power of two between 256 and 8192 cells; default 512)
+    uint32_t cells = 256; while (cells < c->lmax && cells < (uint32_t)PD_TILE) cells <<= 1;
+    r->bshift = 0; while (((uint32_t)PD_TILE >> r->bshift) > cells) ++r->bshift;
+    const uint64_t nb64 = (uint64_t)c->n_tiles << r->bshift;
+    if (nb64 > 0xFFFFFF00ull) { delete r; return fail(c, PD_EINVAL, "pd_runs_create: too many buckets for this genome"); }
+    const uint32_t nb = (uint32_t)nb64;
+    uint32_t *b1 = nullptr, *h2 = nullptr, *o2 = nullptr, *bs = nullptr, *words = nullptr, *d_other = nullptr;
+    auto cleanup = [&]() { for (void *q : {(void *)b1, (void *)h2, (void *)o2, (void *)bs, (void *)words, (void *)d_other}) if (q) (void)hipFree(q); };
+    const size_t nbb = ((size_t)nb + 2) * 4;
+    if (hipMalloc(&r->r8, n * sizeof(Run8)) != hipSuccess || hipMalloc(&r->bstart, nbb) != hipSuccess || hipMalloc(&b1, nbb) != hipSuccess ||
+        hipMalloc(&h2, nbb) != hipSuccess || hipMalloc(&o2, nbb) != hipSuccess || hipMalloc(&bs, ((size_t)nb / 1024 + 4) * 4) != hipSuccess ||
+        hipMalloc(&words, 16) != hipSuccess || hipMalloc(&d_other, 64) != hipSuccess) {
+        (void)hipGetLastError(); cleanup(); runs_free(r);
         return fail(c, PD_ENOMEM, "pd_runs_create: allocation failed");
     }
     uint32_t h[2] = {0, 0};
-    hipError_t e = hipMemsetAsync(words, 0, 16, c->stream);
+    hipStream_t st = c->stream;
+    const ContigTab tab = tab_of(c);
+    hipError_t e = hipMemsetAsync(words, 0, 16, st);
+    if (e == hipSuccess) e = hipMemsetAsync(h2, 0, nbb, st);
     if (e == hipSuccess) {
         ProfScope ps(c, "compact_runs");
-        launch_compact_runs(c->stream, dev_iv, r->n, tab_of(c), c->d_tile_contig, r->lmax, (uint32_t)c->n_tiles, r->r8, r->tile_first, r->look_first, words);
-        e = hipGetLastError();
+        if (n_sorted) launch_c8_scan_sorted(st, sorted, (uint32_t)n_sorted, tab, r->bshift, nb, b1, words);
+        else e = hipMemsetAsync(b1, 0, nbb, st);
+        for (int k = 0; k < n_arr; ++k) if (n_others[k]) launch_c8_hist(st, others[k], (uint32_t)n_others[k], tab, r->bshift, h2, words);
+        launch_excl_scan_u32(st, h2, o2, nb + 1, bs);
+        if (e == hipSuccess) e = hipMemsetAsync(h2, 0, nbb, st);                  // ... and now the buckets' cursors
+        uint32_t no[2] = {n_arr > 0 ? (uint32_t)n_others[0] : 0u, n_arr > 1 ? (uint32_t)n_others[1] : 0u};
+        const pd_iv *po[2] = {n_arr > 0 ? others[0] : nullptr, n_arr > 1 ? others[1] : nullptr};
+        launch_c8_place(st, sorted, (uint32_t)n_sorted, po, no, n_arr, tab, r->bshift, nb, b1, o2, h2, r->r8, r->bstart);
+        if (e == hipSuccess) e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(words);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
     if (e != hipSuccess) { runs_free(r); return fail(c, PD_EHIP, std::string("pd_runs_create: ") + hipGetErrorString(e)); }
-    if (h[0]) { runs_free(r); return fail(c, PD_EINVAL, "pd_runs_create: the batch is not sorted by (tid, beg), or holds a contig id out of range"); }
+    if (h[0]) { runs_free(r); return fail(c, PD_EINVAL, "pd_runs_create: the first batch is not sorted by (tid, beg), or a contig id is out of range"); }
     r->n_long = h[1];
     *out = r;
     return PD_OK;
 }
 
-int pd_runs_create(pd_ctx *c, const pd_iv *dev_iv, size_t n, pd_runs **out)
+int pd_runs_create(pd_ctx *c, const pd_iv *dev_sorted, size_t n_sorted, const pd_iv *dev_other, size_t n_other, pd_runs **out)
 {
-    if (!c || !dev_iv || !out) return PD_EINVAL;
+    if (!c || !out || (!dev_sorted && n_sorted) || (!dev_other && n_other)) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPOK(c, hipSetDevice(c->device));
-    return runs_make(c, dev_iv, n, out);
+    const pd_iv *o[1] = {dev_other}; const size_t no[1] = {n_other};
+    return runs_make(c, dev_sorted, n_sorted, o, no, n_other ? 1 : 0, out);
 }
 
 int pd_runs_destroy(pd_runs *r)
@@ -627,7 +653,7 @@ int pd_push_runs(pd_ctx *c, const pd_runs *runs, unsigned flags)
     std::lock_guard<std::mutex> lk(c->mu);
     if (int rs = need_state(c, 0, "pd_push_runs")) return rs;
     HIPOK(c, hipSetDevice(c->device));
-    int rc = flush_pending(c);                 // a compact sample is the first batch of its pass
+    int rc = flush_pending(c);                 // what was deferred before it is scattered first
     if (rc) return rc;
     Pending p{nullptr, runs->n, 0u, -1};
     p.cr = const_cast<pd_runs *>(runs);
@@ -785,20 +811,14 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     PendSet ps{};
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     uint64_t all = 0;
-    // a compact sample serves wide windows as batch 0 (k_direct_wide3's C8 form); anywhere else it goes on as 12-byte runs
-    for (int b = 0; b < ps.nb; ++b) {
-        Pending &p = c->pend[b];
-        if (p.cr && !p.iv && (b != 0 || w < PD_TILE || p.cr->n_long)) { const int re = expand_compact(c, p); if (re) return re; }
-    }
+    // a compact sample that is ALL there is serves wide windows through k_direct_c8; anywhere else it goes on as 12-byte runs
+    const bool c8 = ps.nb == 1 && c->pend[0].cr && !c->pend[0].iv && w >= PD_TILE && !c->pend[0].cr->n_long;
+    if (!c8) for (auto &p : c->pend) { const int re = expand_compact(c, p); if (re) return re; }
     for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
         all += p.n;
-        if (p.cr && !p.iv) {
-            ps.b[b] = PendBatch{nullptr, p.cr->tile_first, p.cr->look_first, c->desc + b, p.n, 0, p.cr->r8};
-            launch_desc_all_tiles(c->stream, c->desc + b, (uint32_t)c->n_tiles);
-            continue;
-        }
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
+        if (c8) break;
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
         ProfScope sc(c, "scatter_index");
         // a 4x sparser index than the arrays path's: measured neutral for the tile kernel, 0.43 -> 0.13 ms of index
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->direct_sample, c->ub_a[b],
@@ -813,8 +833,10 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     }
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_tiles");
-      launch_direct_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part, d_wo,
-                          d_cov, d_sum, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid, c->direct_un); }
+      if (c8) launch_direct_c8(c->stream, c->pend[0].cr->view(), tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part,
+                               c->direct_words + 16, c->direct_words + 2, grid, c->direct_un);
+      else launch_direct_tiles(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, mask, w, min_dep, d_part, d_wo,
+                               d_cov, d_sum, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid, c->direct_un); }
     if (w >= PD_TILE) {
         ProfScope sc(c, "gather_windows");
         TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
@@ -1323,17 +1345,19 @@ int pd_decode_end(pd_ctx *c)
     // otherwise by the longest gap seen, like the far stream)
     const uint32_t near_dis = nfar ? (c->dec_near_span < span ? c->dec_near_span : span) : span;
     const bool near_sorted = sorted && near_dis <= (1u << 14), far_sorted = sorted && span <= (1u << 14);
-    if (nf && sorted && (c->dec_cfg.flags & PD_DECODE_COMPACT) && c->pend.empty() && nf <= DEV_BATCH_MAX) {
-        // the whole-contig modes: the first runs stay as a compact sample (8 bytes per run + exact tile bounds; the conversion
-        // reads the 12-byte runs once and checks their order again), the 12-byte copy goes
+    if (nf && sorted && (c->dec_cfg.flags & PD_DECODE_COMPACT) && c->pend.empty() && nf + no + nfar <= DEV_BATCH_MAX) {
+        // the whole-contig modes: the sample stays as ONE compact sample (8 bytes per run, grouped by 512-cell bucket: the first
+        // runs keep their order — checked again —, the later runs of multi-run reads are dropped into their buckets), the
+        // 12-byte arrays go
         pd_runs *r = nullptr;
-        if (runs_make(c, c->run_first, (size_t)nf, &r) == PD_OK) {
-            (void)hipFree(c->run_first); c->run_first = nullptr;
+        const pd_iv *o[2] = {c->run_other, c->run_far}; const size_t non[2] = {(size_t)no, (size_t)nfar};
+        if (runs_make(c, c->run_first, (size_t)nf, o, non, 2, &r) == PD_OK) {
+            for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
             c->dec_runs = r;
             Pending p{nullptr, r->n, 0u, -1};
             p.cr = r;
             c->pend.push_back(p);
-            nf = 0;
+            return PD_OK;
         }
     }
     if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, sorted ? (PD_PUSH_SORTED | PD_PUSH_MORE) : PD_PUSH_DEFAULT, -1, nullptr);
@@ -1557,19 +1581,13 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     PendSet ps{};
     ps.nb = (int)c->pend.size(); ps.lmax = c->lmax;
     uint64_t all = 0;
-    for (int b = 0; b < ps.nb; ++b) {
-        Pending &p = c->pend[b];
-        if (p.cr && !p.iv && (b != 0 || p.cr->n_long)) { const int re = expand_compact(c, p); if (re) return re; }
-    }
+    const bool c8 = ps.nb == 1 && c->pend[0].cr && !c->pend[0].iv && !c->pend[0].cr->n_long;
+    if (!c8) for (auto &p : c->pend) { const int re = expand_compact(c, p); if (re) return re; }
     for (int b = 0; b < ps.nb; ++b) {
         const Pending &p = c->pend[b];
         all += p.n;
-        if (p.cr && !p.iv) {
-            ps.b[b] = PendBatch{nullptr, p.cr->tile_first, p.cr->look_first, c->desc + b, p.n, 0, p.cr->r8};
-            launch_desc_all_tiles(c->stream, c->desc + b, (uint32_t)c->n_tiles);
-            continue;
-        }
-        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0, nullptr};
+        if (c8) break;
+        ps.b[b] = PendBatch{p.iv, c->ub_a[b], c->cand_lo[b], c->desc + b, p.n, 0};
         ProfScope sc(c, "scatter_index");
         launch_scatter_index(c->stream, p.iv, p.n, tab_of(c), c->lmax, p.disorder, c->sample < 256 ? 256 : c->sample, c->ub_a[b],
                              c->cand_lo[b], (uint32_t)c->n_tiles, PD_TILE, c->desc + b);
@@ -1583,8 +1601,10 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     }
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_export");
-      launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
-                           c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
+      if (c8) launch_direct_c8_export(c->stream, c->pend[0].cr->view(), tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap,
+                                      dev_count, c->sums, c->direct_words + 16, c->direct_words + 2, grid);
+      else launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
+                                c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
     HIPOK(c, hipGetLastError());
     uint32_t words[2] = {0, 0}, n_exc = 0;
     HIPOK(c, hipMemcpyAsync(words, c->direct_words, 8, hipMemcpyDeviceToHost, c->stream));

@@ -43,19 +43,19 @@ struct CheckWords {           // context-wide, read back at pd_scan / pd_synchro
 #define PD_MAXPEND 4          /* sorted batches merged into one owner-tile pass */
 #define PD_HALF 4096          /* granularity of the "written since reset" flags */
 
-// A sorted sample in the engine's compact form (pd_runs_create): 8 bytes per run — begin inside its contig (already clamped
-// to [0, len]) and length (0: a run without cells) — the contig being implied by WHERE the run stands: tile_first[t] is the
-// index of the first run whose flat begin is >= the first cell of tile t (exact, n_tiles + 1 entries), so a tile's runs are
-// [tile_first[t], tile_first[t + 1]) and all belong to the tile's contig; look_first[t] is the first run of the same contig
-// that begins at or after (tile start - lmax): the runs that may END in the tile without beginning in it.
+// A whole sample in the engine's COMPACT form (pd_runs_create): 8 bytes per run — begin inside its contig (already clamped to
+// [0, len]) and length (0: a run without cells) — GROUPED BY BUCKET of (8192 >> bshift) cells of the flat cell space: bucket k's
+// runs are [bstart[k], bstart[k + 1]), in any order inside the bucket.  Contig slots start on tile boundaries, so a tile's own
+// runs are the 1 << bshift buckets [bstart[t << bshift], bstart[(t + 1) << bshift]) and all belong to the tile's contig; no run
+// is longer than a bucket, so the only other runs that can reach into tile t are those of the bucket right before it.
 struct Run8 { uint32_t b; uint32_t len; };
+struct C8Sample { const Run8 *r8; const uint32_t *bstart; uint32_t bshift, n; };
 
 struct PendBatch {            // one sorted batch of a tile pass (device pointers)
-    const pd_iv *iv;          // 12-byte runs (NULL for a compact batch)
-    const uint32_t *ub_a, *cand_lo;   // candidates of tile t: [cand_lo[t], ub_a[t + 1]) (compact: look_first / tile_first — exact)
+    const pd_iv *iv;
+    const uint32_t *ub_a, *cand_lo;
     BatchDesc *desc;
     uint32_t n, pad;
-    const Run8 *r8;           // compact batch (only ever batch 0 of a set)
 };
 struct PendSet { PendBatch b[PD_MAXPEND]; int nb; uint32_t lmax; };
 
@@ -74,12 +74,18 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
                          uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, const uint64_t *win_off,
                          uint32_t *cover, unsigned long long *sum, uint32_t *n_long, uint32_t *fail,
                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
-// compact samples (Run8): conversion of a sorted 12-byte batch (+ exact tile bounds, order / range checks: words[0] != 0 means
-// "not a sorted batch of valid runs", words[1] = runs longer than lmax), the reverse, and the descriptor of a compact batch
-void launch_compact_runs(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, const uint32_t *tile_contig, uint32_t lmax,
-                         uint32_t n_tiles, Run8 *out, uint32_t *tile_first, uint32_t *look_first, uint32_t *words);
-void launch_expand_runs(hipStream_t st, const Run8 *r8, const uint32_t *tile_first, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out);
-void launch_desc_all_tiles(hipStream_t st, BatchDesc *desc, uint32_t n_tiles);
+// compact samples: the passes of pd_runs_create (words: [0] not sorted / invalid contig, [1] runs longer than a bucket), the
+// reverse (12-byte runs, bucket by bucket), and the direct kernels that read them
+void launch_c8_scan_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets, uint32_t *b1, uint32_t *words);
+void launch_c8_hist(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words);
+void launch_excl_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *block_sums /* n / 1024 + 2 words */);
+void launch_c8_place(hipStream_t st, const pd_iv *sorted, uint32_t n_sorted, const pd_iv *const *others, const uint32_t *n_others, int n_other_arrays,
+                     ContigTab tab, uint32_t bshift, uint32_t n_buckets, const uint32_t *b1, const uint32_t *o2, uint32_t *cursor, Run8 *out, uint32_t *bstart);
+void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out);
+void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
+                      uint32_t min_dep, TilePart *part, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
+void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,
+                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles);
 void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
                           void *img, pd_exc *exc, uint32_t cap, uint32_t *count, int *sums, uint32_t *n_long, uint32_t *fail,
                           uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles);

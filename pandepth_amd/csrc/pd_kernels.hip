@@ -678,6 +678,75 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
 // wave totals through the DPP scan (no LDS crossbar): the last lane holds the sum
 __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
 
+// The 4-bit image of one tile straight from its packed window (pd_export_i4's layout: one nibble d + 8 per cell, cell 2k in the
+// low half of byte k; cells outside [-8, 7] leave as exceptions and are 0 in the image), and the tile's sum.  A lane packs the 4
+// cells of each of its 4 rows to 16 bits per half-tile; the halfwords go through a KiB of LDS per wave and come back as ONE
+// 16-byte piece per lane — lanes 0..31 the wave's 512 bytes of the low half-tile's image, lanes 32..63 those of the high
+// half-tile's: a wave stores its KiB with one 16-byte store per lane (it was eight 2-byte stores per lane).  Exceptions are
+// rare: the hot loop only notes which rows have one, a second look at those words emits them.
+template <int ROWS>
+__device__ __forceinline__ void export_packed_tile(const unsigned *win, const uint64_t a, const uint64_t t, const DirectExport &ex, int *wtot)
+{
+    constexpr uint32_t HT = TILE / 2;
+    __shared__ __attribute__((aligned(16))) unsigned short stage[4][2 * ROWS * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(win);
+    unsigned short *stg = stage[wv];
+    int tsum = 0;                                             // packed: sum over the lane's words
+    unsigned odd = 0;                                         // bit r: row r of this lane has a cell outside [-8, 7]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
+        const unsigned wq[4] = {q.x, q.y, q.z, q.w};
+        unsigned wl = 0, wh = 0, bad = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tsum += (int)wq[k];
+            const int xl = (int)(short)(wq[k] & 0xffffu), xh = ((int)wq[k] - xl) >> 16;
+            const unsigned nl = (unsigned)(xl + 8), nh = (unsigned)(xh + 8);
+            bad |= (nl | nh) >> 4;                            // nonzero: out of the nibble's range
+            wl |= (nl < 16u ? nl : 8u) << (4 * k);
+            wh |= (nh < 16u ? nh : 8u) << (4 * k);
+        }
+        odd |= (bad ? 1u : 0u) << r;
+        stg[r * 64 + lane] = (unsigned short)wl;
+        stg[ROWS * 64 + r * 64 + lane] = (unsigned short)wh;
+    }
+    if (__builtin_amdgcn_ballot_w64(odd != 0)) {              // rare
+#pragma unroll 1
+        for (int idx = 0; idx < ROWS * 4; ++idx) {
+            const int r = idx >> 2, k = idx & 3;
+            if (!((odd >> r) & 1u)) continue;
+            const unsigned wd = win[wv * (ROWS * 256) + r * 256 + lane * 4 + k];
+            const int xl = (int)(short)(wd & 0xffffu), xh = ((int)wd - xl) >> 16;
+            const uint64_t cell = a + (uint64_t)(wv * (ROWS * 256) + r * 256 + lane * 4 + k);
+            if ((unsigned)(xl + 8) > 15u) {
+                const uint32_t slot = atomicAdd(ex.count, 1u);
+                if (slot < ex.cap) { ex.exc[slot].cell = cell; ex.exc[slot].value = xl; ex.exc[slot].pad = 0; }
+            }
+            if ((unsigned)(xh + 8) > 15u) {
+                const uint32_t slot = atomicAdd(ex.count, 1u);
+                if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint4 piece = reinterpret_cast<const uint4 *>(stg)[lane];
+    unsigned char *img = reinterpret_cast<unsigned char *>(ex.img);
+    const uint64_t at = a / 2 + (uint64_t)wv * (ROWS * 128) + (lane < 32 ? (uint64_t)lane * 16 : (uint64_t)(HT / 2) + (uint64_t)(lane - 32) * 16);
+    *reinterpret_cast<uint4 *>(img + at) = piece;
+    tsum = wave_total(tsum);                                  // packed 65536 * H + L over the wave (|H|, |L| <= 32 000)
+    if (lane == 0) wtot[wv] = tsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        const int tl2 = (int)(short)(tp & 0xffff);
+        ex.sums[t] = tl2 + ((tp - tl2) >> 16);
+    }
+    __syncthreads();
+}
+
 // k_direct_wide3 — the wide-window (w >= TILE) direct kernel, second form.  Same results as k_direct_tiles<.., DirectWide>
 // (TilePart per tile, owner / open counters for k_finish_direct, heavy list); the SIMDs were 65 % busy with vector ALU work
 // in that kernel (SQ_ACTIVE_INST_VALU), so this one does the same job in fewer instructions:
@@ -696,13 +765,7 @@ __device__ unsigned long long g_wide3_ticks[16];
 #else
 #define W3_TICK(k) do { } while (0)
 #endif
-//   * C8 (round 3): batch 0 of the set is a COMPACT sample (Run8, pd_runs_create): 8 bytes per run, coordinates clamped when
-//     the sample was made, and EXACT tile bounds — a tile's own runs are [tile_first[t], tile_first[t + 1]), every one of them
-//     begins in the tile (no owner test, the owner count is an index difference), and the look-back candidates before them are
-//     exactly the runs of the same contig that begin within lmax cells of the tile.  No contig compare, no clamps, no empty-run
-//     test (a run without cells adds and subtracts at the same cell): 13 vector instructions per run instead of 26, a third
-//     fewer bytes, no candidates that belong to other tiles.  UN8 = its loads in flight per thread.
-template <int UN, int WPE, bool EXPORT, bool C8 = false, int UN8 = 4>
+template <int UN, int WPE, bool EXPORT>
 __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint32_t n_tiles, ContigTab tab,
                                                         const uint32_t *tile_contig, uint32_t wrap_mask, const DirectWide args,
                                                         uint32_t *heavy_list, uint32_t *heavy_count, const DirectExport ex)
@@ -716,7 +779,6 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
     __shared__ uint32_t s_lo[PD_MAXPEND], s_hi[PD_MAXPEND];
-    __shared__ uint32_t s_mid;                                   // C8: first run that begins in the tile (tile_first[t])
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t n_beg_s = 0; int open_s = 0;                        // owner / open counts: wave-uniform (scalar popcounts of compare masks)
     // the batches' active tile ranges and run arrays do not change from tile to tile; the candidate bounds of the NEXT tile
@@ -739,22 +801,14 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
         }
     };
-    uint32_t nlo = 0, nhi = 0, nmid = 0;
-    auto mid_of = [&](const uint64_t t, const uint32_t lo, const uint32_t hi) -> uint32_t {   // thread 0, compact batch: tile_first[t], inside [lo, hi]
-        if (t >= n_tiles) return 0u;
-        uint32_t m = ps.b[0].ub_a[t];
-        if (m < lo) m = lo;
-        return m > hi ? hi : m;
-    };
+    uint32_t nlo = 0, nhi = 0;
     if (threadIdx.x < PD_MAXPEND) bounds(blockIdx.x, nlo, nhi);
-    if (C8 && threadIdx.x == 0) nmid = mid_of(blockIdx.x, nlo, nhi);
 #ifdef PD_WIDE3_TICKS
     long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = (long long)clock64();
 #endif
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t a = t * ST;
         if (threadIdx.x < PD_MAXPEND) { s_lo[threadIdx.x] = nlo; s_hi[threadIdx.x] = nhi; }
-        if (C8 && threadIdx.x == 0) s_mid = nmid;
         uint4 *w4 = reinterpret_cast<uint4 *>(win);
         for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x == 0) s_carry = 0;
@@ -765,7 +819,6 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         __syncthreads();
         W3_TICK(1);                                               // barrier 1
         if (threadIdx.x < PD_MAXPEND) bounds(t + gridDim.x, nlo, nhi);
-        if (C8 && threadIdx.x == 0) nmid = mid_of(t + gridDim.x, nlo, nhi);
         uint32_t cand = 0;
         for (int b = 0; b < ps.nb; ++b) cand += s_hi[b] - s_lo[b];
         if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
@@ -807,58 +860,6 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
             carry_s += __builtin_popcountll(m_mine & m_ne & m_cov);
         };
 #undef PD_B
-        if constexpr (C8) {
-            // ---- the compact stream: [lo, mid) may end in the tile, [mid, hi) begin in it.  One event pair per run:
-            //   sb = b - p0 (mod 2^32): < ST exactly for the tile's own runs;  se = sb + len: < ST when the end lies in the tile;
-            //   se < len exactly when the run begins before the tile and reaches its first cell or further (the carry-in).
-            const uint32_t lo = s_lo[0], hi = s_hi[0];
-            if (wv == 0) { const uint32_t own = hi - s_mid; n_beg_s += own; open_s += (int)own; }
-            const Run8 *__restrict__ p = ps.b[0].r8;
-            constexpr uint32_t C = UN8 * WG;
-            auto load8 = [&](uint2 (&dst)[UN8], const uint32_t i) {
-                const uint32_t last = hi - 1u;
-#pragma unroll
-                for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (j < last ? j : last)); }
-            };
-            int ends_s = 0;
-            auto ev8 = [&](const uint32_t b, const uint32_t len) {
-                const uint32_t sb = b - p0, se = sb + len;
-                const unsigned long long m_e = __builtin_amdgcn_ballot_w64(se < ST), m_c = __builtin_amdgcn_ballot_w64(se < len);
-                if (sb < ST) atomicAdd(&win[sb & (HT - 1u)], 1u + (sb >> 12) * 0xFFFFu);
-                if (se < ST) atomicSub(&win[se & (HT - 1u)], 1u + (se >> 12) * 0xFFFFu);
-                ends_s += __builtin_popcountll(m_e);
-                carry_s += __builtin_popcountll(m_c);
-            };
-            auto work8 = [&](const uint2 (&c)[UN8], const uint32_t i) {
-                const uint32_t left = hi - i;
-                if (left >= C) {
-#pragma unroll
-                    for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
-                } else {                                          // the tail chunk: slots past the end become runs outside the tile
-                    const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
-#pragma unroll
-                    for (int k = 0; k < UN8; ++k) if (k < nu) {
-                        const bool in = threadIdx.x + k * WG < left;
-                        ev8(in ? c[k].x : p0 + ST, in ? c[k].y : 0u);
-                    }
-                }
-            };
-            if (lo < hi) {
-                uint2 A[UN8], B[UN8];
-                uint32_t i = lo;
-                load8(A, i);
-#pragma unroll 1
-                for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
-                    if (i + C < hi) load8(B, i + C);
-                    work8(A, i);
-                    i += C; if (i >= hi) break;
-                    if (i + C < hi) load8(A, i + C);
-                    work8(B, i);
-                    i += C; if (i >= hi) break;
-                }
-            }
-            open_s -= ends_s;
-        }
         // chunks of UN x WG candidates, stream after stream; the loads of chunk k + 1 (same stream or the next one) are in
         // flight while chunk k is worked on
         {
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
 #pragma unroll
                 for (int k = 0; k < UN; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = p[j < last ? j : last]; }
             };
-            int b = C8 ? 1 : 0;
+            int b = 0;
             while (b < ps.nb && s_lo[b] >= s_hi[b]) ++b;
             uint32_t i = b < ps.nb ? s_lo[b] : 0u;
             pd_iv cur[UN];
@@ -909,65 +910,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_wide3(const PendSet ps, uint
         __syncthreads();
         W3_TICK(3);                                               // barrier 2
         if constexpr (EXPORT) {                                   // the multi-GPU sum's 4-bit image (pd_export_i4)
-            // k_export_i4's layout: one nibble (d + 8) per cell, cell 2k in the low half of byte k.  A lane packs the 4 cells of
-            // each of its 4 rows to 16 bits per half-tile; the 8 halfwords go through the wave's OWN part of the window (its
-            // words are in registers by then, nobody else touches them before the next tile's barrier) and come back as one
-            // 16-byte piece per lane — lanes 0..31 the wave's 512 bytes of the low half-tile's image, lanes 32..63 those of
-            // the high half-tile's — so a wave stores its 1 KiB with ONE 16-byte store per lane (it was eight 2-byte stores).
-            int tsum = 0;                                         // packed: sum over the lane's words
-            unsigned short hw[2 * ROWS];
-            uint4 q4[ROWS];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) q4[r] = w4[wv * (ROWS * 64) + r * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const unsigned wq[4] = {q4[r].x, q4[r].y, q4[r].z, q4[r].w};
-                unsigned wl = 0, wh = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    tsum += (int)wq[k];
-                    int xl = (int)(short)(wq[k] & 0xffffu), xh = ((int)wq[k] - xl) >> 16;
-                    if ((unsigned)(xl + 8) > 15u || (unsigned)(xh + 8) > 15u) {        // rare: a cell outside [-8, 7]
-                        const uint64_t cell = a + (uint64_t)(wv * (ROWS * 256) + r * 256 + lane * 4 + k);
-                        if ((unsigned)(xl + 8) > 15u) {
-                            const uint32_t slot = atomicAdd(ex.count, 1u);
-                            if (slot < ex.cap) { ex.exc[slot].cell = cell; ex.exc[slot].value = xl; ex.exc[slot].pad = 0; }
-                            xl = 0;
-                        }
-                        if ((unsigned)(xh + 8) > 15u) {
-                            const uint32_t slot = atomicAdd(ex.count, 1u);
-                            if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
-                            xh = 0;
-                        }
-                    }
-                    wl |= (unsigned)((xl + 8) & 0xf) << (4 * k);
-                    wh |= (unsigned)((xh + 8) & 0xf) << (4 * k);
-                }
-                hw[r] = (unsigned short)wl; hw[ROWS + r] = (unsigned short)wh;
-            }
-            {
-                // staging: halfword index r * 64 + lane of the low image, ROWS * 64 + the same of the high image (1 KiB per wave)
-                unsigned short *stg = reinterpret_cast<unsigned short *>(win + wv * (ROWS * 256));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the window reads above are complete (registers) before the overwrite
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) { stg[r * 64 + lane] = hw[r]; stg[ROWS * 64 + r * 64 + lane] = hw[ROWS + r]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint4 piece = reinterpret_cast<const uint4 *>(stg)[lane];
-                // lanes 0..31: low half-tile, bytes [a / 2 + wv * 512, + 512); lanes 32..63: high half-tile, HT / 2 bytes further
-                unsigned char *img = reinterpret_cast<unsigned char *>(ex.img);
-                const uint64_t at = a / 2 + (uint64_t)wv * (ROWS * 128) + (lane < 32 ? (uint64_t)lane * 16 : (uint64_t)(HT / 2) + (uint64_t)(lane - 32) * 16);
-                *reinterpret_cast<uint4 *>(img + at) = piece;
-            }
-            tsum = wave_total(tsum);                              // packed 65536 * H + L over the wave (|H|, |L| <= 32 000)
-            if (lane == 0) wtot[wv] = tsum;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int tp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-                const int tl2 = (int)(short)(tp & 0xffff);
-                ex.sums[t] = tl2 + ((tp - tl2) >> 16);
-            }
-            __syncthreads();
+            export_packed_tile<ROWS>(win, a, t, ex, wtot);
             continue;
         }
         // ---- prefix sum of the packed window: both half-tiles at once ----
@@ -1108,7 +1051,8 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
                                                      const uint32_t *tile_contig, uint32_t wrap_mask, const WinArgs wa,
                                                      const uint64_t *win_off, uint32_t *n_long,
                                                      const uint32_t *heavy_list, const uint32_t *heavy_count,
-                                                     const DirectExport ex)          // ex.img != null: export instead of statistics
+                                                     const DirectExport ex,          // ex.img != null: export instead of statistics
+                                                     const C8Sample cs)              // cs.r8 != null: a compact sample (then ps is empty)
 {
     const uint32_t w = wa.w, min_dep = wa.min_dep;
     TilePart *const part = wa.part;
@@ -1149,15 +1093,13 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
             uint32_t hi = ps.b[b].ub_a[t + 1]; if (hi > n) hi = n;
             uint32_t lo = ps.b[b].cand_lo[t]; if (lo > hi) lo = hi;
             const pd_iv *__restrict__ iv = ps.b[b].iv;
-            const Run8 *__restrict__ r8 = ps.b[b].r8;             // a compact batch: the tile's contig, coordinates inside it
             constexpr int UN = 4;
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += UN * WG) {
                 pd_iv vv[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
                     const uint32_t i = i0 + u * WG;
-                    if (r8) { const Run8 r = r8[i < hi ? i : hi - 1]; vv[u] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
-                    else vv[u] = iv[i < hi ? i : hi - 1];
+                    vv[u] = iv[i < hi ? i : hi - 1];
                     if (i >= hi) vv[u].tid = -1;
                 }
 #pragma unroll
@@ -1177,6 +1119,19 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
                         if (sb < 0 && se >= 0) ++carry;           // covers the cell just before the tile
                     }
                 }
+            }
+        }
+        if (cs.r8) {                                              // a compact sample: the tile's own buckets and the one before them
+            const uint32_t k0 = (uint32_t)t << cs.bshift;
+            const uint32_t hi = cs.bstart[k0 + (1u << cs.bshift)];
+            const uint32_t lo = rel < 0 ? cs.bstart[k0 - 1] : cs.bstart[k0];       // (a contig's first tile has nothing before it)
+            for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
+                const Run8 r = cs.r8[i];
+                if (!r.len) continue;
+                const int64_t sb = rel + (int64_t)r.b, se = sb + (int64_t)r.len;
+                if (sb >= 0 && sb < ST) atomicAdd(&win[sb], 1);
+                if (se >= 0 && se < ST) atomicAdd(&win[se], -1);
+                if (sb < 0 && se >= 0) ++carry;
             }
         }
         carry = wave_sum(carry);
@@ -1305,78 +1260,359 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
 }
 
 // ------------------------------------------------------------------------------------------
-// compact samples (pd_runs_create / pd_push_runs)
+// compact samples (pd_runs_create / pd_push_runs): see C8Sample in pd_kernels.h
 // ------------------------------------------------------------------------------------------
-// One pass over a batch that is promised to be sorted by flat begin: the runs leave as Run8 (clamped begin inside the contig,
-// length), every tile learns the index of its first run (exact: thread i writes the tiles between its predecessor's and its
-// own), the same with the threshold moved back by lmax for the look-back bound, and the promise is CHECKED (words[0] != 0:
-// an invalid contig id or a run that begins before its predecessor; words[1]: runs longer than lmax, whose ends the look-back
-// would miss — such a sample is not used in this form).
-__global__ __launch_bounds__(WG) void k_compact_runs(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t lmax, uint32_t n_tiles,
-                                                     Run8 *out, uint32_t *tile_first, uint32_t *look_first, uint32_t *words)
+// flat begin (clamped) and clamped length of a run; valid = its contig id is one
+__device__ __forceinline__ uint64_t c8_flat(const pd_iv v, const ContigTab tab, uint32_t &b, uint32_t &len, bool &valid)
+{
+    valid = v.tid >= 0 && v.tid < tab.n;
+    b = 0; len = 0;
+    if (!valid) return 0;
+    const uint32_t clen = tab.len[v.tid];
+    b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
+    uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
+    len = x > b ? x - b : 0u;
+    return tab.off[v.tid] + b;
+}
+
+// Pass A, the sorted stream: its order is CHECKED (words[0]: a contig id out of range, or a run that begins before its
+// predecessor), runs longer than a bucket are counted (words[1]: such a sample is not used in this form), and every bucket
+// learns the index of its first run — thread i writes the buckets between its predecessor's and its own (b1: n_buckets + 1).
+__global__ __launch_bounds__(WG) void k_c8_scan_sorted(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets,
+                                                       uint32_t *b1, uint32_t *words)
 {
     const uint64_t i64 = (uint64_t)blockIdx.x * WG + threadIdx.x;
     const uint32_t i = i64 < n ? (uint32_t)i64 : n - 1;
-    auto flat = [&](const pd_iv v, uint32_t &b, uint32_t &len, bool &valid) -> uint64_t {
-        valid = v.tid >= 0 && v.tid < tab.n;
-        b = 0; len = 0;
-        if (!valid) return 0;
-        const uint32_t clen = tab.len[v.tid];
-        b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
-        uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
-        len = x > b ? x - b : 0u;
-        return tab.off[v.tid] + b;
-    };
+    const uint32_t cshift = 13u - bshift;                        // log2(cells per bucket)
     uint32_t b, len; bool valid;
-    const uint64_t gb = flat(iv[i], b, len, valid);
-    // the predecessor's flat begin: the left lane's value, except for a wave's first lane
+    const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
     uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(gb >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)gb, 1);
     bool pvalid = __shfl_up((int)valid, 1) != 0;
-    if ((threadIdx.x & 63) == 0 && i > 0) { uint32_t pb, pl; prev = flat(iv[i - 1], pb, pl, pvalid); }
+    if ((threadIdx.x & 63) == 0 && i > 0) { uint32_t pb, pl; prev = c8_flat(iv[i - 1], tab, pb, pl, pvalid); }
     if (i64 >= n) return;
     if (!valid || (i > 0 && (!pvalid || gb < prev))) atomicOr(&words[0], 1u);
-    if (len > lmax) atomicAdd(&words[1], 1u);
-    out[i] = Run8{b, len};
-    const uint64_t T = (uint64_t)TILE;
-    const int64_t t_hi = (int64_t)(gb / T), t_lo = i > 0 ? (int64_t)(prev / T) : -1;
-    for (int64_t t = t_lo + 1; t <= t_hi && t <= (int64_t)n_tiles; ++t) tile_first[t] = i;
-    int64_t l_hi = (int64_t)((gb + lmax) / T), l_lo = i > 0 ? (int64_t)((prev + lmax) / T) : -1;
-    if (l_hi > (int64_t)n_tiles) l_hi = n_tiles;
-    if (l_lo > (int64_t)n_tiles) l_lo = n_tiles;
-    for (int64_t t = l_lo + 1; t <= l_hi; ++t) look_first[t] = i;
-    if (i == n - 1) {
-        for (int64_t t = t_hi + 1; t <= (int64_t)n_tiles; ++t) tile_first[t] = n;
-        for (int64_t t = l_hi + 1; t <= (int64_t)n_tiles; ++t) look_first[t] = n;
+    if (len > (1u << cshift)) atomicAdd(&words[1], 1u);
+    int64_t k_hi = (int64_t)(gb >> cshift), k_lo = i > 0 ? (int64_t)(prev >> cshift) : -1;
+    if (k_hi > (int64_t)n_buckets) k_hi = n_buckets;
+    if (k_lo > (int64_t)n_buckets) k_lo = n_buckets;
+    for (int64_t k = k_lo + 1; k <= k_hi; ++k) b1[k] = i;
+    if (i == n - 1) for (int64_t k = k_hi + 1; k <= (int64_t)n_buckets; ++k) b1[k] = n;
+}
+
+// Pass B, the other streams (any order): how many of their runs begin in each bucket
+__global__ __launch_bounds__(WG) void k_c8_hist(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words)
+{
+    const uint32_t cshift = 13u - bshift;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        uint32_t b, len; bool valid;
+        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
+        if (!valid) { atomicOr(&words[0], 1u); continue; }
+        if (len > (1u << cshift)) atomicAdd(&words[1], 1u);
+        atomicAdd(&hist[gb >> cshift], 1u);
     }
 }
 
-// the look-back never reaches into the previous contig (its runs would be read with the wrong origin): not before the first
-// run of the tile's own contig, whose slot starts on a tile boundary
-__global__ __launch_bounds__(WG) void k_compact_clip(const uint32_t *tile_first, uint32_t *look_first, const uint32_t *tile_contig,
-                                                     ContigTab tab, uint32_t n_tiles)
+// exclusive prefix sum of n 32-bit counts (three small kernels: sums of blocks of 1024, their scan, the blocks)
+__global__ __launch_bounds__(WG) void k_scan_block_sums(const uint32_t *in, uint32_t n, uint32_t *bs)
 {
-    const uint32_t t = blockIdx.x * WG + threadIdx.x;
-    if (t >= n_tiles) return;
-    const uint32_t t0 = (uint32_t)(tab.off[tile_contig[t]] / (uint64_t)TILE);
-    const uint32_t f = tile_first[t0], m = tile_first[t];
-    uint32_t l = look_first[t];
-    if (l < f) l = f;
-    if (l > m) l = m;
-    look_first[t] = l;
+    __shared__ uint32_t ws[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) v += in[base + k];
+    v = (uint32_t)wave_total((int)v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) bs[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_of_sums(uint32_t *bs, uint32_t nb)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t run_s;
+    if (threadIdx.x == 0) run_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? bs[i] : 0u;
+        const uint32_t inc = (uint32_t)wave_incl_scan((int)v);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t off = run_s;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += wsum[k];
+        if (i < nb) bs[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) run_s = off + inc;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(WG) void k_scan_blocks(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *bs)
+{
+    __shared__ uint32_t ws[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t x[4], v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[k] = base + k < n ? in[base + k] : 0u; v += x[k]; }
+    const uint32_t inc = (uint32_t)wave_incl_scan((int)v);
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t off = bs[blockIdx.x] + inc - v;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += ws[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = off; off += x[k]; }
 }
 
-// the reverse (a compact sample that has to take the general path after all): 12-byte runs, tile by tile
-__global__ __launch_bounds__(WG) void k_expand_runs(const Run8 *r8, const uint32_t *tile_first, const uint32_t *tile_contig,
-                                                    uint32_t n_tiles, pd_iv *out)
+// bucket k of the merged sample starts at b1[k] + o2[k]; its sorted-stream runs come first, the others after them
+__global__ __launch_bounds__(WG) void k_c8_bstart(const uint32_t *b1, const uint32_t *o2, uint32_t n_buckets, uint32_t *bstart)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (k <= n_buckets) bstart[k] = b1[k] + o2[k];
+}
+__global__ __launch_bounds__(WG) void k_c8_place_sorted(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o2, Run8 *out)
+{
+    const uint32_t cshift = 13u - bshift;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        uint32_t b, len; bool valid;
+        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
+        if (valid) out[i + o2[gb >> cshift]] = Run8{b, len};
+    }
+}
+__global__ __launch_bounds__(WG) void k_c8_place_other(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *b1, const uint32_t *o2,
+                                                       uint32_t *cursor, Run8 *out)
+{
+    const uint32_t cshift = 13u - bshift;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        uint32_t b, len; bool valid;
+        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
+        if (!valid) continue;
+        const uint64_t k = gb >> cshift;
+        out[b1[k + 1] + o2[k] + atomicAdd(&cursor[k], 1u)] = Run8{b, len};
+    }
+}
+
+// the reverse (a compact sample that has to take a path that reads 12-byte runs): bucket by bucket, so the result is sorted up to
+// one bucket's cells of disorder
+__global__ __launch_bounds__(WG) void k_c8_expand(const C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
 {
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t lo = tile_first[t], hi = tile_first[t + 1];
+        const uint32_t lo = cs.bstart[t << cs.bshift], hi = cs.bstart[(t + 1) << cs.bshift];
         const int32_t ctg = (int32_t)tile_contig[t];
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) { const Run8 r = r8[i]; out[i] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) { const Run8 r = cs.r8[i]; out[i] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
     }
 }
 
-__global__ void k_desc_all_tiles(BatchDesc *desc, uint32_t n_tiles) { desc->t_first = 0; desc->n_active = n_tiles; }
+// k_direct_c8 — the wide-window direct kernel on a compact sample: ONE stream, exact bounds, nothing to test but where the two
+// events of a run fall.  Per run (13 vector instructions; k_direct_wide3: 26, on 12-byte runs with a contig compare and clamps):
+//   sb = b - p0 (mod 2^32): < TILE exactly for the tile's own runs;  se = sb + len: < TILE when the end lies in the tile;
+//   se < len exactly when the run begins before the tile and reaches its first cell or further (the carry-in).
+// A run without cells adds and subtracts at the same cell.  The tile's candidates are its own buckets and the one before them
+// (1/16 more than its own runs with 512-cell buckets; k_direct_wide3's index granularity, look-back and disorder margins made
+// it 37 %).  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more than 32 000 candidates go to
+// the int-window kernel through the same list.
+template <int WPE, int UN8, bool EXPORT>
+__global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32_t n_tiles, ContigTab tab, const uint32_t *tile_contig,
+                                                     uint32_t wrap_mask, const DirectWide args, uint32_t *heavy_list, uint32_t *heavy_count,
+                                                     const DirectExport ex)
+{
+    const uint32_t w = args.w, min_dep = args.min_dep; TilePart *const part = args.part;
+    constexpr uint32_t ST = TILE, HT = TILE / 2;
+    constexpr int ROWS = (int)(HT / (WG * 4));
+    __shared__ __attribute__((aligned(16))) unsigned win[HT];
+    __shared__ int s_carry;
+    __shared__ int wtot[4];
+    __shared__ unsigned long long red_s[4][2];
+    __shared__ int red_c[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const Run8 *__restrict__ p = cs.r8;
+    const uint32_t bsh = cs.bshift;
+    // the bounds of a tile are three entries of bstart (scalar loads); the next tile's are fetched a tile ahead
+    auto bounds = [&](const uint64_t t, uint32_t &lo, uint32_t &hi) {
+        lo = hi = 0;
+        if (t < n_tiles) {
+            const uint32_t k0 = (uint32_t)t << bsh;
+            hi = cs.bstart[k0 + (1u << bsh)];
+            const uint32_t ctg = tile_contig[t];
+            lo = (uint64_t)t * ST > tab.off[ctg] ? cs.bstart[k0 - 1] : cs.bstart[k0];     // a contig's first tile has nothing before it
+        }
+    };
+    uint32_t nlo, nhi;
+    bounds(blockIdx.x, nlo, nhi);
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t a = t * ST;
+        const uint32_t lo = nlo, hi = nhi;
+        uint4 *w4 = reinterpret_cast<uint4 *>(win);
+        for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) s_carry = 0;
+        const int32_t ctg = (int32_t)tile_contig[t];
+        const uint32_t clen = tab.len[ctg];
+        const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);
+        bounds(t + gridDim.x, nlo, nhi);
+        __syncthreads();
+        const uint32_t cand = hi - lo;
+        if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
+            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
+            __syncthreads();
+            continue;
+        }
+        int carry_s = 0;
+        {
+            constexpr uint32_t C = UN8 * WG;
+            auto load8 = [&](uint2 (&dst)[UN8], const uint32_t i) {
+                const uint32_t last = hi - 1u;
+#pragma unroll
+                for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (j < last ? j : last)); }
+            };
+            auto ev8 = [&](const uint32_t b, const uint32_t len) {
+                const uint32_t sb = b - p0, se = sb + len;
+                const unsigned long long m_c = __builtin_amdgcn_ballot_w64(se < len);
+                if (sb < ST) atomicAdd(&win[sb & (HT - 1u)], 1u + (sb >> 12) * 0xFFFFu);
+                if (se < ST) atomicSub(&win[se & (HT - 1u)], 1u + (se >> 12) * 0xFFFFu);
+                carry_s += __builtin_popcountll(m_c);
+            };
+            auto work8 = [&](const uint2 (&c)[UN8], const uint32_t i) {
+                const uint32_t left = hi - i;
+                if (left >= C) {
+#pragma unroll
+                    for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
+                } else {                                          // the tail chunk: slots past the end become runs outside the tile
+                    const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
+#pragma unroll
+                    for (int k = 0; k < UN8; ++k) if (k < nu) {
+                        const bool in = threadIdx.x + k * WG < left;
+                        ev8(in ? c[k].x : p0 + ST, in ? c[k].y : 0u);
+                    }
+                }
+            };
+            if (lo < hi) {
+                uint2 A[UN8], B[UN8];
+                uint32_t i = lo;
+                load8(A, i);
+#pragma unroll 1
+                for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
+                    if (i + C < hi) load8(B, i + C);
+                    work8(A, i);
+                    i += C; if (i >= hi) break;
+                    if (i + C < hi) load8(A, i + C);
+                    work8(B, i);
+                    i += C; if (i >= hi) break;
+                }
+            }
+        }
+        if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
+        __syncthreads();
+        if constexpr (EXPORT) {
+            export_packed_tile<ROWS>(win, a, t, ex, wtot);
+            continue;
+        }
+        // ---- prefix sum of the packed window: both half-tiles at once ----
+        int4 v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
+            v[r] = make_int4((int)q.x, (int)q.x + (int)q.y, 0, 0);
+            v[r].z = v[r].y + (int)q.z; v[r].w = v[r].z + (int)q.w;
+        }
+        int ex[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) ex[r] = wave_incl_scan(v[r].w);
+        int run = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int e = run + ex[r] - v[r].w;                   // exclusive prefix of this lane's group in the wave
+            run += __builtin_amdgcn_readlane(ex[r], 63);
+            ex[r] = e;
+        }
+        if (lane == 0) wtot[wv] = run;
+        __syncthreads();
+        int basep = 0;                                            // packed: words of the waves before this one
+        for (int k = 0; k < wv; ++k) basep += wtot[k];
+        const int totp = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        const int tl = (int)(short)(totp & 0xffff);               // begins - ends over the low half-tile
+        const int carry_l = s_carry, carry_h = carry_l + tl;      // depth just before cell 0 / cell HT of the tile
+        // ---- the tile's share of windows k0 and k0 + 1 ----
+        const uint64_t local0 = p0;
+        int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+        bool uniform_counts = false;                              // c0 is a wave count (ballots), s0 a 32-bit lane sum
+        if (local0 < clen) {
+            const uint64_t k0 = local0 / w;
+            const uint64_t nb64 = (k0 + 1) * (uint64_t)w - local0;   // tile-local start of window k0+1
+            const uint32_t nb = nb64 > (uint64_t)ST ? ST : (uint32_t)nb64;
+            const uint64_t left = (uint64_t)clen - local0;
+            const uint32_t lim = left > (uint64_t)ST ? ST : (uint32_t)left;
+            const uint64_t dmax = (uint64_t)(uint32_t)carry_l + cand;     // no depth in this tile exceeds carry + begins
+            if (nb >= ST && lim >= ST && min_dep <= 1u && dmax < (1u << 27) && dmax <= wrap_mask) {
+                // the common tile — inside one window, inside the contig, no wrap possible, threshold <= 1: the sum is the
+                // sum of the local prefixes + 16 x (carry_l + carry_h) per lane; a cell is covered unless its prefix = -carry
+                int sl = 0; int cnt = 0;
+                const int zl = -carry_l, zh = -carry_h;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        sl += L + H;
+                        if (min_dep) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(L != zl)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(H != zh));
+                    }
+                }
+                c0 = min_dep ? cnt : (int)(ROWS * 8 * 64);
+                s0 = (uint32_t)sl + (uint32_t)(ROWS * 4) * ((uint32_t)carry_l + (uint32_t)carry_h);
+                uniform_counts = true;
+            } else if (nb >= ST && lim >= ST && dmax < (1u << 27)) {
+                uint32_t s32 = 0; int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        const uint32_t dl = (uint32_t)(L + carry_l) & wrap_mask, dh = (uint32_t)(H + carry_h) & wrap_mask;
+                        const bool okl = dl >= min_dep, okh = dh >= min_dep;
+                        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(okl)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(okh));
+                        s32 += (okl ? dl : 0u) + (okh ? dh : 0u);
+                    }
+                }
+                c0 = cnt; s0 = s32; uniform_counts = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const int add = basep + ex[r];
+                    const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
+                    const int pw[4] = {v[r].x + add, v[r].y + add, v[r].z + add, v[r].w + add};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = (int)(short)(pw[q] & 0xffff), H = (pw[q] - L) >> 16;
+                        const uint32_t dl = (uint32_t)(L + carry_l) & wrap_mask, dh = (uint32_t)(H + carry_h) & wrap_mask;
+                        const uint32_t pl = pos + q, ph = pl + HT;
+                        if (pl < lim && dl >= min_dep) { if (pl < nb) { ++c0; s0 += dl; } else { ++c1; s1 += dl; } }
+                        if (ph < lim && dh >= min_dep) { if (ph < nb) { ++c0; s0 += dh; } else { ++c1; s1 += dh; } }
+                    }
+                }
+            }
+        }
+        if (uniform_counts) {                                     // workgroup-uniform
+            const uint32_t s32 = (uint32_t)s0;
+            const unsigned long long lo16 = (unsigned long long)(uint32_t)wave_total((int)(s32 & 0xffffu));
+            const unsigned long long hi16 = (unsigned long long)(uint32_t)wave_total((int)(s32 >> 16));
+            s0 = (hi16 << 16) + lo16;
+        } else {
+            c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        }
+        if (lane == 0) { red_c[wv][0] = c0; red_c[wv][1] = c1; red_s[wv][0] = s0; red_s[wv][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            TilePart tp;
+            tp.c0 = (uint32_t)(red_c[0][0] + red_c[1][0] + red_c[2][0] + red_c[3][0]);
+            tp.c1 = (uint32_t)(red_c[0][1] + red_c[1][1] + red_c[2][1] + red_c[3][1]);
+            tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
+            tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
+            part[t] = tp;
+        }
+    }
+}
 
 // Outcome of a direct pass: *fail = 1 unless every batch was complete and sorted and no run was
 // longer than the look-back; re-arms the descriptors (the batches stay pending for the fallback).
@@ -2060,22 +2296,6 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     if (w < (uint32_t)TILE)
         hipLaunchKernelGGL((k_direct_tiles<4, 4, DirectNarrow>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig,
                            wrap_mask, dn, n_long, heavy_list, heavy_count);
-    else if (ps.nb > 0 && ps.b[0].r8) {      // batch 0 is a compact sample: the C8 instantiations (un: 100 x waves-per-SIMD target + 10 x loads in
-                                             // flight per thread of the compact stream + loads per thread of the other streams; 0 = default)
-#define PD_DIRECT8(UN_, WPE_, UN8_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_, false, true, UN8_>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
-        switch (un) {
-        case 622: PD_DIRECT8(2, 6, 2); break;
-        case 642: PD_DIRECT8(2, 6, 4); break;
-        case 542: PD_DIRECT8(2, 5, 4); break;
-        case 582: PD_DIRECT8(2, 5, 8); break;
-        case 742: PD_DIRECT8(2, 7, 4); break;
-        case 842: PD_DIRECT8(2, 8, 4); break;
-        case 822: PD_DIRECT8(2, 8, 2); break;
-        case 641: PD_DIRECT8(1, 6, 4); break;
-        default: PD_DIRECT8(2, 6, 4); break;
-        }
-#undef PD_DIRECT8
-    }
     else if (un == 0 || un >= 3000) {        // second form (k_direct_wide3): 3000 + 100 x waves-per-SIMD target + loads in flight per thread
 #define PD_DIRECT3(UN_, WPE_) hipLaunchKernelGGL((k_direct_wide3<UN_, WPE_, false>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
         // measured on the bench sample (ms; variants that were tried and are no longer compiled included): <2, 6> 3.08-3.13,
@@ -2094,26 +2314,92 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     }
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,
-                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{});
+                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{}, C8Sample{nullptr, nullptr, 0, 0});
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 
-void launch_compact_runs(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, const uint32_t *tile_contig, uint32_t lmax,
-                         uint32_t n_tiles, Run8 *out, uint32_t *tile_first, uint32_t *look_first, uint32_t *words)
+static unsigned grid_1k(uint64_t n) { return (unsigned)((n + 1023) / 1024 ? (n + 1023) / 1024 : 1); }
+
+void launch_c8_scan_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets, uint32_t *b1, uint32_t *words)
 {
-    hipLaunchKernelGGL(k_compact_runs, dim3((unsigned)(((uint64_t)n + WG - 1) / WG)), dim3(WG), 0, st, iv, n, tab, lmax, n_tiles, out, tile_first,
-                       look_first, words);
-    hipLaunchKernelGGL(k_compact_clip, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const uint32_t *)tile_first, look_first, tile_contig, tab, n_tiles);
+    hipLaunchKernelGGL(k_c8_scan_sorted, dim3((unsigned)(((uint64_t)n + WG - 1) / WG)), dim3(WG), 0, st, iv, n, tab, bshift, n_buckets, b1, words);
 }
 
-void launch_expand_runs(hipStream_t st, const Run8 *r8, const uint32_t *tile_first, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
+void launch_c8_hist(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words)
 {
-    hipLaunchKernelGGL(k_expand_runs, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, r8, tile_first, tile_contig, n_tiles, out);
+    const uint64_t g = ((uint64_t)n + WG - 1) / WG;
+    hipLaunchKernelGGL(k_c8_hist, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, iv, n, tab, bshift, hist, words);
 }
 
-void launch_desc_all_tiles(hipStream_t st, BatchDesc *desc, uint32_t n_tiles)
+void launch_excl_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *block_sums)
 {
-    hipLaunchKernelGGL(k_desc_all_tiles, dim3(1), dim3(1), 0, st, desc, n_tiles);
+    const unsigned nb = grid_1k(n);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(WG), 0, st, in, n, block_sums);
+    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, st, block_sums, nb);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(WG), 0, st, in, out, n, (const uint32_t *)block_sums);
+}
+
+void launch_c8_place(hipStream_t st, const pd_iv *sorted, uint32_t n_sorted, const pd_iv *const *others, const uint32_t *n_others, int n_other_arrays,
+                     ContigTab tab, uint32_t bshift, uint32_t n_buckets, const uint32_t *b1, const uint32_t *o2, uint32_t *cursor, Run8 *out, uint32_t *bstart)
+{
+    hipLaunchKernelGGL(k_c8_bstart, dim3((unsigned)(((uint64_t)n_buckets + 1 + WG - 1) / WG)), dim3(WG), 0, st, b1, o2, n_buckets, bstart);
+    if (n_sorted) {
+        const uint64_t g = ((uint64_t)n_sorted + WG - 1) / WG;
+        hipLaunchKernelGGL(k_c8_place_sorted, dim3((unsigned)(g > 131072 ? 131072 : g)), dim3(WG), 0, st, sorted, n_sorted, tab, bshift, o2, out);
+    }
+    for (int k = 0; k < n_other_arrays; ++k) {
+        if (!n_others[k]) continue;
+        const uint64_t g = ((uint64_t)n_others[k] + WG - 1) / WG;
+        hipLaunchKernelGGL(k_c8_place_other, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, others[k], n_others[k], tab, bshift, b1, o2, cursor, out);
+    }
+}
+
+void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
+{
+    hipLaunchKernelGGL(k_c8_expand, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, cs, tile_contig, n_tiles, out);
+}
+
+void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
+                      uint32_t min_dep, TilePart *part, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un)
+{
+    const DirectWide dw{w, min_dep, part};
+    // "direct_un" for a compact sample: 100 x waves-per-SIMD target + loads in flight per thread (0 = default)
+#define PD_C8(WPE_, UN8_) hipLaunchKernelGGL((k_direct_c8<WPE_, UN8_, false>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{})
+    switch (un) {
+    case 502: PD_C8(5, 2); break;
+    case 504: PD_C8(5, 4); break;
+    case 508: PD_C8(5, 8); break;
+    case 602: PD_C8(6, 2); break;
+    case 604: PD_C8(6, 4); break;
+    case 702: PD_C8(7, 2); break;
+    case 704: PD_C8(7, 4); break;
+    case 802: PD_C8(8, 2); break;
+    case 804: PD_C8(8, 4); break;
+    case 801: PD_C8(8, 1); break;
+    case 708: PD_C8(7, 8); break;
+    case 803: PD_C8(8, 3); break;
+    case 703: PD_C8(7, 3); break;
+    // measured on the bench sample (ms): <7, 4> 1.99, <8, 2> 2.01, <6, 4> 2.16, <7, 2> 2.17, <5, 8> 2.25, <6, 2> 2.40, <5, 4> 2.41, <8, 4> 2.41 (spills),
+    // <8, 1> 2.42, <5, 2> 2.70 — k_direct_wide3 on the same sample as 12-byte streams: 3.11
+    default: PD_C8(7, 4); break;
+    }
+#undef PD_C8
+    WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = nullptr; wa.sum = nullptr; wa.part = part;
+    PendSet none{}; none.nb = 0; none.lmax = 0;
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, none, n_tiles, tab, tile_contig, wrap_mask, wa, (const uint64_t *)nullptr,
+                       heavy_count + 1 /* n_long: unused here */, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{}, cs);
+}
+
+void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,
+                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
+{
+    const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
+    hipLaunchKernelGGL((k_direct_c8<7, 4, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+                       DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
+    WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
+    PendSet none{}; none.nb = 0; none.lmax = 0;
+    hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, none, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa, (const uint64_t *)nullptr,
+                       heavy_count + 1, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de, cs);
 }
 
 void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
@@ -2123,16 +2409,12 @@ void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, cons
     const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
     // the second form of the direct kernel with its export branch (the first form's export instantiation — 128 VGPRs and
     // 160 bytes of spills — took 5.2 ms per sample)
-    if (ps.nb > 0 && ps.b[0].r8)
-        hipLaunchKernelGGL((k_direct_wide3<2, 5, true, true, 4>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
-                           DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
-    else
-        hipLaunchKernelGGL((k_direct_wide3<2, 5, true>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
-                           DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
+    hipLaunchKernelGGL((k_direct_wide3<2, 5, true>), dim3(grid_tiles), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+                       DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
     // tiles with more than 32 000 candidates: the int-window kernel exports them
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa,
-                       (const uint64_t *)nullptr, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de);
+                       (const uint64_t *)nullptr, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de, C8Sample{nullptr, nullptr, 0, 0});
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 

@@ -779,74 +779,90 @@ def _hard_sample(seed, n=60000, long_run=False):
 
 @pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (10000000, 0, 0), (16384, 1, 18), (250000, 2, 0)])
 def test_compact_sample_agrees_with_oracle_on_hard_tiles(w, min_dep, wrap):
-    """The compact form of the sorted stream through every compiled C8 variant of the wide direct kernel, against the oracle:
-    the pile-up tile (int-window kernel reading Run8), runs clipped at both ends of a contig, empty and reversed runs, ends on
-    tile edges, contigs of exactly one tile / one cell / 8191 cells, a second (12-byte, nearly sorted) stream beside it."""
+    """A whole sample in the compact form (sorted first runs + unordered later runs, bucketed) through every compiled variant of
+    k_direct_c8, against the oracle: the pile-up tile (int-window kernel reading Run8), runs clipped at both ends of a contig,
+    empty and reversed runs, ends on tile and bucket edges, contigs of exactly one tile / one cell / 8191 cells."""
     import torch
     dev = torch.device("cuda", 0)
     first, other = _hard_sample(5100 + w % 97)
+    rng = np.random.default_rng(3)
+    other = other[rng.permutation(other.shape[0])]                 # the second array may come in any order
     d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
     cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
-    ft = torch.from_numpy(first).to(dev)
+    ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     with pda.Engine(LENS) as e:
         e.set_param("direct_windows", 1)
-        runs = e.runs_create(ft.data_ptr(), first.shape[0])
-        for un in (0, 622, 642, 542, 582, 742, 842, 822, 641):
+        runs = e.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
+        for un in (0, 502, 504, 508, 602, 604, 702, 704, 802, 804, 801):
             e.set_param("direct_un", un)
             e.reset()
             e.push_runs(runs, pda.PD_PUSH_MORE)
-            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
             woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
             assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref), un
         e.set_param("direct_un", 0)
-        # alone (no second stream), and pushed without PD_PUSH_MORE (scattered at once: the expanded copy)
+        e.reset()
+        e.runs_destroy(runs)
+        # the sorted array alone; pushed with PD_PUSH_MORE (direct) and without (scattered at once: the expanded copy)
         d1, off1 = oracle_depth(LENS, first, wrap == 18)
         c1, t1 = windows_ref(LENS, d1, off1, w, min_dep)
+        runs = e.runs_create(ft.data_ptr(), first.shape[0])
         for flags in (pda.PD_PUSH_MORE, 0):
             e.reset()
             e.push_runs(runs, flags)
             woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
             assert np.array_equal(cover, c1) and np.array_equal(tot, t1), flags
+        # ... and with another batch pushed beside it (the compact sample is expanded, both take the 12-byte kernels)
+        e.reset()
+        e.push_runs(runs, pda.PD_PUSH_MORE)
+        e.push_intervals(sort_iv(other), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
+        woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+        assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
+        e.reset()
+        e.runs_destroy(runs)
+        # only unordered runs (no sorted array at all)
+        runs = e.runs_create(0, 0, ot.data_ptr(), other.shape[0])
+        d2, off2 = oracle_depth(LENS, other, wrap == 18)
+        c2, t2 = windows_ref(LENS, d2, off2, w, min_dep)
+        e.push_runs(runs, pda.PD_PUSH_MORE)
+        woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
+        assert np.array_equal(cover, c2) and np.array_equal(tot, t2)
         e.reset()
         e.runs_destroy(runs)
 
 
 def test_compact_sample_takes_every_other_path_expanded():
-    """Whatever cannot read Run8 — narrow windows, pd_scan + per-base reads, a sample with runs longer than the look-back, an export
-    after such a sample — gets the 12-byte form back and the same answers; an unsorted batch is refused."""
+    """Whatever cannot read Run8 — narrow windows, pd_scan + per-base reads, a sample with runs longer than a bucket, an export
+    of such a sample — gets 12-byte runs back and the same answers; an unsorted first array is refused."""
     import torch
     dev = torch.device("cuda", 0)
     first, other = _hard_sample(77)
     both = np.concatenate([first, other])
-    ft = torch.from_numpy(first).to(dev)
+    ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     with pda.Engine(LENS) as e:
         e.set_param("direct_windows", 1)
-        runs = e.runs_create(ft.data_ptr(), first.shape[0])
+        runs = e.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
         for w, md, wrap in ((100, 1, 0), (1000, 2, 18), (64, 1, 0), (8191, 1, 0)):
             d, off = oracle_depth(LENS, both, wrap == 18)
             cr, tr = windows_ref(LENS, d, off, w, md)
             e.reset()
             e.push_runs(runs, pda.PD_PUSH_MORE)
-            e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
             woff, cover, tot = e.scan_reduce_windows(w, md, wrap)
             assert np.array_equal(cover, cr) and np.array_equal(tot, tr), (w, md, wrap)
         d, off = oracle_depth(LENS, both, False)
         e.reset()
         e.push_runs(runs, pda.PD_PUSH_MORE)
-        e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         e.scan(0)
         for t in range(len(LENS)):
             assert np.array_equal(e.read_depth(t, 0, int(LENS[t])), d[off[t]:off[t] + LENS[t]]), t
         e.reset()
         e.runs_destroy(runs)
-        # runs longer than the look-back: the compact form is made, but the wide path expands it (and then declines to the arrays)
+        # runs longer than a bucket: the compact form is made, but the wide path expands it (and then declines to the arrays)
         fl, ol = _hard_sample(78, long_run=True)
-        flt = torch.from_numpy(fl).to(dev)
-        runs = e.runs_create(flt.data_ptr(), fl.shape[0])
+        flt, olt = torch.from_numpy(fl).to(dev), torch.from_numpy(ol).to(dev)
+        runs = e.runs_create(flt.data_ptr(), fl.shape[0], olt.data_ptr(), ol.shape[0])
         d, off = oracle_depth(LENS, np.concatenate([fl, ol]), True)
         cr, tr = windows_ref(LENS, d, off, 10000, 1)
         e.push_runs(runs, pda.PD_PUSH_MORE)
-        e.push_intervals(ol, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         woff, cover, tot = e.scan_reduce_windows(10000, 1, 18)
         assert np.array_equal(cover, cr) and np.array_equal(tot, tr)
         e.reset()
@@ -860,16 +876,20 @@ def test_compact_sample_takes_every_other_path_expanded():
         bt = torch.from_numpy(bad).to(dev)
         with pytest.raises(pda.PdError):
             e.runs_create(bt.data_ptr(), bad.shape[0])
+        bad = other.copy(); bad[7, 0] = -1
+        bt = torch.from_numpy(bad).to(dev)
+        with pytest.raises(pda.PdError):
+            e.runs_create(ft.data_ptr(), first.shape[0], bt.data_ptr(), bad.shape[0])
 
 
 def test_compact_export_equals_export_of_the_arrays():
-    """pd_export_i4 on a compact deferred sample (the C8 export instantiation, 16-byte image stores): image, exception set and
-    tile sums equal to what the materialising path exports; the sample stays deferred."""
+    """pd_export_i4 on a compact deferred sample (k_direct_c8's export instantiation, 16-byte image stores): image, exception set
+    and tile sums equal to what the materialising path exports; the sample stays deferred."""
     import torch
     from pandepth_amd import multi
     dev = torch.device("cuda", 0)
     first, other = _hard_sample(402)
-    ft = torch.from_numpy(first).to(dev)
+    ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     B = 8192
 
     def export(e):
@@ -887,9 +907,8 @@ def test_compact_export_equals_export_of_the_arrays():
         ea.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(800))
         img_a, exc_a = export(ea)
         ed.set_param("direct_windows", 1)
-        runs = ed.runs_create(ft.data_ptr(), first.shape[0])
+        runs = ed.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
         ed.push_runs(runs, pda.PD_PUSH_MORE)
-        ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         img_d, exc_d = export(ed)
         assert torch.equal(img_a, img_d)
         key = lambda x: sorted(map(tuple, x.tolist()))
@@ -899,7 +918,6 @@ def test_compact_export_equals_export_of_the_arrays():
         sd = multi.SlicedSum(ed, dev)
         ed.reset()
         ed.push_runs(runs, pda.PD_PUSH_MORE)
-        ed.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         sd.start(0); got = sd.finish(0, 10000, 1, 18)
         assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
         w2 = ed.scan_reduce_windows(10000, 1, 18)

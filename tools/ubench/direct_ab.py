@@ -14,14 +14,14 @@ R = int(float(os.environ.get("R", "1e9")))
 first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
 torch.cuda.synchronize()
 eng.set_param("direct_windows", 1)
-runs8 = eng.runs_create(first.data_ptr(), int(first.shape[0]))          # the compact form of the sorted stream (variants "c<un>")
+runs8 = eng.runs_create(first.data_ptr(), int(first.shape[0]), other.data_ptr(), int(other.shape[0]))   # the sample in the compact form (variants "c<un>")
 compact = False
 def scatter():
     eng.reset()
     if compact:
         eng.push_runs(runs8, pda.PD_PUSH_MORE)
-    else:
-        eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+        return
+    eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
     eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN) | pda.PD_PUSH_MORE)
 n_cells, _ = eng.device_layout()
 img = torch.zeros(n_cells // 2, dtype=torch.uint8, device=dev)

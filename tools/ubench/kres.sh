@@ -13,5 +13,5 @@ for r in rows:
     try: nm=subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt',r['name']],capture_output=True,text=True).stdout.strip().split('(')[0]
     except Exception: nm=r['name']
     if flt and flt not in nm: continue
-    print('%-70s VGPR %3s  spill %3s  scratch %4s  occ %s  LDS %s' % (nm[-70:], r.get('VGPRs'), r.get('VGPRs Spill'), r.get('ScratchSize'), r.get('Occupancy'), r.get('LDS Size')))
+    print('%-110s VGPR %3s  spill %3s  scratch %4s  occ %s  LDS %s' % (nm[:110], r.get('VGPRs'), r.get('VGPRs Spill'), r.get('ScratchSize'), r.get('Occupancy'), r.get('LDS Size')))
 " "$2"
