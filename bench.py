@@ -718,7 +718,8 @@ def main():
             pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
             pmc = json.load(open(pmc_file))
             key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
-                   "direct_tiles": "k_direct_wide3<"}.get(dom)
+                   "direct_tiles": "k_direct_c8<" if used_compact else "k_direct_wide3<",
+                   "direct_export": "k_direct_c8<" if used_compact else "k_direct_wide3<"}.get(dom)
             key = next((k for k in pmc["kernels"] if key and k.startswith(key.rstrip(">"))), None)    # template arguments may grow
             if key and R == int(1e9):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
@@ -733,8 +734,8 @@ def main():
             import csv
             import glob
             kf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
-            want = {"direct_tiles": "k_direct_wide3<", "scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
-                    "direct_export": "k_direct_wide3<"}.get(dom)
+            want = {"direct_tiles": "k_direct_c8<" if used_compact else "k_direct_wide3<", "scatter_tiles": "k_scatter_tiles<8192>",
+                    "scan_reduce_windows": "k_sweep<false, true, false>", "direct_export": "k_direct_c8<" if used_compact else "k_direct_wide3<"}.get(dom)
             for row in csv.DictReader(open(kf)):
                 if want and want in row["Name"]:
                     rocprof_avg = {"avg_launch_ms": round(float(row["AverageNs"]) / 1e6, 4), "calls": int(row["Calls"]), "source": "profiles/" + os.path.basename(kf)}

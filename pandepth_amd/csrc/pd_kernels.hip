@@ -2372,16 +2372,16 @@ void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t
     case 602: PD_C8(6, 2); break;
     case 604: PD_C8(6, 4); break;
     case 702: PD_C8(7, 2); break;
-    case 704: PD_C8(7, 4); break;
     case 802: PD_C8(8, 2); break;
     case 804: PD_C8(8, 4); break;
     case 801: PD_C8(8, 1); break;
     case 708: PD_C8(7, 8); break;
     case 803: PD_C8(8, 3); break;
     case 703: PD_C8(7, 3); break;
-    // measured on the bench sample (ms): <7, 4> 1.99, <8, 2> 2.01, <6, 4> 2.16, <7, 2> 2.17, <5, 8> 2.25, <6, 2> 2.40, <5, 4> 2.41, <8, 4> 2.41 (spills),
+    // measured on the bench sample (ms): <8, 3> 1.89, <7, 4> 1.99, <7, 3> 2.01, <8, 2> 2.01, <6, 4> 2.16, <7, 2> 2.17, <5, 8> 2.25, <6, 2> 2.40, <5, 4> 2.41, <8, 4> 2.41 (spills),
     // <8, 1> 2.42, <5, 2> 2.70 — k_direct_wide3 on the same sample as 12-byte streams: 3.11
-    default: PD_C8(7, 4); break;
+    case 704: PD_C8(7, 4); break;
+    default: PD_C8(8, 3); break;
     }
 #undef PD_C8
     WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = nullptr; wa.sum = nullptr; wa.part = part;

@@ -150,8 +150,8 @@ def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, shim
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()
-        assert hashlib.sha256(gzip.decompress(gz)).hexdigest() == meta["sha256"], suffix
-        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix
+        assert hashlib.sha256(gzip.decompress(gz)).hexdigest() == meta["text_sha256"], suffix
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix + " (gz bytes)"
 
 
 def test_messages_are_chunked_at_full_size(shim):

@@ -33,6 +33,23 @@ for it in range(2):
     eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
     eng.scan_reduce_windows(10000000, 1, 0)
     eng.synchronize()
+# the same sample in the compact form (pd_runs_create): k_direct_c8, and its export instantiation (pd_export_i4)
+runs8 = eng.runs_create(first.data_ptr(), int(first.shape[0]), other.data_ptr(), int(other.shape[0]))
+n_cells, _ = eng.device_layout()
+img = torch.zeros(n_cells // 2, dtype=torch.uint8, device=dev)
+exc = torch.zeros((1 << 18, 2), dtype=torch.int64, device=dev)
+cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+for it in range(2):
+    eng.reset()
+    eng.push_runs(runs8, pda.PD_PUSH_MORE)
+    eng.scan_reduce_windows(10000000, 1, 0)
+    eng.reset()
+    eng.push_runs(runs8, pda.PD_PUSH_MORE)
+    eng.export_i4(img.data_ptr(), exc.data_ptr(), 1 << 18, cnt.data_ptr())
+    eng.synchronize()
+eng.reset()
+eng.runs_destroy(runs8)
 eng.set_param("direct_windows", 0)
 eng.reset()
 print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]))
