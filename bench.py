@@ -742,8 +742,16 @@ def main():
                     break
         except (OSError, IndexError, KeyError, ValueError):
             rocprof_avg = None
+        # what the dominant kernel actually has to read when the sample is resident in the compact form: 8 B per run, a tile's own
+        # buckets plus the one bucket (1/16 of a tile) before it, 12 B of bounds and 24 B of partials per tile.  `frac` stays on
+        # SURVEY 8(d)'s 12 B per run (the contract's algorithmic figure, comparable across rounds); this one is reported beside it
+        bytes_read_model = None
+        if used_compact and dom in ("direct_tiles", "direct_export"):
+            bytes_read_model = int((n_first + n_other + n_far) * 8 * (1 + 1 / 16) + (n_cells // 8192) * 36 + (n_cells // 2 if dom == "direct_export" else 0))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kd["frac"], "traffic": None,
+                    "bytes_moved_model": bytes_read_model,
+                    "frac_on_bytes_moved": (round(bytes_read_model / (kd["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if bytes_read_model else None),
                     "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)}
                                              if traffic else None),
                     "avg_launch_ms": kd["avg_ms"], "avg_launch_ms_rocprof": rocprof_avg, "algorithmic_bytes_per_launch": kd["algorithmic_bytes"]}
