@@ -2087,14 +2087,18 @@ struct I4Src {
     const pd_exc *exc; uint64_t exc_stride; const int32_t *counts;
 };
 
+// PATCH = false: the tiles without exceptions (nearly all) — no 32 KB patch window in LDS, so eight workgroups fit a CU instead of
+// five (the kernel waits for its one load per lane and part: residency is its throughput); PATCH = true: only the flagged tiles.
+template <bool PATCH>
 __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
                                                  uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0)
 {
     __shared__ int wtot[4];
-    __shared__ int patch[TILE];
+    __shared__ int patch[PATCH ? TILE : 1];
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
     const uint32_t i = blockIdx.x;
+    if ((src.flags && src.flags[i] != 0) != PATCH) return;       // workgroup-uniform
     const uint64_t t = (uint64_t)i + tile0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int a[32];
@@ -2120,7 +2124,7 @@ __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *car
                 a[8 * m + 2 * b + 1] += (int)((hi[m] >> (8 * b)) & 0xff);
             }
     }
-    if (src.flags && src.flags[i]) {                             // workgroup-uniform
+    if constexpr (PATCH) {
         for (int k = tid; k < TILE; k += WG) patch[k] = 0;
         __syncthreads();
         for (uint32_t j = 0; j < src.n_parts; ++j) {
@@ -2232,7 +2236,8 @@ void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64
                            (uint64_t)tile_first, (uint64_t)tile_count, flags);
     }
     I4Src src{(const uint8_t *)parts, stride, n_parts, with_exc ? flags : nullptr, exc, exc_stride, exc_counts};
-    hipLaunchKernelGGL(k_sweep_i4, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
+    hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
+    if (with_exc) hipLaunchKernelGGL(k_sweep_i4<true>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
 }
 
 void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,

@@ -32,7 +32,7 @@ static int check_stream(const unsigned char *in, size_t n, size_t isize, const c
 {
     std::vector<unsigned char> padded(in, in + n);
     padded.resize(n + 16, 0xA5);
-    std::vector<unsigned char> mine(isize + 9, 0xEE), ref;
+    std::vector<unsigned char> mine(isize + 32, 0xEE), ref;      // (the span path reads up to 15 bytes past a stretch: the product buffers carry 256 bytes of slack)
     const bool zok = zinflate(in, n, ref, isize);
     const int rc = pdw::inflate_block<pdw::HostWave>(padded.data(), (uint32_t)n, mine.data(), (uint32_t)isize, g_T, g_tok, &g_st);
     if (must_decode && !zok) { fprintf(stderr, "%s: zlib itself failed\n", what); return 1; }
