@@ -68,7 +68,7 @@ struct Tables {
 
 struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
     uint64_t blocks = 0, dblocks = 0, steps = 0, sync_rounds = 0, emit_rounds = 0, sym_true = 0, sym_decoded = 0, lanes_redecoded = 0;
-    uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0, span_batches = 0, span_bytes = 0;
+    uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0;
 };
 
 PW_FN uint64_t ld64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
@@ -430,50 +430,6 @@ PW_FN void copy_match(uint8_t *out, uint32_t dst, uint32_t dist, uint32_t len)
     }
 }
 
-// ---- phase 3 inside a SPAN of the output held in LDS (round 3) ----------------------------------------------------------
-// The matches of a batch copy from about one record back, i.e. mostly from bytes that earlier matches OF THE SAME BATCH produce:
-// through global memory every such dependency was a memory round trip (3.8 per batch of 64 matches, ~5 us each under load: 46 %
-// of the kernel).  Here the stretch of output the batch covers — from its first match's destination to its last match's end, at
-// most SPAN_CAP bytes — is brought into LDS (the literals phase 2 wrote are in it), the matches are resolved THERE (sources at or
-// after the span start are LDS reads; sources before it are final bytes in global memory), and the finished stretch goes back
-// with coalesced 16-byte stores.  The dependent rounds cost LDS latency, the global accesses are one coalesced read, one
-// coalesced write and the few scattered reads of sources that lie before the span.
-enum { SPAN_CAP = 4096 };
-PW_FN void ld128(const uint8_t *p, uint64_t &a, uint64_t &b) { a = ld64(p); b = ld64(p + 8); }
-
-// 8 bytes of the output at position pos, where positions >= S live in the span (sp[pos - S]) and earlier ones in `out`
-PW_FN uint64_t span_ld64(const uint8_t *out, const uint8_t *sp, uint32_t S, uint32_t pos)
-{
-    if (pos >= S) return ld64(sp + (pos - S));
-    if (pos + 8 <= S) return ld64(out + pos);
-    const uint32_t k = S - pos;                                            // 1 .. 7 bytes before the span, the rest from its start
-    return (ld64(out + pos) & ((1ull << (8 * k)) - 1)) | (ld64(sp) << (8 * k));
-}
-
-// the match (dst, dist, len) resolved into the span: every source byte is final (before the span), or already in the span
-PW_FN void span_copy(const uint8_t *out, uint8_t *sp, uint32_t S, uint32_t dst, uint32_t dist, uint32_t len)
-{
-    uint8_t *d = sp + (dst - S);
-    const uint32_t src = dst - dist;
-    if (dist < 8) {
-        // period < 8: the 8 bytes at the source hold at least one period; byte j of the result = raw byte (j mod dist)
-        const uint64_t raw = span_ld64(out, sp, S, src);
-        uint32_t phase = 0;
-        const uint32_t step = 8 % dist;
-        for (uint32_t i = 0; i < len; i += 8) {
-            uint64_t v = 0; uint32_t q = phase;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v |= ((raw >> (8 * q)) & 0xff) << (8 * k); q = q + 1 == dist ? 0 : q + 1; }
-            store_bytes(d + i, v, len - i);
-            phase += step; if (phase >= dist) phase -= dist;
-        }
-        return;
-    }
-    // dist >= 8: chunk i reads bytes that lie at least 8 behind where it writes — written by this lane's earlier chunks when the
-    // match overlaps itself (the LDS keeps a wave's accesses in order), final otherwise
-    for (uint32_t i = 0; i < len; i += 8) store_bytes(d + i, span_ld64(out, sp, S, src + i), len - i);
-}
-
 // A match waiting to be copied: out[dst .. dst+len) = out[dst-dist ..] (positions inside the member's output).
 struct Token { uint32_t dst; uint32_t len_dist; };             // len_dist = len | dist << 16
 
@@ -482,7 +438,7 @@ struct Token { uint32_t dst; uint32_t len_dist; };             // len_dist = len
 // `tok` = scratch for out_len / 3 + 64 tokens (global memory on the GPU).
 template <class W>
 PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8_t *out, uint32_t out_len, uint32_t &o_io, Tables &T,
-                      Token *tok, Stats *st, const bool span_ok = true)
+                      Token *tok, Stats *st)
 {
     typedef typename W::template Var<uint32_t> U;
     uint32_t base = q_io, o = o_io;
@@ -585,94 +541,6 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         // on each other (they copy from about a record back), so a batch takes one or two rounds: a lane copies once the
         // earlier matches of the batch that overlap its source are done (the exact set, as a lane mask); everything before
         // the batch — literals of phase 2, earlier batches — is final.  The lowest unfinished lane is always ready.
-        // The last superstep of a deflate block (nearly always its only one) no longer needs the Huffman tables: their LDS holds
-        // the span.  (An earlier superstep of a long block keeps its tables and takes the rounds through global memory below.)
-        if (kend < 64 && span_ok) {
-            uint8_t *sp = reinterpret_cast<uint8_t *>(T.ll);              // SPAN_CAP + 16 bytes of slack fit (5376 bytes)
-            uint32_t b0 = 0;
-            U t_dst, t_ld;
-            W::each([&](int l) { t_dst[l] = t_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; t_dst[l] = k.dst; t_ld[l] = k.len_dist; } });
-            W::sync();                                                    // (every lane is done with the tables)
-            while (b0 < n_tok) {
-                U dst, len, dist, dep_lo, dep_hi, valid, fits;
-                W::each([&](int l) {
-                    valid[l] = b0 + (uint32_t)l < n_tok;
-                    dst[l] = valid[l] ? t_dst[l] : 0u; len[l] = valid[l] ? t_ld[l] & 0xffff : 0u; dist[l] = valid[l] ? t_ld[l] >> 16 : 0u;
-                });
-                const uint32_t S = W::bcast(dst, 0);
-                // the batch: as many consecutive matches as end within SPAN_CAP bytes of S (tokens are in output order; one always fits)
-                W::each([&](int l) { fits[l] = valid[l] && dst[l] + len[l] - S <= (uint32_t)SPAN_CAP; });
-                const uint64_t fm = W::ballot_ne(fits, 0u);
-                const uint32_t nb = (uint32_t)__builtin_ctzll(~fm);       // fits is a prefix of the lanes (fm == ~0: 64)
-                U endv;
-                W::each([&](int l) { endv[l] = dst[l] + len[l]; valid[l] = (uint32_t)l < nb; });
-                const uint32_t E = W::bcast(endv, (int)nb - 1);
-                const uint32_t span_len = E - S;
-                // the next batch's tokens, a batch ahead
-                U n_dst, n_ld;
-                W::each([&](int l) { n_dst[l] = n_ld[l] = 0; const uint32_t i = b0 + nb + (uint32_t)l; if (i < n_tok) { const Token k = tok[i]; n_dst[l] = k.dst; n_ld[l] = k.len_dist; } });
-                // 1. the stretch [S, E) into LDS, 16 bytes per lane and trip (reads up to 15 bytes past E: inside the inflated buffer's slack)
-                W::each([&](int l) {
-                    for (uint32_t off = (uint32_t)l * 16; off < span_len; off += 1024) { uint64_t a, b; ld128(out + S + off, a, b); st64(sp + off, a); st64(sp + off + 8, b); }
-                    T.bdst()[l] = valid[l] ? dst[l] : 0xFFFFFFFFu;
-                    T.bend()[l] = valid[l] ? dst[l] + len[l] : 0xFFFFFFFFu;
-                });
-                W::sync();
-                // 2. dependencies inside the batch (exact: the earlier matches whose destination overlaps the source), then rounds
-                W::each([&](int l) {
-                    dep_lo[l] = 1; dep_hi[l] = 0;                          // empty
-                    if (!valid[l] || l == 0) return;
-                    const uint32_t src = dst[l] - dist[l];
-                    const uint32_t send = src + (len[l] < dist[l] ? len[l] : dist[l]);
-                    if (send <= S) return;                                // the source ends before the batch's first match
-                    int lo = 0, hi = l;                                   // first i in [0, l) with bend[i] > src (l if none)
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
-                    const int i_lo = lo;
-                    lo = 0; hi = l;                                       // number of i in [0, l) with bdst[i] < send
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
-                    dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;
-                });
-                uint64_t done = W::ballot_eq(valid, 0u);
-                for (int round = 0; done != ~0ull; ++round) {
-                    if (round > 64) return -9;
-                    U ready;
-                    W::each([&](int l) {
-                        ready[l] = 0;
-                        if ((done >> l) & 1) return;
-                        uint64_t dm = 0;
-                        if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
-                        if (dm & ~done) return;
-                        ready[l] = 1;
-                        span_copy(out, sp, S, dst[l], dist[l], len[l]);
-                        if (st) st->copy_iters += (len[l] + 7) / 8;
-                    });
-                    W::fence();
-                    done |= W::ballot_ne(ready, 0u);
-                    if (st) st->emit_rounds++;
-                }
-                if (st) { st->batches++; st->span_batches++; st->span_bytes += span_len; }
-                W::sync();
-                // 3. the finished stretch back to global memory: whole 16-byte pieces, then the last bytes exactly (what follows E
-                // belongs to later tokens, or to the next member's wave)
-                W::each([&](int l) {
-                    for (uint32_t off = (uint32_t)l * 16; off < span_len; off += 1024) {
-                        const uint32_t left = span_len - off;
-                        if (left >= 16) { uint64_t a, b; ld128(sp + off, a, b); st64(out + S + off, a); st64(out + S + off + 8, b); }
-                        else {
-                            if (left >= 8) { st64(out + S + off, ld64(sp + off)); if (left > 8) store_bytes(out + S + off + 8, ld64(sp + off + 8), left - 8); }
-                            else store_bytes(out + S + off, ld64(sp + off), left);
-                        }
-                    }
-                });
-                W::sync();
-                b0 += nb;
-                W::each([&](int l) { t_dst[l] = n_dst[l]; t_ld[l] = n_ld[l]; });
-            }
-            PW_TICK(4);
-            o += total;
-            q_io = W::bcast(e, (int)kend); o_io = o;
-            return 0;
-        }
         U nx_dst, nx_ld;                                                  // the next batch's tokens are fetched a batch ahead
         W::each([&](int l) { nx_dst[l] = nx_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
         for (uint32_t b0 = 0; b0 < n_tok; b0 += 64) {
