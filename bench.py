@@ -611,7 +611,7 @@ def main():
         own = torch.from_numpy(eng.scan_reduce_windows(BIN, 1, wrap)[2].astype(np.int64)).to(dev)
         dist.all_reduce(own, op=dist.ReduceOp.SUM)
         if direct:
-            scatter()                              # the direct window call consumed the sample
+            scatter()                              # (a fresh step, as in the timed loop; the direct call itself leaves the sample deferred)
         got = sliced.run(BIN, 1, wrap, 0) if sliced is not None else sum_to_rank0()
         if rank == 0:
             selfcheck = bool(np.array_equal(got[2].astype(np.int64), own.cpu().numpy()))

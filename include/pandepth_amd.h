@@ -98,7 +98,7 @@ int pd_push_intervals_device(pd_ctx *ctx, const pd_iv *dev_iv, size_t n, unsigne
 /* A whole sample kept in the engine's COMPACT form (what the GPU decoder leaves for the whole-contig modes): 8 bytes per
  * run — begin inside its contig, already clipped to [0, len] as PD:449-452's cells are, and length — grouped by bucket of
  * 512 cells (the "lmax" look-back bound) with the exact index of every bucket's first run, the contig implied by the run's
- * place.  The direct window path (pd_scan_reduce_windows with "direct_windows", windows of >= 8192 cells; pd_export_i4)
+ * place.  The direct window path (pd_scan_reduce_windows after pd_keep_deferred, windows of >= 8192 cells; pd_export_i4)
  * then reads a third fewer bytes, tests no contig ids and no bounds, and visits only a tile's own runs and those of the one
  * bucket before it.  pd_runs_create takes the sample as the decoder has it — `dev_sorted`, sorted by (tid, beg) (every read's
  * first run; the order is CHECKED: PD_EINVAL if it does not hold or a contig id is out of range — push such runs the ordinary
@@ -118,11 +118,16 @@ int pd_push_runs(pd_ctx *ctx, const pd_runs *runs, unsigned flags);
 int pd_stage_acquire(pd_ctx *ctx, pd_iv **host_buf, size_t *capacity);
 int pd_stage_submit(pd_ctx *ctx, pd_iv *host_buf, size_t n, unsigned flags);
 
-/* Tuning knobs: "lmax" (owner-tile look-back in cells; longer runs take the overflow path),
- * "sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the tile kernel),
- * "accumulate_packed" (pd_accumulate_from's transport, default 1), "direct_windows" (default 0, see
- * pd_scan_reduce_windows), "direct_un" (tuning variant of the direct kernel). */
-int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
+/* A whole sample that was pushed DEFERRED (every batch with PD_PUSH_SORTED | PD_PUSH_MORE, or pd_push_runs, or what pd_decode_end
+ * leaves) into a context that holds nothing else may be served without ever materialising the difference arrays: wide-window
+ * statistics (pd_scan_reduce_windows, w >= 64) and the multi-GPU image (pd_export_i4) are then computed straight from the runs
+ * (the direct kernels), and pd_synchronize leaves the sample deferred instead of scattering it.  Off by default because it
+ * changes ONE thing for the caller: with it on, the memory of device batches pushed with PD_PUSH_MORE must stay valid until
+ * pd_reset or until a call that materialises the arrays (pd_scan, pd_accumulate_from, narrow windows ...) has returned, not
+ * just until the next pd_synchronize.  Results are identical either way, and the direct calls READ the sample: it stays
+ * deferred and every other call works on it afterwards.  (Tuning knobs that never change results or contracts: pd_set_param,
+ * include/pandepth_amd_dev.h.) */
+int pd_keep_deferred(pd_ctx *ctx, int enable);
 
 /* Difference arrays -> per-base depth, in place (the wavefront prefix-sum sweep).
  * wrap_bits = 18 reproduces the `unsigned Depth:18` cell (DataClass.h:85-88) used by the -a,
@@ -264,9 +269,9 @@ int pd_sliced_sum_start(pd_comm *comm, int slot);
 int pd_sliced_sum_finish(pd_comm *comm, int slot, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
 
 void *pd_stream(pd_ctx *ctx);                     /* hipStream_t */
-/* Waits for everything queued.  Deferred batches (PD_PUSH_MORE) are scattered first — except that with "direct_windows"
- * set a whole deferred sample in an otherwise empty context stays deferred (its memory must then stay valid until the
- * statistics call that consumes it, or pd_reset). */
+/* Waits for everything queued.  Deferred batches (PD_PUSH_MORE) are scattered first — except that with pd_keep_deferred
+ * a whole deferred sample in an otherwise empty context stays deferred (its memory must then stay valid until pd_reset or
+ * a call that materialises the arrays). */
 int pd_synchronize(pd_ctx *ctx);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch.
@@ -278,26 +283,8 @@ int pd_synchronize(pd_ctx *ctx);
 int pd_profile(pd_ctx *ctx, int enable);
 int pd_profile_get(pd_ctx *ctx, const char *name, double *ms, uint64_t *launches);
 
-/* ---- GPU-side BAM decode, the one-call synchronous form (round 1's entry point, kept on top of
- * the pd_decode_* path below): replaces htslib's BGZF inflate + bam_read1 on the host
- * (the producer side of PD:434) for whole-contig modes.  The caller hands over raw BGZF bytes of
- * record-aligned file ranges ("units", e.g. cut at index offsets); the device inflates every block
- * (one wave per block), walks the records of every unit, filters (flag & flag_mask, mapq <
- * min_mapq, contigs shorter than 2) and scatters the M/=/X runs exactly as pd_push_intervals would.
- *   blob            n_bytes of BGZF data (whole blocks, any order)
- *   blocks[k]       deflate payload [in_off, in_off+in_len) of block k inside blob, and where its
- *                   out_len inflated bytes go inside the batch's inflated buffer (out_off)
- *   units[u]        records START in [start, stop) of the inflated buffer; bytes up to `avail`
- *                   belong to the unit's blocks; first_block / n_blocks index `blocks`.  Units
- *                   must be given in file order (the first-run array is then position sorted).
- *   unit_status[u]  OUT: 0 = counted on the device; 1 = not counted, decode this unit on the host
- *                   (a record runs past `avail`, or a CIGAR lives in the CG tag); 2 = corrupt data
- * Synchronous: returns when the batch has been scattered.  The executable uses pd_decode_* (below). */
-typedef struct pd_bgzf_block { uint64_t in_off, out_off; uint32_t in_len, out_len; } pd_bgzf_block;
-typedef struct pd_bgzf_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks; } pd_bgzf_unit;
-int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
-                       const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
-                       int32_t min_mapq, int32_t *unit_status, uint64_t *n_records);
+typedef struct pd_bgzf_block { uint64_t in_off, out_off; uint32_t in_len, out_len; } pd_bgzf_block;   /* one BGZF member of a batch: deflate payload
+                                   [in_off, in_off + in_len) inside the batch's bytes, out_len inflated bytes at out_off of its inflated buffer */
 
 /* ---- GPU-side BAM decode, asynchronous batches (the CLI's default input path for BAM files) --------------------
  * Replaces the producer side of the seam as well — htslib's bgzf_read / bam_read1 and the filter + CIGAR walk of
@@ -359,14 +346,6 @@ int pd_decode_acquire(pd_ctx *ctx, size_t bytes, void **host_buf);
 int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_status, pd_decode_result *res);
 int pd_decode_end(pd_ctx *ctx);
 int pd_decode_abort(pd_ctx *ctx);          /* forget the batches decoded since pd_decode_begin (nothing is counted) */
-
-/* ---- experimental measuring entry for the inflate kernel alone -------------------------------
- * Inflates every block of a BGZF image held in host memory on the GPU (one lane per block) and
- * copies the result back; variant 0 keeps the per-block Huffman tables in LDS, 1 in global
- * memory.  kernel_ms = average kernel time over `reps` launches.  A measuring / validation entry:
- * the production form will keep the inflated records on the device. */
-int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
-                      size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks);
 
 #ifdef __cplusplus
 }

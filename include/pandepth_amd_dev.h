@@ -1,0 +1,52 @@
+/* pandepth_amd_dev.h — development, tuning and measurement entry points of libpandepth_amd.so.
+ *
+ * NOT part of the drop-in boundary (include/pandepth_amd.h): nothing here is needed to replace the reference's depth path,
+ * nothing here changes a result or a contract.  The library exports them for this repository's tests, tuning scripts
+ * (tools/) and kernel micro-benchmarks. */
+#ifndef PANDEPTH_AMD_DEV_H_
+#define PANDEPTH_AMD_DEV_H_
+#include "pandepth_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning knobs (never change results): "lmax" (owner-tile look-back in cells, also the bucket width of compact samples; longer
+ * runs take the overflow path), "sample" / "direct_sample" (sparse-index stride in runs), "grid_tiles" (persistent grid of the
+ * tile kernels), "scatter_tile" (4096 | 8192), "accumulate_packed" (pd_accumulate_from's transport, default 1), "direct_un"
+ * (which compiled variant of the direct kernels runs), "decode_crc" (0: the device decoder skips the members' CRC-32 — kernel
+ * timing only), "decode_near_span" (split of the decoder's later-run stream). */
+int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
+
+/* ---- GPU-side BAM decode, the one-call synchronous form (round 1's entry point, kept on top of
+ * the pd_decode_* path below): replaces htslib's BGZF inflate + bam_read1 on the host
+ * (the producer side of PD:434) for whole-contig modes.  The caller hands over raw BGZF bytes of
+ * record-aligned file ranges ("units", e.g. cut at index offsets); the device inflates every block
+ * (one wave per block), walks the records of every unit, filters (flag & flag_mask, mapq <
+ * min_mapq, contigs shorter than 2) and scatters the M/=/X runs exactly as pd_push_intervals would.
+ *   blob            n_bytes of BGZF data (whole blocks, any order)
+ *   blocks[k]       deflate payload [in_off, in_off+in_len) of block k inside blob, and where its
+ *                   out_len inflated bytes go inside the batch's inflated buffer (out_off)
+ *   units[u]        records START in [start, stop) of the inflated buffer; bytes up to `avail`
+ *                   belong to the unit's blocks; first_block / n_blocks index `blocks`.  Units
+ *                   must be given in file order (the first-run array is then position sorted).
+ *   unit_status[u]  OUT: 0 = counted on the device; 1 = not counted, decode this unit on the host
+ *                   (a record runs past `avail`, or a CIGAR lives in the CG tag); 2 = corrupt data
+ * Synchronous: returns when the batch has been scattered.  The executable uses pd_decode_* (below). */
+typedef struct pd_bgzf_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks; } pd_bgzf_unit;
+int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_bgzf_block *blocks, uint32_t n_blocks,
+                       const pd_bgzf_unit *units, uint32_t n_units, uint64_t inflated_bytes, uint32_t flag_mask,
+                       int32_t min_mapq, int32_t *unit_status, uint64_t *n_records);
+
+/* ---- experimental measuring entry for the inflate kernel alone -------------------------------
+ * Inflates every block of a BGZF image held in host memory on the GPU (one lane per block) and
+ * copies the result back; variant 0 keeps the per-block Huffman tables in LDS, 1 in global
+ * memory.  kernel_ms = average kernel time over `reps` launches.  A measuring / validation entry:
+ * the production form will keep the inflated records on the device. */
+int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
+                      size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDEPTH_AMD_DEV_H_ */

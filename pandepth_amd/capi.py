@@ -60,6 +60,7 @@ def load():
         "pd_stage_acquire": (I, [P, ctypes.POINTER(P), ctypes.POINTER(SZ)]),
         "pd_stage_submit": (I, [P, P, SZ, U]),
         "pd_set_param": (I, [P, ctypes.c_char_p, U64]),
+        "pd_keep_deferred": (I, [P, I]),
         "pd_scan": (I, [P, U]),
         "pd_reduce_intervals": (I, [P, P, SZ, ctypes.c_uint32, P, P]),
         "pd_window_layout": (I, [P, ctypes.c_uint32, P]),
@@ -102,7 +103,7 @@ def load():
 
 
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
-           "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_scan",
+           "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
            "pd_read_depth", "pd_format_sites", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
@@ -231,7 +232,12 @@ class Engine:
     def reset(self):
         self._ck(self.L.pd_reset(self.h))
 
+    def keep_deferred(self, enable=True):
+        self._ck(self.L.pd_keep_deferred(self.h, 1 if enable else 0))
+
     def set_param(self, name, value):
+        if name == "direct_windows":                  # (the tests' and tools' old name for pd_keep_deferred)
+            return self.keep_deferred(bool(value))
         self._ck(self.L.pd_set_param(self.h, name.encode(), int(value)))
 
     def push_intervals(self, iv, flags=PD_PUSH_DEFAULT):

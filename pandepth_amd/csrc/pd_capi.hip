@@ -19,6 +19,7 @@
 #include <vector>
 #include <map>
 #include "pd_kernels.h"
+#include "../../include/pandepth_amd_dev.h"
 #include "pd_bamwalk.h"
 #include <condition_variable>
 #include <algorithm>
@@ -77,7 +78,7 @@ struct pd_ctx {
     uint8_t *hstate = nullptr; uint32_t n_half = 0;               // "written since reset" per 4096 cells
     uint8_t *slice_flags = nullptr;                               // pd_slice_sweep_i4: tiles that own exceptions
     bool accumulate_packed = true;                                // pd_accumulate_from: 4-bit transport
-    bool direct_windows = false;                                  // pd_scan_reduce_windows may consume deferred batches in place
+    bool direct_windows = false;                                  // pd_keep_deferred: a whole deferred sample stays deferred, the direct kernels may read it
     bool pristine = true;                                         // nothing materialised in the arrays since the last reset
     bool sums_stale = false;                                      // the tile sums hold what a direct export wrote while the sample is still deferred
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
@@ -110,7 +111,7 @@ struct pd_ctx {
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
-    int state = 0;                                   // 0 accumulating (diff), 1 depth, 2 consumed by the direct window path
+    int state = 0;                                   // 0 accumulating (diff), 1 depth
     uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
     unsigned grid_tiles = 0;                         // 0 = sized per pass from the number of runs
     int stile = 8192; int n_cu = 256;
@@ -134,8 +135,7 @@ int fail(pd_ctx *c, int code, const std::string &msg)
 int need_state(pd_ctx *c, int want, const char *fn)
 {
     if (c->state == want) return PD_OK;
-    const char *why = c->state == 2 ? "the sample was consumed by the direct window path (\"direct_windows\"), the arrays are empty; call pd_reset"
-                    : c->state == 1 ? "depth already materialised (call pd_reset, or use the pd_reduce_* calls)"
+    const char *why = c->state == 1 ? "depth already materialised (call pd_reset, or use the pd_reduce_* calls)"
                                     : "call pd_scan first";
     return fail(c, PD_ESTATE, std::string(fn) + ": " + why);
 }
@@ -547,6 +547,14 @@ int pd_reset(pd_ctx *c)
     return rc;
 }
 
+int pd_keep_deferred(pd_ctx *c, int enable)
+{
+    if (!c) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->direct_windows = enable != 0;
+    return PD_OK;
+}
+
 int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
 {
     if (!c || !name) return PD_EINVAL;
@@ -559,7 +567,6 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     }
     if (!strcmp(name, "grid_tiles")) { if (value > (1u << 20)) return fail(c, PD_EINVAL, "grid_tiles out of range"); c->grid_tiles = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "accumulate_packed")) { c->accumulate_packed = value != 0; return PD_OK; }
-    if (!strcmp(name, "direct_windows")) { c->direct_windows = value != 0; return PD_OK; }
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
@@ -854,14 +861,7 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
                     (unsigned long long)words[5] | ((unsigned long long)words[6] << 32), words[7], words[8], words[9], words[10]);
         return PD_OK;
     }
-    for (auto &p : c->pend)
-        if (p.slot >= 0) {
-            Stage &st = c->stage[p.slot];
-            HIPOK(c, hipEventRecord(st.done, c->stream));
-            st.state = 2; st.seq = ++c->seq;
-        }
-    c->pend.clear();
-    c->state = 2;
+    // the call READ the sample: it stays deferred (like pd_export_i4's direct form), every other call still works on it
     *done = true;
     return PD_OK;
 }

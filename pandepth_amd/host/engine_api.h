@@ -6,6 +6,7 @@
 #ifndef PD_ENGINE_API_H_
 #define PD_ENGINE_API_H_
 #include "../../include/pandepth_amd.h"
+#include "../../include/pandepth_amd_dev.h"   /* pd_bgzf_unit of the optional one-call decode entry (tests) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -43,6 +44,8 @@ typedef struct pd_engine_api {
     const char *(*comm_strerror)(const pd_comm *);
     /* optional (NULL = the host formats the cells it reads back): per-site rows formatted by the engine, see pd_format_sites */
     int (*format_sites)(pd_ctx *, int32_t, uint32_t, size_t, const char *, size_t, char *, size_t, size_t *);
+    /* optional (NULL = every statistics call materialises the arrays): see pd_keep_deferred */
+    int (*keep_deferred)(pd_ctx *, int);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

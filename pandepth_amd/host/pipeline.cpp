@@ -1007,7 +1007,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     }
     Engine &eng = *engs[0];
     // whole-contig statistics straight from the runs when a sample ends up resident and deferred (pd_scan_reduce_windows)
-    if (api->set_param) for (auto &e : engs) api->set_param(e->ctx, "direct_windows", 1);
+    if (api->keep_deferred) for (auto &e : engs) api->keep_deferred(e->ctx, 1);
     tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);

@@ -556,10 +556,13 @@ def test_direct_windows_equal_oracle(w, min_dep, wrap):
             e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
             woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
             assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref)
-            with pytest.raises(pda.PdError, match="direct"):
-                e.scan(wrap)                                      # the arrays never received the sample
-            with pytest.raises(pda.PdError):
-                e.push_intervals(first)
+            # the direct call READ the sample: it is still deferred, a second call gives the same tables, and pd_scan
+            # materialises it like any other (depth cell by cell against the oracle)
+            woff2, cover2, tot2 = e.scan_reduce_windows(w, min_dep, wrap)
+            assert np.array_equal(cover2, cov_ref) and np.array_equal(tot2, tot_ref)
+            e.scan(wrap)
+            for t in (0, 1, len(LENS) - 1):
+                assert np.array_equal(e.read_depth(t, 0, int(LENS[t])), d[off[t]:off[t] + LENS[t]]), t
         # the same calls without the parameter take the materialising path and agree
         e.set_param("direct_windows", 0)
         e.reset()
@@ -756,8 +759,8 @@ def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
             e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
             woff, cover, tot = e.scan_reduce_windows(w, min_dep, wrap)
             assert np.array_equal(cover, cov_ref) and np.array_equal(tot, tot_ref), form
-            with pytest.raises(pda.PdError, match="direct"):
-                e.scan(wrap)                                      # consumed by the direct path, whichever form
+            e.scan(wrap)                                          # the sample is still there, whichever form read it
+            assert np.array_equal(e.read_depth(0, 0, int(LENS[0])), d[off[0]:off[0] + LENS[0]]), form
 
 
 # ---------------------------------------------------------------------------------------------
