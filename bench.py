@@ -264,7 +264,7 @@ def e2e_leg(records, site_records):
                    "; generated in %.0f s)" % t_gen,
             "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache, best of 2 runs for both executables",
             "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads,
-                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) + k_direct_wide3; host only reads the file",
+                         "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) -> one compact sample (pd_runs) -> k_direct_c8; host only reads the file",
                          "phases_s": ph, "device_decode": dec},
             "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
                                      "path": "PANDEPTH_DEVICE_DECODE=0: libdeflate on the host threads + pd_push_intervals"},
