@@ -171,6 +171,20 @@ int pd_read_depth(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, uint32_t *ou
  * crosses PCIe is the text the gzip stage consumes, not 4-byte cells to be formatted by host threads.  n <= 2^27 per call. */
 int pd_format_sites(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, char *text, size_t cap, size_t *n_bytes);
 
+/* Stage 1 of the reference's gzip streams on the GPU.  The reference writes its tables and its per-site file through ONE zlib
+ * stream (gzstream, PD:4264-4284 / PD:4366-4389): level 6, whose cost is the LZ77 parse (deflate_slow's hash chains and lazy
+ * matching).  pd_deflate_parse produces exactly zlib's parse — literal = byte value, match = len << 16 | dist — of every chunk
+ * [start, end) of `text` (a host buffer of n_text < 2^32 - 64 bytes), each parsed the way zlib parses a stream primed with
+ * deflateSetDictionary(text + origin, start - origin): start - origin <= 32768 bytes of history, the parse beginning afresh at
+ * start.  The symbols of chunk k land at syms[sym_off[k] .. sym_off[k + 1]) (syms: a host buffer of syms_cap entries; sym_off:
+ * n_chunks + 1 entries; PD_ERANGE if syms_cap is too small).  Within MIN_LOOKAHEAD (262 bytes) of a chunk's end the parse
+ * continues as if more text followed, where zlib would see the end of its input: overlap the chunks and stitch them before that
+ * (host/pgzip.cpp: chunks meet where both parses end a match at the same position), and leave a stream's true end to zlib.
+ * Blocks, Huffman codes and bits (stage 2) stay with the caller.  One wave per chunk; chunks of 32-256 KiB fill the device. */
+typedef struct pd_lz_chunk { uint64_t start, end, origin; } pd_lz_chunk;
+int pd_deflate_parse(pd_ctx *ctx, const void *text, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
+                     uint32_t *syms, size_t syms_cap, uint64_t *sym_off);
+
 /* Test / interop access to the accumulating buffer (difference arrays + tile sums are ONE
  * contiguous int32 allocation so that a multi-BAM sum, PD:2704-3014, is a single RCCL
  * all-reduce / reduce-scatter of n_words int32 over xGMI, issued by the caller on the stream

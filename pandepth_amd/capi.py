@@ -68,6 +68,7 @@ def load():
         "pd_reduce_windows": (I, [P, ctypes.c_uint32, ctypes.c_uint32, P, P]),
         "pd_read_depth": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, P]),
         "pd_format_sites": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, ctypes.c_char_p, SZ, P, SZ, ctypes.POINTER(SZ)]),
+        "pd_deflate_parse": (I, [P, P, SZ, P, ctypes.c_uint32, P, SZ, P]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
         "pd_device_count": (I, [ctypes.POINTER(I)]),
         "pd_accumulate_from": (I, [P, P]),
@@ -105,7 +106,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_format_sites", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
+           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
@@ -260,6 +261,17 @@ class Engine:
 
     def push_runs(self, runs, flags=PD_PUSH_MORE):
         self._ck(self.L.pd_push_runs(self.h, runs, int(flags)))
+
+    def deflate_parse(self, text, chunks):
+        """zlib's level-6 LZ77 parse of the chunks [(start, end, origin), ...] of `text` (bytes / uint8 array) on the device:
+        a list of uint32 symbol arrays (literal = byte, match = len << 16 | dist), one per chunk."""
+        t = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+        ch = np.ascontiguousarray(np.asarray(chunks, dtype=np.uint64).reshape(-1, 3))
+        cap = int(sum(int(e - s) for s, e, _ in ch.tolist())) + 16
+        syms = np.zeros(cap, dtype=np.uint32)
+        off = np.zeros(ch.shape[0] + 1, dtype=np.uint64)
+        self._ck(self.L.pd_deflate_parse(self.h, _ptr(t), t.size, _ptr(ch), ch.shape[0], _ptr(syms), cap, _ptr(off)))
+        return [syms[int(off[k]):int(off[k + 1])] for k in range(ch.shape[0])]
 
     def scan(self, wrap_bits=0):
         self._ck(self.L.pd_scan(self.h, int(wrap_bits)))

@@ -1702,6 +1702,74 @@ int pd_gather_windows(pd_ctx *c, const void *dev_partials, uint32_t w, uint32_t 
     return PD_OK;
 }
 
+// zlib's level-6 LZ77 parse of a host text on the device (pd_deflate.hip / pd_lz77.h): positions sorted by (hash, position),
+// one wave per chunk, the symbols gathered and copied back.  Buffers live for the call.
+int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
+                     uint32_t *syms, size_t syms_cap, uint64_t *sym_off)
+{
+    if (!c || !text || !chunks || !syms || !sym_off) return PD_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");
+    uint64_t stride = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const pd_lz_chunk &ch = chunks[k];
+        if (ch.origin > ch.start || ch.start > ch.end || ch.end > n_text || ch.start - ch.origin > 32768)
+            return fail(c, PD_EINVAL, "pd_deflate_parse: a chunk lies outside the text or has more than 32768 bytes of history");
+        stride = std::max<uint64_t>(stride, ch.end - ch.start);
+    }
+    sym_off[0] = 0;
+    if (!n_chunks) return PD_OK;
+    stride += 8;
+    HIPOK(c, hipSetDevice(c->device));
+    const uint32_t np = (uint32_t)(n_text - 2);
+    const uint32_t n_blocks = (np + 2047) / 2048;
+    uint8_t *d_text = nullptr; uint64_t *ka = nullptr, *kb = nullptr, *d_chunks = nullptr, *d_off = nullptr;
+    uint32_t *hist = nullptr, *scan_tmp = nullptr, *S = nullptr, *R = nullptr, *bucket = nullptr, *d_syms = nullptr, *d_cnt = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_text, (void *)ka, (void *)kb, (void *)d_chunks, (void *)d_off, (void *)hist, (void *)scan_tmp, (void *)S, (void *)R,
+                        (void *)bucket, (void *)d_syms, (void *)d_cnt, (void *)d_out}) if (q) (void)hipFree(q);
+    };
+    const size_t nh = (size_t)256 * n_blocks + 16;
+    if (hipMalloc(&d_text, n_text + 64) != hipSuccess || hipMalloc(&ka, (size_t)np * 8 + 64) != hipSuccess || hipMalloc(&kb, (size_t)np * 8 + 64) != hipSuccess ||
+        hipMalloc(&hist, nh * 4) != hipSuccess || hipMalloc(&scan_tmp, (nh / 1024 + 8) * 4) != hipSuccess || hipMalloc(&S, (size_t)np * 4 + 64) != hipSuccess ||
+        hipMalloc(&R, (size_t)n_text * 4 + 64) != hipSuccess || hipMalloc(&bucket, ((size_t)32768 + 8) * 4) != hipSuccess ||
+        hipMalloc(&d_chunks, (size_t)n_chunks * 24) != hipSuccess || hipMalloc(&d_off, ((size_t)n_chunks + 1) * 8) != hipSuccess ||
+        hipMalloc(&d_syms, (size_t)n_chunks * stride * 4) != hipSuccess || hipMalloc(&d_cnt, (size_t)n_chunks * 4 + 16) != hipSuccess) {
+        (void)hipGetLastError(); cleanup();
+        return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed");
+    }
+    hipStream_t st = c->stream;
+    std::vector<uint32_t> counts(n_chunks);
+    hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
+    static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");
+    if (e == hipSuccess) {
+        { ProfScope ps(c, "lz_sort"); launch_lz_sort(st, d_text, np, ka, kb, hist, scan_tmp, S, R, bucket); }
+        { ProfScope ps(c, "lz_parse"); launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt); }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { cleanup(); return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e)); }
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        if (counts[k] == 0xFFFFFFFFu) { cleanup(); return fail(c, PD_EHIP, "pd_deflate_parse: a chunk's symbols did not fit its buffer"); }
+        total += counts[k]; sym_off[k + 1] = total;
+    }
+    if (total > syms_cap) { cleanup(); return fail(c, PD_ERANGE, "pd_deflate_parse: the symbol buffer is too small"); }
+    if (total) {
+        if (hipMalloc(&d_out, total * 4 + 64) != hipSuccess) { (void)hipGetLastError(); cleanup(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
+        e = hipMemcpyAsync(d_off, sym_off, ((size_t)n_chunks + 1) * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) { ProfScope ps(c, "lz_gather"); launch_lz_gather(st, d_syms, stride, d_off, n_chunks, d_out); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(syms, d_out, total * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e));
+    return PD_OK;
+}
+
 void *pd_stream(pd_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int pd_synchronize(pd_ctx *c)

@@ -1,0 +1,166 @@
+// pd_deflate.hip — zlib's level-6 LZ77 parse on the GPU (stage 1 of the byte-identical gzip streams of the per-site and window
+// files, PD:4264-4284 / PD:4366-4389 written through gzstream): csrc/pd_lz77.h holds the parse itself (one wave evaluates the
+// candidates of a position at once); here are the kernels around it:
+//   * the positions of a batch of text sorted by (hash of their 3 bytes, position) — a stable LSD radix sort in two passes of
+//     8 + 7 bits over 64-bit (hash << 32 | position) keys: per-wave-block digit histograms, one exclusive scan, a stable scatter
+//     whose in-block ranks come from ballots (the lanes with my digit below me) — then R[p] (where p stands) and the buckets' starts;
+//   * the parse: ONE WAVE PER CHUNK walks zlib's lazy-evaluation state machine (wave-uniform) and calls the wave-parallel
+//     longest_match; lane 0 writes the symbols into the chunk's stretch of the symbol buffer;
+//   * the chunks' symbols gathered into one contiguous array for the copy back.
+// All HBM-bound or latency-bound integer work; nothing here is a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pd_kernels.h"
+#include "pd_lz77.h"
+
+namespace pdk {
+
+namespace {
+
+constexpr int WGZ = 256;
+constexpr uint32_t RBLK = 2048;                 // elements per wave-block of the radix passes
+
+struct DevWaveZ {                               // the hardware wavefront (pd_lz77.h's W)
+    template <class T> struct Var { T v; __device__ T &operator[](int) { return v; } __device__ const T &operator[](int) const { return v; } };
+    template <class F> __device__ static __forceinline__ void each(F f) { f((int)(threadIdx.x & 63)); }
+    __device__ static __forceinline__ uint64_t ballot_eq(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v == v); }
+    __device__ static __forceinline__ uint64_t ballot_ne(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v != v); }
+    __device__ static __forceinline__ uint32_t reduce_max(const Var<uint32_t> &x)
+    {
+        uint32_t m = x.v;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
+        return m;
+    }
+    __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
+    __device__ static __forceinline__ bool lead() { return (threadIdx.x & 63) == 0; }
+};
+
+// ---- keys: hash << 32 | position, for every position with 3 bytes left ----
+__global__ __launch_bounds__(WGZ) void k_lz_keys(const uint8_t *text, uint32_t np, uint64_t *keys)
+{
+    for (uint64_t p = (uint64_t)blockIdx.x * WGZ + threadIdx.x; p < np; p += (uint64_t)gridDim.x * WGZ)
+        keys[p] = ((uint64_t)pdz::hash3(text + p) << 32) | p;
+}
+
+// ---- one LSD pass over digit (key >> shift) & mask: histogram per wave-block (bin-major layout for the scan) ----
+__global__ __launch_bounds__(WGZ) void k_lz_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t mask, uint32_t n_blocks, uint32_t *hist)
+{
+    __shared__ uint32_t cnt[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t blk = blockIdx.x * 4 + wv;
+    for (int k = lane; k < 256; k += 64) cnt[wv][k] = 0;
+    __syncthreads();
+    if (blk < n_blocks) {
+        const uint64_t lo = (uint64_t)blk * RBLK, hi = lo + RBLK < n ? lo + RBLK : n;
+        for (uint64_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[wv][(uint32_t)(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (blk < n_blocks) for (uint32_t d = lane; d <= mask; d += 64) hist[(uint64_t)d * n_blocks + blk] = cnt[wv][d];
+}
+
+// ---- the stable scatter: rank inside the block = elements of my digit before me (earlier groups: the running count; my group: ballots) ----
+__global__ __launch_bounds__(WGZ) void k_lz_scatter(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t mask, uint32_t n_blocks,
+                                                    const uint32_t *offs, uint64_t *out)
+{
+    __shared__ uint32_t cur[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t blk = blockIdx.x * 4 + wv;
+    if (blk < n_blocks) for (uint32_t d = lane; d <= mask; d += 64) cur[wv][d] = offs[(uint64_t)d * n_blocks + blk];
+    __syncthreads();
+    if (blk >= n_blocks) return;
+    const uint64_t lo = (uint64_t)blk * RBLK, hi = lo + RBLK < n ? lo + RBLK : n;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64) {
+        const uint64_t i = i0 + lane;
+        const bool on = i < hi;
+        const uint64_t key = on ? keys[i] : 0;
+        const uint32_t d = on ? (uint32_t)(key >> shift) & mask : 0xFFFFFFFFu;
+        // the lanes that hold my digit: one ballot per bit of the digit
+        uint64_t same = __ballot(on);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        if (on) {
+            const uint32_t below = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            const uint32_t base = cur[wv][d];
+            out[base + below] = key;
+            // the last lane of my digit moves the block's cursor on (the wave's LDS accesses are in order: every lane above has read `base`)
+            if ((same >> lane) == 1ull) cur[wv][d] = base + (uint32_t)__builtin_popcountll(same);
+        }
+    }
+}
+
+// ---- S, R and the buckets' starts from the sorted keys ----
+__global__ __launch_bounds__(WGZ) void k_lz_ranks(const uint64_t *sorted, uint32_t np, uint32_t *S, uint32_t *R, uint32_t *bucket)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * WGZ + threadIdx.x; i < np; i += (uint64_t)gridDim.x * WGZ) {
+        const uint64_t k = sorted[i];
+        const uint32_t p = (uint32_t)k, h = (uint32_t)(k >> 32);
+        S[i] = p; R[p] = (uint32_t)i;
+        if (i == 0 || (uint32_t)(sorted[i - 1] >> 32) != h) bucket[h] = (uint32_t)i;
+    }
+}
+
+// ---- the parse: one wave per chunk ----
+__global__ __launch_bounds__(64) void k_lz_parse(const pdz::Text T, const uint64_t *chunks /* start, end, origin per chunk */, uint32_t n_chunks,
+                                                 uint32_t *syms, uint64_t stride, uint32_t *counts)
+{
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint64_t start = chunks[3 * c], end = chunks[3 * c + 1], origin = chunks[3 * c + 2];
+        pdz::Out o{syms + (uint64_t)c * stride, 0u, (uint32_t)stride};
+        const bool ok = pdz::parse_chunk<DevWaveZ>(T, start, end, origin, o);
+        if ((threadIdx.x & 63) == 0) counts[c] = ok ? o.n : 0xFFFFFFFFu;
+    }
+}
+
+// ---- the chunks' symbols, one after the other ----
+__global__ __launch_bounds__(WGZ) void k_lz_gather(const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out)
+{
+    for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {
+        const uint64_t a = off[c], n = off[c + 1] - a;
+        const uint32_t *src = syms + (uint64_t)c * stride;
+        for (uint64_t i = (uint64_t)blockIdx.x * WGZ + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WGZ) out[a + i] = src[i];
+    }
+}
+
+} // namespace
+
+// One text -> (S, R, bucket).  keys_a / keys_b: np 64-bit words each; hist: 256 * n_blocks + 1 words; scan_tmp: see launch_excl_scan_u32.
+void launch_lz_sort(hipStream_t st, const uint8_t *text, uint32_t np, uint64_t *keys_a, uint64_t *keys_b, uint32_t *hist, uint32_t *scan_tmp,
+                    uint32_t *S, uint32_t *R, uint32_t *bucket)
+{
+    if (!np) return;
+    const uint32_t n_blocks = (np + RBLK - 1) / RBLK;
+    const unsigned g = (unsigned)((n_blocks + 3) / 4);
+    const uint64_t ge = ((uint64_t)np + WGZ - 1) / WGZ;
+    hipLaunchKernelGGL(k_lz_keys, dim3((unsigned)(ge > 65536 ? 65536 : ge)), dim3(WGZ), 0, st, text, np, keys_a);
+    // pass 1: the low 8 bits of the hash; pass 2: its high 7 bits (the positions are in order to begin with: stable passes keep them so)
+    const uint32_t shifts[2] = {32, 40}, masks[2] = {255u, 127u};
+    uint64_t *src = keys_a, *dst = keys_b;
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t nh = (masks[pass] + 1) * n_blocks;
+        hipLaunchKernelGGL(k_lz_hist, dim3(g), dim3(WGZ), 0, st, (const uint64_t *)src, np, shifts[pass], masks[pass], n_blocks, hist);
+        launch_excl_scan_u32(st, hist, hist, nh, scan_tmp);
+        hipLaunchKernelGGL(k_lz_scatter, dim3(g), dim3(WGZ), 0, st, (const uint64_t *)src, np, shifts[pass], masks[pass], n_blocks, (const uint32_t *)hist, dst);
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    hipLaunchKernelGGL(k_lz_ranks, dim3((unsigned)(ge > 65536 ? 65536 : ge)), dim3(WGZ), 0, st, (const uint64_t *)src, np, S, R, bucket);
+}
+
+void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
+                     const uint64_t *chunks, uint32_t n_chunks, uint32_t *syms, uint64_t stride, uint32_t *counts)
+{
+    if (!n_chunks) return;
+    const pdz::Text T{text, S, R, bucket, n_text};
+    hipLaunchKernelGGL(k_lz_parse, dim3(n_chunks), dim3(64), 0, st, T, chunks, n_chunks, syms, stride, counts);
+}
+
+void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out)
+{
+    if (!n_chunks) return;
+    hipLaunchKernelGGL(k_lz_gather, dim3(64, n_chunks < 4096u ? n_chunks : 4096u), dim3(WGZ), 0, st, syms, stride, off, n_chunks, out);
+}
+
+} // namespace pdk

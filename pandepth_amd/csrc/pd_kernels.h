@@ -127,6 +127,15 @@ void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 } // namespace pdk
 
+// zlib's level-6 LZ77 parse on the device (pd_deflate.hip, pd_lz77.h)
+namespace pdk {
+void launch_lz_sort(hipStream_t st, const uint8_t *text, uint32_t np, uint64_t *keys_a, uint64_t *keys_b, uint32_t *hist, uint32_t *scan_tmp,
+                    uint32_t *S, uint32_t *R, uint32_t *bucket);
+void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
+                     const uint64_t *chunks, uint32_t n_chunks, uint32_t *syms, uint64_t stride, uint32_t *counts);
+void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out);
+}
+
 // per-site text rows (pd_format.hip)
 namespace pdk {
 uint32_t site_rows_blocks(uint64_t n);

@@ -116,7 +116,7 @@ PZ_FN uint32_t longest_match(const Text &T, uint64_t p, uint32_t prev_len, uint6
 }
 
 struct Out { uint32_t *syms; uint32_t n, cap; };               // literal = byte; match = len << 16 | dist
-PZ_FN bool put(Out &o, uint32_t s) { if (o.n >= o.cap) return false; o.syms[o.n++] = s; return true; }
+template <class W> PZ_FN bool put(Out &o, uint32_t s) { if (o.n >= o.cap) return false; if (W::lead()) o.syms[o.n] = s; ++o.n; return true; }
 
 // The parse of text[start, end) with text[start - dict, start) as history.  `origin` = the position zlib's window index 0
 // stands for (start - dict).  Returns false when the symbol buffer is too small.  Only lane 0 writes the symbols.
@@ -141,17 +141,17 @@ PZ_FN bool parse_chunk(const Text &T, uint64_t start, uint64_t end, uint64_t ori
             }
         }
         if (prev_len >= MIN_MATCH && match_len <= prev_len) {
-            ok = ok && put(o, (prev_len << 16) | (uint32_t)(s - 1 - prev_start));
+            ok = ok && put<W>(o, (prev_len << 16) | (uint32_t)(s - 1 - prev_start));
             s += prev_len - 1;                                  // the previous match began at s - 1
             avail = false; match_len = MIN_MATCH - 1;
         } else if (avail) {
-            ok = ok && put(o, (uint32_t)T.text[s - 1]);
+            ok = ok && put<W>(o, (uint32_t)T.text[s - 1]);
             ++s;
         } else {
             avail = true; ++s;
         }
     }
-    if (avail) ok = ok && put(o, (uint32_t)T.text[s - 1]);
+    if (avail) ok = ok && put<W>(o, (uint32_t)T.text[s - 1]);
     return ok;
 }
 
@@ -163,6 +163,7 @@ struct HostWave {
     static uint64_t ballot_ne(const Var<uint32_t> &x, uint32_t v) { uint64_t m = 0; for (int l = 0; l < 64; ++l) if (x.v[l] != v) m |= 1ull << l; return m; }
     static uint32_t reduce_max(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
     static uint32_t bcast(const Var<uint32_t> &x, int lane) { return x.v[lane]; }
+    static bool lead() { return true; }
 };
 
 } // namespace pdz

@@ -702,6 +702,19 @@ bool Stream::finish()
     return true;
 }
 
+// zlib's own parse of data[dict, dict + n) primed with data[0, dict) (what run_chunk computes for one chunk): tests compare
+// the engine's wave-parallel parse (csrc/pd_lz77.h) with it
+bool zlib_chunk_symbols(const uint8_t *data, size_t dict, size_t n, std::vector<uint32_t> &syms)
+{
+    Chunk c;
+    c.start = dict; c.end = dict + n; c.tail_end = dict + n;
+    if (dict > 32768) { data += dict - 32768; c.start = 32768; c.end = c.tail_end = 32768 + n; }
+    run_chunk(data, 0, c);
+    if (!c.ok) return false;
+    syms.swap(c.syms);
+    return true;
+}
+
 bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p)
 {
     std::vector<uint8_t> img;

@@ -54,5 +54,9 @@ bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint
 
 bool gzip_identical(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, const Params &p);
 
+// zlib's own LZ77 parse (literal = byte, match = len << 16 | dist) of data[dict, dict + n) with data[0, dict) as its dictionary
+// (dict <= 32768 is what zlib uses): stage 1 of one chunk, exposed for the tests of the engine's parse.
+bool zlib_chunk_symbols(const uint8_t *data, size_t dict, size_t n, std::vector<uint32_t> &syms);
+
 } // namespace pgz
 #endif

@@ -1,0 +1,76 @@
+"""zlib's level-6 LZ77 parse restated for one wave per position (pandepth_amd/csrc/pd_lz77.h; the reference writes its tables and
+per-site files through one zlib stream — gzstream, PD:4264-4284 — so the .gz bytes are a function of that parse): the host
+emulation (64 lanes in a loop) and, on the GPU, pd_deflate_parse through the C-ABI, both against the symbols ZLIB ITSELF produces
+for the same chunks (deflate primed with the chunk's dictionary, symbols read back out of its stream)."""
+import os
+import random
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+H = os.path.join(HERE, "harness")
+
+
+@pytest.fixture(scope="module")
+def corpus(tmp_path_factory):
+    d = tmp_path_factory.mktemp("lz")
+    rnd = random.Random(5)
+    # a per-site file (PD:4278: "<chr>\t<index>\t<depth>\n") with depths that wander
+    dep, rows = 50, []
+    for j in range(400000):
+        if rnd.random() < 0.3:
+            dep = max(0, dep + rnd.choice((-2, -1, -1, 1, 1, 2)))
+        rows.append("Chr01\t%d\t%d\n" % (j, dep))
+    (d / "site.txt").write_text("".join(rows))
+    # a window table (PD:4381-4388)
+    rows = ["#Chr\tStart\tEnd\tLength\tCoveredSite\tTotalDepth\tCoverage(%)\tMeanDepth\n"]
+    for k in range(80000):
+        c, t = rnd.randint(0, 100), rnd.randint(0, 9000)
+        rows.append("Chr%02d\t%d\t%d\t100\t%d\t%d\t%.2f\t%.2f\n" % (1 + k // 9000, 1 + 100 * k, 100 * k + 100, c, t, c * 1.0, t / 100.0))
+    (d / "win.txt").write_text("".join(rows))
+    A = b"ACDEFGHIKLMNPQRS"
+    rb = lambda n: bytes(rnd.choice(A) for _ in range(n))
+    # repeats at distances around MAX_DIST (32506), 3-byte repeats around TOO_FAR (4096), matches of nice length and of 258
+    out = bytearray()
+    for _ in range(40):
+        blk = rb(rnd.choice((3, 4, 5, 6, 20, 130, 258, 300, 600)))
+        dist = rnd.choice((32500, 32504, 32505, 32506, 32507, 32508, 32600, 4090, 4095, 4096, 4097, 4100, 100, 9, 1))
+        out += blk + rb(max(0, dist - len(blk))) + blk + rb(rnd.randint(10, 3000))
+    (d / "far.txt").write_bytes(bytes(out))
+    # one trigram thousands of times (chains beyond the 128 / 32 budgets), runs of one byte, a short period
+    s = bytearray()
+    for k in range(60000):
+        s += b"ABC" + bytes([rnd.choice(A)]) * rnd.randint(0, 3)
+        if k % 97 == 0:
+            s += b"ABCDEFGHIJKLMNOPQRSTUVWXYZ" * rnd.randint(1, 12)
+    (d / "chains.txt").write_bytes(bytes(s))
+    (d / "runs.bin").write_bytes(b"".join(bytes([rnd.randint(0, 255)]) * rnd.randint(1, 600) for _ in range(6000)))
+    per = bytes(rnd.randint(0, 255) for _ in range(37))
+    (d / "per.bin").write_bytes(per * 20000 + rb(1000) + per * 9000)
+    (d / "dna.txt").write_text("".join(rnd.choice("ACGT") for _ in range(1500000)))
+    subprocess.run(["make", "-C", H, "lz77_check"], check=True, stdout=subprocess.DEVNULL)
+    return d
+
+
+FILES = ["site.txt", "win.txt", "far.txt", "chains.txt", "runs.bin", "per.bin", "dna.txt"]
+GEOMETRIES = [("262144", "16384"), ("65536", "2048"), ("100000", "5000")]
+
+
+@pytest.mark.parametrize("geo", GEOMETRIES, ids=lambda g: "chunk%s_tail%s" % g)
+@pytest.mark.parametrize("name", FILES)
+def test_wave_parse_equals_zlib_on_the_host(corpus, name, geo):
+    p = subprocess.run([os.path.join(H, "lz77_check"), str(corpus / name), geo[0], geo[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and " 0 chunks differ" in p.stdout, p.stdout + p.stderr[-1500:]
+    assert int(p.stdout.split(" chunks, ")[1].split(" symbols")[0]) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", GEOMETRIES[:2], ids=lambda g: "chunk%s_tail%s" % g)
+@pytest.mark.parametrize("name", FILES)
+def test_device_parse_equals_zlib(corpus, name, geo):
+    """pd_deflate_parse (sort by hash on the device, one wave per chunk) = zlib's symbols, chunk by chunk"""
+    subprocess.run(["make", "-C", H, "lz77_gpu_check"], check=True, stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(H, "lz77_gpu_check"), str(corpus / name), geo[0], geo[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and " 0 chunks differ" in p.stdout, p.stdout + p.stderr[-1500:]
