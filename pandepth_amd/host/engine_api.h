@@ -46,6 +46,8 @@ typedef struct pd_engine_api {
     int (*format_sites)(pd_ctx *, int32_t, uint32_t, size_t, const char *, size_t, char *, size_t, size_t *);
     /* optional (NULL = every statistics call materialises the arrays): see pd_keep_deferred */
     int (*keep_deferred)(pd_ctx *, int);
+    /* optional (NULL = zlib parses on the host threads): stage 1 of the byte-identical gzip streams on the engine, see pd_deflate_parse */
+    int (*deflate_parse)(pd_ctx *, const void *, size_t, const pd_lz_chunk *, uint32_t, uint32_t *, size_t, uint64_t *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "../csrc/pd_inflate_core.h"
+#include "../csrc/pd_lz77.h"
 
 namespace pgz {
 namespace {
@@ -480,6 +481,7 @@ struct Stream::Impl {
     uint64_t CH = 1 << 20, TAIL = 1 << 16;
     uint64_t batch_bytes = (uint64_t)96 << 20;
     std::function<bool(const uint8_t *, size_t)> sink;
+    ParseFn parse;
     bool failed = false, finished = false, header_done = false;
     std::vector<uint8_t> buf;        // text [base, base + buf.size())
     uint64_t base = 0, total = 0;
@@ -565,7 +567,35 @@ struct Stream::Impl {
         if (have_carry && nc) { chunks[0].syms.swap(carry.syms); chunks[0].crc = carry.crc; chunks[0].ok = carry.ok;
                                 chunks[0].tail_end = carry.tail_end; chunks[0].end = carry.end; first_new = 1; have_carry = false; }
         const double tp0 = now_s();
-        parallel_for(threads, nc - first_new, [&](size_t k) { run_chunk(buf.data(), base, chunks[first_new + k]); });
+        size_t provided = 0;
+        if (parse && nc > first_new) {
+            // stage 1 by the provider for every new chunk except one that runs to the true end of the text (zlib sees the end of
+            // its input there); their CRCs on the threads
+            std::vector<uint64_t> tri; std::vector<size_t> which;
+            for (size_t k = first_new; k < nc; ++k) {
+                const Chunk &c = chunks[k];
+                if (final && c.tail_end == total) continue;
+                const uint64_t dl = c.start < 32768 ? c.start : 32768;
+                if (c.start - dl < base) continue;                   // (cannot happen: the buffer keeps 32 KiB before the first chunk)
+                tri.push_back(c.start - base); tri.push_back(c.tail_end - base); tri.push_back(c.start - dl - base);
+                which.push_back(k);
+            }
+            std::vector<uint32_t> sy; std::vector<uint64_t> off;
+            if (!which.empty() && parse(buf.data(), buf.size(), tri.data(), which.size(), sy, off) && off.size() == which.size() + 1) {
+                parallel_for(threads, which.size(), [&](size_t j) {
+                    Chunk &c = chunks[which[j]];
+                    c.syms.assign(sy.begin() + (std::ptrdiff_t)off[j], sy.begin() + (std::ptrdiff_t)off[j + 1]);
+                    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + (c.start - base), (uInt)(c.end - c.start));
+                    c.ok = true;
+                });
+                provided = which.size();
+            }
+        }
+        {
+            std::vector<size_t> todo;
+            for (size_t k = first_new; k < nc; ++k) if (!chunks[k].ok) todo.push_back(k);
+            parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(buf.data(), base, chunks[todo[j]]); });
+        }
         const double tp1 = now_s();
         for (auto &c : chunks) if (!c.ok) return false;
         // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position
@@ -656,7 +686,7 @@ struct Stream::Impl {
         }
         if (!flush_out(final)) return false;
         if (getenv("PGZ_DEBUG"))
-            fprintf(stderr, "[pgz] round: %zu chunks, %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, nblocks,
+            fprintf(stderr, "[pgz] round: %zu chunks (%zu parsed by the provider), %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, provided, nblocks,
                     tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
         // forget the text nobody needs any more: everything before the dictionary of the next chunk to parse
         if (!final) {
@@ -672,6 +702,7 @@ Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, c
 {
     p_->threads = threads < 1 ? 1 : threads;
     p_->sink = std::move(sink);
+    p_->parse = p.parse;
     p_->CH = p.chunk < 65536 ? 65536 : p.chunk;
     p_->TAIL = p.tail < 2048 ? 2048 : p.tail;
     if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
@@ -700,6 +731,35 @@ bool Stream::finish()
     p_->finished = true;
     if (!p_->run(true)) { p_->failed = true; return false; }
     return true;
+}
+
+ParseFn host_emulation_parse()
+{
+    return [](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, std::vector<uint32_t> &syms, std::vector<uint64_t> &off) -> bool {
+        if (n < 3) return false;
+        // positions sorted by (hash, position): a stable counting sort (the device does this with a radix sort)
+        std::vector<uint8_t> padded(text, text + n);
+        padded.resize(n + 16, 0);
+        const size_t np = n - 2;
+        std::vector<uint32_t> bucket((1u << pdz::HASH_BITS) + 1, 0), S(np), R(n + 1, 0);
+        for (size_t p = 0; p < np; ++p) bucket[pdz::hash3(&padded[p]) + 1]++;
+        for (size_t h = 0; h < (1u << pdz::HASH_BITS); ++h) bucket[h + 1] += bucket[h];
+        { std::vector<uint32_t> cur(bucket.begin(), bucket.end() - 1);
+          for (size_t p = 0; p < np; ++p) { const uint32_t i = cur[pdz::hash3(&padded[p])]++; S[i] = (uint32_t)p; R[p] = i; } }
+        const pdz::Text T{padded.data(), S.data(), R.data(), bucket.data(), n};
+        off.assign(n_chunks + 1, 0);
+        syms.clear();
+        for (size_t k = 0; k < n_chunks; ++k) {
+            const uint64_t start = chunks[3 * k], end = chunks[3 * k + 1], origin = chunks[3 * k + 2];
+            const size_t at = syms.size();
+            syms.resize(at + (size_t)(end - start) + 8);
+            pdz::Out o{syms.data() + at, 0u, (uint32_t)(end - start + 8)};
+            if (!pdz::parse_chunk<pdz::HostWave>(T, start, end, origin, o)) return false;
+            syms.resize(at + o.n);
+            off[k + 1] = syms.size();
+        }
+        return true;
+    };
 }
 
 // zlib's own parse of data[dict, dict + n) primed with data[0, dict) (what run_chunk computes for one chunk): tests compare

@@ -716,6 +716,26 @@ void format_sites(const std::string &nm, uint32_t b, const uint32_t *d, size_t n
     out->resize((size_t)(p - p0));
 }
 
+// Stage 1 of the byte-identical gzip streams (zlib's LZ77 parse) on the engine: pgz hands over the chunks of a round, the
+// engine returns zlib's symbols (pd_deflate_parse).  PANDEPTH_DEVICE_DEFLATE=0: zlib parses on the host threads as before.
+pgz::ParseFn engine_parse(Engine *eng)
+{
+    if (!eng->api->deflate_parse) return nullptr;
+    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return nullptr;
+    return [eng](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, std::vector<uint32_t> &syms, std::vector<uint64_t> &off) -> bool {
+        static_assert(sizeof(pd_lz_chunk) == 3 * sizeof(uint64_t), "pd_lz_chunk is a (start, end, origin) triple");
+        size_t cap = 16;
+        for (size_t k = 0; k < n_chunks; ++k) cap += (size_t)(chunks[3 * k + 1] - chunks[3 * k]);
+        syms.resize(cap); off.assign(n_chunks + 1, 0);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = eng->api->deflate_parse(eng->ctx, text, n, reinterpret_cast<const pd_lz_chunk *>(chunks), (uint32_t)n_chunks, syms.data(), cap, off.data());
+        if (getenv("PANDEPTH_TIMING"))
+            fprintf(stderr, "[timing]   pd_deflate_parse: %zu chunks of %.1f MB of text in %.3f s%s\n", n_chunks, n / 1e6,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), rc ? " — FAILED, zlib parses these chunks" : "");
+        return rc == 0;                                          // (a failure leaves the chunks to zlib on the host threads)
+    };
+}
+
 // <prefix>.SiteDepth.gz (PD:4264-4284), byte-identical to the reference's single zlib stream at any size, on all
 // threads: 4 M-cell blocks are read back, formatted in parallel slices and fed, in order, to pgz::Stream
 // (host/pgzip.h), which deflates them with zlib's own parse spread over the threads and bounded memory.
@@ -727,7 +747,9 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
     bool io_ok = true;
     int rc = 1;
     {
-        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; });
+        const pgz::ParseFn dev_parse = engine_parse(eng);
+        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; },
+                       dev_parse ? pgz::Params::for_device(dev_parse) : pgz::Params());
         // producer: read-back + formatting of the next blocks (a quarter of the threads) while the consumer deflates
         const size_t CH = (size_t)4 << 20;
         const int nt = std::max(1, threads / 4);
@@ -1006,6 +1028,9 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
     }
     Engine &eng = *engs[0];
+    // the table's gzip stream: zlib's LZ77 parse on the engine (large -w tables); the writer forgets the engine before it goes
+    struct ParseGuard { GzWriter *w; ~ParseGuard() { w->set_parse(nullptr); } } parse_guard{&OUT};
+    OUT.set_parse(engine_parse(&eng));
     // whole-contig statistics straight from the runs when a sample ends up resident and deferred (pd_scan_reduce_windows)
     if (api->keep_deferred) for (auto &e : engs) api->keep_deferred(e->ctx, 1);
     tm.mark("engine create");

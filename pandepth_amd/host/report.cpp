@@ -46,7 +46,8 @@ bool GzWriter::close()
         if (const char *e = getenv("PANDEPTH_PGZ_MIN")) pgz_min = (size_t)strtoull(e, nullptr, 10);
         std::vector<uint8_t> img;
         bool ok;
-        if (text_.size() >= pgz_min && pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img)) {
+        if (text_.size() >= pgz_min && pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img,
+                                                           parse_ ? pgz::Params::for_device(parse_) : pgz::Params())) {
             ok = fwrite(img.data(), 1, img.size(), fp) == img.size();
             ok = fclose(fp) == 0 && ok;
         } else {

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <functional>
 #include <string>
+#include "pgzip.h"
 
 namespace pdh {
 
@@ -18,6 +19,8 @@ public:
     // the SAME bytes as the single zlib stream, with the LZ77 parse spread over the threads; texts
     // below PANDEPTH_PGZ_MIN bytes (default 1 MiB), and texts pgz declines, take zlib's serial stream
     void set_threads(int threads) { threads_ = threads; }
+    // stage 1 of that stream (zlib's LZ77 parse) done by the engine instead of the host threads (pgz::ParseFn; pd_deflate_parse)
+    void set_parse(pgz::ParseFn fn) { parse_ = std::move(fn); }
     void write(const char *p, size_t n);
     void write(const std::string &s) { write(s.data(), s.size()); }
     bool close();
@@ -26,6 +29,7 @@ private:
     void *f_ = nullptr;          // gzFile: streaming mode
     void *fp_ = nullptr;         // FILE*: collecting mode
     int threads_ = 1;
+    pgz::ParseFn parse_;
     std::string path_, text_;
 };
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "../../pandepth_amd/host/engine_api.h"
+#include "../../pandepth_amd/host/pgzip.h"
 #include "../../pandepth_amd/csrc/pd_inflate_wave.h"       // the product's device decode cores, their 64 lanes emulated on the host
 #include "../../pandepth_amd/csrc/pd_bamwalk.h"
 #include <algorithm>
@@ -263,12 +264,24 @@ static int o_decode_end(pd_ctx *c)
 }
 static int o_decode_abort(pd_ctx *c) { std::lock_guard<std::mutex> lk(c->mu); c->runs.clear(); return 0; }
 static int o_set_param(pd_ctx *, const char *, uint64_t) { return 0; }
+// pd_deflate_parse on the CPU: the product's parse (csrc/pd_lz77.h) with its 64 lanes in a loop
+static int o_deflate_parse(pd_ctx *, const void *text, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *off)
+{
+    static const pgz::ParseFn fn = pgz::host_emulation_parse();
+    std::vector<uint32_t> sy; std::vector<uint64_t> of;
+    if (!fn((const uint8_t *)text, n, reinterpret_cast<const uint64_t *>(chunks), n_chunks, sy, of)) return -5;
+    if (sy.size() > cap) return -6;
+    memcpy(syms, sy.data(), sy.size() * 4);
+    memcpy(off, of.data(), of.size() * 8);
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
+    // (keep_deferred: nothing to do on this engine; deflate_parse: the product's parse core in host emulation, like the decoder's cores)
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
                                       o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from,
                                       o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param,
-                                      nullptr, nullptr, nullptr, nullptr, nullptr};
+                                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, getenv("PANDEPTH_TEST_NO_PARSE") ? nullptr : o_deflate_parse};
     return pandepth_main(argc, argv, &api, 0);
 }

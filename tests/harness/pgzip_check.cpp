@@ -33,6 +33,13 @@ int main(int argc, char **argv)
     if (argc > 3) p.chunk = (size_t)atoll(argv[3]);
     if (argc > 4) p.tail = (size_t)atoll(argv[4]);
     if (argc > 5) p.batch = (size_t)atoll(argv[5]);
+    if (getenv("PGZ_NATIVE")) {                              // stage 1 by the engine's parse (host emulation), the geometry a device provider gets
+        const pgz::Params d = pgz::Params::for_device(pgz::host_emulation_parse());
+        p.parse = d.parse;
+        if (argc <= 3) p.chunk = d.chunk;
+        if (argc <= 4) p.tail = d.tail;
+        if (argc <= 5) p.batch = (size_t)24 << 20;           // (small rounds: several per test file)
+    }
     // the reference stream: the way GzWriter (and the reference's gzstream) writes
     char tmp[] = "/tmp/pgzcheckXXXXXX";
     const int fd = mkstemp(tmp);

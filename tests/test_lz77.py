@@ -74,3 +74,33 @@ def test_device_parse_equals_zlib(corpus, name, geo):
     subprocess.run(["make", "-C", H, "lz77_gpu_check"], check=True, stdout=subprocess.DEVNULL)
     p = subprocess.run([os.path.join(H, "lz77_gpu_check"), str(corpus / name), geo[0], geo[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0 and " 0 chunks differ" in p.stdout, p.stdout + p.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
+    """`pandepth -w 100 -a`: both gzip streams with stage 1 on the GPU (pd_deflate_parse) — the same bytes as with zlib parsing on the
+    host threads (PANDEPTH_DEVICE_DEFLATE=0) and as the reference binary's files where it is present."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    names, lens = synth.genome_c2(scale=0.002)
+    rec = synth.gen_records_numpy(lens, 100000, seed=5)
+    bam = str(tmp_path / "g.bam")
+    synth.write_bam(bam, names, lens, rec, procs=2, payload=False)
+    subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
+    cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
+    outs = {}
+    for tag, env in (("dev", {"PANDEPTH_TIMING": "1"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
+        p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "8"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=900, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-600:]
+        outs[tag] = {s: (tmp_path / ("%s.%s" % (tag, s))).read_bytes() for s in ("win.stat.gz", "SiteDepth.gz")}
+        if tag == "dev":
+            err = p.stderr.decode()
+            assert err.count("pd_deflate_parse:") >= 2 and "FAILED" not in err, err[-1500:]
+    assert outs["dev"] == outs["host"]
+    ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+    if os.access(ref, os.X_OK):
+        subprocess.run([ref, "-i", "g.bam", "-w", "100", "-a", "-o", "ref", "-t", "4"], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for s in ("win.stat.gz", "SiteDepth.gz"):
+            assert outs["dev"][s] == (tmp_path / ("ref." + s)).read_bytes(), s
