@@ -580,7 +580,7 @@ struct Stream::Impl {
                 tri.push_back(c.start - base); tri.push_back(c.tail_end - base); tri.push_back(c.start - dl - base);
                 which.push_back(k);
             }
-            std::vector<uint32_t> sy; std::vector<uint64_t> off;
+            SymVec sy; std::vector<uint64_t> off;
             if (!which.empty() && parse(buf.data(), buf.size(), tri.data(), which.size(), sy, off) && off.size() == which.size() + 1) {
                 parallel_for(threads, which.size(), [&](size_t j) {
                     Chunk &c = chunks[which[j]];
@@ -598,63 +598,69 @@ struct Stream::Impl {
         }
         const double tp1 = now_s();
         for (auto &c : chunks) if (!c.ok) return false;
-        // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position
+        // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position.  Where a pair meets depends on
+        // the two parses alone (the earlier hand-over lies a tail's length before the stretch that is searched), so every pair is
+        // searched on the threads; the hand-overs are then chained, checked and the symbols copied into place, again on the threads.
         const size_t n_stitch = final ? nc : (nc ? nc - 1 : 0);   // the last parsed chunk waits for its successor unless final
-        std::vector<Sym> syms;
-        {
-            size_t cap = pending.size();
-            for (size_t k = 0; k < n_stitch; ++k) cap += chunks[k].syms.size();
-            syms.reserve(cap);
-            syms.insert(syms.end(), pending.begin(), pending.end());
-            pending.clear();
-        }
-        bool ended = false;
-        for (size_t k = 0; k < n_stitch && !ended; ++k) {
-            Chunk &a = chunks[k];
-            crc = (uint32_t)crc32_combine(crc, a.crc, (z_off_t)(a.end - a.start));
-            uint64_t stop;
-            size_t i_stop = a.syms.size();                    // index of the first symbol NOT taken from a
-            const bool to_end = final && a.tail_end == total;
-            if (to_end) stop = total;
-            else {
-                const Chunk &b = chunks[k + 1];
-                // match ends of b inside a's tail (b's parse starts at b.start: only its first symbols are walked)
-                std::vector<uint64_t> bends;
-                uint64_t q = b.start;
-                for (const Sym s : b.syms) {
-                    q += sym_len(s);
-                    if (q + MARGIN > a.tail_end) break;
-                    if (is_match(s)) bends.push_back(q);
-                }
-                // a's symbols in the tail, walked BACKWARDS from its end (a's parse covers [start, tail_end) exactly):
-                // the earliest match end beyond b.start (and pos) that b shares
-                uint64_t qe = a.tail_end;                     // end position of symbol i - 1 ... start of symbol i
-                stop = 0;
-                size_t j = bends.size();
-                for (size_t i = a.syms.size(); i-- > 0;) {
-                    // symbol i covers [qe - len, qe)
-                    const Sym sy = a.syms[i];
-                    if (qe <= b.start || qe <= pos) break;
-                    if (is_match(sy) && qe + MARGIN <= a.tail_end) {
-                        while (j > 0 && bends[j - 1] > qe) --j;
-                        if (j > 0 && bends[j - 1] == qe) { stop = qe; i_stop = i + 1; }   // keep going: an earlier one is better
-                    }
-                    qe -= sym_len(sy);
-                }
-                if (stop == 0) return false;                  // the two parses did not meet inside the tail
+        size_t n_eff = n_stitch;                                  // chunks that contribute symbols (the one that runs to the end is the last)
+        if (final) for (size_t k = 0; k < nc; ++k) if (chunks[k].tail_end == total) { n_eff = k + 1; break; }
+        std::vector<uint64_t> stop(n_eff, 0);
+        std::vector<size_t> i_stop(n_eff, 0), i_first(n_eff, 0);
+        std::vector<char> st_ok(n_eff, 1);
+        parallel_for(threads, n_eff, [&](size_t k) {
+            const Chunk &a = chunks[k];
+            i_stop[k] = a.syms.size();
+            if (final && a.tail_end == total) { stop[k] = total; return; }
+            const Chunk &b = chunks[k + 1];
+            // match ends of b inside a's tail (b's parse starts at b.start: only its first symbols are walked)
+            std::vector<uint64_t> bends;
+            uint64_t q = b.start;
+            for (const Sym s : b.syms) {
+                q += sym_len(s);
+                if (q + MARGIN > a.tail_end) break;
+                if (is_match(s)) bends.push_back(q);
             }
-            // first symbol of a at pos: walked from the front (pos lies within a tail's length of a.start)
+            // a's symbols in the tail, walked BACKWARDS from its end (a's parse covers [start, tail_end) exactly):
+            // the earliest match end beyond b.start that b shares
+            uint64_t qe = a.tail_end;                             // end position of symbol i - 1 ... start of symbol i
+            size_t j = bends.size();
+            for (size_t i = a.syms.size(); i-- > 0;) {
+                const Sym sy = a.syms[i];                         // symbol i covers [qe - len, qe)
+                if (qe <= b.start) break;
+                if (is_match(sy) && qe + MARGIN <= a.tail_end) {
+                    while (j > 0 && bends[j - 1] > qe) --j;
+                    if (j > 0 && bends[j - 1] == qe) { stop[k] = qe; i_stop[k] = i + 1; }   // keep going: an earlier one is better
+                }
+                qe -= sym_len(sy);
+            }
+            if (stop[k] == 0) st_ok[k] = 0;                       // the two parses did not meet inside the tail
+        });
+        for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
+        // the chain of hand-overs: chunk k's symbols start at the previous hand-over
+        std::vector<uint64_t> from(n_eff, 0);
+        { uint64_t p = pos; for (size_t k = 0; k < n_eff; ++k) { from[k] = p; if (stop[k] <= p && !(stop[k] == p && p == total)) return false; p = stop[k]; } }
+        parallel_for(threads, n_eff, [&](size_t k) {
+            const Chunk &a = chunks[k];
             uint64_t qa = a.start;
-            size_t i_first = 0;
-            while (i_first < i_stop && qa < pos) { qa += sym_len(a.syms[i_first]); ++i_first; }
-            if (qa != pos) return false;                       // pos is not a symbol boundary of this parse
-            syms.insert(syms.end(), a.syms.begin() + (std::ptrdiff_t)i_first, a.syms.begin() + (std::ptrdiff_t)i_stop);
-            pos = stop;
-            if (to_end) {
-                for (size_t r = k + 1; r < nc; ++r) crc = (uint32_t)crc32_combine(crc, chunks[r].crc, (z_off_t)(chunks[r].end - chunks[r].start));
-                ended = true;
-            }
+            size_t i = 0;
+            while (i < i_stop[k] && qa < from[k]) { qa += sym_len(a.syms[i]); ++i; }
+            if (qa != from[k]) st_ok[k] = 0;                      // the hand-over is not a symbol boundary of this parse
+            i_first[k] = i;
+        });
+        for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
+        SymVec syms;
+        {
+            std::vector<size_t> at(n_eff + 1, pending.size());
+            for (size_t k = 0; k < n_eff; ++k) at[k + 1] = at[k] + (i_stop[k] - i_first[k]);
+            syms.resize(at[n_eff]);
+            if (!pending.empty()) memcpy(syms.data(), pending.data(), pending.size() * sizeof(Sym));
+            pending.clear();
+            parallel_for(threads, n_eff, [&](size_t k) {
+                if (i_stop[k] > i_first[k]) memcpy(syms.data() + at[k], chunks[k].syms.data() + i_first[k], (i_stop[k] - i_first[k]) * sizeof(Sym));
+            });
         }
+        for (size_t k = 0; k < (final ? nc : n_stitch); ++k) crc = (uint32_t)crc32_combine(crc, chunks[k].crc, (z_off_t)(chunks[k].end - chunks[k].start));
+        if (n_eff) pos = stop[n_eff - 1];
         if (final && pos != total) return false;
         if (!final && nc) { carry = std::move(chunks[nc - 1]); have_carry = true; }
         next_chunk += n_stitch;
@@ -735,7 +741,7 @@ bool Stream::finish()
 
 ParseFn host_emulation_parse()
 {
-    return [](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, std::vector<uint32_t> &syms, std::vector<uint64_t> &off) -> bool {
+    return [](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, SymVec &syms, std::vector<uint64_t> &off) -> bool {
         if (n < 3) return false;
         // positions sorted by (hash, position): a stable counting sort (the device does this with a radix sort)
         std::vector<uint8_t> padded(text, text + n);

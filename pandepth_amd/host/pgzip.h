@@ -21,6 +21,8 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <functional>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace pgz {
@@ -28,8 +30,13 @@ namespace pgz {
 // Stage 1 done elsewhere (the engine: pd_deflate_parse on the GPU): the parse of the chunks (start, end, origin triples: positions
 // in text[0, n), origin = where the chunk's <= 32 KiB of history begin) — symbols of chunk k at syms[off[k], off[k + 1]).  It must be
 // zlib's parse of each chunk primed with its history, except within 1 KiB of a chunk's end; false = not available, zlib does it.
-typedef std::function<bool(const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, std::vector<uint32_t> &syms,
-                           std::vector<uint64_t> &off)> ParseFn;
+template <class T> struct NoInit : std::allocator<T> {        // resize() leaves the new elements uninitialised (symbol buffers of hundreds of MB)
+    template <class U> struct rebind { typedef NoInit<U> other; };
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint32_t, NoInit<uint32_t>> SymVec;
+typedef std::function<bool(const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, SymVec &syms, std::vector<uint64_t> &off)> ParseFn;
 
 struct Params {
     size_t chunk = (size_t)1 << 20;      // text per zlib call
@@ -37,7 +44,7 @@ struct Params {
     size_t batch = 0;                    // text buffered between rounds (0 = 96 MiB)
     ParseFn parse;                       // optional stage-1 provider; a stream's last chunk always goes to zlib (it sees the end of the input)
     // the geometry that suits a provider with one wave per chunk: many small chunks, rounds large enough to fill the device
-    static Params for_device(ParseFn fn) { Params p; p.chunk = (size_t)1 << 16; p.tail = (size_t)1 << 13; p.batch = (size_t)512 << 20; p.parse = std::move(fn); return p; }
+    static Params for_device(ParseFn fn) { Params p; p.chunk = (size_t)1 << 16; p.tail = (size_t)1 << 13; p.batch = (size_t)192 << 20; p.parse = std::move(fn); return p; }
 };
 
 // the host emulation of the engine's parse (csrc/pd_lz77.h, 64 lanes in a loop) as a provider: tests of the plumbing without a GPU

@@ -722,13 +722,19 @@ pgz::ParseFn engine_parse(Engine *eng)
 {
     if (!eng->api->deflate_parse) return nullptr;
     if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return nullptr;
-    return [eng](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, std::vector<uint32_t> &syms, std::vector<uint64_t> &off) -> bool {
+    return [eng](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, pgz::SymVec &syms, std::vector<uint64_t> &off) -> bool {
         static_assert(sizeof(pd_lz_chunk) == 3 * sizeof(uint64_t), "pd_lz_chunk is a (start, end, origin) triple");
-        size_t cap = 16;
-        for (size_t k = 0; k < n_chunks; ++k) cap += (size_t)(chunks[3 * k + 1] - chunks[3 * k]);
-        syms.resize(cap); off.assign(n_chunks + 1, 0);
+        size_t bytes = 0;
+        for (size_t k = 0; k < n_chunks; ++k) bytes += (size_t)(chunks[3 * k + 1] - chunks[3 * k]);
+        off.assign(n_chunks + 1, 0);
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = eng->api->deflate_parse(eng->ctx, text, n, reinterpret_cast<const pd_lz_chunk *>(chunks), (uint32_t)n_chunks, syms.data(), cap, off.data());
+        // a symbol per 3 bytes is plenty for tables (they parse to a symbol per 7-8 bytes); text that needs more gets the full size
+        int rc = PD_ERANGE;
+        for (size_t cap : {bytes / 3 + 4096, bytes + 16}) {
+            syms.resize(cap);
+            rc = eng->api->deflate_parse(eng->ctx, text, n, reinterpret_cast<const pd_lz_chunk *>(chunks), (uint32_t)n_chunks, syms.data(), cap, off.data());
+            if (rc != PD_ERANGE) break;
+        }
         if (getenv("PANDEPTH_TIMING"))
             fprintf(stderr, "[timing]   pd_deflate_parse: %zu chunks of %.1f MB of text in %.3f s%s\n", n_chunks, n / 1e6,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), rc ? " — FAILED, zlib parses these chunks" : "");

@@ -268,7 +268,7 @@ static int o_set_param(pd_ctx *, const char *, uint64_t) { return 0; }
 static int o_deflate_parse(pd_ctx *, const void *text, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *off)
 {
     static const pgz::ParseFn fn = pgz::host_emulation_parse();
-    std::vector<uint32_t> sy; std::vector<uint64_t> of;
+    pgz::SymVec sy; std::vector<uint64_t> of;
     if (!fn((const uint8_t *)text, n, reinterpret_cast<const uint64_t *>(chunks), n_chunks, sy, of)) return -5;
     if (sy.size() > cap) return -6;
     memcpy(syms, sy.data(), sy.size() * 4);
