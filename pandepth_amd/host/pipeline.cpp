@@ -762,6 +762,8 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
         std::mutex mu;
         std::condition_variable cv;
         std::deque<std::vector<std::string>> q;              // each entry: one block's slices, in order
+        struct Block { std::unique_ptr<char[]> p; size_t n = 0, cap = 0; };
+        std::deque<Block> qb; size_t qb_bytes = 0;           // ... or one block of text formatted by the engine
         bool done = false, stop = false, prod_ok = true;
         std::thread producer([&] {
             std::vector<uint32_t> d(CH);
@@ -771,17 +773,21 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                 for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
                     const size_t n = std::min<size_t>(CH, len - b);
                     if (eng->api->format_sites) {
-                        // the engine formats the rows where the cells are; one block of text comes back
-                        std::vector<std::string> parts(1);
+                        // the engine formats the rows where the cells are; one block of text comes back (into a buffer that is
+                        // not zero-filled first: 112 MB per block; the queue may hold a round's worth of blocks so that the
+                        // formatting runs ahead of the deflate rounds)
                         const std::string &nm = hdr.names[t];
-                        parts[0].resize(n * (nm.size() + 23));
+                        Block blk;
+                        blk.cap = n * (nm.size() + 23);
+                        blk.p.reset(new char[blk.cap]);
                         size_t got = 0;
-                        if (!eng->ck(eng->api->format_sites(eng->ctx, (int32_t)t, b, n, nm.data(), nm.size(), &parts[0][0], parts[0].size(), &got), "pd_format_sites")) { prod_ok = false; goto out; }
-                        parts[0].resize(got);
+                        if (!eng->ck(eng->api->format_sites(eng->ctx, (int32_t)t, b, n, nm.data(), nm.size(), blk.p.get(), blk.cap, &got), "pd_format_sites")) { prod_ok = false; goto out; }
+                        blk.n = got;
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || q.size() < 2; });
+                        cv.wait(lk, [&] { return stop || qb_bytes < ((size_t)256 << 20); });
                         if (stop) goto out;
-                        q.push_back(std::move(parts));
+                        qb_bytes += blk.n;
+                        qb.push_back(std::move(blk));
                         lk.unlock();
                         cv.notify_all();
                         continue;
@@ -811,13 +817,16 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
         });
         for (;;) {
             std::vector<std::string> parts;
+            Block blk;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return done || !q.empty(); });
-                if (q.empty()) break;
-                parts = std::move(q.front()); q.pop_front();
+                cv.wait(lk, [&] { return done || !q.empty() || !qb.empty(); });
+                if (q.empty() && qb.empty()) break;
+                if (!qb.empty()) { blk = std::move(qb.front()); qb.pop_front(); qb_bytes -= blk.n; }
+                else { parts = std::move(q.front()); q.pop_front(); }
             }
             cv.notify_all();
+            if (rc == 1 && blk.n && !st.write(blk.p.get(), blk.n)) rc = io_ok ? 0 : -1;
             for (auto &p : parts)
                 if (rc == 1 && !p.empty() && !st.write(p.data(), p.size())) rc = io_ok ? 0 : -1;
             if (rc != 1) { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); break; }
