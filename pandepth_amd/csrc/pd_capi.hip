@@ -1708,7 +1708,12 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
                      uint32_t *syms, size_t syms_cap, uint64_t *sym_off)
 {
     if (!c || !text || !chunks || !syms || !sym_off) return PD_EINVAL;
-    std::lock_guard<std::mutex> lk(c->mu);
+    // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
+    // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
+    // waiting for the 0.07 s a round's parse takes.  Calls of several threads are serialised among themselves.
+    static std::mutex lz_mu;
+    std::lock_guard<std::mutex> lz_lock(lz_mu);
+    auto fail = [&](pd_ctx *cc, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(cc->mu); cc->err = msg; return code; };
     if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");
     uint64_t stride = 0;
     for (uint32_t k = 0; k < n_chunks; ++k) {
@@ -1720,7 +1725,13 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     sym_off[0] = 0;
     if (!n_chunks) return PD_OK;
     stride += 8;
-    HIPOK(c, hipSetDevice(c->device));
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, PD_EHIP, "pd_deflate_parse: hipSetDevice failed");
+    static hipStream_t lz_stream = nullptr; static int lz_dev = -1;
+    if (lz_stream && lz_dev != c->device) { (void)hipStreamDestroy(lz_stream); lz_stream = nullptr; }
+    if (!lz_stream) { if (hipStreamCreateWithFlags(&lz_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, PD_EHIP, "pd_deflate_parse: stream creation failed"); lz_dev = c->device; }
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const bool prof = c->prof;
+    if (prof) for (auto &e : ev) (void)hipEventCreate(&e);
     const uint32_t np = (uint32_t)(n_text - 2);
     const uint32_t n_blocks = (np + 2047) / 2048;
     uint8_t *d_text = nullptr; uint64_t *ka = nullptr, *kb = nullptr, *d_chunks = nullptr, *d_off = nullptr;
@@ -1728,6 +1739,7 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     auto cleanup = [&]() {
         for (void *q : {(void *)d_text, (void *)ka, (void *)kb, (void *)d_chunks, (void *)d_off, (void *)hist, (void *)scan_tmp, (void *)S, (void *)R,
                         (void *)bucket, (void *)d_syms, (void *)d_cnt, (void *)d_out}) if (q) (void)hipFree(q);
+        for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; }
     };
     const size_t nh = (size_t)256 * n_blocks + 16;
     if (hipMalloc(&d_text, n_text + 64) != hipSuccess || hipMalloc(&ka, (size_t)np * 8 + 64) != hipSuccess || hipMalloc(&kb, (size_t)np * 8 + 64) != hipSuccess ||
@@ -1738,15 +1750,18 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
         (void)hipGetLastError(); cleanup();
         return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed");
     }
-    hipStream_t st = c->stream;
+    hipStream_t st = lz_stream;
     std::vector<uint32_t> counts(n_chunks);
     hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
     static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");
     if (e == hipSuccess) {
-        { ProfScope ps(c, "lz_sort"); launch_lz_sort(st, d_text, np, ka, kb, hist, scan_tmp, S, R, bucket); }
-        { ProfScope ps(c, "lz_parse"); launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt); }
+        if (prof) (void)hipEventRecord(ev[0], st);
+        launch_lz_sort(st, d_text, np, ka, kb, hist, scan_tmp, S, R, bucket);
+        if (prof) (void)hipEventRecord(ev[1], st);
+        launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt);
+        if (prof) (void)hipEventRecord(ev[2], st);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, st);
@@ -1761,9 +1776,17 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     if (total) {
         if (hipMalloc(&d_out, total * 4 + 64) != hipSuccess) { (void)hipGetLastError(); cleanup(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
         e = hipMemcpyAsync(d_off, sym_off, ((size_t)n_chunks + 1) * 8, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) { ProfScope ps(c, "lz_gather"); launch_lz_gather(st, d_syms, stride, d_off, n_chunks, d_out); e = hipGetLastError(); }
+        if (e == hipSuccess) { launch_lz_gather(st, d_syms, stride, d_off, n_chunks, d_out); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(syms, d_out, total * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (prof) {
+        float a = 0, b = 0;
+        if (e == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(c->mu);
+            auto &s1 = c->prof_acc["lz_sort"]; s1.first += a; s1.second += 1;
+            auto &s2 = c->prof_acc["lz_parse"]; s2.first += b; s2.second += 1;
+        }
     }
     cleanup();
     if (e != hipSuccess) return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e));
