@@ -539,40 +539,36 @@ struct Stream::Impl {
         return ok;
     }
 
-    // stitches and emits everything that can be decided with the text seen so far (all of it when final)
-    bool run(bool final)
+    // ---- a round in two stages, so that stage B of one round runs while stage A of the next is being parsed (on the GPU, with a
+    // provider): A = the parse of the chunks whose text has arrived; B = stitch + blocks + bits of a parsed round.  B needs no text.
+    uint64_t parsed_hi = 0;                                   // first chunk (on the absolute grid) not yet parsed
+    const uint64_t MARGIN = 1024;                             // zlib's look-ahead near the artificial end of a chunk
+    struct RoundInfo { double parse_s = 0; size_t provided = 0; };
+
+    // stage A: parses the chunks [parsed_hi, c_hi) into `chunks` (empty: nothing to do yet)
+    bool parse_round(bool final, std::vector<Chunk> &chunks, RoundInfo &info)
     {
-        if (!header_done) {
-            static const uint8_t HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};      // deflate, no flags, mtime 0, xfl 0, OS unix
-            out.insert(out.end(), HDR, HDR + 10);
-            crc = (uint32_t)crc32(0L, Z_NULL, 0);
-            header_done = true;
-        }
         const uint64_t avail = base + buf.size();            // == total
-        const uint64_t MARGIN = 1024;                        // zlib's look-ahead near the artificial end of a chunk
-        // chunks that can be parsed now: tail inside the text (or final)
-        uint64_t c_hi = next_chunk;                           // exclusive
+        uint64_t c_hi = parsed_hi;                            // exclusive
         if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
         else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
-        if (!final && c_hi < next_chunk + 2) return true;     // a stitch needs a chunk and its successor
-        const size_t nc = (size_t)(c_hi - next_chunk);
-        std::vector<Chunk> chunks(nc);
+        if (c_hi <= parsed_hi) { chunks.clear(); return true; }
+        const size_t nc = (size_t)(c_hi - parsed_hi);
+        chunks.assign(nc, Chunk());
         for (size_t k = 0; k < nc; ++k) {
-            const uint64_t i = next_chunk + k;
+            const uint64_t i = parsed_hi + k;
             chunks[k].start = i * CH;
             chunks[k].end = final ? std::min<uint64_t>(total, (i + 1) * CH) : (i + 1) * CH;
             chunks[k].tail_end = final ? std::min<uint64_t>(total, chunks[k].end + TAIL) : chunks[k].end + TAIL;
         }
-        size_t first_new = 0;
-        if (have_carry && nc) { chunks[0].syms.swap(carry.syms); chunks[0].crc = carry.crc; chunks[0].ok = carry.ok;
-                                chunks[0].tail_end = carry.tail_end; chunks[0].end = carry.end; first_new = 1; have_carry = false; }
+        const size_t zero_ = 0;
         const double tp0 = now_s();
         size_t provided = 0;
-        if (parse && nc > first_new) {
+        if (parse && nc > zero_) {
             // stage 1 by the provider for every new chunk except one that runs to the true end of the text (zlib sees the end of
             // its input there); their CRCs on the threads
             std::vector<uint64_t> tri; std::vector<size_t> which;
-            for (size_t k = first_new; k < nc; ++k) {
+            for (size_t k = zero_; k < nc; ++k) {
                 const Chunk &c = chunks[k];
                 if (final && c.tail_end == total) continue;
                 const uint64_t dl = c.start < 32768 ? c.start : 32768;
@@ -593,10 +589,32 @@ struct Stream::Impl {
         }
         {
             std::vector<size_t> todo;
-            for (size_t k = first_new; k < nc; ++k) if (!chunks[k].ok) todo.push_back(k);
+            for (size_t k = zero_; k < nc; ++k) if (!chunks[k].ok) todo.push_back(k);
             parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(buf.data(), base, chunks[todo[j]]); });
         }
-        const double tp1 = now_s();
+        info.parse_s = now_s() - tp0; info.provided = provided;
+        parsed_hi = c_hi;
+        return true;
+    }
+
+    // stage B: `fresh` behind the chunk the previous round left waiting for its successor; stitches, cuts blocks, emits
+    bool emit_round(std::vector<Chunk> &fresh, bool final, const RoundInfo &info)
+    {
+        if (!header_done) {
+            static const uint8_t HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};      // deflate, no flags, mtime 0, xfl 0, OS unix
+            out.insert(out.end(), HDR, HDR + 10);
+            crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            header_done = true;
+        }
+        std::vector<Chunk> chunks;
+        chunks.reserve(fresh.size() + 1);
+        if (have_carry) { chunks.push_back(std::move(carry)); have_carry = false; }
+        for (auto &c : fresh) chunks.push_back(std::move(c));
+        fresh.clear();
+        const size_t nc = chunks.size();
+        if (!final && nc < 2) { if (nc) { carry = std::move(chunks[0]); have_carry = true; } return true; }   // a stitch needs a chunk and its successor
+        const double tp1 = now_s(), tp0 = tp1 - info.parse_s;
+        const size_t provided = info.provided;
         for (auto &c : chunks) if (!c.ok) return false;
         // stitch: chunk k hands over to chunk k+1 where both parses end a match at the same position.  Where a pair meets depends on
         // the two parses alone (the earlier hand-over lies a tail's length before the stretch that is searched), so every pair is
@@ -664,7 +682,6 @@ struct Stream::Impl {
         if (final && pos != total) return false;
         if (!final && nc) { carry = std::move(chunks[nc - 1]); have_carry = true; }
         next_chunk += n_stitch;
-        if (final) next_chunk = c_hi;
         // blocks: every LIT_BUFSIZE - 1 symbols; at the end the remainder (possibly empty) closes the stream
         const double tp2 = now_s();
         const size_t BS = LIT_BUFSIZE - 1;
@@ -694,12 +711,26 @@ struct Stream::Impl {
         if (getenv("PGZ_DEBUG"))
             fprintf(stderr, "[pgz] round: %zu chunks (%zu parsed by the provider), %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, provided, nblocks,
                     tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
-        // forget the text nobody needs any more: everything before the dictionary of the next chunk to parse
-        if (!final) {
-            const uint64_t keep_from_chunk = next_chunk + (have_carry ? 1 : 0);
-            const uint64_t keep = keep_from_chunk * CH > 32768 ? keep_from_chunk * CH - 32768 : 0;
-            if (keep > base) { buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)(keep - base)); base = keep; }
-        }
+        return true;
+    }
+
+    std::vector<Chunk> waiting; RoundInfo waiting_info;       // a parsed round whose stage B has not run yet
+    bool have_waiting = false;
+
+    // everything that can be decided with the text seen so far (all of it when final)
+    bool run(bool final)
+    {
+        std::vector<Chunk> fresh; RoundInfo fresh_info;
+        bool a_ok = true, b_ok = true;
+        std::thread ta([&] { a_ok = parse_round(final, fresh, fresh_info); });
+        if (have_waiting) { b_ok = emit_round(waiting, false, waiting_info); have_waiting = false; }
+        ta.join();
+        if (!a_ok || !b_ok) return false;
+        if (final) return emit_round(fresh, true, fresh_info);
+        if (!fresh.empty()) { waiting = std::move(fresh); waiting_info = fresh_info; have_waiting = true; }
+        // forget the text nobody needs any more: everything before the dictionary of the next chunk to parse (stage B needs none)
+        const uint64_t keep = parsed_hi * CH > 32768 ? parsed_hi * CH - 32768 : 0;
+        if (keep > base) { buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)(keep - base)); base = keep; }
         return true;
     }
 };

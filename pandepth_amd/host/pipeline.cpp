@@ -765,6 +765,7 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
         struct Block { std::unique_ptr<char[]> p; size_t n = 0, cap = 0; };
         std::deque<Block> qb; size_t qb_bytes = 0;           // ... or one block of text formatted by the engine
         bool done = false, stop = false, prod_ok = true;
+        double t_format = 0, t_prod_wait = 0, t_cons_wait = 0, t_write = 0;      // PANDEPTH_TIMING: where the two threads spend the phase
         std::thread producer([&] {
             std::vector<uint32_t> d(CH);
             for (size_t t = 0; t < hdr.names.size(); ++t) {
@@ -781,10 +782,14 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                         blk.cap = n * (nm.size() + 23);
                         blk.p.reset(new char[blk.cap]);
                         size_t got = 0;
+                        const auto tf0 = std::chrono::steady_clock::now();
                         if (!eng->ck(eng->api->format_sites(eng->ctx, (int32_t)t, b, n, nm.data(), nm.size(), blk.p.get(), blk.cap, &got), "pd_format_sites")) { prod_ok = false; goto out; }
                         blk.n = got;
+                        const auto tf1 = std::chrono::steady_clock::now();
+                        t_format += std::chrono::duration<double>(tf1 - tf0).count();
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&] { return stop || qb_bytes < ((size_t)256 << 20); });
+                        t_prod_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1).count();
                         if (stop) goto out;
                         qb_bytes += blk.n;
                         qb.push_back(std::move(blk));
@@ -818,6 +823,7 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
         for (;;) {
             std::vector<std::string> parts;
             Block blk;
+            const auto tw0 = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return done || !q.empty() || !qb.empty(); });
@@ -826,14 +832,22 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                 else { parts = std::move(q.front()); q.pop_front(); }
             }
             cv.notify_all();
+            const auto tw1 = std::chrono::steady_clock::now();
+            t_cons_wait += std::chrono::duration<double>(tw1 - tw0).count();
             if (rc == 1 && blk.n && !st.write(blk.p.get(), blk.n)) rc = io_ok ? 0 : -1;
+            t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
             for (auto &p : parts)
                 if (rc == 1 && !p.empty() && !st.write(p.data(), p.size())) rc = io_ok ? 0 : -1;
             if (rc != 1) { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); break; }
         }
         producer.join();
         if (!prod_ok) rc = -1;
+        const auto tfin = std::chrono::steady_clock::now();
         if (rc == 1 && !st.finish()) rc = io_ok ? 0 : -1;
+        if (getenv("PANDEPTH_TIMING"))
+            fprintf(stderr, "[timing]   per-site writer: producer formatting %.3f s + waiting for room %.3f s; consumer waiting for text %.3f s, "
+                            "in the stream (copy + deflate rounds) %.3f s, finishing %.3f s\n", t_format, t_prod_wait, t_cons_wait, t_write,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tfin).count());
     }
     if (fclose(fp) != 0 && rc == 1) rc = -1;
     return rc;

@@ -9,9 +9,9 @@ def run(cmd, env=None, tag=""):
     t0=time.time(); p=subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {}))); dt=time.time()-t0
     print("%s: wall %.3f s rc %d" % (tag, dt, p.returncode))
     for l in p.stderr.decode().splitlines():
-        if any(k in l for k in ("per-site file","table gzip","deflate_parse","[pgz]","decode + scatter","engine create","scan + statistics")): print("   ", l[:230])
+        if any(k in l for k in ("per-site writer","per-site file","table gzip","deflate_parse","[pgz]","decode + scatter","engine create","scan + statistics")): print("   ", l[:230])
     return dt
-for k in range(3):
+for k in range(2):
     time.sleep(1); run([cli,"-i","w.bam","-w","100","-a","-o","dev","-t","16"], {"PANDEPTH_TIMING":"1","PGZ_DEBUG":"1"}, "device parse #%d" % k)
 time.sleep(1); run([cli,"-i","w.bam","-w","100","-a","-o","host","-t","16"], {"PANDEPTH_TIMING":"1","PGZ_DEBUG":"1","PANDEPTH_DEVICE_DEFLATE":"0"}, "host parse")
 run([ref,"-i","w.bam","-w","100","-a","-o","ref","-t","36"], None, "reference")
