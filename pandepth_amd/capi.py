@@ -69,6 +69,8 @@ def load():
         "pd_read_depth": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, P]),
         "pd_format_sites": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, ctypes.c_char_p, SZ, P, SZ, ctypes.POINTER(SZ)]),
         "pd_deflate_parse": (I, [P, P, SZ, P, ctypes.c_uint32, P, SZ, P]),
+        "pd_host_register": (I, [P, P, SZ]),
+        "pd_host_unregister": (I, [P, P]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
         "pd_device_count": (I, [ctypes.POINTER(I)]),
         "pd_accumulate_from": (I, [P, P]),
@@ -106,7 +108,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
+           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]

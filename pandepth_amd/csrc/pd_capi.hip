@@ -115,6 +115,21 @@ struct pd_ctx {
     uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
     unsigned grid_tiles = 0;                         // 0 = sized per pass from the number of runs
     int stile = 8192; int n_cu = 256;
+    // pd_deflate_parse's work buffers (device memory, grown on demand, kept until pd_destroy)
+    struct LzWork {
+        static constexpr int N = 13;
+        void *p[N] = {}; size_t cap[N] = {};
+        bool fit(int k, size_t bytes)
+        {
+            if (bytes <= cap[k]) return true;
+            if (p[k]) { (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; }
+            const size_t want = bytes + bytes / 8 + 4096;
+            if (hipMalloc(&p[k], want) != hipSuccess) return false;
+            cap[k] = want;
+            return true;
+        }
+        void release() { for (int k = 0; k < N; ++k) { if (p[k]) (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; } }
+    } lz;
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -484,6 +499,8 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 static void runs_free(pd_runs *r);
 static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out);
 
+std::mutex g_lz_mu;                      // pd_deflate_parse calls run one at a time (they share a stream)
+
 int pd_destroy(pd_ctx *c)
 {
     if (!c) return PD_OK;
@@ -517,6 +534,7 @@ int pd_destroy(pd_ctx *c)
     }
     for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
     runs_free(c->dec_runs);
+    { std::lock_guard<std::mutex> g(g_lz_mu); c->lz.release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -1711,8 +1729,7 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
     // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
     // waiting for the 0.07 s a round's parse takes.  Calls of several threads are serialised among themselves.
-    static std::mutex lz_mu;
-    std::lock_guard<std::mutex> lz_lock(lz_mu);
+    std::lock_guard<std::mutex> lz_lock(g_lz_mu);
     auto fail = [&](pd_ctx *cc, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(cc->mu); cc->err = msg; return code; };
     if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");
     uint64_t stride = 0;
@@ -1732,34 +1749,38 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool prof = c->prof;
     if (prof) for (auto &e : ev) (void)hipEventCreate(&e);
+    const bool dbg = getenv("PD_LZ_DEBUG") != nullptr;
+    double tm[8] = {}; int ti = 0;
+    auto tick = [&]() { if (dbg && ti < 8) tm[ti++] = dec_now() * 1e-6; };
+    tick();
     const uint32_t np = (uint32_t)(n_text - 2);
     const uint32_t n_blocks = (np + 2047) / 2048;
-    uint8_t *d_text = nullptr; uint64_t *ka = nullptr, *kb = nullptr, *d_chunks = nullptr, *d_off = nullptr;
-    uint32_t *hist = nullptr, *scan_tmp = nullptr, *S = nullptr, *R = nullptr, *bucket = nullptr, *d_syms = nullptr, *d_cnt = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() {
-        for (void *q : {(void *)d_text, (void *)ka, (void *)kb, (void *)d_chunks, (void *)d_off, (void *)hist, (void *)scan_tmp, (void *)S, (void *)R,
-                        (void *)bucket, (void *)d_syms, (void *)d_cnt, (void *)d_out}) if (q) (void)hipFree(q);
-        for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; }
-    };
+    // work buffers: kept from call to call (a round of 200 MB of text needs 5 GB of them; allocating and freeing them costs more
+    // than the kernels), grown on demand, released by pd_destroy of the context that made them
+    pd_ctx::LzWork &w = c->lz;
     const size_t nh = (size_t)256 * n_blocks + 16;
-    if (hipMalloc(&d_text, n_text + 64) != hipSuccess || hipMalloc(&ka, (size_t)np * 8 + 64) != hipSuccess || hipMalloc(&kb, (size_t)np * 8 + 64) != hipSuccess ||
-        hipMalloc(&hist, nh * 4) != hipSuccess || hipMalloc(&scan_tmp, (nh / 1024 + 8) * 4) != hipSuccess || hipMalloc(&S, (size_t)np * 4 + 64) != hipSuccess ||
-        hipMalloc(&R, (size_t)n_text * 4 + 64) != hipSuccess || hipMalloc(&bucket, ((size_t)32768 + 8) * 4) != hipSuccess ||
-        hipMalloc(&d_chunks, (size_t)n_chunks * 24) != hipSuccess || hipMalloc(&d_off, ((size_t)n_chunks + 1) * 8) != hipSuccess ||
-        hipMalloc(&d_syms, (size_t)n_chunks * stride * 4) != hipSuccess || hipMalloc(&d_cnt, (size_t)n_chunks * 4 + 16) != hipSuccess) {
-        (void)hipGetLastError(); cleanup();
-        return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed");
-    }
+    const size_t want[pd_ctx::LzWork::N] = {n_text + 64, (size_t)np * 8 + 64, (size_t)np * 8 + 64, nh * 4, (nh / 1024 + 8) * 4, (size_t)np * 4 + 64, (size_t)n_text * 4 + 64,
+                                    ((size_t)32768 + 8) * 4, (size_t)n_chunks * 24, ((size_t)n_chunks + 1) * 8, (size_t)n_chunks * stride * 4, (size_t)n_chunks * 4 + 16, 0};
+    for (int k = 0; k < pd_ctx::LzWork::N; ++k)
+        if (!w.fit(k, want[k])) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
+    uint8_t *d_text = (uint8_t *)w.p[0]; uint64_t *ka = (uint64_t *)w.p[1], *kb = (uint64_t *)w.p[2];
+    uint32_t *hist = (uint32_t *)w.p[3], *scan_tmp = (uint32_t *)w.p[4], *S = (uint32_t *)w.p[5], *R = (uint32_t *)w.p[6], *bucket = (uint32_t *)w.p[7];
+    uint64_t *d_chunks = (uint64_t *)w.p[8], *d_off = (uint64_t *)w.p[9]; uint32_t *d_syms = (uint32_t *)w.p[10], *d_cnt = (uint32_t *)w.p[11];
+    auto cleanup = [&]() { for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } };
+    tick();
     hipStream_t st = lz_stream;
     std::vector<uint32_t> counts(n_chunks);
     hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
     static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");
+    if (dbg && e == hipSuccess) e = hipStreamSynchronize(st);
+    tick();
     if (e == hipSuccess) {
         if (prof) (void)hipEventRecord(ev[0], st);
         launch_lz_sort(st, d_text, np, ka, kb, hist, scan_tmp, S, R, bucket);
         if (prof) (void)hipEventRecord(ev[1], st);
+        if (dbg) { (void)hipStreamSynchronize(st); tick(); }
         launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt);
         if (prof) (void)hipEventRecord(ev[2], st);
         e = hipGetLastError();
@@ -1767,6 +1788,7 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { cleanup(); return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e)); }
+    tick();
     uint64_t total = 0;
     for (uint32_t k = 0; k < n_chunks; ++k) {
         if (counts[k] == 0xFFFFFFFFu) { cleanup(); return fail(c, PD_EHIP, "pd_deflate_parse: a chunk's symbols did not fit its buffer"); }
@@ -1774,12 +1796,18 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     }
     if (total > syms_cap) { cleanup(); return fail(c, PD_ERANGE, "pd_deflate_parse: the symbol buffer is too small"); }
     if (total) {
-        if (hipMalloc(&d_out, total * 4 + 64) != hipSuccess) { (void)hipGetLastError(); cleanup(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
+        if (!w.fit(12, total * 4 + 64)) { (void)hipGetLastError(); cleanup(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
+        uint32_t *d_out = (uint32_t *)w.p[12];
         e = hipMemcpyAsync(d_off, sym_off, ((size_t)n_chunks + 1) * 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) { launch_lz_gather(st, d_syms, stride, d_off, n_chunks, d_out); e = hipGetLastError(); }
+        if (dbg && e == hipSuccess) { e = hipStreamSynchronize(st); tick(); }
         if (e == hipSuccess) e = hipMemcpyAsync(syms, d_out, total * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
+    tick();
+    if (dbg && ti >= 7)
+        fprintf(stderr, "[lz] %.1f MB, %u chunks, %.1f M symbols: buffers %.4f, text to the device %.4f, sort %.4f, parse %.4f, gather %.4f, symbols back %.4f s\n", n_text / 1e6,
+                n_chunks, total / 1e6, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
     if (prof) {
         float a = 0, b = 0;
         if (e == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
@@ -1790,6 +1818,28 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     }
     cleanup();
     if (e != hipSuccess) return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e));
+    return PD_OK;
+}
+
+int pd_host_register(pd_ctx *c, void *ptr, size_t bytes)
+{
+    if (!c || !ptr || !bytes) return PD_EINVAL;
+    if (hipSetDevice(c->device) != hipSuccess || hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(c->mu);
+        return fail(c, PD_EHIP, "pd_host_register: hipHostRegister failed");
+    }
+    return PD_OK;
+}
+
+int pd_host_unregister(pd_ctx *c, void *ptr)
+{
+    if (!c || !ptr) return PD_EINVAL;
+    if (hipSetDevice(c->device) != hipSuccess || hipHostUnregister(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(c->mu);
+        return fail(c, PD_EHIP, "pd_host_unregister: hipHostUnregister failed");
+    }
     return PD_OK;
 }
 

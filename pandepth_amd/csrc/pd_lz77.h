@@ -16,7 +16,8 @@
 // current one is not longer) is sequential and tiny; it runs wave-uniform.
 //
 // A CHUNK is parsed as zlib parses it when primed with deflateSetDictionary: `dict` bytes before `start` are history only
-// (their positions are candidates), the parse starts fresh at `start` and covers [start, end).  The bytes of the last
+// (their positions are candidates), the parse starts fresh at `start` and covers [start, end).  The text's buffer carries at least
+// 32 bytes behind its end (reads of whole words).  The bytes of the last
 // MIN_LOOKAHEAD of a chunk are parsed as if more text followed (zlib there sees the end of its input): callers stitch chunks
 // well before that (host/pgzip.cpp takes a chunk's symbols only up to 1 KiB before its end) and leave a stream's true end to zlib.
 //
@@ -42,14 +43,16 @@ PZ_FN uint32_t hash3(const uint8_t *p) { return (((uint32_t)p[0] << 10) ^ ((uint
 
 PZ_FN uint64_t ld64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
 
-// common prefix of text[p ..] and text[q ..], at most cap bytes (q < p; reads stay below p + cap + 8: buffers carry 8 bytes of slack)
-PZ_FN uint32_t lcp(const uint8_t *text, uint64_t p, uint64_t q, uint32_t cap)
+// common prefix of tp[..] and tq[..], at most cap bytes, 16 bytes per step (tq < tp; reads stay below tp + cap + 16: buffers carry
+// at least 32 bytes of slack behind the text)
+PZ_FN uint32_t lcp(const uint8_t *tp, const uint8_t *tq, uint32_t cap)
 {
     uint32_t n = 0;
     while (n < cap) {
-        const uint64_t x = ld64(text + p + n) ^ ld64(text + q + n);
-        if (x) { n += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
-        n += 8;
+        const uint64_t x0 = ld64(tp + n) ^ ld64(tq + n), x1 = ld64(tp + n + 8) ^ ld64(tq + n + 8);
+        if (x0) { n += (uint32_t)(__builtin_ctzll(x0) >> 3); break; }
+        if (x1) { n += 8u + (uint32_t)(__builtin_ctzll(x1) >> 3); break; }
+        n += 16;
     }
     return n < cap ? n : cap;
 }
@@ -62,39 +65,60 @@ struct Text {
     uint64_t n;                   // bytes of text
 };
 
-// zlib's longest_match for position p (prev_len = length of the match found at p - 1, the bar to beat), `look` bytes left from p.
-// Returns the match length (prev_len if nothing longer was found, as zlib does) and sets *start.  Wave-uniform in, wave-uniform out.
+// zlib's longest_match for position p (prev_len = length of the match found at p - 1, the bar to beat), `look` bytes left from p;
+// r = R[p], b0 = the start of p's bucket.  Returns the match length (prev_len if nothing longer was found, as zlib does; MIN_MATCH - 1
+// when the head of the chain is no candidate at all: zlib does not even call longest_match then) and sets *start.
+// Wave-uniform in, wave-uniform out.
+//
+// The kernel is bound by the latency of dependent loads (candidate positions -> their text), so a lane measures TWO candidates
+// at once — the k-th and the (64 + k)-th most recent — with all their loads in flight together; what zlib's loop would have
+// done with them (budget, the end of the chain, nice_length) is then decided group by group, in order.
+//
+// The two positions the parse may visit next are known before the search (p + 1, or the end of the previous match once it is
+// emitted); `ah` carries their hashes in and the starts of their buckets out: those loads ride along with the candidates' text, so
+// that the next visit starts with everything but its candidates in registers.
+struct Ahead { uint32_t h1, h2, b1, b2; };
+
 template <class W>
-PZ_FN uint32_t longest_match(const Text &T, uint64_t p, uint32_t prev_len, uint64_t look, uint64_t origin, uint32_t *start)
+PZ_FN uint32_t longest_match(const Text &T, uint64_t p, uint32_t prev_len, uint64_t look, uint64_t origin, uint32_t r, uint32_t b0, Ahead &ah, uint32_t *start)
 {
     typedef typename W::template Var<uint32_t> U;
-    const uint32_t h = hash3(T.text + p);
-    const uint32_t r = T.R[p], b0 = T.bucket[h];
-    uint32_t avail = r - b0;                                   // earlier positions with this hash
-    uint32_t budget = prev_len >= GOOD_LEN ? MAX_CHAIN >> 2 : MAX_CHAIN;
+    const uint32_t avail = r - b0;                             // earlier positions with this hash
+    const uint32_t budget = prev_len >= GOOD_LEN ? MAX_CHAIN >> 2 : MAX_CHAIN;
     const uint32_t nice = look < (uint64_t)NICE_LEN ? (uint32_t)look : (uint32_t)NICE_LEN;
     const uint32_t cap = look < (uint64_t)MAX_MATCH ? (uint32_t)look : (uint32_t)MAX_MATCH;
+    const bool two = budget > 64u && avail > 64u;
+    const uint8_t *tp = T.text + p;
+    U len0, pos0, len1, pos1;
+    W::each([&](int l) {
+        const uint32_t k0 = (uint32_t)l, k1 = 64u + (uint32_t)l;
+        const bool in0 = k0 < avail && k0 < budget, in1 = two && k1 < avail && k1 < budget;
+        const uint32_t q0 = in0 ? T.S[r - 1 - k0] : 0u, q1 = in1 ? T.S[r - 1 - k1] : 0u;
+        pos0[l] = q0; pos1[l] = q1;
+        // zlib: the head of the chain may be exactly MAX_DIST away, the others must be nearer; position `origin` is NIL
+        const bool ok0 = in0 && q0 != (uint32_t)origin && (l == 0 ? p - q0 <= (uint64_t)MAX_DIST : p - q0 < (uint64_t)MAX_DIST);
+        const bool ok1 = in1 && q1 != (uint32_t)origin && p - q1 < (uint64_t)MAX_DIST;
+        // the first 16 bytes of both candidates at once (a lane without a candidate compares p with itself and drops the result)
+        const uint8_t *t0 = ok0 ? T.text + q0 : tp, *t1 = ok1 ? T.text + q1 : tp;
+        const uint64_t a0 = ld64(tp), a1 = ld64(tp + 8);
+        const uint64_t x00 = a0 ^ ld64(t0), x01 = a1 ^ ld64(t0 + 8), x10 = a0 ^ ld64(t1), x11 = a1 ^ ld64(t1 + 8);
+        ah.b1 = T.bucket[ah.h1]; ah.b2 = T.bucket[ah.h2];     // (the same for every lane)
+        uint32_t n0 = x00 ? (uint32_t)(__builtin_ctzll(x00) >> 3) : x01 ? 8u + (uint32_t)(__builtin_ctzll(x01) >> 3) : 16u;
+        uint32_t n1 = x10 ? (uint32_t)(__builtin_ctzll(x10) >> 3) : x11 ? 8u + (uint32_t)(__builtin_ctzll(x11) >> 3) : 16u;
+        if (ok0 && n0 == 16u && cap > 16u) n0 = 16u + lcp(tp + 16, t0 + 16, cap - 16u);
+        if (ok1 && n1 == 16u && cap > 16u) n1 = 16u + lcp(tp + 16, t1 + 16, cap - 16u);
+        len0[l] = ok0 ? (n0 < cap ? n0 : cap) + 1u : 0u;      // + 1: 0 marks "the chain ends here"
+        len1[l] = ok1 ? (n1 < cap ? n1 : cap) + 1u : 0u;
+    });
     uint32_t best = prev_len, best_q = 0;
-    bool first = true;
-    uint32_t k0 = 0;                                           // candidates already looked at
-    while (budget && k0 < avail) {
-        U len, pos;
-        W::each([&](int l) {
-            len[l] = 0; pos[l] = 0;
-            const uint32_t k = k0 + (uint32_t)l;               // k-th most recent
-            if (k >= avail || (uint32_t)l >= budget) return;
-            const uint32_t q = T.S[r - 1 - k];
-            pos[l] = q;
-            // zlib: the head of the chain may be exactly MAX_DIST away, the others must be nearer; position `origin` is NIL
-            const uint64_t dist = p - q;
-            const bool ok = q != (uint32_t)origin && (first && l == 0 ? dist <= (uint64_t)MAX_DIST : dist < (uint64_t)MAX_DIST);
-            len[l] = ok ? lcp(T.text, p, q, cap) + 1u : 0u;    // + 1: 0 marks "the chain ends here"
-        });
+    bool head_ok = true;
+    // one group of 64 candidates as zlib's loop takes them; true = the loop goes on behind them
+    auto take = [&](const U &len, const U &pos, uint32_t bud, bool first) -> bool {
         // the chain ends at the first invalid candidate (positions only get older)
         const uint64_t dead = W::ballot_eq(len, 0u);
         const uint32_t n_here = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;
-        const uint32_t n_look = n_here < budget ? n_here : budget;
-        if (n_look == 0) break;
+        const uint32_t n_look = n_here < bud ? n_here : bud;
+        if (n_look == 0) { if (first) head_ok = false; return false; }
         // the first candidate of nice length or more ends the loop (it is looked at)
         U nice_hit;
         W::each([&](int l) { nice_hit[l] = (uint32_t)l < n_look && len[l] - 1u >= nice ? 1u : 0u; });
@@ -108,9 +132,10 @@ PZ_FN uint32_t longest_match(const Text &T, uint64_t p, uint32_t prev_len, uint6
             const uint64_t at = W::ballot_eq(cand, mx);
             best = mx; best_q = W::bcast(pos, (int)__builtin_ctzll(at));
         }
-        if (nm || n_here < 64u || n_look < 64u) break;         // nice hit, chain ended, or budget used up inside this group
-        budget -= 64u; k0 += 64u; first = false;
-    }
+        return !(nm || n_here < 64u || n_look < 64u);          // nice hit, chain ended, or budget used up inside this group
+    };
+    if (take(len0, pos0, budget, true) && two) (void)take(len1, pos1, budget - 64u, false);
+    if (!head_ok) { *start = 0; return MIN_MATCH - 1; }
     *start = best_q;
     return (uint64_t)best <= look ? best : (uint32_t)look;
 }
@@ -127,18 +152,32 @@ PZ_FN bool parse_chunk(const Text &T, uint64_t start, uint64_t end, uint64_t ori
     uint32_t match_len = MIN_MATCH - 1, match_start = 0;
     bool avail = false;
     bool ok = true;
+    // what the previous visit fetched for the positions that could follow it: R[] and the bucket's start
+    uint64_t p1 = ~0ull, p2 = ~0ull;
+    uint32_t r1 = 0, r2 = 0;
+    Ahead ah{0u, 0u, 0u, 0u};
     while (s < end) {
         const uint64_t look = end - s;
         const uint32_t prev_len = match_len, prev_start = match_start;
         match_len = MIN_MATCH - 1;
+        const bool search = look >= MIN_MATCH && prev_len < MAX_LAZY;
+        uint32_t r = 0, b0 = 0;
+        if (search) {
+            if (s == p1) { r = r1; b0 = ah.b1; }
+            else if (s == p2) { r = r2; b0 = ah.b2; }
+            else { r = T.R[s]; b0 = T.bucket[hash3(T.text + s)]; }
+        }
+        // the next visit: s + 1, or — when this visit emits the previous match — the position behind that match
+        p1 = s + 1; p2 = prev_len >= MIN_MATCH ? s + prev_len - 1 : p1;
+        { const uint64_t c1 = p1 + MIN_MATCH <= T.n ? p1 : 0, c2 = p2 + MIN_MATCH <= T.n ? p2 : 0;   // (behind the text: never visited with a search)
+          r1 = T.R[c1]; r2 = T.R[c2]; ah.h1 = hash3(T.text + c1); ah.h2 = hash3(T.text + c2); }
         // (the string at s enters the chains here in zlib: the chain of s is every earlier position of its bucket)
-        if (look >= MIN_MATCH && prev_len < MAX_LAZY && T.R[s] > T.bucket[hash3(T.text + s)]) {
-            const uint32_t head = T.S[T.R[s] - 1];
-            if (head != (uint32_t)origin && s - head <= (uint64_t)MAX_DIST) {
-                match_len = longest_match<W>(T, s, prev_len, look, origin, &match_start);
-                if (match_len <= prev_len) match_start = prev_start;       // (zlib leaves match_start alone unless it found something longer)
-                if (match_len == MIN_MATCH && s - match_start > (uint64_t)TOO_FAR) match_len = MIN_MATCH - 1;
-            }
+        if (search && r > b0) {
+            match_len = longest_match<W>(T, s, prev_len, look, origin, r, b0, ah, &match_start);
+            if (match_len <= prev_len) match_start = prev_start;               // (zlib leaves match_start alone unless it found something longer)
+            if (match_len == MIN_MATCH && s - match_start > (uint64_t)TOO_FAR) match_len = MIN_MATCH - 1;
+        } else {
+            ah.b1 = T.bucket[ah.h1]; ah.b2 = T.bucket[ah.h2];
         }
         if (prev_len >= MIN_MATCH && match_len <= prev_len) {
             ok = ok && put<W>(o, (prev_len << 16) | (uint32_t)(s - 1 - prev_start));

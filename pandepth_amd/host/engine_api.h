@@ -48,6 +48,9 @@ typedef struct pd_engine_api {
     int (*keep_deferred)(pd_ctx *, int);
     /* optional (NULL = zlib parses on the host threads): stage 1 of the byte-identical gzip streams on the engine, see pd_deflate_parse */
     int (*deflate_parse)(pd_ctx *, const void *, size_t, const pd_lz_chunk *, uint32_t, uint32_t *, size_t, uint64_t *);
+    /* optional (NULL = buffers stay pageable): see pd_host_register */
+    int (*host_register)(pd_ctx *, void *, size_t);
+    int (*host_unregister)(pd_ctx *, void *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

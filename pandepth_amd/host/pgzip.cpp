@@ -424,7 +424,18 @@ bool parse_symbols(const uint8_t *in, size_t in_len, std::vector<Sym> &syms)
 
 struct Chunk {
     uint64_t start = 0, end = 0, tail_end = 0;   // absolute text positions
-    std::vector<Sym> syms;           // zlib's parse of [start, tail_end), primed with the 32 KiB before start
+    // zlib's parse of [start, tail_end), primed with the 32 KiB before start: the chunk's own (zlib ran here), or a stretch of a
+    // provider's symbols, kept alive by `hold`
+    struct View {
+        const Sym *p = nullptr; size_t n = 0;
+        size_t size() const { return n; }
+        const Sym &operator[](size_t i) const { return p[i]; }
+        const Sym *begin() const { return p; }
+        const Sym *end() const { return p + n; }
+        const Sym *data() const { return p; }
+    } syms;
+    std::vector<Sym> own;
+    std::shared_ptr<SymVec> hold;
     uint32_t crc = 0;                // of [start, end)
     bool ok = false;
 };
@@ -433,7 +444,7 @@ struct Chunk {
 void run_chunk(const uint8_t *text, uint64_t base, Chunk &c)
 {
     c.ok = false;
-    c.syms.clear();
+    c.own.clear(); c.syms = Chunk::View();
     z_stream z;
     memset(&z, 0, sizeof z);
     if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
@@ -450,10 +461,34 @@ void run_chunk(const uint8_t *text, uint64_t base, Chunk &c)
     const size_t produced = raw.size() - z.avail_out;
     deflateEnd(&z);
     if (rc != Z_STREAM_END) return;
-    c.syms.reserve(n / 3 + 16);
-    if (!parse_symbols(raw.data(), produced, c.syms)) return;
+    c.own.reserve(n / 3 + 16);
+    if (!parse_symbols(raw.data(), produced, c.own)) return;
+    c.syms.p = c.own.data(); c.syms.n = c.own.size();
     c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)(c.end - c.start));
     c.ok = true;
+}
+
+// GF(2) polynomial arithmetic modulo the CRC-32 polynomial, bit-reflected (bit 31 = x^0)
+uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+// x^(8 * len) mod P: appending `len` bytes multiplies a CRC by this
+uint32_t crc_shift_op(uint64_t len)
+{
+    uint32_t sq = 1u << 23;                                   // x^8
+    uint32_t p = 1u << 31;                                    // x^0
+    for (; len; len >>= 1) {
+        if (len & 1) p = crc_mulmod(sq, p);
+        sq = crc_mulmod(sq, sq);
+    }
+    return p;
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -545,13 +580,32 @@ struct Stream::Impl {
     const uint64_t MARGIN = 1024;                             // zlib's look-ahead near the artificial end of a chunk
     struct RoundInfo { double parse_s = 0; size_t provided = 0; };
 
-    // stage A: parses the chunks [parsed_hi, c_hi) into `chunks` (empty: nothing to do yet)
-    bool parse_round(bool final, std::vector<Chunk> &chunks, RoundInfo &info)
+    // the text stage A reads: a round's text is handed over by the writer, which goes on filling `buf` meanwhile
+    std::vector<uint8_t> work; uint64_t work_base = 0;
+    // page-locked stretches of the two text buffers (Params::pin; the buffers are reserved once and never move)
+    std::function<bool(void *, size_t)> pin; std::function<void(void *)> unpin;
+    struct Pin { void *p; size_t n; };
+    std::vector<Pin> pins;
+    void ensure_pinned(void *p, size_t used, size_t cap)
     {
-        const uint64_t avail = base + buf.size();            // == total
-        uint64_t c_hi = parsed_hi;                            // exclusive
-        if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
-        else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
+        if (!pin || !unpin || used < ((size_t)32 << 20)) return;
+        for (size_t i = 0; i < pins.size(); ++i)
+            if (pins[i].p == p) { if (pins[i].n >= used) return; unpin(p); pins.erase(pins.begin() + (std::ptrdiff_t)i); break; }
+        if (pin(p, cap)) pins.push_back({p, cap});
+    }
+    // symbol buffers of the provider, taken in turn (a buffer is free again when no chunk holds it; fresh memory costs a page
+    // fault per 4 KiB, more than the parse itself)
+    std::vector<std::shared_ptr<SymVec>> sym_pool;
+    std::shared_ptr<SymVec> take_symvec()
+    {
+        for (auto &p : sym_pool) if (p.use_count() == 1) return p;
+        sym_pool.push_back(std::make_shared<SymVec>());
+        return sym_pool.back();
+    }
+
+    // stage A: parses the chunks [parsed_hi, c_hi) of `work` into `chunks`
+    bool parse_round(bool final, uint64_t c_hi, std::vector<Chunk> &chunks, RoundInfo &info)
+    {
         if (c_hi <= parsed_hi) { chunks.clear(); return true; }
         const size_t nc = (size_t)(c_hi - parsed_hi);
         chunks.assign(nc, Chunk());
@@ -572,16 +626,16 @@ struct Stream::Impl {
                 const Chunk &c = chunks[k];
                 if (final && c.tail_end == total) continue;
                 const uint64_t dl = c.start < 32768 ? c.start : 32768;
-                if (c.start - dl < base) continue;                   // (cannot happen: the buffer keeps 32 KiB before the first chunk)
-                tri.push_back(c.start - base); tri.push_back(c.tail_end - base); tri.push_back(c.start - dl - base);
+                if (c.start - dl < work_base) continue;                   // (cannot happen: the buffer keeps 32 KiB before the first chunk)
+                tri.push_back(c.start - work_base); tri.push_back(c.tail_end - work_base); tri.push_back(c.start - dl - work_base);
                 which.push_back(k);
             }
-            SymVec sy; std::vector<uint64_t> off;
-            if (!which.empty() && parse(buf.data(), buf.size(), tri.data(), which.size(), sy, off) && off.size() == which.size() + 1) {
+            std::shared_ptr<SymVec> sy = take_symvec(); std::vector<uint64_t> off;
+            if (!which.empty() && parse(work.data(), work.size(), tri.data(), which.size(), *sy, off) && off.size() == which.size() + 1 && off.back() <= sy->size()) {
                 parallel_for(threads, which.size(), [&](size_t j) {
                     Chunk &c = chunks[which[j]];
-                    c.syms.assign(sy.begin() + (std::ptrdiff_t)off[j], sy.begin() + (std::ptrdiff_t)off[j + 1]);
-                    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + (c.start - base), (uInt)(c.end - c.start));
+                    c.syms.p = sy->data() + off[j]; c.syms.n = (size_t)(off[j + 1] - off[j]); c.hold = sy;
+                    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), work.data() + (c.start - work_base), (uInt)(c.end - c.start));
                     c.ok = true;
                 });
                 provided = which.size();
@@ -590,7 +644,7 @@ struct Stream::Impl {
         {
             std::vector<size_t> todo;
             for (size_t k = zero_; k < nc; ++k) if (!chunks[k].ok) todo.push_back(k);
-            parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(buf.data(), base, chunks[todo[j]]); });
+            parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(work.data(), work_base, chunks[todo[j]]); });
         }
         info.parse_s = now_s() - tp0; info.provided = provided;
         parsed_hi = c_hi;
@@ -656,7 +710,7 @@ struct Stream::Impl {
         for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
         // the chain of hand-overs: chunk k's symbols start at the previous hand-over
         std::vector<uint64_t> from(n_eff, 0);
-        { uint64_t p = pos; for (size_t k = 0; k < n_eff; ++k) { from[k] = p; if (stop[k] <= p && !(stop[k] == p && p == total)) return false; p = stop[k]; } }
+        { uint64_t p = pos; for (size_t k = 0; k < n_eff; ++k) { from[k] = p; if (stop[k] <= p && !(final && stop[k] == p && p == total)) return false; p = stop[k]; } }
         parallel_for(threads, n_eff, [&](size_t k) {
             const Chunk &a = chunks[k];
             uint64_t qa = a.start;
@@ -666,7 +720,7 @@ struct Stream::Impl {
             i_first[k] = i;
         });
         for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
-        SymVec syms;
+        SymVec &syms = stitched;
         {
             std::vector<size_t> at(n_eff + 1, pending.size());
             for (size_t k = 0; k < n_eff; ++k) at[k + 1] = at[k] + (i_stop[k] - i_first[k]);
@@ -677,7 +731,16 @@ struct Stream::Impl {
                 if (i_stop[k] > i_first[k]) memcpy(syms.data() + at[k], chunks[k].syms.data() + i_first[k], (i_stop[k] - i_first[k]) * sizeof(Sym));
             });
         }
-        for (size_t k = 0; k < (final ? nc : n_stitch); ++k) crc = (uint32_t)crc32_combine(crc, chunks[k].crc, (z_off_t)(chunks[k].end - chunks[k].start));
+        // CRC-32 of the concatenation: crc(A B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P.  Nearly all chunks have one length, so the
+        // power is computed once per length (zlib 1.2.11's crc32_combine squares a 32 x 32 matrix per call: 10 us x thousands of chunks)
+        {
+            uint64_t op_len = ~0ull; uint32_t op = 0;
+            for (size_t k = 0; k < (final ? nc : n_stitch); ++k) {
+                const uint64_t len = chunks[k].end - chunks[k].start;
+                if (len != op_len) { op = crc_shift_op(len); op_len = len; }
+                crc = crc_mulmod(op, crc) ^ chunks[k].crc;
+            }
+        }
         if (n_eff) pos = stop[n_eff - 1];
         if (final && pos != total) return false;
         if (!final && nc) { carry = std::move(chunks[nc - 1]); have_carry = true; }
@@ -714,33 +777,59 @@ struct Stream::Impl {
         return true;
     }
 
+    SymVec stitched;                                          // a round's stitched symbols (kept: see sym_pool)
     std::vector<Chunk> waiting; RoundInfo waiting_info;       // a parsed round whose stage B has not run yet
     bool have_waiting = false;
+    std::thread worker; bool worker_on = false, worker_ok = true;
 
-    // everything that can be decided with the text seen so far (all of it when final)
-    bool run(bool final)
+    // one round: stage A of the text in `work` while stage B of the round before runs
+    bool round_body(bool final, uint64_t c_hi)
     {
         std::vector<Chunk> fresh; RoundInfo fresh_info;
         bool a_ok = true, b_ok = true;
-        std::thread ta([&] { a_ok = parse_round(final, fresh, fresh_info); });
+        std::thread ta([&] { a_ok = parse_round(final, c_hi, fresh, fresh_info); });
         if (have_waiting) { b_ok = emit_round(waiting, false, waiting_info); have_waiting = false; }
         ta.join();
         if (!a_ok || !b_ok) return false;
         if (final) return emit_round(fresh, true, fresh_info);
         if (!fresh.empty()) { waiting = std::move(fresh); waiting_info = fresh_info; have_waiting = true; }
-        // forget the text nobody needs any more: everything before the dictionary of the next chunk to parse (stage B needs none)
-        const uint64_t keep = parsed_hi * CH > 32768 ? parsed_hi * CH - 32768 : 0;
-        if (keep > base) { buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)(keep - base)); base = keep; }
         return true;
     }
+    bool join_worker() { if (worker_on) { worker.join(); worker_on = false; } return worker_ok; }
+
+    // everything that can be decided with the text seen so far (all of it when final).  Not final: the round runs on a worker
+    // thread behind the caller, who goes on writing; a failure is reported by the next call.
+    bool run(bool final, size_t room)
+    {
+        if (!join_worker()) return false;
+        const uint64_t avail = base + buf.size();            // == total
+        uint64_t c_hi = parsed_hi;                            // exclusive
+        if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
+        else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
+        if (!final && c_hi <= parsed_hi) return true;
+        if (work.capacity() < room) work.reserve(room);      // (first round: both buffers get their final size before any is locked)
+        work.swap(buf); work_base = base;
+        if (final) { buf.clear(); return round_body(true, c_hi); }
+        if (parse) ensure_pinned(work.data(), work.size(), work.capacity());
+        // the writer keeps what the next round needs: everything from the dictionary of the next chunk to parse
+        const uint64_t keep = std::max<uint64_t>(work_base, c_hi * CH > 32768 ? c_hi * CH - 32768 : 0);
+        buf.clear();
+        if (buf.capacity() < room) buf.reserve(room);
+        buf.insert(buf.end(), work.begin() + (std::ptrdiff_t)(keep - work_base), work.end());
+        base = keep;
+        worker_ok = true; worker_on = true;
+        worker = std::thread([this, c_hi] { worker_ok = round_body(false, c_hi); });
+        return true;
+    }
+    ~Impl() { if (worker_on) worker.join(); for (auto &x : pins) unpin(x.p); }
 };
 
 Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p) : p_(new Impl)
 {
     p_->threads = threads < 1 ? 1 : threads;
     p_->sink = std::move(sink);
-    p_->parse = p.parse;
-    p_->CH = p.chunk < 65536 ? 65536 : p.chunk;
+    p_->parse = p.parse; p_->pin = p.pin; p_->unpin = p.unpin;
+    p_->CH = p.chunk < 16384 ? 16384 : p.chunk;
     p_->TAIL = p.tail < 2048 ? 2048 : p.tail;
     if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
     if (p.batch) p_->batch_bytes = p.batch;
@@ -752,12 +841,13 @@ bool Stream::write(const void *data, size_t n)
     if (p_->failed || p_->finished) return false;
     const uint8_t *q = (const uint8_t *)data;
     const size_t limit = (size_t)(p_->batch_bytes + 2 * p_->CH + p_->TAIL);
+    if (p_->buf.capacity() < limit + (size_t)p_->CH) p_->buf.reserve(limit + (size_t)p_->CH);   // (address space; pages come as the text does)
     while (n) {
         const size_t have = p_->buf.size();
         const size_t k = std::min(n, have < limit ? limit - have : (size_t)p_->CH);
         p_->buf.insert(p_->buf.end(), q, q + k);
         p_->total += k; q += k; n -= k;
-        if (p_->buf.size() >= limit && !p_->run(false)) { p_->failed = true; return false; }
+        if (p_->buf.size() >= limit && !p_->run(false, limit + (size_t)p_->CH)) { p_->failed = true; return false; }
     }
     return true;
 }
@@ -766,8 +856,20 @@ bool Stream::finish()
 {
     if (p_->failed || p_->finished) return false;
     p_->finished = true;
-    if (!p_->run(true)) { p_->failed = true; return false; }
+    if (!p_->run(true, 0)) { p_->failed = true; return false; }
     return true;
+}
+
+Params Params::for_device(ParseFn fn)
+{
+    Params p;
+    p.chunk = (size_t)1 << 16; p.tail = (size_t)1 << 13; p.batch = (size_t)192 << 20;
+    // (measurement knobs: the geometry in KiB / KiB / MiB)
+    if (const char *e = getenv("PGZ_DEV_CHUNK_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 16 && v <= 4096) p.chunk = v << 10; }
+    if (const char *e = getenv("PGZ_DEV_TAIL_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 2 && (v << 10) < p.chunk) p.tail = v << 10; }
+    if (const char *e = getenv("PGZ_DEV_BATCH_MB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 2048) p.batch = v << 20; }
+    p.parse = std::move(fn);
+    return p;
 }
 
 ParseFn host_emulation_parse()
@@ -776,7 +878,7 @@ ParseFn host_emulation_parse()
         if (n < 3) return false;
         // positions sorted by (hash, position): a stable counting sort (the device does this with a radix sort)
         std::vector<uint8_t> padded(text, text + n);
-        padded.resize(n + 16, 0);
+        padded.resize(n + 32, 0);
         const size_t np = n - 2;
         std::vector<uint32_t> bucket((1u << pdz::HASH_BITS) + 1, 0), S(np), R(n + 1, 0);
         for (size_t p = 0; p < np; ++p) bucket[pdz::hash3(&padded[p]) + 1]++;
@@ -808,7 +910,7 @@ bool zlib_chunk_symbols(const uint8_t *data, size_t dict, size_t n, std::vector<
     if (dict > 32768) { data += dict - 32768; c.start = 32768; c.end = c.tail_end = 32768 + n; }
     run_chunk(data, 0, c);
     if (!c.ok) return false;
-    syms.swap(c.syms);
+    syms.swap(c.own);
     return true;
 }
 

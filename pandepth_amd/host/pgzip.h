@@ -43,8 +43,12 @@ struct Params {
     size_t tail = (size_t)1 << 16;       // overlap in which neighbouring parses must meet
     size_t batch = 0;                    // text buffered between rounds (0 = 96 MiB)
     ParseFn parse;                       // optional stage-1 provider; a stream's last chunk always goes to zlib (it sees the end of the input)
+    // optional, with a provider that copies the text elsewhere: page-lock / release a text buffer of the stream (two buffers of
+    // batch + 3 chunks each, never reallocated while locked; pin returns false if it could not)
+    std::function<bool(void *, size_t)> pin;
+    std::function<void(void *)> unpin;
     // the geometry that suits a provider with one wave per chunk: many small chunks, rounds large enough to fill the device
-    static Params for_device(ParseFn fn) { Params p; p.chunk = (size_t)1 << 16; p.tail = (size_t)1 << 13; p.batch = (size_t)192 << 20; p.parse = std::move(fn); return p; }
+    static Params for_device(ParseFn fn);
 };
 
 // the host emulation of the engine's parse (csrc/pd_lz77.h, 64 lanes in a loop) as a provider: tests of the plumbing without a GPU

@@ -752,10 +752,17 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
     if (!fp) { std::cerr << "open OUT File error: " << path << std::endl; return -1; }
     bool io_ok = true;
     int rc = 1;
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto t_leave = t_enter;
     {
         const pgz::ParseFn dev_parse = engine_parse(eng);
-        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; },
-                       dev_parse ? pgz::Params::for_device(dev_parse) : pgz::Params());
+        pgz::Params prm = dev_parse ? pgz::Params::for_device(dev_parse) : pgz::Params();
+        if (dev_parse && eng->api->host_register && eng->api->host_unregister) {
+            // the stream's two text buffers are handed to pd_deflate_parse round after round: page-locked, the copy runs at the link's rate
+            prm.pin = [eng](void *p, size_t n) { return eng->api->host_register(eng->ctx, p, n) == 0; };
+            prm.unpin = [eng](void *p) { (void)eng->api->host_unregister(eng->ctx, p); };
+        }
+        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; }, prm);
         // producer: read-back + formatting of the next blocks (a quarter of the threads) while the consumer deflates
         const size_t CH = (size_t)4 << 20;
         const int nt = std::max(1, threads / 4);
@@ -848,8 +855,14 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
             fprintf(stderr, "[timing]   per-site writer: producer formatting %.3f s + waiting for room %.3f s; consumer waiting for text %.3f s, "
                             "in the stream (copy + deflate rounds) %.3f s, finishing %.3f s\n", t_format, t_prod_wait, t_cons_wait, t_write,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - tfin).count());
+        t_leave = std::chrono::steady_clock::now();
     }
+    const auto t_torn = std::chrono::steady_clock::now();
     if (fclose(fp) != 0 && rc == 1) rc = -1;
+    if (getenv("PANDEPTH_TIMING"))
+        fprintf(stderr, "[timing]   per-site writer: %.3f s in all; releasing the stream's buffers %.3f s, closing the file %.3f s\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count(), std::chrono::duration<double>(t_torn - t_leave).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_torn).count());
     return rc;
 }
 

@@ -29,7 +29,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t> text = slurp(argv[1]);
     const size_t CH = argc > 2 ? (size_t)atoll(argv[2]) : (size_t)1 << 18, TAIL = argc > 3 ? (size_t)atoll(argv[3]) : (size_t)1 << 14;
     const size_t N = text.size();
-    text.resize(N + 16, 0);
+    text.resize(N + 32, 0);
     // positions sorted by (hash, position): a stable counting sort
     const size_t NP = N >= 3 ? N - 2 : 0;
     std::vector<uint32_t> bucket((1u << pdz::HASH_BITS) + 1, 0), S(NP ? NP : 1), R(N + 1, 0);
