@@ -115,7 +115,8 @@ struct pd_ctx {
     uint32_t lmax = LMAX_DEFAULT, sample = SAMPLE_DEFAULT;
     unsigned grid_tiles = 0;                         // 0 = sized per pass from the number of runs
     int stile = 8192; int n_cu = 256;
-    // pd_deflate_parse's work buffers (device memory, grown on demand, kept until pd_destroy)
+    // pd_deflate_parse's work buffers (device memory, grown on demand, kept until pd_destroy): two slots, each with its stream, so that
+    // two calls overlap (one's copies under the other's kernels)
     struct LzWork {
         static constexpr int N = 13;
         void *p[N] = {}; size_t cap[N] = {};
@@ -128,8 +129,11 @@ struct pd_ctx {
             cap[k] = want;
             return true;
         }
-        void release() { for (int k = 0; k < N; ++k) { if (p[k]) (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; } }
-    } lz;
+        void release() { for (int k = 0; k < N; ++k) { if (p[k]) (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; } if (st) { (void)hipStreamDestroy(st); st = nullptr; } }
+        hipStream_t st = nullptr;
+        std::mutex mu;
+    } lz[2];
+    std::atomic<unsigned> lz_turn{0};
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -499,8 +503,6 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 static void runs_free(pd_runs *r);
 static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out);
 
-std::mutex g_lz_mu;                      // pd_deflate_parse calls run one at a time (they share a stream)
-
 int pd_destroy(pd_ctx *c)
 {
     if (!c) return PD_OK;
@@ -534,7 +536,7 @@ int pd_destroy(pd_ctx *c)
     }
     for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
     runs_free(c->dec_runs);
-    { std::lock_guard<std::mutex> g(g_lz_mu); c->lz.release(); }
+    for (auto &w : c->lz) { std::lock_guard<std::mutex> g(w.mu); w.release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -1728,8 +1730,9 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     if (!c || !text || !chunks || !syms || !sym_off) return PD_EINVAL;
     // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
     // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
-    // waiting for the 0.07 s a round's parse takes.  Calls of several threads are serialised among themselves.
-    std::lock_guard<std::mutex> lz_lock(g_lz_mu);
+    // waiting for the time a round's parse takes.  Two calls run at a time, each in its own slot (buffers + stream).
+    pd_ctx::LzWork &w = c->lz[c->lz_turn.fetch_add(1) & 1u];
+    std::lock_guard<std::mutex> lz_lock(w.mu);
     auto fail = [&](pd_ctx *cc, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(cc->mu); cc->err = msg; return code; };
     if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");
     uint64_t stride = 0;
@@ -1743,9 +1746,7 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     if (!n_chunks) return PD_OK;
     stride += 8;
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, PD_EHIP, "pd_deflate_parse: hipSetDevice failed");
-    static hipStream_t lz_stream = nullptr; static int lz_dev = -1;
-    if (lz_stream && lz_dev != c->device) { (void)hipStreamDestroy(lz_stream); lz_stream = nullptr; }
-    if (!lz_stream) { if (hipStreamCreateWithFlags(&lz_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, PD_EHIP, "pd_deflate_parse: stream creation failed"); lz_dev = c->device; }
+    if (!w.st && hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking) != hipSuccess) { w.st = nullptr; return fail(c, PD_EHIP, "pd_deflate_parse: stream creation failed"); }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool prof = c->prof;
     if (prof) for (auto &e : ev) (void)hipEventCreate(&e);
@@ -1757,7 +1758,6 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     const uint32_t n_blocks = (np + 2047) / 2048;
     // work buffers: kept from call to call (a round of 200 MB of text needs 5 GB of them; allocating and freeing them costs more
     // than the kernels), grown on demand, released by pd_destroy of the context that made them
-    pd_ctx::LzWork &w = c->lz;
     const size_t nh = (size_t)256 * n_blocks + 16;
     const size_t want[pd_ctx::LzWork::N] = {n_text + 64, (size_t)np * 8 + 64, (size_t)np * 8 + 64, nh * 4, (nh / 1024 + 8) * 4, (size_t)np * 4 + 64, (size_t)n_text * 4 + 64,
                                     ((size_t)32768 + 8) * 4, (size_t)n_chunks * 24, ((size_t)n_chunks + 1) * 8, (size_t)n_chunks * stride * 4, (size_t)n_chunks * 4 + 16, 0};
@@ -1768,7 +1768,7 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     uint64_t *d_chunks = (uint64_t *)w.p[8], *d_off = (uint64_t *)w.p[9]; uint32_t *d_syms = (uint32_t *)w.p[10], *d_cnt = (uint32_t *)w.p[11];
     auto cleanup = [&]() { for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } };
     tick();
-    hipStream_t st = lz_stream;
+    hipStream_t st = w.st;
     std::vector<uint32_t> counts(n_chunks);
     hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);

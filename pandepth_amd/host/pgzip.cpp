@@ -630,15 +630,36 @@ struct Stream::Impl {
                 tri.push_back(c.start - work_base); tri.push_back(c.tail_end - work_base); tri.push_back(c.start - dl - work_base);
                 which.push_back(k);
             }
-            std::shared_ptr<SymVec> sy = take_symvec(); std::vector<uint64_t> off;
-            if (!which.empty() && parse(work.data(), work.size(), tri.data(), which.size(), *sy, off) && off.size() == which.size() + 1 && off.back() <= sy->size()) {
-                parallel_for(threads, which.size(), [&](size_t j) {
-                    Chunk &c = chunks[which[j]];
-                    c.syms.p = sy->data() + off[j]; c.syms.n = (size_t)(off[j + 1] - off[j]); c.hold = sy;
+            // two calls at a time (each on its half of the chunks and the text they cover): a provider that copies the text elsewhere
+            // moves one half while it parses the other
+            struct Group { size_t lo = 0, hi = 0; std::shared_ptr<SymVec> sy; std::vector<uint64_t> off; bool ok = false; };
+            const size_t n_groups = which.size() >= 512 ? 2 : 1;
+            Group grp[2];
+            for (size_t g = 0; g < n_groups; ++g) { grp[g].lo = which.size() * g / n_groups; grp[g].hi = which.size() * (g + 1) / n_groups; grp[g].sy = take_symvec(); }
+            auto call = [&](Group &G) {
+                if (G.hi <= G.lo) return;
+                const uint64_t t_lo = tri[3 * G.lo + 2], t_hi = tri[3 * (G.hi - 1) + 1];       // first origin .. last tail end
+                std::vector<uint64_t> local(tri.begin() + (std::ptrdiff_t)(3 * G.lo), tri.begin() + (std::ptrdiff_t)(3 * G.hi));
+                for (auto &x : local) x -= t_lo;
+                G.ok = parse(work.data() + t_lo, (size_t)(t_hi - t_lo), local.data(), G.hi - G.lo, *G.sy, G.off) && G.off.size() == G.hi - G.lo + 1 &&
+                       G.off.back() <= G.sy->size();
+            };
+            {
+                std::thread second;
+                if (n_groups > 1) second = std::thread([&] { call(grp[1]); });
+                call(grp[0]);
+                if (second.joinable()) second.join();
+            }
+            for (size_t g = 0; g < n_groups; ++g) {
+                Group &G = grp[g];
+                if (!G.ok) continue;
+                parallel_for(threads, G.hi - G.lo, [&](size_t j) {
+                    Chunk &c = chunks[which[G.lo + j]];
+                    c.syms.p = G.sy->data() + G.off[j]; c.syms.n = (size_t)(G.off[j + 1] - G.off[j]); c.hold = G.sy;
                     c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), work.data() + (c.start - work_base), (uInt)(c.end - c.start));
                     c.ok = true;
                 });
-                provided = which.size();
+                provided += G.hi - G.lo;
             }
         }
         {

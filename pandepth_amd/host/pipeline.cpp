@@ -762,7 +762,8 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
             prm.pin = [eng](void *p, size_t n) { return eng->api->host_register(eng->ctx, p, n) == 0; };
             prm.unpin = [eng](void *p) { (void)eng->api->host_unregister(eng->ctx, p); };
         }
-        pgz::Stream st(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; }, prm);
+        std::unique_ptr<pgz::Stream> st_own(new pgz::Stream(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; }, prm));
+        pgz::Stream &st = *st_own;
         // producer: read-back + formatting of the next blocks (a quarter of the threads) while the consumer deflates
         const size_t CH = (size_t)4 << 20;
         const int nt = std::max(1, threads / 4);
@@ -856,6 +857,8 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                             "in the stream (copy + deflate rounds) %.3f s, finishing %.3f s\n", t_format, t_prod_wait, t_cons_wait, t_write,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - tfin).count());
         t_leave = std::chrono::steady_clock::now();
+        // (the process is about to end, main.cpp: returning 0.7 GB of buffers page by page would only delay that)
+        if (getenv("PANDEPTH_KEEP_CONTEXT")) (void)st_own.release();
     }
     const auto t_torn = std::chrono::steady_clock::now();
     if (fclose(fp) != 0 && rc == 1) rc = -1;
@@ -1217,11 +1220,24 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         return eng.ck(rc, "window reduction");
     };
 
+    // The per-site file is written behind the statistics and the tables: both read the same depth cells, the engine serialises
+    // its entry points, and the file's gzip stream keeps the host threads busy only part of the time.
+    struct SiteJob {
+        std::thread th; bool ok = true;
+        void wait() { if (th.joinable()) th.join(); }
+        ~SiteJob() { wait(); }
+    } site_job;
     if (o.site_out) {
         if (!need_scan()) return bail();
-        if (!write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng, o.threads)) { if (!eng.ok()) return bail(); }
-        tm.mark("per-site file");
+        site_job.th = std::thread([&] { site_job.ok = write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng, o.threads); });
+        if (getenv("PANDEPTH_SITE_OVERLAP") && getenv("PANDEPTH_SITE_OVERLAP")[0] == '0') { site_job.wait(); tm.mark("per-site file"); }
     }
+    auto site_done = [&]() -> bool {
+        const bool was_running = site_job.th.joinable();
+        site_job.wait();
+        if (was_running) tm.mark("per-site file (the rest of it)");
+        return site_job.ok || eng.ok();
+    };
 
     const size_t nctg = hdr.lens.size();
     uint64_t SL = 0, SC = 0, SD = 0, SG = 0;
@@ -1270,6 +1286,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         tm.mark("scan + statistics + table text");
         OUT.close();
         tm.mark("table gzip");
+        if (!site_done()) return bail();
         std::cout << "INFO: Input data read done" << std::endl;
         return 0;
     }
@@ -1399,5 +1416,6 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     tm.mark("table text");
     OUT.close();
     tm.mark("table gzip");
+    if (!site_done()) return bail();
     return 0;
 }
