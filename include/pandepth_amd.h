@@ -184,6 +184,25 @@ int pd_format_sites(pd_ctx *ctx, int32_t tid, uint32_t beg, size_t n, const char
 typedef struct pd_lz_chunk { uint64_t start, end, origin; } pd_lz_chunk;
 int pd_deflate_parse(pd_ctx *ctx, const void *text, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
                      uint32_t *syms, size_t syms_cap, uint64_t *sym_off);
+/* The per-site file without its text ever leaving HBM (PD:4264-4284 written through gzstream): a text stream that lives on the
+ * device.  pd_text_append_sites formats the rows of cells [beg, beg + n) of contig tid (as pd_format_sites does) at the end of the
+ * stream; pd_text_parse is pd_deflate_parse on the stretch [off, off + n_text) of the stream (chunk positions relative to `off`), and
+ * also returns the CRC-32 of the first crc_span bytes of every chunk, [start, min(start + crc_span, end)) — the chunk's own bytes, without
+ * the overlap into its successor (crc: n_chunks entries, may be NULL) — with the symbols and the
+ * CRCs the host has all that stage 2 of the gzip stream needs; pd_text_read copies a stretch to the host (the stream's last chunk,
+ * which zlib parses itself because it sees the end of the input); pd_text_release tells the stream that nothing before `off` will
+ * be asked for again.  The stream is a ring of `capacity` bytes: an append that finds no room returns PD_ERANGE and can be
+ * repeated after a release.  Appends and parses may come from different threads.  What crosses PCIe: 4 bytes per symbol, about
+ * 0.6 bytes per byte of text, instead of the text twice. */
+typedef struct pd_text pd_text;
+int pd_text_open(pd_ctx *ctx, size_t capacity, pd_text **out);
+int pd_text_close(pd_text *t);
+int pd_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, uint64_t *n_bytes);
+int pd_text_parse(pd_text *t, uint64_t off, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
+                  uint32_t *syms, size_t syms_cap, uint64_t *sym_off, uint32_t *crc, uint64_t crc_span);
+int pd_text_read(pd_text *t, uint64_t off, size_t n, void *out);
+int pd_text_release(pd_text *t, uint64_t off);
+
 /* Optional: page-locks a host buffer the caller owns (text handed to pd_deflate_parse round after round, blobs for the decoder),
  * so that copies from it run at the link's rate (57 GB/s against 20-33 GB/s from pageable memory on the measured host).
  * The caller unregisters before freeing or reallocating the buffer.  Registering costs about 35 us per MB. */

@@ -71,6 +71,12 @@ def load():
         "pd_deflate_parse": (I, [P, P, SZ, P, ctypes.c_uint32, P, SZ, P]),
         "pd_host_register": (I, [P, P, SZ]),
         "pd_host_unregister": (I, [P, P]),
+        "pd_text_open": (I, [P, SZ, ctypes.POINTER(P)]),
+        "pd_text_close": (I, [P]),
+        "pd_text_append_sites": (I, [P, ctypes.c_int32, ctypes.c_uint32, SZ, ctypes.c_char_p, SZ, ctypes.POINTER(ctypes.c_uint64)]),
+        "pd_text_parse": (I, [P, ctypes.c_uint64, SZ, P, ctypes.c_uint32, P, SZ, P, P, ctypes.c_uint64]),
+        "pd_text_read": (I, [P, ctypes.c_uint64, SZ, P]),
+        "pd_text_release": (I, [P, ctypes.c_uint64]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
         "pd_device_count": (I, [ctypes.POINTER(I)]),
         "pd_accumulate_from": (I, [P, P]),
@@ -108,7 +114,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
+           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
@@ -338,6 +344,10 @@ class Engine:
         self._ck(self.L.pd_format_sites(self.h, int(tid), int(beg), int(n), nm, len(nm), _ptr(buf), buf.size, ctypes.byref(got)))
         return buf[:got.value].tobytes()
 
+    def text_open(self, capacity):
+        """A device-resident text stream (pd_text_*): see TextStream."""
+        return TextStream(self, capacity)
+
     def device_layout(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
         self._ck(self.L.pd_device_layout(self.h, ctypes.byref(a), ctypes.byref(b)))
@@ -402,3 +412,48 @@ class Engine:
         n = ctypes.c_uint64()
         self._ck(self.L.pd_profile_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
+
+
+class TextStream:
+    """pd_text_*: per-site rows formatted at the end of a stream that lives in HBM, parsed (zlib's LZ77 parse) and check-summed
+    there; `append_sites` returns the bytes added (PdError(-6) when the ring has no room), `parse` a list of symbol arrays and the
+    chunks' CRCs, `read` a stretch of the text."""
+
+    def __init__(self, eng, capacity):
+        self.e = eng
+        self.h = ctypes.c_void_p()
+        eng._ck(eng.L.pd_text_open(eng.h, int(capacity), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.e.L.pd_text_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def append_sites(self, tid, beg, n, name):
+        nm = name.encode() if isinstance(name, str) else bytes(name)
+        got = ctypes.c_uint64()
+        self.e._ck(self.e.L.pd_text_append_sites(self.h, int(tid), int(beg), int(n), nm, len(nm), ctypes.byref(got)))
+        return int(got.value)
+
+    def parse(self, off, n, chunks, crc_span):
+        ch = np.ascontiguousarray(np.asarray(chunks, dtype=np.uint64).reshape(-1, 3))
+        cap = int(sum(int(e - s) for s, e, _ in ch.tolist())) + 16
+        syms = np.zeros(cap, dtype=np.uint32)
+        soff = np.zeros(ch.shape[0] + 1, dtype=np.uint64)
+        crc = np.zeros(max(1, ch.shape[0]), dtype=np.uint32)
+        self.e._ck(self.e.L.pd_text_parse(self.h, int(off), int(n), _ptr(ch), ch.shape[0], _ptr(syms), cap, _ptr(soff), _ptr(crc), int(crc_span)))
+        return [syms[int(soff[k]):int(soff[k + 1])] for k in range(ch.shape[0])], crc[:ch.shape[0]]
+
+    def read(self, off, n):
+        buf = np.empty(max(1, int(n)), dtype=np.uint8)
+        self.e._ck(self.e.L.pd_text_read(self.h, int(off), int(n), _ptr(buf)))
+        return buf[:int(n)].tobytes()
+
+    def release(self, off):
+        self.e._ck(self.e.L.pd_text_release(self.h, int(off)))

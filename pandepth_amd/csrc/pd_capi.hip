@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <chrono>
 
 using namespace pdk;
@@ -118,7 +119,7 @@ struct pd_ctx {
     // pd_deflate_parse's work buffers (device memory, grown on demand, kept until pd_destroy): two slots, each with its stream, so that
     // two calls overlap (one's copies under the other's kernels)
     struct LzWork {
-        static constexpr int N = 13;
+        static constexpr int N = 14;
         void *p[N] = {}; size_t cap[N] = {};
         bool fit(int k, size_t bytes)
         {
@@ -1724,10 +1725,22 @@ int pd_gather_windows(pd_ctx *c, const void *dev_partials, uint32_t w, uint32_t 
 
 // zlib's level-6 LZ77 parse of a host text on the device (pd_deflate.hip / pd_lz77.h): positions sorted by (hash, position),
 // one wave per chunk, the symbols gathered and copied back.  Buffers live for the call.
-int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
-                     uint32_t *syms, size_t syms_cap, uint64_t *sym_off)
+// A text stream that lives in HBM (include/pandepth_amd.h: pd_text_*): a ring of segments, each one append's bytes, contiguous.
+struct pd_text {
+    pd_ctx *ctx = nullptr;
+    uint8_t *ring = nullptr; size_t cap = 0;
+    struct Seg { uint64_t off; size_t phys, len; };
+    std::deque<Seg> segs;
+    uint64_t tail_off = 0; size_t phys_tail = 0;
+    void *scratch = nullptr; size_t scratch_bytes = 0;         // name | block counts | block offsets of an append
+    std::mutex mu;
+};
+
+// The parse of pd_deflate_parse / pd_text_parse: the text comes from the host (`text`) or from a device stream (`tx`, bytes
+// [tx_off, tx_off + n_text)); crc_out (optional): CRC-32 of every chunk's first crc_span bytes.
+static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
+                  uint32_t *syms, size_t syms_cap, uint64_t *sym_off, uint32_t *crc_out, uint64_t crc_span)
 {
-    if (!c || !text || !chunks || !syms || !sym_off) return PD_EINVAL;
     // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
     // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
     // waiting for the time a round's parse takes.  Two calls run at a time, each in its own slot (buffers + stream).
@@ -1760,18 +1773,30 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     // than the kernels), grown on demand, released by pd_destroy of the context that made them
     const size_t nh = (size_t)256 * n_blocks + 16;
     const size_t want[pd_ctx::LzWork::N] = {n_text + 64, (size_t)np * 8 + 64, (size_t)np * 8 + 64, nh * 4, (nh / 1024 + 8) * 4, (size_t)np * 4 + 64, (size_t)n_text * 4 + 64,
-                                    ((size_t)32768 + 8) * 4, (size_t)n_chunks * 24, ((size_t)n_chunks + 1) * 8, (size_t)n_chunks * stride * 4, (size_t)n_chunks * 4 + 16, 0};
+                                    ((size_t)32768 + 8) * 4, (size_t)n_chunks * 24, ((size_t)n_chunks + 1) * 8, (size_t)n_chunks * stride * 4, (size_t)n_chunks * 4 + 16, 0,
+                                    (size_t)n_chunks * 4 + 16};
     for (int k = 0; k < pd_ctx::LzWork::N; ++k)
         if (!w.fit(k, want[k])) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
     uint8_t *d_text = (uint8_t *)w.p[0]; uint64_t *ka = (uint64_t *)w.p[1], *kb = (uint64_t *)w.p[2];
     uint32_t *hist = (uint32_t *)w.p[3], *scan_tmp = (uint32_t *)w.p[4], *S = (uint32_t *)w.p[5], *R = (uint32_t *)w.p[6], *bucket = (uint32_t *)w.p[7];
-    uint64_t *d_chunks = (uint64_t *)w.p[8], *d_off = (uint64_t *)w.p[9]; uint32_t *d_syms = (uint32_t *)w.p[10], *d_cnt = (uint32_t *)w.p[11];
+    uint64_t *d_chunks = (uint64_t *)w.p[8], *d_off = (uint64_t *)w.p[9]; uint32_t *d_syms = (uint32_t *)w.p[10], *d_cnt = (uint32_t *)w.p[11], *d_crc = (uint32_t *)w.p[13];
     auto cleanup = [&]() { for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } };
     tick();
     hipStream_t st = w.st;
     std::vector<uint32_t> counts(n_chunks);
     hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
+    if (tx) {
+        // the stretch, segment by segment (the segments stay where they are until the caller releases them)
+        std::lock_guard<std::mutex> tlk(tx->mu);
+        uint64_t got = 0;
+        for (const auto &sg : tx->segs) {
+            const uint64_t lo = std::max<uint64_t>(sg.off, tx_off), hi = std::min<uint64_t>(sg.off + sg.len, tx_off + n_text);
+            if (lo >= hi) continue;
+            if (e == hipSuccess) e = hipMemcpyAsync(d_text + (lo - tx_off), tx->ring + sg.phys + (lo - sg.off), (size_t)(hi - lo), hipMemcpyDeviceToDevice, st);
+            got += hi - lo;
+        }
+        if (got != n_text) { cleanup(); return fail(c, PD_EINVAL, "pd_text_parse: the stretch is not (or no longer) in the stream"); }
+    } else if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
     static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");
     if (dbg && e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1783,8 +1808,10 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
         if (dbg) { (void)hipStreamSynchronize(st); tick(); }
         launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt);
         if (prof) (void)hipEventRecord(ev[2], st);
+        if (crc_out) launch_lz_crc(st, d_text, d_chunks, n_chunks, crc_span, d_crc);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && crc_out) e = hipMemcpyAsync(crc_out, d_crc, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { cleanup(); return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e)); }
@@ -1818,6 +1845,139 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     }
     cleanup();
     if (e != hipSuccess) return fail(c, PD_EHIP, std::string("pd_deflate_parse: ") + hipGetErrorString(e));
+    return PD_OK;
+}
+
+int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
+                     uint32_t *syms, size_t syms_cap, uint64_t *sym_off)
+{
+    if (!c || !text || !chunks || !syms || !sym_off) return PD_EINVAL;
+    return lz_run(c, text, nullptr, 0, n_text, chunks, n_chunks, syms, syms_cap, sym_off, nullptr, 0);
+}
+
+// ---- a text stream in HBM: the per-site rows are formatted, parsed and check-summed where the cells are ----
+int pd_text_open(pd_ctx *c, size_t capacity, pd_text **out)
+{
+    if (!c || !out || capacity < ((size_t)1 << 20)) return PD_EINVAL;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    pd_text *t = new pd_text;
+    t->ctx = c; t->cap = capacity;
+    if (hipMalloc(&t->ring, capacity + 64) != hipSuccess) { (void)hipGetLastError(); delete t; return fail(c, PD_ENOMEM, "pd_text_open: device allocation failed"); }
+    *out = t;
+    return PD_OK;
+}
+
+int pd_text_close(pd_text *t)
+{
+    if (!t) return PD_OK;
+    pd_ctx *c = t->ctx;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        (void)hipSetDevice(c->device);
+        for (auto &w : c->lz) { std::lock_guard<std::mutex> g(w.mu); if (w.st) (void)hipStreamSynchronize(w.st); }
+        (void)hipStreamSynchronize(c->stream);
+        if (t->ring) (void)hipFree(t->ring);
+        if (t->scratch) (void)hipFree(t->scratch);
+    }
+    delete t;
+    return PD_OK;
+}
+
+int pd_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, uint64_t *n_bytes)
+{
+    if (!t || !n_bytes || (!name && name_len)) return PD_EINVAL;
+    *n_bytes = 0;
+    pd_ctx *c = t->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rs = need_state(c, 1, "pd_text_append_sites")) return rs;
+    if (tid < 0 || tid >= c->n_contigs) return fail(c, PD_EINVAL, "pd_text_append_sites: contig id out of range");
+    if ((uint64_t)beg + n > c->off[tid + 1] - c->off[tid]) return fail(c, PD_EINVAL, "pd_text_append_sites: range past the contig slot");
+    if (name_len > 4096 || n > ((size_t)1 << 27)) return fail(c, PD_EINVAL, "pd_text_append_sites: at most 2^27 cells per call and 4096 bytes of name");
+    if (n == 0) return PD_OK;
+    HIPOK(c, hipSetDevice(c->device));
+    const uint32_t nb = pdk::site_rows_blocks(n);
+    const size_t b_name = (name_len + 15) / 16 * 16 + 16, b_cnt = ((size_t)nb * 4 + 15) / 16 * 16, b_off = ((size_t)nb + 1) * 8;
+    if (t->scratch_bytes < b_name + b_cnt + b_off) {
+        if (t->scratch) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(t->scratch)); t->scratch = nullptr; t->scratch_bytes = 0; }
+        const size_t want = (b_name + b_cnt + b_off) * 2;
+        if (hipMalloc(&t->scratch, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_text_append_sites: device allocation failed"); }
+        t->scratch_bytes = want;
+    }
+    unsigned char *s = (unsigned char *)t->scratch;
+    char *d_name = (char *)s; uint32_t *d_cnt = (uint32_t *)(s + b_name); uint64_t *d_off = (uint64_t *)(s + b_name + b_cnt);
+    ProfScope ps(c, "format_sites");
+    if (name_len) HIPOK(c, hipMemcpyAsync(d_name, name, name_len, hipMemcpyHostToDevice, c->stream));
+    const uint32_t *depth = (const uint32_t *)(c->buf + c->off[tid] + beg);
+    // pass 1: the rows' lengths and where each workgroup's rows begin
+    pdk::launch_site_rows(c->stream, depth, beg, n, (uint32_t)name_len, d_name, d_cnt, d_off, nullptr, false);
+    uint64_t total = 0;
+    HIPOK(c, hipMemcpyAsync(&total, d_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    HIPOK(c, hipGetLastError());
+    // a place in the ring: behind the last segment, or at the ring's start once that end is free again
+    size_t phys = 0;
+    {
+        std::lock_guard<std::mutex> tlk(t->mu);
+        if (total > t->cap) return fail(c, PD_EINVAL, "pd_text_append_sites: the rows do not fit the stream's capacity");
+        if (t->segs.empty()) { t->phys_tail = 0; phys = 0; }
+        else {
+            const size_t head = t->segs.front().phys;
+            if (t->phys_tail >= head) {                        // live bytes in [head, tail)
+                if (t->phys_tail + total <= t->cap) phys = t->phys_tail;
+                else if (total < head) phys = 0;
+                else return fail(c, PD_ERANGE, "pd_text_append_sites: the stream is full (release what has been consumed)");
+            } else {                                           // wrapped: live bytes in [head, ...) and [0, tail)
+                if (t->phys_tail + total < head) phys = t->phys_tail;
+                else return fail(c, PD_ERANGE, "pd_text_append_sites: the stream is full (release what has been consumed)");
+            }
+        }
+    }
+    // pass 2: the bytes
+    pdk::launch_site_rows(c->stream, depth, beg, n, (uint32_t)name_len, d_name, d_cnt, d_off, (char *)t->ring + phys, true);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> tlk(t->mu);
+        t->segs.push_back(pd_text::Seg{t->tail_off, phys, (size_t)total});
+        t->tail_off += total; t->phys_tail = phys + (size_t)total;
+    }
+    *n_bytes = total;
+    return PD_OK;
+}
+
+int pd_text_parse(pd_text *t, uint64_t off, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t syms_cap,
+                  uint64_t *sym_off, uint32_t *crc, uint64_t crc_span)
+{
+    if (!t || !chunks || !syms || !sym_off) return PD_EINVAL;
+    return lz_run(t->ctx, nullptr, t, off, n_text, chunks, n_chunks, syms, syms_cap, sym_off, crc, crc_span);
+}
+
+int pd_text_read(pd_text *t, uint64_t off, size_t n, void *out)
+{
+    if (!t || (!out && n)) return PD_EINVAL;
+    pd_ctx *c = t->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    std::lock_guard<std::mutex> tlk(t->mu);
+    uint64_t got = 0;
+    for (const auto &sg : t->segs) {
+        const uint64_t lo = std::max<uint64_t>(sg.off, off), hi = std::min<uint64_t>(sg.off + sg.len, off + n);
+        if (lo >= hi) continue;
+        HIPOK(c, hipMemcpyAsync((uint8_t *)out + (lo - off), t->ring + sg.phys + (lo - sg.off), (size_t)(hi - lo), hipMemcpyDeviceToHost, c->stream));
+        got += hi - lo;
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (got != n) return fail(c, PD_EINVAL, "pd_text_read: the stretch is not (or no longer) in the stream");
+    return PD_OK;
+}
+
+int pd_text_release(pd_text *t, uint64_t off)
+{
+    if (!t) return PD_EINVAL;
+    std::lock_guard<std::mutex> tlk(t->mu);
+    while (!t->segs.empty() && t->segs.front().off + t->segs.front().len <= off) t->segs.pop_front();
     return PD_OK;
 }
 

@@ -125,6 +125,51 @@ __global__ __launch_bounds__(WGZ) void k_lz_gather(const uint32_t *syms, uint64_
     }
 }
 
+// ---- CRC-32 of every chunk's own bytes [start, min(start + span, end)): one wave per chunk.  A lane runs the byte-wise table loop over its 1/64 of the
+// chunk; the 64 pieces are then joined in GF(2)[x] mod P: crc(A B) = crc(A) x^(8 |B|) + crc(B) (what zlib's crc32_combine computes).
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+__device__ __forceinline__ uint32_t crc_shift_op(uint64_t len)             // x^(8 len) mod P
+{
+    uint32_t sq = 1u << 23, p = 1u << 31;
+    for (; len; len >>= 1) { if (len & 1) p = crc_mulmod(sq, p); sq = crc_mulmod(sq, sq); }
+    return p;
+}
+__global__ __launch_bounds__(WGZ) void k_lz_crc(const uint8_t *text, const uint64_t *chunks, uint32_t n_chunks, uint64_t span, uint32_t *crc)
+{
+    __shared__ uint32_t tab[256];
+    { uint32_t c = threadIdx.x; for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1; tab[threadIdx.x] = c; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t ch = blockIdx.x * (WGZ / 64) + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    const uint64_t start = chunks[3 * ch], end = chunks[3 * ch + 1] - start > span ? start + span : chunks[3 * ch + 1];
+    const uint64_t len = end - start, piece = (len + 63) / 64;
+    const uint64_t lo = start + (uint64_t)lane * piece < end ? start + (uint64_t)lane * piece : end;
+    const uint64_t hi = lo + piece < end ? lo + piece : end;
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint64_t i = lo; i < hi; ++i) c = tab[(c ^ text[i]) & 0xFFu] ^ (c >> 8);
+    c ^= 0xFFFFFFFFu;                                                      // (an empty piece: 0)
+    const uint32_t op_full = crc_shift_op(piece);
+    uint32_t acc = 0;
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t cl = (uint32_t)__shfl((int)c, l);
+        const uint64_t l_lo = start + (uint64_t)l * piece < end ? start + (uint64_t)l * piece : end;
+        const uint64_t l_len = (l_lo + piece < end ? l_lo + piece : end) - l_lo;
+        if (l_len == 0) break;
+        acc = crc_mulmod(l_len == piece ? op_full : crc_shift_op(l_len), acc) ^ cl;
+    }
+    if (lane == 0) crc[ch] = acc;
+}
+
 } // namespace
 
 // One text -> (S, R, bucket).  keys_a / keys_b: np 64-bit words each; hist: 256 * n_blocks + 1 words; scan_tmp: see launch_excl_scan_u32.
@@ -161,6 +206,12 @@ void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, con
 {
     if (!n_chunks) return;
     hipLaunchKernelGGL(k_lz_gather, dim3(64, n_chunks < 4096u ? n_chunks : 4096u), dim3(WGZ), 0, st, syms, stride, off, n_chunks, out);
+}
+
+void launch_lz_crc(hipStream_t st, const uint8_t *text, const uint64_t *chunks, uint32_t n_chunks, uint64_t span, uint32_t *crc)
+{
+    if (!n_chunks) return;
+    hipLaunchKernelGGL(k_lz_crc, dim3((n_chunks + WGZ / 64 - 1) / (WGZ / 64)), dim3(WGZ), 0, st, text, chunks, n_chunks, span, crc);
 }
 
 } // namespace pdk

@@ -134,6 +134,8 @@ void launch_lz_sort(hipStream_t st, const uint8_t *text, uint32_t np, uint64_t *
 void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
                      const uint64_t *chunks, uint32_t n_chunks, uint32_t *syms, uint64_t stride, uint32_t *counts);
 void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out);
+// CRC-32 (zlib's) of text[start, min(start + span, end)) of every chunk (start, end, origin triples)
+void launch_lz_crc(hipStream_t st, const uint8_t *text, const uint64_t *chunks, uint32_t n_chunks, uint64_t span, uint32_t *crc);
 }
 
 // per-site text rows (pd_format.hip)

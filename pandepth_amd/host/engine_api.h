@@ -51,6 +51,13 @@ typedef struct pd_engine_api {
     /* optional (NULL = buffers stay pageable): see pd_host_register */
     int (*host_register)(pd_ctx *, void *, size_t);
     int (*host_unregister)(pd_ctx *, void *);
+    /* optional (NULL = the per-site text is produced on, or copied to, the host): the device-resident text stream, see pd_text_* */
+    int (*text_open)(pd_ctx *, size_t, pd_text **);
+    int (*text_close)(pd_text *);
+    int (*text_append_sites)(pd_text *, int32_t, uint32_t, size_t, const char *, size_t, uint64_t *);
+    int (*text_parse)(pd_text *, uint64_t, size_t, const pd_lz_chunk *, uint32_t, uint32_t *, size_t, uint64_t *, uint32_t *, uint64_t);
+    int (*text_read)(pd_text *, uint64_t, size_t, void *);
+    int (*text_release)(pd_text *, uint64_t);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

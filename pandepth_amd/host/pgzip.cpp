@@ -582,6 +582,8 @@ struct Stream::Impl {
 
     // the text stage A reads: a round's text is handed over by the writer, which goes on filling `buf` meanwhile
     std::vector<uint8_t> work; uint64_t work_base = 0;
+    // ... or the text is elsewhere (Remote): no buffers here, positions are the source's
+    Remote remote; bool is_remote = false;
     // page-locked stretches of the two text buffers (Params::pin; the buffers are reserved once and never move)
     std::function<bool(void *, size_t)> pin; std::function<void(void *)> unpin;
     struct Pin { void *p; size_t n; };
@@ -618,7 +620,7 @@ struct Stream::Impl {
         const size_t zero_ = 0;
         const double tp0 = now_s();
         size_t provided = 0;
-        if (parse && nc > zero_) {
+        if ((is_remote ? (bool)remote.parse : (bool)parse) && nc > zero_) {
             // stage 1 by the provider for every new chunk except one that runs to the true end of the text (zlib sees the end of
             // its input there); their CRCs on the threads
             std::vector<uint64_t> tri; std::vector<size_t> which;
@@ -632,7 +634,7 @@ struct Stream::Impl {
             }
             // two calls at a time (each on its half of the chunks and the text they cover): a provider that copies the text elsewhere
             // moves one half while it parses the other
-            struct Group { size_t lo = 0, hi = 0; std::shared_ptr<SymVec> sy; std::vector<uint64_t> off; bool ok = false; };
+            struct Group { size_t lo = 0, hi = 0; std::shared_ptr<SymVec> sy; std::vector<uint64_t> off; std::vector<uint32_t> crc; bool ok = false; };
             const size_t n_groups = which.size() >= 512 ? 2 : 1;
             Group grp[2];
             for (size_t g = 0; g < n_groups; ++g) { grp[g].lo = which.size() * g / n_groups; grp[g].hi = which.size() * (g + 1) / n_groups; grp[g].sy = take_symvec(); }
@@ -641,8 +643,12 @@ struct Stream::Impl {
                 const uint64_t t_lo = tri[3 * G.lo + 2], t_hi = tri[3 * (G.hi - 1) + 1];       // first origin .. last tail end
                 std::vector<uint64_t> local(tri.begin() + (std::ptrdiff_t)(3 * G.lo), tri.begin() + (std::ptrdiff_t)(3 * G.hi));
                 for (auto &x : local) x -= t_lo;
-                G.ok = parse(work.data() + t_lo, (size_t)(t_hi - t_lo), local.data(), G.hi - G.lo, *G.sy, G.off) && G.off.size() == G.hi - G.lo + 1 &&
-                       G.off.back() <= G.sy->size();
+                if (is_remote) {
+                    G.crc.assign(G.hi - G.lo, 0);
+                    G.ok = remote.parse(work_base + t_lo, (size_t)(t_hi - t_lo), local.data(), G.hi - G.lo, *G.sy, G.off, G.crc.data(), CH);
+                } else
+                    G.ok = parse(work.data() + t_lo, (size_t)(t_hi - t_lo), local.data(), G.hi - G.lo, *G.sy, G.off);
+                G.ok = G.ok && G.off.size() == G.hi - G.lo + 1 && G.off.back() <= G.sy->size();
             };
             {
                 std::thread second;
@@ -656,7 +662,7 @@ struct Stream::Impl {
                 parallel_for(threads, G.hi - G.lo, [&](size_t j) {
                     Chunk &c = chunks[which[G.lo + j]];
                     c.syms.p = G.sy->data() + G.off[j]; c.syms.n = (size_t)(G.off[j + 1] - G.off[j]); c.hold = G.sy;
-                    c.crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), work.data() + (c.start - work_base), (uInt)(c.end - c.start));
+                    c.crc = is_remote ? G.crc[j] : (uint32_t)crc32(crc32(0L, Z_NULL, 0), work.data() + (c.start - work_base), (uInt)(c.end - c.start));
                     c.ok = true;
                 });
                 provided += G.hi - G.lo;
@@ -665,7 +671,19 @@ struct Stream::Impl {
         {
             std::vector<size_t> todo;
             for (size_t k = zero_; k < nc; ++k) if (!chunks[k].ok) todo.push_back(k);
-            parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(work.data(), work_base, chunks[todo[j]]); });
+            if (is_remote) {
+                // zlib's chunks (the ones that run to the end of the text; any the source did not parse) on text fetched for them
+                std::vector<char> fetched(todo.size(), 1);
+                parallel_for(threads, todo.size(), [&](size_t j) {
+                    Chunk &c = chunks[todo[j]];
+                    const uint64_t dl = c.start < 32768 ? c.start : 32768;
+                    std::vector<uint8_t> tmp((size_t)(c.tail_end - (c.start - dl)) + 64, 0);
+                    if (!remote.fetch || !remote.fetch(c.start - dl, (size_t)(c.tail_end - (c.start - dl)), tmp.data())) { fetched[j] = 0; return; }
+                    run_chunk(tmp.data(), c.start - dl, c);
+                });
+                for (char f : fetched) if (!f) return false;
+            } else
+                parallel_for(threads, todo.size(), [&](size_t j) { run_chunk(work.data(), work_base, chunks[todo[j]]); });
         }
         info.parse_s = now_s() - tp0; info.provided = provided;
         parsed_hi = c_hi;
@@ -823,11 +841,19 @@ struct Stream::Impl {
     bool run(bool final, size_t room)
     {
         if (!join_worker()) return false;
-        const uint64_t avail = base + buf.size();            // == total
+        const uint64_t avail = is_remote ? total : base + buf.size();   // == total
         uint64_t c_hi = parsed_hi;                            // exclusive
         if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
         else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
         if (!final && c_hi <= parsed_hi) return true;
+        if (is_remote) {
+            work_base = 0;
+            if (final) return round_body(true, c_hi);
+            base = c_hi * CH > 32768 ? c_hi * CH - 32768 : 0;      // what the next round still needs
+            worker_ok = true; worker_on = true;
+            worker = std::thread([this, c_hi] { worker_ok = round_body(false, c_hi); if (worker_ok && remote.release) remote.release(base); });
+            return true;
+        }
         if (work.capacity() < room) work.reserve(room);      // (first round: both buffers get their final size before any is locked)
         work.swap(buf); work_base = base;
         if (final) { buf.clear(); return round_body(true, c_hi); }
@@ -855,11 +881,30 @@ Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, c
     if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
     if (p.batch) p_->batch_bytes = p.batch;
 }
+Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p, const Remote &source) : Stream(threads, std::move(sink), p)
+{
+    p_->remote = source; p_->is_remote = true;
+}
 Stream::~Stream() { delete p_; }
+
+bool Stream::announce(uint64_t n)
+{
+    if (p_->failed || p_->finished || !p_->is_remote) return false;
+    p_->total += n;
+    const uint64_t limit = p_->batch_bytes + 2 * p_->CH + p_->TAIL;
+    if (p_->total - p_->base >= limit && !p_->run(false, 0)) { p_->failed = true; return false; }
+    return true;
+}
+
+bool Stream::wait_idle()
+{
+    if (!p_->join_worker()) { p_->failed = true; return false; }
+    return !p_->failed;
+}
 
 bool Stream::write(const void *data, size_t n)
 {
-    if (p_->failed || p_->finished) return false;
+    if (p_->failed || p_->finished || p_->is_remote) return false;
     const uint8_t *q = (const uint8_t *)data;
     const size_t limit = (size_t)(p_->batch_bytes + 2 * p_->CH + p_->TAIL);
     if (p_->buf.capacity() < limit + (size_t)p_->CH) p_->buf.reserve(limit + (size_t)p_->CH);   // (address space; pages come as the text does)

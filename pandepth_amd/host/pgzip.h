@@ -51,6 +51,16 @@ struct Params {
     static Params for_device(ParseFn fn);
 };
 
+// A text source that is not host memory (the engine's device-resident stream, pd_text_*): the stream is only told how many bytes
+// exist (announce); `parse` is a ParseFn on the stretch [off, off + n) of the source that also returns the CRC-32 of the first
+// crc_span bytes of every chunk (its own bytes, without the overlap); `fetch` copies a stretch to the host (the stream's tail, which zlib parses itself); `release`: nothing before `off`
+// will be asked for again.
+struct Remote {
+    std::function<bool(uint64_t off, size_t n, const uint64_t *chunks, size_t n_chunks, SymVec &syms, std::vector<uint64_t> &sym_off, uint32_t *crc, uint64_t crc_span)> parse;
+    std::function<bool(uint64_t off, size_t n, uint8_t *dst)> fetch;
+    std::function<void(uint64_t off)> release;
+};
+
 // the host emulation of the engine's parse (csrc/pd_lz77.h, 64 lanes in a loop) as a provider: tests of the plumbing without a GPU
 ParseFn host_emulation_parse();
 
@@ -61,8 +71,11 @@ ParseFn host_emulation_parse();
 class Stream {
 public:
     Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p = Params());
+    Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p, const Remote &source);   // text at `source`: announce(), not write()
     ~Stream();
     bool write(const void *data, size_t n);
+    bool announce(uint64_t n);           // (a Remote source) n more bytes of text exist there
+    bool wait_idle();                    // the round in flight, if any, is over when this returns (its failure: false)
     bool finish();
 private:
     struct Impl;

@@ -742,6 +742,80 @@ pgz::ParseFn engine_parse(Engine *eng)
     };
 }
 
+// <prefix>.SiteDepth.gz (PD:4264-4284) with its text resident on the device (pd_text_*): the engine formats the rows, parses them
+// the way zlib would (stage 1) and check-sums them where the cells are; the host receives symbols and CRCs, cuts blocks, builds the
+// Huffman codes and writes the bits (pgz::Stream with a Remote source).  Only the stream's last chunk comes back as text (zlib
+// parses it itself).  Returns 1 done, 0 declined (nothing usable written: the caller takes the host-text path), -1 error.
+int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
+{
+    const pd_engine_api *api = eng->api;
+    if (!api->text_open || !api->text_close || !api->text_append_sites || !api->text_parse || !api->text_read || !api->text_release) return 0;
+    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return 0;
+    if (const char *e = getenv("PANDEPTH_SITE_RESIDENT")) if (e[0] == '0') return 0;
+    const bool timing = getenv("PANDEPTH_TIMING") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
+    pgz::Params prm = pgz::Params::for_device(nullptr);
+    const size_t ring = std::max<size_t>((size_t)1 << 30, 4 * prm.batch);
+    pd_text *tx = nullptr;
+    if (api->text_open(eng->ctx, ring, &tx) != 0 || !tx) return 0;
+    struct Closer { const pd_engine_api *api; pd_text *t; ~Closer() { if (t && !getenv("PANDEPTH_KEEP_CONTEXT")) api->text_close(t); } } closer{api, tx};
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { std::cerr << "open OUT File error: " << path << std::endl; return -1; }
+    bool io_ok = true;
+    int rc = 1;
+    double t_parse = 0, t_append = 0; size_t n_calls = 0;
+    std::mutex tm_mu;
+    pgz::Remote src;
+    src.parse = [&](uint64_t off, size_t n, const uint64_t *chunks, size_t n_chunks, pgz::SymVec &syms, std::vector<uint64_t> &soff, uint32_t *crc, uint64_t crc_span) -> bool {
+        size_t bytes = 0;
+        for (size_t k = 0; k < n_chunks; ++k) bytes += (size_t)(chunks[3 * k + 1] - chunks[3 * k]);
+        soff.assign(n_chunks + 1, 0);
+        const auto t0 = std::chrono::steady_clock::now();
+        int r = PD_ERANGE;
+        for (size_t cap : {bytes / 3 + 4096, bytes + 16}) {
+            if (syms.size() < cap) syms.resize(cap);
+            r = api->text_parse(tx, off, n, reinterpret_cast<const pd_lz_chunk *>(chunks), (uint32_t)n_chunks, syms.data(), syms.size(), soff.data(), crc, crc_span);
+            if (r != PD_ERANGE) break;
+        }
+        { std::lock_guard<std::mutex> lk(tm_mu); t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++n_calls; }
+        if (r != 0) eng->ck(r, "pd_text_parse");
+        return r == 0;
+    };
+    src.fetch = [&](uint64_t off, size_t n, uint8_t *dst) { return api->text_read(tx, off, n, dst) == 0; };
+    src.release = [&](uint64_t off) { (void)api->text_release(tx, off); };
+    {
+        std::unique_ptr<pgz::Stream> st(new pgz::Stream(threads, [&](const uint8_t *b, size_t n) { io_ok = fwrite(b, 1, n, fp) == n && io_ok; return io_ok; }, prm, src));
+        const size_t CH = (size_t)2 << 20;                 // cells per append: 30-60 MB of rows
+        for (size_t t = 0; t < hdr.names.size() && rc == 1; ++t) {
+            if (!rm.has((int32_t)t)) continue;
+            const uint32_t len = hdr.lens[t];
+            const std::string &nm = hdr.names[t];
+            for (uint32_t b = 0; b < len && rc == 1; b += (uint32_t)CH) {
+                const size_t n = std::min<size_t>(CH, len - b);
+                uint64_t got = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                int r = api->text_append_sites(tx, (int32_t)t, b, n, nm.data(), nm.size(), &got);
+                if (r == PD_ERANGE) {                       // the ring is full: what the round in flight holds is released when it is over
+                    if (!st->wait_idle()) { rc = io_ok ? 0 : -1; break; }
+                    r = api->text_append_sites(tx, (int32_t)t, b, n, nm.data(), nm.size(), &got);
+                }
+                t_append += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (r != 0) { rc = r == PD_ERANGE ? 0 : (eng->ck(r, "pd_text_append_sites"), -1); break; }
+                if (!st->announce(got)) rc = io_ok ? 0 : -1;
+            }
+        }
+        if (rc == 1 && !st->finish()) rc = io_ok ? 0 : -1;
+        if (rc != 1) (void)st->wait_idle();
+        if (timing)
+            fprintf(stderr, "[timing]   per-site writer (text resident on the device): appends %.3f s; %zu parse calls, %.3f s in them (two at a time); %.3f s in all\n", t_append,
+                    n_calls, t_parse, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+        if (getenv("PANDEPTH_KEEP_CONTEXT")) (void)st.release();   // (the process is about to end, main.cpp)
+    }
+    if (fclose(fp) != 0 && rc == 1) rc = -1;
+    if (rc == 0 && !eng->ok()) { std::lock_guard<std::mutex> lk(eng->err_mu); eng->err.clear(); }   // declined: the host-text path starts the file over
+    return rc;
+}
+
 // <prefix>.SiteDepth.gz (PD:4264-4284), byte-identical to the reference's single zlib stream at any size, on all
 // threads: 4 M-cell blocks are read back, formatted in parallel slices and fed, in order, to pgz::Stream
 // (host/pgzip.h), which deflates them with zlib's own parse spread over the threads and bounded memory.
@@ -878,7 +952,8 @@ bool write_site_depth(const std::string &path, const AlnHeader &hdr, const Regio
 {
     const char *ident = getenv("PANDEPTH_SITE_IDENTICAL");
     if (threads > 1 && !(ident && ident[0] == '0')) {
-        const int r = write_site_depth_identical(path, hdr, rm, eng, threads);
+        int r = write_site_depth_resident(path, hdr, rm, eng, threads);
+        if (r == 0) r = write_site_depth_identical(path, hdr, rm, eng, threads);
         if (r == 1) return true;
         if (r < 0) return false;
     }

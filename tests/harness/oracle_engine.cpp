@@ -6,6 +6,7 @@
 // libpandepth_amd.so, libpandepth_host.a or the `pandepth` binary.
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -276,12 +277,68 @@ static int o_deflate_parse(pd_ctx *, const void *text, size_t n, const pd_lz_chu
     return 0;
 }
 
+// pd_text_* on the CPU: the stream is a byte vector (with a small capacity, so that the ring's "full" answer is exercised too), rows
+// formatted with printf, the parse by the product's core in host emulation, CRCs by zlib
+struct pd_text { pd_ctx *c; std::vector<uint8_t> bytes; uint64_t base = 0; size_t cap; std::mutex mu; };
+static int o_text_open(pd_ctx *c, size_t cap, pd_text **out)
+{
+    pd_text *t = new pd_text; t->c = c;
+    t->cap = getenv("PANDEPTH_TEST_TEXT_CAP") ? (size_t)atoll(getenv("PANDEPTH_TEST_TEXT_CAP")) : cap;
+    *out = t; return 0;
+}
+static int o_text_close(pd_text *t) { delete t; return 0; }
+static int o_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, uint64_t *n_bytes)
+{
+    pd_ctx *c = t->c;
+    if (!c->scanned) { c->err = "scan first"; return -4; }
+    std::string rows, nm(name, name_len);
+    char num[64];
+    for (size_t j = 0; j < n; ++j) {
+        rows += nm;
+        snprintf(num, sizeof num, "\t%u\t%u\n", beg + (uint32_t)j, c->depth[(size_t)c->off[tid] + beg + j]);
+        rows += num;
+    }
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (t->bytes.size() + rows.size() > t->cap) { c->err = "text stream full"; return -6; }
+    t->bytes.insert(t->bytes.end(), rows.begin(), rows.end());
+    *n_bytes = rows.size();
+    return 0;
+}
+static int o_text_parse(pd_text *t, uint64_t off, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *soff, uint32_t *crc, uint64_t crc_span)
+{
+    std::vector<uint8_t> text;
+    {
+        std::lock_guard<std::mutex> lk(t->mu);
+        if (off < t->base || off + n > t->base + t->bytes.size()) { t->c->err = "stretch not in the stream"; return -1; }
+        text.assign(t->bytes.begin() + (std::ptrdiff_t)(off - t->base), t->bytes.begin() + (std::ptrdiff_t)(off - t->base + n));
+    }
+    const int rc = o_deflate_parse(t->c, text.data(), n, chunks, n_chunks, syms, cap, soff);
+    if (rc) return rc;
+    if (crc) for (uint32_t k = 0; k < n_chunks; ++k) crc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), text.data() + chunks[k].start, (uInt)std::min<uint64_t>(crc_span, chunks[k].end - chunks[k].start));
+    return 0;
+}
+static int o_text_read(pd_text *t, uint64_t off, size_t n, void *out)
+{
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (off < t->base || off + n > t->base + t->bytes.size()) { t->c->err = "stretch not in the stream"; return -1; }
+    memcpy(out, t->bytes.data() + (off - t->base), n);
+    return 0;
+}
+static int o_text_release(pd_text *t, uint64_t off)
+{
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (off > t->base) { const uint64_t k = std::min<uint64_t>(off - t->base, t->bytes.size()); t->bytes.erase(t->bytes.begin(), t->bytes.begin() + (std::ptrdiff_t)k); t->base += k; }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     // (keep_deferred: nothing to do on this engine; deflate_parse: the product's parse core in host emulation, like the decoder's cores)
+    const bool no_parse = getenv("PANDEPTH_TEST_NO_PARSE") != nullptr;      // (zlib alone writes the gzip streams)
     static const pd_engine_api api = {o_create, o_destroy, o_strerror, o_push, o_scan, o_reduce_intervals,
                                       o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from,
                                       o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param,
-                                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, getenv("PANDEPTH_TEST_NO_PARSE") ? nullptr : o_deflate_parse};
+                                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, no_parse ? nullptr : o_deflate_parse, nullptr, nullptr,
+                                      no_parse ? nullptr : o_text_open, o_text_close, o_text_append_sites, o_text_parse, o_text_read, o_text_release};
     return pandepth_main(argc, argv, &api, 0);
 }

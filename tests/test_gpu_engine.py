@@ -734,6 +734,67 @@ def test_format_sites_equals_host_formatting(wrap):
             e.format_sites(0, 0, 10, "x")                       # before pd_scan: the cells are not depths yet
 
 
+def test_text_stream_rows_parse_and_checksums():
+    """pd_text_*: the rows appended to the device-resident stream are pd_format_sites' bytes; pd_text_parse of a stretch is
+    pd_deflate_parse of the same bytes (which tests/test_lz77.py holds to zlib's own parse) and its CRCs are zlib.crc32 of the
+    chunks' first crc_span bytes; the ring answers "full" (-6), takes appends again after a release — at its start, wrapping —
+    and a stretch that spans the wrap reads and parses like any other."""
+    import zlib
+    rng = np.random.default_rng(78)
+    lens = np.array([1500000, 50000], dtype=np.uint32)
+    iv = rand_intervals(rng, lens, 80000)
+    with pda.Engine(lens) as e:
+        e.push_intervals(iv)
+        with pytest.raises(pda.PdError):
+            with e.text_open(1 << 22) as t:
+                t.append_sites(0, 0, 10, "x")                    # before pd_scan
+        e.scan(0)
+        host = b""
+        with e.text_open(6 << 20) as t:                          # 6 MiB: three appends of ~1.9 MB fit, the fourth does not
+            pieces = [(0, 0, 130000, "Chr01"), (0, 130000, 130000, "Chr01"), (0, 260000, 120000, "Chr01")]
+            for tid, beg, n, name in pieces:
+                want = e.format_sites(tid, beg, n, name)
+                assert t.append_sites(tid, beg, n, name) == len(want)
+                host += want
+            assert t.read(0, len(host)) == host
+            assert t.read(1000000, 777) == host[1000000:1000777]
+            with pytest.raises(pda.PdError) as ei:
+                t.append_sites(0, 380000, 130000, "Chr01")
+            assert ei.value.code == -6
+            # chunks the way host/pgzip.cpp cuts them: 32 KiB + 8 KiB of overlap, 32 KiB of history
+            CH, TAIL = 32768, 8192
+            def chunks_of(lo, hi):
+                out = []
+                for s0 in range(lo, hi - TAIL, CH):
+                    if s0 + CH + TAIL <= hi:
+                        out.append((s0 - lo_text, s0 + CH + TAIL - lo_text, max(lo_text, s0 - 32768) - lo_text))
+                return out
+            lo_text = 0
+            ch = chunks_of(0, len(host))
+            syms, crc = t.parse(0, len(host), ch, CH)
+            ref = e.deflate_parse(host, ch)
+            assert len(syms) == len(ref) and all(np.array_equal(a, b) for a, b in zip(syms, ref))
+            assert [int(x) for x in crc] == [zlib.crc32(host[s0:s0 + CH]) for s0, _, _ in ch]
+            # release the first two appends; the next append wraps to the ring's start
+            cut = len(e.format_sites(0, 0, 130000, "Chr01")) + len(e.format_sites(0, 130000, 130000, "Chr01"))
+            t.release(cut)
+            with pytest.raises(pda.PdError):
+                t.read(0, 10)                                    # released
+            more = e.format_sites(0, 380000, 130000, "Chr01")
+            assert t.append_sites(0, 380000, 130000, "Chr01") == len(more)
+            host += more
+            assert t.read(cut, len(host) - cut) == host[cut:]
+            lo_text = cut
+            ch = chunks_of(cut, len(host))
+            assert len(ch) > 20
+            syms, crc = t.parse(cut, len(host) - cut, ch, CH)
+            ref = e.deflate_parse(host[cut:], ch)
+            assert all(np.array_equal(a, b) for a, b in zip(syms, ref))
+            assert [int(x) for x in crc] == [zlib.crc32(host[cut + s0:cut + s0 + CH]) for s0, _, _ in ch]
+            with pytest.raises(pda.PdError):
+                t.parse(0, 100000, [(0, 50000, 0)], CH)          # a stretch that is no longer there
+
+
 @pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (10000000, 0, 0), (16384, 1, 18)])
 def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
     """Both forms of the wide-window direct kernel (k_direct_wide3, the default; k_direct_tiles<.., DirectWide>, "direct_un" 504)

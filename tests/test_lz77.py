@@ -90,17 +90,47 @@ def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
     subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
     cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
     outs = {}
-    for tag, env in (("dev", {"PANDEPTH_TIMING": "1"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
+    for tag, env in (("dev", {"PANDEPTH_TIMING": "1"}), ("hosttext", {"PANDEPTH_TIMING": "1", "PANDEPTH_SITE_RESIDENT": "0"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "8"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=900, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-600:]
         outs[tag] = {s: (tmp_path / ("%s.%s" % (tag, s))).read_bytes() for s in ("win.stat.gz", "SiteDepth.gz")}
-        if tag == "dev":
-            err = p.stderr.decode()
-            assert err.count("pd_deflate_parse:") >= 2 and "FAILED" not in err, err[-1500:]
+        err = p.stderr.decode()
+        if tag == "dev":          # the per-site text stays on the device (pd_text_*), the table goes through pd_deflate_parse
+            assert "text resident on the device" in err and " 0 parse calls" not in err and err.count("pd_deflate_parse:") >= 1 and "FAILED" not in err, err[-1500:]
+        if tag == "hosttext":     # both streams through pd_deflate_parse on host text
+            assert "text resident on the device" not in err and err.count("pd_deflate_parse:") >= 2 and "FAILED" not in err, err[-1500:]
+    assert outs["dev"] == outs["hosttext"]
     assert outs["dev"] == outs["host"]
     ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
     if os.access(ref, os.X_OK):
         subprocess.run([ref, "-i", "g.bam", "-w", "100", "-a", "-o", "ref", "-t", "4"], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         for s in ("win.stat.gz", "SiteDepth.gz"):
             assert outs["dev"][s] == (tmp_path / ("ref." + s)).read_bytes(), s
+
+
+def test_resident_text_stream_through_the_host_logic(tmp_path):
+    """host/pgzip.cpp with a Remote text source (the per-site file whose text stays with the engine: pd_text_*), driven on the CPU
+    by the oracle engine's stand-in (tests/harness/oracle_engine.cpp: a byte vector, the product's parse core in host emulation):
+    several rounds, a ring that runs full and is waited for — the same bytes as the host-text path and as zlib-only."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    subprocess.run(["make", "-C", H, "pandepth_oracle_cli"], check=True, stdout=subprocess.DEVNULL)
+    names, lens = synth.genome_c2(scale=0.0004)
+    rec = synth.gen_records_numpy(lens, 20000, seed=6)
+    bam = str(tmp_path / "g.bam")
+    synth.write_bam(bam, names, lens, rec, procs=2, payload=False)
+    cli = os.path.join(H, "pandepth_oracle_cli")
+    outs = {}
+    for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32"}),
+                     ("full", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_CAP": "4000000"}),
+                     ("hosttext", {"PANDEPTH_SITE_RESIDENT": "0", "PGZ_DEV_BATCH_MB": "1"}), ("zlib", {"PANDEPTH_TEST_NO_PARSE": "1"})):
+        p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "4"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=1500, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-600:]
+        outs[tag] = {s: (tmp_path / ("%s.%s" % (tag, s))).read_bytes() for s in ("win.stat.gz", "SiteDepth.gz")}
+        if tag in ("resident", "full"):
+            err = p.stderr.decode()
+            assert "text resident on the device" in err and " 0 parse calls" not in err, err[-1500:]
+    assert outs["resident"] == outs["zlib"] and outs["full"] == outs["zlib"] and outs["hosttext"] == outs["zlib"]
