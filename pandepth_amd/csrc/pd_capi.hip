@@ -504,9 +504,13 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
 static void runs_free(pd_runs *r);
 static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out);
 
+static inline uint64_t dec_now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int pd_destroy(pd_ctx *c)
 {
     if (!c) return PD_OK;
+    const bool tm = getenv("PANDEPTH_TIMING") != nullptr;
+    const uint64_t t0 = dec_now_us(); uint64_t t1 = t0, t2 = t0, t3 = t0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -520,7 +524,9 @@ int pd_destroy(pd_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
                     c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->direct_words, c->desc, c->chk, c->ovf, c->scratch};
+    t1 = dec_now_us();
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    t2 = dec_now_us();
     for (auto &sl : c->dec) {
         if (sl.st) (void)hipStreamSynchronize(sl.st);
         if (sl.h_blob) (void)hipHostFree(sl.h_blob);
@@ -537,10 +543,13 @@ int pd_destroy(pd_ctx *c)
     }
     for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
     runs_free(c->dec_runs);
+    t3 = dec_now_us();
     for (auto &w : c->lz) { std::lock_guard<std::mutex> g(w.mu); w.release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
+    if (tm) fprintf(stderr, "[timing]   pd_destroy: sync + staging %.3f s, cells and tables %.3f s, decode slots and runs %.3f s, parse buffers and streams %.3f s\n",
+                    (t1 - t0) * 1e-6, (t2 - t1) * 1e-6, (t3 - t2) * 1e-6, (dec_now_us() - t3) * 1e-6);
     return PD_OK;
 }
 

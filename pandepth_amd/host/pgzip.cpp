@@ -929,7 +929,10 @@ bool Stream::finish()
 Params Params::for_device(ParseFn fn)
 {
     Params p;
-    p.chunk = (size_t)1 << 16; p.tail = (size_t)1 << 13; p.batch = (size_t)192 << 20;
+    // one wave parses one chunk, and the parse is bound by the latency of dependent loads: many small chunks (8 waves per SIMD at
+    // 6144 chunks a round) beat few large ones; 4 KiB of overlap is ample for tables and per-site rows (the parses meet within a few
+    // lines), and a stream whose parses do not meet there is started over with larger chunks by the caller
+    p.chunk = (size_t)1 << 14; p.tail = (size_t)1 << 12; p.batch = (size_t)96 << 20;
     // (measurement knobs: the geometry in KiB / KiB / MiB)
     if (const char *e = getenv("PGZ_DEV_CHUNK_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 16 && v <= 4096) p.chunk = v << 10; }
     if (const char *e = getenv("PGZ_DEV_TAIL_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 2 && (v << 10) < p.chunk) p.tail = v << 10; }

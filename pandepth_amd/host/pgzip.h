@@ -47,7 +47,7 @@ struct Params {
     // batch + 3 chunks each, never reallocated while locked; pin returns false if it could not)
     std::function<bool(void *, size_t)> pin;
     std::function<void(void *)> unpin;
-    // the geometry that suits a provider with one wave per chunk: many small chunks, rounds large enough to fill the device
+    // the geometry that suits a provider with one wave per chunk: many small chunks (16 KiB + 4 KiB of overlap), rounds of 96 MiB
     static Params for_device(ParseFn fn);
 };
 

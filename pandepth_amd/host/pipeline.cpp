@@ -820,7 +820,7 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
 // threads: 4 M-cell blocks are read back, formatted in parallel slices and fed, in order, to pgz::Stream
 // (host/pgzip.h), which deflates them with zlib's own parse spread over the threads and bounded memory.
 // Returns 1 done, 0 the parallel form declined (nothing usable written), -1 error.
-int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
+int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads, bool device_parse)
 {
     FILE *fp = fopen(path.c_str(), "wb");
     if (!fp) { std::cerr << "open OUT File error: " << path << std::endl; return -1; }
@@ -829,7 +829,7 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
     const auto t_enter = std::chrono::steady_clock::now();
     auto t_leave = t_enter;
     {
-        const pgz::ParseFn dev_parse = engine_parse(eng);
+        const pgz::ParseFn dev_parse = device_parse ? engine_parse(eng) : nullptr;
         pgz::Params prm = dev_parse ? pgz::Params::for_device(dev_parse) : pgz::Params();
         if (dev_parse && eng->api->host_register && eng->api->host_unregister) {
             // the stream's two text buffers are handed to pd_deflate_parse round after round: page-locked, the copy runs at the link's rate
@@ -952,8 +952,11 @@ bool write_site_depth(const std::string &path, const AlnHeader &hdr, const Regio
 {
     const char *ident = getenv("PANDEPTH_SITE_IDENTICAL");
     if (threads > 1 && !(ident && ident[0] == '0')) {
+        // the text on the device; else the text on the host with the engine's parse; else zlib's own parse on the host threads, whose
+        // chunks are large (1 MiB + 64 KiB of overlap): a text whose parses do not meet inside the small chunks' overlap ends up there
         int r = write_site_depth_resident(path, hdr, rm, eng, threads);
-        if (r == 0) r = write_site_depth_identical(path, hdr, rm, eng, threads);
+        if (r == 0) r = write_site_depth_identical(path, hdr, rm, eng, threads, true);
+        if (r == 0 && engine_parse(eng)) r = write_site_depth_identical(path, hdr, rm, eng, threads, false);
         if (r == 1) return true;
         if (r < 0) return false;
     }

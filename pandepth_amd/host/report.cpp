@@ -46,8 +46,14 @@ bool GzWriter::close()
         if (const char *e = getenv("PANDEPTH_PGZ_MIN")) pgz_min = (size_t)strtoull(e, nullptr, 10);
         std::vector<uint8_t> img;
         bool ok;
-        if (text_.size() >= pgz_min && pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img,
-                                                           parse_ ? pgz::Params::for_device(parse_) : pgz::Params())) {
+        // with the engine's parse (small chunks); else zlib's own parse on the threads (1 MiB chunks with 64 KiB of overlap: a text
+        // whose parses do not meet inside the small chunks' overlap); else one zlib stream
+        bool done = false;
+        if (text_.size() >= pgz_min) {
+            if (parse_) done = pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img, pgz::Params::for_device(parse_));
+            if (!done) { img.clear(); done = pgz::gzip_identical((const uint8_t *)text_.data(), text_.size(), threads_, img, pgz::Params()); }
+        }
+        if (done) {
             ok = fwrite(img.data(), 1, img.size(), fp) == img.size();
             ok = fclose(fp) == 0 && ok;
         } else {
