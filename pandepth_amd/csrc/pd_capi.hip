@@ -793,7 +793,7 @@ static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     const uint64_t nw = wo[c->n_contigs];
     const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
     const size_t b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
-    const size_t b_part = w >= PD_TILE ? (size_t)c->n_tiles * sizeof(TilePart) : 0;
+    const size_t b_part = (size_t)c->n_tiles * sizeof(TilePart);      // wide windows: every tile's shares; narrow ones: the shares of the windows across tile boundaries
     int rc = ensure_scratch(c, b_off + b_sum + b_cov + b_part + 64);
     if (rc) return rc;
     unsigned char *s = (unsigned char *)c->scratch;

@@ -329,13 +329,74 @@ struct WinArgs {
     TilePart *part;          // w >= TILE: per-tile partials for the (at most two) windows it touches
 };
 
+// ---- narrow windows (4 <= w < TILE): one row of a wave (64 lanes x 4 consecutive cells) into the tile's LDS accumulators ----
+// A window's share of a row is a difference of two row-prefix values, so only the lanes that hold a window's last cell touch LDS:
+// the (cover << 48 | depth sum) words of the lanes are prefix-summed over the wave, the lane holding the cell before a window
+// start adds the prefix there to the window that ends and subtracts it from the one that begins (the fields borrow from each other
+// in between; the finished word is exact), and lane 63 adds the row's total to the window of the row's last cell.  About 2 w / 256 + 1
+// LDS atomics per row on distinct addresses, where one atomic per lane and window piece (64-128 per row, on 3-4 addresses) was
+// what bound these sweeps.
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x)
+{
+#define PD_SCAN64_STEP(ctrl, rmask)                                                                                       \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rmask, 0xf, false);          \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rmask, 0xf, false);  \
+        x += ((unsigned long long)hi_ << 32) | lo_;                                                                       \
+    }
+    PD_SCAN64_STEP(0x111, 0xf) PD_SCAN64_STEP(0x112, 0xf) PD_SCAN64_STEP(0x114, 0xf) PD_SCAN64_STEP(0x118, 0xf)
+    PD_SCAN64_STEP(0x142, 0xa) PD_SCAN64_STEP(0x143, 0xc)
+#undef PD_SCAN64_STEP
+    return x;
+}
+
+__device__ __forceinline__ void narrow_window_row(const uint32_t (&d)[4], uint32_t pos, uint32_t phase, uint32_t w, float inv_w, uint32_t min_dep,
+                                                  uint64_t cells_left /* cells of the contig from the tile's first */, unsigned long long *acc, int lane)
+{
+    const uint32_t x = pos + phase;
+    uint32_t q = (uint32_t)((float)x * inv_w);
+    if ((uint64_t)q * w > x) --q;
+    if ((uint64_t)(q + 1) * w <= x) ++q;
+    const uint32_t k = (uint32_t)((uint64_t)(q + 1) * w - phase - pos);      // window q + 1 starts k cells behind this lane's first (k >= 1)
+    unsigned long long v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((uint64_t)pos + e < cells_left && d[e] >= min_dep) ? ((1ull << 48) | d[e]) : 0ull;
+    const unsigned long long T = v[0] + v[1] + v[2] + v[3];
+    const unsigned long long L = wave_incl_scan_u64(T);
+    if (k <= 4u && !(lane == 63 && k == 4u)) {
+        const unsigned long long I = L - T + v[0] + (k >= 2u ? v[1] : 0ull) + (k >= 3u ? v[2] : 0ull) + (k >= 4u ? v[3] : 0ull);
+        if (I) { atomicAdd(&acc[q], I); atomicAdd(&acc[q + 1], 0ull - I); }
+    }
+    if (lane == 63 && L) atomicAdd(&acc[k <= 3u ? q + 1 : q], L);
+}
+
+// The tile's finished accumulators go out with plain stores: windows inside the tile to the window arrays, the share of a window
+// that began in the previous tile or goes on in the next one to the tile's TilePart (c0 / s0: first window, c1 / s1: last);
+// k_window_edges adds the two halves.  (Global atomics for those two windows kept every workgroup resident for the atomics' round trip
+// at its very end: 2.16 ms against 1.49 ms for widths that divide the tile, 2.0e9 cells.)
+__device__ __forceinline__ void narrow_write_out(const unsigned long long *acc, uint32_t nacc, uint64_t k0, uint32_t w, uint64_t local0, uint32_t clen,
+                                                 uint64_t wbase, const WinArgs &wa, TilePart *pt)
+{
+    for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
+        const unsigned long long a = acc[j];
+        const uint32_t c = (uint32_t)(a >> 48);
+        const unsigned long long sm = a & 0xFFFFFFFFFFFFull;
+        const uint64_t k = k0 + j;
+        const bool before = k * w < local0;                                                       // began in the previous tile
+        const bool after = (k + 1) * (uint64_t)w > local0 + TILE && local0 + TILE < (uint64_t)clen;   // goes on in the next tile
+        if (before) { pt->c0 = c; pt->s0 = sm; }
+        else if (after) { pt->c1 = c; pt->s1 = sm; }
+        else if (c) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = sm; }
+    }
+}
+
 // Narrow windows (64 <= w < TILE) for the direct kernels: k_sweep's LDS accumulators (one packed
 // 64-bit word per window overlapping the tile: cover in the top 16 bits, depth sum below), fed from
 // the registers that hold the tile's local prefix sums.  Called by the whole workgroup.
 template <int ROWS>
 __device__ __forceinline__ void direct_small_windows(const int4 (&v)[ROWS], const int (&rowex)[ROWS], int base,
                                                      uint32_t wrap_mask, uint32_t local0, uint32_t clen, const WinArgs &wa,
-                                                     uint64_t wbase, unsigned long long *acc)
+                                                     uint64_t wbase, unsigned long long *acc, TilePart *pt)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w = wa.w;
@@ -350,34 +411,10 @@ __device__ __forceinline__ void direct_small_windows(const int4 (&v)[ROWS], cons
         const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
         const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
                                (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
-        const uint32_t x = pos + phase;
-        uint32_t q = (uint32_t)((float)x * wa.inv_w);
-        if ((uint64_t)q * w > x) --q;
-        if ((uint64_t)(q + 1) * w <= x) ++q;
-        uint64_t nb = (uint64_t)(q + 1) * w - phase;             // tile-local cell where window q+1 starts
-        uint32_t c = 0; unsigned long long sm = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t pe = pos + e;
-            if (pe == nb) {
-                if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | sm);
-                c = 0; sm = 0; ++q; nb += w;
-            }
-            if ((uint64_t)local0 + pe < clen && d[e] >= wa.min_dep) { ++c; sm += d[e]; }
-        }
-        if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | sm);
+        narrow_window_row(d, pos, phase, w, wa.inv_w, wa.min_dep, clen > local0 ? (uint64_t)clen - local0 : 0ull, acc, lane);
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
-        const unsigned long long a = acc[j];
-        const uint32_t c = (uint32_t)(a >> 48);
-        if (!c) continue;
-        const unsigned long long sm = a & 0xFFFFFFFFFFFFull;
-        const uint64_t k = (uint64_t)k0 + j;
-        const bool inside = (k * w >= local0) && ((k + 1) * (uint64_t)w <= (uint64_t)local0 + TILE);
-        if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = sm; }
-        else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], sm); }
-    }
+    narrow_write_out(acc, nacc, k0, w, local0, clen, wbase, wa, pt);
 }
 
 // One candidate run of the direct pass; per-lane counters (summed over the wave by the caller).
@@ -564,7 +601,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_tiles(const PendSet ps, uint
         int base = s_carry;
         for (int k = 0; k < wv; ++k) base += wtot[k];
         if constexpr (NARROW) {                                   // narrow windows: LDS accumulators
-            if (p0 < clen) direct_small_windows<ROWS>(v, tot, base, wrap_mask, p0, clen, args.wa, args.win_off[ctg], acc);
+            if (p0 < clen) direct_small_windows<ROWS>(v, tot, base, wrap_mask, p0, clen, args.wa, args.win_off[ctg], acc, args.wa.part + t);
             __syncthreads();
             continue;
         }
@@ -1190,7 +1227,7 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
         for (int k = 0; k < wv; ++k) base += wtot[k];
         if (w < (uint32_t)ST) {                                   // narrow windows: LDS accumulators (uniform branch)
             const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);
-            if (p0 < clen) direct_small_windows<ROWS>(v, excl, base, wrap_mask, p0, clen, wa, win_off[ctg], acc);
+            if (p0 < clen) direct_small_windows<ROWS>(v, excl, base, wrap_mask, p0, clen, wa, win_off[ctg], acc, wa.part + t);
             __syncthreads();
             continue;
         }
@@ -1741,6 +1778,8 @@ __global__ __launch_bounds__(1024) void k_tile_carry(const int *sums, const int 
 //   FROM_DEPTH : input already holds depth (reduction only)
 // ------------------------------------------------------------------------------------------
 
+typedef int v4i_nt __attribute__((ext_vector_type(4)));
+
 template <bool WRITE, bool WIN, bool FROM_DEPTH>
 __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32_t wrap_mask,
                                               const TileMap tmap, WinArgs wa, const uint8_t *hstate)
@@ -1756,8 +1795,12 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
     // 0-1 cover the first 4096 cells of the tile, waves 2-3 the second (wave-uniform branch)
     const bool live = FROM_DEPTH || hstate[t * (TILE / PD_HALF) + (wv >> 1)] != 0;
     if (live) {
+        // every cell is read once (and, written back, written once): non-temporal, so that the lines do not wait in L2 for a reuse that never comes
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) v[r] = p4[r * 64];
+        for (int r = 0; r < ROWS; ++r) {
+            const v4i_nt x = __builtin_nontemporal_load(reinterpret_cast<const v4i_nt *>(p4 + r * 64));
+            v[r] = make_int4(x.x, x.y, x.z, x.w);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) v[r] = make_int4(0, 0, 0, 0);
@@ -1794,7 +1837,10 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
     }
     if (WRITE) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) p4[r * 64] = v[r];
+        for (int r = 0; r < ROWS; ++r) {
+            v4i_nt x; x.x = v[r].x; x.y = v[r].y; x.z = v[r].z; x.w = v[r].w;
+            __builtin_nontemporal_store(x, reinterpret_cast<v4i_nt *>(p4 + r * 64));
+        }
     }
     if (WIN) {
         // contig-local position of this tile's first cell and the contig's length
@@ -1854,6 +1900,8 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
         for (int r = 0; r < ROWS; ++r) {
             const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
             const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
+            if (w >= 4u) { narrow_window_row(d, pos, phase, w, wa.inv_w, wa.min_dep, (uint64_t)clen - local0, acc, lane); continue; }
+            // windows of 1-3 cells: several begin inside a lane's four cells; one atomic per window piece
             const uint32_t x = pos + phase;
             uint32_t q = (uint32_t)((float)x * wa.inv_w);
             if ((uint64_t)q * w > x) --q;
@@ -1872,17 +1920,27 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
             if (c) atomicAdd(&acc[q], ((unsigned long long)c << 48) | s);
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nacc; j += WG) {
-            const unsigned long long a = acc[j];
-            const uint32_t c = (uint32_t)(a >> 48);
-            if (!c) continue;
-            const unsigned long long sm = a & 0xFFFFFFFFFFFFull;
-            const uint64_t k = k0 + j;
-            const bool inside = (k * w >= local0) && ((k + 1) * (uint64_t)w <= local0 + TILE);
-            if (inside) { wa.cover[wbase + k] = c; wa.sum[wbase + k] = sm; }
-            else { atomicAdd(&wa.cover[wbase + k], c); atomicAdd(&wa.sum[wbase + k], sm); }
-        }
+        narrow_write_out(acc, nacc, k0, w, local0, clen, wbase, wa, wa.part + t);
     }
+}
+
+// w < TILE: the windows that lie across a tile boundary = the last share of the tile before it + the first share of the tile behind it
+__global__ __launch_bounds__(WG) void k_window_edges(const TilePart *part, const TileMap tmap, uint32_t n_tiles, uint32_t w, uint32_t *cover,
+                                                     unsigned long long *sum)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (t + 1 >= n_tiles) return;
+    const uint32_t ctg = tmap.tile_contig[t];
+    const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
+    const uint64_t clen = tmap.contig_len[ctg];
+    if (local0 + TILE >= clen) return;                           // the contig's last tile (or padding): nothing goes on behind it
+    const uint64_t k = (local0 + TILE - 1) / w;                  // the window of the tile's last cell
+    if ((k + 1) * (uint64_t)w <= local0 + TILE) return;          // ends with the tile
+    const TilePart a = part[t], b = part[t + 1];
+    const uint32_t c = a.c1 + b.c0;
+    if (!c) return;
+    cover[tmap.win_off[ctg] + k] = c;
+    sum[tmap.win_off[ctg] + k] = a.s1 + b.s0;
 }
 
 // w >= TILE: one wave per window adds up the partials of the tiles it spans (plain loads/stores).
@@ -2320,6 +2378,9 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,
                        n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{}, C8Sample{nullptr, nullptr, 0, 0});
+    if (w < (uint32_t)TILE && n_tiles > 1)
+        hipLaunchKernelGGL(k_window_edges, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const TilePart *)part, TileMap{tile_contig, tab.off, tab.len, win_off},
+                           n_tiles, w, cover, sum);
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 
@@ -2487,6 +2548,8 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
     if (w >= (uint32_t)TILE && n_windows)
         hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n_windows + 3) / 4)), dim3(WG), 0, st, part, tm, n_contigs,
                            w, n_windows, cover, sum);
+    if (w < (uint32_t)TILE && n_tiles > 1)
+        hipLaunchKernelGGL(k_window_edges, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const TilePart *)part, tm, n_tiles, w, cover, sum);
     return 0;
 }
 
