@@ -64,6 +64,8 @@ struct pd_runs {
     C8Sample view() const { return C8Sample{r8, bstart, bshift, n}; }
 };
 
+static inline size_t slice_flag_bytes(uint64_t n_tiles) { return (size_t)((n_tiles + 16 + 15) / 16 * 16); }
+
 struct pd_ctx {
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -479,7 +481,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     }
     c->n_half = (uint32_t)(c->n_cells / PD_HALF);
     CREATE_OK(hipMalloc(&c->hstate, c->n_half + 16));
-    CREATE_OK(hipMalloc(&c->slice_flags, c->n_tiles + 16));
+    CREATE_OK(hipMalloc(&c->slice_flags, slice_flag_bytes(c->n_tiles) + 16 + c->n_tiles * 4 + 16));   // flags | counter | list of flagged tiles
     CREATE_OK(hipMalloc(&c->direct_words, 64 + (c->n_tiles + 4) * 4));       // [n_long, fail, heavy_count, diagnostics ... | heavy tile list at +16]
     CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc) * PD_MAXPEND));
     CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
@@ -1698,7 +1700,7 @@ int pd_slice_sweep_i4(pd_ctx *c, const void *dev_parts, uint32_t n_parts, uint64
     { ProfScope ps(c, "slice_sweep");
       TileMap tm{c->d_tile_contig, c->d_off, c->d_len, nullptr};
       launch_sweep_i4(c->stream, dev_parts, n_parts, part_stride, (uint32_t)tile_first, (uint32_t)tile_count, dev_exc, exc_stride,
-                      dev_exc_counts, c->slice_flags, c->carry, mask, tm, w, min_dep, (TilePart *)dev_partials); }
+                      dev_exc_counts, c->slice_flags, slice_flag_bytes(c->n_tiles), c->carry, mask, tm, w, min_dep, (TilePart *)dev_partials); }
     HIPOK(c, hipGetLastError());
     return PD_OK;
 }

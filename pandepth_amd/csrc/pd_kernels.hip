@@ -2149,14 +2149,18 @@ struct I4Src {
 // five (the kernel waits for its one load per lane and part: residency is its throughput); PATCH = true: only the flagged tiles.
 template <bool PATCH>
 __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
-                                                 uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0)
+                                                 uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, const uint32_t *list,
+                                                 const uint32_t *n_list)
 {
     __shared__ int wtot[4];
     __shared__ int patch[PATCH ? TILE : 1];
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
-    const uint32_t i = blockIdx.x;
-    if ((src.flags && src.flags[i] != 0) != PATCH) return;       // workgroup-uniform
+    // PATCH: a few workgroups walk the list of the tiles that own exceptions (k_list_flagged); else one workgroup per tile
+    const uint32_t n_it = PATCH ? *n_list : blockIdx.x + 1;
+    for (uint32_t it = blockIdx.x; it < n_it; it += gridDim.x) {
+    const uint32_t i = PATCH ? list[it] : blockIdx.x;
+    if (!PATCH && src.flags && src.flags[i] != 0) return;        // workgroup-uniform
     const uint64_t t = (uint64_t)i + tile0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int a[32];
@@ -2232,6 +2236,102 @@ __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *car
         tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
         part[i] = tp;
     }
+    __syncthreads();
+    }
+}
+
+// the tiles of the slice whose flag is set, as a list
+__global__ __launch_bounds__(WG) void k_list_flagged(const uint8_t *flags, uint32_t n_tiles, uint32_t *list, uint32_t *count)
+{
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n_tiles; i += gridDim.x * WG)
+        if (flags[i]) list[atomicAdd(count, 1u)] = i;
+}
+
+// The same sweep with ONE WAVE PER TILE (tiles without exceptions, at most 16 parts): a lane owns 4 x 32 consecutive cells (the
+// 32 cells at lane * 32 of each of the tile's four 2048-cell quarters = one 16-byte load per quarter and part), the quarters are
+// swept in order with the running depth carried in a register — no barriers, no LDS, and four loads per part in flight per lane,
+// where the workgroup-per-tile form lived for one load's latency and three barriers per 4 KiB of image.
+__global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
+                                                      uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t tile_count)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (i >= tile_count) return;
+    if (src.flags && src.flags[i] != 0) return;                  // a tile with exceptions: k_sweep_i4<true>
+    const uint64_t t = (uint64_t)i + tile0;
+    const uint8_t *p = src.parts + (uint64_t)i * (TILE / 2) + (uint64_t)lane * 16;
+    // the parts are added as packed bytes (even / odd nibbles of each word widened to bytes: 16 parts fit, 15 * 16 < 256)
+    unsigned lo[4][4], hi[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { lo[q][m] = 0; hi[q][m] = 0; }
+    for (uint32_t j = 0; j < src.n_parts; ++j) {
+        uint4 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const uint4 *>(p + (uint64_t)j * src.stride + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned wd[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { lo[q][m] += wd[m] & 0x0F0F0F0Fu; hi[q][m] += (wd[m] >> 4) & 0x0F0F0F0Fu; }
+        }
+    }
+    const uint32_t ctg = tmap.tile_contig[t];
+    const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
+    const uint32_t clen = tmap.contig_len[ctg];
+    int base = carry[t];                                          // depth just before the quarter's first cell
+    int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
+    const bool any = local0 < clen;
+    const uint64_t k0 = any ? local0 / w : 0;
+    const uint64_t nb64 = (k0 + 1) * (uint64_t)w - local0;        // tile-local start of window k0 + 1
+    const uint32_t nb = nb64 < (uint64_t)TILE ? (uint32_t)nb64 : (uint32_t)TILE;
+    const uint32_t left = !any ? 0u : ((uint64_t)clen - local0 < (uint64_t)TILE ? (uint32_t)(clen - local0) : (uint32_t)TILE);   // cells of the contig in the tile
+    const int bias = -8 * (int)src.n_parts;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int a[32];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                a[8 * m + 2 * b] = bias + (int)((lo[q][m] >> (8 * b)) & 0xff);
+                a[8 * m + 2 * b + 1] = bias + (int)((hi[q][m] >> (8 * b)) & 0xff);
+            }
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { run += a[k]; a[k] = run; }
+        const int incl = wave_incl_scan(run);
+        const int b0 = base + incl - run;
+        const uint32_t pos0 = (uint32_t)(q * 2048 + lane * 32);
+        // a lane's 32 cells lie on one side of the window boundary and inside the contig, except in the one quarter of a tile that
+        // holds the boundary or the contig's end: there every cell is tested (wave-uniform branch), elsewhere none is
+        const bool plain = pos0 + 32u <= left && (pos0 + 32u <= nb || pos0 >= nb);
+        if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+            uint32_t cnt = 0; unsigned long long sm = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t d = (uint32_t)(a[k] + b0) & wrap_mask;
+                const bool ok = d >= min_dep;
+                cnt += ok ? 1u : 0u; sm += ok ? d : 0u;
+            }
+            const bool first = pos0 < nb;
+            c0 += first ? (int)cnt : 0; s0 += first ? sm : 0ull;
+            c1 += first ? 0 : (int)cnt; s1 += first ? 0ull : sm;
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t pos = pos0 + k;
+                const uint32_t d = (uint32_t)(a[k] + b0) & wrap_mask;
+                if (pos < left && d >= min_dep) { if (pos < nb) { ++c0; s0 += d; } else { ++c1; s1 += d; } }
+            }
+        }
+        base += __builtin_amdgcn_readlane(incl, 63);
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (lane == 0) { TilePart tp; tp.c0 = (uint32_t)c0; tp.c1 = (uint32_t)c1; tp.s0 = s0; tp.s1 = s1; part[i] = tp; }
 }
 
 __global__ __launch_bounds__(WG) void k_add_i32(int4 *dst, const int4 *src, size_t n16)
@@ -2283,19 +2383,29 @@ void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, 
 }
 
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
-                     uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags,
+                     uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes,
                      const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part)
 {
     if (!tile_count) return;
     const bool with_exc = exc && exc_counts && exc_stride && flags;
+    // behind the flags (one byte per tile of the buffer): a counter and the list of the flagged tiles of this slice
+    uint32_t *n_list = with_exc ? reinterpret_cast<uint32_t *>(flags + flags_bytes) : nullptr, *list = with_exc ? n_list + 4 : nullptr;
     if (with_exc) {
         (void)hipMemsetAsync(flags, 0, tile_count, st);
+        (void)hipMemsetAsync(n_list, 0, 16, st);
         hipLaunchKernelGGL(k_flag_exception_tiles, dim3(64, n_parts), dim3(WG), 0, st, exc, exc_stride, exc_counts,
                            (uint64_t)tile_first, (uint64_t)tile_count, flags);
+        hipLaunchKernelGGL(k_list_flagged, dim3(256), dim3(WG), 0, st, (const uint8_t *)flags, tile_count, list, n_list);
     }
     I4Src src{(const uint8_t *)parts, stride, n_parts, with_exc ? flags : nullptr, exc, exc_stride, exc_counts};
-    hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
-    if (with_exc) hipLaunchKernelGGL(k_sweep_i4<true>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first);
+    if (n_parts <= 16)
+        hipLaunchKernelGGL(k_sweep_i4_wave, dim3((tile_count + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count);
+    else
+        hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    if (with_exc)
+        hipLaunchKernelGGL(k_sweep_i4<true>, dim3(512), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, (const uint32_t *)list,
+                           (const uint32_t *)n_list);
 }
 
 void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
