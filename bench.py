@@ -20,7 +20,7 @@ A "step" is ONE whole pass of the hot path over one sample's run stream, whole-c
                                   are also run after the timed region: their kernel figures are reported under
                                   "arrays_path" and their results must equal the direct path's.
     [N > 1, instead of the last]  the samples' difference arrays are summed SLICED (pd_comm_init + pd_sliced_sum_start / _finish:
-                                  RCCL issued inside the library; PD_BENCH_SUM=sliced_torch: pandepth_amd.multi.SlicedSum):
+                                  RCCL issued inside the library; PD_BENCH_SUM=sliced_torch: tools/multi_torch.py's SlicedSum):
                                   4-bit image (pd_export_i4; packed straight from the tile windows in LDS, the arrays
                                   are not written on any rank), all-to-all over RCCL so that every xGMI link of a
                                   GPU carries 1/N of it at once, every rank sums + sweeps its 1/N of the tiles
@@ -477,7 +477,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pandepth_amd as pda
-    from pandepth_amd import multi
+    from tools import multi_torch as multi      # torch.distributed forms of the sum, kept for comparison (PD_BENCH_SUM=sliced_torch|int8|int32)
     from tools import synth
 
     rank = int(os.environ.get("RANK", "0"))

@@ -288,7 +288,7 @@ def test_buffer_view_is_zero_copy_and_linear():
     """The multi-BAM path sums accumulating buffers with a collective on a torch view of the engine's
     memory: adding one engine's buffer into another's must equal pushing both samples into one."""
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     rng = np.random.default_rng(12)
     a = sort_iv(rand_intervals(rng, LENS, 60000))
     b = rand_intervals(rng, LENS, 60000)
@@ -311,7 +311,7 @@ def test_int8_transport_of_difference_arrays(world):
     """pd_export_i8 / pd_import_i8: summing the int8 images (+ exceptions) of several samples and
     importing the result equals pushing every sample into one context (list mode, PD:2704-3014)."""
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(30 + world)
     samples = []
@@ -357,7 +357,7 @@ def test_int8_transport_of_difference_arrays(world):
 
 def test_packed_sum_single_rank_roundtrip():
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     rng = np.random.default_rng(41)
     iv = np.concatenate([rand_intervals(rng, LENS, 50000), np.tile(np.array([[0, 10, 50]], dtype=np.int32), (1000, 1))])
     d, off = oracle_depth(LENS, iv)
@@ -414,7 +414,7 @@ def test_sliced_sum_kernels_manual_exchange(world, w, min_dep):
     "rank" -> pd_gather_windows on the root  ==  pd_scan_reduce_windows(18-bit) on one context that
     received every sample (list mode, PD:2704-3014), and == the oracle's per-base increments."""
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(70 + world)
     samples = _sliced_samples(rng, world)
@@ -471,7 +471,7 @@ def test_sliced_sum_kernels_manual_exchange(world, w, min_dep):
 @pytest.mark.parametrize("mode", ["engine", "sync"])
 def test_sliced_sum_single_rank(mode):
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     rng = np.random.default_rng(81)
     iv = np.concatenate([rand_intervals(rng, LENS, 50000), np.tile(np.array([[0, 10, 50]], dtype=np.int32), (1000, 1))])
     d, off = oracle_depth(LENS, iv, True)
@@ -498,7 +498,7 @@ def test_sliced_sum_one_rank_rccl_group(tmp_path):
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
 import pandepth_amd as pda
-from pandepth_amd import multi
+from tools import multi_torch as multi
 from test_gpu_engine import LENS, rand_intervals, oracle_depth, windows_ref
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29877", RANK="0", WORLD_SIZE="1")
 torch.cuda.set_device(0)
@@ -641,7 +641,7 @@ def test_direct_export_equals_export_of_the_arrays():
     """pd_export_i4 on a deferred sample ("direct_windows"): image, exception set and tile sums straight from the tile windows
     must equal what the materialising path exports; runs the sliced finish on them too"""
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(401)
     first, other = _split_streams(rng, LENS, 90000)
@@ -950,7 +950,7 @@ def test_compact_export_equals_export_of_the_arrays():
     """pd_export_i4 on a compact deferred sample (k_direct_c8's export instantiation, 16-byte image stores): image, exception set
     and tile sums equal to what the materialising path exports; the sample stays deferred."""
     import torch
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     dev = torch.device("cuda", 0)
     first, other = _hard_sample(402)
     ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)

@@ -1,6 +1,6 @@
 """world_size-2 CPU (gloo) coverage of the multi-BAM path: each rank builds the accumulating
 buffer of its own sample (difference arrays + tile sums, same layout as the engine), the buffers
-are summed with pandepth_amd.multi.sum_to_root, the root prefix-sums with the 18-bit wrap of list
+are summed with tools/multi_torch.py: sum_to_root, the root prefix-sums with the 18-bit wrap of list
 mode — and must equal the oracle's per-base increments over BOTH samples (PD:2704-3014)."""
 import os
 import sys
@@ -38,7 +38,7 @@ def sample_runs(seed, n=40000, pile=0):
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -77,7 +77,7 @@ def _worker(rank, world, port, out):
 
 class FakeEngine:
     """CPU stand-in with the engine's export/import contract (pd_export_i8 / pd_import_i8), so that
-    pandepth_amd.multi.PackedSum's collective protocol can run under gloo."""
+    tools/multi_torch.py: PackedSum's collective protocol can run under gloo."""
 
     def __init__(self, buf, n_cells):
         self.buf, self.n_cells, self.reg = buf, n_cells, {}
@@ -109,7 +109,7 @@ class FakeEngine:
 def _worker_packed(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -181,7 +181,7 @@ def test_sum_of_difference_arrays_equals_list_mode():
 
 
 # ---------------------------------------------------------------------------------------------
-# sliced sum (pandepth_amd.multi.SlicedSum): all-to-all of 4-bit images, every rank sweeps its slice
+# sliced sum (tools/multi_torch.py: SlicedSum): all-to-all of 4-bit images, every rank sweeps its slice
 # ---------------------------------------------------------------------------------------------
 PART = np.dtype([("c0", "<u4"), ("c1", "<u4"), ("s0", "<u8"), ("s1", "<u8")])      # PD_TILE_PARTIAL_BYTES = 24
 
@@ -280,7 +280,7 @@ class FakeSliceEngine:
 def _worker_sliced(rank, world, port, out, lens, pipelined):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pandepth_amd import multi
+    from tools import multi_torch as multi
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

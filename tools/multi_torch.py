@@ -1,4 +1,8 @@
-"""Multi-GPU plumbing for the `#.list` path: one sample (BAM) per GPU, then ONE sum of the
+"""TEST AND MEASUREMENT TOOLING, not part of the product (the product's multi-GPU sum is C++ inside libpandepth_amd.so:
+pd_comm_*, pd_sliced_sum_start / _finish, csrc/pd_capi.hip).  The same protocols written with torch.distributed: the world_size-2
+gloo tests drive them on the CPU, bench.py keeps them as comparison modes.
+
+Multi-GPU plumbing for the `#.list` path: one sample (BAM) per GPU, then ONE sum of the
 accumulating buffers (difference arrays + tile sums are contiguous int32, include/pandepth_amd.h
 pd_device_buffer) over RCCL/xGMI, scan on the root.  Difference arrays are linear, so summing them
 before the prefix sum equals the reference's sequential accumulation of every file into one array
