@@ -198,6 +198,15 @@ typedef struct pd_text pd_text;
 int pd_text_open(pd_ctx *ctx, size_t capacity, pd_text **out);
 int pd_text_close(pd_text *t);
 int pd_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const char *name, size_t name_len, uint64_t *n_bytes);
+/* The rows of the `-w` table (PD:4381-4388: "<name>\t<start>\t<end>\t<length>\t<covered>\t<depth>\t<coverage>\t<mean>\n", depth being the
+ * reference's `int`, the last two columns what printf("%.2f") prints for covered * 100.0 / length and depth * 1.0 / length) for windows
+ * [row_first, row_first + n_rows) of contig tid, formatted from the statistics that the last pd_scan_reduce_windows / pd_reduce_windows
+ * call with this `w` left on the device (they stay there until the next window call or pd_reset; PD_ESTATE otherwise).  The reference
+ * drops a contig's final window when it holds one base only: the caller does not ask for that row.  pd_text_append_bytes puts host
+ * bytes (the table's header and total lines) into the stream. */
+int pd_text_append_window_rows(pd_text *t, int32_t tid, uint32_t w, uint64_t row_first, size_t n_rows, const char *name, size_t name_len,
+                               uint64_t *n_bytes);
+int pd_text_append_bytes(pd_text *t, const void *bytes, size_t n);
 int pd_text_parse(pd_text *t, uint64_t off, size_t n_text, const pd_lz_chunk *chunks, uint32_t n_chunks,
                   uint32_t *syms, size_t syms_cap, uint64_t *sym_off, uint32_t *crc, uint64_t crc_span);
 int pd_text_read(pd_text *t, uint64_t off, size_t n, void *out);

@@ -77,6 +77,8 @@ def load():
         "pd_text_parse": (I, [P, ctypes.c_uint64, SZ, P, ctypes.c_uint32, P, SZ, P, P, ctypes.c_uint64]),
         "pd_text_read": (I, [P, ctypes.c_uint64, SZ, P]),
         "pd_text_release": (I, [P, ctypes.c_uint64]),
+        "pd_text_append_window_rows": (I, [P, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, SZ, ctypes.c_char_p, SZ, ctypes.POINTER(ctypes.c_uint64)]),
+        "pd_text_append_bytes": (I, [P, P, SZ]),
         "pd_device_buffer": (I, [P, ctypes.POINTER(P), ctypes.POINTER(U64), P]),
         "pd_device_count": (I, [ctypes.POINTER(I)]),
         "pd_accumulate_from": (I, [P, P]),
@@ -114,7 +116,7 @@ def load():
 EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset", "pd_push_intervals",
            "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
-           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
+           "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_text_append_window_rows", "pd_text_append_bytes", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
@@ -440,6 +442,16 @@ class TextStream:
         got = ctypes.c_uint64()
         self.e._ck(self.e.L.pd_text_append_sites(self.h, int(tid), int(beg), int(n), nm, len(nm), ctypes.byref(got)))
         return int(got.value)
+
+    def append_window_rows(self, tid, w, row_first, n_rows, name):
+        nm = name.encode() if isinstance(name, str) else bytes(name)
+        got = ctypes.c_uint64()
+        self.e._ck(self.e.L.pd_text_append_window_rows(self.h, int(tid), int(w), int(row_first), int(n_rows), nm, len(nm), ctypes.byref(got)))
+        return int(got.value)
+
+    def append_bytes(self, data):
+        b = np.frombuffer(bytes(data), dtype=np.uint8)
+        self.e._ck(self.e.L.pd_text_append_bytes(self.h, _ptr(b) if b.size else None, b.size))
 
     def parse(self, off, n, chunks, crc_span):
         ch = np.ascontiguousarray(np.asarray(chunks, dtype=np.uint64).reshape(-1, 3))

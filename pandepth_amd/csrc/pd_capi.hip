@@ -137,6 +137,8 @@ struct pd_ctx {
         std::mutex mu;
     } lz[2];
     std::atomic<unsigned> lz_turn{0};
+    // the statistics of the last window call stay on the device (pd_text_append_window_rows formats the table's rows from them)
+    unsigned char *wk = nullptr; size_t wk_bytes = 0; uint32_t wk_w = 0; uint64_t wk_nw = 0; bool wk_valid = false; std::vector<uint64_t> wk_woff;
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -525,7 +527,7 @@ int pd_destroy(pd_ctx *c)
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
-                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->direct_words, c->desc, c->chk, c->ovf, c->scratch};
+                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->direct_words, c->desc, c->chk, c->ovf, c->scratch, c->wk};
     t1 = dec_now_us();
     for (void *p : ptrs) if (p) (void)hipFree(p);
     t2 = dec_now_us();
@@ -559,6 +561,7 @@ int pd_reset(pd_ctx *c)
 {
     if (!c) return PD_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
+    c->wk_valid = false;
     HIPOK(c, hipSetDevice(c->device));
     // deferred batches are forgotten with everything else (they used to be scattered first, a whole-genome pass for nothing);
     // their staging slots are free once the stream has passed this point
@@ -787,6 +790,17 @@ int pd_window_layout(const pd_ctx *c, uint32_t w, uint64_t *win_off)
     return PD_OK;
 }
 
+static int win_keep_fit(pd_ctx *c, size_t bytes)
+{
+    c->wk_valid = false;
+    if (bytes <= c->wk_bytes) return PD_OK;
+    if (c->wk) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(c->wk)); c->wk = nullptr; c->wk_bytes = 0; }
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&c->wk, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "window statistics: device allocation failed"); }
+    c->wk_bytes = want;
+    return PD_OK;
+}
+
 static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask, bool from_depth,
                           uint32_t *cover, uint64_t *sum)
 {
@@ -796,16 +810,19 @@ static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
     const size_t b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
     const size_t b_part = (size_t)c->n_tiles * sizeof(TilePart);      // wide windows: every tile's shares; narrow ones: the shares of the windows across tile boundaries
-    int rc = ensure_scratch(c, b_off + b_sum + b_cov + b_part + 64);
+    const size_t b_offr = (b_off + 15) / 16 * 16;
+    int rc = ensure_scratch(c, b_offr + b_part + 64);
+    if (rc) return rc;
+    rc = win_keep_fit(c, b_sum + b_cov + 64);
     if (rc) return rc;
     unsigned char *s = (unsigned char *)c->scratch;
     uint64_t *d_wo = (uint64_t *)s;
-    unsigned long long *d_sum = (unsigned long long *)(s + b_off);
-    uint32_t *d_cov = (uint32_t *)(s + b_off + b_sum);
-    TilePart *d_part = (TilePart *)(s + b_off + b_sum + b_cov);
+    unsigned long long *d_sum = (unsigned long long *)c->wk;
+    uint32_t *d_cov = (uint32_t *)(c->wk + b_sum);
+    TilePart *d_part = (TilePart *)(s + b_offr);
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
-    if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // edge windows are accumulated
+    if (w < PD_TILE) HIPOK(c, hipMemsetAsync(d_sum, 0, b_sum + b_cov, c->stream));   // windows nobody writes stay zero
     if (!from_depth) { ProfScope ps(c, "tile_carry"); launch_tile_carry(c->stream, c->sums, c->bsum, c->carry, (uint32_t)c->n_tiles); }
     {
         ProfScope ps(c, from_depth ? "reduce_windows" : "scan_reduce_windows");
@@ -818,6 +835,7 @@ static int windows_common(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     HIPOK(c, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipMemcpyAsync(cover, d_cov, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
+    c->wk_w = w; c->wk_nw = nw; c->wk_woff = wo; c->wk_valid = true;
     return PD_OK;
 }
 
@@ -835,13 +853,16 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     const size_t b_off = ((size_t)c->n_contigs + 1) * 8;
     const size_t b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
     const size_t b_part = (size_t)c->n_tiles * sizeof(TilePart);
-    int rc = ensure_scratch(c, b_off + b_sum + b_cov + b_part + 64);
+    const size_t b_offr = (b_off + 15) / 16 * 16;
+    int rc = ensure_scratch(c, b_offr + b_part + 64);
+    if (rc) return rc;
+    rc = win_keep_fit(c, b_sum + b_cov + 64);
     if (rc) return rc;
     unsigned char *s = (unsigned char *)c->scratch;
     uint64_t *d_wo = (uint64_t *)s;
-    unsigned long long *d_sum = (unsigned long long *)(s + b_off);
-    uint32_t *d_cov = (uint32_t *)(s + b_off + b_sum);
-    TilePart *d_part = (TilePart *)(s + b_off + b_sum + b_cov);
+    unsigned long long *d_sum = (unsigned long long *)c->wk;
+    uint32_t *d_cov = (uint32_t *)(c->wk + b_sum);
+    TilePart *d_part = (TilePart *)(s + b_offr);
     HIPOK(c, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));          // wo is a local
     HIPOK(c, hipMemsetAsync(c->direct_words, 0, 64, c->stream));
@@ -895,6 +916,7 @@ static int direct_windows(pd_ctx *c, uint32_t w, uint32_t min_dep, uint32_t mask
     }
     // the call READ the sample: it stays deferred (like pd_export_i4's direct form), every other call still works on it
     *done = true;
+    c->wk_w = w; c->wk_nw = nw; c->wk_woff = wo; c->wk_valid = true;
     return PD_OK;
 }
 
@@ -1866,6 +1888,38 @@ int pd_deflate_parse(pd_ctx *c, const void *text, size_t n_text, const pd_lz_chu
     return lz_run(c, text, nullptr, 0, n_text, chunks, n_chunks, syms, syms_cap, sym_off, nullptr, 0);
 }
 
+// (the callers hold the context's lock)
+static int text_scratch(pd_text *t, size_t bytes)
+{
+    pd_ctx *c = t->ctx;
+    if (t->scratch_bytes >= bytes) return PD_OK;
+    if (t->scratch) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(t->scratch)); t->scratch = nullptr; t->scratch_bytes = 0; }
+    const size_t want = bytes * 2;
+    if (hipMalloc(&t->scratch, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_text: device allocation failed"); }
+    t->scratch_bytes = want;
+    return PD_OK;
+}
+// a place for `total` bytes in the ring: behind the last segment, or at the ring's start once that end is free again
+static int text_place(pd_text *t, uint64_t total, size_t *phys, const char *who)
+{
+    pd_ctx *c = t->ctx;
+    std::lock_guard<std::mutex> tlk(t->mu);
+    if (total > t->cap) return fail(c, PD_EINVAL, std::string(who) + ": more bytes than the stream's capacity");
+    if (t->segs.empty()) { t->phys_tail = 0; *phys = 0; return PD_OK; }
+    const size_t head = t->segs.front().phys;
+    if (t->phys_tail >= head) {                                // live bytes in [head, tail)
+        if (t->phys_tail + total <= t->cap) { *phys = t->phys_tail; return PD_OK; }
+        if (total < head) { *phys = 0; return PD_OK; }
+    } else if (t->phys_tail + total < head) { *phys = t->phys_tail; return PD_OK; }   // wrapped: live bytes in [head, ...) and [0, tail)
+    return fail(c, PD_ERANGE, std::string(who) + ": the stream is full (release what has been consumed)");
+}
+static void text_commit(pd_text *t, size_t phys, uint64_t total)
+{
+    std::lock_guard<std::mutex> tlk(t->mu);
+    t->segs.push_back(pd_text::Seg{t->tail_off, phys, (size_t)total});
+    t->tail_off += total; t->phys_tail = phys + (size_t)total;
+}
+
 // ---- a text stream in HBM: the per-site rows are formatted, parsed and check-summed where the cells are ----
 int pd_text_open(pd_ctx *c, size_t capacity, pd_text **out)
 {
@@ -1910,12 +1964,7 @@ int pd_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const 
     HIPOK(c, hipSetDevice(c->device));
     const uint32_t nb = pdk::site_rows_blocks(n);
     const size_t b_name = (name_len + 15) / 16 * 16 + 16, b_cnt = ((size_t)nb * 4 + 15) / 16 * 16, b_off = ((size_t)nb + 1) * 8;
-    if (t->scratch_bytes < b_name + b_cnt + b_off) {
-        if (t->scratch) { HIPOK(c, hipStreamSynchronize(c->stream)); HIPOK(c, hipFree(t->scratch)); t->scratch = nullptr; t->scratch_bytes = 0; }
-        const size_t want = (b_name + b_cnt + b_off) * 2;
-        if (hipMalloc(&t->scratch, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_text_append_sites: device allocation failed"); }
-        t->scratch_bytes = want;
-    }
+    if (int rs = text_scratch(t, b_name + b_cnt + b_off)) return rs;
     unsigned char *s = (unsigned char *)t->scratch;
     char *d_name = (char *)s; uint32_t *d_cnt = (uint32_t *)(s + b_name); uint64_t *d_off = (uint64_t *)(s + b_name + b_cnt);
     ProfScope ps(c, "format_sites");
@@ -1927,34 +1976,67 @@ int pd_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, const 
     HIPOK(c, hipMemcpyAsync(&total, d_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     HIPOK(c, hipGetLastError());
-    // a place in the ring: behind the last segment, or at the ring's start once that end is free again
     size_t phys = 0;
-    {
-        std::lock_guard<std::mutex> tlk(t->mu);
-        if (total > t->cap) return fail(c, PD_EINVAL, "pd_text_append_sites: the rows do not fit the stream's capacity");
-        if (t->segs.empty()) { t->phys_tail = 0; phys = 0; }
-        else {
-            const size_t head = t->segs.front().phys;
-            if (t->phys_tail >= head) {                        // live bytes in [head, tail)
-                if (t->phys_tail + total <= t->cap) phys = t->phys_tail;
-                else if (total < head) phys = 0;
-                else return fail(c, PD_ERANGE, "pd_text_append_sites: the stream is full (release what has been consumed)");
-            } else {                                           // wrapped: live bytes in [head, ...) and [0, tail)
-                if (t->phys_tail + total < head) phys = t->phys_tail;
-                else return fail(c, PD_ERANGE, "pd_text_append_sites: the stream is full (release what has been consumed)");
-            }
-        }
-    }
+    if (int rp = text_place(t, total, &phys, "pd_text_append_sites")) return rp;
     // pass 2: the bytes
     pdk::launch_site_rows(c->stream, depth, beg, n, (uint32_t)name_len, d_name, d_cnt, d_off, (char *)t->ring + phys, true);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
-    {
-        std::lock_guard<std::mutex> tlk(t->mu);
-        t->segs.push_back(pd_text::Seg{t->tail_off, phys, (size_t)total});
-        t->tail_off += total; t->phys_tail = phys + (size_t)total;
-    }
+    text_commit(t, phys, total);
     *n_bytes = total;
+    return PD_OK;
+}
+
+int pd_text_append_window_rows(pd_text *t, int32_t tid, uint32_t w, uint64_t row_first, size_t n_rows, const char *name, size_t name_len, uint64_t *n_bytes)
+{
+    if (!t || !n_bytes || (!name && name_len) || !w) return PD_EINVAL;
+    *n_bytes = 0;
+    pd_ctx *c = t->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->wk_valid || c->wk_w != w) return fail(c, PD_ESTATE, "pd_text_append_window_rows: the last window call (pd_scan_reduce_windows / pd_reduce_windows) was not for this width");
+    if (tid < 0 || tid >= c->n_contigs) return fail(c, PD_EINVAL, "pd_text_append_window_rows: contig id out of range");
+    const uint64_t rows_here = c->wk_woff[(size_t)tid + 1] - c->wk_woff[(size_t)tid];
+    if (row_first > rows_here || n_rows > rows_here - row_first) return fail(c, PD_EINVAL, "pd_text_append_window_rows: rows beyond the contig's windows");
+    if (name_len > 4096 || n_rows > ((size_t)1 << 27)) return fail(c, PD_EINVAL, "pd_text_append_window_rows: at most 2^27 rows per call and 4096 bytes of name");
+    if (n_rows == 0) return PD_OK;
+    HIPOK(c, hipSetDevice(c->device));
+    const uint32_t nb = pdk::window_rows_blocks(n_rows);
+    const size_t b_name = (name_len + 15) / 16 * 16 + 16, b_cnt = ((size_t)nb * 4 + 15) / 16 * 16, b_off = ((size_t)nb + 1) * 8;
+    if (int rs = text_scratch(t, b_name + b_cnt + b_off)) return rs;
+    unsigned char *s = (unsigned char *)t->scratch;
+    char *d_name = (char *)s; uint32_t *d_cnt = (uint32_t *)(s + b_name); uint64_t *d_off = (uint64_t *)(s + b_name + b_cnt);
+    ProfScope ps(c, "format_window_rows");
+    if (name_len) HIPOK(c, hipMemcpyAsync(d_name, name, name_len, hipMemcpyHostToDevice, c->stream));
+    const uint64_t g0 = c->wk_woff[(size_t)tid] + row_first;
+    const unsigned long long *d_sum = (const unsigned long long *)c->wk + g0;
+    const uint32_t *d_cov = (const uint32_t *)(c->wk + (size_t)c->wk_nw * 8) + g0;
+    pdk::launch_window_rows(c->stream, d_cov, d_sum, row_first, n_rows, w, c->len[(size_t)tid], (uint32_t)name_len, d_name, d_cnt, d_off, nullptr, false);
+    uint64_t total = 0;
+    HIPOK(c, hipMemcpyAsync(&total, d_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    HIPOK(c, hipGetLastError());
+    size_t phys = 0;
+    if (int rp = text_place(t, total, &phys, "pd_text_append_window_rows")) return rp;
+    pdk::launch_window_rows(c->stream, d_cov, d_sum, row_first, n_rows, w, c->len[(size_t)tid], (uint32_t)name_len, d_name, d_cnt, d_off, (char *)t->ring + phys, true);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    text_commit(t, phys, total);
+    *n_bytes = total;
+    return PD_OK;
+}
+
+int pd_text_append_bytes(pd_text *t, const void *bytes, size_t n)
+{
+    if (!t || (!bytes && n)) return PD_EINVAL;
+    if (!n) return PD_OK;
+    pd_ctx *c = t->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPOK(c, hipSetDevice(c->device));
+    size_t phys = 0;
+    if (int rp = text_place(t, n, &phys, "pd_text_append_bytes")) return rp;
+    HIPOK(c, hipMemcpyAsync(t->ring + phys, bytes, n, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    text_commit(t, phys, n);
     return PD_OK;
 }
 

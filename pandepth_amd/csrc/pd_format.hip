@@ -98,6 +98,117 @@ __global__ __launch_bounds__(FWG) void k_site_scan(const uint32_t *blk_bytes, ui
     }
     if (threadIdx.x == 0) blk_off[n_blk] = carry;
 }
+
+// ---- rows of the `-w` table (PD:4381-4388): "<name>\t<start>\t<end>\t<length>\t<covered>\t<depth>\t<coverage %.2f>\t<mean %.2f>\n" ----
+// One row per thread.  The two %.2f columns are what glibc's correctly rounded printf prints for the doubles the reference computes
+// (covered * 100.0 / length and depth * 1.0 / length, depth being the reference's `int`): the double is M * 2^e exactly, so the value
+// times 100 is (M * 100) >> -e with an exact remainder, rounded half to even (host/report.cpp: fmt2_to — the same arithmetic).
+struct Fmt2 { uint64_t ip; uint32_t fp; bool neg; };
+__device__ __forceinline__ Fmt2 fmt2_of(double v)
+{
+    uint64_t bits = (uint64_t)__double_as_longlong(v);
+    Fmt2 r; r.neg = (bits >> 63) != 0;
+    bits &= ~(1ull << 63);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e;
+    if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
+    const uint64_t n = m * 100ull;                                // < 2^60 (|v| < 2^52 for every table value)
+    const int sh = -e;
+    uint64_t q = 0;
+    if (sh < 64) {
+        q = n >> sh;
+        const uint64_t rem = n & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1ull))) ++q;
+    }
+    r.ip = q / 100ull; r.fp = (uint32_t)(q % 100ull);
+    return r;
+}
+__device__ __forceinline__ uint32_t dec_digits64(uint64_t v)
+{
+    uint32_t n = 1;
+    while (v >= 10ull) { v /= 10ull; ++n; }
+    return n;
+}
+__device__ __forceinline__ char *put_dec64(char *p, uint64_t v, uint32_t nd)   // writes nd digits at p, returns p + nd
+{
+    char *e = p + nd;
+    for (uint32_t k = 0; k < nd; ++k) { const uint64_t q = v / 10ull; *--e = (char)('0' + (uint32_t)(v - q * 10ull)); v = q; }
+    return p + nd;
+}
+__device__ __forceinline__ uint32_t fmt2_len(const Fmt2 &f) { return (f.neg ? 1u : 0u) + dec_digits64(f.ip) + 3u; }
+__device__ __forceinline__ char *put_fmt2(char *p, const Fmt2 &f)
+{
+    if (f.neg) *p++ = '-';
+    p = put_dec64(p, f.ip, dec_digits64(f.ip));
+    *p++ = '.'; *p++ = (char)('0' + f.fp / 10u); *p++ = (char)('0' + f.fp % 10u);
+    return p;
+}
+
+constexpr int WPER = 4;                                         // rows per thread
+constexpr uint32_t WBLK = FWG * WPER;
+
+template <bool WRITE>
+__global__ __launch_bounds__(FWG) void k_window_rows(const uint32_t *cover, const unsigned long long *sum, uint64_t row_first, uint64_t n_rows, uint32_t w,
+                                                    uint32_t clen, uint32_t name_len, const char *name, uint32_t *blk_bytes, const uint64_t *blk_off,
+                                                    char *text)
+{
+    __shared__ uint32_t wsum[FWG / 64];
+    const uint64_t r0 = (uint64_t)blockIdx.x * WBLK + (uint64_t)threadIdx.x * WPER;
+    uint32_t len[WPER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < WPER; ++k) {
+        const uint64_t r = r0 + k;
+        len[k] = 0;
+        if (r < n_rows) {
+            const uint64_t row = row_first + r;
+            const int64_t j = 1 + (int64_t)row * w;
+            int64_t end = j - 1 + w; if (end > (int64_t)clen) end = clen;
+            const int64_t L = end - j + 1;
+            const int32_t c = (int32_t)cover[r], d = (int32_t)sum[r];          // `int GeneDepth` (PD:4364)
+            const Fmt2 f1 = fmt2_of(c * 100.0 / (double)L), f2 = fmt2_of(d * 1.0 / (double)L);
+            len[k] = name_len + 8u + dec_digits64((uint64_t)j) + dec_digits64((uint64_t)end) + dec_digits64((uint64_t)L) +
+                     (c < 0 ? 1u : 0u) + dec_digits64((uint64_t)(c < 0 ? -(int64_t)c : (int64_t)c)) +
+                     (d < 0 ? 1u : 0u) + dec_digits64((uint64_t)(d < 0 ? -(int64_t)d : (int64_t)d)) + fmt2_len(f1) + fmt2_len(f2);
+        }
+        mine += len[k];
+    }
+    const uint32_t incl = wave_incl_scan_u32(mine);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    if (!WRITE) {
+        if (threadIdx.x == FWG - 1) blk_bytes[blockIdx.x] = base + mine;
+        return;
+    }
+    char *p = text + blk_off[blockIdx.x] + base;
+#pragma unroll 1
+    for (int k = 0; k < WPER; ++k) {
+        if (!len[k]) break;
+        const uint64_t r = r0 + k, row = row_first + r;
+        const int64_t j = 1 + (int64_t)row * w;
+        int64_t end = j - 1 + w; if (end > (int64_t)clen) end = clen;
+        const int64_t L = end - j + 1;
+        const int32_t c = (int32_t)cover[r], d = (int32_t)sum[r];
+        const Fmt2 f1 = fmt2_of(c * 100.0 / (double)L), f2 = fmt2_of(d * 1.0 / (double)L);
+        char *q = p;
+        for (uint32_t x = 0; x < name_len; ++x) q[x] = name[x];
+        q += name_len;
+        *q++ = '\t'; q = put_dec64(q, (uint64_t)j, dec_digits64((uint64_t)j));
+        *q++ = '\t'; q = put_dec64(q, (uint64_t)end, dec_digits64((uint64_t)end));
+        *q++ = '\t'; q = put_dec64(q, (uint64_t)L, dec_digits64((uint64_t)L));
+        *q++ = '\t'; if (c < 0) *q++ = '-';
+        { const uint64_t a = (uint64_t)(c < 0 ? -(int64_t)c : (int64_t)c); q = put_dec64(q, a, dec_digits64(a)); }
+        *q++ = '\t'; if (d < 0) *q++ = '-';
+        { const uint64_t a = (uint64_t)(d < 0 ? -(int64_t)d : (int64_t)d); q = put_dec64(q, a, dec_digits64(a)); }
+        *q++ = '\t'; q = put_fmt2(q, f1);
+        *q++ = '\t'; q = put_fmt2(q, f2);
+        *q = '\n';
+        p += len[k];
+    }
+}
 } // namespace
 
 uint32_t site_rows_blocks(uint64_t n) { return (uint32_t)((n + FBLK - 1) / FBLK); }
@@ -114,4 +225,19 @@ void launch_site_rows(hipStream_t st, const uint32_t *depth, uint32_t first_inde
         hipLaunchKernelGGL((k_site_rows<true>), dim3(nb), dim3(FWG), 0, st, depth, first_index, n, name_len, dev_name, blk_bytes, blk_off, text);
     }
 }
+uint32_t window_rows_blocks(uint64_t n) { return (uint32_t)((n + WBLK - 1) / WBLK); }
+
+void launch_window_rows(hipStream_t st, const uint32_t *cover, const unsigned long long *sum, uint64_t row_first, uint64_t n_rows, uint32_t w, uint32_t clen,
+                        uint32_t name_len, const char *dev_name, uint32_t *blk_bytes, uint64_t *blk_off, char *text, bool write)
+{
+    const uint32_t nb = window_rows_blocks(n_rows);
+    if (!nb) return;
+    if (!write) {
+        hipLaunchKernelGGL((k_window_rows<false>), dim3(nb), dim3(FWG), 0, st, cover, sum, row_first, n_rows, w, clen, name_len, dev_name, blk_bytes, blk_off, text);
+        hipLaunchKernelGGL(k_site_scan, dim3(1), dim3(FWG), 0, st, blk_bytes, nb, blk_off);
+    } else {
+        hipLaunchKernelGGL((k_window_rows<true>), dim3(nb), dim3(FWG), 0, st, cover, sum, row_first, n_rows, w, clen, name_len, dev_name, blk_bytes, blk_off, text);
+    }
+}
+
 } // namespace pdk

@@ -141,6 +141,10 @@ void launch_lz_crc(hipStream_t st, const uint8_t *text, const uint64_t *chunks, 
 // per-site text rows (pd_format.hip)
 namespace pdk {
 uint32_t site_rows_blocks(uint64_t n);
+uint32_t window_rows_blocks(uint64_t n);
+// rows of the `-w` table for windows [row_first, row_first + n_rows) of one contig; cover / sum point at the first of them
+void launch_window_rows(hipStream_t st, const uint32_t *cover, const unsigned long long *sum, uint64_t row_first, uint64_t n_rows, uint32_t w, uint32_t clen,
+                        uint32_t name_len, const char *dev_name, uint32_t *blk_bytes, uint64_t *blk_off, char *text, bool write);
 void launch_site_rows(hipStream_t st, const uint32_t *depth, uint32_t first_index, uint64_t n, uint32_t name_len, const char *dev_name,
                       uint32_t *blk_bytes, uint64_t *blk_off, char *text, bool write);
 }

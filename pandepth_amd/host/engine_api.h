@@ -58,6 +58,8 @@ typedef struct pd_engine_api {
     int (*text_parse)(pd_text *, uint64_t, size_t, const pd_lz_chunk *, uint32_t, uint32_t *, size_t, uint64_t *, uint32_t *, uint64_t);
     int (*text_read)(pd_text *, uint64_t, size_t, void *);
     int (*text_release)(pd_text *, uint64_t);
+    int (*text_append_window_rows)(pd_text *, int32_t, uint32_t, uint64_t, size_t, const char *, size_t, uint64_t *);
+    int (*text_append_bytes)(pd_text *, const void *, size_t);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

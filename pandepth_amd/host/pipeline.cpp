@@ -816,6 +816,80 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
     return rc;
 }
 
+// The `-w` table (PD:4366-4389) with its text resident on the device: the engine formats the rows from the window statistics its
+// last window call left in HBM (pd_text_append_window_rows), parses and check-sums them there; header and total lines go in as bytes.
+// The finished gzip stream is written through `out` (GzWriter::raw).  Returns 1 done, 0 declined (nothing left in `out`), -1 error.
+struct TableContig { int32_t tid; size_t n_rows; const std::string *name; };
+int write_window_table_resident(GzWriter &out, Engine *eng, int threads, uint32_t w, const std::string &header, const std::vector<TableContig> &contigs,
+                                const std::string &footer_line)
+{
+    const pd_engine_api *api = eng->api;
+    if (!api->text_open || !api->text_close || !api->text_append_window_rows || !api->text_append_bytes || !api->text_parse || !api->text_read ||
+        !api->text_release || !out.collecting())
+        return 0;
+    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return 0;
+    if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT")) if (e[0] == '0') return 0;
+    size_t rows = 0;
+    for (const auto &tc : contigs) rows += tc.n_rows;
+    size_t min_rows = 100000;                                  // (small tables: the host formats them in milliseconds)
+    if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT_MIN")) min_rows = (size_t)strtoull(e, nullptr, 10);
+    if (rows < min_rows) return 0;
+    const auto t_enter = std::chrono::steady_clock::now();
+    pgz::Params prm = pgz::Params::for_device(nullptr);
+    pd_text *tx = nullptr;
+    if (api->text_open(eng->ctx, std::max<size_t>((size_t)1 << 30, 4 * prm.batch), &tx) != 0 || !tx) return 0;
+    struct Closer { const pd_engine_api *api; pd_text *t; ~Closer() { if (t && !getenv("PANDEPTH_KEEP_CONTEXT")) api->text_close(t); } } closer{api, tx};
+    bool io_ok = true;
+    int rc = 1;
+    pgz::Remote src;
+    src.parse = [&](uint64_t off, size_t n, const uint64_t *chunks, size_t n_chunks, pgz::SymVec &syms, std::vector<uint64_t> &soff, uint32_t *crc, uint64_t crc_span) -> bool {
+        size_t bytes = 0;
+        for (size_t k = 0; k < n_chunks; ++k) bytes += (size_t)(chunks[3 * k + 1] - chunks[3 * k]);
+        soff.assign(n_chunks + 1, 0);
+        int r = PD_ERANGE;
+        for (size_t cap : {bytes / 3 + 4096, bytes + 16}) {
+            if (syms.size() < cap) syms.resize(cap);
+            r = api->text_parse(tx, off, n, reinterpret_cast<const pd_lz_chunk *>(chunks), (uint32_t)n_chunks, syms.data(), syms.size(), soff.data(), crc, crc_span);
+            if (r != PD_ERANGE) break;
+        }
+        return r == 0;
+    };
+    src.fetch = [&](uint64_t off, size_t n, uint8_t *dst) { return api->text_read(tx, off, n, dst) == 0; };
+    src.release = [&](uint64_t off) { (void)api->text_release(tx, off); };
+    {
+        std::unique_ptr<pgz::Stream> st(new pgz::Stream(threads, [&](const uint8_t *b, size_t n) { io_ok = out.raw(b, n) && io_ok; return io_ok; }, prm, src));
+        auto bytes_in = [&](const std::string &s) {
+            if (rc != 1 || s.empty()) return;
+            int r = api->text_append_bytes(tx, s.data(), s.size());
+            if (r == PD_ERANGE) { if (!st->wait_idle()) { rc = io_ok ? 0 : -1; return; } r = api->text_append_bytes(tx, s.data(), s.size()); }
+            if (r != 0) { rc = 0; return; }
+            if (!st->announce(s.size())) rc = io_ok ? 0 : -1;
+        };
+        bytes_in(header);
+        const size_t STEP = (size_t)1 << 20;                    // rows per append: about 45 MB of text
+        for (const auto &tc : contigs) {
+            for (size_t k = 0; k < tc.n_rows && rc == 1; k += STEP) {
+                const size_t n = std::min(STEP, tc.n_rows - k);
+                uint64_t got = 0;
+                int r = api->text_append_window_rows(tx, tc.tid, w, k, n, tc.name->data(), tc.name->size(), &got);
+                if (r == PD_ERANGE) { if (!st->wait_idle()) { rc = io_ok ? 0 : -1; break; } r = api->text_append_window_rows(tx, tc.tid, w, k, n, tc.name->data(), tc.name->size(), &got); }
+                if (r != 0) { rc = 0; break; }                  // (e.g. the statistics were summed over several GPUs and are not on this device)
+                if (!st->announce(got)) rc = io_ok ? 0 : -1;
+            }
+            if (rc != 1) break;
+        }
+        bytes_in(footer_line);
+        if (rc == 1 && !st->finish()) rc = io_ok ? 0 : -1;
+        if (rc != 1) (void)st->wait_idle();
+        if (getenv("PANDEPTH_TIMING"))
+            fprintf(stderr, "[timing]   window table (text resident on the device): %zu rows, %s, %.3f s\n", rows, rc == 1 ? "written" : "declined",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+        if (getenv("PANDEPTH_KEEP_CONTEXT")) (void)st.release();
+    }
+    if (rc != 1) { if (!out.raw_rewind()) return -1; if (!eng->ok()) { std::lock_guard<std::mutex> lk(eng->err_mu); eng->err.clear(); } }
+    return rc;
+}
+
 // <prefix>.SiteDepth.gz (PD:4264-4284), byte-identical to the reference's single zlib stream at any size, on all
 // threads: 4 M-cell blocks are read back, formatted in parallel slices and fed, in order, to pgz::Stream
 // (host/pgzip.h), which deflates them with zlib's own parse spread over the threads and bounded memory.
@@ -1330,6 +1404,57 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         std::vector<uint32_t> cov(woff[nctg] ? woff[nctg] : 1);
         std::vector<uint64_t> sum(woff[nctg] ? woff[nctg] : 1);
         if (!window_stats(w, cov.data(), sum.data())) return bail();
+        // Large tables without the GC column: the rows are formatted, parsed and check-summed on the device from the statistics the
+        // window call left there; the host adds up the three totals of the last line and writes the finished stream.
+        bool table_done = false;
+        if (!gc) {
+            std::vector<TableContig> tcs;
+            for (size_t t = 0; t < nctg; ++t) {
+                if (!rm.has((int32_t)t)) continue;
+                const int64_t len = hdr.lens[t];
+                tcs.push_back(TableContig{(int32_t)t, len > 1 ? (size_t)((len - 1 + (int64_t)w - 1) / (int64_t)w) : 0, &hdr.names[t]});
+            }
+            size_t rows = 0;
+            for (const auto &tc : tcs) rows += tc.n_rows;
+            size_t min_rows = 100000;
+            if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT_MIN")) min_rows = (size_t)strtoull(e, nullptr, 10);
+            if (rows >= min_rows && api->text_append_window_rows && OUT.collecting()) {
+                RowSums tot;
+                const int nt = std::max(1, std::min(o.threads, 16));
+                for (const auto &tc : tcs) {
+                    const int64_t len = hdr.lens[(size_t)tc.tid];
+                    const uint64_t base = woff[(size_t)tc.tid];
+                    std::vector<RowSums> part((size_t)nt);
+                    std::vector<std::thread> th;
+                    for (int k = 0; k < nt; ++k)
+                        th.emplace_back([&, k] {
+                            const size_t lo = tc.n_rows * (size_t)k / (size_t)nt, hi = tc.n_rows * (size_t)(k + 1) / (size_t)nt;
+                            RowSums r;
+                            for (size_t i = lo; i < hi; ++i) {
+                                const int64_t j = 1 + (int64_t)i * w;
+                                int64_t end = j - 1 + w; if (end > len) end = len;
+                                r.L += (uint64_t)(end - j + 1);
+                                r.C += (uint64_t)(int64_t)(int32_t)cov[base + i];
+                                r.D += (uint64_t)(int64_t)(int32_t)sum[base + i];
+                            }
+                            part[(size_t)k] = r;
+                        });
+                    for (auto &x : th) x.join();
+                    for (const auto &r : part) { tot.L += r.L; tot.C += r.C; tot.D += r.D; }
+                }
+                const int r = write_window_table_resident(OUT, &eng, o.threads, w, header_line, tcs, footer(tot.L, tot.C, tot.D, -1));
+                if (r < 0) return bail();
+                table_done = r == 1;
+            }
+        }
+        if (table_done) {
+            tm.mark("scan + statistics + table (rows, parse and checksums on the device)");
+            OUT.close();
+            tm.mark("table close");
+            if (!site_done()) return bail();
+            std::cout << "INFO: Input data read done" << std::endl;
+            return 0;
+        }
         OUT.write(header_line);
         RowSums tot;
         for (size_t t = 0; t < nctg; ++t) {

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <condition_variable>
 #include <deque>
@@ -37,8 +38,28 @@ void GzWriter::write(const char *p, size_t n)
     }
 }
 
+bool GzWriter::raw(const uint8_t *p, size_t n)
+{
+    if (!fp_ || !text_.empty()) return false;
+    raw_ = true;
+    return fwrite(p, 1, n, (FILE *)fp_) == n;
+}
+
+bool GzWriter::raw_rewind()
+{
+    if (!fp_) return false;
+    FILE *fp = (FILE *)fp_;
+    raw_ = false;
+    return fflush(fp) == 0 && ftruncate(fileno(fp), 0) == 0 && fseek(fp, 0, SEEK_SET) == 0;
+}
+
 bool GzWriter::close()
 {
+    if (fp_ && raw_) {                                           // the stream's bytes are in the file already
+        FILE *fp = (FILE *)fp_;
+        fp_ = nullptr; raw_ = false;
+        return fclose(fp) == 0;
+    }
     if (fp_) {
         FILE *fp = (FILE *)fp_;
         fp_ = nullptr;

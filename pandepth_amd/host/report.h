@@ -23,6 +23,11 @@ public:
     void set_parse(pgz::ParseFn fn) { parse_ = std::move(fn); }
     void write(const char *p, size_t n);
     void write(const std::string &s) { write(s.data(), s.size()); }
+    // the finished gzip stream's bytes from elsewhere (the engine parsed text that never came to the host: pipeline.cpp's resident
+    // table writer) instead of text; collecting mode only (threads > 1), nothing written as text before.  raw_rewind(): forget them.
+    bool raw(const uint8_t *p, size_t n);
+    bool raw_rewind();
+    bool collecting() const { return fp_ != nullptr && text_.empty(); }
     bool close();
     bool good() const { return f_ != nullptr || fp_ != nullptr; }
 private:
@@ -31,6 +36,7 @@ private:
     int threads_ = 1;
     pgz::ParseFn parse_;
     std::string path_, text_;
+    bool raw_ = false;
 };
 
 // Large per-site outputs: text chunks are produced AND deflated on worker threads, each chunk

@@ -28,6 +28,8 @@ struct pd_ctx {
     std::vector<int64_t> off;
     std::vector<uint32_t> depth;
     bool scanned = false;
+    // the last window call's statistics (pd_text_append_window_rows formats the table's rows from them)
+    uint32_t wk_w = 0; std::vector<uint32_t> wk_cov; std::vector<uint64_t> wk_sum, wk_woff;
     std::mutex mu;
     std::string err;
     // decode_*: the same batch protocol as libpandepth_amd.so's, run with the product's cores (pd_inflate_wave.h,
@@ -113,9 +115,12 @@ static int o_layout(const pd_ctx *c, uint32_t w, uint64_t *wo)
     wo[c->len.size()] = o;
     return 0;
 }
-static void windows(const pd_ctx *c, uint32_t w, uint32_t md, uint32_t mask, uint32_t *cov, uint64_t *sum)
+static void windows(pd_ctx *c, uint32_t w, uint32_t md, uint32_t mask, uint32_t *cov, uint64_t *sum)
 {
     uint64_t k = 0;
+    c->wk_woff.assign(c->len.size() + 1, 0);
+    for (size_t t = 0; t < c->len.size(); ++t) c->wk_woff[t + 1] = c->wk_woff[t] + ((uint64_t)c->len[t] + w - 1) / w;
+    struct Keep { pd_ctx *c; uint32_t w; uint32_t *cov; uint64_t *sum; ~Keep() { c->wk_w = w; c->wk_cov.assign(cov, cov + c->wk_woff.back()); c->wk_sum.assign(sum, sum + c->wk_woff.back()); } } keep{c, w, cov, sum};
     for (size_t t = 0; t < c->len.size(); ++t)
         for (uint64_t s = 0; s < c->len[t]; s += w, ++k) {
             uint64_t e = s + w; if (e > c->len[t]) e = c->len[t];
@@ -304,6 +309,35 @@ static int o_text_append_sites(pd_text *t, int32_t tid, uint32_t beg, size_t n, 
     *n_bytes = rows.size();
     return 0;
 }
+static int text_put(pd_text *t, const char *p, size_t n)
+{
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (t->bytes.size() + n > t->cap) { t->c->err = "text stream full"; return -6; }
+    t->bytes.insert(t->bytes.end(), p, p + n);
+    return 0;
+}
+static int o_text_append_window_rows(pd_text *t, int32_t tid, uint32_t w, uint64_t row_first, size_t n_rows, const char *name, size_t name_len, uint64_t *n_bytes)
+{
+    pd_ctx *c = t->c;
+    if (c->wk_w != w || c->wk_woff.empty()) { c->err = "no window statistics of this width"; return -4; }
+    std::string rows, nm(name, name_len);
+    char buf[256];
+    const int64_t len = c->len[(size_t)tid];
+    for (size_t i = 0; i < n_rows; ++i) {
+        const uint64_t k = row_first + i;
+        const int64_t j = 1 + (int64_t)k * w;
+        int64_t end = j - 1 + w; if (end > len) end = len;
+        const int64_t L = end - j + 1;
+        const int32_t cc = (int32_t)c->wk_cov[(size_t)(c->wk_woff[(size_t)tid] + k)], d = (int32_t)c->wk_sum[(size_t)(c->wk_woff[(size_t)tid] + k)];
+        snprintf(buf, sizeof buf, "\t%lld\t%lld\t%lld\t%d\t%d\t%.2f\t%.2f\n", (long long)j, (long long)end, (long long)L, cc, d, cc * 100.0 / L, d * 1.0 / L);
+        rows += nm; rows += buf;
+    }
+    const int rc = text_put(t, rows.data(), rows.size());
+    if (rc) return rc;
+    *n_bytes = rows.size();
+    return 0;
+}
+static int o_text_append_bytes(pd_text *t, const void *p, size_t n) { return text_put(t, (const char *)p, n); }
 static int o_text_parse(pd_text *t, uint64_t off, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *soff, uint32_t *crc, uint64_t crc_span)
 {
     std::vector<uint8_t> text;
@@ -339,6 +373,7 @@ int main(int argc, char **argv)
                                       o_layout, o_scan_reduce_windows, o_reduce_windows, o_read_depth, o_sync, nullptr, o_device_count, o_accumulate_from,
                                       o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param,
                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, no_parse ? nullptr : o_deflate_parse, nullptr, nullptr,
-                                      no_parse ? nullptr : o_text_open, o_text_close, o_text_append_sites, o_text_parse, o_text_read, o_text_release};
+                                      no_parse ? nullptr : o_text_open, o_text_close, o_text_append_sites, o_text_parse, o_text_read, o_text_release,
+                                      no_parse ? nullptr : o_text_append_window_rows, o_text_append_bytes};
     return pandepth_main(argc, argv, &api, 0);
 }

@@ -795,6 +795,49 @@ def test_text_stream_rows_parse_and_checksums():
                 t.parse(0, 100000, [(0, 50000, 0)], CH)          # a stretch that is no longer there
 
 
+@pytest.mark.parametrize("w", [100, 149, 4096, 10000, 300000])
+def test_window_table_rows_formatted_on_the_device(w):
+    """pd_text_append_window_rows == the rows of the reference's `-w` table (PD:4381-4388) formatted on the host from the same
+    statistics: "%d" columns with the depth as the reference's `int` (a pile-up makes sums beyond 2^31: negative depth, negative
+    mean), the two "%.2f" columns exactly as printf rounds them (Python's % formatting is correctly rounded like glibc's), the last
+    window of a contig shorter than w, row ranges that start and end inside workgroup blocks; after a window call of another width
+    the rows are refused."""
+    rng = np.random.default_rng(79)
+    lens = np.array([1234567, 50001, 9], dtype=np.uint32)
+    iv = np.concatenate([rand_intervals(rng, lens, 80000), np.tile(np.array([[0, 200000, 230000]], dtype=np.int32), (150000, 1))])
+    with pda.Engine(lens) as e:
+        e.push_intervals(iv)
+        e.scan(0)
+        woff, cov, tot = e.reduce_windows(w, 1)
+        assert int(tot.max()) > 2 ** 31 or w < 4096
+        with e.text_open(64 << 20) as t:
+            host = b""
+            for tid, name in ((0, "Chr01"), (1, "scaffold_7"), (2, "s")):
+                n_all = int(woff[tid + 1] - woff[tid])
+                for first, n in ((0, n_all), (1, max(0, n_all - 2)), (n_all // 2, n_all - n_all // 2)):
+                    if n <= 0:
+                        continue
+                    L = int(lens[tid])
+                    rows = []
+                    for k in range(first, first + n):
+                        j = 1 + k * w
+                        end = min(j - 1 + w, L)
+                        ln = end - j + 1
+                        c = int(np.int32(np.uint32(cov[int(woff[tid]) + k])))
+                        d = int(np.uint64(tot[int(woff[tid]) + k]).astype(np.uint32).astype(np.int32))
+                        rows.append("%s\t%d\t%d\t%d\t%d\t%d\t%.2f\t%.2f\n" % (name, j, end, ln, c, d, c * 100.0 / ln, d * 1.0 / ln))
+                    want = "".join(rows).encode()
+                    off0 = len(host)
+                    assert t.append_window_rows(tid, w, first, n, name) == len(want), (tid, first, n)
+                    host += want
+                    assert t.read(off0, len(want)) == want, (tid, first, n)
+            t.append_bytes(b"##tail\n")
+            assert t.read(len(host), 7) == b"##tail\n"
+            e.reduce_windows(w + 1, 1)
+            with pytest.raises(pda.PdError):
+                t.append_window_rows(0, w, 0, 1, "x")
+
+
 @pytest.mark.parametrize("w,min_dep,wrap", [(10000, 1, 0), (8192, 3, 18), (10000000, 0, 0), (16384, 1, 18)])
 def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
     """Both forms of the wide-window direct kernel (k_direct_wide3, the default; k_direct_tiles<.., DirectWide>, "direct_un" 504)

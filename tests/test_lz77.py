@@ -90,14 +90,16 @@ def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
     subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
     cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
     outs = {}
-    for tag, env in (("dev", {"PANDEPTH_TIMING": "1"}), ("hosttext", {"PANDEPTH_TIMING": "1", "PANDEPTH_SITE_RESIDENT": "0"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
+    for tag, env in (("dev", {"PANDEPTH_TIMING": "1", "PANDEPTH_TABLE_RESIDENT_MIN": "1"}),
+                     ("hosttext", {"PANDEPTH_TIMING": "1", "PANDEPTH_SITE_RESIDENT": "0", "PANDEPTH_TABLE_RESIDENT": "0"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "8"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=900, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-600:]
         outs[tag] = {s: (tmp_path / ("%s.%s" % (tag, s))).read_bytes() for s in ("win.stat.gz", "SiteDepth.gz")}
         err = p.stderr.decode()
-        if tag == "dev":          # the per-site text stays on the device (pd_text_*), the table goes through pd_deflate_parse
-            assert "text resident on the device" in err and " 0 parse calls" not in err and err.count("pd_deflate_parse:") >= 1 and "FAILED" not in err, err[-1500:]
+        if tag == "dev":          # the per-site text and the table's rows stay on the device (pd_text_*)
+            assert "per-site writer (text resident on the device)" in err and " 0 parse calls" not in err and "FAILED" not in err, err[-1500:]
+            assert "window table (text resident on the device)" in err and "rows, written" in err, err[-1500:]
         if tag == "hosttext":     # both streams through pd_deflate_parse on host text
             assert "text resident on the device" not in err and err.count("pd_deflate_parse:") >= 2 and "FAILED" not in err, err[-1500:]
     assert outs["dev"] == outs["hosttext"]
@@ -123,7 +125,7 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
     synth.write_bam(bam, names, lens, rec, procs=2, payload=False)
     cli = os.path.join(H, "pandepth_oracle_cli")
     outs = {}
-    for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32"}),
+    for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32", "PANDEPTH_TABLE_RESIDENT_MIN": "1"}),
                      ("full", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_CAP": "4000000"}),
                      ("hosttext", {"PANDEPTH_SITE_RESIDENT": "0", "PGZ_DEV_BATCH_MB": "1"}), ("zlib", {"PANDEPTH_TEST_NO_PARSE": "1"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "4"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -132,5 +134,7 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
         outs[tag] = {s: (tmp_path / ("%s.%s" % (tag, s))).read_bytes() for s in ("win.stat.gz", "SiteDepth.gz")}
         if tag in ("resident", "full"):
             err = p.stderr.decode()
-            assert "text resident on the device" in err and " 0 parse calls" not in err, err[-1500:]
+            assert "per-site writer (text resident on the device)" in err and " 0 parse calls" not in err, err[-1500:]
+        if tag == "resident":
+            assert "window table (text resident on the device)" in err and "rows, written" in err, err[-1500:]
     assert outs["resident"] == outs["zlib"] and outs["full"] == outs["zlib"] and outs["hosttext"] == outs["zlib"]
