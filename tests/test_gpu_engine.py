@@ -804,12 +804,12 @@ def test_window_table_rows_formatted_on_the_device(w):
     the rows are refused."""
     rng = np.random.default_rng(79)
     lens = np.array([1234567, 50001, 9], dtype=np.uint32)
-    iv = np.concatenate([rand_intervals(rng, lens, 80000), np.tile(np.array([[0, 200000, 230000]], dtype=np.int32), (150000, 1))])
+    iv = np.concatenate([rand_intervals(rng, lens, 80000), np.tile(np.array([[0, 200000, 220000]], dtype=np.int32), (150000, 1))])
     with pda.Engine(lens) as e:
         e.push_intervals(iv)
         e.scan(0)
         woff, cov, tot = e.reduce_windows(w, 1)
-        assert int(tot.max()) > 2 ** 31 or w < 4096
+        assert w != 300000 or 2 ** 31 < int(tot.max()) < 2 ** 32          # a depth column that is negative as the reference's `int`
         with e.text_open(64 << 20) as t:
             host = b""
             for tid, name in ((0, "Chr01"), (1, "scaffold_7"), (2, "s")):
