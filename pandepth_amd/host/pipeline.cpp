@@ -1419,23 +1419,33 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             size_t min_rows = 100000;
             if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT_MIN")) min_rows = (size_t)strtoull(e, nullptr, 10);
             if (rows >= min_rows && api->text_append_window_rows && OUT.collecting()) {
+                tm.mark("scan + window statistics");
                 RowSums tot;
-                const int nt = std::max(1, std::min(o.threads, 16));
-                for (const auto &tc : tcs) {
-                    const int64_t len = hdr.lens[(size_t)tc.tid];
-                    const uint64_t base = woff[(size_t)tc.tid];
+                {   // the three totals of the last line, over slices of a million rows on the threads
+                    struct Item { size_t tc, lo, hi; };
+                    std::vector<Item> items;
+                    for (size_t x = 0; x < tcs.size(); ++x)
+                        for (size_t lo = 0; lo < tcs[x].n_rows; lo += (size_t)1 << 20) items.push_back(Item{x, lo, std::min(tcs[x].n_rows, lo + ((size_t)1 << 20))});
+                    const int nt = std::max(1, std::min(o.threads, 16));
                     std::vector<RowSums> part((size_t)nt);
+                    std::atomic<size_t> next{0};
                     std::vector<std::thread> th;
                     for (int k = 0; k < nt; ++k)
                         th.emplace_back([&, k] {
-                            const size_t lo = tc.n_rows * (size_t)k / (size_t)nt, hi = tc.n_rows * (size_t)(k + 1) / (size_t)nt;
                             RowSums r;
-                            for (size_t i = lo; i < hi; ++i) {
-                                const int64_t j = 1 + (int64_t)i * w;
-                                int64_t end = j - 1 + w; if (end > len) end = len;
-                                r.L += (uint64_t)(end - j + 1);
-                                r.C += (uint64_t)(int64_t)(int32_t)cov[base + i];
-                                r.D += (uint64_t)(int64_t)(int32_t)sum[base + i];
+                            for (;;) {
+                                const size_t it = next.fetch_add(1);
+                                if (it >= items.size()) break;
+                                const TableContig &tc = tcs[items[it].tc];
+                                const int64_t len = hdr.lens[(size_t)tc.tid];
+                                const uint64_t base = woff[(size_t)tc.tid];
+                                for (size_t i = items[it].lo; i < items[it].hi; ++i) {
+                                    const int64_t j = 1 + (int64_t)i * w;
+                                    int64_t end = j - 1 + w; if (end > len) end = len;
+                                    r.L += (uint64_t)(end - j + 1);
+                                    r.C += (uint64_t)(int64_t)(int32_t)cov[base + i];
+                                    r.D += (uint64_t)(int64_t)(int32_t)sum[base + i];
+                                }
                             }
                             part[(size_t)k] = r;
                         });
@@ -1448,7 +1458,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             }
         }
         if (table_done) {
-            tm.mark("scan + statistics + table (rows, parse and checksums on the device)");
+            tm.mark("totals + table (rows, parse and checksums on the device)");
             OUT.close();
             tm.mark("table close");
             if (!site_done()) return bail();

@@ -33,10 +33,18 @@ with open(gff, "w") as fh:
             el = int(min(5000, max(30, rng.lognormal(np.log(150), 0.7))))
             fh.write("%s\tsynth\tCDS\t%d\t%d\t.\t+\t0\tID=cds%d.%d;Parent=tx%05d\n" % (names[c], s0, s0 + el - 1, t, e, t))
             s0 += el + int(rng.integers(80, 3000))
+# PD_E2E_TAGS: a subset of the cases, e.g. "w100,w1000" (w100: the 3e7-row, 1.3 GB table whose rows the engine formats and parses on the device)
+only = [x for x in os.environ.get("PD_E2E_TAGS", "chr,w1000,chr_s,gff").split(",") if x]
 for tag, extra, suffix in (("chr", [], "chr.stat.gz"), ("w1000", ["-w", "1000"], "win.stat.gz"), ("chr_s", ["-s"], "chr.stat.gz"),
-                           ("gff", ["-g", gff], "gene.stat.gz")):
+                           ("gff", ["-g", gff], "gene.stat.gz"), ("w100", ["-w", "100"], "win.stat.gz")):
+    if tag not in only:
+        continue
     t0 = time.perf_counter()
-    subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "m_" + tag), "-t", "16"] + extra, check=True, stdout=subprocess.DEVNULL, timeout=280)
+    pm = subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "m_" + tag), "-t", "16"] + extra, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=280,
+                        env=dict(os.environ, PANDEPTH_TIMING="1"))
+    for ln in pm.stderr.decode().splitlines():
+        if any(k in ln for k in ("window table", "scan + ", "totals + table", "table gzip", "table close", "decode + scatter", "engine create")):
+            print("      " + ln[:200], flush=True)
     t1 = time.perf_counter()
     subprocess.run([ref, "-i", bam, "-o", os.path.join(td, "r_" + tag), "-t", "16"] + extra, check=True, stdout=subprocess.DEVNULL, timeout=280)
     t2 = time.perf_counter()
