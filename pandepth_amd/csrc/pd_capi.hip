@@ -1722,7 +1722,7 @@ int pd_slice_sweep_i4(pd_ctx *c, const void *dev_parts, uint32_t n_parts, uint64
     { ProfScope ps(c, "slice_sweep");
       TileMap tm{c->d_tile_contig, c->d_off, c->d_len, nullptr};
       launch_sweep_i4(c->stream, dev_parts, n_parts, part_stride, (uint32_t)tile_first, (uint32_t)tile_count, dev_exc, exc_stride,
-                      dev_exc_counts, c->slice_flags, slice_flag_bytes(c->n_tiles), c->carry, mask, tm, w, min_dep, (TilePart *)dev_partials); }
+                      dev_exc_counts, c->slice_flags, slice_flag_bytes(c->n_tiles), c->carry, mask, tm, w, min_dep, (TilePart *)dev_partials, nullptr); }
     HIPOK(c, hipGetLastError());
     return PD_OK;
 }

@@ -112,7 +112,8 @@ void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, 
                    uint64_t n_cells_total, int *dst_base);
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
                      uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes /* bytes of flags; behind them: 16 + 4 * tiles bytes for the list */,
-                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part);
+                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part,
+                     int *depth_out /* non-null: no statistics, the slice's summed depth as int32 cells instead */);
 void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
                           uint64_t n_windows, uint32_t *cover, unsigned long long *sum);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,

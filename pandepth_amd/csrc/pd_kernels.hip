@@ -2150,7 +2150,7 @@ struct I4Src {
 template <bool PATCH>
 __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
                                                  uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, const uint32_t *list,
-                                                 const uint32_t *n_list)
+                                                 const uint32_t *n_list, int *depth_out)
 {
     __shared__ int wtot[4];
     __shared__ int patch[PATCH ? TILE : 1];
@@ -2209,6 +2209,12 @@ __global__ __launch_bounds__(WG) void k_sweep_i4(const I4Src src, const int *car
     int base = carry[t] + incl - run;
     for (int k = 0; k < wv; ++k) base += wtot[k];
 
+    if (depth_out) {                                              // (uniform) the slice's depth instead of statistics
+#pragma unroll
+        for (int k = 0; k < 32; ++k) depth_out[(uint64_t)i * TILE + (uint32_t)(tid * 32 + k)] = (int)((uint32_t)(a[k] + base) & wrap_mask);
+        __syncthreads();
+        continue;
+    }
     const uint32_t ctg = tmap.tile_contig[t];
     const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
     const uint32_t clen = tmap.contig_len[ctg];
@@ -2251,8 +2257,11 @@ __global__ __launch_bounds__(WG) void k_list_flagged(const uint8_t *flags, uint3
 // 32 cells at lane * 32 of each of the tile's four 2048-cell quarters = one 16-byte load per quarter and part), the quarters are
 // swept in order with the running depth carried in a register — no barriers, no LDS, and four loads per part in flight per lane,
 // where the workgroup-per-tile form lived for one load's latency and three barriers per 4 KiB of image.
+// DEPTH: no statistics — the summed, prefix-summed and wrapped cells of the slice are written out as int32 depth (depth_out: the slice's
+// first cell), for the statistics that need the cells themselves (narrow windows, annotation intervals) on the rank that owns the slice.
+template <bool DEPTH>
 __global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
-                                                      uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t tile_count)
+                                                      uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t tile_count, int *depth_out)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
@@ -2304,6 +2313,15 @@ __global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int
         const int incl = wave_incl_scan(run);
         const int b0 = base + incl - run;
         const uint32_t pos0 = (uint32_t)(q * 2048 + lane * 32);
+        if constexpr (DEPTH) {
+            int4 *o = reinterpret_cast<int4 *>(depth_out + (uint64_t)i * TILE + pos0);
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                o[k >> 2] = make_int4((int)((uint32_t)(a[k] + b0) & wrap_mask), (int)((uint32_t)(a[k + 1] + b0) & wrap_mask),
+                                      (int)((uint32_t)(a[k + 2] + b0) & wrap_mask), (int)((uint32_t)(a[k + 3] + b0) & wrap_mask));
+            base += __builtin_amdgcn_readlane(incl, 63);
+            continue;
+        }
         // a lane's 32 cells lie on one side of the window boundary and inside the contig, except in the one quarter of a tile that
         // holds the boundary or the contig's end: there every cell is tested (wave-uniform branch), elsewhere none is
         const bool plain = pos0 + 32u <= left && (pos0 + 32u <= nb || pos0 >= nb);
@@ -2331,6 +2349,7 @@ __global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int
     c0 = wave_sum(c0); c1 = wave_sum(c1);
 #pragma unroll
     for (int o = 32; o; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (DEPTH) return;
     if (lane == 0) { TilePart tp; tp.c0 = (uint32_t)c0; tp.c1 = (uint32_t)c1; tp.s0 = s0; tp.s1 = s1; part[i] = tp; }
 }
 
@@ -2384,7 +2403,7 @@ void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, 
 
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
                      uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes,
-                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part)
+                     const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part, int *depth_out)
 {
     if (!tile_count) return;
     const bool with_exc = exc && exc_counts && exc_stride && flags;
@@ -2398,14 +2417,19 @@ void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64
         hipLaunchKernelGGL(k_list_flagged, dim3(256), dim3(WG), 0, st, (const uint8_t *)flags, tile_count, list, n_list);
     }
     I4Src src{(const uint8_t *)parts, stride, n_parts, with_exc ? flags : nullptr, exc, exc_stride, exc_counts};
-    if (n_parts <= 16)
-        hipLaunchKernelGGL(k_sweep_i4_wave, dim3((tile_count + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count);
-    else
+    if (n_parts <= 16) {
+        const dim3 g((tile_count + WG / 64 - 1) / (WG / 64));
+        if (depth_out) hipLaunchKernelGGL(k_sweep_i4_wave<true>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out);
+        else hipLaunchKernelGGL(k_sweep_i4_wave<false>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out);
+    } else if (depth_out) {                                      // (more than 16 parts: the workgroup form, every tile through the list-less PATCH-free kernel's depth branch)
         hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, depth_out);
+    } else
+        hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (int *)nullptr);
     if (with_exc)
         hipLaunchKernelGGL(k_sweep_i4<true>, dim3(512), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, (const uint32_t *)list,
-                           (const uint32_t *)n_list);
+                           (const uint32_t *)n_list, depth_out);
 }
 
 void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
