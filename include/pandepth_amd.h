@@ -295,7 +295,8 @@ int pd_gather_windows(pd_ctx *ctx, const void *dev_partials, uint32_t w, uint32_
  * pd_sliced_window_sum is COLLECTIVE — every rank calls it, in one process from one thread per rank — and does, on each context's
  * stream: pd_export_i4 -> grouped ncclSend / ncclRecv of the 1/n slices between all pairs (messages of <= 256 MiB) ->
  * ncclAllReduce of the int32 tile sums + ncclAllGather of the exception blocks -> pd_slice_sweep_i4 on the rank's slice ->
- * 24 B per tile to `root` -> pd_gather_windows there.  Windows of w >= 8192 cells (whole-chromosome mode, PD:2704-3014 + PD:3978). */
+ * 24 B per tile to `root` -> pd_gather_windows there (windows of w >= 8192 cells: whole-chromosome mode, PD:2704-3014 + PD:3978; narrower
+ * windows: see below). */
 typedef struct pd_comm pd_comm;          /* belongs to its context: pd_comm_destroy before pd_destroy */
 #define PD_UNIQUE_ID_BYTES 128
 int pd_comm_unique_id(void *id128);
@@ -304,6 +305,15 @@ int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms);
 int pd_comm_destroy(pd_comm *comm);
 const char *pd_comm_strerror(const pd_comm *comm);
 int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
+/* Windows narrower than 8192 cells and annotation intervals need the summed CELLS, not per-tile partials: for those every rank turns its
+ * slice of the exchanged images into int32 depth cells (1/n of the genome per GPU — still no GPU holds everybody's arrays) and reduces
+ * the windows / the stretches of the regions that lie in its slice.  pd_sliced_window_sum does that for w < 8192 (the window arrays are
+ * merged with an all-reduce — every window has one writer — and the windows across tile edges put together from the tiles' shares);
+ * pd_sliced_interval_sum is pd_reduce_intervals (PD:329-348 over the merged CDS / BED regions, PD:3002-3410 for `#.list` inputs) on
+ * the sum of all ranks' samples: per-region partial results are gathered and added on `root`.  Both are COLLECTIVE like
+ * pd_sliced_window_sum and return PD_ERANGE on every rank, with every sample intact, when a sample does not fit the 4-bit image. */
+int pd_sliced_interval_sum(pd_comm *comm, const pd_region *regs, size_t n, uint32_t min_dep, unsigned wrap_bits, int root,
+                           int32_t *cover, uint64_t *sum);
 /* The same in two halves, with two slots of exchange buffers (slot 0 or 1), for a caller with several samples per rank:
  * pd_sliced_sum_start only enqueues (pack on the context's stream, the collectives on the communicator's own stream, ordered
  * by events), so the context can be reset and sample k+1 scattered while sample k's image is on the xGMI links;

@@ -95,6 +95,7 @@ def load():
         "pd_comm_destroy": (I, [P]),
         "pd_comm_strerror": (ctypes.c_char_p, [P]),
         "pd_sliced_window_sum": (I, [P, ctypes.c_uint32, ctypes.c_uint32, U, I, P, P]),
+        "pd_sliced_interval_sum": (I, [P, P, SZ, ctypes.c_uint32, U, I, P, P]),
         "pd_sliced_sum_start": (I, [P, I]),
         "pd_sliced_sum_finish": (I, [P, I, ctypes.c_uint32, ctypes.c_uint32, U, I, P, P]),
         "pd_push_bgzf_units": (I, [P, P, SZ, P, ctypes.c_uint32, P, ctypes.c_uint32, U64, ctypes.c_uint32, ctypes.c_int32, P,
@@ -118,7 +119,7 @@ EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
            "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_text_append_window_rows", "pd_text_append_bytes", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
-           "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
+           "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_interval_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get"]
 
 
@@ -208,6 +209,30 @@ class Comm:
     def run(self, w=10000000, min_dep=1, wrap_bits=18, root=0):
         self.start(0)
         return self.finish(0, w, min_dep, wrap_bits, root)
+
+    def window_sum(self, w, min_dep=1, wrap_bits=18, root=0):
+        """pd_sliced_window_sum (any window width): (win_off, cover, depth_sum) on the root, else None."""
+        if self.rank != root:
+            self._ck(self.L.pd_sliced_window_sum(self.h, int(w), int(min_dep), int(wrap_bits), int(root), None, None))
+            return None
+        off = self.e.window_layout(w)
+        n = int(off[-1])
+        cover = np.zeros(max(n, 1), dtype=np.uint32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_sliced_window_sum(self.h, int(w), int(min_dep), int(wrap_bits), int(root), _ptr(cover), _ptr(tot)))
+        return off, cover[:n], tot[:n]
+
+    def interval_sum(self, regs, min_dep=1, wrap_bits=18, root=0):
+        """pd_sliced_interval_sum: (cover, depth_sum) per region on the root, else None."""
+        regs = np.ascontiguousarray(regs, dtype=np.int32).reshape(-1, 3)
+        n = regs.shape[0]
+        if self.rank != root:
+            self._ck(self.L.pd_sliced_interval_sum(self.h, _ptr(regs), n, int(min_dep), int(wrap_bits), int(root), None, None))
+            return None
+        cover = np.zeros(max(n, 1), dtype=np.int32)
+        tot = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.pd_sliced_interval_sum(self.h, _ptr(regs), n, int(min_dep), int(wrap_bits), int(root), _ptr(cover), _ptr(tot)))
+        return cover[:n], tot[:n]
 
 
 class Engine:

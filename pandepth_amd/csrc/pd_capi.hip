@@ -2157,6 +2157,7 @@ struct pd_comm {
         bool busy = false;
     } slot[2];
     uint8_t *part_mine = nullptr, *part_all = nullptr;
+    int *slice_depth = nullptr;                   // the summed depth of this rank's slice (narrow windows, intervals), made on demand
     hipStream_t links = nullptr;                  // every RCCL call is issued on this stream, ordered against the context's by events
     hipEvent_t swept = nullptr, gathered = nullptr;
     std::string err;
@@ -2324,6 +2325,7 @@ int pd_comm_destroy(pd_comm *m)
     }
     if (m->part_mine) (void)hipFree(m->part_mine);
     if (m->part_all) (void)hipFree(m->part_all);
+    if (m->slice_depth) (void)hipFree(m->slice_depth);
     if (m->swept) (void)hipEventDestroy(m->swept);
     if (m->gathered) (void)hipEventDestroy(m->gathered);
     if (m->links) (void)hipStreamDestroy(m->links);
@@ -2418,12 +2420,177 @@ int pd_sliced_sum_finish(pd_comm *m, int slot, uint32_t w, uint32_t min_dep, uns
     return PD_OK;
 }
 
+// Collective: after pd_sliced_sum_start(slot) — this rank's slice of the SUMMED sample as int32 depth cells (prefix-summed, wrapped) in
+// m->slice_depth: what pd_scan would leave in cells [tile_first, tile_first + tile_count) x 8192 of a context holding every rank's sample.
+// The statistics that need the cells themselves (narrow windows, annotation intervals) then run on the rank that owns them.
+static int sliced_depth(pd_comm *m, int slot, unsigned wrap_bits)
+{
+    pd_comm::Slot &s = m->slot[slot];
+    if (!s.busy) return comm_fail(m, PD_EINVAL, "sliced statistics: the slot has not been started");
+    s.busy = false;
+    pd_ctx *c = m->ctx;
+    const size_t W = (size_t)m->world, sb = (size_t)m->slice_bytes;
+    HIPCM(m, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCM(m, hipStreamWaitEvent(st, s.landed, 0));
+    std::vector<int32_t> counts(W);
+    HIPCM(m, hipMemcpyAsync(counts.data(), s.meta + m->n_sums, W * 4, hipMemcpyDeviceToHost, st));
+    HIPCM(m, hipStreamSynchronize(st));
+    for (int32_t k : counts) if (k < 0 || (uint32_t)k > COMM_EXC_BLOCK)
+        return comm_fail(m, PD_ERANGE, "a sample has more cells outside the 4-bit range than the exception block holds: the sliced sum does not apply, "
+                                       "every context still holds its sample (pd_accumulate_from adds them up)");
+    if (!m->slice_depth && hipMalloc(&m->slice_depth, (size_t)m->slice_tiles * PD_TILE * 4 + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return comm_fail(m, PD_ENOMEM, "sliced statistics: the slice's depth cells could not be allocated");
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);          // (comm_fail takes this lock: nothing below fails under it)
+        const uint32_t mask = (wrap_bits == 0 || wrap_bits == 32) ? 0xFFFFFFFFu : ((1u << wrap_bits) - 1u);
+        { ProfScope ps(c, "tile_carry"); launch_tile_carry(st, s.meta, c->bsum, c->carry, (uint32_t)c->n_tiles); }
+        { ProfScope ps(c, "slice_depth");
+          TileMap tm{c->d_tile_contig, c->d_off, c->d_len, nullptr};
+          launch_sweep_i4(st, s.recv, (uint32_t)W, sb, (uint32_t)m->tile_first, (uint32_t)m->tile_count, s.exc_all, COMM_EXC_BLOCK, s.meta + m->n_sums,
+                          c->slice_flags, slice_flag_bytes(c->n_tiles), c->carry, mask, tm, PD_TILE, 0, nullptr, m->slice_depth); }
+    }
+    HIPCM(m, hipGetLastError());
+    return PD_OK;
+}
+
+// windows of w < 8192 cells: every rank reduces the windows of its slice's cells; the window arrays are merged (each window has one
+// writer: an all-reduce of the words adds zeros to it), the windows across tile edges are put together from the tiles' shares
+static int sliced_narrow_windows(pd_comm *m, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
+{
+    int rc = pd_sliced_sum_start(m, 0);
+    if (rc) return rc;
+    rc = sliced_depth(m, 0, wrap_bits);
+    if (rc) return rc;
+    pd_ctx *c = m->ctx;
+    hipStream_t st = c->stream, ln = m->links;
+    // (the collective is the context's only user while it runs — one thread per rank; the context's lock is taken only where its
+    // shared scratch and profile records are touched, never across a comm_fail, which takes it itself)
+    std::vector<uint64_t> wo((size_t)c->n_contigs + 1);
+    pd_window_layout(c, w, wo.data());
+    const uint64_t nw = wo[c->n_contigs];
+    const size_t b_off = ((size_t)c->n_contigs + 1) * 8, b_sum = (size_t)nw * 8, b_cov = ((size_t)nw * 4 + 15) / 16 * 16;
+    std::string emsg;
+    { std::lock_guard<std::mutex> lk(c->mu);
+      rc = ensure_scratch(c, b_off + 64);
+      if (!rc) rc = win_keep_fit(c, b_sum + b_cov + 64);
+      if (rc) emsg = c->err; }
+    if (rc) return comm_fail(m, rc, emsg);
+    uint64_t *d_wo = (uint64_t *)c->scratch;
+    unsigned long long *d_sum = (unsigned long long *)c->wk;
+    uint32_t *d_cov = (uint32_t *)(c->wk + b_sum);
+    HIPCM(m, hipMemcpyAsync(d_wo, wo.data(), b_off, hipMemcpyHostToDevice, st));
+    HIPCM(m, hipStreamSynchronize(st));                 // wo is a local
+    HIPCM(m, hipMemsetAsync(d_sum, 0, b_sum + b_cov, st));
+    TileMap tm{c->d_tile_contig, c->d_off, c->d_len, d_wo};
+    TilePart *parts = (TilePart *)m->part_all;           // indexed by tile of the genome: the ranks' slices are consecutive blocks of it
+    int e_lds = 0;
+    { std::lock_guard<std::mutex> lk(c->mu);
+      ProfScope ps(c, "slice_windows");
+      e_lds = launch_sweep_windows_slice(st, m->slice_depth, (uint32_t)m->tile_first, (uint32_t)m->tile_count, tm, w, min_dep, d_cov, d_sum, parts); }
+    if (e_lds) return comm_fail(m, PD_EHIP, "window sweep: cannot reserve LDS");
+    HIPCM(m, hipGetLastError());
+    if (m->world > 1) {
+        HIPCM(m, hipEventRecord(m->swept, st));
+        HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
+        const size_t pb = (size_t)m->slice_tiles * PD_TILE_PARTIAL_BYTES;
+        NCCLOK(m, rccl().AllGather(m->part_all + (size_t)m->rank * pb, m->part_all, pb, ncclUint8, m->nccl, ln));
+        NCCLOK(m, rccl().AllReduce(d_sum, d_sum, (b_sum + b_cov) / 4, ncclInt32, ncclSum, m->nccl, ln));
+        HIPCM(m, hipEventRecord(m->gathered, ln));
+        HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
+    }
+    launch_window_edges(st, parts, tm, (uint32_t)c->n_tiles, w, d_cov, d_sum);
+    HIPCM(m, hipGetLastError());
+    if (m->rank == root) {
+        HIPCM(m, hipMemcpyAsync(sum, d_sum, b_sum, hipMemcpyDeviceToHost, st));
+        HIPCM(m, hipMemcpyAsync(cover, d_cov, (size_t)nw * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCM(m, hipStreamSynchronize(st));
+    { std::lock_guard<std::mutex> lk(c->mu); c->wk_w = w; c->wk_nw = nw; c->wk_woff = wo; c->wk_valid = true; }   // (every rank holds the merged statistics)
+    return PD_OK;
+}
+
 int pd_sliced_window_sum(pd_comm *m, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum)
 {
-    if (!m || root < 0 || root >= m->world || w < PD_TILE || wrap_bits > 32) return PD_EINVAL;
+    if (!m || root < 0 || root >= m->world || w == 0 || wrap_bits > 32) return PD_EINVAL;
     if (m->rank == root && (!cover || !sum)) return PD_EINVAL;
+    if (w < PD_TILE) return sliced_narrow_windows(m, w, min_dep, wrap_bits, root, cover, sum);
     const int rc = pd_sliced_sum_start(m, 0);
     return rc ? rc : pd_sliced_sum_finish(m, 0, w, min_dep, wrap_bits, root, cover, sum);
+}
+
+// Collective: pd_reduce_intervals (PD:329-348 over the CDS / BED regions) on the sum of every rank's sample without any GPU holding the
+// summed arrays: a rank reduces the stretches of the regions that lie in its slice, the per-region partial results of all ranks are
+// gathered and added on `root`.
+int pd_sliced_interval_sum(pd_comm *m, const pd_region *regs, size_t n, uint32_t min_dep, unsigned wrap_bits, int root, int32_t *cover, uint64_t *sum)
+{
+    if (!m || root < 0 || root >= m->world || wrap_bits > 32 || (n && !regs)) return PD_EINVAL;
+    if (m->rank == root && n && (!cover || !sum)) return PD_EINVAL;
+    if (n > 0xFFFFFFF0ull) return comm_fail(m, PD_EINVAL, "too many regions");
+    int rc = pd_sliced_sum_start(m, 0);
+    if (rc) return rc;
+    rc = sliced_depth(m, 0, wrap_bits);
+    if (rc) return rc;
+    if (n == 0) return PD_OK;
+    pd_ctx *c = m->ctx;
+    hipStream_t st = c->stream, ln = m->links;
+    constexpr uint32_t PIECE = 16384;
+    const uint64_t lo_cell = m->tile_first * PD_TILE, hi_cell = (m->tile_first + m->tile_count) * PD_TILE;
+    std::vector<Piece> pieces;
+    for (size_t i = 0; i < n; ++i) {
+        const pd_region &r = regs[i];
+        if (r.tid < 0 || r.tid >= c->n_contigs) return comm_fail(m, PD_EINVAL, "pd_sliced_interval_sum: contig id out of range");
+        int64_t b = (int64_t)r.first - 1, e = r.second;          // cells [first - 1, second), clipped to the slot
+        const int64_t slot = (int64_t)(c->off[r.tid + 1] - c->off[r.tid]);
+        if (b < 0) b = 0;
+        if (e > slot) e = slot;
+        if (b >= e) continue;
+        uint64_t gb = c->off[r.tid] + (uint64_t)b, ge = c->off[r.tid] + (uint64_t)e;
+        if (gb < lo_cell) gb = lo_cell;
+        if (ge > hi_cell) ge = hi_cell;
+        for (uint64_t p = gb; p < ge; p += PIECE) {
+            Piece pc; pc.start = p - lo_cell; pc.count = (uint32_t)std::min<uint64_t>(PIECE, ge - p); pc.region = (uint32_t)i;
+            pieces.push_back(pc);
+        }
+    }
+    const size_t W = (size_t)m->world;
+    const size_t b_sum = n * 8, b_cov = (n * 4 + 7) / 8 * 8, blk = b_sum + b_cov, b_p = (pieces.size() * sizeof(Piece) + 15) / 16 * 16;
+    std::string emsg;
+    { std::lock_guard<std::mutex> lk(c->mu); rc = ensure_scratch(c, b_p + blk * (W + 1) + 64); if (rc) emsg = c->err; }
+    if (rc) return comm_fail(m, rc, emsg);
+    unsigned char *sc = (unsigned char *)c->scratch;
+    Piece *d_p = (Piece *)sc;
+    unsigned char *mine = sc + b_p, *all = mine + blk;
+    unsigned long long *d_sum = (unsigned long long *)mine;
+    int *d_cov = (int *)(mine + b_sum);
+    if (!pieces.empty()) HIPCM(m, hipMemcpyAsync(d_p, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice, st));
+    HIPCM(m, hipMemsetAsync(mine, 0, blk, st));
+    HIPCM(m, hipStreamSynchronize(st));                 // pieces is a local
+    { std::lock_guard<std::mutex> lk(c->mu);
+      ProfScope ps(c, "slice_intervals");
+      launch_reduce_pieces(st, m->slice_depth, d_p, (uint32_t)pieces.size(), min_dep, d_cov, d_sum); }
+    HIPCM(m, hipGetLastError());
+    if (m->world > 1) {
+        HIPCM(m, hipEventRecord(m->swept, st));
+        HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
+        NCCLOK(m, rccl().AllGather(mine, all, blk, ncclUint8, m->nccl, ln));
+        HIPCM(m, hipEventRecord(m->gathered, ln));
+        HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
+    } else HIPCM(m, hipMemcpyAsync(all, mine, blk, hipMemcpyDeviceToDevice, st));
+    if (m->rank == root) {
+        std::vector<unsigned char> host(blk * W);
+        HIPCM(m, hipMemcpyAsync(host.data(), all, blk * W, hipMemcpyDeviceToHost, st));
+        HIPCM(m, hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; ++i) { cover[i] = 0; sum[i] = 0; }
+        for (size_t k = 0; k < W; ++k) {
+            const uint64_t *hs = (const uint64_t *)(host.data() + k * blk);
+            const int32_t *hc = (const int32_t *)(host.data() + k * blk + b_sum);
+            for (size_t i = 0; i < n; ++i) { cover[i] += hc[i]; sum[i] += hs[i]; }
+        }
+    } else HIPCM(m, hipStreamSynchronize(st));
+    return PD_OK;
 }
 
 } // extern "C"

@@ -114,6 +114,9 @@ void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64
                      uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes /* bytes of flags; behind them: 16 + 4 * tiles bytes for the list */,
                      const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part,
                      int *depth_out /* non-null: no statistics, the slice's summed depth as int32 cells instead */);
+int launch_sweep_windows_slice(hipStream_t st, int *depth_slice, uint32_t tile_first, uint32_t tile_count, TileMap tm, uint32_t w, uint32_t min_dep,
+                               uint32_t *cover, unsigned long long *sum, TilePart *part);
+void launch_window_edges(hipStream_t st, const TilePart *part, TileMap tm, uint32_t n_tiles, uint32_t w, uint32_t *cover, unsigned long long *sum);
 void launch_window_gather(hipStream_t st, const TilePart *part, TileMap tm, int32_t n_contigs, uint32_t w,
                           uint64_t n_windows, uint32_t *cover, unsigned long long *sum);
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,

@@ -1782,14 +1782,15 @@ typedef int v4i_nt __attribute__((ext_vector_type(4)));
 
 template <bool WRITE, bool WIN, bool FROM_DEPTH>
 __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32_t wrap_mask,
-                                              const TileMap tmap, WinArgs wa, const uint8_t *hstate)
+                                              const TileMap tmap, WinArgs wa, const uint8_t *hstate, uint32_t tile0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wtot[4];
     constexpr int ROWS = TILE / (WG * 4);                        // 8
-    const uint64_t t = blockIdx.x;
+    // tile0: the sweep of a slice (a rank's share of the summed depth in the sharded list mode): `buf` holds tiles tile0, tile0 + 1, ...
+    const uint64_t t = (uint64_t)blockIdx.x + tile0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int4 *p4 = reinterpret_cast<int4 *>(buf + t * TILE) + wv * (ROWS * 64) + lane;
+    int4 *p4 = reinterpret_cast<int4 *>(buf + (uint64_t)blockIdx.x * TILE) + wv * (ROWS * 64) + lane;
     int4 v[ROWS];
     // a half-tile nobody has written since the reset holds stale bytes and counts as zeros; waves
     // 0-1 cover the first 4096 cells of the tile, waves 2-3 the second (wave-uniform branch)
@@ -2649,7 +2650,7 @@ void launch_scan_write(hipStream_t st, int *buf, const int *carry, uint32_t n_ti
                        const uint8_t *hstate)
 {
     TileMap tm{}; WinArgs wa{};
-    hipLaunchKernelGGL((k_sweep<true, false, false>), dim3(n_tiles), dim3(WG), 0, st, buf, carry, wrap_mask, tm, wa, hstate);
+    hipLaunchKernelGGL((k_sweep<true, false, false>), dim3(n_tiles), dim3(WG), 0, st, buf, carry, wrap_mask, tm, wa, hstate, 0u);
 }
 
 static size_t win_lds_bytes(uint32_t w)
@@ -2672,12 +2673,12 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, true>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate);
+        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate, 0u);
     } else {
         if (lds > 48 * 1024) e = hipFuncSetAttribute((const void *)k_sweep<false, true, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate);
+        hipLaunchKernelGGL((k_sweep<false, true, false>), dim3(n_tiles), dim3(WG), lds, st, buf, carry, wrap_mask, tm, wa, hstate, 0u);
     }
     if (w >= (uint32_t)TILE && n_windows)
         hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n_windows + 3) / 4)), dim3(WG), 0, st, part, tm, n_contigs,
@@ -2685,6 +2686,29 @@ int launch_sweep_windows(hipStream_t st, int *buf, const int *carry, uint32_t n_
     if (w < (uint32_t)TILE && n_tiles > 1)
         hipLaunchKernelGGL(k_window_edges, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const TilePart *)part, tm, n_tiles, w, cover, sum);
     return 0;
+}
+
+// Narrow windows over a SLICE of the summed depth (tiles [tile_first, tile_first + tile_count) of the genome, `depth_slice` holding exactly
+// those): windows inside the slice's tiles into the (whole-genome) window arrays, the shares of the windows across tile edges into
+// part[tile] (whole-genome indexing); the caller merges ranks and runs launch_window_edges once everything is together.
+int launch_sweep_windows_slice(hipStream_t st, int *depth_slice, uint32_t tile_first, uint32_t tile_count, TileMap tm, uint32_t w, uint32_t min_dep,
+                               uint32_t *cover, unsigned long long *sum, TilePart *part)
+{
+    if (!tile_count) return 0;
+    WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = cover; wa.sum = sum; wa.part = part;
+    const size_t lds = win_lds_bytes(w);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_sweep<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(tile_count), dim3(WG), lds, st, depth_slice, (const int *)nullptr, 0xFFFFFFFFu, tm, wa,
+                       (const uint8_t *)nullptr, tile_first);
+    return 0;
+}
+
+void launch_window_edges(hipStream_t st, const TilePart *part, TileMap tm, uint32_t n_tiles, uint32_t w, uint32_t *cover, unsigned long long *sum)
+{
+    if (n_tiles > 1) hipLaunchKernelGGL(k_window_edges, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, part, tm, n_tiles, w, cover, sum);
 }
 
 void launch_reduce_pieces(hipStream_t st, const int *depth, const Piece *pieces, uint32_t n_pieces,

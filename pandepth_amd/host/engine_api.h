@@ -60,6 +60,8 @@ typedef struct pd_engine_api {
     int (*text_release)(pd_text *, uint64_t);
     int (*text_append_window_rows)(pd_text *, int32_t, uint32_t, uint64_t, size_t, const char *, size_t, uint64_t *);
     int (*text_append_bytes)(pd_text *, const void *, size_t);
+    /* optional (NULL = `#.list` inputs with -g / -b add the contexts into one GPU): see pd_sliced_interval_sum */
+    int (*sliced_interval_sum)(pd_comm *, const pd_region *, size_t, uint32_t, unsigned, int, int32_t *, uint64_t *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

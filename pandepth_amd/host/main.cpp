@@ -13,7 +13,7 @@ int main(int argc, char **argv)
         pd_window_layout, pd_scan_reduce_windows, pd_reduce_windows, pd_read_depth, pd_synchronize, pd_push_bgzf_units, pd_device_count, pd_accumulate_from,
         pd_decode_begin, pd_decode_acquire, pd_decode_submit, pd_decode_end, pd_decode_abort, pd_set_param,
         pd_comm_init_all, pd_sliced_window_sum, pd_comm_destroy, pd_comm_strerror, pd_format_sites, pd_keep_deferred, pd_deflate_parse, pd_host_register, pd_host_unregister,
-        pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes,
+        pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes, pd_sliced_interval_sum,
     };
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in

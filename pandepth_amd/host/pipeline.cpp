@@ -1331,45 +1331,66 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         return eng.ck(api->scan(eng.ctx, wrap_bits), "pd_scan");
     };
     auto bail = [&]() { std::cerr << "Error: " << eng.err << std::endl; return 2; };
+    // A collective over the contexts (one thread per rank): what several GPUs' statistics have in common.  `call(k, comm)` is the
+    // rank's collective; returns 1 done, 0 not applicable (no communicator, or the samples do not fit the sliced sum's 4-bit images:
+    // PD_ERANGE on every rank, nothing consumed — the contexts are then added into the first one), -1 error.
+    auto sliced = [&](const std::function<int(int, pd_comm *)> &call, const char *what) -> int {
+        if (merged || scanned || !(n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) || !api->comm_init_all || getenv("PANDEPTH_NO_RCCL")) return 0;
+        std::vector<pd_ctx *> ctxs;
+        for (auto &e : engs) ctxs.push_back(e->ctx);
+        std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
+        // RCCL announces itself on stdout (a version banner, from whichever thread first gets there); this program's stdout
+        // is compared byte for byte with the reference's, and nothing of ours is printed until the sum is done
+        struct Quiet {
+            int saved = -1;
+            Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
+            ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
+        };
+        std::unique_ptr<Quiet> quiet(getenv("PANDEPTH_RCCL_VERBOSE") ? nullptr : new Quiet);
+        if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) != 0) {
+            quiet.reset();
+            if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
+            return 0;
+        }
+        std::vector<int> rcs((size_t)n_ctx, 0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < n_ctx; ++k) th.emplace_back([&, k]() { rcs[(size_t)k] = call(k, comms[(size_t)k]); });
+        for (auto &t : th) t.join();
+        // PD_ERANGE (-6) on every rank: a sample with more cells outside the 4-bit image's range than the exception block
+        // holds (amplicon, very deep RNA-seq).  Nothing was consumed; the contexts are added into the first one instead.
+        bool ok = true, too_wide = true;
+        for (int k = 0; k < n_ctx; ++k) if (rcs[(size_t)k] != PD_ERANGE) too_wide = false;
+        for (int k = 0; k < n_ctx && !too_wide; ++k)
+            if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string(what) + ": " + (m ? m : "?")); }
+        if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
+        quiet.reset();
+        if (too_wide) {
+            if (tm.on) fprintf(stderr, "[timing] the samples do not fit the sliced sum's 4-bit images: the contexts are added into GPU %d instead\n", device);
+            return 0;
+        }
+        if (ok && tm.on) fprintf(stderr, "[timing] %s summed over %d GPUs in slices (RCCL)\n", what, n_ctx);
+        return ok ? 1 : -1;
+    };
     // cover / depth sum of every window of `width` cells (pd_window_layout order), whichever way the sample is held
     auto window_stats = [&](uint32_t width, uint32_t *cov, uint64_t *sum) -> bool {
-        if (!merged && !scanned && width >= PD_TILE_CELLS && (n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) && api->comm_init_all && api->sliced_window_sum && !getenv("PANDEPTH_NO_RCCL")) {
-            std::vector<pd_ctx *> ctxs;
-            for (auto &e : engs) ctxs.push_back(e->ctx);
-            std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
-            // RCCL announces itself on stdout (a version banner, from whichever thread first gets there); this program's stdout
-            // is compared byte for byte with the reference's, and nothing of ours is printed until the sum is done
-            struct Quiet {
-                int saved = -1;
-                Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
-                ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
-            };
-            std::unique_ptr<Quiet> quiet(getenv("PANDEPTH_RCCL_VERBOSE") ? nullptr : new Quiet);
-            if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) == 0) {
-                std::vector<int> rcs((size_t)n_ctx, 0);
-                std::vector<std::thread> th;
-                for (int k = 0; k < n_ctx; ++k)
-                    th.emplace_back([&, k]() { rcs[(size_t)k] = api->sliced_window_sum(comms[(size_t)k], width, min_dep, wrap_bits, 0, k == 0 ? cov : nullptr, k == 0 ? sum : nullptr); });
-                for (auto &t : th) t.join();
-                // PD_ERANGE (-6) on every rank: a sample with more cells outside the 4-bit image's range than the exception block
-                // holds (amplicon, very deep RNA-seq).  Nothing was consumed; the contexts are added into the first one instead.
-                bool ok = true, too_wide = true;
-                for (int k = 0; k < n_ctx; ++k) if (rcs[(size_t)k] != PD_ERANGE) too_wide = false;
-                for (int k = 0; k < n_ctx && !too_wide; ++k)
-                    if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string("pd_sliced_window_sum: ") + (m ? m : "?")); }
-                if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
-                quiet.reset();
-                if (!too_wide) {
-                    if (tm.on) fprintf(stderr, "[timing] window statistics summed over %d GPUs in slices (RCCL)\n", n_ctx);
-                    return ok;
-                }
-                if (tm.on) fprintf(stderr, "[timing] the samples do not fit the sliced sum's 4-bit images: the contexts are added into GPU %d instead\n", device);
-            } else
-            if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
+        if (api->sliced_window_sum && (width >= PD_TILE_CELLS || (api->sliced_interval_sum && !o.site_out))) {   // (narrow windows: engines with the cell-level collectives)
+            const int r = sliced([&](int k, pd_comm *cm) { return api->sliced_window_sum(cm, width, min_dep, wrap_bits, 0, k == 0 ? cov : nullptr, k == 0 ? sum : nullptr); },
+                                 "window statistics");
+            if (r) return r > 0;
         }
         if (!merge_contexts()) return false;
         const int rc = scanned ? api->reduce_windows(eng.ctx, width, min_dep, cov, sum) : api->scan_reduce_windows(eng.ctx, width, min_dep, wrap_bits, cov, sum);
         return eng.ck(rc, "window reduction");
+    };
+    // CoveredSite / TotalDepth of every region (PD:329-348), whichever way the sample is held
+    auto interval_stats = [&](const std::vector<pd_region> &regs, int32_t *cov, uint64_t *sum) -> bool {
+        if (api->sliced_interval_sum && !o.site_out) {
+            const int r = sliced([&](int k, pd_comm *cm) { return api->sliced_interval_sum(cm, regs.data(), regs.size(), min_dep, wrap_bits, 0, k == 0 ? cov : nullptr, k == 0 ? sum : nullptr); },
+                                 "interval statistics");
+            if (r) return r > 0;
+        }
+        if (!need_scan()) return false;
+        return eng.ck(api->reduce_intervals(eng.ctx, regs.data(), regs.size(), min_dep, cov, sum), "pd_reduce_intervals");
     };
 
     // The per-site file is written behind the statistics and the tables: both read the same depth cells, the engine serialises
@@ -1519,15 +1540,13 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
                 b.depth = sum[woff[kv.first] + k];
             }
     } else {
-        if (!need_scan()) return bail();
         std::vector<pd_region> regs;
         for (auto &kv : rm.genes)
             for (auto &g : kv.second)
                 for (auto &c : g.second.cds) regs.push_back(pd_region{kv.first, c.first, c.second});
         std::vector<int32_t> cov(regs.size() ? regs.size() : 1);
         std::vector<uint64_t> sum(regs.size() ? regs.size() : 1);
-        if (!eng.ck(api->reduce_intervals(eng.ctx, regs.data(), regs.size(), min_dep, cov.data(), sum.data()), "pd_reduce_intervals"))
-            return bail();
+        if (!interval_stats(regs, cov.data(), sum.data())) return bail();
         size_t i = 0;
         for (auto &kv : rm.genes)
             for (auto &g : kv.second)

@@ -44,6 +44,11 @@ def sample(r, k, n=20000):
     return np.concatenate([iv, np.tile(np.array([[0, 10 + k + r, 50]], dtype=np.int32), (500, 1)),
                            np.tile(np.array([[0, 8190, 8200 + r]], dtype=np.int32), (40, 1)),
                            np.tile(np.array([[1, 16380 + r, 16390 + r]], dtype=np.int32), (30, 1))])
+_rg = np.random.default_rng(99)
+_tid = _rg.integers(0, len(LENS), 4000)
+_first = (_rg.random(4000) * np.asarray(LENS)[_tid]).astype(np.int64) + 1
+REGS = np.stack([_tid, _first, np.minimum(_first + _rg.integers(0, 60000, 4000), np.asarray(LENS)[_tid])], axis=1).astype(np.int32)
+REGS[0] = [0, 1, LENS[0]]; REGS[1] = [1, 8192, 8193]; REGS[2] = [0, 8193, 16384]
 _b = np.repeat(np.arange(1000, 451000, 3, dtype=np.int32), 10)
 OVER = np.ascontiguousarray(np.stack([np.zeros_like(_b), _b, _b + 100], axis=1))
 assert int(LENS[0]) > 452000
@@ -63,6 +68,19 @@ def rank_main(rank):
                 iv = sample(rank, 7); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
                 e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
                 res.append(c.run(8192, 2, 18, 0))
+            elif mode == "cells":
+                # statistics that need the summed CELLS: every rank makes its slice's depth and reduces what lies in it
+                # (pd_sliced_window_sum below 8192 cells, pd_sliced_interval_sum); root 0, then root on the last rank
+                e.push_intervals(sample(rank, 3))
+                for w in (100, 149, 1000, 4096, 8191):
+                    res.append(c.window_sum(w, 2 if w == 149 else 1, 18, 0))
+                res.append(c.interval_sum(REGS, 1, 18, world - 1))
+                res.append(c.interval_sum(REGS[:7], 3, 0, 0))
+                # ... and from a deferred (sorted, pending) sample: the export comes straight from the tile windows
+                e.reset(); e.set_param("direct_windows", 1)
+                iv = sample(rank, 5); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
+                e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
+                res.append(c.window_sum(100, 1, 18, 0))
             elif mode == "overflow":
                 # more cells outside the 4-bit range than the exception block holds (2^18): ten reads start on every third base
                 # of 450 000 bases on rank 0 (+10 at 150 000 cells, -10 at 150 000 others: the ends fall on another residue, nothing
@@ -100,6 +118,28 @@ if mode == "pipeline":
                 assert np.array_equal(got[1], cov) and np.array_equal(got[2], tot), (k, r)
             else:
                 assert got is None
+elif mode == "cells":
+    import pd_oracle as O
+    d, off = oracle_depth(LENS, np.concatenate([sample(r, 3) for r in range(world)]), True)
+    for j, w in enumerate((100, 149, 1000, 4096, 8191)):
+        cov, tot = windows_ref(LENS, d, off, w, 2 if w == 149 else 1)
+        for r in range(world):
+            got = results[r][j]
+            if r == 0:
+                assert np.array_equal(got[1], cov) and np.array_equal(got[2], tot), (w, int((got[1] != cov).sum()), int((got[2] != tot).sum()))
+            else:
+                assert got is None
+    ec, es = O.stat_regions(d, off, REGS, 1)
+    got = results[world - 1][5]
+    assert np.array_equal(got[0], ec) and np.array_equal(got[1], es), (int((got[0] != ec).sum()), int((got[1] != es).sum()))
+    d0, off0 = oracle_depth(LENS, np.concatenate([sample(r, 3) for r in range(world)]), False)
+    ec, es = O.stat_regions(d0, off0, REGS[:7], 3)
+    got = results[0][6]
+    assert np.array_equal(got[0], ec) and np.array_equal(got[1], es)
+    d, off = oracle_depth(LENS, np.concatenate([sample(r, 5) for r in range(world)]), True)
+    cov, tot = windows_ref(LENS, d, off, 100, 1)
+    got = results[0][7]
+    assert np.array_equal(got[1], cov) and np.array_equal(got[2], tot)
 else:
     for r in range(world):
         assert results[r][0] == -6, (r, results[r][0])            # PD_ERANGE on every rank
@@ -125,28 +165,36 @@ def test_sliced_sum_n_ranks_through_the_library(world, shim):
     _run(world, "pipeline", shim)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_cell_level_statistics_n_ranks(world, shim):
+    """pd_sliced_window_sum for windows below 8192 cells and pd_sliced_interval_sum: every rank turns its slice of the exchanged
+    images into depth cells and reduces the windows / region stretches that lie in it — against the oracle on the summed samples
+    (windows of 100, 149, 1000, 4096 and 8191 cells incl. the ones across tile and slice boundaries; 4000 regions incl. a whole
+    contig and regions that start or end on a tile edge; with and without the 18-bit wrap; a deferred sample)."""
+    _run(world, "cells", shim)
+
+
 def test_exception_overflow_is_a_clean_decline_on_every_rank(shim):
     """A sample whose 4-bit image has more out-of-range cells than the exception block holds: PD_ERANGE everywhere, and every
     context still holds its sample (the executable then adds the contexts up with pd_accumulate_from)."""
     _run(3, "overflow", shim)
 
 
-LIST_WIDE = [e for e in MANIFEST if ".list" in e["args"][1] and e["fixture"] in ("f1", "f2") and
-             not any(a in e["args"] for a in ("-g", "-b", "-a"))]
+LIST_WIDE = [e for e in MANIFEST if ".list" in e["args"][1] and e["fixture"] in ("f1", "f2") and "-a" not in e["args"]]
 
 
 @pytest.mark.parametrize("gpus", ["2", "3"])
 @pytest.mark.parametrize("case", LIST_WIDE, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, shim, tmp_path):
-    """`#.list` inputs: one context per (stand-in) GPU, pd_comm_init_all + pd_sliced_window_sum with N = 2 and 3 ranks — the same
-    bytes as the reference (narrow -w cases take pd_accumulate_from and must agree as well)."""
+    """`#.list` inputs: one context per (stand-in) GPU, pd_comm_init_all + pd_sliced_window_sum / pd_sliced_interval_sum with N = 2
+    and 3 ranks — the same bytes as the reference for whole-chromosome tables, `-w` tables of any width and `-g` / `-b` tables."""
     d = os.path.join(HERE, "golden", case["fixture"])
     env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_GPUS=gpus, PANDEPTH_RCCL_LIB=shim)
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
-    if "-w" not in case["args"]:
-        assert b"in slices (RCCL)" in p.stderr, p.stderr.decode()[-800:]
+    # whole-chromosome bins, narrow windows and annotation intervals alike: nobody adds the contexts into one GPU
+    assert b"in slices (RCCL)" in p.stderr and b"added into GPU" not in p.stderr, p.stderr.decode()[-800:]
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()
