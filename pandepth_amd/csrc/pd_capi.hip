@@ -132,8 +132,10 @@ struct pd_ctx {
             cap[k] = want;
             return true;
         }
-        void release() { for (int k = 0; k < N; ++k) { if (p[k]) (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; } if (st) { (void)hipStreamDestroy(st); st = nullptr; } }
+        void release() { for (int k = 0; k < N; ++k) { if (p[k]) (void)hipFree(p[k]); p[k] = nullptr; cap[k] = 0; } if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+                         if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; } for (auto &e : ev_stage) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
         hipStream_t st = nullptr;
+        void *h_stage = nullptr; hipEvent_t ev_stage[2] = {nullptr, nullptr};     // page-locked staging of the symbols' way back
         std::mutex mu;
     } lz[2];
     std::atomic<unsigned> lz_turn{0};
@@ -1861,8 +1863,31 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
         e = hipMemcpyAsync(d_off, sym_off, ((size_t)n_chunks + 1) * 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) { launch_lz_gather(st, d_syms, stride, d_off, n_chunks, d_out); e = hipGetLastError(); }
         if (dbg && e == hipSuccess) { e = hipStreamSynchronize(st); tick(); }
-        if (e == hipSuccess) e = hipMemcpyAsync(syms, d_out, total * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // the symbols come back through a page-locked buffer of the slot, in pieces, and are copied on from there: a large copy
+        // straight into the caller's pageable memory makes the runtime lock and unlock those pages around it
+        const size_t PIECE = (size_t)8 << 20;                        // bytes
+        if (!w.h_stage && hipHostMalloc(&w.h_stage, 2 * PIECE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w.h_stage = nullptr; }
+        if (w.h_stage && getenv("PD_LZ_DIRECT_COPY") == nullptr) {
+            if (!w.ev_stage[0]) { (void)hipEventCreateWithFlags(&w.ev_stage[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&w.ev_stage[1], hipEventDisableTiming); }
+            const size_t bytes = total * 4;
+            const size_t n_pieces = (bytes + PIECE - 1) / PIECE;
+            // piece k is on the wire while piece k - 1 is copied out of the other half of the buffer
+            for (size_t k = 0; k <= n_pieces && e == hipSuccess; ++k) {
+                if (k < n_pieces) {
+                    const size_t off = k * PIECE, n = std::min(PIECE, bytes - off);
+                    e = hipMemcpyAsync((uint8_t *)w.h_stage + (k & 1) * PIECE, (const uint8_t *)d_out + off, n, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipEventRecord(w.ev_stage[k & 1], st);
+                }
+                if (k > 0 && e == hipSuccess) {
+                    const size_t off = (k - 1) * PIECE, n = std::min(PIECE, bytes - off);
+                    e = hipEventSynchronize(w.ev_stage[(k - 1) & 1]);
+                    if (e == hipSuccess) memcpy((uint8_t *)syms + off, (const uint8_t *)w.h_stage + ((k - 1) & 1) * PIECE, n);
+                }
+            }
+        } else {
+            if (e == hipSuccess) e = hipMemcpyAsync(syms, d_out, total * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
     }
     tick();
     if (dbg && ti >= 7)

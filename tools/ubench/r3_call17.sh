@@ -15,13 +15,10 @@ def run(cmd, env=None, tag="", keys=("pd_destroy",)):
     print("%s: wall %.3f s rc %d; last stderr line at %.3f s, exit %.3f s later" % (tag, dt, p.returncode, last or 0, dt-(last or 0)))
     for l in lines:
         if any(k in l for k in keys): print("    %s" % l[:230])
-G={"PGZ_DEV_CHUNK_KB":"16","PGZ_DEV_TAIL_KB":"4","PGZ_DEV_BATCH_MB":"96","PANDEPTH_TIMING":"1"}
-for tag,env,args in (("resident -w 100 -a",{},["-w","100","-a"]),("resident -a only",{},["-a"]),("-w 100 only",{},["-w","100"]),
-                     ("orderly exit -w 100 -a",{"PANDEPTH_ORDERLY_EXIT":"1"},["-w","100","-a"]),
-                     ("host parse -a only",{"PANDEPTH_DEVICE_DEFLATE":"0"},["-a"]),
-                     ("no site overlap",{"PANDEPTH_SITE_OVERLAP":"0"},["-w","100","-a"])):
-    for k in range(4):
+for tag,env,args in (("staged symbol copies",{},["-w","100","-a"]),("direct copies into pageable memory",{"PD_LZ_DIRECT_COPY":"1"},["-w","100","-a"]),
+                     ("staged, -a only",{},["-a"]),("direct, -a only",{"PD_LZ_DIRECT_COPY":"1"},["-a"])):
+    for k in range(5):
         time.sleep(0.7)
-        run([cli,"-i","w.bam"]+args+["-o","dev","-t","16"], dict(G, **env), "%s #%d" % (tag,k))
+        run([cli,"-i","w.bam"]+args+["-o","dev","-t","16"], dict({"PANDEPTH_TIMING":"1"}, **env), "%s #%d" % (tag,k), ("per-site writer",))
 PY
 rm -rf /tmp/e2e
