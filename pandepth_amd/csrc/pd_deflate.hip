@@ -10,6 +10,7 @@
 // All HBM-bound or latency-bound integer work; nothing here is a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "pd_kernels.h"
 #include "pd_lz77.h"
 
@@ -104,10 +105,17 @@ __global__ __launch_bounds__(WGZ) void k_lz_ranks(const uint64_t *sorted, uint32
 }
 
 // ---- the parse: one wave per chunk ----
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each XCD with its own L2.  A chunk's candidates
+// lie in the 32 KiB before it, so neighbouring chunks share their text: XCD x takes the x-th eighth of the chunks (xcd_chunks each) and
+// walks it with `per_xcd` waves that take consecutive chunks — the text an XCD works on at any time is per_xcd x 16 KiB, not the
+// whole round (the counters showed 48 GB fetched for 48 MB of text with chunks dealt round-robin).
 __global__ __launch_bounds__(64) void k_lz_parse(const pdz::Text T, const uint64_t *chunks /* start, end, origin per chunk */, uint32_t n_chunks,
-                                                 uint32_t *syms, uint64_t stride, uint32_t *counts)
+                                                 uint32_t *syms, uint64_t stride, uint32_t *counts, uint32_t xcd_chunks, uint32_t per_xcd)
 {
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    for (uint32_t j = slot; j < xcd_chunks; j += per_xcd) {
+        const uint32_t c = xcd * xcd_chunks + j;
+        if (c >= n_chunks) break;
         const uint64_t start = chunks[3 * c], end = chunks[3 * c + 1], origin = chunks[3 * c + 2];
         pdz::Out o{syms + (uint64_t)c * stride, 0u, (uint32_t)stride};
         const bool ok = pdz::parse_chunk<DevWaveZ>(T, start, end, origin, o);
@@ -199,7 +207,11 @@ void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const
 {
     if (!n_chunks) return;
     const pdz::Text T{text, S, R, bucket, n_text};
-    hipLaunchKernelGGL(k_lz_parse, dim3(n_chunks), dim3(64), 0, st, T, chunks, n_chunks, syms, stride, counts);
+    const uint32_t xcd_chunks = (n_chunks + 7) / 8;
+    uint32_t per_xcd = 1024;                                    // waves per XCD: 32 CUs x 4 SIMDs x 8 (all that fit)
+    if (const char *e = getenv("PD_LZ_PER_XCD")) { const long v = atol(e); if (v >= 1 && v <= 65536) per_xcd = (uint32_t)v; }
+    if (per_xcd > xcd_chunks) per_xcd = xcd_chunks;
+    hipLaunchKernelGGL(k_lz_parse, dim3(8 * per_xcd), dim3(64), 0, st, T, chunks, n_chunks, syms, stride, counts, xcd_chunks, per_xcd);
 }
 
 void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out)

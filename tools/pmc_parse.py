@@ -13,7 +13,7 @@ dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
 
 
 def short(name):
-    m = re.search(r"pdk::(k_\w+(?:<[^>]*>)?)", name)
+    m = re.search(r"pdk::(?:\(anonymous namespace\)::)?(k_\w+(?:<[^>]*>)?)", name)
     return m.group(1) if m else name
 
 

@@ -24,6 +24,7 @@ for it in range(2):
     eng.push_intervals_device(other.data_ptr(), int(other.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))
     eng.scan_reduce_windows(10000000, 1, 0)
     eng.scan(0)          # write-back sweep: reads AND writes every cell once = the calibration kernel
+    eng.reduce_windows(100, 1)      # narrow windows off the depth (k_sweep<false, true, true>: LDS accumulators + k_window_edges)
     eng.synchronize()
 # the direct window path (k_direct_tiles): both streams deferred, difference arrays never materialised
 eng.set_param("direct_windows", 1)
@@ -48,8 +49,21 @@ for it in range(2):
     eng.push_runs(runs8, pda.PD_PUSH_MORE)
     eng.export_i4(img.data_ptr(), exc.data_ptr(), 1 << 18, cnt.data_ptr())
     eng.synchronize()
+# the sliced sum's receiving side on the image just exported: one part, the whole genome (k_sweep_i4_wave)
+n_tiles = n_cells // 8192
+sums = torch.zeros(n_tiles + 16, dtype=torch.int32, device=dev)
+part = torch.zeros(n_tiles * 24 + 64, dtype=torch.uint8, device=dev)
+for it in range(2):
+    eng.slice_sweep_i4(img.data_ptr(), 1, n_cells // 2, 0, n_tiles, sums.data_ptr(), 0, 0, 0, 10000000, 1, 18, part.data_ptr())
+    eng.synchronize()
+# zlib's LZ77 parse on the device (pd_deflate_parse): 48 MB of per-site rows in 16 KiB chunks with 4 KiB of overlap
+rows = b"".join(b"Chr01\t%d\t%d\n" % (j, 30 + (j * 2654435761 >> 7) % 23) for j in range(3200000))
+CH, TAIL = 16384, 4096
+chunks = [(s0, min(len(rows), s0 + CH + TAIL), max(0, s0 - 32768)) for s0 in range(0, len(rows) - TAIL, CH)]
+for it in range(2):
+    eng.deflate_parse(rows, chunks)
 eng.reset()
 eng.runs_destroy(runs8)
 eng.set_param("direct_windows", 0)
 eng.reset()
-print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]))
+print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]), "lz text", len(rows), "chunks", len(chunks))
