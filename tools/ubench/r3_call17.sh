@@ -15,10 +15,10 @@ def run(cmd, env=None, tag="", keys=("pd_destroy",)):
     print("%s: wall %.3f s rc %d; last stderr line at %.3f s, exit %.3f s later" % (tag, dt, p.returncode, last or 0, dt-(last or 0)))
     for l in lines:
         if any(k in l for k in keys): print("    %s" % l[:230])
-for tag,env,args in (("staged symbol copies",{},["-w","100","-a"]),("direct copies into pageable memory",{"PD_LZ_DIRECT_COPY":"1"},["-w","100","-a"]),
-                     ("staged, -a only",{},["-a"]),("direct, -a only",{"PD_LZ_DIRECT_COPY":"1"},["-a"])):
+for tag,env,args in (("quick exit",{},["-w","100","-a"]),("quick exit after freeing the text rings and parse buffers",{"PANDEPTH_EXIT_FREE":"1"},["-w","100","-a"]),
+                     ("orderly",{"PANDEPTH_ORDERLY_EXIT":"1"},["-w","100","-a"])):
     for k in range(5):
         time.sleep(0.7)
-        run([cli,"-i","w.bam"]+args+["-o","dev","-t","16"], dict({"PANDEPTH_TIMING":"1"}, **env), "%s #%d" % (tag,k), ("per-site writer",))
+        run([cli,"-i","w.bam"]+args+["-o","dev","-t","16"], dict({"PANDEPTH_TIMING":"1"}, **env), "%s #%d" % (tag,k), ("per-site writer (","pd_destroy"))
 PY
 rm -rf /tmp/e2e
