@@ -68,6 +68,7 @@ struct Tables {
 
 struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
     uint64_t blocks = 0, dblocks = 0, steps = 0, sync_rounds = 0, emit_rounds = 0, sym_true = 0, sym_decoded = 0, lanes_redecoded = 0;
+    uint64_t copy_serial = 0, long_matches = 0;     // per round: the longest ready match's 8-byte pieces (what the wave waits for); matches > 16 bytes
     uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0;
 };
 
@@ -583,6 +584,11 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     copy_match(out, dst[l], dist[l], len[l]);
                     if (st) st->copy_iters += (len[l] + 31) / 32;
                 });
+                if (st) {
+                    uint32_t mx = 0;
+                    W::each([&](int l) { if (ready[l]) { const uint32_t it = (len[l] + 7) / 8; if (it > mx) mx = it; if (len[l] > 16) st->long_matches++; } });
+                    st->copy_serial += mx;
+                }
                 W::fence();
                 done |= W::ballot_ne(ready, 0u);
                 if (st) st->emit_rounds++;

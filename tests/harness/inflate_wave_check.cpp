@@ -181,6 +181,8 @@ int main(int argc, char **argv)
         printf("wave-serial loop trips per member: sync %.0f, emit %.0f, header symbols %.0f, copy chunk-iterations %.0f; bytes per member %.0f\n",
                (double)s.wave_iters_sync / s.blocks, (double)s.wave_iters_emit / s.blocks, (double)s.hdr_syms / s.blocks, (double)s.copy_iters / s.blocks,
                (double)bytes / blocks);
+        printf("match copies: the wave waits for %.0f 8-byte pieces per member (the longest ready match of every round); %.0f matches per member are longer than 16 bytes\n",
+               (double)s.copy_serial / s.blocks, (double)s.long_matches / s.blocks);
     }
     return bad ? 1 : 0;
 }
