@@ -90,25 +90,39 @@ PZ_FN uint32_t longest_match(const Text &T, uint64_t p, uint32_t prev_len, uint6
     const bool two = budget > 64u && avail > 64u;
     const uint8_t *tp = T.text + p;
     U len0, pos0, len1, pos1;
+    const uint32_t p32 = (uint32_t)p, org = (uint32_t)origin;   // (a round's text is below 4 GB)
     W::each([&](int l) {
-        const uint32_t k0 = (uint32_t)l, k1 = 64u + (uint32_t)l;
-        const bool in0 = k0 < avail && k0 < budget, in1 = two && k1 < avail && k1 < budget;
-        const uint32_t q0 = in0 ? T.S[r - 1 - k0] : 0u, q1 = in1 ? T.S[r - 1 - k1] : 0u;
-        pos0[l] = q0; pos1[l] = q1;
-        // zlib: the head of the chain may be exactly MAX_DIST away, the others must be nearer; position `origin` is NIL
-        const bool ok0 = in0 && q0 != (uint32_t)origin && (l == 0 ? p - q0 <= (uint64_t)MAX_DIST : p - q0 < (uint64_t)MAX_DIST);
-        const bool ok1 = in1 && q1 != (uint32_t)origin && p - q1 < (uint64_t)MAX_DIST;
-        // the first 16 bytes of both candidates at once (a lane without a candidate compares p with itself and drops the result)
-        const uint8_t *t0 = ok0 ? T.text + q0 : tp, *t1 = ok1 ? T.text + q1 : tp;
         const uint64_t a0 = ld64(tp), a1 = ld64(tp + 8);
-        const uint64_t x00 = a0 ^ ld64(t0), x01 = a1 ^ ld64(t0 + 8), x10 = a0 ^ ld64(t1), x11 = a1 ^ ld64(t1 + 8);
+        // zlib: the head of the chain may be exactly MAX_DIST away, the others must be nearer; position `origin` is NIL
+        const uint32_t k0 = (uint32_t)l;
+        const bool in0 = k0 < avail && k0 < budget;
+        const uint32_t q0 = in0 ? T.S[r - 1 - k0] : 0u;
+        const bool ok0 = in0 && q0 != org && (l == 0 ? p32 - q0 <= (uint32_t)MAX_DIST : p32 - q0 < (uint32_t)MAX_DIST);
+        // the first 16 bytes at once (a lane without a candidate compares p with itself and drops the result)
+        const uint8_t *t0 = ok0 ? T.text + q0 : tp;
+        uint32_t q1 = 0; bool ok1 = false;
+        const uint8_t *t1 = tp;
+        if (two) {                                             // (wave-uniform) the second 64 candidates, their loads in flight with the first
+            const uint32_t k1 = 64u + (uint32_t)l;
+            const bool in1 = k1 < avail && k1 < budget;
+            q1 = in1 ? T.S[r - 1 - k1] : 0u;
+            ok1 = in1 && q1 != org && p32 - q1 < (uint32_t)MAX_DIST;
+            t1 = ok1 ? T.text + q1 : tp;
+        }
+        const uint64_t x00 = a0 ^ ld64(t0), x01 = a1 ^ ld64(t0 + 8);
+        uint64_t x10 = 0, x11 = 0;
+        if (two) { x10 = a0 ^ ld64(t1); x11 = a1 ^ ld64(t1 + 8); }
         ah.b1 = T.bucket[ah.h1]; ah.b2 = T.bucket[ah.h2];     // (the same for every lane)
         uint32_t n0 = x00 ? (uint32_t)(__builtin_ctzll(x00) >> 3) : x01 ? 8u + (uint32_t)(__builtin_ctzll(x01) >> 3) : 16u;
-        uint32_t n1 = x10 ? (uint32_t)(__builtin_ctzll(x10) >> 3) : x11 ? 8u + (uint32_t)(__builtin_ctzll(x11) >> 3) : 16u;
         if (ok0 && n0 == 16u && cap > 16u) n0 = 16u + lcp(tp + 16, t0 + 16, cap - 16u);
-        if (ok1 && n1 == 16u && cap > 16u) n1 = 16u + lcp(tp + 16, t1 + 16, cap - 16u);
+        pos0[l] = q0;
         len0[l] = ok0 ? (n0 < cap ? n0 : cap) + 1u : 0u;      // + 1: 0 marks "the chain ends here"
-        len1[l] = ok1 ? (n1 < cap ? n1 : cap) + 1u : 0u;
+        pos1[l] = q1; len1[l] = 0u;
+        if (two) {
+            uint32_t n1 = x10 ? (uint32_t)(__builtin_ctzll(x10) >> 3) : x11 ? 8u + (uint32_t)(__builtin_ctzll(x11) >> 3) : 16u;
+            if (ok1 && n1 == 16u && cap > 16u) n1 = 16u + lcp(tp + 16, t1 + 16, cap - 16u);
+            len1[l] = ok1 ? (n1 < cap ? n1 : cap) + 1u : 0u;
+        }
     });
     uint32_t best = prev_len, best_q = 0;
     bool head_ok = true;
