@@ -350,17 +350,20 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long l
     return x;
 }
 
-__device__ __forceinline__ void narrow_window_row(const uint32_t (&d)[4], uint32_t pos, uint32_t phase, uint32_t w, float inv_w, uint32_t min_dep,
-                                                  uint64_t cells_left /* cells of the contig from the tile's first */, unsigned long long *acc, int lane)
+// (x / w by a multiplication: x = cell + phase < 2^14 and w < 2^13, so floor(x * ceil(2^32 / w) / 2^32) is exact — one instruction per
+// row where a float reciprocal with its two corrections took a dozen; these sweeps are bound by their vector instructions, a
+// wave64 instruction occupying its SIMD for four cycles, not by HBM)
+__device__ __forceinline__ uint32_t narrow_magic(uint32_t w) { return (uint32_t)((0x100000000ull + w - 1) / w); }
+
+__device__ __forceinline__ void narrow_window_row(const uint32_t (&d)[4], uint32_t pos, uint32_t phase, uint32_t w, uint32_t magic, uint32_t min_dep,
+                                                  uint32_t cells_left /* cells of the contig from the tile's first, at most TILE */, unsigned long long *acc, int lane)
 {
     const uint32_t x = pos + phase;
-    uint32_t q = (uint32_t)((float)x * inv_w);
-    if ((uint64_t)q * w > x) --q;
-    if ((uint64_t)(q + 1) * w <= x) ++q;
-    const uint32_t k = (uint32_t)((uint64_t)(q + 1) * w - phase - pos);      // window q + 1 starts k cells behind this lane's first (k >= 1)
+    const uint32_t q = __umulhi(x, magic);
+    const uint32_t k = (q + 1u) * w - x;                          // window q + 1 starts k cells behind this lane's first (k >= 1)
     unsigned long long v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ((uint64_t)pos + e < cells_left && d[e] >= min_dep) ? ((1ull << 48) | d[e]) : 0ull;
+    for (int e = 0; e < 4; ++e) v[e] = (pos + e < cells_left && d[e] >= min_dep) ? ((1ull << 48) | d[e]) : 0ull;
     const unsigned long long T = v[0] + v[1] + v[2] + v[3];
     const unsigned long long L = wave_incl_scan_u64(T);
     if (k <= 4u && !(lane == 63 && k == 4u)) {
@@ -405,13 +408,15 @@ __device__ __forceinline__ void direct_small_windows(const int4 (&v)[ROWS], cons
     for (uint32_t j = threadIdx.x; j < nacc; j += WG) acc[j] = 0;
     __syncthreads();
     const uint32_t phase = local0 - k0 * w;                      // offset of the tile inside window k0
+    const uint32_t magic = narrow_magic(w);
+    const uint32_t left = clen > local0 ? (clen - local0 < (uint32_t)TILE ? clen - local0 : (uint32_t)TILE) : 0u;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int bsum = base + rowex[r];
         const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
         const uint32_t d[4] = {(uint32_t)(v[r].x + bsum) & wrap_mask, (uint32_t)(v[r].y + bsum) & wrap_mask,
                                (uint32_t)(v[r].z + bsum) & wrap_mask, (uint32_t)(v[r].w + bsum) & wrap_mask};
-        narrow_window_row(d, pos, phase, w, wa.inv_w, wa.min_dep, clen > local0 ? (uint64_t)clen - local0 : 0ull, acc, lane);
+        narrow_window_row(d, pos, phase, w, magic, wa.min_dep, left, acc, lane);
     }
     __syncthreads();
     narrow_write_out(acc, nacc, k0, w, local0, clen, wbase, wa, pt);
@@ -1897,11 +1902,13 @@ __global__ __launch_bounds__(WG) void k_sweep(int *buf, const int *carry, uint32
         for (uint32_t j = threadIdx.x; j < nacc; j += WG) acc[j] = 0;
         __syncthreads();
         const uint32_t phase = (uint32_t)(local0 - k0 * w);      // offset of the tile inside window k0
+        const uint32_t magic = w >= 2u ? narrow_magic(w) : 0u;
+        const uint32_t left = (uint64_t)clen - local0 < (uint64_t)TILE ? (uint32_t)(clen - local0) : (uint32_t)TILE;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const uint32_t pos = (uint32_t)(wv * (ROWS * 256) + r * 256 + lane * 4);
             const uint32_t d[4] = {(uint32_t)v[r].x, (uint32_t)v[r].y, (uint32_t)v[r].z, (uint32_t)v[r].w};
-            if (w >= 4u) { narrow_window_row(d, pos, phase, w, wa.inv_w, wa.min_dep, (uint64_t)clen - local0, acc, lane); continue; }
+            if (w >= 4u) { narrow_window_row(d, pos, phase, w, magic, wa.min_dep, left, acc, lane); continue; }
             // windows of 1-3 cells: several begin inside a lane's four cells; one atomic per window piece
             const uint32_t x = pos + phase;
             uint32_t q = (uint32_t)((float)x * wa.inv_w);
