@@ -138,3 +138,54 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
         if tag == "resident":
             assert "window table (text resident on the device)" in err and "rows, written" in err, err[-1500:]
     assert outs["resident"] == outs["zlib"] and outs["full"] == outs["zlib"] and outs["hosttext"] == outs["zlib"]
+
+
+def _pgz(check, path, env, *args):
+    r = subprocess.run([check, str(path)] + [str(a) for a in args], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    return r.stdout.split()[0] if r.stdout.split() else r.stderr[-300:]
+
+
+def test_gzip_streams_with_the_engines_parse_in_the_devices_geometry(tmp_path):
+    """host/pgzip.cpp with stage 1 by the engine's parse (host emulation) in the geometry a device provider gets — 16 KiB chunks
+    with 4 KiB of overlap, rounds of a few MiB running behind the writer, two provider calls per round — whole buffers and the
+    streaming interface fed in irregular pieces: the bytes of zlib's single stream; texts whose parses cannot meet inside the
+    overlap (a pure period) decline, never differ."""
+    import random
+    subprocess.run(["make", "-C", H, "pgzip_check"], check=True, stdout=subprocess.DEVNULL)
+    check = os.path.join(H, "pgzip_check")
+    rnd = random.Random(9)
+    site = "".join("Chr%02d\t%d\t%d\n" % (1 + i // 400000, i % 400000, max(0, int(rnd.gauss(40, 15)))) for i in range(700000)).encode()
+    win = "".join("Chr%02d\t%d\t%d\t100\t%d\t%d\t%.2f\t%.2f\n" % (1 + k // 9000, 1 + 100 * k, 100 * k + 100, c, t, c * 1.0, t / 100.0)
+                  for k, c, t in ((k, rnd.randint(0, 100), rnd.randint(0, 9000)) for k in range(120000))).encode()
+    zero = "".join("scaffold_%d\t%d\t0\n" % (i // 50000, i % 50000) for i in range(400000)).encode()
+    for name, data in (("site", site), ("win", win), ("zero", zero)):
+        f = tmp_path / (name + ".txt")
+        f.write_bytes(data)
+        for env in ({"PGZ_NATIVE": "1", "PGZ_DEV_BATCH_MB": "2"}, {"PGZ_NATIVE": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_PIECES": "1"},
+                    {"PGZ_NATIVE": "1", "PGZ_DEV_CHUNK_KB": "32", "PGZ_DEV_TAIL_KB": "8", "PGZ_DEV_BATCH_MB": "3"}):
+            assert _pgz(check, f, env, 4) == "identical", (name, env)
+    per = bytes(rnd.randint(0, 255) for _ in range(37))
+    f = tmp_path / "per.bin"
+    f.write_bytes(per * 60000 + bytes(rnd.randint(0, 255) for _ in range(900)) + per * 20000)
+    assert _pgz(check, f, {"PGZ_NATIVE": "1", "PGZ_DEV_BATCH_MB": "1"}, 4) in ("identical", "declined")
+    # mutated records, digit streams, skewed alphabets: identical or declined
+    seen = {"identical": 0, "declined": 0}
+    for it in range(24):
+        k = rnd.randrange(3)
+        if k == 0:
+            base = bytes(rnd.choices(range(97, 110), k=rnd.randrange(20, 300)))
+            out = bytearray()
+            for _ in range(rnd.randrange(2000, 12000)):
+                b = bytearray(base)
+                for _ in range(rnd.randrange(0, 4)):
+                    b[rnd.randrange(len(b))] = rnd.randrange(97, 123)
+                out += b + b"\n"
+            data = bytes(out)
+        elif k == 1:
+            data = b"".join(b"%d\t%d\t%.2f\n" % (rnd.randrange(10 ** rnd.randrange(1, 9)), i, rnd.random() * 100) for i in range(rnd.randrange(20000, 90000)))
+        else:
+            data = bytes(rnd.choices(range(256), weights=[1 / (i + 1) ** rnd.uniform(0.5, 3) for i in range(256)], k=rnd.randrange(200000, 900000)))
+        f = tmp_path / "fz.bin"
+        f.write_bytes(data)
+        seen[_pgz(check, f, {"PGZ_NATIVE": "1", "PGZ_DEV_BATCH_MB": "1"}, 3)] += 1
+    assert seen["identical"] >= 18, seen
