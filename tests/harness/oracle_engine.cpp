@@ -6,6 +6,7 @@
 // libpandepth_amd.so, libpandepth_host.a or the `pandepth` binary.
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <zlib.h>
 #include <mutex>
 #include <string>
@@ -340,6 +341,9 @@ static int o_text_append_window_rows(pd_text *t, int32_t tid, uint32_t w, uint64
 static int o_text_append_bytes(pd_text *t, const void *p, size_t n) { return text_put(t, (const char *)p, n); }
 static int o_text_parse(pd_text *t, uint64_t off, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *soff, uint32_t *crc, uint64_t crc_span)
 {
+    // PANDEPTH_TEST_TEXT_PARSE_FAIL=k: every k-th call fails (the host logic must then parse those chunks with zlib itself)
+    static std::atomic<unsigned> calls{0};
+    if (const char *e = getenv("PANDEPTH_TEST_TEXT_PARSE_FAIL")) { const unsigned k = (unsigned)atoi(e); if (k && (++calls % k) == 0) { t->c->err = "injected failure"; return -5; } }
     std::vector<uint8_t> text;
     {
         std::lock_guard<std::mutex> lk(t->mu);
