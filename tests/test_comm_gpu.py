@@ -112,7 +112,7 @@ def test_cli_list_mode_sums_through_the_communicator(case, tmp_path):
     d = os.path.join(HERE, "golden", case["fixture"])
     env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=600, env=env)
+                       stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
     assert b"in slices (RCCL)" in p.stderr, p.stderr.decode()[-800:]
     assert p.stdout.decode() == case["stdout"]

@@ -103,7 +103,7 @@ def rank_main(rank):
         errors.append("rank %d: %s" % (rank, traceback.format_exc()))
 th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
 for t in th: t.start()
-for t in th: t.join(600)
+for t in th: t.join(240)
 assert not errors, "\n".join(errors)
 assert len(results) == world
 if mode == "pipeline":
@@ -154,7 +154,7 @@ print("LOOPBACK-OK", world, mode)
 
 def _run(world, mode, shim):
     p = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(world), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                       timeout=900, env=dict(os.environ, PANDEPTH_RCCL_LIB=shim))
+                       timeout=360, env=dict(os.environ, PANDEPTH_RCCL_LIB=shim))
     assert p.returncode == 0 and "LOOPBACK-OK %d %s" % (world, mode) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
@@ -191,7 +191,7 @@ def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, shim
     d = os.path.join(HERE, "golden", case["fixture"])
     env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_GPUS=gpus, PANDEPTH_RCCL_LIB=shim)
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=600, env=env)
+                       stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
     # whole-chromosome bins, narrow windows and annotation intervals alike: nobody adds the contexts into one GPU
     assert b"in slices (RCCL)" in p.stderr and b"added into GPU" not in p.stderr, p.stderr.decode()[-800:]
@@ -238,6 +238,6 @@ assert np.array_equal(out[0][1], want[1]) and np.array_equal(out[0][2], want[2])
 assert int(want[2].sum()) > 4.0e8
 print("CHUNKED-OK")
 '''
-    p = subprocess.run([sys.executable, "-c", code, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200,
+    p = subprocess.run([sys.executable, "-c", code, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
                        env=dict(os.environ, PANDEPTH_RCCL_LIB=shim))
     assert p.returncode == 0 and "CHUNKED-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
