@@ -46,6 +46,19 @@ int pd_push_bgzf_units(pd_ctx *ctx, const void *blob, size_t n_bytes, const pd_b
 int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_bytes, void *host_out, size_t out_cap,
                       size_t *out_len, int variant, int reps, double *kernel_ms, uint32_t *n_blocks);
 
+/* ---- guarded device allocations (a debugging aid for the library's own kernels) -----------------
+ * With PANDEPTH_GUARD=1 in the environment every device buffer the library allocates is surrounded by two 256-byte canaries (the
+ * one behind it starting exactly at the buffer's last byte + 1).  pd_guard_check waits for the device, compares every live
+ * buffer's canaries and returns the number of buffers found overwritten since the process started (0 when the guard is off); the
+ * text of the last finding — size and allocating source line of the buffer, how many bytes at which offsets — goes to `msg` (may be
+ * NULL) and to stderr.  pd_reset checks too, and every buffer is checked when it is freed.  The GPU test suite runs with the guard
+ * on (tests/conftest.py) and fails a test that leaves a finding. */
+int pd_guard_check(char *msg, size_t cap);
+/* Proves the guard sees what it is there for: allocates a guarded buffer, writes ONE byte just behind it (then just in front of it) and
+ * expects the check to report exactly that.  0 = both found; 1 = the guard is off; -1 = the guard is on and missed a write.  The findings it
+ * provokes are not counted by pd_guard_check. */
+int pd_guard_selftest(void);
+
 #ifdef __cplusplus
 }
 #endif

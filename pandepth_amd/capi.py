@@ -106,6 +106,8 @@ def load():
         "pd_synchronize": (I, [P]),
         "pd_profile": (I, [P, I]),
         "pd_profile_get": (I, [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(U64)]),
+        "pd_guard_check": (I, [ctypes.c_char_p, SZ]),
+        "pd_guard_selftest": (I, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -120,7 +122,7 @@ EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset
            "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_text_append_window_rows", "pd_text_append_bytes", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
            "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_interval_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
-           "pd_profile_get"]
+           "pd_profile_get", "pd_guard_check", "pd_guard_selftest"]
 
 
 def _ptr(a):

@@ -29,9 +29,146 @@
 
 using namespace pdk;
 
+// ---- guarded device allocations (PANDEPTH_GUARD=1; pd_guard_check in include/pandepth_amd_dev.h) ---------------------------
+// Every device buffer this file allocates goes through the two functions below.  Normally they ARE hipMalloc / hipFree.  With
+// PANDEPTH_GUARD set, a buffer of n bytes is allocated as [256 B canary | n bytes | 256 B canary] (the second canary starting at
+// byte n exactly, not at a rounded size), the canaries are filled with a pattern, and they are compared — after a device
+// synchronize — whenever the buffer is freed and whenever pd_guard_check runs (pd_reset, pd_destroy, pd_comm_destroy call it):
+// a kernel that writes in front of or behind its buffer is named by the line that allocated the buffer, instead of landing in
+// the allocator's padding unseen.
+namespace pdguard {
+constexpr size_t G = 256;
+constexpr unsigned char PAT = 0xC5;
+struct Rec { size_t bytes; int line; };
+std::mutex mu;
+std::map<void *, Rec> live;
+std::atomic<uint64_t> n_bad{0};
+std::string last_msg;
+bool on() { static const bool v = [] { const char *e = getenv("PANDEPTH_GUARD"); return e && *e && strcmp(e, "0") != 0; }(); return v; }
+
+// caller holds mu; the device is idle
+uint64_t check_one(void *user, const Rec &r)
+{
+    unsigned char h[2 * G];
+    uint8_t *raw = (uint8_t *)user - G;
+    if (hipMemcpy(h, raw, G, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h + G, (uint8_t *)user + r.bytes, G, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int front = 0, back = 0, first_back = -1, last_back = -1, first_front = -1;
+    for (size_t i = 0; i < G; ++i) if (h[i] != PAT) { ++front; if (first_front < 0) first_front = (int)i; }
+    for (size_t i = 0; i < G; ++i) if (h[G + i] != PAT) { ++back; if (first_back < 0) first_back = (int)i; last_back = (int)i; }
+    if (!front && !back) return 0;
+    char m[320];
+    snprintf(m, sizeof m, "[guard] device buffer of %zu bytes allocated at pd_capi.hip:%d was written out of bounds: %d byte(s) in front (first at -%d), "
+             "%d byte(s) behind (offsets +%d .. +%d past the end)", r.bytes, r.line, front, first_front < 0 ? 0 : (int)G - first_front, back, first_back, last_back);
+    fprintf(stderr, "%s\n", m);
+    last_msg = m;
+    // repair the canaries so that one overrun is reported once
+    (void)hipMemset(raw, PAT, G); (void)hipMemset((uint8_t *)user + r.bytes, PAT, G);
+    return 1;
+}
+
+hipError_t gmalloc(void **out, size_t bytes, int line)
+{
+    if (!on()) return hipMalloc(out, bytes);
+    uint8_t *raw = nullptr;
+    const hipError_t e = hipMalloc((void **)&raw, bytes + 2 * G);
+    if (e != hipSuccess) return e;
+    (void)hipMemset(raw, PAT, G);
+    (void)hipMemset(raw + G + bytes, PAT, G);
+    (void)hipDeviceSynchronize();
+    *out = raw + G;
+    std::lock_guard<std::mutex> g(mu);
+    live[raw + G] = Rec{bytes, line};
+    return hipSuccess;
+}
+
+hipError_t gfree(void *user)
+{
+    if (!on() || !user) return hipFree(user);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = live.find(user);
+    if (it == live.end()) return hipFree(user);          // not one of ours (cannot happen; stay safe)
+    (void)hipDeviceSynchronize();
+    n_bad += check_one(user, it->second);
+    live.erase(it);
+    return hipFree((uint8_t *)user - G);
+}
+
+// a sub-buffer of a larger allocation (pd_create packs the context's small buffers into one): the caller has left G bytes in front of
+// and behind it; they become canaries, checked like everybody else's until drop()
+void adopt(void *user, size_t bytes, int line)
+{
+    if (!on()) return;
+    (void)hipMemset((uint8_t *)user - G, PAT, G);
+    (void)hipMemset((uint8_t *)user + bytes, PAT, G);
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> g(mu);
+    live[user] = Rec{bytes, line};
+}
+void drop(void *user)
+{
+    if (!on() || !user) return;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = live.find(user);
+    if (it == live.end()) return;
+    (void)hipDeviceSynchronize();
+    n_bad += check_one(user, it->second);
+    live.erase(it);
+}
+
+uint64_t check_all()
+{
+    if (!on()) return 0;
+    std::lock_guard<std::mutex> g(mu);
+    int dev = 0; (void)hipGetDevice(&dev);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : live) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, kv.first) == hipSuccess && at.device != dev) { (void)hipSetDevice(at.device); (void)hipDeviceSynchronize(); }
+        n_bad += check_one(kv.first, kv.second);
+    }
+    (void)hipSetDevice(dev);
+    return n_bad.load();
+}
+} // namespace pdguard
+
+template <class T> static inline hipError_t pd_dmalloc(T **out, size_t bytes, int line) { return pdguard::gmalloc((void **)out, bytes, line); }
+#define hipMalloc(p, n) pd_dmalloc((p), (n), __LINE__)
+#define hipFree(p) pdguard::gfree((void *)(p))
+
+extern "C" int pd_guard_check(char *msg, size_t cap)
+{
+    const uint64_t n = pdguard::check_all();
+    if (msg && cap) { std::lock_guard<std::mutex> g(pdguard::mu); snprintf(msg, cap, "%s", pdguard::last_msg.c_str()); }
+    return n > 0x7fffffff ? 0x7fffffff : (int)n;
+}
+
+// proves that the guard sees what it is there to see: a guarded buffer is allocated, ONE byte is written just behind it (and, second
+// round, just in front of it), and the check must report exactly that.  Returns 0 when both are found, 1 when the guard is off, -1 when the
+// guard is on and misses a write.  The findings it provokes are not counted (pd_guard_check's count is unchanged).
+extern "C" int pd_guard_selftest(void)
+{
+    if (!pdguard::on()) return 1;
+    int found = 0;
+    for (int side = 0; side < 2; ++side) {
+        uint8_t *p = nullptr;
+        if (hipMalloc(&p, 1000) != hipSuccess) return -1;
+        (void)hipMemset(side ? p - 1 : p + 1000, 0, 1);
+        (void)hipDeviceSynchronize();
+        const uint64_t before = pdguard::n_bad.load();
+        (void)hipFree(p);
+        if (pdguard::n_bad.load() == before + 1) ++found;
+        pdguard::n_bad.store(before);
+    }
+    { std::lock_guard<std::mutex> g(pdguard::mu); pdguard::last_msg.clear(); }
+    return found == 2 ? 0 : -1;
+}
+
 namespace {
 
-constexpr int N_STAGE = 1024;                        // upper bound; slots are created on demand
+constexpr int N_STAGE = 1024;                       // upper bound; slots are created on demand
 constexpr size_t STAGE_CAP = (size_t)1 << 18;        // runs per staging slot (3 MiB pinned + 3 MiB HBM)
 constexpr size_t DEV_BATCH_MAX = 0xFFFFFF00ull;       // runs per sorted batch (32-bit run indices)
 constexpr uint64_t OVF_MAX = (uint64_t)64 << 20;     // overflow-list entries (ends of runs longer than lmax) per tile pass
@@ -74,6 +211,7 @@ struct pd_ctx {
     std::vector<uint64_t> off;                       // first cell of each slot
     uint64_t n_cells = 0, n_tiles = 0, n_words = 0;
     int *buf = nullptr;                              // [n_cells diff | n_tiles sums | pad]
+    uint8_t *slab = nullptr;                         // ONE allocation behind the seventeen small buffers below (carry .. chk)
     int *sums = nullptr, *carry = nullptr, *bsum = nullptr;
     uint64_t *d_off = nullptr; uint32_t *d_len = nullptr; uint32_t *d_tile_contig = nullptr;
     uint32_t *ub_a[PD_MAXPEND] = {}, *cand_lo[PD_MAXPEND] = {};   // per pending batch, indexed by 4096-cell tile
@@ -474,21 +612,35 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     CREATE_OK(hipMalloc(&c->buf, c->n_words * 4));
     tm_mark("cell buffer");
     c->sums = c->buf + c->n_cells;
-    CREATE_OK(hipMalloc(&c->carry, (c->n_tiles + 4) * 4));
-    CREATE_OK(hipMalloc(&c->bsum, (c->n_tiles / 1024 + 4) * 4));
-    CREATE_OK(hipMalloc(&c->d_off, ((size_t)n_contigs + 1) * 8));
-    CREATE_OK(hipMalloc(&c->d_len, (size_t)n_contigs * 4));
-    CREATE_OK(hipMalloc(&c->d_tile_contig, (c->n_tiles + 1) * 4));
-    for (int b = 0; b < PD_MAXPEND; ++b) {
-        CREATE_OK(hipMalloc(&c->ub_a[b], (c->n_tiles * 2 + 4) * 4));      // indexed by 4096-cell scatter tile
-        CREATE_OK(hipMalloc(&c->cand_lo[b], (c->n_tiles * 2 + 4) * 4));
-    }
     c->n_half = (uint32_t)(c->n_cells / PD_HALF);
-    CREATE_OK(hipMalloc(&c->hstate, c->n_half + 16));
-    CREATE_OK(hipMalloc(&c->slice_flags, slice_flag_bytes(c->n_tiles) + 16 + c->n_tiles * 4 + 16));   // flags | counter | list of flagged tiles
-    CREATE_OK(hipMalloc(&c->direct_words, 64 + (c->n_tiles + 4) * 4));       // [n_long, fail, heavy_count, diagnostics ... | heavy tile list at +16]
-    CREATE_OK(hipMalloc(&c->desc, sizeof(BatchDesc) * PD_MAXPEND));
-    CREATE_OK(hipMalloc(&c->chk, sizeof(CheckWords)));
+    {
+        // the small buffers come out of ONE allocation (seventeen hipMalloc calls were 17 ms of every run's start-up), each on a 256-byte
+        // boundary; with PANDEPTH_GUARD they keep a canary in front of and behind them inside the slab, like separate allocations would
+        struct Want { void **pp; size_t bytes; int line; };
+        std::vector<Want> wants;
+#define WANT(field, bytes_) wants.push_back(Want{(void **)&(field), (size_t)(bytes_), __LINE__})
+        WANT(c->carry, (c->n_tiles + 4) * 4);
+        WANT(c->bsum, (c->n_tiles / 1024 + 4) * 4);
+        WANT(c->d_off, ((size_t)n_contigs + 1) * 8);
+        WANT(c->d_len, (size_t)n_contigs * 4);
+        WANT(c->d_tile_contig, (c->n_tiles + 1) * 4);
+        for (int b = 0; b < PD_MAXPEND; ++b) {
+            WANT(c->ub_a[b], (c->n_tiles * 2 + 4) * 4);          // indexed by 4096-cell scatter tile
+            WANT(c->cand_lo[b], (c->n_tiles * 2 + 4) * 4);
+        }
+        WANT(c->hstate, c->n_half + 16);
+        WANT(c->slice_flags, slice_flag_bytes(c->n_tiles) + 16 + c->n_tiles * 4 + 16);   // flags | counter | list of flagged tiles
+        WANT(c->direct_words, 64 + (c->n_tiles + 4) * 4);        // [n_long, fail, heavy_count, diagnostics ... | heavy tile list at +16]
+        WANT(c->desc, sizeof(BatchDesc) * PD_MAXPEND);
+        WANT(c->chk, sizeof(CheckWords));
+#undef WANT
+        const size_t gap = pdguard::on() ? pdguard::G : 0;
+        std::vector<size_t> at(wants.size());
+        size_t total = 0;
+        for (size_t k = 0; k < wants.size(); ++k) { total += gap; at[k] = total; total = (total + wants[k].bytes + gap + 255) / 256 * 256; }
+        CREATE_OK(hipMalloc(&c->slab, total + 256));
+        for (size_t k = 0; k < wants.size(); ++k) { *wants[k].pp = c->slab + at[k]; pdguard::adopt(*wants[k].pp, wants[k].bytes, wants[k].line); }
+    }
     {
         std::vector<uint32_t> tc(c->n_tiles + 1, 0);
         for (int32_t i = 0; i < n_contigs; ++i)
@@ -528,8 +680,10 @@ int pd_destroy(pd_ctx *c)
     }
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    void *ptrs[] = {c->buf, c->carry, c->bsum, c->d_off, c->d_len, c->d_tile_contig, c->ub_a[0], c->ub_a[1], c->ub_a[2], c->ub_a[3],
-                    c->cand_lo[0], c->cand_lo[1], c->cand_lo[2], c->cand_lo[3], c->hstate, c->slice_flags, c->direct_words, c->desc, c->chk, c->ovf, c->scratch, c->wk};
+    for (void *p : {(void *)c->carry, (void *)c->bsum, (void *)c->d_off, (void *)c->d_len, (void *)c->d_tile_contig, (void *)c->ub_a[0], (void *)c->ub_a[1], (void *)c->ub_a[2],
+                    (void *)c->ub_a[3], (void *)c->cand_lo[0], (void *)c->cand_lo[1], (void *)c->cand_lo[2], (void *)c->cand_lo[3], (void *)c->hstate, (void *)c->slice_flags,
+                    (void *)c->direct_words, (void *)c->desc, (void *)c->chk}) pdguard::drop(p);            // (parts of the slab)
+    void *ptrs[] = {c->buf, c->slab, c->ovf, c->scratch, c->wk};
     t1 = dec_now_us();
     for (void *p : ptrs) if (p) (void)hipFree(p);
     t2 = dec_now_us();
@@ -575,6 +729,7 @@ int pd_reset(pd_ctx *c)
         }
     c->pend.clear();
     c->state = 0;
+    if (pdguard::on()) (void)pdguard::check_all();
     int rc = do_reset(c);
     if (rc == PD_OK && (c->run_first || c->run_other || c->run_far || c->dec_runs)) {          // the decoded sample's runs go with it
         HIPOK(c, hipStreamSynchronize(c->stream));
@@ -1821,16 +1976,19 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
     std::vector<uint32_t> counts(n_chunks);
     hipError_t e = hipMemsetAsync(d_text + n_text, 0, 64, st);
     if (tx) {
-        // the stretch, segment by segment (the segments stay where they are until the caller releases them)
-        std::lock_guard<std::mutex> tlk(tx->mu);
+        // the stretch, segment by segment (the segments stay where they are until the caller releases them).  The stream's lock is
+        // released before anything is reported: fail() takes the context's lock, and the append paths take the two in the other order.
         uint64_t got = 0;
-        for (const auto &sg : tx->segs) {
-            const uint64_t lo = std::max<uint64_t>(sg.off, tx_off), hi = std::min<uint64_t>(sg.off + sg.len, tx_off + n_text);
-            if (lo >= hi) continue;
-            if (e == hipSuccess) e = hipMemcpyAsync(d_text + (lo - tx_off), tx->ring + sg.phys + (lo - sg.off), (size_t)(hi - lo), hipMemcpyDeviceToDevice, st);
-            got += hi - lo;
+        {
+            std::lock_guard<std::mutex> tlk(tx->mu);
+            for (const auto &sg : tx->segs) {
+                const uint64_t lo = std::max<uint64_t>(sg.off, tx_off), hi = std::min<uint64_t>(sg.off + sg.len, tx_off + n_text);
+                if (lo >= hi) continue;
+                if (e == hipSuccess) e = hipMemcpyAsync(d_text + (lo - tx_off), tx->ring + sg.phys + (lo - sg.off), (size_t)(hi - lo), hipMemcpyDeviceToDevice, st);
+                got += hi - lo;
+            }
         }
-        if (got != n_text) { cleanup(); return fail(c, PD_EINVAL, "pd_text_parse: the stretch is not (or no longer) in the stream"); }
+        if (got != n_text) { (void)hipStreamSynchronize(st); cleanup(); return fail(c, PD_EINVAL, "pd_text_parse: the stretch is not (or no longer) in the stream"); }
     } else if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
     static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");

@@ -23,6 +23,11 @@ int main(int argc, char **argv)
     const bool orderly = getenv("PANDEPTH_ORDERLY_EXIT") != nullptr;
     if (!orderly) setenv("PANDEPTH_KEEP_CONTEXT", "1", 1);
     const int rc = pandepth_main(argc, argv, &api, dev ? atoi(dev) : 0);
+    if (getenv("PANDEPTH_GUARD") && pd_guard_check(nullptr, 0) > 0) {          // debugging aid: a kernel wrote outside one of the engine's buffers
+        fprintf(stderr, "pandepth: PANDEPTH_GUARD found an out-of-bounds device write (see above)\n");
+        fflush(stderr);
+        _exit(97);
+    }
     fflush(stdout); fflush(stderr);
     if (orderly) return rc;
     _exit(rc);

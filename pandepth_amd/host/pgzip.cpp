@@ -844,7 +844,10 @@ struct Stream::Impl {
         const uint64_t avail = is_remote ? total : base + buf.size();   // == total
         uint64_t c_hi = parsed_hi;                            // exclusive
         if (final) c_hi = total == 0 ? 1 : (total + CH - 1) / CH;
-        else while ((c_hi + 1) * CH + TAIL <= avail) ++c_hi;
+        // (strictly inside the text seen so far: a chunk parsed in a round that is not the last one then never has tail_end == total,
+        // so the "runs to the end of the stream" branches of the final round only ever meet chunks that zlib itself parsed with the
+        // end of its input in sight — the provider's parse is not zlib's within MIN_LOOKAHEAD of a chunk's end)
+        else while ((c_hi + 1) * CH + TAIL < avail) ++c_hi;
         if (!final && c_hi <= parsed_hi) return true;
         if (is_remote) {
             work_base = 0;

@@ -56,8 +56,10 @@ struct Engine {
     pd_ctx *ctx = nullptr;
     std::mutex err_mu;
     std::string err;
+    std::atomic<bool> cancel{false};            // the run is being abandoned: a writer working behind the statistics stops where it is
     void fail(const std::string &m) { std::lock_guard<std::mutex> lk(err_mu); if (err.empty()) err = m; }
     bool ok() { std::lock_guard<std::mutex> lk(err_mu); return err.empty(); }
+    std::string message() { std::lock_guard<std::mutex> lk(err_mu); return err; }
     bool ck(int rc, const char *what)
     {
         if (rc == 0) return true;
@@ -792,6 +794,7 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
             const uint32_t len = hdr.lens[t];
             const std::string &nm = hdr.names[t];
             for (uint32_t b = 0; b < len && rc == 1; b += (uint32_t)CH) {
+                if (eng->cancel.load()) { rc = -1; break; }
                 const size_t n = std::min<size_t>(CH, len - b);
                 uint64_t got = 0;
                 const auto t0 = std::chrono::steady_clock::now();
@@ -813,8 +816,7 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
         if (getenv("PANDEPTH_KEEP_CONTEXT")) (void)st.release();   // (the process is about to end, main.cpp)
     }
     if (fclose(fp) != 0 && rc == 1) rc = -1;
-    if (rc == 0 && !eng->ok()) { std::lock_guard<std::mutex> lk(eng->err_mu); eng->err.clear(); }   // declined: the host-text path starts the file over
-    return rc;
+    return rc;                                                   // (0 = declined, and nothing here has touched the run's error text: the host-text path starts the file over)
 }
 
 // The `-w` table (PD:4366-4389) with its text resident on the device: the engine formats the rows from the window statistics its
@@ -887,7 +889,7 @@ int write_window_table_resident(GzWriter &out, Engine *eng, int threads, uint32_
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
         if (getenv("PANDEPTH_KEEP_CONTEXT")) (void)st.release();
     }
-    if (rc != 1) { if (!out.raw_rewind()) return -1; if (!eng->ok()) { std::lock_guard<std::mutex> lk(eng->err_mu); eng->err.clear(); } }
+    if (rc != 1 && !out.raw_rewind()) return -1;
     return rc;
 }
 
@@ -929,6 +931,7 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
                 if (!rm.has((int32_t)t)) continue;
                 const uint32_t len = hdr.lens[t];
                 for (uint32_t b = 0; b < len; b += (uint32_t)CH) {
+                    if (eng->cancel.load()) { prod_ok = false; goto out; }
                     const size_t n = std::min<size_t>(CH, len - b);
                     if (eng->api->format_sites) {
                         // the engine formats the rows where the cells are; one block of text comes back (into a buffer that is
@@ -1331,7 +1334,8 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         scanned = true;
         return eng.ck(api->scan(eng.ctx, wrap_bits), "pd_scan");
     };
-    auto bail = [&]() { std::cerr << "Error: " << eng.err << std::endl; return 2; };
+    std::function<void()> abandon_site_file = [] {};           // (set below: stops a per-site writer working behind the statistics)
+    auto bail = [&]() { abandon_site_file(); std::cerr << "Error: " << eng.message() << std::endl; return 2; };
     // A collective over the contexts (one thread per rank): what several GPUs' statistics have in common.  `call(k, comm)` is the
     // rank's collective; returns 1 done, 0 not applicable (no communicator, or the samples do not fit the sliced sum's 4-bit images:
     // PD_ERANGE on every rank, nothing consumed — the contexts are then added into the first one), -1 error.
@@ -1406,6 +1410,13 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         site_job.th = std::thread([&] { site_job.ok = write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng, o.threads); });
         if (getenv("PANDEPTH_SITE_OVERLAP") && getenv("PANDEPTH_SITE_OVERLAP")[0] == '0') { site_job.wait(); tm.mark("per-site file"); }
     }
+    // a failed run does not wait for the whole per-site file: the writer is told to stop, and what it wrote is removed
+    abandon_site_file = [&] {
+        if (!site_job.th.joinable()) return;
+        eng.cancel.store(true);
+        site_job.wait();
+        ::remove((prefix + ".SiteDepth.gz").c_str());
+    };
     auto site_done = [&]() -> bool {
         const bool was_running = site_job.th.joinable();
         site_job.wait();

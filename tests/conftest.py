@@ -25,6 +25,12 @@ def _has_gpu():
 
 HAS_GPU = _has_gpu()
 
+# On a GPU box the suite runs with the library's guarded device allocations (include/pandepth_amd_dev.h: pd_guard_check): every
+# buffer the engine allocates is surrounded by canaries, the executable exits with 97 when one of its kernels wrote outside a
+# buffer, and every gpu test is followed by a check of the buffers still alive.  PANDEPTH_GUARD=0 switches it off.
+if HAS_GPU:
+    os.environ.setdefault("PANDEPTH_GUARD", "1")
+
 
 def pytest_collection_modifyitems(config, items):
     # A gpu-marked test on a box without a GPU is a hard error on purpose when selected with
@@ -37,6 +43,21 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _no_out_of_bounds_device_writes(request):
+    yield
+    if not HAS_GPU or "gpu" not in request.keywords or os.environ.get("PANDEPTH_GUARD", "0") in ("", "0"):
+        return
+    import ctypes
+    import pandepth_amd as pda
+    L = pda.load()
+    msg = ctypes.create_string_buffer(400)
+    before = getattr(_no_out_of_bounds_device_writes, "seen", 0)
+    n = L.pd_guard_check(msg, 400)
+    _no_out_of_bounds_device_writes.seen = n
+    assert n == before, "a kernel wrote outside a device buffer: " + msg.value.decode()
 
 
 @pytest.fixture(scope="session")
