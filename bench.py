@@ -225,7 +225,104 @@ def e2e_site_windows(td, gen, cli, ref, threads, records=20000000):
     return out
 
 
-def e2e_leg(records, site_records):
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def e2e_site_windows_fullsize(td, bam, cli, threads, records):
+    """configs[3] at FULL size, on the configs[1] file itself (3.0 Gb genome, 1e9 records): `pandepth -w 100 -a` — 3.0e7 window rows and
+    3.0e9 per-site lines (~60 GB of text through the device-side formatter, LZ77 parse and CRC, ~8 GB of gzip on disk).  The reference
+    needs ~16 minutes for this run, so it is not repeated here: tools/bamgen is deterministic (the file is a function of -n and -S,
+    not of the thread count), the reference was run ONCE on the identical file builder-side and the SHA-256 of its two outputs is
+    committed (profiles/r04_fullsize_reference.json); this leg compares hashes.  Without that file the per-site stream is checked
+    against the window table instead (line count and depth sum, tools/sitecheck)."""
+    mine = os.path.join(td, "mine_wfull")
+    w_dev, err = _best_wall([cli, "-i", bam, "-w", "100", "-a", "-o", mine, "-t", str(threads)], 1, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
+    ph, _ = parse_timing(err)
+    out = {"mode": "pandepth -i s.bam -w 100 -a -o out -t N on the configs[1] file (full size)", "records": int(records),
+           "pandepth": {"wall_s": round(w_dev, 3), "records_per_s": records / w_dev, "threads": threads, "phases_s": ph},
+           "win_stat_gz_bytes": os.path.getsize(mine + ".win.stat.gz"), "site_depth_gz_bytes": os.path.getsize(mine + ".SiteDepth.gz")}
+    t0 = time.perf_counter()
+    got = {"win.stat.gz": _sha256(mine + ".win.stat.gz"), "SiteDepth.gz": _sha256(mine + ".SiteDepth.gz")}
+    out["sha256"] = got
+    out["hash_s"] = round(time.perf_counter() - t0, 1)
+    ref_file = os.path.join(ROOT, "profiles", "r04_fullsize_reference.json")
+    ref = None
+    try:
+        ref = json.load(open(ref_file))
+    except (OSError, ValueError):
+        ref = None
+    if ref and int(ref.get("records", 0)) == int(records) and "w100a" in ref:
+        same = {k: got[k] == ref["w100a"]["sha256"].get(k) for k in got}
+        out["byte_identical_files"] = same
+        out["byte_identical"] = all(same.values())
+        out["reference"] = {"wall_s": ref["w100a"].get("wall_s"), "threads": ref["w100a"].get("threads"), "where": ref.get("where"),
+                            "source": "profiles/" + os.path.basename(ref_file)}
+        if ref["w100a"].get("wall_s"):
+            out["speedup_vs_reference_builder_side"] = round(ref["w100a"]["wall_s"] / w_dev, 1)
+    else:
+        chk = os.path.join(ROOT, "tools", "sitecheck")
+        if not os.access(chk, os.X_OK):
+            subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "sitecheck.cpp"), "-lz", "-o", chk], check=True)
+        p = subprocess.run([chk, mine + ".SiteDepth.gz", mine + ".win.stat.gz"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=3000)
+        out["site_stream_check"] = p.stdout.decode().strip()[-400:]
+        out["site_stream_consistent_with_window_table"] = p.returncode == 0
+    for suf in ("win.stat.gz", "SiteDepth.gz"):
+        os.remove(mine + "." + suf)
+    return out
+
+
+def e2e_multi_leg(n_bams, records):
+    """Multi-BAM `#.list` end to end (configs[4]'s shape): n_bams payload BAMs (tools/bamgen, seeds 42 ..), `pandepth -i s.list` — ONE
+    process, one context per visible GPU, the files decoded in parallel, the per-GPU samples summed in slices over RCCL / xGMI — against
+    the reference binary's list mode on the same files (it reads them one after another into one array, PD:2704-3014), chr.stat.gz
+    compared byte for byte.  records/s = n_bams x records / wall: THE figure on which the sharded path can scale with the number of
+    GPUs (the device-only `value` is bounded by the links)."""
+    gen = os.path.join(ROOT, "tools", "bamgen")
+    cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
+    ref = os.path.join(ROOT, "oracle", "_ref", "pandepth_ref")
+    quota = cpu_quota()
+    td = tempfile.mkdtemp(prefix="pdmulti", dir="/tmp")
+    try:
+        free = os.statvfs(td).f_bavail * os.statvfs(td).f_frsize
+        while records > 1e7 and n_bams * records * 56 > 0.6 * free:
+            records = int(records // 2)
+        t0 = time.perf_counter()
+        lst = os.path.join(td, "s.list")
+        total_bytes = 0
+        with open(lst, "w") as fh:
+            for k in range(n_bams):
+                b = os.path.join(td, "s%d.bam" % k)
+                subprocess.run([gen, "-o", b, "-n", str(int(records)), "-S", str(42 + k), "-t", str(min(32, os.cpu_count() or 1))], check=True,
+                               stderr=subprocess.PIPE, timeout=3600)
+                total_bytes += os.path.getsize(b)
+                fh.write(b + "\n")
+        t_gen = time.perf_counter() - t0
+        threads = max(4, min(16 * n_bams, quota, 64))
+        mine = os.path.join(td, "mine")
+        w_dev, err = _best_wall([cli, "-i", lst, "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
+        ph, _ = parse_timing(err)
+        how = [ln.strip() for ln in err.splitlines() if "summed over" in ln or "added into" in ln or "RCCL" in ln][:4]
+        out = {"n_bams": n_bams, "records_per_bam": int(records), "bam_bytes_total": total_bytes, "generated_in_s": round(t_gen, 1),
+               "mode": "pandepth -i s.list -o out -t N (one context per visible GPU; process wall clock exec-to-exit, warm page cache, best of 2)",
+               "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": n_bams * records / w_dev, "threads": threads, "phases_s": ph, "sum": how}}
+        if os.access(ref, os.X_OK):
+            w_ref = _best_wall([ref, "-i", lst, "-o", os.path.join(td, "ref"), "-t", "36"], 1)
+            out["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": n_bams * records / w_ref, "threads": 36}
+            out["byte_identical"] = open(mine + ".chr.stat.gz", "rb").read() == open(os.path.join(td, "ref.chr.stat.gz"), "rb").read()
+            out["speedup_vs_reference"] = round(w_ref / w_dev, 2)
+        return out
+    finally:
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def e2e_leg(records, site_records, fullsize_site=False):
     """END TO END, product path: the `pandepth` executable (GPU-side BGZF inflate + record parsing + the direct window
     kernel) and the reference binary on the SAME coordinate-sorted BAM with SEQ/QUAL/tag payload, written here by
     tools/bamgen (libdeflate level 6, BAI alongside), whole-chromosome mode, process wall clock (exec to exit, warm page
@@ -301,6 +398,11 @@ def e2e_leg(records, site_records):
                 e2e["annotation"] = e2e_annotation(td, bam, cli, ref, threads, records)
             except Exception as ex:                 # noqa: BLE001
                 e2e["annotation"] = {"failed": repr(ex)[:300]}
+        if fullsize_site and records >= 9e8:
+            try:                                    # configs[3] at full size on this very file
+                e2e["site_windows_fullsize"] = e2e_site_windows_fullsize(td, bam, cli, threads, records)
+            except Exception as ex:                 # noqa: BLE001
+                e2e["site_windows_fullsize"] = {"failed": repr(ex)[:300]}
         os.remove(bam)
         if site_records > 0:
             try:
@@ -323,7 +425,7 @@ def config_leg(args, which, eng, pda, synth, torch, dist, first, other, lens, ra
     n_runs = n_first + n_other
     R = int(args.records)
     n_cells = eng.device_layout()[0]
-    eng.set_param("direct_windows", 0)
+    eng.keep_deferred(False)
     regs, region_bases = None, 0
     if which == "gff":
         # synthetic annotation of configs[2] (README:128): 33 688 transcripts / 175 274 CDS entries, exon length log-normal
@@ -455,14 +557,28 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
-    ap.add_argument("--e2e-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_RECORDS", "3.0e8")),
+    ap.add_argument("--e2e-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_RECORDS", "-1")),
                     help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip; "
-                         "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write)")
+                         "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write; -1 (default) = 1e9 when /tmp has 120 GB "
+                         "free, otherwise 3e8 — the line says which and why)")
+    ap.add_argument("--e2e-multi-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_MULTI_RECORDS", "1.0e8")),
+                    help="records per BAM of the multi-BAM `#.list` end-to-end leg (one BAM per GPU of the run; 0 = skip)")
     ap.add_argument("--e2e-site-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_SITE_RECORDS", "2.0e7")),
                     help="records of the `-w 100 -a` end-to-end pair (configs[3]; 0 = skip)")
     ap.add_argument("--config", choices=["chr", "gff", "w100a"], default="chr",
                     help="chr = configs[1] (BASELINE.json's metric; default); gff = configs[2]; w100a = configs[3]")
     args = ap.parse_args()
+    e2e_size_note = "asked for"
+    if args.e2e_records < 0:
+        try:
+            st = os.statvfs("/tmp")
+            free = st.f_bavail * st.f_frsize
+        except OSError:
+            free = 0
+        if free >= 120e9:
+            args.e2e_records, e2e_size_note = 1.0e9, "BASELINE's configs[1] in full (1e9 records, 3.0 Gb genome): /tmp has %.0f GB free" % (free / 1e9)
+        else:
+            args.e2e_records, e2e_size_note = 3.0e8, "3e8 records instead of configs[1]'s 1e9: /tmp has only %.0f GB free (the 53 GB file and its outputs want 120)" % (free / 1e9)
 
     # the contract: rank 0 prints ONE JSON line on stdout.  Libraries loaded below write there too (RCCL announces its version
     # when a communicator is made): file descriptor 1 is pointed at stderr for the life of the process and the line goes to
@@ -493,6 +609,9 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
+    # a CPU-side group for the one long wait of an N > 1 run: while rank 0 runs the multi-BAM executable on every GPU the other ranks
+    # must not sit in an RCCL barrier (a kernel spinning on their GPUs)
+    cpu_group = dist.new_group(backend="gloo") if use_dist and world > 1 else None
 
     R = int(args.records)
     names, lens = synth.genome_c2()
@@ -542,7 +661,7 @@ def main():
     # N > 1 with the sliced sum: the same deferred pushes, and pd_export_i4 packs the tile windows straight from LDS
     # (no arrays on any rank); the reduce-to-rank-0 forms need the arrays
     direct = os.environ.get("PD_BENCH_PATH", "direct") == "direct" and (not use_dist or sliced is not None)
-    eng.set_param("direct_windows", 1 if direct else 0)
+    eng.keep_deferred(bool(direct))
     # the sample in the engine's compact form (pd_runs_create: 8 bytes per run, bucketed, exact bounds) — what pd_decode_end
     # leaves for the whole-contig modes (PD_DECODE_COMPACT), made once before the timed region like the rest of the resident input
     runs8 = None
@@ -635,12 +754,34 @@ def main():
     prof = {k: eng.profile_get(k) for k in PROF_KEYS}
     eng.profile(False)
 
+    # What making the resident compact sample costs (it is made ONCE per sample, before the timed region): pd_runs_create in two parts —
+    # "compact_runs" turns the sorted 12-byte stream into 8-byte runs and marks the buckets' first runs, which in the product is not a
+    # pass at all (the GPU decoder's emit kernel writes its runs that way as it goes); "compact_finish" is what pd_decode_end really does
+    # at the end of a file: bucket starts from the marks, and the counting sort of the later runs.  value_from_decoder_output charges
+    # that second part to every step — the rate of ONE pass over a sample exactly as the decoder's batches leave it.
+    sample_prep = None
+    if used_compact and not use_dist:
+        eng.synchronize()
+        eng.profile(True)
+        PREP = 3
+        for _ in range(PREP):
+            tmp_runs = eng.runs_create(first.data_ptr(), n_first, other.data_ptr(), n_other)
+            eng.runs_destroy(tmp_runs)
+        a_ms, a_n = eng.profile_get("compact_runs")
+        b_ms, b_n = eng.profile_get("compact_finish")
+        eng.profile(False)
+        if a_n and b_n:
+            sample_prep = {"from_12_byte_runs_ms": round(a_ms / a_n, 3), "decode_end_ms": round(b_ms / b_n, 3), "repeats": PREP,
+                           "note": "from_12_byte_runs_ms: pd_runs_create's first pass (k_c8_from_sorted; the decoder's emit kernel does this work as it writes, "
+                                   "no pass); decode_end_ms: bucket starts + counting sort of the later runs (k_sfx_*, k_c8_hist, k_scan_*, k_c8_place_other) = "
+                                   "what pd_decode_end runs per sample"}
+
     # the general (materialising) path next to the direct one: a few untimed-for-`value` steps, same inputs
     arrays_path = None
     if direct and not use_dist:
         ASTEPS = 3
         direct = False
-        eng.set_param("direct_windows", 0)
+        eng.keep_deferred(False)
         step()
         eng.synchronize()
         eng.profile(True)
@@ -657,6 +798,18 @@ def main():
         arrays_path = {"ms_per_step": ta / ASTEPS * 1e3, "steps": ASTEPS, "equals_direct": same, "prof": prof_a}
         direct = True
 
+    run_multi = world > 1 and args.e2e_multi_records > 0
+    if run_multi:
+        # every rank lets go of its GPU before rank 0 starts the executable, which makes its own context on every GPU
+        dist.barrier()
+        if isinstance(sliced, pda.Comm):
+            sliced.close()
+        sliced = None
+        if runs8 is not None:
+            eng.reset(); eng.runs_destroy(runs8); runs8 = None
+        eng.close()
+        first = other = None
+        torch.cuda.empty_cache()
     if rank == 0:
         # sanity: the result of the last step must account for every base that was pushed
         woff, cover, tot = res
@@ -753,7 +906,10 @@ def main():
         if used_compact and dom in ("direct_tiles", "direct_export"):
             bytes_read_model = int((n_first + n_other + n_far) * 8 * (1 + 1 / 16) + (n_cells // 8192) * 36 + (n_cells // 2 if dom == "direct_export" else 0))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kd["frac"], "traffic": None,
+                    "unit": "GB/s", "frac": kd["frac"],
+                    # HBM bytes per launch by the PMC counters (separate rocprofv3 --pmc passes of this command, committed under profiles/:
+                    # bench.py itself never runs under a profiler); null when no committed pass matches this kernel and sample size
+                    "traffic": traffic,
                     "bytes_moved_model": bytes_read_model,
                     "frac_on_bytes_moved": (round(bytes_read_model / (kd["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if bytes_read_model else None),
                     "traffic_from_profile": ({"hbm_bytes_per_launch": traffic, "source": "profiles/" + os.path.basename(pmc_file)}
@@ -784,19 +940,41 @@ def main():
                 eng.close()                                        # the CLI makes its own context on this GPU
                 del first, other                                   # ... and the bench sample's 13 GB of runs go too
                 torch.cuda.empty_cache()
-                e2e, cb = e2e_leg(int(args.e2e_records), int(args.e2e_site_records))
+                e2e, cb = e2e_leg(int(args.e2e_records), int(args.e2e_site_records), fullsize_site=os.environ.get("PD_BENCH_E2E_FULLSIZE_SITE", "1") == "1")
+                if isinstance(e2e, dict):
+                    e2e["size_note"] = e2e_size_note
             except Exception as ex:                                # never lose the GPU line over this leg
                 e2e = {"failed": repr(ex)}
                 cb = {"value": None, "unit": "records/s", "cores": 0, "kind": "failed", "sample": repr(ex)}
+        e2e_multi = None
+        if args.e2e_multi_records > 0 and (world > 1 or args.e2e_records > 0):
+            try:
+                if eng.h:                                          # (N > 1: this rank's context goes before the executable makes its own on every GPU)
+                    if runs8 is not None:
+                        eng.reset(); eng.runs_destroy(runs8); runs8 = None
+                    if isinstance(sliced, pda.Comm):
+                        sliced.close(); sliced = None
+                    eng.close()
+                    first = other = None
+                    torch.cuda.empty_cache()
+                e2e_multi = e2e_multi_leg(world, int(args.e2e_multi_records))
+            except Exception as ex:                                # noqa: BLE001
+                e2e_multi = {"failed": repr(ex)[:300]}
         if configs is not None and isinstance(e2e, dict):
             # the same two configurations end to end (executable vs reference binary on a generated BAM, bytes compared)
             if "gff" in configs and "annotation" in e2e:
                 configs["gff"]["e2e"] = e2e["annotation"]
             if "w100a" in configs and "site_windows" in e2e:
                 configs["w100a"]["e2e"] = e2e["site_windows"]
+        value_dec = None
+        if sample_prep is not None:
+            value_dec = world * R / ((ms_step + sample_prep["decode_end_ms"]) * 1e-3)
         line = {
             "metric": "alignment records/sec (3 Gb genome, 50x BAM, whole-chromosome mode)",
             "value": value, "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # `value` passes over a sample that is resident in the engine's compact form (made once per sample); this one adds what
+            # pd_decode_end does to get there from the decoder's batches (sample_preparation.decode_end_ms) to EVERY step
+            "value_from_decoder_output": value_dec, "sample_preparation": sample_prep,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
@@ -815,9 +993,14 @@ def main():
             "arrays_path": arrays_path,
             "configs": configs,
             "e2e": e2e,
+            # configs[4]'s shape end to end: `world` BAMs through `pandepth -i s.list` on `world` GPUs vs the reference's list mode; the
+            # figure to read weak scaling from (value stays the device-only step, whose 1 -> N efficiency the links bound: DESIGN.md 6)
+            "e2e_multi": e2e_multi,
             "cpu_baseline": cb,
         }
         emit(line)
+    if run_multi:
+        dist.barrier(group=cpu_group)
     if use_dist:
         dist.barrier()
         if isinstance(sliced, pda.Comm):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 2
+#define PD_ABI_VERSION 3
 
 enum {
     PD_OK = 0,
@@ -146,16 +146,14 @@ int pd_reduce_intervals(pd_ctx *ctx, const pd_region *regs, size_t n, uint32_t m
  * win_off[t] + k, where win_off comes from pd_window_layout (n_contigs+1 entries, last = total).
  *   pd_scan_reduce_windows : fused — reads the DIFFERENCE arrays once, never writes depth
  *                            (4 B/base of HBM traffic); state stays "accumulating".
- *                            With pd_set_param(ctx, "direct_windows", 1), w >= 64, a context that
- *                            holds nothing since pd_reset and a sample that is entirely DEFERRED
- *                            (every batch pushed with PD_PUSH_SORTED | PD_PUSH_MORE, at most 4), the
- *                            difference arrays are never materialised at all: one pass over the runs
- *                            builds each tile's window in LDS, counts its carry-in from the same runs,
- *                            prefix-sums and reduces it (12 B/run of HBM traffic, results identical).
- *                            The sample is then CONSUMED: the arrays stay empty and every call except
- *                            pd_reset / pd_destroy fails with PD_ESTATE.  Runs longer than the
- *                            look-back ("lmax") or a batch that is not sorted make the call fall back
- *                            to the materialising path on its own.
+ *                            After pd_keep_deferred(ctx, 1), with w >= 64, a context that holds nothing since
+ *                            pd_reset and a sample that is entirely DEFERRED (see pd_keep_deferred), the
+ *                            difference arrays are never materialised at all: one pass over the runs builds
+ *                            each tile's window in LDS, counts its carry-in from the same runs, prefix-sums
+ *                            and reduces it (8 or 12 B/run of HBM traffic, results identical).  The call READS
+ *                            the sample: it stays deferred and every other call works on it afterwards.  Runs
+ *                            longer than the look-back ("lmax") or a batch that is not sorted make the call
+ *                            fall back to the materialising path on its own.
  *   pd_reduce_windows      : from the depth arrays left by pd_scan. */
 int pd_window_layout(const pd_ctx *ctx, uint32_t w, uint64_t *win_off);
 int pd_scan_reduce_windows(pd_ctx *ctx, uint32_t w, uint32_t min_dep, unsigned wrap_bits,
@@ -256,8 +254,8 @@ int pd_import_i8(pd_ctx *ctx, const void *dev_i8, int bias, const pd_exc *dev_ex
  * the wire, so the value range does not shrink with the number of ranks.
  *   pd_export_i4      one nibble per cell into dev_i4 (n_cells / 2 bytes; cell 2k in the low
  *                     nibble of byte k), BIASED: d + 8 in [0, 15]; cells outside [-8, 7] are
- *                     written as 0 (+bias) and appended to dev_exc as in pd_export_i8.  With
- *                     "direct_windows" set, a pristine context and an entirely deferred sample
+ *                     written as 0 (+bias) and appended to dev_exc as in pd_export_i8.  After
+ *                     pd_keep_deferred(ctx, 1), with a pristine context and an entirely deferred sample
  *                     (see pd_scan_reduce_windows) the image, the exceptions and the tile sums
  *                     come straight from the tile windows in LDS — same bytes, the difference
  *                     arrays are never written.  An export READS the sample: it stays deferred (a later
@@ -356,7 +354,7 @@ typedef struct pd_bgzf_block { uint64_t in_off, out_off; uint32_t in_len, out_le
  * contigs with targets, optionally htslib's region test against `spans`) + CIGAR walk -> the batch's runs, dense and
  * in file order, in HBM.  pd_decode_end concatenates the batches by `order` and leaves the sample DEFERRED exactly
  * as pd_push_intervals_device(.., PD_PUSH_SORTED | PD_PUSH_MORE) would: the statistics calls then take the direct
- * path (pd_set_param "direct_windows") or materialise the arrays.  Units the device does not finish are handed back:
+ * path (pd_keep_deferred) or materialise the arrays.  Units the device does not finish are handed back:
  *   unit_status[u] 0 counted; 1 decode it on the host (a record runs past the unit's bytes, a CIGAR lives in the CG
  *   tag, a Huffman code this decoder leaves to zlib); 2 a member read for the unit does not inflate or fails
  *   its CRC-32; 3 the record chain could not be followed: in both cases decode the unit on the host, which reads only what the
@@ -377,6 +375,13 @@ typedef struct pd_decode_cfg {
                                     /* flags: PD_DECODE_COMPACT — the caller will ask for whole-contig statistics                */
                                     /* (pd_scan_reduce_windows, w >= 8192): pd_decode_end leaves a sorted file's runs as ONE        */
                                     /* compact sample (pd_runs) instead of 12-byte arrays                                          */
+    uint64_t n_batches;             /* 0 = unknown.  Otherwise the caller promises to submit exactly this many batches, once each, with */
+                                    /* pd_decode_batch::order = 0 .. n_batches - 1 in file order (a batch with nothing to decode is still   */
+                                    /* submitted, empty; orders need not ARRIVE in order, but a thread must hold its buffer — pd_decode_-   */
+                                    /* acquire — BEFORE it takes the next order, so that the lowest outstanding order always has one).      */
+                                    /* With PD_DECODE_COMPACT on a sorted file this lets every batch write its runs straight to their      */
+                                    /* final places in the compact sample (places are handed out in batch order): pd_decode_end then only  */
+                                    /* sorts the later runs of multi-run reads (about a tenth of all runs) by bucket.                       */
 } pd_decode_cfg;
 #define PD_DECODE_COMPACT 1u
 typedef struct pd_decode_unit { uint64_t start, stop, avail; uint32_t first_block, n_blocks, flags, pad; } pd_decode_unit;
@@ -385,14 +390,14 @@ typedef struct pd_decode_batch {
     const pd_bgzf_block *blocks; uint32_t n_blocks; uint32_t pad;
     uint64_t inflated_bytes;
     const pd_decode_unit *units; uint32_t n_units; uint32_t pad2;
-    uint64_t order;                                              /* file position of the batch                           */
+    uint64_t order;                                              /* file position of the batch (see pd_decode_cfg::n_batches) */
 } pd_decode_batch;
 typedef struct pd_decode_result {
     uint64_t n_reads, n_first, n_other;    /* records seen in the units that were counted; first runs; other runs       */
     uint64_t first_start, next_start;      /* unit 0: first record it owns / first record start >= its stop (~0: none)   */
     double ms_h2d, ms_inflate, ms_walk, ms_emit;
-    /* order of the batch's first runs (key = tid << 32 | begin; file order): unsorted = 1 when a key is smaller than the one
-     * before it; first_key / last_key for the check across batches (valid when n_first > 0).  A file whose header says
+    /* order of the batch's first runs (key = a value that orders like (tid, begin); file order): unsorted = 1 when a key is smaller than the
+     * one before it; first_key / last_key for the check across batches (valid when n_first > 0).  A file whose header says
      * SO:coordinate but whose records are not in that order must not go on as a sorted stream: the caller abandons the
      * device pass (pd_decode_abort) and reads such a file the way the reference does; pd_decode_end, for its part, pushes
      * the first runs as PD_PUSH_DEFAULT when it sees a violation. */
@@ -401,7 +406,7 @@ typedef struct pd_decode_result {
 } pd_decode_result;
 int pd_decode_begin(pd_ctx *ctx, const pd_decode_cfg *cfg);
 int pd_decode_acquire(pd_ctx *ctx, size_t bytes, void **host_buf);
-int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_status, pd_decode_result *res);
+int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_status, pd_decode_result *res);   /* (a batch without units only hands its buffer back) */
 int pd_decode_end(pd_ctx *ctx);
 int pd_decode_abort(pd_ctx *ctx);          /* forget the batches decoded since pd_decode_begin (nothing is counted) */
 

@@ -32,7 +32,8 @@ class PdError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpandepth_amd.so")
+    # (PANDEPTH_AMD_LIB: a tuning build of the library, tools/ubench only)
+    return os.environ.get("PANDEPTH_AMD_LIB") or os.path.join(_HERE, "libpandepth_amd.so")
 
 
 def load():
@@ -274,8 +275,6 @@ class Engine:
         self._ck(self.L.pd_keep_deferred(self.h, 1 if enable else 0))
 
     def set_param(self, name, value):
-        if name == "direct_windows":                  # (the tests' and tools' old name for pd_keep_deferred)
-            return self.keep_deferred(bool(value))
         self._ck(self.L.pd_set_param(self.h, name.encode(), int(value)))
 
     def push_intervals(self, iv, flags=PD_PUSH_DEFAULT):

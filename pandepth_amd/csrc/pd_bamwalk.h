@@ -34,13 +34,36 @@ enum { SUB = 1024, SEG_BYTES = 64 * SUB };
 enum { WF_BAD = 1, WF_MORE = 2, WF_HOST = 4 };     // corrupt record / record runs past the batch / CIGAR in the CG tag
 static const uint64_t NONE = ~0ull, STOPPED = 1ull << 62;
 
+// Compact emission (whole-contig modes of a coordinate-sorted file, PD_DECODE_COMPACT): pass 2 writes every read's first run straight to
+// its FINAL place in the sample's sorted stream as 8 bytes — the low 32 bits of its flat begin (cell index in the engine's buffer, the
+// begin clamped to [0, len] as PD:449-452's cells are) and its clamped length —, the first run a lane writes and every run that opens
+// a new 512-cell bucket leave their index in b1[bucket] (an atomic minimum: the buckets' first runs, which is all the direct kernels
+// need to find a tile's runs), and the order of the stream is checked on the way: inside a lane, across the lanes of a segment, and
+// (by the host, from SegOut) across segments and batches.
+struct R8 { uint32_t b, len; };           // = pdk::Run8
+struct SegOut { uint64_t first_key, last_key; uint32_t unsorted, n_long; };   // keys: flat begins (order like (tid, begin)); first_key = NONE: no first run
+struct C8Out {
+    R8 *r8 = nullptr;                     // the sorted stream (global index = Seg::base_first + ...); null: 12-byte runs as before
+    uint32_t *b1 = nullptr;               // bucket -> index of its first run (pre-set to 0xFFFFFFFF)
+    const uint64_t *contig_off = nullptr; // first cell of every contig's slot
+    uint32_t cshift = 0;                  // log2(cells per bucket)
+    SegOut *seg_out = nullptr;            // one per segment of the batch
+};
+
 struct Cfg {                              // wave-uniform
     const uint8_t *buf; uint64_t avail;   // the batch's inflated bytes
     int32_t n_ref; const uint32_t *contig_len; const uint8_t *contig_on;      // contig_on[tid] != 0: the contig has targets
     uint32_t flag_mask; int32_t min_mapq;
     const uint32_t *span_off; const int32_t *spans;                            // -g / -b: (begin0, end) per contig, sorted; or null
     uint32_t near_span;
+    C8Out c8;
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+PW_FN void min_u32(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+#else
+PW_FN void min_u32(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
+#endif
 
 struct Seg {
     uint64_t begin, end;                  // records STARTING in [begin, end) belong to the segment
@@ -126,13 +149,14 @@ PW_FN bool span_hit(const Cfg &c, int32_t tid, int32_t pos, int32_t endpos)
     return lo < top && endpos > c.spans[2 * lo];
 }
 
-struct LaneWalk { uint64_t e; uint32_t n_first, n_other, n_far, flags, max_span, n_rec; };
+struct LaneWalk { uint64_t e; uint32_t n_first, n_other, n_far, flags, max_span, n_rec; uint64_t key_first, key_last; uint32_t unsorted, n_long; };
 
 // records starting in [s, b): counts (emit == false) or runs written at first[of..] / other[oo..] (emit == true)
 template <bool EMIT>
 PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_iv *other, pd_iv *far, uint64_t of, uint64_t oo, uint64_t ofar)
 {
     LaneWalk w; w.e = s; w.n_first = w.n_other = w.n_far = w.flags = w.max_span = w.n_rec = 0;
+    w.key_first = NONE; w.key_last = 0; w.unsorted = w.n_long = 0;
     uint64_t p = s;
     for (uint32_t guard = 0; p < b && guard < SUB / 36 + 2; ++guard) {
         // a record that cannot be finished here stops the chain: nothing after it may be taken for a record start
@@ -155,7 +179,21 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
             if (take) {
                 uint32_t nf = 0, no = 0, nfar = 0, span = 0;
                 walk_cigar(x, [&](bool is_first, int32_t beg, int32_t end) {
-                    if (is_first) { if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end}; nf = 1; return; }
+                    if (is_first) {
+                        if (EMIT && c.c8.r8) {                            // compact emission (wave-uniform choice)
+                            const uint32_t clen = c.contig_len[x.tid];
+                            uint32_t cb = beg < 0 ? 0u : (uint32_t)beg; if (cb > clen) cb = clen;
+                            uint32_t ce = end < 0 ? 0u : (uint32_t)end; if (ce > clen) ce = clen;
+                            const uint32_t len = ce > cb ? ce - cb : 0u;
+                            const uint64_t flat = c.c8.contig_off[x.tid] + cb, G = of + w.n_first;
+                            c.c8.r8[G] = R8{(uint32_t)flat, len};
+                            if (w.key_first == NONE || (w.key_last >> c.c8.cshift) != (flat >> c.c8.cshift)) min_u32(&c.c8.b1[flat >> c.c8.cshift], (uint32_t)G);
+                            if (w.key_first == NONE) w.key_first = flat; else if (flat < w.key_last) w.unsorted = 1;
+                            w.key_last = flat;
+                            if (len > (1u << c.c8.cshift)) ++w.n_long;
+                        } else if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end};
+                        nf = 1; return;
+                    }
                     const uint32_t d = (uint32_t)beg - (uint32_t)x.pos;
                     if (d > span) span = d;
                     if (d <= c.near_span) { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; }
@@ -265,7 +303,7 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
 
 // pass 2: the same lanes write their runs; sg.base_first / base_other say where the segment's runs go
 template <class W>
-PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_iv *first, pd_iv *other, pd_iv *far)
+PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_iv *first, pd_iv *other, pd_iv *far, SegOut *seg_out = nullptr)
 {
     Cfg c = cfg; c.avail = sg.avail;
     typedef typename W::template Var<uint32_t> U;
@@ -275,13 +313,27 @@ PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_
     const U ef = W::excl_scan(nf, &tf);
     const U eo = W::excl_scan(no, &to);
     const U efar = W::excl_scan(nfar, &tfar);
+    typedef typename W::template Var<uint64_t> U64;
+    U64 kf, kl; U bad, nl;
     W::each([&](int l) {
+        kf[l] = NONE; kl[l] = 0; bad[l] = 0; nl[l] = 0;
         const uint64_t a = sg.begin + (uint64_t)l * SUB;
         uint64_t b = a + SUB < sg.end ? a + SUB : sg.end;
         const uint64_t s = lanes[l].start;
         if (a >= sg.end || s == NONE || s >= b || (nf[l] | no[l] | nfar[l]) == 0) return;
-        (void)walk_lane<true>(c, s, b, first, other, far, sg.base_first + ef[l], sg.base_other + eo[l], sg.base_far + efar[l]);
+        const LaneWalk w = walk_lane<true>(c, s, b, first, other, far, sg.base_first + ef[l], sg.base_other + eo[l], sg.base_far + efar[l]);
+        kf[l] = w.key_first; kl[l] = w.key_last; bad[l] = w.unsorted; nl[l] = w.n_long;
     });
+    if (c.c8.r8 && seg_out) {
+        // the order across the lanes: a lane's first key against the largest key of the lanes before it
+        const U64 pm = W::excl_scan_max64(kl);
+        W::each([&](int l) { if (kf[l] != NONE && kf[l] < pm[l]) bad[l] = 1; });
+        const uint64_t first_key = W::reduce_min64(kf), last_key = W::reduce_max64(kl);
+        const uint32_t any_bad = W::reduce_or(bad);
+        uint32_t n_long = 0;
+        (void)W::excl_scan(nl, &n_long);
+        W::each([&](int l) { if (l == 0) { seg_out->first_key = first_key; seg_out->last_key = last_key; seg_out->unsorted = any_bad; seg_out->n_long = n_long; } });
+    }
 }
 
 // The host side after pass 1 (and after every repeat): is every segment's speculated first record the one the chain of

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
 // One WAVE per BGZF member (pd_inflate_wave.h): persistent one-wave workgroups walk the members with a grid stride
 // (members of a BAM are alike, so a static split balances); Huffman tables in LDS (9 KiB per wave), match tokens in a
 // per-workgroup slice of global scratch.
-__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
+#ifndef PD_INFLATE_MIN_WAVES
+#define PD_INFLATE_MIN_WAVES 1            /* waves per SIMD the register allocation must leave room for (tuning builds) */
+#endif
+__global__ __launch_bounds__(64, PD_INFLATE_MIN_WAVES) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
                                                      pdw::Token *tok_scratch, int check_crc)
 {
     __shared__ pdw::Tables T;
@@ -70,8 +73,12 @@ __global__ __launch_bounds__(64) void k_emit_segments(const pdb2::Cfg cfg, const
 {
     const uint32_t j = blockIdx.x;
     if (j >= n_seg) return;
-    if ((segs[j].n_first | segs[j].n_other | segs[j].n_far) == 0) return;
-    pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other, far);
+    pdb2::SegOut *so = cfg.c8.seg_out ? cfg.c8.seg_out + j : nullptr;       // compact emission: the segment's keys for the host's order check
+    if ((segs[j].n_first | segs[j].n_other | segs[j].n_far) == 0) {
+        if (so && threadIdx.x == 0) { so->first_key = pdb2::NONE; so->last_key = 0; so->unsorted = 0; so->n_long = 0; }
+        return;
+    }
+    pdb2::emit_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, first, other, far, so);
 }
 
 // are the first runs of a batch in (tid, begin) order?  out[0] = 1 if not; out[2..3] / out[4..5] = first / last key

@@ -193,12 +193,14 @@ struct Pending { const pd_iv *iv; uint32_t n; uint32_t disorder; int slot; pd_ru
 // a whole sample in the compact form (include/pandepth_amd.h: pd_runs_create; layout: C8Sample in pd_kernels.h)
 struct pd_runs {
     pd_ctx *ctx = nullptr;
-    Run8 *r8 = nullptr; uint32_t n = 0;
-    uint32_t *bstart = nullptr;                                  // (n_tiles << bshift) + 1 entries
+    Run8 *r8 = nullptr;                                          // [sorted stream: n_s runs, file order | ... | other runs by bucket at o_base]
+    uint32_t n_s = 0, n_o = 0, o_base = 0, n = 0;                // n = n_s + n_o
+    uint32_t *b1 = nullptr, *o1 = nullptr;                       // (n_tiles << bshift) + 1 bucket starts per stream (one allocation: b1 | o1)
     uint32_t bshift = 4;                                         // 16 buckets of 512 cells per tile
     uint32_t n_long = 0;                                         // runs longer than a bucket: the direct kernels cannot use the sample
     pd_iv *iv12 = nullptr;                                       // the expanded copy, made on first need
-    C8Sample view() const { return C8Sample{r8, bstart, bshift, n}; }
+    bool own_r8 = true;                                          // r8 is this object's allocation (false: it lives in the decode session's arena)
+    C8Sample view() const { return C8Sample{r8, b1, o1, o_base, bshift}; }
 };
 
 static inline size_t slice_flag_bytes(uint64_t n_tiles) { return (size_t)((n_tiles + 16 + 15) / 16 * 16); }
@@ -234,10 +236,10 @@ struct pd_ctx {
         hipStream_t st = nullptr;
         hipEvent_t ev[6] = {};
         uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
-        void *d[7] = {}; size_t cap[7] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list
+        void *d[8] = {}; size_t cap[8] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list, per-segment keys (compact emission)
         void *d_tok = nullptr;                                    // wave scratch (match tokens)
     };
-    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; uint32_t unsorted; uint64_t first_key, last_key; };
+    struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; uint32_t unsorted; uint64_t first_key, last_key; uint64_t n_long = 0; };
     static constexpr int N_DEC = 6;
     uint8_t *arena = nullptr; size_t arena_cap = 0; std::atomic<size_t> arena_used{0};   // the batches' run arrays (bump allocated)
     DecSlot dec[N_DEC];
@@ -247,7 +249,21 @@ struct pd_ctx {
     pd_decode_cfg dec_cfg{}; uint8_t *d_contig_on = nullptr; uint32_t *d_span_off = nullptr; int32_t *d_spans = nullptr;
     std::vector<RunSeg> run_segs;
     pd_iv *run_first = nullptr, *run_other = nullptr, *run_far = nullptr;   // the concatenated sample (owned until the next reset)
-    pd_runs *dec_runs = nullptr;                                  // ... its first runs as a compact sample (PD_DECODE_COMPACT)
+    pd_runs *dec_runs = nullptr;                                  // ... or the whole of it as a compact sample (PD_DECODE_COMPACT)
+    // A decode session that emits the compact form directly (PD_DECODE_COMPACT + pd_decode_cfg::n_batches): every batch's pass 2 writes its
+    // first runs to their FINAL places in the sample's sorted stream, 8 bytes each, and its later runs behind those of the batches before it.
+    // The places are handed out in batch order (`turn`), so nothing is concatenated, converted or sorted at the end except the later runs.
+    struct C8Dec {
+        bool on = false;
+        uint8_t *base = nullptr; size_t bytes = 0;               // ONE allocation: [Run8 x (cap_s + cap_o) | pd_iv x cap_o]
+        size_t cap_s = 0, cap_o = 0;
+        uint32_t *b1 = nullptr; size_t nbw = 0;                  // bucket starts: b1 | o1, nbw words each
+        uint32_t bshift = 4;
+        uint64_t n_s = 0, n_o = 0, turn = 0, n_batches = 0;
+        std::mutex mu; std::condition_variable cv;
+        Run8 *r8() const { return (Run8 *)base; }
+        pd_iv *oth() const { return (pd_iv *)(base + (cap_s + cap_o) * sizeof(Run8)); }
+    } c8;
     uint64_t *ovf = nullptr; uint32_t ovf_cap = 0;    // ends of runs longer than lmax (grown on demand)
     std::vector<Stage> stage;                        // grows on demand, up to N_STAGE
     uint64_t seq = 0;
@@ -393,7 +409,7 @@ int expand_compact(pd_ctx *c, Pending &p)
     if (!r->iv12) {
         if (hipMalloc(&r->iv12, (size_t)r->n * sizeof(pd_iv)) != hipSuccess) return fail(c, PD_ENOMEM, "compact sample: allocation of the expanded runs failed");
         ProfScope ps(c, "expand_runs");
-        launch_c8_expand(c->stream, r->view(), c->d_tile_contig, (uint32_t)c->n_tiles, r->iv12);
+        launch_c8_expand(c->stream, r->view(), c->d_tile_contig, c->d_off, (uint32_t)c->n_tiles, r->iv12);
         HIPOK(c, hipGetLastError());
     }
     p.iv = r->iv12;
@@ -703,6 +719,7 @@ int pd_destroy(pd_ctx *c)
     }
     for (void *p : {(void *)c->d_contig_on, (void *)c->d_span_off, (void *)c->d_spans, (void *)c->run_first, (void *)c->run_other, (void *)c->run_far, (void *)c->arena}) if (p) (void)hipFree(p);
     runs_free(c->dec_runs);
+    for (void *p : {(void *)c->c8.base, (void *)c->c8.b1}) if (p) (void)hipFree(p);
     t3 = dec_now_us();
     for (auto &w : c->lz) { std::lock_guard<std::mutex> g(w.mu); w.release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -769,55 +786,78 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
 static void runs_free(pd_runs *r)
 {
     if (!r) return;
-    for (void *q : {(void *)r->r8, (void *)r->bstart, (void *)r->iv12}) if (q) (void)hipFree(q);
+    if (r->own_r8 && r->r8) (void)hipFree(r->r8);
+    for (void *q : {(void *)r->b1, (void *)r->iv12}) if (q) (void)hipFree(q);
     delete r;
+}
+
+static uint32_t runs_bshift(const pd_ctx *c)
+{
+    // buckets as wide as the look-back bound ("lmax", a power of two between 256 and 8192 cells; default 512)
+    uint32_t cells = 256; while (cells < c->lmax && cells < (uint32_t)PD_TILE) cells <<= 1;
+    uint32_t bs = 0; while (((uint32_t)PD_TILE >> bs) > cells) ++bs;
+    return bs;
+}
+
+// The second half of making a compact sample, shared by pd_runs_create and pd_decode_end: the sorted stream is in r->r8[0 .. n_s) and the
+// first run of every bucket has left its index in r->b1 (everything else 0xFFFFFFFF); `others` are the remaining runs as 12-byte arrays, any
+// order.  Fills the bucket starts of the sorted stream (a suffix minimum over the marks), counts the other runs per bucket, places them
+// behind o_base.  words (device, 2 x uint32, already holding the sorted stream's flags): [0] bad contig id, [1] runs longer than a bucket.
+// Only enqueues on c->stream; `tmp` must hold 2 x (nb + 2) + (nb / 1024 + 4) words.
+static void runs_finish(pd_ctx *c, pd_runs *r, const pd_iv *const *others, const size_t *n_others, int n_arr, uint32_t *tmp, uint32_t *words)
+{
+    hipStream_t st = c->stream;
+    const uint32_t nb = (uint32_t)((uint64_t)c->n_tiles << r->bshift);
+    const size_t nbw = (size_t)nb + 2;
+    uint32_t *hist = tmp, *cursor = tmp + nbw, *bs = tmp + 2 * nbw;
+    const ContigTab tab = tab_of(c);
+    ProfScope ps(c, "compact_finish");
+    launch_c8_fill_starts(st, r->b1, nb, r->n_s, bs);
+    (void)hipMemsetAsync(hist, 0, 2 * nbw * 4, st);                       // the histogram and the buckets' cursors
+    for (int k = 0; k < n_arr; ++k) launch_c8_hist(st, others[k], (uint32_t)n_others[k], tab, r->bshift, hist, words);
+    launch_excl_scan_u32(st, hist, r->o1, nb + 1, bs);
+    for (int k = 0; k < n_arr; ++k) launch_c8_place_other(st, others[k], (uint32_t)n_others[k], tab, r->bshift, r->o1, cursor, r->r8 + r->o_base);
 }
 
 // caller holds c->mu and has set the device.  `sorted` must be sorted by (tid, beg) — checked; the `others` may be in any order.
 static int runs_make(pd_ctx *c, const pd_iv *sorted, size_t n_sorted, const pd_iv *const *others, const size_t *n_others, int n_arr, pd_runs **out)
 {
     *out = nullptr;
-    size_t n = n_sorted;
-    for (int k = 0; k < n_arr; ++k) n += n_others[k];
+    size_t n = n_sorted, n_o = 0;
+    for (int k = 0; k < n_arr; ++k) n_o += n_others[k];
+    n += n_o;
     if (n == 0 || n > DEV_BATCH_MAX) return fail(c, PD_EINVAL, "pd_runs_create: between 1 and 2^32 - 256 runs");
     if (n_arr > 2) return PD_EINVAL;
     pd_runs *r = new pd_runs;
-    r->ctx = c; r->n = (uint32_t)n;
-    // buckets as wide as the look-back bound ("lmax", a power of two between 256 and 8192 cells; default 512)
-    uint32_t cells = 256; while (cells < c->lmax && cells < (uint32_t)PD_TILE) cells <<= 1;
-    r->bshift = 0; while (((uint32_t)PD_TILE >> r->bshift) > cells) ++r->bshift;
+    r->ctx = c; r->n = (uint32_t)n; r->n_s = (uint32_t)n_sorted; r->n_o = (uint32_t)n_o; r->o_base = (uint32_t)n_sorted;
+    r->bshift = runs_bshift(c);
     const uint64_t nb64 = (uint64_t)c->n_tiles << r->bshift;
     if (nb64 > 0xFFFFFF00ull) { delete r; return fail(c, PD_EINVAL, "pd_runs_create: too many buckets for this genome"); }
     const uint32_t nb = (uint32_t)nb64;
-    uint32_t *b1 = nullptr, *h2 = nullptr, *o2 = nullptr, *bs = nullptr, *words = nullptr, *d_other = nullptr;
-    auto cleanup = [&]() { for (void *q : {(void *)b1, (void *)h2, (void *)o2, (void *)bs, (void *)words, (void *)d_other}) if (q) (void)hipFree(q); };
-    const size_t nbb = ((size_t)nb + 2) * 4;
-    if (hipMalloc(&r->r8, n * sizeof(Run8)) != hipSuccess || hipMalloc(&r->bstart, nbb) != hipSuccess || hipMalloc(&b1, nbb) != hipSuccess ||
-        hipMalloc(&h2, nbb) != hipSuccess || hipMalloc(&o2, nbb) != hipSuccess || hipMalloc(&bs, ((size_t)nb / 1024 + 4) * 4) != hipSuccess ||
-        hipMalloc(&words, 16) != hipSuccess || hipMalloc(&d_other, 64) != hipSuccess) {
-        (void)hipGetLastError(); cleanup(); runs_free(r);
+    const size_t nbw = (size_t)nb + 2;
+    uint32_t *tmp = nullptr, *words = nullptr;
+    if (hipMalloc(&r->r8, n * sizeof(Run8) + 64) != hipSuccess || hipMalloc(&r->b1, 2 * nbw * 4) != hipSuccess ||
+        hipMalloc(&tmp, (2 * nbw + nb / 1024 + 8) * 4) != hipSuccess || hipMalloc(&words, 16) != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *q : {(void *)tmp, (void *)words}) if (q) (void)hipFree(q);
+        runs_free(r);
         return fail(c, PD_ENOMEM, "pd_runs_create: allocation failed");
     }
+    r->o1 = r->b1 + nbw;
     uint32_t h[2] = {0, 0};
     hipStream_t st = c->stream;
-    const ContigTab tab = tab_of(c);
     hipError_t e = hipMemsetAsync(words, 0, 16, st);
-    if (e == hipSuccess) e = hipMemsetAsync(h2, 0, nbb, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->b1, 0xFF, nbw * 4, st);
     if (e == hipSuccess) {
-        ProfScope ps(c, "compact_runs");
-        if (n_sorted) launch_c8_scan_sorted(st, sorted, (uint32_t)n_sorted, tab, r->bshift, nb, b1, words);
-        else e = hipMemsetAsync(b1, 0, nbb, st);
-        for (int k = 0; k < n_arr; ++k) if (n_others[k]) launch_c8_hist(st, others[k], (uint32_t)n_others[k], tab, r->bshift, h2, words);
-        launch_excl_scan_u32(st, h2, o2, nb + 1, bs);
-        if (e == hipSuccess) e = hipMemsetAsync(h2, 0, nbb, st);                  // ... and now the buckets' cursors
-        uint32_t no[2] = {n_arr > 0 ? (uint32_t)n_others[0] : 0u, n_arr > 1 ? (uint32_t)n_others[1] : 0u};
-        const pd_iv *po[2] = {n_arr > 0 ? others[0] : nullptr, n_arr > 1 ? others[1] : nullptr};
-        launch_c8_place(st, sorted, (uint32_t)n_sorted, po, no, n_arr, tab, r->bshift, nb, b1, o2, h2, r->r8, r->bstart);
-        if (e == hipSuccess) e = hipGetLastError();
+        // (this first pass is what the GPU decoder's emit kernel does as it writes a file's runs: 8-byte runs in file order, the buckets'
+        // first runs marked)
+        { ProfScope ps(c, "compact_runs"); launch_c8_from_sorted(st, sorted, (uint32_t)n_sorted, tab_of(c), r->bshift, r->r8, r->b1, words); }
+        runs_finish(c, r, others, n_others, n_arr, tmp, words);
+        e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    cleanup();
+    (void)hipFree(tmp); (void)hipFree(words);
     if (e != hipSuccess) { runs_free(r); return fail(c, PD_EHIP, std::string("pd_runs_create: ") + hipGetErrorString(e)); }
     if (h[0]) { runs_free(r); return fail(c, PD_EINVAL, "pd_runs_create: the first batch is not sorted by (tid, beg), or a contig id is out of range"); }
     r->n_long = h[1];
@@ -1225,7 +1265,7 @@ int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *con
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG, DS_LANE, DS_ONLY };
+enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG, DS_LANE, DS_ONLY, DS_SEGOUT };
 
 // PANDEPTH_TIMING=1: where the host side of the decode path spends its time (thread-microseconds, summed)
 std::atomic<uint64_t> g_dec_us[8];
@@ -1252,6 +1292,54 @@ int dec_ensure(pd_ctx *c, pd_ctx::DecSlot &sl, int k, size_t bytes)
 // the host side of a batch after pass 1: pdb2::check_chain (pd_bamwalk.h)
 uint32_t dec_finish(std::vector<pdb2::Seg> &segs, std::vector<uint32_t> *redo) { return pdb2::check_chain(segs, redo); }
 
+static_assert(sizeof(pdb2::R8) == sizeof(Run8), "the decoder's 8-byte run is the kernels' Run8");
+
+// ---- compact decode sessions (pd_ctx::C8Dec) ----
+void c8_drop(pd_ctx *c)
+{
+    pd_ctx::C8Dec &x = c->c8;
+    if (x.base) { (void)hipFree(x.base); x.base = nullptr; }
+    if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
+    x.on = false; x.bytes = 0; x.cap_s = x.cap_o = 0; x.n_s = x.n_o = x.turn = x.n_batches = 0;
+}
+
+// room for n_s first runs and n_o later runs (the caller holds c8.mu and the turn: nobody else is placing runs; batches placed
+// earlier may still be writing theirs — the device is waited for before anything moves).  Returns PD_OK / PD_ENOMEM / PD_EHIP, no message.
+int c8_reserve(pd_ctx *c, uint64_t n_s, uint64_t n_o)
+{
+    pd_ctx::C8Dec &x = c->c8;
+    if (n_s <= x.cap_s && n_o <= x.cap_o && x.base) return PD_OK;
+    const size_t ns = std::max<size_t>((size_t)n_s + (size_t)n_s / 2 + ((size_t)1 << 16), x.cap_s), no = std::max<size_t>((size_t)n_o + (size_t)n_o / 2 + ((size_t)1 << 16), x.cap_o);
+    const size_t bytes = (ns + no) * sizeof(Run8) + no * sizeof(pd_iv) + 256;
+    uint8_t *nb = nullptr;
+    if (x.base) (void)hipDeviceSynchronize();
+    if (hipMalloc(&nb, bytes) != hipSuccess) { (void)hipGetLastError(); return PD_ENOMEM; }
+    if (x.base) {
+        hipError_t e = hipSuccess;
+        if (x.n_s) e = hipMemcpy(nb, x.base, (size_t)x.n_s * sizeof(Run8), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && x.n_o) e = hipMemcpy(nb + (ns + no) * sizeof(Run8), x.oth(), (size_t)x.n_o * sizeof(pd_iv), hipMemcpyDeviceToDevice);
+        (void)hipFree(x.base);
+        if (e != hipSuccess) { (void)hipFree(nb); x.base = nullptr; return PD_EHIP; }
+    }
+    x.base = nb; x.bytes = bytes; x.cap_s = ns; x.cap_o = no;
+    return PD_OK;
+}
+
+// every batch with an order below n_batches passes the turn exactly once, whatever way its submit call ends
+struct C8Turn {
+    pd_ctx *c; uint64_t order; bool armed;
+    ~C8Turn()
+    {
+        if (!armed) return;
+        pd_ctx::C8Dec &x = c->c8;
+        std::unique_lock<std::mutex> lk(x.mu);
+        x.cv.wait_for(lk, std::chrono::seconds(300), [&] { return x.turn >= order; });
+        if (x.turn == order) x.turn = order + 1;
+        lk.unlock();
+        x.cv.notify_all();
+    }
+};
+
 } // namespace
 
 extern "C" {
@@ -1277,9 +1365,30 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (ns) HIPOK(c, hipMemcpy(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice));
     }
     c->dec_cfg.contig_on = nullptr; c->dec_cfg.span_off = nullptr; c->dec_cfg.spans = nullptr;      // (the caller's arrays are not kept)
+    // A sorted file read for whole-contig statistics (PD_DECODE_COMPACT), its batches numbered 0 .. n_batches - 1, on a genome of fewer than
+    // 2^32 cells: the batches' runs go straight to their final places in a compact sample (C8Dec).  Sized from the compressed bytes
+    // (>= 32 B of BGZF per record of a real file; denser files make it grow): a first run per record, a later run for every fourth.
+    {
+        std::lock_guard<std::mutex> l8(c->c8.mu);
+        pd_ctx::C8Dec &x = c->c8;
+        x.on = false; x.n_s = x.n_o = x.turn = 0; x.n_batches = 0;
+        const uint64_t nb64 = (uint64_t)c->n_tiles << runs_bshift(c);
+        if ((cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->sorted && !cfg->spans && c->pend.empty() && c->n_cells < (1ull << 32) && nb64 <= 0xFFFFFF00ull) {
+            x.bshift = runs_bshift(c);
+            x.nbw = (size_t)nb64 + 2;
+            if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
+            if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
+            HIPOK(c, hipMemset(x.b1, 0xFF, x.nbw * 4));
+            const uint64_t est = cfg->bytes_hint ? cfg->bytes_hint / 32 + (1u << 20) : (uint64_t)8 << 20;
+            const int rr = c8_reserve(c, est, est / 4);
+            if (rr) return fail(c, rr, "pd_decode_begin: the run arena could not be allocated");
+            x.n_batches = cfg->n_batches;
+            x.on = true;
+        }
+    }
     // one arena for the batches' run arrays (a hipMalloc per batch waits for the other streams): about half the compressed
     // bytes is plenty for short reads (12 B per run against >= 30 B of BGZF per record); what does not fit is allocated singly
-    const size_t want = cfg->bytes_hint ? (size_t)(cfg->bytes_hint / 2) + ((size_t)16 << 20) : (size_t)256 << 20;
+    const size_t want = c->c8.on ? 0 : cfg->bytes_hint ? (size_t)(cfg->bytes_hint / 2) + ((size_t)16 << 20) : (size_t)256 << 20;
     if (c->arena_cap < want) {
         if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_cap = 0; }
         if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
@@ -1346,6 +1455,9 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_submit: buffer was not handed out by pd_decode_acquire");
     pd_ctx::DecSlot &sl = *slp;
     struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; } c->dec_cv.notify_one(); } } rel{c, slp};
+    const bool c8 = c->c8.on;
+    if (c8 && bt->order >= c->c8.n_batches && bt->n_units) return dec_fail(c, PD_EINVAL, "pd_decode_submit: batch order outside [0, n_batches) of this session");
+    C8Turn turn{c, bt->order, c8 && bt->order < c->c8.n_batches};     // (declared after `rel`: the turn is passed before the slot is given back)
     if (res) memset(res, 0, sizeof *res);
     if (res) res->first_start = res->next_start = ~0ull;
     for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
@@ -1385,7 +1497,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
         (rc = dec_ensure(c, sl, DS_BLK, (size_t)bt->n_blocks * sizeof(pd_bgzf_block))) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
         (rc = dec_ensure(c, sl, DS_SEG, (size_t)n_seg * sizeof(pdb2::Seg))) || (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
-        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16))) return rc;
+        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || (c8 && (rc = dec_ensure(c, sl, DS_SEGOUT, (size_t)n_seg * sizeof(pdb2::SegOut))))) return rc;
     if (!sl.d_tok) {
         std::lock_guard<std::mutex> al(g_alloc_mu);
         if (hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
@@ -1397,7 +1509,9 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
     pdb2::Cfg cfg;
     cfg.buf = d_inf; cfg.avail = bt->inflated_bytes; cfg.n_ref = c->n_contigs; cfg.contig_len = c->d_len; cfg.contig_on = c->d_contig_on;
-    cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans; cfg.near_span = c->dec_near_span;
+    cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans;
+    cfg.near_span = c8 ? 0xFFFFFFFFu : c->dec_near_span;                   // (a compact session has one stream of later runs)
+    cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
     // ---- H2D, inflate, pass 1 ----
     HIPDEC(hipEventRecord(sl.ev[0], st));
     HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes, hipMemcpyHostToDevice, st));
@@ -1457,7 +1571,32 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         ~RunGuard() { if (keep) return; for (pd_iv *q : {r->first, r->other, r->far}) if (q && !(c->arena && (const uint8_t *)q >= c->arena && (const uint8_t *)q < c->arena + c->arena_cap)) (void)hipFree(q); }
     } run_guard{c, &rs};
     lap(4);                                                               // host: chain check, unit outcomes
-    if (nf + no + nfar) {
+    std::vector<pdb2::SegOut> seg_out;
+    if (c8) {
+        // compact session: this batch's place in the sample's two streams, handed out in batch order; pass 2 writes there
+        pd_ctx::C8Dec &x = c->c8;
+        std::unique_lock<std::mutex> lk(x.mu);
+        if (!x.cv.wait_for(lk, std::chrono::seconds(300), [&] { return x.turn >= bt->order; }) || x.turn != bt->order)
+            return dec_fail(c, PD_ESTATE, "pd_decode_submit: the batches of a compact session must be submitted once each, numbered 0 .. n_batches - 1");
+        const uint64_t base_s = x.n_s, base_o = x.n_o;
+        if (nf + no) {
+            if (const int rr = c8_reserve(c, base_s + nf, base_o + no)) { lk.unlock(); return dec_fail(c, rr, "device decode: the run arena could not be grown"); }
+            for (auto &sg : segs) { sg.base_first += base_s; sg.base_other += base_o; }
+            HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+            cfg.c8 = pdb2::C8Out{(pdb2::R8 *)x.r8(), x.b1, c->d_off, 13u - x.bshift, (pdb2::SegOut *)sl.d[DS_SEGOUT]};
+            launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, x.oth(), nullptr);
+            x.n_s += nf; x.n_o += no;
+        }
+        x.turn = bt->order + 1;
+        turn.armed = false;
+        lk.unlock();
+        x.cv.notify_all();
+        if (nf + no) {
+            seg_out.resize(n_seg);
+            HIPDEC(hipMemcpyAsync(seg_out.data(), sl.d[DS_SEGOUT], (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
+        }
+        lap(5);
+    } else if (nf + no + nfar) {
         auto grab = [&](uint64_t n, pd_iv **out) -> bool {
             const size_t bytes = ((size_t)n * sizeof(pd_iv) + 255) & ~(size_t)255;
             const size_t at = c->arena_used.fetch_add(bytes);
@@ -1471,7 +1610,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     }
     // are the first runs in (tid, begin) order, as the header's SO:coordinate promises?  (DS_ONLY is free again: 6 words)
     uint32_t order_words[6] = {0, 0, 0, 0, 0, 0};
-    if (nf) {
+    if (nf && !c8) {
         HIPDEC(hipMemsetAsync(sl.d[DS_ONLY], 0, 24, st));
         launch_runs_sorted(st, rs.first, nf, (uint32_t *)sl.d[DS_ONLY]);
         HIPDEC(hipMemcpyAsync(order_words, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
@@ -1479,6 +1618,19 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    if (c8 && !seg_out.empty()) {
+        // compact emission checked the order itself: inside every lane and across the lanes of a segment; here across the segments
+        uint64_t prev = 0, first = pdb2::NONE, n_long = 0; uint32_t bad = 0;
+        for (const auto &so : seg_out) {
+            bad |= so.unsorted; n_long += so.n_long;
+            if (so.first_key == pdb2::NONE) continue;
+            if (first == pdb2::NONE) first = so.first_key; else if (so.first_key < prev) bad = 1;
+            prev = so.last_key;
+        }
+        order_words[0] = bad ? 1u : 0u;
+        order_words[2] = (uint32_t)first; order_words[3] = (uint32_t)(first >> 32); order_words[4] = (uint32_t)prev; order_words[5] = (uint32_t)(prev >> 32);
+        rs.n_long = n_long;
+    }
     rs.unsorted = order_words[0];
     rs.first_key = (uint64_t)order_words[2] | ((uint64_t)order_words[3] << 32);
     rs.last_key = (uint64_t)order_words[4] | ((uint64_t)order_words[5] << 32);
@@ -1521,6 +1673,68 @@ int pd_decode_end(pd_ctx *c)
         HIPOK(c, hipStreamSynchronize(c->stream));
         for (pd_iv **q : {&c->run_first, &c->run_other, &c->run_far}) if (*q) { (void)hipFree(*q); *q = nullptr; }
         runs_free(c->dec_runs); c->dec_runs = nullptr;
+    }
+    if (c->c8.on) {
+        // ---- a compact session: the runs are where they belong already ----
+        pd_ctx::C8Dec &x = c->c8;
+        std::lock_guard<std::mutex> l8(x.mu);
+        x.on = false;
+        if (x.turn != x.n_batches) { c8_drop(c); return fail(c, PD_ESTATE, "pd_decode_end: not every batch of the compact session was submitted"); }
+        bool ok_order = true; uint64_t prev = 0, n_long = 0; bool have = false;
+        for (auto &r : segs) {
+            n_long += r.n_long;
+            if (!r.n_first) continue;
+            if (r.unsorted || (have && r.first_key < prev)) ok_order = false;
+            prev = r.last_key; have = true;
+        }
+        if (getenv("PANDEPTH_TIMING"))
+            fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
+                            "host chain check %.3f, placement + emit launch %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs (compact session): %llu first, %llu later (span %u)\n",
+                    g_dec_us[0] / 1e6, g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, g_dec_us[7] / 1e6, segs.size(),
+                    (unsigned long long)x.n_s, (unsigned long long)x.n_o, span);
+        if (x.n_s + x.n_o == 0) { c8_drop(c); return PD_OK; }
+        HIPOK(c, hipDeviceSynchronize());                         // (the batches' streams: every emit kernel has finished)
+        if (ok_order && x.n_s && c->pend.empty() && x.n_s + x.n_o <= DEV_BATCH_MAX && x.cap_s + x.cap_o < 0xFFFFFF00ull) {
+            pd_runs *r = new pd_runs;
+            r->ctx = c; r->r8 = x.r8(); r->own_r8 = true; r->n_s = (uint32_t)x.n_s; r->n_o = (uint32_t)x.n_o; r->n = r->n_s + r->n_o; r->o_base = (uint32_t)x.cap_s;
+            r->b1 = x.b1; r->o1 = x.b1 + x.nbw; r->bshift = x.bshift;
+            const pd_iv *oth = x.oth(); const size_t no1 = (size_t)x.n_o;
+            uint32_t *tmp = nullptr, *words = nullptr;
+            const size_t nbw = x.nbw;
+            x.base = nullptr; x.b1 = nullptr; x.bytes = 0; x.cap_s = x.cap_o = 0;       // (they belong to the sample now)
+            if (hipMalloc(&tmp, (2 * nbw + nbw / 1024 + 8) * 4) != hipSuccess || hipMalloc(&words, 16) != hipSuccess) {
+                (void)hipGetLastError(); if (tmp) (void)hipFree(tmp); runs_free(r);
+                return fail(c, PD_ENOMEM, "pd_decode_end: allocation failed");
+            }
+            uint32_t h[2] = {0, 0};
+            hipError_t e = hipMemsetAsync(words, 0, 16, c->stream);
+            if (e == hipSuccess) { const pd_iv *o[1] = {oth}; const size_t non[1] = {no1}; runs_finish(c, r, o, non, no1 ? 1 : 0, tmp, words); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(tmp); (void)hipFree(words);
+            if (e != hipSuccess) { runs_free(r); return fail(c, PD_EHIP, std::string("pd_decode_end: ") + hipGetErrorString(e)); }
+            r->n_long = (uint32_t)std::min<uint64_t>(n_long + h[1], 0xFFFFFFFFull);
+            c->dec_runs = r;
+            Pending p{nullptr, r->n, 0u, -1};
+            p.cr = r;
+            c->pend.push_back(p);
+            return PD_OK;
+        }
+        // not usable as a compact sample after all (the records are not in the order the header promised, the context holds other runs):
+        // back to 12-byte arrays, which take the general paths below
+        nf = x.n_s; no = x.n_o; nfar = 0;
+        if ((nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) || (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess)) {
+            c8_drop(c); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
+        if (nf) launch_r8_to_iv(c->stream, x.r8(), nf, tab_of(c), c->run_first);
+        if (no) HIPOK(c, hipMemcpyAsync(c->run_other, x.oth(), (size_t)no * sizeof(pd_iv), hipMemcpyDeviceToDevice, c->stream));
+        HIPOK(c, hipGetLastError());
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        c8_drop(c);
+        int rc = PD_OK;
+        const bool near_ok = ok_order && span <= (1u << 14);
+        if (nf) rc = scatter_device(c, c->run_first, (size_t)nf, ok_order ? (PD_PUSH_SORTED | PD_PUSH_MORE) : PD_PUSH_DEFAULT, -1, nullptr);
+        if (rc == PD_OK && no) rc = scatter_device(c, c->run_other, (size_t)no, near_ok ? (PD_PUSH_SORTED | PD_PUSH_MORE | PD_PUSH_DISORDER(span + 1)) : PD_PUSH_DEFAULT, -1, nullptr);
+        return rc;
     }
     if ((nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) || (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess) ||
         (nfar && hipMalloc(&c->run_far, (size_t)nfar * sizeof(pd_iv)) != hipSuccess)) { drop(); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
@@ -1587,6 +1801,7 @@ int pd_decode_abort(pd_ctx *c)
     auto in_arena = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
     for (auto &r : c->run_segs) for (pd_iv *q : {r.first, r.other, r.far}) if (q && !in_arena(q)) (void)hipFree(q);
     c->run_segs.clear();
+    { std::lock_guard<std::mutex> l8(c->c8.mu); if (c->c8.on || c->c8.base) { (void)hipDeviceSynchronize(); c8_drop(c); } }
     return PD_OK;
 }
 

@@ -47,7 +47,10 @@
 
 namespace pdw {
 
-enum { LL_ROOT = 10, LL_SUBCAP = 320, D_ROOT = 8, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
+#ifndef PD_LL_ROOT
+#define PD_LL_ROOT 10                     /* bits of the literal/length table's root (tuning builds: 9 frees 2 KiB of LDS per wave) */
+#endif
+enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = 320, D_ROOT = 8, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
 enum { PD_W_OK = 0, PD_W_HOST = 1 };      // negative values: corrupt stream (same codes as pd_inflate_core.h)
 enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2, KIND_BAD = 3 };
 enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };
@@ -431,6 +434,35 @@ PW_FN void copy_match(uint8_t *out, uint32_t dst, uint32_t dist, uint32_t len)
     }
 }
 
+// off mod d for 0 <= off < 2^16, 1 <= d < 2^16, without an integer division (a float quotient, corrected by one step either way)
+PW_FN uint32_t small_mod(uint32_t off, uint32_t d)
+{
+    const uint32_t q = (uint32_t)((float)off * (1.0f / (float)d));
+    int32_t o = (int32_t)(off - q * d);
+    if (o < 0) o += (int32_t)d;
+    if ((uint32_t)o >= d) o -= (int32_t)d;
+    return (uint32_t)o;
+}
+
+// 8 bytes of an OVERLAPPING match (dist < len) starting `off` bytes into it: byte j of such a match is s[j mod dist], where
+// s[0 .. dist) — the `dist` bytes in front of the match — exist before the match is copied.  Reads only those bytes (and up to 7 behind).
+PW_FN uint64_t periodic8(const uint8_t *s, uint32_t dist, uint32_t off)
+{
+    const uint32_t o = small_mod(off, dist);
+    if (dist >= 8) {
+        const uint64_t a = ld64(s + o);
+        if (o + 8 <= dist) return a;
+        const uint32_t k1 = dist - o;                                     // 1 .. 7 bytes to the end of the period, the rest from its start
+        return (a & ((1ull << (8 * k1)) - 1ull)) | (ld64(s) << (8 * k1));
+    }
+    const uint64_t raw = ld64(s);
+    uint64_t v = 0;
+    uint32_t q = o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v |= ((raw >> (8 * q)) & 0xff) << (8 * k); q = q + 1 == dist ? 0 : q + 1; }
+    return v;
+}
+
 // A match waiting to be copied: out[dst .. dst+len) = out[dst-dist ..] (positions inside the member's output).
 struct Token { uint32_t dst; uint32_t len_dist; };             // len_dist = len | dist << 16
 
@@ -570,25 +602,59 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
                 dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
             });
+            // The ready matches of a round are copied in 8-byte PIECES dealt out over the whole wave — piece p of the round belongs to the
+            // match whose first piece is the last one at or before p — so a round costs its bytes / 512 trips of one uniform step, not the
+            // trips of its longest match through a divergent per-lane copy loop (the wave used to wait for 1 350 pieces per member that
+            // way; dealt out, a member's 8 900 pieces are 140 trips + one per round).  A piece is a full 8-byte load and store (the last
+            // piece of a match overlaps the one before it so that it ends where the match ends; matches shorter than 8 bytes are one
+            // byte-exact piece); a piece of a self-overlapping match (dist < len) takes its bytes from the period in front of the match.
+            const U packB = [&] { U x; W::each([&](int l) { x[l] = len[l] | (dist[l] << 16); }); return x; }();
+            uint16_t *const own = T.sorted;                               // (free since the tables were built) 64 entries: a chunk's piece -> match marks
             uint64_t done = W::ballot_eq(valid, 0u);
             for (int round = 0; done != ~0ull; ++round) {
                 if (round > 64) return -9;
-                U ready;
+                U ready, np;
                 W::each([&](int l) {
-                    ready[l] = 0;
+                    ready[l] = 0; np[l] = 0;
                     if ((done >> l) & 1) return;
                     uint64_t dm = 0;
                     if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
                     if (dm & ~done) return;
-                    ready[l] = 1;
-                    copy_match(out, dst[l], dist[l], len[l]);
+                    ready[l] = 1; np[l] = (len[l] + 7) >> 3;
                     if (st) st->copy_iters += (len[l] + 31) / 32;
                 });
-                if (st) {
-                    uint32_t mx = 0;
-                    W::each([&](int l) { if (ready[l]) { const uint32_t it = (len[l] + 7) / 8; if (it > mx) mx = it; if (len[l] > 16) st->long_matches++; } });
-                    st->copy_serial += mx;
+                uint32_t P = 0;
+                const U ps = W::excl_scan(np, &P);                        // a ready match's first piece
+                U packA;
+                W::each([&](int l) { packA[l] = dst[l] | (ps[l] << 16); });
+                uint32_t carry = 0;                                       // (1 + match) of the piece in front of the chunk
+                for (uint32_t c0 = 0; c0 < P; c0 += 64) {
+                    W::each([&](int l) { own[l] = 0; });
+                    W::sync();
+                    W::each([&](int l) { if (ready[l] && ps[l] - c0 < 64u) own[ps[l] - c0] = (uint16_t)(l + 1); });
+                    W::sync();
+                    U id;
+                    W::each([&](int l) { id[l] = own[l]; });
+                    id = W::incl_scan_max(id);
+                    W::each([&](int l) { if (id[l] < carry) id[l] = carry; });
+                    carry = W::bcast(id, 63);
+                    U src_lane;
+                    W::each([&](int l) { src_lane[l] = id[l] ? id[l] - 1 : 0u; });
+                    const U a = W::shfl(packA, src_lane), b = W::shfl(packB, src_lane);
+                    W::each([&](int l) {
+                        const uint32_t p = c0 + (uint32_t)l;
+                        if (p >= P) return;
+                        const uint32_t dstm = a[l] & 0xffff, lenm = b[l] & 0xffff, distm = b[l] >> 16;
+                        uint32_t off = (p - (a[l] >> 16)) * 8;
+                        if (lenm >= 8 && off > lenm - 8) off = lenm - 8;
+                        const uint8_t *s = out + dstm - distm;
+                        const uint64_t v = distm >= lenm ? ld64(s + off) : periodic8(s, distm, off);
+                        if (lenm >= 8) st64(out + dstm + off, v); else store_bytes(out + dstm, v, lenm);
+                    });
+                    if (st) st->copy_serial += 1;
+                    W::sync();
                 }
+                if (st) W::each([&](int l) { if (ready[l] && len[l] > 16) st->long_matches++; });
                 W::fence();
                 done |= W::ballot_ne(ready, 0u);
                 if (st) st->emit_rounds++;
@@ -809,6 +875,8 @@ struct HostWave {                         // 64 emulated lanes
     static Var<uint32_t> excl_scan(const Var<uint32_t> &x, uint32_t *total) { Var<uint32_t> r; uint32_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; a += x.v[l]; } *total = a; return r; }
     static Var<uint32_t> shift_up1(const Var<uint32_t> &x, uint32_t fill) { Var<uint32_t> r; r.v[0] = fill; for (int l = 1; l < 64; ++l) r.v[l] = x.v[l - 1]; return r; }
     static uint32_t bcast(const Var<uint32_t> &x, int lane) { return x.v[lane]; }
+    static Var<uint32_t> incl_scan_max(const Var<uint32_t> &x) { Var<uint32_t> r; uint32_t a = 0; for (int l = 0; l < 64; ++l) { if (x.v[l] > a) a = x.v[l]; r.v[l] = a; } return r; }
+    static Var<uint32_t> shfl(const Var<uint32_t> &x, const Var<uint32_t> &from) { Var<uint32_t> r; for (int l = 0; l < 64; ++l) r.v[l] = x.v[from.v[l] & 63]; return r; }
     static uint64_t bcast64(const Var<uint64_t> &x, int lane) { return x.v[lane]; }
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
@@ -846,6 +914,20 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         Var<uint32_t> r; const uint32_t y = (uint32_t)__shfl_up((int)x.v, 1); r.v = (threadIdx.x & 63) ? y : fill; return r;
     }
     __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
+    __device__ static __forceinline__ Var<uint32_t> incl_scan_max(const Var<uint32_t> &x)
+    {
+        // (unsigned maximum with the row-shift / row-broadcast pattern of the prefix sum; lanes that receive nothing keep their value: 0 is the identity)
+        uint32_t m = x.v;
+        auto mx = [](uint32_t p, uint32_t q) { return p > q ? p : q; };
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, false));
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, false));
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, false));
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, false));
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false));
+        m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xc, 0xf, false));
+        Var<uint32_t> r; r.v = m; return r;
+    }
+    __device__ static __forceinline__ Var<uint32_t> shfl(const Var<uint32_t> &x, const Var<uint32_t> &from) { Var<uint32_t> r; r.v = (uint32_t)__shfl((int)x.v, (int)(from.v & 63u)); return r; }
     __device__ static __forceinline__ uint64_t bcast64(const Var<uint64_t> &x, int lane)        // lane must be wave-uniform
     {
         const int sl = __builtin_amdgcn_readfirstlane(lane);

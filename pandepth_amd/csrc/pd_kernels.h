@@ -43,13 +43,19 @@ struct CheckWords {           // context-wide, read back at pd_scan / pd_synchro
 #define PD_MAXPEND 4          /* sorted batches merged into one owner-tile pass */
 #define PD_HALF 4096          /* granularity of the "written since reset" flags */
 
-// A whole sample in the engine's COMPACT form (pd_runs_create): 8 bytes per run — begin inside its contig (already clamped to
-// [0, len]) and length (0: a run without cells) — GROUPED BY BUCKET of (8192 >> bshift) cells of the flat cell space: bucket k's
-// runs are [bstart[k], bstart[k + 1]), in any order inside the bucket.  Contig slots start on tile boundaries, so a tile's own
-// runs are the 1 << bshift buckets [bstart[t << bshift], bstart[(t + 1) << bshift]) and all belong to the tile's contig; no run
-// is longer than a bucket, so the only other runs that can reach into tile t are those of the bucket right before it.
+// A whole sample in the engine's COMPACT form (pd_runs_create; what the GPU decoder leaves for the whole-contig modes): 8 bytes per run —
+// the low 32 bits of its FLAT begin (cell index in the context's buffer; the begin is already clamped to [0, len] of its contig) and its
+// clamped length (0: a run without cells) — in TWO streams, each grouped by bucket of (8192 >> bshift) cells of the flat cell space:
+//   r8[0 ..) / b1        the file's sorted stream (every read's first run) in file order, exactly as the decoder's emit kernel wrote it;
+//                        bucket k's runs are r8[b1[k] .. b1[k + 1])
+//   r8[o_base ..) / o1   the other runs (later runs of reads with deletions / skips), counting-sorted by bucket:
+//                        r8[o_base + o1[k] .. o_base + o1[k + 1]), any order inside
+// (both streams in ONE array, so that a kernel walking a tile's candidates of both selects a 32-bit index, not a pointer)
+// Contig slots start on tile boundaries, so a tile's own runs are those of its 1 << bshift buckets and all belong to the tile's contig
+// (which is why 32 bits of the begin are enough: a consumer only ever needs a begin relative to the tile it is working on); no run is
+// longer than a bucket, so the only other runs that can reach into tile t are those of the bucket right before it.
 struct Run8 { uint32_t b; uint32_t len; };
-struct C8Sample { const Run8 *r8; const uint32_t *bstart; uint32_t bshift, n; };
+struct C8Sample { const Run8 *r8; const uint32_t *b1, *o1; uint32_t o_base, bshift; };
 
 struct PendBatch {            // one sorted batch of a tile pass (device pointers)
     const pd_iv *iv;
@@ -74,14 +80,15 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
                          uint32_t wrap_mask, uint32_t w, uint32_t min_dep, TilePart *part, const uint64_t *win_off,
                          uint32_t *cover, unsigned long long *sum, uint32_t *n_long, uint32_t *fail,
                          uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
-// compact samples: the passes of pd_runs_create (words: [0] not sorted / invalid contig, [1] runs longer than a bucket), the
-// reverse (12-byte runs, bucket by bucket), and the direct kernels that read them
-void launch_c8_scan_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets, uint32_t *b1, uint32_t *words);
+// compact samples: the passes that make one (words: [0] not sorted / invalid contig, [1] runs longer than a bucket), the reverse
+// (12-byte runs, bucket by bucket), and the direct kernels that read them
+void launch_c8_from_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, Run8 *out, uint32_t *b1 /* pre-set to 0xFF */, uint32_t *words);
 void launch_c8_hist(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words);
 void launch_excl_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *block_sums /* n / 1024 + 2 words */);
-void launch_c8_place(hipStream_t st, const pd_iv *sorted, uint32_t n_sorted, const pd_iv *const *others, const uint32_t *n_others, int n_other_arrays,
-                     ContigTab tab, uint32_t bshift, uint32_t n_buckets, const uint32_t *b1, const uint32_t *o2, uint32_t *cursor, Run8 *out, uint32_t *bstart);
-void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out);
+void launch_c8_fill_starts(hipStream_t st, uint32_t *b1, uint32_t n_buckets, uint32_t n_runs, uint32_t *tmp /* n_buckets / 1024 + 2 words */);
+void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1, uint32_t *cursor, Run8 *out);
+void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out);
+void launch_r8_to_iv(hipStream_t st, const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out);
 void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
                       uint32_t min_dep, TilePart *part, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
 void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,

@@ -1163,17 +1163,21 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
                 }
             }
         }
-        if (cs.r8) {                                              // a compact sample: the tile's own buckets and the one before them
-            const uint32_t k0 = (uint32_t)t << cs.bshift;
-            const uint32_t hi = cs.bstart[k0 + (1u << cs.bshift)];
-            const uint32_t lo = rel < 0 ? cs.bstart[k0 - 1] : cs.bstart[k0];       // (a contig's first tile has nothing before it)
-            for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
-                const Run8 r = cs.r8[i];
-                if (!r.len) continue;
-                const int64_t sb = rel + (int64_t)r.b, se = sb + (int64_t)r.len;
-                if (sb >= 0 && sb < ST) atomicAdd(&win[sb], 1);
-                if (se >= 0 && se < ST) atomicAdd(&win[se], -1);
-                if (sb < 0 && se >= 0) ++carry;
+        if (cs.r8) {                                              // a compact sample: the tile's own buckets and the one before them, in both streams
+            const uint32_t k0 = (uint32_t)t << cs.bshift, kl = rel < 0 ? k0 - 1 : k0;           // (a contig's first tile has nothing before it)
+            const uint32_t a32 = (uint32_t)a;
+            for (int strm = 0; strm < 2; ++strm) {
+                const uint32_t *bs = strm ? cs.o1 : cs.b1;
+                const Run8 *r8 = strm ? cs.r8 + cs.o_base : cs.r8;
+                const uint32_t lo = bs[kl], hi = bs[k0 + (1u << cs.bshift)];
+                for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
+                    const Run8 r = r8[i];
+                    if (!r.len) continue;
+                    const int64_t sb = (int64_t)(int32_t)(r.b - a32), se = sb + (int64_t)r.len;   // tile-relative (the begins are flat, mod 2^32)
+                    if (sb >= 0 && sb < ST) atomicAdd(&win[sb], 1);
+                    if (se >= 0 && se < ST) atomicAdd(&win[se], -1);
+                    if (sb < 0 && se >= 0) ++carry;
+                }
             }
         }
         carry = wave_sum(carry);
@@ -1302,55 +1306,74 @@ __global__ __launch_bounds__(WG) void k_direct_tiles_heavy(const PendSet ps, uin
 }
 
 // ------------------------------------------------------------------------------------------
-// compact samples (pd_runs_create / pd_push_runs): see C8Sample in pd_kernels.h
+// compact samples (pd_runs_create / pd_push_runs, and what the GPU decoder leaves behind): see C8Sample in pd_kernels.h
 // ------------------------------------------------------------------------------------------
-// flat begin (clamped) and clamped length of a run; valid = its contig id is one
-__device__ __forceinline__ uint64_t c8_flat(const pd_iv v, const ContigTab tab, uint32_t &b, uint32_t &len, bool &valid)
+// flat begin (clamped to the contig) and clamped length of a run; valid = its contig id is one
+__device__ __forceinline__ uint64_t c8_flat(const pd_iv v, const ContigTab tab, uint32_t &len, bool &valid)
 {
     valid = v.tid >= 0 && v.tid < tab.n;
-    b = 0; len = 0;
+    len = 0;
     if (!valid) return 0;
     const uint32_t clen = tab.len[v.tid];
-    b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
+    uint32_t b = v.beg < 0 ? 0u : (uint32_t)v.beg; if (b > clen) b = clen;
     uint32_t x = v.end < 0 ? 0u : (uint32_t)v.end; if (x > clen) x = clen;
     len = x > b ? x - b : 0u;
-    return tab.off[v.tid] + b;
+    return tab.off[v.tid] + b;             // (b <= clen < the slot's cells: always inside the contig's own slot, so below n_buckets << cshift)
 }
 
-// Pass A, the sorted stream: its order is CHECKED (words[0]: a contig id out of range, or a run that begins before its
-// predecessor), runs longer than a bucket are counted (words[1]: such a sample is not used in this form), and every bucket
-// learns the index of its first run — thread i writes the buckets between its predecessor's and its own (b1: n_buckets + 1).
-__global__ __launch_bounds__(WG) void k_c8_scan_sorted(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets,
-                                                       uint32_t *b1, uint32_t *words)
+// The sorted stream from 12-byte runs (pd_runs_create; the decoder's emit kernel, pd_bamwalk.h, does the same while it writes its runs):
+// every run becomes 8 bytes — the low 32 bits of its flat begin, its clamped length —, its order is CHECKED against its predecessor
+// (words[0]: a contig id out of range, or a run that begins before the one in front of it), runs longer than a bucket are counted
+// (words[1]: such a sample is not used in this form), and the first run of every bucket leaves its index in b1[bucket] (pre-set to
+// 0xFFFFFFFF; the buckets nobody begins in are filled by launch_c8_fill_starts).
+__global__ __launch_bounds__(WG) void k_c8_from_sorted(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, Run8 *out, uint32_t *b1, uint32_t *words)
 {
     const uint64_t i64 = (uint64_t)blockIdx.x * WG + threadIdx.x;
     const uint32_t i = i64 < n ? (uint32_t)i64 : n - 1;
     const uint32_t cshift = 13u - bshift;                        // log2(cells per bucket)
-    uint32_t b, len; bool valid;
-    const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
+    uint32_t len; bool valid;
+    const uint64_t gb = c8_flat(iv[i], tab, len, valid);
     uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(gb >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)gb, 1);
     bool pvalid = __shfl_up((int)valid, 1) != 0;
-    if ((threadIdx.x & 63) == 0 && i > 0) { uint32_t pb, pl; prev = c8_flat(iv[i - 1], tab, pb, pl, pvalid); }
+    if ((threadIdx.x & 63) == 0 && i > 0) { uint32_t pl; prev = c8_flat(iv[i - 1], tab, pl, pvalid); }
     if (i64 >= n) return;
     if (!valid || (i > 0 && (!pvalid || gb < prev))) atomicOr(&words[0], 1u);
     if (len > (1u << cshift)) atomicAdd(&words[1], 1u);
-    int64_t k_hi = (int64_t)(gb >> cshift), k_lo = i > 0 ? (int64_t)(prev >> cshift) : -1;
-    if (k_hi > (int64_t)n_buckets) k_hi = n_buckets;
-    if (k_lo > (int64_t)n_buckets) k_lo = n_buckets;
-    for (int64_t k = k_lo + 1; k <= k_hi; ++k) b1[k] = i;
-    if (i == n - 1) for (int64_t k = k_hi + 1; k <= (int64_t)n_buckets; ++k) b1[k] = n;
+    out[i] = Run8{(uint32_t)gb, len};
+    if (valid && (i == 0 || !pvalid || (prev >> cshift) != (gb >> cshift))) atomicMin(&b1[gb >> cshift], i);
 }
 
-// Pass B, the other streams (any order): how many of their runs begin in each bucket
+// The other streams (any order, but in practice the later runs of a file's reads in file order: nearly sorted).  Neighbouring lanes
+// whose runs begin in the same bucket act ONCE: the first of them adds their number to the bucket's counter (a device atomic per
+// run was 4.4 ms for the 1.1e8 later runs of the 1e9-record sample; per group of equal neighbours it is a tenth of that).
+// group(key): the lane's group of equal neighbours as (first lane, size); every lane of the wave must call it
+__device__ __forceinline__ void c8_group(const uint32_t key, int &head_lane, uint32_t &size)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t pk = (uint32_t)__shfl_up((int)key, 1);
+    const unsigned long long heads = __ballot(lane == 0 || pk != key);
+    const unsigned long long le = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    head_lane = 63 - __builtin_clzll(le);                         // (bit 0 is always set)
+    // size of the group = distance from its first lane to the next group's first lane
+    const unsigned long long above_h = head_lane == 63 ? 0ull : heads & ~((2ull << head_lane) - 1ull);
+    size = (uint32_t)((above_h ? __builtin_ctzll(above_h) : 64) - head_lane);
+}
 __global__ __launch_bounds__(WG) void k_c8_hist(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words)
 {
     const uint32_t cshift = 13u - bshift;
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
-        uint32_t b, len; bool valid;
-        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
-        if (!valid) { atomicOr(&words[0], 1u); continue; }
-        if (len > (1u << cshift)) atomicAdd(&words[1], 1u);
-        atomicAdd(&hist[gb >> cshift], 1u);
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * WG; base < n; base += (uint64_t)gridDim.x * WG) {      // (workgroup-uniform trip count)
+        const uint64_t i = base + threadIdx.x;
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < n) {
+            uint32_t len; bool valid;
+            const uint64_t gb = c8_flat(iv[i], tab, len, valid);
+            if (!valid) atomicOr(&words[0], 1u);
+            else { key = (uint32_t)(gb >> cshift); if (len > (1u << cshift)) atomicAdd(&words[1], 1u); }
+        }
+        int hl; uint32_t sz;
+        c8_group(key, hl, sz);
+        if (hl == lane && key != 0xFFFFFFFFu) atomicAdd(&hist[key], sz);
     }
 }
 
@@ -1403,53 +1426,139 @@ __global__ __launch_bounds__(WG) void k_scan_blocks(const uint32_t *in, uint32_t
     for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = off; off += x[k]; }
 }
 
-// bucket k of the merged sample starts at b1[k] + o2[k]; its sorted-stream runs come first, the others after them
-__global__ __launch_bounds__(WG) void k_c8_bstart(const uint32_t *b1, const uint32_t *o2, uint32_t n_buckets, uint32_t *bstart)
+// Bucket starts from the marks the first runs of the buckets left: a[k] = min(a[k], a[k + 1], ..., a[n - 1]) in place (a SUFFIX minimum;
+// the caller has put the number of runs into a[n - 1]).  Same three-kernel shape as the prefix sum above, walked from the far end.
+__device__ __forceinline__ uint32_t wave_suffix_min(uint32_t m)      // lane l: min over lanes l .. 63
 {
-    const uint64_t k = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    if (k <= n_buckets) bstart[k] = b1[k] + o2[k];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_down((int)m, d); if (lane + d < 64 && y < m) m = y; }
+    return m;
 }
-__global__ __launch_bounds__(WG) void k_c8_place_sorted(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o2, Run8 *out)
+__global__ __launch_bounds__(WG) void k_sfx_block_min(const uint32_t *a, uint32_t n, uint32_t *bm)
 {
-    const uint32_t cshift = 13u - bshift;
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
-        uint32_t b, len; bool valid;
-        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
-        if (valid) out[i + o2[gb >> cshift]] = Run8{b, len};
+    __shared__ uint32_t ws[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n && a[base + k] < v) v = a[base + k];
+    v = wave_suffix_min(v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t m = ws[0]; for (int k = 1; k < 4; ++k) if (ws[k] < m) m = ws[k]; bm[blockIdx.x] = m; }
+}
+// bm[j] := min(bm[j + 1 ..]) (what lies strictly behind block j), one workgroup
+__global__ __launch_bounds__(1024) void k_sfx_of_mins(uint32_t *bm, uint32_t nb)
+{
+    __shared__ uint32_t wmin[16];
+    __shared__ uint32_t run_s;
+    if (threadIdx.x == 0) run_s = 0xFFFFFFFFu;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t top = (nb + 1023u) / 1024u * 1024u; top > 0; top -= 1024) {
+        const uint32_t i = top - 1024 + threadIdx.x;
+        const uint32_t v = i < nb ? bm[i] : 0xFFFFFFFFu;
+        const uint32_t inc = wave_suffix_min(v);                 // min over this wave's lanes lane .. 63
+        if (lane == 0) wmin[wv] = inc;
+        __syncthreads();
+        uint32_t behind = run_s;                                  // later chunks
+        for (int k = wv + 1; k < 16; ++k) if (wmin[k] < behind) behind = wmin[k];
+        const uint32_t nxt = (uint32_t)__shfl_down((int)inc, 1);  // lanes lane + 1 .. 63 of this wave
+        uint32_t ex = behind;
+        if (lane < 63 && nxt < ex) ex = nxt;
+        uint32_t all = behind; if (inc < all) all = inc;          // (thread 0: everything from this chunk on)
+        __syncthreads();
+        if (i < nb) bm[i] = ex;
+        if (threadIdx.x == 0) run_s = all;
+        __syncthreads();
     }
 }
-__global__ __launch_bounds__(WG) void k_c8_place_other(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *b1, const uint32_t *o2,
+__global__ __launch_bounds__(WG) void k_sfx_blocks(uint32_t *a, uint32_t n, const uint32_t *bmx)
+{
+    __shared__ uint32_t ws[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = base + k < n ? a[base + k] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) if (x[k + 1] < x[k]) x[k] = x[k + 1];       // suffix minimum inside the thread's four
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t inc = wave_suffix_min(x[0]);
+    if (lane == 0) ws[wv] = inc;
+    __syncthreads();
+    uint32_t behind = bmx[blockIdx.x];
+    for (int k = wv + 1; k < 4; ++k) if (ws[k] < behind) behind = ws[k];
+    const uint32_t nxt = (uint32_t)__shfl_down((int)inc, 1);
+    if (lane < 63 && nxt < behind) behind = nxt;                   // what lies behind this thread's four
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] = x[k] < behind ? x[k] : behind;
+}
+__global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+
+// the other streams' runs to their buckets: o1 = exclusive prefix sum of the histogram; the runs of a group of equal neighbours take
+// consecutive places from ONE atomic on the bucket's cursor
+__global__ __launch_bounds__(WG) void k_c8_place_other(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1,
                                                        uint32_t *cursor, Run8 *out)
 {
     const uint32_t cshift = 13u - bshift;
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
-        uint32_t b, len; bool valid;
-        const uint64_t gb = c8_flat(iv[i], tab, b, len, valid);
-        if (!valid) continue;
-        const uint64_t k = gb >> cshift;
-        out[b1[k + 1] + o2[k] + atomicAdd(&cursor[k], 1u)] = Run8{b, len};
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * WG; base < n; base += (uint64_t)gridDim.x * WG) {
+        const uint64_t i = base + threadIdx.x;
+        uint32_t key = 0xFFFFFFFFu, len = 0; uint64_t gb = 0;
+        if (i < n) { bool valid; gb = c8_flat(iv[i], tab, len, valid); if (valid) key = (uint32_t)(gb >> cshift); }
+        int hl; uint32_t sz;
+        c8_group(key, hl, sz);
+        uint32_t at = 0;
+        if (hl == lane && key != 0xFFFFFFFFu) at = o1[key] + atomicAdd(&cursor[key], sz);
+        at = (uint32_t)__shfl((int)at, hl);
+        if (key != 0xFFFFFFFFu) out[at + (uint32_t)(lane - hl)] = Run8{(uint32_t)gb, len};
     }
 }
 
-// the reverse (a compact sample that has to take a path that reads 12-byte runs): bucket by bucket, so the result is sorted up to
-// one bucket's cells of disorder
-__global__ __launch_bounds__(WG) void k_c8_expand(const C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
+// the reverse (a compact sample that has to take a path that reads 12-byte runs): bucket by bucket — a bucket's sorted-stream runs,
+// then its other runs —, so the result is sorted up to one bucket's cells of disorder
+__global__ __launch_bounds__(WG) void k_c8_expand(const C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out)
 {
+    const uint32_t cshift = 13u - cs.bshift, nbk = 1u << cs.bshift;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t lo = cs.bstart[t << cs.bshift], hi = cs.bstart[(t + 1) << cs.bshift];
+        const uint32_t k0 = t << cs.bshift;
         const int32_t ctg = (int32_t)tile_contig[t];
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) { const Run8 r = cs.r8[i]; out[i] = pd_iv{ctg, (int32_t)r.b, (int32_t)(r.b + r.len)}; }
+        const uint32_t a32 = (uint32_t)((uint64_t)t * TILE), c32 = (uint32_t)contig_off[ctg];
+        for (uint32_t i = cs.b1[k0] + threadIdx.x; i < cs.b1[k0 + nbk]; i += WG) {
+            const Run8 r = cs.r8[i];
+            const uint32_t kb = k0 + ((r.b - a32) >> cshift), beg = r.b - c32;
+            out[i + cs.o1[kb]] = pd_iv{ctg, (int32_t)beg, (int32_t)(beg + r.len)};
+        }
+        for (uint32_t j = cs.o1[k0] + threadIdx.x; j < cs.o1[k0 + nbk]; j += WG) {
+            const Run8 r = cs.r8[cs.o_base + j];
+            const uint32_t kb = k0 + ((r.b - a32) >> cshift), beg = r.b - c32;
+            out[j + cs.b1[kb + 1]] = pd_iv{ctg, (int32_t)beg, (int32_t)(beg + r.len)};
+        }
     }
 }
 
-// k_direct_c8 — the wide-window direct kernel on a compact sample: ONE stream, exact bounds, nothing to test but where the two
+// a sorted stream of compact runs whose sample turned out not to be usable as one (the file's order does not hold after all): back to
+// 12-byte runs; the contig of a flat begin by bisection over the slots (genomes below 2^32 cells only: the caller has made sure)
+__global__ __launch_bounds__(WG) void k_r8_to_iv(const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        const Run8 r = r8[i];
+        int lo = 0, hi = tab.n - 1;                               // last contig whose slot starts at or before r.b
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab.off[mid] <= (uint64_t)r.b) lo = mid; else hi = mid - 1; }
+        const uint32_t beg = r.b - (uint32_t)tab.off[lo];
+        out[i] = pd_iv{lo, (int32_t)beg, (int32_t)(beg + r.len)};
+    }
+}
+
+// k_direct_c8 — the wide-window direct kernel on a compact sample: exact bounds, nothing to test but where the two
 // events of a run fall.  Per run (13 vector instructions; k_direct_wide3: 26, on 12-byte runs with a contig compare and clamps):
-//   sb = b - p0 (mod 2^32): < TILE exactly for the tile's own runs;  se = sb + len: < TILE when the end lies in the tile;
-//   se < len exactly when the run begins before the tile and reaches its first cell or further (the carry-in).
-// A run without cells adds and subtracts at the same cell.  The tile's candidates are its own buckets and the one before them
-// (1/16 more than its own runs with 512-cell buckets; k_direct_wide3's index granularity, look-back and disorder margins made
-// it 37 %).  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more than 32 000 candidates go to
-// the int-window kernel through the same list.
+//   sb = b - p0 (mod 2^32; b = the low 32 bits of the run's flat begin, p0 those of the tile's first cell): < TILE exactly for the tile's
+//   own runs;  se = sb + len: < TILE when the end lies in the tile;  se < len exactly when the run begins before the tile and reaches
+//   its first cell or further (the carry-in).
+// A run without cells adds and subtracts at the same cell.  The tile's candidates are its own buckets and the one before them, in
+// BOTH streams of the sample (the file's sorted first runs as the decoder wrote them, and the later runs counting-sorted by bucket):
+// one loop over the two ranges laid end to end.  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more
+// than 32 000 candidates go to the int-window kernel through the same list.
 template <int WPE, int UN8, bool EXPORT>
 __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32_t n_tiles, ContigTab tab, const uint32_t *tile_contig,
                                                      uint32_t wrap_mask, const DirectWide args, uint32_t *heavy_list, uint32_t *heavy_count,
@@ -1464,39 +1573,48 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const Run8 *__restrict__ p = cs.r8;
     const uint32_t bsh = cs.bshift;
-    // the bounds of a tile are three entries of bstart (scalar loads); the next tile's are fetched a tile ahead
-    auto bounds = [&](const uint64_t t, uint32_t &lo, uint32_t &hi) {
-        lo = hi = 0;
+    // the bounds of a tile are three entries of each stream's bucket starts (scalar loads); the sorted stream's are fetched a tile ahead,
+    // the other stream's at the top of the tile (they are not needed before the sorted stream's runs are through)
+    auto bounds = [&](const uint64_t t, uint32_t &slo, uint32_t &shi) {
+        slo = shi = 0;
         if (t < n_tiles) {
             const uint32_t k0 = (uint32_t)t << bsh;
-            hi = cs.bstart[k0 + (1u << bsh)];
+            shi = cs.b1[k0 + (1u << bsh)];
             const uint32_t ctg = tile_contig[t];
-            lo = (uint64_t)t * ST > tab.off[ctg] ? cs.bstart[k0 - 1] : cs.bstart[k0];     // a contig's first tile has nothing before it
+            slo = cs.b1[(uint64_t)t * ST > tab.off[ctg] ? k0 - 1 : k0];            // a contig's first tile has nothing before it
         }
     };
-    uint32_t nlo, nhi;
-    bounds(blockIdx.x, nlo, nhi);
+    uint32_t nslo, nshi;
+    bounds(blockIdx.x, nslo, nshi);
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t a = t * ST;
-        const uint32_t lo = nlo, hi = nhi;
+        const uint32_t ns = nshi - nslo, s_at = nslo;             // the tile's candidates in the sorted stream
         uint4 *w4 = reinterpret_cast<uint4 *>(win);
         for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x == 0) s_carry = 0;
         const int32_t ctg = (int32_t)tile_contig[t];
         const uint32_t clen = tab.len[ctg];
-        const uint32_t p0 = (uint32_t)(a - tab.off[ctg]);
-        bounds(t + gridDim.x, nlo, nhi);
+        const uint32_t p0 = (uint32_t)a;                          // the runs' begins are flat (mod 2^32), like this
+        const uint32_t pc = (uint32_t)(a - tab.off[ctg]);         // the tile's first cell inside its contig
+        const uint32_t k0 = (uint32_t)t << bsh;
+        const uint32_t olo = cs.o1[pc ? k0 - 1 : k0], ohi = cs.o1[k0 + (1u << bsh)];        // ... and in the other stream
+        bounds(t + gridDim.x, nslo, nshi);
         __syncthreads();
-        const uint32_t cand = hi - lo;
-        if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
+        if (ns > 32000u) {                                        // workgroup-uniform: the int-window kernel does this tile
             if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
             __syncthreads();
             continue;
         }
+        uint32_t cand = ns;
         int carry_s = 0;
-        {
+        // the same loop over one stream, then the other (ONE copy of the code: the stream is a scalar choice of base pointer and count)
+        bool heavy = false;
+#pragma unroll 1
+        for (int strm = 0; strm < 2; ++strm) {
+            const Run8 *__restrict__ const p = cs.r8 + (strm ? cs.o_base + olo : s_at);
+            const uint32_t hi = strm ? ohi - olo : ns;
+            if (strm) { cand += hi; if (cand > 32000u) { heavy = true; break; } }     // (workgroup-uniform)
             constexpr uint32_t C = UN8 * WG;
             auto load8 = [&](uint2 (&dst)[UN8], const uint32_t i) {
                 const uint32_t last = hi - 1u;
@@ -1524,9 +1642,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                     }
                 }
             };
-            if (lo < hi) {
+            if (hi) {
                 uint2 A[UN8], B[UN8];
-                uint32_t i = lo;
+                uint32_t i = 0;
                 load8(A, i);
 #pragma unroll 1
                 for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
@@ -1538,6 +1656,11 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                     i += C; if (i >= hi) break;
                 }
             }
+        }
+        if (heavy) {                                              // too many candidates for the packed counters after all: the int-window kernel redoes the tile
+            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
+            __syncthreads();
+            continue;
         }
         if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
         __syncthreads();
@@ -1571,7 +1694,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
         const int tl = (int)(short)(totp & 0xffff);               // begins - ends over the low half-tile
         const int carry_l = s_carry, carry_h = carry_l + tl;      // depth just before cell 0 / cell HT of the tile
         // ---- the tile's share of windows k0 and k0 + 1 ----
-        const uint64_t local0 = p0;
+        const uint64_t local0 = pc;
         int c0 = 0, c1 = 0; unsigned long long s0 = 0, s1 = 0;
         bool uniform_counts = false;                              // c0 is a wave count (ballots), s0 a 32-bit lane sum
         if (local0 < clen) {
@@ -2519,7 +2642,7 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
     }
 #undef PD_DIRECT
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, wrap_mask, wa, win_off,
-                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{}, C8Sample{nullptr, nullptr, 0, 0});
+                       n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, DirectExport{}, C8Sample{});
     if (w < (uint32_t)TILE && n_tiles > 1)
         hipLaunchKernelGGL(k_window_edges, dim3((n_tiles + WG - 1) / WG), dim3(WG), 0, st, (const TilePart *)part, TileMap{tile_contig, tab.off, tab.len, win_off},
                            n_tiles, w, cover, sum);
@@ -2528,13 +2651,15 @@ void launch_direct_tiles(hipStream_t st, const PendSet &ps, ContigTab tab, const
 
 static unsigned grid_1k(uint64_t n) { return (unsigned)((n + 1023) / 1024 ? (n + 1023) / 1024 : 1); }
 
-void launch_c8_scan_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t n_buckets, uint32_t *b1, uint32_t *words)
+void launch_c8_from_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, Run8 *out, uint32_t *b1, uint32_t *words)
 {
-    hipLaunchKernelGGL(k_c8_scan_sorted, dim3((unsigned)(((uint64_t)n + WG - 1) / WG)), dim3(WG), 0, st, iv, n, tab, bshift, n_buckets, b1, words);
+    if (!n) return;
+    hipLaunchKernelGGL(k_c8_from_sorted, dim3((unsigned)(((uint64_t)n + WG - 1) / WG)), dim3(WG), 0, st, iv, n, tab, bshift, out, b1, words);
 }
 
 void launch_c8_hist(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words)
 {
+    if (!n) return;
     const uint64_t g = ((uint64_t)n + WG - 1) / WG;
     hipLaunchKernelGGL(k_c8_hist, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, iv, n, tab, bshift, hist, words);
 }
@@ -2547,24 +2672,35 @@ void launch_excl_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uin
     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(WG), 0, st, in, out, n, (const uint32_t *)block_sums);
 }
 
-void launch_c8_place(hipStream_t st, const pd_iv *sorted, uint32_t n_sorted, const pd_iv *const *others, const uint32_t *n_others, int n_other_arrays,
-                     ContigTab tab, uint32_t bshift, uint32_t n_buckets, const uint32_t *b1, const uint32_t *o2, uint32_t *cursor, Run8 *out, uint32_t *bstart)
+// b1[0 .. n_buckets]: the marks of the buckets' first runs (0xFFFFFFFF where nobody begins) -> the index of the first run at or behind
+// every bucket; b1[n_buckets] = n_runs.  tmp: n_buckets / 1024 + 2 words.
+void launch_c8_fill_starts(hipStream_t st, uint32_t *b1, uint32_t n_buckets, uint32_t n_runs, uint32_t *tmp)
 {
-    hipLaunchKernelGGL(k_c8_bstart, dim3((unsigned)(((uint64_t)n_buckets + 1 + WG - 1) / WG)), dim3(WG), 0, st, b1, o2, n_buckets, bstart);
-    if (n_sorted) {
-        const uint64_t g = ((uint64_t)n_sorted + WG - 1) / WG;
-        hipLaunchKernelGGL(k_c8_place_sorted, dim3((unsigned)(g > 131072 ? 131072 : g)), dim3(WG), 0, st, sorted, n_sorted, tab, bshift, o2, out);
-    }
-    for (int k = 0; k < n_other_arrays; ++k) {
-        if (!n_others[k]) continue;
-        const uint64_t g = ((uint64_t)n_others[k] + WG - 1) / WG;
-        hipLaunchKernelGGL(k_c8_place_other, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, others[k], n_others[k], tab, bshift, b1, o2, cursor, out);
-    }
+    const uint32_t n = n_buckets + 1;
+    const unsigned nb = grid_1k(n);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, b1 + n_buckets, n_runs);
+    hipLaunchKernelGGL(k_sfx_block_min, dim3(nb), dim3(WG), 0, st, (const uint32_t *)b1, n, tmp);
+    hipLaunchKernelGGL(k_sfx_of_mins, dim3(1), dim3(1024), 0, st, tmp, nb);
+    hipLaunchKernelGGL(k_sfx_blocks, dim3(nb), dim3(WG), 0, st, b1, n, (const uint32_t *)tmp);
 }
 
-void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, uint32_t n_tiles, pd_iv *out)
+void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1, uint32_t *cursor, Run8 *out)
 {
-    hipLaunchKernelGGL(k_c8_expand, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, cs, tile_contig, n_tiles, out);
+    if (!n) return;
+    const uint64_t g = ((uint64_t)n + WG - 1) / WG;
+    hipLaunchKernelGGL(k_c8_place_other, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, iv, n, tab, bshift, o1, cursor, out);
+}
+
+void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out)
+{
+    hipLaunchKernelGGL(k_c8_expand, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, cs, tile_contig, contig_off, n_tiles, out);
+}
+
+void launch_r8_to_iv(hipStream_t st, const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out)
+{
+    if (!n) return;
+    const uint64_t g = (n + WG - 1) / WG;
+    hipLaunchKernelGGL(k_r8_to_iv, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(WG), 0, st, r8, n, tab, out);
 }
 
 void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
@@ -2622,7 +2758,7 @@ void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, cons
     // tiles with more than 32 000 candidates: the int-window kernel exports them
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
     hipLaunchKernelGGL(k_direct_tiles_heavy, dim3(128), dim3(WG), 0, st, ps, n_tiles, tab, tile_contig, 0xFFFFFFFFu, wa,
-                       (const uint64_t *)nullptr, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de, C8Sample{nullptr, nullptr, 0, 0});
+                       (const uint64_t *)nullptr, n_long, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, de, C8Sample{});
     hipLaunchKernelGGL(k_finish_direct, dim3(1), dim3(1), 0, st, ps, n_long, fail);
 }
 

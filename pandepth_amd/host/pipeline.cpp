@@ -427,6 +427,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + spare_of(r.vend)); t += b - a; } mx = std::max(mx, t); }
         cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
     }
+    cfg.n_batches = batches.size();
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
     const size_t n_batches = batches.size();
@@ -450,8 +451,14 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         std::vector<pd_decode_unit> units;
         std::vector<int32_t> status;
         for (;;) {
+            // The buffer FIRST, then the batch number: the engine hands the batches of a compact session their places in batch order, so
+            // the lowest number any thread holds must always belong to a thread that also holds a buffer (pd_decode_cfg::n_batches).
+            void *hb = nullptr;
+            if (!eng->ck(api->decode_acquire(eng->ctx, (size_t)cfg.batch_bytes, &hb), "pd_decode_acquire")) break;
+            auto hand_back = [&](uint64_t order) { pd_decode_batch e{}; e.host_buf = hb; e.order = order; int32_t dummy = 0; api->decode_submit(eng->ctx, &e, &dummy, nullptr); };
             const size_t bi = next.fetch_add(1);
-            if (bi >= n_batches || !eng->ok() || declined.load()) break;
+            if (bi >= n_batches) { hand_back(UINT64_MAX); break; }
+            if (!eng->ok() || declined.load()) { hand_back(bi); continue; }      // (the run is being abandoned: every number is still passed on)
             const std::vector<DevRange> &rs = batches[bi];
             // bytes to read: every unit's members + spare
             std::vector<std::pair<uint64_t, uint64_t>> fr;   // file ranges
@@ -462,8 +469,6 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 if (guess && bi > 0) a = r.vbeg >> 16;       // arbitrary offset: the first member is found below
                 fr.emplace_back(a, b); total += b - a;
             }
-            void *hb = nullptr;
-            if (!eng->ck(api->decode_acquire(eng->ctx, (size_t)total + 64, &hb), "pd_decode_acquire")) break;
             uint8_t *buf = (uint8_t *)hb;
             const uint64_t t_a = now_us();
             blocks.clear(); bfile.clear(); units.clear();
@@ -534,9 +539,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             const uint64_t t_b = now_us();
             us_read += t_b - t_a;
             if (bad || units.empty()) {
-                // nothing to do for this batch: hand the buffer back with an empty submit
-                pd_decode_batch e{}; e.host_buf = hb; int32_t dummy = 0; api->decode_submit(eng->ctx, &e, &dummy, nullptr);
-                if (bad) break; else continue;
+                // nothing to do for this batch: hand the buffer back with an empty submit (the other threads go on passing their numbers)
+                hand_back(bi);
+                continue;
             }
             status.assign(units.size(), 0);
             pd_decode_batch bt{}; bt.host_buf = hb; bt.n_bytes = (size_t)pos; bt.blocks = blocks.data(); bt.n_blocks = (uint32_t)blocks.size();
@@ -544,7 +549,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             pd_decode_result res;
             const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
             us_submit += now_us() - t_b;
-            if (!ok) break;
+            if (!ok) continue;                               // (the loop's head passes the remaining numbers on)
             n_dev += res.n_reads; b_comp += pos; b_inf += uo;
             if (res.n_first) { key_first[bi] = res.first_key; key_last[bi] = res.last_key; key_have[bi] = 1; if (res.unsorted) order_broken = 1; }
             { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
@@ -558,7 +563,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 return (bfile[lo] << 16) | (u - blocks[lo].out_off);
             };
             if (guess) {
-                if (status[0] != 0) { declined = 1; break; }
+                if (status[0] != 0) { declined = 1; continue; }
                 chain_first[bi] = bi == 0 ? first_voff : voff_of(res.first_start);
                 chain_next[bi] = voff_of(res.next_start);
             } else {

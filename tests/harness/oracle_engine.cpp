@@ -40,6 +40,10 @@ struct pd_ctx {
     std::vector<Buf *> bufs;
     struct Runs { uint64_t order; std::vector<pd_iv> first, other, far; };
     std::vector<Runs> runs;
+    // a compact session (PD_DECODE_COMPACT + n_batches on a sorted file): pass 2 runs the product's COMPACT emission (8-byte runs with
+    // flat begins, bucket marks, order keys) in host emulation; the stand-in turns the runs back into 12-byte ones for the oracle and
+    // holds the emission to what the engine relies on.  orders_seen: every batch number exactly once (the feeder's side of the contract)
+    bool compact = false; std::vector<uint64_t> flat_off; std::vector<uint8_t> orders_seen; std::string compact_err;
 };
 
 
@@ -170,6 +174,11 @@ static int o_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     c->soff.clear(); c->spans.clear();
     if (cfg->span_off && cfg->spans) { c->soff.assign(cfg->span_off, cfg->span_off + n + 1); c->spans.assign(cfg->spans, cfg->spans + 2 * (size_t)cfg->span_off[n]); c->spans.push_back(0); }
     c->runs.clear();
+    c->compact = (cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->sorted && !cfg->spans;
+    c->orders_seen.assign(c->compact ? (size_t)cfg->n_batches : 0, 0);
+    c->compact_err.clear();
+    c->flat_off.assign(n + 1, 0);                                 // the engine's flat cell space: every contig's slot rounded up to a tile
+    for (size_t t = 0; t < n; ++t) c->flat_off[t + 1] = c->flat_off[t] + ((uint64_t)c->len[t] + 1 + 8191) / 8192 * 8192;
     return 0;
 }
 static int o_decode_acquire(pd_ctx *c, size_t bytes, void **out)
@@ -189,6 +198,10 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     if (!mine) { c->err = "submit: unknown buffer"; return -1; }
     struct Rel { pd_ctx *c; pd_ctx::Buf *b; ~Rel() { std::lock_guard<std::mutex> lk(c->mu); b->busy = false; } } rel{c, mine};
     if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
+    if (c->compact && bt->order < c->orders_seen.size()) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->orders_seen[(size_t)bt->order]++) c->compact_err = "a batch number was submitted twice";
+    } else if (c->compact && bt->n_units) { std::lock_guard<std::mutex> lk(c->mu); c->compact_err = "a batch with units has a number outside the session"; }
     if (!bt->n_units || !bt->n_blocks) return 0;
     const uint8_t *blob = (const uint8_t *)bt->host_buf;
     std::vector<uint8_t> inf((size_t)bt->inflated_bytes + 256, 0);
@@ -203,7 +216,8 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     cfg.buf = inf.data(); cfg.avail = bt->inflated_bytes; cfg.n_ref = (int32_t)c->len.size(); cfg.contig_len = c->len.data(); cfg.contig_on = c->on.data();
     cfg.flag_mask = c->dcfg.flag_mask; cfg.min_mapq = c->dcfg.min_mapq;
     cfg.span_off = c->soff.empty() ? nullptr : c->soff.data(); cfg.spans = c->soff.empty() ? nullptr : c->spans.data();
-    cfg.near_span = getenv("PANDEPTH_TEST_NEAR_SPAN") ? (uint32_t)atoi(getenv("PANDEPTH_TEST_NEAR_SPAN")) : 0xFFFFFFFFu;
+    cfg.near_span = getenv("PANDEPTH_TEST_NEAR_SPAN") && !c->compact ? (uint32_t)atoi(getenv("PANDEPTH_TEST_NEAR_SPAN")) : 0xFFFFFFFFu;
+    cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
     std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0(bt->n_units + 1, 0);
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         const pd_decode_unit &un = bt->units[u];
@@ -243,6 +257,42 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
         res->first_start = fs; res->next_start = E ? E : ~0ull;
     }
     pd_ctx::Runs r; r.order = bt->order; r.first.resize(nf + 1); r.other.resize(no + 1); r.far.resize(nfar + 1);
+    if (c->compact) {
+        // the product's compact emission, then back to 12-byte runs; everything the engine relies on is checked on the way
+        const uint32_t cshift = 9;
+        std::vector<pdb2::R8> r8(nf + 1);
+        std::vector<uint32_t> b1((size_t)(c->flat_off.back() >> cshift) + 2, 0xFFFFFFFFu);
+        std::vector<pdb2::SegOut> so(segs.size());
+        cfg.c8 = pdb2::C8Out{r8.data(), b1.data(), c->flat_off.data(), cshift, so.data()};
+        for (size_t j = 0; j < segs.size(); ++j) {
+            if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], nullptr, r.other.data(), r.far.data(), &so[j]);
+            else so[j] = pdb2::SegOut{pdb2::NONE, 0, 0, 0};
+        }
+        std::string bad;
+        uint64_t prev_flat = 0;
+        for (uint64_t i = 0; i < nf; ++i) {
+            // (the harness' genomes are far below 2^32 cells: the 32 bits are the flat begin)
+            const uint64_t flat = r8[i].b;
+            size_t t = std::upper_bound(c->flat_off.begin(), c->flat_off.end(), flat) - c->flat_off.begin() - 1;
+            if (t >= c->len.size()) { bad = "a compact run lies outside the genome"; break; }
+            const uint32_t beg = (uint32_t)(flat - c->flat_off[t]);
+            if (beg > c->len[t] || r8[i].len > c->len[t] - beg) { bad = "a compact run is not clamped to its contig"; break; }
+            r.first[i] = pd_iv{(int32_t)t, (int32_t)beg, (int32_t)(beg + r8[i].len)};
+            const bool head = i == 0 || (prev_flat >> cshift) != (flat >> cshift);
+            if (head && b1[flat >> cshift] != (uint32_t)i && flat >= prev_flat) { bad = "the first run of a bucket did not leave its index"; break; }
+            prev_flat = flat;
+        }
+        uint64_t first = pdb2::NONE, last = 0; uint32_t uns = 0;
+        for (const auto &x : so) { uns |= x.unsorted; if (x.first_key == pdb2::NONE) continue; if (first == pdb2::NONE) first = x.first_key; else if (x.first_key < last) uns = 1; last = x.last_key; }
+        if (bad.empty() && nf) {
+            bool really = false;
+            for (uint64_t i = 1; i < nf; ++i) if (r8[i].b < r8[i - 1].b) really = true;
+            if (really != (uns != 0)) bad = "the emission's order flag disagrees with the runs";
+            else if (!really && (first != r8[0].b || last != r8[nf - 1].b)) bad = "the emission's first / last keys disagree with the runs";
+        }
+        if (!bad.empty()) { std::lock_guard<std::mutex> lk(c->mu); c->compact_err = bad; }
+        cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
+    } else
     for (size_t j = 0; j < segs.size(); ++j)
         if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data());
     r.first.resize(nf); r.other.resize(no); r.far.resize(nfar);
@@ -257,6 +307,11 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
 }
 static int o_decode_end(pd_ctx *c)
 {
+    if (c->compact) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (uint8_t seen : c->orders_seen) if (seen != 1 && c->compact_err.empty()) c->compact_err = "a batch number of the session was never submitted";
+        if (!c->compact_err.empty()) { c->err = "compact decode session: " + c->compact_err; return -4; }
+    }
     std::vector<pd_ctx::Runs> rs;
     { std::lock_guard<std::mutex> lk(c->mu); rs.swap(c->runs); }
     std::sort(rs.begin(), rs.end(), [](const pd_ctx::Runs &a, const pd_ctx::Runs &b) { return a.order < b.order; });

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(capi.EXPORTS) == names
-    assert L.pd_abi_version() == 2
+    assert L.pd_abi_version() == 3
 
 
 def test_no_cpu_fallback():

@@ -86,3 +86,37 @@ def test_pandepth_cli_list_over_two_contexts(case, tmp_path):
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()
         assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix
+
+
+def _run_cli(args, env_extra, cwd):
+    p = subprocess.run([CLI] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, PANDEPTH_TIMING="1", **env_extra))
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    return p.stderr.decode()
+
+
+@pytest.mark.parametrize("kind", ["payload", "dense"])
+def test_compact_session_over_many_batches(kind, tmp_path):
+    """Whole-chromosome mode on a generated sorted BAM cut into dozens of small batches (six feeders): every batch's pass 2 writes its
+    runs straight to their final places in the compact sample, the places being handed out in batch order (pd_decode_cfg::n_batches).
+    "dense" is a file with ~7 bytes of BGZF per record (no SEQ / QUAL): far more runs than the arena was sized for from the compressed
+    bytes, so the arena grows while batches are in flight.  Same bytes as the host readers' run, and the timing line names the session."""
+    import sys
+    sys.path.insert(0, ROOT)
+    bam = str(tmp_path / "s.bam")
+    if kind == "payload":
+        gen = os.path.join(ROOT, "tools", "bamgen")
+        assert os.access(gen, os.X_OK), "tools/bamgen not built (__graft_entry__.build)"
+        subprocess.run([gen, "-o", bam, "-n", "3000000", "-t", "16"], check=True, stderr=subprocess.PIPE, timeout=600)
+    else:
+        from tools import synth
+        names, lens = synth.genome_c2(scale=0.004)
+        rec = synth.gen_records_numpy(lens, 4000000, seed=5)
+        synth.write_bam(bam, names, lens, rec, procs=8, payload=False)
+    err_d = _run_cli(["-i", bam, "-o", str(tmp_path / "dev"), "-t", "8"], {"PANDEPTH_DD_BATCH_MB": "1" if kind == "dense" else "4"}, str(tmp_path))
+    assert "runs (compact session)" in err_d, err_d[-1500:]
+    _run_cli(["-i", bam, "-o", str(tmp_path / "host"), "-t", "8"], {"PANDEPTH_DEVICE_DECODE": "0"}, str(tmp_path))
+    assert (tmp_path / "dev.chr.stat.gz").read_bytes() == (tmp_path / "host.chr.stat.gz").read_bytes()
+    # the same file through a mode that needs the cells (no compact session): still the same table as the host readers give
+    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "devw"), "-t", "8"], {"PANDEPTH_DD_BATCH_MB": "4"}, str(tmp_path))
+    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "hostw"), "-t", "8"], {"PANDEPTH_DEVICE_DECODE": "0"}, str(tmp_path))
+    assert (tmp_path / "devw.win.stat.gz").read_bytes() == (tmp_path / "hostw.win.stat.gz").read_bytes()

@@ -48,7 +48,7 @@ with pda.Engine(LENS, device=rank) as e:
         if k: res.append(c.finish((k - 1) % 2, 10000, 1, 18, 0))
     res.append(c.finish((K - 1) % 2, 10000, 1, 18, 0))
     # the deferred form: sorted batches stay pending, pd_export_i4 packs the tile windows straight from LDS
-    e.reset(); e.set_param("direct_windows", 1)
+    e.reset(); e.keep_deferred(True)
     iv = sample(rank, 7); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
     e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
     res.append(c.run(8192, 2, 18, 0))

@@ -64,7 +64,7 @@ def rank_main(rank):
                     if k: res.append(c.finish((k - 1) % 2, 10000, 1, 18, world - 1))
                 res.append(c.finish((K - 1) % 2, 10000, 1, 18, world - 1))
                 # the deferred form: sorted batches stay pending, pd_export_i4 packs the tile windows straight from LDS
-                e.reset(); e.set_param("direct_windows", 1)
+                e.reset(); e.keep_deferred(True)
                 iv = sample(rank, 7); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
                 e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
                 res.append(c.run(8192, 2, 18, 0))
@@ -77,7 +77,7 @@ def rank_main(rank):
                 res.append(c.interval_sum(REGS, 1, 18, world - 1))
                 res.append(c.interval_sum(REGS[:7], 3, 0, 0))
                 # ... and from a deferred (sorted, pending) sample: the export comes straight from the tile windows
-                e.reset(); e.set_param("direct_windows", 1)
+                e.reset(); e.keep_deferred(True)
                 iv = sample(rank, 5); iv = iv[np.lexsort((iv[:, 1], iv[:, 0]))]
                 e.push_intervals(iv, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
                 res.append(c.window_sum(100, 1, 18, 0))
@@ -85,7 +85,7 @@ def rank_main(rank):
                 # more cells outside the 4-bit range than the exception block holds (2^18): ten reads start on every third base
                 # of 450 000 bases on rank 0 (+10 at 150 000 cells, -10 at 150 000 others: the ends fall on another residue, nothing
                 # cancels) -> every rank gets PD_ERANGE, no sample is consumed, the contexts still add up
-                e.set_param("direct_windows", 1)
+                e.keep_deferred(True)
                 if rank == 0:
                     iv = OVER
                 else:

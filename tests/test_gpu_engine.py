@@ -61,8 +61,25 @@ def sort_iv(iv):
     return iv[k]
 
 
+def test_guarded_allocations_see_a_one_byte_overrun():
+    """The suite runs with PANDEPTH_GUARD=1 (tests/conftest.py): canaries in front of and behind every device buffer of the engine, checked
+    after every gpu test.  This is the proof that the check works: the library writes ONE byte behind, then one byte in front of, a guarded
+    buffer and must find both."""
+    import os
+    L = pda.load()
+    if os.environ.get("PANDEPTH_GUARD", "0") in ("", "0"):
+        assert L.pd_guard_selftest() == 1
+        pytest.skip("the guard is switched off")
+    assert L.pd_guard_selftest() == 0
+    with pda.Engine(LENS, device=0) as e:               # ... and a context's buffers (one slab, canaries inside it) are clean after ordinary use
+        e.push_intervals(rand_intervals(np.random.default_rng(3), LENS, 5000), pda.PD_PUSH_DEFAULT)
+        e.scan_reduce_windows(100, 1, 0)
+        e.reset()
+    assert L.pd_guard_check(None, 0) == 0
+
+
 def test_abi_version():
-    assert pda.load().pd_abi_version() == 2
+    assert pda.load().pd_abi_version() == 3
 
 
 @pytest.mark.parametrize("wrap", [0, 18])
@@ -549,7 +566,7 @@ def test_direct_windows_equal_oracle(w, min_dep, wrap):
     d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
     cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         for rep in range(2):
             e.reset()
             e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
@@ -564,7 +581,7 @@ def test_direct_windows_equal_oracle(w, min_dep, wrap):
             for t in (0, 1, len(LENS) - 1):
                 assert np.array_equal(e.read_depth(t, 0, int(LENS[t])), d[off[t]:off[t] + LENS[t]]), t
         # the same calls without the parameter take the materialising path and agree
-        e.set_param("direct_windows", 0)
+        e.keep_deferred(False)
         e.reset()
         e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
@@ -588,7 +605,7 @@ def test_direct_windows_device_batches_and_wrap():
     tf, to = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     torch.cuda.synchronize()
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         e.push_intervals_device(tf.data_ptr(), tf.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         e.push_intervals_device(to.data_ptr(), to.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         woff, cover, tot = e.scan_reduce_windows(10000, 1, 18)
@@ -605,7 +622,7 @@ def test_direct_windows_fall_back():
     first_l = sort_iv(np.concatenate([first, long_runs]))
     d, off = oracle_depth(LENS, np.concatenate([first_l, other]), False)
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         e.push_intervals(first_l, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         e.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(800))
         woff, cover, tot = e.scan_reduce_windows(10000, 1, 0)
@@ -652,7 +669,7 @@ def test_direct_export_equals_export_of_the_arrays():
 
     def export(direct):
         e = pda.Engine(LENS)
-        e.set_param("direct_windows", 1 if direct else 0)
+        e.keep_deferred(bool(direct))
         more = pda.PD_PUSH_MORE if direct else 0
         e.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         e.push_intervals(other, pda.PD_PUSH_SORTED | more | pda.PD_PUSH_DISORDER(800))
@@ -855,7 +872,7 @@ def test_direct_wide_forms_agree_with_oracle_on_hard_tiles(w, min_dep, wrap):
     d, off = oracle_depth(LENS, np.concatenate([first, other]), wrap == 18)
     cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         for form in (0, 504, 3504, 3404):
             e.set_param("direct_un", form)
             e.reset()
@@ -898,7 +915,7 @@ def test_compact_sample_agrees_with_oracle_on_hard_tiles(w, min_dep, wrap):
     cov_ref, tot_ref = windows_ref(LENS, d, off, w, min_dep)
     ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         runs = e.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
         for un in (0, 502, 504, 508, 602, 604, 702, 704, 802, 804, 801):
             e.set_param("direct_un", un)
@@ -946,7 +963,7 @@ def test_compact_sample_takes_every_other_path_expanded():
     both = np.concatenate([first, other])
     ft, ot = torch.from_numpy(first).to(dev), torch.from_numpy(other).to(dev)
     with pda.Engine(LENS) as e:
-        e.set_param("direct_windows", 1)
+        e.keep_deferred(True)
         runs = e.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
         for w, md, wrap in ((100, 1, 0), (1000, 2, 18), (64, 1, 0), (8191, 1, 0)):
             d, off = oracle_depth(LENS, both, wrap == 18)
@@ -1013,7 +1030,7 @@ def test_compact_export_equals_export_of_the_arrays():
         ea.push_intervals(first, pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
         ea.push_intervals(other, pda.PD_PUSH_SORTED | pda.PD_PUSH_DISORDER(800))
         img_a, exc_a = export(ea)
-        ed.set_param("direct_windows", 1)
+        ed.keep_deferred(True)
         runs = ed.runs_create(ft.data_ptr(), first.shape[0], ot.data_ptr(), other.shape[0])
         ed.push_runs(runs, pda.PD_PUSH_MORE)
         img_d, exc_d = export(ed)

@@ -122,10 +122,10 @@ def test_fullsize_direct_path(sample):
     s = sample
     eng = s["eng"]
     load(s, flags_sorted=False)
-    eng.set_param("direct_windows", 0)
+    eng.keep_deferred(False)
     _, cov_a, tot_a = eng.scan_reduce_windows(BIN, 1, 0)
     w1off, c1_a, t1_a = eng.scan_reduce_windows(1000, 1, 0)
-    eng.set_param("direct_windows", 1)
+    eng.keep_deferred(True)
     try:
         for w, wrap, ec, et in ((BIN, 0, cov_a, tot_a), (BIN, 18, cov_a, tot_a), (1000, 0, c1_a, t1_a)):
             load3(s)
@@ -136,7 +136,7 @@ def test_fullsize_direct_path(sample):
             assert int(tot.sum()) == s["mass"]
             if not (np.array_equal(cov, ec) and np.array_equal(tot, et)):
                 # which side is off?  a third computation (sorted pushes, arrays path) on the same engine
-                eng.set_param("direct_windows", 0)
+                eng.keep_deferred(False)
                 load(s)
                 _, c3, t3 = eng.scan_reduce_windows(w, 1, wrap)
                 bad = np.nonzero(tot != et)[0]
@@ -144,7 +144,54 @@ def test_fullsize_direct_path(sample):
                                      "atomic-path mass %d vs %d" % (w, wrap, bad.size, bad[:6].tolist(), tot[bad[:6]].tolist(), et[bad[:6]].tolist(), t3[bad[:6]].tolist(),
                                                                     bool(np.array_equal(tot, t3)), bool(np.array_equal(et, t3)), int(et.sum()), s["mass"]))
     finally:
-        eng.set_param("direct_windows", 0)
+        eng.keep_deferred(False)
+
+
+def test_fullsize_compact_path(sample):
+    """What the executable runs in whole-chromosome mode, at full size: the sample as ONE compact sample (pd_runs_create: 8-byte runs, the
+    sorted stream in file order + the later runs bucketed; the GPU decoder leaves the same object) -> pd_push_runs -> k_direct_c8.
+    Mass conservation; the same tables as the atomic path for 10 Mb bins with and without the 18-bit wrap; the call READS the sample
+    (asking twice gives the same); the 4-bit image straight from the compact sample equals the image of the arrays."""
+    s = sample
+    eng, pda, torch = s["eng"], s["pda"], s["torch"]
+    load(s, flags_sorted=False)
+    eng.keep_deferred(False)
+    _, cov_a, tot_a = eng.scan_reduce_windows(BIN, 1, 0)
+    _, cov_a18, tot_a18 = eng.scan_reduce_windows(BIN, 1, 18)
+    n_cells, n_sums = eng.device_layout()
+    img_a = torch.empty(n_cells // 2, dtype=torch.uint8, device="cuda")
+    exc = torch.zeros(1 << 18, 2, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    eng.export_i4(img_a.data_ptr(), exc.data_ptr(), 1 << 18, cnt.data_ptr())
+    torch.cuda.synchronize()
+    n_exc_a = int(cnt[0].item())
+    exc_a = exc[:n_exc_a].clone()
+    eng.reset()
+    runs = eng.runs_create(s["first"].data_ptr(), int(s["first"].shape[0]), s["other"].data_ptr(), int(s["other"].shape[0]))
+    eng.keep_deferred(True)
+    try:
+        for wrap, ec, et in ((0, cov_a, tot_a), (18, cov_a18, tot_a18)):
+            eng.reset()
+            eng.push_runs(runs, pda.PD_PUSH_MORE)
+            _, cov, tot = eng.scan_reduce_windows(BIN, 1, wrap)
+            _, cov2, tot2 = eng.scan_reduce_windows(BIN, 1, wrap)
+            assert np.array_equal(cov, cov2) and np.array_equal(tot, tot2)
+            assert int(tot.sum()) == s["mass"]
+            assert np.array_equal(cov, ec) and np.array_equal(tot, et), "compact path differs from the atomic path (wrap %d)" % wrap
+        eng.reset()
+        eng.push_runs(runs, pda.PD_PUSH_MORE)
+        img_c = torch.empty(n_cells // 2, dtype=torch.uint8, device="cuda")
+        exc.zero_(); cnt.zero_()
+        eng.export_i4(img_c.data_ptr(), exc.data_ptr(), 1 << 18, cnt.data_ptr())
+        torch.cuda.synchronize()
+        assert int(cnt[0].item()) == n_exc_a
+        assert bool(torch.equal(img_c, img_a))
+        ka = exc_a[torch.argsort(exc_a[:, 0])]; kc = exc[:n_exc_a][torch.argsort(exc[:n_exc_a, 0])]
+        assert bool(torch.equal(ka, kc))
+    finally:
+        eng.keep_deferred(False)
+        eng.reset()
+        eng.runs_destroy(runs)
 
 
 def test_fullsize_gff_config(sample):

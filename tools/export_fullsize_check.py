@@ -12,7 +12,7 @@ for R in (int(1e8), int(1e9)):
     n_cells, n_sums = eng.device_layout()
     img = torch.zeros(n_cells // 2, dtype=torch.uint8, device=dev); exc = torch.zeros((1 << 18, 2), dtype=torch.int64, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    eng.set_param("direct_windows", 1)
+    eng.keep_deferred(True)
     eng.reset()
     eng.push_intervals_device(first.data_ptr(), first.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
     eng.push_intervals_device(other.data_ptr(), other.shape[0], pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE | pda.PD_PUSH_DISORDER(synth.MAX_SPAN))

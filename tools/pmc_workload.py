@@ -27,7 +27,7 @@ for it in range(2):
     eng.reduce_windows(100, 1)      # narrow windows off the depth (k_sweep<false, true, true>: LDS accumulators + k_window_edges)
     eng.synchronize()
 # the direct window path (k_direct_tiles): both streams deferred, difference arrays never materialised
-eng.set_param("direct_windows", 1)
+eng.keep_deferred(True)
 for it in range(2):
     eng.reset()
     eng.push_intervals_device(first.data_ptr(), int(first.shape[0]), pda.PD_PUSH_SORTED | pda.PD_PUSH_MORE)
@@ -64,6 +64,6 @@ for it in range(2):
     eng.deflate_parse(rows, chunks)
 eng.reset()
 eng.runs_destroy(runs8)
-eng.set_param("direct_windows", 0)
+eng.keep_deferred(False)
 eng.reset()
 print("cells", eng.device_buffer()[1], "runs", int(first.shape[0]) + int(other.shape[0]), "lz text", len(rows), "chunks", len(chunks))

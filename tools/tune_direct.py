@@ -13,7 +13,7 @@ names, lens = synth.genome_c2()
 eng = pda.Engine(lens.astype(np.uint32), device=0)
 first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
 torch.cuda.synchronize()
-eng.set_param("direct_windows", 1)
+eng.keep_deferred(True)
 out = {}
 ref = None
 for grid in (256,):

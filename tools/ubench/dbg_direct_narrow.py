@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 W = 1000
 def load(direct, streams):
     eng.reset()
-    eng.set_param("direct_windows", 1 if direct else 0)
+    eng.keep_deferred(bool(direct))
     for k, (t, dis) in enumerate(streams):
         last = k == len(streams) - 1
         eng.push_intervals_device(t.data_ptr(), int(t.shape[0]), pda.PD_PUSH_SORTED | (pda.PD_PUSH_DISORDER(dis) if dis else 0) | (pda.PD_PUSH_MORE if (direct or not last) else 0))

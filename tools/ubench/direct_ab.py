@@ -13,7 +13,7 @@ eng = pda.Engine(lens.astype(np.uint32), device=0)
 R = int(float(os.environ.get("R", "1e9")))
 first, other = synth.gen_runs_torch(lens, R, dev, seed=42)
 torch.cuda.synchronize()
-eng.set_param("direct_windows", 1)
+eng.keep_deferred(True)
 runs8 = eng.runs_create(first.data_ptr(), int(first.shape[0]), other.data_ptr(), int(other.shape[0]))   # the sample in the compact form (variants "c<un>")
 compact = False
 def scatter():

@@ -14,7 +14,7 @@ names, lens = synth.genome_c2()
 eng = pda.Engine(lens.astype(np.uint32), device=0)
 first, other = synth.gen_runs_torch(lens, int(1e9), dev, seed=42)
 torch.cuda.synchronize()
-eng.set_param("direct_windows", 1)
+eng.keep_deferred(True)
 L = capi.load()
 L.pd_x_wide3_ticks.restype = ctypes.c_int
 L.pd_x_wide3_ticks.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
