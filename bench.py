@@ -258,6 +258,8 @@ def e2e_site_windows_fullsize(td, bam, cli, threads, records):
     except (OSError, ValueError):
         ref = None
     if ref and int(ref.get("records", 0)) == int(records) and "w100a" in ref:
+        # the same input?  (size of the file + hash of its index: the index names every record's virtual offset)
+        out["same_input_as_reference_run"] = os.path.getsize(bam) == ref.get("bam_bytes") and _sha256(bam + ".bai") == ref.get("bai_sha256")
         same = {k: got[k] == ref["w100a"]["sha256"].get(k) for k in got}
         out["byte_identical_files"] = same
         out["byte_identical"] = all(same.values())
@@ -353,7 +355,7 @@ def e2e_leg(records, site_records, fullsize_site=False):
         w_dev, err = _best_wall([cli, "-i", bam, "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
         ph, dec = parse_timing(err)
         w_host = _best_wall([cli, "-i", bam, "-o", os.path.join(td, "host"), "-t", str(threads)], 1,
-                            env=dict(os.environ, PANDEPTH_DEVICE_DECODE="0"))
+                            env=dict(os.environ, PANDEPTH_TUNE="device_decode=0"))
         e2e = {
             "records": int(records), "records_asked": asked, "bam_bytes": size, "bam_bytes_per_record": round(size / records, 1),
             "bam": "tools/bamgen: coordinate-sorted, 150-base reads with names, SEQ from a synthetic reference, binned QUAL, "
@@ -364,7 +366,7 @@ def e2e_leg(records, site_records, fullsize_site=False):
                          "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) -> one compact sample (pd_runs) -> k_direct_c8; host only reads the file",
                          "phases_s": ph, "device_decode": dec},
             "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
-                                     "path": "PANDEPTH_DEVICE_DECODE=0: libdeflate on the host threads + pd_push_intervals"},
+                                     "path": "-X device_decode=0: libdeflate on the host threads + pd_push_intervals"},
             "cpu_quota": quota, "host_cpus": os.cpu_count(),
         }
         # what bounds the end-to-end run: the compressed bytes cross PCIe once (host page cache -> pinned buffer -> HBM), the

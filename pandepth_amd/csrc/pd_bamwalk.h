@@ -35,19 +35,20 @@ enum { WF_BAD = 1, WF_MORE = 2, WF_HOST = 4 };     // corrupt record / record ru
 static const uint64_t NONE = ~0ull, STOPPED = 1ull << 62;
 
 // Compact emission (whole-contig modes of a coordinate-sorted file, PD_DECODE_COMPACT): pass 2 writes every read's first run straight to
-// its FINAL place in the sample's sorted stream as 8 bytes — the low 32 bits of its flat begin (cell index in the engine's buffer, the
+// the batch's segment of the sample's sorted stream as 8 bytes — the low 32 bits of its flat begin (cell index in the engine's buffer, the
 // begin clamped to [0, len] as PD:449-452's cells are) and its clamped length —, the first run a lane writes and every run that opens
-// a new 512-cell bucket leave their index in b1[bucket] (an atomic minimum: the buckets' first runs, which is all the direct kernels
-// need to find a tile's runs), and the order of the stream is checked on the way: inside a lane, across the lanes of a segment, and
-// (by the host, from SegOut) across segments and batches.
+// a new 512-cell bucket leave (batch, index) in marks[bucket] (an atomic minimum: the buckets' first runs in file order, which is all the
+// direct kernels need to find a tile's runs), and the order of the stream is checked on the way: inside a lane, across the lanes of a
+// segment, and (by the host, from SegOut) across segments and batches.
 struct R8 { uint32_t b, len; };           // = pdk::Run8
 struct SegOut { uint64_t first_key, last_key; uint32_t unsorted, n_long; };   // keys: flat begins (order like (tid, begin)); first_key = NONE: no first run
 struct C8Out {
-    R8 *r8 = nullptr;                     // the sorted stream (global index = Seg::base_first + ...); null: 12-byte runs as before
-    uint32_t *b1 = nullptr;               // bucket -> index of its first run (pre-set to 0xFFFFFFFF)
+    R8 *r8 = nullptr;                     // the batch's first runs (index = Seg::base_first + ...); null: 12-byte runs as before
+    unsigned long long *marks = nullptr;  // bucket -> min (batch << 32 | index in the batch) of a run that begins there (pre-set to all ones)
     const uint64_t *contig_off = nullptr; // first cell of every contig's slot
     uint32_t cshift = 0;                  // log2(cells per bucket)
     SegOut *seg_out = nullptr;            // one per segment of the batch
+    uint32_t batch = 0;                   // the batch's number in file order
 };
 
 struct Cfg {                              // wave-uniform
@@ -60,9 +61,9 @@ struct Cfg {                              // wave-uniform
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-PW_FN void min_u32(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+PW_FN void min_u64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 #else
-PW_FN void min_u32(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
+PW_FN void min_u64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 #endif
 
 struct Seg {
@@ -187,7 +188,8 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
                             const uint32_t len = ce > cb ? ce - cb : 0u;
                             const uint64_t flat = c.c8.contig_off[x.tid] + cb, G = of + w.n_first;
                             c.c8.r8[G] = R8{(uint32_t)flat, len};
-                            if (w.key_first == NONE || (w.key_last >> c.c8.cshift) != (flat >> c.c8.cshift)) min_u32(&c.c8.b1[flat >> c.c8.cshift], (uint32_t)G);
+                            if (w.key_first == NONE || (w.key_last >> c.c8.cshift) != (flat >> c.c8.cshift))
+                                min_u64(&c.c8.marks[flat >> c.c8.cshift], ((unsigned long long)c.c8.batch << 32) | (uint32_t)G);
                             if (w.key_first == NONE) w.key_first = flat; else if (flat < w.key_last) w.unsorted = 1;
                             w.key_last = flat;
                             if (len > (1u << c.c8.cshift)) ++w.n_long;

@@ -39,20 +39,25 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
 // (members of a BAM are alike, so a static split balances); Huffman tables in LDS (9 KiB per wave), match tokens in a
 // per-workgroup slice of global scratch.
 #ifndef PD_INFLATE_MIN_WAVES
-#define PD_INFLATE_MIN_WAVES 1            /* waves per SIMD the register allocation must leave room for (tuning builds) */
+#define PD_INFLATE_MIN_WAVES 6            /* waves per SIMD the register allocation leaves room for (80 VGPRs; at 8 — 64 VGPRs — the kernel spills and loses a quarter) */
 #endif
 __global__ __launch_bounds__(64, PD_INFLATE_MIN_WAVES) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
-                                                     pdw::Token *tok_scratch, int check_crc)
+                                                                           pdw::Token *tok_scratch, int check_crc, uint32_t *next)
 {
     __shared__ pdw::Tables T;
     pdw::Token *tok = tok_scratch + (size_t)blockIdx.x * PD_WAVE_TOKENS;
-    for (uint32_t i = blockIdx.x; i < n_blk; i += gridDim.x) {
+    // members are handed out one at a time from a counter (`next`, zeroed by the launcher): members differ in cost, and a launch may hold
+    // several times more of them than there are waves — a static split would leave most waves idle behind the unlucky ones
+    for (uint32_t i = blockIdx.x;;) {
+        if (next) { uint32_t t = 0; if (threadIdx.x == 0) t = atomicAdd(next, 1u); i = (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
+        if (i >= n_blk) break;
         const BlkDesc d = blk[i];
         int rc = 0;
         // inflate + the CRC-32 of the output against the member's trailer (an empty member still has one: 0)
         rc = pdw::inflate_member<pdw::DevWave>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, T, tok, nullptr, check_crc != 0);
         if (threadIdx.x == 0) status[i] = rc;
         __syncthreads();
+        if (!next) i += gridDim.x;
     }
 }
 
@@ -106,11 +111,12 @@ void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t 
 
 // the wave-cooperative decoder: n_wg persistent one-wave workgroups; `scratch` = bgzf_wave_scratch_bytes(n_wg) bytes
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg, bool check_crc)
+                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next)
 {
     if (!n_blk) return;
     if (n_wg > n_blk) n_wg = n_blk;
-    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch, check_crc ? 1 : 0);
+    if (next) (void)hipMemsetAsync(next, 0, 4, st);
+    hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch, check_crc ? 1 : 0, next);
 }
 size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token) + 64; }
 
@@ -176,7 +182,7 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
     if (variant >= 2) {
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, device) != hipSuccess) return PD_ENODEV;
-        const unsigned per_cu = (variant >> 4) ? (unsigned)(variant >> 4) : 16u;
+        const unsigned per_cu = (variant >> 4) ? (unsigned)(variant >> 4) : 20u;
         n_wg = (unsigned)pr.multiProcessorCount * per_cu;
     }
     if (hipMalloc(&d_in, n_bytes + 16) != hipSuccess || hipMalloc(&d_out, uo + 16) != hipSuccess ||
@@ -190,7 +196,7 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
         for (int r = 0; r < reps + 1; ++r) {
             if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
             const dim3 g((nb + 63) / 64), b(64);
-            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg, !no_crc);
+            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg, !no_crc, (uint32_t *)(d_st + nb));
             else if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
             else hipLaunchKernelGGL(k_inflate_blocks<false>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
         }

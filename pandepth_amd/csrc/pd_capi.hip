@@ -226,6 +226,7 @@ struct pd_ctx {
     bool sums_stale = false;                                      // the tile sums hold what a direct export wrote while the sample is still deferred
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
     bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
+    unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
     uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
     int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
     bool all_valid_host = false;
@@ -236,11 +237,12 @@ struct pd_ctx {
         hipStream_t st = nullptr;
         hipEvent_t ev[6] = {};
         uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
+        uint8_t *h_small = nullptr; size_t h_small_cap = 0;       // pinned: the batch's small tables on their way to and from the device
         void *d[8] = {}; size_t cap[8] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list, per-segment keys (compact emission)
         void *d_tok = nullptr;                                    // wave scratch (match tokens)
     };
     struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; uint32_t unsorted; uint64_t first_key, last_key; uint64_t n_long = 0; };
-    static constexpr int N_DEC = 6;
+    static constexpr int N_DEC = 12;
     uint8_t *arena = nullptr; size_t arena_cap = 0; std::atomic<size_t> arena_used{0};   // the batches' run arrays (bump allocated)
     DecSlot dec[N_DEC];
     std::mutex dec_mu; std::condition_variable dec_cv;
@@ -251,16 +253,24 @@ struct pd_ctx {
     pd_iv *run_first = nullptr, *run_other = nullptr, *run_far = nullptr;   // the concatenated sample (owned until the next reset)
     pd_runs *dec_runs = nullptr;                                  // ... or the whole of it as a compact sample (PD_DECODE_COMPACT)
     // A decode session that emits the compact form directly (PD_DECODE_COMPACT + pd_decode_cfg::n_batches): every batch's pass 2 writes its
-    // first runs to their FINAL places in the sample's sorted stream, 8 bytes each, and its later runs behind those of the batches before it.
-    // The places are handed out in batch order (`turn`), so nothing is concatenated, converted or sorted at the end except the later runs.
+    // first runs as 8-byte compact runs (and marks the buckets' first runs, keyed by (batch, index in the batch)); as soon as every
+    // earlier batch has been counted, a batch's runs are copied — on a stream of their own, behind the decode — to their FINAL places in
+    // the sample's sorted stream, and its later runs behind those of the batches before it.  No feeder ever waits for another one, and at
+    // the end nothing is concatenated or converted: only the marks become indices and the later runs are sorted by bucket.
     struct C8Dec {
         bool on = false;
         uint8_t *base = nullptr; size_t bytes = 0;               // ONE allocation: [Run8 x (cap_s + cap_o) | pd_iv x cap_o]
         size_t cap_s = 0, cap_o = 0;
         uint32_t *b1 = nullptr; size_t nbw = 0;                  // bucket starts: b1 | o1, nbw words each
+        unsigned long long *marks = nullptr;                     // per bucket: min (batch << 32 | index in the batch) of a run that begins there
         uint32_t bshift = 4;
         uint64_t n_s = 0, n_o = 0, turn = 0, n_batches = 0;
-        std::mutex mu; std::condition_variable cv;
+        struct Batch { bool counted = false; uint64_t nf = 0, no = 0; Run8 *seg_s = nullptr; pd_iv *seg_o = nullptr; hipEvent_t ev = nullptr; };
+        std::vector<Batch> batch;                                // by order
+        std::vector<uint32_t> base_s;                            // first place of every batch's first runs in the sorted stream
+        hipStream_t compose = nullptr;
+        std::string err;                                         // what went wrong while runs were being placed (reported by pd_decode_end)
+        std::mutex mu;
         Run8 *r8() const { return (Run8 *)base; }
         pd_iv *oth() const { return (pd_iv *)(base + (cap_s + cap_o) * sizeof(Run8)); }
     } c8;
@@ -706,6 +716,7 @@ int pd_destroy(pd_ctx *c)
     for (auto &sl : c->dec) {
         if (sl.st) (void)hipStreamSynchronize(sl.st);
         if (sl.h_blob) (void)hipHostFree(sl.h_blob);
+        if (sl.h_small) (void)hipHostFree(sl.h_small);
         for (void *p : sl.d) if (p) (void)hipFree(p);
         if (sl.d_tok) (void)hipFree(sl.d_tok);
         for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
@@ -779,6 +790,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
+    if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 20) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 20]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
@@ -1298,13 +1310,22 @@ static_assert(sizeof(pdb2::R8) == sizeof(Run8), "the decoder's 8-byte run is the
 void c8_drop(pd_ctx *c)
 {
     pd_ctx::C8Dec &x = c->c8;
+    if (x.compose) (void)hipStreamSynchronize(x.compose);
     if (x.base) { (void)hipFree(x.base); x.base = nullptr; }
     if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
+    if (x.marks) { (void)hipFree(x.marks); x.marks = nullptr; }
+    const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+    for (auto &b : x.batch) {
+        if (b.seg_s && !ina(b.seg_s)) (void)hipFree(b.seg_s);
+        if (b.seg_o && !ina(b.seg_o)) (void)hipFree(b.seg_o);
+        if (b.ev) (void)hipEventDestroy(b.ev);
+    }
+    x.batch.clear(); x.base_s.clear();
     x.on = false; x.bytes = 0; x.cap_s = x.cap_o = 0; x.n_s = x.n_o = x.turn = x.n_batches = 0;
 }
 
-// room for n_s first runs and n_o later runs (the caller holds c8.mu and the turn: nobody else is placing runs; batches placed
-// earlier may still be writing theirs — the device is waited for before anything moves).  Returns PD_OK / PD_ENOMEM / PD_EHIP, no message.
+// room for n_s first runs and n_o later runs in the sample's final arrays (the caller holds c8.mu; copies placed earlier may still be
+// running — the device is waited for before anything moves).  Returns PD_OK / PD_ENOMEM / PD_EHIP, no message.
 int c8_reserve(pd_ctx *c, uint64_t n_s, uint64_t n_o)
 {
     pd_ctx::C8Dec &x = c->c8;
@@ -1325,19 +1346,35 @@ int c8_reserve(pd_ctx *c, uint64_t n_s, uint64_t n_o)
     return PD_OK;
 }
 
-// every batch with an order below n_batches passes the turn exactly once, whatever way its submit call ends
-struct C8Turn {
-    pd_ctx *c; uint64_t order; bool armed;
-    ~C8Turn()
-    {
-        if (!armed) return;
-        pd_ctx::C8Dec &x = c->c8;
-        std::unique_lock<std::mutex> lk(x.mu);
-        x.cv.wait_for(lk, std::chrono::seconds(300), [&] { return x.turn >= order; });
-        if (x.turn == order) x.turn = order + 1;
-        lk.unlock();
-        x.cv.notify_all();
+// A batch has been counted (its runs are being written to its own segment, `ev` follows that kernel): it and every batch behind it whose
+// predecessors are all counted now get their final places, and the copies there are queued on the compose stream.  Nobody waits.
+void c8_counted(pd_ctx *c, uint64_t order, uint64_t nf, uint64_t no, Run8 *seg_s, pd_iv *seg_o, hipEvent_t ev)
+{
+    pd_ctx::C8Dec &x = c->c8;
+    std::lock_guard<std::mutex> lk(x.mu);
+    if (order >= x.batch.size() || x.batch[(size_t)order].counted) { if (x.err.empty()) x.err = "a batch number was submitted twice or lies outside the session"; return; }
+    pd_ctx::C8Dec::Batch &me = x.batch[(size_t)order];
+    me.counted = true; me.nf = nf; me.no = no; me.seg_s = seg_s; me.seg_o = seg_o; me.ev = ev;
+    while (x.turn < x.n_batches && x.batch[(size_t)x.turn].counted) {
+        pd_ctx::C8Dec::Batch &b = x.batch[(size_t)x.turn];
+        x.base_s[(size_t)x.turn] = (uint32_t)x.n_s;
+        if (b.nf + b.no) {
+            hipError_t e = hipSuccess;
+            if (c8_reserve(c, x.n_s + b.nf, x.n_o + b.no) != PD_OK) e = hipErrorOutOfMemory;
+            if (e == hipSuccess && b.ev) e = hipStreamWaitEvent(x.compose, b.ev, 0);
+            if (e == hipSuccess && b.nf) e = hipMemcpyAsync(x.r8() + x.n_s, b.seg_s, (size_t)b.nf * sizeof(Run8), hipMemcpyDeviceToDevice, x.compose);
+            if (e == hipSuccess && b.no) e = hipMemcpyAsync(x.oth() + x.n_o, b.seg_o, (size_t)b.no * sizeof(pd_iv), hipMemcpyDeviceToDevice, x.compose);
+            if (e != hipSuccess && x.err.empty()) x.err = std::string("placing a batch's runs: ") + hipGetErrorString(e);
+            x.n_s += b.nf; x.n_o += b.no;
+        }
+        ++x.turn;
     }
+}
+
+// every batch with an order below n_batches is counted exactly once, whatever way its submit call ends
+struct C8Mark {
+    pd_ctx *c; uint64_t order; bool armed;
+    ~C8Mark() { if (armed) c8_counted(c, order, 0, 0, nullptr, nullptr, nullptr); }
 };
 
 } // namespace
@@ -1371,24 +1408,31 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     {
         std::lock_guard<std::mutex> l8(c->c8.mu);
         pd_ctx::C8Dec &x = c->c8;
-        x.on = false; x.n_s = x.n_o = x.turn = 0; x.n_batches = 0;
+        if (x.on || !x.batch.empty()) { (void)hipDeviceSynchronize(); c8_drop(c); }     // (a session that was never ended)
+        x.on = false; x.n_s = x.n_o = x.turn = 0; x.n_batches = 0; x.err.clear();
         const uint64_t nb64 = (uint64_t)c->n_tiles << runs_bshift(c);
-        if ((cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->sorted && !cfg->spans && c->pend.empty() && c->n_cells < (1ull << 32) && nb64 <= 0xFFFFFF00ull) {
+        if ((cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->n_batches < (1ull << 31) && cfg->sorted && !cfg->spans && c->pend.empty() &&
+            c->n_cells < (1ull << 32) && nb64 <= 0xFFFFFF00ull) {
             x.bshift = runs_bshift(c);
             x.nbw = (size_t)nb64 + 2;
             if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
-            if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
-            HIPOK(c, hipMemset(x.b1, 0xFF, x.nbw * 4));
+            if (x.marks) { (void)hipFree(x.marks); x.marks = nullptr; }
+            if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess || hipMalloc(&x.marks, x.nbw * 8) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
+            HIPOK(c, hipMemset(x.marks, 0xFF, x.nbw * 8));
+            if (!x.compose) HIPOK(c, hipStreamCreateWithFlags(&x.compose, hipStreamNonBlocking));
             const uint64_t est = cfg->bytes_hint ? cfg->bytes_hint / 32 + (1u << 20) : (uint64_t)8 << 20;
             const int rr = c8_reserve(c, est, est / 4);
             if (rr) return fail(c, rr, "pd_decode_begin: the run arena could not be allocated");
             x.n_batches = cfg->n_batches;
+            x.batch.assign((size_t)cfg->n_batches, pd_ctx::C8Dec::Batch());
+            x.base_s.assign((size_t)cfg->n_batches, 0u);
             x.on = true;
         }
     }
     // one arena for the batches' run arrays (a hipMalloc per batch waits for the other streams): about half the compressed
     // bytes is plenty for short reads (12 B per run against >= 30 B of BGZF per record); what does not fit is allocated singly
-    const size_t want = c->c8.on ? 0 : cfg->bytes_hint ? (size_t)(cfg->bytes_hint / 2) + ((size_t)16 << 20) : (size_t)256 << 20;
+    // (a compact session's segments are 8-byte first runs + 12-byte later runs: a third less)
+    const size_t want = cfg->bytes_hint ? (size_t)(cfg->bytes_hint / (c->c8.on ? 3 : 2)) + ((size_t)16 << 20) : (size_t)256 << 20;
     if (c->arena_cap < want) {
         if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_cap = 0; }
         if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
@@ -1457,7 +1501,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; } c->dec_cv.notify_one(); } } rel{c, slp};
     const bool c8 = c->c8.on;
     if (c8 && bt->order >= c->c8.n_batches && bt->n_units) return dec_fail(c, PD_EINVAL, "pd_decode_submit: batch order outside [0, n_batches) of this session");
-    C8Turn turn{c, bt->order, c8 && bt->order < c->c8.n_batches};     // (declared after `rel`: the turn is passed before the slot is given back)
+    C8Mark mark{c, bt->order, c8 && bt->order < c->c8.n_batches};     // (every batch number is counted once, however this call ends)
     if (res) memset(res, 0, sizeof *res);
     if (res) res->first_start = res->next_start = ~0ull;
     for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
@@ -1490,7 +1534,8 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
             return dec_fail(c, PD_EINVAL, "pd_decode_submit: block outside its buffer");
     const uint32_t n_seg = (uint32_t)segs.size();
     if (!n_seg) return PD_OK;
-    const unsigned n_wg = (unsigned)c->n_cu * 16u;
+    // (the inflate kernel's LDS lets 20 one-wave workgroups share a CU; "inflate_waves": fewer per launch, so that several batches' launches share the GPU)
+    const unsigned n_wg = (unsigned)c->n_cu * c->dec_waves;
     int rc;
     uint64_t t_mark = dec_now();
     auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - t_mark; t_mark = n; };
@@ -1502,6 +1547,20 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         std::lock_guard<std::mutex> al(g_alloc_mu);
         if (hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
     }
+    // The batch's small tables (member list, segments, statuses, per-segment keys) travel through a page-locked staging area of the
+    // slot: an "asynchronous" copy from or to pageable memory is staged by the runtime on the calling thread, under a lock all streams
+    // share — with six feeders making seven such copies per batch that, not the kernels, paced the decode.
+    const auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_blk = 0, o_seg = o_blk + al((size_t)bt->n_blocks * sizeof(pd_bgzf_block)), o_bst = o_seg + al((size_t)n_seg * sizeof(pdb2::Seg)),
+                 o_so = o_bst + al((size_t)bt->n_blocks * 4), o_ord = o_so + al((size_t)n_seg * sizeof(pdb2::SegOut)), small_need = o_ord + 256;
+    if (small_need > sl.h_small_cap) {
+        std::lock_guard<std::mutex> al2(g_alloc_mu);
+        if (sl.h_small) { (void)hipHostFree(sl.h_small); sl.h_small = nullptr; sl.h_small_cap = 0; }
+        const size_t want = small_need + small_need / 4 + 4096;
+        if (hipHostMalloc((void **)&sl.h_small, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "pinned staging allocation failed"); }
+        sl.h_small_cap = want;
+    }
+    uint8_t *const pin = sl.h_small;
     lap(2);                                                               // device buffers
     hipStream_t st = sl.st;
     uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF];
@@ -1511,23 +1570,28 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     cfg.buf = d_inf; cfg.avail = bt->inflated_bytes; cfg.n_ref = c->n_contigs; cfg.contig_len = c->d_len; cfg.contig_on = c->d_contig_on;
     cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans;
     cfg.near_span = c8 ? 0xFFFFFFFFu : c->dec_near_span;                   // (a compact session has one stream of later runs)
-    cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
+    cfg.c8 = pdb2::C8Out{};
     // ---- H2D, inflate, pass 1 ----
     HIPDEC(hipEventRecord(sl.ev[0], st));
     HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes, hipMemcpyHostToDevice, st));
     HIPDEC(hipMemsetAsync(d_blob + bt->n_bytes, 0, 64, st));
-    HIPDEC(hipMemcpyAsync(sl.d[DS_BLK], bt->blocks, (size_t)bt->n_blocks * sizeof(pd_bgzf_block), hipMemcpyHostToDevice, st));
-    HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+    memcpy(pin + o_blk, bt->blocks, (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
+    memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+    HIPDEC(hipMemcpyAsync(sl.d[DS_BLK], pin + o_blk, (size_t)bt->n_blocks * sizeof(pd_bgzf_block), hipMemcpyHostToDevice, st));
+    HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
     HIPDEC(hipEventRecord(sl.ev[1], st));
-    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc);
+    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc,
+                             (uint32_t *)sl.d[DS_ST] + bt->n_blocks);
     HIPDEC(hipEventRecord(sl.ev[2], st));
     launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, 0);
     std::vector<int> bst(bt->n_blocks);
-    HIPDEC(hipMemcpyAsync(bst.data(), sl.d[DS_ST], (size_t)bt->n_blocks * 4, hipMemcpyDeviceToHost, st));
-    HIPDEC(hipMemcpyAsync(segs.data(), d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+    HIPDEC(hipMemcpyAsync(pin + o_bst, sl.d[DS_ST], (size_t)bt->n_blocks * 4, hipMemcpyDeviceToHost, st));
+    HIPDEC(hipMemcpyAsync(pin + o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
     HIPDEC(hipEventRecord(sl.ev[3], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    memcpy(bst.data(), pin + o_bst, (size_t)bt->n_blocks * 4);
+    memcpy(segs.data(), pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
     lap(3);                                                               // H2D + inflate + pass 1 (waiting)
     // ---- the chain across segments; segments whose guess was wrong walk again from the corrected start ----
     std::vector<uint32_t> redo;
@@ -1536,8 +1600,9 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         for (uint32_t j : redo) HIPDEC(hipMemcpyAsync(&d_seg[j].hint, &segs[j].hint, 8, hipMemcpyHostToDevice, st));
         HIPDEC(hipMemcpyAsync(sl.d[DS_ONLY], redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
         launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, (const uint32_t *)sl.d[DS_ONLY], (uint32_t)redo.size());
-        HIPDEC(hipMemcpyAsync(segs.data(), d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
         HIPDEC(hipStreamSynchronize(st));
+        memcpy(segs.data(), pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
     }
     // ---- unit outcomes; units handed back emit nothing ----
     uint64_t nf = 0, no = 0, nfar = 0, nrec = 0; uint32_t max_span = 0;
@@ -1572,28 +1637,37 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     } run_guard{c, &rs};
     lap(4);                                                               // host: chain check, unit outcomes
     std::vector<pdb2::SegOut> seg_out;
+    auto grab_bytes = [&](size_t bytes, void **out) -> bool {
+        bytes = (bytes + 255) & ~(size_t)255;
+        const size_t at = c->arena_used.fetch_add(bytes);
+        if (at + bytes <= c->arena_cap) { *out = c->arena + at; return true; }
+        return hipMalloc(out, bytes) == hipSuccess;
+    };
     if (c8) {
-        // compact session: this batch's place in the sample's two streams, handed out in batch order; pass 2 writes there
+        // compact session: pass 2 writes the batch's first runs as 8-byte runs into a segment of its own and marks the buckets' first runs;
+        // c8_counted then queues the copies to the runs' final places for every batch whose predecessors are all counted
         pd_ctx::C8Dec &x = c->c8;
-        std::unique_lock<std::mutex> lk(x.mu);
-        if (!x.cv.wait_for(lk, std::chrono::seconds(300), [&] { return x.turn >= bt->order; }) || x.turn != bt->order)
-            return dec_fail(c, PD_ESTATE, "pd_decode_submit: the batches of a compact session must be submitted once each, numbered 0 .. n_batches - 1");
-        const uint64_t base_s = x.n_s, base_o = x.n_o;
+        Run8 *seg_s = nullptr; pd_iv *seg_o = nullptr; hipEvent_t ev = nullptr;
         if (nf + no) {
-            if (const int rr = c8_reserve(c, base_s + nf, base_o + no)) { lk.unlock(); return dec_fail(c, rr, "device decode: the run arena could not be grown"); }
-            for (auto &sg : segs) { sg.base_first += base_s; sg.base_other += base_o; }
-            HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
-            cfg.c8 = pdb2::C8Out{(pdb2::R8 *)x.r8(), x.b1, c->d_off, 13u - x.bshift, (pdb2::SegOut *)sl.d[DS_SEGOUT]};
-            launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, x.oth(), nullptr);
-            x.n_s += nf; x.n_o += no;
+            const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
+            if ((nf && !grab_bytes((size_t)nf * sizeof(Run8), (void **)&seg_s)) || (no && !grab_bytes((size_t)no * sizeof(pd_iv), (void **)&seg_o)) ||
+                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (seg_s && !ina(seg_s)) (void)hipFree(seg_s);
+                if (seg_o && !ina(seg_o)) (void)hipFree(seg_o);
+                return dec_fail(c, PD_ENOMEM, "run segment allocation failed");
+            }
+            memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+            HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+            cfg.c8 = pdb2::C8Out{(pdb2::R8 *)seg_s, x.marks, c->d_off, 13u - x.bshift, (pdb2::SegOut *)sl.d[DS_SEGOUT], (uint32_t)bt->order};
+            launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, seg_o, nullptr);
+            HIPDEC(hipEventRecord(ev, st));
         }
-        x.turn = bt->order + 1;
-        turn.armed = false;
-        lk.unlock();
-        x.cv.notify_all();
+        mark.armed = false;
+        c8_counted(c, bt->order, nf, no, seg_s, seg_o, ev);
         if (nf + no) {
             seg_out.resize(n_seg);
-            HIPDEC(hipMemcpyAsync(seg_out.data(), sl.d[DS_SEGOUT], (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
+            HIPDEC(hipMemcpyAsync(pin + o_so, sl.d[DS_SEGOUT], (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
         }
         lap(5);
     } else if (nf + no + nfar) {
@@ -1604,7 +1678,8 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
             return hipMalloc(out, bytes) == hipSuccess;
         };
         if ((nf && !grab(nf, &rs.first)) || (no && !grab(no, &rs.other)) || (nfar && !grab(nfar, &rs.far))) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
-        HIPDEC(hipMemcpyAsync(d_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+        memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+        HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
         lap(5);                                                           // run array allocation
         launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far);
     }
@@ -1613,11 +1688,13 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     if (nf && !c8) {
         HIPDEC(hipMemsetAsync(sl.d[DS_ONLY], 0, 24, st));
         launch_runs_sorted(st, rs.first, nf, (uint32_t *)sl.d[DS_ONLY]);
-        HIPDEC(hipMemcpyAsync(order_words, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + o_ord, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
     }
     HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
+    if (nf && !c8) memcpy(order_words, pin + o_ord, 24);
+    if (!seg_out.empty()) memcpy(seg_out.data(), pin + o_so, (size_t)n_seg * sizeof(pdb2::SegOut));
     if (c8 && !seg_out.empty()) {
         // compact emission checked the order itself: inside every lane and across the lanes of a segment; here across the segments
         uint64_t prev = 0, first = pdb2::NONE, n_long = 0; uint32_t bad = 0;
@@ -1675,11 +1752,15 @@ int pd_decode_end(pd_ctx *c)
         runs_free(c->dec_runs); c->dec_runs = nullptr;
     }
     if (c->c8.on) {
-        // ---- a compact session: the runs are where they belong already ----
+        // ---- a compact session: the runs are where they belong already (or on their way there, on the compose stream) ----
         pd_ctx::C8Dec &x = c->c8;
         std::lock_guard<std::mutex> l8(x.mu);
         x.on = false;
-        if (x.turn != x.n_batches) { c8_drop(c); return fail(c, PD_ESTATE, "pd_decode_end: not every batch of the compact session was submitted"); }
+        if (x.turn != x.n_batches || !x.err.empty()) {
+            const std::string why = x.err.empty() ? "not every batch of the compact session was submitted" : x.err;
+            (void)hipDeviceSynchronize(); c8_drop(c);
+            return fail(c, PD_ESTATE, "pd_decode_end: " + why);
+        }
         bool ok_order = true; uint64_t prev = 0, n_long = 0; bool have = false;
         for (auto &r : segs) {
             n_long += r.n_long;
@@ -1689,29 +1770,39 @@ int pd_decode_end(pd_ctx *c)
         }
         if (getenv("PANDEPTH_TIMING"))
             fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
-                            "host chain check %.3f, placement + emit launch %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs (compact session): %llu first, %llu later (span %u)\n",
+                            "host chain check %.3f, segment + emit launch %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs (compact session): %llu first, %llu later (span %u)\n",
                     g_dec_us[0] / 1e6, g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, g_dec_us[7] / 1e6, segs.size(),
                     (unsigned long long)x.n_s, (unsigned long long)x.n_o, span);
-        if (x.n_s + x.n_o == 0) { c8_drop(c); return PD_OK; }
-        HIPOK(c, hipDeviceSynchronize());                         // (the batches' streams: every emit kernel has finished)
+        if (x.n_s + x.n_o == 0) { (void)hipStreamSynchronize(x.compose); c8_drop(c); return PD_OK; }
+        HIPOK(c, hipStreamSynchronize(x.compose));                 // every batch's runs have reached their places
         if (ok_order && x.n_s && c->pend.empty() && x.n_s + x.n_o <= DEV_BATCH_MAX && x.cap_s + x.cap_o < 0xFFFFFF00ull) {
             pd_runs *r = new pd_runs;
             r->ctx = c; r->r8 = x.r8(); r->own_r8 = true; r->n_s = (uint32_t)x.n_s; r->n_o = (uint32_t)x.n_o; r->n = r->n_s + r->n_o; r->o_base = (uint32_t)x.cap_s;
             r->b1 = x.b1; r->o1 = x.b1 + x.nbw; r->bshift = x.bshift;
             const pd_iv *oth = x.oth(); const size_t no1 = (size_t)x.n_o;
-            uint32_t *tmp = nullptr, *words = nullptr;
+            uint32_t *tmp = nullptr, *words = nullptr, *d_base = nullptr;
             const size_t nbw = x.nbw;
-            x.base = nullptr; x.b1 = nullptr; x.bytes = 0; x.cap_s = x.cap_o = 0;       // (they belong to the sample now)
-            if (hipMalloc(&tmp, (2 * nbw + nbw / 1024 + 8) * 4) != hipSuccess || hipMalloc(&words, 16) != hipSuccess) {
-                (void)hipGetLastError(); if (tmp) (void)hipFree(tmp); runs_free(r);
+            unsigned long long *marks = x.marks;
+            const std::vector<uint32_t> base_s = x.base_s;
+            x.base = nullptr; x.b1 = nullptr; x.marks = nullptr; x.bytes = 0; x.cap_s = x.cap_o = 0;       // (they belong to the sample now; the marks go below)
+            c8_drop(c);                                                                                        // the batches' segments and events
+            if (hipMalloc(&tmp, (2 * nbw + nbw / 1024 + 8) * 4) != hipSuccess || hipMalloc(&words, 16) != hipSuccess || hipMalloc(&d_base, base_s.size() * 4 + 16) != hipSuccess) {
+                (void)hipGetLastError(); for (void *q : {(void *)tmp, (void *)words, (void *)d_base, (void *)marks}) if (q) (void)hipFree(q); runs_free(r);
                 return fail(c, PD_ENOMEM, "pd_decode_end: allocation failed");
             }
             uint32_t h[2] = {0, 0};
             hipError_t e = hipMemsetAsync(words, 0, 16, c->stream);
-            if (e == hipSuccess) { const pd_iv *o[1] = {oth}; const size_t non[1] = {no1}; runs_finish(c, r, o, non, no1 ? 1 : 0, tmp, words); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipMemcpyAsync(d_base, base_s.data(), base_s.size() * 4, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                // the marks (batch, index in the batch) of the buckets' first runs become indices into the sorted stream
+                { ProfScope ps(c, "compact_finish"); launch_c8_marks_to_index(c->stream, marks, (uint32_t)(nbw - 1), d_base, r->b1); }
+                const pd_iv *o[1] = {oth}; const size_t non[1] = {no1};
+                runs_finish(c, r, o, non, no1 ? 1 : 0, tmp, words);
+                e = hipGetLastError();
+            }
             if (e == hipSuccess) e = hipMemcpyAsync(h, words, 8, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            (void)hipFree(tmp); (void)hipFree(words);
+            (void)hipFree(tmp); (void)hipFree(words); (void)hipFree(d_base); (void)hipFree(marks);
             if (e != hipSuccess) { runs_free(r); return fail(c, PD_EHIP, std::string("pd_decode_end: ") + hipGetErrorString(e)); }
             r->n_long = (uint32_t)std::min<uint64_t>(n_long + h[1], 0xFFFFFFFFull);
             c->dec_runs = r;

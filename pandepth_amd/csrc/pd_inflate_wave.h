@@ -47,10 +47,17 @@
 
 namespace pdw {
 
+// Root widths of the two lookup tables.  The tables are most of a wave's LDS (one wave per workgroup), and LDS is what limits the waves
+// per CU of this latency-bound kernel: a 9-bit literal/length root instead of 10 (2 KiB less; codes of 10+ bits take the second lookup) lets
+// 20 waves share a CU instead of 16 — measured on 61 220 members of a 50x payload BAM: 178 -> 209 GB/s of inflated bytes
+// (tools/ubench/inflate_ab.py, profiles/r04_inflate_ab.txt).
 #ifndef PD_LL_ROOT
-#define PD_LL_ROOT 10                     /* bits of the literal/length table's root (tuning builds: 9 frees 2 KiB of LDS per wave) */
+#define PD_LL_ROOT 9
 #endif
-enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = 320, D_ROOT = 8, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
+#ifndef PD_D_ROOT
+#define PD_D_ROOT 8
+#endif
+enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = 320, D_ROOT = PD_D_ROOT, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
 enum { PD_W_OK = 0, PD_W_HOST = 1 };      // negative values: corrupt stream (same codes as pd_inflate_core.h)
 enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2, KIND_BAD = 3 };
 enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };

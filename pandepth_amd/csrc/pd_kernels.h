@@ -86,6 +86,7 @@ void launch_c8_from_sorted(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTa
 void launch_c8_hist(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, uint32_t *hist, uint32_t *words);
 void launch_excl_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *block_sums /* n / 1024 + 2 words */);
 void launch_c8_fill_starts(hipStream_t st, uint32_t *b1, uint32_t n_buckets, uint32_t n_runs, uint32_t *tmp /* n_buckets / 1024 + 2 words */);
+void launch_c8_marks_to_index(hipStream_t st, const unsigned long long *marks, uint32_t n_buckets, const uint32_t *base, uint32_t *b1);
 void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1, uint32_t *cursor, Run8 *out);
 void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out);
 void launch_r8_to_iv(hipStream_t st, const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out);
@@ -134,7 +135,7 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_bloc
                          int *status, void *scratch);
 size_t bgzf_scratch_bytes(uint32_t n_blk);
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg, bool check_crc);
+                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next /* device word for the member counter, or null: static split */);
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 } // namespace pdk
 

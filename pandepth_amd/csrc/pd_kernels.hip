@@ -1495,6 +1495,16 @@ __global__ __launch_bounds__(WG) void k_sfx_blocks(uint32_t *a, uint32_t n, cons
 }
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
+// the decoder's marks — per bucket the smallest (batch << 32 | index in the batch) of a run that begins there, all ones where none does —
+// become indices into the sample's sorted stream: base[batch] + index (0xFFFFFFFF stays "nobody")
+__global__ __launch_bounds__(WG) void k_c8_marks_to_index(const unsigned long long *marks, uint32_t n, const uint32_t *base, uint32_t *b1)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long m = marks[k];
+    b1[k] = m == ~0ull ? 0xFFFFFFFFu : base[(uint32_t)(m >> 32)] + (uint32_t)m;
+}
+
 // the other streams' runs to their buckets: o1 = exclusive prefix sum of the histogram; the runs of a group of equal neighbours take
 // consecutive places from ONE atomic on the bucket's cursor
 __global__ __launch_bounds__(WG) void k_c8_place_other(const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1,
@@ -1598,28 +1608,30 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
         const uint32_t p0 = (uint32_t)a;                          // the runs' begins are flat (mod 2^32), like this
         const uint32_t pc = (uint32_t)(a - tab.off[ctg]);         // the tile's first cell inside its contig
         const uint32_t k0 = (uint32_t)t << bsh;
-        const uint32_t olo = cs.o1[pc ? k0 - 1 : k0], ohi = cs.o1[k0 + (1u << bsh)];        // ... and in the other stream
+        // ... and in the other stream (both possible lower bounds are fetched, so that the loads do not wait for the contig's offset)
+        const uint32_t o_prev = cs.o1[k0 ? k0 - 1 : 0], o_own = cs.o1[k0], ohi = cs.o1[k0 + (1u << bsh)];
         bounds(t + gridDim.x, nslo, nshi);
         __syncthreads();
-        if (ns > 32000u) {                                        // workgroup-uniform: the int-window kernel does this tile
+        const uint32_t olo = pc ? o_prev : o_own, no = ohi - olo;
+        const uint32_t cand = ns + no;
+        if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
             if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
             __syncthreads();
             continue;
         }
-        uint32_t cand = ns;
         int carry_s = 0;
-        // the same loop over one stream, then the other (ONE copy of the code: the stream is a scalar choice of base pointer and count)
-        bool heavy = false;
-#pragma unroll 1
-        for (int strm = 0; strm < 2; ++strm) {
-            const Run8 *__restrict__ const p = cs.r8 + (strm ? cs.o_base + olo : s_at);
-            const uint32_t hi = strm ? ohi - olo : ns;
-            if (strm) { cand += hi; if (cand > 32000u) { heavy = true; break; } }     // (workgroup-uniform)
+        {
+            // ONE sequence of chunks: those of the sorted stream's candidates, then those of the other stream's — which stream a chunk
+            // belongs to is a scalar decision (base index, position, end), so the double-buffered loop runs through both without a restart
             constexpr uint32_t C = UN8 * WG;
-            auto load8 = [&](uint2 (&dst)[UN8], const uint32_t i) {
-                const uint32_t last = hi - 1u;
+            const Run8 *__restrict__ const p = cs.r8;
+            const uint32_t c1 = (ns + C - 1) / C, nq = c1 + (no + C - 1) / C;
+            const uint32_t o_at = cs.o_base + olo;
+            auto load8 = [&](uint2 (&dst)[UN8], const uint32_t q) {
+                const bool second = q >= c1;
+                const uint32_t at = second ? o_at : s_at, i = (second ? q - c1 : q) * C, last = (second ? no : ns) - 1u;
 #pragma unroll
-                for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (j < last ? j : last)); }
+                for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (at + (j < last ? j : last))); }
             };
             auto ev8 = [&](const uint32_t b, const uint32_t len) {
                 const uint32_t sb = b - p0, se = sb + len;
@@ -1628,12 +1640,13 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                 if (se < ST) atomicSub(&win[se & (HT - 1u)], 1u + (se >> 12) * 0xFFFFu);
                 carry_s += __builtin_popcountll(m_c);
             };
-            auto work8 = [&](const uint2 (&c)[UN8], const uint32_t i) {
-                const uint32_t left = hi - i;
+            auto work8 = [&](const uint2 (&c)[UN8], const uint32_t q) {
+                const bool second = q >= c1;
+                const uint32_t left = (second ? no : ns) - (second ? q - c1 : q) * C;
                 if (left >= C) {
 #pragma unroll
                     for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
-                } else {                                          // the tail chunk: slots past the end become runs outside the tile
+                } else {                                          // a stream's tail chunk: slots past the end become runs outside the tile
                     const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
 #pragma unroll
                     for (int k = 0; k < UN8; ++k) if (k < nu) {
@@ -1642,25 +1655,20 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                     }
                 }
             };
-            if (hi) {
+            if (nq) {
                 uint2 A[UN8], B[UN8];
-                uint32_t i = 0;
-                load8(A, i);
+                uint32_t q = 0;
+                load8(A, q);
 #pragma unroll 1
                 for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
-                    if (i + C < hi) load8(B, i + C);
-                    work8(A, i);
-                    i += C; if (i >= hi) break;
-                    if (i + C < hi) load8(A, i + C);
-                    work8(B, i);
-                    i += C; if (i >= hi) break;
+                    if (q + 1 < nq) load8(B, q + 1);
+                    work8(A, q);
+                    if (++q >= nq) break;
+                    if (q + 1 < nq) load8(A, q + 1);
+                    work8(B, q);
+                    if (++q >= nq) break;
                 }
             }
-        }
-        if (heavy) {                                              // too many candidates for the packed counters after all: the int-window kernel redoes the tile
-            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
-            __syncthreads();
-            continue;
         }
         if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
         __syncthreads();
@@ -2682,6 +2690,12 @@ void launch_c8_fill_starts(hipStream_t st, uint32_t *b1, uint32_t n_buckets, uin
     hipLaunchKernelGGL(k_sfx_block_min, dim3(nb), dim3(WG), 0, st, (const uint32_t *)b1, n, tmp);
     hipLaunchKernelGGL(k_sfx_of_mins, dim3(1), dim3(1024), 0, st, tmp, nb);
     hipLaunchKernelGGL(k_sfx_blocks, dim3(nb), dim3(WG), 0, st, b1, n, (const uint32_t *)tmp);
+}
+
+void launch_c8_marks_to_index(hipStream_t st, const unsigned long long *marks, uint32_t n_buckets, const uint32_t *base, uint32_t *b1)
+{
+    if (!n_buckets) return;
+    hipLaunchKernelGGL(k_c8_marks_to_index, dim3((unsigned)(((uint64_t)n_buckets + WG - 1) / WG)), dim3(WG), 0, st, marks, n_buckets, base, b1);
 }
 
 void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1, uint32_t *cursor, Run8 *out)

@@ -3,9 +3,45 @@
 #include <stdlib.h>
 #include <zlib.h>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <sstream>
 
 namespace pdh {
+
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, std::string> g_tune;
+bool g_tune_env_read = false;
+void tune_parse(const std::string &list)
+{
+    size_t o = 0;
+    while (o <= list.size()) {
+        size_t e = list.find(',', o);
+        if (e == std::string::npos) e = list.size();
+        const std::string kv = list.substr(o, e - o);
+        const size_t q = kv.find('=');
+        if (!kv.empty()) g_tune[q == std::string::npos ? kv : kv.substr(0, q)] = q == std::string::npos ? std::string("1") : kv.substr(q + 1);
+        o = e + 1;
+    }
+}
+void tune_env()
+{
+    if (g_tune_env_read) return;
+    g_tune_env_read = true;
+    if (const char *e = getenv("PANDEPTH_TUNE")) tune_parse(e);
+}
+} // namespace
+
+const char *tune(const char *key)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_env();
+    auto it = g_tune.find(key);
+    return it == g_tune.end() ? nullptr : it->second.c_str();       // (entries are never removed: the pointer stays valid)
+}
+long long tune_int(const char *key, long long dflt) { const char *v = tune(key); return v ? strtoll(v, nullptr, 10) : dflt; }
+void tune_add(const std::string &kv_list) { std::lock_guard<std::mutex> lk(g_tune_mu); tune_env(); tune_parse(kv_list); }
 
 void print_help()
 {
@@ -132,6 +168,7 @@ int parse_options(int argc, char **argv, Options *o)
             if (o->win < 1) { std::cerr << "Warning: -w should >= 1, set to 1\n"; o->win = 1; }
         } else if (flag == "q") { if (!arg(&v)) return 0; o->min_mapq = atoi(v.c_str()); }
         else if (flag == "s") o->use_index = false;
+        else if (flag == "X") { if (!arg(&v)) return 0; tune_add(v); }          // hidden: development switches (options.h)
         else if (flag == "d") { if (!arg(&v)) return 0; o->min_dep = atoi(v.c_str()); if (o->min_dep < 1) o->min_dep = 1; }
         else if (flag == "help" || flag == "h") { print_help(); return 0; }
         else { std::cerr << "Error UnKnow argument -" << flag << std::endl; return 0; }

@@ -34,6 +34,15 @@ struct Options {
 int parse_options(int argc, char **argv, Options *o);
 void print_help();
 
+// Development switches of the executable — which of its equivalent paths runs (device or host decode, where the gzip streams are
+// parsed, how many decode threads / GPUs ...), never what it prints — come in through ONE door: the hidden option `-X key=value[,key=value]`
+// or the environment variable PANDEPTH_TUNE with the same syntax (tests, benchmarks).  tune("key") returns the value or NULL.
+//   device_decode=0  device_deflate=0  site_resident=0  table_resident=0  table_resident_min=N  site_overlap=0  site_identical=0|1
+//   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_batch_mb=N  inflate_waves=N  decode_only=1
+const char *tune(const char *key);
+long long tune_int(const char *key, long long dflt);
+void tune_add(const std::string &kv_list);
+
 // text-file helper shared with the region parser: whole file (plain or gzip) split into lines
 // the way `while(!in.eof()) getline(in, line)` sees them
 bool read_lines(const std::string &path, std::vector<std::string> *lines);

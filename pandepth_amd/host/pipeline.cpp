@@ -99,7 +99,7 @@ public:
     void flush() { flush_sorted(); flush_other(); }
 private:
     // PANDEPTH_DECODE_ONLY=1 (diagnostics): decode and expand, but drop the batches
-    const bool drop_ = getenv("PANDEPTH_DECODE_ONLY") != nullptr;
+    const bool drop_ = tune("decode_only") != nullptr;
     void flush_sorted()
     {
         if (!drop_ && !s_.empty() && e_->ok()) e_->ck(e_->api->push_intervals(e_->ctx, s_.data(), s_.size(), PD_PUSH_SORTED), "pd_push_intervals");
@@ -326,7 +326,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
 {
     const pd_engine_api *api = eng->api;
     if (!api->decode_begin || !api->decode_acquire || !api->decode_submit || !api->decode_end || !api->decode_abort) return 0;
-    if (const char *e = getenv("PANDEPTH_DEVICE_DECODE")) if (e[0] == '0') return 0;
+    if (const char *e = tune("device_decode")) if (e[0] == '0') return 0;
     if (kind != 0 && !spans.synthetic) return 0;            // the no-index span cursor (PD:4608-4646) stays on the host
     const uint64_t F = file_size(path);
     if (F < 28) return 0;
@@ -338,7 +338,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     const bool chunk_units = kind == 0 && !spans.synthetic;
     auto spare_of = [&](uint64_t vend) -> uint64_t { return !chunk_units || vend == UINT64_MAX ? SPARE : (vend & 0xffff) ? 65536 : 0; };
     uint64_t batch_bytes = (uint64_t)32 << 20;
-    if (const char *e = getenv("PANDEPTH_DD_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+    if (const char *e = tune("dd_batch_mb")) batch_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     // ---- the work list: batches of units ----
     std::vector<std::vector<DevRange>> batches;
     std::vector<BaiIndex::Chunk> orig;                       // region fetch: the index chunks as the host reader visits them
@@ -420,7 +420,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         cfg.span_off = soff.data(); cfg.spans = sflat.data();
     }
     int feeders = std::min<int>(std::max(1, o.threads), 6);
-    if (const char *e = getenv("PANDEPTH_DD_THREADS")) feeders = std::max(1, atoi(e));
+    if (const char *e = tune("dd_threads")) feeders = std::max(1, atoi(e));
     if ((size_t)feeders > batches.size()) feeders = (int)batches.size();
     {   // the largest batch the feeders will ask a buffer for
         uint64_t mx = 0;
@@ -428,6 +428,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
     }
     cfg.n_batches = batches.size();
+    if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
     const size_t n_batches = batches.size();
@@ -724,11 +725,11 @@ void format_sites(const std::string &nm, uint32_t b, const uint32_t *d, size_t n
 }
 
 // Stage 1 of the byte-identical gzip streams (zlib's LZ77 parse) on the engine: pgz hands over the chunks of a round, the
-// engine returns zlib's symbols (pd_deflate_parse).  PANDEPTH_DEVICE_DEFLATE=0: zlib parses on the host threads as before.
+// engine returns zlib's symbols (pd_deflate_parse).  -X device_deflate=0: zlib parses on the host threads as before.
 pgz::ParseFn engine_parse(Engine *eng)
 {
     if (!eng->api->deflate_parse) return nullptr;
-    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return nullptr;
+    if (const char *e = tune("device_deflate")) if (e[0] == '0') return nullptr;
     return [eng](const uint8_t *text, size_t n, const uint64_t *chunks, size_t n_chunks, pgz::SymVec &syms, std::vector<uint64_t> &off) -> bool {
         static_assert(sizeof(pd_lz_chunk) == 3 * sizeof(uint64_t), "pd_lz_chunk is a (start, end, origin) triple");
         size_t bytes = 0;
@@ -757,8 +758,8 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
 {
     const pd_engine_api *api = eng->api;
     if (!api->text_open || !api->text_close || !api->text_append_sites || !api->text_parse || !api->text_read || !api->text_release) return 0;
-    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return 0;
-    if (const char *e = getenv("PANDEPTH_SITE_RESIDENT")) if (e[0] == '0') return 0;
+    if (const char *e = tune("device_deflate")) if (e[0] == '0') return 0;
+    if (const char *e = tune("site_resident")) if (e[0] == '0') return 0;
     const bool timing = getenv("PANDEPTH_TIMING") != nullptr;
     const auto t_enter = std::chrono::steady_clock::now();
     pgz::Params prm = pgz::Params::for_device(nullptr);
@@ -835,12 +836,12 @@ int write_window_table_resident(GzWriter &out, Engine *eng, int threads, uint32_
     if (!api->text_open || !api->text_close || !api->text_append_window_rows || !api->text_append_bytes || !api->text_parse || !api->text_read ||
         !api->text_release || !out.collecting())
         return 0;
-    if (const char *e = getenv("PANDEPTH_DEVICE_DEFLATE")) if (e[0] == '0') return 0;
-    if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT")) if (e[0] == '0') return 0;
+    if (const char *e = tune("device_deflate")) if (e[0] == '0') return 0;
+    if (const char *e = tune("table_resident")) if (e[0] == '0') return 0;
     size_t rows = 0;
     for (const auto &tc : contigs) rows += tc.n_rows;
     size_t min_rows = 100000;                                  // (small tables: the host formats them in milliseconds)
-    if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT_MIN")) min_rows = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = tune("table_resident_min")) min_rows = (size_t)strtoull(e, nullptr, 10);
     if (rows < min_rows) return 0;
     const auto t_enter = std::chrono::steady_clock::now();
     pgz::Params prm = pgz::Params::for_device(nullptr);
@@ -1033,7 +1034,7 @@ int write_site_depth_identical(const std::string &path, const AlnHeader &hdr, co
 // skips the first attempt.
 bool write_site_depth(const std::string &path, const AlnHeader &hdr, const RegionModel &rm, Engine *eng, int threads)
 {
-    const char *ident = getenv("PANDEPTH_SITE_IDENTICAL");
+    const char *ident = tune("site_identical");
     if (threads > 1 && !(ident && ident[0] == '0')) {
         // the text on the device; else the text on the host with the engine's parse; else zlib's own parse on the host threads, whose
         // chunks are large (1 MiB + 64 KiB of overlap): a text whose parses do not meet inside the small chunks' overlap ends up there
@@ -1047,7 +1048,7 @@ bool write_site_depth(const std::string &path, const AlnHeader &hdr, const Regio
     for (size_t t = 0; t < hdr.names.size(); ++t)
         if (rm.has((int32_t)t)) estimate += (uint64_t)hdr.lens[t] * (hdr.names[t].size() + 12);
     uint64_t par_min = (uint64_t)256 << 20;
-    if (const char *e = getenv("PANDEPTH_SITE_PARALLEL_MIN")) par_min = strtoull(e, nullptr, 10);
+    if (const char *e = tune("site_parallel_min")) par_min = strtoull(e, nullptr, 10);
     const size_t CH = (size_t)4 << 20;
     if (estimate >= par_min && threads > 1) {
         ParallelGzWriter out;
@@ -1218,7 +1219,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     int n_dev = 1, n_ctx = 1;
     if (list_mode && !paf && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
         n_ctx = n_dev;
-        if (const char *e = getenv("PANDEPTH_GPUS")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
+        if (const char *e = tune("gpus")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
         if (n_ctx > n_files) n_ctx = n_files;
     }
     std::vector<std::unique_ptr<Engine>> engs;
@@ -1322,7 +1323,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     // Several GPUs hold one partial sample each.  Wide-window statistics are summed in slices over RCCL (pd_sliced_window_sum:
     // every GPU receives 1/n of the others' 4-bit images, no GPU ever holds everybody's arrays); whatever needs the summed
     // cells themselves (per-site output, annotation intervals, narrow windows) adds the contexts into the first one.
-    bool merged = n_ctx == 1 && !getenv("PANDEPTH_FORCE_RCCL");      // (the variable: a 1-rank communicator, so that single-GPU boxes test this path)
+    bool merged = n_ctx == 1 && !(tune("rccl") && !strcmp(tune("rccl"), "force"));      // (the variable: a 1-rank communicator, so that single-GPU boxes test this path)
     auto merge_contexts = [&]() -> bool {
         if (merged) return true;
         merged = true;
@@ -1345,7 +1346,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     // rank's collective; returns 1 done, 0 not applicable (no communicator, or the samples do not fit the sliced sum's 4-bit images:
     // PD_ERANGE on every rank, nothing consumed — the contexts are then added into the first one), -1 error.
     auto sliced = [&](const std::function<int(int, pd_comm *)> &call, const char *what) -> int {
-        if (merged || scanned || !(n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) || !api->comm_init_all || getenv("PANDEPTH_NO_RCCL")) return 0;
+        if (merged || scanned || !(n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) || !api->comm_init_all || (tune("rccl") && tune("rccl")[0] == '0')) return 0;
         std::vector<pd_ctx *> ctxs;
         for (auto &e : engs) ctxs.push_back(e->ctx);
         std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
@@ -1356,7 +1357,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
             ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
         };
-        std::unique_ptr<Quiet> quiet(getenv("PANDEPTH_RCCL_VERBOSE") ? nullptr : new Quiet);
+        std::unique_ptr<Quiet> quiet(tune("rccl_verbose") ? nullptr : new Quiet);
         if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) != 0) {
             quiet.reset();
             if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
@@ -1413,7 +1414,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     if (o.site_out) {
         if (!need_scan()) return bail();
         site_job.th = std::thread([&] { site_job.ok = write_site_depth(prefix + ".SiteDepth.gz", hdr, rm, &eng, o.threads); });
-        if (getenv("PANDEPTH_SITE_OVERLAP") && getenv("PANDEPTH_SITE_OVERLAP")[0] == '0') { site_job.wait(); tm.mark("per-site file"); }
+        if (tune("site_overlap") && tune("site_overlap")[0] == '0') { site_job.wait(); tm.mark("per-site file"); }
     }
     // a failed run does not wait for the whole per-site file: the writer is told to stop, and what it wrote is removed
     abandon_site_file = [&] {
@@ -1455,7 +1456,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             size_t rows = 0;
             for (const auto &tc : tcs) rows += tc.n_rows;
             size_t min_rows = 100000;
-            if (const char *e = getenv("PANDEPTH_TABLE_RESIDENT_MIN")) min_rows = (size_t)strtoull(e, nullptr, 10);
+            if (const char *e = tune("table_resident_min")) min_rows = (size_t)strtoull(e, nullptr, 10);
             if (rows >= min_rows && api->text_append_window_rows && OUT.collecting()) {
                 tm.mark("scan + window statistics");
                 RowSums tot;

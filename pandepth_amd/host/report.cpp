@@ -1,6 +1,7 @@
 // report.cpp — see report.h
 #include "report.h"
 #include "pgzip.h"
+#include "options.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,7 +65,7 @@ bool GzWriter::close()
         FILE *fp = (FILE *)fp_;
         fp_ = nullptr;
         size_t pgz_min = (size_t)1 << 20;
-        if (const char *e = getenv("PANDEPTH_PGZ_MIN")) pgz_min = (size_t)strtoull(e, nullptr, 10);
+        if (const char *e = tune("pgz_min")) pgz_min = (size_t)strtoull(e, nullptr, 10);
         std::vector<uint8_t> img;
         bool ok;
         // with the engine's parse (small chunks); else zlib's own parse on the threads (1 MiB chunks with 64 KiB of overlap: a text

@@ -34,7 +34,7 @@ def main():
     if os.environ.get("E2E_DECODE_ONLY"):
         for t in (8, 16, 32, 64, 128):
             subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "mine"), "-t", str(t)], check=True,
-                           stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_DECODE_ONLY="1"))
+                           stdout=subprocess.DEVNULL, env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="decode_only=1"))
         return
     if os.environ.get("E2E_DEVICE_DECODE"):
         for bmb, t in (("2048", 2), ("1024", 16), ("2048", 16), ("2048", 32)):
@@ -42,7 +42,7 @@ def main():
             for rep in range(2):
                 a = time.perf_counter()
                 subprocess.run([cli, "-i", bam, "-o", os.path.join(td, "dd"), "-t", str(t)], check=True, stdout=subprocess.DEVNULL,
-                               env=dict(os.environ, PANDEPTH_DEVICE_DECODE="1", PANDEPTH_DD_BATCH_MB=bmb,
+                               env=dict(os.environ, PANDEPTH_TUNE="device_decode=1,dd_batch_mb=" + bmb,
                                         **({"PANDEPTH_TIMING": "1"} if rep == 1 else {})))
                 best = min(best, time.perf_counter() - a)
             print("pandepth(MI355X, device decode) batch %s MB -t %d  %.2f s  %.3e records/s" % (bmb, t, best, R / best), flush=True)

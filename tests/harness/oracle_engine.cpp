@@ -217,7 +217,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     cfg.flag_mask = c->dcfg.flag_mask; cfg.min_mapq = c->dcfg.min_mapq;
     cfg.span_off = c->soff.empty() ? nullptr : c->soff.data(); cfg.spans = c->soff.empty() ? nullptr : c->spans.data();
     cfg.near_span = getenv("PANDEPTH_TEST_NEAR_SPAN") && !c->compact ? (uint32_t)atoi(getenv("PANDEPTH_TEST_NEAR_SPAN")) : 0xFFFFFFFFu;
-    cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
+    cfg.c8 = pdb2::C8Out{};
     std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0(bt->n_units + 1, 0);
     for (uint32_t u = 0; u < bt->n_units; ++u) {
         const pd_decode_unit &un = bt->units[u];
@@ -261,9 +261,9 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
         // the product's compact emission, then back to 12-byte runs; everything the engine relies on is checked on the way
         const uint32_t cshift = 9;
         std::vector<pdb2::R8> r8(nf + 1);
-        std::vector<uint32_t> b1((size_t)(c->flat_off.back() >> cshift) + 2, 0xFFFFFFFFu);
+        std::vector<unsigned long long> b1((size_t)(c->flat_off.back() >> cshift) + 2, ~0ull);
         std::vector<pdb2::SegOut> so(segs.size());
-        cfg.c8 = pdb2::C8Out{r8.data(), b1.data(), c->flat_off.data(), cshift, so.data()};
+        cfg.c8 = pdb2::C8Out{r8.data(), b1.data(), c->flat_off.data(), cshift, so.data(), (uint32_t)bt->order};
         for (size_t j = 0; j < segs.size(); ++j) {
             if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], nullptr, r.other.data(), r.far.data(), &so[j]);
             else so[j] = pdb2::SegOut{pdb2::NONE, 0, 0, 0};
@@ -279,7 +279,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
             if (beg > c->len[t] || r8[i].len > c->len[t] - beg) { bad = "a compact run is not clamped to its contig"; break; }
             r.first[i] = pd_iv{(int32_t)t, (int32_t)beg, (int32_t)(beg + r8[i].len)};
             const bool head = i == 0 || (prev_flat >> cshift) != (flat >> cshift);
-            if (head && b1[flat >> cshift] != (uint32_t)i && flat >= prev_flat) { bad = "the first run of a bucket did not leave its index"; break; }
+            if (head && b1[flat >> cshift] != (((unsigned long long)(uint32_t)bt->order << 32) | (uint32_t)i) && flat >= prev_flat) { bad = "the first run of a bucket did not leave its (batch, index) mark"; break; }
             prev_flat = flat;
         }
         uint64_t first = pdb2::NONE, last = 0; uint32_t uns = 0;
@@ -291,7 +291,7 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
             else if (!really && (first != r8[0].b || last != r8[nf - 1].b)) bad = "the emission's first / last keys disagree with the runs";
         }
         if (!bad.empty()) { std::lock_guard<std::mutex> lk(c->mu); c->compact_err = bad; }
-        cfg.c8 = pdb2::C8Out{nullptr, nullptr, nullptr, 0, nullptr};
+        cfg.c8 = pdb2::C8Out{};
     } else
     for (size_t j = 0; j < segs.size(); ++j)
         if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data());

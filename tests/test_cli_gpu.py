@@ -62,9 +62,9 @@ def test_pandepth_cli_device_decode_is_the_default(case, tmp_path):
 
 @pytest.mark.parametrize("case", BAM_CASES[::3], ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_pandepth_cli_host_decode_byte_identical(case, tmp_path):
-    """PANDEPTH_DEVICE_DECODE=0: the host readers (libdeflate + pd_push_intervals) still give the same bytes."""
+    """-X device_decode=0 (PANDEPTH_TUNE): the host readers (libdeflate + pd_push_intervals) still give the same bytes."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_DEVICE_DECODE="0", PANDEPTH_TIMING="1")
+    env = dict(os.environ, PANDEPTH_TUNE="device_decode=0", PANDEPTH_TIMING="1")
     args = [CLI] + case["args"] + ["-o", str(tmp_path / "o")] + ([] if "-t" in case["args"] else ["-t", "3"])
     p = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
@@ -77,10 +77,10 @@ def test_pandepth_cli_host_decode_byte_identical(case, tmp_path):
 
 @pytest.mark.parametrize("case", [e for e in MANIFEST if ".list" in e["args"][1]], ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_pandepth_cli_list_over_two_contexts(case, tmp_path):
-    """PANDEPTH_GPUS=2 on a one-GPU box: two contexts (sharing the GPU), pd_accumulate_from at the end."""
+    """gpus=2 (PANDEPTH_TUNE) on a one-GPU box: two contexts (sharing the GPU), pd_accumulate_from at the end."""
     d = os.path.join(HERE, "golden", case["fixture"])
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANDEPTH_GPUS="2"))
+                       stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, PANDEPTH_TUNE="gpus=2"))
     assert p.returncode == case["returncode"], p.stderr.decode()[-500:]
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
@@ -112,11 +112,11 @@ def test_compact_session_over_many_batches(kind, tmp_path):
         names, lens = synth.genome_c2(scale=0.004)
         rec = synth.gen_records_numpy(lens, 4000000, seed=5)
         synth.write_bam(bam, names, lens, rec, procs=8, payload=False)
-    err_d = _run_cli(["-i", bam, "-o", str(tmp_path / "dev"), "-t", "8"], {"PANDEPTH_DD_BATCH_MB": "1" if kind == "dense" else "4"}, str(tmp_path))
+    err_d = _run_cli(["-i", bam, "-o", str(tmp_path / "dev"), "-t", "8"], {"PANDEPTH_TUNE": "dd_batch_mb=" + ("1" if kind == "dense" else "4")}, str(tmp_path))
     assert "runs (compact session)" in err_d, err_d[-1500:]
-    _run_cli(["-i", bam, "-o", str(tmp_path / "host"), "-t", "8"], {"PANDEPTH_DEVICE_DECODE": "0"}, str(tmp_path))
+    _run_cli(["-i", bam, "-o", str(tmp_path / "host"), "-t", "8"], {"PANDEPTH_TUNE": "device_decode=0"}, str(tmp_path))
     assert (tmp_path / "dev.chr.stat.gz").read_bytes() == (tmp_path / "host.chr.stat.gz").read_bytes()
     # the same file through a mode that needs the cells (no compact session): still the same table as the host readers give
-    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "devw"), "-t", "8"], {"PANDEPTH_DD_BATCH_MB": "4"}, str(tmp_path))
-    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "hostw"), "-t", "8"], {"PANDEPTH_DEVICE_DECODE": "0"}, str(tmp_path))
+    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "devw"), "-t", "8"], {"PANDEPTH_TUNE": "dd_batch_mb=4"}, str(tmp_path))
+    _run_cli(["-i", bam, "-w", "1000", "-o", str(tmp_path / "hostw"), "-t", "8"], {"PANDEPTH_TUNE": "device_decode=0"}, str(tmp_path))
     assert (tmp_path / "devw.win.stat.gz").read_bytes() == (tmp_path / "hostw.win.stat.gz").read_bytes()

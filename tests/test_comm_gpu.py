@@ -108,9 +108,9 @@ LIST_WIDE = [e for e in MANIFEST if ".list" in e["args"][1] and e["fixture"] in 
 @pytest.mark.parametrize("case", LIST_WIDE, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
 def test_cli_list_mode_sums_through_the_communicator(case, tmp_path):
     """`#.list` inputs in whole-chromosome mode: one context per GPU (all of them when the box has several; one, with
-    PANDEPTH_FORCE_RCCL, otherwise), statistics through pd_comm_init_all + pd_sliced_window_sum — same bytes as the reference."""
+    rccl=force in PANDEPTH_TUNE, otherwise), statistics through pd_comm_init_all + pd_sliced_window_sum — same bytes as the reference."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="rccl=force", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]

@@ -189,7 +189,7 @@ def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, shim
     """`#.list` inputs: one context per (stand-in) GPU, pd_comm_init_all + pd_sliced_window_sum / pd_sliced_interval_sum with N = 2
     and 3 ranks — the same bytes as the reference for whole-chromosome tables, `-w` tables of any width and `-g` / `-b` tables."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_GPUS=gpus, PANDEPTH_RCCL_LIB=shim)
+    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="gpus=" + gpus, PANDEPTH_RCCL_LIB=shim)
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]

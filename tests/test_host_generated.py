@@ -98,10 +98,10 @@ def test_generated_inputs_match_reference(data, cli, name, args, suffix):
     # the pandepth binary decodes BAM on the GPU by default (inflate, record boundaries, filter, CIGAR walk)
     if cli.endswith(":dd"):            # ... in small batches: several per file, several feeder threads
         cli = cli[:-3]
-        env.update(PANDEPTH_DD_BATCH_MB="2")
+        env.update(PANDEPTH_TUNE="dd_batch_mb=2")
     elif cli.endswith(":host"):        # ... or not at all: the host readers (libdeflate) feed pd_push_intervals
         cli = cli[:-5]
-        env.update(PANDEPTH_DEVICE_DECODE="0")
+        env.update(PANDEPTH_TUNE="device_decode=0")
     for t in ("1", "5"):
         p = subprocess.run([cli] + args + ["-o", "mine_" + name, "-t", t], cwd=data, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=900, env=env)
@@ -210,7 +210,7 @@ def test_damage_between_target_chunks_is_nobodys_business(data):
         b[(offs[m] + 18 + offs[m + 1] - 8) // 2] ^= 0x10             # inside the member's deflate stream
         (work / "m.bam").write_bytes(bytes(b))
         got = []
-        for env in ({"PANDEPTH_DD_BATCH_MB": "2", "PANDEPTH_TIMING": "1"}, {"PANDEPTH_DEVICE_DECODE": "0"}):
+        for env in ({"PANDEPTH_TUNE": "dd_batch_mb=2", "PANDEPTH_TIMING": "1"}, {"PANDEPTH_TUNE": "device_decode=0"}):
             p = subprocess.run([cli, "-i", "m.bam", "-b", "gap.bed", "-o", "o", "-t", "3"], cwd=work, stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
             f = work / "o.bed.stat.gz"
@@ -267,7 +267,7 @@ def test_declined_pass_has_counted_nothing(data):
     (work / "m.bam.bai").write_bytes(bai)
     (work / "m.bam").write_bytes(bam)
     subprocess.run([cli, "-i", "m.bam", "-b", "gap.bed", "-o", "clean"], cwd=work, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                   env=dict(os.environ, PANDEPTH_DEVICE_DECODE="0"))
+                   env=dict(os.environ, PANDEPTH_TUNE="device_decode=0"))
     want = (work / "clean.bed.stat.gz").read_bytes()
     hit = 0
     for ga, gb in [(gaps[0], gaps[-1]), (gaps[1], gaps[-2]), (gaps[0], gaps[len(gaps) // 2])]:
@@ -277,7 +277,7 @@ def test_declined_pass_has_counted_nothing(data):
         b[(offs[ga] + 18 + offs[ga + 1] - 8) // 2] ^= 0x10             # early gap member: its deflate stream (the unit goes back)
         b[offs[gb]] ^= 0xff                                            # late gap member: its magic (the member scan stops short)
         (work / "m.bam").write_bytes(bytes(b))
-        for env in ({"PANDEPTH_DD_BATCH_MB": "1", "PANDEPTH_TIMING": "1"}, {"PANDEPTH_DEVICE_DECODE": "0"}):
+        for env in ({"PANDEPTH_TUNE": "dd_batch_mb=1", "PANDEPTH_TIMING": "1"}, {"PANDEPTH_TUNE": "device_decode=0"}):
             p = subprocess.run([cli, "-i", "m.bam", "-b", "gap.bed", "-o", "o", "-t", "1"], cwd=work, stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
             assert p.returncode == 0, p.stderr.decode()[-400:]

@@ -103,7 +103,7 @@ def test_parallel_site_writer_same_text_as_single_stream(cli, tmp_path, golden_d
     threads (pgz::Stream).  The fallback for text pgz declines — concatenated gzip members above a size threshold — has
     different .gz bytes, identical decompressed bytes (and is still one valid gzip file)."""
     d = os.path.join(golden_dir, "f3")
-    for name, env in (("serial", {}), ("par", {"PANDEPTH_SITE_IDENTICAL": "0", "PANDEPTH_SITE_PARALLEL_MIN": "1"})):
+    for name, env in (("serial", {}), ("par", {"PANDEPTH_TUNE": "site_identical=0,site_parallel_min=1"})):
         p = subprocess.run([cli, "-i", "tiny.bam", "-w", "100", "-a", "-t", "4", "-o", str(tmp_path / name)], cwd=d,
                            env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-300:]
@@ -122,7 +122,7 @@ def test_parallel_site_writer_backpressure(cli, tmp_path):
     sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:30000000\nr\t0\tc\t1000\t60\t100M\t*\t0\t0\t*\t*\n"
     (tmp_path / "big.sam").write_text(sam)
     p = subprocess.run([cli, "-i", "big.sam", "-a", "-t", "2", "-o", "o"], cwd=tmp_path, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, PANDEPTH_SITE_IDENTICAL="0"))
+                       stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, PANDEPTH_TUNE="site_identical=0"))
     assert p.returncode == 0, p.stderr.decode()[-300:]
     import zlib
     d = zlib.decompressobj(31)

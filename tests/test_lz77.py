@@ -79,7 +79,7 @@ def test_device_parse_equals_zlib(corpus, name, geo):
 @pytest.mark.gpu
 def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
     """`pandepth -w 100 -a`: both gzip streams with stage 1 on the GPU (pd_deflate_parse) — the same bytes as with zlib parsing on the
-    host threads (PANDEPTH_DEVICE_DEFLATE=0) and as the reference binary's files where it is present."""
+    host threads (device_deflate=0 in PANDEPTH_TUNE) and as the reference binary's files where it is present."""
     import sys
     sys.path.insert(0, ROOT)
     from tools import synth
@@ -90,8 +90,8 @@ def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
     subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth_index"), bam], check=True)
     cli = os.path.join(ROOT, "pandepth_amd", "pandepth")
     outs = {}
-    for tag, env in (("dev", {"PANDEPTH_TIMING": "1", "PANDEPTH_TABLE_RESIDENT_MIN": "1"}),
-                     ("hosttext", {"PANDEPTH_TIMING": "1", "PANDEPTH_SITE_RESIDENT": "0", "PANDEPTH_TABLE_RESIDENT": "0"}), ("host", {"PANDEPTH_DEVICE_DEFLATE": "0"})):
+    for tag, env in (("dev", {"PANDEPTH_TIMING": "1", "PANDEPTH_TUNE": "table_resident_min=1"}),
+                     ("hosttext", {"PANDEPTH_TIMING": "1", "PANDEPTH_TUNE": "site_resident=0,table_resident=0"}), ("host", {"PANDEPTH_TUNE": "device_deflate=0"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "8"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=900, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-600:]
@@ -125,10 +125,10 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
     synth.write_bam(bam, names, lens, rec, procs=2, payload=False)
     cli = os.path.join(H, "pandepth_oracle_cli")
     outs = {}
-    for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32", "PANDEPTH_TABLE_RESIDENT_MIN": "1"}),
+    for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32", "PANDEPTH_TUNE": "table_resident_min=1"}),
                      ("full", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_CAP": "4000000"}),
-                     ("flaky", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_PARSE_FAIL": "3", "PANDEPTH_TABLE_RESIDENT_MIN": "1"}),
-                     ("hosttext", {"PANDEPTH_SITE_RESIDENT": "0", "PGZ_DEV_BATCH_MB": "1"}), ("zlib", {"PANDEPTH_TEST_NO_PARSE": "1"})):
+                     ("flaky", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_PARSE_FAIL": "3", "PANDEPTH_TUNE": "table_resident_min=1"}),
+                     ("hosttext", {"PANDEPTH_TUNE": "site_resident=0", "PGZ_DEV_BATCH_MB": "1"}), ("zlib", {"PANDEPTH_TEST_NO_PARSE": "1"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "4"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=1500, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-600:]

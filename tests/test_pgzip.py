@@ -110,7 +110,7 @@ def test_edge_cases(check, tmp_path):
 
 
 def test_cli_tables_through_the_parallel_writer(check, tmp_path):
-    """the host pipeline with the writer forced onto pgz for every output (PANDEPTH_PGZ_MIN=0): the golden gz bytes"""
+    """the host pipeline with the writer forced onto pgz for every output (pgz_min=0 in PANDEPTH_TUNE): the golden gz bytes"""
     import json
     import hashlib
     cli = os.path.join(HERE, "harness", "pandepth_oracle_cli")
@@ -123,7 +123,7 @@ def test_cli_tables_through_the_parallel_writer(check, tmp_path):
         args = [cli] + case["args"] + ["-o", str(out)]
         if "-t" not in case["args"]:
             args += ["-t", "4"]
-        p = subprocess.run(args, cwd=d, capture_output=True, timeout=600, env=dict(os.environ, PANDEPTH_PGZ_MIN="0"))
+        p = subprocess.run(args, cwd=d, capture_output=True, timeout=600, env=dict(os.environ, PANDEPTH_TUNE="pgz_min=0"))
         assert p.returncode == case["returncode"]
         for suffix, meta in case["outputs"].items():
             gz = open(str(out) + "." + suffix, "rb").read()

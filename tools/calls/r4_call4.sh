@@ -11,4 +11,4 @@ for pass in 1 2; do
 done
 cat $O/ab.log
 # the GPU tests of the decoder with the working tree's library (v1)
-cd $GRAFT_REPO_ROOT && timeout 600 python -m pytest tests/test_gpu_bgzf.py tests/test_cli_gpu.py -q -x --timeout 300 > $O/pytest_bgzf.log 2>&1; tail -3 $O/pytest_bgzf.log
+cd $GRAFT_REPO_ROOT && VARIANTS=c803,c703,c704,c802 EXPORT=0 timeout 300 python tools/ubench/direct_ab.py > $O/direct_ab.log 2>&1; tail -5 $O/direct_ab.log; timeout 900 python -m pytest tests/test_gpu_bgzf.py tests/test_cli_gpu.py tests/test_gpu_engine.py -q -x --timeout 300 > $O/pytest_bgzf.log 2>&1; tail -3 $O/pytest_bgzf.log

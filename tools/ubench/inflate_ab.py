@@ -24,7 +24,7 @@ name = os.path.basename(os.environ.get("PANDEPTH_AMD_LIB", "libpandepth_amd.so")
 for w in [int(x) for x in os.environ.get("WAVES", "16").split(",")]:
     variant = 2 + (w << 4)
     try:
-        out, ms, nb, n = capi.bgzf_inflate(data, variant=variant, reps=5, want_output=True)
+        out, ms, nb, n = capi.bgzf_inflate(data, variant=variant, reps=int(os.environ.get("REPS", "5")), want_output=True)
     except Exception as ex:  # noqa: BLE001
         print("%-28s %2d waves/CU: FAILED %r" % (name, w, ex), flush=True)
         continue
