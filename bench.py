@@ -400,8 +400,8 @@ def e2e_leg(records, site_records, fullsize_site=False):
                 e2e["annotation"] = e2e_annotation(td, bam, cli, ref, threads, records)
             except Exception as ex:                 # noqa: BLE001
                 e2e["annotation"] = {"failed": repr(ex)[:300]}
-        if fullsize_site and records >= 9e8:
-            try:                                    # configs[3] at full size on this very file
+        if fullsize_site and records >= 9e8 and os.statvfs(td).f_bavail * os.statvfs(td).f_frsize > 12e9:
+            try:                                    # configs[3] at full size on this very file (9.5 GB of output)
                 e2e["site_windows_fullsize"] = e2e_site_windows_fullsize(td, bam, cli, threads, records)
             except Exception as ex:                 # noqa: BLE001
                 e2e["site_windows_fullsize"] = {"failed": repr(ex)[:300]}
@@ -561,7 +561,7 @@ def main():
     ap.add_argument("--records", type=float, default=1.0e9, help="alignment records per GPU (per sample)")
     ap.add_argument("--e2e-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_RECORDS", "-1")),
                     help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip; "
-                         "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write; -1 (default) = 1e9 when /tmp has 120 GB "
+                         "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write; -1 (default) = 1e9 when /tmp has 70 GB "
                          "free, otherwise 3e8 — the line says which and why)")
     ap.add_argument("--e2e-multi-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_MULTI_RECORDS", "1.0e8")),
                     help="records per BAM of the multi-BAM `#.list` end-to-end leg (one BAM per GPU of the run; 0 = skip)")
@@ -577,10 +577,10 @@ def main():
             free = st.f_bavail * st.f_frsize
         except OSError:
             free = 0
-        if free >= 120e9:
+        if free >= 70e9:
             args.e2e_records, e2e_size_note = 1.0e9, "BASELINE's configs[1] in full (1e9 records, 3.0 Gb genome): /tmp has %.0f GB free" % (free / 1e9)
         else:
-            args.e2e_records, e2e_size_note = 3.0e8, "3e8 records instead of configs[1]'s 1e9: /tmp has only %.0f GB free (the 53 GB file and its outputs want 120)" % (free / 1e9)
+            args.e2e_records, e2e_size_note = 3.0e8, "3e8 records instead of configs[1]'s 1e9: /tmp has only %.0f GB free (the 53 GB file and the 9.5 GB of `-w 100 -a` output want 70)" % (free / 1e9)
 
     # the contract: rank 0 prints ONE JSON line on stdout.  Libraries loaded below write there too (RCCL announces its version
     # when a communicator is made): file descriptor 1 is pointed at stderr for the life of the process and the line goes to

@@ -15,6 +15,10 @@ int main(int argc, char **argv)
         pd_comm_init_all, pd_sliced_window_sum, pd_comm_destroy, pd_comm_strerror, pd_format_sites, pd_keep_deferred, pd_deflate_parse, pd_host_register, pd_host_unregister,
         pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes, pd_sliced_interval_sum,
     };
+    // The decoder keeps six batches in flight on six streams (plus the statistics, compose and parse streams); the runtime maps a
+    // process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait for
+    // each other's kernels.  Eight queues: 0.83-0.91 s instead of 0.94 s of decode on the 3e8-record file (profiles/r04_decode_matrix.txt).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
     // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory
