@@ -226,6 +226,7 @@ struct pd_ctx {
     bool sums_stale = false;                                      // the tile sums hold what a direct export wrote while the sample is still deferred
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
     bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
+    unsigned lz_group = 0;                                        // chunks per workgroup of the LDS parse ("lz_group", up to 16; 0, the default: every chunk parses with its text in memory — measured faster at 16 + 4 KiB chunks)
     unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
     uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
     int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
@@ -285,7 +286,7 @@ struct pd_ctx {
     // pd_deflate_parse's work buffers (device memory, grown on demand, kept until pd_destroy): two slots, each with its stream, so that
     // two calls overlap (one's copies under the other's kernels)
     struct LzWork {
-        static constexpr int N = 14;
+        static constexpr int N = 16;
         void *p[N] = {}; size_t cap[N] = {};
         bool fit(int k, size_t bytes)
         {
@@ -790,6 +791,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
+    if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 20) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 20]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
@@ -2270,13 +2272,43 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
     const size_t nh = (size_t)256 * n_blocks + 16;
     const size_t want[pd_ctx::LzWork::N] = {n_text + 64, (size_t)np * 8 + 64, (size_t)np * 8 + 64, nh * 4, (nh / 1024 + 8) * 4, (size_t)np * 4 + 64, (size_t)n_text * 4 + 64,
                                     ((size_t)32768 + 8) * 4, (size_t)n_chunks * 24, ((size_t)n_chunks + 1) * 8, (size_t)n_chunks * stride * 4, (size_t)n_chunks * 4 + 16, 0,
-                                    (size_t)n_chunks * 4 + 16};
+                                    (size_t)n_chunks * 4 + 16, (size_t)n_chunks * sizeof(pdk::LzGroup) + 16, (size_t)n_chunks * 4 + 16};
     for (int k = 0; k < pd_ctx::LzWork::N; ++k)
         if (!w.fit(k, want[k])) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_deflate_parse: device allocation failed"); }
     uint8_t *d_text = (uint8_t *)w.p[0]; uint64_t *ka = (uint64_t *)w.p[1], *kb = (uint64_t *)w.p[2];
     uint32_t *hist = (uint32_t *)w.p[3], *scan_tmp = (uint32_t *)w.p[4], *S = (uint32_t *)w.p[5], *R = (uint32_t *)w.p[6], *bucket = (uint32_t *)w.p[7];
     uint64_t *d_chunks = (uint64_t *)w.p[8], *d_off = (uint64_t *)w.p[9]; uint32_t *d_syms = (uint32_t *)w.p[10], *d_cnt = (uint32_t *)w.p[11], *d_crc = (uint32_t *)w.p[13];
     auto cleanup = [&]() { for (auto &x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } };
+    // Consecutive chunks whose text — the first one's history up to the last one's end — fits a CU's LDS parse as one workgroup
+    // (pd_deflate.hip: k_lz_parse_lds).  A chunk qualifies when its history is zlib's whole window or begins with the text: its
+    // candidates (nearer than 32 506 bytes) then lie inside what the group holds.  The others parse with the text in memory.
+    std::vector<pdk::LzGroup> groups;
+    std::vector<uint32_t> loose;
+    uint32_t group_waves = 0; size_t lds_bytes = 0;
+    {
+        int lds_max = 0;
+        if (c->lz_group == 0 || hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) { (void)hipGetLastError(); lds_max = 0; }
+        if (lds_max > (int)pdk::LZ_LDS_MAX) lds_max = (int)pdk::LZ_LDS_MAX;
+        if (lds_max > 0 && !pdk::lz_parse_lds_ready((size_t)lds_max)) lds_max = 0;
+        auto fits = [&](const pd_lz_chunk &ch) { return ch.origin == 0 || ch.start - ch.origin == 32768; };
+        uint32_t k = 0;
+        while (k < n_chunks) {
+            const uint64_t base = chunks[k].origin;
+            uint32_t count = 0; uint64_t hi = 0, len = 0;
+            for (uint32_t j = k; lds_max > 0 && j < n_chunks && count < c->lz_group && fits(chunks[j]) && chunks[j].origin >= base; ++j) {
+                const uint64_t nhi = std::max<uint64_t>(hi, chunks[j].end);
+                const uint64_t nlen = std::min<uint64_t>(nhi + pdk::LZ_LDS_SLACK, (uint64_t)n_text + 32) - base;
+                if ((base & 15) + nlen + 16 > (uint64_t)lds_max) break;
+                hi = nhi; len = nlen; ++count;
+            }
+            if (!count) { loose.push_back(k); ++k; continue; }
+            groups.push_back(pdk::LzGroup{k, count, base, len});
+            group_waves = std::max(group_waves, count);
+            lds_bytes = std::max<size_t>(lds_bytes, (size_t)(((base & 15) + len + 15) & ~(uint64_t)15));
+            k += count;
+        }
+    }
+    pdk::LzGroup *d_groups = (pdk::LzGroup *)w.p[14]; uint32_t *d_loose = (uint32_t *)w.p[15];
     tick();
     hipStream_t st = w.st;
     std::vector<uint32_t> counts(n_chunks);
@@ -2297,6 +2329,8 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
         if (got != n_text) { (void)hipStreamSynchronize(st); cleanup(); return fail(c, PD_EINVAL, "pd_text_parse: the stretch is not (or no longer) in the stream"); }
     } else if (e == hipSuccess) e = hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chunks, chunks, (size_t)n_chunks * 24, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !groups.empty()) e = hipMemcpyAsync(d_groups, groups.data(), groups.size() * sizeof(pdk::LzGroup), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !loose.empty()) e = hipMemcpyAsync(d_loose, loose.data(), loose.size() * 4, hipMemcpyHostToDevice, st);
     static_assert(sizeof(pd_lz_chunk) == 24, "pd_lz_chunk layout");
     if (dbg && e == hipSuccess) e = hipStreamSynchronize(st);
     tick();
@@ -2305,7 +2339,7 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
         launch_lz_sort(st, d_text, np, ka, kb, hist, scan_tmp, S, R, bucket);
         if (prof) (void)hipEventRecord(ev[1], st);
         if (dbg) { (void)hipStreamSynchronize(st); tick(); }
-        launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, n_chunks, d_syms, stride, d_cnt);
+        launch_lz_parse(st, d_text, n_text, S, R, bucket, d_chunks, d_groups, (uint32_t)groups.size(), group_waves, lds_bytes, d_loose, (uint32_t)loose.size(), d_syms, stride, d_cnt);
         if (prof) (void)hipEventRecord(ev[2], st);
         if (crc_out) launch_lz_crc(st, d_text, d_chunks, n_chunks, crc_span, d_crc);
         e = hipGetLastError();
@@ -2354,6 +2388,8 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
         }
     }
     tick();
+    if (dbg && ti >= 7)
+        fprintf(stderr, "[lz] %zu groups of up to %u chunks with their text in LDS (%zu bytes a workgroup), %zu chunks with the text in memory\n", groups.size(), group_waves, lds_bytes, loose.size());
     if (dbg && ti >= 7)
         fprintf(stderr, "[lz] %.1f MB, %u chunks, %.1f M symbols: buffers %.4f, text to the device %.4f, sort %.4f, parse %.4f, gather %.4f, symbols back %.4f s\n", n_text / 1e6,
                 n_chunks, total / 1e6, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);

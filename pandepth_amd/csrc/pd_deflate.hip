@@ -33,7 +33,10 @@ struct DevWaveZ {                               // the hardware wavefront (pd_lz
         for (int o = 32; o; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
         return m;
     }
-    __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
+    // (lane is the same in every lane: a lane read through a scalar register instead of a trip through the LDS crossbar)
+    __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x.v, __builtin_amdgcn_readfirstlane(lane)); }
+    __device__ static __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    __device__ static __forceinline__ void loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }            // s_waitcnt vmcnt(0)
     __device__ static __forceinline__ bool lead() { return (threadIdx.x & 63) == 0; }
 };
 
@@ -105,22 +108,48 @@ __global__ __launch_bounds__(WGZ) void k_lz_ranks(const uint64_t *sorted, uint32
 }
 
 // ---- the parse: one wave per chunk ----
-// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each XCD with its own L2.  A chunk's candidates
-// lie in the 32 KiB before it, so neighbouring chunks share their text: XCD x takes the x-th eighth of the chunks (xcd_chunks each) and
-// walks it with `per_xcd` waves that take consecutive chunks — the text an XCD works on at any time is per_xcd x 16 KiB, not the
-// whole round (the counters showed 48 GB fetched for 48 MB of text with chunks dealt round-robin).
-__global__ __launch_bounds__(64) void k_lz_parse(const pdz::Text T, const uint64_t *chunks /* start, end, origin per chunk */, uint32_t n_chunks,
-                                                 uint32_t *syms, uint64_t stride, uint32_t *counts, uint32_t xcd_chunks, uint32_t per_xcd)
+// A chunk's candidates lie in the 32 KiB before it and every visited position compares up to 128 of them: with the text in HBM that
+// was a cache line per candidate (the counters: 48 GB fetched for a 48 MB text), and a visit lasted two dependent trips to memory.
+// k_lz_parse_lds: a workgroup takes a GROUP of consecutive chunks (pdk::LzGroup, made by the caller), copies the text they read —
+// the first chunk's history up to the last chunk's end — into LDS once (152 KiB for seven chunks of 16 + 4 KiB) and every wave
+// parses its chunk from there; S[] and R[] stay in memory and are fetched a visit ahead (pd_lz77.h: fetch, RWin).  Workgroups are
+// handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each XCD with its own L2: XCD x takes the x-th eighth of the
+// groups, so the S / R lines an XCD has in its L2 belong to one stretch of the text.
+// k_lz_parse: the same parse with the text read from memory — chunks that fit no group (a history shorter than zlib's window in the
+// middle of a text, a lone oversized chunk).
+__global__ __launch_bounds__(64) void k_lz_parse(const pdz::Text T, const uint64_t *chunks /* start, end, origin per chunk */, const uint32_t *list, uint32_t n_list,
+                                                 uint32_t *syms, uint64_t stride, uint32_t *counts)
 {
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    for (uint32_t j = slot; j < xcd_chunks; j += per_xcd) {
-        const uint32_t c = xcd * xcd_chunks + j;
-        if (c >= n_chunks) break;
+    for (uint32_t j = blockIdx.x; j < n_list; j += gridDim.x) {
+        const uint32_t c = list[j];
         const uint64_t start = chunks[3 * c], end = chunks[3 * c + 1], origin = chunks[3 * c + 2];
         pdz::Out o{syms + (uint64_t)c * stride, 0u, (uint32_t)stride};
         const bool ok = pdz::parse_chunk<DevWaveZ>(T, start, end, origin, o);
         if ((threadIdx.x & 63) == 0) counts[c] = ok ? o.n : 0xFFFFFFFFu;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_lz_parse_lds(const pdz::Text T, const uint64_t *chunks, const LzGroup *groups, uint32_t n_groups, uint32_t per_xcd,
+                                                       uint32_t *syms, uint64_t stride, uint32_t *counts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_text[];
+    const uint32_t g = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (g >= n_groups) return;
+    const LzGroup G = groups[g];
+    const uint64_t a16 = G.base & ~15ull;                       // (the text's buffer is 256-byte aligned and carries 64 bytes behind its end)
+    const uint32_t pad = (uint32_t)(G.base - a16), bytes = pad + (uint32_t)G.len;
+    for (uint32_t i = threadIdx.x * 16u; i < bytes; i += blockDim.x * 16u)
+        *reinterpret_cast<uint4 *>(lds_text + i) = *reinterpret_cast<const uint4 *>(T.text + a16 + i);
+    __syncthreads();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // (the wave's number, in a scalar register: so is the parse's whole state)
+    if (w >= G.count) return;
+    pdz::Text L = T;
+    L.text = lds_text + pad; L.lo = G.base;
+    const uint32_t c = G.first + w;
+    const uint64_t start = chunks[3 * c], end = chunks[3 * c + 1], origin = chunks[3 * c + 2];
+    pdz::Out o{syms + (uint64_t)c * stride, 0u, (uint32_t)stride};
+    const bool ok = pdz::parse_chunk<DevWaveZ>(L, start, end, origin, o);
+    if ((threadIdx.x & 63) == 0) counts[c] = ok ? o.n : 0xFFFFFFFFu;
 }
 
 // ---- the chunks' symbols, one after the other ----
@@ -202,16 +231,28 @@ void launch_lz_sort(hipStream_t st, const uint8_t *text, uint32_t np, uint64_t *
     hipLaunchKernelGGL(k_lz_ranks, dim3((unsigned)(ge > 65536 ? 65536 : ge)), dim3(WGZ), 0, st, (const uint64_t *)src, np, S, R, bucket);
 }
 
-void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
-                     const uint64_t *chunks, uint32_t n_chunks, uint32_t *syms, uint64_t stride, uint32_t *counts)
+// Chunks in groups (the text of a group fits LDS) + the list of chunks outside any group; groups / list: device copies.
+bool lz_parse_lds_ready(size_t lds_bytes)
 {
-    if (!n_chunks) return;
+    static int state = 0;                                       // 0 unknown, 1 usable, -1 not
+    static size_t granted = 0;
+    if (state == 0 || (state == 1 && lds_bytes > granted)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lz_parse_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_LDS_MAX);
+        if (e != hipSuccess) { (void)hipGetLastError(); state = -1; } else { state = 1; granted = LZ_LDS_MAX; }
+    }
+    return state == 1 && lds_bytes <= granted;
+}
+
+void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
+                     const uint64_t *chunks, const LzGroup *groups, uint32_t n_groups, uint32_t group_waves, size_t lds_bytes,
+                     const uint32_t *list, uint32_t n_list, uint32_t *syms, uint64_t stride, uint32_t *counts)
+{
     const pdz::Text T{text, S, R, bucket, n_text};
-    const uint32_t xcd_chunks = (n_chunks + 7) / 8;
-    uint32_t per_xcd = 1024;                                    // waves per XCD: 32 CUs x 4 SIMDs x 8 (all that fit)
-    if (const char *e = getenv("PD_LZ_PER_XCD")) { const long v = atol(e); if (v >= 1 && v <= 65536) per_xcd = (uint32_t)v; }
-    if (per_xcd > xcd_chunks) per_xcd = xcd_chunks;
-    hipLaunchKernelGGL(k_lz_parse, dim3(8 * per_xcd), dim3(64), 0, st, T, chunks, n_chunks, syms, stride, counts, xcd_chunks, per_xcd);
+    if (n_groups) {
+        const uint32_t per_xcd = (n_groups + 7) / 8;
+        hipLaunchKernelGGL(k_lz_parse_lds, dim3(8 * per_xcd), dim3(64 * group_waves), lds_bytes, st, T, chunks, groups, n_groups, per_xcd, syms, stride, counts);
+    }
+    if (n_list) hipLaunchKernelGGL(k_lz_parse, dim3(n_list < 8192u ? n_list : 8192u), dim3(64), 0, st, T, chunks, list, n_list, syms, stride, counts);
 }
 
 void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out)

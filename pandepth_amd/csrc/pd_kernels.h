@@ -143,8 +143,14 @@ size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 namespace pdk {
 void launch_lz_sort(hipStream_t st, const uint8_t *text, uint32_t np, uint64_t *keys_a, uint64_t *keys_b, uint32_t *hist, uint32_t *scan_tmp,
                     uint32_t *S, uint32_t *R, uint32_t *bucket);
+// The parse takes consecutive chunks in GROUPS whose text — the first chunk's history up to the last chunk's end plus LZ_LDS_SLACK — fits the
+// LDS of a CU (one wave per chunk, at most LZ_GROUP_MAX); the chunks of no group are listed and parsed with the text in memory.
+struct LzGroup { uint32_t first, count; uint64_t base, len; };     // chunks [first, first + count); text [base, base + len) goes to LDS
+enum : uint32_t { LZ_LDS_MAX = 160u * 1024u, LZ_LDS_SLACK = 512u, LZ_GROUP_MAX = 16u };
+bool lz_parse_lds_ready(size_t lds_bytes);                         // the device grants a workgroup that much LDS
 void launch_lz_parse(hipStream_t st, const uint8_t *text, uint64_t n_text, const uint32_t *S, const uint32_t *R, const uint32_t *bucket,
-                     const uint64_t *chunks, uint32_t n_chunks, uint32_t *syms, uint64_t stride, uint32_t *counts);
+                     const uint64_t *chunks, const LzGroup *groups, uint32_t n_groups, uint32_t group_waves, size_t lds_bytes,
+                     const uint32_t *list, uint32_t n_list, uint32_t *syms, uint64_t stride, uint32_t *counts);
 void launch_lz_gather(hipStream_t st, const uint32_t *syms, uint64_t stride, const uint64_t *off, uint32_t n_chunks, uint32_t *out);
 // CRC-32 (zlib's) of text[start, min(start + span, end)) of every chunk (start, end, origin triples)
 void launch_lz_crc(hipStream_t st, const uint8_t *text, const uint64_t *chunks, uint32_t n_chunks, uint64_t span, uint32_t *crc);

@@ -38,7 +38,7 @@ void print_help();
 // parsed, how many decode threads / GPUs ...), never what it prints — come in through ONE door: the hidden option `-X key=value[,key=value]`
 // or the environment variable PANDEPTH_TUNE with the same syntax (tests, benchmarks).  tune("key") returns the value or NULL.
 //   device_decode=0  device_deflate=0  site_resident=0  table_resident=0  table_resident_min=N  site_overlap=0  site_identical=0|1
-//   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_batch_mb=N  inflate_waves=N  decode_only=1
+//   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_batch_mb=N  inflate_waves=N  lz_group=N  decode_only=1
 const char *tune(const char *key);
 long long tune_int(const char *key, long long dflt);
 void tune_add(const std::string &kv_list);

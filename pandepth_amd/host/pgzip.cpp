@@ -438,6 +438,8 @@ struct Chunk {
     std::shared_ptr<SymVec> hold;
     uint32_t crc = 0;                // of [start, end)
     bool ok = false;
+    uint64_t from = ~0ull;           // where the symbols begin when that is not `start` (a chunk parsed again from a hand-over point, see emit_round)
+    uint64_t first() const { return from != ~0ull ? from : start; }
 };
 
 // `text` holds the absolute range [base, ...)
@@ -718,14 +720,16 @@ struct Stream::Impl {
         std::vector<uint64_t> stop(n_eff, 0);
         std::vector<size_t> i_stop(n_eff, 0), i_first(n_eff, 0);
         std::vector<char> st_ok(n_eff, 1);
-        parallel_for(threads, n_eff, [&](size_t k) {
+        size_t mended = 0;
+        auto search = [&](size_t k) {
             const Chunk &a = chunks[k];
+            stop[k] = 0; st_ok[k] = 1;
             i_stop[k] = a.syms.size();
             if (final && a.tail_end == total) { stop[k] = total; return; }
             const Chunk &b = chunks[k + 1];
             // match ends of b inside a's tail (b's parse starts at b.start: only its first symbols are walked)
             std::vector<uint64_t> bends;
-            uint64_t q = b.start;
+            uint64_t q = b.first();
             for (const Sym s : b.syms) {
                 q += sym_len(s);
                 if (q + MARGIN > a.tail_end) break;
@@ -737,7 +741,7 @@ struct Stream::Impl {
             size_t j = bends.size();
             for (size_t i = a.syms.size(); i-- > 0;) {
                 const Sym sy = a.syms[i];                         // symbol i covers [qe - len, qe)
-                if (qe <= b.start) break;
+                if (qe <= b.first()) break;
                 if (is_match(sy) && qe + MARGIN <= a.tail_end) {
                     while (j > 0 && bends[j - 1] > qe) --j;
                     if (j > 0 && bends[j - 1] == qe) { stop[k] = qe; i_stop[k] = i + 1; }   // keep going: an earlier one is better
@@ -745,14 +749,42 @@ struct Stream::Impl {
                 qe -= sym_len(sy);
             }
             if (stop[k] == 0) st_ok[k] = 0;                       // the two parses did not meet inside the tail
-        });
-        for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
+        };
+        parallel_for(threads, n_eff, search);
+        // A pair that did not meet (the two parses can stay out of step for longer than a tail where the text repeats with a long
+        // period) is mended in place: the successor is parsed AGAIN by zlib from a's last match end before it — after a match zlib is
+        // in its start state, so that parse is a's own continuation — and takes over there; its own hand-over to the chunk behind
+        // it is then searched afresh.  Needs the text (a Remote source keeps a round's text until the round behind it is done).
+        for (size_t k = 0; k < n_eff; ++k) {
+            if (st_ok[k]) continue;
+            if (!is_remote || !remote.fetch) return false;
+            const Chunk &a = chunks[k];
+            Chunk &b = chunks[k + 1];
+            uint64_t q = a.first(), q0 = 0; size_t i0 = 0;
+            for (size_t i = 0; i < a.syms.size(); ++i) {
+                q += sym_len(a.syms[i]);
+                if (q > b.start) break;
+                if (is_match(a.syms[i])) { q0 = q; i0 = i + 1; }
+            }
+            if (q0 <= a.start + TAIL || q0 <= a.first()) return false;      // (no match to restart from behind the stretch a's own hand-over lies in)
+            const uint64_t dl = q0 < 32768 ? q0 : 32768;
+            std::vector<uint8_t> tmp((size_t)(b.tail_end - (q0 - dl)) + 64, 0);
+            if (!remote.fetch(q0 - dl, (size_t)(b.tail_end - (q0 - dl)), tmp.data())) return false;
+            Chunk again;
+            again.start = q0; again.end = b.tail_end; again.tail_end = b.tail_end;
+            run_chunk(tmp.data(), q0 - dl, again);
+            if (!again.ok) return false;
+            b.own.swap(again.own); b.syms.p = b.own.data(); b.syms.n = b.own.size(); b.hold.reset(); b.from = q0;
+            stop[k] = q0; i_stop[k] = i0; st_ok[k] = 1;
+            ++mended;
+            if (k + 1 < n_eff) search(k + 1);
+        }
         // the chain of hand-overs: chunk k's symbols start at the previous hand-over
         std::vector<uint64_t> from(n_eff, 0);
         { uint64_t p = pos; for (size_t k = 0; k < n_eff; ++k) { from[k] = p; if (stop[k] <= p && !(final && stop[k] == p && p == total)) return false; p = stop[k]; } }
         parallel_for(threads, n_eff, [&](size_t k) {
             const Chunk &a = chunks[k];
-            uint64_t qa = a.start;
+            uint64_t qa = a.first();
             size_t i = 0;
             while (i < i_stop[k] && qa < from[k]) { qa += sym_len(a.syms[i]); ++i; }
             if (qa != from[k]) st_ok[k] = 0;                      // the hand-over is not a symbol boundary of this parse
@@ -811,7 +843,7 @@ struct Stream::Impl {
         }
         if (!flush_out(final)) return false;
         if (getenv("PGZ_DEBUG"))
-            fprintf(stderr, "[pgz] round: %zu chunks (%zu parsed by the provider), %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, provided, nblocks,
+            fprintf(stderr, "[pgz] round: %zu chunks (%zu parsed by the provider, %zu parsed again where a pair did not meet), %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, provided, mended, nblocks,
                     tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
         return true;
     }
@@ -852,9 +884,12 @@ struct Stream::Impl {
         if (is_remote) {
             work_base = 0;
             if (final) return round_body(true, c_hi);
-            base = c_hi * CH > 32768 ? c_hi * CH - 32768 : 0;      // what the next round still needs
+            // what the next round still needs; released one round late: stage B of a round (run with the next round's stage A) may
+            // fetch text of its chunks (emit_round: a pair of parses that did not meet)
+            const uint64_t rel = base;
+            base = c_hi * CH > 32768 ? c_hi * CH - 32768 : 0;
             worker_ok = true; worker_on = true;
-            worker = std::thread([this, c_hi] { worker_ok = round_body(false, c_hi); if (worker_ok && remote.release) remote.release(base); });
+            worker = std::thread([this, c_hi, rel] { worker_ok = round_body(false, c_hi); if (worker_ok && remote.release && rel) remote.release(rel); });
             return true;
         }
         if (work.capacity() < room) work.reserve(room);      // (first round: both buffers get their final size before any is locked)
@@ -879,7 +914,7 @@ Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, c
     p_->threads = threads < 1 ? 1 : threads;
     p_->sink = std::move(sink);
     p_->parse = p.parse; p_->pin = p.pin; p_->unpin = p.unpin;
-    p_->CH = p.chunk < 16384 ? 16384 : p.chunk;
+    p_->CH = p.chunk < 8192 ? 8192 : p.chunk;
     p_->TAIL = p.tail < 2048 ? 2048 : p.tail;
     if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
     if (p.batch) p_->batch_bytes = p.batch;
@@ -937,7 +972,7 @@ Params Params::for_device(ParseFn fn)
     // lines), and a stream whose parses do not meet there is started over with larger chunks by the caller
     p.chunk = (size_t)1 << 14; p.tail = (size_t)1 << 12; p.batch = (size_t)96 << 20;
     // (measurement knobs: the geometry in KiB / KiB / MiB)
-    if (const char *e = getenv("PGZ_DEV_CHUNK_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 16 && v <= 4096) p.chunk = v << 10; }
+    if (const char *e = getenv("PGZ_DEV_CHUNK_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 8 && v <= 4096) p.chunk = v << 10; }
     if (const char *e = getenv("PGZ_DEV_TAIL_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 2 && (v << 10) < p.chunk) p.tail = v << 10; }
     if (const char *e = getenv("PGZ_DEV_BATCH_MB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= 2048) p.batch = v << 20; }
     p.parse = std::move(fn);

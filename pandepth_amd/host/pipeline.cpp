@@ -428,6 +428,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
     }
     cfg.n_batches = batches.size();
+    if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 

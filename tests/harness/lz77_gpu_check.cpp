@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/pandepth_amd.h"
+#include "../../include/pandepth_amd_dev.h"
 #include "../../pandepth_amd/host/pgzip.h"
 
 static std::vector<uint8_t> slurp(const char *path)
@@ -34,6 +35,7 @@ int main(int argc, char **argv)
     const uint32_t len1[1] = {1000};
     pd_ctx *ctx = nullptr;
     if (pd_create(0, 1, len1, &ctx) != 0) { fprintf(stderr, "pd_create: %s\n", pd_strerror(nullptr)); return 3; }
+    if (const char *e = getenv("LZ_GROUP")) if (pd_set_param(ctx, "lz_group", (uint64_t)atoll(e)) != 0) { fprintf(stderr, "lz_group: %s\n", pd_strerror(ctx)); return 3; }   // (A/B of the LDS parse)
     size_t cap = 16;
     for (auto &c : chunks) cap += c.end - c.start;
     std::vector<uint32_t> syms(cap);

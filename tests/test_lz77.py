@@ -114,7 +114,8 @@ def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
 def test_resident_text_stream_through_the_host_logic(tmp_path):
     """host/pgzip.cpp with a Remote text source (the per-site file whose text stays with the engine: pd_text_*), driven on the CPU
     by the oracle engine's stand-in (tests/harness/oracle_engine.cpp: a byte vector, the product's parse core in host emulation):
-    several rounds, a ring that runs full and is waited for — the same bytes as the host-text path and as zlib-only."""
+    several rounds, a ring that runs full and is waited for, a pair of neighbouring parses that does not meet inside its overlap
+    (mended in place: the successor is parsed again by zlib from the hand-over point) — the same bytes as the host-text path and as zlib-only."""
     import sys
     sys.path.insert(0, ROOT)
     from tools import synth
@@ -128,6 +129,7 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
     for tag, env in (("resident", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_CHUNK_KB": "32", "PANDEPTH_TUNE": "table_resident_min=1"}),
                      ("full", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_CAP": "4000000"}),
                      ("flaky", {"PANDEPTH_TIMING": "1", "PGZ_DEV_BATCH_MB": "1", "PANDEPTH_TEST_TEXT_PARSE_FAIL": "3", "PANDEPTH_TUNE": "table_resident_min=1"}),
+                     ("mended", {"PANDEPTH_TIMING": "1", "PGZ_DEBUG": "1", "PGZ_DEV_BATCH_MB": "1", "PGZ_DEV_TAIL_KB": "2", "PANDEPTH_TUNE": "table_resident_min=1"}),
                      ("hosttext", {"PANDEPTH_TUNE": "site_resident=0", "PGZ_DEV_BATCH_MB": "1"}), ("zlib", {"PANDEPTH_TEST_NO_PARSE": "1"})):
         p = subprocess.run([cli, "-i", "g.bam", "-w", "100", "-a", "-o", tag, "-t", "4"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=1500, env=dict(os.environ, **env))
@@ -138,10 +140,16 @@ def test_resident_text_stream_through_the_host_logic(tmp_path):
             assert "per-site writer (text resident on the device)" in err and " 0 parse calls" not in err, err[-1500:]
         if tag == "resident":
             assert "window table (text resident on the device)" in err and "rows, written" in err, err[-1500:]
+        if tag == "mended":       # 2 KiB of overlap: a pair of neighbouring parses does not meet in it — the successor is parsed again from the hand-over point
+            import re
+            err = p.stderr.decode()
+            assert "per-site writer (text resident on the device)" in err and "per-site writer: producer" not in err, err[-1500:]
+            assert sum(int(m) for m in re.findall(r"(\d+) parsed again", err)) >= 1, err[-1500:]
         if tag == "flaky":        # every third parse call of the engine fails: those chunks are fetched and parsed by zlib on the host
             err = p.stderr.decode()
             assert "pd_text_parse failed" in err and "per-site writer (text resident on the device)" in err, err[-1500:]
     assert outs["resident"] == outs["zlib"] and outs["full"] == outs["zlib"] and outs["hosttext"] == outs["zlib"] and outs["flaky"] == outs["zlib"]
+    assert outs["mended"] == outs["zlib"]
 
 
 def _pgz(check, path, env, *args):
