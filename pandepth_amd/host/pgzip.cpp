@@ -584,6 +584,15 @@ struct Stream::Impl {
 
     // the text stage A reads: a round's text is handed over by the writer, which goes on filling `buf` meanwhile
     std::vector<uint8_t> work; uint64_t work_base = 0;
+    // ... and the text of the round before, which stage B may want to look at again (a pair of parses that did not meet)
+    std::vector<uint8_t> old; uint64_t old_base = 0;
+    bool text_of(uint64_t off, size_t n, uint8_t *dst)
+    {
+        if (is_remote) return remote.fetch && remote.fetch(off, n, dst);
+        if (off >= work_base && off + n <= work_base + work.size()) { memcpy(dst, work.data() + (off - work_base), n); return true; }
+        if (off >= old_base && off + n <= old_base + old.size()) { memcpy(dst, old.data() + (off - old_base), n); return true; }
+        return false;
+    }
     // ... or the text is elsewhere (Remote): no buffers here, positions are the source's
     Remote remote; bool is_remote = false;
     // page-locked stretches of the two text buffers (Params::pin; the buffers are reserved once and never move)
@@ -754,10 +763,10 @@ struct Stream::Impl {
         // A pair that did not meet (the two parses can stay out of step for longer than a tail where the text repeats with a long
         // period) is mended in place: the successor is parsed AGAIN by zlib from a's last match end before it — after a match zlib is
         // in its start state, so that parse is a's own continuation — and takes over there; its own hand-over to the chunk behind
-        // it is then searched afresh.  Needs the text (a Remote source keeps a round's text until the round behind it is done).
+        // it is then searched afresh.  Needs the text: a Remote source keeps a round's text until the round behind it is done, a host
+        // text stays in `old` that long.
         for (size_t k = 0; k < n_eff; ++k) {
             if (st_ok[k]) continue;
-            if (!is_remote || !remote.fetch) return false;
             const Chunk &a = chunks[k];
             Chunk &b = chunks[k + 1];
             uint64_t q = a.first(), q0 = 0; size_t i0 = 0;
@@ -769,7 +778,7 @@ struct Stream::Impl {
             if (q0 <= a.start + TAIL || q0 <= a.first()) return false;      // (no match to restart from behind the stretch a's own hand-over lies in)
             const uint64_t dl = q0 < 32768 ? q0 : 32768;
             std::vector<uint8_t> tmp((size_t)(b.tail_end - (q0 - dl)) + 64, 0);
-            if (!remote.fetch(q0 - dl, (size_t)(b.tail_end - (q0 - dl)), tmp.data())) return false;
+            if (!text_of(q0 - dl, (size_t)(b.tail_end - (q0 - dl)), tmp.data())) return false;
             Chunk again;
             again.start = q0; again.end = b.tail_end; again.tail_end = b.tail_end;
             run_chunk(tmp.data(), q0 - dl, again);
@@ -892,7 +901,9 @@ struct Stream::Impl {
             worker = std::thread([this, c_hi, rel] { worker_ok = round_body(false, c_hi); if (worker_ok && remote.release && rel) remote.release(rel); });
             return true;
         }
-        if (work.capacity() < room) work.reserve(room);      // (first round: both buffers get their final size before any is locked)
+        if (work.capacity() < room) work.reserve(room);      // (first round: the buffers get their final size before any is locked)
+        if (!final && old.capacity() < room) old.reserve(room);
+        old.swap(work); old_base = work_base;                // the text of the round whose stage B is still to come
         work.swap(buf); work_base = base;
         if (final) { buf.clear(); return round_body(true, c_hi); }
         if (parse) ensure_pinned(work.data(), work.size(), work.capacity());

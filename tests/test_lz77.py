@@ -77,6 +77,20 @@ def test_device_parse_equals_zlib(corpus, name, geo):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geo", [("16384", "4096"), ("65536", "2048")], ids=lambda g: "chunk%s_tail%s" % g)
+@pytest.mark.parametrize("name", FILES)
+def test_device_parse_with_the_text_in_lds_equals_zlib(corpus, name, geo):
+    """the same with "lz_group" = 16: consecutive chunks parsed by one workgroup out of the LDS copy of their text (k_lz_parse_lds; nine
+    chunks of 16 + 4 KiB a workgroup, one of 64 + 2 KiB) — opt-in in the product, zlib's symbols all the same"""
+    subprocess.run(["make", "-C", H, "lz77_gpu_check"], check=True, stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(H, "lz77_gpu_check"), str(corpus / name), geo[0], geo[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, LZ_GROUP="16", PD_LZ_DEBUG="1"))
+    assert p.returncode == 0 and " 0 chunks differ" in p.stdout, p.stdout + p.stderr[-1500:]
+    groups = [int(l.split()[1]) for l in p.stderr.splitlines() if l.startswith("[lz] ") and " groups of up to " in l]
+    assert groups and max(groups) > 0, p.stderr[-1500:]
+
+
+@pytest.mark.gpu
 def test_cli_per_site_and_window_files_through_the_device_parse(tmp_path):
     """`pandepth -w 100 -a`: both gzip streams with stage 1 on the GPU (pd_deflate_parse) — the same bytes as with zlib parsing on the
     host threads (device_deflate=0 in PANDEPTH_TUNE) and as the reference binary's files where it is present."""
