@@ -62,6 +62,11 @@ CH, TAIL = 16384, 4096
 chunks = [(s0, min(len(rows), s0 + CH + TAIL), max(0, s0 - 32768)) for s0 in range(0, len(rows) - TAIL, CH)]
 for it in range(2):
     eng.deflate_parse(rows, chunks)
+# the same call with the chunks' text in LDS (k_lz_parse_lds, opt-in "lz_group")
+eng.set_param("lz_group", 16)
+for it in range(2):
+    eng.deflate_parse(rows, chunks)
+eng.set_param("lz_group", 0)
 eng.reset()
 eng.runs_destroy(runs8)
 eng.keep_deferred(False)
