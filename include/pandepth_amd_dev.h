@@ -16,7 +16,7 @@ extern "C" {
  * tile kernels), "scatter_tile" (4096 | 8192), "accumulate_packed" (pd_accumulate_from's transport, default 1), "direct_un"
  * (which compiled variant of the direct kernels runs), "decode_crc" (0: the device decoder skips the members' CRC-32 — kernel
  * timing only), "decode_near_span" (split of the decoder's later-run stream), "inflate_waves" (one-wave inflate workgroups per CU and
- * launch, 1..20), "lz_group" (consecutive chunks per workgroup of pd_deflate_parse's LDS parse, 0..16; 0: every chunk reads its
+ * launch, 1..23: what the kernel's 6 976 bytes of LDS a wave allow; default 20), "lz_group" (consecutive chunks per workgroup of pd_deflate_parse's LDS parse, 0..16; 0: every chunk reads its
  * text from memory). */
 int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
 

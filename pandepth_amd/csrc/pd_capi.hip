@@ -792,7 +792,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
     if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
-    if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 20) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 20]"); c->dec_waves = (unsigned)value; return PD_OK; }
+    if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 23) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 23]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
