@@ -656,7 +656,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
             WANT(c->cand_lo[b], (c->n_tiles * 2 + 4) * 4);
         }
         WANT(c->hstate, c->n_half + 16);
-        WANT(c->slice_flags, slice_flag_bytes(c->n_tiles) + 16 + c->n_tiles * 4 + 16);   // flags | counter | list of flagged tiles
+        WANT(c->slice_flags, slice_flag_bytes(c->n_tiles) + 2 * (16 + ((size_t)c->n_tiles + 4) * 4) + 16);   // flags | counter | list of flagged tiles | counter | list of the tiles the packed sweep leaves
         WANT(c->direct_words, 64 + (c->n_tiles + 4) * 4);        // [n_long, fail, heavy_count, diagnostics ... | heavy tile list at +16]
         WANT(c->desc, sizeof(BatchDesc) * PD_MAXPEND);
         WANT(c->chk, sizeof(CheckWords));
@@ -791,6 +791,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_un")) { c->direct_un = (int)value; return PD_OK; }
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
+    if (!strcmp(name, "sweep_i4_fast")) { pdk::set_sweep_i4_fast(value != 0); return PD_OK; }
     if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 23) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 23]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }

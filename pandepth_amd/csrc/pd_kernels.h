@@ -118,6 +118,7 @@ void launch_export_i4(hipStream_t st, const int *diff, const uint8_t *hstate, vo
                       pd_exc *exc, uint32_t cap, uint32_t *count);
 void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, const pd_exc *exc, uint64_t n_exc,
                    uint64_t n_cells_total, int *dst_base);
+void set_sweep_i4_fast(bool on);               // process-wide A/B switch of the packed statistics kernel of the sliced sum's sweep
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
                      uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes /* bytes of flags; behind them: 16 + 4 * tiles bytes for the list */,
                      const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part,

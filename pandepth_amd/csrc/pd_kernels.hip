@@ -2399,12 +2399,10 @@ __global__ __launch_bounds__(WG) void k_list_flagged(const uint8_t *flags, uint3
 // DEPTH: no statistics — the summed, prefix-summed and wrapped cells of the slice are written out as int32 depth (depth_out: the slice's
 // first cell), for the statistics that need the cells themselves (narrow windows, annotation intervals) on the rank that owns the slice.
 template <bool DEPTH>
-__global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
-                                                      uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t tile_count, int *depth_out)
+__device__ __forceinline__ void sweep_i4_tile_wave(const I4Src &src, const int *carry, uint32_t wrap_mask, const TileMap &tmap,
+                                                   uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t i, int *depth_out)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
-    if (i >= tile_count) return;
     if (src.flags && src.flags[i] != 0) return;                  // a tile with exceptions: k_sweep_i4<true>
     const uint64_t t = (uint64_t)i + tile0;
     const uint8_t *p = src.parts + (uint64_t)i * (TILE / 2) + (uint64_t)lane * 16;
@@ -2545,6 +2543,105 @@ __global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int
     if (lane == 0) { TilePart tp; tp.c0 = (uint32_t)c0; tp.c1 = (uint32_t)c1; tp.s0 = s0; tp.s1 = s1; part[i] = tp; }
 }
 
+// one wave per tile of the slice, or (only != null) the waves of a fixed grid over a list of tiles (the ones k_sweep_i4_fast left)
+template <bool DEPTH>
+__global__ __launch_bounds__(WG) void k_sweep_i4_wave(const I4Src src, const int *carry, uint32_t wrap_mask, const TileMap tmap,
+                                                      uint32_t w, uint32_t min_dep, TilePart *part, uint32_t tile0, uint32_t tile_count, int *depth_out,
+                                                      const uint32_t *only, const uint32_t *n_only)
+{
+    const uint32_t wave = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (!only) {
+        if (wave < tile_count) sweep_i4_tile_wave<DEPTH>(src, carry, wrap_mask, tmap, w, min_dep, part, tile0, wave, depth_out);
+        return;
+    }
+    const uint32_t n = *n_only;
+    for (uint32_t k = wave; k < n; k += gridDim.x * (WG / 64)) sweep_i4_tile_wave<DEPTH>(src, carry, wrap_mask, tmap, w, min_dep, part, tile0, only[k], depth_out);
+}
+
+// The statistics sweep of the tiles that are nothing but common quarters — inside one window, inside the contig, no exceptions, threshold <= 1,
+// depths below 2^16 — in a kernel of their own: the packed path of sweep_i4_tile_wave alone, taken quarter by quarter, needs a third of
+// its registers, so eight waves share a SIMD instead of four.  A tile that turns out not to qualify
+// (a window boundary or a contig's end inside it, a depth of 60 000 or more at some lane's first cell) goes to `slow`, the list
+// k_sweep_i4_wave works through afterwards.
+__global__ __launch_bounds__(WG, 8) void k_sweep_i4_fast(const I4Src src, const int *carry, const TileMap tmap, uint32_t w, uint32_t min_dep, TilePart *part,
+                                                        uint32_t tile0, uint32_t tile_count, uint32_t *slow, uint32_t *n_slow)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (i >= tile_count) return;
+    if (src.flags && src.flags[i] != 0) return;                  // a tile with exceptions: k_sweep_i4<true>
+    const uint64_t t = (uint64_t)i + tile0;
+    const uint32_t ctg = tmap.tile_contig[t];
+    const uint64_t local0 = t * TILE - tmap.contig_off[ctg];
+    const uint32_t clen = tmap.contig_len[ctg];
+    bool fast = local0 < clen && (uint64_t)clen - local0 >= (uint64_t)TILE;
+    if (fast) { const uint64_t k0 = local0 / w; fast = (k0 + 1) * (uint64_t)w - local0 >= (uint64_t)TILE; }
+    if (!fast) { if (lane == 0) slow[atomicAdd(n_slow, 1u)] = i; return; }
+    const uint8_t *p = src.parts + (uint64_t)i * (TILE / 2) + (uint64_t)lane * 16;
+    int base = carry[t];
+    uint32_t c0 = 0; unsigned long long s0 = 0;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint32_t bN = 8u * src.n_parts, ones = 0x01010101u;
+    // quarter by quarter (the running depth makes them sequential anyway), one 16-byte load per part with the next one — the next part's,
+    // or the next quarter's first — in flight: eight accumulators instead of thirty-two
+    uint4 x = *reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t j = 0; j < src.n_parts; ++j) {
+            const bool more = j + 1 < src.n_parts;
+            uint4 nx = x;
+            if (more) nx = *reinterpret_cast<const uint4 *>(p + (uint64_t)(j + 1) * src.stride + q * 1024);
+            else if (q < 3) nx = *reinterpret_cast<const uint4 *>(p + (q + 1) * 1024);
+            const unsigned wd[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { lo[m] += wd[m] & 0x0F0F0F0Fu; hi[m] += (wd[m] >> 4) & 0x0F0F0F0Fu; }
+            x = nx;
+        }
+        // (the arithmetic of sweep_i4_tile_wave's common quarter, see there)
+        const uint32_t t16 = __builtin_amdgcn_udot4(lo[0], ones, 0u, false) + __builtin_amdgcn_udot4(lo[1], ones, 0u, false) +
+                             __builtin_amdgcn_udot4(hi[0], ones, 0u, false) + __builtin_amdgcn_udot4(hi[1], ones, 0u, false);
+        const uint32_t t32 = t16 + __builtin_amdgcn_udot4(lo[2], ones, 0u, false) + __builtin_amdgcn_udot4(lo[3], ones, 0u, false) +
+                             __builtin_amdgcn_udot4(hi[2], ones, 0u, false) + __builtin_amdgcn_udot4(hi[3], ones, 0u, false);
+        const int run = (int)t32 - (int)(32u * bN);
+        const int incl = wave_incl_scan(run);
+        const int b0 = base + incl - run;
+        if (__ballot((uint32_t)b0 >= 60000u) != 0ull) { if (lane == 0) slow[atomicAdd(n_slow, 1u)] = i; return; }
+        uint32_t wsum = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t wl = (32u - (8u * m)) | ((30u - 8u * m) << 8) | ((28u - 8u * m) << 16) | ((26u - 8u * m) << 24);
+            const uint32_t wh = (31u - (8u * m)) | ((29u - 8u * m) << 8) | ((27u - 8u * m) << 16) | ((25u - 8u * m) << 24);
+            wsum = __builtin_amdgcn_udot4(lo[m], wl, wsum, false);
+            wsum = __builtin_amdgcn_udot4(hi[m], wh, wsum, false);
+        }
+        s0 += 32u * (uint32_t)b0 + wsum - bN * 528u;
+        uint32_t cnt = 32u;
+        if (min_dep) {
+            const uint32_t tl = (bN - (uint32_t)b0) & 0xffffu, th = (bN - ((uint32_t)b0 + t16 - 16u * bN)) & 0xffffu;
+            us2 tgt = __builtin_bit_cast(us2, tl | (th << 16)), r = __builtin_bit_cast(us2, 0u), acc = __builtin_bit_cast(us2, 0u);
+            const us2 step = __builtin_bit_cast(us2, bN | (bN << 16)), one2 = __builtin_bit_cast(us2, 0x00010001u);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m = k >> 3, b = (k & 7) >> 1;
+                const uint32_t sel = (uint32_t)b | (0x0cu << 8) | ((4u + (uint32_t)b) << 16) | (0x0cu << 24);
+                const uint32_t pair = (k & 1) ? __builtin_amdgcn_perm(hi[m + 2], hi[m], sel) : __builtin_amdgcn_perm(lo[m + 2], lo[m], sel);
+                r += __builtin_bit_cast(us2, pair);
+                acc += __builtin_elementwise_min((us2)(r - tgt), one2);
+                tgt += step;
+            }
+            const uint32_t a32 = __builtin_bit_cast(uint32_t, acc);
+            cnt = (a32 & 0xffffu) + (a32 >> 16);
+        }
+        c0 += cnt;
+        base += __builtin_amdgcn_readlane(incl, 63);
+    }
+    c0 = (uint32_t)wave_sum((int)c0);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) s0 += __shfl_xor(s0, o);
+    if (lane == 0) { TilePart tp; tp.c0 = c0; tp.c1 = 0; tp.s0 = s0; tp.s1 = 0; part[i] = tp; }
+}
+
 __global__ __launch_bounds__(WG) void k_add_i32(int4 *dst, const int4 *src, size_t n16)
 {
     size_t i = blockIdx.x * (size_t)WG + threadIdx.x;
@@ -2593,6 +2690,11 @@ void launch_add_i4(hipStream_t st, int *dst, const void *img, uint32_t n_tiles, 
     if (n_exc) hipLaunchKernelGGL(k_apply_exceptions, dim3(256), dim3(WG), 0, st, exc, n_exc, dst_base, n_cells_total);
 }
 
+// (A/B switch of the packed statistics kernel: pd_set_param "sweep_i4_fast")
+static bool g_sweep_i4_fast = true;
+void set_sweep_i4_fast(bool on) { g_sweep_i4_fast = on; }
+static bool sweep_i4_fast_on() { return g_sweep_i4_fast; }
+
 void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64_t stride, uint32_t tile_first,
                      uint32_t tile_count, const pd_exc *exc, uint64_t exc_stride, const int32_t *exc_counts, uint8_t *flags, size_t flags_bytes,
                      const int *carry, uint32_t wrap_mask, TileMap tm, uint32_t w, uint32_t min_dep, TilePart *part, int *depth_out)
@@ -2611,8 +2713,16 @@ void launch_sweep_i4(hipStream_t st, const void *parts, uint32_t n_parts, uint64
     I4Src src{(const uint8_t *)parts, stride, n_parts, with_exc ? flags : nullptr, exc, exc_stride, exc_counts};
     if (n_parts <= 16) {
         const dim3 g((tile_count + WG / 64 - 1) / (WG / 64));
-        if (depth_out) hipLaunchKernelGGL(k_sweep_i4_wave<true>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out);
-        else hipLaunchKernelGGL(k_sweep_i4_wave<false>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out);
+        const uint32_t *none = nullptr;
+        // behind the flags and the list of the flagged tiles: a second counter and list, for the tiles the packed kernel leaves
+        uint32_t *n_slow = flags ? reinterpret_cast<uint32_t *>(flags + flags_bytes) + 4 + ((tile_count + 3u) & ~3u) : nullptr, *slow = n_slow ? n_slow + 4 : nullptr;
+        if (depth_out) hipLaunchKernelGGL(k_sweep_i4_wave<true>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out, none, none);
+        else if (n_slow && min_dep <= 1u && wrap_mask >= 0xFFFFu && sweep_i4_fast_on()) {
+            (void)hipMemsetAsync(n_slow, 0, 16, st);
+            hipLaunchKernelGGL(k_sweep_i4_fast, g, dim3(WG), 0, st, src, carry, tm, w, min_dep, part, tile_first, tile_count, slow, n_slow);
+            hipLaunchKernelGGL(k_sweep_i4_wave<false>, dim3(g.x < 1024u ? g.x : 1024u), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count,
+                               depth_out, (const uint32_t *)slow, (const uint32_t *)n_slow);
+        } else hipLaunchKernelGGL(k_sweep_i4_wave<false>, g, dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first, tile_count, depth_out, none, none);
     } else if (depth_out) {                                      // (more than 16 parts: the workgroup form, every tile through the list-less PATCH-free kernel's depth branch)
         hipLaunchKernelGGL(k_sweep_i4<false>, dim3(tile_count), dim3(WG), 0, st, src, carry, wrap_mask, tm, w, min_dep, part, tile_first,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, depth_out);

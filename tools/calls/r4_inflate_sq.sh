@@ -1,10 +1,10 @@
 #!/bin/bash
 # round 4: SQ counters + kernel trace of the ISOLATED wave inflate kernel (pd_x_bgzf_inflate through tools/bgzf_gpu_bench.py,
 # variant 258 = wave per member, 16 waves per CU, CRC check on) — one rocprofv3 --pmc pass per counter set, no tracing with them
-# usage: r4_inflate_sq.sh <out dir under gpurun_out> [records]
+# usage: r4_inflate_sq.sh <out dir under gpurun_out> [records] [variant: 258 = 16 waves per CU (round 3), 322 = 20 (round 4)]
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-inflate_sq}; R=${2:-2e6}
 mkdir -p $O; cd /tmp && export TMPDIR=/tmp
-export BGZF_VARIANTS=258
+export BGZF_VARIANTS=${3:-258}
 timeout 200 python $GRAFT_REPO_ROOT/tools/bgzf_gpu_bench.py $R > $O/bench.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o run -- python $GRAFT_REPO_ROOT/tools/bgzf_gpu_bench.py $R > $O/kt.log 2>&1
 F=$(find $O/kt -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $O/kernel_stats.csv; rm -rf $O/kt
