@@ -613,7 +613,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     # a CPU-side group for the one long wait of an N > 1 run: while rank 0 runs the multi-BAM executable on every GPU the other ranks
     # must not sit in an RCCL barrier (a kernel spinning on their GPUs)
-    cpu_group = dist.new_group(backend="gloo") if use_dist and world > 1 else None
+    cpu_group = dist.new_group(backend="gloo", timeout=__import__("datetime").timedelta(hours=2)) if use_dist and world > 1 else None
 
     R = int(args.records)
     names, lens = synth.genome_c2()
