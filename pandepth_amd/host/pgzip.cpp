@@ -896,7 +896,7 @@ struct Stream::Impl {
             // what the next round still needs; released one round late: stage B of a round (run with the next round's stage A) may
             // fetch text of its chunks (emit_round: a pair of parses that did not meet)
             const uint64_t rel = base;
-            base = c_hi * CH > 32768 ? c_hi * CH - 32768 : 0;
+            base = c_hi * CH > 32768 + CH ? c_hi * CH - 32768 - CH : 0;    // (the history of the chunk that waits for its successor too: it may have to be mended)
             worker_ok = true; worker_on = true;
             worker = std::thread([this, c_hi, rel] { worker_ok = round_body(false, c_hi); if (worker_ok && remote.release && rel) remote.release(rel); });
             return true;
@@ -908,7 +908,7 @@ struct Stream::Impl {
         if (final) { buf.clear(); return round_body(true, c_hi); }
         if (parse) ensure_pinned(work.data(), work.size(), work.capacity());
         // the writer keeps what the next round needs: everything from the dictionary of the next chunk to parse
-        const uint64_t keep = std::max<uint64_t>(work_base, c_hi * CH > 32768 ? c_hi * CH - 32768 : 0);
+        const uint64_t keep = std::max<uint64_t>(work_base, c_hi * CH > 32768 + CH ? c_hi * CH - 32768 - CH : 0);   // (+ the waiting chunk and its history: see emit_round)
         buf.clear();
         if (buf.capacity() < room) buf.reserve(room);
         buf.insert(buf.end(), work.begin() + (std::ptrdiff_t)(keep - work_base), work.end());

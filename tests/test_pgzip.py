@@ -95,6 +95,8 @@ def test_edge_cases(check, tmp_path):
         p = tmp_path / name
         p.write_bytes(data)
         assert verdict(check, p, 4, 65536, 2048) == want, name
+        if name == "zeros":       # rounds of 100 KB: the pairs at the rounds' boundaries are mended from the text the stream keeps of the round before
+            assert verdict(check, p, 4, 65536, 2048, 100000) == want, name
     # mixtures may go either way, but never to different bytes
     rng = random.Random(9)
     for k in range(6):
