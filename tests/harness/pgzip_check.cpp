@@ -6,6 +6,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -55,7 +56,31 @@ int main(int argc, char **argv)
     unlink(tmp);
     std::vector<uint8_t> out;
     bool ok;
-    if (getenv("PGZ_PIECES")) {
+    if (getenv("PGZ_REMOTE")) {
+        // a Remote source (the engine's resident text, pd_text_*): the stream is only told how many bytes exist; parse / fetch answer from `data`, and
+        // what has been RELEASED is gone — a parse or a fetch below the release mark fails, as it does on the device's ring
+        std::atomic<uint64_t> released{0}, n_fetch{0};
+        const pgz::ParseFn emu = pgz::host_emulation_parse();
+        pgz::Remote src;
+        src.parse = [&](uint64_t off, size_t n, const uint64_t *chunks, size_t n_chunks, pgz::SymVec &syms, std::vector<uint64_t> &soff, uint32_t *crc, uint64_t crc_span) -> bool {
+            if (off < released.load() || off + n > data.size()) return false;
+            if (!emu(data.data() + off, n, chunks, n_chunks, syms, soff)) return false;
+            for (size_t k = 0; k < n_chunks; ++k)
+                crc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data.data() + off + chunks[3 * k], (uInt)std::min<uint64_t>(crc_span, chunks[3 * k + 1] - chunks[3 * k]));
+            return true;
+        };
+        src.fetch = [&](uint64_t off, size_t n, uint8_t *dst) { if (off < released.load() || off + n > data.size()) return false; memcpy(dst, data.data() + off, n); ++n_fetch; return true; };
+        src.release = [&](uint64_t off) { if (off > released.load()) released = off; };
+        pgz::Params d = pgz::Params::for_device(nullptr);
+        if (argc > 3) d.chunk = p.chunk;
+        if (argc > 4) d.tail = p.tail;
+        d.batch = argc > 5 ? p.batch : (size_t)2 << 20;
+        pgz::Stream st(threads, [&](const uint8_t *b, size_t k) { out.insert(out.end(), b, b + k); return true; }, d, src);
+        ok = true;
+        for (size_t o = 0; o < data.size() && ok; o += 700000) ok = st.announce(std::min<size_t>(700000, data.size() - o));
+        ok = ok && st.finish();
+        fprintf(stderr, "remote source: %llu fetches, released up to %llu of %zu\n", (unsigned long long)n_fetch.load(), (unsigned long long)released.load(), data.size());
+    } else if (getenv("PGZ_PIECES")) {
         // the streaming interface, fed in pieces of irregular size (as the per-site writer does)
         pgz::Stream st(threads, [&](const uint8_t *b, size_t k) { out.insert(out.end(), b, b + k); return true; }, p);
         unsigned long long x = 88172645463325252ull;

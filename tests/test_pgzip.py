@@ -112,6 +112,23 @@ def test_edge_cases(check, tmp_path):
         verdict(check, p, 2, 131072, 4096)
 
 
+def test_remote_text_source_rounds_release_and_mends(check, tmp_path):
+    """pgz::Stream over a Remote source (what the engine's resident text is to it): the harness answers parse / fetch from the file's bytes and REFUSES
+    anything below the release mark, as the device's ring does.  Small rounds, so that hand-overs at the rounds' boundaries occur; a pure run and a pure
+    period, whose pairs of chunk parses never meet (every successor is parsed again from text the stream must still be able to fetch), and per-site rows."""
+    rng = random.Random(4)
+    per = bytes(rng.randint(0, 255) for _ in range(37))
+    cases = {"zeros": b"\0" * 700000, "period": per * 50000 + bytes(rng.randint(0, 255) for _ in range(900)) + per * 20000, "site": site_table(400000, 5)}
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        for cfg in ((4, 16384, 4096, 200000), (3, 16384, 2048, 100000), (4, 32768, 4096, 1000000)):
+            r = subprocess.run([check, str(p)] + [str(c) for c in cfg], capture_output=True, text=True, timeout=600, env=dict(os.environ, PGZ_REMOTE="1"))
+            assert r.stdout.split()[0] == "identical", (name, cfg, r.stdout, r.stderr[-300:])
+            if name != "site":
+                assert int(r.stderr.split("remote source: ")[1].split()[0]) > 10, r.stderr        # the pairs were mended from fetched text
+
+
 def test_cli_tables_through_the_parallel_writer(check, tmp_path):
     """the host pipeline with the writer forced onto pgz for every output (pgz_min=0 in PANDEPTH_TUNE): the golden gz bytes"""
     import json
