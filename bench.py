@@ -877,10 +877,11 @@ def main():
             key = {"scatter_tiles": "k_scatter_tiles<8192>", "scan_reduce_windows": "k_sweep<false, true, false>",
                    "direct_tiles": "k_direct_c8<" if used_compact else "k_direct_wide3<",
                    "direct_export": "k_direct_c8<" if used_compact else "k_direct_wide3<"}.get(dom)
-            # (template arguments may grow; the compact kernel's export instantiation ends in "true>", the statistics one in "false>")
-            tail = "true>" if dom == "direct_export" else "false>"
+            # (the compact kernel's third template argument says which instantiation it is: true = the export, false = the statistics)
+            import re
+            third = "true" if dom == "direct_export" else "false"
             cands = [k for k in pmc["kernels"] if key and k.startswith(key.rstrip(">"))]
-            key = next((k for k in cands if not used_compact or k.endswith(tail)), None)
+            key = next((k for k in cands if not used_compact or re.match(r"k_direct_c8<\d+, \d+, " + third + r"\b", k)), None)
             if key and R == int(1e9):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except (OSError, IndexError, KeyError, ValueError):
@@ -896,9 +897,10 @@ def main():
             kf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
             want = {"direct_tiles": "k_direct_c8<" if used_compact else "k_direct_wide3<", "scatter_tiles": "k_scatter_tiles<8192>",
                     "scan_reduce_windows": "k_sweep<false, true, false>", "direct_export": "k_direct_c8<" if used_compact else "k_direct_wide3<"}.get(dom)
-            tail = "true>(" if dom == "direct_export" else "false>("
+            import re
+            third = "true" if dom == "direct_export" else "false"
             for row in csv.DictReader(open(kf)):
-                if want and want in row["Name"] and (not used_compact or not want.startswith("k_direct_c8") or tail in row["Name"]):
+                if want and want in row["Name"] and (not used_compact or not want.startswith("k_direct_c8") or re.search(r"k_direct_c8<\d+, \d+, " + third + r"\b", row["Name"])):
                     rocprof_avg = {"avg_launch_ms": round(float(row["AverageNs"]) / 1e6, 4), "calls": int(row["Calls"]), "source": "profiles/" + os.path.basename(kf)}
                     break
         except (OSError, IndexError, KeyError, ValueError):

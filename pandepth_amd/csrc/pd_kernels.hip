@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(WG) void k_r8_to_iv(const Run8 *r8, uint64_t n, Con
 // BOTH streams of the sample (the file's sorted first runs as the decoder wrote them, and the later runs counting-sorted by bucket):
 // one loop over the two ranges laid end to end.  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more
 // than 32 000 candidates go to the int-window kernel through the same list.
-template <int WPE, int UN8, bool EXPORT>
+template <int WPE, int UN8, bool EXPORT, bool JOIN = false>
 __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32_t n_tiles, ContigTab tab, const uint32_t *tile_contig,
                                                      uint32_t wrap_mask, const DirectWide args, uint32_t *heavy_list, uint32_t *heavy_count,
                                                      const DirectExport ex)
@@ -1625,10 +1625,28 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
             // belongs to is a scalar decision (base index, position, end), so the double-buffered loop runs through both without a restart
             constexpr uint32_t C = UN8 * WG;
             const Run8 *__restrict__ const p = cs.r8;
-            const uint32_t c1 = (ns + C - 1) / C, nq = c1 + (no + C - 1) / C;
+            // JOIN: the sorted stream's full chunks, then its remainder and the other stream's runs as ONE sequence (a lane picks its array by
+            // its index there) — four chunks for the typical tile's 2 730 + 300 candidates instead of four + one
+            const uint32_t c1 = JOIN ? ns / C : (ns + C - 1) / C;
+            const uint32_t rem = JOIN ? ns - c1 * C : 0u, tail = rem + no;
+            const uint32_t nq = c1 + ((JOIN ? tail : no) + C - 1) / C;
             const uint32_t o_at = cs.o_base + olo;
             auto load8 = [&](uint2 (&dst)[UN8], const uint32_t q) {
                 const bool second = q >= c1;
+                if constexpr (JOIN) {
+                    if (!second) {
+#pragma unroll
+                        for (int k = 0; k < UN8; ++k) dst[k] = *reinterpret_cast<const uint2 *>(p + (s_at + q * C + threadIdx.x + k * WG));
+                    } else {
+                        const uint32_t i = (q - c1) * C, s_rem = s_at + c1 * C, o_rem = o_at - rem, last = tail - 1u;
+#pragma unroll
+                        for (int k = 0; k < UN8; ++k) {
+                            uint32_t j = i + threadIdx.x + k * WG; j = j < last ? j : last;
+                            dst[k] = *reinterpret_cast<const uint2 *>(p + ((j < rem ? s_rem : o_rem) + j));
+                        }
+                    }
+                    return;
+                }
                 const uint32_t at = second ? o_at : s_at, i = (second ? q - c1 : q) * C, last = (second ? no : ns) - 1u;
 #pragma unroll
                 for (int k = 0; k < UN8; ++k) { const uint32_t j = i + threadIdx.x + k * WG; dst[k] = *reinterpret_cast<const uint2 *>(p + (at + (j < last ? j : last))); }
@@ -1642,7 +1660,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
             };
             auto work8 = [&](const uint2 (&c)[UN8], const uint32_t q) {
                 const bool second = q >= c1;
-                const uint32_t left = (second ? no : ns) - (second ? q - c1 : q) * C;
+                const uint32_t left = JOIN ? (second ? tail - (q - c1) * C : C) : (second ? no : ns) - (second ? q - c1 : q) * C;
                 if (left >= C) {
 #pragma unroll
                     for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
@@ -2902,7 +2920,13 @@ void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t
     // measured on the bench sample (ms): <8, 3> 1.89, <7, 4> 1.99, <7, 3> 2.01, <8, 2> 2.01, <6, 4> 2.16, <7, 2> 2.17, <5, 8> 2.25, <6, 2> 2.40, <5, 4> 2.41, <8, 4> 2.41 (spills),
     // <8, 1> 2.42, <5, 2> 2.70 — k_direct_wide3 on the same sample as 12-byte streams: 3.11
     case 704: PD_C8(7, 4); break;
-    default: PD_C8(8, 3); break;
+    // the joined tail (JOIN): 1000 + the numbers above
+    case 1803: hipLaunchKernelGGL((k_direct_c8<8, 3, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 1703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 1704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 1802: hipLaunchKernelGGL((k_direct_c8<8, 2, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    // round 4, two streams (ms by the context's events, which also bracket the pile-up and finish launches): <8, 3> 2.35; joined tail: <8, 3> 2.33, <8, 2> 2.07, <7, 3> 2.07, <7, 4> 2.04
+    default: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     }
 #undef PD_C8
     WinArgs wa; wa.w = w; wa.min_dep = min_dep; wa.inv_w = 1.0f / (float)w; wa.cover = nullptr; wa.sum = nullptr; wa.part = part;
@@ -2915,7 +2939,7 @@ void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const u
                              uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
 {
     const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
-    hipLaunchKernelGGL((k_direct_c8<7, 4, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
+    hipLaunchKernelGGL((k_direct_c8<7, 4, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
                        DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;
     PendSet none{}; none.nb = 0; none.lmax = 0;
