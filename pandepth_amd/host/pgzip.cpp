@@ -732,9 +732,10 @@ struct Stream::Impl {
         size_t mended = 0;
         auto search = [&](size_t k) {
             const Chunk &a = chunks[k];
-            stop[k] = 0; st_ok[k] = 1;
-            i_stop[k] = a.syms.size();
-            if (final && a.tail_end == total) { stop[k] = total; return; }
+            // (the results are kept in locals and stored once: neighbouring k belong to different threads, and a store per shared match end
+            // — a few hundred per chunk — made the line that holds stop[k] and stop[k + 1] travel between their cores every time)
+            uint64_t stop_k = 0; size_t i_stop_k = a.syms.size();
+            if (final && a.tail_end == total) { stop[k] = total; i_stop[k] = i_stop_k; st_ok[k] = 1; return; }
             const Chunk &b = chunks[k + 1];
             // match ends of b inside a's tail (b's parse starts at b.start: only its first symbols are walked)
             std::vector<uint64_t> bends;
@@ -753,11 +754,12 @@ struct Stream::Impl {
                 if (qe <= b.first()) break;
                 if (is_match(sy) && qe + MARGIN <= a.tail_end) {
                     while (j > 0 && bends[j - 1] > qe) --j;
-                    if (j > 0 && bends[j - 1] == qe) { stop[k] = qe; i_stop[k] = i + 1; }   // keep going: an earlier one is better
+                    if (j > 0 && bends[j - 1] == qe) { stop_k = qe; i_stop_k = i + 1; }     // keep going: an earlier one is better
                 }
                 qe -= sym_len(sy);
             }
-            if (stop[k] == 0) st_ok[k] = 0;                       // the two parses did not meet inside the tail
+            stop[k] = stop_k; i_stop[k] = i_stop_k;
+            st_ok[k] = stop_k != 0;                               // 0: the two parses did not meet inside the tail
         };
         parallel_for(threads, n_eff, search);
         // A pair that did not meet (the two parses can stay out of step for longer than a tail where the text repeats with a long
