@@ -407,6 +407,18 @@ typedef struct pd_decode_result {
 int pd_decode_begin(pd_ctx *ctx, const pd_decode_cfg *cfg);
 int pd_decode_acquire(pd_ctx *ctx, size_t bytes, void **host_buf);
 int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_status, pd_decode_result *res);   /* (a batch without units only hands its buffer back) */
+/* The same batch in two halves, so that the thread that read it can go and read the next one while the device works (round 5; what
+ * PD:726-760 gets from htslib's reader threads).  pd_decode_queue puts EVERYTHING the batch needs on its stream and returns: the
+ * copy, the inflate, the record passes — and, where the session allows it (a PD_DECODE_COMPACT session, no PD_UNIT_GUESS unit), the
+ * confirmation of the record chain between the two passes on the device as well (csrc/pd_bamwalk.h: chain_device), so that no host
+ * round trip is left inside a batch.  `batch`'s arrays are copied by the call; `batch->host_buf` stays the engine's until the batch is
+ * collected.  pd_decode_collect(ticket) waits for that batch and reports exactly what pd_decode_submit would have (which IS these two
+ * calls back to back); a batch the device found out of the ordinary (a member it leaves to zlib, a record that runs past its
+ * unit, more wrong guesses than it repeats itself) is finished there the way pd_decode_submit always did.  Every queued batch must be
+ * collected; pd_decode_end / pd_decode_abort collect and drop what the caller left behind.  A thread may hold several queued batches
+ * (two per reader keeps a GPU busy); the rule of pd_decode_cfg::n_batches — buffer first, then the order — holds for each of them. */
+int pd_decode_queue(pd_ctx *ctx, const pd_decode_batch *batch, uint64_t *ticket);
+int pd_decode_collect(pd_ctx *ctx, uint64_t ticket, int32_t *unit_status /* batch->n_units entries */, pd_decode_result *res);
 int pd_decode_end(pd_ctx *ctx);
 int pd_decode_abort(pd_ctx *ctx);          /* forget the batches decoded since pd_decode_begin (nothing is counted) */
 

@@ -79,6 +79,8 @@ struct Seg {
 };
 static const int SCAN = 64;               // positions of the header search tested per step (one group of loads)
 struct LaneOut { uint64_t start; uint32_t n_first, n_other, n_far, pad; };
+// what one walk of a segment found (wave-uniform; the same values go to the Seg in memory)
+struct WalkOut { uint64_t used_start, e_last; uint32_t n_first, n_other, n_far, n_rec, flags, max_span; };
 
 PW_FN int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 PW_FN uint32_t rd32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
@@ -211,16 +213,18 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
     return w;
 }
 
-// pass 1: one wave, one segment.  lanes[64] receives every lane's start and counts for pass 2.
+// pass 1: one wave, one segment.  lanes[64] receives every lane's start and counts for pass 2.  `hint_in` (or null: the
+// segment's own) is the first record start to walk from — the chain kernel passes a corrected start in a register, so that
+// no lane has to read what another lane of the wave has just stored.
 template <class W>
-PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
+PW_FN WalkOut walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes, const uint64_t *hint_in = nullptr)
 {
     Cfg c = cfg; c.avail = sg.avail;
     typedef typename W::template Var<uint64_t> U64;
     typedef typename W::template Var<uint32_t> U;
     U64 a, b, s, e;
     U nf, no, fl, ms, need, nr, nfar;
-    const uint64_t hint = sg.hint;
+    const uint64_t hint = hint_in ? *hint_in : sg.hint;
     W::each([&](int l) {
         a[l] = sg.begin + (uint64_t)l * SUB; b[l] = a[l] + SUB < sg.end ? a[l] + SUB : sg.end;
         if (a[l] >= sg.end) { a[l] = b[l] = sg.end; }
@@ -299,8 +303,10 @@ PW_FN void walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes)
         lanes[l].start = s[l]; lanes[l].n_first = nf[l]; lanes[l].n_other = no[l]; lanes[l].n_far = nfar[l]; lanes[l].pad = 0;
         if (l == 0) {
             sg.used_start = first_start; sg.e_last = last_e; sg.n_first = tf; sg.n_other = to; sg.flags = allf; sg.max_span = mspan; sg.n_rec = tr; sg.n_far = tfar;
+            if (hint_in) sg.hint = hint;
         }
     });
+    return WalkOut{first_start, last_e, tf, to, tfar, tr, allf, mspan};
 }
 
 // pass 2: the same lanes write their runs; sg.base_first / base_other say where the segment's runs go
@@ -369,6 +375,102 @@ inline uint32_t check_chain(Vec &segs, Redo *redo)
         } else if (s.e_last != 0 && s.e_last < STOPPED) { E = s.e_last; known = true; }          // taken at its word for this round
     }
     return (uint32_t)redo->size();
+}
+
+// The same confirmation ON THE DEVICE, by one wave (round 5: a batch no longer waits for the host between its two passes).  The
+// wave goes through the segments in order, 64 at a time: the end of the chain before every segment is a prefix maximum of the
+// ends before it (restarting at the first segment of a unit), so a stretch of segments whose guesses were all right is confirmed
+// by ONE scan and compare.  The first segment of a stretch that starts somewhere else walks again at once — `rewalk(j, start)`,
+// the whole wave, from the corrected start — and the stretch is compared again: what comes out is the sequential chain, which is
+// also the fixed point check_chain's rounds arrive at.  Then every segment gets the places of its runs (running sums of the
+// counts: Seg::base_first / base_other), which is all pass 2 needs.
+// Anything out of the ordinary is NOT handled here: a member that did not inflate (or that the device leaves to zlib), a flag on
+// any segment (a record that cannot be one, that runs past the unit's bytes, a CIGAR in the CG tag), more repeats than
+// `max_redo`, far runs, or more runs than the batch's arrays hold set ChainOut::slow — pass 2 then writes nothing and the host
+// goes through the batch the way it always did (check_chain, unit outcomes, hand-backs).
+struct ChainOut { uint64_t n_first, n_other, n_rec; uint32_t max_span, slow, n_redo, pad; uint64_t pad2[3]; };   // 64 bytes
+enum { CH_MEMBER = 1, CH_FLAG = 2, CH_REDO = 4, CH_ROOM = 8, CH_FAR = 16 };
+
+template <class W, class RW>
+PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uint32_t n_members, uint64_t cap_first, uint64_t cap_other,
+                        uint32_t max_redo, RW rewalk, ChainOut *out)
+{
+    typedef typename W::template Var<uint64_t> U64;
+    typedef typename W::template Var<uint32_t> U;
+    uint32_t slow = 0, n_redo = 0, max_span = 0;
+    for (uint32_t b0 = 0; b0 < n_members && !slow; b0 += 64) {
+        U bad;
+        W::each([&](int l) { bad[l] = b0 + (uint32_t)l < n_members && member_status[b0 + (uint32_t)l] != 0 ? 1u : 0u; });
+        if (W::ballot_ne(bad, 0u)) slow |= CH_MEMBER;
+    }
+    uint64_t E = 0, nf = 0, no = 0, nr = 0;
+    for (uint32_t j0 = 0; j0 < n_seg && !slow; j0 += 64) {
+        const uint32_t cnt = n_seg - j0 < 64u ? n_seg - j0 : 64u;
+        U64 us, el, en;
+        U uf, fl, cf, co, cr, ms;
+        W::each([&](int l) {
+            us[l] = NONE; el[l] = 0; en[l] = 0; uf[l] = fl[l] = cf[l] = co[l] = cr[l] = ms[l] = 0;
+            if ((uint32_t)l >= cnt) return;
+            const Seg &s = segs[j0 + (uint32_t)l];
+            us[l] = s.used_start; el[l] = s.e_last; en[l] = s.end; uf[l] = s.unit_first; cf[l] = s.n_first; co[l] = s.n_other; cr[l] = s.n_rec; ms[l] = s.max_span;
+            fl[l] = s.flags | (s.n_far ? 0x80000000u : 0u);
+        });
+        uint32_t lo = 0;
+        while (lo < cnt && !slow) {
+            // the stretch [lo, hi) of this group that belongs to one unit
+            U m;
+            W::each([&](int l) { m[l] = (uint32_t)l > lo && (uint32_t)l < cnt && uf[l] ? 1u : 0u; });
+            const uint64_t ufm = W::ballot_ne(m, 0u);
+            const uint32_t hi = ufm ? (uint32_t)ctz64(ufm) : cnt;
+            const bool head = W::bcast(uf, (int)lo) != 0;             // the stretch begins its unit: nothing before it to be checked against
+            if (head) E = 0;
+            for (;;) {
+                U64 e, eb;
+                W::each([&](int l) { e[l] = (uint32_t)l >= lo && (uint32_t)l < hi ? el[l] : 0ull; });
+                const U64 pm = W::excl_scan_max64(e);
+                U bad;
+                W::each([&](int l) {
+                    eb[l] = pm[l] > E ? pm[l] : E;
+                    const bool chk = (uint32_t)l >= lo && (uint32_t)l < hi && !((uint32_t)l == lo && head);
+                    const uint64_t expect = eb[l] >= en[l] ? NONE : eb[l];
+                    bad[l] = chk && us[l] != expect ? 1u : 0u;
+                });
+                const uint64_t bm = W::ballot_ne(bad, 0u);
+                // a flag counts once its segment's start is confirmed (a wrong guess usually ends in garbage and carries one: the
+                // repeat clears it); the confirmed segments are those of the stretch before the first one that does not fit
+                const int jb = bm ? ctz64(bm) : (int)hi;
+                const uint64_t confirmed = ((uint32_t)jb >= 64u ? ~0ull : (1ull << jb) - 1) & ~((1ull << lo) - 1);
+                const uint64_t flm = W::ballot_ne(fl, 0u) & confirmed;
+                if (flm) { U f2; W::each([&](int l) { f2[l] = (confirmed >> l) & 1 ? fl[l] : 0u; }); slow |= W::reduce_or(f2) & 0x80000000u ? CH_FAR : CH_FLAG; break; }
+                if (!bm) { const uint64_t mx = W::reduce_max64(e); if (mx > E) E = mx; break; }
+                if (++n_redo > max_redo) { slow |= CH_REDO; break; }
+                const uint64_t start = W::bcast64(eb, jb), seg_end = W::bcast64(en, jb);
+                const WalkOut w = rewalk(j0 + (uint32_t)jb, start);
+                if (w.flags) { slow |= CH_FLAG; break; }
+                if (w.n_far) { slow |= CH_FAR; break; }
+                if (w.used_start != (start >= seg_end ? NONE : start)) { slow |= CH_REDO; break; }      // (a walk that does not start where it was told to: the host looks at it)
+                W::each([&](int l) { if (l == jb) { us[l] = w.used_start; el[l] = w.e_last; cf[l] = w.n_first; co[l] = w.n_other; cr[l] = w.n_rec; ms[l] = w.max_span; fl[l] = 0; } });
+            }
+            lo = hi;
+        }
+        if (slow) break;
+        uint32_t tf = 0, to = 0, tr = 0;
+        const U ef = W::excl_scan(cf, &tf);
+        const U eo = W::excl_scan(co, &to);
+        (void)W::excl_scan(cr, &tr);
+        W::each([&](int l) {
+            if ((uint32_t)l >= cnt) return;
+            Seg &s = segs[j0 + (uint32_t)l];
+            s.base_first = nf + ef[l]; s.base_other = no + eo[l]; s.base_far = 0;
+        });
+        nf += tf; no += to; nr += tr;
+        const uint32_t mspan = W::reduce_max(ms);
+        if (mspan > max_span) max_span = mspan;
+    }
+    if (nf > cap_first || no > cap_other) slow |= CH_ROOM;
+    W::each([&](int l) {
+        if (l == 0) { out->n_first = nf; out->n_other = no; out->n_rec = nr; out->max_span = max_span; out->slow = slow; out->n_redo = n_redo; out->pad = 0; out->pad2[0] = out->pad2[1] = out->pad2[2] = 0; }
+    });
 }
 
 } // namespace pdb2

@@ -72,12 +72,35 @@ __global__ __launch_bounds__(64) void k_walk_segments(const pdb2::Cfg cfg, pdb2:
     pdb2::walk_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64);
 }
 
-// pass 2: the runs, at the offsets the host gave every segment (base_first / base_other)
+// Test hook ("decode_spoil" = k): every k-th segment behind a unit's first walks again from a start that is no record — what a wrong guess
+// of the header search looks like to whoever confirms the chain, planted far more often than real data ever shows one (one in ~1e8 records),
+// so that the suite exercises the repair (k_chain_segments' repeats, the host's rounds) on the device.
+__global__ __launch_bounds__(64) void k_spoil_segments(const pdb2::Cfg cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, uint32_t k)
+{
+    const uint32_t j = blockIdx.x;
+    if (j >= n_seg || segs[j].unit_first || j % k != 0) return;
+    const uint64_t h = segs[j].begin + 1 + (j % 7);
+    pdb2::walk_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, &h);
+}
+
+// The chain across a batch's segments, confirmed by ONE wave on the device (pdb2::chain_device): segments whose guessed start is not
+// where the chain before them ends walk again right here, every segment gets the places of its runs, and `out` says how many runs
+// there are — or that the batch is out of the ordinary and the host must go through it (ChainOut::slow; pass 2 then writes nothing).
+__global__ __launch_bounds__(64) void k_chain_segments(const pdb2::Cfg cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, const int *member_status,
+                                                       uint32_t n_members, uint64_t cap_first, uint64_t cap_other, uint32_t max_redo, pdb2::ChainOut *out)
+{
+    pdb2::chain_device<pdw::DevWave>(segs, n_seg, member_status, n_members, cap_first, cap_other, max_redo,
+        [&](uint32_t j, uint64_t start) { return pdb2::walk_segment<pdw::DevWave>(cfg, segs[j], lanes + (size_t)j * 64, &start); }, out);
+}
+
+// pass 2: the runs, at the offsets every segment was given (base_first / base_other: by the host, or by k_chain_segments — `gate`
+// is then its verdict, and a batch it left to the host writes nothing)
 __global__ __launch_bounds__(64) void k_emit_segments(const pdb2::Cfg cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                                                      pd_iv *first, pd_iv *other, pd_iv *far)
+                                                      pd_iv *first, pd_iv *other, pd_iv *far, const pdb2::ChainOut *gate)
 {
     const uint32_t j = blockIdx.x;
     if (j >= n_seg) return;
+    if (gate && gate->slow) return;
     pdb2::SegOut *so = cfg.c8.seg_out ? cfg.c8.seg_out + j : nullptr;       // compact emission: the segment's keys for the host's order check
     if ((segs[j].n_first | segs[j].n_other | segs[j].n_far) == 0) {
         if (so && threadIdx.x == 0) { so->first_key = pdb2::NONE; so->last_key = 0; so->unsorted = 0; so->n_long = 0; }
@@ -111,11 +134,11 @@ void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t 
 
 // the wave-cooperative decoder: n_wg persistent one-wave workgroups; `scratch` = bgzf_wave_scratch_bytes(n_wg) bytes
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next)
+                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next, bool zero_next)
 {
     if (!n_blk) return;
     if (n_wg > n_blk) n_wg = n_blk;
-    if (next) (void)hipMemsetAsync(next, 0, 4, st);
+    if (next && zero_next) (void)hipMemsetAsync(next, 0, 4, st);
     hipLaunchKernelGGL(k_inflate_wave, dim3(n_wg), dim3(64), 0, st, comp, blk, n_blk, out, status, (pdw::Token *)scratch, check_crc ? 1 : 0, next);
 }
 size_t bgzf_wave_scratch_bytes(unsigned n_wg) { return (size_t)n_wg * PD_WAVE_TOKENS * sizeof(pdw::Token) + 64; }
@@ -128,10 +151,20 @@ void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs,
     hipLaunchKernelGGL(k_walk_segments, dim3(n), dim3(64), 0, st, cfg, segs, n_seg, lanes, only, n_only);
 }
 void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                          pd_iv *first, pd_iv *other, pd_iv *far)
+                          pd_iv *first, pd_iv *other, pd_iv *far, const pdb2::ChainOut *gate)
 {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_emit_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, first, other, far);
+    hipLaunchKernelGGL(k_emit_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, first, other, far, gate);
+}
+void launch_spoil_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, uint32_t k)
+{
+    if (!n_seg || !k) return;
+    hipLaunchKernelGGL(k_spoil_segments, dim3(n_seg), dim3(64), 0, st, cfg, segs, n_seg, lanes, k);
+}
+void launch_chain_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, const int *member_status,
+                           uint32_t n_members, uint64_t cap_first, uint64_t cap_other, uint32_t max_redo, pdb2::ChainOut *out)
+{
+    hipLaunchKernelGGL(k_chain_segments, dim3(1), dim3(64), 0, st, cfg, segs, n_seg, lanes, member_status, n_members, cap_first, cap_other, max_redo, out);
 }
 
 void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
@@ -196,7 +229,7 @@ extern "C" int pd_x_bgzf_inflate(int device, const void *host_bgzf, size_t n_byt
         for (int r = 0; r < reps + 1; ++r) {
             if (r == 1 || reps == 0) HIPV(hipEventRecord(e0, 0));
             const dim3 g((nb + 63) / 64), b(64);
-            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg, !no_crc, (uint32_t *)(d_st + nb));
+            if (variant >= 2) pdk::launch_bgzf_inflate_wave(0, d_in, d_blk, nb, d_out, d_st, d_scr, n_wg, !no_crc, (uint32_t *)(d_st + nb), true);
             else if (variant == 0) hipLaunchKernelGGL(k_inflate_blocks<true>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
             else hipLaunchKernelGGL(k_inflate_blocks<false>, g, b, 0, 0, d_in, d_blk, nb, d_out, d_st, d_scr);
         }

@@ -228,6 +228,10 @@ struct pd_ctx {
     bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
     unsigned lz_group = 0;                                        // chunks per workgroup of the LDS parse ("lz_group", up to 16; 0, the default: every chunk parses with its text in memory — measured faster at 16 + 4 KiB chunks)
     unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
+    bool dec_fast = true;                                         // the record chain of a batch is confirmed on the device where the session allows it ("decode_fast")
+    uint32_t dec_spoil = 0;                                       // test hook: every k-th segment's guess is spoilt after pass 1 ("decode_spoil")
+    uint32_t dec_max_redo = 256;                                  // ... with at most this many segments walking again per batch ("decode_max_redo")
+    std::atomic<uint64_t> dec_n_fast{0}, dec_n_slow{0}, dec_n_redo{0};   // batches finished without / with the host's chain check; segments the device walked again
     uint32_t direct_sample = 256;                                 // index stride of the direct path (runs)
     int direct_un = 0;                                           // 0 = the default form of the wide direct kernel (launch_direct_tiles)
     bool all_valid_host = false;
@@ -239,8 +243,20 @@ struct pd_ctx {
         hipEvent_t ev[6] = {};
         uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
         uint8_t *h_small = nullptr; size_t h_small_cap = 0;       // pinned: the batch's small tables on their way to and from the device
-        void *d[8] = {}; size_t cap[8] = {};                      // blob, inflated, blocks, status, segs, lanes, redo list, per-segment keys (compact emission)
-        void *d_tok = nullptr;                                    // wave scratch (match tokens)
+        void *d[10] = {}; size_t cap[10] = {};                    // blob, inflated, tables (members | segments | member counter), status, -, lanes, redo list,
+                                                                  // ChainOut + per-segment keys (compact emission), and the runs of a batch whose chain the device
+                                                                  // confirms itself: first runs (8 B), later runs (12 B) — copied to exact arrays when the batch is collected
+        void *d_tok = nullptr; unsigned tok_wg = 0;               // wave scratch (match tokens) and the number of workgroups it was sized for
+        // a batch between pd_decode_queue and pd_decode_collect (pd_decode_submit: the two back to back)
+        struct Job {
+            bool open = false, queued = false, c8 = false, fast = false, owes_count = false, timed = false;
+            uint64_t order = 0; size_t n_bytes = 0; uint64_t inflated = 0; uint32_t n_seg = 0;
+            std::vector<pd_bgzf_block> blocks; std::vector<pd_decode_unit> units; std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0;
+            size_t o_blk = 0, o_seg = 0, o_next = 0, o_up = 0, o_bst = 0, o_co = 0, o_so = 0, o_ord = 0;
+            pdb2::Cfg cfg{};
+            uint64_t cap_first = 0, cap_other = 0, t_mark = 0;
+        } job;
+        uint32_t gen = 0;
     };
     struct RunSeg { uint64_t order; pd_iv *first; uint64_t n_first; pd_iv *other; uint64_t n_other; pd_iv *far; uint64_t n_far; uint32_t max_span; uint32_t unsorted; uint64_t first_key, last_key; uint64_t n_long = 0; };
     static constexpr int N_DEC = 12;
@@ -794,6 +810,9 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "sweep_i4_fast")) { pdk::set_sweep_i4_fast(value != 0); return PD_OK; }
     if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 23) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 23]"); c->dec_waves = (unsigned)value; return PD_OK; }
+    if (!strcmp(name, "decode_spoil")) { c->dec_spoil = value > 0xFFFFFFFFull ? 0u : (uint32_t)value; return PD_OK; }
+    if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
+    if (!strcmp(name, "decode_max_redo")) { c->dec_max_redo = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
 }
@@ -1280,7 +1299,7 @@ int pd_device_buffer(pd_ctx *c, void **dev_ptr, uint64_t *n_words, uint64_t *con
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG, DS_LANE, DS_ONLY, DS_SEGOUT };
+enum { DS_BLOB, DS_INF, DS_BLK, DS_ST, DS_SEG /* (unused since the tables travel as one) */, DS_LANE, DS_ONLY, DS_SEGOUT, DS_R8, DS_OTH };
 
 // PANDEPTH_TIMING=1: where the host side of the decode path spends its time (thread-microseconds, summed)
 std::atomic<uint64_t> g_dec_us[8];
@@ -1329,11 +1348,11 @@ void c8_drop(pd_ctx *c)
 
 // room for n_s first runs and n_o later runs in the sample's final arrays (the caller holds c8.mu; copies placed earlier may still be
 // running — the device is waited for before anything moves).  Returns PD_OK / PD_ENOMEM / PD_EHIP, no message.
-int c8_reserve(pd_ctx *c, uint64_t n_s, uint64_t n_o)
+int c8_reserve(pd_ctx *c, uint64_t n_s, uint64_t n_o, bool exact = false)
 {
     pd_ctx::C8Dec &x = c->c8;
     if (n_s <= x.cap_s && n_o <= x.cap_o && x.base) return PD_OK;
-    const size_t ns = std::max<size_t>((size_t)n_s + (size_t)n_s / 2 + ((size_t)1 << 16), x.cap_s), no = std::max<size_t>((size_t)n_o + (size_t)n_o / 2 + ((size_t)1 << 16), x.cap_o);
+    const size_t ns = std::max<size_t>((size_t)n_s + (exact ? 0 : (size_t)n_s / 2) + ((size_t)1 << 16), x.cap_s), no = std::max<size_t>((size_t)n_o + (exact ? 0 : (size_t)n_o / 2) + ((size_t)1 << 16), x.cap_o);
     const size_t bytes = (ns + no) * sizeof(Run8) + no * sizeof(pd_iv) + 256;
     uint8_t *nb = nullptr;
     if (x.base) (void)hipDeviceSynchronize();
@@ -1373,12 +1392,6 @@ void c8_counted(pd_ctx *c, uint64_t order, uint64_t nf, uint64_t no, Run8 *seg_s
         ++x.turn;
     }
 }
-
-// every batch with an order below n_batches is counted exactly once, whatever way its submit call ends
-struct C8Mark {
-    pd_ctx *c; uint64_t order; bool armed;
-    ~C8Mark() { if (armed) c8_counted(c, order, 0, 0, nullptr, nullptr, nullptr); }
-};
 
 } // namespace
 
@@ -1423,13 +1436,21 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
             if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess || hipMalloc(&x.marks, x.nbw * 8) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
             HIPOK(c, hipMemset(x.marks, 0xFF, x.nbw * 8));
             if (!x.compose) HIPOK(c, hipStreamCreateWithFlags(&x.compose, hipStreamNonBlocking));
-            const uint64_t est = cfg->bytes_hint ? cfg->bytes_hint / 32 + (1u << 20) : (uint64_t)8 << 20;
-            const int rr = c8_reserve(c, est, est / 4);
-            if (rr) return fail(c, rr, "pd_decode_begin: the run arena could not be allocated");
-            x.n_batches = cfg->n_batches;
-            x.batch.assign((size_t)cfg->n_batches, pd_ctx::C8Dec::Batch());
-            x.base_s.assign((size_t)cfg->n_batches, 0u);
-            x.on = true;
+            // (>= 32 B of BGZF per record of a real short-read file: a first run per record, a later run for every fourth; c8_reserve adds
+            // half again when the sample has to GROW, not to this first estimate — a 70 GB file would otherwise ask for 50 GB up front.)
+            const uint64_t est = std::min<uint64_t>(cfg->bytes_hint ? cfg->bytes_hint / 32 + (1u << 20) : (uint64_t)8 << 20, DEV_BATCH_MAX);
+            if (c8_reserve(c, est, est / 4, /*exact=*/true) == PD_OK) {
+                x.n_batches = cfg->n_batches;
+                x.batch.assign((size_t)cfg->n_batches, pd_ctx::C8Dec::Batch());
+                x.base_s.assign((size_t)cfg->n_batches, 0u);
+                x.on = true;
+            } else {
+                // not enough memory for the compact sample's arrays: the session goes on with 12-byte runs per batch, as sessions without
+                // PD_DECODE_COMPACT do (pd_decode_end then takes the general paths)
+                (void)hipGetLastError();
+                if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
+                if (x.marks) { (void)hipFree(x.marks); x.marks = nullptr; }
+            }
         }
     }
     // one arena for the batches' run arrays (a hipMalloc per batch waits for the other streams): about half the compressed
@@ -1441,6 +1462,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
     }
     c->arena_used = 0;
+    c->dec_n_fast = 0; c->dec_n_slow = 0; c->dec_n_redo = 0;
+    for (auto &g : g_dec_us) g = 0;
     if (cfg->batch_bytes && cfg->batches_in_flight) {
         DecTimer ta(1);
         const size_t want = std::max<size_t>((size_t)cfg->batch_bytes + 128, (size_t)8 << 20);
@@ -1491,74 +1514,129 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     return PD_OK;
 }
 
-int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status, pd_decode_result *res)
+} // extern "C"
+
+namespace {
+
+const bool g_dec_timing = getenv("PANDEPTH_TIMING") != nullptr;     // the per-batch device events are recorded only when somebody reads them
+
+inline bool in_arena(const pd_ctx *c, const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; }
+
+// room for a batch's runs: the arena first, an allocation of its own when that is full
+bool dec_grab(pd_ctx *c, size_t bytes, void **out)
 {
-    if (!c || !bt || !bt->host_buf || !unit_status) return PD_EINVAL;
-    pd_ctx::DecSlot *slp = nullptr;
-    {   // (other feeders may be in pd_decode_acquire, re-allocating THEIR slots' pinned buffers: look the slot up under the lock)
-        std::lock_guard<std::mutex> l0(c->dec_mu);
-        for (auto &x : c->dec) if (x.busy && x.h_blob == bt->host_buf) slp = &x;
+    bytes = (bytes + 255) & ~(size_t)255;
+    const size_t at = c->arena_used.fetch_add(bytes);
+    if (at + bytes <= c->arena_cap) { *out = c->arena + at; return true; }
+    if (hipMalloc(out, bytes) == hipSuccess) return true;
+    (void)hipGetLastError(); *out = nullptr;
+    return false;
+}
+
+// a compact batch's segments and event belong to the call that made them until c8_counted has taken them
+struct C8Segs {
+    pd_ctx *c; Run8 *seg_s = nullptr; pd_iv *seg_o = nullptr; hipEvent_t ev = nullptr; bool kept = false;
+    ~C8Segs()
+    {
+        if (kept) return;
+        if (seg_s && !in_arena(c, seg_s)) (void)hipFree(seg_s);
+        if (seg_o && !in_arena(c, seg_o)) (void)hipFree(seg_o);
+        if (ev) (void)hipEventDestroy(ev);
     }
-    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_submit: buffer was not handed out by pd_decode_acquire");
-    pd_ctx::DecSlot &sl = *slp;
-    struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; } c->dec_cv.notify_one(); } } rel{c, slp};
-    const bool c8 = c->c8.on;
+};
+
+// every batch with an order below n_batches is counted exactly once, whatever way its calls end; a batch that had something queued
+// and is counted empty through an error path leaves the session in error (its totals would silently disagree with the file)
+struct C8Owes {
+    pd_ctx *c; pd_ctx::DecSlot::Job *j; bool armed = true;
+    ~C8Owes()
+    {
+        if (!armed || !j->owes_count) return;
+        j->owes_count = false;
+        if (j->queued) { std::lock_guard<std::mutex> lk(c->c8.mu); if (c->c8.err.empty()) c->c8.err = "a batch of the session failed on the device"; }
+        c8_counted(c, j->order, 0, 0, nullptr, nullptr, nullptr);
+    }
+};
+
+// ---- first half: everything the batch needs is put on the slot's stream; nothing is waited for -------------------------------------
+int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
+{
+    pd_ctx::DecSlot::Job &J = sl.job;
+    J.open = true; J.queued = false; J.fast = false; J.timed = false; J.order = bt->order; J.n_bytes = bt->n_bytes; J.inflated = bt->inflated_bytes; J.n_seg = 0;
+    J.blocks.clear(); J.units.clear(); J.segs.clear(); J.seg0.clear();
+    const bool c8 = J.c8 = c->c8.on;
+    J.owes_count = c8 && bt->order < c->c8.n_batches;
+    C8Owes owes{c, &J};
     if (c8 && bt->order >= c->c8.n_batches && bt->n_units) return dec_fail(c, PD_EINVAL, "pd_decode_submit: batch order outside [0, n_batches) of this session");
-    C8Mark mark{c, bt->order, c8 && bt->order < c->c8.n_batches};     // (every batch number is counted once, however this call ends)
-    if (res) memset(res, 0, sizeof *res);
-    if (res) res->first_start = res->next_start = ~0ull;
-    for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
-    if (!bt->n_units || !bt->n_blocks) return PD_OK;
+    if (!bt->n_units || !bt->n_blocks) return PD_OK;                  // (nothing to decode: the order is counted, empty)
+    if (!bt->units || !bt->blocks) return dec_fail(c, PD_EINVAL, "pd_decode_submit: a batch with units needs its unit and member tables");
     if (bt->n_bytes + 64 > sl.h_cap) return dec_fail(c, PD_EINVAL, "pd_decode_submit: more bytes than were acquired");
     HIPDEC(hipSetDevice(c->device));
     if (!sl.st) {
         HIPDEC(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
         for (auto &e : sl.ev) HIPDEC(hipEventCreate(&e));
     }
+    J.units.assign(bt->units, bt->units + bt->n_units);
+    J.blocks.assign(bt->blocks, bt->blocks + bt->n_blocks);
     // ---- segments of every unit (host) ----
-    std::vector<pdb2::Seg> segs;
-    std::vector<uint32_t> seg0(bt->n_units + 1, 0);
+    std::vector<pdb2::Seg> &segs = J.segs;
+    J.seg0.assign(bt->n_units + 1, 0);
+    bool guess = false;
     for (uint32_t u = 0; u < bt->n_units; ++u) {
-        const pd_decode_unit &un = bt->units[u];
+        const pd_decode_unit &un = J.units[u];
         if (un.start > un.stop || un.start > un.avail || un.avail > bt->inflated_bytes || (uint64_t)un.first_block + un.n_blocks > bt->n_blocks)
             return dec_fail(c, PD_EINVAL, "pd_decode_submit: unit outside the inflated buffer");
-        seg0[u] = (uint32_t)segs.size();
+        if (un.flags & PD_UNIT_GUESS) guess = true;
+        J.seg0[u] = (uint32_t)segs.size();
         for (uint64_t b = un.start; b < un.stop; b += pdb2::SEG_BYTES) {
-            pdb2::Seg s; memset(&s, 0, sizeof s);
-            s.begin = b; s.end = std::min<uint64_t>(b + pdb2::SEG_BYTES, un.stop); s.avail = un.avail;
-            s.unit_first = b == un.start;
-            s.hint = (b == un.start && !(un.flags & PD_UNIT_GUESS)) ? un.start : pdb2::NONE;
-            segs.push_back(s);
+            pdb2::Seg sg; memset(&sg, 0, sizeof sg);
+            sg.begin = b; sg.end = std::min<uint64_t>(b + pdb2::SEG_BYTES, un.stop); sg.avail = un.avail;
+            sg.unit_first = b == un.start;
+            sg.hint = (b == un.start && !(un.flags & PD_UNIT_GUESS)) ? un.start : pdb2::NONE;
+            segs.push_back(sg);
         }
     }
-    seg0[bt->n_units] = (uint32_t)segs.size();
+    J.seg0[bt->n_units] = (uint32_t)segs.size();
     for (uint32_t b = 0; b < bt->n_blocks; ++b)
-        if (bt->blocks[b].in_off + bt->blocks[b].in_len + 8 > bt->n_bytes + 8 || bt->blocks[b].out_off + bt->blocks[b].out_len > bt->inflated_bytes)
+        if (J.blocks[b].in_off + J.blocks[b].in_len + 8 > bt->n_bytes + 8 || J.blocks[b].out_off + J.blocks[b].out_len > bt->inflated_bytes)
             return dec_fail(c, PD_EINVAL, "pd_decode_submit: block outside its buffer");
-    const uint32_t n_seg = (uint32_t)segs.size();
+    const uint32_t n_seg = J.n_seg = (uint32_t)segs.size();
     if (!n_seg) return PD_OK;
+    // The device confirms the record chain itself — no host round trip between the two passes — in compact sessions whose units all
+    // start at known records.  A kept read has at least one CIGAR operation, so its record is at least 41 bytes (4 + 32 fixed, a name of
+    // one byte, one operation): inflated / 41 first runs is a bound, not an estimate.  Later runs are bounded only by the CIGAR bytes;
+    // the same number of slots (several times what real reads need) is given and the chain kernel checks that they suffice.
+    J.fast = c8 && c->dec_fast && !guess;
+    J.cap_first = J.cap_other = J.fast ? bt->inflated_bytes / 41 + 64 : 0;
     // (the inflate kernel's LDS lets 20 one-wave workgroups share a CU; "inflate_waves": fewer per launch, so that several batches' launches share the GPU)
     const unsigned n_wg = (unsigned)c->n_cu * c->dec_waves;
     int rc;
-    uint64_t t_mark = dec_now();
-    auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - t_mark; t_mark = n; };
-    if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
-        (rc = dec_ensure(c, sl, DS_BLK, (size_t)bt->n_blocks * sizeof(pd_bgzf_block))) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
-        (rc = dec_ensure(c, sl, DS_SEG, (size_t)n_seg * sizeof(pdb2::Seg))) || (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
-        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || (c8 && (rc = dec_ensure(c, sl, DS_SEGOUT, (size_t)n_seg * sizeof(pdb2::SegOut))))) return rc;
-    if (!sl.d_tok) {
-        std::lock_guard<std::mutex> al(g_alloc_mu);
-        if (hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed");
-    }
-    // The batch's small tables (member list, segments, statuses, per-segment keys) travel through a page-locked staging area of the
-    // slot: an "asynchronous" copy from or to pageable memory is staged by the runtime on the calling thread, under a lock all streams
-    // share — with six feeders making seven such copies per batch that, not the kernels, paced the decode.
+    J.t_mark = dec_now();
+    auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - J.t_mark; J.t_mark = n; };
+    // The batch's small tables travel through a page-locked staging area of the slot — an "asynchronous" copy from or to pageable memory
+    // is staged by the runtime on the calling thread, under a lock all streams share — and since round 5 as ONE copy each way: members,
+    // segments and the (zeroed) member counter go up together into one device buffer laid out the same way; ChainOut + the segments'
+    // keys (or, on the host's path, the member statuses and the segments) come back together.
     const auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_blk = 0, o_seg = o_blk + al((size_t)bt->n_blocks * sizeof(pd_bgzf_block)), o_bst = o_seg + al((size_t)n_seg * sizeof(pdb2::Seg)),
-                 o_so = o_bst + al((size_t)bt->n_blocks * 4), o_ord = o_so + al((size_t)n_seg * sizeof(pdb2::SegOut)), small_need = o_ord + 256;
+    J.o_blk = 0; J.o_seg = J.o_blk + al((size_t)bt->n_blocks * sizeof(pd_bgzf_block)); J.o_next = J.o_seg + al((size_t)n_seg * sizeof(pdb2::Seg)); J.o_up = J.o_next + 256;
+    J.o_bst = J.o_up; J.o_co = J.o_bst + al((size_t)bt->n_blocks * 4); J.o_so = J.o_co + sizeof(pdb2::ChainOut);
+    J.o_ord = J.o_so + al((size_t)n_seg * sizeof(pdb2::SegOut));
+    const size_t small_need = J.o_ord + 256;
+    if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
+        (rc = dec_ensure(c, sl, DS_BLK, J.o_up)) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
+        (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
+        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || (c8 && (rc = dec_ensure(c, sl, DS_SEGOUT, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut)))) ||
+        (J.fast && ((rc = dec_ensure(c, sl, DS_R8, (size_t)J.cap_first * sizeof(Run8))) || (rc = dec_ensure(c, sl, DS_OTH, (size_t)J.cap_other * sizeof(pd_iv)))))) return rc;
+    if (!sl.d_tok || sl.tok_wg < n_wg) {
+        // (the scratch is indexed by workgroup: "inflate_waves" may have been raised since it was sized)
+        std::lock_guard<std::mutex> al2(g_alloc_mu);
+        if (sl.d_tok) { HIPDEC(hipStreamSynchronize(sl.st)); HIPDEC(hipFree(sl.d_tok)); sl.d_tok = nullptr; sl.tok_wg = 0; }
+        if (hipMalloc(&sl.d_tok, bgzf_wave_scratch_bytes(n_wg)) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "device-decode scratch allocation failed"); }
+        sl.tok_wg = n_wg;
+    }
     if (small_need > sl.h_small_cap) {
         std::lock_guard<std::mutex> al2(g_alloc_mu);
-        if (sl.h_small) { (void)hipHostFree(sl.h_small); sl.h_small = nullptr; sl.h_small_cap = 0; }
+        if (sl.h_small) { HIPDEC(hipStreamSynchronize(sl.st)); (void)hipHostFree(sl.h_small); sl.h_small = nullptr; sl.h_small_cap = 0; }
         const size_t want = small_need + small_need / 4 + 4096;
         if (hipHostMalloc((void **)&sl.h_small, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "pinned staging allocation failed"); }
         sl.h_small_cap = want;
@@ -1566,36 +1644,135 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     uint8_t *const pin = sl.h_small;
     lap(2);                                                               // device buffers
     hipStream_t st = sl.st;
-    uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF];
-    pdb2::Seg *d_seg = (pdb2::Seg *)sl.d[DS_SEG];
+    uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF], *d_tab = (uint8_t *)sl.d[DS_BLK];
+    pdb2::Seg *d_seg = (pdb2::Seg *)(d_tab + J.o_seg);
     pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
-    pdb2::Cfg cfg;
+    pdb2::Cfg &cfg = J.cfg;
+    cfg = pdb2::Cfg{};
     cfg.buf = d_inf; cfg.avail = bt->inflated_bytes; cfg.n_ref = c->n_contigs; cfg.contig_len = c->d_len; cfg.contig_on = c->d_contig_on;
     cfg.flag_mask = c->dec_cfg.flag_mask; cfg.min_mapq = c->dec_cfg.min_mapq; cfg.span_off = c->d_span_off; cfg.spans = c->d_spans;
     cfg.near_span = c8 ? 0xFFFFFFFFu : c->dec_near_span;                   // (a compact session has one stream of later runs)
     cfg.c8 = pdb2::C8Out{};
     // ---- H2D, inflate, pass 1 ----
-    HIPDEC(hipEventRecord(sl.ev[0], st));
-    HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes, hipMemcpyHostToDevice, st));
-    HIPDEC(hipMemsetAsync(d_blob + bt->n_bytes, 0, 64, st));
-    memcpy(pin + o_blk, bt->blocks, (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
-    memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
-    HIPDEC(hipMemcpyAsync(sl.d[DS_BLK], pin + o_blk, (size_t)bt->n_blocks * sizeof(pd_bgzf_block), hipMemcpyHostToDevice, st));
-    HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
-    HIPDEC(hipEventRecord(sl.ev[1], st));
-    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)sl.d[DS_BLK], bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc,
-                             (uint32_t *)sl.d[DS_ST] + bt->n_blocks);
-    HIPDEC(hipEventRecord(sl.ev[2], st));
+    J.timed = g_dec_timing;
+    if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], st));
+    memset((uint8_t *)bt->host_buf + bt->n_bytes, 0, 64);                  // (the decoder reads up to 8 bytes past a member's end)
+    HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, st));
+    memcpy(pin + J.o_blk, J.blocks.data(), (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
+    memcpy(pin + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+    memset(pin + J.o_next, 0, 256);
+    HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, st));
+    if (J.timed) HIPDEC(hipEventRecord(sl.ev[1], st));
+    launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)(d_tab + J.o_blk), bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc,
+                             (uint32_t *)(d_tab + J.o_next), false);
+    if (J.timed) HIPDEC(hipEventRecord(sl.ev[2], st));
     launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, 0);
-    std::vector<int> bst(bt->n_blocks);
-    HIPDEC(hipMemcpyAsync(pin + o_bst, sl.d[DS_ST], (size_t)bt->n_blocks * 4, hipMemcpyDeviceToHost, st));
-    HIPDEC(hipMemcpyAsync(pin + o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
-    HIPDEC(hipEventRecord(sl.ev[3], st));
+    if (c->dec_spoil) launch_spoil_segments(st, cfg, d_seg, n_seg, d_lane, c->dec_spoil);     // (test hook)
+    if (J.fast) {
+        pd_ctx::C8Dec &x = c->c8;
+        pdb2::ChainOut *d_co = (pdb2::ChainOut *)sl.d[DS_SEGOUT];
+        launch_chain_segments(st, cfg, d_seg, n_seg, d_lane, (const int *)sl.d[DS_ST], bt->n_blocks, J.cap_first, J.cap_other, c->dec_max_redo, d_co);
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[3], st));
+        pdb2::Cfg c2 = cfg;
+        c2.c8 = pdb2::C8Out{(pdb2::R8 *)sl.d[DS_R8], x.marks, c->d_off, 13u - x.bshift, (pdb2::SegOut *)(d_co + 1), (uint32_t)bt->order};
+        launch_emit_segments(st, c2, d_seg, n_seg, d_lane, nullptr, (pd_iv *)sl.d[DS_OTH], nullptr, d_co);
+        HIPDEC(hipMemcpyAsync(pin + J.o_co, d_co, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[4], st));
+    } else {
+        HIPDEC(hipMemcpyAsync(pin + J.o_bst, sl.d[DS_ST], (size_t)bt->n_blocks * 4, hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + J.o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[3], st));
+    }
+    HIPDEC(hipGetLastError());
+    J.queued = true;
+    owes.armed = false;                                                   // (the second half counts the order)
+    return PD_OK;
+}
+
+// ---- second half: wait for the batch, finish it, report what pd_decode_submit reports ------------------------------------------------
+int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_result *res)
+{
+    pd_ctx::DecSlot::Job &J = sl.job;
+    J.open = false;
+    if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
+    const uint32_t n_units = (uint32_t)J.units.size(), n_blocks = (uint32_t)J.blocks.size(), n_seg = J.n_seg;
+    if (unit_status) for (uint32_t u = 0; u < n_units; ++u) unit_status[u] = 0;
+    C8Owes owes{c, &J};
+    if (!J.queued) return PD_OK;
+    if (!unit_status) return dec_fail(c, PD_EINVAL, "pd_decode_collect: unit_status is required for a batch with units");
+    const bool c8 = J.c8;
+    std::vector<pdb2::Seg> &segs = J.segs;
+    const std::vector<uint32_t> &seg0 = J.seg0;
+    HIPDEC(hipSetDevice(c->device));
+    hipStream_t st = sl.st;
+    uint8_t *const pin = sl.h_small;
+    uint8_t *d_tab = (uint8_t *)sl.d[DS_BLK];
+    pdb2::Seg *d_seg = (pdb2::Seg *)(d_tab + J.o_seg);
+    pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
+    pdb2::SegOut *d_so = c8 ? (pdb2::SegOut *)((uint8_t *)sl.d[DS_SEGOUT] + sizeof(pdb2::ChainOut)) : nullptr;
+    pdb2::Cfg cfg = J.cfg;
+    J.t_mark = dec_now();
+    auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - J.t_mark; J.t_mark = n; };
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
-    memcpy(bst.data(), pin + o_bst, (size_t)bt->n_blocks * 4);
-    memcpy(segs.data(), pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
-    lap(3);                                                               // H2D + inflate + pass 1 (waiting)
+    lap(3);                                                               // waiting for the device
+    auto times = [&](bool emitted) {
+        if (!res || !J.timed) return;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) res->ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) res->ms_inflate = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) res->ms_walk = ms;
+        if (emitted && hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]) == hipSuccess) res->ms_emit = ms;
+    };
+    // the order of a compact batch's first runs across its segments (inside a lane and across the lanes of a segment the emission checked it)
+    auto order_of = [&](const pdb2::SegOut *so, pd_ctx::RunSeg *rs) {
+        uint64_t prev = 0, first = pdb2::NONE, n_long = 0; uint32_t bad = 0;
+        for (uint32_t j = 0; j < n_seg; ++j) {
+            bad |= so[j].unsorted; n_long += so[j].n_long;
+            if (so[j].first_key == pdb2::NONE) continue;
+            if (first == pdb2::NONE) first = so[j].first_key; else if (so[j].first_key < prev) bad = 1;
+            prev = so[j].last_key;
+        }
+        rs->unsorted = bad ? 1u : 0u; rs->first_key = first; rs->last_key = prev; rs->n_long = n_long;
+    };
+    if (J.fast) {
+        pdb2::ChainOut co;
+        memcpy(&co, pin + J.o_co, sizeof co);
+        c->dec_n_redo += co.n_redo;
+        if (!co.slow) {
+            // ---- the device has confirmed the chain and written the runs to the slot's arrays: exact arrays for them, copied behind the
+            // emission on this stream (the slot's arrays are free again when its next batch gets there), and the batch is counted
+            ++c->dec_n_fast;
+            const uint64_t nf = co.n_first, no = co.n_other;
+            pd_ctx::RunSeg rs{J.order, nullptr, nf, nullptr, no, nullptr, 0, co.max_span, 0u, 0ull, 0ull};
+            C8Segs g{c};
+            if (nf + no) {
+                if ((nf && !dec_grab(c, (size_t)nf * sizeof(Run8), (void **)&g.seg_s)) || (no && !dec_grab(c, (size_t)no * sizeof(pd_iv), (void **)&g.seg_o)) ||
+                    hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "run segment allocation failed"); }
+                if (nf) HIPDEC(hipMemcpyAsync(g.seg_s, sl.d[DS_R8], (size_t)nf * sizeof(Run8), hipMemcpyDeviceToDevice, st));
+                if (no) HIPDEC(hipMemcpyAsync(g.seg_o, sl.d[DS_OTH], (size_t)no * sizeof(pd_iv), hipMemcpyDeviceToDevice, st));
+                HIPDEC(hipEventRecord(g.ev, st));
+            }
+            J.owes_count = false; g.kept = true;
+            c8_counted(c, J.order, nf, no, g.seg_s, g.seg_o, g.ev);
+            if (nf + no) order_of((const pdb2::SegOut *)(pin + J.o_so), &rs);
+            if (res) { res->n_first = nf; res->n_other = no; res->n_reads = co.n_rec; res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key; }
+            times(true);
+            lap(5);
+            if (nf + no) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
+            return PD_OK;
+        }
+        // ---- out of the ordinary (ChainOut::slow says why; nothing was emitted): the member statuses and the segments as they stand come
+        // to the host, which goes through the batch the way it always has
+        ++c->dec_n_slow;
+        HIPDEC(hipMemcpyAsync(pin + J.o_bst, sl.d[DS_ST], (size_t)n_blocks * 4, hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + J.o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+        HIPDEC(hipStreamSynchronize(st));
+    }
+    if (!J.fast) ++c->dec_n_slow;
+    std::vector<int> bst(n_blocks);
+    memcpy(bst.data(), pin + J.o_bst, (size_t)n_blocks * 4);
+    memcpy(segs.data(), pin + J.o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
     // ---- the chain across segments; segments whose guess was wrong walk again from the corrected start ----
     std::vector<uint32_t> redo;
     for (int round = 0; dec_finish(segs, &redo) > 0; ++round) {
@@ -1603,15 +1780,15 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         for (uint32_t j : redo) HIPDEC(hipMemcpyAsync(&d_seg[j].hint, &segs[j].hint, 8, hipMemcpyHostToDevice, st));
         HIPDEC(hipMemcpyAsync(sl.d[DS_ONLY], redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
         launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, (const uint32_t *)sl.d[DS_ONLY], (uint32_t)redo.size());
-        HIPDEC(hipMemcpyAsync(pin + o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + J.o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
         HIPDEC(hipStreamSynchronize(st));
-        memcpy(segs.data(), pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
+        memcpy(segs.data(), pin + J.o_seg, (size_t)n_seg * sizeof(pdb2::Seg));
     }
     // ---- unit outcomes; units handed back emit nothing ----
     uint64_t nf = 0, no = 0, nfar = 0, nrec = 0; uint32_t max_span = 0;
-    for (uint32_t u = 0; u < bt->n_units; ++u) {
+    for (uint32_t u = 0; u < n_units; ++u) {
         int stt = 0;
-        const pd_decode_unit &un = bt->units[u];
+        const pd_decode_unit &un = J.units[u];
         for (uint32_t b = 0; b < un.n_blocks; ++b) { const int v = bst[un.first_block + b]; if (v < 0) stt = 2; else if (v > 0 && stt == 0) stt = 1; }
         for (uint32_t j = seg0[u]; j < seg0[u + 1]; ++j) {
             if (segs[j].flags & pdb2::WF_BAD) { if (stt != 2) stt = 3; }
@@ -1632,106 +1809,138 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
         res->first_start = fs; res->next_start = E ? E : ~0ull;
     }
     // ---- pass 2: the runs ----
-    pd_ctx::RunSeg rs{bt->order, nullptr, nf, nullptr, no, nullptr, nfar, max_span, 0u, 0ull, 0ull};
+    pd_ctx::RunSeg rs{J.order, nullptr, nf, nullptr, no, nullptr, nfar, max_span, 0u, 0ull, 0ull};
     // run arrays taken outside the arena belong to this call until the batch is listed: every early return gives them back
     struct RunGuard {
         pd_ctx *c; pd_ctx::RunSeg *r; bool keep = false;
-        ~RunGuard() { if (keep) return; for (pd_iv *q : {r->first, r->other, r->far}) if (q && !(c->arena && (const uint8_t *)q >= c->arena && (const uint8_t *)q < c->arena + c->arena_cap)) (void)hipFree(q); }
+        ~RunGuard() { if (keep) return; for (pd_iv *q : {r->first, r->other, r->far}) if (q && !in_arena(c, q)) (void)hipFree(q); }
     } run_guard{c, &rs};
     lap(4);                                                               // host: chain check, unit outcomes
-    std::vector<pdb2::SegOut> seg_out;
-    auto grab_bytes = [&](size_t bytes, void **out) -> bool {
-        bytes = (bytes + 255) & ~(size_t)255;
-        const size_t at = c->arena_used.fetch_add(bytes);
-        if (at + bytes <= c->arena_cap) { *out = c->arena + at; return true; }
-        return hipMalloc(out, bytes) == hipSuccess;
-    };
+    bool have_so = false;
     if (c8) {
         // compact session: pass 2 writes the batch's first runs as 8-byte runs into a segment of its own and marks the buckets' first runs;
         // c8_counted then queues the copies to the runs' final places for every batch whose predecessors are all counted
         pd_ctx::C8Dec &x = c->c8;
-        Run8 *seg_s = nullptr; pd_iv *seg_o = nullptr; hipEvent_t ev = nullptr;
+        C8Segs g{c};
         if (nf + no) {
-            const auto ina = [&](const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; };
-            if ((nf && !grab_bytes((size_t)nf * sizeof(Run8), (void **)&seg_s)) || (no && !grab_bytes((size_t)no * sizeof(pd_iv), (void **)&seg_o)) ||
-                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                if (seg_s && !ina(seg_s)) (void)hipFree(seg_s);
-                if (seg_o && !ina(seg_o)) (void)hipFree(seg_o);
-                return dec_fail(c, PD_ENOMEM, "run segment allocation failed");
-            }
-            memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
-            HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
-            cfg.c8 = pdb2::C8Out{(pdb2::R8 *)seg_s, x.marks, c->d_off, 13u - x.bshift, (pdb2::SegOut *)sl.d[DS_SEGOUT], (uint32_t)bt->order};
-            launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, seg_o, nullptr);
-            HIPDEC(hipEventRecord(ev, st));
+            if ((nf && !dec_grab(c, (size_t)nf * sizeof(Run8), (void **)&g.seg_s)) || (no && !dec_grab(c, (size_t)no * sizeof(pd_iv), (void **)&g.seg_o)) ||
+                hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "run segment allocation failed"); }
+            memcpy(pin + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+            HIPDEC(hipMemcpyAsync(d_seg, pin + J.o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+            cfg.c8 = pdb2::C8Out{(pdb2::R8 *)g.seg_s, x.marks, c->d_off, 13u - x.bshift, d_so, (uint32_t)J.order};
+            launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, g.seg_o, nullptr, nullptr);
+            HIPDEC(hipEventRecord(g.ev, st));
         }
-        mark.armed = false;
-        c8_counted(c, bt->order, nf, no, seg_s, seg_o, ev);
+        J.owes_count = false; g.kept = true;
+        c8_counted(c, J.order, nf, no, g.seg_s, g.seg_o, g.ev);
         if (nf + no) {
-            seg_out.resize(n_seg);
-            HIPDEC(hipMemcpyAsync(pin + o_so, sl.d[DS_SEGOUT], (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
+            have_so = true;
+            HIPDEC(hipMemcpyAsync(pin + J.o_so, d_so, (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
         }
         lap(5);
     } else if (nf + no + nfar) {
-        auto grab = [&](uint64_t n, pd_iv **out) -> bool {
-            const size_t bytes = ((size_t)n * sizeof(pd_iv) + 255) & ~(size_t)255;
-            const size_t at = c->arena_used.fetch_add(bytes);
-            if (at + bytes <= c->arena_cap) { *out = (pd_iv *)(c->arena + at); return true; }
-            return hipMalloc(out, bytes) == hipSuccess;
-        };
-        if ((nf && !grab(nf, &rs.first)) || (no && !grab(no, &rs.other)) || (nfar && !grab(nfar, &rs.far))) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
-        memcpy(pin + o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
-        HIPDEC(hipMemcpyAsync(d_seg, pin + o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
+        if ((nf && !dec_grab(c, (size_t)nf * sizeof(pd_iv), (void **)&rs.first)) || (no && !dec_grab(c, (size_t)no * sizeof(pd_iv), (void **)&rs.other)) ||
+            (nfar && !dec_grab(c, (size_t)nfar * sizeof(pd_iv), (void **)&rs.far))) return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+        memcpy(pin + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+        HIPDEC(hipMemcpyAsync(d_seg, pin + J.o_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyHostToDevice, st));
         lap(5);                                                           // run array allocation
-        launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far);
+        launch_emit_segments(st, cfg, d_seg, n_seg, d_lane, rs.first, rs.other, rs.far, nullptr);
     }
     // are the first runs in (tid, begin) order, as the header's SO:coordinate promises?  (DS_ONLY is free again: 6 words)
     uint32_t order_words[6] = {0, 0, 0, 0, 0, 0};
     if (nf && !c8) {
         HIPDEC(hipMemsetAsync(sl.d[DS_ONLY], 0, 24, st));
         launch_runs_sorted(st, rs.first, nf, (uint32_t *)sl.d[DS_ONLY]);
-        HIPDEC(hipMemcpyAsync(pin + o_ord, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
+        HIPDEC(hipMemcpyAsync(pin + J.o_ord, sl.d[DS_ONLY], 24, hipMemcpyDeviceToHost, st));
     }
-    HIPDEC(hipEventRecord(sl.ev[4], st));
+    if (J.timed) HIPDEC(hipEventRecord(sl.ev[4], st));
     HIPDEC(hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
-    if (nf && !c8) memcpy(order_words, pin + o_ord, 24);
-    if (!seg_out.empty()) memcpy(seg_out.data(), pin + o_so, (size_t)n_seg * sizeof(pdb2::SegOut));
-    if (c8 && !seg_out.empty()) {
-        // compact emission checked the order itself: inside every lane and across the lanes of a segment; here across the segments
-        uint64_t prev = 0, first = pdb2::NONE, n_long = 0; uint32_t bad = 0;
-        for (const auto &so : seg_out) {
-            bad |= so.unsorted; n_long += so.n_long;
-            if (so.first_key == pdb2::NONE) continue;
-            if (first == pdb2::NONE) first = so.first_key; else if (so.first_key < prev) bad = 1;
-            prev = so.last_key;
-        }
-        order_words[0] = bad ? 1u : 0u;
-        order_words[2] = (uint32_t)first; order_words[3] = (uint32_t)(first >> 32); order_words[4] = (uint32_t)prev; order_words[5] = (uint32_t)(prev >> 32);
-        rs.n_long = n_long;
+    if (nf && !c8) {
+        memcpy(order_words, pin + J.o_ord, 24);
+        rs.unsorted = order_words[0];
+        rs.first_key = (uint64_t)order_words[2] | ((uint64_t)order_words[3] << 32);
+        rs.last_key = (uint64_t)order_words[4] | ((uint64_t)order_words[5] << 32);
     }
-    rs.unsorted = order_words[0];
-    rs.first_key = (uint64_t)order_words[2] | ((uint64_t)order_words[3] << 32);
-    rs.last_key = (uint64_t)order_words[4] | ((uint64_t)order_words[5] << 32);
+    if (have_so) order_of((const pdb2::SegOut *)(pin + J.o_so), &rs);
     if (res) { res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key; }
     lap(6);                                                               // pass 2 (waiting)
-    if (res) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) res->ms_h2d = ms;
-        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) res->ms_inflate = ms;
-        if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) res->ms_walk = ms;
-        if (hipEventElapsedTime(&ms, sl.ev[3], sl.ev[4]) == hipSuccess) res->ms_emit = ms;
-    }
+    times(!J.fast);
     if (nf + no + nfar) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
     run_guard.keep = true;
     return PD_OK;
 }
 
+pd_ctx::DecSlot *dec_slot_of(pd_ctx *c, const void *host_buf)
+{
+    // (other feeders may be in pd_decode_acquire, re-allocating THEIR slots' pinned buffers: look the slot up under the lock)
+    std::lock_guard<std::mutex> l0(c->dec_mu);
+    for (auto &x : c->dec) if (x.busy && !x.job.open && x.h_blob == host_buf) return &x;
+    return nullptr;
+}
+void dec_release(pd_ctx *c, pd_ctx::DecSlot *s) { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; s->job.open = false; } c->dec_cv.notify_all(); }
+
+} // namespace
+
+extern "C" {
+
+int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status, pd_decode_result *res)
+{
+    if (!c || !bt || !bt->host_buf || !unit_status) return PD_EINVAL;
+    pd_ctx::DecSlot *slp = dec_slot_of(c, bt->host_buf);
+    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_submit: buffer was not handed out by pd_decode_acquire");
+    struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { dec_release(c, s); } } rel{c, slp};
+    if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
+    for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
+    const int rc = dec_queue(c, *slp, bt);
+    if (rc) { slp->job.open = false; return rc; }
+    return dec_collect(c, *slp, unit_status, res);
+}
+
+int pd_decode_queue(pd_ctx *c, const pd_decode_batch *bt, uint64_t *ticket)
+{
+    if (!c || !bt || !bt->host_buf || !ticket) return PD_EINVAL;
+    *ticket = 0;
+    pd_ctx::DecSlot *slp = dec_slot_of(c, bt->host_buf);
+    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_queue: buffer was not handed out by pd_decode_acquire");
+    const int rc = dec_queue(c, *slp, bt);
+    if (rc) { dec_release(c, slp); return rc; }
+    *ticket = ((uint64_t)++slp->gen << 8) | (uint64_t)(slp - c->dec + 1);
+    return PD_OK;
+}
+
+int pd_decode_collect(pd_ctx *c, uint64_t ticket, int32_t *unit_status, pd_decode_result *res)
+{
+    if (!c) return PD_EINVAL;
+    const uint64_t k = ticket & 0xff;
+    pd_ctx::DecSlot *slp = k >= 1 && k <= (uint64_t)pd_ctx::N_DEC ? &c->dec[k - 1] : nullptr;
+    {
+        std::lock_guard<std::mutex> l0(c->dec_mu);
+        if (!slp || !slp->busy || !slp->job.open || slp->gen != (uint32_t)(ticket >> 8)) slp = nullptr;
+    }
+    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_collect: not the ticket of a queued batch");
+    struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { dec_release(c, s); } } rel{c, slp};
+    return dec_collect(c, *slp, unit_status, res);
+}
+
+// batches that were queued and never collected: finished here (pd_decode_end: they count) or waited for and dropped (pd_decode_abort)
+static void dec_drain(pd_ctx *c, bool finish)
+{
+    for (auto &sl : c->dec) {
+        bool mine = false;
+        { std::lock_guard<std::mutex> lk(c->dec_mu); mine = sl.busy && sl.job.open; }
+        if (!mine) continue;
+        if (finish) { std::vector<int32_t> st(sl.job.units.size() + 1, 0); (void)dec_collect(c, sl, st.data(), nullptr); }
+        else { (void)hipSetDevice(c->device); if (sl.st) (void)hipStreamSynchronize(sl.st); C8Owes owes{c, &sl.job}; sl.job.queued = false; }
+        dec_release(c, &sl);
+    }
+}
+
 int pd_decode_end(pd_ctx *c)
 {
     if (!c) return PD_EINVAL;
-    {   // every batch has returned (submit is synchronous per caller); wait for stragglers that still hold a slot
+    dec_drain(c, true);
+    {   // every batch has returned; wait for stragglers that still hold a slot
         std::unique_lock<std::mutex> lk(c->dec_mu);
         c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });
         c->dec_open = false;
@@ -1772,15 +1981,16 @@ int pd_decode_end(pd_ctx *c)
             prev = r.last_key; have = true;
         }
         if (getenv("PANDEPTH_TIMING"))
-            fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
-                            "host chain check %.3f, segment + emit launch %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs (compact session): %llu first, %llu later (span %u)\n",
+            fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers + queueing %.3f, waiting for the device %.3f, "
+                            "host chain check %.3f, runs to their arrays %.3f, wait emit (host's path) %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs (compact session): %llu first, %llu later (span %u); "
+                            "chain confirmed on the device for %llu batches, by the host for %llu; segments the device walked again: %llu\n",
                     g_dec_us[0] / 1e6, g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, g_dec_us[7] / 1e6, segs.size(),
-                    (unsigned long long)x.n_s, (unsigned long long)x.n_o, span);
+                    (unsigned long long)x.n_s, (unsigned long long)x.n_o, span, (unsigned long long)c->dec_n_fast.load(), (unsigned long long)c->dec_n_slow.load(), (unsigned long long)c->dec_n_redo.load());
         if (x.n_s + x.n_o == 0) { (void)hipStreamSynchronize(x.compose); c8_drop(c); return PD_OK; }
         HIPOK(c, hipStreamSynchronize(x.compose));                 // every batch's runs have reached their places
-        if (ok_order && x.n_s && c->pend.empty() && x.n_s + x.n_o <= DEV_BATCH_MAX && x.cap_s + x.cap_o < 0xFFFFFF00ull) {
+        if (ok_order && x.n_s && c->pend.empty() && x.n_s + x.n_o <= DEV_BATCH_MAX) {
             pd_runs *r = new pd_runs;
-            r->ctx = c; r->r8 = x.r8(); r->own_r8 = true; r->n_s = (uint32_t)x.n_s; r->n_o = (uint32_t)x.n_o; r->n = r->n_s + r->n_o; r->o_base = (uint32_t)x.cap_s;
+            r->ctx = c; r->r8 = x.r8(); r->own_r8 = true; r->n_s = (uint32_t)x.n_s; r->n_o = (uint32_t)x.n_o; r->n = r->n_s + r->n_o; r->o_base = r->n_s;      // (the later runs go right behind the sorted stream, as in pd_runs_create: what counts is how many runs there ARE, not how many were reserved)
             r->b1 = x.b1; r->o1 = x.b1 + x.nbw; r->bshift = x.bshift;
             const pd_iv *oth = x.oth(); const size_t no1 = (size_t)x.n_o;
             uint32_t *tmp = nullptr, *words = nullptr, *d_base = nullptr;
@@ -1888,6 +2098,7 @@ int pd_decode_end(pd_ctx *c)
 int pd_decode_abort(pd_ctx *c)
 {
     if (!c) return PD_EINVAL;
+    dec_drain(c, false);
     std::unique_lock<std::mutex> lk(c->dec_mu);
     c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });
     c->dec_open = false;

@@ -57,7 +57,9 @@ namespace pdw {
 #ifndef PD_D_ROOT
 #define PD_D_ROOT 8
 #endif
-enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = 320, D_ROOT = PD_D_ROOT, D_SUBCAP = 256 };       // sub-table areas: zlib's `enough` bounds; a code that needs more goes to the host
+// sub-table areas: zlib's `enough` bounds — 286 literal/length symbols of at most 15 bits need 852 entries with a 9-bit root (340 behind the
+// root) and 820 with a 10-bit one (308 are needed, 320 kept); a code that would need more goes to the host (build_table checks)
+enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = PD_LL_ROOT <= 9 ? 340 : 320, D_ROOT = PD_D_ROOT, D_SUBCAP = 256 };
 enum { PD_W_OK = 0, PD_W_HOST = 1 };      // negative values: corrupt stream (same codes as pd_inflate_core.h)
 enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2, KIND_BAD = 3 };
 enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };

@@ -136,7 +136,8 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t *comp, const pd_bgzf_bloc
                          int *status, void *scratch);
 size_t bgzf_scratch_bytes(uint32_t n_blk);
 void launch_bgzf_inflate_wave(hipStream_t st, const uint8_t *comp, const pd_bgzf_block *blk, uint32_t n_blk, uint8_t *out,
-                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next /* device word for the member counter, or null: static split */);
+                              int *status, void *scratch, unsigned n_wg, bool check_crc, uint32_t *next /* device word for the member counter, or null: static split */,
+                              bool zero_next /* false: the caller has zeroed the counter on this stream already */);
 size_t bgzf_wave_scratch_bytes(unsigned n_wg);
 } // namespace pdk
 
@@ -169,12 +170,15 @@ void launch_site_rows(hipStream_t st, const uint32_t *depth, uint32_t first_inde
 }
 
 // the record walk of the device decode path (pd_bamwalk.h)
-namespace pdb2 { struct Cfg; struct Seg; struct LaneOut; }
+namespace pdb2 { struct Cfg; struct Seg; struct LaneOut; struct ChainOut; }
 namespace pdk {
 void launch_walk_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes,
                           const uint32_t *only, uint32_t n_only);
 void launch_emit_segments(hipStream_t st, const pdb2::Cfg &cfg, const pdb2::Seg *segs, uint32_t n_seg, const pdb2::LaneOut *lanes,
-                          pd_iv *first, pd_iv *other, pd_iv *far);
+                          pd_iv *first, pd_iv *other, pd_iv *far, const pdb2::ChainOut *gate /* k_chain_segments' verdict, or null */);
+void launch_spoil_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, uint32_t k /* test hook: plants wrong guesses */);
+void launch_chain_segments(hipStream_t st, const pdb2::Cfg &cfg, pdb2::Seg *segs, uint32_t n_seg, pdb2::LaneOut *lanes, const int *member_status,
+                           uint32_t n_members, uint64_t cap_first, uint64_t cap_other, uint32_t max_redo, pdb2::ChainOut *out);
 void launch_runs_sorted(hipStream_t st, const pd_iv *runs, uint64_t n, uint32_t *out);
 }
 #endif

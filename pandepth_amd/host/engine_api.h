@@ -62,6 +62,9 @@ typedef struct pd_engine_api {
     int (*text_append_bytes)(pd_text *, const void *, size_t);
     /* optional (NULL = `#.list` inputs with -g / -b add the contexts into one GPU): see pd_sliced_interval_sum */
     int (*sliced_interval_sum)(pd_comm *, const pd_region *, size_t, uint32_t, unsigned, int, int32_t *, uint64_t *);
+    /* optional (NULL = every batch is submitted and waited for by the thread that read it): the two halves of decode_submit, see pd_decode_queue */
+    int (*decode_queue)(pd_ctx *, const pd_decode_batch *, uint64_t *);
+    int (*decode_collect)(pd_ctx *, uint64_t, int32_t *, pd_decode_result *);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -1,5 +1,6 @@
 // options.cpp — see options.h
 #include "options.h"
+#include <string.h>
 #include <stdlib.h>
 #include <zlib.h>
 #include <iostream>
@@ -30,6 +31,15 @@ void tune_env()
     if (g_tune_env_read) return;
     g_tune_env_read = true;
     if (const char *e = getenv("PANDEPTH_TUNE")) tune_parse(e);
+    // the development switches these variables used to be (rounds 1-3) are keys of PANDEPTH_TUNE / -X now: a script that still sets one
+    // would silently get the default path instead of the one it asked for
+    static const char *const legacy[][2] = {
+        {"PANDEPTH_DEVICE_DECODE", "device_decode"}, {"PANDEPTH_DEVICE_DEFLATE", "device_deflate"}, {"PANDEPTH_DD_BATCH_MB", "dd_batch_mb"}, {"PANDEPTH_DD_THREADS", "dd_threads"},
+        {"PANDEPTH_NO_RCCL", "rccl=0"}, {"PANDEPTH_FORCE_RCCL", "rccl=force"}, {"PANDEPTH_RCCL_VERBOSE", "rccl_verbose"}, {"PANDEPTH_GPUS", "gpus"},
+        {"PANDEPTH_SITE_RESIDENT", "site_resident"}, {"PANDEPTH_SITE_OVERLAP", "site_overlap"}, {"PANDEPTH_SITE_IDENTICAL", "site_identical"}, {"PANDEPTH_SITE_PARALLEL_MIN", "site_parallel_min"},
+        {"PANDEPTH_TABLE_RESIDENT", "table_resident"}, {"PANDEPTH_TABLE_RESIDENT_MIN", "table_resident_min"}, {"PANDEPTH_DECODE_ONLY", "decode_only"}};
+    for (const auto &l : legacy)
+        if (getenv(l[0])) fprintf(stderr, "pandepth: note: %s is no longer read; use PANDEPTH_TUNE=%s%s (or -X)\n", l[0], l[1], strchr(l[1], '=') ? "" : "=<value>");
 }
 } // namespace
 

@@ -38,7 +38,10 @@ void print_help();
 // parsed, how many decode threads / GPUs ...), never what it prints — come in through ONE door: the hidden option `-X key=value[,key=value]`
 // or the environment variable PANDEPTH_TUNE with the same syntax (tests, benchmarks).  tune("key") returns the value or NULL.
 //   device_decode=0  device_deflate=0  site_resident=0  table_resident=0  table_resident_min=N  site_overlap=0  site_identical=0|1
-//   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_batch_mb=N  inflate_waves=N  lz_group=N  decode_only=1
+//   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_depth=N  dd_batch_mb=N  inflate_waves=N  lz_group=N  decode_only=1
+//   decode_fast=0 (the host confirms every batch's record chain, as before round 5)  decode_max_redo=N  decode_spoil=K (test hook: plants wrong guesses)
+// -X is not part of the reference's command line (which answers an unknown flag with "Error UnKnow argument"): it is accepted only in this
+// spelling, is not listed by -h, and a PANDEPTH_* variable of the earlier rounds that is still set gets a note on stderr.
 const char *tune(const char *key);
 long long tune_int(const char *key, long long dflt);
 void tune_add(const std::string &kv_list);

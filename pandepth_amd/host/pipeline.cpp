@@ -422,13 +422,22 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     int feeders = std::min<int>(std::max(1, o.threads), 6);
     if (const char *e = tune("dd_threads")) feeders = std::max(1, atoi(e));
     if ((size_t)feeders > batches.size()) feeders = (int)batches.size();
+    // A reader does not wait for the device: it queues its batch (decode_queue: copy, inflate, both record passes and the chain check between
+    // them all go on the batch's stream) and reads the next one meanwhile; it holds `depth` buffers — the one it is filling and depth - 1
+    // queued batches — and collects the oldest when it needs a buffer back.  (The engine has twelve batch slots.)
+    int depth = api->decode_queue && api->decode_collect ? 2 : 1;
+    if (const char *e = tune("dd_depth")) depth = std::max(1, atoi(e));
+    if (!api->decode_queue || !api->decode_collect) depth = 1;
+    depth = std::max(1, std::min(depth, 12 / std::max(1, feeders)));
     {   // the largest batch the feeders will ask a buffer for
         uint64_t mx = 0;
         for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + spare_of(r.vend)); t += b - a; } mx = std::max(mx, t); }
-        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)feeders;
+        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)std::min<size_t>((size_t)feeders * (size_t)depth, batches.size());
     }
     cfg.n_batches = batches.size();
     if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
+    for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo"})                                                                           // (tuning / test hooks)
+        if (const char *e = tune(k)) if (api->set_param) (void)api->set_param(eng->ctx, k, (uint64_t)std::max(0, atoi(e)));
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
@@ -448,11 +457,71 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     auto feeder = [&]() {
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
-        std::vector<pd_bgzf_block> blocks;
-        std::vector<uint64_t> bfile;                         // file offset of every scanned member
-        std::vector<pd_decode_unit> units;
-        std::vector<int32_t> status;
+        // what a batch's answer is read against, kept from the moment the batch is queued until it is collected
+        struct InFlight {
+            size_t bi = 0; uint64_t ticket = 0, pos = 0, uo = 0;
+            std::vector<pd_bgzf_block> blocks;
+            std::vector<uint64_t> bfile;                     // file offset of every scanned member
+            std::vector<pd_decode_unit> units;
+            std::vector<int32_t> status;
+        };
+        std::deque<InFlight> fly;
+        std::vector<InFlight> spare;                         // (recycled: their vectors keep their capacity)
+        // the answer to one batch: counts, order keys, the record chain of a no-index stream, units handed back
+        auto take = [&](InFlight &f, const pd_decode_result &res) {
+            const size_t bi = f.bi;
+            const std::vector<DevRange> &rs = batches[bi];
+            const std::vector<pd_bgzf_block> &blocks = f.blocks; const std::vector<uint64_t> &bfile = f.bfile; const std::vector<int32_t> &status = f.status;
+            n_dev += res.n_reads; b_comp += f.pos; b_inf += f.uo;
+            if (res.n_first) { key_first[bi] = res.first_key; key_last[bi] = res.last_key; key_have[bi] = 1; if (res.unsorted) order_broken = 1; }
+            { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
+            auto voff_of = [&](uint64_t u) -> uint64_t {      // inflated offset of the batch -> virtual file offset
+                if (u == UINT64_MAX) return UINT64_MAX;
+                size_t lo = 0, hi = blocks.size();
+                while (hi - lo > 1) { const size_t m = (lo + hi) / 2; if (blocks[m].out_off <= u) lo = m; else hi = m; }
+                // the end of a member is the start of the next one
+                while (lo + 1 < blocks.size() && u >= blocks[lo].out_off + blocks[lo].out_len) ++lo;
+                if (u >= blocks[lo].out_off + blocks[lo].out_len) return UINT64_MAX - 1;          // past everything this batch saw
+                return (bfile[lo] << 16) | (u - blocks[lo].out_off);
+            };
+            if (guess) {
+                if (status[0] != 0) { declined = 1; return; }
+                chain_first[bi] = bi == 0 ? first_voff : voff_of(res.first_start);
+                chain_next[bi] = voff_of(res.next_start);
+            } else {
+                for (size_t k = 0; k < f.units.size(); ++k) {
+                    if (status[k] == 0) continue;
+                    // 1: the device leaves this unit to the host; 2: one of the members read for it does not inflate or fails its
+                    // CRC-32 — possibly one of the spare members behind the unit that no record of it needs; 3: it could not follow
+                    // the record chain.  In every case the host reader goes through exactly the bytes the unit needs and says what
+                    // is wrong with them, if anything is
+                    // It is only NOTED here: the pass can still be declined (a member scan that stops short in another batch, an
+                    // SO:coordinate header that does not hold), and a declined pass must not have counted anything — the host reader
+                    // then goes through the whole file.  The backlog is decoded after those checks, before pd_decode_end.
+                    // (a unit made of several chunks goes back chunk by chunk: what lies between them is not the host reader's
+                    // business, damaged or not)
+                    ++n_back;
+                    std::lock_guard<std::mutex> lk(back_mu);
+                    if (orig.empty()) backlog.emplace_back(rs[k].vbeg, rs[k].vend);
+                    else
+                        for (auto it = std::upper_bound(orig.begin(), orig.end(), rs[k].vbeg, [](uint64_t v, const BaiIndex::Chunk &c) { return v < c.second; });
+                             it != orig.end() && it->first < rs[k].vend; ++it)
+                            backlog.emplace_back(std::max(it->first, rs[k].vbeg), std::min(it->second, rs[k].vend));
+                }
+            }
+        };
+        auto collect_oldest = [&]() {
+            InFlight f = std::move(fly.front());
+            fly.pop_front();
+            const uint64_t t0 = now_us();
+            pd_decode_result res;
+            const bool ok = eng->ck(api->decode_collect(eng->ctx, f.ticket, f.status.data(), &res), "pd_decode_collect");
+            us_submit += now_us() - t0;
+            if (ok) take(f, res);
+            spare.push_back(std::move(f));
+        };
         for (;;) {
+            while ((int)fly.size() >= depth) collect_oldest();   // (depth 1: nothing is ever queued)
             // The buffer FIRST, then the batch number: the engine hands the batches of a compact session their places in batch order, so
             // the lowest number any thread holds must always belong to a thread that also holds a buffer (pd_decode_cfg::n_batches).
             void *hb = nullptr;
@@ -473,6 +542,10 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             }
             uint8_t *buf = (uint8_t *)hb;
             const uint64_t t_a = now_us();
+            InFlight f;
+            if (!spare.empty()) { f = std::move(spare.back()); spare.pop_back(); }
+            f.bi = bi;
+            std::vector<pd_bgzf_block> &blocks = f.blocks; std::vector<uint64_t> &bfile = f.bfile; std::vector<pd_decode_unit> &units = f.units; std::vector<int32_t> &status = f.status;
             blocks.clear(); bfile.clear(); units.clear();
             uint64_t pos = 0, uo = 0; bool bad = false;
             for (size_t k = 0; k < rs.size() && !bad; ++k) {
@@ -546,50 +619,22 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 continue;
             }
             status.assign(units.size(), 0);
+            f.pos = pos; f.uo = uo;
             pd_decode_batch bt{}; bt.host_buf = hb; bt.n_bytes = (size_t)pos; bt.blocks = blocks.data(); bt.n_blocks = (uint32_t)blocks.size();
             bt.inflated_bytes = uo; bt.units = units.data(); bt.n_units = (uint32_t)units.size(); bt.order = bi;
+            if (depth > 1) {
+                const bool ok = eng->ck(api->decode_queue(eng->ctx, &bt, &f.ticket), "pd_decode_queue");
+                us_submit += now_us() - t_b;
+                if (ok) fly.push_back(std::move(f)); else spare.push_back(std::move(f));      // (the loop's head passes the remaining numbers on)
+                continue;
+            }
             pd_decode_result res;
             const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
             us_submit += now_us() - t_b;
-            if (!ok) continue;                               // (the loop's head passes the remaining numbers on)
-            n_dev += res.n_reads; b_comp += pos; b_inf += uo;
-            if (res.n_first) { key_first[bi] = res.first_key; key_last[bi] = res.last_key; key_have[bi] = 1; if (res.unsorted) order_broken = 1; }
-            { std::lock_guard<std::mutex> lk(ms_mu); ms_sum[0] += res.ms_h2d; ms_sum[1] += res.ms_inflate; ms_sum[2] += res.ms_walk; ms_sum[3] += res.ms_emit; }
-            auto voff_of = [&](uint64_t u) -> uint64_t {      // inflated offset of the batch -> virtual file offset
-                if (u == UINT64_MAX) return UINT64_MAX;
-                size_t lo = 0, hi = blocks.size();
-                while (hi - lo > 1) { const size_t m = (lo + hi) / 2; if (blocks[m].out_off <= u) lo = m; else hi = m; }
-                // the end of a member is the start of the next one
-                while (lo + 1 < blocks.size() && u >= blocks[lo].out_off + blocks[lo].out_len) ++lo;
-                if (u >= blocks[lo].out_off + blocks[lo].out_len) return UINT64_MAX - 1;          // past everything this batch saw
-                return (bfile[lo] << 16) | (u - blocks[lo].out_off);
-            };
-            if (guess) {
-                if (status[0] != 0) { declined = 1; continue; }
-                chain_first[bi] = bi == 0 ? first_voff : voff_of(res.first_start);
-                chain_next[bi] = voff_of(res.next_start);
-            } else {
-                for (size_t k = 0; k < units.size(); ++k) {
-                    if (status[k] == 0) continue;
-                    // 1: the device leaves this unit to the host; 2: one of the members read for it does not inflate or fails its
-                    // CRC-32 — possibly one of the spare members behind the unit that no record of it needs; 3: it could not follow
-                    // the record chain.  In every case the host reader goes through exactly the bytes the unit needs and says what
-                    // is wrong with them, if anything is
-                    // It is only NOTED here: the pass can still be declined (a member scan that stops short in another batch, an
-                    // SO:coordinate header that does not hold), and a declined pass must not have counted anything — the host reader
-                    // then goes through the whole file.  The backlog is decoded after those checks, before pd_decode_end.
-                    // (a unit made of several chunks goes back chunk by chunk: what lies between them is not the host reader's
-                    // business, damaged or not)
-                    ++n_back;
-                    std::lock_guard<std::mutex> lk(back_mu);
-                    if (orig.empty()) backlog.emplace_back(rs[k].vbeg, rs[k].vend);
-                    else
-                        for (auto it = std::upper_bound(orig.begin(), orig.end(), rs[k].vbeg, [](uint64_t v, const BaiIndex::Chunk &c) { return v < c.second; });
-                             it != orig.end() && it->first < rs[k].vend; ++it)
-                            backlog.emplace_back(std::max(it->first, rs[k].vbeg), std::min(it->second, rs[k].vend));
-                }
-            }
+            if (ok) take(f, res);
+            spare.push_back(std::move(f));
         }
+        while (!fly.empty()) collect_oldest();
         ::close(fd);
     };
     {
@@ -615,10 +660,10 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         if (order_broken.load()) declined = 1;
     }
     if (getenv("PANDEPTH_TIMING"))
-        fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders, %llu records on the device, %llu units handed back (%llu records on the host)%s; "
+        fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders holding %d buffers each, %llu records on the device, %llu units handed back (%llu records on the host)%s; "
                         "feeder thread-seconds: read+scan %.2f, submit %.2f; device ms summed over batches: H2D %.1f, inflate %.1f, walk %.1f, emit %.1f; "
                         "bytes: compressed %llu, inflated %llu\n",
-                n_batches, guess ? "no index: guessed starts" : spans.synthetic ? "index cuts" : "index chunks of the targets", feeders,
+                n_batches, guess ? "no index: guessed starts" : spans.synthetic ? "index cuts" : "index chunks of the targets", feeders, depth,
                 (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(), (unsigned long long)n_host.load(), declined.load() ? " — DECLINED" : "",
                 us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3], (unsigned long long)b_comp.load(), (unsigned long long)b_inf.load());
     if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }

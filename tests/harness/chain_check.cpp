@@ -54,6 +54,32 @@ static int run_case(const Model &m, uint64_t seg_bytes, const std::set<size_t> &
         if (wrong_late.count(j) && g == pdb2::NONE) g = segs[j].begin + 1;                           // a start where none is (inside a long record)
         m.walk(segs[j], g);
     }
+    {   // the device form of the same confirmation (pdb2::chain_device, one wave; here its 64 lanes in a loop) on a copy: whenever it
+        // does not leave the batch to the host, it must arrive where check_chain's rounds arrive, and give every segment its place
+        std::vector<pdb2::Seg> dv = segs, hv = segs;
+        for (auto &x : dv) x.n_first = x.n_rec;
+        std::vector<int> member_ok(7, 0);
+        pdb2::ChainOut co; memset(&co, 0xAB, sizeof co);
+        uint32_t walks = 0;
+        pdb2::chain_device<pdw::HostWave>(dv.data(), (uint32_t)dv.size(), member_ok.data(), (uint32_t)member_ok.size(), ~0ull, ~0ull, 1000000u,
+            [&](uint32_t j, uint64_t start) { ++walks; m.walk(dv[j], start); dv[j].hint = start; dv[j].n_first = dv[j].n_rec;
+                                              return pdb2::WalkOut{dv[j].used_start, dv[j].e_last, dv[j].n_first, 0u, 0u, dv[j].n_rec, dv[j].flags, 0u}; }, &co);
+        std::vector<uint32_t> r2; int rr = 0;
+        while (pdb2::check_chain(hv, &r2) > 0 && ++rr <= 64) for (uint32_t j : r2) m.walk(hv[j], hv[j].hint);
+        bool host_flag = false;
+        for (auto &x : hv) if (x.flags) host_flag = true;
+        if (host_flag != (co.slow != 0)) { fprintf(stderr, "%s: device chain slow = %u, the host's chain %s a flag\n", what, co.slow, host_flag ? "carries" : "carries no"); return 1; }
+        if (!co.slow) {
+            uint64_t nf = 0, nr = 0;
+            for (size_t j = 0; j < dv.size(); ++j) {
+                if (dv[j].used_start != hv[j].used_start || dv[j].e_last != hv[j].e_last || dv[j].n_rec != hv[j].n_rec) { fprintf(stderr, "%s: device chain differs from the host's at segment %zu\n", what, j); return 1; }
+                if (dv[j].base_first != nf) { fprintf(stderr, "%s: device chain: place of segment %zu is %llu, the sum before it %llu\n", what, j, (unsigned long long)dv[j].base_first, (unsigned long long)nf); return 1; }
+                nf += dv[j].n_first; nr += dv[j].n_rec;
+            }
+            if (co.n_first != nf || co.n_rec != nr || co.n_redo != walks) { fprintf(stderr, "%s: device chain totals\n", what); return 1; }
+            if (walks > wrong_early.size() + wrong_late.size() + (size_t)max_rounds * 4 + 8) { fprintf(stderr, "%s: device chain walked %u segments again\n", what, walks); return 1; }
+        }
+    }
     std::vector<uint32_t> redo;
     int rounds = 0;
     while (pdb2::check_chain(segs, &redo) > 0) {

@@ -36,7 +36,10 @@ struct pd_ctx {
     // decode_*: the same batch protocol as libpandepth_amd.so's, run with the product's cores (pd_inflate_wave.h,
     // pd_bamwalk.h) in host emulation, so that the CPU suite drives the feeder of host/pipeline.cpp too
     pd_decode_cfg dcfg{}; std::vector<uint8_t> on; std::vector<uint32_t> soff; std::vector<int32_t> spans;
-    struct Buf { std::vector<uint8_t> b; bool busy = false; };
+    struct Buf { std::vector<uint8_t> b; bool busy = false;
+                 // a batch between decode_queue and decode_collect: what decode_submit answered, kept until it is asked for
+                 bool queued = false; uint64_t ticket = 0; int rc = 0; std::vector<int32_t> status; pd_decode_result res{}; };
+    uint64_t tickets = 0; uint64_t n_chain_dev = 0, n_chain_host = 0, n_chain_redo = 0;
     std::vector<Buf *> bufs;
     struct Runs { uint64_t order; std::vector<pd_iv> first, other, far; };
     std::vector<Runs> runs;
@@ -191,12 +194,44 @@ static int o_decode_acquire(pd_ctx *c, size_t bytes, void **out)
     *out = b->b.data();
     return 0;
 }
+static int o_decode_batch(pd_ctx *c, const pd_decode_batch *bt, int32_t *status, pd_decode_result *res);
 static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status, pd_decode_result *res)
 {
     pd_ctx::Buf *mine = nullptr;
-    { std::lock_guard<std::mutex> lk(c->mu); for (auto *x : c->bufs) if (x->busy && x->b.data() == bt->host_buf) mine = x; }
+    { std::lock_guard<std::mutex> lk(c->mu); for (auto *x : c->bufs) if (x->busy && !x->queued && x->b.data() == bt->host_buf) mine = x; }
     if (!mine) { c->err = "submit: unknown buffer"; return -1; }
     struct Rel { pd_ctx *c; pd_ctx::Buf *b; ~Rel() { std::lock_guard<std::mutex> lk(c->mu); b->busy = false; } } rel{c, mine};
+    return o_decode_batch(c, bt, status, res);
+}
+// pd_decode_queue / pd_decode_collect: the batch is decoded at once (there is no device to wait for here) and its answer kept under a
+// ticket; the buffer stays the engine's until the batch is collected, as the product's does
+static int o_decode_queue(pd_ctx *c, const pd_decode_batch *bt, uint64_t *ticket)
+{
+    pd_ctx::Buf *mine = nullptr;
+    { std::lock_guard<std::mutex> lk(c->mu); for (auto *x : c->bufs) if (x->busy && !x->queued && x->b.data() == bt->host_buf) mine = x; }
+    if (!mine) { c->err = "queue: unknown buffer"; return -1; }
+    mine->status.assign(bt->n_units + 1, 0);
+    mine->rc = o_decode_batch(c, bt, mine->status.data(), &mine->res);
+    if (mine->rc) { std::lock_guard<std::mutex> lk(c->mu); mine->busy = false; return mine->rc; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    mine->queued = true; mine->ticket = *ticket = ++c->tickets;
+    return 0;
+}
+static int o_decode_collect(pd_ctx *c, uint64_t ticket, int32_t *status, pd_decode_result *res)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (auto *x : c->bufs)
+        if (x->busy && x->queued && x->ticket == ticket) {
+            if (status) for (size_t u = 0; u + 1 < x->status.size(); ++u) status[u] = x->status[u];
+            if (res) *res = x->res;
+            x->queued = false; x->busy = false;
+            return 0;
+        }
+    c->err = "collect: not the ticket of a queued batch";
+    return -1;
+}
+static int o_decode_batch(pd_ctx *c, const pd_decode_batch *bt, int32_t *status, pd_decode_result *res)
+{
     if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
     if (c->compact && bt->order < c->orders_seen.size()) {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -232,7 +267,37 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
     seg0[bt->n_units] = (uint32_t)segs.size();
     std::vector<pdb2::LaneOut> lanes(segs.size() * 64);
     for (size_t j = 0; j < segs.size(); ++j) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64]);
-    std::vector<uint32_t> redo;                                  // the chain across segments, as pd_decode_submit does it
+    if (const char *e = getenv("PANDEPTH_TEST_SPOIL_GUESS")) {
+        // (test hook: every k-th segment behind a unit's first walks again from a start that is no record — what a wrong guess of the
+        // header search looks like to whoever confirms the chain, here far more often than real data ever shows one)
+        const size_t k = (size_t)std::max(1, atoi(e));
+        for (size_t j = 0; j < segs.size(); ++j)
+            if (!segs[j].unit_first && j % k == 0) { const uint64_t h = segs[j].begin + 1 + (j % 7); pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], &h); }
+    }
+    // the chain across segments, as the product confirms it: in a compact session whose units start at known records by the device form
+    // (pdb2::chain_device, here with its lanes in a loop) — and, whenever that leaves the batch to the host, or in any other session, by
+    // check_chain's rounds
+    bool guess_unit = false;
+    for (uint32_t u = 0; u < bt->n_units; ++u) if (bt->units[u].flags & PD_UNIT_GUESS) guess_unit = true;
+    if (c->compact && !guess_unit && !segs.empty() && !getenv("PANDEPTH_TEST_HOST_CHAIN")) {
+        pdb2::ChainOut co;
+        const uint32_t max_redo = getenv("PANDEPTH_TEST_MAX_REDO") ? (uint32_t)atoi(getenv("PANDEPTH_TEST_MAX_REDO")) : 256u;
+        pdb2::chain_device<pdw::HostWave>(segs.data(), (uint32_t)segs.size(), bst.data(), bt->n_blocks, bt->inflated_bytes / 41 + 64, bt->inflated_bytes / 41 + 64, max_redo,
+            [&](uint32_t j, uint64_t start) { return pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[(size_t)j * 64], &start); }, &co);
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (co.slow) ++c->n_chain_host; else ++c->n_chain_dev;
+        c->n_chain_redo += co.n_redo;
+        if (!co.slow) {
+            // what the device reports must be what the host's rounds would have arrived at: they now find nothing left to do
+            uint64_t nf0 = 0, no0 = 0, nr0 = 0;
+            for (auto &x : segs) { if (x.base_first != nf0 || x.base_other != no0) c->compact_err = "chain_device: a segment's place is not the sum of the counts before it"; nf0 += x.n_first; no0 += x.n_other; nr0 += x.n_rec; }
+            if (co.n_first != nf0 || co.n_other != no0 || co.n_rec != nr0) c->compact_err = "chain_device: totals disagree with the segments";
+            std::vector<uint32_t> r0;
+            if (pdb2::check_chain(segs, &r0) != 0) c->compact_err = "chain_device: the host's check finds a segment that does not start where the chain ends";
+            for (auto &x : segs) if (x.flags) c->compact_err = "chain_device: a flagged segment was not left to the host";
+        }
+    }
+    std::vector<uint32_t> redo;
     for (int round = 0; pdb2::check_chain(segs, &redo) > 0; ++round) {
         if (round >= 24) { for (uint32_t j : redo) segs[j].flags |= pdb2::WF_BAD; break; }
         for (uint32_t j : redo) pdb2::walk_segment<pdw::HostWave>(cfg, segs[j], &lanes[(size_t)j * 64]);
@@ -307,6 +372,11 @@ static int o_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *status
 }
 static int o_decode_end(pd_ctx *c)
 {
+    {   // (the product collects and drops what the caller left queued; the stand-in holds the feeder to collecting every batch itself)
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (auto *x : c->bufs) if (x->queued) { c->err = "decode_end: a queued batch was never collected"; return -4; }
+        if (getenv("PANDEPTH_TEST_CHAIN_STATS")) fprintf(stderr, "[chain] batches confirmed by chain_device: %llu, left to check_chain: %llu, segments chain_device walked again: %llu\n", (unsigned long long)c->n_chain_dev, (unsigned long long)c->n_chain_host, (unsigned long long)c->n_chain_redo);
+    }
     if (c->compact) {
         std::lock_guard<std::mutex> lk(c->mu);
         for (uint8_t seen : c->orders_seen) if (seen != 1 && c->compact_err.empty()) c->compact_err = "a batch number of the session was never submitted";
@@ -324,7 +394,7 @@ static int o_decode_end(pd_ctx *c)
     if (!rc && !far.empty()) rc = o_push(c, far.data(), far.size(), PD_PUSH_DEFAULT);
     return rc;
 }
-static int o_decode_abort(pd_ctx *c) { std::lock_guard<std::mutex> lk(c->mu); c->runs.clear(); return 0; }
+static int o_decode_abort(pd_ctx *c) { std::lock_guard<std::mutex> lk(c->mu); c->runs.clear(); for (auto *x : c->bufs) { x->queued = false; x->busy = false; } return 0; }
 static int o_set_param(pd_ctx *, const char *, uint64_t) { return 0; }
 // pd_deflate_parse on the CPU: the product's parse (csrc/pd_lz77.h) with its 64 lanes in a loop
 static int o_deflate_parse(pd_ctx *, const void *text, size_t n, const pd_lz_chunk *chunks, uint32_t n_chunks, uint32_t *syms, size_t cap, uint64_t *off)
@@ -433,6 +503,7 @@ int main(int argc, char **argv)
                                       o_decode_begin, o_decode_acquire, o_decode_submit, o_decode_end, o_decode_abort, o_set_param,
                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, no_parse ? nullptr : o_deflate_parse, nullptr, nullptr,
                                       no_parse ? nullptr : o_text_open, o_text_close, o_text_append_sites, o_text_parse, o_text_read, o_text_release,
-                                      no_parse ? nullptr : o_text_append_window_rows, o_text_append_bytes};
+                                      no_parse ? nullptr : o_text_append_window_rows, o_text_append_bytes, nullptr,
+                                      getenv("PANDEPTH_TEST_NO_QUEUE") ? nullptr : o_decode_queue, getenv("PANDEPTH_TEST_NO_QUEUE") ? nullptr : o_decode_collect};
     return pandepth_main(argc, argv, &api, 0);
 }

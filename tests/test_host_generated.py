@@ -288,3 +288,87 @@ def test_declined_pass_has_counted_nothing(data):
                 if "DECLINED" in line and " 0 units handed back" not in line:
                     hit += 1
     assert hit, "no case had a unit handed back before the pass was declined: the test does not exercise what it is for"
+
+
+# ---- round 5: the record chain confirmed on the device, batches queued and collected ----------------------------------------------
+def _expected_chr(data):
+    """the whole-chromosome table of g.bam: the reference's when it is here, else the oracle's"""
+    if os.access(REF, os.X_OK):
+        subprocess.run([REF, "-i", "g.bam", "-o", "ref_chain"], cwd=data, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        return gzip.decompress((data / "ref_chain.chr.stat.gz").read_bytes()).decode()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pd_oracle as O
+    return O.run(["-i", "g.bam"], cwd=str(data))["chr.stat.gz"]
+
+
+QUEUE_CASES = [
+    # (id, PANDEPTH_TUNE, extra environment of the stand-in engine, what its [chain] line must say)
+    ("depth1", "dd_batch_mb=1,dd_depth=1,dd_threads=4", {}, "dev"),
+    ("depth2", "dd_batch_mb=1,dd_depth=2,dd_threads=6", {}, "dev"),
+    ("depth3", "dd_batch_mb=1,dd_depth=3,dd_threads=4", {}, "dev"),
+    ("depth_clamped", "dd_batch_mb=1,dd_depth=5,dd_threads=6", {}, "dev"),          # twelve slots: six readers hold two each
+    ("no_queue_entry", "dd_batch_mb=1", {"PANDEPTH_TEST_NO_QUEUE": "1"}, "dev"),      # an engine without decode_queue: submit, as before
+    ("spoil_every", "dd_batch_mb=1", {"PANDEPTH_TEST_SPOIL_GUESS": "1"}, "redo"),
+    ("spoil_third", "dd_batch_mb=2", {"PANDEPTH_TEST_SPOIL_GUESS": "3"}, "redo"),
+    ("spoil_left_to_host", "dd_batch_mb=1", {"PANDEPTH_TEST_SPOIL_GUESS": "2", "PANDEPTH_TEST_MAX_REDO": "1"}, "host"),
+    ("host_chain", "dd_batch_mb=1", {"PANDEPTH_TEST_HOST_CHAIN": "1", "PANDEPTH_TEST_SPOIL_GUESS": "2"}, "none"),
+]
+
+
+@pytest.mark.parametrize("name,tune,extra,expect", QUEUE_CASES, ids=[c[0] for c in QUEUE_CASES])
+def test_queued_batches_and_device_chain(data, name, tune, extra, expect):
+    """pd_decode_queue / pd_decode_collect through the product's feeder (host/pipeline.cpp) on the stand-in engine, whose batches run
+    the product's cores — pdb2::chain_device included — with their lanes in a loop: whatever the readers hold in flight, and however many
+    guessed record starts are spoilt behind the first pass, the table is the reference's; chain_device repairs what it is allowed to
+    and leaves the rest to check_chain."""
+    import re
+    env = dict(os.environ, PANDEPTH_TUNE=tune, PANDEPTH_TEST_CHAIN_STATS="1", **extra)
+    p = subprocess.run([os.path.join(HERE, "harness", "pandepth_oracle_cli"), "-i", "g.bam", "-o", "q_" + name, "-t", "6"], cwd=data,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    assert gzip.decompress((data / ("q_%s.chr.stat.gz" % name)).read_bytes()).decode() == _expected_chr(data)
+    m = re.search(r"confirmed by chain_device: (\d+), left to check_chain: (\d+), segments chain_device walked again: (\d+)", p.stderr.decode())
+    assert m, p.stderr.decode()[-400:]
+    dev, host, redo = (int(x) for x in m.groups())
+    if expect == "dev":
+        assert dev > 3 and host == 0 and redo == 0
+    elif expect == "redo":
+        assert dev > 3 and host == 0 and redo > 10
+    elif expect == "host":
+        assert host > 3
+    else:
+        assert dev == 0 and host == 0
+
+
+GPU_CHAIN_CASES = [
+    ("fast_depth2", "dd_batch_mb=1"),
+    ("fast_depth3", "dd_batch_mb=1,dd_depth=3,dd_threads=4"),
+    ("fast_depth1", "dd_batch_mb=2,dd_depth=1"),
+    ("host_chain", "dd_batch_mb=1,decode_fast=0"),
+    ("spoil_every", "dd_batch_mb=1,decode_spoil=1"),
+    ("spoil_third_depth1", "dd_batch_mb=2,decode_spoil=3,dd_depth=1"),
+    ("spoil_left_to_host", "dd_batch_mb=1,decode_spoil=2,decode_max_redo=1"),
+    ("spoil_host_chain", "dd_batch_mb=1,decode_spoil=2,decode_fast=0"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tune", GPU_CHAIN_CASES, ids=[c[0] for c in GPU_CHAIN_CASES])
+def test_queued_batches_and_device_chain_gpu(data, name, tune):
+    """the same on the MI355X: k_chain_segments confirms (and, with decode_spoil, repairs) every batch's chain between the two record
+    passes, the readers queue and collect; byte-identical with the reference whatever is in flight and whoever repairs."""
+    import re
+    env = dict(os.environ, PANDEPTH_TUNE=tune, PANDEPTH_TIMING="1")
+    p = subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth"), "-i", "g.bam", "-o", "gq_" + name, "-t", "6"], cwd=data,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    assert gzip.decompress((data / ("gq_%s.chr.stat.gz" % name)).read_bytes()).decode() == _expected_chr(data)
+    m = re.search(r"chain confirmed on the device for (\d+) batches, by the host for (\d+); segments the device walked again: (\d+)", p.stderr.decode())
+    assert m, p.stderr.decode()[-600:]
+    dev, host, redo = (int(x) for x in m.groups())
+    if "decode_fast=0" in tune:
+        assert dev == 0
+    elif "decode_max_redo=1" in tune:
+        assert host > 3
+    else:
+        assert dev > 3 and host == 0 and (redo > 10) == ("decode_spoil" in tune)
