@@ -114,7 +114,12 @@ def parse_timing(err):
         if m:
             ph[m.group(1).strip()] = float(m.group(2))
             ph["total_in_main"] = float(m.group(3))
-        m = re.search(r"device decode: (\d+) batches .*?(\d+) feeders, (\d+) records on the device, (\d+) units handed back \((\d+) records on the host\).*?"
+        m = re.match(r"\[timing\] comm init\s+([0-9.]+) s   \((.*?)\)", ln)
+        if m:
+            ph["comm_init"] = float(m.group(1))
+            w = re.search(r"waited ([0-9.]+) s", m.group(2))
+            ph["comm_init_waited_for"] = float(w.group(1)) if w else float(m.group(1))
+        m = re.search(r"device decode: (\d+) batches .*?(\d+) feeders(?: holding \d+ buffers each)?, (\d+) records on the device, (\d+) units handed back \((\d+) records on the host\).*?"
                       r"device ms summed over batches: H2D ([0-9.]+), inflate ([0-9.]+), walk ([0-9.]+), emit ([0-9.]+); bytes: compressed (\d+), inflated (\d+)", ln)
         if m:
             dec = {"batches": int(m.group(1)), "feeders": int(m.group(2)), "records_on_device": int(m.group(3)), "units_handed_back": int(m.group(4)),

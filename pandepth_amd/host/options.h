@@ -22,6 +22,7 @@ struct Options {
     int min_dep = 1;
     uint32_t flag_mask = 1796;
     int threads = 3;
+    int decode_readers = 0;                                // device decode: reader threads per context (0: min(threads, 6)); a `#.list` run sets it so that a context's readers do not shrink with -t / #GPUs — they wait for the device most of the time
     std::string reference;            // -r: FASTA behind -c's GC(%) column (host/fasta.h)
     int win = 0;
     bool site_out = false;               // -a

@@ -419,13 +419,13 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         if (sflat.empty()) sflat.push_back(0);
         cfg.span_off = soff.data(); cfg.spans = sflat.data();
     }
-    int feeders = std::min<int>(std::max(1, o.threads), 6);
+    int feeders = o.decode_readers > 0 ? o.decode_readers : std::min<int>(std::max(1, o.threads), 6);
     if (const char *e = tune("dd_threads")) feeders = std::max(1, atoi(e));
     if ((size_t)feeders > batches.size()) feeders = (int)batches.size();
     // A reader does not wait for the device: it queues its batch (decode_queue: copy, inflate, both record passes and the chain check between
     // them all go on the batch's stream) and reads the next one meanwhile; it holds `depth` buffers — the one it is filling and depth - 1
     // queued batches — and collects the oldest when it needs a buffer back.  (The engine has twelve batch slots.)
-    int depth = api->decode_queue && api->decode_collect ? 2 : 1;
+    int depth = api->decode_queue && api->decode_collect ? 3 : 1;                    // (clamped below: six readers hold two each, four hold three)
     if (const char *e = tune("dd_depth")) depth = std::max(1, atoi(e));
     if (!api->decode_queue || !api->decode_collect) depth = 1;
     depth = std::max(1, std::min(depth, 12 / std::max(1, feeders)));
@@ -1271,14 +1271,23 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     std::vector<std::unique_ptr<Engine>> engs;
     // (the executable leaves without tearing the engine down — the process is about to end; library users of pandepth_main keep the destroy)
     struct CtxGuard { std::vector<std::unique_ptr<Engine>> *v; ~CtxGuard() { if (getenv("PANDEPTH_KEEP_CONTEXT")) return; for (auto &e : *v) if (e->ctx) e->api->destroy(e->ctx); } } guard{&engs};
-    for (int k = 0; k < n_ctx; ++k) {
-        engs.emplace_back(new Engine);
-        engs.back()->api = api;
-        if (api->create((device + k) % n_dev, (int32_t)hdr.lens.size(), hdr.lens.data(), &engs.back()->ctx) != 0) {
-            const char *m = api->strerror(nullptr);
-            std::cerr << "Error: depth engine unavailable: " << (m ? m : "?") << std::endl;
-            return 2;
+    for (int k = 0; k < n_ctx; ++k) { engs.emplace_back(new Engine); engs.back()->api = api; }
+    {   // the contexts are made side by side (a context costs 0.04-0.09 s of runtime start-up, queues and buffers: eight in a row were 0.5 s
+        // before the first byte was read); the first failure is the one reported
+        std::vector<int> rcs((size_t)n_ctx, 0);
+        auto make = [&](int k) { rcs[(size_t)k] = api->create((device + k) % n_dev, (int32_t)hdr.lens.size(), hdr.lens.data(), &engs[(size_t)k]->ctx); };
+        if (n_ctx == 1) make(0);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < n_ctx; ++k) th.emplace_back(make, k);
+            for (auto &t : th) t.join();
         }
+        for (int k = 0; k < n_ctx; ++k)
+            if (rcs[(size_t)k] != 0) {
+                const char *m = api->strerror(nullptr);
+                std::cerr << "Error: depth engine unavailable: " << (m ? m : "?") << std::endl;
+                return 2;
+            }
     }
     Engine &eng = *engs[0];
     // the table's gzip stream: zlib's LZ77 parse on the engine (large -w tables); the writer forgets the engine before it goes
@@ -1289,6 +1298,41 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
+    // Several contexts: their RCCL communicator is made on a side thread WHILE the files are decoded (an eight-rank bootstrap takes longer
+    // than a small list run does) and joined by the first collective.  RCCL prints a banner on stdout when a communicator is made; this
+    // program's stdout is compared byte for byte with the reference's, so descriptor 1 points at /dev/null meanwhile — nothing of ours is
+    // printed between the inputs' classification (before the job starts) and "Input data read done" (after it has been joined).
+    struct Quiet {
+        int saved = -1;
+        Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
+        ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
+    };
+    struct CommJob {
+        std::thread th; std::vector<pd_comm *> comms; int rc = -1; bool started = false, taken = false; double secs = 0; std::string why;
+        const pd_engine_api *api = nullptr;
+        void wait() { if (th.joinable()) th.join(); }
+        ~CommJob() { wait(); if (started && !taken && rc == 0 && api && api->comm_destroy) for (pd_comm *m : comms) if (m) api->comm_destroy(m); }      // (made, never used: a run that failed meanwhile)
+    } comm_job;
+    comm_job.api = api;
+    const bool comm_possible = !paf && api->comm_init_all && (n_ctx > 1 || (tune("rccl") && !strcmp(tune("rccl"), "force"))) &&
+                               (n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) && !(tune("rccl") && tune("rccl")[0] == '0');
+    auto start_comm = [&]() {
+        // (the modes whose statistics go through the sliced sum: everything but the per-site file, which adds the contexts into one GPU)
+        if (!comm_possible || o.site_out || comm_job.started) return;
+        if (tune("comm_overlap") && tune("comm_overlap")[0] == '0') return;
+        comm_job.started = true;
+        comm_job.comms.assign((size_t)n_ctx, nullptr);
+        comm_job.th = std::thread([&]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::unique_ptr<Quiet> quiet(tune("rccl_verbose") ? nullptr : new Quiet);
+            std::vector<pd_ctx *> ctxs;
+            for (auto &e : engs) ctxs.push_back(e->ctx);
+            comm_job.rc = api->comm_init_all(ctxs.data(), n_ctx, comm_job.comms.data());
+            if (comm_job.rc != 0) { const char *m = api->strerror(engs[0]->ctx); comm_job.why = m ? m : "?"; }
+            quiet.reset();
+            comm_job.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    };
 
     bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
     if (paf) {
@@ -1328,7 +1372,14 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             inputs.push_back({fp, sorted ? 1 : 2});
         }
         Options o_part = o;
-        if (n_ctx > 1) o_part.threads = std::max(1, o.threads / n_ctx);
+        if (n_ctx > 1) {
+            // the CPU-heavy parts of a context (host readers, handed-back units) get their share of -t; the device decode's readers do not
+            // shrink with it — a reader copies a batch out of the page cache (2 ms per 32 MB) and then waits for the device — so every
+            // GPU keeps four of them, three buffers each, whatever -t / #GPUs comes to
+            o_part.threads = std::max(1, o.threads / n_ctx);
+            o_part.decode_readers = 4;
+        }
+        start_comm();
         auto run_inputs = [&](int k) {
             Engine *e = engs[k].get();
             for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
@@ -1398,16 +1449,30 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
         // RCCL announces itself on stdout (a version banner, from whichever thread first gets there); this program's stdout
         // is compared byte for byte with the reference's, and nothing of ours is printed until the sum is done
-        struct Quiet {
-            int saved = -1;
-            Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
-            ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
-        };
-        std::unique_ptr<Quiet> quiet(tune("rccl_verbose") ? nullptr : new Quiet);
-        if (api->comm_init_all(ctxs.data(), n_ctx, comms.data()) != 0) {
-            quiet.reset();
-            if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
-            return 0;
+        std::unique_ptr<Quiet> quiet;
+        if (comm_job.started && !comm_job.taken) {
+            // the communicator made behind the decode
+            const auto t0 = std::chrono::steady_clock::now();
+            comm_job.wait();
+            comm_job.taken = true;
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (on a side thread behind the decode; the first collective waited %.3f s for it)\n", "comm init", comm_job.secs, waited);
+            if (comm_job.rc != 0) {
+                if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", comm_job.why.c_str(), device);
+                return 0;
+            }
+            comms = comm_job.comms;
+            quiet.reset(tune("rccl_verbose") ? nullptr : new Quiet);
+        } else {
+            quiet.reset(tune("rccl_verbose") ? nullptr : new Quiet);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int irc = api->comm_init_all(ctxs.data(), n_ctx, comms.data());
+            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (in line, before the first collective)\n", "comm init", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            if (irc != 0) {
+                quiet.reset();
+                if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
+                return 0;
+            }
         }
         std::vector<int> rcs((size_t)n_ctx, 0);
         std::vector<std::thread> th;
