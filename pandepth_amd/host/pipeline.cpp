@@ -445,6 +445,8 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     std::atomic<size_t> next{0};
     std::atomic<uint64_t> n_dev{0}, n_host{0}, n_back{0}, us_read{0}, us_submit{0}, b_comp{0}, b_inf{0};
     std::atomic<int> declined{0};
+    std::mutex why_mu; std::string decline_why;                  // (PANDEPTH_TIMING: what made the device pass give the file back)
+    auto decline = [&](const std::string &why) { { std::lock_guard<std::mutex> lk(why_mu); if (decline_why.empty()) decline_why = why; } declined = 1; };
     std::vector<uint64_t> chain_first(n_batches, UINT64_MAX), chain_next(n_batches, UINT64_MAX);   // no-index: virtual offsets
     std::vector<uint64_t> key_first(n_batches, 0), key_last(n_batches, 0);                         // order of the first runs across batches
     std::vector<uint8_t> key_have(n_batches, 0);
@@ -485,7 +487,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 return (bfile[lo] << 16) | (u - blocks[lo].out_off);
             };
             if (guess) {
-                if (status[0] != 0) { declined = 1; return; }
+                if (status[0] != 0) { decline("batch " + std::to_string(bi) + ": unit status " + std::to_string(status[0])); return; }
                 chain_first[bi] = bi == 0 ? first_voff : voff_of(res.first_start);
                 chain_next[bi] = voff_of(res.next_start);
             } else {
@@ -567,7 +569,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                         for (; okc < 3 && q + 18 <= wn; ++okc) { uint32_t d0 = 0; const uint32_t bs = bgzf_block_size(w + q, wn - q, &d0); if (!bs) break; q += bs; }
                         if (okc == 3 || (okc > 0 && q + 18 > wn)) { found = true; break; }
                     }
-                    if (!found) { declined = 1; bad = true; break; }
+                    if (!found) { decline("batch " + std::to_string(bi) + ": no BGZF member found at the guessed offset"); bad = true; break; }
                 }
                 const size_t b0 = blocks.size();
                 const uint64_t own_end = guess ? std::min(F, (rs[k].vbeg >> 16) + batch_bytes) : 0;      // members starting before this belong to the batch
@@ -585,7 +587,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 {   // the member scan must have covered what this unit owns: stopping earlier means a member header that is not one
                     // (or a file that ends inside a member) — the host reader goes through such a file and says what is wrong
                     const uint64_t need = guess ? own_end : (rs[k].vend == UINT64_MAX ? F : std::min(F, rs[k].vend >> 16));
-                    if (a + p < need) { declined = 1; bad = true; break; }
+                    if (a + p < need) { decline("batch " + std::to_string(bi) + ": the member scan stopped short"); bad = true; break; }
                 }
                 if (blocks.size() == b0) { if (guess) { continue; } eng->fail("index offsets of " + path + " do not match its BGZF blocks"); bad = true; break; }
                 pd_decode_unit un{};
@@ -646,7 +648,10 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     if (guess && eng->ok() && !declined.load()) {
         // the record chain across the batches (virtual offsets; the end of a member equals the start of the next one)
         for (size_t k = 0; k + 1 < n_batches; ++k)
-            if (chain_next[k] != chain_first[k + 1] || chain_next[k] >= UINT64_MAX - 1) { declined = 1; break; }
+            if (chain_next[k] != chain_first[k + 1] || chain_next[k] >= UINT64_MAX - 1) {
+                char b[160]; snprintf(b, sizeof b, "the record chain of batch %zu ends at %llx, batch %zu starts at %llx", k, (unsigned long long)chain_next[k], k + 1, (unsigned long long)chain_first[k + 1]);
+                decline(b); break;
+            }
     }
     if (sorted && eng->ok() && !declined.load()) {
         // the header said SO:coordinate; a file whose records are not in that order is read on the host, the reference's way
@@ -657,14 +662,14 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             if (have && key_first[k] < prev) order_broken = 1;
             prev = key_last[k]; have = true;
         }
-        if (order_broken.load()) declined = 1;
+        if (order_broken.load()) decline("the records are not in the order SO:coordinate promises");
     }
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing] device decode: %zu batches (%s), %d feeders holding %d buffers each, %llu records on the device, %llu units handed back (%llu records on the host)%s; "
                         "feeder thread-seconds: read+scan %.2f, submit %.2f; device ms summed over batches: H2D %.1f, inflate %.1f, walk %.1f, emit %.1f; "
                         "bytes: compressed %llu, inflated %llu\n",
                 n_batches, guess ? "no index: guessed starts" : spans.synthetic ? "index cuts" : "index chunks of the targets", feeders, depth,
-                (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(), (unsigned long long)n_host.load(), declined.load() ? " — DECLINED" : "",
+                (unsigned long long)n_dev.load(), (unsigned long long)n_back.load(), (unsigned long long)n_host.load(), declined.load() ? (" — DECLINED (" + decline_why + ")").c_str() : "",
                 us_read.load() / 1e6, us_submit.load() / 1e6, ms_sum[0], ms_sum[1], ms_sum[2], ms_sum[3], (unsigned long long)b_comp.load(), (unsigned long long)b_inf.load());
     if (!eng->ok()) { api->decode_abort(eng->ctx); return -1; }
     if (declined.load()) { api->decode_abort(eng->ctx); return 0; }          // nothing of this input has been counted
