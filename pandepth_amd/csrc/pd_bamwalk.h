@@ -388,7 +388,7 @@ inline uint32_t check_chain(Vec &segs, Redo *redo)
 // any segment (a record that cannot be one, that runs past the unit's bytes, a CIGAR in the CG tag), more repeats than
 // `max_redo`, far runs, or more runs than the batch's arrays hold set ChainOut::slow — pass 2 then writes nothing and the host
 // goes through the batch the way it always did (check_chain, unit outcomes, hand-backs).
-struct ChainOut { uint64_t n_first, n_other, n_rec; uint32_t max_span, slow, n_redo, pad; uint64_t pad2[3]; };   // 64 bytes
+struct ChainOut { uint64_t n_first, n_other, n_rec; uint32_t max_span, slow, n_redo, pad; uint64_t first_start, next_start /* unit 0: pd_decode_result's */, pad2; };   // 64 bytes
 enum { CH_MEMBER = 1, CH_FLAG = 2, CH_REDO = 4, CH_ROOM = 8, CH_FAR = 16 };
 
 template <class W, class RW>
@@ -404,6 +404,7 @@ PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uin
         if (W::ballot_ne(bad, 0u)) slow |= CH_MEMBER;
     }
     uint64_t E = 0, nf = 0, no = 0, nr = 0;
+    uint64_t fs0 = NONE, e0 = 0; uint32_t units_seen = 0;           // unit 0: the first record it owns, and where its chain ends
     for (uint32_t j0 = 0; j0 < n_seg && !slow; j0 += 64) {
         const uint32_t cnt = n_seg - j0 < 64u ? n_seg - j0 : 64u;
         U64 us, el, en;
@@ -423,7 +424,7 @@ PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uin
             const uint64_t ufm = W::ballot_ne(m, 0u);
             const uint32_t hi = ufm ? (uint32_t)ctz64(ufm) : cnt;
             const bool head = W::bcast(uf, (int)lo) != 0;             // the stretch begins its unit: nothing before it to be checked against
-            if (head) E = 0;
+            if (head) { E = 0; ++units_seen; }
             for (;;) {
                 U64 e, eb;
                 W::each([&](int l) { e[l] = (uint32_t)l >= lo && (uint32_t)l < hi ? el[l] : 0ull; });
@@ -451,6 +452,13 @@ PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uin
                 if (w.used_start != (start >= seg_end ? NONE : start)) { slow |= CH_REDO; break; }      // (a walk that does not start where it was told to: the host looks at it)
                 W::each([&](int l) { if (l == jb) { us[l] = w.used_start; el[l] = w.e_last; cf[l] = w.n_first; co[l] = w.n_other; cr[l] = w.n_rec; ms[l] = w.max_span; fl[l] = 0; } });
             }
+            if (units_seen == 1 && !slow) {
+                U64 own;
+                W::each([&](int l) { own[l] = (uint32_t)l >= lo && (uint32_t)l < hi ? us[l] : NONE; });
+                const uint64_t f = W::reduce_min64(own);
+                if (fs0 == NONE) fs0 = f;
+                e0 = E;
+            }
             lo = hi;
         }
         if (slow) break;
@@ -469,7 +477,7 @@ PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uin
     }
     if (nf > cap_first || no > cap_other) slow |= CH_ROOM;
     W::each([&](int l) {
-        if (l == 0) { out->n_first = nf; out->n_other = no; out->n_rec = nr; out->max_span = max_span; out->slow = slow; out->n_redo = n_redo; out->pad = 0; out->pad2[0] = out->pad2[1] = out->pad2[2] = 0; }
+        if (l == 0) { out->n_first = nf; out->n_other = no; out->n_rec = nr; out->max_span = max_span; out->slow = slow; out->n_redo = n_redo; out->pad = 0; out->first_start = fs0; out->next_start = e0 ? e0 : NONE; out->pad2 = 0; }
     });
 }
 

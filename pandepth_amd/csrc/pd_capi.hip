@@ -226,7 +226,9 @@ struct pd_ctx {
     bool sums_stale = false;                                      // the tile sums hold what a direct export wrote while the sample is still deferred
     uint32_t *direct_words = nullptr;                             // [n_long, fail, heavy_count, pad | heavy tile list]
     bool dec_crc = true;                                          // the decoder checks every member's CRC-32 ("decode_crc")
-    unsigned lz_group = 0;                                        // chunks per workgroup of the LDS parse ("lz_group", up to 16; 0, the default: every chunk parses with its text in memory — measured faster at 16 + 4 KiB chunks)
+    unsigned lz_group = 16;                                       // chunks per workgroup of the LDS parse ("lz_group", up to 16; 0: every chunk parses with its text in memory).  Round 5's default: sixteen
+                                                                  // chunks of 8 + 2 KiB share a CU's LDS (158 KB: 32 KiB of history + their text), 16 waves per CU — 8.6 ms against 11.8 for the 60 MB call of
+                                                                  // profiles/r04_lz_parse_ab.txt, and the text is fetched once instead of ~1 000 times; chunks of 16 KiB fit seven to a CU and lose
     unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
     bool dec_fast = true;                                         // the record chain of a batch is confirmed on the device where the session allows it ("decode_fast")
     uint32_t dec_spoil = 0;                                       // test hook: every k-th segment's guess is spoilt after pass 1 ("decode_spoil")
@@ -1418,8 +1420,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (ns) HIPOK(c, hipMemcpy(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice));
     }
     c->dec_cfg.contig_on = nullptr; c->dec_cfg.span_off = nullptr; c->dec_cfg.spans = nullptr;      // (the caller's arrays are not kept)
-    // A sorted file read for whole-contig statistics (PD_DECODE_COMPACT), its batches numbered 0 .. n_batches - 1, on a genome of fewer than
-    // 2^32 cells: the batches' runs go straight to their final places in a compact sample (C8Dec).  Sized from the compressed bytes
+    // A sorted file read for whole-contig statistics (PD_DECODE_COMPACT), its batches numbered 0 .. n_batches - 1: the batches' runs go
+    // straight to their final places in a compact sample (C8Dec).  Sized from the compressed bytes
     // (>= 32 B of BGZF per record of a real file; denser files make it grow): a first run per record, a later run for every fourth.
     {
         std::lock_guard<std::mutex> l8(c->c8.mu);
@@ -1427,8 +1429,10 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         if (x.on || !x.batch.empty()) { (void)hipDeviceSynchronize(); c8_drop(c); }     // (a session that was never ended)
         x.on = false; x.n_s = x.n_o = x.turn = 0; x.n_batches = 0; x.err.clear();
         const uint64_t nb64 = (uint64_t)c->n_tiles << runs_bshift(c);
+        // (any genome size: a compact run keeps the low 32 bits of its flat begin and every consumer works relative to a tile; what is bounded is
+        // the number of runs — 32-bit indices — so a file that promises more than that many records keeps 12-byte runs per batch)
         if ((cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->n_batches < (1ull << 31) && cfg->sorted && !cfg->spans && c->pend.empty() &&
-            c->n_cells < (1ull << 32) && nb64 <= 0xFFFFFF00ull) {
+            cfg->bytes_hint / 16 < DEV_BATCH_MAX && nb64 <= 0xFFFFFF00ull) {
             x.bshift = runs_bshift(c);
             x.nbw = (size_t)nb64 + 2;
             if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
@@ -1756,7 +1760,8 @@ int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_
             J.owes_count = false; g.kept = true;
             c8_counted(c, J.order, nf, no, g.seg_s, g.seg_o, g.ev);
             if (nf + no) order_of((const pdb2::SegOut *)(pin + J.o_so), &rs);
-            if (res) { res->n_first = nf; res->n_other = no; res->n_reads = co.n_rec; res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key; }
+            if (res) { res->n_first = nf; res->n_other = no; res->n_reads = co.n_rec; res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key;
+                       res->first_start = co.first_start; res->next_start = co.next_start; }
             times(true);
             lap(5);
             if (nf + no) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
@@ -1988,6 +1993,12 @@ int pd_decode_end(pd_ctx *c)
                     (unsigned long long)x.n_s, (unsigned long long)x.n_o, span, (unsigned long long)c->dec_n_fast.load(), (unsigned long long)c->dec_n_slow.load(), (unsigned long long)c->dec_n_redo.load());
         if (x.n_s + x.n_o == 0) { (void)hipStreamSynchronize(x.compose); c8_drop(c); return PD_OK; }
         HIPOK(c, hipStreamSynchronize(x.compose));                 // every batch's runs have reached their places
+        if (ok_order && x.n_s && x.n_s + x.n_o <= DEV_BATCH_MAX && !c->pend.empty()) {
+            // the context holds other runs already (units the device handed back and the host decoded meanwhile, an earlier file of a list):
+            // they go into the arrays now, and the compact sample is pushed behind them like any other deferred batch
+            const int rf = flush_pending(c);
+            if (rf) { (void)hipDeviceSynchronize(); c8_drop(c); return rf; }
+        }
         if (ok_order && x.n_s && c->pend.empty() && x.n_s + x.n_o <= DEV_BATCH_MAX) {
             pd_runs *r = new pd_runs;
             r->ctx = c; r->r8 = x.r8(); r->own_r8 = true; r->n_s = (uint32_t)x.n_s; r->n_o = (uint32_t)x.n_o; r->n = r->n_s + r->n_o; r->o_base = r->n_s;      // (the later runs go right behind the sorted stream, as in pd_runs_create: what counts is how many runs there ARE, not how many were reserved)
@@ -2024,9 +2035,17 @@ int pd_decode_end(pd_ctx *c)
             c->pend.push_back(p);
             return PD_OK;
         }
-        // not usable as a compact sample after all (the records are not in the order the header promised, the context holds other runs):
+        // not usable as a compact sample after all (the records are not in the order the header promised, more than 2^32 runs):
         // back to 12-byte arrays, which take the general paths below
         nf = x.n_s; no = x.n_o; nfar = 0;
+        if (nf && c->n_cells >= (1ull << 32)) {
+            // 32 bits of a flat begin name a cell only below 2^32 cells; above, it takes the sample's own bucket index to say which contig a
+            // run lies in, and that index is exactly what an unordered stream does not have.  (The executable never gets here: it gives a
+            // file whose records are not in the promised order to the host readers before anything is counted.)
+            (void)hipDeviceSynchronize(); c8_drop(c);
+            return fail(c, PD_ESTATE, "pd_decode_end: the records of this compact session are not in coordinate order (or are more than 2^32 - 256 runs) on a genome of 2^32 cells or more: "
+                                      "decode it again without PD_DECODE_COMPACT");
+        }
         if ((nf && hipMalloc(&c->run_first, (size_t)nf * sizeof(pd_iv)) != hipSuccess) || (no && hipMalloc(&c->run_other, (size_t)no * sizeof(pd_iv)) != hipSuccess)) {
             c8_drop(c); return fail(c, PD_ENOMEM, "pd_decode_end: run array allocation failed"); }
         if (nf) launch_r8_to_iv(c->stream, x.r8(), nf, tab_of(c), c->run_first);

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <functional>
 #include <thread>
+#include <mutex>
 
 #include "../csrc/pd_inflate_core.h"
 #include "../csrc/pd_lz77.h"
@@ -767,28 +768,64 @@ struct Stream::Impl {
         // in its start state, so that parse is a's own continuation — and takes over there; its own hand-over to the chunk behind
         // it is then searched afresh.  Needs the text: a Remote source keeps a round's text until the round behind it is done, a host
         // text stays in `old` that long.
-        for (size_t k = 0; k < n_eff; ++k) {
-            if (st_ok[k]) continue;
-            const Chunk &a = chunks[k];
-            Chunk &b = chunks[k + 1];
-            uint64_t q = a.first(), q0 = 0; size_t i0 = 0;
-            for (size_t i = 0; i < a.syms.size(); ++i) {
-                q += sym_len(a.syms[i]);
-                if (q > b.start) break;
-                if (is_match(a.syms[i])) { q0 = q; i0 = i + 1; }
+        // Round 5: the pairs that did not meet are mended TOGETHER — with 8 + 2 KiB chunks (twice the waves per CU on the device) about
+        // one pair in a hundred needs it, a hundred per round: their restart points are found, the text they need is fetched in ONE
+        // piece (a Remote source answers a fetch with a device synchronise: one per pair was 0.1 ms each, in a row), zlib parses the
+        // successors again on the threads, and every mended successor's own hand-over is searched afresh; what that turns up (a
+        // mended parse that no longer meets ITS successor) is the next pass's work.  Runs of neighbouring failures stay in order.
+        for (int pass = 0; pass < 64; ++pass) {
+            std::vector<size_t> bad;
+            for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) bad.push_back(k);
+            if (bad.empty()) break;
+            if (pass == 63) return false;
+            // runs of consecutive failures [bad[r0], bad[r1]) are mended front to back by one thread: pair k + 1 restarts inside the parse pair k has just made
+            std::vector<std::pair<size_t, size_t>> runs;
+            for (size_t i = 0; i < bad.size();) { size_t j = i + 1; while (j < bad.size() && bad[j] == bad[j - 1] + 1) ++j; runs.emplace_back(i, j); i = j; }
+            // the text: from 32 KiB before the first pair's predecessor to the last successor's end, one fetch when that is a round's worth or less
+            uint64_t lo = ~0ull, hi = 0;
+            for (size_t k : bad) {
+                // (a restart point lies behind a.start + TAIL — checked below —, its dictionary at most 32 KiB before it: what a source keeps)
+                const uint64_t a0 = chunks[k].start + TAIL > 32768 ? chunks[k].start + TAIL - 32768 : 0;
+                lo = std::min(lo, a0); hi = std::max(hi, chunks[k + 1].tail_end);
             }
-            if (q0 <= a.start + TAIL || q0 <= a.first()) return false;      // (no match to restart from behind the stretch a's own hand-over lies in)
-            const uint64_t dl = q0 < 32768 ? q0 : 32768;
-            std::vector<uint8_t> tmp((size_t)(b.tail_end - (q0 - dl)) + 64, 0);
-            if (!text_of(q0 - dl, (size_t)(b.tail_end - (q0 - dl)), tmp.data())) return false;
-            Chunk again;
-            again.start = q0; again.end = b.tail_end; again.tail_end = b.tail_end;
-            run_chunk(tmp.data(), q0 - dl, again);
-            if (!again.ok) return false;
-            b.own.swap(again.own); b.syms.p = b.own.data(); b.syms.n = b.own.size(); b.hold.reset(); b.from = q0;
-            stop[k] = q0; i_stop[k] = i0; st_ok[k] = 1;
-            ++mended;
-            if (k + 1 < n_eff) search(k + 1);
+            const bool one_fetch = hi - lo <= ((uint64_t)512 << 20);
+            std::vector<uint8_t> &mt = mend_text;
+            if (one_fetch) {
+                if (mt.size() < (size_t)(hi - lo) + 64) mt.resize((size_t)(hi - lo) + 64);
+                if (!text_of(lo, (size_t)(hi - lo), mt.data())) return false;
+            }
+            std::vector<char> run_ok(runs.size(), 1);
+            std::mutex fetch_mu;
+            parallel_for(threads, runs.size(), [&](size_t r) {
+                for (size_t bi = runs[r].first; bi < runs[r].second; ++bi) {
+                    const size_t k = bad[bi];
+                    if (st_ok[k]) continue;                           // (met after all: its predecessor's mend changed the parse it is searched against)
+                    const Chunk &a = chunks[k];
+                    Chunk &b = chunks[k + 1];
+                    uint64_t q = a.first(), q0 = 0; size_t i0 = 0;
+                    for (size_t i = 0; i < a.syms.size(); ++i) {
+                        q += sym_len(a.syms[i]);
+                        if (q > b.start) break;
+                        if (is_match(a.syms[i])) { q0 = q; i0 = i + 1; }
+                    }
+                    if (q0 <= a.start + TAIL || q0 <= a.first()) { run_ok[r] = 0; return; }      // (no match to restart from behind the stretch a's own hand-over lies in)
+                    const uint64_t dl = q0 < 32768 ? q0 : 32768;
+                    Chunk again;
+                    again.start = q0; again.end = b.tail_end; again.tail_end = b.tail_end;
+                    if (one_fetch && q0 - dl >= lo) run_chunk(mt.data(), lo, again);
+                    else {
+                        std::vector<uint8_t> tmp((size_t)(b.tail_end - (q0 - dl)) + 64, 0);
+                        { std::lock_guard<std::mutex> lk(fetch_mu); if (!text_of(q0 - dl, (size_t)(b.tail_end - (q0 - dl)), tmp.data())) { run_ok[r] = 0; return; } }
+                        run_chunk(tmp.data(), q0 - dl, again);
+                    }
+                    if (!again.ok) { run_ok[r] = 0; return; }
+                    b.own.swap(again.own); b.syms.p = b.own.data(); b.syms.n = b.own.size(); b.hold.reset(); b.from = q0;
+                    stop[k] = q0; i_stop[k] = i0; st_ok[k] = 1;
+                    if (k + 1 < n_eff) search(k + 1);                 // (pair k + 1: in this run if it had failed before, else found failing by the next pass)
+                }
+            });
+            for (char ok1 : run_ok) if (!ok1) return false;
+            mended += bad.size();
         }
         // the chain of hand-overs: chunk k's symbols start at the previous hand-over
         std::vector<uint64_t> from(n_eff, 0);
@@ -859,6 +896,7 @@ struct Stream::Impl {
         return true;
     }
 
+    std::vector<uint8_t> mend_text;                           // the text of a round's pairs that are parsed again (kept between rounds)
     SymVec stitched;                                          // a round's stitched symbols (kept: see sym_pool)
     std::vector<Chunk> waiting; RoundInfo waiting_info;       // a parsed round whose stage B has not run yet
     bool have_waiting = false;
@@ -980,10 +1018,11 @@ bool Stream::finish()
 Params Params::for_device(ParseFn fn)
 {
     Params p;
-    // one wave parses one chunk, and the parse is bound by the latency of dependent loads: many small chunks (8 waves per SIMD at
-    // 6144 chunks a round) beat few large ones; 4 KiB of overlap is ample for tables and per-site rows (the parses meet within a few
-    // lines), and a stream whose parses do not meet there is started over with larger chunks by the caller
-    p.chunk = (size_t)1 << 14; p.tail = (size_t)1 << 12; p.batch = (size_t)96 << 20;
+    // one wave parses one chunk, and the parse is bound by the latency of dependent loads: many small chunks beat few large ones.  Round 5:
+    // 8 KiB chunks with 2 KiB of overlap — sixteen of them share a CU's LDS with their text (the engine's "lz_group" default), twice the waves
+    // of 16 + 4 KiB.  The parses of tables and per-site rows meet within a few lines; about one pair in a few thousand does not meet inside
+    // 2 KiB and is parsed again by zlib from the hand-over point (emit_round: a round's pairs together, on the threads, from one text fetch).
+    p.chunk = (size_t)1 << 13; p.tail = (size_t)1 << 11; p.batch = (size_t)96 << 20;
     // (measurement knobs: the geometry in KiB / KiB / MiB)
     if (const char *e = getenv("PGZ_DEV_CHUNK_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 8 && v <= 4096) p.chunk = v << 10; }
     if (const char *e = getenv("PGZ_DEV_TAIL_KB")) { const size_t v = strtoull(e, nullptr, 10); if (v >= 2 && (v << 10) < p.chunk) p.tail = v << 10; }

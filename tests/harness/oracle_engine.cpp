@@ -295,6 +295,9 @@ static int o_decode_batch(pd_ctx *c, const pd_decode_batch *bt, int32_t *status,
             std::vector<uint32_t> r0;
             if (pdb2::check_chain(segs, &r0) != 0) c->compact_err = "chain_device: the host's check finds a segment that does not start where the chain ends";
             for (auto &x : segs) if (x.flags) c->compact_err = "chain_device: a flagged segment was not left to the host";
+            uint64_t fs = ~0ull, E0 = 0;                          // unit 0's first record and chain end, as pd_decode_result reports them
+            for (uint32_t j = seg0[0]; j < seg0[1]; ++j) { if (fs == ~0ull && segs[j].used_start != pdb2::NONE) fs = segs[j].used_start; if (segs[j].e_last > E0) E0 = segs[j].e_last; }
+            if (co.first_start != fs || co.next_start != (E0 ? E0 : ~0ull)) c->compact_err = "chain_device: unit 0's first record / chain end disagree with the segments";
         }
     }
     std::vector<uint32_t> redo;
