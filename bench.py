@@ -119,6 +119,9 @@ def parse_timing(err):
             ph["comm_init"] = float(m.group(1))
             w = re.search(r"waited ([0-9.]+) s", m.group(2))
             ph["comm_init_waited_for"] = float(w.group(1)) if w else float(m.group(1))
+        m = re.match(r"\[timing\] collective\s+([0-9.]+) s", ln)
+        if m:
+            ph["collective"] = float(m.group(1))
         m = re.search(r"device decode: (\d+) batches .*?(\d+) feeders(?: holding \d+ buffers each)?, (\d+) records on the device, (\d+) units handed back \((\d+) records on the host\).*?"
                       r"device ms summed over batches: H2D ([0-9.]+), inflate ([0-9.]+), walk ([0-9.]+), emit ([0-9.]+); bytes: compressed (\d+), inflated (\d+)", ln)
         if m:
@@ -319,6 +322,18 @@ def e2e_multi_leg(n_bams, records):
         out = {"n_bams": n_bams, "records_per_bam": int(records), "bam_bytes_total": total_bytes, "generated_in_s": round(t_gen, 1),
                "mode": "pandepth -i s.list -o out -t N (one context per visible GPU; process wall clock exec-to-exit, warm page cache, best of 2)",
                "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": n_bams * records / w_dev, "threads": threads, "phases_s": ph, "sum": how}}
+        if n_bams == 1:
+            # one GPU: the list path's collective code with REAL RCCL and one rank (-X rccl=force) — what making a communicator costs here and
+            # that it hides behind the decode; the table must not change
+            try:
+                w_f, err_f = _best_wall([cli, "-i", lst, "-o", mine + "_rccl1", "-t", str(threads)], 1,
+                                        env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="rccl=force"), want_stderr=True)
+                ph_f, _ = parse_timing(err_f)
+                out["one_rank_rccl"] = {"wall_s": round(w_f, 4), "phases_s": ph_f,
+                                        "sum": [ln.strip() for ln in err_f.splitlines() if "summed over" in ln or "added into" in ln or "RCCL" in ln][:4],
+                                        "same_table": open(mine + ".chr.stat.gz", "rb").read() == open(mine + "_rccl1.chr.stat.gz", "rb").read()}
+            except Exception as ex:                                # noqa: BLE001
+                out["one_rank_rccl"] = {"failed": repr(ex)[:300]}
         if os.access(ref, os.X_OK):
             w_ref = _best_wall([ref, "-i", lst, "-o", os.path.join(td, "ref"), "-t", "36"], 1)
             out["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": n_bams * records / w_ref, "threads": 36}
@@ -574,8 +589,9 @@ def main():
                     help="records of the end-to-end leg's BAM (product CLI and reference binary on the same file; 0 = skip; "
                          "1e9 = BASELINE's configs[1] in full: a 53 GB file, ~4 min to write; -1 (default) = 1e9 when /tmp has 70 GB "
                          "free, otherwise 3e8 — the line says which and why)")
-    ap.add_argument("--e2e-multi-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_MULTI_RECORDS", "1.0e8")),
-                    help="records per BAM of the multi-BAM `#.list` end-to-end leg (one BAM per GPU of the run; 0 = skip)")
+    ap.add_argument("--e2e-multi-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_MULTI_RECORDS", "3.0e8")),
+                    help="records per BAM of the multi-BAM `#.list` end-to-end leg (one BAM per GPU of the run; 0 = skip).  3e8 (16 GB per file) so that "
+                         "the run is the sharded decode and not process start-up; halved until the N files fit 60 %% of /tmp")
     ap.add_argument("--e2e-site-records", type=float, default=float(os.environ.get("PD_BENCH_E2E_SITE_RECORDS", "2.0e7")),
                     help="records of the `-w 100 -a` end-to-end pair (configs[3]; 0 = skip)")
     ap.add_argument("--config", choices=["chr", "gff", "w100a"], default="chr",

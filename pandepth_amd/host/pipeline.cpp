@@ -432,7 +432,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     {   // the largest batch the feeders will ask a buffer for
         uint64_t mx = 0;
         for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + spare_of(r.vend)); t += b - a; } mx = std::max(mx, t); }
-        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)std::min<size_t>((size_t)feeders * (size_t)depth, batches.size());
+        // (one buffer per reader is pinned up front, from one thread; a reader pins its further buffers itself when it first asks for them — by
+        // then the device is at work on the first batches, and page-locking costs 0.12 s per GB: twelve 32 MB buffers in a row were 46 ms before the first read)
+        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)std::min<size_t>((size_t)feeders, batches.size());
     }
     cfg.n_batches = batches.size();
     if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
@@ -1481,8 +1483,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
         std::vector<int> rcs((size_t)n_ctx, 0);
         std::vector<std::thread> th;
+        const auto t_coll = std::chrono::steady_clock::now();
         for (int k = 0; k < n_ctx; ++k) th.emplace_back([&, k]() { rcs[(size_t)k] = call(k, comms[(size_t)k]); });
         for (auto &t : th) t.join();
+        if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (%s: export, exchange over the links, every rank's sweep of its slice, results to rank 0)\n", "collective",
+                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t_coll).count(), what);
         // PD_ERANGE (-6) on every rank: a sample with more cells outside the 4-bit image's range than the exception block
         // holds (amplicon, very deep RNA-seq).  Nothing was consumed; the contexts are added into the first one instead.
         bool ok = true, too_wide = true;
