@@ -13,6 +13,8 @@
 #include <atomic>
 #include <functional>
 #include <thread>
+#include <deque>
+#include <condition_variable>
 #include <mutex>
 
 #include "../csrc/pd_inflate_core.h"
@@ -107,12 +109,22 @@ struct TreeDesc { Ct *dyn; const Ct *stat; const int *extra; int extra_base, ele
 class BlockEncoder {
 public:
     // false: zlib would have STORED this block (incompressible data) — not re-stated
-    bool encode(const Sym *syms, size_t n, bool last, std::vector<uint8_t> *out, uint64_t *nbits)
+    struct Piece { const Sym *p; size_t n; };
+    bool encode(const Sym *syms, size_t n, bool last, std::vector<uint8_t> *out, uint64_t *nbits) { const Piece pc{syms, n}; return encode_pieces(&pc, 1, last, out, nbits); }
+    // the block's symbols as stretches of several arrays (a round's stitched stream is never made contiguous: every block's thread gathers
+    // its own 16 383 symbols into the encoder's buffer, in cache, instead of a 50 MB copy through memory per round)
+    bool encode_pieces(const Piece *pc, size_t np, bool last, std::vector<uint8_t> *out, uint64_t *nbits)
     {
-        out_.clear();
-        bi_buf_ = 0; bi_valid_ = 0;
         init_block();
-        syms_.assign(syms, syms + n);
+        size_t n = 0;
+        for (size_t k = 0; k < np; ++k) n += pc[k].n;
+        // room for the worst case up front (a match: 15 + 5 + 15 + 13 bits; the trees' description: < 1 KB), so that a code costs a shift,
+        // an OR and now and then a 4-byte store — not two vector push_backs per 16 bits
+        out_.resize(n * 6 + 2048);
+        wp_ = out_.data(); acc_ = 0; acc_bits_ = 0;
+        syms_.resize(n);
+        { size_t o = 0; for (size_t k = 0; k < np; ++k) { if (pc[k].n) memcpy(syms_.data() + o, pc[k].p, pc[k].n * sizeof(Sym)); o += pc[k].n; } }
+        const Sym *const syms = syms_.data();
         for (size_t i = 0; i < n; ++i) {
             const Sym s = syms[i];
             if (is_match(s)) {
@@ -126,9 +138,10 @@ public:
             }
         }
         if (!flush_block(last)) return false;
-        *nbits = (uint64_t)out_.size() * 8 + (uint64_t)bi_valid_;
-        if (bi_valid_ > 8) { out_.push_back((uint8_t)bi_buf_); out_.push_back((uint8_t)(bi_buf_ >> 8)); }
-        else if (bi_valid_ > 0) out_.push_back((uint8_t)bi_buf_);
+        *nbits = (uint64_t)(wp_ - out_.data()) * 8 + (uint64_t)acc_bits_;
+        for (; acc_bits_ > 0; acc_bits_ -= 8) { *wp_++ = (uint8_t)acc_; acc_ >>= 8; }
+        acc_bits_ = 0;
+        out_.resize((size_t)(wp_ - out_.data()));
         out->swap(out_);
         return true;
     }
@@ -142,7 +155,7 @@ private:
     int heap_[2 * L_CODES + 1], heap_len_ = 0, heap_max_ = 0;
     uint8_t depth_[2 * L_CODES + 1];
     unsigned long opt_len_ = 0, static_len_ = 0;
-    uint16_t bi_buf_ = 0; int bi_valid_ = 0;
+    uint64_t acc_ = 0; int acc_bits_ = 0; uint8_t *wp_ = nullptr;      // bit accumulator (least significant bit first), write pointer into out_
 
     void init_block()
     {
@@ -155,15 +168,13 @@ private:
     }
     void send_bits(unsigned value, int length)
     {
-        // 16-bit bit buffer, least significant bit first
-        if (bi_valid_ > 16 - length) {
-            bi_buf_ |= (uint16_t)(value << bi_valid_);
-            out_.push_back((uint8_t)bi_buf_); out_.push_back((uint8_t)(bi_buf_ >> 8));
-            bi_buf_ = (uint16_t)(value >> (16 - bi_valid_));
-            bi_valid_ += length - 16;
-        } else {
-            bi_buf_ |= (uint16_t)(value << bi_valid_);
-            bi_valid_ += length;
+        // (length <= 16, fewer than 32 bits pending: never more than 47 in the accumulator)
+        acc_ |= (uint64_t)value << acc_bits_;
+        acc_bits_ += length;
+        if (acc_bits_ >= 32) {
+            const uint32_t w = (uint32_t)acc_;
+            memcpy(wp_, &w, 4); wp_ += 4;
+            acc_ >>= 32; acc_bits_ -= 32;
         }
     }
     void send_code(int c, const Ct *tree) { send_bits(tree[c].code, tree[c].len); }
@@ -531,6 +542,73 @@ struct Stream::Impl {
     // output bit splicing
     std::vector<uint8_t> out; uint8_t part = 0; int part_bits = 0;
 
+    // All blocks of a round at once: block b's bits start at bit (part_bits + sum of the bit counts before it) of the stretch behind
+    // `out`'s end.  Every thread shifts its block into place and stores the bytes that belong to it alone; the (at most two) bytes a
+    // block shares with its neighbours are OR-ed together afterwards, in order.  Same bytes as put_bits block by block.
+    void splice_blocks(const std::vector<std::vector<uint8_t>> &bytes, const std::vector<uint64_t> &nbits)
+    {
+        const size_t nb = bytes.size();
+        if (nb < 4 || threads < 2) { for (size_t b = 0; b < nb; ++b) put_bits(bytes[b].data(), nbits[b]); return; }
+        std::vector<uint64_t> start(nb + 1, 0);
+        start[0] = (uint64_t)part_bits;
+        for (size_t b = 0; b < nb; ++b) start[b + 1] = start[b] + nbits[b];
+        const size_t old_sz = out.size();
+        const uint64_t end_bit = start[nb];
+        const size_t whole = (size_t)(end_bit / 8);                   // complete bytes of the stretch
+        out.resize(old_sz + whole + 16);
+        uint8_t *const o = out.data() + old_sz;
+        struct Edge { size_t at; uint8_t v; };                        // a shared byte's share
+        std::vector<Edge> head(nb, Edge{(size_t)-1, 0}), tail(nb, Edge{(size_t)-1, 0});
+        parallel_for(threads, nb, [&](size_t b) {
+            const uint64_t s0 = start[b], s1 = start[b + 1];
+            if (s1 == s0) return;
+            const uint8_t *p = bytes[b].data();
+            const unsigned sh = (unsigned)(s0 & 7);
+            const size_t B0 = (size_t)(s0 / 8), B1 = (size_t)((s1 + 7) / 8);      // bytes [B0, B1) hold bits of this block
+            auto byte_at = [&](size_t j) -> uint8_t {               // output byte j's share from this block (bits outside the block are zero)
+                // output bit 8 j + t  =  block bit 8 j + t - s0
+                const int64_t q = (int64_t)(8 * j) - (int64_t)s0;    // block bit of output bit 0 of byte j (may be negative)
+                unsigned v = 0;
+                for (int t = 0; t < 8; ++t) {
+                    const int64_t bb = q + t;
+                    if (bb < 0 || (uint64_t)bb >= s1 - s0) continue;
+                    v |= (unsigned)((p[bb >> 3] >> (bb & 7)) & 1u) << t;
+                }
+                return (uint8_t)v;
+            };
+            const bool head_shared = sh != 0, tail_shared = (s1 & 7) != 0;
+            size_t lo = B0, hi = B1;                                  // bytes this block owns alone: [lo, hi)
+            if (head_shared) { head[b] = Edge{B0, byte_at(B0)}; lo = B0 + 1; }
+            if (tail_shared && B1 - 1 >= lo) { tail[b] = Edge{B1 - 1, byte_at(B1 - 1)}; hi = B1 - 1; }
+            else if (tail_shared) hi = lo;                            // (the block lies inside one shared byte: its head edge carries all of it)
+            if (hi <= lo) return;
+            // owned bytes: output byte j = (p[k] >> r) | (p[k + 1] << (8 - r)) with 8 j - s0 = 8 k + r — eight at a time
+            const uint64_t first_bit = 8 * (uint64_t)lo - s0;        // >= 0
+            size_t k = (size_t)(first_bit / 8); const unsigned r = (unsigned)(first_bit & 7);
+            const size_t n_src = bytes[b].size();
+            size_t j = lo;
+            if (r == 0) { memcpy(o + j, p + k, hi - lo); return; }
+            for (; j + 8 <= hi && k + 9 <= n_src; j += 8, k += 8) {
+                uint64_t w0; memcpy(&w0, p + k, 8);
+                const uint64_t v = (w0 >> r) | ((uint64_t)p[k + 8] << (64 - r));
+                memcpy(o + j, &v, 8);
+            }
+            for (; j < hi; ++j, ++k) {
+                const unsigned a = p[k], c = k + 1 < n_src ? p[k + 1] : 0u;
+                o[j] = (uint8_t)((a >> r) | (c << (8 - r)));
+            }
+        });
+        // shared bytes: the partial byte carried in from before, then every block's edges, in order
+        std::vector<size_t> shared;
+        auto add = [&](const Edge &e) { if (e.at == (size_t)-1) return; if (shared.empty() || shared.back() != e.at) { shared.push_back(e.at); o[e.at] = 0; } o[e.at] |= e.v; };
+        if (part_bits) { shared.push_back(0); o[0] = part; }
+        for (size_t b = 0; b < nb; ++b) { add(head[b]); add(tail[b]); }
+        // what is left over: the bits of the last, incomplete byte
+        part_bits = (int)(end_bit & 7);
+        part = part_bits ? (uint8_t)(o[whole] & ((1u << part_bits) - 1)) : 0;
+        out.resize(old_sz + whole);
+    }
+
     void put_bits(const uint8_t *p, uint64_t nbits)
     {
         if (part_bits == 0) {
@@ -568,13 +646,56 @@ struct Stream::Impl {
         out.resize(old + produced);
         part = (uint8_t)acc; part_bits = have;
     }
+    // The finished bytes go to the sink on a thread of their own (a round's 15 MB took as long to write as its blocks took to encode),
+    // in order, at most two rounds behind; drain_writer() waits until the sink has seen everything handed over so far — every path on
+    // which the caller may look at what the sink wrote (finish, a failure, wait_idle) goes through it.
+    std::thread writer; std::mutex wmu; std::condition_variable wcv;
+    std::deque<std::vector<uint8_t>> wq; bool w_on = false, w_stop = false, w_busy = false, w_fail = false;
+    void writer_loop()
+    {
+        for (;;) {
+            std::vector<uint8_t> b;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return w_stop || !wq.empty(); });
+                if (wq.empty()) return;
+                b.swap(wq.front()); wq.pop_front(); w_busy = true;
+            }
+            const bool ok = w_fail ? false : sink(b.data(), b.size());
+            { std::lock_guard<std::mutex> lk(wmu); if (!ok) w_fail = true; w_busy = false; }
+            wcv.notify_all();
+        }
+    }
+    bool drain_writer()
+    {
+        std::unique_lock<std::mutex> lk(wmu);
+        wcv.wait(lk, [&] { return wq.empty() && !w_busy; });
+        return !w_fail;
+    }
+    void stop_writer()
+    {
+        if (!w_on) return;
+        { std::lock_guard<std::mutex> lk(wmu); w_stop = true; }
+        wcv.notify_all();
+        writer.join(); w_on = false;
+    }
     bool flush_out(bool final)
     {
         if (final && part_bits) { out.push_back(part); part = 0; part_bits = 0; }
-        if (out.empty()) return true;
-        const bool ok = sink(out.data(), out.size());
-        out.clear();
-        return ok;
+        if (!out.empty()) {
+            if (!w_on) { w_on = true; writer = std::thread([this] { writer_loop(); }); }
+            std::unique_lock<std::mutex> lk(wmu);
+            wcv.wait(lk, [&] { return wq.size() < 2; });
+            const size_t cap = out.capacity();
+            wq.emplace_back();
+            wq.back().swap(out);
+            out.reserve(cap);
+            lk.unlock();
+            wcv.notify_all();
+        }
+        if (final) return drain_writer();
+        std::lock_guard<std::mutex> lk(wmu);
+        return !w_fail;
     }
 
     // ---- a round in two stages, so that stage B of one round runs while stage A of the next is being parsed (on the GPU, with a
@@ -763,6 +884,7 @@ struct Stream::Impl {
             st_ok[k] = stop_k != 0;                               // 0: the two parses did not meet inside the tail
         };
         parallel_for(threads, n_eff, search);
+        const double tq1 = now_s();
         // A pair that did not meet (the two parses can stay out of step for longer than a tail where the text repeats with a long
         // period) is mended in place: the successor is parsed AGAIN by zlib from a's last match end before it — after a match zlib is
         // in its start state, so that parse is a's own continuation — and takes over there; its own hand-over to the chunk behind
@@ -827,6 +949,7 @@ struct Stream::Impl {
             for (char ok1 : run_ok) if (!ok1) return false;
             mended += bad.size();
         }
+        const double tq2 = now_s();
         // the chain of hand-overs: chunk k's symbols start at the previous hand-over
         std::vector<uint64_t> from(n_eff, 0);
         { uint64_t p = pos; for (size_t k = 0; k < n_eff; ++k) { from[k] = p; if (stop[k] <= p && !(final && stop[k] == p && p == total)) return false; p = stop[k]; } }
@@ -839,17 +962,31 @@ struct Stream::Impl {
             i_first[k] = i;
         });
         for (size_t k = 0; k < n_eff; ++k) if (!st_ok[k]) return false;
-        SymVec &syms = stitched;
-        {
-            std::vector<size_t> at(n_eff + 1, pending.size());
-            for (size_t k = 0; k < n_eff; ++k) at[k + 1] = at[k] + (i_stop[k] - i_first[k]);
-            syms.resize(at[n_eff]);
-            if (!pending.empty()) memcpy(syms.data(), pending.data(), pending.size() * sizeof(Sym));
-            pending.clear();
-            parallel_for(threads, n_eff, [&](size_t k) {
-                if (i_stop[k] > i_first[k]) memcpy(syms.data() + at[k], chunks[k].syms.data() + i_first[k], (i_stop[k] - i_first[k]) * sizeof(Sym));
-            });
+        const double tq3 = now_s();
+        // the round's symbol stream = what the round before left over + every chunk's stretch between its two hand-overs — kept as PIECES
+        // (piece 0: the left-over; piece k + 1: chunk k), with their start offsets in the stream
+        std::vector<BlockEncoder::Piece> piece(n_eff + 1);
+        std::vector<size_t> at(n_eff + 2, 0);
+        const std::vector<Sym> carried(pending.begin(), pending.end());
+        pending.clear();
+        piece[0] = BlockEncoder::Piece{carried.data(), carried.size()};
+        at[1] = carried.size();
+        for (size_t k = 0; k < n_eff; ++k) {
+            piece[k + 1] = BlockEncoder::Piece{chunks[k].syms.data() + i_first[k], i_stop[k] > i_first[k] ? i_stop[k] - i_first[k] : 0};
+            at[k + 2] = at[k + 1] + piece[k + 1].n;
         }
+        const size_t n_syms = at[n_eff + 1];
+        // the stretch [lo, hi) of the stream as pieces
+        auto stretch = [&](size_t lo, size_t hi, std::vector<BlockEncoder::Piece> *out_pc) {
+            out_pc->clear();
+            if (hi <= lo) return;
+            size_t k = (size_t)(std::upper_bound(at.begin(), at.end(), lo) - at.begin()) - 1;      // at[k] <= lo < at[k + 1]
+            for (; k <= n_eff && at[k] < hi; ++k) {
+                const size_t a0 = std::max(lo, at[k]), a1 = std::min(hi, at[k + 1]);
+                if (a1 > a0) out_pc->push_back(BlockEncoder::Piece{piece[k].p + (a0 - at[k]), a1 - a0});
+            }
+        };
+        const double tq4 = now_s();
         // CRC-32 of the concatenation: crc(A B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P.  Nearly all chunks have one length, so the
         // power is computed once per length (zlib 1.2.11's crc32_combine squares a 32 x 32 matrix per call: 10 us x thousands of chunks)
         {
@@ -867,23 +1004,27 @@ struct Stream::Impl {
         // blocks: every LIT_BUFSIZE - 1 symbols; at the end the remainder (possibly empty) closes the stream
         const double tp2 = now_s();
         const size_t BS = LIT_BUFSIZE - 1;
-        const size_t full = syms.size() / BS;
+        const size_t full = n_syms / BS;
         const size_t nblocks = full + (final ? 1 : 0);
         std::vector<std::vector<uint8_t>> bytes(nblocks);
         std::vector<uint64_t> nbits(nblocks, 0);
         std::vector<char> good(nblocks, 1);
         parallel_for(threads, nblocks, [&](size_t b) {
             BlockEncoder enc;
-            const size_t lo = b * BS, hi = b < full ? lo + BS : syms.size();
-            good[b] = enc.encode(syms.data() + lo, hi - lo, final && b + 1 == nblocks, &bytes[b], &nbits[b]) ? 1 : 0;
+            std::vector<BlockEncoder::Piece> pc;
+            const size_t lo = b * BS, hi = b < full ? lo + BS : n_syms;
+            stretch(lo, hi, &pc);
+            good[b] = enc.encode_pieces(pc.data(), pc.size(), final && b + 1 == nblocks, &bytes[b], &nbits[b]) ? 1 : 0;
         });
         const double tp3 = now_s();
-        for (size_t b = 0; b < nblocks; ++b) {
-            if (!good[b]) return false;
-            put_bits(bytes[b].data(), nbits[b]);
-        }
+        for (size_t b = 0; b < nblocks; ++b) if (!good[b]) return false;
+        splice_blocks(bytes, nbits);
         const double tp4 = now_s();
-        if (!final) pending.assign(syms.begin() + (std::ptrdiff_t)(full * BS), syms.end());
+        if (!final) {
+            std::vector<BlockEncoder::Piece> pc;
+            stretch(full * BS, n_syms, &pc);
+            for (const auto &q : pc) pending.insert(pending.end(), q.p, q.p + q.n);
+        }
         if (final) {
             if (part_bits) { out.push_back(part); part = 0; part_bits = 0; }
             for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(crc >> (8 * k)));
@@ -893,6 +1034,7 @@ struct Stream::Impl {
         if (getenv("PGZ_DEBUG"))
             fprintf(stderr, "[pgz] round: %zu chunks (%zu parsed by the provider, %zu parsed again where a pair did not meet), %zu blocks: parse %.3f s, stitch %.3f s, encode %.3f s, splice %.3f s\n", nc, provided, mended, nblocks,
                     tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
+        if (getenv("PGZ_DEBUG")) fprintf(stderr, "[pgz]   stitch: search %.4f, mend %.4f, chain + first %.4f, copy %.4f, crc + rest %.4f; flush %.4f\n", tq1 - tp1, tq2 - tq1, tq3 - tq2, tq4 - tq3, tp2 - tq4, now_s() - tp4);
         return true;
     }
 
@@ -957,7 +1099,7 @@ struct Stream::Impl {
         worker = std::thread([this, c_hi] { worker_ok = round_body(false, c_hi); });
         return true;
     }
-    ~Impl() { if (worker_on) worker.join(); for (auto &x : pins) unpin(x.p); }
+    ~Impl() { if (worker_on) worker.join(); stop_writer(); for (auto &x : pins) unpin(x.p); }
 };
 
 Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p) : p_(new Impl)
@@ -981,13 +1123,14 @@ bool Stream::announce(uint64_t n)
     if (p_->failed || p_->finished || !p_->is_remote) return false;
     p_->total += n;
     const uint64_t limit = p_->batch_bytes + 2 * p_->CH + p_->TAIL;
-    if (p_->total - p_->base >= limit && !p_->run(false, 0)) { p_->failed = true; return false; }
+    if (p_->total - p_->base >= limit && !p_->run(false, 0)) { p_->failed = true; (void)p_->drain_writer(); return false; }
     return true;
 }
 
 bool Stream::wait_idle()
 {
-    if (!p_->join_worker()) { p_->failed = true; return false; }
+    if (!p_->join_worker()) { p_->failed = true; (void)p_->drain_writer(); return false; }
+    if (!p_->drain_writer()) p_->failed = true;
     return !p_->failed;
 }
 
@@ -1002,7 +1145,7 @@ bool Stream::write(const void *data, size_t n)
         const size_t k = std::min(n, have < limit ? limit - have : (size_t)p_->CH);
         p_->buf.insert(p_->buf.end(), q, q + k);
         p_->total += k; q += k; n -= k;
-        if (p_->buf.size() >= limit && !p_->run(false, limit + (size_t)p_->CH)) { p_->failed = true; return false; }
+        if (p_->buf.size() >= limit && !p_->run(false, limit + (size_t)p_->CH)) { p_->failed = true; (void)p_->drain_writer(); return false; }
     }
     return true;
 }
@@ -1011,7 +1154,7 @@ bool Stream::finish()
 {
     if (p_->failed || p_->finished) return false;
     p_->finished = true;
-    if (!p_->run(true, 0)) { p_->failed = true; return false; }
+    if (!p_->run(true, 0)) { p_->failed = true; (void)p_->join_worker(); (void)p_->drain_writer(); return false; }
     return true;
 }
 
