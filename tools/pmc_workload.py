@@ -56,17 +56,19 @@ part = torch.zeros(n_tiles * 24 + 64, dtype=torch.uint8, device=dev)
 for it in range(2):
     eng.slice_sweep_i4(img.data_ptr(), 1, n_cells // 2, 0, n_tiles, sums.data_ptr(), 0, 0, 0, 10000000, 1, 18, part.data_ptr())
     eng.synchronize()
-# zlib's LZ77 parse on the device (pd_deflate_parse): 48 MB of per-site rows in 16 KiB chunks with 4 KiB of overlap
+# zlib's LZ77 parse on the device (pd_deflate_parse), 48 MB of per-site rows: the DEFAULT path of round 5 first — 8 KiB chunks with 2 KiB of
+# overlap, sixteen to a workgroup with their text in LDS (k_lz_parse_lds, "lz_group" 16) — then round 4's default for comparison: 16 + 4 KiB
+# chunks parsed with the text in memory (k_lz_parse, "lz_group" 0)
 rows = b"".join(b"Chr01\t%d\t%d\n" % (j, 30 + (j * 2654435761 >> 7) % 23) for j in range(3200000))
-CH, TAIL = 16384, 4096
-chunks = [(s0, min(len(rows), s0 + CH + TAIL), max(0, s0 - 32768)) for s0 in range(0, len(rows) - TAIL, CH)]
-for it in range(2):
-    eng.deflate_parse(rows, chunks)
-# the same call with the chunks' text in LDS (k_lz_parse_lds, opt-in "lz_group")
-eng.set_param("lz_group", 16)
+def grid(CH, TAIL):
+    return [(s0, min(len(rows), s0 + CH + TAIL), max(0, s0 - 32768)) for s0 in range(0, len(rows) - TAIL, CH)]
+chunks = grid(8192, 2048)
 for it in range(2):
     eng.deflate_parse(rows, chunks)
 eng.set_param("lz_group", 0)
+for it in range(2):
+    eng.deflate_parse(rows, grid(16384, 4096))
+eng.set_param("lz_group", 16)
 eng.reset()
 eng.runs_destroy(runs8)
 eng.keep_deferred(False)
