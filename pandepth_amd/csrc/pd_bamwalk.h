@@ -47,7 +47,7 @@ struct C8Out {
     unsigned long long *marks = nullptr;  // bucket -> min (batch << 32 | index in the batch) of a run that begins there (pre-set to all ones)
     const uint64_t *contig_off = nullptr; // first cell of every contig's slot
     uint32_t cshift = 0;                  // log2(cells per bucket)
-    SegOut *seg_out = nullptr;            // one per segment of the batch
+    SegOut *seg_out = nullptr;            // one per segment of the batch (also without r8: 12-byte first runs, keys (tid << 32 | begin))
     uint32_t batch = 0;                   // the batch's number in file order
 };
 
@@ -195,7 +195,14 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
                             if (w.key_first == NONE) w.key_first = flat; else if (flat < w.key_last) w.unsorted = 1;
                             w.key_last = flat;
                             if (len > (1u << c.c8.cshift)) ++w.n_long;
-                        } else if (EMIT) first[of + w.n_first] = pd_iv{x.tid, beg, end};
+                        } else if (EMIT) {
+                            first[of + w.n_first] = pd_iv{x.tid, beg, end};
+                            if (c.c8.seg_out) {                           // (12-byte emission with the order check riding along: key = (tid, begin) as k_runs_sorted's)
+                                const uint64_t key = ((uint64_t)(uint32_t)x.tid << 32) | (uint32_t)beg;
+                                if (w.key_first == NONE) w.key_first = key; else if (key < w.key_last) w.unsorted = 1;
+                                w.key_last = key;
+                            }
+                        }
                         nf = 1; return;
                     }
                     const uint32_t d = (uint32_t)beg - (uint32_t)x.pos;
@@ -332,7 +339,7 @@ PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_
         const LaneWalk w = walk_lane<true>(c, s, b, first, other, far, sg.base_first + ef[l], sg.base_other + eo[l], sg.base_far + efar[l]);
         kf[l] = w.key_first; kl[l] = w.key_last; bad[l] = w.unsorted; nl[l] = w.n_long;
     });
-    if (c.c8.r8 && seg_out) {
+    if (seg_out) {
         // the order across the lanes: a lane's first key against the largest key of the lanes before it
         const U64 pm = W::excl_scan_max64(kl);
         W::each([&](int l) { if (kf[l] != NONE && kf[l] < pm[l]) bad[l] = 1; });

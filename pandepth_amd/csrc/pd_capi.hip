@@ -1386,8 +1386,9 @@ void c8_counted(pd_ctx *c, uint64_t order, uint64_t nf, uint64_t no, Run8 *seg_s
             hipError_t e = hipSuccess;
             if (c8_reserve(c, x.n_s + b.nf, x.n_o + b.no) != PD_OK) e = hipErrorOutOfMemory;
             if (e == hipSuccess && b.ev) e = hipStreamWaitEvent(x.compose, b.ev, 0);
-            if (e == hipSuccess && b.nf) e = hipMemcpyAsync(x.r8() + x.n_s, b.seg_s, (size_t)b.nf * sizeof(Run8), hipMemcpyDeviceToDevice, x.compose);
-            if (e == hipSuccess && b.no) e = hipMemcpyAsync(x.oth() + x.n_o, b.seg_o, (size_t)b.no * sizeof(pd_iv), hipMemcpyDeviceToDevice, x.compose);
+            if (e == hipSuccess && b.nf) launch_copy_words(x.compose, x.r8() + x.n_s, b.seg_s, b.nf * (sizeof(Run8) / 4));
+            if (e == hipSuccess && b.no) launch_copy_words(x.compose, x.oth() + x.n_o, b.seg_o, b.no * (sizeof(pd_iv) / 4));
+            if (e == hipSuccess) e = hipGetLastError();
             if (e != hipSuccess && x.err.empty()) x.err = std::string("placing a batch's runs: ") + hipGetErrorString(e);
             x.n_s += b.nf; x.n_o += b.no;
         }
@@ -1606,11 +1607,11 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
             return dec_fail(c, PD_EINVAL, "pd_decode_submit: block outside its buffer");
     const uint32_t n_seg = J.n_seg = (uint32_t)segs.size();
     if (!n_seg) return PD_OK;
-    // The device confirms the record chain itself — no host round trip between the two passes — in compact sessions whose units all
-    // start at known records.  A kept read has at least one CIGAR operation, so its record is at least 41 bytes (4 + 32 fixed, a name of
+    // The device confirms the record chain itself — no host round trip between the two passes — in sessions whose units all start at
+    // known records (index cuts and index chunks: everything but no-index streams).  A kept read has at least one CIGAR operation, so its record is at least 41 bytes (4 + 32 fixed, a name of
     // one byte, one operation): inflated / 41 first runs is a bound, not an estimate.  Later runs are bounded only by the CIGAR bytes;
     // the same number of slots (several times what real reads need) is given and the chain kernel checks that they suffice.
-    J.fast = c8 && c->dec_fast && !guess;
+    J.fast = c->dec_fast && !guess && (c8 || c->dec_near_span == 0xFFFFFFFFu);      // (every session whose units start at known records and whose later runs are one stream)
     J.cap_first = J.cap_other = J.fast ? bt->inflated_bytes / 41 + 64 : 0;
     // (the inflate kernel's LDS lets 20 one-wave workgroups share a CU; "inflate_waves": fewer per launch, so that several batches' launches share the GPU)
     const unsigned n_wg = (unsigned)c->n_cu * c->dec_waves;
@@ -1629,8 +1630,8 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
         (rc = dec_ensure(c, sl, DS_BLK, J.o_up)) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
         (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
-        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || (c8 && (rc = dec_ensure(c, sl, DS_SEGOUT, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut)))) ||
-        (J.fast && ((rc = dec_ensure(c, sl, DS_R8, (size_t)J.cap_first * sizeof(Run8))) || (rc = dec_ensure(c, sl, DS_OTH, (size_t)J.cap_other * sizeof(pd_iv)))))) return rc;
+        (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || ((c8 || J.fast) && (rc = dec_ensure(c, sl, DS_SEGOUT, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut)))) ||
+        (J.fast && ((rc = dec_ensure(c, sl, DS_R8, (size_t)J.cap_first * (c8 ? sizeof(Run8) : sizeof(pd_iv)))) || (rc = dec_ensure(c, sl, DS_OTH, (size_t)J.cap_other * sizeof(pd_iv)))))) return rc;
     if (!sl.d_tok || sl.tok_wg < n_wg) {
         // (the scratch is indexed by workgroup: "inflate_waves" may have been raised since it was sized)
         std::lock_guard<std::mutex> al2(g_alloc_mu);
@@ -1678,8 +1679,9 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
         launch_chain_segments(st, cfg, d_seg, n_seg, d_lane, (const int *)sl.d[DS_ST], bt->n_blocks, J.cap_first, J.cap_other, c->dec_max_redo, d_co);
         if (J.timed) HIPDEC(hipEventRecord(sl.ev[3], st));
         pdb2::Cfg c2 = cfg;
-        c2.c8 = pdb2::C8Out{(pdb2::R8 *)sl.d[DS_R8], x.marks, c->d_off, 13u - x.bshift, (pdb2::SegOut *)(d_co + 1), (uint32_t)bt->order};
-        launch_emit_segments(st, c2, d_seg, n_seg, d_lane, nullptr, (pd_iv *)sl.d[DS_OTH], nullptr, d_co);
+        if (c8) c2.c8 = pdb2::C8Out{(pdb2::R8 *)sl.d[DS_R8], x.marks, c->d_off, 13u - x.bshift, (pdb2::SegOut *)(d_co + 1), (uint32_t)bt->order};
+        else { c2.c8 = pdb2::C8Out{}; c2.c8.seg_out = (pdb2::SegOut *)(d_co + 1); }      // (12-byte runs; the order keys ride along)
+        launch_emit_segments(st, c2, d_seg, n_seg, d_lane, c8 ? nullptr : (pd_iv *)sl.d[DS_R8], (pd_iv *)sl.d[DS_OTH], nullptr, d_co);
         HIPDEC(hipMemcpyAsync(pin + J.o_co, d_co, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut), hipMemcpyDeviceToHost, st));
         if (J.timed) HIPDEC(hipEventRecord(sl.ev[4], st));
     } else {
@@ -1749,12 +1751,35 @@ int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_
             ++c->dec_n_fast;
             const uint64_t nf = co.n_first, no = co.n_other;
             pd_ctx::RunSeg rs{J.order, nullptr, nf, nullptr, no, nullptr, 0, co.max_span, 0u, 0ull, 0ull};
+            if (!c8) {
+                // 12-byte runs (every mode that needs the arrays): exact arrays from the arena, the batch listed for pd_decode_end
+                struct Guard { pd_ctx *c; pd_ctx::RunSeg *r; bool keep = false;
+                               ~Guard() { if (keep) return; for (pd_iv *q : {r->first, r->other}) if (q && !in_arena(c, q)) (void)hipFree(q); } } guard{c, &rs};
+                if (nf + no) {
+                    if ((nf && !dec_grab(c, (size_t)nf * sizeof(pd_iv), (void **)&rs.first)) || (no && !dec_grab(c, (size_t)no * sizeof(pd_iv), (void **)&rs.other)))
+                        return dec_fail(c, PD_ENOMEM, "run array allocation failed");
+                    if (nf) launch_copy_words(st, rs.first, sl.d[DS_R8], nf * (sizeof(pd_iv) / 4));
+                    if (no) launch_copy_words(st, rs.other, sl.d[DS_OTH], no * (sizeof(pd_iv) / 4));
+                    HIPDEC(hipGetLastError());
+                    HIPDEC(hipStreamSynchronize(st));                 // (pd_decode_end reads these arrays from another stream; a few MB)
+                    order_of((const pdb2::SegOut *)(pin + J.o_so), &rs);
+                    rs.n_long = 0;
+                }
+                if (res) { res->n_first = nf; res->n_other = no; res->n_reads = co.n_rec; res->unsorted = rs.unsorted; res->first_key = rs.first_key; res->last_key = rs.last_key;
+                           res->first_start = co.first_start; res->next_start = co.next_start; }
+                times(true);
+                lap(5);
+                if (nf + no) { std::lock_guard<std::mutex> lk(c->dec_mu); c->run_segs.push_back(rs); }
+                guard.keep = true;
+                return PD_OK;
+            }
             C8Segs g{c};
             if (nf + no) {
                 if ((nf && !dec_grab(c, (size_t)nf * sizeof(Run8), (void **)&g.seg_s)) || (no && !dec_grab(c, (size_t)no * sizeof(pd_iv), (void **)&g.seg_o)) ||
                     hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return dec_fail(c, PD_ENOMEM, "run segment allocation failed"); }
-                if (nf) HIPDEC(hipMemcpyAsync(g.seg_s, sl.d[DS_R8], (size_t)nf * sizeof(Run8), hipMemcpyDeviceToDevice, st));
-                if (no) HIPDEC(hipMemcpyAsync(g.seg_o, sl.d[DS_OTH], (size_t)no * sizeof(pd_iv), hipMemcpyDeviceToDevice, st));
+                if (nf) launch_copy_words(st, g.seg_s, sl.d[DS_R8], nf * (sizeof(Run8) / 4));
+                if (no) launch_copy_words(st, g.seg_o, sl.d[DS_OTH], no * (sizeof(pd_iv) / 4));
+                HIPDEC(hipGetLastError());
                 HIPDEC(hipEventRecord(g.ev, st));
             }
             J.owes_count = false; g.kept = true;
@@ -2085,9 +2110,10 @@ int pd_decode_end(pd_ctx *c)
     }
     if (getenv("PANDEPTH_TIMING"))
         fprintf(stderr, "[timing]   decode entry points, thread-seconds: slot wait %.3f, pinned alloc %.3f, device buffers %.3f, wait H2D+inflate+walk %.3f, "
-                        "host chain check %.3f, run arrays %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u)\n", g_dec_us[0] / 1e6,
+                        "host chain check %.3f, run arrays %.3f, wait emit %.3f, first HIP call of the feeder threads %.3f; %zu batches; runs: %llu first, %llu near, %llu far (span %u); "
+                        "chain confirmed on the device for %llu batches, by the host for %llu; segments the device walked again: %llu\n", g_dec_us[0] / 1e6,
                 g_dec_us[1] / 1e6, g_dec_us[2] / 1e6, g_dec_us[3] / 1e6, g_dec_us[4] / 1e6, g_dec_us[5] / 1e6, g_dec_us[6] / 1e6, g_dec_us[7] / 1e6, segs.size(),
-                (unsigned long long)nf, (unsigned long long)no, (unsigned long long)nfar, span);
+                (unsigned long long)nf, (unsigned long long)no, (unsigned long long)nfar, span, (unsigned long long)c->dec_n_fast.load(), (unsigned long long)c->dec_n_slow.load(), (unsigned long long)c->dec_n_redo.load());
     int rc = PD_OK;
     // disorder of a stream = how far its runs may trail the sorted order: the near stream by near_span (when the split is on,
     // otherwise by the longest gap seen, like the far stream)

@@ -90,6 +90,7 @@ void launch_c8_marks_to_index(hipStream_t st, const unsigned long long *marks, u
 void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTab tab, uint32_t bshift, const uint32_t *o1, uint32_t *cursor, Run8 *out);
 void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out);
 void launch_r8_to_iv(hipStream_t st, const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out);
+void launch_copy_words(hipStream_t st, void *dst, const void *src, uint64_t n_words);      // device-to-device, 4-byte words (both pointers 4-byte aligned)
 void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
                       uint32_t min_dep, TilePart *part, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
 void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,

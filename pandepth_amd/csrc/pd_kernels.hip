@@ -1547,6 +1547,22 @@ __global__ __launch_bounds__(WG) void k_c8_expand(const C8Sample cs, const uint3
     }
 }
 
+// A batch's runs on their way to their places (a few MB, twice per decode batch): the runtime's device-to-device copy is a blit kernel that
+// took 0.15 ms per call among the decode kernels (13 % of the decode phase's kernel time, profiles/r05_decode_timeline.txt); this one moves
+// 4-byte words with every lane on its own 16 bytes where source and destination allow it.
+__global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const uint64_t n4 = n / 4;
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst); const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) d4[i] = s4[i];
+        for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+        return;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // a sorted stream of compact runs whose sample turned out not to be usable as one (the file's order does not hold after all): back to
 // 12-byte runs; the contig of a flat begin by bisection over the slots (genomes below 2^32 cells only: the caller has made sure)
 __global__ __launch_bounds__(WG) void k_r8_to_iv(const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out)
@@ -2889,6 +2905,13 @@ void launch_c8_place_other(hipStream_t st, const pd_iv *iv, uint32_t n, ContigTa
 void launch_c8_expand(hipStream_t st, C8Sample cs, const uint32_t *tile_contig, const uint64_t *contig_off, uint32_t n_tiles, pd_iv *out)
 {
     hipLaunchKernelGGL(k_c8_expand, dim3(n_tiles < 16384u ? (n_tiles ? n_tiles : 1u) : 16384u), dim3(WG), 0, st, cs, tile_contig, contig_off, n_tiles, out);
+}
+
+void launch_copy_words(hipStream_t st, void *dst, const void *src, uint64_t n_words)
+{
+    if (!n_words) return;
+    const uint64_t g = (n_words / 4 + 255) / 256 + 1;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src, n_words);
 }
 
 void launch_r8_to_iv(hipStream_t st, const Run8 *r8, uint64_t n, ContigTab tab, pd_iv *out)

@@ -279,7 +279,7 @@ static int o_decode_batch(pd_ctx *c, const pd_decode_batch *bt, int32_t *status,
     // check_chain's rounds
     bool guess_unit = false;
     for (uint32_t u = 0; u < bt->n_units; ++u) if (bt->units[u].flags & PD_UNIT_GUESS) guess_unit = true;
-    if (c->compact && !guess_unit && !segs.empty() && !getenv("PANDEPTH_TEST_HOST_CHAIN")) {
+    if (!guess_unit && (c->compact || cfg.near_span == 0xFFFFFFFFu) && !segs.empty() && !getenv("PANDEPTH_TEST_HOST_CHAIN")) {
         pdb2::ChainOut co;
         const uint32_t max_redo = getenv("PANDEPTH_TEST_MAX_REDO") ? (uint32_t)atoi(getenv("PANDEPTH_TEST_MAX_REDO")) : 256u;
         pdb2::chain_device<pdw::HostWave>(segs.data(), (uint32_t)segs.size(), bst.data(), bt->n_blocks, bt->inflated_bytes / 41 + 64, bt->inflated_bytes / 41 + 64, max_redo,
@@ -360,9 +360,23 @@ static int o_decode_batch(pd_ctx *c, const pd_decode_batch *bt, int32_t *status,
         }
         if (!bad.empty()) { std::lock_guard<std::mutex> lk(c->mu); c->compact_err = bad; }
         cfg.c8 = pdb2::C8Out{};
-    } else
-    for (size_t j = 0; j < segs.size(); ++j)
-        if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data());
+    } else {
+        // 12-byte emission with the order keys riding along (what the product's device-confirmed batches report their order from)
+        std::vector<pdb2::SegOut> so(segs.size(), pdb2::SegOut{pdb2::NONE, 0, 0, 0});
+        cfg.c8 = pdb2::C8Out{}; cfg.c8.seg_out = so.data();
+        for (size_t j = 0; j < segs.size(); ++j)
+            if (segs[j].n_first | segs[j].n_other | segs[j].n_far) pdb2::emit_segment<pdw::HostWave>(cfg, segs[j], &lanes[j * 64], r.first.data(), r.other.data(), r.far.data(), &so[j]);
+        cfg.c8 = pdb2::C8Out{};
+        uint64_t first = pdb2::NONE, last = 0; uint32_t uns = 0;
+        for (const auto &x : so) { uns |= x.unsorted; if (x.first_key == pdb2::NONE) continue; if (first == pdb2::NONE) first = x.first_key; else if (x.first_key < last) uns = 1; last = x.last_key; }
+        auto key = [](const pd_iv &v) { return ((uint64_t)(uint32_t)v.tid << 32) | (uint32_t)v.beg; };
+        bool really = false;
+        for (uint64_t i = 1; i < nf; ++i) if (key(r.first[i]) < key(r.first[i - 1])) really = true;
+        std::string bad;
+        if (nf && really != (uns != 0)) bad = "the 12-byte emission's order flag disagrees with the runs";
+        else if (nf && !really && (first != key(r.first[0]) || last != key(r.first[nf - 1]))) bad = "the 12-byte emission's first / last keys disagree with the runs";
+        if (!bad.empty()) { std::lock_guard<std::mutex> lk(c->mu); c->err = bad; return -4; }
+    }
     r.first.resize(nf); r.other.resize(no); r.far.resize(nfar);
     if (res && nf) {                                             // order of the first runs, as pd_decode_submit reports it
         auto key = [](const pd_iv &v) { return ((uint64_t)(uint32_t)v.tid << 32) | (uint32_t)v.beg; };
@@ -380,10 +394,10 @@ static int o_decode_end(pd_ctx *c)
         for (auto *x : c->bufs) if (x->queued) { c->err = "decode_end: a queued batch was never collected"; return -4; }
         if (getenv("PANDEPTH_TEST_CHAIN_STATS")) fprintf(stderr, "[chain] batches confirmed by chain_device: %llu, left to check_chain: %llu, segments chain_device walked again: %llu\n", (unsigned long long)c->n_chain_dev, (unsigned long long)c->n_chain_host, (unsigned long long)c->n_chain_redo);
     }
-    if (c->compact) {
+    {
         std::lock_guard<std::mutex> lk(c->mu);
-        for (uint8_t seen : c->orders_seen) if (seen != 1 && c->compact_err.empty()) c->compact_err = "a batch number of the session was never submitted";
-        if (!c->compact_err.empty()) { c->err = "compact decode session: " + c->compact_err; return -4; }
+        if (c->compact) for (uint8_t seen : c->orders_seen) if (seen != 1 && c->compact_err.empty()) c->compact_err = "a batch number of the session was never submitted";
+        if (!c->compact_err.empty()) { c->err = "decode session: " + c->compact_err; return -4; }      // (what the stand-in held the product's cores to, in any session)
     }
     std::vector<pd_ctx::Runs> rs;
     { std::lock_guard<std::mutex> lk(c->mu); rs.swap(c->runs); }

@@ -340,6 +340,48 @@ def test_queued_batches_and_device_chain(data, name, tune, extra, expect):
         assert dev == 0 and host == 0
 
 
+def _expected(data, args, suffix, tag):
+    """a table of g.bam in the given mode: the reference's when it is here, else the oracle's"""
+    if os.access(REF, os.X_OK):
+        subprocess.run([REF] + args + ["-o", "ref_" + tag], cwd=data, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        return gzip.decompress((data / ("ref_%s.%s" % (tag, suffix))).read_bytes()).decode()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pd_oracle as O
+    return O.run(args, cwd=str(data))[suffix]
+
+
+# the modes whose sessions keep 12-byte runs (everything that needs the arrays): the device confirms their chains too
+GPU_CHAIN_MODES = [
+    ("w100", ["-i", "g.bam", "-w", "100"], "win.stat.gz"),
+    ("gff", ["-i", "g.bam", "-g", "g.gff"], "gene.stat.gz"),
+    ("bed_whole_a", ["-i", "g.bam", "-b", "w.bed", "-a", "-q", "20"], "bed.stat.gz"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tune", ["dd_batch_mb=1", "dd_batch_mb=1,decode_spoil=2", "dd_batch_mb=1,decode_spoil=1,decode_max_redo=2", "dd_batch_mb=2,decode_fast=0"],
+                         ids=["fast", "spoil", "spoil_left_to_host", "host_chain"])
+@pytest.mark.parametrize("mode,args,suffix", GPU_CHAIN_MODES, ids=[m[0] for m in GPU_CHAIN_MODES])
+def test_device_chain_in_12_byte_sessions_gpu(data, mode, args, suffix, tune):
+    """`-w 100`, `-g` (region fetch: units are index chunks) and `-b … -a` on the MI355X: batches queued and collected, the chain confirmed —
+    and with decode_spoil repaired — on the device, the order of the 12-byte first runs reported by the emission itself; the reference's table"""
+    import re
+    env = dict(os.environ, PANDEPTH_TUNE=tune, PANDEPTH_TIMING="1")
+    tag = "c12_%s_%s" % (mode, re.sub(r"\W", "_", tune))
+    p = subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth")] + args + ["-o", tag, "-t", "6"], cwd=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    assert gzip.decompress((data / ("%s.%s" % (tag, suffix))).read_bytes()).decode() == _expected(data, args, suffix, "c12_" + mode)
+    m = re.search(r"chain confirmed on the device for (\d+) batches, by the host for (\d+); segments the device walked again: (\d+)", p.stderr.decode())
+    assert m, p.stderr.decode()[-600:]
+    dev, host, redo = (int(x) for x in m.groups())
+    if "decode_fast=0" in tune:
+        assert dev == 0 and host > 0
+    elif "decode_max_redo" in tune:
+        assert host > 0
+    else:
+        assert dev > 0 and host == 0 and (redo > 0) == ("decode_spoil" in tune)
+
+
 GPU_CHAIN_CASES = [
     ("fast_depth2", "dd_batch_mb=1"),
     ("fast_depth3", "dd_batch_mb=1,dd_depth=3,dd_threads=4"),
