@@ -411,15 +411,24 @@ def e2e_leg(records, site_records, fullsize_site=False):
             }
         cb = None
         if os.access(ref, os.X_OK):
+            # the reference at -t 36 (12 chromosome workers x (1 + 2 BGZF threads): its best shape on an unrestricted host) AND at -t <the
+            # job's CPU quota> (no oversubscription on these boxes): the FASTER of the two is the baseline, both are in the line
             rthreads = 36
-            w_ref = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", str(rthreads)], 2)
+            w_ref36 = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", str(rthreads)], 2)
             same = open(mine + ".chr.stat.gz", "rb").read() == open(os.path.join(td, "ref.chr.stat.gz"), "rb").read()
-            e2e["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": records / w_ref, "threads": rthreads}
+            by_threads = {str(rthreads): round(w_ref36, 4)}
+            w_ref = w_ref36
+            if quota != rthreads:
+                w_q = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "refq"), "-t", str(quota)], 1)
+                by_threads[str(quota)] = round(w_q, 4)
+                if w_q < w_ref:
+                    w_ref, rthreads = w_q, quota
+            e2e["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": records / w_ref, "threads": rthreads, "wall_s_by_threads": by_threads}
             e2e["byte_identical"] = same
             e2e["speedup_vs_reference"] = round(w_ref / w_dev, 2)
             cb = {"value": records / w_ref, "unit": "records/s", "cores": min(rthreads, quota), "kind": "reference",
                   "sample": "%d records of the configs[1] workload with payload (%.2f GB BAM, %.0f B/record compressed), BAM+BAI, warm "
-                            "cache; pandepth_ref -t %d = 12 chromosome workers x (1 + 2 BGZF threads) on a cgroup quota of %d CPUs, "
+                            "cache; pandepth_ref -t %d (the faster of -t 36 — 12 chromosome workers x (1 + 2 BGZF threads) — and -t <quota>) on a cgroup quota of %d CPUs, "
                             "%.2f s wall" % (records, size / 1e9, size / records, rthreads, quota, w_ref)}
         if os.environ.get("PD_BENCH_E2E_ANNOTATION", "1") == "1":
             try:                                    # an extra: whatever goes wrong here must not cost the line its e2e object

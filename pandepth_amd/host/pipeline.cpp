@@ -425,7 +425,10 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     // A reader does not wait for the device: it queues its batch (decode_queue: copy, inflate, both record passes and the chain check between
     // them all go on the batch's stream) and reads the next one meanwhile; it holds `depth` buffers — the one it is filling and depth - 1
     // queued batches — and collects the oldest when it needs a buffer back.  (The engine has twelve batch slots.)
-    int depth = api->decode_queue && api->decode_collect ? 3 : 1;                    // (clamped below: six readers hold two each, four hold three)
+    // Measured (profiles/r05_decode_matrix.txt): with six readers the GPU is the bound already (some kernel runs 91 % of the phase) and a second
+    // buffer per reader only puts twelve batches' working sets on the device at once — 0.75-0.81 s with one buffer each against 0.79-0.89 with
+    // two on the 3e8-record file.  Fewer readers per context (a `#.list` run: four per GPU) get a second buffer each.
+    int depth = api->decode_queue && api->decode_collect ? (feeders >= 6 ? 1 : 2) : 1;
     if (const char *e = tune("dd_depth")) depth = std::max(1, atoi(e));
     if (!api->decode_queue || !api->decode_collect) depth = 1;
     depth = std::max(1, std::min(depth, 12 / std::max(1, feeders)));
@@ -1382,7 +1385,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         if (n_ctx > 1) {
             // the CPU-heavy parts of a context (host readers, handed-back units) get their share of -t; the device decode's readers do not
             // shrink with it — a reader copies a batch out of the page cache (2 ms per 32 MB) and then waits for the device — so every
-            // GPU keeps four of them, three buffers each, whatever -t / #GPUs comes to
+            // GPU keeps four of them, two buffers each, whatever -t / #GPUs comes to
             o_part.threads = std::max(1, o.threads / n_ctx);
             o_part.decode_readers = 4;
         }
