@@ -420,53 +420,62 @@ PW_FN void chain_device(Seg *segs, uint32_t n_seg, const int *member_status, uin
             us[l] = NONE; el[l] = 0; en[l] = 0; uf[l] = fl[l] = cf[l] = co[l] = cr[l] = ms[l] = 0;
             if ((uint32_t)l >= cnt) return;
             const Seg &s = segs[j0 + (uint32_t)l];
-            us[l] = s.used_start; el[l] = s.e_last; en[l] = s.end; uf[l] = s.unit_first; cf[l] = s.n_first; co[l] = s.n_other; cr[l] = s.n_rec; ms[l] = s.max_span;
+            us[l] = s.used_start; el[l] = s.e_last; en[l] = s.end; uf[l] = s.unit_first ? 1u : 0u; cf[l] = s.n_first; co[l] = s.n_other; cr[l] = s.n_rec; ms[l] = s.max_span;
             fl[l] = s.flags | (s.n_far ? 0x80000000u : 0u);
         });
-        uint32_t lo = 0;
-        while (lo < cnt && !slow) {
-            // the stretch [lo, hi) of this group that belongs to one unit
-            U m;
-            W::each([&](int l) { m[l] = (uint32_t)l > lo && (uint32_t)l < cnt && uf[l] ? 1u : 0u; });
-            const uint64_t ufm = W::ballot_ne(m, 0u);
-            const uint32_t hi = ufm ? (uint32_t)ctz64(ufm) : cnt;
-            const bool head = W::bcast(uf, (int)lo) != 0;             // the stretch begins its unit: nothing before it to be checked against
-            if (head) { E = 0; ++units_seen; }
-            for (;;) {
-                U64 e, eb;
-                W::each([&](int l) { e[l] = (uint32_t)l >= lo && (uint32_t)l < hi ? el[l] : 0ull; });
-                const U64 pm = W::excl_scan_max64(e);
-                U bad;
+        // A group may hold segments of many units (region fetch: a unit per joined index chunk, often one segment long): the chain's end
+        // before a segment is the maximum of the ends of ITS unit's segments before it — a SEGMENTED prefix maximum over the group, the
+        // unit that was open when the group began continuing with the carried end E.  head1[l] = 1 + the lane of the last first-of-unit
+        // segment at or before l (0: none in this group).
+        U h1;
+        W::each([&](int l) { h1[l] = uf[l] ? (uint32_t)l + 1u : 0u; });
+        const U head1 = W::incl_scan_max(h1);
+        for (;;) {
+            const U64 pm = W::seg_excl_scan_max64(el, head1);
+            U64 eb;
+            U bad;
+            W::each([&](int l) {
+                eb[l] = head1[l] == 0u && E > pm[l] ? E : pm[l];
+                const bool chk = (uint32_t)l < cnt && !uf[l];             // (a unit's first segment has nothing before it to be checked against)
+                const uint64_t expect = eb[l] >= en[l] ? NONE : eb[l];
+                bad[l] = chk && us[l] != expect ? 1u : 0u;
+            });
+            const uint64_t bm = W::ballot_ne(bad, 0u);
+            // a flag counts once its segment's start is confirmed (a wrong guess usually ends in garbage and carries one: the repeat
+            // clears it); confirmed are the segments before the first one that does not fit
+            const int jb = bm ? ctz64(bm) : 64;
+            const uint64_t confirmed = jb >= 64 ? ~0ull : (1ull << jb) - 1;
+            const uint64_t flm = W::ballot_ne(fl, 0u) & confirmed;
+            if (flm) { U f2; W::each([&](int l) { f2[l] = (confirmed >> l) & 1 ? fl[l] : 0u; }); slow |= W::reduce_or(f2) & 0x80000000u ? CH_FAR : CH_FLAG; break; }
+            if (!bm) {
+                // the end the chain has reached behind this group's last segment (the carry for the next group)
+                const int last = (int)cnt - 1;
+                const uint64_t pl = W::bcast64(pm, last), ll = W::bcast64(el, last);
+                const bool open_last = W::bcast(head1, last) == 0u;
+                uint64_t e1 = pl > ll ? pl : ll;
+                if (open_last && E > e1) e1 = E;
+                // unit 0's first record and chain end, as pd_decode_result reports them
+                uint32_t n_heads = 0;
+                const U upc = W::excl_scan(uf, &n_heads);                            // units begun in this group before lane l
+                U64 o0, e00;
                 W::each([&](int l) {
-                    eb[l] = pm[l] > E ? pm[l] : E;
-                    const bool chk = (uint32_t)l >= lo && (uint32_t)l < hi && !((uint32_t)l == lo && head);
-                    const uint64_t expect = eb[l] >= en[l] ? NONE : eb[l];
-                    bad[l] = chk && us[l] != expect ? 1u : 0u;
+                    const bool in0 = (uint32_t)l < cnt && units_seen + upc[l] + uf[l] == 1u;
+                    o0[l] = in0 ? us[l] : NONE; e00[l] = in0 ? el[l] : 0ull;
                 });
-                const uint64_t bm = W::ballot_ne(bad, 0u);
-                // a flag counts once its segment's start is confirmed (a wrong guess usually ends in garbage and carries one: the
-                // repeat clears it); the confirmed segments are those of the stretch before the first one that does not fit
-                const int jb = bm ? ctz64(bm) : (int)hi;
-                const uint64_t confirmed = ((uint32_t)jb >= 64u ? ~0ull : (1ull << jb) - 1) & ~((1ull << lo) - 1);
-                const uint64_t flm = W::ballot_ne(fl, 0u) & confirmed;
-                if (flm) { U f2; W::each([&](int l) { f2[l] = (confirmed >> l) & 1 ? fl[l] : 0u; }); slow |= W::reduce_or(f2) & 0x80000000u ? CH_FAR : CH_FLAG; break; }
-                if (!bm) { const uint64_t mx = W::reduce_max64(e); if (mx > E) E = mx; break; }
-                if (++n_redo > max_redo) { slow |= CH_REDO; break; }
-                const uint64_t start = W::bcast64(eb, jb), seg_end = W::bcast64(en, jb);
-                const WalkOut w = rewalk(j0 + (uint32_t)jb, start);
-                if (w.flags) { slow |= CH_FLAG; break; }
-                if (w.n_far) { slow |= CH_FAR; break; }
-                if (w.used_start != (start >= seg_end ? NONE : start)) { slow |= CH_REDO; break; }      // (a walk that does not start where it was told to: the host looks at it)
-                W::each([&](int l) { if (l == jb) { us[l] = w.used_start; el[l] = w.e_last; cf[l] = w.n_first; co[l] = w.n_other; cr[l] = w.n_rec; ms[l] = w.max_span; fl[l] = 0; } });
-            }
-            if (units_seen == 1 && !slow) {
-                U64 own;
-                W::each([&](int l) { own[l] = (uint32_t)l >= lo && (uint32_t)l < hi ? us[l] : NONE; });
-                const uint64_t f = W::reduce_min64(own);
+                const uint64_t f = W::reduce_min64(o0), m0 = W::reduce_max64(e00);
                 if (fs0 == NONE) fs0 = f;
-                e0 = E;
+                if (m0 > e0) e0 = m0;
+                units_seen += n_heads;
+                E = e1;
+                break;
             }
-            lo = hi;
+            if (++n_redo > max_redo) { slow |= CH_REDO; break; }
+            const uint64_t start = W::bcast64(eb, jb), seg_end = W::bcast64(en, jb);
+            const WalkOut w = rewalk(j0 + (uint32_t)jb, start);
+            if (w.flags) { slow |= CH_FLAG; break; }
+            if (w.n_far) { slow |= CH_FAR; break; }
+            if (w.used_start != (start >= seg_end ? NONE : start)) { slow |= CH_REDO; break; }      // (a walk that does not start where it was told to: the host looks at it)
+            W::each([&](int l) { if (l == jb) { us[l] = w.used_start; el[l] = w.e_last; cf[l] = w.n_first; co[l] = w.n_other; cr[l] = w.n_rec; ms[l] = w.max_span; fl[l] = 0; } });
         }
         if (slow) break;
         uint32_t tf = 0, to = 0, tr = 0;

@@ -1760,8 +1760,7 @@ int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_
                         return dec_fail(c, PD_ENOMEM, "run array allocation failed");
                     if (nf) launch_copy_words(st, rs.first, sl.d[DS_R8], nf * (sizeof(pd_iv) / 4));
                     if (no) launch_copy_words(st, rs.other, sl.d[DS_OTH], no * (sizeof(pd_iv) / 4));
-                    HIPDEC(hipGetLastError());
-                    HIPDEC(hipStreamSynchronize(st));                 // (pd_decode_end reads these arrays from another stream; a few MB)
+                    HIPDEC(hipGetLastError());                       // (pd_decode_end waits for the slots' streams before it reads these arrays)
                     order_of((const pdb2::SegOut *)(pin + J.o_so), &rs);
                     rs.n_long = 0;
                 }
@@ -1978,6 +1977,7 @@ int pd_decode_end(pd_ctx *c)
     std::lock_guard<std::mutex> lk(c->mu);
     if (int rs = need_state(c, 0, "pd_decode_end")) return rs;
     HIPOK(c, hipSetDevice(c->device));
+    for (auto &sl : c->dec) if (sl.st) HIPOK(c, hipStreamSynchronize(sl.st));      // (the last copies of the batches' runs to their arrays)
     std::vector<pd_ctx::RunSeg> segs;
     { std::lock_guard<std::mutex> l2(c->dec_mu); segs.swap(c->run_segs); }
     std::sort(segs.begin(), segs.end(), [](const pd_ctx::RunSeg &a, const pd_ctx::RunSeg &b) { return a.order < b.order; });
@@ -2180,6 +2180,7 @@ int pd_push_bgzf_units(pd_ctx *c, const void *blob, size_t n_bytes, const pd_bgz
     bt.units = du.data(); bt.n_units = n_units; bt.order = ((uint64_t)1 << 63) + key.fetch_add(1);
     pd_decode_result res;
     if ((rc = pd_decode_submit(c, &bt, unit_status, &res))) return rc;
+    for (auto &sl : c->dec) if (sl.st) (void)hipStreamSynchronize(sl.st);           // (the batch's runs are scattered from another stream below)
     if (n_records) *n_records = res.n_reads;
     pd_ctx::RunSeg mine{0, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     {

@@ -890,6 +890,13 @@ struct HostWave {                         // 64 emulated lanes
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
     static Var<uint64_t> excl_scan_max64(const Var<uint64_t> &x) { Var<uint64_t> r; uint64_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; if (x.v[l] > a) a = x.v[l]; } return r; }
+    // segmented exclusive prefix maximum: head1[l] = 1 + the lane where l's segment begins (0: it began before lane 0); lane l gets the maximum over its segment's lanes before it (0: none)
+    static Var<uint64_t> seg_excl_scan_max64(const Var<uint64_t> &x, const Var<uint32_t> &head1)
+    {
+        Var<uint64_t> r;
+        for (int l = 0; l < 64; ++l) { const int h = head1.v[l] ? (int)head1.v[l] - 1 : 0; uint64_t a = 0; for (int i = h; i < l; ++i) if (x.v[i] > a) a = x.v[i]; r.v[l] = a; }
+        return r;
+    }
     static uint32_t reduce_or(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) a |= x.v[l]; return a; }
     static uint32_t reduce_xor(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) a ^= x.v[l]; return a; }
     static uint32_t reduce_max(const Var<uint32_t> &x) { uint32_t a = 0; for (int l = 0; l < 64; ++l) if (x.v[l] > a) a = x.v[l]; return a; }
@@ -969,6 +976,16 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         for (int d = 1; d < 64; d <<= 1) { const uint64_t y = shfl_up64(m, d); if (lane >= d && y > m) m = y; }
         const uint64_t up = shfl_up64(m, 1);
         Var<uint64_t> r; r.v = lane ? up : 0ull; return r;
+    }
+    __device__ static __forceinline__ Var<uint64_t> seg_excl_scan_max64(const Var<uint64_t> &x, const Var<uint32_t> &head1)
+    {
+        // Hillis-Steele with the segment's first lane as the fence: a partner d lanes down counts only if it lies in the same segment
+        const int lane = (int)(threadIdx.x & 63), h = head1.v ? (int)head1.v - 1 : 0;
+        uint64_t m = x.v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = shfl_up64(m, d); if (lane - d >= h && y > m) m = y; }
+        const uint64_t up = shfl_up64(m, 1);
+        Var<uint64_t> r; r.v = lane > h ? up : 0ull; return r;
     }
     __device__ static __forceinline__ uint32_t reduce_or(const Var<uint32_t> &x)
     {

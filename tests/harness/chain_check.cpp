@@ -104,6 +104,57 @@ static int run_case(const Model &m, uint64_t seg_bytes, const std::set<size_t> &
     return 0;
 }
 
+// several units in one batch (region fetch: a unit per joined index chunk, many of them a segment or two long): the device form confirms
+// every unit's chain by itself — a segmented prefix maximum — and must arrive where check_chain arrives, with the places running through
+static int run_units(std::mt19937_64 &rng, int rep)
+{
+    const int n_units = 2 + (int)(rng() % 90);
+    std::vector<Model> ms((size_t)n_units);
+    std::vector<pdb2::Seg> segs; std::vector<int> unit_of;
+    uint64_t p = 5000;
+    for (int u = 0; u < n_units; ++u) {
+        const size_t nrec = 1 + rng() % (rep % 2 ? 40 : 900);
+        for (size_t i = 0; i < nrec; ++i) { ms[(size_t)u].rec.push_back(p); p += 150 + rng() % 400; }
+        ms[(size_t)u].rec.push_back(p);
+        const uint64_t first = ms[(size_t)u].rec[0], stop = p;
+        for (uint64_t b = first; b < stop; b += 65536) {
+            pdb2::Seg sg{}; sg.begin = b; sg.end = std::min<uint64_t>(b + 65536, stop); sg.avail = stop; sg.unit_first = b == first; sg.hint = sg.unit_first ? b : pdb2::NONE;
+            segs.push_back(sg); unit_of.push_back(u);
+        }
+        p += 1000 + rng() % 200000;
+    }
+    for (size_t j = 0; j < segs.size(); ++j) {
+        const Model &m = ms[(size_t)unit_of[j]];
+        uint64_t g = segs[j].unit_first ? segs[j].begin : m.first_in(segs[j].begin, segs[j].end);
+        if (!segs[j].unit_first && rng() % 5 == 0 && g != pdb2::NONE && g >= segs[j].begin + 2) g -= 2;          // a false start
+        else if (!segs[j].unit_first && rng() % 7 == 0) { const uint64_t h = g == pdb2::NONE ? segs[j].begin + 1 : m.first_in(g + 1, segs[j].end); if (h != pdb2::NONE) g = h; }
+        m.walk(segs[j], g);
+    }
+    std::vector<pdb2::Seg> dv = segs, hv = segs;
+    for (auto &x : dv) x.n_first = x.n_rec;
+    std::vector<int> member_ok(3, 0);
+    pdb2::ChainOut co; memset(&co, 0xAB, sizeof co);
+    pdb2::chain_device<pdw::HostWave>(dv.data(), (uint32_t)dv.size(), member_ok.data(), (uint32_t)member_ok.size(), ~0ull, ~0ull, 1000000u,
+        [&](uint32_t j, uint64_t start) { ms[(size_t)unit_of[j]].walk(dv[j], start); dv[j].hint = start; dv[j].n_first = dv[j].n_rec;
+                                          return pdb2::WalkOut{dv[j].used_start, dv[j].e_last, dv[j].n_first, 0u, 0u, dv[j].n_rec, dv[j].flags, 0u}; }, &co);
+    std::vector<uint32_t> r2; int rr = 0;
+    while (pdb2::check_chain(hv, &r2) > 0 && ++rr <= 64) for (uint32_t j : r2) ms[(size_t)unit_of[j]].walk(hv[j], hv[j].hint);
+    bool host_flag = false;
+    for (auto &x : hv) if (x.flags) host_flag = true;
+    if (host_flag != (co.slow != 0)) { fprintf(stderr, "units rep %d: device chain slow = %u, the host's chain %s a flag\n", rep, co.slow, host_flag ? "carries" : "carries no"); return 1; }
+    if (co.slow) return 0;
+    uint64_t nf = 0;
+    for (size_t j = 0; j < dv.size(); ++j) {
+        if (dv[j].used_start != hv[j].used_start || dv[j].e_last != hv[j].e_last || dv[j].n_rec != hv[j].n_rec) { fprintf(stderr, "units rep %d: device chain differs from the host's at segment %zu of %zu (%d units)\n", rep, j, dv.size(), n_units); return 1; }
+        if (dv[j].base_first != nf) { fprintf(stderr, "units rep %d: place of segment %zu\n", rep, j); return 1; }
+        nf += dv[j].n_first;
+    }
+    uint64_t fs = ~0ull, E0 = 0;
+    for (size_t j = 0; j < hv.size() && unit_of[j] == 0; ++j) { if (fs == ~0ull && hv[j].used_start != pdb2::NONE) fs = hv[j].used_start; if (hv[j].e_last > E0) E0 = hv[j].e_last; }
+    if (co.n_first != nf || co.first_start != fs || co.next_start != (E0 ? E0 : ~0ull)) { fprintf(stderr, "units rep %d: totals / unit 0's ends\n", rep); return 1; }
+    return 0;
+}
+
 int main()
 {
     std::mt19937_64 rng(3);
@@ -132,6 +183,7 @@ int main()
           std::set<size_t> e; for (size_t j = 3; j + 1 < nseg; j += 4) e.insert(j);
           snprintf(what, sizeof what, "rep %d stop", rep); bad += run_case(c, seg, e, {}, long_reads ? 8 : 1, what); ++cases; }
     }
+    for (int rep = 0; rep < 400; ++rep) { bad += run_units(rng, rep); ++cases; }
     printf("chain_check: %d cases, %d failures\n", cases, bad);
     return bad ? 1 : 0;
 }
