@@ -322,6 +322,7 @@ struct pd_ctx {
         std::mutex mu;
     } lz[2];
     std::atomic<unsigned> lz_turn{0};
+    bool lz_mix = false;                                          // "lz_mix": see lz_run
     // the statistics of the last window call stay on the device (pd_text_append_window_rows formats the table's rows from them)
     unsigned char *wk = nullptr; size_t wk_bytes = 0; uint32_t wk_w = 0; uint64_t wk_nw = 0; bool wk_valid = false; std::vector<uint64_t> wk_woff;
     bool prof = false;
@@ -810,6 +811,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "direct_sample")) { if (value < 1 || value > 65536) return fail(c, PD_EINVAL, "direct_sample must be in [1, 65536]"); c->direct_sample = (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_crc")) { c->dec_crc = value != 0; return PD_OK; }
     if (!strcmp(name, "sweep_i4_fast")) { pdk::set_sweep_i4_fast(value != 0); return PD_OK; }
+    if (!strcmp(name, "lz_mix")) { c->lz_mix = value != 0; return PD_OK; }
     if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 23) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 23]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_spoil")) { c->dec_spoil = value > 0xFFFFFFFFull ? 0u : (uint32_t)value; return PD_OK; }
@@ -2500,7 +2502,11 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
     // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
     // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
     // waiting for the time a round's parse takes.  Two calls run at a time, each in its own slot (buffers + stream).
-    pd_ctx::LzWork &w = c->lz[c->lz_turn.fetch_add(1) & 1u];
+    const unsigned lz_slot = c->lz_turn.fetch_add(1) & 1u;
+    pd_ctx::LzWork &w = c->lz[lz_slot];
+    // "lz_mix": of the two calls a stream keeps in flight, the second parses with its text in memory — a workgroup of the LDS parse fills a CU's
+    // LDS, so two LDS parses run one after the other, while a parse from memory shares the CUs with either kind
+    const unsigned lz_group = c->lz_mix && lz_slot == 1u ? 0u : c->lz_group;
     std::lock_guard<std::mutex> lz_lock(w.mu);
     auto fail = [&](pd_ctx *cc, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(cc->mu); cc->err = msg; return code; };
     if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");
@@ -2545,7 +2551,7 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
     uint32_t group_waves = 0; size_t lds_bytes = 0;
     {
         int lds_max = 0;
-        if (c->lz_group == 0 || hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) { (void)hipGetLastError(); lds_max = 0; }
+        if (lz_group == 0 || hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) { (void)hipGetLastError(); lds_max = 0; }
         if (lds_max > (int)pdk::LZ_LDS_MAX) lds_max = (int)pdk::LZ_LDS_MAX;
         if (lds_max > 0 && !pdk::lz_parse_lds_ready((size_t)lds_max)) lds_max = 0;
         auto fits = [&](const pd_lz_chunk &ch) { return ch.origin == 0 || ch.start - ch.origin == 32768; };
@@ -2553,7 +2559,7 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
         while (k < n_chunks) {
             const uint64_t base = chunks[k].origin;
             uint32_t count = 0; uint64_t hi = 0, len = 0;
-            for (uint32_t j = k; lds_max > 0 && j < n_chunks && count < c->lz_group && fits(chunks[j]) && chunks[j].origin >= base; ++j) {
+            for (uint32_t j = k; lds_max > 0 && j < n_chunks && count < lz_group && fits(chunks[j]) && chunks[j].origin >= base; ++j) {
                 const uint64_t nhi = std::max<uint64_t>(hi, chunks[j].end);
                 const uint64_t nlen = std::min<uint64_t>(nhi + pdk::LZ_LDS_SLACK, (uint64_t)n_text + 32) - base;
                 if ((base & 15) + nlen + 16 > (uint64_t)lds_max) break;

@@ -441,7 +441,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     }
     cfg.n_batches = batches.size();
     if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
-    for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo"})                                                                           // (tuning / test hooks)
+    for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo", "lz_mix"})                                                                           // (tuning / test hooks)
         if (const char *e = tune(k)) if (api->set_param) (void)api->set_param(eng->ctx, k, (uint64_t)std::max(0, atoi(e)));
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
