@@ -1568,8 +1568,8 @@ struct C8Owes {
 // ---- first half: everything the batch needs is put on the slot's stream; nothing is waited for -------------------------------------
 int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
 {
-    pd_ctx::DecSlot::Job &J = sl.job;
-    J.open = true; J.queued = false; J.fast = false; J.timed = false; J.order = bt->order; J.n_bytes = bt->n_bytes; J.inflated = bt->inflated_bytes; J.n_seg = 0;
+    pd_ctx::DecSlot::Job &J = sl.job;                                 // (claimed by dec_slot_of: J.open is set)
+    J.queued = false; J.fast = false; J.timed = false; J.order = bt->order; J.n_bytes = bt->n_bytes; J.inflated = bt->inflated_bytes; J.n_seg = 0;
     J.blocks.clear(); J.units.clear(); J.segs.clear(); J.seg0.clear();
     const bool c8 = J.c8 = c->c8.on;
     J.owes_count = c8 && bt->order < c->c8.n_batches;
@@ -1661,6 +1661,9 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     cfg.near_span = c8 ? 0xFFFFFFFFu : c->dec_near_span;                   // (a compact session has one stream of later runs)
     cfg.c8 = pdb2::C8Out{};
     // ---- H2D, inflate, pass 1 ----
+    // (from here on the device may be reading the caller's buffer and the slot's staging area: a call that fails half way waits for
+    // what it has queued before the slot goes back)
+    struct Settle { hipStream_t st; bool armed = true; ~Settle() { if (armed) (void)hipStreamSynchronize(st); } } settle{st};
     J.timed = g_dec_timing;
     if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], st));
     memset((uint8_t *)bt->host_buf + bt->n_bytes, 0, 64);                  // (the decoder reads up to 8 bytes past a member's end)
@@ -1694,14 +1697,14 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     HIPDEC(hipGetLastError());
     J.queued = true;
     owes.armed = false;                                                   // (the second half counts the order)
+    settle.armed = false;
     return PD_OK;
 }
 
 // ---- second half: wait for the batch, finish it, report what pd_decode_submit reports ------------------------------------------------
 int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_result *res)
 {
-    pd_ctx::DecSlot::Job &J = sl.job;
-    J.open = false;
+    pd_ctx::DecSlot::Job &J = sl.job;                                 // (J.open goes with the slot: dec_release)
     if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
     const uint32_t n_units = (uint32_t)J.units.size(), n_blocks = (uint32_t)J.blocks.size(), n_seg = J.n_seg;
     if (unit_status) for (uint32_t u = 0; u < n_units; ++u) unit_status[u] = 0;
@@ -1906,7 +1909,7 @@ pd_ctx::DecSlot *dec_slot_of(pd_ctx *c, const void *host_buf)
 {
     // (other feeders may be in pd_decode_acquire, re-allocating THEIR slots' pinned buffers: look the slot up under the lock)
     std::lock_guard<std::mutex> l0(c->dec_mu);
-    for (auto &x : c->dec) if (x.busy && !x.job.open && x.h_blob == host_buf) return &x;
+    for (auto &x : c->dec) if (x.busy && !x.job.open && x.h_blob == host_buf) { x.job.open = true; return &x; }      // (claimed: a batch is under way in this slot)
     return nullptr;
 }
 void dec_release(pd_ctx *c, pd_ctx::DecSlot *s) { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; s->job.open = false; } c->dec_cv.notify_all(); }
@@ -1924,7 +1927,7 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
     for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
     const int rc = dec_queue(c, *slp, bt);
-    if (rc) { slp->job.open = false; return rc; }
+    if (rc) return rc;
     return dec_collect(c, *slp, unit_status, res);
 }
 
@@ -1936,7 +1939,7 @@ int pd_decode_queue(pd_ctx *c, const pd_decode_batch *bt, uint64_t *ticket)
     if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_queue: buffer was not handed out by pd_decode_acquire");
     const int rc = dec_queue(c, *slp, bt);
     if (rc) { dec_release(c, slp); return rc; }
-    *ticket = ((uint64_t)++slp->gen << 8) | (uint64_t)(slp - c->dec + 1);
+    { std::lock_guard<std::mutex> l0(c->dec_mu); *ticket = ((uint64_t)++slp->gen << 8) | (uint64_t)(slp - c->dec + 1); }
     return PD_OK;
 }
 
