@@ -27,7 +27,10 @@
 
 namespace pdb2 {
 
-enum { SUB = 1024, SEG_BYTES = 64 * SUB };
+#ifndef PD_WALK_SUB
+#define PD_WALK_SUB 1024                  /* bytes of a segment a lane owns (a segment = 64 of them = one wave) */
+#endif
+enum { SUB = PD_WALK_SUB, SEG_BYTES = 64 * SUB };
 // Later runs of a read that begin more than Cfg::near_span bases after its start may go to a separate ("far") stream.  Measured
 // on the 50x sample a third stream costs the tile kernels more (per-batch bookkeeping in every tile) than its tighter disorder
 // bound saves, so the split is off by default (near_span = 0xFFFFFFFF) and every later run goes to the one "other" stream.
