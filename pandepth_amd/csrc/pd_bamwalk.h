@@ -5,8 +5,8 @@
 //
 // Records form a chain (each record's length says where the next one starts), so a stretch of the inflated stream is
 // walked SPECULATIVELY, like the Huffman streams in pd_inflate_wave.h:
-//   * a SEGMENT is up to 64 KiB whose first record start is known (an index offset) or guessed; lane l of the wave owns
-//     the records that start in the l-th KiB;
+//   * a SEGMENT is up to 64 x PD_WALK_SUB bytes (256 KiB) whose first record start is known (an index offset) or guessed; lane l of the wave owns
+//     the records that start in its l-th stretch of PD_WALK_SUB bytes ("its KiB" below, from the days when that was 1024);
 //   * every lane looks for the first position in its KiB that passes a strict record-header test (sizes consistent with
 //     each other, ids inside the header's tables, a NUL where the name ends, and the same for the record it points to),
 //     and walks from there to the end of its KiB;
@@ -28,7 +28,11 @@
 namespace pdb2 {
 
 #ifndef PD_WALK_SUB
-#define PD_WALK_SUB 1024                  /* bytes of a segment a lane owns (a segment = 64 of them = one wave) */
+// bytes of a segment a lane owns (a segment = 64 of them = one wave).  Round 5, measured on the 3e8-record file (profiles/r05_walk_sub.txt): a lane pays for
+// its header search and the three-records-deep test of its guess once, whatever it owns — at 1 KiB (three records of a short-read file) that is
+// half its work; 4 KiB: pass 1 takes 256 ms of kernel time instead of 410, the chain kernel has a quarter of the segments to go through (8 KiB: the same;
+// 512 B: 590 ms)
+#define PD_WALK_SUB 4096
 #endif
 enum { SUB = PD_WALK_SUB, SEG_BYTES = 64 * SUB };
 // Later runs of a read that begin more than Cfg::near_span bases after its start may go to a separate ("far") stream.  Measured
