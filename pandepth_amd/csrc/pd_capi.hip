@@ -813,7 +813,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "sweep_i4_fast")) { pdk::set_sweep_i4_fast(value != 0); return PD_OK; }
     if (!strcmp(name, "lz_mix")) { c->lz_mix = value != 0; return PD_OK; }
     if (!strcmp(name, "lz_group")) { if (value > pdk::LZ_GROUP_MAX) return fail(c, PD_EINVAL, "lz_group must be in [0, 16]"); c->lz_group = (unsigned)value; return PD_OK; }
-    if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 23) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 23]"); c->dec_waves = (unsigned)value; return PD_OK; }
+    if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 24) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 24]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_spoil")) { c->dec_spoil = value > 0xFFFFFFFFull ? 0u : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_max_redo")) { c->dec_max_redo = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
