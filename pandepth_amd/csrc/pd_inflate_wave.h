@@ -29,6 +29,7 @@
 // an out-of-bounds write.
 #ifndef PD_INFLATE_WAVE_H_
 #define PD_INFLATE_WAVE_H_
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -56,6 +57,12 @@ namespace pdw {
 #endif
 #ifndef PD_D_ROOT
 #define PD_D_ROOT 8
+#endif
+#ifndef PD_REDIRECT_JUMPS
+#define PD_REDIRECT_JUMPS 0               /* phase 3: levels a match's source is followed through earlier matches of its batch */
+#endif
+#ifndef PD_PIECE_BYTES
+#define PD_PIECE_BYTES 8                  /* phase 3: bytes of a match one lane copies in one step (8 or 16) */
 #endif
 // sub-table areas: zlib's `enough` bounds — 286 literal/length symbols of at most 15 bits need 852 entries with a 9-bit root (340 behind the
 // root) and 820 with a 10-bit one (308 are needed, 320 kept); a code that would need more goes to the host (build_table checks)
@@ -518,6 +525,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     if (act[l]) act[l] = count_step(T, in, in_lim, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l]);
                 });
             }
+            if (round == 0) PW_TICK(7);
             if (st) { st->sync_rounds++; st->wave_iters_sync += trips;
                       W::each([&](int l) { if (need[l]) { st->sym_decoded += c[l].ns; st->lanes_redecoded++; } }); }
             U e, f;
@@ -597,27 +605,60 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 T.bend()[l] = valid[l] ? dst[l] + len[l] : 0xFFFFFFFFu;
             });
             W::sync();
-            const uint32_t d0 = W::bcast(dst, 0);
-            W::each([&](int l) {
-                dep_lo[l] = 1; dep_hi[l] = 0;                              // empty
-                if (!valid[l] || l == 0) return;
-                const uint32_t src = dst[l] - dist[l];
-                const uint32_t send = src + (len[l] < dist[l] ? len[l] : dist[l]);
-                if (send <= d0) return;                                   // the source ends before the batch's first match
-                int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
-                const int i_lo = lo;
-                lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
-                dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
-            });
+            const uint32_t d0 = W::bcast_u(dst, 0);
+            // srcp / per: where a match's bytes come from and with what period (dst - dist and dist, unless the source is redirected below)
+            U srcp, per;
+            W::each([&](int l) { srcp[l] = dst[l] - dist[l]; per[l] = dist[l]; });
+            auto find_deps = [&]() {
+                W::each([&](int l) {
+                    dep_lo[l] = 1; dep_hi[l] = 0;                              // empty
+                    if (!valid[l] || l == 0) return;
+                    const uint32_t src = srcp[l];
+                    const uint32_t send = src + (len[l] < per[l] ? len[l] : per[l]);
+                    if (send <= d0) return;                                   // the source ends before the batch's first match
+                    int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
+                    const int i_lo = lo;
+                    lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
+                    dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
+                });
+            };
+            find_deps();
+#if PD_REDIRECT_JUMPS > 0
+            // (an experiment kept behind a switch, profiles/r03_inflate_span_experiment.txt: a source that lies INSIDE one earlier plain copy of
+            // the batch reads where that match reads — 3.8 -> 2.85 rounds per batch with one jump — at the price of a second dependency search)
+            for (int jump = 0; jump < PD_REDIRECT_JUMPS; ++jump) {
+                U from, can;
+                W::each([&](int l) {
+                    from[l] = 0; can[l] = 0;
+                    if (!valid[l] || dep_lo[l] + 1u != dep_hi[l]) return;
+                    const uint32_t a = dep_lo[l], src = srcp[l], send = src + (len[l] < per[l] ? len[l] : per[l]);
+                    if (src >= T.bdst()[a] && send <= T.bend()[a]) { from[l] = a; can[l] = 1; }
+                });
+                if (!W::ballot_ne(can, 0u)) break;
+                const U a_src = W::shfl(srcp, from), a_per = W::shfl(per, from);
+                U moved;
+                W::each([&](int l) {
+                    moved[l] = 0;
+                    if (!can[l]) return;
+                    const uint32_t a = from[l], a_len = T.bend()[a] - T.bdst()[a];
+                    if (a_per[l] < a_len) return;                             // (a self-overlapping match: its bytes are not its source's)
+                    srcp[l] = a_src[l] + (srcp[l] - T.bdst()[a]);
+                    moved[l] = 1;
+                });
+                if (!W::ballot_ne(moved, 0u)) break;
+                find_deps();
+            }
+#endif
+            PW_TICK(8);
             // The ready matches of a round are copied in 8-byte PIECES dealt out over the whole wave — piece p of the round belongs to the
             // match whose first piece is the last one at or before p — so a round costs its bytes / 512 trips of one uniform step, not the
             // trips of its longest match through a divergent per-lane copy loop (the wave used to wait for 1 350 pieces per member that
             // way; dealt out, a member's 8 900 pieces are 140 trips + one per round).  A piece is a full 8-byte load and store (the last
             // piece of a match overlaps the one before it so that it ends where the match ends; matches shorter than 8 bytes are one
             // byte-exact piece); a piece of a self-overlapping match (dist < len) takes its bytes from the period in front of the match.
-            const U packB = [&] { U x; W::each([&](int l) { x[l] = len[l] | (dist[l] << 16); }); return x; }();
+            const U packB = [&] { U x; W::each([&](int l) { x[l] = len[l] | (per[l] << 16); }); return x; }();
             uint16_t *const own = T.sorted;                               // (free since the tables were built) 64 entries: a chunk's piece -> match marks
             uint64_t done = W::ballot_eq(valid, 0u);
             for (int round = 0; done != ~0ull; ++round) {
@@ -629,13 +670,14 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     uint64_t dm = 0;
                     if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
                     if (dm & ~done) return;
-                    ready[l] = 1; np[l] = (len[l] + 7) >> 3;
+                    ready[l] = 1; np[l] = (len[l] + (PD_PIECE_BYTES - 1)) / PD_PIECE_BYTES;
                     if (st) st->copy_iters += (len[l] + 31) / 32;
                 });
                 uint32_t P = 0;
                 const U ps = W::excl_scan(np, &P);                        // a ready match's first piece
                 U packA;
                 W::each([&](int l) { packA[l] = dst[l] | (ps[l] << 16); });
+                PW_TICK(9);
                 uint32_t carry = 0;                                       // (1 + match) of the piece in front of the chunk
                 for (uint32_t c0 = 0; c0 < P; c0 += 64) {
                     W::each([&](int l) { own[l] = 0; });
@@ -646,26 +688,55 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     W::each([&](int l) { id[l] = own[l]; });
                     id = W::incl_scan_max(id);
                     W::each([&](int l) { if (id[l] < carry) id[l] = carry; });
-                    carry = W::bcast(id, 63);
+                    carry = W::bcast_u(id, 63);
                     U src_lane;
                     W::each([&](int l) { src_lane[l] = id[l] ? id[l] - 1 : 0u; });
                     const U a = W::shfl(packA, src_lane), b = W::shfl(packB, src_lane);
+#if PD_REDIRECT_JUMPS > 0
+                    const U sp = W::shfl(srcp, src_lane);
+#endif
                     W::each([&](int l) {
                         const uint32_t p = c0 + (uint32_t)l;
                         if (p >= P) return;
                         const uint32_t dstm = a[l] & 0xffff, lenm = b[l] & 0xffff, distm = b[l] >> 16;
+#if PD_REDIRECT_JUMPS > 0
+                        const uint8_t *s = out + sp[l];                    // (distm is then the PERIOD of the match's bytes, not where they are)
+#else
+                        const uint8_t *s = out + dstm - distm;
+#endif
+#if PD_PIECE_BYTES == 16
+                        // a piece = two 8-byte halves at lo and hi: 16 consecutive bytes of a long match (the last piece moved back so that it
+                        // ends where the match ends), the first and the last 8 bytes of a match of 8 .. 15, one byte-exact store below that
+                        uint32_t off = (p - (a[l] >> 16)) * 16;
+                        if (lenm >= 16 && off > lenm - 16) off = lenm - 16;
+                        const uint32_t lo = lenm >= 16 ? off : 0u, hi = lenm >= 16 ? off + 8 : lenm >= 8 ? lenm - 8 : 0u;
+                        uint64_t v0, v1;
+                        if (distm >= lenm) { v0 = ld64(s + lo); v1 = ld64(s + hi); }
+                        else { v0 = periodic8(s, distm, lo); v1 = periodic8(s, distm, hi); }
+                        if (lenm >= 8) { st64(out + dstm + lo, v0); st64(out + dstm + hi, v1); } else store_bytes(out + dstm, v0, lenm);
+#else
                         uint32_t off = (p - (a[l] >> 16)) * 8;
                         if (lenm >= 8 && off > lenm - 8) off = lenm - 8;
-                        const uint8_t *s = out + dstm - distm;
+#ifdef PD_X_ALIGN_LD      /* timing experiment only (wrong bytes): what the misalignment of the loads costs */
+                        const uint64_t v = distm >= lenm ? ld64((const uint8_t *)((uintptr_t)(s + off) & ~(uintptr_t)7)) : periodic8(s, distm, off);
+#else
                         const uint64_t v = distm >= lenm ? ld64(s + off) : periodic8(s, distm, off);
+#endif
+#ifdef PD_X_ALIGN_ST      /* timing experiment only (wrong bytes): what the misalignment of the stores costs */
+                        if (lenm >= 8) st64((uint8_t *)((uintptr_t)(out + dstm + off) & ~(uintptr_t)7), v); else store_bytes(out + dstm, v, lenm);
+#else
                         if (lenm >= 8) st64(out + dstm + off, v); else store_bytes(out + dstm, v, lenm);
+#endif
+#endif
                     });
                     if (st) st->copy_serial += 1;
                     W::sync();
                 }
                 if (st) W::each([&](int l) { if (ready[l] && len[l] > 16) st->long_matches++; });
+                PW_TICK(10);
                 W::fence();
                 done |= W::ballot_ne(ready, 0u);
+                PW_TICK(11);
                 if (st) st->emit_rounds++;
             }
             if (st) st->batches++;
@@ -685,6 +756,7 @@ template <class W>
 PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st)
 {
     static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    typedef typename W::template Var<uint32_t> U;
     if (in_len > (1u << 17) || out_len > (1u << 16)) return PD_W_HOST;        // not a BGZF member: 16-bit token fields
     const uint32_t in_bits = in_len * 8;
     uint32_t q = 0, o = 0;
@@ -740,35 +812,83 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                 // the code lengths themselves: a short serial stream (every lane runs it, lane l stores).  Its bytes are
                 // fetched ONCE: lane l holds the 8 bytes at l * 8 of a 512-byte window, and the bit buffer is fed by
                 // readlane (a register access) instead of a dependent memory load per symbol
+                // The code lengths themselves: a stream of symbols of 1 .. 14 bits, decoded 64 bit positions at a time.  Lane l decodes the
+                // symbol that WOULD start at bit q + l (one table look-up; 63 of 64 lanes guess wrong and nobody minds), the wave follows
+                // the chain of true starts through the 64 positions with readlane (a register access per symbol — the loop that decoded one
+                // symbol per trip, every lane alike, took 860 cycles per symbol: a sixth of a member's time for 360 symbols), and the true
+                // symbols then store their lengths together: places from a prefix sum of the repeat counts, "repeat the previous length"
+                // resolved by a prefix maximum.  The array starts out zero, so runs of zeros (symbols 17 and 18) store nothing.
+                // The stream's bytes are fetched ONCE: lane l holds the 8 bytes at l * 8 of a 512-byte window.
+                W::each([&](int l) { for (int s2 = l; s2 < 320; s2 += 64) T.cl[s2] = 0; });   // (the code-length code's own lengths are in its table now)
                 uint32_t idx = 0, prev = 0;
-                const uint32_t want = nlen + ndist;
-                uint32_t wbase = q >> 3;                                   // byte position of the window in `in`
+                const uint32_t want = W::uni(nlen + ndist);
+                uint32_t wbase = W::uni(q >> 3);                           // byte position of the window in `in`
+                q = W::uni(q);
                 typename W::template Var<uint64_t> hw;
                 W::each([&](int l) { const uint32_t at = wbase + 8u * (uint32_t)l; hw[l] = at <= in_len ? ld64(in + at) : 0ull; });
+                W::sync();
                 while (idx < want) {
-                    if (q >= in_bits) return -7;
                     uint32_t r = q - 8 * wbase;                            // bit offset inside the window
-                    if (r > 62 * 64) {                                     // (a header longer than the window: move it)
+                    if (r >= 61 * 64) {                                    // (a header longer than the window: move it)
                         wbase = q >> 3;
                         W::each([&](int l) { const uint32_t at = wbase + 8u * (uint32_t)l; hw[l] = at <= in_len ? ld64(in + at) : 0ull; });
                         r = q - 8 * wbase;
                     }
                     const uint32_t k = r >> 6, sh = r & 63;
-                    const uint64_t a = W::bcast64(hw, (int)k), b = W::bcast64(hw, (int)k + 1);
-                    uint32_t w = (uint32_t)(sh ? (a >> sh) | (b << (64 - sh)) : a);
-                    const uint32_t e = T.d[w & 127];
-                    const uint32_t n = e & 15;
-                    if (!n || ((e >> 4) & 3) != KIND_LIT) return -4;
-                    const uint32_t sym = (e >> 8) & 0xff;
-                    w >>= n; q += n;
-                    if (st) st->hdr_syms++;
-                    uint32_t rep = 1, val = sym;
-                    if (sym == 16) { if (idx == 0) return -3; val = prev; rep = 3 + (w & 3); q += 2; }
-                    else if (sym == 17) { val = 0; rep = 3 + (w & 7); q += 3; }
-                    else if (sym == 18) { val = 0; rep = 11 + (w & 127); q += 7; }
-                    if (idx + rep > want) return -3;
-                    W::each([&](int l) { for (uint32_t j = (uint32_t)l; j < rep; j += 64) T.cl[idx + j] = (uint8_t)val; });   // rep <= 138
-                    idx += rep; prev = val;
+                    const uint64_t a = W::bcast64(hw, (int)k), b = W::bcast64(hw, (int)k + 1), c = W::bcast64(hw, (int)k + 2);
+                    const uint64_t lo = sh ? (a >> sh) | (b << (64 - sh)) : a, hi = sh ? (b >> sh) | (c << (64 - sh)) : b;   // 128 bits from q
+                    U nxt, rep, val, bad;
+                    W::each([&](int l) {
+                        const uint32_t w = (uint32_t)(l ? (lo >> l) | (hi << (64 - l)) : lo);
+                        const uint32_t e = T.d[w & 127];
+                        const uint32_t n = e & 15, sym = (e >> 8) & 0xff;
+                        const uint32_t x = w >> n;
+                        const uint32_t ext = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+                        const uint32_t xv = x & ((1u << ext) - 1u);
+                        bad[l] = !n || ((e >> 4) & 3) != KIND_LIT;
+                        rep[l] = sym < 16 ? 1u : sym == 18 ? 11u + xv : 3u + xv;
+                        val[l] = sym;                                      // 16: the previous length; 17, 18: zeros
+                        nxt[l] = bad[l] ? 255u : (uint32_t)l + n + ext;
+                    });
+                    uint64_t starts = 0;
+                    uint32_t pos = 0;
+                    while (pos < 64) { starts |= 1ull << pos; pos = W::bcast_u(nxt, pos); }
+                    // the symbols of this stretch that are still wanted, with their places; the first one at fault decides
+                    U cnt, err, used;
+                    W::each([&](int l) { cnt[l] = (starts >> l) & 1 ? rep[l] : 0u; });
+                    uint32_t tot = 0;
+                    const U ex = W::excl_scan(cnt, &tot);
+                    W::each([&](int l) {
+                        const uint32_t at = idx + ex[l];
+                        used[l] = ((starts >> l) & 1) && at < want;
+                        err[l] = 0;
+                        if (!used[l]) return;
+                        if (q + (uint32_t)l >= in_bits) err[l] = 7;
+                        else if (bad[l]) err[l] = 4;
+                        else if ((val[l] == 16 && at == 0) || at + rep[l] > want) err[l] = 3;
+                    });
+                    const uint64_t em = W::ballot_ne(err, 0u);
+                    if (em) return -(int)W::bcast_u(err, (uint32_t)__builtin_ctzll(em));
+                    if (st) st->hdr_syms += (uint64_t)__builtin_popcountll(W::ballot_ne(used, 0u));
+                    // "the previous length" = the length of the nearest symbol before that is not itself a repeat (across stretches: prev)
+                    U key;
+                    W::each([&](int l) { key[l] = used[l] && val[l] != 16 ? ((uint32_t)(l + 1) << 8) | (val[l] < 16 ? val[l] : 0u) : 0u; });
+                    key = W::incl_scan_max(key);
+                    W::each([&](int l) {
+                        if (!used[l]) return;
+                        const uint32_t v = val[l] < 16 ? val[l] : val[l] == 16 ? (key[l] ? key[l] & 0xffu : prev) : 0u;
+                        if (!v) return;
+                        const uint32_t at = idx + ex[l];
+                        for (uint32_t j = 0; j < rep[l]; ++j) T.cl[at + j] = (uint8_t)v;   // rep <= 6 here
+                    });
+                    const uint32_t k63 = W::bcast_u(key, 63);
+                    if (k63) prev = k63 & 0xffu;
+                    const uint64_t um = W::ballot_ne(used, 0u);
+                    const uint64_t over = starts & ~um;                    // true starts behind the last wanted symbol
+                    if (idx + tot >= want) {                                // the stream ends inside this stretch
+                        q += over ? (uint32_t)__builtin_ctzll(over) : pos;
+                        idx = want;
+                    } else { idx += tot; q += pos; }
                 }
                 if (q > in_bits) return -7;
                 W::sync();
@@ -797,33 +917,57 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 }
 
 // ---- CRC-32 of a member's inflated bytes (RFC 1952; htslib checks it for every BGZF block it reads, so a flipped bit that
-// still inflates must not go unnoticed here either).  One wave, lane l takes bytes [1024 l, 1024 (l + 1)): the register
-// update is linear over GF(2) — R(s, data) = R(s, zeros) ^ R(0, data), and running over n zero bytes is the multiplication
-// by x^(8n) modulo the CRC polynomial — so every lane runs its KiB from a zero register through a 256-entry table, shifts its
-// result past the bytes behind it with that multiplication, and the wave XORs the 64 results with the shifted start value.
+// still inflates must not go unnoticed here either).  One wave; the output is cut into 1 KiB chunks of which the FIRST is the short
+// one, and the chunks sit in the LAST lanes (chunk L - 1 in lane 63), so that lane l's bytes are followed by exactly 1024 (63 - l)
+// more.  The register update is linear over GF(2) — R(s, data) = R(s, zeros) ^ R(0, data), and running over n zero bytes is the
+// multiplication by x^(8n) modulo the CRC polynomial — so every lane runs its chunk through the tables from a zero register (the
+// first chunk from the start value 0xFFFFFFFF), and the wave adds the 64 results up as the polynomial sum(part_l X^(63 - l)),
+// X = x^8192: six pairing steps, each a multiplication by a CONSTANT (X, X^2, X^4 ...).  (Until round 5 the last chunk was the
+// short one: every lane then multiplied by its own power of x — seventeen squarings and as many products, 2 900 instructions —
+// which cost more than the bytes.)
 static const uint32_t CRC_POLY = 0xEDB88320u;                            // reflected: bit 31 is the coefficient of x^0
-PW_FN uint32_t crc_mul(uint32_t a, uint32_t b)                            // a(x) b(x) mod P(x)
+constexpr uint32_t crc_mul(uint32_t a, uint32_t b)                        // a(x) b(x) mod P(x)
 {
     uint32_t p = 0;
+    for (int k = 0; k < 32; ++k) {
+        p ^= b & (0u - ((a >> (31 - k)) & 1u));
+        b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+constexpr uint32_t crc_x8192_pow(int s)                                   // (x^8192)^(2^s) mod P(x)
+{
+    uint32_t p = 0x00800000u;                                             // x^8
+    for (int j = 0; j < 10 + s; ++j) p = crc_mul(p, p);
+    return p;
+}
+template <uint32_t B>
+PW_FN uint32_t crc_mul_by(uint32_t a)                                     // a(x) B(x) mod P(x): B's 32 shifts are literals
+{
+    uint32_t p = 0, b = B;
+#pragma unroll
     for (int k = 0; k < 32; ++k) {
         p ^= b & (0u - ((a >> (31 - k)) & 1u));
         b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
     }
     return p;
 }
-PW_FN uint32_t crc_shift(uint32_t v, uint32_t n_bytes)                    // v(x) x^(8 n) mod P(x), n < 2^17
-{
-    uint32_t e = 0x80000000u, p = 0x00800000u;                             // x^0, x^8
-    for (int j = 0; j < 17; ++j) {
-        if ((n_bytes >> j) & 1u) e = crc_mul(e, p);
-        p = crc_mul(p, p);
-    }
-    return crc_mul(e, v);
-}
-template <class W>
-PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 256 words of LDS */)
+template <class W, int S>
+PW_FN void crc_pair_step(typename W::template Var<uint32_t> &part)
 {
     typedef typename W::template Var<uint32_t> U;
+    U t, from;
+    W::each([&](int l) { t[l] = crc_mul_by<crc_x8192_pow(S)>(part[l]); from[l] = (uint32_t)(l - (1 << S)) & 63u; });
+    const U got = W::shfl(t, from);
+    W::each([&](int l) { if ((l & ((2 << S) - 1)) == (2 << S) - 1) part[l] ^= got[l]; });
+}
+template <class W>
+PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 1024 words of LDS */)
+{
+    typedef typename W::template Var<uint32_t> U;
+    if (n == 0) return 0;
+    // Four tables ("slicing by 4"): tab[256 k + i] = the register after byte i followed by k zero bytes, so that four bytes are one step —
+    // four INDEPENDENT look-ups instead of four that wait for each other
     W::each([&](int l) {
         for (int k = 0; k < 4; ++k) {
             uint32_t c = (uint32_t)(l * 4 + k);
@@ -832,29 +976,38 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 256 
         }
     });
     W::sync();
+    for (int t = 1; t < 4; ++t) {
+        W::each([&](int l) {
+            for (int k = 0; k < 4; ++k) { const uint32_t c = tab[256 * (t - 1) + l * 4 + k]; tab[256 * t + l * 4 + k] = (c >> 8) ^ tab[c & 0xffu]; }
+        });
+        W::sync();
+    }
+    const uint32_t L = (n + 1023u) >> 10;                                 // chunks (<= 64); the first has n - 1024 (L - 1) bytes
+    const uint32_t first = n - 1024u * (L - 1u);
     U part;
     W::each([&](int l) {
-        const uint32_t a = (uint32_t)l * 1024u;
-        const uint32_t b = a + 1024u < n ? a + 1024u : n;
-        uint32_t r = 0, i = a;
+        part[l] = 0;
+        const int c = l - (int)(64u - L);
+        if (c < 0) return;
+        const uint32_t a = c == 0 ? 0u : first + 1024u * (uint32_t)(c - 1), b = c == 0 ? first : a + 1024u;
+        uint32_t r = c == 0 ? 0xFFFFFFFFu : 0u, i = a;
         // 16 bytes per load (a byte per load made every step a cache miss: 64 lanes x 16 waves stream 1 000 different lines)
         for (; i + 16 <= b; i += 16) {
             uint32_t w[4]; __builtin_memcpy(w, data + i, 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t x = w[k];
-                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
-                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
-                r = tab[(r ^ x) & 0xffu] ^ (r >> 8); x >>= 8;
-                r = tab[(r ^ x) & 0xffu] ^ (r >> 8);
+                const uint32_t x = r ^ w[k];
+                r = tab[768 + (x & 0xffu)] ^ tab[512 + ((x >> 8) & 0xffu)] ^ tab[256 + ((x >> 16) & 0xffu)] ^ tab[x >> 24];
             }
         }
         for (; i < b; ++i) r = tab[(r ^ data[i]) & 0xffu] ^ (r >> 8);
-        part[l] = a < n ? crc_shift(r, n - b) : 0u;
+        part[l] = r;
     });
-    const uint32_t body = W::reduce_xor(part);
-    W::sync();                                                            // (the table's LDS is the caller's again)
-    return body ^ crc_shift(0xFFFFFFFFu, n) ^ 0xFFFFFFFFu;
+    crc_pair_step<W, 0>(part); crc_pair_step<W, 1>(part); crc_pair_step<W, 2>(part);
+    crc_pair_step<W, 3>(part); crc_pair_step<W, 4>(part); crc_pair_step<W, 5>(part);
+    const uint32_t body = W::bcast_u(part, 63);
+    W::sync();                                                            // (the tables' LDS is the caller's again)
+    return body ^ 0xFFFFFFFFu;
 }
 
 // A whole BGZF member: inflate, then the CRC-32 of the output against the member's trailer (the 4 bytes behind the payload).
@@ -868,7 +1021,9 @@ PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint3
     }
     if (!check_crc) return 0;
     W::fence();
+    PW_TICK(6);
     uint32_t want; __builtin_memcpy(&want, in + in_len, 4);
+    static_assert(sizeof(T.ll) + sizeof(T.d) >= 4096 && offsetof(Tables, d) == sizeof(T.ll), "the CRC tables take the first 4 KiB of the (now free) code tables");
     return crc32_wave<W>(out, out_len, T.ll) == want ? 0 : -20;
 }
 
@@ -887,6 +1042,8 @@ struct HostWave {                         // 64 emulated lanes
     static Var<uint32_t> incl_scan_max(const Var<uint32_t> &x) { Var<uint32_t> r; uint32_t a = 0; for (int l = 0; l < 64; ++l) { if (x.v[l] > a) a = x.v[l]; r.v[l] = a; } return r; }
     static Var<uint32_t> shfl(const Var<uint32_t> &x, const Var<uint32_t> &from) { Var<uint32_t> r; for (int l = 0; l < 64; ++l) r.v[l] = x.v[from.v[l] & 63]; return r; }
     static uint64_t bcast64(const Var<uint64_t> &x, int lane) { return x.v[lane]; }
+    static uint32_t uni(uint32_t x) { return x; }                                               // a value every lane holds alike
+    static uint32_t bcast_u(const Var<uint32_t> &x, uint32_t lane) { return x.v[lane & 63]; }      // lane must be wave-uniform
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
     static Var<uint64_t> excl_scan_max64(const Var<uint64_t> &x) { Var<uint64_t> r; uint64_t a = 0; for (int l = 0; l < 64; ++l) { r.v[l] = a; if (x.v[l] > a) a = x.v[l]; } return r; }
@@ -949,6 +1106,11 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         const int sl = __builtin_amdgcn_readfirstlane(lane);
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x.v, sl), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x.v >> 32), sl);
         return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ static __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }   // (tells the compiler: scalar)
+    __device__ static __forceinline__ uint32_t bcast_u(const Var<uint32_t> &x, uint32_t lane)
+    {
+        return (uint32_t)__builtin_amdgcn_readlane((int)x.v, __builtin_amdgcn_readfirstlane((int)lane));
     }
     __device__ static __forceinline__ uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip)
     {
