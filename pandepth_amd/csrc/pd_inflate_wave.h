@@ -58,12 +58,6 @@ namespace pdw {
 #ifndef PD_D_ROOT
 #define PD_D_ROOT 8
 #endif
-#ifndef PD_REDIRECT_JUMPS
-#define PD_REDIRECT_JUMPS 0               /* phase 3: levels a match's source is followed through earlier matches of its batch */
-#endif
-#ifndef PD_PIECE_BYTES
-#define PD_PIECE_BYTES 8                  /* phase 3: bytes of a match one lane copies in one step (8 or 16) */
-#endif
 // sub-table areas: zlib's `enough` bounds — 286 literal/length symbols of at most 15 bits need 852 entries with a 9-bit root (340 behind the
 // root) and 820 with a 10-bit one (308 are needed, 320 kept); a code that would need more goes to the host (build_table checks)
 enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = PD_LL_ROOT <= 9 ? 340 : 320, D_ROOT = PD_D_ROOT, D_SUBCAP = 256 };
@@ -73,7 +67,7 @@ enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };
 
 // Table entry: [3:0] code length in bits (sub-table pointer: index width)  [5:4] kind  [6] sub-table pointer
 //              [15:8] literal byte / number of extra bits  [31:16] base value / sub-table offset
-struct Tables {
+struct alignas(16) Tables {
     uint32_t ll[(1 << LL_ROOT) + LL_SUBCAP];
     uint32_t d[(1 << D_ROOT) + D_SUBCAP];
     uint16_t sorted[320];                 // symbols ordered by (code length, symbol)
@@ -83,6 +77,7 @@ struct Tables {
     PW_FN uint16_t *rank() { return reinterpret_cast<uint16_t *>(work); }
     PW_FN uint32_t *bdst() { return work; }
     PW_FN uint32_t *bend() { return work + 64; }
+    PW_FN uint64_t *psel() { return reinterpret_cast<uint64_t *>(sorted + 64); }   // phase 3: 56 selectors (sorted[0 .. 64): a chunk's marks)
 };
 
 struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
@@ -93,6 +88,9 @@ struct Stats {                            // host builds only (tuning): how much
 
 PW_FN uint64_t ld64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
 PW_FN void st64(uint8_t *p, uint64_t w) { __builtin_memcpy(p, &w, 8); }
+struct V16 { uint64_t a, b; };
+PW_FN V16 ld128(const uint8_t *p) { V16 w; __builtin_memcpy(&w, p, 16); return w; }
+PW_FN void st128(uint8_t *p, V16 w) { __builtin_memcpy(p, &w, 16); }
 PW_FN uint32_t bitrev32(uint32_t x)
 {
 #if defined(__clang__)
@@ -390,93 +388,42 @@ PW_FN void store_bytes(uint8_t *p, uint64_t v, uint32_t n)
     else p[0] = (uint8_t)v;
 }
 
-// out[dst .. dst+len) = the LZ77 copy from `dist` back.  Every source byte below dst exists already.  Written so that a
-// match costs ONE memory round trip, not one per chunk: loads of a group are issued before its stores (the hardware
-// keeps a wave's accesses in order, the dependency is only through registers), a tail is an overlapping 8-byte store
-// that ends exactly at dst+len, short periods (dist < 8) are expanded in registers, and a long overlapping match
-// (8 <= dist < len) proceeds in generations of `dist` bytes.  May READ up to 7 bytes past its source (never stores
-// them): the output buffer is padded by 8 bytes.
-PW_FN void copy_match(uint8_t *out, uint32_t dst, uint32_t dist, uint32_t len)
-{
-    uint8_t *d = out + dst;
-    const uint8_t *s = d - dist;
-    if (dist < 8) {
-        // period < 8: the first 8 bytes of the periodic sequence, then each next chunk's phase moves on by 8 mod dist
-        const uint64_t raw = ld64(s);
-        uint64_t pat = 0;
-        uint32_t ph = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { pat |= ((raw >> (8 * ph)) & 0xff) << (8 * k); ph = ph + 1 == dist ? 0 : ph + 1; }
-        // pat = bytes 0..7 of the sequence; byte j of the sequence = raw byte (j mod dist); rotate by (8 mod dist) per chunk
-        const uint32_t step = 8 % dist;                                   // dist 1,2,4: 0 (the same chunk again and again)
-        uint32_t i = 0, phase = 0;                                        // phase = (8 * chunk) mod dist
-        for (; i < len; i += 8) {
-            uint64_t v = pat;
-            if (phase) {                                                  // sequence bytes phase .. phase+7
-                v = 0; uint32_t q = phase;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { v |= ((raw >> (8 * q)) & 0xff) << (8 * k); q = q + 1 == dist ? 0 : q + 1; }
-            }
-            store_bytes(d + i, v, len - i);
-            phase += step; if (phase >= dist) phase -= dist;
-        }
-        return;
-    }
-    // generations: [0, g) reads only bytes that existed before this match; each next generation reads the previous one
-    uint32_t done = 0;
-    while (done < len) {
-        const uint32_t g = len - done < dist ? len - done : dist;         // bytes of this generation (>= 1)
-        const uint8_t *sg = s + done;
-        uint8_t *dg = d + done;
-        if (g < 8) {                                                      // (only as the tail of an overlapping match or len < 8)
-            store_bytes(dg, ld64(sg), g);
-        } else {
-            uint32_t i = 0;
-            for (; i + 32 <= g; i += 32) {                                // four loads in flight, then four stores
-                const uint64_t a = ld64(sg + i), b = ld64(sg + i + 8), c = ld64(sg + i + 16), e = ld64(sg + i + 24);
-                st64(dg + i, a); st64(dg + i + 8, b); st64(dg + i + 16, c); st64(dg + i + 24, e);
-            }
-            const uint32_t r = g - i;                                     // 0..31 left: up to three chunks + an overlapping last one
-            if (r) {
-                const uint64_t a = ld64(sg + i), b = r > 8 ? ld64(sg + i + 8) : 0, c = r > 16 ? ld64(sg + i + 16) : 0;
-                const uint64_t t = ld64(sg + g - 8);                      // the last 8 bytes of the generation (g >= 8)
-                if (r >= 8) st64(dg + i, a);
-                if (r >= 16) st64(dg + i + 8, b);
-                if (r >= 24) st64(dg + i + 16, c);
-                st64(dg + g - 8, t);
-            }
-        }
-        done += g;
-    }
-}
-
-// off mod d for 0 <= off < 2^16, 1 <= d < 2^16, without an integer division (a float quotient, corrected by one step either way)
+// off mod d for 0 <= off < 2^16, 1 <= d < 2^16, without an integer division: a float quotient from the reciprocal (the one-instruction
+// approximation on the GPU — a full-precision 1/d is a dozen instructions), corrected by one step either way
 PW_FN uint32_t small_mod(uint32_t off, uint32_t d)
 {
-    const uint32_t q = (uint32_t)((float)off * (1.0f / (float)d));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf((float)d);
+#else
+    const float r = 1.0f / (float)d;
+#endif
+    const uint32_t q = (uint32_t)((float)off * r);
     int32_t o = (int32_t)(off - q * d);
     if (o < 0) o += (int32_t)d;
     if ((uint32_t)o >= d) o -= (int32_t)d;
     return (uint32_t)o;
 }
 
-// 8 bytes of an OVERLAPPING match (dist < len) starting `off` bytes into it: byte j of such a match is s[j mod dist], where
-// s[0 .. dist) — the `dist` bytes in front of the match — exist before the match is copied.  Reads only those bytes (and up to 7 behind).
-PW_FN uint64_t periodic8(const uint8_t *s, uint32_t dist, uint32_t off)
+// The bytes of `raw` picked by the eight 3-bit indices in the bytes of `sel` (byte k of the result = byte sel_k of raw)
+PW_FN uint64_t gather8(uint64_t raw, uint64_t sel)
 {
-    const uint32_t o = small_mod(off, dist);
-    if (dist >= 8) {
-        const uint64_t a = ld64(s + o);
-        if (o + 8 <= dist) return a;
-        const uint32_t k1 = dist - o;                                     // 1 .. 7 bytes to the end of the period, the rest from its start
-        return (a & ((1ull << (8 * k1)) - 1ull)) | (ld64(s) << (8 * k1));
-    }
-    const uint64_t raw = ld64(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
+    return ((uint64_t)__builtin_amdgcn_perm(hi, lo, (uint32_t)(sel >> 32)) << 32) | __builtin_amdgcn_perm(hi, lo, (uint32_t)sel);
+#else
     uint64_t v = 0;
-    uint32_t q = o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v |= ((raw >> (8 * q)) & 0xff) << (8 * k); q = q + 1 == dist ? 0 : q + 1; }
+    for (int k = 0; k < 8; ++k) v |= ((raw >> (8 * ((sel >> (8 * k)) & 7))) & 0xff) << (8 * k);
     return v;
+#endif
+}
+// Selectors of the short periods: psel[(d - 1) * 8 + o], d = 1 .. 7, o = 0 .. d - 1: byte k = (o + k) mod d — the eight bytes of a
+// sequence of period d from its o-th byte on, as indices into the period.  56 words of LDS, filled once per superstep.
+PW_FN uint64_t period_selector(uint32_t d, uint32_t o)
+{
+    uint64_t sel = 0;
+    uint32_t q = o;
+    for (int k = 0; k < 8; ++k) { sel |= (uint64_t)q << (8 * k); q = q + 1 == d ? 0 : q + 1; }
+    return sel;
 }
 
 // A match waiting to be copied: out[dst .. dst+len) = out[dst-dist ..] (positions inside the member's output).
@@ -587,70 +534,125 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         if (W::ballot_ne(err, 0u)) return -6;
         W::fence();
         PW_TICK(3);
-        // ---- phase 3: the matches, 64 CONSECUTIVE ones at a time, one per lane.  Neighbouring matches rarely depend
-        // on each other (they copy from about a record back), so a batch takes one or two rounds: a lane copies once the
-        // earlier matches of the batch that overlap its source are done (the exact set, as a lane mask); everything before
-        // the batch — literals of phase 2, earlier batches — is final.  The lowest unfinished lane is always ready.
+        // ---- phase 3: the matches, up to 64 CONSECUTIVE ones at a time, one per lane.  Neighbouring matches depend on each other (a
+        // record repeats the record before it, and a batch spans about four records), so a batch takes three to four rounds: a lane
+        // copies once the earlier matches of the batch that overlap its source are done (the exact set, as a lane mask); everything
+        // before the batch — literals of phase 2, earlier batches — is final.  The lowest unfinished lane is always ready.
+        //
+        // The rounds run in LDS.  Through the output in global memory every round read what the round before it had just stored, and on
+        // this hardware a load's data cannot be waited for without waiting for the stores issued before it as well: a round trip to L2 per
+        // 64 pieces, 185 rounds per member, 40 % of the kernel (profiles/r05_inflate_ticks.txt).  The code tables are free once the block's
+        // LAST superstep has emitted its tokens (the usual case: a superstep covers the rest of the payload), so their 5.4 KB hold a
+        // WINDOW of the output: out[wbase, wend) is loaded (the literals are in it; the matches' bytes are not yet), the batches whose
+        // matches end inside it are resolved there — sources below wbase are final in the output and read from there — and when the
+        // next batch reaches past wend the stretch the batches covered is stored to the output and the window starts again at that
+        // batch: about four batches per window, so the wait for the stores and the load is paid once per four batches.
+        // In a superstep that is not the block's last there is no window and everything goes through the output.
+        uint8_t *const win = reinterpret_cast<uint8_t *>(T.ll);
+        enum { WIN_CAP = (int)(sizeof(T.ll) + sizeof(T.d)) - 8 };            // (8-byte accesses may reach 7 bytes past what they need)
+        const bool use_win = kend < 64;
+        const uint32_t sup_end = o + total;                                 // the output of this superstep ends here; its literals are all written
+        uint32_t wbase = 0xFFFFFFFFu, wend = 0, wb_lo = 0, whi = 0;         // window out[wbase, wend); [wb_lo, whi): resolved there, not yet in the output
+        // 8 bytes of the output from `pos` on, of which the caller needs only bytes that are final
+        auto fetch8 = [&](uint32_t pos) -> uint64_t {
+            if (pos >= wbase) return ld64(win + (pos - wbase));
+            if (pos + 8 <= wbase) return ld64(out + pos);
+            const uint32_t k8 = 8 * (wbase - pos);                           // 1 .. 7 bytes from below the window, the rest from its start
+            return (ld64(out + pos) & ((1ull << k8) - 1ull)) | (ld64(win) << k8);
+        };
+        // (both ways 16 bytes per lane and three steps in flight: a step at a time, every step waited for the one before — eleven
+        // round trips to fill a window)
+        auto write_back = [&]() {                                           // out[wb_lo, whi) = the window's bytes, exactly; wb_lo == wbase
+            if (whi <= wb_lo) return;
+            const uint32_t n_wb = whi - wb_lo;
+            uint8_t *const to = out + wb_lo;
+            W::each([&](int l) {
+                for (uint32_t g = 16u * (uint32_t)l; g < n_wb; g += 3072) {
+                    V16 v[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v[k] = ld128(win + (g + 1024u * k < (uint32_t)WIN_CAP ? g + 1024u * k : 0u));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t i = g + 1024u * k;
+                        if (i + 16 <= n_wb) st128(to + i, v[k]);
+                        else if (i + 8 <= n_wb) { st64(to + i, v[k].a); if (i + 8 < n_wb) store_bytes(to + i + 8, v[k].b, n_wb - i - 8); }
+                        else if (i < n_wb) store_bytes(to + i, v[k].a, n_wb - i);
+                    }
+                }
+            });
+            wb_lo = whi;
+        };
+        auto fill_window = [&]() {                                          // win[0, wend - wbase) = out[wbase, wend)
+            const uint32_t n_new = wend - wbase;
+            const uint8_t *const from = out + wbase;
+            W::each([&](int l) {
+                for (uint32_t g = 16u * (uint32_t)l; g < n_new; g += 3072) {
+                    V16 v[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t i = g + 1024u * k;
+                        v[k].a = v[k].b = 0;
+                        if (i + 8 < n_new) v[k] = ld128(from + i);         // (reads at most 7 bytes past the superstep's output: the buffer is padded by 8)
+                        else if (i < n_new) v[k].a = ld64(from + i);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const uint32_t i = g + 1024u * k; if (i < n_new) st128(win + i, v[k]); }
+                }
+            });
+        };
+        W::each([&](int l) { if (l < 56) T.psel()[l] = period_selector((uint32_t)(l >> 3) + 1, (uint32_t)(l & 7)); });
         U nx_dst, nx_ld;                                                  // the next batch's tokens are fetched a batch ahead
         W::each([&](int l) { nx_dst[l] = nx_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
-        for (uint32_t b0 = 0; b0 < n_tok; b0 += 64) {
+        for (uint32_t b0 = 0; b0 < n_tok;) {
             PW_MARK(50, b0);
             U dst, len, dist, dep_lo, dep_hi, valid;
             W::each([&](int l) {
                 const uint32_t i = b0 + (uint32_t)l;
                 valid[l] = i < n_tok;
                 dst[l] = valid[l] ? nx_dst[l] : 0u; len[l] = valid[l] ? nx_ld[l] & 0xffff : 0u; dist[l] = valid[l] ? nx_ld[l] >> 16 : 0u;
-                if (i + 64 < n_tok) { const Token k = tok[i + 64]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; }
+            });
+            const uint32_t d0 = W::bcast_u(dst, 0);
+            uint32_t take = n_tok - b0 < 64u ? n_tok - b0 : 64u;            // matches of this batch
+            if (use_win) {
+                U end;
+                W::each([&](int l) { end[l] = dst[l] + len[l]; });
+                uint32_t e = W::bcast_u(end, take - 1);
+                if (wbase == 0xFFFFFFFFu || e > wend) {                     // the batch reaches past the window: move it here
+                    W::sync();
+                    write_back();
+                    wbase = wb_lo = d0;
+                    wend = sup_end - d0 > (uint32_t)WIN_CAP ? d0 + (uint32_t)WIN_CAP : sup_end;
+                    fill_window();
+                    if (e > wend) {                                         // long matches: the first `take` of them fit (one always does)
+                        U fits;
+                        W::each([&](int l) { fits[l] = valid[l] && end[l] <= wend; });
+                        take = (uint32_t)__builtin_ctzll(~W::ballot_ne(fits, 0u));
+                        W::each([&](int l) { if ((uint32_t)l >= take) valid[l] = 0; });
+                        e = W::bcast_u(end, take - 1);
+                    }
+                }
+                whi = e;
+            }
+            W::each([&](int l) {
                 T.bdst()[l] = valid[l] ? dst[l] : 0xFFFFFFFFu;
                 T.bend()[l] = valid[l] ? dst[l] + len[l] : 0xFFFFFFFFu;
             });
+            // (the next batch's tokens; a batch cut short leaves them to be fetched when it is done)
+            if (take == 64) W::each([&](int l) { const uint32_t i = b0 + 64u + (uint32_t)l; if (i < n_tok) { const Token k = tok[i]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
             W::sync();
-            const uint32_t d0 = W::bcast_u(dst, 0);
-            // srcp / per: where a match's bytes come from and with what period (dst - dist and dist, unless the source is redirected below)
-            U srcp, per;
-            W::each([&](int l) { srcp[l] = dst[l] - dist[l]; per[l] = dist[l]; });
-            auto find_deps = [&]() {
-                W::each([&](int l) {
-                    dep_lo[l] = 1; dep_hi[l] = 0;                              // empty
-                    if (!valid[l] || l == 0) return;
-                    const uint32_t src = srcp[l];
-                    const uint32_t send = src + (len[l] < per[l] ? len[l] : per[l]);
-                    if (send <= d0) return;                                   // the source ends before the batch's first match
-                    int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
-                    const int i_lo = lo;
-                    lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
-                    dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
-                });
-            };
-            find_deps();
-#if PD_REDIRECT_JUMPS > 0
-            // (an experiment kept behind a switch, profiles/r03_inflate_span_experiment.txt: a source that lies INSIDE one earlier plain copy of
-            // the batch reads where that match reads — 3.8 -> 2.85 rounds per batch with one jump — at the price of a second dependency search)
-            for (int jump = 0; jump < PD_REDIRECT_JUMPS; ++jump) {
-                U from, can;
-                W::each([&](int l) {
-                    from[l] = 0; can[l] = 0;
-                    if (!valid[l] || dep_lo[l] + 1u != dep_hi[l]) return;
-                    const uint32_t a = dep_lo[l], src = srcp[l], send = src + (len[l] < per[l] ? len[l] : per[l]);
-                    if (src >= T.bdst()[a] && send <= T.bend()[a]) { from[l] = a; can[l] = 1; }
-                });
-                if (!W::ballot_ne(can, 0u)) break;
-                const U a_src = W::shfl(srcp, from), a_per = W::shfl(per, from);
-                U moved;
-                W::each([&](int l) {
-                    moved[l] = 0;
-                    if (!can[l]) return;
-                    const uint32_t a = from[l], a_len = T.bend()[a] - T.bdst()[a];
-                    if (a_per[l] < a_len) return;                             // (a self-overlapping match: its bytes are not its source's)
-                    srcp[l] = a_src[l] + (srcp[l] - T.bdst()[a]);
-                    moved[l] = 1;
-                });
-                if (!W::ballot_ne(moved, 0u)) break;
-                find_deps();
-            }
-#endif
+            W::each([&](int l) {
+                dep_lo[l] = 1; dep_hi[l] = 0;                              // empty
+                if (!valid[l] || l == 0) return;
+                const uint32_t src = dst[l] - dist[l];
+                const uint32_t send = src + (len[l] < dist[l] ? len[l] : dist[l]);
+                if (send <= d0) return;                                   // the source ends before the batch's first match
+                int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
+                const int i_lo = lo;
+                lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
+                dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
+            });
             PW_TICK(8);
             // The ready matches of a round are copied in 8-byte PIECES dealt out over the whole wave — piece p of the round belongs to the
             // match whose first piece is the last one at or before p — so a round costs its bytes / 512 trips of one uniform step, not the
@@ -658,7 +660,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
             // way; dealt out, a member's 8 900 pieces are 140 trips + one per round).  A piece is a full 8-byte load and store (the last
             // piece of a match overlaps the one before it so that it ends where the match ends; matches shorter than 8 bytes are one
             // byte-exact piece); a piece of a self-overlapping match (dist < len) takes its bytes from the period in front of the match.
-            const U packB = [&] { U x; W::each([&](int l) { x[l] = len[l] | (per[l] << 16); }); return x; }();
+            const U packB = [&] { U x; W::each([&](int l) { x[l] = len[l] | (dist[l] << 16); }); return x; }();
             uint16_t *const own = T.sorted;                               // (free since the tables were built) 64 entries: a chunk's piece -> match marks
             uint64_t done = W::ballot_eq(valid, 0u);
             for (int round = 0; done != ~0ull; ++round) {
@@ -670,7 +672,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     uint64_t dm = 0;
                     if (dep_lo[l] < dep_hi[l]) dm = (dep_hi[l] >= 64 ? ~0ull : ((1ull << dep_hi[l]) - 1)) & ~((1ull << dep_lo[l]) - 1);
                     if (dm & ~done) return;
-                    ready[l] = 1; np[l] = (len[l] + (PD_PIECE_BYTES - 1)) / PD_PIECE_BYTES;
+                    ready[l] = 1; np[l] = (len[l] + 7) >> 3;
                     if (st) st->copy_iters += (len[l] + 31) / 32;
                 });
                 uint32_t P = 0;
@@ -692,42 +694,25 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     U src_lane;
                     W::each([&](int l) { src_lane[l] = id[l] ? id[l] - 1 : 0u; });
                     const U a = W::shfl(packA, src_lane), b = W::shfl(packB, src_lane);
-#if PD_REDIRECT_JUMPS > 0
-                    const U sp = W::shfl(srcp, src_lane);
-#endif
                     W::each([&](int l) {
                         const uint32_t p = c0 + (uint32_t)l;
                         if (p >= P) return;
                         const uint32_t dstm = a[l] & 0xffff, lenm = b[l] & 0xffff, distm = b[l] >> 16;
-#if PD_REDIRECT_JUMPS > 0
-                        const uint8_t *s = out + sp[l];                    // (distm is then the PERIOD of the match's bytes, not where they are)
-#else
-                        const uint8_t *s = out + dstm - distm;
-#endif
-#if PD_PIECE_BYTES == 16
-                        // a piece = two 8-byte halves at lo and hi: 16 consecutive bytes of a long match (the last piece moved back so that it
-                        // ends where the match ends), the first and the last 8 bytes of a match of 8 .. 15, one byte-exact store below that
-                        uint32_t off = (p - (a[l] >> 16)) * 16;
-                        if (lenm >= 16 && off > lenm - 16) off = lenm - 16;
-                        const uint32_t lo = lenm >= 16 ? off : 0u, hi = lenm >= 16 ? off + 8 : lenm >= 8 ? lenm - 8 : 0u;
-                        uint64_t v0, v1;
-                        if (distm >= lenm) { v0 = ld64(s + lo); v1 = ld64(s + hi); }
-                        else { v0 = periodic8(s, distm, lo); v1 = periodic8(s, distm, hi); }
-                        if (lenm >= 8) { st64(out + dstm + lo, v0); st64(out + dstm + hi, v1); } else store_bytes(out + dstm, v0, lenm);
-#else
                         uint32_t off = (p - (a[l] >> 16)) * 8;
                         if (lenm >= 8 && off > lenm - 8) off = lenm - 8;
-#ifdef PD_X_ALIGN_LD      /* timing experiment only (wrong bytes): what the misalignment of the loads costs */
-                        const uint64_t v = distm >= lenm ? ld64((const uint8_t *)((uintptr_t)(s + off) & ~(uintptr_t)7)) : periodic8(s, distm, off);
-#else
-                        const uint64_t v = distm >= lenm ? ld64(s + off) : periodic8(s, distm, off);
-#endif
-#ifdef PD_X_ALIGN_ST      /* timing experiment only (wrong bytes): what the misalignment of the stores costs */
-                        if (lenm >= 8) st64((uint8_t *)((uintptr_t)(out + dstm + off) & ~(uintptr_t)7), v); else store_bytes(out + dstm, v, lenm);
-#else
-                        if (lenm >= 8) st64(out + dstm + off, v); else store_bytes(out + dstm, v, lenm);
-#endif
-#endif
+                        const uint32_t sp = dstm - distm;                  // where the match's bytes (its period, if it overlaps itself) begin
+                        uint64_t v;
+                        if (distm >= lenm) v = fetch8(sp + off);
+                        else {
+                            // byte j of a self-overlapping match is byte (j mod dist) of the `dist` bytes in front of it
+                            const uint32_t om = small_mod(off, distm);
+                            if (distm >= 8) {
+                                v = fetch8(sp + om);
+                                if (om + 8 > distm) { const uint32_t k1 = distm - om; v = (v & ((1ull << (8 * k1)) - 1ull)) | (fetch8(sp) << (8 * k1)); }
+                            } else v = gather8(fetch8(sp), T.psel()[(distm - 1) * 8 + om]);
+                        }
+                        if (use_win) { if (lenm >= 8) st64(win + (dstm - wbase) + off, v); else store_bytes(win + (dstm - wbase), v, lenm); }
+                        else { if (lenm >= 8) st64(out + dstm + off, v); else store_bytes(out + dstm, v, lenm); }
                     });
                     if (st) st->copy_serial += 1;
                     W::sync();
@@ -740,8 +725,12 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 if (st) st->emit_rounds++;
             }
             if (st) st->batches++;
+            b0 += take;
+            if (take != 64 && b0 < n_tok)
+                W::each([&](int l) { const uint32_t i = b0 + (uint32_t)l; if (i < n_tok) { const Token k = tok[i]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
             W::sync();
         }
+        if (use_win) { W::sync(); write_back(); W::sync(); }
         PW_TICK(4);
         o += total;
         if (kend < 64) { q_io = W::bcast(e, (int)kend); o_io = o; return 0; }
@@ -1065,7 +1054,10 @@ struct HostWave {                         // 64 emulated lanes
 struct DevWave {                          // the hardware wavefront (one wave per workgroup)
     template <class T> struct Var { T v; __device__ T &operator[](int) { return v; } __device__ const T &operator[](int) const { return v; } };
     template <class F> __device__ static __forceinline__ void each(F f) { f((int)(threadIdx.x & 63)); }
-    __device__ static __forceinline__ void sync() { __syncthreads(); }
+    // One wave IS the workgroup: its LDS (and global) accesses execute in program order, so what one lane wrote another lane's later
+    // read sees — nothing to wait for, the compiler only must not move accesses across (__syncthreads() also waits for every global
+    // store the wave has in flight)
+    __device__ static __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
     __device__ static __forceinline__ void fence() { asm volatile("" ::: "memory"); }   // compiler-only: the wave issues in order
     __device__ static __forceinline__ uint64_t ballot_eq(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v == v); }
     __device__ static __forceinline__ uint64_t ballot_ne(const Var<uint32_t> &x, uint32_t v) { return __ballot(x.v != v); }
