@@ -262,7 +262,10 @@ struct Sym { uint32_t kind, val, dist, used; };
 // moves on only every 64 bits (several symbols), so no symbol waits for memory.  Reads stay below in + lim.
 struct BitWin { uint64_t cur, nxt, ahead; uint32_t base; };
 
-PW_FN uint64_t win_load(const uint8_t *in, uint32_t at, uint32_t lim) { return at + 8 <= lim ? ld64(in + at) : 0ull; }
+// (a load from a clamped address, not a predicated one: bits at and beyond lim are never a symbol that counts — the passes stop at their
+// bounds — and an unconditional load can land in the window's own register, where nothing waits for it until the window moves again;
+// the predicated form went through a temporary whose copy waited for the load the moment it was issued, in every trip of phases 1 and 2)
+PW_FN uint64_t win_load(const uint8_t *in, uint32_t at, uint32_t lim) { return ld64(in + (at + 8 <= lim ? at : lim - 8)); }
 PW_FN void win_init(BitWin &b, const uint8_t *in, uint32_t q, uint32_t lim)
 {
     b.base = q >> 3;
@@ -274,6 +277,9 @@ PW_FN uint64_t win_bits(BitWin &b, const uint8_t *in, uint32_t q, uint32_t lim)
     uint32_t off = q - 8 * b.base;
     if (off >= 64) {                                                      // moved past `cur` (a symbol is <= 48 bits: at most once)
         b.cur = b.nxt; b.nxt = b.ahead; b.base += 8; off -= 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);                                 // (the load is issued AFTER the two copies, into the register they freed)
+#endif
         b.ahead = win_load(in, b.base + 16, lim);
     }
     return off ? (b.cur >> off) | (b.nxt << (64 - off)) : b.cur;
@@ -600,7 +606,8 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 }
             });
         };
-        W::each([&](int l) { if (l < 56) T.psel()[l] = period_selector((uint32_t)(l >> 3) + 1, (uint32_t)(l & 7)); });
+        W::each([&](int l) { if (l < 56) T.psel()[l] = period_selector((uint32_t)(l >> 3) + 1, (uint32_t)(l & 7)); T.sorted[l] = 0; });
+        uint32_t gen = 0;                                                   // chunks of this superstep so far (mod 1024): the tag of own[]'s marks
         U nx_dst, nx_ld;                                                  // the next batch's tokens are fetched a batch ahead
         W::each([&](int l) { nx_dst[l] = nx_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
         for (uint32_t b0 = 0; b0 < n_tok;) {
@@ -646,12 +653,17 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 const uint32_t src = dst[l] - dist[l];
                 const uint32_t send = src + (len[l] < dist[l] ? len[l] : dist[l]);
                 if (send <= d0) return;                                   // the source ends before the batch's first match
-                int lo = 0, hi = l;                                       // first i in [0, l) with bend[i] > src (l if none)
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bend()[mid] > src) hi = mid; else lo = mid + 1; }
-                const int i_lo = lo;
-                lo = 0; hi = l;                                           // number of i in [0, l) with bdst[i] < send
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.bdst()[mid] < send) lo = mid + 1; else hi = mid; }
-                dep_lo[l] = (uint32_t)i_lo; dep_hi[l] = (uint32_t)lo;     // matches [i_lo, lo) overlap the source
+                // two binary searches over [0, l), side by side (their LDS reads do not wait for each other), six halvings for l < 64:
+                // lo1 = the first i with bend[i] > src (l if none), lo2 = the number of i with bdst[i] < send
+                int lo1 = 0, hi1 = l, lo2 = 0, hi2 = l;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                    const uint32_t e1 = T.bend()[m1], d2 = T.bdst()[m2];
+                    if (lo1 < hi1) { if (e1 > src) hi1 = m1; else lo1 = m1 + 1; }
+                    if (lo2 < hi2) { if (d2 < send) lo2 = m2 + 1; else hi2 = m2; }
+                }
+                dep_lo[l] = (uint32_t)lo1; dep_hi[l] = (uint32_t)lo2;     // matches [lo1, lo2) overlap the source
             });
             PW_TICK(8);
             // The ready matches of a round are copied in 8-byte PIECES dealt out over the whole wave — piece p of the round belongs to the
@@ -682,12 +694,12 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 PW_TICK(9);
                 uint32_t carry = 0;                                       // (1 + match) of the piece in front of the chunk
                 for (uint32_t c0 = 0; c0 < P; c0 += 64) {
-                    W::each([&](int l) { own[l] = 0; });
-                    W::sync();
-                    W::each([&](int l) { if (ready[l] && ps[l] - c0 < 64u) own[ps[l] - c0] = (uint16_t)(l + 1); });
+                    // (a mark carries the number of its chunk, so that the marks of earlier chunks need not be cleared: one LDS trip less)
+                    if (++gen == 1024u) { W::each([&](int l) { own[l] = 0; }); W::sync(); gen = 1; }
+                    W::each([&](int l) { if (ready[l] && ps[l] - c0 < 64u) own[ps[l] - c0] = (uint16_t)((gen << 6) | (uint32_t)l); });
                     W::sync();
                     U id;
-                    W::each([&](int l) { id[l] = own[l]; });
+                    W::each([&](int l) { const uint32_t m = own[l]; id[l] = (m >> 6) == gen ? (m & 63u) + 1u : 0u; });
                     id = W::incl_scan_max(id);
                     W::each([&](int l) { if (id[l] < carry) id[l] = carry; });
                     carry = W::bcast_u(id, 63);
