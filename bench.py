@@ -207,7 +207,7 @@ def e2e_annotation(td, bam, cli, ref, threads, records):
 
 
 PCIE_PEAK_GBS = 64.0           # PCIe Gen5 x16, one direction, raw (MI355X_MICROARCH.md: host link); ~55 GB/s is what a pinned H2D copy reaches
-INFLATE_ISOLATED_GBS = 242.0      # k_inflate_wave on 61 220 members in one launch (profiles/r04_inflate_ab.txt)
+INFLATE_ISOLATED_GBS = 285.0      # k_inflate_wave on 102 037 members in one launch, 20 waves per CU: 277-293 (profiles/r05_inflate_ab.txt; round 4: 242)
 
 
 def e2e_site_windows(td, gen, cli, ref, threads, records=20000000):
@@ -407,7 +407,7 @@ def e2e_leg(records, site_records, fullsize_site=False):
                 "inflate_kernel_busy_s_summed_over_streams": round(dec["device_ms_summed"]["inflate"] / 1e3, 3),
                 "inflate_kernel_GBps_in_situ": round(dec["inflated_bytes"] / (dec["device_ms_summed"]["inflate"] / 1e3) / 1e9, 1) if dec["device_ms_summed"]["inflate"] else None,
                 # the decode phase against ITS dominant kernel's own ceiling: k_inflate_wave alone, on launches that keep the CUs full, inflates
-                # 242 GB/s (profiles/r04_inflate_ab.txt; its instruction count at 20 waves per CU puts the ceiling at 225-258 GB/s)
+                # 285 GB/s (profiles/r05_inflate_ab.txt: 277-293 on one box)
                 "inflate_kernel_isolated_GBps": INFLATE_ISOLATED_GBS,
                 "frac": round(dec["inflated_bytes"] / t_dec / 1e9 / INFLATE_ISOLATED_GBS, 3),
                 "frac_is": "inflated bytes / decode-phase seconds / the inflate kernel's isolated rate: 1.0 = the phase runs as fast as that kernel alone could",
