@@ -39,7 +39,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_inflate_blocks(const uin
 // (members of a BAM are alike, so a static split balances); Huffman tables in LDS (9 KiB per wave), match tokens in a
 // per-workgroup slice of global scratch.
 #ifndef PD_INFLATE_MIN_WAVES
-#define PD_INFLATE_MIN_WAVES 6            /* waves per SIMD the register allocation leaves room for (80 VGPRs; at 8 — 64 VGPRs — the kernel spills and loses a quarter) */
+#define PD_INFLATE_MIN_WAVES 5            /* waves per SIMD the register allocation leaves room for: 96 VGPRs, no scratch.  The launcher puts 20 waves on a CU (5 per
+                                             SIMD; the kernel's LDS would allow 22), so the 80-VGPR cap of "6" bought nothing and cost 112 B of spills: 294 -> 298 GB/s
+                                             (profiles/r05_inflate_ticks.txt, r5c28); at 8 — 64 VGPRs — the kernel loses a quarter */
 #endif
 __global__ __launch_bounds__(64, PD_INFLATE_MIN_WAVES) void k_inflate_wave(const uint8_t *comp, const BlkDesc *blk, uint32_t n_blk, uint8_t *out, int *status,
                                                                            pdw::Token *tok_scratch, int check_crc, uint32_t *next)

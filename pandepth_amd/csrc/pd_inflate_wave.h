@@ -77,7 +77,8 @@ struct alignas(16) Tables {
     PW_FN uint16_t *rank() { return reinterpret_cast<uint16_t *>(work); }
     PW_FN uint32_t *bdst() { return work; }
     PW_FN uint32_t *bend() { return work + 64; }
-    PW_FN uint64_t *psel() { return reinterpret_cast<uint64_t *>(sorted + 64); }   // phase 3: 56 selectors (sorted[0 .. 64): a chunk's marks)
+    PW_FN uint64_t *psel() { return reinterpret_cast<uint64_t *>(sorted + 64); }
+    PW_FN uint32_t *ckpt() { return reinterpret_cast<uint32_t *>(sorted); }       // phase 1: 2 checkpoints x 3 fields x 64 lanes over sorted | work | cl   // phase 3: 56 selectors (sorted[0 .. 64): a chunk's marks)
 };
 
 struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
@@ -313,15 +314,19 @@ PW_FN Sym decode_sym(const Tables &T, uint64_t w)
 // Phase 1 state of one lane.  The speculative pass over a subsequence runs from bit p until the first symbol boundary
 // at or after `bound` (or a stop: end of block, invalid code, end of input); nothing is written: e = where it ended,
 // n = bytes it would emit, m = matches among its symbols.
-// Three checkpoints (S/8, S/4, S/2 bits into the subsequence) remember where the previous pass of this lane crossed
+// Two checkpoints (S/8 and S/2 bits into the subsequence) remember where the previous pass of this lane crossed
 // them: a re-decode from a corrected start that crosses a checkpoint at the SAME bit has merged with the previous
-// pass (from a common symbol boundary on, two passes are identical), so it stops there and keeps the old tail.
+// pass (from a common symbol boundary on, two passes are identical), so it stops there and keeps the old tail.  A corrected start lies a
+// few bits behind the old one and the codes re-synchronise within a few symbols, so the first checkpoint catches nearly every merge.
+// The checkpoints live in LDS (Tables::ckpt(): the table builder's scratch, idle while a block is decoded), a column per lane:
+// word (k * 3 + f) * 64 of a lane's column = field f (0 position, 1 bytes, 2 matches) of checkpoint k.  (Until round 5 there were three
+// checkpoints in nine registers, chosen by chains of selects: most of the vector instructions of a symbol step, and the reason the kernel spilled.)
 struct SubCount {
     uint32_t e, n, m, f, ns;                     // results of the last complete pass
-    uint32_t cp0, cp1, cp2, co0, co1, co2, cm0, cm1, cm2;
     uint32_t q, out, nm, stage, next_t;          // the pass in progress
     BitWin win;
 };
+enum { CK_STRIDE = 3 * 64, CK_NONE = 0xFFFFFFFFu };
 
 PW_FN void count_begin(SubCount &c, const uint8_t *in, uint32_t in_lim, uint32_t p, uint32_t nominal, uint32_t S)
 {
@@ -330,35 +335,27 @@ PW_FN void count_begin(SubCount &c, const uint8_t *in, uint32_t in_lim, uint32_t
 }
 
 // one symbol of the pass in progress; returns false when the pass is over
-// (lim = min(bound, in_bits): a pass that stops at lim before reaching its bound ran out of input)
+// (lim = min(bound, in_bits): a pass that stops at lim before reaching its bound ran out of input; ck = the lane's checkpoint column)
 PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint32_t nominal, uint32_t S, uint32_t bound, uint32_t lim, bool have_prev,
-                      SubCount &c)
+                      SubCount &c, uint32_t *ck)
 {
     uint32_t flag = 0;
     const uint32_t q = c.q;
     bool stop = q >= lim;
     if (stop && q < bound) flag = F_OVERRUN;
-    if (!stop && q >= c.next_t) {                                         // crossing a checkpoint (3 times per pass)
-        // (every field is read into a value first: selecting between the fields' ADDRESSES would pin the state in memory)
-        const uint32_t st = c.stage, cp0 = c.cp0, cp1 = c.cp1, cp2 = c.cp2, co0 = c.co0, co1 = c.co1, co2 = c.co2, cm0 = c.cm0, cm1 = c.cm1,
-                       cm2 = c.cm2, out = c.out, nm = c.nm;
-        const bool s0 = st == 0, s1 = st == 1;
-        const uint32_t old_p = s0 ? cp0 : s1 ? cp1 : cp2;
-        if (have_prev && old_p == q) {
-            // same tail as before; the counts remembered beyond this point were relative to the old start
-            const uint32_t d_o = out - (s0 ? co0 : s1 ? co1 : co2);
-            const uint32_t d_m = nm - (s0 ? cm0 : s1 ? cm1 : cm2);
-            c.co0 = co0 + (s0 ? d_o : 0u); c.cm0 = cm0 + (s0 ? d_m : 0u);
-            c.co1 = co1 + (s0 || s1 ? d_o : 0u); c.cm1 = cm1 + (s0 || s1 ? d_m : 0u);
-            c.co2 = co2 + d_o; c.cm2 = cm2 + d_m;
+    if (!stop && q >= c.next_t) {                                         // crossing a checkpoint (twice per pass)
+        const uint32_t st = c.stage;                                      // 0 or 1
+        uint32_t *const e = ck + st * CK_STRIDE;
+        if (have_prev && e[0] == q) {
+            // same tail as before; the counts remembered from here on were relative to the old start
+            const uint32_t d_o = c.out - e[64], d_m = c.nm - e[128];
+            e[64] += d_o; e[128] += d_m;
+            if (st == 0) { ck[CK_STRIDE + 64] += d_o; ck[CK_STRIDE + 128] += d_m; }
             c.n += d_o; c.m += d_m;
-            return false;                                                 // e, f and the later checkpoints stay
+            return false;                                                 // e, f and the later checkpoint stay
         }
-        c.cp0 = s0 ? q : cp0; c.co0 = s0 ? out : co0; c.cm0 = s0 ? nm : cm0;
-        c.cp1 = s1 ? q : cp1; c.co1 = s1 ? out : co1; c.cm1 = s1 ? nm : cm1;
-        const bool s2 = !s0 && !s1;
-        c.cp2 = s2 ? q : cp2; c.co2 = s2 ? out : co2; c.cm2 = s2 ? nm : cm2;
-        c.next_t = s0 ? nominal + (S >> 2) : s1 ? nominal + (S >> 1) : 0xFFFFFFFFu;
+        e[0] = q; e[64] = c.out; e[128] = c.nm;
+        c.next_t = st == 0 ? nominal + (S >> 1) : 0xFFFFFFFFu;
         c.stage = st + 1;
     }
     if (!stop) {
@@ -374,9 +371,8 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint3
     if (!stop) return true;
     // the pass ran to its end: a checkpoint it did not reach must not stay behind for the next comparison
     const uint32_t st = c.stage;
-    c.cp0 = st <= 0 ? 0xFFFFFFFFu : c.cp0;
-    c.cp1 = st <= 1 ? 0xFFFFFFFFu : c.cp1;
-    c.cp2 = st <= 2 ? 0xFFFFFFFFu : c.cp2;
+    if (st <= 0) ck[0] = CK_NONE;
+    if (st <= 1) ck[CK_STRIDE] = CK_NONE;
     c.e = c.q; c.f = flag; c.n = c.out; c.m = c.nm;
     return false;
 }
@@ -459,9 +455,8 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
             need[l] = 1;
             SubCount &x = c[l];
             x.e = x.n = x.m = x.f = x.ns = 0;
-            x.cp0 = x.cp1 = x.cp2 = 0xFFFFFFFFu;
-            x.co0 = x.co1 = x.co2 = x.cm0 = x.cm1 = x.cm2 = 0;
             x.q = x.out = x.nm = x.stage = x.next_t = 0;
+            for (int k = 0; k < 6; ++k) T.ckpt()[k * 64 + l] = k % 3 ? 0u : (uint32_t)CK_NONE;
         });
         // ---- phase 1: speculate and synchronise (nothing is written) ----
         uint32_t kend = 64;
@@ -475,7 +470,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
             while (W::ballot_ne(act, 0u)) {
                 if (++trips > 2 * S + 64) return -9;
                 W::each([&](int l) {
-                    if (act[l]) act[l] = count_step(T, in, in_lim, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l]);
+                    if (act[l]) act[l] = count_step(T, in, in_lim, base + (uint32_t)l * S, S, bound[l], bound[l] < in_bits ? bound[l] : in_bits, round > 0, c[l], T.ckpt() + l);
                 });
             }
             if (round == 0) PW_TICK(7);
@@ -1024,6 +1019,8 @@ PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint3
     W::fence();
     PW_TICK(6);
     uint32_t want; __builtin_memcpy(&want, in + in_len, 4);
+    static_assert(offsetof(Tables, work) == offsetof(Tables, sorted) + sizeof(T.sorted) && offsetof(Tables, cl) == offsetof(Tables, work) + sizeof(T.work) &&
+                  sizeof(T.sorted) + sizeof(T.work) + sizeof(T.cl) >= 2 * CK_STRIDE * 4, "phase 1's checkpoints lie over sorted | work | cl");
     static_assert(sizeof(T.ll) + sizeof(T.d) >= 4096 && offsetof(Tables, d) == sizeof(T.ll), "the CRC tables take the first 4 KiB of the (now free) code tables");
     return crc32_wave<W>(out, out_len, T.ll) == want ? 0 : -20;
 }
