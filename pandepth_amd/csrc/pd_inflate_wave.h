@@ -987,14 +987,29 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 1024
         if (c < 0) return;
         const uint32_t a = c == 0 ? 0u : first + 1024u * (uint32_t)(c - 1), b = c == 0 ? first : a + 1024u;
         uint32_t r = c == 0 ? 0xFFFFFFFFu : 0u, i = a;
-        // 16 bytes per load (a byte per load made every step a cache miss: 64 lanes x 16 waves stream 1 000 different lines)
+        auto step4 = [&](uint32_t w) {
+            const uint32_t x = r ^ w;
+            r = tab[768 + (x & 0xffu)] ^ tab[512 + ((x >> 8) & 0xffu)] ^ tab[256 + ((x >> 16) & 0xffu)] ^ tab[x >> 24];
+        };
+        // 64 bytes a step, the NEXT step's bytes on their way while this one's go through the tables (a step that waited for its own 16 bytes
+        // was a round trip to memory per 16 bytes: 64 of them per lane, most of the CRC's time)
+        uint32_t cur[16], nxt[16];
+        if (i + 64 <= b) __builtin_memcpy(cur, data + i, 64);
+        for (; i + 64 <= b; i += 64) {
+            // (always a load, from a clamped address when nothing follows: a load under a condition makes the compiler wait for it at once)
+            __builtin_memcpy(nxt, data + (i + 128 <= b ? i + 64 : b - 64), 64);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);                             // (the loads stay HERE: sunk to where their data is used they are no prefetch)
+#endif
+#pragma unroll
+            for (int k = 0; k < 16; ++k) step4(cur[k]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+        }
         for (; i + 16 <= b; i += 16) {
             uint32_t w[4]; __builtin_memcpy(w, data + i, 16);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t x = r ^ w[k];
-                r = tab[768 + (x & 0xffu)] ^ tab[512 + ((x >> 8) & 0xffu)] ^ tab[256 + ((x >> 16) & 0xffu)] ^ tab[x >> 24];
-            }
+            for (int k = 0; k < 4; ++k) step4(w[k]);
         }
         for (; i < b; ++i) r = tab[(r ^ data[i]) & 0xffu] ^ (r >> 8);
         part[l] = r;
