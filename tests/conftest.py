@@ -9,6 +9,26 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# Several test modules (re)build the same harness binaries and the host library with `make` / `g++` from their fixtures.  Under pytest-xdist two
+# workers doing that at once relink a binary a third is executing ("Text file busy", "Permission denied"): right after a rebuild of the tree the
+# first run failed two tests that way and the second passed.  The builds of a session — all workers — therefore take turns on a lock file.
+import fcntl
+import subprocess
+
+_real_run = subprocess.run
+
+
+def _run_builds_in_turn(cmd, *args, **kwargs):
+    if isinstance(cmd, (list, tuple)) and cmd and os.path.basename(str(cmd[0])) in ("make", "g++", "gcc", "hipcc"):
+        with open(os.path.join(ROOT, "tests", "harness", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            return _real_run(cmd, *args, **kwargs)
+    return _real_run(cmd, *args, **kwargs)
+
+
+subprocess.run = _run_builds_in_turn
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
