@@ -1,7 +1,11 @@
-// tools/ubench/wave_debug.hip — DEVELOPMENT TOOL (not product code): runs pd_inflate_wave.h on the GPU over the
-// members of a BGZF file with host-visible progress marks and a polling watchdog, and compares with zlib.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wave_debug.hip -lz -o tools/ubench/wave_debug
-//   wave_debug file.bam [n_wg] [max_blocks] [seconds]
+// tools/ubench/wave_debug.hip — DEVELOPMENT TOOL (not product code): runs pd_inflate_wave.h on the GPU over the members of a BGZF file the way
+// k_inflate_wave does (one-wave workgroups, members handed out from a counter, every member's CRC checked), compares the first CHECK members
+// with zlib, and — unless built with -DNO_TICKS — says where a member's time goes: the decoder's PW_TICK(phase) hooks charge the shader clock
+// since the previous tick to a phase, summed per workgroup in LDS and added up once when the workgroup ends.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wave_debug.hip -lz -o tools/ubench/wave_debug      (tools/ubench/build_wave_variants.sh builds
+//   several: -DNO_TICKS, -DPD_INFLATE_MIN_WAVES=n, -DPDW_HEADER='"/path/to/an/older/pd_inflate_wave.h"' for A/B runs on one box)
+//   [CHECK=n] [MARKS=1] wave_debug file.bam [n_wg] [max_blocks] [seconds]        MARKS: host-visible progress marks + a polling watchdog (hang hunting)
+// Results of round 5: profiles/r05_inflate_ticks.txt (tools/calls/r5_call16.sh ... r5_call32.sh).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
