@@ -107,7 +107,21 @@ static int generated()
             if (mine != ref) { fprintf(stderr, "crc32_wave: length %zu fill %d: %08x, zlib %08x\n", len, rep, mine, ref); ++bad; }
             ++n;
         }
-    printf("generated: %d streams, %d failures\n", n, bad);
+    // the small pieces of phase 3: the remainder without a division, the byte gather of a short period through its selector
+    for (uint32_t d = 1; d <= 300; ++d)
+        for (uint32_t off = 0; off < 65536; off += (d < 9 ? 1 : 37)) {
+            if (pdw::small_mod(off, d) != off % d) { fprintf(stderr, "small_mod(%u, %u) = %u\n", off, d, pdw::small_mod(off, d)); ++bad; }
+            ++n;
+        }
+    for (uint32_t d = 1; d <= 7; ++d)
+        for (uint32_t o = 0; o < d; ++o) {
+            const uint64_t raw = ((uint64_t)rng() << 32) | rng();
+            uint64_t want = 0;
+            for (int k = 0; k < 8; ++k) want |= ((raw >> (8 * ((o + k) % d))) & 0xff) << (8 * k);
+            if (pdw::gather8(raw, pdw::period_selector(d, o)) != want) { fprintf(stderr, "gather8: period %u from %u\n", d, o); ++bad; }
+            ++n;
+        }
+    printf("generated: %d streams and unit checks, %d failures\n", n, bad);
     return bad;
 }
 
