@@ -104,6 +104,39 @@ def _best_wall(cmd, reps, env=None, want_stderr=False):
     return (best, err) if want_stderr else best
 
 
+def _timed_runs(cmd, warmup, steps, env=None):
+    """`warmup` untimed runs, then `steps` timed ones (process wall, exec to exit), back to back with the pause a process needs to find the
+    HBM of the one before it released.  Returns (walls, stderr texts) of the timed runs."""
+    walls, errs = [], []
+    for k in range(warmup + steps):
+        if k:
+            time.sleep(1.0)
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=3600)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError("%s: exit %d: %s" % (os.path.basename(cmd[0]), p.returncode, p.stderr.decode(errors="replace")[-600:]))
+        if k >= warmup:
+            walls.append(dt)
+            errs.append(p.stderr.decode(errors="replace"))
+    return walls, errs
+
+
+def _spread(walls, digits=4):
+    """median / min / max / mean of a list of wall times: the end-to-end legs scatter +-10 % from run to run and box to box, so a
+    single run (or the best of two) cannot show a 10 % change"""
+    w = sorted(walls)
+    n = len(w)
+    med = w[n // 2] if n % 2 else 0.5 * (w[n // 2 - 1] + w[n // 2])
+    return {"median": round(med, digits), "min": round(w[0], digits), "max": round(w[-1], digits), "mean": round(sum(w) / n, digits), "runs": n}
+
+
+def _median_run(walls):
+    """index of the run whose wall time is the (upper) median"""
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    return order[len(order) // 2]
+
+
 def parse_timing(err):
     """PANDEPTH_TIMING=1 lines of one run -> {phase: seconds} + the device-decode totals (diagnostics printed by the executable:
     host/pipeline.cpp PhaseTimer and read_bam_device)"""
@@ -207,7 +240,8 @@ def e2e_annotation(td, bam, cli, ref, threads, records):
 
 
 PCIE_PEAK_GBS = 64.0           # PCIe Gen5 x16, one direction, raw (MI355X_MICROARCH.md: host link); ~55 GB/s is what a pinned H2D copy reaches
-INFLATE_ISOLATED_GBS = 285.0      # k_inflate_wave on 102 037 members in one launch, 20 waves per CU: 277-293 (profiles/r05_inflate_ab.txt; round 4: 242)
+INFLATE_ISOLATED_GBS = 285.0      # k_inflate_wave on 102 037 members in one launch, 20 waves per CU: 277-293 (profiles/r05_inflate_ab.txt, commit 56623c4, round 5; round 4: 242).
+INFLATE_ISOLATED_SOURCE = "profiles/r05_inflate_ab.txt (round 5, commit 56623c4: 277-293 GB/s on one box); a constant, not measured in this run"
 
 
 def e2e_site_windows(td, gen, cli, ref, threads, records=20000000):
@@ -288,7 +322,45 @@ def e2e_site_windows_fullsize(td, bam, cli, threads, records):
     return out
 
 
-def e2e_multi_leg(n_bams, records):
+def e2e_variant_leg(td, gen, cli, ref, threads, what, gen_args, records, runs=3):
+    """The whole-chromosome run on a generated BAM of another SHAPE than configs[1]'s (tools/bamgen flags): `--long` — 10-20 kb reads with
+    ~2 600 CIGAR operations each, 1 % of them in the CG tag (reference: README.md:149-150, PD:440-460) — or `-Q 40` — the short reads of
+    configs[1] with unbinned qualities, about twice the compressed bytes per record.  The executable (median of `runs`) against the
+    reference binary (one run, -t <quota>), chr.stat.gz compared byte for byte; what the device decoder did with the file (batches, units
+    handed back to the host readers, the compact session's fallbacks) is read off PANDEPTH_TIMING's lines."""
+    bam = os.path.join(td, what + ".bam")
+    g = subprocess.run([gen, "-o", bam, "-n", str(int(records)), "-t", str(min(32, os.cpu_count() or 1))] + gen_args, check=True, stderr=subprocess.PIPE, timeout=3600)
+    try:
+        size = os.path.getsize(bam)
+        mine = os.path.join(td, "mine_" + what)
+        walls, errs = _timed_runs([cli, "-i", bam, "-o", mine, "-t", str(threads)], 1, runs, env=dict(os.environ, PANDEPTH_TIMING="1"))
+        sp = _spread(walls)
+        err = errs[_median_run(walls)]
+        ph, dec = parse_timing(err)
+        out = {"mode": "pandepth -i %s.bam -o out -t N (tools/bamgen %s: %s)" % (what, " ".join(gen_args), g.stderr.decode().strip().replace("bamgen: ", "")),
+               "records": int(records), "bam_bytes": size, "bam_bytes_per_record": round(size / records, 1),
+               "pandepth": {"wall_s": sp["median"], "wall_s_spread": sp, "records_per_s": records / sp["median"], "threads": threads, "phases_s": ph, "device_decode": dec,
+                            "decoder_said": [ln.strip()[:400] for ln in err.splitlines() if "device decode" in ln or "declin" in ln or "compact" in ln or "slow path" in ln][:6]}}
+        t_dec = ph.get("decode + scatter")
+        if dec and t_dec:
+            out["roofline"] = {"phase": "decode + scatter", "seconds": t_dec, "compressed_GBps": round(dec["compressed_bytes"] / t_dec / 1e9, 2),
+                               "frac_pcie": round(dec["compressed_bytes"] / t_dec / 1e9 / PCIE_PEAK_GBS, 3), "inflated_GBps": round(dec["inflated_bytes"] / t_dec / 1e9, 1),
+                               "share_of_units_handed_back": (round(dec["units_handed_back"] / max(1, dec["batches"]), 3) if dec.get("batches") else None),
+                               "records_on_host": dec.get("records_on_host")}
+        if os.access(ref, os.X_OK):
+            q = cpu_quota()
+            w_ref = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref_" + what), "-t", str(q)], 1)
+            out["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": records / w_ref, "threads": q}
+            out["byte_identical"] = open(mine + ".chr.stat.gz", "rb").read() == open(os.path.join(td, "ref_" + what + ".chr.stat.gz"), "rb").read()
+            out["speedup_vs_reference"] = round(w_ref / sp["median"], 2)
+        return out
+    finally:
+        for f in (bam, bam + ".bai"):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def e2e_multi_leg(n_bams, records, steps=3, warmup=1):
     """Multi-BAM `#.list` end to end (configs[4]'s shape): n_bams payload BAMs (tools/bamgen, seeds 42 ..), `pandepth -i s.list` — ONE
     process, one context per visible GPU, the files decoded in parallel, the per-GPU samples summed in slices over RCCL / xGMI — against
     the reference binary's list mode on the same files (it reads them one after another into one array, PD:2704-3014), chr.stat.gz
@@ -316,29 +388,36 @@ def e2e_multi_leg(n_bams, records):
         t_gen = time.perf_counter() - t0
         threads = max(4, min(16 * n_bams, quota, 64))
         mine = os.path.join(td, "mine")
-        w_dev, err = _best_wall([cli, "-i", lst, "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
+        walls, errs = _timed_runs([cli, "-i", lst, "-o", mine, "-t", str(threads)], warmup, steps, env=dict(os.environ, PANDEPTH_TIMING="1"))
+        sp = _spread(walls)
+        w_dev = sp["median"]
+        err = errs[_median_run(walls)]
         ph, _ = parse_timing(err)
-        how = [ln.strip() for ln in err.splitlines() if "summed over" in ln or "added into" in ln or "RCCL" in ln][:4]
+        said = lambda e: [ln.strip() for ln in e.splitlines() if "summed over" in ln or "added into" in ln or "communicator" in ln or "comm ahead" in ln][:4]
         out = {"n_bams": n_bams, "records_per_bam": int(records), "bam_bytes_total": total_bytes, "generated_in_s": round(t_gen, 1),
-               "mode": "pandepth -i s.list -o out -t N (one context per visible GPU; process wall clock exec-to-exit, warm page cache, best of 2)",
-               "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": n_bams * records / w_dev, "threads": threads, "phases_s": ph, "sum": how}}
+               "mode": "pandepth -i s.list -o out -t N (one context per visible GPU; process wall clock exec-to-exit, warm page cache, %d warm-up + %d timed runs, median)" % (warmup, steps),
+               "pandepth": {"wall_s": w_dev, "wall_s_spread": sp, "records_per_s": n_bams * records / w_dev, "threads": threads, "phases_s": ph, "sum": said(err)}}
         if n_bams == 1:
-            # one GPU: the list path's collective code with REAL RCCL and one rank (-X rccl=force) — what making a communicator costs here and
-            # that it hides behind the decode; the table must not change
-            try:
-                # twice: the first process on a fresh box that loads librccl reads its gigabyte from disk (4-5 s: profiles/r05_comm_init.txt), the
-                # second finds it in the page cache
-                w_c, err_c = _best_wall([cli, "-i", lst, "-o", mine + "_rccl1", "-t", str(threads)], 1,
-                                        env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="rccl=force"), want_stderr=True)
-                time.sleep(1.0)
-                w_f, err_f = _best_wall([cli, "-i", lst, "-o", mine + "_rccl1", "-t", str(threads)], 1,
-                                        env=dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="rccl=force"), want_stderr=True)
-                ph_f, _ = parse_timing(err_f)
-                out["one_rank_rccl"] = {"wall_s": round(w_f, 4), "phases_s": ph_f, "first_run_on_the_box": {"wall_s": round(w_c, 4), "phases_s": parse_timing(err_c)[0]},
-                                        "sum": [ln.strip() for ln in err_f.splitlines() if "summed over" in ln or "added into" in ln or "RCCL" in ln][:4],
-                                        "same_table": open(mine + ".chr.stat.gz", "rb").read() == open(mine + "_rccl1.chr.stat.gz", "rb").read()}
-            except Exception as ex:                                # noqa: BLE001
-                out["one_rank_rccl"] = {"failed": repr(ex)[:300]}
+            # one GPU: the list path's COLLECTIVE code with one rank (-X comm=force) over both transports — the executable's default
+            # (in-process peer copies: nothing to load) and real RCCL (-X transport=rccl: librccl loaded and the communicator bootstrapped
+            # at process entry, ahead of the contexts).  What a communicator costs a list run here; the table must not change.
+            # RCCL: the first process on a fresh box that loads librccl reads its gigabyte from disk (4-5 s: profiles/r05_comm_init.txt) — run
+            # once untimed-for-the-median and reported as first_run_on_the_box.
+            for key, tune_s in (("one_rank_collective", "comm=force"), ("one_rank_rccl", "comm=force,transport=rccl")):
+                try:
+                    envk = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE=tune_s)
+                    cmdk = [cli, "-i", lst, "-o", mine + "_" + key, "-t", str(threads)]
+                    w_c, err_c = _best_wall(cmdk, 1, env=envk, want_stderr=True)
+                    time.sleep(1.0)
+                    wk, ek = _timed_runs(cmdk, 0, 3, env=envk)
+                    spk = _spread(wk)
+                    err_f = ek[_median_run(wk)]
+                    out[key] = {"wall_s": spk["median"], "wall_s_spread": spk, "phases_s": parse_timing(err_f)[0], "transport": tune_s,
+                                "vs_no_communicator": round(spk["median"] / w_dev, 3),
+                                "first_run_on_the_box": {"wall_s": round(w_c, 4), "phases_s": parse_timing(err_c)[0]}, "sum": said(err_f),
+                                "same_table": open(mine + ".chr.stat.gz", "rb").read() == open(mine + "_" + key + ".chr.stat.gz", "rb").read()}
+                except Exception as ex:                                # noqa: BLE001
+                    out[key] = {"failed": repr(ex)[:300]}
         if os.access(ref, os.X_OK):
             w_ref = _best_wall([ref, "-i", lst, "-o", os.path.join(td, "ref"), "-t", "36"], 1)
             out["reference"] = {"wall_s": round(w_ref, 4), "records_per_s": n_bams * records / w_ref, "threads": 36}
@@ -350,7 +429,7 @@ def e2e_multi_leg(n_bams, records):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def e2e_leg(records, site_records, fullsize_site=False):
+def e2e_leg(records, site_records, fullsize_site=False, steps=5, warmup=1):
     """END TO END, product path: the `pandepth` executable (GPU-side BGZF inflate + record parsing + the direct window
     kernel) and the reference binary on the SAME coordinate-sorted BAM with SEQ/QUAL/tag payload, written here by
     tools/bamgen (libdeflate level 6, BAI alongside), whole-chromosome mode, process wall clock (exec to exit, warm page
@@ -378,8 +457,19 @@ def e2e_leg(records, site_records, fullsize_site=False):
         size = os.path.getsize(bam)
         threads = max(4, min(16, quota))
         mine = os.path.join(td, "mine")
-        w_dev, err = _best_wall([cli, "-i", bam, "-o", mine, "-t", str(threads)], 2, env=dict(os.environ, PANDEPTH_TIMING="1"), want_stderr=True)
-        ph, dec = parse_timing(err)
+        # THE METRIC (BASELINE.json: alignment records/sec + wall-clock on the configs[1] BAM): `warmup` untimed runs of the executable (page
+        # cache, clocks), then `steps` timed ones; the line's `value` is records / the MEDIAN wall of those (min / max / mean beside it)
+        walls, errs = _timed_runs([cli, "-i", bam, "-o", mine, "-t", str(threads)], warmup, steps, env=dict(os.environ, PANDEPTH_TIMING="1"))
+        sp = _spread(walls)
+        w_dev = sp["median"]
+        parsed = [parse_timing(e) for e in errs]
+        ph, dec = parsed[_median_run(walls)]
+        ph_spread = {}
+        for key in ("decode + scatter", "engine create", "scan + statistics"):
+            vals = [q[0][key] for q in parsed if key in q[0]]
+            if vals:
+                ph_spread[key] = _spread(vals)
+        insitu = [q[1]["inflated_bytes"] / (q[1]["device_ms_summed"]["inflate"] / 1e3) / 1e9 for q in parsed if q[1] and q[1]["device_ms_summed"]["inflate"]]
         w_host = _best_wall([cli, "-i", bam, "-o", os.path.join(td, "host"), "-t", str(threads)], 1,
                             env=dict(os.environ, PANDEPTH_TUNE="device_decode=0"))
         e2e = {
@@ -387,10 +477,12 @@ def e2e_leg(records, site_records, fullsize_site=False):
             "bam": "tools/bamgen: coordinate-sorted, 150-base reads with names, SEQ from a synthetic reference, binned QUAL, "
                    "NM/MD/AS/XS/RG tags; BGZF by libdeflate level 6; .bai alongside (" + g.stderr.decode().strip().replace("bamgen: ", "") +
                    "; generated in %.0f s)" % t_gen,
-            "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache, best of 2 runs for both executables",
-            "pandepth": {"wall_s": round(w_dev, 4), "records_per_s": records / w_dev, "threads": threads,
+            "mode": "whole-chromosome (pandepth -i s.bam -o out -t N), process wall clock exec-to-exit, warm page cache; pandepth: %d warm-up + %d timed runs, "
+                    "MEDIAN reported (min / max / mean beside it); the reference: best of its runs" % (warmup, steps),
+            "pandepth": {"wall_s": w_dev, "wall_s_spread": sp, "walls_s": [round(w, 4) for w in walls], "records_per_s": records / w_dev, "threads": threads,
                          "path": "GPU decode (k_inflate_wave, k_walk_segments, k_emit_segments) -> one compact sample (pd_runs) -> k_direct_c8; host only reads the file",
-                         "phases_s": ph, "device_decode": dec},
+                         "phases_s": ph, "phases_s_spread": ph_spread, "device_decode": dec,
+                         "inflate_kernel_GBps_in_situ_spread": (_spread(insitu, 1) if insitu else None)},
             "pandepth_host_decode": {"wall_s": round(w_host, 4), "records_per_s": records / w_host, "threads": threads,
                                      "path": "-X device_decode=0: libdeflate on the host threads + pd_push_intervals"},
             "cpu_quota": quota, "host_cpus": os.cpu_count(),
@@ -408,7 +500,7 @@ def e2e_leg(records, site_records, fullsize_site=False):
                 "inflate_kernel_GBps_in_situ": round(dec["inflated_bytes"] / (dec["device_ms_summed"]["inflate"] / 1e3) / 1e9, 1) if dec["device_ms_summed"]["inflate"] else None,
                 # the decode phase against ITS dominant kernel's own ceiling: k_inflate_wave alone, on launches that keep the CUs full, inflates
                 # 285 GB/s (profiles/r05_inflate_ab.txt: 277-293 on one box)
-                "inflate_kernel_isolated_GBps": INFLATE_ISOLATED_GBS,
+                "inflate_kernel_isolated_GBps": INFLATE_ISOLATED_GBS, "inflate_kernel_isolated_source": INFLATE_ISOLATED_SOURCE,
                 "frac": round(dec["inflated_bytes"] / t_dec / 1e9 / INFLATE_ISOLATED_GBS, 3),
                 "frac_is": "inflated bytes / decode-phase seconds / the inflate kernel's isolated rate: 1.0 = the phase runs as fast as that kernel alone could",
                 "note": "inflate_kernel_GBps_in_situ = inflated bytes / sum of the batches' inflate-kernel times (batches of different feeders "
@@ -419,7 +511,7 @@ def e2e_leg(records, site_records, fullsize_site=False):
             # the reference at -t 36 (12 chromosome workers x (1 + 2 BGZF threads): its best shape on an unrestricted host) AND at -t <the
             # job's CPU quota> (no oversubscription on these boxes): the FASTER of the two is the baseline, both are in the line
             rthreads = 36
-            w_ref36 = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", str(rthreads)], 2)
+            w_ref36 = _best_wall([ref, "-i", bam, "-o", os.path.join(td, "ref"), "-t", str(rthreads)], 1)
             same = open(mine + ".chr.stat.gz", "rb").read() == open(os.path.join(td, "ref.chr.stat.gz"), "rb").read()
             by_threads = {str(rthreads): round(w_ref36, 4)}
             w_ref = w_ref36
@@ -446,6 +538,16 @@ def e2e_leg(records, site_records, fullsize_site=False):
             except Exception as ex:                 # noqa: BLE001
                 e2e["site_windows_fullsize"] = {"failed": repr(ex)[:300]}
         os.remove(bam)
+        # two other input shapes (round 6): long reads through the device decoder, and the configs[1] reads with unbinned qualities (a BAM of
+        # about twice the compressed bytes per record: how close to the PCIe link the decode phase then runs)
+        for key, gen_args, recs in (("long_reads", ["--long"], float(os.environ.get("PD_BENCH_LONG_RECORDS", "6.0e5"))),
+                                    ("q40", ["-Q", "40"], float(os.environ.get("PD_BENCH_Q40_RECORDS", "2.0e8")))):
+            if recs <= 0:
+                continue
+            try:
+                e2e[key] = e2e_variant_leg(td, gen, cli, ref, threads, key, gen_args, recs)
+            except Exception as ex:                 # noqa: BLE001
+                e2e[key] = {"failed": repr(ex)[:300]}
         if site_records > 0:
             try:
                 e2e["site_windows"] = e2e_site_windows(td, gen, cli, ref, threads, site_records)
@@ -995,7 +1097,8 @@ def main():
                 eng.close()                                        # the CLI makes its own context on this GPU
                 del first, other                                   # ... and the bench sample's 13 GB of runs go too
                 torch.cuda.empty_cache()
-                e2e, cb = e2e_leg(int(args.e2e_records), int(args.e2e_site_records), fullsize_site=os.environ.get("PD_BENCH_E2E_FULLSIZE_SITE", "1") == "1")
+                e2e, cb = e2e_leg(int(args.e2e_records), int(args.e2e_site_records), fullsize_site=os.environ.get("PD_BENCH_E2E_FULLSIZE_SITE", "1") == "1",
+                                  steps=args.steps, warmup=args.warmup)
                 if isinstance(e2e, dict):
                     e2e["size_note"] = e2e_size_note
             except Exception as ex:                                # never lose the GPU line over this leg
@@ -1012,7 +1115,8 @@ def main():
                     eng.close()
                     first = other = None
                     torch.cuda.empty_cache()
-                e2e_multi = e2e_multi_leg(world, int(args.e2e_multi_records))
+                # N > 1: the `#.list` run over N BAMs on N GPUs IS the step the line's value is quoted on (K timed runs); N = 1: a leg beside it
+                e2e_multi = e2e_multi_leg(world, int(args.e2e_multi_records), steps=(args.steps if world > 1 else 3), warmup=(min(args.warmup, 2) if world > 1 else 1))
             except Exception as ex:                                # noqa: BLE001
                 e2e_multi = {"failed": repr(ex)[:300]}
         if configs is not None and isinstance(e2e, dict):
@@ -1024,27 +1128,53 @@ def main():
         value_dec = None
         if sample_prep is not None:
             value_dec = world * R / ((ms_step + sample_prep["decode_end_ms"]) * 1e-3)
+        # ---- the headline.  BASELINE.json's metric is "alignment records/sec (whole node) + wall-clock, 3 Gb genome 50x BAM": the rate at
+        # which the EXECUTABLE turns the BAM file(s) into the .stat.gz table, process wall clock.  Since round 6 that is `value` (rounds
+        # 1-5 quoted the repeated device pass over a resident sample here — three orders of magnitude above what a user gets; it stays in
+        # the line as `device_step`, with its roofline).  N = 1: the configs[1] file through `pandepth -i s.bam`; N > 1: N BAMs through
+        # `pandepth -i s.list` on the N GPUs.  A step = one run of the executable; `warmup` untimed runs, `steps` timed ones, MEDIAN wall.
+        device_step = {"records_per_s": value, "ms_per_step": ms_step, "steps": args.steps, "warmup": args.warmup,
+                       "what": "pd_reset + pd_push_runs (the sample resident in HBM in the decoder's compact form) + pd_scan_reduce_windows incl. copy-back: a REPEATED pass "
+                               "of the statistics kernels over one resident sample; `roofline` is this step's dominant kernel",
+                       "records_per_s_from_decoder_output": value_dec}
+        headline = None
+        if world == 1 and isinstance(e2e, dict) and isinstance(e2e.get("pandepth"), dict):
+            pe = e2e["pandepth"]
+            headline = {"value": pe["records_per_s"], "ms": pe["wall_s"] * 1e3, "steps": pe["wall_s_spread"]["runs"], "spread": pe["wall_s_spread"],
+                        "records": e2e["records"], "is": "the `pandepth` executable on the configs[1] BAM (%d records, %.1f GB), exec to exit, warm page cache: "
+                        "file read + PCIe + GPU inflate + record walk + statistics + table; median of %d timed runs" % (e2e["records"], e2e["bam_bytes"] / 1e9, pe["wall_s_spread"]["runs"])}
+        elif world > 1 and isinstance(e2e_multi, dict) and isinstance(e2e_multi.get("pandepth"), dict):
+            pm = e2e_multi["pandepth"]
+            headline = {"value": pm["records_per_s"], "ms": pm["wall_s"] * 1e3, "steps": pm["wall_s_spread"]["runs"], "spread": pm["wall_s_spread"],
+                        "records": e2e_multi["n_bams"] * e2e_multi["records_per_bam"],
+                        "is": "`pandepth -i s.list` over %d BAMs of %d records on %d GPUs (one process, a context and a rank thread per GPU), exec to exit; median of %d timed runs"
+                              % (e2e_multi["n_bams"], e2e_multi["records_per_bam"], world, pm["wall_s_spread"]["runs"])}
         line = {
-            "metric": "alignment records/sec (3 Gb genome, 50x BAM, whole-chromosome mode)",
-            "value": value, "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            # `value` passes over a sample that is resident in the engine's compact form (made once per sample); this one adds what
-            # pd_decode_end does to get there from the decoder's batches (sample_preparation.decode_end_ms) to EVERY step
-            "value_from_decoder_output": value_dec, "sample_preparation": sample_prep,
-            # the metric's other half ("+ wall-clock"): the executable on the configs[1] BAM, exec to exit, records / wall — what a user gets
+            "metric": "alignment records/sec (whole node) + wall-clock, 3 Gb genome 50x BAM (whole-chromosome mode, BAM file -> chr.stat.gz)",
+            "value": (headline["value"] if headline else value), "unit": "records/s", "n_gpus": world,
+            "steps": (headline["steps"] if headline else args.steps), "warmup": args.warmup,
+            "ms_per_step": (headline["ms"] if headline else ms_step), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "wall_s_spread": (headline["spread"] if headline else None),
+            # the repeated device pass over a resident sample (rounds 1-5's `value`) and the figure that adds pd_decode_end's work to every step
+            "device_step": device_step,
+            "device_step_records_per_s": value, "value_from_decoder_output": value_dec, "sample_preparation": sample_prep,
+            # (kept under their round-5 names: the same figures as `value` / `ms_per_step` at N = 1)
             "e2e_records_per_s": (e2e.get("pandepth", {}).get("records_per_s") if isinstance(e2e, dict) else None),
             "e2e_wall_s": (e2e.get("pandepth", {}).get("wall_s") if isinstance(e2e, dict) else None),
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
             "config": {"workload": "configs[1]: 3 Gb ref (12 chr + 500 scaffolds, %d bp), 50x short-read BAM, "
                                    "whole-chromosome mode" % G,
-                       "records_per_gpu": R, "runs_sorted": n_first, "runs_unsorted": n_other,
-                       "value_is": "a REPEATED pass of the statistics kernels over one sample that stays resident in HBM (the step the contract times); "
-                                   "the product reads a sample once — e2e_records_per_s (same line) is that figure, BAM file to .stat.gz",
+                       "records_per_gpu": (headline["records"] // world if headline else R), "runs_sorted": n_first, "runs_unsorted": n_other,
+                       "value_is": (headline["is"] if headline else
+                                    "NO end-to-end leg in this invocation (--e2e-records 0 / no room in /tmp): `value` falls back to the device step — a REPEATED pass of the "
+                                    "statistics kernels over one sample resident in HBM"),
+                       "device_step_is": device_step["what"],
                        "cells": int(n_words), "path": ("direct (difference windows stay in LDS" + (", exported as 4-bit images)" if use_dist else "; the kernel path the pandepth CLI runs in this mode)") +
                                 (" — sample resident in the compact form (8 B/run, grouped by 512-cell bucket with exact bounds), as pd_decode_end leaves it" if used_compact else "")) if direct
                                else "arrays (difference arrays in HBM)",
                        "parallelism": "1 BAM per GPU" + ((", " + {
-                           "sliced": "sliced sum behind the C-ABI (pd_sliced_sum_start / _finish: RCCL grouped send/recv of 4-bit slices issued by the library), every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
+                           "sliced": "device step: sliced sum behind the C-ABI (pd_sliced_sum_start / _finish: RCCL grouped send/recv of 4-bit slices issued by the library), every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else "") +
+                                     "; the executable (`value`): one process, in-process peer-copy transport by default (-X transport=rccl: RCCL)",
                            "sliced_torch": "sliced sum: 4-bit all-to-all issued from torch.distributed, every rank sweeps 1/N of the tiles" + (", steps pipelined" if pipelined else ""),
                            "int8": "RCCL reduce to rank 0 (int8 transport)", "int32": "RCCL reduce to rank 0 (int32)"}[sum_mode]) if use_dist else ""),
                        "total_depth_check": total_depth, "multi_gpu_sum_selfcheck": selfcheck},

@@ -300,6 +300,17 @@ typedef struct pd_comm pd_comm;          /* belongs to its context: pd_comm_dest
 int pd_comm_unique_id(void *id128);
 int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm **out);
 int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms);
+/* The same communicator WITHOUT RCCL, for ranks that are threads of one process (the executable's `#.list` mode, its default since
+ * round 6): a rank pulls its slices out of its peers' buffers with xGMI peer copies (hipMemcpyPeerAsync on its own stream, ordered by
+ * events), int32 sums with the engine's add kernel; nothing is loaded or bootstrapped (librccl's load costs a short-lived process
+ * 1.1-5 s and slows every kernel launch while it runs).  Every pd_sliced_* call works on such a communicator as on an RCCL one.
+ * Contexts may share a GPU.  Fails (PD_EHIP) when two of the GPUs have no peer access to each other. */
+int pd_comm_init_local(pd_ctx **ctxs, int n, pd_comm **comms);
+/* librccl loaded and an n-rank communicator made over `devices` AHEAD of the contexts (ncclCommInitAll needs device numbers only);
+ * the next pd_comm_init_all over contexts on exactly these devices adopts it.  Meant to be called at process entry, before
+ * pd_create: the load registers its code objects under the lock kernel launches need, so behind a running decode it slows the
+ * decode down 3x, ahead of it nothing.  devices == NULL: load the library only.  PD_ENODEV without librccl. */
+int pd_comm_preinit(const int *devices, int n);
 int pd_comm_destroy(pd_comm *comm);
 const char *pd_comm_strerror(const pd_comm *comm);
 int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);

@@ -19,6 +19,7 @@
 #include <vector>
 #include <map>
 #include "pd_kernels.h"
+#include "pd_local_comm.h"
 #include "../../include/pandepth_amd_dev.h"
 #include "pd_bamwalk.h"
 #include <condition_variable>
@@ -175,7 +176,8 @@ constexpr uint64_t OVF_MAX = (uint64_t)64 << 20;     // overflow-list entries (e
 constexpr uint32_t LMAX_DEFAULT = 512;               // look-back bound for owner tiles (cells)
 constexpr uint32_t SAMPLE_DEFAULT = 64;              // sparse index stride (runs)
 
-std::string g_create_err;
+std::string g_create_err;                   // why the last pd_create failed (contexts may be created on several threads at once:
+std::mutex g_create_err_mu;                 // written and read under this lock, handed out as a copy of the calling thread's own)
 
 struct Stage {
     pd_iv *host = nullptr, *dev = nullptr;
@@ -252,6 +254,7 @@ struct pd_ctx {
         // a batch between pd_decode_queue and pd_decode_collect (pd_decode_submit: the two back to back)
         struct Job {
             bool open = false, queued = false, c8 = false, fast = false, owes_count = false, timed = false;
+            bool collecting = false;                               // some thread is inside dec_collect on this slot (set and tested under dec_mu): one ticket, one collect
             uint64_t order = 0; size_t n_bytes = 0; uint64_t inflated = 0; uint32_t n_seg = 0;
             std::vector<pd_bgzf_block> blocks; std::vector<pd_decode_unit> units; std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0;
             size_t o_blk = 0, o_seg = 0, o_next = 0, o_up = 0, o_bst = 0, o_co = 0, o_so = 0, o_ord = 0;
@@ -337,7 +340,7 @@ namespace {
 
 int fail(pd_ctx *c, int code, const std::string &msg)
 {
-    if (c) c->err = msg; else g_create_err = msg;
+    if (c) c->err = msg; else { std::lock_guard<std::mutex> lk(g_create_err_mu); g_create_err = msg; }
     return code;
 }
 
@@ -609,7 +612,13 @@ extern "C" {
 
 int pd_abi_version(void) { return PD_ABI_VERSION; }
 
-const char *pd_strerror(const pd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char *pd_strerror(const pd_ctx *ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    static thread_local std::string mine;
+    { std::lock_guard<std::mutex> lk(g_create_err_mu); mine = g_create_err; }
+    return mine.c_str();
+}
 
 int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out)
 {
@@ -700,7 +709,7 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
     int rc = do_reset(c);
     if (rc == PD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PD_EHIP;
     tm_mark("first reset (kernels loaded)");
-    if (rc != PD_OK) { g_create_err = c->err; pd_destroy(c); return rc; }
+    if (rc != PD_OK) { { std::lock_guard<std::mutex> lk(g_create_err_mu); g_create_err = c->err; } pd_destroy(c); return rc; }
     *out = c;
     return PD_OK;
 }
@@ -1435,7 +1444,10 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
         // (any genome size: a compact run keeps the low 32 bits of its flat begin and every consumer works relative to a tile; what is bounded is
         // the number of runs — 32-bit indices — so a file that promises more than that many records keeps 12-byte runs per batch)
         if ((cfg->flags & PD_DECODE_COMPACT) && cfg->n_batches && cfg->n_batches < (1ull << 31) && cfg->sorted && !cfg->spans && c->pend.empty() &&
-            cfg->bytes_hint / 16 < DEV_BATCH_MAX && nb64 <= 0xFFFFFF00ull) {
+            cfg->bytes_hint / 16 < DEV_BATCH_MAX && nb64 <= 0xFFFFFF00ull &&
+            // (above 2^32 cells a compact session that outgrows its 32-bit run indices cannot fall back to 12-byte runs afterwards — pd_decode_end
+            // would have to refuse a file already decoded — so there the caller must have said how large the file is; the executable always does)
+            (c->n_cells < (1ull << 32) || cfg->bytes_hint != 0)) {
             x.bshift = runs_bshift(c);
             x.nbw = (size_t)nb64 + 2;
             if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
@@ -1912,7 +1924,7 @@ pd_ctx::DecSlot *dec_slot_of(pd_ctx *c, const void *host_buf)
     for (auto &x : c->dec) if (x.busy && !x.job.open && x.h_blob == host_buf) { x.job.open = true; return &x; }      // (claimed: a batch is under way in this slot)
     return nullptr;
 }
-void dec_release(pd_ctx *c, pd_ctx::DecSlot *s) { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; s->job.open = false; } c->dec_cv.notify_all(); }
+void dec_release(pd_ctx *c, pd_ctx::DecSlot *s) { { std::lock_guard<std::mutex> l(c->dec_mu); s->busy = false; s->job.open = false; s->job.collecting = false; } c->dec_cv.notify_all(); }
 
 } // namespace
 
@@ -1926,6 +1938,8 @@ int pd_decode_submit(pd_ctx *c, const pd_decode_batch *bt, int32_t *unit_status,
     struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { dec_release(c, s); } } rel{c, slp};
     if (res) { memset(res, 0, sizeof *res); res->first_start = res->next_start = ~0ull; }
     for (uint32_t u = 0; u < bt->n_units; ++u) unit_status[u] = 0;
+    // (a ticket of an earlier batch on this slot is stale from here on, and nobody else may collect or drain the batch about to be queued)
+    { std::lock_guard<std::mutex> l0(c->dec_mu); ++slp->gen; slp->job.collecting = true; }
     const int rc = dec_queue(c, *slp, bt);
     if (rc) return rc;
     return dec_collect(c, *slp, unit_status, res);
@@ -1950,9 +1964,10 @@ int pd_decode_collect(pd_ctx *c, uint64_t ticket, int32_t *unit_status, pd_decod
     pd_ctx::DecSlot *slp = k >= 1 && k <= (uint64_t)pd_ctx::N_DEC ? &c->dec[k - 1] : nullptr;
     {
         std::lock_guard<std::mutex> l0(c->dec_mu);
-        if (!slp || !slp->busy || !slp->job.open || slp->gen != (uint32_t)(ticket >> 8)) slp = nullptr;
+        if (!slp || !slp->busy || !slp->job.open || slp->job.collecting || slp->gen != (uint32_t)(ticket >> 8)) slp = nullptr;
+        else slp->job.collecting = true;
     }
-    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_collect: not the ticket of a queued batch");
+    if (!slp) return dec_fail(c, PD_EINVAL, "pd_decode_collect: not the ticket of a queued batch (or the batch is being collected already)");
     struct Release { pd_ctx *c; pd_ctx::DecSlot *s; ~Release() { dec_release(c, s); } } rel{c, slp};
     return dec_collect(c, *slp, unit_status, res);
 }
@@ -1962,7 +1977,8 @@ static void dec_drain(pd_ctx *c, bool finish)
 {
     for (auto &sl : c->dec) {
         bool mine = false;
-        { std::lock_guard<std::mutex> lk(c->dec_mu); mine = sl.busy && sl.job.open; }
+        // (a slot some thread is collecting, or is inside pd_decode_submit on, is left to that thread: the callers wait on dec_cv for it)
+        { std::lock_guard<std::mutex> lk(c->dec_mu); mine = sl.busy && sl.job.open && !sl.job.collecting; if (mine) sl.job.collecting = true; }
         if (!mine) continue;
         if (finish) { std::vector<int32_t> st(sl.job.units.size() + 1, 0); (void)dec_collect(c, sl, st.data(), nullptr); }
         else { (void)hipSetDevice(c->device); if (sl.st) (void)hipStreamSynchronize(sl.st); C8Owes owes{c, &sl.job}; sl.job.queued = false; }
@@ -2934,8 +2950,10 @@ int pd_profile_get(pd_ctx *c, const char *name, double *ms, uint64_t *launches)
 // Multi-sample sum over several GPUs with RCCL called from here (include/pandepth_amd.h: pd_comm_*, pd_sliced_window_sum):
 // the C++ form of pandepth_amd/multi.py's SlicedSum, for the CLI's `#.list` mode and for any host that is not Python.
 // ---------------------------------------------------------------------------------------------------------------
+namespace { struct Rccl; }
 struct pd_comm {
     pd_ctx *ctx = nullptr;
+    const Rccl *tp = nullptr;                     // the transport's entry points: librccl's (between processes) or the in-process peer-copy one
     ncclComm_t nccl = nullptr;
     int rank = 0, world = 1;
     uint64_t n_tiles = 0, slice_tiles = 0, slice_bytes = 0, tile_first = 0, tile_count = 0, n_sums = 0;
@@ -2992,28 +3010,30 @@ Rccl &rccl()
     });
     return r;
 }
-// RCCL 2.27 prints a version banner on stdout when a communicator is made, whatever NCCL_DEBUG says; the executable's stdout
-// is part of its contract (compared byte for byte with the reference's).  While a communicator is being made, and unless the
-// user asked RCCL to talk (NCCL_DEBUG set), file descriptor 1 points at /dev/null.  Callers make communicators at a quiet point.
-struct QuietStdout {
-    int saved = -1;
-    QuietStdout()
-    {
-        if (getenv("NCCL_DEBUG")) return;
-        fflush(stdout); std::cout.flush();          // (the banner comes through std::cout, which may not share stdio's buffer)
-        const int nul = open("/dev/null", O_WRONLY);
-        if (nul < 0) return;
-        saved = dup(1);
-        if (saved >= 0) dup2(nul, 1);
-        close(nul);
-    }
-    ~QuietStdout() { if (saved >= 0) { fflush(stdout); std::cout.flush(); dup2(saved, 1); close(saved); } }
-};
+// (RCCL 2.27 prints a version banner on stdout when the first communicator is made, whatever NCCL_DEBUG says.  The library leaves
+// descriptor 1 alone — until round 6 it pointed it at /dev/null meanwhile, which in a multi-threaded process can eat somebody else's
+// line; a caller whose stdout is a contract keeps its own lines on a descriptor of its own: host/pipeline.cpp, OwnStdout.)
+//
+// The in-process transport (pd_local_comm.h) behind the same table: pd_comm_init_local.
+Rccl &local_tp()
+{
+    static Rccl r = [] {
+        Rccl t;
+        t.CommInitAll = pdlocal::CommInitAll; t.CommDestroy = pdlocal::CommDestroy; t.GroupStart = pdlocal::GroupStart; t.GroupEnd = pdlocal::GroupEnd;
+        t.Send = pdlocal::Send; t.Recv = pdlocal::Recv; t.AllReduce = pdlocal::AllReduce; t.AllGather = pdlocal::AllGather; t.GetErrorString = pdlocal::GetErrorString;
+        t.ok = true; t.alt = true;                 // (alt: ranks may share a device)
+        return t;
+    }();
+    return r;
+}
+// Communicators made ahead of their contexts (pd_comm_preinit): ncclCommInitAll wants device numbers only, and a short-lived process
+// wants librccl's load and bootstrap over BEFORE its contexts load code objects and its readers launch kernels (see pd_comm_preinit).
+struct ParkedComms { std::mutex mu; std::vector<int> devs; std::vector<ncclComm_t> nc; } g_parked;
 constexpr uint32_t COMM_EXC_BLOCK = 1u << 18;       // exceptions (cells outside the 4-bit range) per rank
 constexpr size_t COMM_MSG_BYTES = (size_t)1 << 28;  // RCCL 2.26 delivers only the first half of a send/recv above 1 GiB: stay far below
 
 int comm_fail(pd_comm *m, int code, const std::string &msg) { m->err = msg; if (m->ctx) { std::lock_guard<std::mutex> lk(m->ctx->mu); m->ctx->err = msg; } return code; }
-#define NCCLOK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); } while (0)
+#define NCCLOK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + (m)->tp->GetErrorString(r_)); } while (0)
 #define HIPCM(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 int comm_setup(pd_comm *m)
@@ -3066,10 +3086,9 @@ int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm 
     if (!ctx || !id128 || !out || rank < 0 || rank >= n_ranks) return PD_EINVAL;
     *out = nullptr;
     if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
-    pd_comm *m = new pd_comm; m->ctx = ctx; m->rank = rank; m->world = n_ranks;
+    pd_comm *m = new pd_comm; m->ctx = ctx; m->tp = &rccl(); m->rank = rank; m->world = n_ranks;
     ncclUniqueId id; memcpy(&id, id128, sizeof id);
-    bool made;
-    { QuietStdout q; made = hipSetDevice(ctx->device) == hipSuccess && rccl().CommInitRank(&m->nccl, n_ranks, id, rank) == ncclSuccess; }
+    const bool made = hipSetDevice(ctx->device) == hipSuccess && rccl().CommInitRank(&m->nccl, n_ranks, id, rank) == ncclSuccess;
     if (!made) {
         { std::lock_guard<std::mutex> lk(ctx->mu); ctx->err = "pd_comm_init: ncclCommInitRank failed"; }
         delete m; return PD_EHIP;
@@ -3080,22 +3099,49 @@ int pd_comm_init(pd_ctx *ctx, const void *id128, int rank, int n_ranks, pd_comm 
     return PD_OK;
 }
 
-int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms)
+// librccl loaded and an n-rank communicator bootstrapped over `devices` NOW, before any context exists; the next pd_comm_init_all
+// over contexts on exactly these devices adopts it.  For a short-lived process: the load registers half a gigabyte of code objects
+// under the runtime lock every kernel launch needs, so behind a running decode it costs the decode (profiles/r05_comm_init.txt:
+// 0.68 -> 2.19 s); ahead of pd_create it overlaps header and index reads and slows nothing down.  devices == NULL: load only.
+int pd_comm_preinit(const int *devices, int n)
+{
+    if (!rccl().ok) return PD_ENODEV;
+    if (!devices || n < 1) return PD_OK;
+    std::vector<int> devs(devices, devices + n);
+    if (!rccl().alt)
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (devs[(size_t)i] == devs[(size_t)j]) return PD_EINVAL;
+    std::vector<ncclComm_t> nc((size_t)n, nullptr);
+    if (rccl().CommInitAll(nc.data(), n, devs.data()) != ncclSuccess) return PD_EHIP;
+    std::lock_guard<std::mutex> lk(g_parked.mu);
+    for (ncclComm_t old : g_parked.nc) if (old) (void)rccl().CommDestroy(old);         // (made, never adopted)
+    g_parked.devs = devs; g_parked.nc = nc;
+    return PD_OK;
+}
+
+static int comm_init_over(Rccl &tp, const char *what, pd_ctx **ctxs, int n, pd_comm **comms)
 {
     if (!ctxs || !comms || n < 1) return PD_EINVAL;
     std::vector<int> devs((size_t)n);
     for (int i = 0; i < n; ++i) { if (!ctxs[i]) return PD_EINVAL; devs[(size_t)i] = ctxs[i]->device; comms[i] = nullptr; }
-    if (!rccl().alt)
+    if (!tp.ok) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = std::string(what) + ": librccl.so.1 cannot be loaded"; return PD_ENODEV; }
+    if (!tp.alt)
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (devs[(size_t)i] == devs[(size_t)j]) {
-            std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
-    if (!rccl().ok) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "pd_comm_init_all: librccl.so.1 cannot be loaded"; return PD_ENODEV; }
+            std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = std::string(what) + ": two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
-    bool made;
-    { QuietStdout q; made = rccl().CommInitAll(nc.data(), n, devs.data()) == ncclSuccess; }
-    if (!made) { std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = "ncclCommInitAll failed"; return PD_EHIP; }
+    bool made = false;
+    if (&tp == &rccl()) {          // a communicator made ahead of the contexts (pd_comm_preinit) over the same devices
+        std::lock_guard<std::mutex> lk(g_parked.mu);
+        if (g_parked.devs == devs && !g_parked.nc.empty()) { nc = g_parked.nc; g_parked.nc.clear(); g_parked.devs.clear(); made = true; }
+    }
+    if (!made) made = tp.CommInitAll(nc.data(), n, devs.data()) == ncclSuccess;
+    if (!made) {
+        std::lock_guard<std::mutex> lk(ctxs[0]->mu);
+        ctxs[0]->err = &tp == &rccl() ? std::string("ncclCommInitAll failed") : std::string(what) + ": no peer access between the contexts' GPUs";
+        return PD_EHIP;
+    }
     int rc = PD_OK;
     for (int i = 0; i < n; ++i) {
-        pd_comm *m = new pd_comm; m->ctx = ctxs[i]; m->rank = i; m->world = n; m->nccl = nc[(size_t)i];
+        pd_comm *m = new pd_comm; m->ctx = ctxs[i]; m->tp = &tp; m->rank = i; m->world = n; m->nccl = nc[(size_t)i];
         comms[i] = m;
         if (rc == PD_OK) rc = comm_setup(m);
     }
@@ -3103,13 +3149,17 @@ int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms)
     return rc;
 }
 
+int pd_comm_init_all(pd_ctx **ctxs, int n, pd_comm **comms) { return comm_init_over(rccl(), "pd_comm_init_all", ctxs, n, comms); }
+
+int pd_comm_init_local(pd_ctx **ctxs, int n, pd_comm **comms) { return comm_init_over(local_tp(), "pd_comm_init_local", ctxs, n, comms); }
+
 int pd_comm_destroy(pd_comm *m)
 {
     if (!m) return PD_OK;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->links) (void)hipStreamSynchronize(m->links);
     if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
-    if (m->nccl) (void)rccl().CommDestroy(m->nccl);
+    if (m->nccl && m->tp) (void)m->tp->CommDestroy(m->nccl);
     for (pd_comm::Slot &s : m->slot) {
         for (void *p : {(void *)s.send, (void *)s.recv, (void *)s.meta, (void *)s.exc, (void *)s.exc_all, (void *)s.count}) if (p) (void)hipFree(p);
         if (s.packed) (void)hipEventDestroy(s.packed);
@@ -3150,17 +3200,17 @@ int pd_sliced_sum_start(pd_comm *m, int slot)
     // 2. the all-to-all: every pair of GPUs moves 1/world of the image over its own xGMI link, all links at once
     for (size_t c0 = 0; c0 < sb && W > 1; c0 += COMM_MSG_BYTES) {
         const size_t n = std::min(COMM_MSG_BYTES, sb - c0);
-        NCCLOK(m, rccl().GroupStart());
+        NCCLOK(m, m->tp->GroupStart());
         for (int p = 0; p < m->world; ++p) {
             if (p == m->rank) continue;
-            NCCLOK(m, rccl().Send(s.send + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
-            NCCLOK(m, rccl().Recv(s.recv + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
+            NCCLOK(m, m->tp->Send(s.send + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
+            NCCLOK(m, m->tp->Recv(s.recv + (size_t)p * sb + c0, n, ncclUint8, p, m->nccl, ln));
         }
-        NCCLOK(m, rccl().GroupEnd());
+        NCCLOK(m, m->tp->GroupEnd());
     }
     // 3. tile sums (+ exception counts) summed over the ranks; everybody's exception block to everybody
-    NCCLOK(m, rccl().AllReduce(s.meta, s.meta, (size_t)m->n_sums + W, ncclInt32, ncclSum, m->nccl, ln));
-    NCCLOK(m, rccl().AllGather(s.exc, s.exc_all, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), ncclUint8, m->nccl, ln));
+    NCCLOK(m, m->tp->AllReduce(s.meta, s.meta, (size_t)m->n_sums + W, ncclInt32, ncclSum, m->nccl, ln));
+    NCCLOK(m, m->tp->AllGather(s.exc, s.exc_all, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), ncclUint8, m->nccl, ln));
     HIPCM(m, hipEventRecord(s.landed, ln));
     s.busy = true;
     return PD_OK;
@@ -3190,10 +3240,10 @@ int pd_sliced_sum_finish(pd_comm *m, int slot, uint32_t w, uint32_t min_dep, uns
     if (W > 1) {
         HIPCM(m, hipEventRecord(m->swept, st));
         HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
-        NCCLOK(m, rccl().GroupStart());
-        if (m->rank == root) { for (int p = 0; p < m->world; ++p) if (p != root) NCCLOK(m, rccl().Recv(m->part_all + (size_t)p * pb, pb, ncclUint8, p, m->nccl, ln)); }
-        else NCCLOK(m, rccl().Send(m->part_mine, pb, ncclUint8, root, m->nccl, ln));
-        NCCLOK(m, rccl().GroupEnd());
+        NCCLOK(m, m->tp->GroupStart());
+        if (m->rank == root) { for (int p = 0; p < m->world; ++p) if (p != root) NCCLOK(m, m->tp->Recv(m->part_all + (size_t)p * pb, pb, ncclUint8, p, m->nccl, ln)); }
+        else NCCLOK(m, m->tp->Send(m->part_mine, pb, ncclUint8, root, m->nccl, ln));
+        NCCLOK(m, m->tp->GroupEnd());
         HIPCM(m, hipEventRecord(m->gathered, ln));
         HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
     }
@@ -3288,8 +3338,8 @@ static int sliced_narrow_windows(pd_comm *m, uint32_t w, uint32_t min_dep, unsig
         HIPCM(m, hipEventRecord(m->swept, st));
         HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
         const size_t pb = (size_t)m->slice_tiles * PD_TILE_PARTIAL_BYTES;
-        NCCLOK(m, rccl().AllGather(m->part_all + (size_t)m->rank * pb, m->part_all, pb, ncclUint8, m->nccl, ln));
-        NCCLOK(m, rccl().AllReduce(d_sum, d_sum, (b_sum + b_cov) / 4, ncclInt32, ncclSum, m->nccl, ln));
+        NCCLOK(m, m->tp->AllGather(m->part_all + (size_t)m->rank * pb, m->part_all, pb, ncclUint8, m->nccl, ln));
+        NCCLOK(m, m->tp->AllReduce(d_sum, d_sum, (b_sum + b_cov) / 4, ncclInt32, ncclSum, m->nccl, ln));
         HIPCM(m, hipEventRecord(m->gathered, ln));
         HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
     }
@@ -3367,7 +3417,7 @@ int pd_sliced_interval_sum(pd_comm *m, const pd_region *regs, size_t n, uint32_t
     if (m->world > 1) {
         HIPCM(m, hipEventRecord(m->swept, st));
         HIPCM(m, hipStreamWaitEvent(ln, m->swept, 0));
-        NCCLOK(m, rccl().AllGather(mine, all, blk, ncclUint8, m->nccl, ln));
+        NCCLOK(m, m->tp->AllGather(mine, all, blk, ncclUint8, m->nccl, ln));
         HIPCM(m, hipEventRecord(m->gathered, ln));
         HIPCM(m, hipStreamWaitEvent(st, m->gathered, 0));
     } else HIPCM(m, hipMemcpyAsync(all, mine, blk, hipMemcpyDeviceToDevice, st));

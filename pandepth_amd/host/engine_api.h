@@ -65,6 +65,10 @@ typedef struct pd_engine_api {
     /* optional (NULL = every batch is submitted and waited for by the thread that read it): the two halves of decode_submit, see pd_decode_queue */
     int (*decode_queue)(pd_ctx *, const pd_decode_batch *, uint64_t *);
     int (*decode_collect)(pd_ctx *, uint64_t, int32_t *, pd_decode_result *);
+    /* optional (NULL = RCCL only): the in-process communicator over xGMI peer copies, see pd_comm_init_local; and RCCL loaded and
+     * bootstrapped ahead of the contexts, see pd_comm_preinit */
+    int (*comm_init_local)(pd_ctx **, int, pd_comm **);
+    int (*comm_preinit)(const int *, int);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

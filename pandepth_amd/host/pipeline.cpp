@@ -1188,6 +1188,73 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     std::string path = o.input, err;
     if (path.empty()) { std::cerr << "Error: Failed to open the BAM/CRAM file: " << path << std::endl; return 1; }
     const bool paf = is_paf_path(path);                  // PD:3466-3479 / PD:3420-3432: the first input's extension decides
+    // One context per GPU for a `#.list` input (round robin over the files); see the transport notes below.
+    int n_dev = 1, n_ctx = 1;
+    if (list_mode && !paf && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
+        n_ctx = n_dev;
+        if (const char *e = tune("gpus")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
+        if (n_ctx > n_files) n_ctx = n_files;
+    }
+    const bool want_rccl = tune("transport") && !strncmp(tune("transport"), "rccl", 4);
+    // -X comm=force: a communicator even for ONE context (single-GPU boxes exercise the collective path that way); comm=0: never one
+    // (the contexts are added into the first GPU).  `rccl=force` / `rccl=0` are the names these had while RCCL was the only transport.
+    const bool comm_forced = (tune("comm") && !strcmp(tune("comm"), "force")) || (tune("rccl") && !strcmp(tune("rccl"), "force"));
+    const bool comm_off = (tune("comm") && tune("comm")[0] == '0') || (tune("rccl") && tune("rccl")[0] == '0');
+    // RCCL prints a version banner on descriptor 1 when the first communicator is made, whatever NCCL_DEBUG says, and this program's
+    // stdout is compared byte for byte with the reference's.  Until round 6 descriptor 1 pointed at /dev/null around every RCCL call,
+    // which in a process with reader threads could eat a line of OURS.  Now: when RCCL may be used, our own lines (all of them go
+    // through std::cout) are written to a private duplicate of the real stdout for the whole run and descriptor 1 belongs to the
+    // libraries — pointed at /dev/null unless -X rccl_verbose asks to see them.  Nothing of ours can be lost, whoever prints when.
+    struct OwnStdout {
+        struct Buf : std::streambuf {       // (line-buffered, and locked: reader threads print warnings too)
+            int fd = -1; std::string pend; std::mutex mu;
+            void flush_locked() { size_t o = 0; while (o < pend.size()) { const ssize_t k = ::write(fd, pend.data() + o, pend.size() - o); if (k <= 0) break; o += (size_t)k; } pend.clear(); }
+            int overflow(int c) override { std::lock_guard<std::mutex> lk(mu); if (c != EOF) { pend.push_back((char)c); if (c == '\n') flush_locked(); } return c == EOF ? 0 : c; }
+            std::streamsize xsputn(const char *p, std::streamsize n) override { std::lock_guard<std::mutex> lk(mu); pend.append(p, (size_t)n); if (memchr(p, '\n', (size_t)n)) flush_locked(); return n; }
+            int sync() override { std::lock_guard<std::mutex> lk(mu); flush_locked(); return 0; }
+        } buf;
+        std::streambuf *old = nullptr; int saved = -1;
+        void engage(bool silence)
+        {
+            std::cout.flush(); fflush(stdout);
+            buf.fd = dup(1);
+            if (buf.fd < 0) return;
+            old = std::cout.rdbuf(&buf);
+            if (!silence) return;
+            const int nul = ::open("/dev/null", O_WRONLY);
+            if (nul < 0) return;
+            saved = dup(1);
+            if (saved >= 0) dup2(nul, 1);
+            ::close(nul);
+        }
+        ~OwnStdout()
+        {
+            if (old) { std::cout.flush(); buf.sync(); std::cout.rdbuf(old); }
+            if (saved >= 0) { fflush(stdout); dup2(saved, 1); ::close(saved); }
+            if (buf.fd >= 0) ::close(buf.fd);
+        }
+    } own_stdout;
+    const bool rccl_maybe = list_mode && !paf && !o.site_out && api->comm_init_all && (n_ctx > 1 || comm_forced) && !comm_off;
+    if (rccl_maybe) own_stdout.engage(!tune("rccl_verbose"));
+    // -X transport=rccl: librccl's load (1.1 s warm, 5 s the first time on a box) and the communicator's bootstrap (0.6 s) start NOW, on
+    // a thread beside the header / index / annotation reads, and are waited for BEFORE the contexts are made — while the library
+    // registers its code objects it holds the runtime lock every kernel launch needs, so behind a running decode (round 5) the
+    // decode crawled (0.68 -> 2.19 s on the 3e8-record list run).  The contexts' communicators adopt the one made here.
+    struct CommAhead {
+        std::thread th; bool started = false; int rc = 0; double secs = 0;
+        void wait() { if (th.joinable()) th.join(); }
+        ~CommAhead() { wait(); }
+    } comm_ahead;
+    if (rccl_maybe && want_rccl && api->comm_preinit && (n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB"))) {
+        comm_ahead.started = true;
+        comm_ahead.th = std::thread([&, n_ctx, n_dev]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<int> devs;
+            for (int k = 0; k < n_ctx; ++k) devs.push_back((device + k) % n_dev);
+            comm_ahead.rc = api->comm_preinit(devs.data(), n_ctx);
+            comm_ahead.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
     AlnReader first;
     AlnHeader hdr;
     RefSeqs ref;                                         // -c -r: the GC(%) column (PD:3506-3538); host-side text work
@@ -1272,11 +1339,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     // One context per GPU.  A `#.list` input is sharded one file per GPU (round robin) when the engine
     // offers several devices; the contexts are summed into the first one before the statistics
     // (difference arrays are linear: PD:2704-3014 accumulates every file into one array).
-    int n_dev = 1, n_ctx = 1;
-    if (list_mode && !paf && api->device_count && api->accumulate_from && api->device_count(&n_dev) == 0 && n_dev > 0) {
-        n_ctx = n_dev;
-        if (const char *e = tune("gpus")) n_ctx = atoi(e) > 0 ? atoi(e) : 1;     // may exceed n_dev (contexts then share GPUs)
-        if (n_ctx > n_files) n_ctx = n_files;
+    if (comm_ahead.started) {
+        const auto t0 = std::chrono::steady_clock::now();
+        comm_ahead.wait();
+        if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (RCCL load + bootstrap on a thread since process entry, ahead of the contexts, rc %d; the contexts waited %.3f s for it)\n",
+                           "comm ahead", comm_ahead.secs, comm_ahead.rc, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     std::vector<std::unique_ptr<Engine>> engs;
     // (the executable leaves without tearing the engine down — the process is about to end; library users of pandepth_main keep the destroy)
@@ -1308,40 +1375,32 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     tm.mark("engine create");
     SpanIndex spans;
     spans.build(rm, hdr, synthetic);
-    // Several contexts: their RCCL communicator is made on a side thread WHILE the files are decoded (an eight-rank bootstrap takes longer
-    // than a small list run does) and joined by the first collective.  RCCL prints a banner on stdout when a communicator is made; this
-    // program's stdout is compared byte for byte with the reference's, so descriptor 1 points at /dev/null meanwhile — nothing of ours is
-    // printed between the inputs' classification (before the job starts) and "Input data read done" (after it has been joined).
-    struct Quiet {
-        int saved = -1;
-        Quiet() { std::cout.flush(); fflush(stdout); const int nul = ::open("/dev/null", O_WRONLY); if (nul < 0) return; saved = dup(1); if (saved >= 0) dup2(nul, 1); ::close(nul); }
-        ~Quiet() { if (saved >= 0) { std::cout.flush(); fflush(stdout); dup2(saved, 1); ::close(saved); } }
-    };
-    struct CommJob {
-        std::thread th; std::vector<pd_comm *> comms; int rc = -1; bool started = false, taken = false; double secs = 0; std::string why;
-        const pd_engine_api *api = nullptr;
-        void wait() { if (th.joinable()) th.join(); }
-        ~CommJob() { wait(); if (started && !taken && rc == 0 && api && api->comm_destroy) for (pd_comm *m : comms) if (m) api->comm_destroy(m); }      // (made, never used: a run that failed meanwhile)
-    } comm_job;
-    comm_job.api = api;
-    const bool comm_possible = !paf && api->comm_init_all && (n_ctx > 1 || (tune("rccl") && !strcmp(tune("rccl"), "force"))) &&
-                               (n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) && !(tune("rccl") && tune("rccl")[0] == '0');
-    auto start_comm = [&]() {
-        // (the modes whose statistics go through the sliced sum: everything but the per-site file, which adds the contexts into one GPU)
-        if (!comm_possible || o.site_out || comm_job.started) return;
-        if (tune("comm_overlap") && tune("comm_overlap")[0] == '0') return;
-        comm_job.started = true;
-        comm_job.comms.assign((size_t)n_ctx, nullptr);
-        comm_job.th = std::thread([&]() {
-            const auto t0 = std::chrono::steady_clock::now();
-            std::unique_ptr<Quiet> quiet(tune("rccl_verbose") ? nullptr : new Quiet);
-            std::vector<pd_ctx *> ctxs;
-            for (auto &e : engs) ctxs.push_back(e->ctx);
-            comm_job.rc = api->comm_init_all(ctxs.data(), n_ctx, comm_job.comms.data());
-            if (comm_job.rc != 0) { const char *m = api->strerror(engs[0]->ctx); comm_job.why = m ? m : "?"; }
-            quiet.reset();
-            comm_job.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        });
+    // Several contexts: their statistics are summed in slices by a collective (pd_sliced_*).  Transport (-X transport=peer|rccl):
+    //   peer (default)  the in-process one — this executable IS one process with a rank thread per GPU, so a rank pulls its slices out of
+    //                   its peers' buffers with xGMI peer copies; nothing to load or bootstrap (pd_comm_init_local), made in line;
+    //   rccl            north_star's transport and the one between processes (bench.py --gpus N): librccl was loaded and the communicator
+    //                   bootstrapped at process entry, AHEAD of the contexts (comm_ahead, above), and is adopted here.
+    // Whichever is chosen falls back to the other when it cannot be made, and to adding the contexts into the first GPU after that.
+    const bool comm_possible = !paf && (n_ctx > 1 || comm_forced) && !comm_off;
+    auto make_comms = [&](std::vector<pd_comm *> *comms, std::string *how) -> int {
+        std::vector<pd_ctx *> ctxs;
+        for (auto &e : engs) ctxs.push_back(e->ctx);
+        comms->assign((size_t)n_ctx, nullptr);
+        int rc = -1;
+        for (int attempt = 0; attempt < 2 && rc != 0; ++attempt) {
+            const bool rccl = (attempt == 0) == want_rccl;
+            if (rccl) {
+                if (!api->comm_init_all || !(n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB"))) continue;
+                rc = api->comm_init_all(ctxs.data(), n_ctx, comms->data());
+                *how = "RCCL";
+            } else {
+                if (!api->comm_init_local || (tune("transport") && !strcmp(tune("transport"), "rccl_only"))) continue;
+                rc = api->comm_init_local(ctxs.data(), n_ctx, comms->data());
+                *how = "in-process peer copies";
+            }
+            if (rc != 0 && tm.on) fprintf(stderr, "[timing] %s communicator unavailable (%s)\n", how->c_str(), api->strerror(eng.ctx));
+        }
+        return rc;
     };
 
     bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
@@ -1389,7 +1448,6 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             o_part.threads = std::max(1, o.threads / n_ctx);
             o_part.decode_readers = 4;
         }
-        start_comm();
         auto run_inputs = [&](int k) {
             Engine *e = engs[k].get();
             for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
@@ -1430,7 +1488,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     // Several GPUs hold one partial sample each.  Wide-window statistics are summed in slices over RCCL (pd_sliced_window_sum:
     // every GPU receives 1/n of the others' 4-bit images, no GPU ever holds everybody's arrays); whatever needs the summed
     // cells themselves (per-site output, annotation intervals, narrow windows) adds the contexts into the first one.
-    bool merged = n_ctx == 1 && !(tune("rccl") && !strcmp(tune("rccl"), "force"));      // (the variable: a 1-rank communicator, so that single-GPU boxes test this path)
+    bool merged = n_ctx == 1 && !comm_forced;            // (comm=force: a 1-rank communicator, so that single-GPU boxes test this path)
     auto merge_contexts = [&]() -> bool {
         if (merged) return true;
         merged = true;
@@ -1453,34 +1511,16 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
     // rank's collective; returns 1 done, 0 not applicable (no communicator, or the samples do not fit the sliced sum's 4-bit images:
     // PD_ERANGE on every rank, nothing consumed — the contexts are then added into the first one), -1 error.
     auto sliced = [&](const std::function<int(int, pd_comm *)> &call, const char *what) -> int {
-        if (merged || scanned || !(n_ctx <= n_dev || getenv("PANDEPTH_RCCL_LIB")) || !api->comm_init_all || (tune("rccl") && tune("rccl")[0] == '0')) return 0;
-        std::vector<pd_ctx *> ctxs;
-        for (auto &e : engs) ctxs.push_back(e->ctx);
-        std::vector<pd_comm *> comms((size_t)n_ctx, nullptr);
-        // RCCL announces itself on stdout (a version banner, from whichever thread first gets there); this program's stdout
-        // is compared byte for byte with the reference's, and nothing of ours is printed until the sum is done
-        std::unique_ptr<Quiet> quiet;
-        if (comm_job.started && !comm_job.taken) {
-            // the communicator made behind the decode
+        if (merged || scanned || !comm_possible || (!api->comm_init_all && !api->comm_init_local)) return 0;
+        std::vector<pd_comm *> comms;
+        std::string how;
+        {
             const auto t0 = std::chrono::steady_clock::now();
-            comm_job.wait();
-            comm_job.taken = true;
-            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (on a side thread behind the decode; the first collective waited %.3f s for it)\n", "comm init", comm_job.secs, waited);
-            if (comm_job.rc != 0) {
-                if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", comm_job.why.c_str(), device);
-                return 0;
-            }
-            comms = comm_job.comms;
-            quiet.reset(tune("rccl_verbose") ? nullptr : new Quiet);
-        } else {
-            quiet.reset(tune("rccl_verbose") ? nullptr : new Quiet);
-            const auto t0 = std::chrono::steady_clock::now();
-            const int irc = api->comm_init_all(ctxs.data(), n_ctx, comms.data());
-            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (in line, before the first collective)\n", "comm init", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            const int irc = make_comms(&comms, &how);
+            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (%s, in line before the first collective%s)\n", "comm init", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                               how.c_str(), comm_ahead.started ? "; librccl's load and bootstrap were done ahead of the contexts" : "");
             if (irc != 0) {
-                quiet.reset();
-                if (tm.on) fprintf(stderr, "[timing] RCCL communicator unavailable (%s): the contexts are added into GPU %d instead\n", api->strerror(eng.ctx), device);
+                if (tm.on) fprintf(stderr, "[timing] no communicator: the contexts are added into GPU %d instead\n", device);
                 return 0;
             }
         }
@@ -1498,12 +1538,11 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         for (int k = 0; k < n_ctx && !too_wide; ++k)
             if (rcs[(size_t)k] != 0 && ok) { ok = false; const char *m = api->comm_strerror ? api->comm_strerror(comms[(size_t)k]) : nullptr; eng.fail(std::string(what) + ": " + (m ? m : "?")); }
         if (api->comm_destroy) for (pd_comm *c : comms) api->comm_destroy(c);
-        quiet.reset();
         if (too_wide) {
             if (tm.on) fprintf(stderr, "[timing] the samples do not fit the sliced sum's 4-bit images: the contexts are added into GPU %d instead\n", device);
             return 0;
         }
-        if (ok && tm.on) fprintf(stderr, "[timing] %s summed over %d GPUs in slices (RCCL)\n", what, n_ctx);
+        if (ok && tm.on) fprintf(stderr, "[timing] %s summed over %d GPUs in slices (%s)\n", what, n_ctx, how.c_str());
         return ok ? 1 : -1;
     };
     // cover / depth sum of every window of `width` cells (pd_window_layout order), whichever way the sample is held

@@ -80,6 +80,17 @@ def _no_out_of_bounds_device_writes(request):
     assert n == before, "a kernel wrote outside a device buffer: " + msg.value.decode()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_backed_cli():
+    """The product's host code on the oracle-backed engine (tests/harness/pandepth_oracle_cli) is what most CPU tests execute; several
+    of them take it for granted.  It is made here once per session — per pytest-xdist worker, in turn on the build lock — so that no
+    test depends on another one's fixture having run first (a fresh tree under `-n 4` failed the fuzz test that way)."""
+    if not HAS_GPU and not os.path.exists(os.path.join(ROOT, "tests", "harness", "pandepth_oracle_cli")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pandepth_amd"), "libpandepth_host.a"], check=False, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "harness"), "pandepth_oracle_cli"], check=False, stdout=subprocess.DEVNULL)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

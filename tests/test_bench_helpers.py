@@ -35,3 +35,11 @@ def test_parse_timing_reads_the_executables_diagnostics():
     assert ph["engine create"] == 0.093 and ph["decode + scatter"] == 0.745 and ph["total_in_main"] == 0.846
     assert dec["batches"] == 498 and dec["feeders"] == 6 and dec["records_on_device"] == 300000000
     assert dec["device_ms_summed"]["inflate"] == 3000.2 and dec["inflated_bytes"] == 99000000000 and dec["compressed_bytes"] == 15900000000
+
+
+def test_spread_and_median_run():
+    sp = bench._spread([3.0, 1.0, 2.0, 10.0])
+    assert sp == {"median": 2.5, "min": 1.0, "max": 10.0, "mean": 4.0, "runs": 4}
+    assert bench._spread([5.0])["median"] == 5.0
+    walls = [2.9, 2.7, 3.4, 2.8, 3.0]
+    assert walls[bench._median_run(walls)] == 2.9 == bench._spread(walls)["median"]

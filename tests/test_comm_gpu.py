@@ -105,16 +105,19 @@ LIST_WIDE = [e for e in MANIFEST if ".list" in e["args"][1] and e["fixture"] in 
              not any(a in e["args"] for a in ("-g", "-b", "-w", "-a"))]
 
 
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
 @pytest.mark.parametrize("case", LIST_WIDE, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
-def test_cli_list_mode_sums_through_the_communicator(case, tmp_path):
+def test_cli_list_mode_sums_through_the_communicator(case, transport, tmp_path):
     """`#.list` inputs in whole-chromosome mode: one context per GPU (all of them when the box has several; one, with
-    rccl=force in PANDEPTH_TUNE, otherwise), statistics through pd_comm_init_all + pd_sliced_window_sum — same bytes as the reference."""
+    comm=force in PANDEPTH_TUNE, otherwise), statistics through the in-process communicator (default) or REAL RCCL made ahead of
+    the contexts (-X transport=rccl: pd_comm_preinit + pd_comm_init_all) + pd_sliced_window_sum — same bytes as the reference, and
+    the same stdout: RCCL's version banner must not reach it and none of our lines may be lost."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="rccl=force", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="comm=force" + (",transport=rccl" if transport == "rccl" else ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
-    assert b"in slices (RCCL)" in p.stderr, p.stderr.decode()[-800:]
+    assert (b"in slices (RCCL)" if transport == "rccl" else b"in slices (in-process peer copies)") in p.stderr, p.stderr.decode()[-800:]
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()

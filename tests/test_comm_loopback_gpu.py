@@ -31,11 +31,23 @@ def shim():
 
 CHILD = r'''
 import os, sys, threading, traceback, numpy as np
-root, world, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+root, world, mode, transport = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import pandepth_amd as pda
 from test_gpu_engine import LENS, rand_intervals, oracle_depth, windows_ref
-uid = pda.comm_unique_id()
+uid = pda.comm_unique_id() if transport == "rccl" else None
+engines, comms, bar = [None] * world, [None] * world, threading.Barrier(world)
+def make_comm(e, rank):
+    """rccl: pd_comm_init with the unique id, every rank for itself (here: the loopback stand-in for librccl);
+    local: pd_comm_init_local over every rank's context at once — the executable's in-process transport (no library)"""
+    if transport == "rccl":
+        return pda.Comm(e, uid, rank, world)
+    engines[rank] = e
+    bar.wait()
+    if rank == 0:
+        comms[:] = pda.Comm.local(engines)
+    bar.wait()
+    return comms[rank]
 K = 3                                                     # samples per rank, two in flight
 def sample(r, k, n=20000):
     rng = np.random.default_rng(1000 + 10 * r + k)
@@ -56,7 +68,7 @@ results, errors = {}, []
 def rank_main(rank):
     try:
         with pda.Engine(LENS, device=0) as e:
-            c = pda.Comm(e, uid, rank, world)
+            c = make_comm(e, rank)
             res = []
             if mode == "pipeline":
                 for k in range(K):                        # software pipeline: start(k), then finish(k - 1)
@@ -98,6 +110,7 @@ def rank_main(rank):
                     res.append(ex.code)
                 res.append(e.scan_reduce_windows(8192, 1, 18))      # the sample is still whole on this context
             results[rank] = res
+            if transport != "rccl": bar.wait()            # (a local communicator's buffers are read by the peers until every rank is done)
             c.close()
     except Exception:                                       # noqa: BLE001
         errors.append("rank %d: %s" % (rank, traceback.format_exc()))
@@ -152,49 +165,61 @@ print("LOOPBACK-OK", world, mode)
 '''
 
 
-def _run(world, mode, shim):
-    p = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(world), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                       timeout=360, env=dict(os.environ, PANDEPTH_RCCL_LIB=shim))
+TRANSPORTS = ["rccl", "local"]       # rccl: the library's RCCL calls through the loopback stand-in; local: the in-process peer-copy transport (pd_local_comm.h)
+
+
+def _run(world, mode, shim, transport="rccl"):
+    env = dict(os.environ, PANDEPTH_RCCL_LIB=shim) if transport == "rccl" else {k: v for k, v in os.environ.items() if k != "PANDEPTH_RCCL_LIB"}
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(world), mode, transport], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=360, env=env)
     assert p.returncode == 0 and "LOOPBACK-OK %d %s" % (world, mode) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_sliced_sum_n_ranks_through_the_library(world, shim):
+def test_sliced_sum_n_ranks_through_the_library(world, shim, transport):
     """pd_comm_init (unique id, one thread per rank) + pd_sliced_sum_start / _finish: three samples pipelined through the two
     slots with the root on the LAST rank, then the deferred (direct export) form with the root on rank 0."""
-    _run(world, "pipeline", shim)
+    _run(world, "pipeline", shim, transport)
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_cell_level_statistics_n_ranks(world, shim):
+def test_cell_level_statistics_n_ranks(world, shim, transport):
     """pd_sliced_window_sum for windows below 8192 cells and pd_sliced_interval_sum: every rank turns its slice of the exchanged
     images into depth cells and reduces the windows / region stretches that lie in it — against the oracle on the summed samples
     (windows of 100, 149, 1000, 4096 and 8191 cells incl. the ones across tile and slice boundaries; 4000 regions incl. a whole
     contig and regions that start or end on a tile edge; with and without the 18-bit wrap; a deferred sample)."""
-    _run(world, "cells", shim)
+    _run(world, "cells", shim, transport)
 
 
-def test_exception_overflow_is_a_clean_decline_on_every_rank(shim):
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_exception_overflow_is_a_clean_decline_on_every_rank(shim, transport):
     """A sample whose 4-bit image has more out-of-range cells than the exception block holds: PD_ERANGE everywhere, and every
     context still holds its sample (the executable then adds the contexts up with pd_accumulate_from)."""
-    _run(3, "overflow", shim)
+    _run(3, "overflow", shim, transport)
 
 
 LIST_WIDE = [e for e in MANIFEST if ".list" in e["args"][1] and e["fixture"] in ("f1", "f2") and "-a" not in e["args"]]
 
 
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
 @pytest.mark.parametrize("gpus", ["2", "3"])
 @pytest.mark.parametrize("case", LIST_WIDE, ids=lambda e: "%s-%s" % (e["fixture"], e["name"]))
-def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, shim, tmp_path):
-    """`#.list` inputs: one context per (stand-in) GPU, pd_comm_init_all + pd_sliced_window_sum / pd_sliced_interval_sum with N = 2
-    and 3 ranks — the same bytes as the reference for whole-chromosome tables, `-w` tables of any width and `-g` / `-b` tables."""
+def test_cli_list_mode_over_n_contexts_through_the_communicator(case, gpus, transport, shim, tmp_path):
+    """`#.list` inputs: one context per (stand-in) GPU, pd_comm_init_local (the executable's default: in-process peer copies) or
+    pd_comm_preinit + pd_comm_init_all (-X transport=rccl: here the loopback stand-in) + pd_sliced_window_sum / pd_sliced_interval_sum
+    with N = 2 and 3 ranks — the same bytes as the reference for whole-chromosome tables, `-w` tables of any width and `-g` / `-b` tables."""
     d = os.path.join(HERE, "golden", case["fixture"])
-    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="gpus=" + gpus, PANDEPTH_RCCL_LIB=shim)
+    env = dict(os.environ, PANDEPTH_TIMING="1", PANDEPTH_TUNE="gpus=" + gpus + (",transport=rccl" if transport == "rccl" else ""), PANDEPTH_RCCL_LIB=shim)
     p = subprocess.run([CLI] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
     # whole-chromosome bins, narrow windows and annotation intervals alike: nobody adds the contexts into one GPU
-    assert b"in slices (RCCL)" in p.stderr and b"added into GPU" not in p.stderr, p.stderr.decode()[-800:]
+    how = b"in slices (RCCL)" if transport == "rccl" else b"in slices (in-process peer copies)"
+    assert how in p.stderr and b"added into GPU" not in p.stderr and b"communicator unavailable" not in p.stderr, p.stderr.decode()[-800:]
+    if transport == "rccl":
+        assert b"comm ahead" in p.stderr, p.stderr.decode()[-800:]      # made at process entry, adopted by the contexts
     assert p.stdout.decode() == case["stdout"]
     for suffix, meta in case["outputs"].items():
         gz = (tmp_path / ("o." + suffix)).read_bytes()

@@ -38,3 +38,34 @@ def test_patch_blocks_are_the_documents():
     assert sorted(b[0] for b in bl) == sorted(ip.ANCHOR)
     src = ip.patched_source()
     assert src.count('#include "pandepth_amd.h"') == 1 and src.count("pd_reduce_intervals(ctx") == 1 and "pd_push_intervals(ctx, runs.data()" in src
+
+
+# ---- the patched reference RUNS: built by __graft_entry__.build() in the dev container (oracle/_ref/pandepth_patched, untracked like pandepth_ref,
+# travels to the GPU box), executed here on the MI355X on the golden fixtures' per-site cases — the reference's own main, option parser, region model,
+# htslib record loop, table and per-site writers, with the depth arrays, the increments and the statistics behind the C-ABI (PD:434-461, 329-348, 4278-4281)
+import hashlib
+import json
+
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "pandepth_patched")
+MANIFEST = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
+# the indexed per-site path the six blocks cover (PD:4127-4284): indexed BAM + -a, not the mode-6 sweep (-w < 150), not -s / lists / SAM
+PATCHED_CASES = [c for c in MANIFEST if (c["fixture"], c["name"]) in {("f1", "chr_a"), ("f1", "w200_a"), ("f1", "gff_a"), ("f1", "bed3_a"), ("f2", "chr_a"),
+                                                                         ("f2", "bed4_a"), ("f4", "bed4_a")}]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PATCHED_CASES, ids=lambda c: "%s-%s" % (c["fixture"], c["name"]))
+def test_patched_reference_runs_on_the_engine(case, tmp_path):
+    if not os.access(PATCHED, os.X_OK):
+        if os.access(os.path.join(ROOT, "oracle", "_ref", "pandepth_ref"), os.X_OK):
+            pytest.fail("oracle/_ref/pandepth_ref travelled here but pandepth_patched did not: __graft_entry__.build() makes both")
+        pytest.skip("oracle/_ref/ was not built where this tree comes from (no reference checkout there)")
+    d = os.path.join(HERE, "golden", case["fixture"])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "pandepth_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([PATCHED] + case["args"] + ["-o", str(tmp_path / "o"), "-t", "4"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert p.returncode == case["returncode"], p.stderr.decode()[-800:]
+    assert p.stdout.decode() == case["stdout"]
+    assert len(case["outputs"]) == 2
+    for suffix, meta in case["outputs"].items():
+        gz = (tmp_path / ("o." + suffix)).read_bytes()
+        assert hashlib.sha256(gz).hexdigest() == meta["gz_sha256"], suffix + " (gz bytes)"

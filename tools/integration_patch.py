@@ -13,7 +13,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 # marker kind -> a token that must occur on the first line of the range (replace) or on the line itself (insert after)
-ANCHOR = {"include": "unordered_map", "create": "}", "increment": "sam_itr_next", "no_stat_in_worker": "StatChrDepthLowMEM", "statistics": "}"}
+ANCHOR = {"include": "unordered_map", "create": "}", "increment": "sam_itr_next", "no_stat_in_worker": "StatChrDepthLowMEM", "statistics": "}", "site_rows": "int32_t j"}
 
 
 def blocks(md):
