@@ -764,6 +764,8 @@ def main():
     eng = pda.Engine(lens.astype(np.uint32), device=local)
     if os.environ.get("PD_BENCH_SWEEP_I4_FAST") == "0":     # (A/B of the sliced sum's packed statistics kernel, N > 1 legs only)
         eng.set_param("sweep_i4_fast", 0)
+    if os.environ.get("PD_BENCH_DIRECT_UN"):                # (A/B of the direct kernel's forms: "direct_un", see launch_direct_c8)
+        eng.set_param("direct_un", int(os.environ["PD_BENCH_DIRECT_UN"]))
     # the two run streams the product's GPU decoder leaves in HBM (pd_decode_end): every read's first run (position sorted)
     # and its later runs (D / I / N reads), which trail the sorted order by at most the longest gap
     first, other = synth.gen_runs_torch(lens, R, dev, seed=42 + rank)

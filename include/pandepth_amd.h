@@ -312,6 +312,10 @@ int pd_comm_init_local(pd_ctx **ctxs, int n, pd_comm **comms);
  * decode down 3x, ahead of it nothing.  devices == NULL: load the library only.  PD_ENODEV without librccl. */
 int pd_comm_preinit(const int *devices, int n);
 int pd_comm_destroy(pd_comm *comm);
+/* A slot's exchange buffers (twice the 4-bit image: 3 GB per rank for a 3 Gb genome) are allocated by the first pd_sliced_sum_start
+ * that uses the slot; pd_comm_prepare makes them NOW — not collective, callable from any thread while the context is being filled
+ * (the executable does, beside the decode of the rank's file: the allocation costs tenths of a second). */
+int pd_comm_prepare(pd_comm *comm, int slot);
 const char *pd_comm_strerror(const pd_comm *comm);
 int pd_sliced_window_sum(pd_comm *comm, uint32_t w, uint32_t min_dep, unsigned wrap_bits, int root, uint32_t *cover, uint64_t *sum);
 /* Windows narrower than 8192 cells and annotation intervals need the summed CELLS, not per-tile partials: for those every rank turns its

@@ -96,6 +96,7 @@ def load():
         "pd_comm_init_local": (I, [ctypes.POINTER(P), I, ctypes.POINTER(P)]),
         "pd_comm_preinit": (I, [ctypes.POINTER(I), I]),
         "pd_comm_destroy": (I, [P]),
+        "pd_comm_prepare": (I, [P, I]),
         "pd_comm_strerror": (ctypes.c_char_p, [P]),
         "pd_sliced_window_sum": (I, [P, ctypes.c_uint32, ctypes.c_uint32, U, I, P, P]),
         "pd_sliced_interval_sum": (I, [P, P, SZ, ctypes.c_uint32, U, I, P, P]),
@@ -123,7 +124,7 @@ EXPORTS = ["pd_abi_version", "pd_create", "pd_destroy", "pd_strerror", "pd_reset
            "pd_push_intervals_device", "pd_runs_create", "pd_runs_destroy", "pd_push_runs", "pd_stage_acquire", "pd_stage_submit", "pd_set_param", "pd_keep_deferred", "pd_scan",
            "pd_reduce_intervals", "pd_window_layout", "pd_scan_reduce_windows", "pd_reduce_windows",
            "pd_read_depth", "pd_format_sites", "pd_deflate_parse", "pd_host_register", "pd_host_unregister", "pd_text_open", "pd_text_close", "pd_text_append_sites", "pd_text_parse", "pd_text_read", "pd_text_release", "pd_text_append_window_rows", "pd_text_append_bytes", "pd_device_buffer", "pd_device_count", "pd_accumulate_from", "pd_device_layout", "pd_export_i8", "pd_import_i8", "pd_export_i4",
-           "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_queue", "pd_decode_collect", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_init_local", "pd_comm_preinit", "pd_comm_destroy",
+           "pd_slice_sweep_i4", "pd_gather_windows", "pd_push_bgzf_units", "pd_decode_begin", "pd_decode_acquire", "pd_decode_submit", "pd_decode_queue", "pd_decode_collect", "pd_decode_end", "pd_decode_abort", "pd_comm_unique_id", "pd_comm_init", "pd_comm_init_all", "pd_comm_init_local", "pd_comm_preinit", "pd_comm_prepare", "pd_comm_destroy",
            "pd_comm_strerror", "pd_sliced_window_sum", "pd_sliced_interval_sum", "pd_sliced_sum_start", "pd_sliced_sum_finish", "pd_x_bgzf_inflate", "pd_stream", "pd_synchronize", "pd_profile",
            "pd_profile_get", "pd_guard_check", "pd_guard_selftest"]
 

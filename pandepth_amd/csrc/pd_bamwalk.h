@@ -127,8 +127,41 @@ PW_FN Rec open_record(const Cfg &c, uint64_t p, uint32_t bs)
     x.keep = !(flag & c.flag_mask) && (int32_t)mapq >= c.min_mapq && x.tid >= 0 && x.tid < c.n_ref;
     if (x.keep && !c.contig_on[x.tid]) x.keep = 0;
     if ((uint64_t)32 + l_name + 4ull * x.n_cig > bs) { x.keep = 0; x.flags = WF_BAD; }      // the host reader fails such a record
-    // CIGAR kept in the CG tag (htslib: first operation <l_seq>S on a placed read): the host decodes that unit
-    else if (x.n_cig >= 1 && x.tid >= 0 && x.pos >= 0 && (rd32(x.cig) & 0xf) == 4 && (rd32(x.cig) >> 4) == l_seq && x.keep) x.flags = WF_HOST;
+    // CIGAR kept in the CG tag (more than 65 535 operations: long reads).  htslib's test (bam_tag2cigar), as host/bam.cpp restates it: a
+    // first operation <l_seq>S on a placed read, and the FIRST CG tag of the record of type B,I or B,i with at least n_cigar entries that
+    // lie inside the record — then the tag's operations are the CIGAR; without such a tag the placeholder is kept.  Until round 6 the
+    // lane flagged the record (WF_HOST) and the whole unit went to the host reader: every batch of a long-read file.  The record's
+    // bytes all lie below c.avail (the caller has checked p + 4 + bs), so the lane may walk its tags here; one record in a hundred.
+    else if (x.n_cig >= 1 && x.tid >= 0 && x.pos >= 0 && (rd32(x.cig) & 0xf) == 4 && (rd32(x.cig) >> 4) == l_seq && x.keep) {
+        const uint64_t end = p + 4 + (uint64_t)bs;
+        uint64_t a = p + 36 + l_name + 4ull * x.n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+        if (a > end) a = end;
+        while (a + 3 <= end) {
+            const uint8_t t0 = c.buf[a], t1 = c.buf[a + 1], ty = c.buf[a + 2];
+            a += 3;
+            uint64_t sz = 0;
+            if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+            else if (ty == 's' || ty == 'S') sz = 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+            else if (ty == 'Z' || ty == 'H') {
+                uint64_t z = a;
+                while (z < end && c.buf[z] != 0) ++z;
+                if (z >= end) break;
+                sz = z - a + 1;
+            } else if (ty == 'B') {
+                if (a + 5 > end) break;
+                const uint8_t st = c.buf[a];
+                const uint32_t cnt = rd32(c.buf + a + 1);
+                const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G') {
+                    if ((st == 'I' || st == 'i') && cnt >= x.n_cig && cnt < (1u << 29) && a + 5 + 4ull * cnt <= end) { x.cig = c.buf + a + 5; x.n_cig = cnt; }
+                    break;
+                }
+                sz = 5 + es * cnt;
+            } else break;
+            a += sz;
+        }
+    }
     return x;
 }
 

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <map>
@@ -232,6 +233,9 @@ struct pd_ctx {
                                                                   // chunks of 8 + 2 KiB share a CU's LDS (158 KB: 32 KiB of history + their text), 16 waves per CU — 8.6 ms against 11.8 for the 60 MB call of
                                                                   // profiles/r04_lz_parse_ab.txt, and the text is fetched once instead of ~1 000 times; chunks of 16 KiB fit seven to a CU and lose
     unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
+    std::atomic<uint32_t> dec_oth_div{41};                        // inflated bytes per slot for a later run in a batch's arrays: 41 (a kept record's minimum size) until a batch
+                                                                  // does not fit (long reads: a later run per 8 bytes of CIGAR), then 8 for the batches that follow
+    int dec_h2d_kernel = 0;                                       // "decode_h2d_kernel": a batch's compressed bytes fetched from the pinned buffer by a copy KERNEL on the batch's stream instead of the copy engine
     bool dec_fast = true;                                         // the record chain of a batch is confirmed on the device where the session allows it ("decode_fast")
     uint32_t dec_spoil = 0;                                       // test hook: every k-th segment's guess is spoilt after pass 1 ("decode_spoil")
     uint32_t dec_max_redo = 256;                                  // ... with at most this many segments walking again per batch ("decode_max_redo")
@@ -825,6 +829,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "inflate_waves")) { if (value < 1 || value > 24) return fail(c, PD_EINVAL, "inflate_waves must be in [1, 24]"); c->dec_waves = (unsigned)value; return PD_OK; }
     if (!strcmp(name, "decode_spoil")) { c->dec_spoil = value > 0xFFFFFFFFull ? 0u : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
+    if (!strcmp(name, "decode_h2d_kernel")) { c->dec_h2d_kernel = (int)value; return PD_OK; }
     if (!strcmp(name, "decode_max_redo")) { c->dec_max_redo = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
@@ -1626,7 +1631,8 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     // one byte, one operation): inflated / 41 first runs is a bound, not an estimate.  Later runs are bounded only by the CIGAR bytes;
     // the same number of slots (several times what real reads need) is given and the chain kernel checks that they suffice.
     J.fast = c->dec_fast && !guess && (c8 || c->dec_near_span == 0xFFFFFFFFu);      // (every session whose units start at known records and whose later runs are one stream)
-    J.cap_first = J.cap_other = J.fast ? bt->inflated_bytes / 41 + 64 : 0;
+    J.cap_first = J.fast ? bt->inflated_bytes / 41 + 64 : 0;
+    J.cap_other = J.fast ? bt->inflated_bytes / c->dec_oth_div.load() + 64 : 0;
     // (the inflate kernel's LDS lets 20 one-wave workgroups share a CU; "inflate_waves": fewer per launch, so that several batches' launches share the GPU)
     const unsigned n_wg = (unsigned)c->n_cu * c->dec_waves;
     int rc;
@@ -1679,11 +1685,17 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     J.timed = g_dec_timing;
     if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], st));
     memset((uint8_t *)bt->host_buf + bt->n_bytes, 0, 64);                  // (the decoder reads up to 8 bytes past a member's end)
-    HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, st));
+    // ("decode_h2d_kernel": the copy engine's transfer and the kernel behind it are ordered by a signal between two engines — 2.2 ms of idle queue per
+    // batch in profiles/r05_decode_timeline.txt; a copy kernel reads the pinned bytes over the link itself and the inflate kernel follows it in the same queue)
+    // (3: no copy at all — the inflate kernel reads the members straight out of the pinned buffer, which the slot holds until the batch is collected)
+    if (c->dec_h2d_kernel == 3) d_blob = (uint8_t *)bt->host_buf;
+    else if (c->dec_h2d_kernel) launch_copy_words(st, d_blob, bt->host_buf, (bt->n_bytes + 64 + 3) / 4);
+    else HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, st));
     memcpy(pin + J.o_blk, J.blocks.data(), (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
     memcpy(pin + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
     memset(pin + J.o_next, 0, 256);
-    HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, st));
+    if (c->dec_h2d_kernel >= 2) launch_copy_words(st, d_tab, pin, (J.o_up + 3) / 4);
+    else HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, st));
     if (J.timed) HIPDEC(hipEventRecord(sl.ev[1], st));
     launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)(d_tab + J.o_blk), bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc,
                              (uint32_t *)(d_tab + J.o_next), false);
@@ -1811,6 +1823,9 @@ int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_
         // ---- out of the ordinary (ChainOut::slow says why; nothing was emitted): the member statuses and the segments as they stand come
         // to the host, which goes through the batch the way it always has
         ++c->dec_n_slow;
+        // (more later runs than the batch's array holds — reads with thousands of CIGAR operations: the batches queued from now on get
+        // a slot per 8 inflated bytes, which an alternation of matches and gaps cannot exceed)
+        if ((co.slow & pdb2::CH_ROOM) && co.n_first <= J.cap_first) c->dec_oth_div.store(8);
         HIPDEC(hipMemcpyAsync(pin + J.o_bst, sl.d[DS_ST], (size_t)n_blocks * 4, hipMemcpyDeviceToHost, st));
         HIPDEC(hipMemcpyAsync(pin + J.o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
         HIPDEC(hipStreamSynchronize(st));
@@ -2400,7 +2415,7 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_export");
       if (c8) launch_direct_c8_export(c->stream, c->pend[0].cr->view(), tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap,
-                                      dev_count, c->sums, c->direct_words + 16, c->direct_words + 2, grid);
+                                      dev_count, c->sums, c->direct_words + 16, c->direct_words + 2, grid, c->direct_un);
       else launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
                                 c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
     HIPOK(c, hipGetLastError());
@@ -3036,6 +3051,28 @@ int comm_fail(pd_comm *m, int code, const std::string &msg) { m->err = msg; if (
 #define NCCLOK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + (m)->tp->GetErrorString(r_)); } while (0)
 #define HIPCM(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return comm_fail(m, PD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
+// a slot's exchange buffers, on first use (the calling rank's thread; its device is current)
+int slot_setup(pd_comm *m, pd_comm::Slot &s)
+{
+    if (s.send) return PD_OK;
+    pd_ctx *c = m->ctx;
+    const size_t W = (size_t)m->world, img = (size_t)(c->n_cells / 2), all = W * (size_t)m->slice_bytes + 256;
+    // one rank: nothing is received — the "received" slices are the image itself
+    if (hipMalloc(&s.send, all) != hipSuccess || (W > 1 && hipMalloc(&s.recv, all) != hipSuccess) ||
+        hipMalloc(&s.meta, (m->n_sums + W + 16) * 4) != hipSuccess || hipMalloc(&s.exc, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess ||
+        hipMalloc(&s.exc_all, W * COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess || hipMalloc(&s.count, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
+    }
+    if (W == 1) s.recv = s.send;
+    HIPCM(m, hipEventCreateWithFlags(&s.packed, hipEventDisableTiming));
+    HIPCM(m, hipEventCreateWithFlags(&s.landed, hipEventDisableTiming));
+    // (the export writes every byte of the image every time: only the padding behind it — the last slice's tail — must be, and stay, zero)
+    if (all > img) HIPCM(m, hipMemsetAsync(s.send + img, 0, all - img, c->stream));
+    HIPCM(m, hipMemsetAsync(s.exc, 0, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), c->stream));
+    return PD_OK;
+}
+
 int comm_setup(pd_comm *m)
 {
     pd_ctx *c = m->ctx;
@@ -3049,16 +3086,8 @@ int comm_setup(pd_comm *m)
     HIPCM(m, hipStreamCreateWithFlags(&m->links, hipStreamNonBlocking));
     HIPCM(m, hipEventCreateWithFlags(&m->swept, hipEventDisableTiming));
     HIPCM(m, hipEventCreateWithFlags(&m->gathered, hipEventDisableTiming));
-    for (pd_comm::Slot &s : m->slot) {
-        if (hipMalloc(&s.send, W * m->slice_bytes + 256) != hipSuccess || hipMalloc(&s.recv, W * m->slice_bytes + 256) != hipSuccess ||
-            hipMalloc(&s.meta, (m->n_sums + W + 16) * 4) != hipSuccess || hipMalloc(&s.exc, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess ||
-            hipMalloc(&s.exc_all, W * COMM_EXC_BLOCK * sizeof(pd_exc)) != hipSuccess || hipMalloc(&s.count, 64) != hipSuccess)
-            return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
-        HIPCM(m, hipEventCreateWithFlags(&s.packed, hipEventDisableTiming));
-        HIPCM(m, hipEventCreateWithFlags(&s.landed, hipEventDisableTiming));
-        HIPCM(m, hipMemsetAsync(s.send, 0, W * m->slice_bytes + 256, c->stream));          // the tail beyond n_cells / 2 stays zero
-        HIPCM(m, hipMemsetAsync(s.exc, 0, (size_t)COMM_EXC_BLOCK * sizeof(pd_exc), c->stream));
-    }
+    // (the slots' exchange buffers — twice the 4-bit image per slot, 3 GB for a 3 Gb genome — are made by the first pd_sliced_sum_start that
+    // uses the slot: a device allocation of that size costs tenths of a second, and the executable only ever uses slot 0)
     if (hipMalloc(&m->part_mine, m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess ||
         hipMalloc(&m->part_all, W * m->slice_tiles * PD_TILE_PARTIAL_BYTES + 64) != hipSuccess)
         return comm_fail(m, PD_ENOMEM, "pd_comm: buffer allocation failed");
@@ -3139,12 +3168,20 @@ static int comm_init_over(Rccl &tp, const char *what, pd_ctx **ctxs, int n, pd_c
         ctxs[0]->err = &tp == &rccl() ? std::string("ncclCommInitAll failed") : std::string(what) + ": no peer access between the contexts' GPUs";
         return PD_EHIP;
     }
-    int rc = PD_OK;
+    // every rank's buffers side by side (one thread per rank: allocations on eight devices in a row were most of a list run's start-up)
+    std::vector<int> rcs((size_t)n, PD_OK);
     for (int i = 0; i < n; ++i) {
         pd_comm *m = new pd_comm; m->ctx = ctxs[i]; m->tp = &tp; m->rank = i; m->world = n; m->nccl = nc[(size_t)i];
         comms[i] = m;
-        if (rc == PD_OK) rc = comm_setup(m);
     }
+    if (n == 1) rcs[0] = comm_setup(comms[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[(size_t)i] = comm_setup(comms[i]); });
+        for (auto &t : th) t.join();
+    }
+    int rc = PD_OK;
+    for (int i = 0; i < n; ++i) if (rcs[(size_t)i] != PD_OK && rc == PD_OK) { rc = rcs[(size_t)i]; std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = comms[i]->err; }
     if (rc) for (int i = 0; i < n; ++i) { pd_comm_destroy(comms[i]); comms[i] = nullptr; }
     return rc;
 }
@@ -3161,7 +3198,7 @@ int pd_comm_destroy(pd_comm *m)
     if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
     if (m->nccl && m->tp) (void)m->tp->CommDestroy(m->nccl);
     for (pd_comm::Slot &s : m->slot) {
-        for (void *p : {(void *)s.send, (void *)s.recv, (void *)s.meta, (void *)s.exc, (void *)s.exc_all, (void *)s.count}) if (p) (void)hipFree(p);
+        for (void *p : {(void *)s.send, (void *)(s.recv == s.send ? nullptr : s.recv), (void *)s.meta, (void *)s.exc, (void *)s.exc_all, (void *)s.count}) if (p) (void)hipFree(p);
         if (s.packed) (void)hipEventDestroy(s.packed);
         if (s.landed) (void)hipEventDestroy(s.landed);
     }
@@ -3177,6 +3214,15 @@ int pd_comm_destroy(pd_comm *m)
 
 const char *pd_comm_strerror(const pd_comm *m) { return m ? m->err.c_str() : ""; }
 
+// The slot's exchange buffers now instead of at its first pd_sliced_sum_start: not collective, any thread (the executable calls it on a
+// side thread while the rank's file is being decoded: 3 GB of device allocations per rank for a 3 Gb genome are tenths of a second).
+int pd_comm_prepare(pd_comm *m, int slot)
+{
+    if (!m || slot < 0 || slot > 1) return PD_EINVAL;
+    HIPCM(m, hipSetDevice(m->ctx->device));
+    return slot_setup(m, m->slot[slot]);
+}
+
 // Collective, first half: packs the context's sample (pd_export_i4) into `slot` and puts it on the links.  Only enqueues: the
 // context may be reset and refilled right away, and the other slot may be started before this one is finished.
 int pd_sliced_sum_start(pd_comm *m, int slot)
@@ -3189,12 +3235,14 @@ int pd_sliced_sum_start(pd_comm *m, int slot)
     HIPCM(m, hipSetDevice(c->device));
     hipStream_t st = c->stream, ln = m->links;
     // 1. this rank's 4-bit image (straight from the tile windows in LDS when the sample is still deferred), its own slice in place
-    int rc = pd_export_i4(c, s.send, s.exc, COMM_EXC_BLOCK, s.count);
+    int rc = slot_setup(m, s);
+    if (rc) return rc;
+    rc = pd_export_i4(c, s.send, s.exc, COMM_EXC_BLOCK, s.count);
     if (rc) return comm_fail(m, rc, std::string("pd_export_i4: ") + c->err);
     HIPCM(m, hipMemcpyAsync(s.meta, c->sums, (size_t)m->n_sums * 4, hipMemcpyDeviceToDevice, st));
     HIPCM(m, hipMemsetAsync(s.meta + m->n_sums, 0, W * 4, st));
     HIPCM(m, hipMemcpyAsync(s.meta + m->n_sums + m->rank, s.count, 4, hipMemcpyDeviceToDevice, st));
-    HIPCM(m, hipMemcpyAsync(s.recv + (size_t)m->rank * sb, s.send + (size_t)m->rank * sb, sb, hipMemcpyDeviceToDevice, st));
+    if (W > 1) HIPCM(m, hipMemcpyAsync(s.recv + (size_t)m->rank * sb, s.send + (size_t)m->rank * sb, sb, hipMemcpyDeviceToDevice, st));
     HIPCM(m, hipEventRecord(s.packed, st));
     HIPCM(m, hipStreamWaitEvent(ln, s.packed, 0));
     // 2. the all-to-all: every pair of GPUs moves 1/world of the image over its own xGMI link, all links at once

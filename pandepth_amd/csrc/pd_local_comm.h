@@ -46,6 +46,27 @@ struct World {
 };
 struct Op { int kind; const void *sbuf; void *rbuf; size_t bytes; int peer; Comm *c; hipStream_t st; SendRec *rec; };   // kind 0 send, 1 receive
 
+// dst[i] += src[i] for any word count and any 4-byte alignment (the engine's own add kernel works on whole int4s of aligned arrays)
+__global__ __launch_bounds__(256) void k_local_add_words(int *__restrict__ dst, const int *__restrict__ src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const size_t n4 = n / 4;
+        int4 *d4 = reinterpret_cast<int4 *>(dst); const int4 *s4 = reinterpret_cast<const int4 *>(src);
+        for (size_t k = i; k < n4; k += stride) { int4 a = d4[k]; const int4 b = s4[k]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; d4[k] = a; }
+        for (size_t k = n4 * 4 + i; k < n; k += stride) dst[k] += src[k];
+        return;
+    }
+    for (; i < n; i += stride) dst[i] += src[i];
+}
+inline void add_words(hipStream_t st, int *dst, const int *src, size_t n)
+{
+    if (!n) return;
+    size_t g = (n / 4 + 255) / 256 + 1; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_local_add_words, dim3((unsigned)g), dim3(256), 0, st, dst, src, n);
+}
+
 inline void break_world(World *w) { { std::lock_guard<std::mutex> lk(w->mu); w->broken = true; } w->cv.notify_all(); }
 #define PDL_HIP(c, call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); break_world((c)->w); return ncclUnhandledCudaError; } } while (0)
 
@@ -172,13 +193,13 @@ inline ncclResult_t AllReduce(const void *sendbuf, void *recvbuf, size_t count, 
     Comm *c = (Comm *)comm;
     if (!c || (dt != ncclInt32 && dt != ncclUint32) || op != ncclSum) return ncclInvalidArgument;
     World *w = c->w;
-    const size_t bytes = count * 4, peers = (size_t)w->n - 1;
-    if (c->stage_cap < peers * bytes) {
+    const size_t bytes = count * 4, slot = (bytes + 255) & ~(size_t)255, peers = (size_t)w->n - 1;
+    if (c->stage_cap < peers * slot) {
         PDL_HIP(c, hipStreamSynchronize(st));
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr; c->stage_cap = 0;
-        if (peers * bytes && hipMalloc(&c->stage, peers * bytes + 256) != hipSuccess) { (void)hipGetLastError(); break_world(w); return ncclSystemError; }
-        c->stage_cap = peers * bytes;
+        if (peers * slot && hipMalloc(&c->stage, peers * slot + 256) != hipSuccess) { (void)hipGetLastError(); break_world(w); return ncclSystemError; }
+        c->stage_cap = peers * slot;
     }
     ncclResult_t rc = publish(c, sendbuf, st);
     if (rc != ncclSuccess) return rc;
@@ -187,13 +208,13 @@ inline ncclResult_t AllReduce(const void *sendbuf, void *recvbuf, size_t count, 
         if (p == c->rank) continue;
         const Comm *pc = w->member[(size_t)p];
         PDL_HIP(c, hipStreamWaitEvent(st, pc->ready, 0));
-        if (bytes) PDL_HIP(c, hipMemcpyPeerAsync((char *)c->stage + k * bytes, c->device, w->pub[(size_t)p], pc->device, bytes, st));
+        if (bytes) PDL_HIP(c, hipMemcpyPeerAsync((char *)c->stage + k * slot, c->device, w->pub[(size_t)p], pc->device, bytes, st));
         ++k;
     }
     rc = retire(c, st);
     if (rc != ncclSuccess) return rc;
     if (recvbuf != sendbuf && bytes) PDL_HIP(c, hipMemcpyAsync(recvbuf, sendbuf, bytes, hipMemcpyDeviceToDevice, st));
-    for (k = 0; k < peers && count; ++k) pdk::launch_add_i32(st, (int *)recvbuf, (const int *)((const char *)c->stage + k * bytes), count);
+    for (k = 0; k < peers && count; ++k) add_words(st, (int *)recvbuf, (const int *)((const char *)c->stage + k * slot), count);
     PDL_HIP(c, hipGetLastError());
     return ncclSuccess;
 }

@@ -69,6 +69,8 @@ typedef struct pd_engine_api {
      * bootstrapped ahead of the contexts, see pd_comm_preinit */
     int (*comm_init_local)(pd_ctx **, int, pd_comm **);
     int (*comm_preinit)(const int *, int);
+    /* optional (NULL = a communicator's exchange buffers are made by its first collective): see pd_comm_prepare */
+    int (*comm_prepare)(pd_comm *, int);
 } pd_engine_api;
 
 /* Runs one `pandepth` invocation (argv as given to main) on the engine behind `api`. */

@@ -14,7 +14,7 @@ int main(int argc, char **argv)
         pd_decode_begin, pd_decode_acquire, pd_decode_submit, pd_decode_end, pd_decode_abort, pd_set_param,
         pd_comm_init_all, pd_sliced_window_sum, pd_comm_destroy, pd_comm_strerror, pd_format_sites, pd_keep_deferred, pd_deflate_parse, pd_host_register, pd_host_unregister,
         pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes, pd_sliced_interval_sum,
-        pd_decode_queue, pd_decode_collect, pd_comm_init_local, pd_comm_preinit,
+        pd_decode_queue, pd_decode_collect, pd_comm_init_local, pd_comm_preinit, pd_comm_prepare,
     };
     // The decoder keeps six batches in flight on six streams (plus the statistics, compose and parse streams); the runtime maps a
     // process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait for

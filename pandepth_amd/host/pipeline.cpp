@@ -444,6 +444,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo", "lz_mix"})                                                                           // (tuning / test hooks)
         if (const char *e = tune(k)) if (api->set_param) (void)api->set_param(eng->ctx, k, (uint64_t)std::max(0, atoi(e)));
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
+    if (const char *e = tune("h2d_kernel")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_kernel", (uint64_t)std::max(0, atoi(e)));      // (tuning)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
     const size_t n_batches = batches.size();
@@ -1234,7 +1235,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             if (buf.fd >= 0) ::close(buf.fd);
         }
     } own_stdout;
-    const bool rccl_maybe = list_mode && !paf && !o.site_out && api->comm_init_all && (n_ctx > 1 || comm_forced) && !comm_off;
+    const bool rccl_maybe = !paf && !o.site_out && api->comm_init_all && (n_ctx > 1 || comm_forced) && !comm_off;      // (comm=force: also for a single input)
     if (rccl_maybe) own_stdout.engage(!tune("rccl_verbose"));
     // -X transport=rccl: librccl's load (1.1 s warm, 5 s the first time on a box) and the communicator's bootstrap (0.6 s) start NOW, on
     // a thread beside the header / index / annotation reads, and are waited for BEFORE the contexts are made — while the library
@@ -1402,6 +1403,31 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         }
         return rc;
     };
+    // The communicator and its exchange buffers (3 GB of device allocations per rank for a 3 Gb genome: tenths of a second) are made on a
+    // side thread BESIDE the decode and picked up by the first collective (-X comm_early=0: in line, before the first collective).  With the
+    // in-process transport nothing is loaded meanwhile — round 5's side thread loaded librccl there, which starved the decode's launches.
+    struct CommEarly {
+        std::thread th; std::vector<pd_comm *> comms; std::string how; int rc = -1; bool started = false, taken = false; double secs = 0;
+        const pd_engine_api *api = nullptr;
+        void wait() { if (th.joinable()) th.join(); }
+        ~CommEarly() { wait(); if (started && !taken && rc == 0 && api && api->comm_destroy) for (pd_comm *m : comms) if (m) api->comm_destroy(m); }   // (made, never used: a run that failed meanwhile)
+    } comm_early;
+    comm_early.api = api;
+    auto start_comm_early = [&]() {
+        if (!comm_possible || o.site_out || comm_early.started || (!api->comm_init_all && !api->comm_init_local)) return;
+        if (tune("comm_early") && tune("comm_early")[0] == '0') return;
+        comm_early.started = true;
+        comm_early.th = std::thread([&]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            comm_early.rc = make_comms(&comm_early.comms, &comm_early.how);
+            if (comm_early.rc == 0 && api->comm_prepare) {
+                std::vector<std::thread> th;
+                for (pd_comm *m : comm_early.comms) th.emplace_back([this_api = api, m] { (void)this_api->comm_prepare(m, 0); });     // (a failure shows again, with its message, at the first collective)
+                for (auto &t : th) t.join();
+            }
+            comm_early.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    };
 
     bool wrap18 = list_mode;                     // PD:2687: the #.list path always uses SiteInfo cells
     if (paf) {
@@ -1448,6 +1474,7 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
             o_part.threads = std::max(1, o.threads / n_ctx);
             o_part.decode_readers = 4;
         }
+        start_comm_early();
         auto run_inputs = [&](int k) {
             Engine *e = engs[k].get();
             for (size_t i = (size_t)k; i < inputs.size(); i += (size_t)n_ctx) {
@@ -1514,7 +1541,18 @@ extern "C" int pandepth_main(int argc, char **argv, const pd_engine_api *api, in
         if (merged || scanned || !comm_possible || (!api->comm_init_all && !api->comm_init_local)) return 0;
         std::vector<pd_comm *> comms;
         std::string how;
-        {
+        if (comm_early.started && !comm_early.taken) {
+            const auto t0 = std::chrono::steady_clock::now();
+            comm_early.wait();
+            comm_early.taken = true;
+            if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (%s: communicator + exchange buffers on a side thread beside the decode; the first collective waited %.3f s for it)\n", "comm init", comm_early.secs,
+                               comm_early.how.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            if (comm_early.rc != 0) {
+                if (tm.on) fprintf(stderr, "[timing] no communicator: the contexts are added into GPU %d instead\n", device);
+                return 0;
+            }
+            comms = comm_early.comms; how = comm_early.how;
+        } else {
             const auto t0 = std::chrono::steady_clock::now();
             const int irc = make_comms(&comms, &how);
             if (tm.on) fprintf(stderr, "[timing] %-28s %8.3f s   (%s, in line before the first collective%s)\n", "comm init", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
