@@ -194,14 +194,48 @@ PW_FN bool span_hit(const Cfg &c, int32_t tid, int32_t pos, int32_t endpos)
 
 struct LaneWalk { uint64_t e; uint32_t n_first, n_other, n_far, flags, max_span, n_rec; uint64_t key_first, key_last; uint32_t unsorted, n_long; };
 
-// records starting in [s, b): counts (emit == false) or runs written at first[of..] / other[oo..] (emit == true)
+// A record whose CIGAR the whole wave walks (round 6: long reads).  A lane walks a CIGAR one operation — one dependent load — at a
+// time; with the ~2 600 operations of a 15 kb HiFi / ONT read that is a millisecond per record while the other 63 lanes of the wave
+// idle (only a handful of records start in a 256 KiB segment).  A lane that meets a CIGAR of COOP_MIN operations or more therefore
+// stops there and leaves the record to coop_cigar: 64 operations per step, reference positions by a prefix sum of the advancing
+// lengths, the places of the runs by a prefix count.
+enum { COOP_MIN = 96 };
+struct Pending { uint64_t cig_off, next_p; uint32_t n_cig; int32_t tid, pos; };
+
+// one first run: written (EMIT) in the session's form, with the order keys and bucket marks of the compact emission riding along
 template <bool EMIT>
-PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_iv *other, pd_iv *far, uint64_t of, uint64_t oo, uint64_t ofar)
+PW_FN void first_run(const Cfg &c, LaneWalk &w, int32_t tid, int32_t beg, int32_t end, pd_iv *first, uint64_t of)
 {
-    LaneWalk w; w.e = s; w.n_first = w.n_other = w.n_far = w.flags = w.max_span = w.n_rec = 0;
-    w.key_first = NONE; w.key_last = 0; w.unsorted = w.n_long = 0;
-    uint64_t p = s;
-    for (uint32_t guard = 0; p < b && guard < SUB / 36 + 2; ++guard) {
+    if (EMIT && c.c8.r8) {                            // compact emission (wave-uniform choice)
+        const uint32_t clen = c.contig_len[tid];
+        uint32_t cb = beg < 0 ? 0u : (uint32_t)beg; if (cb > clen) cb = clen;
+        uint32_t ce = end < 0 ? 0u : (uint32_t)end; if (ce > clen) ce = clen;
+        const uint32_t len = ce > cb ? ce - cb : 0u;
+        const uint64_t flat = c.c8.contig_off[tid] + cb, G = of + w.n_first;
+        c.c8.r8[G] = R8{(uint32_t)flat, len};
+        if (w.key_first == NONE || (w.key_last >> c.c8.cshift) != (flat >> c.c8.cshift))
+            min_u64(&c.c8.marks[flat >> c.c8.cshift], ((unsigned long long)c.c8.batch << 32) | (uint32_t)G);
+        if (w.key_first == NONE) w.key_first = flat; else if (flat < w.key_last) w.unsorted = 1;
+        w.key_last = flat;
+        if (len > (1u << c.c8.cshift)) ++w.n_long;
+    } else if (EMIT) {
+        first[of + w.n_first] = pd_iv{tid, beg, end};
+        if (c.c8.seg_out) {                           // (12-byte emission with the order check riding along: key = (tid, begin) as k_runs_sorted's)
+            const uint64_t key = ((uint64_t)(uint32_t)tid << 32) | (uint32_t)beg;
+            if (w.key_first == NONE) w.key_first = key; else if (key < w.key_last) w.unsorted = 1;
+            w.key_last = key;
+        }
+    }
+}
+
+// Records starting in [p, b): counts (EMIT == false) or runs written at first[of..] / other[oo..] (EMIT == true), from where the lane
+// stands (p, guard, w: its state, so that the walk can be taken up again).  Returns true when it has stopped AT a record whose CIGAR
+// the wave is to walk (`pend` says which; nothing of that record has been counted yet but ++n_rec) — the caller adds the record's
+// runs and calls again with p = pend.next_p — and false when the lane is through (w.e = where its chain ends).
+template <bool EMIT>
+PW_FN bool walk_lane(const Cfg &c, uint64_t &p, uint64_t b, uint32_t &guard, LaneWalk &w, Pending &pend, pd_iv *first, pd_iv *other, pd_iv *far, uint64_t of, uint64_t oo, uint64_t ofar)
+{
+    for (; p < b && guard < SUB / 36 + 2; ++guard) {
         // a record that cannot be finished here stops the chain: nothing after it may be taken for a record start
         if (p + 36 > c.avail) { w.flags |= WF_MORE; p = STOPPED; break; }
         const uint32_t bs = rd32(c.buf + p);
@@ -210,6 +244,11 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
         const Rec x = open_record(c, p, bs);
         w.flags |= x.flags; ++w.n_rec;
         if (x.keep && !x.flags) {
+            if (x.n_cig >= (uint32_t)COOP_MIN && c.near_span == 0xFFFFFFFFu && !(c.spans && x.unmapped)) {
+                pend.cig_off = (uint64_t)(x.cig - c.buf); pend.next_p = p + 4 + (uint64_t)bs; pend.n_cig = x.n_cig; pend.tid = x.tid; pend.pos = x.pos;
+                ++guard;
+                return true;
+            }
             bool take = true;
             if (c.spans) {                                               // endpos first: the filter needs it
                 // htslib's bam_endpos: unmapped reads and alignments without reference bases count as one base
@@ -222,29 +261,7 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
             if (take) {
                 uint32_t nf = 0, no = 0, nfar = 0, span = 0;
                 walk_cigar(x, [&](bool is_first, int32_t beg, int32_t end) {
-                    if (is_first) {
-                        if (EMIT && c.c8.r8) {                            // compact emission (wave-uniform choice)
-                            const uint32_t clen = c.contig_len[x.tid];
-                            uint32_t cb = beg < 0 ? 0u : (uint32_t)beg; if (cb > clen) cb = clen;
-                            uint32_t ce = end < 0 ? 0u : (uint32_t)end; if (ce > clen) ce = clen;
-                            const uint32_t len = ce > cb ? ce - cb : 0u;
-                            const uint64_t flat = c.c8.contig_off[x.tid] + cb, G = of + w.n_first;
-                            c.c8.r8[G] = R8{(uint32_t)flat, len};
-                            if (w.key_first == NONE || (w.key_last >> c.c8.cshift) != (flat >> c.c8.cshift))
-                                min_u64(&c.c8.marks[flat >> c.c8.cshift], ((unsigned long long)c.c8.batch << 32) | (uint32_t)G);
-                            if (w.key_first == NONE) w.key_first = flat; else if (flat < w.key_last) w.unsorted = 1;
-                            w.key_last = flat;
-                            if (len > (1u << c.c8.cshift)) ++w.n_long;
-                        } else if (EMIT) {
-                            first[of + w.n_first] = pd_iv{x.tid, beg, end};
-                            if (c.c8.seg_out) {                           // (12-byte emission with the order check riding along: key = (tid, begin) as k_runs_sorted's)
-                                const uint64_t key = ((uint64_t)(uint32_t)x.tid << 32) | (uint32_t)beg;
-                                if (w.key_first == NONE) w.key_first = key; else if (key < w.key_last) w.unsorted = 1;
-                                w.key_last = key;
-                            }
-                        }
-                        nf = 1; return;
-                    }
+                    if (is_first) { first_run<EMIT>(c, w, x.tid, beg, end, first, of); nf = 1; return; }
                     const uint32_t d = (uint32_t)beg - (uint32_t)x.pos;
                     if (d > span) span = d;
                     if (d <= c.near_span) { if (EMIT) other[oo + w.n_other + no] = pd_iv{x.tid, beg, end}; ++no; }
@@ -257,7 +274,118 @@ PW_FN LaneWalk walk_lane(const Cfg &c, uint64_t s, uint64_t b, pd_iv *first, pd_
         p += 4 + (uint64_t)bs;
     }
     w.e = p;
-    return w;
+    return false;
+}
+
+// The M/=/X runs of ONE record's CIGAR (n operations at c.buf + cig_off), walked by the whole wave — what walk_cigar does one
+// operation at a time: a run that is the record's first and comes before any D / N is its FIRST run (reported, not written: the
+// lane that owns the record writes it, with the keys and marks of its stream), every other run is written (emit) at
+// other[obase + its rank] and counted; span = the largest distance of such a run's begin from the record's position.
+struct CoopOut { uint32_t has_first; int32_t fbeg, fend; uint32_t n_other, span; int32_t endpos; };
+template <class W>
+PW_FN CoopOut coop_cigar(const Cfg &c, uint64_t cig_off, uint32_t n, int32_t tid, int32_t pos, pd_iv *other, uint64_t obase, bool emit)
+{
+    typedef typename W::template Var<uint32_t> U;
+    CoopOut r; r.has_first = 0; r.fbeg = r.fend = 0; r.n_other = 0; r.span = 0;
+    uint32_t cur0 = (uint32_t)pos;
+    bool first_done = false, moved = false;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+        U adv, isrun, isgap, len;
+        W::each([&](int l) {
+            const uint32_t i = k0 + (uint32_t)l;
+            const uint32_t cg = i < n ? rd32(c.buf + cig_off + 4ull * i) : 0xFu;         // (15: no operation)
+            const uint32_t op = cg & 0xf;
+            len[l] = cg >> 4;
+            isrun[l] = (op == 0 || op == 7 || op == 8) ? 1u : 0u;
+            isgap[l] = (op == 2 || op == 3) ? 1u : 0u;
+            adv[l] = (isrun[l] | isgap[l]) ? len[l] : 0u;
+        });
+        uint32_t tot = 0;
+        const U ea = W::excl_scan(adv, &tot);                                              // (wraps like the reference's int cursor)
+        const uint64_t rm = W::ballot_ne(isrun, 0u), gm = W::ballot_ne(isgap, 0u);
+        int fl = -1;
+        if (!first_done) {
+            if (rm) {
+                const int f0 = ctz64(rm);
+                if (gm & (f0 ? (1ull << f0) - 1 : 0ull)) moved = true;
+                if (!moved) fl = f0;
+                first_done = true;
+            } else if (gm) moved = true;
+        }
+        const uint64_t om = fl >= 0 ? rm & ~(1ull << fl) : rm;                            // the runs that are not the record's first
+        U dd;
+        W::each([&](int l) {
+            dd[l] = 0;
+            if (!((om >> l) & 1)) return;
+            const uint32_t beg = cur0 + ea[l], d = beg - (uint32_t)pos;
+            dd[l] = d;
+            if (emit) other[obase + r.n_other + W::prefix_count(om, l)] = pd_iv{tid, (int32_t)beg, (int32_t)(beg + len[l])};
+        });
+        if (om) { const uint32_t mx = W::reduce_max(dd); if (mx > r.span) r.span = mx; }
+        if (fl >= 0) { const uint32_t fb = cur0 + W::bcast(ea, fl); r.has_first = 1; r.fbeg = (int32_t)fb; r.fend = (int32_t)(fb + W::bcast(len, fl)); }
+        r.n_other += (uint32_t)__builtin_popcountll(om);
+        cur0 += tot;
+    }
+    r.endpos = (int32_t)cur0;
+    return r;
+}
+
+// Every lane's walk of its stretch, to the end: the lanes walk on their own until each is through or stands at a record for the
+// wave; those records are walked by the wave one after the other, their runs added to their lanes' counts (or written behind the runs
+// the lane has written so far), and the lanes go on.  active[l] = 0: the lane has nothing to walk.
+template <class W, bool EMIT>
+PW_FN void run_lanes(const Cfg &c, typename W::template Var<uint32_t> &active, typename W::template Var<uint64_t> &p, const typename W::template Var<uint64_t> &b,
+                     typename W::template Var<LaneWalk> &lw, pd_iv *first, pd_iv *other, pd_iv *far, const typename W::template Var<uint64_t> &of,
+                     const typename W::template Var<uint64_t> &oo, const typename W::template Var<uint64_t> &ofar)
+{
+    typedef typename W::template Var<uint32_t> U;
+    typedef typename W::template Var<uint64_t> U64;
+    U guard, pending, pn, ptid, ppos;
+    U64 pcig, pnext, pob;
+    W::each([&](int l) { guard[l] = 0; pending[l] = 0; pn[l] = 0; ptid[l] = 0; ppos[l] = 0; pcig[l] = 0; pnext[l] = 0; pob[l] = 0; });
+    for (;;) {
+        W::each([&](int l) {
+            if (!active[l]) return;
+            Pending pd; pd.cig_off = 0; pd.next_p = 0; pd.n_cig = 0; pd.tid = 0; pd.pos = 0;
+            uint64_t pp = p[l]; uint32_t g = guard[l];
+            const bool stop = walk_lane<EMIT>(c, pp, b[l], g, lw[l], pd, first, other, far, of[l], oo[l], ofar[l]);
+            p[l] = pp; guard[l] = g;
+            pending[l] = stop ? 1u : 0u;
+            if (stop) { pcig[l] = pd.cig_off; pnext[l] = pd.next_p; pn[l] = pd.n_cig; ptid[l] = (uint32_t)pd.tid; ppos[l] = (uint32_t)pd.pos; pob[l] = oo[l] + lw[l].n_other; }
+            else active[l] = 0;
+        });
+        uint64_t pm = W::ballot_ne(pending, 0u);
+        if (!pm) break;
+        while (pm) {
+            const int j = ctz64(pm);
+            pm &= pm - 1;
+            const uint64_t cig_off = W::bcast64(pcig, j), obase = W::bcast64(pob, j);
+            const uint32_t n = W::bcast(pn, j);
+            const int32_t tid = (int32_t)W::bcast(ptid, j), pos = (int32_t)W::bcast(ppos, j);
+            // -g / -b sessions: the read counts only when it meets a target span, which takes its end — a pass that only counts, first
+            CoopOut r = coop_cigar<W>(c, cig_off, n, tid, pos, other, obase, EMIT && !c.spans);
+            U tk;
+            W::each([&](int l) {
+                tk[l] = 0;
+                if (l != j) return;
+                bool take = true;
+                if (c.spans) { const int32_t one = (int32_t)((uint32_t)pos + 1u); take = span_hit(c, tid, pos, r.endpos == pos ? one : r.endpos); }
+                tk[l] = take ? 1u : 0u;
+            });
+            const bool take = W::ballot_ne(tk, 0u) != 0;
+            if (take && EMIT && c.spans) r = coop_cigar<W>(c, cig_off, n, tid, pos, other, obase, true);
+            W::each([&](int l) {
+                if (l != j) return;
+                LaneWalk &w = lw[l];
+                if (take) {
+                    if (r.has_first) { first_run<EMIT>(c, w, tid, r.fbeg, r.fend, first, of[l]); w.n_first += 1; }
+                    w.n_other += r.n_other;
+                    if (r.span > w.max_span) w.max_span = r.span;
+                }
+                p[l] = pnext[l]; pending[l] = 0;
+            });
+        }
+    }
 }
 
 // pass 1: one wave, one segment.  lanes[64] receives every lane's start and counts for pass 2.  `hint_in` (or null: the
@@ -313,13 +441,27 @@ PW_FN WalkOut walk_segment(const Cfg &cfg, Seg &sg, LaneOut *lanes, const uint64
         }
         s[l] = g; need[l] = 1; e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = nfar[l] = 0;
     });
+    typename W::template Var<LaneWalk> lw;
+    U active;
+    U64 wp, zero64;
+    W::each([&](int l) { zero64[l] = 0; });
     for (int round = 0; round < 70; ++round) {
         W::each([&](int l) {
+            active[l] = 0; wp[l] = 0;
+            LaneWalk &w = lw[l];
+            w.e = 0; w.n_first = w.n_other = w.n_far = w.flags = w.max_span = w.n_rec = 0; w.key_first = NONE; w.key_last = 0; w.unsorted = w.n_long = 0;
             if (!need[l]) return;
             e[l] = 0; nf[l] = no[l] = fl[l] = ms[l] = nr[l] = nfar[l] = 0;
             if (s[l] == NONE) return;                                     // nothing known to start here: no information
             if (s[l] >= b[l]) { e[l] = s[l]; return; }                     // the chain passes over this lane's KiB
-            const LaneWalk w = walk_lane<false>(c, s[l], b[l], nullptr, nullptr, nullptr, 0, 0, 0);
+            active[l] = 2; wp[l] = s[l];                                   // (2: walks in this round; run_lanes clears the low states)
+        });
+        U walked;
+        W::each([&](int l) { walked[l] = active[l]; });
+        run_lanes<W, false>(c, active, wp, b, lw, nullptr, nullptr, nullptr, zero64, zero64, zero64);
+        W::each([&](int l) {
+            if (!walked[l]) return;
+            const LaneWalk &w = lw[l];
             e[l] = w.e; nf[l] = w.n_first; no[l] = w.n_other; fl[l] = w.flags; ms[l] = w.max_span; nr[l] = w.n_rec; nfar[l] = w.n_far;
         });
         // where the chain of the lanes before l ends = prefix maximum of their ends
@@ -370,13 +512,27 @@ PW_FN void emit_segment(const Cfg &cfg, const Seg &sg, const LaneOut *lanes, pd_
     const U efar = W::excl_scan(nfar, &tfar);
     typedef typename W::template Var<uint64_t> U64;
     U64 kf, kl; U bad, nl;
+    typename W::template Var<LaneWalk> lw;
+    U active;
+    U64 wp, bb, of, oo, ofr;
     W::each([&](int l) {
         kf[l] = NONE; kl[l] = 0; bad[l] = 0; nl[l] = 0;
+        LaneWalk &w = lw[l];
+        w.e = 0; w.n_first = w.n_other = w.n_far = w.flags = w.max_span = w.n_rec = 0; w.key_first = NONE; w.key_last = 0; w.unsorted = w.n_long = 0;
         const uint64_t a = sg.begin + (uint64_t)l * SUB;
-        uint64_t b = a + SUB < sg.end ? a + SUB : sg.end;
+        const uint64_t b = a + SUB < sg.end ? a + SUB : sg.end;
         const uint64_t s = lanes[l].start;
+        active[l] = 0; wp[l] = 0; bb[l] = b;
+        of[l] = sg.base_first + ef[l]; oo[l] = sg.base_other + eo[l]; ofr[l] = sg.base_far + efar[l];
         if (a >= sg.end || s == NONE || s >= b || (nf[l] | no[l] | nfar[l]) == 0) return;
-        const LaneWalk w = walk_lane<true>(c, s, b, first, other, far, sg.base_first + ef[l], sg.base_other + eo[l], sg.base_far + efar[l]);
+        active[l] = 1; wp[l] = s;
+    });
+    U walked;
+    W::each([&](int l) { walked[l] = active[l]; });
+    run_lanes<W, true>(c, active, wp, bb, lw, first, other, far, of, oo, ofr);
+    W::each([&](int l) {
+        if (!walked[l]) return;
+        const LaneWalk &w = lw[l];
         kf[l] = w.key_first; kl[l] = w.key_last; bad[l] = w.unsorted; nl[l] = w.n_long;
     });
     if (seg_out) {

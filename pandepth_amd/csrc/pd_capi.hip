@@ -2415,7 +2415,7 @@ static int direct_export(pd_ctx *c, void *dev_i4, pd_exc *dev_exc, uint32_t exc_
     if (grid > c->n_tiles) grid = (unsigned)c->n_tiles;
     { ProfScope sc(c, "direct_export");
       if (c8) launch_direct_c8_export(c->stream, c->pend[0].cr->view(), tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap,
-                                      dev_count, c->sums, c->direct_words + 16, c->direct_words + 2, grid, c->direct_un);
+                                      dev_count, c->sums, c->direct_words + 16, c->direct_words + 2, grid);
       else launch_direct_export(c->stream, ps, tab_of(c), c->d_tile_contig, (uint32_t)c->n_tiles, dev_i4, dev_exc, exc_cap, dev_count,
                                 c->sums, c->direct_words, c->direct_words + 1, c->direct_words + 16, c->direct_words + 2, grid); }
     HIPOK(c, hipGetLastError());
@@ -3158,14 +3158,17 @@ static int comm_init_over(Rccl &tp, const char *what, pd_ctx **ctxs, int n, pd_c
             std::lock_guard<std::mutex> lk(ctxs[0]->mu); ctxs[0]->err = std::string(what) + ": two contexts share a GPU (RCCL wants one rank per device)"; return PD_EINVAL; }
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
     bool made = false;
-    if (&tp == &rccl()) {          // a communicator made ahead of the contexts (pd_comm_preinit) over the same devices
+    // (NOT `&tp == &rccl()`: rccl() LOADS librccl — round 6's first in-process communicators spent 1.1 s doing exactly that, and slowed the decode
+    // beside them the way round 5's side thread had: profiles/r06_comm_transports.txt)
+    const bool is_local = &tp == &local_tp();
+    if (!is_local) {               // a communicator made ahead of the contexts (pd_comm_preinit) over the same devices
         std::lock_guard<std::mutex> lk(g_parked.mu);
         if (g_parked.devs == devs && !g_parked.nc.empty()) { nc = g_parked.nc; g_parked.nc.clear(); g_parked.devs.clear(); made = true; }
     }
     if (!made) made = tp.CommInitAll(nc.data(), n, devs.data()) == ncclSuccess;
     if (!made) {
         std::lock_guard<std::mutex> lk(ctxs[0]->mu);
-        ctxs[0]->err = &tp == &rccl() ? std::string("ncclCommInitAll failed") : std::string(what) + ": no peer access between the contexts' GPUs";
+        ctxs[0]->err = !is_local ? std::string("ncclCommInitAll failed") : std::string(what) + ": no peer access between the contexts' GPUs";
         return PD_EHIP;
     }
     // every rank's buffers side by side (one thread per rank: allocations on eight devices in a row were most of a list run's start-up)

@@ -94,7 +94,7 @@ void launch_copy_words(hipStream_t st, void *dst, const void *src, uint64_t n_wo
 void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, uint32_t wrap_mask, uint32_t w,
                       uint32_t min_dep, TilePart *part, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un);
 void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,
-                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un = 0);
+                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles);
 void launch_direct_export(hipStream_t st, const PendSet &ps, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles,
                           void *img, pd_exc *exc, uint32_t cap, uint32_t *count, int *sums, uint32_t *n_long, uint32_t *fail,
                           uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles);

@@ -727,7 +727,7 @@ __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readl
 // half-tile's: a wave stores its KiB with one 16-byte store per lane (it was eight 2-byte stores per lane).  Exceptions are
 // rare: the hot loop only notes which rows have one, a second look at those words emits them.
 template <int ROWS>
-__device__ __forceinline__ void export_packed_tile(unsigned *win, const uint64_t a, const uint64_t t, const DirectExport &ex, int *wtot, const bool zero_after = false)
+__device__ __forceinline__ void export_packed_tile(const unsigned *win, const uint64_t a, const uint64_t t, const DirectExport &ex, int *wtot)
 {
     constexpr uint32_t HT = TILE / 2;
     __shared__ __attribute__((aligned(16))) unsigned short stage[4][2 * ROWS * 64];
@@ -771,11 +771,6 @@ __device__ __forceinline__ void export_packed_tile(unsigned *win, const uint64_t
                 if (slot < ex.cap) { ex.exc[slot].cell = cell + HT; ex.exc[slot].value = xh; ex.exc[slot].pad = 0; }
             }
         }
-    }
-    if (zero_after) {                                         // (k_direct_c8<ZR>: the window is left cleared for the next tile — every lane its own rows)
-        uint4 *wz = reinterpret_cast<uint4 *>(win);
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) wz[wv * (ROWS * 64) + r * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1590,13 +1585,7 @@ __global__ __launch_bounds__(WG) void k_r8_to_iv(const Run8 *r8, uint64_t n, Con
 // BOTH streams of the sample (the file's sorted first runs as the decoder wrote them, and the later runs counting-sorted by bucket):
 // one loop over the two ranges laid end to end.  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more
 // than 32 000 candidates go to the int-window kernel through the same list.
-// ZR ("zero on read", round 6): the window is cleared by the prefix-sum phase as it reads it — the store rides on the read's address, the
-// separate fill pass at the top of a tile and the barrier behind it go (three barriers per tile instead of four); the carry-in cell is
-// double-buffered by tile parity so that nobody has to clear it between a tile's last reader and the next tile's first writer.
-// PF ("prefetch", round 6, JOIN only): the first chunk of the NEXT tile's sorted-stream candidates — whose place the bucket starts fetched a
-// tile ahead already name — is requested as soon as this tile's runs are in the window, so its latency passes under the prefix sum and the
-// statistics instead of at the top of the next tile, where nothing else of this workgroup is in flight.
-template <int WPE, int UN8, bool EXPORT, bool JOIN = false, bool ZR = false, bool PF = false, bool TOUCH = false>
+template <int WPE, int UN8, bool EXPORT, bool JOIN = false>
 __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32_t n_tiles, ContigTab tab, const uint32_t *tile_contig,
                                                      uint32_t wrap_mask, const DirectWide args, uint32_t *heavy_list, uint32_t *heavy_count,
                                                      const DirectExport ex)
@@ -1605,7 +1594,7 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
     constexpr uint32_t ST = TILE, HT = TILE / 2;
     constexpr int ROWS = (int)(HT / (WG * 4));
     __shared__ __attribute__((aligned(16))) unsigned win[HT];
-    __shared__ int s_carry2[2];
+    __shared__ int s_carry;
     __shared__ int wtot[4];
     __shared__ unsigned long long red_s[4][2];
     __shared__ int red_c[4][2];
@@ -1624,28 +1613,12 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
     };
     uint32_t nslo, nshi;
     bounds(blockIdx.x, nslo, nshi);
-    uint4 *const w4 = reinterpret_cast<uint4 *>(win);
-    constexpr bool ZRK = ZR;
-    if constexpr (ZRK) {
-        for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (threadIdx.x == 0) { s_carry2[0] = 0; s_carry2[1] = 0; }
-        __syncthreads();
-    }
-    uint32_t par = 0;
-    uint2 A[UN8], B[UN8];                                         // the two chunk buffers (PF: A holds chunk 0 of the tile about to be worked on when `pre`)
-    bool pre = false;
-    // TOUCH: instead of registers, one dword per thread out of every 128-byte line of the next tile's sorted-stream candidates (256 threads
-    // x 16 runs = 4 096 runs: more than a tile has) is requested when this tile's runs are in the window and consumed — folded into `sink` —
-    // at the tile's end: the lines are in L2 when the next tile's chunks ask for them, for ONE register across the prefix sum
-    uint32_t sink = 0;
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t a = t * ST;
         const uint32_t ns = nshi - nslo, s_at = nslo;             // the tile's candidates in the sorted stream
-        if constexpr (!ZRK) {
-            for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (threadIdx.x == 0) s_carry2[0] = 0;
-        }
-        int &s_carry = s_carry2[ZRK ? par : 0u];
+        uint4 *w4 = reinterpret_cast<uint4 *>(win);
+        for (uint32_t j = threadIdx.x; j < HT / 4; j += WG) w4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) s_carry = 0;
         const int32_t ctg = (int32_t)tile_contig[t];
         const uint32_t clen = tab.len[ctg];
         const uint32_t p0 = (uint32_t)a;                          // the runs' begins are flat (mod 2^32), like this
@@ -1654,13 +1627,12 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
         // ... and in the other stream (both possible lower bounds are fetched, so that the loads do not wait for the contig's offset)
         const uint32_t o_prev = cs.o1[k0 ? k0 - 1 : 0], o_own = cs.o1[k0], ohi = cs.o1[k0 + (1u << bsh)];
         bounds(t + gridDim.x, nslo, nshi);
-        if constexpr (!ZRK) __syncthreads();
+        __syncthreads();
         const uint32_t olo = pc ? o_prev : o_own, no = ohi - olo;
         const uint32_t cand = ns + no;
         if (cand > 32000u) {                                      // workgroup-uniform: the int-window kernel does this tile
             if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)t;
-            if constexpr (!ZRK) __syncthreads();
-            pre = false;
+            __syncthreads();
             continue;
         }
         int carry_s = 0;
@@ -1718,8 +1690,9 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                 }
             };
             if (nq) {
+                uint2 A[UN8], B[UN8];
                 uint32_t q = 0;
-                if (!(PF && JOIN && pre && c1 >= 1u)) load8(A, q);
+                load8(A, q);
 #pragma unroll 1
                 for (;;) {                                        // two buffers, no register copies: B is in flight while A is worked on
                     if (q + 1 < nq) load8(B, q + 1);
@@ -1731,25 +1704,10 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                 }
             }
         }
-        uint32_t touched = 0;
-        if constexpr (TOUCH) {
-            if (t + gridDim.x < n_tiles && nshi > nslo) {
-                const uint32_t j = nslo + threadIdx.x * 16u;
-                touched = reinterpret_cast<const uint32_t *>(cs.r8 + (j < nshi ? j : nshi - 1u))[0];
-            }
-        }
-        if constexpr (PF && JOIN) {
-            // (nslo / nshi are the NEXT tile's by now: bounds() above)
-            pre = t + gridDim.x < n_tiles && nshi - nslo >= (uint32_t)(UN8 * WG);
-            if (pre) {
-#pragma unroll
-                for (int k = 0; k < UN8; ++k) A[k] = *reinterpret_cast<const uint2 *>(cs.r8 + (nslo + threadIdx.x + k * WG));
-            }
-        }
         if (lane == 0 && carry_s != 0) atomicAdd(&s_carry, carry_s);
         __syncthreads();
         if constexpr (EXPORT) {
-            export_packed_tile<ROWS>(win, a, t, ex, wtot, ZRK);
+            export_packed_tile<ROWS>(win, a, t, ex, wtot);
             continue;
         }
         // ---- prefix sum of the packed window: both half-tiles at once ----
@@ -1757,7 +1715,6 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const uint4 q = w4[wv * (ROWS * 64) + r * 64 + lane];
-            if constexpr (ZRK) w4[wv * (ROWS * 64) + r * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
             v[r] = make_int4((int)q.x, (int)q.x + (int)q.y, 0, 0);
             v[r].z = v[r].y + (int)q.z; v[r].w = v[r].z + (int)q.w;
         }
@@ -1860,12 +1817,8 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
             tp.s0 = red_s[0][0] + red_s[1][0] + red_s[2][0] + red_s[3][0];
             tp.s1 = red_s[0][1] + red_s[1][1] + red_s[2][1] + red_s[3][1];
             part[t] = tp;
-            if constexpr (ZRK) s_carry = 0;                       // (every wave has read it: the barrier above; written again two tiles from now)
         }
-        par ^= 1u;
-        if constexpr (TOUCH) sink ^= touched;
     }
-    if constexpr (TOUCH) { if (sink == 0x9E3779B9u && n_tiles == 0xFFFFFFFFu) heavy_count[3] = sink; }       // (never: keeps the touches alive)
 }
 
 // Outcome of a direct pass: *fail = 1 unless every batch was complete and sorted and no run was
@@ -3008,18 +2961,6 @@ void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t
     case 1703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     case 1704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     case 1802: hipLaunchKernelGGL((k_direct_c8<8, 2, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 2704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 2804: hipLaunchKernelGGL((k_direct_c8<8, 4, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 2703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    // 3000 +: zero on read + the next tile's first chunk prefetched
-    case 3704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 3604: hipLaunchKernelGGL((k_direct_c8<6, 4, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 3703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 3803: hipLaunchKernelGGL((k_direct_c8<8, 3, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 3702: hipLaunchKernelGGL((k_direct_c8<7, 2, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 4704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true, true, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 4703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true, true, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
-    case 3802: hipLaunchKernelGGL((k_direct_c8<8, 2, false, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     // round 4, two streams (ms by the context's events, which also bracket the pile-up and finish launches): <8, 3> 2.35; joined tail: <8, 3> 2.33, <8, 2> 2.07, <7, 3> 2.07, <7, 4> 2.04
     default: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     }
@@ -3031,13 +2972,9 @@ void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t
 }
 
 void launch_direct_c8_export(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t *tile_contig, uint32_t n_tiles, void *img, pd_exc *exc,
-                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles, int un)
+                             uint32_t cap, uint32_t *count, int *sums, uint32_t *heavy_list, uint32_t *heavy_count, unsigned grid_tiles)
 {
     const DirectExport de{(unsigned short *)img, exc, cap, count, sums};
-    // ("direct_un" >= 2000: the zero-on-read form, as for the statistics kernel)
-    if (un >= 2000) hipLaunchKernelGGL((k_direct_c8<7, 4, true, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
-                                       DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
-    else
     hipLaunchKernelGGL((k_direct_c8<7, 4, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, 0xFFFFFFFFu,
                        DirectWide{(uint32_t)TILE, 1u, nullptr}, heavy_list, heavy_count, de);
     WinArgs wa; wa.w = (uint32_t)TILE; wa.min_dep = 1; wa.inv_w = 0.f; wa.cover = nullptr; wa.sum = nullptr; wa.part = nullptr;

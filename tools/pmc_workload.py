@@ -51,7 +51,12 @@ for it in range(2):
     eng.synchronize()
 # the sliced sum's receiving side on the image just exported: one part, the whole genome (k_sweep_i4_wave)
 n_tiles = n_cells // 8192
+# (the tile sums the collective would all-reduce, here from the image itself — with zeros every tile would start at depth 0, the running depth
+# would dip below zero and k_sweep_i4_fast would send every tile to the slow list: not the kernel a real exchange runs)
+_t = img[:n_tiles * 4096].view(n_tiles, 4096)
 sums = torch.zeros(n_tiles + 16, dtype=torch.int32, device=dev)
+sums[:n_tiles] = (_t & 15).sum(1, dtype=torch.int32) + (_t >> 4).sum(1, dtype=torch.int32) - 8 * 8192
+del _t
 part = torch.zeros(n_tiles * 24 + 64, dtype=torch.uint8, device=dev)
 for it in range(2):
     eng.slice_sweep_i4(img.data_ptr(), 1, n_cells // 2, 0, n_tiles, sums.data_ptr(), 0, 0, 0, 10000000, 1, 18, part.data_ptr())
