@@ -1400,6 +1400,15 @@ void c8_counted(pd_ctx *c, uint64_t order, uint64_t nf, uint64_t no, Run8 *seg_s
         x.base_s[(size_t)x.turn] = (uint32_t)x.n_s;
         if (b.nf + b.no) {
             hipError_t e = hipSuccess;
+            // (when the sample outgrows its arrays — every growth waits for the device and moves what is there — they are made large enough for
+            // the REST of the file at the rate seen so far, not half again: a long-read file has 1 600 later runs per first run where the first
+            // estimate assumed one in four, and eight growths of gigabytes stalled every feeder — 8 thread-seconds on 128 batches)
+            uint64_t want_s = x.n_s + b.nf, want_o = x.n_o + b.no;
+            if ((want_s > x.cap_s || want_o > x.cap_o) && x.n_batches > x.turn + 1) {
+                const double f = 1.05 * (double)x.n_batches / (double)(x.turn + 1);
+                want_s = std::max<uint64_t>(want_s, (uint64_t)((double)want_s * f)); want_o = std::max<uint64_t>(want_o, (uint64_t)((double)want_o * f));
+                if (c8_reserve(c, want_s, want_o, /*exact=*/true) != PD_OK) { want_s = x.n_s + b.nf; want_o = x.n_o + b.no; }      // (no room for the projection: what is needed now)
+            }
             if (c8_reserve(c, x.n_s + b.nf, x.n_o + b.no) != PD_OK) e = hipErrorOutOfMemory;
             if (e == hipSuccess && b.ev) e = hipStreamWaitEvent(x.compose, b.ev, 0);
             if (e == hipSuccess && b.nf) launch_copy_words(x.compose, x.r8() + x.n_s, b.seg_s, b.nf * (sizeof(Run8) / 4));

@@ -41,6 +41,10 @@ void print_help();
 //   device_decode=0  device_deflate=0  site_resident=0  table_resident=0  table_resident_min=N  site_overlap=0  site_identical=0|1
 //   site_parallel_min=N  pgz_min=N  rccl=0|force  rccl_verbose=1  gpus=N  dd_threads=N  dd_depth=N  dd_batch_mb=N  inflate_waves=N  lz_group=N  decode_only=1
 //   decode_fast=0 (the host confirms every batch's record chain, as before round 5)  decode_max_redo=N  decode_spoil=K (test hook: plants wrong guesses)
+//   round 6: transport=peer|rccl (the list mode's collective: in-process peer copies — the default — or RCCL made ahead of the contexts)
+//   comm=0|force (no communicator / one even for a single context; `rccl=0|force` are the same switches under their older names)
+//   comm_early=0 (the communicator and its buffers in line before the first collective instead of beside the decode)
+//   h2d_kernel=1|2|3 (a batch's bytes fetched by a copy kernel / + its tables / read in place by the inflate kernel: all measured slower)
 // -X is not part of the reference's command line (which answers an unknown flag with "Error UnKnow argument"): it is accepted only in this
 // spelling, is not listed by -h, and a PANDEPTH_* variable of the earlier rounds that is still set gets a note on stderr.
 const char *tune(const char *key);

@@ -57,9 +57,15 @@ _t = img[:n_tiles * 4096].view(n_tiles, 4096)
 sums = torch.zeros(n_tiles + 16, dtype=torch.int32, device=dev)
 sums[:n_tiles] = (_t & 15).sum(1, dtype=torch.int32) + (_t >> 4).sum(1, dtype=torch.int32) - 8 * 8192
 del _t
+# ... plus what the cells outside the nibble's range (exported as exceptions, their nibble written as 8 = a difference of zero) really hold
+_n = int(cnt[0].item())
+if _n:
+    _cells = exc[:_n, 0]
+    _vals = (exc[:_n, 1] << 32) >> 32                      # pd_exc {uint64 cell; int32 value; int32 pad}: the low word, sign-extended
+    sums.index_add_(0, (_cells // 8192).to(torch.int64), _vals.to(torch.int32))
 part = torch.zeros(n_tiles * 24 + 64, dtype=torch.uint8, device=dev)
 for it in range(2):
-    eng.slice_sweep_i4(img.data_ptr(), 1, n_cells // 2, 0, n_tiles, sums.data_ptr(), 0, 0, 0, 10000000, 1, 18, part.data_ptr())
+    eng.slice_sweep_i4(img.data_ptr(), 1, n_cells // 2, 0, n_tiles, sums.data_ptr(), exc.data_ptr(), 1 << 18, cnt.data_ptr(), 10000000, 1, 18, part.data_ptr())
     eng.synchronize()
 # zlib's LZ77 parse on the device (pd_deflate_parse), 48 MB of per-site rows: the DEFAULT path of round 5 first — 8 KiB chunks with 2 KiB of
 # overlap, sixteen to a workgroup with their text in LDS (k_lz_parse_lds, "lz_group" 16) — then round 4's default for comparison: 16 + 4 KiB
