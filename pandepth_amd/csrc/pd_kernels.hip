@@ -1585,7 +1585,9 @@ __global__ __launch_bounds__(WG) void k_r8_to_iv(const Run8 *r8, uint64_t n, Con
 // BOTH streams of the sample (the file's sorted first runs as the decoder wrote them, and the later runs counting-sorted by bucket):
 // one loop over the two ranges laid end to end.  Same window arithmetic, prefix sum and statistics as k_direct_wide3; tiles with more
 // than 32 000 candidates go to the int-window kernel through the same list.
-template <int WPE, int UN8, bool EXPORT, bool JOIN = false>
+// V4 (round 6, JOIN only, UN8 even): the full chunks of the sorted stream are fetched 16 bytes per lane — two runs per load, a kilobyte per wave and
+// instruction instead of 512 bytes; which thread works on which run changes, nothing else (the window's updates commute).
+template <int WPE, int UN8, bool EXPORT, bool JOIN = false, bool V4 = false>
 __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32_t n_tiles, ContigTab tab, const uint32_t *tile_contig,
                                                      uint32_t wrap_mask, const DirectWide args, uint32_t *heavy_list, uint32_t *heavy_count,
                                                      const DirectExport ex)
@@ -1651,13 +1653,21 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
                 const bool second = q >= c1;
                 if constexpr (JOIN) {
                     if (!second) {
+                        if constexpr (V4) {
+#pragma unroll
+                            for (int k2 = 0; k2 < UN8 / 2; ++k2) {
+                                const uint4 u = *reinterpret_cast<const uint4 *>(p + (s_at + q * C + 2u * (threadIdx.x + k2 * WG)));
+                                dst[2 * k2] = make_uint2(u.x, u.y); dst[2 * k2 + 1] = make_uint2(u.z, u.w);
+                            }
+                        } else {
 #pragma unroll
                         for (int k = 0; k < UN8; ++k) dst[k] = *reinterpret_cast<const uint2 *>(p + (s_at + q * C + threadIdx.x + k * WG));
+                        }
                     } else {
                         const uint32_t i = (q - c1) * C, s_rem = s_at + c1 * C, o_rem = o_at - rem, last = tail - 1u;
 #pragma unroll
                         for (int k = 0; k < UN8; ++k) {
-                            uint32_t j = i + threadIdx.x + k * WG; j = j < last ? j : last;
+                            uint32_t j = i + (V4 ? 2u * (threadIdx.x + (k >> 1) * WG) + (k & 1) : threadIdx.x + k * WG); j = j < last ? j : last;
                             dst[k] = *reinterpret_cast<const uint2 *>(p + ((j < rem ? s_rem : o_rem) + j));
                         }
                     }
@@ -1681,10 +1691,10 @@ __global__ __launch_bounds__(WG, WPE) void k_direct_c8(const C8Sample cs, uint32
 #pragma unroll
                     for (int k = 0; k < UN8; ++k) ev8(c[k].x, c[k].y);
                 } else {                                          // a stream's tail chunk: slots past the end become runs outside the tile
-                    const int nu = (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
+                    const int nu = V4 ? 2 * (int)((left + 2 * WG - 1) / (2 * WG)) : (int)((left + WG - 1) / WG);   // uniform, 1 .. UN8
 #pragma unroll
                     for (int k = 0; k < UN8; ++k) if (k < nu) {
-                        const bool in = threadIdx.x + k * WG < left;
+                        const bool in = (V4 ? 2u * (threadIdx.x + (k >> 1) * WG) + (k & 1) : threadIdx.x + k * WG) < left;
                         ev8(in ? c[k].x : p0 + ST, in ? c[k].y : 0u);
                     }
                 }
@@ -2961,6 +2971,11 @@ void launch_direct_c8(hipStream_t st, C8Sample cs, ContigTab tab, const uint32_t
     case 1703: hipLaunchKernelGGL((k_direct_c8<7, 3, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     case 1704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     case 1802: hipLaunchKernelGGL((k_direct_c8<8, 2, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    // 5000 +: 16-byte loads (two runs per lane and load) for the sorted stream's full chunks
+    case 5704: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 5702: hipLaunchKernelGGL((k_direct_c8<7, 2, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 5802: hipLaunchKernelGGL((k_direct_c8<8, 2, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
+    case 5706: hipLaunchKernelGGL((k_direct_c8<7, 6, false, true, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     // round 4, two streams (ms by the context's events, which also bracket the pile-up and finish launches): <8, 3> 2.35; joined tail: <8, 3> 2.33, <8, 2> 2.07, <7, 3> 2.07, <7, 4> 2.04
     default: hipLaunchKernelGGL((k_direct_c8<7, 4, false, true>), dim3(grid_tiles), dim3(WG), 0, st, cs, n_tiles, tab, tile_contig, wrap_mask, dw, heavy_list, heavy_count, DirectExport{}); break;
     }
