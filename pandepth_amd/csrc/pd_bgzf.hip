@@ -18,7 +18,7 @@
 namespace {
 
 typedef pd_bgzf_block BlkDesc;      // { in_off, out_off, in_len, out_len }
-#define PD_WAVE_TOKENS (65536 / 3 + 64)
+#define PD_WAVE_TOKENS ((int)pdw::TOK_SCRATCH)
 
 // One lane per block.  The fast (one-lookup) tables of a wave's 64 lanes live in LDS (64 x 576 B =
 // 36 KiB, four waves per CU); the cold canonical arrays in a global scratch area.  LDS_FAST = false

@@ -235,6 +235,9 @@ struct pd_ctx {
     unsigned dec_waves = 20;                                      // one-wave inflate workgroups per CU and launch ("inflate_waves")
     std::atomic<uint32_t> dec_oth_div{41};                        // inflated bytes per slot for a later run in a batch's arrays: 41 (a kept record's minimum size) until a batch
                                                                   // does not fit (long reads: a later run per 8 bytes of CIGAR), then 8 for the batches that follow
+    int dec_sync_event = 1;                                       // "decode_sync_event": pd_decode_collect waits for the batch's last event (0: for its stream, as until round 6)
+    int dec_h2d_fifo = 1;                                         // "decode_h2d_fifo": the batches' compressed bytes go up ONE after the other on a copy stream of their own (see pd_decode_queue)
+    std::mutex dec_copy_mu; int dec_h2d_lanes = 1; uint64_t dec_copy_seq = 0; hipStream_t dec_copy_st2 = nullptr;   // "decode_h2d_lanes": 2 = the batches' copies alternate between the main stream and a second one (two on the link at a time)
     int dec_h2d_kernel = 0;                                       // "decode_h2d_kernel": a batch's compressed bytes fetched from the pinned buffer by a copy KERNEL on the batch's stream instead of the copy engine
     bool dec_fast = true;                                         // the record chain of a batch is confirmed on the device where the session allows it ("decode_fast")
     uint32_t dec_spoil = 0;                                       // test hook: every k-th segment's guess is spoilt after pass 1 ("decode_spoil")
@@ -249,6 +252,7 @@ struct pd_ctx {
         bool busy = false;
         hipStream_t st = nullptr;
         hipEvent_t ev[6] = {};
+        hipEvent_t ev_done = nullptr;                             // recorded behind everything pd_decode_queue puts on the stream: what pd_decode_collect waits for
         uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
         uint8_t *h_small = nullptr; size_t h_small_cap = 0;       // pinned: the batch's small tables on their way to and from the device
         void *d[10] = {}; size_t cap[10] = {};                    // blob, inflated, tables (members | segments | member counter), status, -, lanes, redo list,
@@ -263,7 +267,8 @@ struct pd_ctx {
             std::vector<pd_bgzf_block> blocks; std::vector<pd_decode_unit> units; std::vector<pdb2::Seg> segs; std::vector<uint32_t> seg0;
             size_t o_blk = 0, o_seg = 0, o_next = 0, o_up = 0, o_bst = 0, o_co = 0, o_so = 0, o_ord = 0;
             pdb2::Cfg cfg{};
-            uint64_t cap_first = 0, cap_other = 0, t_mark = 0;
+            uint8_t *d_tab = nullptr;                              // the batch's tables on the device: the slot's table buffer, or behind the members in the blob buffer (one copy)
+            uint64_t cap_first = 0, cap_other = 0, t_mark = 0, t_q0 = 0, t_q1 = 0;      // (t_q0 / t_q1: PANDEPTH_DEVTRACE)
         } job;
         uint32_t gen = 0;
     };
@@ -753,6 +758,7 @@ int pd_destroy(pd_ctx *c)
         for (void *p : sl.d) if (p) (void)hipFree(p);
         if (sl.d_tok) (void)hipFree(sl.d_tok);
         for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.st) (void)hipStreamDestroy(sl.st);
     }
     for (auto &r : c->run_segs) {
@@ -768,6 +774,7 @@ int pd_destroy(pd_ctx *c)
     for (auto &w : c->lz) { std::lock_guard<std::mutex> g(w.mu); w.release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->dec_copy_st2) (void)hipStreamDestroy(c->dec_copy_st2);
     delete c;
     if (tm) fprintf(stderr, "[timing]   pd_destroy: sync + staging %.3f s, cells and tables %.3f s, decode slots and runs %.3f s, parse buffers and streams %.3f s\n",
                     (t1 - t0) * 1e-6, (t2 - t1) * 1e-6, (t3 - t2) * 1e-6, (dec_now_us() - t3) * 1e-6);
@@ -830,6 +837,9 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "decode_spoil")) { c->dec_spoil = value > 0xFFFFFFFFull ? 0u : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_h2d_kernel")) { c->dec_h2d_kernel = (int)value; return PD_OK; }
+    if (!strcmp(name, "decode_h2d_fifo")) { c->dec_h2d_fifo = value != 0; return PD_OK; }
+    if (!strcmp(name, "decode_h2d_lanes")) { c->dec_h2d_lanes = value > 1 ? 2 : 1; return PD_OK; }
+    if (!strcmp(name, "decode_sync_event")) { c->dec_sync_event = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_max_redo")) { c->dec_max_redo = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     if (!strcmp(name, "decode_near_span")) { c->dec_near_span = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
     return fail(c, PD_EINVAL, std::string("unknown parameter ") + name);
@@ -1533,7 +1543,8 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     DecTimer ta(1);
     if (bytes + 64 > sl->h_cap) {
         if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
-        const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20);
+        // (room behind the caller's bytes for the batch's small tables, which then travel with them in ONE copy: dec_queue)
+        const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20) + std::max<size_t>((size_t)1 << 20, bytes / 32);
         // one allocation at a time: six feeders pinning their first buffers at once took 75-100 ms EACH (4-5 ms alone)
         std::lock_guard<std::mutex> al(g_alloc_mu);
         if (hipHostMalloc((void **)&sl->h_blob, want, hipHostMallocDefault) != hipSuccess) {
@@ -1551,7 +1562,8 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
 
 namespace {
 
-const bool g_dec_timing = getenv("PANDEPTH_TIMING") != nullptr;     // the per-batch device events are recorded only when somebody reads them
+const bool g_dec_devtrace = getenv("PANDEPTH_DEVTRACE") != nullptr;  // (development: host-clock times at which a batch's stages were seen to end, a line per batch)
+const bool g_dec_timing = getenv("PANDEPTH_TIMING") != nullptr || g_dec_devtrace;     // the per-batch device events are recorded only when somebody reads them
 
 inline bool in_arena(const pd_ctx *c, const void *p) { return c->arena && (const uint8_t *)p >= c->arena && (const uint8_t *)p < c->arena + c->arena_cap; }
 
@@ -1595,7 +1607,7 @@ struct C8Owes {
 int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
 {
     pd_ctx::DecSlot::Job &J = sl.job;                                 // (claimed by dec_slot_of: J.open is set)
-    J.queued = false; J.fast = false; J.timed = false; J.order = bt->order; J.n_bytes = bt->n_bytes; J.inflated = bt->inflated_bytes; J.n_seg = 0;
+    J.queued = false; J.fast = false; J.timed = false; J.t_q0 = dec_now_us(); J.order = bt->order; J.n_bytes = bt->n_bytes; J.inflated = bt->inflated_bytes; J.n_seg = 0;
     J.blocks.clear(); J.units.clear(); J.segs.clear(); J.seg0.clear();
     const bool c8 = J.c8 = c->c8.on;
     J.owes_count = c8 && bt->order < c->c8.n_batches;
@@ -1605,9 +1617,13 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     if (!bt->units || !bt->blocks) return dec_fail(c, PD_EINVAL, "pd_decode_submit: a batch with units needs its unit and member tables");
     if (bt->n_bytes + 64 > sl.h_cap) return dec_fail(c, PD_EINVAL, "pd_decode_submit: more bytes than were acquired");
     HIPDEC(hipSetDevice(c->device));
+    uint64_t dq[8] = {}; int dqn = 0;                                  // (PANDEPTH_DEVTRACE: where the call's own time goes, first batches)
+    auto dq_mark = [&]() { if (g_dec_devtrace && dqn < 8) dq[dqn++] = dec_now_us(); };
+    dq_mark();
     if (!sl.st) {
         HIPDEC(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
         for (auto &e : sl.ev) HIPDEC(hipEventCreate(&e));
+        HIPDEC(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     }
     J.units.assign(bt->units, bt->units + bt->n_units);
     J.blocks.assign(bt->blocks, bt->blocks + bt->n_blocks);
@@ -1645,6 +1661,7 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     // (the inflate kernel's LDS lets 20 one-wave workgroups share a CU; "inflate_waves": fewer per launch, so that several batches' launches share the GPU)
     const unsigned n_wg = (unsigned)c->n_cu * c->dec_waves;
     int rc;
+    dq_mark();
     J.t_mark = dec_now();
     auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - J.t_mark; J.t_mark = n; };
     // The batch's small tables travel through a page-locked staging area of the slot — an "asynchronous" copy from or to pageable memory
@@ -1656,7 +1673,10 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     J.o_bst = J.o_up; J.o_co = J.o_bst + al((size_t)bt->n_blocks * 4); J.o_so = J.o_co + sizeof(pdb2::ChainOut);
     J.o_ord = J.o_so + al((size_t)n_seg * sizeof(pdb2::SegOut));
     const size_t small_need = J.o_ord + 256;
-    if ((rc = dec_ensure(c, sl, DS_BLOB, bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
+    // the tables behind the members in the caller's (page-locked) buffer when it has the room: one host-to-device copy per batch instead of two
+    const size_t tab_at = (bt->n_bytes + 64 + 255) & ~(size_t)255;
+    const bool one_copy = c->dec_h2d_kernel == 0 && c->dec_h2d_fifo && tab_at + J.o_up <= sl.h_cap;
+    if ((rc = dec_ensure(c, sl, DS_BLOB, one_copy ? tab_at + J.o_up : bt->n_bytes + 64)) || (rc = dec_ensure(c, sl, DS_INF, (size_t)bt->inflated_bytes + 256)) ||
         (rc = dec_ensure(c, sl, DS_BLK, J.o_up)) || (rc = dec_ensure(c, sl, DS_ST, (size_t)bt->n_blocks * 4 + 16)) ||
         (rc = dec_ensure(c, sl, DS_LANE, (size_t)n_seg * 64 * sizeof(pdb2::LaneOut))) ||
         (rc = dec_ensure(c, sl, DS_ONLY, (size_t)n_seg * 4 + 16)) || ((c8 || J.fast) && (rc = dec_ensure(c, sl, DS_SEGOUT, sizeof(pdb2::ChainOut) + (size_t)n_seg * sizeof(pdb2::SegOut)))) ||
@@ -1678,7 +1698,9 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     uint8_t *const pin = sl.h_small;
     lap(2);                                                               // device buffers
     hipStream_t st = sl.st;
-    uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF], *d_tab = (uint8_t *)sl.d[DS_BLK];
+    dq_mark();
+    uint8_t *d_blob = (uint8_t *)sl.d[DS_BLOB], *d_inf = (uint8_t *)sl.d[DS_INF], *d_tab = one_copy ? (uint8_t *)sl.d[DS_BLOB] + tab_at : (uint8_t *)sl.d[DS_BLK];
+    J.d_tab = d_tab;
     pdb2::Seg *d_seg = (pdb2::Seg *)(d_tab + J.o_seg);
     pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
     pdb2::Cfg &cfg = J.cfg;
@@ -1692,22 +1714,49 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
     // what it has queued before the slot goes back)
     struct Settle { hipStream_t st; bool armed = true; ~Settle() { if (armed) (void)hipStreamSynchronize(st); } } settle{st};
     J.timed = g_dec_timing;
-    if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], st));
     memset((uint8_t *)bt->host_buf + bt->n_bytes, 0, 64);                  // (the decoder reads up to 8 bytes past a member's end)
+    uint8_t *const up = one_copy ? (uint8_t *)bt->host_buf + tab_at : pin;    // where the tables are put together
+    memcpy(up + J.o_blk, J.blocks.data(), (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
+    memcpy(up + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
+    memset(up + J.o_next, 0, 256);
     // ("decode_h2d_kernel": the copy engine's transfer and the kernel behind it are ordered by a signal between two engines — 2.2 ms of idle queue per
     // batch in profiles/r05_decode_timeline.txt; a copy kernel reads the pinned bytes over the link itself and the inflate kernel follows it in the same queue)
     // (3: no copy at all — the inflate kernel reads the members straight out of the pinned buffer, which the slot holds until the batch is collected)
-    if (c->dec_h2d_kernel == 3) d_blob = (uint8_t *)bt->host_buf;
-    else if (c->dec_h2d_kernel) launch_copy_words(st, d_blob, bt->host_buf, (bt->n_bytes + 64 + 3) / 4);
-    else HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, st));
-    memcpy(pin + J.o_blk, J.blocks.data(), (size_t)bt->n_blocks * sizeof(pd_bgzf_block));
-    memcpy(pin + J.o_seg, segs.data(), (size_t)n_seg * sizeof(pdb2::Seg));
-    memset(pin + J.o_next, 0, 256);
-    if (c->dec_h2d_kernel >= 2) launch_copy_words(st, d_tab, pin, (J.o_up + 3) / 4);
-    else HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, st));
-    if (J.timed) HIPDEC(hipEventRecord(sl.ev[1], st));
+    if (c->dec_h2d_kernel == 0 && c->dec_h2d_fifo) {
+        // ONE batch's bytes on the link at a time, in the order the batches were queued (round 6).  Copies issued on the batches' own streams share the
+        // link: six readers that happen to queue together get their bytes together, six times later than the first of them could have had them, their
+        // kernels then share the GPU and finish together, and the readers come back together — a convoy in which reading, copying and decoding take
+        // turns instead of overlapping (tools/feeder_trace.py, profiles/r06_feeder_trace.txt: 1.25-1.35 ms per batch whatever the readers x buffers).
+        // First come, first served, the first batch decodes while the second is on the link.  The copies ride on the context's main stream, which has
+        // nothing else to do while a file is decoded (a stream of their own would be one more hardware queue to make: 10 ms).
+        std::lock_guard<std::mutex> lk(c->dec_copy_mu);
+        hipStream_t cs = c->stream;
+        if (c->dec_h2d_lanes > 1 && (c->dec_copy_seq++ & 1)) {
+            if (!c->dec_copy_st2) HIPDEC(hipStreamCreateWithFlags(&c->dec_copy_st2, hipStreamNonBlocking));
+            cs = c->dec_copy_st2;
+        }
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], cs));
+        if (one_copy) HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, tab_at + J.o_up, hipMemcpyHostToDevice, cs));
+        else {
+            HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, cs));
+            HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, cs));
+        }
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[1], cs));
+        HIPDEC(hipEventRecord(sl.ev[5], cs));
+        HIPDEC(hipStreamWaitEvent(st, sl.ev[5], 0));
+    } else {
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[0], st));
+        if (c->dec_h2d_kernel == 3) d_blob = (uint8_t *)bt->host_buf;
+        else if (c->dec_h2d_kernel) launch_copy_words(st, d_blob, bt->host_buf, (bt->n_bytes + 64 + 3) / 4);
+        else HIPDEC(hipMemcpyAsync(d_blob, bt->host_buf, bt->n_bytes + 64, hipMemcpyHostToDevice, st));
+        if (c->dec_h2d_kernel >= 2) launch_copy_words(st, d_tab, pin, (J.o_up + 3) / 4);
+        else HIPDEC(hipMemcpyAsync(d_tab, pin, J.o_up, hipMemcpyHostToDevice, st));
+        if (J.timed) HIPDEC(hipEventRecord(sl.ev[1], st));
+    }
+    dq_mark();
     launch_bgzf_inflate_wave(st, d_blob, (const pd_bgzf_block *)(d_tab + J.o_blk), bt->n_blocks, d_inf, (int *)sl.d[DS_ST], sl.d_tok, n_wg, c->dec_crc,
                              (uint32_t *)(d_tab + J.o_next), false);
+    dq_mark();
     if (J.timed) HIPDEC(hipEventRecord(sl.ev[2], st));
     launch_walk_segments(st, cfg, d_seg, n_seg, d_lane, nullptr, 0);
     if (c->dec_spoil) launch_spoil_segments(st, cfg, d_seg, n_seg, d_lane, c->dec_spoil);     // (test hook)
@@ -1727,8 +1776,16 @@ int dec_queue(pd_ctx *c, pd_ctx::DecSlot &sl, const pd_decode_batch *bt)
         HIPDEC(hipMemcpyAsync(pin + J.o_seg, d_seg, (size_t)n_seg * sizeof(pdb2::Seg), hipMemcpyDeviceToHost, st));
         if (J.timed) HIPDEC(hipEventRecord(sl.ev[3], st));
     }
+    // (what the collecting call waits for.  hipStreamSynchronize would put a marker of its own into the stream's HARDWARE queue at the time of the call — and
+    // the process's streams share eight of those: the marker landed behind whatever another batch's stream had in the same queue, and a batch that had long
+    // finished was "collected" 2 ms later, when the other batch was through: tools/calls/r6_call14.sh, profiles/r06_devtrace.txt)
+    HIPDEC(hipEventRecord(sl.ev_done, st));
     HIPDEC(hipGetLastError());
-    J.queued = true;
+    dq_mark();
+    if (g_dec_devtrace && bt->order < 14)
+        fprintf(stderr, "[devtrace] batch %llu pd_decode_queue: stream + events + segments %llu us, buffers %llu, copies issued %llu, inflate launched %llu, the rest launched %llu\n", (unsigned long long)bt->order,
+                (unsigned long long)(dq[1] - dq[0]), (unsigned long long)(dq[2] - dq[1]), (unsigned long long)(dq[3] - dq[2]), (unsigned long long)(dq[4] - dq[3]), (unsigned long long)(dq[5] - dq[4]));
+    J.queued = true; J.t_q1 = dec_now_us();
     owes.armed = false;                                                   // (the second half counts the order)
     settle.armed = false;
     return PD_OK;
@@ -1750,14 +1807,22 @@ int dec_collect(pd_ctx *c, pd_ctx::DecSlot &sl, int32_t *unit_status, pd_decode_
     HIPDEC(hipSetDevice(c->device));
     hipStream_t st = sl.st;
     uint8_t *const pin = sl.h_small;
-    uint8_t *d_tab = (uint8_t *)sl.d[DS_BLK];
+    uint8_t *d_tab = J.d_tab ? J.d_tab : (uint8_t *)sl.d[DS_BLK];
     pdb2::Seg *d_seg = (pdb2::Seg *)(d_tab + J.o_seg);
     pdb2::LaneOut *d_lane = (pdb2::LaneOut *)sl.d[DS_LANE];
     pdb2::SegOut *d_so = c8 ? (pdb2::SegOut *)((uint8_t *)sl.d[DS_SEGOUT] + sizeof(pdb2::ChainOut)) : nullptr;
     pdb2::Cfg cfg = J.cfg;
     J.t_mark = dec_now();
     auto lap = [&](int k) { const uint64_t n = dec_now(); g_dec_us[k] += n - J.t_mark; J.t_mark = n; };
-    HIPDEC(hipStreamSynchronize(st));
+    if (g_dec_devtrace && J.timed) {
+        uint64_t t[6] = {};
+        for (int k = 0; k < 5; ++k) { if (k < 4 || J.fast) (void)hipEventSynchronize(sl.ev[k]); t[k] = dec_now_us(); }
+        (void)hipEventSynchronize(sl.ev_done); t[5] = dec_now_us();
+        fprintf(stderr, "[devtrace] batch %llu queue call %llu us; since its start: collect entered %llu, copy begun %llu, copied %llu, inflated %llu, walked %llu, emitted %llu, stream idle %llu\n",
+                (unsigned long long)J.order, (unsigned long long)(J.t_q1 - J.t_q0), (unsigned long long)(J.t_mark - J.t_q0), (unsigned long long)(t[0] - J.t_q0), (unsigned long long)(t[1] - J.t_q0),
+                (unsigned long long)(t[2] - J.t_q0), (unsigned long long)(t[3] - J.t_q0), (unsigned long long)(t[4] - J.t_q0), (unsigned long long)(t[5] - J.t_q0));
+    }
+    HIPDEC(c->dec_sync_event ? hipEventSynchronize(sl.ev_done) : hipStreamSynchronize(st));
     HIPDEC(hipGetLastError());
     lap(3);                                                               // waiting for the device
     auto times = [&](bool emitted) {

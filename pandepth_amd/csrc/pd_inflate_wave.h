@@ -58,9 +58,28 @@ namespace pdw {
 #ifndef PD_D_ROOT
 #define PD_D_ROOT 8
 #endif
+// phase 2 (decode_body): the parts of the subsequences behind their second checkpoints handed to idle lanes
+#ifndef PD_P2_BALANCE
+#define PD_P2_BALANCE 1
+#endif
+#ifndef PD_CK_N
+#define PD_CK_N 3                         /* checkpoints per subsequence (3 or 4) */
+#endif
+// Match tokens of one superstep a wave's scratch holds; a superstep with more goes to the host decoder (PD_W_HOST).  A superstep cannot have more than
+// out_len / 3 + 1 (a match emits three bytes or more): the default never declines.
+#ifndef PD_TOK_CAP
+#define PD_TOK_CAP (65536 / 3 + 1)
+#endif
+#ifndef PD_CRC_STEP
+#define PD_CRC_STEP 64                    /* bytes of a lane's CRC step (the next step's bytes are in flight meanwhile: 2 x PD_CRC_STEP / 4 registers) */
+#endif
+#ifndef PD_P2_HANDOVER
+#define PD_P2_HANDOVER 16                 /* idle lanes it takes for a hand-over */
+#endif
 // sub-table areas: zlib's `enough` bounds — 286 literal/length symbols of at most 15 bits need 852 entries with a 9-bit root (340 behind the
 // root) and 820 with a 10-bit one (308 are needed, 320 kept); a code that would need more goes to the host (build_table checks)
 enum { LL_ROOT = PD_LL_ROOT, LL_SUBCAP = PD_LL_ROOT <= 9 ? 340 : 320, D_ROOT = PD_D_ROOT, D_SUBCAP = 256 };
+enum { TOK_SCRATCH = PD_TOK_CAP + 63 };   // entries of a wave's token scratch
 enum { PD_W_OK = 0, PD_W_HOST = 1 };      // negative values: corrupt stream (same codes as pd_inflate_core.h)
 enum { KIND_LIT = 0, KIND_LEN = 1, KIND_EOB = 2, KIND_BAD = 3 };
 enum { F_EOB = 1, F_INVALID = 2, F_OVERRUN = 4 };
@@ -74,17 +93,18 @@ struct alignas(16) Tables {
     uint32_t work[160];                   // table building: uint16 rank[320] (position of a symbol inside its length class);
                                           // phase 3: bdst[64] | bend[64] (destination range of every match of the current batch)
     uint8_t cl[320];                      // code lengths of the deflate block being set up
+    uint32_t ck_more[PD_CK_N * 128 > 400 ? PD_CK_N * 128 - 400 : 4];   // the rest of phase 1's checkpoints (PD_CK_N x 512 B over sorted | work | cl | ck_more)
     PW_FN uint16_t *rank() { return reinterpret_cast<uint16_t *>(work); }
     PW_FN uint32_t *bdst() { return work; }
     PW_FN uint32_t *bend() { return work + 64; }
     PW_FN uint64_t *psel() { return reinterpret_cast<uint64_t *>(sorted + 64); }
-    PW_FN uint32_t *ckpt() { return reinterpret_cast<uint32_t *>(sorted); }       // phase 1: 2 checkpoints x 3 fields x 64 lanes over sorted | work | cl   // phase 3: 56 selectors (sorted[0 .. 64): a chunk's marks)
+    PW_FN uint32_t *ckpt() { return reinterpret_cast<uint32_t *>(sorted); }       // phase 1: PD_CK_N checkpoints x 2 fields x 64 lanes over sorted | work | cl | ck_more   // phase 3: 56 selectors (sorted[0 .. 64): a chunk's marks)
 };
 
 struct Stats {                            // host builds only (tuning): how much redundant work the speculation costs
     uint64_t blocks = 0, dblocks = 0, steps = 0, sync_rounds = 0, emit_rounds = 0, sym_true = 0, sym_decoded = 0, lanes_redecoded = 0;
     uint64_t copy_serial = 0, long_matches = 0;     // per round: the longest ready match's 8-byte pieces (what the wave waits for); matches > 16 bytes
-    uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0;
+    uint64_t wave_iters_sync = 0, wave_iters_emit = 0, copy_iters = 0, hdr_syms = 0, matches = 0, batches = 0, tmp_max = 0, handovers = 0;
 };
 
 PW_FN uint64_t ld64(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
@@ -326,11 +346,19 @@ struct SubCount {
     uint32_t q, out, nm, stage, next_t;          // the pass in progress
     BitWin win;
 };
-enum { CK_STRIDE = 3 * 64, CK_NONE = 0xFFFFFFFFu };
+enum { CK_STRIDE = 2 * 64, CK_N = PD_CK_N, CK_NONE = 0xFFFFFFFFu };
+// where checkpoint k lies in a subsequence of S bits that nominally starts at bit `nominal`: S/8 (the one that catches the merges), then — four
+// checkpoints — 11S/32, 9S/16 and 25S/32, or — three — 7S/16 and 23S/32: they cut a subsequence into a first part (11/32; 7/16) and equal further
+// parts (7/32; 9/32), which phase 2 hands to whoever is idle (round 6)
+PW_FN uint32_t ck_at(uint32_t nominal, uint32_t S, uint32_t k)
+{
+    if (CK_N >= 4) return k == 0 ? nominal + (S >> 3) : k == 1 ? nominal + ((11u * S) >> 5) : k == 2 ? nominal + ((9u * S) >> 4) : k == 3 ? nominal + ((25u * S) >> 5) : 0xFFFFFFFFu;
+    return k == 0 ? nominal + (S >> 3) : k == 1 ? nominal + ((7u * S) >> 4) : k == 2 ? nominal + ((23u * S) >> 5) : 0xFFFFFFFFu;
+}
 
 PW_FN void count_begin(SubCount &c, const uint8_t *in, uint32_t in_lim, uint32_t p, uint32_t nominal, uint32_t S)
 {
-    c.q = p; c.out = 0; c.nm = 0; c.stage = 0; c.next_t = nominal + (S >> 3); c.ns = 0;
+    c.q = p; c.out = 0; c.nm = 0; c.stage = 0; c.next_t = ck_at(nominal, S, 0); c.ns = 0;
     win_init(c.win, in, p, in_lim);
 }
 
@@ -343,19 +371,24 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint3
     const uint32_t q = c.q;
     bool stop = q >= lim;
     if (stop && q < bound) flag = F_OVERRUN;
-    if (!stop && q >= c.next_t) {                                         // crossing a checkpoint (twice per pass)
-        const uint32_t st = c.stage;                                      // 0 or 1
+    if (!stop && q >= c.next_t) {                                         // crossing a checkpoint (CK_N times per pass)
+        const uint32_t st = c.stage;                                      // 0 .. CK_N - 1
         uint32_t *const e = ck + st * CK_STRIDE;
         if (have_prev && e[0] == q) {
             // same tail as before; the counts remembered from here on were relative to the old start
-            const uint32_t d_o = c.out - e[64], d_m = c.nm - e[128];
-            e[64] += d_o; e[128] += d_m;
-            if (st == 0) { ck[CK_STRIDE + 64] += d_o; ck[CK_STRIDE + 128] += d_m; }
-            c.n += d_o; c.m += d_m;
-            return false;                                                 // e, f and the later checkpoint stay
+            // (bytes in 17 bits | matches in 15: a pass from a wrong start may have counted anything, what is kept is kept modulo the fields' widths —
+            // the TRUE counts of a subsequence fit them, and sums and differences of counts are exact modulo a power of two)
+            const uint32_t was = e[64], d_o = c.out - (was & 0x1ffffu), d_m = c.nm - (was >> 17);
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)CK_N; ++k) if (k >= st) {
+                const uint32_t w = ck[k * CK_STRIDE + 64];
+                ck[k * CK_STRIDE + 64] = ((w + d_o) & 0x1ffffu) | (((w >> 17) + d_m) << 17);
+            }
+            c.n = (c.n + d_o) & 0x1ffffu; c.m = (c.m + d_m) & 0x7fffu;
+            return false;                                                 // e, f and the later checkpoints stay
         }
-        e[0] = q; e[64] = c.out; e[128] = c.nm;
-        c.next_t = st == 0 ? nominal + (S >> 1) : 0xFFFFFFFFu;
+        e[0] = q; e[64] = (c.out & 0x1ffffu) | (c.nm << 17);
+        c.next_t = ck_at(nominal, S, st + 1);
         c.stage = st + 1;
     }
     if (!stop) {
@@ -371,8 +404,8 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint3
     if (!stop) return true;
     // the pass ran to its end: a checkpoint it did not reach must not stay behind for the next comparison
     const uint32_t st = c.stage;
-    if (st <= 0) ck[0] = CK_NONE;
-    if (st <= 1) ck[CK_STRIDE] = CK_NONE;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)CK_N; ++k) if (st <= k) ck[k * CK_STRIDE] = CK_NONE;
     c.e = c.q; c.f = flag; c.n = c.out; c.m = c.nm;
     return false;
 }
@@ -456,7 +489,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
             SubCount &x = c[l];
             x.e = x.n = x.m = x.f = x.ns = 0;
             x.q = x.out = x.nm = x.stage = x.next_t = 0;
-            for (int k = 0; k < 6; ++k) T.ckpt()[k * 64 + l] = k % 3 ? 0u : (uint32_t)CK_NONE;
+            for (int k = 0; k < 2 * CK_N; ++k) T.ckpt()[k * 64 + l] = k % 2 ? 0u : (uint32_t)CK_NONE;
         });
         // ---- phase 1: speculate and synchronise (nothing is written) ----
         uint32_t kend = 64;
@@ -501,32 +534,89 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
         const U exm = W::excl_scan(m, &n_tok);
         if (total > out_len - o) return -5;
         if (n_tok > out_len / 3 + 1) return -5;                          // (cannot happen: a match emits >= 3 bytes)
+        if (n_tok > (uint32_t)PD_TOK_CAP) return PD_W_HOST;              // (more than the scratch was made for)
         if (st) st->steps++;
         PW_MARK(40, total);
         PW_TICK(2);
         // ---- phase 2: every lane writes its literals and lists its matches, in output order (no lane waits) ----
-        U err, q2, w2, t2, act2;
+        // The subsequences are equal in BITS, not in symbols: a stretch of literals has three times the symbols of a stretch of matches, and a
+        // loop of this kind lasts as long as its busiest lane (207 trips against 99 on average on a 50x short-read file).  Phase 1 left the
+        // means to even that out (round 6): a lane's checkpoints behind the first are symbol boundaries of its TRUE pass (ck_at), with the bytes and
+        // matches before them — so a lane stops at its second checkpoint, the parts behind it go to a POOL
+        // (part k of the pool = what follows checkpoint 1 + k / 64 of lane k % 64), and whoever has nothing to do takes the next part from the
+        // pool, sixteen lanes at a time (a hand-over costs the newcomers' first window loads, which everybody waits for).
+        U err, q2, w2, t2, act2, end2;
         typename W::template Var<BitWin> bw;
+        uint32_t pool_n = 0, pool_next = 0; (void)pool_n; (void)pool_next;
         W::each([&](int l) {
-            err[l] = 0; q2[l] = p[l]; w2[l] = o + ex[l]; t2[l] = exm[l]; act2[l] = (uint32_t)l < n_valid;
+            err[l] = 0; q2[l] = p[l]; w2[l] = o + ex[l]; t2[l] = exm[l]; act2[l] = (uint32_t)l < n_valid; end2[l] = bound[l];
             if (act2[l]) win_init(bw[l], in, p[l], in_lim); else { bw[l].cur = bw[l].nxt = bw[l].ahead = 0; bw[l].base = 0; }
         });
+#if PD_P2_BALANCE
+        W::each([&](int l) {
+            uint32_t *const ck = T.ckpt() + l;
+            ck[0] = o + ex[l]; ck[64] = exm[l];                                // (the first checkpoint has done its work: its words hold the lane's bases)
+#pragma unroll
+            for (uint32_t k = 1; k < (uint32_t)CK_N; ++k) {
+                const uint32_t mq = ck[k * CK_STRIDE];
+                const bool ok = (uint32_t)l < n_valid && mq != (uint32_t)CK_NONE && mq > p[l] && mq < bound[l];
+                if (!ok) ck[k * CK_STRIDE] = CK_NONE;
+                else if (end2[l] == bound[l]) end2[l] = mq;                    // the lane's own part ends at its first usable checkpoint behind the first
+            }
+        });
+        W::sync();
+        pool_n = (uint32_t)(CK_N - 1) * 64u;
+#endif
         {
             uint32_t trips = 0;
-            while (W::ballot_ne(act2, 0u)) {
-                if (++trips > 2 * S + 64) return -9;
+            for (;;) {
+                const uint64_t am = W::ballot_ne(act2, 0u);
+#if PD_P2_BALANCE
+                if (pool_next < pool_n) {
+                    const uint64_t idle = ~am;
+                    const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                    if (n_idle >= (uint32_t)PD_P2_HANDOVER) {                  // (am == 0: all 64)
+                        W::each([&](int l) {
+                            if (act2[l]) return;
+                            const uint32_t k = pool_next + W::prefix_count(idle, l);
+                            if (k >= pool_n) return;
+                            const uint32_t j = k & 63u, part = 1u + (k >> 6);
+                            const uint32_t *const ck = T.ckpt() + j;
+                            const uint32_t from = ck[part * CK_STRIDE];
+                            if (from == (uint32_t)CK_NONE) return;
+                            uint32_t to = base + (j + 1u) * S;
+#pragma unroll
+                            for (uint32_t n = (uint32_t)CK_N - 1u; n >= 2u; --n) if (n > part && ck[n * CK_STRIDE] != (uint32_t)CK_NONE) to = ck[n * CK_STRIDE];
+                            const uint32_t cnt = ck[part * CK_STRIDE + 64];
+                            q2[l] = from; end2[l] = to; w2[l] = ck[0] + (cnt & 0x1ffffu); t2[l] = ck[64] + (cnt >> 17); act2[l] = 1;
+                            win_init(bw[l], in, from, in_lim);
+                        });
+                        pool_next = pool_n - pool_next < n_idle ? pool_n : pool_next + n_idle;
+                        if (st) st->handovers++;
+                        continue;
+                    }
+                }
+#endif
+                if (!am) break;
+                if (++trips > 3 * S + 128) return -9;
                 W::each([&](int l) {
                     if (!act2[l]) return;
-                    if (q2[l] >= bound[l]) { act2[l] = 0; return; }
+                    if (q2[l] >= end2[l]) {
+                        act2[l] = 0; return;
+                    }
                     const Sym s = decode_sym(T, win_bits(bw[l], in, q2[l], in_lim));
                     const uint32_t wl = w2[l];
                     if (st) st->sym_true++;
-                    if (s.kind == KIND_LIT) { out[wl] = (uint8_t)s.val; w2[l] = wl + 1; }
-                    else if (s.kind == KIND_LEN) {
+                    if (s.kind == KIND_LIT) {
+                        out[wl] = (uint8_t)s.val;
+                        w2[l] = wl + 1;
+                    } else if (s.kind == KIND_LEN) {
                         if (s.dist > wl) { err[l] = 6; act2[l] = 0; return; }
                         tok[t2[l]].dst = wl; tok[t2[l]].len_dist = s.val | (s.dist << 16); t2[l] += 1;
                         w2[l] = wl + s.val;
-                    } else { act2[l] = 0; return; }                       // end of block
+                    } else {                                              // end of block
+                        act2[l] = 0; return;
+                    }
                     q2[l] += s.used;
                 });
             }
@@ -601,7 +691,7 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                 }
             });
         };
-        W::each([&](int l) { if (l < 56) T.psel()[l] = period_selector((uint32_t)(l >> 3) + 1, (uint32_t)(l & 7)); T.sorted[l] = 0; });
+        W::each([&](int l) { const int lo = W::opaque(l); if (lo < 56) T.psel()[lo] = period_selector((uint32_t)(lo >> 3) + 1, (uint32_t)(lo & 7)); T.sorted[l] = 0; });   // (opaque: computed HERE, not kept in registers from the kernel's first instruction on)
         uint32_t gen = 0;                                                   // chunks of this superstep so far (mod 1024): the tag of own[]'s marks
         U nx_dst, nx_ld;                                                  // the next batch's tokens are fetched a batch ahead
         W::each([&](int l) { nx_dst[l] = nx_ld[l] = 0; if ((uint32_t)l < n_tok) { const Token k = tok[l]; nx_dst[l] = k.dst; nx_ld[l] = k.len_dist; } });
@@ -751,7 +841,13 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
 template <class W>
 PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tables &T, Token *tok, Stats *st)
 {
-    static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    // the order of the code-length code's lengths in the header: 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 — five bits each in two
+    // constants (a table in memory cost the kernel an address register for its whole life)
+    auto clord = [](int l) -> uint32_t {
+        const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+        const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+        return (uint32_t)((l < 12 ? lo >> (5 * l) : hi >> (5 * (l - 12))) & 31u);
+    };
     typedef typename W::template Var<uint32_t> U;
     if (in_len > (1u << 17) || out_len > (1u << 16)) return PD_W_HOST;        // not a BGZF member: 16-bit token fields
     const uint32_t in_bits = in_len * 8;
@@ -796,7 +892,7 @@ PW_FN int inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                 W::sync();
                 {
                     const uint64_t w64 = ld64(in + (q >> 3)) >> (q & 7);   // 19 x 3 = 57 bits
-                    W::each([&](int l) { if ((uint32_t)l < ncode) T.cl[CLORD[l]] = (uint8_t)((w64 >> (3 * l)) & 7); });
+                    W::each([&](int l) { if ((uint32_t)l < ncode) T.cl[clord(W::opaque(l))] = (uint8_t)((w64 >> (3 * l)) & 7); });
                     q += ncode * 3;
                 }
                 W::sync();
@@ -953,7 +1049,7 @@ PW_FN void crc_pair_step(typename W::template Var<uint32_t> &part)
 {
     typedef typename W::template Var<uint32_t> U;
     U t, from;
-    W::each([&](int l) { t[l] = crc_mul_by<crc_x8192_pow(S)>(part[l]); from[l] = (uint32_t)(l - (1 << S)) & 63u; });
+    W::each([&](int l) { t[l] = crc_mul_by<crc_x8192_pow(S)>(part[l]); from[l] = (uint32_t)(W::opaque(l) - (1 << S)) & 63u; });   // (opaque: six index registers were kept from the kernel's first instruction to here)
     const U got = W::shfl(t, from);
     W::each([&](int l) { if ((l & ((2 << S) - 1)) == (2 << S) - 1) part[l] ^= got[l]; });
 }
@@ -964,7 +1060,8 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 1024
     if (n == 0) return 0;
     // Four tables ("slicing by 4"): tab[256 k + i] = the register after byte i followed by k zero bytes, so that four bytes are one step —
     // four INDEPENDENT look-ups instead of four that wait for each other
-    W::each([&](int l) {
+    W::each([&](int l0) {
+        const int l = W::opaque(l0);                                          // (opaque: the entries and their address are computed HERE)
         for (int k = 0; k < 4; ++k) {
             uint32_t c = (uint32_t)(l * 4 + k);
             for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1u)));
@@ -991,20 +1088,21 @@ PW_FN uint32_t crc32_wave(const uint8_t *data, uint32_t n, uint32_t *tab /* 1024
             const uint32_t x = r ^ w;
             r = tab[768 + (x & 0xffu)] ^ tab[512 + ((x >> 8) & 0xffu)] ^ tab[256 + ((x >> 16) & 0xffu)] ^ tab[x >> 24];
         };
-        // 64 bytes a step, the NEXT step's bytes on their way while this one's go through the tables (a step that waited for its own 16 bytes
+        // PD_CRC_STEP (64) bytes a step, the NEXT step's bytes on their way while this one's go through the tables (a step that waited for its own 16 bytes
         // was a round trip to memory per 16 bytes: 64 of them per lane, most of the CRC's time)
-        uint32_t cur[16], nxt[16];
-        if (i + 64 <= b) __builtin_memcpy(cur, data + i, 64);
-        for (; i + 64 <= b; i += 64) {
+        enum { CS = PD_CRC_STEP, CW = PD_CRC_STEP / 4 };
+        uint32_t cur[CW], nxt[CW];
+        if (i + CS <= b) __builtin_memcpy(cur, data + i, CS);
+        for (; i + CS <= b; i += CS) {
             // (always a load, from a clamped address when nothing follows: a load under a condition makes the compiler wait for it at once)
-            __builtin_memcpy(nxt, data + (i + 128 <= b ? i + 64 : b - 64), 64);
+            __builtin_memcpy(nxt, data + (i + 2 * CS <= b ? i + CS : b - CS), CS);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);                             // (the loads stay HERE: sunk to where their data is used they are no prefetch)
 #endif
 #pragma unroll
-            for (int k = 0; k < 16; ++k) step4(cur[k]);
+            for (int k = 0; k < CW; ++k) step4(cur[k]);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < CW; ++k) cur[k] = nxt[k];
         }
         for (; i + 16 <= b; i += 16) {
             uint32_t w[4]; __builtin_memcpy(w, data + i, 16);
@@ -1035,7 +1133,8 @@ PW_FN int inflate_member(const uint8_t *in, uint32_t in_len, uint8_t *out, uint3
     PW_TICK(6);
     uint32_t want; __builtin_memcpy(&want, in + in_len, 4);
     static_assert(offsetof(Tables, work) == offsetof(Tables, sorted) + sizeof(T.sorted) && offsetof(Tables, cl) == offsetof(Tables, work) + sizeof(T.work) &&
-                  sizeof(T.sorted) + sizeof(T.work) + sizeof(T.cl) >= 2 * CK_STRIDE * 4, "phase 1's checkpoints lie over sorted | work | cl");
+                  offsetof(Tables, ck_more) == offsetof(Tables, cl) + sizeof(T.cl) &&
+                  sizeof(T.sorted) + sizeof(T.work) + sizeof(T.cl) + sizeof(T.ck_more) >= CK_N * CK_STRIDE * 4 && sizeof(Tables) <= 7680, "phase 1's checkpoints lie over sorted | work | cl | ck_more");
     static_assert(sizeof(T.ll) + sizeof(T.d) >= 4096 && offsetof(Tables, d) == sizeof(T.ll), "the CRC tables take the first 4 KiB of the (now free) code tables");
     return crc32_wave<W>(out, out_len, T.ll) == want ? 0 : -20;
 }
@@ -1056,6 +1155,7 @@ struct HostWave {                         // 64 emulated lanes
     static Var<uint32_t> shfl(const Var<uint32_t> &x, const Var<uint32_t> &from) { Var<uint32_t> r; for (int l = 0; l < 64; ++l) r.v[l] = x.v[from.v[l] & 63]; return r; }
     static uint64_t bcast64(const Var<uint64_t> &x, int lane) { return x.v[lane]; }
     static uint32_t uni(uint32_t x) { return x; }                                               // a value every lane holds alike
+    static int opaque(int l) { return l; }                                                      // the lane number, in a form the GPU compiler does not hoist computations on out of their loops
     static uint32_t bcast_u(const Var<uint32_t> &x, uint32_t lane) { return x.v[lane & 63]; }      // lane must be wave-uniform
     static uint32_t min_where(const Var<uint32_t> &x, const Var<uint32_t> &skip) { uint32_t m = 0xFFFFFFFFu; for (int l = 0; l < 64; ++l) if (!skip.v[l] && x.v[l] < m) m = x.v[l]; return m; }
     static uint32_t uniform_u8(const uint8_t *p) { return *p; }
@@ -1100,7 +1200,8 @@ struct DevWave {                          // the hardware wavefront (one wave pe
     }
     __device__ static __forceinline__ Var<uint32_t> shift_up1(const Var<uint32_t> &x, uint32_t fill)
     {
-        Var<uint32_t> r; const uint32_t y = (uint32_t)__shfl_up((int)x.v, 1); r.v = (threadIdx.x & 63) ? y : fill; return r;
+        // (wave_shr:1 — lane 0 keeps `old`, which is the fill value; no index register, no LDS crossbar)
+        Var<uint32_t> r; r.v = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x.v, 0x138, 0xf, 0xf, false); return r;
     }
     __device__ static __forceinline__ uint32_t bcast(const Var<uint32_t> &x, int lane) { return (uint32_t)__shfl((int)x.v, lane); }
     __device__ static __forceinline__ Var<uint32_t> incl_scan_max(const Var<uint32_t> &x)
@@ -1123,6 +1224,7 @@ struct DevWave {                          // the hardware wavefront (one wave pe
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x.v, sl), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x.v >> 32), sl);
         return ((uint64_t)hi << 32) | lo;
     }
+    __device__ static __forceinline__ int opaque(int l) { asm volatile("" : "+v"(l)); return l; }
     __device__ static __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }   // (tells the compiler: scalar)
     __device__ static __forceinline__ uint32_t bcast_u(const Var<uint32_t> &x, uint32_t lane)
     {

@@ -4,10 +4,21 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
+#include <time.h>
 #include "engine_api.h"
+
+// PANDEPTH_TIMING: wall-clock stamps at both ends of main, so that a caller that notes the clock around the process sees what lies
+// outside (the loader before, the kernel's teardown of the process's device and pinned memory after)
+static void stamp(const char *what)
+{
+    if (!getenv("PANDEPTH_TIMING")) return;
+    timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    fprintf(stderr, "[timing] %s at %lld.%06ld (epoch)\n", what, (long long)ts.tv_sec, ts.tv_nsec / 1000);
+}
 
 int main(int argc, char **argv)
 {
+    stamp("main entered");
     static const pd_engine_api api = {
         pd_create, pd_destroy, pd_strerror, pd_push_intervals, pd_scan, pd_reduce_intervals,
         pd_window_layout, pd_scan_reduce_windows, pd_reduce_windows, pd_read_depth, pd_synchronize, pd_push_bgzf_units, pd_device_count, pd_accumulate_from,
@@ -16,10 +27,11 @@ int main(int argc, char **argv)
         pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes, pd_sliced_interval_sum,
         pd_decode_queue, pd_decode_collect, pd_comm_init_local, pd_comm_preinit, pd_comm_prepare,
     };
-    // The decoder keeps six batches in flight on six streams (plus the statistics, compose and parse streams); the runtime maps a
-    // process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait for
-    // each other's kernels.  Eight queues: 0.83-0.91 s instead of 0.94 s of decode on the 3e8-record file (profiles/r04_decode_matrix.txt).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // The decoder keeps six batches in flight on six streams (plus the context's main stream, which carries the batches' copies, and the compose and parse
+    // streams); the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait
+    // for each other's kernels AND for each other's markers: a batch's "done" event sat behind another batch's kernels, and a finished batch was collected
+    // 2 ms late (profiles/r06_devtrace.txt).  Sixteen: every stream of the process its own queue (a queue is made when its stream first launches: 9 ms each).
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
     // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory
@@ -33,6 +45,7 @@ int main(int argc, char **argv)
         fflush(stderr);
         _exit(97);
     }
+    stamp("main leaving");
     fflush(stdout); fflush(stderr);
     if (orderly) return rc;
     _exit(rc);

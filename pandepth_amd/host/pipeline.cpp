@@ -445,6 +445,9 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         if (const char *e = tune(k)) if (api->set_param) (void)api->set_param(eng->ctx, k, (uint64_t)std::max(0, atoi(e)));
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (const char *e = tune("h2d_kernel")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_kernel", (uint64_t)std::max(0, atoi(e)));      // (tuning)
+    if (const char *e = tune("h2d_lanes")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_lanes", (uint64_t)std::max(1, atoi(e)));        // (tuning)
+    if (const char *e = tune("sync_event")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_sync_event", (uint64_t)std::max(0, atoi(e)));      // (tuning: 0 = collect waits for the stream)
+    if (const char *e = tune("h2d_fifo")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_fifo", (uint64_t)std::max(0, atoi(e)));          // (tuning: 0 = every batch's copy on its own stream, as until round 6)
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
 
     const size_t n_batches = batches.size();
@@ -462,7 +465,14 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     double ms_sum[4] = {0, 0, 0, 0}; std::mutex ms_mu;
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // -X dd_trace=1 (with PANDEPTH_TIMING): a line per batch — who read it and when it was acquired, read, queued, waited for and collected (us since the
+    // decode began), and the device's stage times — the raw material of tools/feeder_trace.py
+    struct BatchTrace { int thread = -1; uint64_t acq = 0, rd0 = 0, rd1 = 0, queued = 0, col0 = 0, col1 = 0; float ms[4] = {0, 0, 0, 0}; };
+    std::vector<BatchTrace> trace(tune("dd_trace") ? n_batches : 0);
+    std::atomic<int> next_thread{0};
+    const uint64_t trace_t0 = now_us();
     auto feeder = [&]() {
+        const int my_thread = next_thread.fetch_add(1);
         int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) { eng->fail("cannot open " + path); return; }
         // what a batch's answer is read against, kept from the moment the batch is queued until it is collected
@@ -525,6 +535,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             pd_decode_result res;
             const bool ok = eng->ck(api->decode_collect(eng->ctx, f.ticket, f.status.data(), &res), "pd_decode_collect");
             us_submit += now_us() - t0;
+            if (!trace.empty()) { BatchTrace &tr = trace[f.bi]; tr.col0 = t0 - trace_t0; tr.col1 = now_us() - trace_t0; tr.ms[0] = res.ms_h2d; tr.ms[1] = res.ms_inflate; tr.ms[2] = res.ms_walk; tr.ms[3] = res.ms_emit; }
             if (ok) take(f, res);
             spare.push_back(std::move(f));
         };
@@ -533,6 +544,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             // The buffer FIRST, then the batch number: the engine hands the batches of a compact session their places in batch order, so
             // the lowest number any thread holds must always belong to a thread that also holds a buffer (pd_decode_cfg::n_batches).
             void *hb = nullptr;
+            const uint64_t t_acq = now_us();
             if (!eng->ck(api->decode_acquire(eng->ctx, (size_t)cfg.batch_bytes, &hb), "pd_decode_acquire")) break;
             auto hand_back = [&](uint64_t order) { pd_decode_batch e{}; e.host_buf = hb; e.order = order; int32_t dummy = 0; api->decode_submit(eng->ctx, &e, &dummy, nullptr); };
             const size_t bi = next.fetch_add(1);
@@ -630,15 +642,18 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
             f.pos = pos; f.uo = uo;
             pd_decode_batch bt{}; bt.host_buf = hb; bt.n_bytes = (size_t)pos; bt.blocks = blocks.data(); bt.n_blocks = (uint32_t)blocks.size();
             bt.inflated_bytes = uo; bt.units = units.data(); bt.n_units = (uint32_t)units.size(); bt.order = bi;
+            if (!trace.empty()) { BatchTrace &tr = trace[bi]; tr.thread = my_thread; tr.acq = t_acq - trace_t0; tr.rd0 = t_a - trace_t0; tr.rd1 = t_b - trace_t0; }
             if (depth > 1) {
                 const bool ok = eng->ck(api->decode_queue(eng->ctx, &bt, &f.ticket), "pd_decode_queue");
                 us_submit += now_us() - t_b;
+                if (!trace.empty()) trace[bi].queued = now_us() - trace_t0;
                 if (ok) fly.push_back(std::move(f)); else spare.push_back(std::move(f));      // (the loop's head passes the remaining numbers on)
                 continue;
             }
             pd_decode_result res;
             const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
             us_submit += now_us() - t_b;
+            if (!trace.empty()) { BatchTrace &tr = trace[bi]; tr.queued = tr.col0 = t_b - trace_t0; tr.col1 = now_us() - trace_t0; tr.ms[0] = res.ms_h2d; tr.ms[1] = res.ms_inflate; tr.ms[2] = res.ms_walk; tr.ms[3] = res.ms_emit; }
             if (ok) take(f, res);
             spare.push_back(std::move(f));
         }
@@ -651,6 +666,13 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         feeder();
         for (auto &t : th) t.join();
     }
+    if (!trace.empty() && getenv("PANDEPTH_TIMING"))
+        for (size_t k = 0; k < trace.size(); ++k) {
+            const BatchTrace &tr = trace[k];
+            fprintf(stderr, "[trace] batch %zu thread %d acquire %llu read %llu %llu queued %llu collect %llu %llu device ms h2d %.3f inflate %.3f walk %.3f emit %.3f\n", k, tr.thread,
+                    (unsigned long long)tr.acq, (unsigned long long)tr.rd0, (unsigned long long)tr.rd1, (unsigned long long)tr.queued, (unsigned long long)tr.col0, (unsigned long long)tr.col1,
+                    tr.ms[0], tr.ms[1], tr.ms[2], tr.ms[3]);
+        }
     if (guess && eng->ok() && !declined.load()) {
         // the record chain across the batches (virtual offsets; the end of a member equals the start of the next one)
         for (size_t k = 0; k + 1 < n_batches; ++k)

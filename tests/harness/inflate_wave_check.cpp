@@ -192,8 +192,8 @@ int main(int argc, char **argv)
                s.batches ? (double)s.emit_rounds / s.batches : 0.0);
         printf("symbols: %.0f true per member, decoded %.2fx while speculating; lanes re-decoded per sync round %.1f\n", (double)s.sym_true / s.blocks,
                (double)s.sym_decoded / s.sym_true, (double)s.lanes_redecoded / s.sync_rounds);
-        printf("wave-serial loop trips per member: sync %.0f, emit %.0f, header symbols %.0f, copy chunk-iterations %.0f; bytes per member %.0f\n",
-               (double)s.wave_iters_sync / s.blocks, (double)s.wave_iters_emit / s.blocks, (double)s.hdr_syms / s.blocks, (double)s.copy_iters / s.blocks,
+        printf("wave-serial loop trips per member: sync %.0f, emit %.0f (+ %.1f hand-overs), header symbols %.0f, copy chunk-iterations %.0f; bytes per member %.0f\n",
+               (double)s.wave_iters_sync / s.blocks, (double)s.wave_iters_emit / s.blocks, (double)s.handovers / s.blocks, (double)s.hdr_syms / s.blocks, (double)s.copy_iters / s.blocks,
                (double)bytes / blocks);
         printf("match copies: the wave waits for %.0f 8-byte pieces per member (the longest ready match of every round); %.0f matches per member are longer than 16 bytes\n",
                (double)s.copy_serial / s.blocks, (double)s.long_matches / s.blocks);

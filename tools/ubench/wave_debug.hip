@@ -12,6 +12,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <chrono>
 #include <vector>
 #define PW_MARK(code, val) do { if (g_dbg && (threadIdx.x & 63) == 0) { g_dbg[blockIdx.x * 8 + 0] = (code); g_dbg[blockIdx.x * 8 + 1] = (val); g_dbg[blockIdx.x * 8 + 2] += 1; } } while (0)
 __device__ volatile unsigned *g_dbg;
@@ -30,7 +31,11 @@ __shared__ long long s_last;
 #endif
 #include PDW_HEADER
 struct Blk { unsigned long long in_off, out_off; unsigned in_len, out_len; };
+#ifdef PD_TOK_CAP
+#define NTOK (PD_TOK_CAP + 63)
+#else
 #define NTOK (65536 / 3 + 64)
+#endif
 #ifndef PD_INFLATE_MIN_WAVES
 #define PD_INFLATE_MIN_WAVES 5
 #endif
@@ -83,16 +88,34 @@ int main(int argc, char **argv)
     hipMemcpy(d_in, d.data(), d.size(), hipMemcpyHostToDevice); hipMemcpy(d_blk, blks.data(), nb * sizeof(Blk), hipMemcpyHostToDevice);
     hipMemset(d_next, 0, 64); hipMemset(d_st, 0xff, nb * 4); hipMemset(d_out, 0xEE, uo);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, 0);
     const bool marks = getenv("MARKS") != nullptr;
+    // STREAMS=K BATCH=n: the members in launches of n on K streams (every stream its own token scratch, every launch its own counter) — what the
+    // decode pipeline's batch-sized launches on several streams can reach together, without the host, the copies and the other kernels
+    const int n_streams = getenv("STREAMS") ? atoi(getenv("STREAMS")) : 0;
+    const unsigned batch = getenv("BATCH") ? atoi(getenv("BATCH")) : 3200;
+    bool done = false;
+    if (n_streams > 0) {
+        std::vector<hipStream_t> sts(n_streams); std::vector<pdw::Token *> toks(n_streams);
+        for (int k = 0; k < n_streams; ++k) { hipStreamCreateWithFlags(&sts[k], hipStreamNonBlocking); hipMalloc(&toks[k], (size_t)n_wg * NTOK * sizeof(pdw::Token)); }
+        const unsigned n_launch = (nb + batch - 1) / batch;
+        unsigned *d_ctr; hipMalloc(&d_ctr, (size_t)n_launch * 4); hipMemset(d_ctr, 0, (size_t)n_launch * 4);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0); hipEventSynchronize(e0);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned j = 0; j < n_launch; ++j) {
+            const unsigned first = j * batch, n = nb - first < batch ? nb - first : batch;
+            hipLaunchKernelGGL(k_dbg, dim3(n_wg < n ? n_wg : n), dim3(64), 0, sts[j % n_streams], d_in, d_blk + first, n, d_out, d_st + first, toks[j % n_streams], d_ctr + j, (volatile unsigned *)nullptr);
+        }
+        for (int k = 0; k < n_streams; ++k) hipStreamSynchronize(sts[k]);
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("%d streams, launches of %u members: %u launches in %.3f ms = %.1f GB/s\n", n_streams, batch, n_launch, wall_ms, uo / wall_ms / 1e6);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        done = true;
+    } else {
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_dbg, dim3(n_wg), dim3(64), 0, 0, d_in, d_blk, nb, d_out, d_st, d_tok, d_next, marks ? (volatile unsigned *)h_dbg : (volatile unsigned *)nullptr);
     hipEventRecord(e1, 0);
-    bool done = false;
     for (int t = 0; t < secs * 10; ++t) { if (hipEventQuery(e1) == hipSuccess) { done = true; break; } usleep(100000); }
-    if (!done) {
-        printf("NOT FINISHED after %d s; progress of the first workgroups (mark code, value, count, member, state):\n", secs);
-        for (unsigned w = 0; w < n_wg && w < 16; ++w) printf("  wg %u: mark %u val %u count %u member %u state %u exec after the decoder %08x%08x (flag/rc %u)\n", w, h_dbg[w * 8], h_dbg[w * 8 + 1], h_dbg[w * 8 + 2], h_dbg[w * 8 + 3], h_dbg[w * 8 + 4], h_dbg[w * 8 + 6], h_dbg[w * 8 + 5], h_dbg[w * 8 + 7]);
-        fflush(stdout); _exit(3);
     }
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     const unsigned n_check = getenv("CHECK") ? atoi(getenv("CHECK")) : nb;    // (zlib on one host thread: bound it on big files)
