@@ -332,8 +332,8 @@ struct pd_ctx {
         hipStream_t st = nullptr;
         void *h_stage = nullptr; hipEvent_t ev_stage[2] = {nullptr, nullptr};     // page-locked staging of the symbols' way back
         std::mutex mu;
-    } lz[2];
-    std::atomic<unsigned> lz_turn{0};
+    } lz[4];                                                      // (a round's provider calls in flight at once: two until round 6, up to four)
+    std::atomic<unsigned> lz_turn{0}; unsigned lz_slots = 2;         // "lz_slots": 2 or 4 of lz[] in use
     bool lz_mix = false;                                          // "lz_mix": see lz_run
     // the statistics of the last window call stay on the device (pd_text_append_window_rows formats the table's rows from them)
     unsigned char *wk = nullptr; size_t wk_bytes = 0; uint32_t wk_w = 0; uint64_t wk_nw = 0; bool wk_valid = false; std::vector<uint64_t> wk_woff;
@@ -838,6 +838,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_h2d_kernel")) { c->dec_h2d_kernel = (int)value; return PD_OK; }
     if (!strcmp(name, "decode_h2d_fifo")) { c->dec_h2d_fifo = value != 0; return PD_OK; }
+    if (!strcmp(name, "lz_slots")) { c->lz_slots = value >= 4 ? 4 : 2; return PD_OK; }
     if (!strcmp(name, "decode_h2d_lanes")) { c->dec_h2d_lanes = value > 1 ? 2 : 1; return PD_OK; }
     if (!strcmp(name, "decode_sync_event")) { c->dec_sync_event = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_max_redo")) { c->dec_max_redo = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return PD_OK; }
@@ -2610,11 +2611,11 @@ static int lz_run(pd_ctx *c, const void *text, pd_text *tx, uint64_t tx_off, siz
     // The call works on its own stream and its own buffers: the context's lock is held only where the context is touched (its
     // error text, the profile), so that the per-site writer's producer (pd_format_sites on the context's stream) is not kept
     // waiting for the time a round's parse takes.  Two calls run at a time, each in its own slot (buffers + stream).
-    const unsigned lz_slot = c->lz_turn.fetch_add(1) & 1u;
+    const unsigned lz_slot = c->lz_turn.fetch_add(1) & (c->lz_slots >= 4 ? 3u : 1u);
     pd_ctx::LzWork &w = c->lz[lz_slot];
     // "lz_mix": of the two calls a stream keeps in flight, the second parses with its text in memory — a workgroup of the LDS parse fills a CU's
     // LDS, so two LDS parses run one after the other, while a parse from memory shares the CUs with either kind
-    const unsigned lz_group = c->lz_mix && lz_slot == 1u ? 0u : c->lz_group;
+    const unsigned lz_group = c->lz_mix && (lz_slot & 1u) ? 0u : c->lz_group;
     std::lock_guard<std::mutex> lz_lock(w.mu);
     auto fail = [&](pd_ctx *cc, int code, const std::string &msg) { std::lock_guard<std::mutex> lk(cc->mu); cc->err = msg; return code; };
     if (n_text < 3 || n_text > 0xFFFFFF00ull - 64) return fail(c, PD_EINVAL, "pd_deflate_parse: between 3 and 2^32 - 320 bytes of text");

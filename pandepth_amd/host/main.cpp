@@ -27,11 +27,12 @@ int main(int argc, char **argv)
         pd_text_open, pd_text_close, pd_text_append_sites, pd_text_parse, pd_text_read, pd_text_release, pd_text_append_window_rows, pd_text_append_bytes, pd_sliced_interval_sum,
         pd_decode_queue, pd_decode_collect, pd_comm_init_local, pd_comm_preinit, pd_comm_prepare,
     };
-    // The decoder keeps six batches in flight on six streams (plus the context's main stream, which carries the batches' copies, and the compose and parse
-    // streams); the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait
-    // for each other's kernels AND for each other's markers: a batch's "done" event sat behind another batch's kernels, and a finished batch was collected
-    // 2 ms late (profiles/r06_devtrace.txt).  Sixteen: every stream of the process its own queue (a queue is made when its stream first launches: 9 ms each).
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // The decoder keeps six batches in flight on six streams (plus the context's main stream, which carries the batches' copies, and the compose stream:
+    // eight); the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues — 4 unless told otherwise — and streams that share a queue wait
+    // for each other's kernels AND for each other's markers (profiles/r06_devtrace.txt: with nine streams on eight queues a finished batch was collected
+    // 2 ms late).  Eight: every stream of a whole-contig run its own queue (a queue is made when its stream first launches: 9 ms each); sixteen measured
+    // the same there and 3 % slower on the per-site writer (tools/calls/r6_call21.sh).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
     // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory

@@ -529,6 +529,7 @@ struct Stream::Impl {
     int threads = 1;
     uint64_t CH = 1 << 20, TAIL = 1 << 16;
     uint64_t batch_bytes = (uint64_t)96 << 20;
+    unsigned calls = 2;
     std::function<bool(const uint8_t *, size_t)> sink;
     ParseFn parse;
     bool failed = false, finished = false, header_done = false;
@@ -765,11 +766,13 @@ struct Stream::Impl {
                 tri.push_back(c.start - work_base); tri.push_back(c.tail_end - work_base); tri.push_back(c.start - dl - work_base);
                 which.push_back(k);
             }
-            // two calls at a time (each on its half of the chunks and the text they cover): a provider that copies the text elsewhere
-            // moves one half while it parses the other
+            // two (or four) calls at a time, each on its share of the chunks and the text they cover: a provider that copies the text elsewhere
+            // moves one share while it parses another — and a provider whose parse kernels cannot share the device (the engine's LDS parse: one
+            // workgroup fills a CU's LDS) sorts, check-sums and returns the symbols of the other calls under the one that parses
             struct Group { size_t lo = 0, hi = 0; std::shared_ptr<SymVec> sy; std::vector<uint64_t> off; std::vector<uint32_t> crc; bool ok = false; };
-            const size_t n_groups = which.size() >= 512 ? 2 : 1;
-            Group grp[2];
+            const size_t want_groups = calls >= 4 ? 4 : calls >= 2 ? 2 : 1;
+            const size_t n_groups = which.size() >= 256 * want_groups ? want_groups : which.size() >= 512 ? 2 : 1;
+            Group grp[4];
             for (size_t g = 0; g < n_groups; ++g) { grp[g].lo = which.size() * g / n_groups; grp[g].hi = which.size() * (g + 1) / n_groups; grp[g].sy = take_symvec(); }
             auto call = [&](Group &G) {
                 if (G.hi <= G.lo) return;
@@ -784,10 +787,10 @@ struct Stream::Impl {
                 G.ok = G.ok && G.off.size() == G.hi - G.lo + 1 && G.off.back() <= G.sy->size();
             };
             {
-                std::thread second;
-                if (n_groups > 1) second = std::thread([&] { call(grp[1]); });
+                std::thread others[3];
+                for (size_t g = 1; g < n_groups; ++g) others[g - 1] = std::thread([&, g] { call(grp[g]); });
                 call(grp[0]);
-                if (second.joinable()) second.join();
+                for (auto &t : others) if (t.joinable()) t.join();
             }
             for (size_t g = 0; g < n_groups; ++g) {
                 Group &G = grp[g];
@@ -1049,9 +1052,15 @@ struct Stream::Impl {
     {
         std::vector<Chunk> fresh; RoundInfo fresh_info;
         bool a_ok = true, b_ok = true;
-        std::thread ta([&] { a_ok = parse_round(final, c_hi, fresh, fresh_info); });
-        if (have_waiting) { b_ok = emit_round(waiting, false, waiting_info); have_waiting = false; }
+        const bool dbg = getenv("PGZ_DEBUG") != nullptr;
+        static double t_first = 0, t_prev_end = 0;
+        const double r0 = now_s();
+        if (t_first == 0) t_first = t_prev_end = r0;
+        double a_s = 0, b_s = 0;
+        std::thread ta([&] { const double t = now_s(); a_ok = parse_round(final, c_hi, fresh, fresh_info); a_s = now_s() - t; });
+        if (have_waiting) { const double t = now_s(); b_ok = emit_round(waiting, false, waiting_info); have_waiting = false; b_s = now_s() - t; }
         ta.join();
+        if (dbg) { const double r1 = now_s(); fprintf(stderr, "[pgz] round body at %.4f s (%.4f s after the one before ended): stage A %.4f s, stage B (the round before) %.4f s, body %.4f s\n", r0 - t_first, r0 - t_prev_end, a_s, b_s, r1 - r0); t_prev_end = r1; }
         if (!a_ok || !b_ok) return false;
         if (final) return emit_round(fresh, true, fresh_info);
         if (!fresh.empty()) { waiting = std::move(fresh); waiting_info = fresh_info; have_waiting = true; }
@@ -1111,6 +1120,7 @@ Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, c
     p_->TAIL = p.tail < 2048 ? 2048 : p.tail;
     if (p_->TAIL > p_->CH / 2) p_->TAIL = p_->CH / 2;
     if (p.batch) p_->batch_bytes = p.batch;
+    p_->calls = p.calls;
 }
 Stream::Stream(int threads, std::function<bool(const uint8_t *, size_t)> sink, const Params &p, const Remote &source) : Stream(threads, std::move(sink), p)
 {

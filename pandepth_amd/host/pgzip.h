@@ -42,6 +42,7 @@ struct Params {
     size_t chunk = (size_t)1 << 20;      // text per zlib call
     size_t tail = (size_t)1 << 16;       // overlap in which neighbouring parses must meet
     size_t batch = 0;                    // text buffered between rounds (0 = 96 MiB)
+    unsigned calls = 2;                  // provider calls of a round in flight at once (1, 2 or 4; each on its share of the round's chunks)
     ParseFn parse;                       // optional stage-1 provider; a stream's last chunk always goes to zlib (it sees the end of the input)
     // optional, with a provider that copies the text elsewhere: page-lock / release a text buffer of the stream (two buffers of
     // batch + 3 chunks each, never reallocated while locked; pin returns false if it could not)

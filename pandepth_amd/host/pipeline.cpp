@@ -842,6 +842,8 @@ int write_site_depth_resident(const std::string &path, const AlnHeader &hdr, con
     const bool timing = getenv("PANDEPTH_TIMING") != nullptr;
     const auto t_enter = std::chrono::steady_clock::now();
     pgz::Params prm = pgz::Params::for_device(nullptr);
+    prm.calls = (unsigned)tune_int("lz_calls", 2);            // (a round's parse calls in flight: four measured the same as two — the parse kernels of a round take turns on the CUs' LDS either way, tools/calls/r6_call22.sh)
+    if (api->set_param) (void)api->set_param(eng->ctx, "lz_slots", prm.calls >= 4 ? 4 : 2);
     const size_t ring = std::max<size_t>((size_t)1 << 30, 4 * prm.batch);
     pd_text *tx = nullptr;
     if (api->text_open(eng->ctx, ring, &tx) != 0 || !tx) return 0;
