@@ -87,6 +87,9 @@ def cpu_quota():
     return os.cpu_count() or 1
 
 
+RUN_PAUSE_S = 2.5
+
+
 def _best_wall(cmd, reps, env=None, want_stderr=False):
     """best wall time (exec to exit) of `reps` runs; with want_stderr also the stderr text of that run"""
     best, err = None, ""
@@ -110,7 +113,10 @@ def _timed_runs(cmd, warmup, steps, env=None):
     walls, errs = [], []
     for k in range(warmup + steps):
         if k:
-            time.sleep(1.0)
+            # (the device memory a process held — tens of GB here — is wiped after it has left, and a process that allocates GBs meanwhile waits for
+            # that: a 17 GB hipMalloc took 1.0-1.8 s in every third run one second behind another, none in runs three seconds apart
+            # (profiles/r06_alloc_after_exit.txt).  The pause is between the steps, not inside one.)
+            time.sleep(RUN_PAUSE_S)
         t0 = time.perf_counter()
         p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=3600)
         dt = time.perf_counter() - t0

@@ -250,6 +250,7 @@ struct pd_ctx {
     // ---- device decode (pd_decode_*): a few batch slots, each with its own stream and buffers ----
     struct DecSlot {
         bool busy = false;
+        bool warming = false;                                     // the session's warm-up thread is still making this slot's buffer and stream (dec_mu)
         hipStream_t st = nullptr;
         hipEvent_t ev[6] = {};
         hipEvent_t ev_done = nullptr;                             // recorded behind everything pd_decode_queue puts on the stream: what pd_decode_collect waits for
@@ -278,6 +279,9 @@ struct pd_ctx {
     DecSlot dec[N_DEC];
     std::mutex dec_mu; std::condition_variable dec_cv;
     bool dec_open = false;
+    bool dec_warm_on = false;                                     // "decode_warm"
+    std::thread dec_warm;                                         // pd_decode_begin's helper: the first slots' page-locked buffers, streams and hardware queues, one after the other, beside the caller
+    void *dec_warm_word = nullptr;
     uint32_t dec_near_span = 0xFFFFFFFFu;                         // "decode_near_span": split the later runs into two streams (off)
     pd_decode_cfg dec_cfg{}; uint8_t *d_contig_on = nullptr; uint32_t *d_span_off = nullptr; int32_t *d_spans = nullptr;
     std::vector<RunSeg> run_segs;
@@ -731,6 +735,7 @@ static inline uint64_t dec_now_us() { return (uint64_t)std::chrono::duration_cas
 int pd_destroy(pd_ctx *c)
 {
     if (!c) return PD_OK;
+    if (c->dec_warm.joinable()) c->dec_warm.join();
     const bool tm = getenv("PANDEPTH_TIMING") != nullptr;
     const uint64_t t0 = dec_now_us(); uint64_t t1 = t0, t2 = t0, t3 = t0;
     (void)hipSetDevice(c->device);
@@ -775,6 +780,7 @@ int pd_destroy(pd_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->dec_copy_st2) (void)hipStreamDestroy(c->dec_copy_st2);
+    if (c->dec_warm_word) (void)hipFree(c->dec_warm_word);
     delete c;
     if (tm) fprintf(stderr, "[timing]   pd_destroy: sync + staging %.3f s, cells and tables %.3f s, decode slots and runs %.3f s, parse buffers and streams %.3f s\n",
                     (t1 - t0) * 1e-6, (t2 - t1) * 1e-6, (t3 - t2) * 1e-6, (dec_now_us() - t3) * 1e-6);
@@ -838,6 +844,7 @@ int pd_set_param(pd_ctx *c, const char *name, uint64_t value)
     if (!strcmp(name, "decode_fast")) { c->dec_fast = value != 0; return PD_OK; }
     if (!strcmp(name, "decode_h2d_kernel")) { c->dec_h2d_kernel = (int)value; return PD_OK; }
     if (!strcmp(name, "decode_h2d_fifo")) { c->dec_h2d_fifo = value != 0; return PD_OK; }
+    if (!strcmp(name, "decode_warm")) { c->dec_warm_on = value != 0; return PD_OK; }
     if (!strcmp(name, "lz_slots")) { c->lz_slots = value >= 4 ? 4 : 2; return PD_OK; }
     if (!strcmp(name, "decode_h2d_lanes")) { c->dec_h2d_lanes = value > 1 ? 2 : 1; return PD_OK; }
     if (!strcmp(name, "decode_sync_event")) { c->dec_sync_event = value != 0; return PD_OK; }
@@ -1442,6 +1449,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     std::lock_guard<std::mutex> lk(c->mu);
     if (int rs = need_state(c, 0, "pd_decode_begin")) return rs;
     HIPOK(c, hipSetDevice(c->device));
+    const uint64_t tb0 = dec_now_us(); uint64_t tb[6] = {tb0, tb0, tb0, tb0, tb0, tb0};
+    struct BeginMarks { const uint64_t *t; ~BeginMarks() { if (getenv("PANDEPTH_TIMING") && t[5] - t[0] > 20000) fprintf(stderr, "[timing]   pd_decode_begin: tables %.3f s, marks + compose stream %.3f s, sample arrays %.3f s, arena %.3f s, buffers %.3f s\n", (t[1] - t[0]) / 1e6, (t[2] - t[1]) / 1e6, (t[3] - t[2]) / 1e6, (t[4] - t[3]) / 1e6, (t[5] - t[4]) / 1e6); } } begin_marks{tb};
     c->dec_cfg = *cfg;
     std::vector<uint8_t> on((size_t)c->n_contigs, 1);
     for (int32_t t = 0; t < c->n_contigs; ++t) on[(size_t)t] = cfg->contig_on ? (cfg->contig_on[t] != 0) : (c->len[(size_t)t] >= 2);
@@ -1460,6 +1469,7 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     // A sorted file read for whole-contig statistics (PD_DECODE_COMPACT), its batches numbered 0 .. n_batches - 1: the batches' runs go
     // straight to their final places in a compact sample (C8Dec).  Sized from the compressed bytes
     // (>= 32 B of BGZF per record of a real file; denser files make it grow): a first run per record, a later run for every fourth.
+    tb[1] = tb[2] = tb[3] = dec_now_us();
     {
         std::lock_guard<std::mutex> l8(c->c8.mu);
         pd_ctx::C8Dec &x = c->c8;
@@ -1480,10 +1490,13 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
             if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess || hipMalloc(&x.marks, x.nbw * 8) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
             HIPOK(c, hipMemset(x.marks, 0xFF, x.nbw * 8));
             if (!x.compose) HIPOK(c, hipStreamCreateWithFlags(&x.compose, hipStreamNonBlocking));
+            tb[2] = tb[3] = dec_now_us();
             // (>= 32 B of BGZF per record of a real short-read file: a first run per record, a later run for every fourth; c8_reserve adds
             // half again when the sample has to GROW, not to this first estimate — a 70 GB file would otherwise ask for 50 GB up front.)
             const uint64_t est = std::min<uint64_t>(cfg->bytes_hint ? cfg->bytes_hint / 32 + (1u << 20) : (uint64_t)8 << 20, DEV_BATCH_MAX);
-            if (c8_reserve(c, est, est / 4, /*exact=*/true) == PD_OK) {
+            const int rsv = c8_reserve(c, est, est / 4, /*exact=*/true);
+            tb[3] = dec_now_us();
+            if (rsv == PD_OK) {
                 x.n_batches = cfg->n_batches;
                 x.batch.assign((size_t)cfg->n_batches, pd_ctx::C8Dec::Batch());
                 x.base_s.assign((size_t)cfg->n_batches, 0u);
@@ -1500,25 +1513,77 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     // one arena for the batches' run arrays (a hipMalloc per batch waits for the other streams): about half the compressed
     // bytes is plenty for short reads (12 B per run against >= 30 B of BGZF per record); what does not fit is allocated singly
     // (a compact session's segments are 8-byte first runs + 12-byte later runs: a third less)
-    const size_t want = cfg->bytes_hint ? (size_t)(cfg->bytes_hint / (c->c8.on ? 3 : 2)) + ((size_t)16 << 20) : (size_t)256 << 20;
+    // (round 6: a fifth in a compact session — 8 bytes per record and 12 per later run are 0.18 of a 53-bytes-per-record file — instead of a third: device
+    // memory a process HOLDS is wiped when it leaves, and the next process's large allocations wait for that: 1.0-1.8 s now and then in this very call when
+    // one run followed another within a second, tools/calls/r6_call27.sh)
+    const size_t want = cfg->bytes_hint ? (size_t)(cfg->bytes_hint / (c->c8.on ? 5 : 2)) + ((size_t)16 << 20) : (size_t)256 << 20;
     if (c->arena_cap < want) {
         if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_cap = 0; }
         if (hipMalloc(&c->arena, want) == hipSuccess) c->arena_cap = want; else (void)hipGetLastError();
     }
     c->arena_used = 0;
+    tb[4] = tb[5] = dec_now_us();
     c->dec_n_fast = 0; c->dec_n_slow = 0; c->dec_n_redo = 0;
     for (auto &g : g_dec_us) g = 0;
+    if (c->dec_warm.joinable()) c->dec_warm.join();
     if (cfg->batch_bytes && cfg->batches_in_flight) {
-        DecTimer ta(1);
-        const size_t want = std::max<size_t>((size_t)cfg->batch_bytes + 128, (size_t)8 << 20);
-        uint32_t k = 0;
-        for (auto &sl : c->dec) {
-            if (k++ >= cfg->batches_in_flight) break;
-            if (sl.h_cap >= want) continue;
-            if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
-            if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+        const size_t need = std::max<size_t>((size_t)cfg->batch_bytes + 128, (size_t)8 << 20);
+        const size_t want = need + std::max<size_t>((size_t)1 << 20, need / 32);            // (room for the batch's tables behind its bytes: pd_decode_acquire)
+        if (!c->dec_warm_on) {
+            // the first buffers page-locked here, from ONE thread (six readers pinning at once took 75-100 ms EACH, 5-8 ms alone)
+            DecTimer ta(1);
+            uint32_t k = 0;
+            for (auto &sl : c->dec) {
+                if (k++ >= cfg->batches_in_flight) break;
+                if (sl.h_cap >= need) continue;
+                if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
+                if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+            }
+        } else {
+        // "decode_warm" (measured and left off, tools/calls/r6_call26.sh): the first slots made ready by a helper thread, one after the other, while the caller
+        // goes on — a slot's page-locked buffer, its stream and events, and by a first, empty launch the stream's hardware queue (the runtime makes it when
+        // something is launched: 9 ms each, one after the other whoever asks); pd_decode_acquire hands a slot out when it is ready.  The first reader does
+        // start after 20 ms — and its kernels wait until the LAST queue is made: every queue the process makes stops the ones it has (first batches collected
+        // after 140-155 ms instead of 58-66 after a 50 ms pd_decode_begin).
+        uint32_t n_warm = 0;
+        {
+            std::lock_guard<std::mutex> l2(c->dec_mu);
+            for (auto &sl : c->dec) { if (n_warm >= cfg->batches_in_flight) break; sl.warming = true; ++n_warm; }
+        }
+        if (!c->dec_warm_word && hipMalloc(&c->dec_warm_word, 256) != hipSuccess) { (void)hipGetLastError(); c->dec_warm_word = nullptr; }
+        c->dec_warm = std::thread([c, n_warm, need, want]() {
+            (void)hipSetDevice(c->device);
+            for (uint32_t k = 0; k < n_warm; ++k) {
+                pd_ctx::DecSlot &sl = c->dec[k];
+                {
+                    DecTimer ta(1);
+                    if (sl.h_cap < need) {
+                        std::lock_guard<std::mutex> al(g_alloc_mu);
+                        if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
+                        if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+                    }
+                }
+                if (!sl.st) {
+                    bool ok = hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) == hipSuccess;
+                    for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+                    ok = ok && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+                    if (!ok) {                                              // (dec_queue makes what is missing and reports what cannot be made)
+                        (void)hipGetLastError();
+                        for (auto &e : sl.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+                        if (sl.ev_done) { (void)hipEventDestroy(sl.ev_done); sl.ev_done = nullptr; }
+                        if (sl.st) { (void)hipStreamDestroy(sl.st); sl.st = nullptr; }
+                    } else if (c->dec_warm_word) {
+                        (void)hipMemsetAsync(c->dec_warm_word, 0, 4, sl.st);      // the stream's first launch: its hardware queue is made now
+                        (void)hipStreamSynchronize(sl.st);
+                    }
+                }
+                { std::lock_guard<std::mutex> l2(c->dec_mu); sl.warming = false; }
+                c->dec_cv.notify_all();
+            }
+        });
         }
     }
+    tb[5] = dec_now_us();
     c->dec_open = true;
     return PD_OK;
 }
@@ -1530,7 +1595,7 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     std::unique_lock<std::mutex> lk(c->dec_mu);
     if (!c->dec_open) return dec_fail(c, PD_ESTATE, "pd_decode_acquire: call pd_decode_begin first");
     pd_ctx::DecSlot *sl = nullptr;
-    { DecTimer tw(0); c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy) { sl = &x; return true; } return false; }); }
+    { DecTimer tw(0); c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (!x.busy && !x.warming) { sl = &x; return true; } return false; }); }
     sl->busy = true;
     lk.unlock();
     {
@@ -2079,6 +2144,7 @@ static void dec_drain(pd_ctx *c, bool finish)
 int pd_decode_end(pd_ctx *c)
 {
     if (!c) return PD_EINVAL;
+    if (c->dec_warm.joinable()) c->dec_warm.join();
     dec_drain(c, true);
     {   // every batch has returned; wait for stragglers that still hold a slot
         std::unique_lock<std::mutex> lk(c->dec_mu);
@@ -2254,6 +2320,7 @@ int pd_decode_end(pd_ctx *c)
 int pd_decode_abort(pd_ctx *c)
 {
     if (!c) return PD_EINVAL;
+    if (c->dec_warm.joinable()) c->dec_warm.join();
     dec_drain(c, false);
     std::unique_lock<std::mutex> lk(c->dec_mu);
     c->dec_cv.wait(lk, [&] { for (auto &x : c->dec) if (x.busy) return false; return true; });

@@ -2,7 +2,10 @@
 #include "bam.h"
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
 #include <map>
@@ -256,36 +259,47 @@ int AlnReader::next(AlnRec *r)
 
 bool BaiIndex::load(const std::string &path, std::string *err)
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) { if (err) *err = "cannot open " + path; return false; }
-    std::vector<uint8_t> d;
-    uint8_t buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
-    fclose(f);
+    // the file mapped (a 50x human-sized .bai is 100 MB: no copy, no zeroed pages), read into memory where it cannot be
+    raw_.reset(); raw_n_ = 0;
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { if (err) *err = "cannot open " + path; return false; }
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m != MAP_FAILED) { const size_t n = (size_t)sb.st_size; raw_ = std::shared_ptr<const uint8_t>((const uint8_t *)m, [n](const uint8_t *q) { munmap((void *)q, n); }); raw_n_ = n; }
+        }
+        if (!raw_) {
+            std::vector<uint8_t> tmp; uint8_t buf[1 << 16]; ssize_t n;
+            while ((n = ::read(fd, buf, sizeof buf)) > 0) tmp.insert(tmp.end(), buf, buf + n);
+            uint8_t *q = new uint8_t[tmp.size() + 1];
+            memcpy(q, tmp.data(), tmp.size());
+            raw_ = std::shared_ptr<const uint8_t>(q, [](const uint8_t *x) { delete[] x; }); raw_n_ = tmp.size();
+        }
+        ::close(fd);
+    }
+    struct View { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; } } d{raw_.get(), raw_n_};
     size_t o = 0;
     auto need = [&](size_t k) { return o + k <= d.size(); };
-    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) { if (err) *err = path + " is not a BAI index"; return false; }
+    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) { if (err) *err = path + " is not a BAI index"; raw_.reset(); return false; }
     const uint32_t n_ref = le32(d.data() + 4); o = 8;
-    if ((size_t)n_ref > (d.size() - 8) / 8) { if (err) *err = path + ": damaged BAI index (reference count)"; return false; }   // 8 bytes per reference at least
-    linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {});
+    if ((size_t)n_ref > (d.size() - 8) / 8) { if (err) *err = path + ": damaged BAI index (reference count)"; raw_.reset(); return false; }   // 8 bytes per reference at least
+    linear.assign(n_ref, {}); ref_beg.assign(n_ref, 0); ref_end.assign(n_ref, 0); bins.assign(n_ref, {}); bin_at_.assign(n_ref, UINT64_MAX);
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!need(4)) goto bad;
         {
+            bin_at_[r] = o;
             const uint32_t n_bin = le32(d.data() + o); o += 4;
             uint64_t lo = UINT64_MAX, hi = 0;
             for (uint32_t b = 0; b < n_bin; ++b) {
                 if (!need(8)) goto bad;
                 const uint32_t bin = le32(d.data() + o), n_chunk = le32(d.data() + o + 4); o += 8;
                 if (!need(16 * (size_t)n_chunk)) goto bad;
-                if (bin != 37450) {
-                    auto &v = bins[r][bin];
+                if (bin != 37450)
                     for (uint32_t c = 0; c < n_chunk; ++c) {
                         const uint64_t cb = le64(d.data() + o + 16 * c), ce = le64(d.data() + o + 16 * c + 8);
                         lo = std::min(lo, cb); hi = std::max(hi, ce);
-                        v.emplace_back(cb, ce);
                     }
-                }
                 o += 16 * (size_t)n_chunk;
             }
             if (hi) { ref_beg[r] = lo; ref_end[r] = hi; }
@@ -300,7 +314,28 @@ bool BaiIndex::load(const std::string &path, std::string *err)
     return true;
 bad:
     if (err) *err = path + ": truncated BAI index";
+    raw_.reset(); bin_at_.clear();
     return false;
+}
+
+// a reference's bins out of the .bai's bytes (load has been through them: every size is inside the file); not for concurrent first use
+void BaiIndex::ensure_bins(size_t r) const
+{
+    if (r >= bin_at_.size() || bin_at_[r] == UINT64_MAX) return;
+    struct View { const uint8_t *p; const uint8_t *data() const { return p; } } d{raw_.get()};
+    size_t o = (size_t)bin_at_[r];
+    bin_at_[r] = UINT64_MAX;
+    const uint32_t n_bin = le32(d.data() + o); o += 4;
+    bins[r].reserve(n_bin);
+    for (uint32_t b = 0; b < n_bin; ++b) {
+        const uint32_t bin = le32(d.data() + o), n_chunk = le32(d.data() + o + 4); o += 8;
+        if (bin != 37450) {
+            auto &v = bins[r][bin];
+            v.reserve(n_chunk);
+            for (uint32_t c = 0; c < n_chunk; ++c) v.emplace_back(le64(d.data() + o + 16 * c), le64(d.data() + o + 16 * c + 8));
+        }
+        o += 16 * (size_t)n_chunk;
+    }
 }
 
 static inline uint32_t reg2bin(int64_t beg, int64_t end)
@@ -445,6 +480,7 @@ void BaiIndex::query(int32_t tid, int64_t beg0, int64_t end, std::vector<Chunk> 
     const int64_t maxpos = (int64_t)1 << (min_shift + 3 * depth);
     if (end > maxpos) end = maxpos;
     if (beg0 >= end) return;
+    ensure_bins((size_t)tid);
     const auto &bm = bins[tid];
     const int64_t e = end - 1;
     // lower bound on the file offset of anything overlapping [beg0, ...): BAI's linear index, or
@@ -489,6 +525,7 @@ std::vector<uint64_t> BaiIndex::record_starts() const
     for (size_t r = 0; r < linear.size(); ++r) {
         if (ref_beg[r]) cand.push_back(ref_beg[r]);
         for (uint64_t v : linear[r]) if (v) cand.push_back(v);
+        if (linear[r].empty() && r < bins.size()) ensure_bins(r);
         if (linear[r].empty() && r < bins.size())              // CSI: chunk begins are record starts too
             for (auto &b : bins[r]) for (const Chunk &c : b.second) cand.push_back(c.first);
     }

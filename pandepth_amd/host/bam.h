@@ -6,6 +6,7 @@
 #ifndef PD_BAM_H_
 #define PD_BAM_H_
 #include <stdint.h>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,7 +68,13 @@ struct BaiIndex {
     std::vector<std::vector<uint64_t>> linear;    // per reference: 16 kb window -> smallest voffset
     std::vector<uint64_t> ref_beg, ref_end;       // per reference: span of its chunks (0,0 if none)
     typedef std::pair<uint64_t, uint64_t> Chunk;  // [begin, end) virtual offsets
-    std::vector<std::unordered_map<uint32_t, std::vector<Chunk>>> bins;   // per reference
+    // per reference.  A .bai's bins are kept as the file's bytes until somebody asks for a reference's bins (query, record_starts of a CSI):
+    // the whole-genome modes only use the linear index, and turning the 6.4 million chunks of a 50x human-sized index into hash maps of vectors
+    // was 0.15-0.2 s of every run
+    mutable std::vector<std::unordered_map<uint32_t, std::vector<Chunk>>> bins;
+    std::shared_ptr<const uint8_t> raw_; size_t raw_n_ = 0;   // the .bai's bytes (the file mapped, or read where it cannot be)
+    mutable std::vector<uint64_t> bin_at_;        // per reference: where its bins begin in raw_ (UINT64_MAX: made already)
+    void ensure_bins(size_t r) const;
     int min_shift = 14, depth = 5;                // BAI's fixed scheme; CSI stores its own
     std::vector<std::unordered_map<uint32_t, uint64_t>> loffset;          // CSI: per-bin lower bound (no linear index)
     bool load(const std::string &path, std::string *err);       // .bai

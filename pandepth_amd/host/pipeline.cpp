@@ -189,7 +189,9 @@ bool read_indexed(const std::string &path, const Options &o, const AlnHeader &ma
     ReadFilter flt{o.flag_mask, o.min_mapq, (int32_t)main_hdr.names.size()};
     BaiIndex bai;
     std::string err;
+    const auto t_idx = std::chrono::steady_clock::now();
     const bool have_bai = bai.load_for(path, &err);        // .bai or .csi
+    if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing]   index of %s: %s in %.3f s\n", path.c_str(), have_bai ? "loaded" : "none", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_idx).count());
     AlnReader probe;
     if (!probe.open(path, &err)) { std::cerr << "Error: Failed to open the index file or BAM/CRAM file: " << path << std::endl; return true; }
     if (probe.is_cram()) {
@@ -325,6 +327,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                     int kind, uint64_t first_voff, const BaiIndex *bai, bool sorted, Engine *eng)
 {
     const pd_engine_api *api = eng->api;
+    const auto t_enter = std::chrono::steady_clock::now();
     if (!api->decode_begin || !api->decode_acquire || !api->decode_submit || !api->decode_end || !api->decode_abort) return 0;
     if (const char *e = tune("device_decode")) if (e[0] == '0') return 0;
     if (kind != 0 && !spans.synthetic) return 0;            // the no-index span cursor (PD:4608-4646) stays on the host
@@ -441,14 +444,17 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     }
     cfg.n_batches = batches.size();
     if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
-    for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo", "lz_mix"})                                                                           // (tuning / test hooks)
+    for (const char *k : {"decode_fast", "decode_spoil", "decode_max_redo", "lz_mix", "decode_warm"})                                                                           // (tuning / test hooks)
         if (const char *e = tune(k)) if (api->set_param) (void)api->set_param(eng->ctx, k, (uint64_t)std::max(0, atoi(e)));
     if (const char *e = tune("inflate_waves")) if (api->set_param) (void)api->set_param(eng->ctx, "inflate_waves", (uint64_t)std::max(1, atoi(e)));   // (tuning)
     if (const char *e = tune("h2d_kernel")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_kernel", (uint64_t)std::max(0, atoi(e)));      // (tuning)
     if (const char *e = tune("h2d_lanes")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_lanes", (uint64_t)std::max(1, atoi(e)));        // (tuning)
     if (const char *e = tune("sync_event")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_sync_event", (uint64_t)std::max(0, atoi(e)));      // (tuning: 0 = collect waits for the stream)
     if (const char *e = tune("h2d_fifo")) if (api->set_param) (void)api->set_param(eng->ctx, "decode_h2d_fifo", (uint64_t)std::max(0, atoi(e)));          // (tuning: 0 = every batch's copy on its own stream, as until round 6)
+    const auto t_begin = std::chrono::steady_clock::now();
     if (!eng->ck(api->decode_begin(eng->ctx, &cfg), "pd_decode_begin")) return -1;
+    if (getenv("PANDEPTH_TIMING")) fprintf(stderr, "[timing]   work list of %zu batches %.3f s, pd_decode_begin %.3f s\n", batches.size(), std::chrono::duration<double>(t_begin - t_enter).count(),
+                                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
 
     const size_t n_batches = batches.size();
     std::atomic<size_t> next{0};
@@ -470,6 +476,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
     struct BatchTrace { int thread = -1; uint64_t acq = 0, rd0 = 0, rd1 = 0, queued = 0, col0 = 0, col1 = 0; float ms[4] = {0, 0, 0, 0}; };
     std::vector<BatchTrace> trace(tune("dd_trace") ? n_batches : 0);
     std::atomic<int> next_thread{0};
+    std::mutex inflight_mu; std::condition_variable inflight_cv; int inflight_now = 0; const int inflight_cap = (int)tune_int("dd_inflight", 0);
     const uint64_t trace_t0 = now_us();
     auto feeder = [&]() {
         const int my_thread = next_thread.fetch_add(1);
@@ -651,9 +658,14 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
                 continue;
             }
             pd_decode_result res;
+            // (-X dd_inflight=n: at most n batches on the device at a time, the other readers read meanwhile — an experiment in keeping the device's
+            // batches in flight constant: tools/calls/r6_call24.sh)
+            if (inflight_cap > 0) { std::unique_lock<std::mutex> lk(inflight_mu); inflight_cv.wait(lk, [&] { return inflight_now < inflight_cap; }); ++inflight_now; }
+            const uint64_t t_sub = now_us();
             const bool ok = eng->ck(api->decode_submit(eng->ctx, &bt, status.data(), &res), "pd_decode_submit");
+            if (inflight_cap > 0) { { std::lock_guard<std::mutex> lk(inflight_mu); --inflight_now; } inflight_cv.notify_one(); }
             us_submit += now_us() - t_b;
-            if (!trace.empty()) { BatchTrace &tr = trace[bi]; tr.queued = tr.col0 = t_b - trace_t0; tr.col1 = now_us() - trace_t0; tr.ms[0] = res.ms_h2d; tr.ms[1] = res.ms_inflate; tr.ms[2] = res.ms_walk; tr.ms[3] = res.ms_emit; }
+            if (!trace.empty()) { BatchTrace &tr = trace[bi]; tr.queued = tr.col0 = t_sub - trace_t0; tr.col1 = now_us() - trace_t0; tr.ms[0] = res.ms_h2d; tr.ms[1] = res.ms_inflate; tr.ms[2] = res.ms_walk; tr.ms[3] = res.ms_emit; }
             if (ok) take(f, res);
             spare.push_back(std::move(f));
         }
