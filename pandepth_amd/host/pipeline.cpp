@@ -440,7 +440,7 @@ int read_bam_device(const std::string &path, const Options &o, const AlnHeader &
         for (auto &v : batches) { uint64_t t = 0; for (auto &r : v) { const uint64_t a = r.vbeg >> 16, b = std::min(F, (r.vend == UINT64_MAX ? (guess ? std::min(F, a + batch_bytes) : F) : (r.vend >> 16)) + spare_of(r.vend)); t += b - a; } mx = std::max(mx, t); }
         // (one buffer per reader is pinned up front, from one thread; a reader pins its further buffers itself when it first asks for them — by
         // then the device is at work on the first batches, and page-locking costs 0.12 s per GB: twelve 32 MB buffers in a row were 46 ms before the first read)
-        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)std::min<size_t>((size_t)feeders, batches.size());
+        cfg.batch_bytes = mx + 64; cfg.batches_in_flight = (uint32_t)std::min<size_t>((size_t)tune_int("dd_pin_ahead", feeders), std::min<size_t>((size_t)feeders, batches.size()));   // (-X dd_pin_ahead=n: only n buffers pinned before the readers start)
     }
     cfg.n_batches = batches.size();
     if (const char *e = tune("lz_group")) if (api->set_param) (void)api->set_param(eng->ctx, "lz_group", (uint64_t)std::max(0, atoi(e)));             // (tuning: 0 = the parse reads its text from memory)
