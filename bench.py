@@ -246,8 +246,8 @@ def e2e_annotation(td, bam, cli, ref, threads, records):
 
 
 PCIE_PEAK_GBS = 64.0           # PCIe Gen5 x16, one direction, raw (MI355X_MICROARCH.md: host link); ~55 GB/s is what a pinned H2D copy reaches
-INFLATE_ISOLATED_GBS = 285.0      # k_inflate_wave on 102 037 members in one launch, 20 waves per CU: 277-293 (profiles/r05_inflate_ab.txt, commit 56623c4, round 5; round 4: 242).
-INFLATE_ISOLATED_SOURCE = "profiles/r05_inflate_ab.txt (round 5, commit 56623c4: 277-293 GB/s on one box); a constant, not measured in this run"
+INFLATE_ISOLATED_GBS = 300.0      # k_inflate_wave on 102 037 members in one launch, 20 waves per CU: 299-314 on three boxes (profiles/r06_inflate_ab.txt, round 6; round 5: 277-293; round 4: 242).
+INFLATE_ISOLATED_SOURCE = "profiles/r06_inflate_ab.txt (round 6, commit ca5ca02: 299-314 GB/s on three boxes, wave_debug cur / b3h16); a constant, not measured in this run"
 
 
 def e2e_site_windows(td, gen, cli, ref, threads, records=20000000):

@@ -45,6 +45,11 @@ void print_help();
 //   comm=0|force (no communicator / one even for a single context; `rccl=0|force` are the same switches under their older names)
 //   comm_early=0 (the communicator and its buffers in line before the first collective instead of beside the decode)
 //   h2d_kernel=1|2|3 (a batch's bytes fetched by a copy kernel / + its tables / read in place by the inflate kernel: all measured slower)
+//   h2d_fifo=0 (every batch's copy on its own stream, as until round 6; default: first come, first served on the main stream, one copy per batch)
+//   sync_event=0 (collect waits for the batch's stream instead of its last event)  h2d_lanes=2 (two copies on the link at a time)
+//   dd_trace=1 (with PANDEPTH_TIMING: a [trace] line per batch, tools/feeder_trace.py)  dd_inflight=N (at most N batches queued at a time)
+//   dd_pin_ahead=N (buffers page-locked before the readers start)  decode_warm=1 (the slots made ready by a helper thread)  lz_calls=4 (provider calls of a gzip round in flight)
+//   environment: PANDEPTH_DEVTRACE=1 (a [devtrace] line per batch: host-clock times of its stage events; first batches: what pd_decode_queue's own time went to)
 // -X is not part of the reference's command line (which answers an unknown flag with "Error UnKnow argument"): it is accepted only in this
 // spelling, is not listed by -h, and a PANDEPTH_* variable of the earlier rounds that is still set gets a note on stderr.
 const char *tune(const char *key);
