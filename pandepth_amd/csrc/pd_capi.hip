@@ -16,6 +16,7 @@
 #include <string.h>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -254,7 +255,8 @@ struct pd_ctx {
         hipStream_t st = nullptr;
         hipEvent_t ev[6] = {};
         hipEvent_t ev_done = nullptr;                             // recorded behind everything pd_decode_queue puts on the stream: what pd_decode_collect waits for
-        uint8_t *h_blob = nullptr; size_t h_cap = 0;              // pinned
+        uint8_t *h_blob = nullptr; size_t h_cap = 0;              // page-locked (pin_alloc)
+        bool h_mapped = false;                                    // ... as huge pages of its own registered with the runtime (freed by pin_free)
         uint8_t *h_small = nullptr; size_t h_small_cap = 0;       // pinned: the batch's small tables on their way to and from the device
         void *d[10] = {}; size_t cap[10] = {};                    // blob, inflated, tables (members | segments | member counter), status, -, lanes, redo list,
                                                                   // ChainOut + per-segment keys (compact emission), and the runs of a batch whose chain the device
@@ -633,6 +635,41 @@ const char *pd_strerror(const pd_ctx *ctx)
     return mine.c_str();
 }
 
+// A page-locked host buffer for a decode slot.  hipHostMalloc of 34 MB takes 7-8 ms (the runtime allocates and maps it 4 KiB page by page): six of them were
+// 46 ms in front of every run's first read.  Anonymous memory the kernel backs with 2 MiB pages (MADV_HUGEPAGE; where transparent huge pages are off it is
+// ordinary memory), touched, then registered with the runtime (hipHostRegister) takes 1.5 ms and copies at the same 56 GB/s (tools/ubench/pin_cost.hip,
+// profiles/r06_h2d_fill.txt).  Falls back to hipHostMalloc.
+static uint8_t *pin_alloc(size_t bytes, bool *mapped)
+{
+    *mapped = false;
+    if (!getenv("PANDEPTH_NO_HUGE_PIN")) {
+        const size_t al = (size_t)2 << 20, len = (bytes + al - 1) / al * al;
+        void *m = mmap(nullptr, len + al, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            uint8_t *q = (uint8_t *)(((uintptr_t)m + al - 1) / al * al);
+            // (the unaligned head and tail go back at once: the region is exactly [q, q + len))
+            if (q > (uint8_t *)m) munmap(m, (size_t)(q - (uint8_t *)m));
+            if ((uint8_t *)m + len + al > q + len) munmap(q + len, (size_t)((uint8_t *)m + len + al - (q + len)));
+            (void)madvise(q, len, MADV_HUGEPAGE);
+            for (size_t o = 0; o < len; o += 4096) q[o] = 0;              // (fault it in before the runtime walks it)
+            if (hipHostRegister(q, len, hipHostRegisterDefault) == hipSuccess) { *mapped = true; return q; }
+            (void)hipGetLastError();
+            munmap(q, len);
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (uint8_t *)p;
+}
+static void pin_free(uint8_t *p, size_t bytes, bool mapped)
+{
+    if (!p) return;
+    if (!mapped) { (void)hipHostFree(p); return; }
+    const size_t al = (size_t)2 << 20, len = (bytes + al - 1) / al * al;
+    (void)hipHostUnregister(p);
+    munmap(p, len);
+}
+
 int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx **out)
 {
     if (!out || n_contigs <= 0 || !contig_len) return fail(nullptr, PD_EINVAL, "pd_create: bad arguments");
@@ -713,9 +750,11 @@ int pd_create(int device, int32_t n_contigs, const uint32_t *contig_len, pd_ctx 
         std::vector<uint32_t> tc(c->n_tiles + 1, 0);
         for (int32_t i = 0; i < n_contigs; ++i)
             for (uint64_t t = c->off[i] / PD_TILE; t < c->off[i + 1] / PD_TILE; ++t) tc[t] = (uint32_t)i;
-        CREATE_OK(hipMemcpy(c->d_tile_contig, tc.data(), (c->n_tiles + 1) * 4, hipMemcpyHostToDevice));
-        CREATE_OK(hipMemcpy(c->d_off, c->off.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice));
-        CREATE_OK(hipMemcpy(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice));
+        // (on the context's stream, not the null stream: the process's null stream would be one more hardware queue to make — 9 ms — for three small copies)
+        CREATE_OK(hipMemcpyAsync(c->d_tile_contig, tc.data(), (c->n_tiles + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        CREATE_OK(hipMemcpyAsync(c->d_off, c->off.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        CREATE_OK(hipMemcpyAsync(c->d_len, c->len.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, c->stream));
+        CREATE_OK(hipStreamSynchronize(c->stream));
     }
 #undef CREATE_OK
     tm_mark("other buffers + tables");
@@ -758,7 +797,7 @@ int pd_destroy(pd_ctx *c)
     t2 = dec_now_us();
     for (auto &sl : c->dec) {
         if (sl.st) (void)hipStreamSynchronize(sl.st);
-        if (sl.h_blob) (void)hipHostFree(sl.h_blob);
+        pin_free(sl.h_blob, sl.h_cap, sl.h_mapped);
         if (sl.h_small) (void)hipHostFree(sl.h_small);
         for (void *p : sl.d) if (p) (void)hipFree(p);
         if (sl.d_tok) (void)hipFree(sl.d_tok);
@@ -1455,20 +1494,21 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
     std::vector<uint8_t> on((size_t)c->n_contigs, 1);
     for (int32_t t = 0; t < c->n_contigs; ++t) on[(size_t)t] = cfg->contig_on ? (cfg->contig_on[t] != 0) : (c->len[(size_t)t] >= 2);
     if (!c->d_contig_on && hipMalloc(&c->d_contig_on, (size_t)c->n_contigs + 16) != hipSuccess) return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed");
-    HIPOK(c, hipMemcpy(c->d_contig_on, on.data(), on.size(), hipMemcpyHostToDevice));
+    HIPOK(c, hipMemcpyAsync(c->d_contig_on, on.data(), on.size(), hipMemcpyHostToDevice, c->stream));
     if (c->d_span_off) { (void)hipFree(c->d_span_off); c->d_span_off = nullptr; }
     if (c->d_spans) { (void)hipFree(c->d_spans); c->d_spans = nullptr; }
     if (cfg->span_off && cfg->spans) {
         const size_t ns = cfg->span_off[c->n_contigs];
         if (hipMalloc(&c->d_span_off, ((size_t)c->n_contigs + 1) * 4) != hipSuccess || hipMalloc(&c->d_spans, ns * 8 + 16) != hipSuccess)
             return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed");
-        HIPOK(c, hipMemcpy(c->d_span_off, cfg->span_off, ((size_t)c->n_contigs + 1) * 4, hipMemcpyHostToDevice));
-        if (ns) HIPOK(c, hipMemcpy(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice));
+        HIPOK(c, hipMemcpyAsync(c->d_span_off, cfg->span_off, ((size_t)c->n_contigs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (ns) HIPOK(c, hipMemcpyAsync(c->d_spans, cfg->spans, ns * 8, hipMemcpyHostToDevice, c->stream));
     }
     c->dec_cfg.contig_on = nullptr; c->dec_cfg.span_off = nullptr; c->dec_cfg.spans = nullptr;      // (the caller's arrays are not kept)
     // A sorted file read for whole-contig statistics (PD_DECODE_COMPACT), its batches numbered 0 .. n_batches - 1: the batches' runs go
     // straight to their final places in a compact sample (C8Dec).  Sized from the compressed bytes
     // (>= 32 B of BGZF per record of a real file; denser files make it grow): a first run per record, a later run for every fourth.
+    HIPOK(c, hipStreamSynchronize(c->stream));                        // (the caller's arrays have been read)
     tb[1] = tb[2] = tb[3] = dec_now_us();
     {
         std::lock_guard<std::mutex> l8(c->c8.mu);
@@ -1488,7 +1528,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
             if (x.b1) { (void)hipFree(x.b1); x.b1 = nullptr; }
             if (x.marks) { (void)hipFree(x.marks); x.marks = nullptr; }
             if (hipMalloc(&x.b1, 2 * x.nbw * 4) != hipSuccess || hipMalloc(&x.marks, x.nbw * 8) != hipSuccess) { (void)hipGetLastError(); return fail(c, PD_ENOMEM, "pd_decode_begin: allocation failed"); }
-            HIPOK(c, hipMemset(x.marks, 0xFF, x.nbw * 8));
+            HIPOK(c, hipMemsetAsync(x.marks, 0xFF, x.nbw * 8, c->stream));
+            HIPOK(c, hipStreamSynchronize(c->stream));                // (the batches' kernels run on other streams)
             if (!x.compose) HIPOK(c, hipStreamCreateWithFlags(&x.compose, hipStreamNonBlocking));
             tb[2] = tb[3] = dec_now_us();
             // (>= 32 B of BGZF per record of a real short-read file: a first run per record, a later run for every fourth; c8_reserve adds
@@ -1536,8 +1577,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
             for (auto &sl : c->dec) {
                 if (k++ >= cfg->batches_in_flight) break;
                 if (sl.h_cap >= need) continue;
-                if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
-                if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+                if (sl.h_blob) { pin_free(sl.h_blob, sl.h_cap, sl.h_mapped); sl.h_blob = nullptr; sl.h_cap = 0; }
+                if ((sl.h_blob = pin_alloc(want, &sl.h_mapped)) != nullptr) sl.h_cap = want;
             }
         } else {
         // "decode_warm" (measured and left off, tools/calls/r6_call26.sh): the first slots made ready by a helper thread, one after the other, while the caller
@@ -1559,8 +1600,8 @@ int pd_decode_begin(pd_ctx *c, const pd_decode_cfg *cfg)
                     DecTimer ta(1);
                     if (sl.h_cap < need) {
                         std::lock_guard<std::mutex> al(g_alloc_mu);
-                        if (sl.h_blob) { (void)hipHostFree(sl.h_blob); sl.h_blob = nullptr; sl.h_cap = 0; }
-                        if (hipHostMalloc((void **)&sl.h_blob, want, hipHostMallocDefault) == hipSuccess) sl.h_cap = want; else (void)hipGetLastError();
+                        if (sl.h_blob) { pin_free(sl.h_blob, sl.h_cap, sl.h_mapped); sl.h_blob = nullptr; sl.h_cap = 0; }
+                        if ((sl.h_blob = pin_alloc(want, &sl.h_mapped)) != nullptr) sl.h_cap = want;
                     }
                 }
                 if (!sl.st) {
@@ -1608,12 +1649,12 @@ int pd_decode_acquire(pd_ctx *c, size_t bytes, void **host_buf)
     }
     DecTimer ta(1);
     if (bytes + 64 > sl->h_cap) {
-        if (sl->h_blob) { (void)hipHostFree(sl->h_blob); sl->h_blob = nullptr; sl->h_cap = 0; }
+        if (sl->h_blob) { pin_free(sl->h_blob, sl->h_cap, sl->h_mapped); sl->h_blob = nullptr; sl->h_cap = 0; }
         // (room behind the caller's bytes for the batch's small tables, which then travel with them in ONE copy: dec_queue)
         const size_t want = std::max<size_t>(bytes + 64, (size_t)8 << 20) + std::max<size_t>((size_t)1 << 20, bytes / 32);
         // one allocation at a time: six feeders pinning their first buffers at once took 75-100 ms EACH (4-5 ms alone)
         std::lock_guard<std::mutex> al(g_alloc_mu);
-        if (hipHostMalloc((void **)&sl->h_blob, want, hipHostMallocDefault) != hipSuccess) {
+        if ((sl->h_blob = pin_alloc(want, &sl->h_mapped)) == nullptr) {
             { std::lock_guard<std::mutex> l2(c->dec_mu); sl->busy = false; }
             c->dec_cv.notify_one();
             return dec_fail(c, PD_ENOMEM, "pinned batch buffer allocation failed");
