@@ -3,6 +3,7 @@
 // gfx950 device pd_create fails and the program exits with an error (no CPU fallback).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 #include <time.h>
 #include "engine_api.h"
@@ -32,7 +33,11 @@ int main(int argc, char **argv)
     // for each other's kernels AND for each other's markers (profiles/r06_devtrace.txt: with nine streams on eight queues a finished batch was collected
     // 2 ms late).  Eight: every stream of a whole-contig run its own queue (a queue is made when its stream first launches: 9 ms each); sixteen measured
     // the same there and 3 % slower on the per-site writer (tools/calls/r6_call21.sh).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    {   // (a `#.list` input: every context keeps four readers x two buffers — eight slot streams + the main and the compose stream per GPU: sixteen there)
+        bool list = false;
+        for (int a = 1; a < argc; ++a) { const char *x = argv[a]; const size_t n = strlen(x); if (n > 5 && !strcmp(x + n - 5, ".list")) list = true; }
+        setenv("GPU_MAX_HW_QUEUES", list ? "16" : "8", 0);
+    }
     const char *dev = getenv("PANDEPTH_DEVICE");
     // every output file is closed when pandepth_main returns; freeing tens of GB of HBM and unloading the HIP runtime in
     // order would only delay the exit (0.1-0.2 s), so the process ends here and the driver reclaims the device memory
