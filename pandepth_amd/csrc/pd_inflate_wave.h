@@ -73,6 +73,21 @@ namespace pdw {
 #ifndef PD_CRC_STEP
 #define PD_CRC_STEP 64                    /* bytes of a lane's CRC step (the next step's bytes are in flight meanwhile: 2 x PD_CRC_STEP / 4 registers) */
 #endif
+#ifndef PD_EACH_OPAQUE
+#define PD_EACH_OPAQUE 1
+#endif
+#ifndef PD_LIT2
+#define PD_LIT2 1                         /* two literals per trip of phases 1 and 2 where the second follows the first without reaching a bound */
+#endif
+#ifndef PD_LIT2_P2
+#define PD_LIT2_P2 PD_LIT2               /* ... in phase 2 as well */
+#endif
+#ifndef PD_P2_LITS
+#define PD_P2_LITS 2                      /* literals per trip of phase 2 (2 .. 4: a symbol is at most 15 bits, the window holds 64) */
+#endif
+#ifndef PD_LIT3
+#define PD_LIT3 0                         /* a third literal per trip of phase 1 */
+#endif
 #ifndef PD_P2_HANDOVER
 #define PD_P2_HANDOVER 16                 /* idle lanes it takes for a hand-over */
 #endif
@@ -331,6 +346,16 @@ PW_FN Sym decode_sym(const Tables &T, uint64_t w)
     return s;
 }
 
+// A plain literal right behind a symbol (PD_LIT2, round 6): its code length, 0 when what follows is anything else (a length, the end of the block, a code of more
+// than LL_ROOT bits, an invalid code); w = the bits from that second symbol on.  The lanes that make a wave's loops long are the ones inside stretches of
+// literals (a record's packed bases: ~75 literals in a row) — two of them per trip halve those lanes' trips, for one more table look-up per trip of everybody.
+PW_FN uint32_t peek_literal(const Tables &T, uint64_t w, uint32_t *lit)
+{
+    const uint32_t e = T.ll[(uint32_t)w & ((1u << LL_ROOT) - 1)];
+    *lit = (e >> 8) & 0xffu;
+    return (e & 0x70u) == (uint32_t)(KIND_LIT << 4) ? (e & 15u) : 0u;     // (bit 6: a sub-table pointer; bits 5:4: the kind)
+}
+
 // Phase 1 state of one lane.  The speculative pass over a subsequence runs from bit p until the first symbol boundary
 // at or after `bound` (or a stop: end of block, invalid code, end of input); nothing is written: e = where it ended,
 // n = bytes it would emit, m = matches among its symbols.
@@ -392,11 +417,29 @@ PW_FN bool count_step(const Tables &T, const uint8_t *in, uint32_t in_lim, uint3
         c.stage = st + 1;
     }
     if (!stop) {
-        const Sym s = decode_sym(T, win_bits(c.win, in, q, in_lim));
+        const uint64_t w = win_bits(c.win, in, q, in_lim);
+        const Sym s = decode_sym(T, w);
         const bool bad = s.kind == KIND_BAD, eob = s.kind == KIND_EOB;
-        c.q = q + (bad ? 0u : s.used);
-        c.ns += bad ? 0u : 1u;
-        c.out += bad ? 0u : s.kind == KIND_LIT ? 1u : s.kind == KIND_LEN ? s.val : 0u;
+        uint32_t used = bad ? 0u : s.used, n_sym = bad ? 0u : 1u, n_out = bad ? 0u : s.kind == KIND_LIT ? 1u : s.kind == KIND_LEN ? s.val : 0u;
+#if PD_LIT2
+        if (s.kind == KIND_LIT) {
+            // a second literal in the same trip — exactly what the next trip would have done, as long as that trip would not have stopped or crossed
+            // a checkpoint at its start (q1 below the limit and below the next checkpoint): the pass visits the same boundaries either way
+            uint32_t b2;
+            const uint32_t q1 = q + s.used, n2 = peek_literal(T, w >> s.used, &b2);
+            if (n2 && q1 < lim && q1 < c.next_t) {
+                used += n2; n_sym = 2; n_out = 2;
+#if PD_LIT3
+                uint32_t b3;
+                const uint32_t q2 = q1 + n2, n3 = peek_literal(T, w >> used, &b3);
+                if (n3 && q2 < lim && q2 < c.next_t) { used += n3; n_sym = 3; n_out = 3; }
+#endif
+            }
+        }
+#endif
+        c.q = q + used;
+        c.ns += n_sym;
+        c.out += n_out;
         c.nm += !bad && s.kind == KIND_LEN ? 1u : 0u;
         flag = bad ? (uint32_t)F_INVALID : eob ? (uint32_t)F_EOB : 0u;
         stop = bad || eob;
@@ -604,10 +647,29 @@ PW_FN int decode_body(const uint8_t *in, uint32_t in_bits, uint32_t &q_io, uint8
                     if (q2[l] >= end2[l]) {
                         act2[l] = 0; return;
                     }
-                    const Sym s = decode_sym(T, win_bits(bw[l], in, q2[l], in_lim));
+                    const uint64_t wb = win_bits(bw[l], in, q2[l], in_lim);
+                    const Sym s = decode_sym(T, wb);
                     const uint32_t wl = w2[l];
                     if (st) st->sym_true++;
                     if (s.kind == KIND_LIT) {
+#if PD_LIT2_P2
+                        // (a further literal that begins before the part's end belongs to the part: its end is a symbol boundary; up to PD_P2_LITS per trip,
+                        // their bytes in one store)
+                        uint32_t word = s.val, nb = 1, used = s.used;
+#pragma unroll
+                        for (int k = 1; k < PD_P2_LITS; ++k) {
+                            uint32_t b2;
+                            const uint32_t n2 = nb == (uint32_t)k ? peek_literal(T, wb >> used, &b2) : 0u;
+                            if (n2 && q2[l] + used < end2[l]) { word |= b2 << (8 * k); used += n2; ++nb; if (st) st->sym_true++; }
+                        }
+                        if (nb > 1) {
+                            if (nb == 2) st16(out + wl, word);
+                            else if (nb == 3) { st16(out + wl, word); out[wl + 2] = (uint8_t)(word >> 16); }
+                            else st32(out + wl, word);
+                            w2[l] = wl + nb; q2[l] += used;
+                            return;
+                        }
+#endif
                         out[wl] = (uint8_t)s.val;
                         w2[l] = wl + 1;
                     } else if (s.kind == KIND_LEN) {
@@ -1177,7 +1239,14 @@ struct HostWave {                         // 64 emulated lanes
 #if defined(__HIPCC__)
 struct DevWave {                          // the hardware wavefront (one wave per workgroup)
     template <class T> struct Var { T v; __device__ T &operator[](int) { return v; } __device__ const T &operator[](int) const { return v; } };
+    // (the lane number through an empty asm: what a lambda computes from it is computed where the lambda stands — the compiler otherwise hoists every
+    // lane-only expression of the whole kernel (16 * lane, 3 * lane, (lane - 8) & 63 ...) to its first instructions and keeps them in registers to its last;
+    // with 96 registers for 5 waves per SIMD that meant spills, and a kernel with scratch costs 7 ms per hardware queue at its first launch)
+#if PD_EACH_OPAQUE
+    template <class F> __device__ static __forceinline__ void each(F f) { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); f(l); }
+#else
     template <class F> __device__ static __forceinline__ void each(F f) { f((int)(threadIdx.x & 63)); }
+#endif
     // One wave IS the workgroup: its LDS (and global) accesses execute in program order, so what one lane wrote another lane's later
     // read sees — nothing to wait for, the compiler only must not move accesses across (__syncthreads() also waits for every global
     // store the wave has in flight)
