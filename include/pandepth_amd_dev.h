@@ -16,8 +16,11 @@ extern "C" {
  * tile kernels), "scatter_tile" (4096 | 8192), "accumulate_packed" (pd_accumulate_from's transport, default 1), "direct_un"
  * (which compiled variant of the direct kernels runs), "decode_crc" (0: the device decoder skips the members' CRC-32 — kernel
  * timing only), "decode_near_span" (split of the decoder's later-run stream), "inflate_waves" (one-wave inflate workgroups per CU and
- * launch, 1..23: what the kernel's 6 976 bytes of LDS a wave allow; default 20), "lz_group" (consecutive chunks per workgroup of pd_deflate_parse's LDS parse, 0..16; 0: every chunk reads its
- * text from memory). */
+ * launch, 1..23: what the kernel's 7 KB of LDS a wave allow; default 20), "lz_group" (consecutive chunks per workgroup of pd_deflate_parse's LDS parse, 0..16; 0: every chunk reads its
+ * text from memory), "lz_slots" (2 | 4 parse calls in flight).  Round 6, the decode pipeline: "decode_h2d_fifo" (default 1: the batches' host-to-device copies
+ * first come, first served on the context's main stream, one copy per batch; 0: on the batch's own stream), "decode_h2d_lanes" (1 | 2 copies on the link at a
+ * time), "decode_sync_event" (default 1: pd_decode_collect waits for the batch's last event; 0: for its stream), "decode_h2d_kernel" (1..3: a copy kernel /
+ * + the tables / the members read in place: all measured slower), "decode_warm" (1: the session's first slots made ready by a helper thread). */
 int pd_set_param(pd_ctx *ctx, const char *name, uint64_t value);
 
 /* ---- GPU-side BAM decode, the one-call synchronous form (round 1's entry point, kept on top of

@@ -41,6 +41,7 @@ int main(int argc, char **argv)
         if (argc <= 4) p.tail = d.tail;
         if (argc <= 5) p.batch = (size_t)24 << 20;           // (small rounds: several per test file)
     }
+    if (const char *e = getenv("PGZ_CALLS")) p.calls = (unsigned)atoi(e);       // provider calls of a round in flight (1, 2, 4)
     // the reference stream: the way GzWriter (and the reference's gzstream) writes
     char tmp[] = "/tmp/pgzcheckXXXXXX";
     const int fd = mkstemp(tmp);

@@ -132,6 +132,21 @@ def test_remote_text_source_rounds_release_and_mends(check, tmp_path):
                 assert sum(int(m) for m in re.findall(r"(\d+) parsed again where a pair did not meet", r.stderr)) > 10, r.stderr[-600:]
 
 
+def test_four_provider_calls_of_a_round_in_flight(check, tmp_path):
+    """pgz::Params::calls (round 6): a round's chunks split over four provider calls running side by side (the engine's four parse slots) instead of two —
+    the stream's bytes must not depend on how a round is shared out.  Native parse (host emulation of the device's), 8 KiB chunks, rounds of 12 MiB = 1 536
+    chunks: four groups of 384; with two and with one call the same bytes."""
+    p = tmp_path / "site"
+    p.write_bytes(site_table(1500000, 9))
+    outs = []
+    for calls in ("4", "2", "1"):
+        r = subprocess.run([check, str(p), "4", "8192", "2048", str(12 << 20)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, PGZ_NATIVE="1", PGZ_CALLS=calls))
+        assert r.stdout.split()[0] == "identical", (calls, r.stdout, r.stderr[-300:])
+        outs.append(r.stdout.split()[0])
+    assert len(set(outs)) == 1
+
+
 def test_cli_tables_through_the_parallel_writer(check, tmp_path):
     """the host pipeline with the writer forced onto pgz for every output (pgz_min=0 in PANDEPTH_TUNE): the golden gz bytes"""
     import json
