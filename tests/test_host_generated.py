@@ -414,3 +414,35 @@ def test_queued_batches_and_device_chain_gpu(data, name, tune):
         assert host > 3
     else:
         assert dev > 3 and host == 0 and (redo > 10) == ("decode_spoil" in tune)
+
+
+# Round 6: how a batch's bytes reach the device and how it is collected are choices with alternatives kept behind -X keys; the table must not know which ran.
+GPU_TRANSPORT_CASES = [
+    ("default", "dd_batch_mb=1"),
+    ("copies_on_the_batch_streams", "dd_batch_mb=1,h2d_fifo=0"),
+    ("collect_on_the_stream", "dd_batch_mb=1,sync_event=0"),
+    ("both_as_in_round_5", "dd_batch_mb=1,h2d_fifo=0,sync_event=0,dd_depth=2,dd_threads=4"),
+    ("two_copy_lanes", "dd_batch_mb=1,h2d_lanes=2"),
+    ("copy_kernel", "dd_batch_mb=1,h2d_kernel=2"),
+    ("helper_thread_for_the_slots", "dd_batch_mb=1,decode_warm=1"),
+    ("one_buffer_pinned_ahead", "dd_batch_mb=1,dd_pin_ahead=1,dd_threads=5"),
+    ("more_readers_than_batches_on_the_device", "dd_batch_mb=1,dd_threads=8,dd_inflight=3"),
+    ("tables_do_not_fit_behind_the_members", "dd_batch_mb=1,dd_depth=2,dd_threads=3,dd_trace=1"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tune", GPU_TRANSPORT_CASES, ids=[c[0] for c in GPU_TRANSPORT_CASES])
+def test_decode_transport_alternatives_gpu(data, name, tune):
+    """first come, first served copies on the main stream (one per batch) / per-batch streams / two lanes / a copy kernel; collect on the batch's
+    event / on its stream; slots made ready by a helper thread; readers capped: the same bytes as the reference in every case, all batches on the device."""
+    import re
+    env = dict(os.environ, PANDEPTH_TUNE=tune, PANDEPTH_TIMING="1")
+    p = subprocess.run([os.path.join(ROOT, "pandepth_amd", "pandepth"), "-i", "g.bam", "-o", "gt_" + name, "-t", "6"], cwd=data,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    assert gzip.decompress((data / ("gt_%s.chr.stat.gz" % name)).read_bytes()).decode() == _expected_chr(data)
+    m = re.search(r"device decode: (\d+) batches.*?(\d+) records on the device, (\d+) units handed back", p.stderr.decode())
+    assert m and int(m.group(1)) > 3 and int(m.group(3)) == 0, p.stderr.decode()[-600:]
+    if "dd_trace" in tune:
+        assert len(re.findall(r"\[trace\] batch \d+ thread \d+", p.stderr.decode())) == int(m.group(1))
