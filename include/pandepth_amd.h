@@ -431,7 +431,11 @@ int pd_decode_submit(pd_ctx *ctx, const pd_decode_batch *batch, int32_t *unit_st
  * calls back to back); a batch the device found out of the ordinary (a member it leaves to zlib, a record that runs past its
  * unit, more wrong guesses than it repeats itself) is finished there the way pd_decode_submit always did.  Every queued batch must be
  * collected; pd_decode_end / pd_decode_abort collect and drop what the caller left behind.  A thread may hold several queued batches
- * (two per reader keeps a GPU busy); the rule of pd_decode_cfg::n_batches — buffer first, then the order — holds for each of them. */
+ * (two per reader keeps a GPU busy); the rule of pd_decode_cfg::n_batches — buffer first, then the order — holds for each of them.
+ * Round 6: the batches' host-to-device copies are issued first come, first served on the context's main stream — ONE copy per batch, the
+ * batch's tables behind its members in the buffer pd_decode_acquire handed out (which has the room: the call owns the bytes behind
+ * `bytes` as well) — and pd_decode_collect waits for an event recorded behind the batch's last command, not for its stream
+ * ("the convoy"; pd_set_param "decode_h2d_fifo" / "decode_sync_event" = 0 give the older behaviour). */
 int pd_decode_queue(pd_ctx *ctx, const pd_decode_batch *batch, uint64_t *ticket);
 int pd_decode_collect(pd_ctx *ctx, uint64_t ticket, int32_t *unit_status /* batch->n_units entries */, pd_decode_result *res);
 int pd_decode_end(pd_ctx *ctx);
