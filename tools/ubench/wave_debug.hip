@@ -12,7 +12,10 @@
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 #define PW_MARK(code, val) do { if (g_dbg && (threadIdx.x & 63) == 0) { g_dbg[blockIdx.x * 8 + 0] = (code); g_dbg[blockIdx.x * 8 + 1] = (val); g_dbg[blockIdx.x * 8 + 2] += 1; } } while (0)
 __device__ volatile unsigned *g_dbg;
@@ -102,13 +105,42 @@ int main(int argc, char **argv)
         hipDeviceSynchronize();
         hipEventRecord(e0, 0); hipEventSynchronize(e0);
         const auto t0 = std::chrono::steady_clock::now();
+        // COPY=1: beside the launches a thread copies a 32 MB page-locked buffer to the device again and again on a stream of its own: what a batch's copy takes
+        // beside the decoder's kernels IN THE SAME PROCESS
+        std::atomic<bool> copy_stop{false}; std::vector<float> copy_ms; std::thread copier;
+        if (getenv("COPY")) {
+            copier = std::thread([&]() {
+                void *h = nullptr, *dv = nullptr; hipStream_t cs; hipEvent_t a, b;
+                const size_t n = (size_t)32 << 20;
+                hipHostMalloc(&h, n, hipHostMallocDefault); memset(h, 1, n); hipMalloc(&dv, n); hipStreamCreateWithFlags(&cs, hipStreamNonBlocking); hipEventCreate(&a); hipEventCreate(&b);
+                while (!copy_stop.load()) {
+                    hipEventRecord(a, cs); hipMemcpyAsync(dv, h, n, hipMemcpyHostToDevice, cs); hipEventRecord(b, cs); hipEventSynchronize(b);
+                    float ms = 0; hipEventElapsedTime(&ms, a, b); copy_ms.push_back(ms);
+                    usleep(300);
+                }
+            });
+            usleep(200000);
+        }
+        const int repeat = getenv("REPEAT") ? atoi(getenv("REPEAT")) : 1;      // (REPEAT=n: the whole file n times over — a steady load for something measured beside it)
+        for (int rp = 0; rp < repeat; ++rp) {
+        if (rp) { for (int k = 0; k < n_streams; ++k) hipStreamSynchronize(sts[k]); hipMemset(d_ctr, 0, (size_t)n_launch * 4); }
         for (unsigned j = 0; j < n_launch; ++j) {
             const unsigned first = j * batch, n = nb - first < batch ? nb - first : batch;
             hipLaunchKernelGGL(k_dbg, dim3(n_wg < n ? n_wg : n), dim3(64), 0, sts[j % n_streams], d_in, d_blk + first, n, d_out, d_st + first, toks[j % n_streams], d_ctr + j, (volatile unsigned *)nullptr);
         }
+        }
         for (int k = 0; k < n_streams; ++k) hipStreamSynchronize(sts[k]);
         const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         printf("%d streams, launches of %u members: %u launches in %.3f ms = %.1f GB/s\n", n_streams, batch, n_launch, wall_ms, uo / wall_ms / 1e6);
+        if (copier.joinable()) {
+            copy_stop = true; copier.join();
+            std::vector<float> during(copy_ms.begin() + std::min<size_t>(copy_ms.size(), 150), copy_ms.end());      // (the first 0.2 s ran before the launches)
+            std::sort(during.begin(), during.end());
+            std::vector<float> before(copy_ms.begin(), copy_ms.begin() + std::min<size_t>(copy_ms.size(), 150)); std::sort(before.begin(), before.end());
+            if (!during.empty() && !before.empty())
+                printf("32 MB host-to-device copies beside the launches: %zu, median %.3f ms (p10 %.3f, p90 %.3f); before the launches: median %.3f ms\n", during.size(), during[during.size() / 2],
+                       during[during.size() / 10], during[during.size() * 9 / 10], before[before.size() / 2]);
+        }
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         done = true;
     } else {
